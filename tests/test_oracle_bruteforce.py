@@ -1,0 +1,92 @@
+"""Pins oracle/mor_oracle.c (kd-tree + BFS + octree-growth restatement) against the independent
+definition-level brute force in tests/bruteforce.py.  CPU only."""
+import numpy as np
+import pytest
+
+from bruteforce import BruteMOR
+from oracle.oracle import Oracle
+from scenes import small_stream, scene_params
+
+
+def _compare_frame(o, b, tag):
+    c = o.counts()
+    cb = b.cb
+    assert c.n_trim == len(cb["raw"]), tag
+    assert c.n_cloud == len(cb["cloud"]), tag
+    assert c.n_ground == len(cb["gp"]), tag
+    assert np.array_equal(o.ground_indices(), cb["gp"].astype(np.int32)), tag
+    assert c.n_clusters == len(cb["comps"]), tag
+    assert np.array_equal(o.labels(), b.labels()), tag
+    off, idx = o.clusters()
+    for k, comp in enumerate(cb["comps"]):
+        assert np.array_equal(idx[off[k]:off[k + 1]], comp.astype(np.int32)), tag
+    assert np.array_equal(o.centroids().view(np.uint32), cb["cents"].view(np.uint32)), tag  # same sequential fp64 sum ⇒ bit-equal
+    q, m, d, s = o.correspondences()
+    assert len(q) == len(b.last_corr), tag
+    for j, (bq, bm, bd) in enumerate(b.last_corr):
+        assert (q[j], m[j]) == (bq, bm), tag
+        assert d[j] == bd, tag
+        assert s[j] == b.last_score[j], tag
+    assert np.array_equal(o.detection().astype(bool), cb["det"]), tag
+
+
+def _compare_tracks(o, b, tag):
+    xyz, conf, mx = o.tracks()
+    assert len(conf) == len(b.mo), tag
+    for i, m in enumerate(b.mo):
+        assert np.array_equal(xyz[i], m["c"]), tag
+        assert conf[i] == m["conf"] and mx[i] == m["maxc"], tag
+
+
+@pytest.mark.parametrize("method", [1, 2])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_oracle_matches_bruteforce_stream(seed, method):
+    p = scene_params(method_choice=method)
+    o, b = Oracle(p, 4, 3), BruteMOR(p, 4, 3)
+    n_tracks_seen = 0
+    for f, (pts, pose) in enumerate(small_stream(seed, n_frames=8)):
+        o.push(pts, pose)
+        b.push(pts, pose)
+        tag = "seed %d method %d frame %d" % (seed, method, f)
+        _compare_frame(o, b, tag)
+        _compare_tracks(o, b, tag + " after push")
+        out_o, out_b = o.filter(), b.filter()
+        assert out_o.shape == out_b.shape, tag
+        assert np.array_equal(out_o.view(np.uint32), out_b.view(np.uint32)), tag
+        _compare_tracks(o, b, tag + " after filter")
+        n_tracks_seen = max(n_tracks_seen, o.counts().n_tracks)
+    assert o.counts().n_clusters >= 3
+
+
+def test_stream_exercises_tracking():
+    """At least one seed/method must actually create tracks and remove points, otherwise the
+    comparisons above are vacuous for T1/F1."""
+    p = scene_params(method_choice=2)
+    o = Oracle(p, 4, 3)
+    removed = 0
+    tracks = 0
+    for pts, pose in small_stream(1, n_frames=8):
+        o.push(pts, pose)
+        c = o.counts()
+        out = o.filter()
+        removed = max(removed, int(c.n_trim) - len(out))
+        tracks = max(tracks, o.counts().n_tracks)
+    assert tracks >= 1 and removed > 0
+
+
+def test_blob_layouts_equivalent():
+    """fromPCLPointCloud2 semantics: 32-byte Velodyne-style records and packed 16-byte records give
+    the same result; a blob without intensity yields intensity 0."""
+    p = scene_params()
+    pts, pose = small_stream(5, n_frames=1)[0]
+    o16, o32, o12 = Oracle(p), Oracle(p), Oracle(p)
+    o16.push(pts, pose)
+    blob = np.zeros((len(pts), 8), np.float32)
+    blob[:, 0:3] = pts[:, 0:3]
+    blob[:, 4] = pts[:, 3]
+    o32.push(blob, pose, point_step=32, offsets=(0, 4, 8, 16))
+    o12.push(np.ascontiguousarray(pts[:, :3]), pose, point_step=12, offsets=(0, 4, 8, 0xFFFFFFFF))
+    a, b, c = o16.filter(), o32.filter(), o12.filter()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(a[:, :3].view(np.uint32), c[:, :3].view(np.uint32))
+    assert np.all(c[:, 3] == 0)
