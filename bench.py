@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py — LiDAR frame-pairs/s of the MovingObjectRemoval hot path on MI355X.
+
+One "step" = one pushRawCloudAndPose + filterCloud pass over a batch of B independent sensor
+streams (B frame-pairs at steady state).  Workload at N=1: BASELINE.json configs[1] — B=64 synthetic
+KITTI-HDL-64 streams (120 000 pts per frame, SURVEY.md §8d generator), KITTI parameter profile,
+method 1 (NN-distance).  Inputs are resident in HBM before the timed region; outputs stay in HBM.
+Multi-GPU: one process per GPU, each runs its own B streams (weak scaling, no data-path
+collective); torch.distributed (gloo, CPU tensors) only provides the barrier and the max-over-ranks.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (sensor, streams per GPU, profile)
+    "hdl64_b64": ("hdl64", 64),
+    "os128_b64": ("os128", 64),
+    "agg10_b32": ("agg10", 32),
+}
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4-copy ceiling)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="hdl64_b64", choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
+    ap.add_argument("--method", type=int, default=1, choices=[1, 2])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--e2e", action="store_true", help="also time a few steps with host-resident clouds (PCIe-inclusive)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    from dynamicslamtool_amd import engine, kitti_params, synth
+
+    sensor, B = WORKLOADS[args.workload]
+    if args.streams:
+        B = args.streams
+    npts = synth.n_points(sensor)
+    p = kitti_params(args.method)
+    ndev = engine.device_count()
+    if ndev < 1:
+        raise RuntimeError("bench.py needs an MI355X (no CPU fallback in the product path)")
+    device = local_rank % ndev
+
+    # ---- synthetic streams, resident in HBM: frame f of stream s at offset ((f*B)+s)*npts*16
+    n_frames = min(args.warmup + args.steps + 1, 24)
+    seeds = [1000 * 2 + rank * B + s for s in range(B)]   # seed = 1000·config + stream (config 2)
+    cloud_bytes = npts * 16
+    buf = engine.DeviceBuffer(n_frames * B * cloud_bytes, device)
+    poses = np.empty((n_frames, B, 7))
+    t_gen = time.time()
+    for f in range(n_frames):
+        xs, ps = synth.batch(seeds, [f] * B, sensor)
+        buf.upload(xs, f * B * cloud_bytes)
+        poses[f] = ps
+    t_gen = time.time() - t_gen
+
+    batch = engine.MorBatch(p, B, npts, 4, 3, device)
+
+    def frame_of(step):   # walk forward, then ping-pong so consecutive frames stay consecutive
+        period = 2 * (n_frames - 1)
+        k = step % period
+        return k if k < n_frames else period - k
+
+    def run_step(step):
+        f = frame_of(step)
+        clouds = [(buf.ptr + (f * B + s) * cloud_bytes, npts) for s in range(B)]
+        batch.push(clouds, poses[f])
+        return batch.filter(to_host=False)
+
+    for i in range(args.warmup):
+        run_step(i)
+    batch.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    n_out_total = 0
+    for i in range(args.steps):
+        n_out = run_step(args.warmup + i)
+        a, b_ = batch.last_timing()
+        dev_ms += a + b_
+        n_out_total += sum(n_out)
+    batch.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    value = world * B * args.steps / elapsed
+
+    # ---- algorithmic bytes per frame-pair: 16·N + 16·C_prev + 16·N_out + 4·T + 32·K
+    b_alg = 0.0
+    for s in range(B):
+        c = batch.counts(s)
+        b_alg += 16 * c.n_in + 16 * c.n_clustered + 16 * (n_out_total / (args.steps * B)) + 4 * c.n_trim + 32 * c.n_clusters
+    b_alg /= B
+
+    roofline = None
+    kernels = None
+    if not args.no_kernel_timing:
+        # live HIP-event timing of every launch on the batch's own stream, over extra (untimed) steps
+        batch.kernel_timing_enable(True)
+        batch.kernel_timing(reset=True)
+        nk = max(3, min(args.steps, 10))
+        for i in range(nk):
+            run_step(args.warmup + args.steps + i)
+        kt = batch.kernel_timing(reset=True)
+        batch.kernel_timing_enable(False)
+        kernels = {k: {"ms_total": round(v[0], 4), "launches": v[1], "avg_us": round(1e3 * v[0] / max(v[1], 1), 2)} for k, v in kt.items() if v[1]}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_total"])
+        avg_s = kernels[dom]["ms_total"] / kernels[dom]["launches"] * 1e-3
+        achieved = B * b_alg / avg_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(B * b_alg), "avg_launch_us": round(avg_s * 1e6, 2),
+                    "job_GBps": round(b_alg * value / world / 1e9, 2)}
+
+    e2e = None
+    if args.e2e and rank == 0:
+        xs, ps = synth.batch(seeds, [0] * B, sensor)
+        xs1, ps1 = synth.batch(seeds, [1] * B, sensor)
+        hb = engine.MorBatch(p, B, npts, 4, 3, device)
+        hb.push(list(xs), ps)
+        hb.filter()
+        t1 = time.perf_counter()
+        reps = 3
+        for r in range(reps):
+            hb.push(list(xs1 if r % 2 == 0 else xs), ps1 if r % 2 == 0 else ps)
+            hb.filter()
+        e2e = B * reps / (time.perf_counter() - t1)
+        hb.close()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.oracle import Oracle   # the checker, timed here only as the reported CPU baseline
+        S, P = 4, 8
+        t_cpu = 0.0
+        for s in range(S):
+            o = Oracle(p, 4, 3)
+            x, ps = synth.frame(seeds[s], sensor, 0)
+            o.push(x, ps)
+            o.filter()
+            for f in range(1, P + 1):
+                x, ps = synth.frame(seeds[s], sensor, f)
+                t1 = time.perf_counter()
+                o.push(x, ps)
+                o.filter()
+                t_cpu += time.perf_counter() - t1
+            o.close()
+        cpu = {"value": round(S * P / t_cpu, 3), "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+               "sample": "%d streams x %d steady-state frame-pairs of %s (%d pts), single thread, oracle/mor_oracle.c (kd-tree+BFS restatement, not PCL)" % (S, P, sensor, npts),
+               "host_cpus": os.cpu_count()}
+
+    if rank == 0:
+        c0 = batch.counts(0)
+        line = {
+            "metric": "LiDAR frame-pairs/sec (120k pts, batched)", "value": round(value, 2), "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d streams/GPU x %d pts (%s), kitti profile, method %d" % (args.workload, B, npts, sensor, args.method),
+                       "streams_per_gpu": B, "points_per_frame": npts, "parallelism": "streams sharded over %d GPU(s), no collective" % world,
+                       "profile": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in p.as_dict().items()}},
+            "device_ms_per_step": round(dev_ms / args.steps, 4),
+            "algorithmic_bytes_per_frame_pair": int(b_alg),
+            "stream0": {"T": int(c0.n_trim), "M": int(c0.n_cloud), "G": int(c0.n_ground), "K": int(c0.n_clusters), "C": int(c0.n_clustered), "pairs": int(c0.n_corr), "tracks": int(c0.n_tracks)},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "e2e_host_frame_pairs_per_s": None if e2e is None else round(e2e, 2),
+            "setup_s": round(t_gen, 2),
+        }
+        print(json.dumps(line))
+    batch.close()
+    buf.free()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

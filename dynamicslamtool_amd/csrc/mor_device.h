@@ -1,0 +1,111 @@
+// mor_device.h — device-visible descriptors shared by mor_kernels.hip and mor_engine.cpp.
+// Vocabulary follows the reference: streams (one MovingObjectRemoval instance each), frames ca/cb,
+// `cloud` (non-ground points), `gp_indices`, clusters, centroids, correspondences.
+#pragma once
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+#define MOR_TILE 2048   // points per workgroup tile: 4 waves × 8 coalesced 1-KiB rows of float4
+#define MOR_BT 256      // threads per workgroup
+#define MOR_KGRID 128   // workgroups per stream for per-cluster kernels (grid-stride over clusters)
+
+// Uniform grid over the trim box ("perfect spatial hash": key = linear cell id). Cell edge ≥ r so a
+// 3×3×3 stencil covers every neighbour within r; the cell map is monotone and clamped, so points
+// outside the nominal box land in border cells and are still found.
+struct MorGrid {
+  float ox, oy, oz, inv_cs;
+  int nx, ny, nz, ncells;
+};
+
+struct MorStreamArgs {       // per stream, per push (host → device, one small copy)
+  const void *data;          // incoming blob (device pointer)
+  uint32_t n, step, off_x, off_y, off_z, off_i;
+  float xf[12];              // row-major 3×4 fp32 transform prev → cur (:536, cast as pcl_ros does)
+};
+
+struct MorFrameInfo {        // per stream, produced on device
+  uint32_t N, T, M, G, K, C, n_pairs, flags;   // flags bit0: cluster capacity exceeded, bit1: voxel key overflow
+  uint32_t Kprev, Cprev, n_keep, pad;
+};
+
+struct MorDev {
+  // ---- static configuration
+  int B, Nmax, Kcap, tiles_max, ctiles, radix_passes, Hcap;
+  float trim_x, trim_y, trim_z, gp_limit, r2;
+  long long min_cs, max_cs;
+  float pde_lb, pde_ub;
+  double pde_thr, vol_thr, opc_res;
+  int method, opc_norm, score_R;
+  MorGrid g;
+  // ---- per call
+  int tiles;                 // ceil(max n_points of this batch / MOR_TILE)
+  int cur, has_prev;         // frame slot of cb (ca = cur^1); whether ca exists (:534)
+  // ---- device arrays (per-stream stride noted)
+  const MorStreamArgs *args; // [B]
+  MorFrameInfo *info;        // [B]
+  int *tile_cnt, *tile_off;  // [B][tiles_max][2]   (non-ground, ground) counts / exclusive offsets
+  float4 *cloud;             // [B][Nmax]  non-ground points, input order (`cloud`, :85)
+  int *cloud_tidx;           // [B][Nmax]  index of each cloud point in the trimmed cloud
+  float4 *ground;            // [B][Nmax]  removed points in order (raw_cloud[gp_indices], :683)
+  int *gp_idx;               // [B][Nmax]  gp_indices (:86)
+  int *cell_of;              // [B][Nmax]
+  int *cell_cnt;             // [B][ncells]   histogram, then fill cursor
+  int *cell_start;           // [B][ncells+1]
+  int *ctile_sum;            // [B][ctiles]
+  float4 *sorted;            // [B][Nmax]  (x,y,z, bits(cloud index)) in cell order; .w becomes the cluster id after labelling
+  int *parent;               // [B][Nmax]  union-find forest over cloud indices (parent ≤ child)
+  int *csize;                // [B][Nmax]  component size at its root
+  int *cid_of_root;          // [B][Nmax]
+  int *label;                // [B][Nmax]  component root per cloud point
+  int *pcid;                 // [B][Nmax]  cluster id (−1 none) per cloud point
+  int *ktile_cnt;            // [B][tiles_max]
+  int *kroot, *ksize;        // [B][Kcap]  kept roots ascending, their sizes
+  int *csz;                  // [B][Kcap]  sizes in final cluster order
+  int *rkeys[2], *rvals[2];  // [B][Nmax]  radix ping-pong (cluster id, cloud index)
+  int *rhist;                // [B][tiles_max][256]
+  int *cl_idx;               // [B][Nmax]  cluster_indices flattened (:218)
+  // frame-slotted (cb / ca)
+  float4 *cl_pts[2];         // [B][Nmax]  clusters[k] points, (cluster, index) order (:229); ca's are transformed in place (:550)
+  int *cl_cid[2];            // [B][Nmax]  cluster id per cl_pts entry
+  int *cl_off[2];            // [B][Kcap+1]
+  float4 *centroid[2];       // [B][Kcap]  centroid_collection (:243)
+  float4 *amin[2], *amax[2]; // [B][Kcap]  cluster AABBs (getMinMax3D, :272-274)
+  // pair stage
+  int *nn_fwd, *nn_bwd;      // [B][Kcap]
+  float *nn_fwd_d;           // [B][Kcap]
+  int *pair_q, *pair_m;      // [B][Kcap]
+  float *pair_d;             // [B][Kcap]
+  int *pair_cnt;             // [B][Kcap]
+  int *pair_of_prev, *pair_of_cur; // [B][Kcap]
+  unsigned long long *vox;   // [B][Hcap]
+  unsigned char *det;        // [B][Kcap]  detection_results of cb
+  // filter stage
+  const unsigned char *moving; // [B][Kcap] + [B] extract-error flags at the end
+  int *otile_cnt;            // [B][tiles_max]
+  float4 *out;               // [B][Nmax] (or caller-provided per-stream pointers through out_ptrs)
+  float4 *const *out_ptrs;   // [B] or null
+  // ---- pinned host mirrors written by the device (zero-copy summaries)
+  MorFrameInfo *h_info;      // [B]
+  float4 *h_centroid;        // [B][Kcap]
+  int *h_cl_off;             // [B][Kcap+1]
+  unsigned char *h_det;      // [B][Kcap]
+  int *h_pair_q, *h_pair_m;  // [B][Kcap]
+  float *h_pair_d;           // [B][Kcap]
+  double *h_score;           // [B][Kcap]
+  unsigned long long *h_nout;// [B]
+};
+
+// kernel ids for optional per-kernel event timing
+enum MorKernelId {
+  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_CELL_REDUCE, MK_CELL_SCAN, MK_CELL_FINAL, MK_FILL, MK_HOOK, MK_FLATTEN,
+  MK_SELECT_COUNT, MK_SELECT_SCAN, MK_SELECT_SCATTER, MK_RANK, MK_OFFSETS, MK_LABEL, MK_RHIST, MK_RSCAN, MK_RSCATTER,
+  MK_STATS, MK_XFORM_PREV, MK_NN, MK_PAIRS, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
+  MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_COUNT
+};
+extern const char *const mor_kernel_names[MK_COUNT];
+
+struct MorLaunchTimer;   // engine-owned; records event pairs when enabled
+void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);
+void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);
+void mor_timer_begin(MorLaunchTimer *tm, int kernel_id, hipStream_t st);
+void mor_timer_end(MorLaunchTimer *tm, int kernel_id, hipStream_t st);

@@ -1,0 +1,380 @@
+// mor_engine.cpp — host side of libmor_hip.so: the C ABI of include/mor_hip.h, buffer management
+// in HBM, the per-batch launch sequence, and the glue to the host tracker.
+// Mirrors MovingObjectRemoval::pushRawCloudAndPose / filterCloud
+// (/root/reference/src/MovingObjectRemoval.cpp:516-611, :613-696) for B independent streams.
+#include "mor_device.h"
+#include "mor_tracker.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_last_error;
+static int set_error(int code, const char *fmt, ...) {
+  char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_last_error = buf; return code;
+}
+#define HIP_TRY(expr)                                                                                         \
+  do { hipError_t e_ = (expr); if (e_ != hipSuccess) return set_error(MOR_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+// ------------------------------------------------------------------ per-kernel event timing
+struct MorLaunchTimer {
+  bool enabled = false;
+  struct Rec { int id; hipEvent_t a, b; };
+  std::vector<Rec> recs; size_t used = 0;
+  double ms[MK_COUNT] = {0}; uint32_t launches[MK_COUNT] = {0};
+  void collect() {
+    for (size_t i = 0; i < used; ++i) { float t = 0; if (hipEventElapsedTime(&t, recs[i].a, recs[i].b) == hipSuccess) { ms[recs[i].id] += t; launches[recs[i].id]++; } }
+    used = 0;
+  }
+  ~MorLaunchTimer() { for (auto &r : recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); } }
+};
+void mor_timer_begin(MorLaunchTimer *tm, int id, hipStream_t st) {
+  if (!tm || !tm->enabled) return;
+  if (tm->used == tm->recs.size()) { MorLaunchTimer::Rec r; r.id = id; hipEventCreate(&r.a); hipEventCreate(&r.b); tm->recs.push_back(r); }
+  tm->recs[tm->used].id = id;
+  hipEventRecord(tm->recs[tm->used].a, st);
+}
+void mor_timer_end(MorLaunchTimer *tm, int id, hipStream_t st) {
+  if (!tm || !tm->enabled) return;
+  (void)id; hipEventRecord(tm->recs[tm->used].b, st); tm->used++;
+}
+
+// ------------------------------------------------------------------ batch
+struct PoseTf { double R[3][3], o[3]; };
+
+struct mor_batch {
+  mor_params p; int n_bad, n_good, B, device; uint64_t Nmax;
+  hipStream_t st = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  MorDev d;                                  // template descriptor (static part + pointers)
+  std::vector<void *> dev_allocs, host_allocs;
+  MorStreamArgs *h_args = nullptr, *d_args = nullptr;
+  unsigned char *h_moving = nullptr, *d_moving = nullptr;
+  float4 **h_outptrs = nullptr, **d_outptrs = nullptr;
+  unsigned char *d_stage = nullptr; size_t stage_stride = 0;   // staging for host-resident input blobs
+  std::vector<mor_tracker> trackers;
+  std::vector<PoseTf> prev_pose;
+  uint64_t frame = 0;
+  bool filtered = false;
+  float push_ms = 0, filter_ms = 0;
+  MorLaunchTimer timer;
+};
+
+template <class T> static bool dalloc(mor_batch *b, T *&ptr, size_t n) {
+  void *v = nullptr; if (hipMalloc(&v, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return false;
+  b->dev_allocs.push_back(v); ptr = (T *)v; return true;
+}
+template <class T> static bool halloc(mor_batch *b, T *&ptr, size_t n) {
+  void *v = nullptr; if (hipHostMalloc(&v, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault) != hipSuccess) return false;
+  b->host_allocs.push_back(v); memset(v, 0, std::max<size_t>(n, 1) * sizeof(T)); ptr = (T *)v; return true;
+}
+
+// tf::poseMsgToTF (:524) — quaternion renormalised only when |len² − 1| > 0.1, setRotation with s = 2/len²
+static void pose_to_tf(const double *p, PoseTf &t) {
+  double x = p[3], y = p[4], z = p[5], w = p[6];
+  double l2 = x * x + y * y + z * z + w * w;
+  if (std::fabs(l2 - 1.0) > 0.1) { double l = std::sqrt(l2); x /= l; y /= l; z /= l; w /= l; l2 = x * x + y * y + z * z + w * w; }
+  double s = 2.0 / l2, xs = x * s, ys = y * s, zs = z * s;
+  double wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+  t.R[0][0] = 1.0 - (yy + zz); t.R[0][1] = xy - wz; t.R[0][2] = xz + wy;
+  t.R[1][0] = xy + wz; t.R[1][1] = 1.0 - (xx + zz); t.R[1][2] = yz - wx;
+  t.R[2][0] = xz - wy; t.R[2][1] = yz + wx; t.R[2][2] = 1.0 - (xx + yy);
+  t.o[0] = p[0]; t.o[1] = p[1]; t.o[2] = p[2];
+}
+// cb.ps.inverseTimes(ca.ps) (:536) in fp64, cast to the fp32 matrix pcl_ros::transformPointCloud applies
+static void relative_transform(const PoseTf &cb, const PoseTf &ca, float m[12]) {
+  double v[3] = {ca.o[0] - cb.o[0], ca.o[1] - cb.o[1], ca.o[2] - cb.o[2]};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) m[4 * i + j] = (float)(cb.R[0][i] * ca.R[0][j] + cb.R[1][i] * ca.R[1][j] + cb.R[2][i] * ca.R[2][j]);
+    m[4 * i + 3] = (float)(cb.R[0][i] * v[0] + cb.R[1][i] * v[1] + cb.R[2][i] * v[2]);
+  }
+}
+
+static int configure(mor_batch *b) {
+  const mor_params &p = b->p; MorDev &d = b->d;
+  if (!(p.ec_distance_threshold > 0.f) || !(p.trim_x > 0.f) || !(p.trim_y > 0.f)) return set_error(MOR_ERR_INVALID, "ec_distance_threshold, trim_x, trim_y must be > 0");
+  if (p.method_choice == 2 && p.opc_normalization_factor <= 0) return set_error(MOR_ERR_INVALID, "opc_normalization_factor must be > 0 for method 2");
+  if (p.method_choice == 2 && !(p.opc_resolution > 0.f)) return set_error(MOR_ERR_INVALID, "opc_resolution must be > 0");
+  if (p.ground_method != 0) return set_error(MOR_ERR_INVALID, "ground_method %d not available in this build (0 = crop box)", p.ground_method);
+  d.B = b->B; d.Nmax = (int)b->Nmax;
+  long long mn = std::max<long long>(p.min_cluster_size, 1);
+  d.Kcap = (int)std::min<long long>((long long)b->Nmax / mn + 1, 16384);
+  d.tiles_max = (int)((b->Nmax + MOR_TILE - 1) / MOR_TILE);
+  d.trim_x = p.trim_x; d.trim_y = p.trim_y; d.trim_z = p.trim_z; d.gp_limit = p.gp_limit;
+  double tol = (double)p.ec_distance_threshold; d.r2 = (float)(tol * tol);   // KdTreeFLANN::radiusSearch: (float)(radius·radius)
+  d.min_cs = p.min_cluster_size; d.max_cs = p.max_cluster_size;
+  d.pde_lb = p.pde_lb; d.pde_ub = p.pde_ub; d.pde_thr = (double)p.pde_distance_threshold; d.vol_thr = (double)p.volume_constraint;
+  d.opc_res = (double)p.opc_resolution; d.method = p.method_choice; d.opc_norm = p.opc_normalization_factor;
+  // grid: cell edge ≥ r·1.001 (slack for the fp32 cell map), ≤ 2048 cells per axis, ≤ 4 Mi cells
+  float cs = p.ec_distance_threshold * 1.001f;
+  float zlo = p.gp_limit, zhi = std::max(p.trim_z, p.gp_limit);
+  for (;;) {
+    double nx = std::floor(2.0 * p.trim_x / cs) + 1, ny = std::floor(2.0 * p.trim_y / cs) + 1, nz = std::floor((double)(zhi - zlo) / cs) + 1;
+    if (nx <= 2048 && ny <= 2048 && nz <= 2048 && nx * ny * nz <= 4.0 * 1024 * 1024) { d.g.nx = (int)nx; d.g.ny = (int)ny; d.g.nz = (int)nz; break; }
+    cs *= 1.25f;
+  }
+  d.g.ox = -p.trim_x; d.g.oy = -p.trim_y; d.g.oz = zlo; d.g.inv_cs = 1.0f / cs; d.g.ncells = d.g.nx * d.g.ny * d.g.nz;
+  d.ctiles = (d.g.ncells + MOR_TILE - 1) / MOR_TILE;
+  d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
+  int bits = 1; while ((1 << bits) < d.Kcap) ++bits;
+  d.radix_passes = (bits + 7) / 8;
+  d.Hcap = 64; while (d.Hcap < 2 * d.Nmax) d.Hcap <<= 1;
+  return MOR_OK;
+}
+
+extern "C" {
+
+size_t mor_sizeof_params(void) { return sizeof(mor_params); }
+const char *mor_last_error(void) { return g_last_error.c_str(); }
+int mor_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+
+void mor_batch_destroy(mor_batch *b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  if (b->st) hipStreamSynchronize(b->st);
+  for (void *p : b->dev_allocs) hipFree(p);
+  for (void *p : b->host_allocs) hipHostFree(p);
+  if (b->d_stage) hipFree(b->d_stage);
+  for (auto &e : b->ev) if (e) hipEventDestroy(e);
+  if (b->st) hipStreamDestroy(b->st);
+  delete b;
+}
+
+mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_streams, uint64_t max_points, int device, int *err) {
+  int rc = MOR_OK; mor_batch *b = nullptr;
+  auto fail = [&](int code) -> mor_batch * { if (err) *err = code; if (b) mor_batch_destroy(b); return nullptr; };
+  if (!p || n_streams < 1 || max_points < 1 || max_points > (1ull << 27)) return fail(set_error(MOR_ERR_INVALID, "bad arguments to mor_batch_create"));
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(set_error(MOR_ERR_HIP, "no HIP device available (this library has no CPU fallback)"));
+  if (device < 0 || device >= ndev) return fail(set_error(MOR_ERR_INVALID, "device %d out of range (%d devices)", device, ndev));
+  if (hipSetDevice(device) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipSetDevice(%d) failed", device));
+  b = new mor_batch(); memset(&b->d, 0, sizeof b->d);
+  b->p = *p; b->n_bad = n_bad; b->n_good = n_good; b->B = n_streams; b->device = device; b->Nmax = max_points;
+  if ((rc = configure(b)) != MOR_OK) return fail(rc);
+  if (hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
+  for (auto &e : b->ev) if (hipEventCreate(&e) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+  MorDev &d = b->d; const size_t B = d.B, N = d.Nmax, K = d.Kcap, T = d.tiles_max;
+  bool ok = true;
+  MorStreamArgs *dargs = nullptr;
+  ok = ok && dalloc(b, dargs, B) && dalloc(b, d.info, B) && dalloc(b, d.tile_cnt, B * T * 2) && dalloc(b, d.tile_off, B * T * 2);
+  b->d_args = dargs; d.args = dargs;
+  ok = ok && dalloc(b, d.cloud, B * N) && dalloc(b, d.cloud_tidx, B * N) && dalloc(b, d.ground, B * N) && dalloc(b, d.gp_idx, B * N) && dalloc(b, d.cell_of, B * N);
+  ok = ok && dalloc(b, d.cell_cnt, B * (size_t)d.g.ncells) && dalloc(b, d.cell_start, B * ((size_t)d.g.ncells + 1)) && dalloc(b, d.ctile_sum, B * (size_t)d.ctiles);
+  ok = ok && dalloc(b, d.sorted, B * N) && dalloc(b, d.parent, B * N) && dalloc(b, d.csize, B * N) && dalloc(b, d.cid_of_root, B * N) && dalloc(b, d.label, B * N) && dalloc(b, d.pcid, B * N);
+  ok = ok && dalloc(b, d.ktile_cnt, B * T) && dalloc(b, d.kroot, B * K) && dalloc(b, d.ksize, B * K) && dalloc(b, d.csz, B * K);
+  for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, d.rkeys[i], B * N) && dalloc(b, d.rvals[i], B * N);
+  ok = ok && dalloc(b, d.rhist, B * T * 256) && dalloc(b, d.cl_idx, B * N);
+  for (int i = 0; i < 2; ++i)
+    ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K);
+  ok = ok && dalloc(b, d.nn_fwd, B * K) && dalloc(b, d.nn_bwd, B * K) && dalloc(b, d.nn_fwd_d, B * K) && dalloc(b, d.pair_q, B * K) && dalloc(b, d.pair_m, B * K) && dalloc(b, d.pair_d, B * K);
+  ok = ok && dalloc(b, d.pair_cnt, B * K) && dalloc(b, d.pair_of_prev, B * K) && dalloc(b, d.pair_of_cur, B * K) && dalloc(b, d.det, B * K);
+  if (p->method_choice == 2) ok = ok && dalloc(b, d.vox, B * (size_t)d.Hcap);
+  ok = ok && dalloc(b, b->d_moving, B * K + B) && dalloc(b, d.otile_cnt, B * T) && dalloc(b, d.out, B * N) && dalloc(b, b->d_outptrs, B);
+  d.moving = b->d_moving;
+  ok = ok && halloc(b, b->h_args, B) && halloc(b, b->h_moving, B * K + B) && halloc(b, b->h_outptrs, B);
+  ok = ok && halloc(b, d.h_info, B) && halloc(b, d.h_centroid, B * K) && halloc(b, d.h_cl_off, B * (K + 1)) && halloc(b, d.h_det, B * K);
+  ok = ok && halloc(b, d.h_pair_q, B * K) && halloc(b, d.h_pair_m, B * K) && halloc(b, d.h_pair_d, B * K) && halloc(b, d.h_score, B * K) && halloc(b, d.h_nout, B);
+  if (!ok) return fail(set_error(MOR_ERR_HIP, "device/host allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
+  if (hipMemsetAsync(d.info, 0, B * sizeof(MorFrameInfo), b->st) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "memset failed"));
+  hipStreamSynchronize(b->st);
+  b->trackers.reserve(B);
+  for (size_t s = 0; s < B; ++s) b->trackers.emplace_back(*p, n_bad, n_good);
+  b->prev_pose.resize(B);
+  if (err) *err = MOR_OK;
+  return b;
+}
+
+int mor_batch_streams(const mor_batch *b) { return b ? b->B : 0; }
+
+int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *poses) {
+  if (!b || !clouds || !poses) return set_error(MOR_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(b->device));
+  MorDev d = b->d; const int B = d.B;
+  uint64_t maxn = 0; size_t max_host_bytes = 0;
+  for (int s = 0; s < B; ++s) {
+    const mor_cloud_view &c = clouds[s];
+    if (c.n_points > b->Nmax) return set_error(MOR_ERR_CAPACITY, "stream %d: %llu points > max_points %llu", s, (unsigned long long)c.n_points, (unsigned long long)b->Nmax);
+    if (c.n_points && (!c.data || c.point_step < 12 || c.off_x + 4 > c.point_step || c.off_y + 4 > c.point_step || c.off_z + 4 > c.point_step ||
+                       (c.off_intensity != MOR_NO_FIELD && c.off_intensity + 4 > c.point_step) || ((c.off_x | c.off_y | c.off_z | c.point_step) & 3) ||
+                       (c.off_intensity != MOR_NO_FIELD && (c.off_intensity & 3))))
+      return set_error(MOR_ERR_INVALID, "stream %d: bad blob layout", s);
+    maxn = std::max<uint64_t>(maxn, c.n_points);
+    if (!c.on_device) max_host_bytes = std::max<size_t>(max_host_bytes, (size_t)c.n_points * c.point_step);
+  }
+  if (max_host_bytes > b->stage_stride) {   // (re)allocate the staging area for host-resident blobs
+    if (b->d_stage) { HIP_TRY(hipStreamSynchronize(b->st)); HIP_TRY(hipFree(b->d_stage)); b->d_stage = nullptr; }
+    b->stage_stride = (max_host_bytes + 255) & ~(size_t)255;
+    HIP_TRY(hipMalloc((void **)&b->d_stage, b->stage_stride * B));
+  }
+  std::vector<PoseTf> cur(B);
+  for (int s = 0; s < B; ++s) {
+    const mor_cloud_view &c = clouds[s]; MorStreamArgs &a = b->h_args[s];
+    a.n = (uint32_t)c.n_points; a.step = c.point_step; a.off_x = c.off_x; a.off_y = c.off_y; a.off_z = c.off_z; a.off_i = c.off_intensity;
+    if (c.on_device || c.n_points == 0) a.data = c.data;
+    else { a.data = b->d_stage + b->stage_stride * s; HIP_TRY(hipMemcpyAsync((void *)a.data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, b->st)); }
+    pose_to_tf(poses + 7 * s, cur[s]);
+    if (b->frame > 0) relative_transform(cur[s], b->prev_pose[s], a.xf); else memset(a.xf, 0, sizeof a.xf);
+  }
+  HIP_TRY(hipMemcpyAsync(b->d_args, b->h_args, sizeof(MorStreamArgs) * B, hipMemcpyHostToDevice, b->st));
+  d.tiles = std::max<int>(1, (int)((maxn + MOR_TILE - 1) / MOR_TILE));
+  d.cur = (int)(b->frame & 1); d.has_prev = b->frame > 0;
+  HIP_TRY(hipEventRecord(b->ev[0], b->st));
+  mor_launch_push(d, b->st, &b->timer);
+  HIP_TRY(hipEventRecord(b->ev[1], b->st));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(b->st));
+  hipEventElapsedTime(&b->push_ms, b->ev[0], b->ev[1]);
+  b->timer.collect();
+  b->d.tiles = d.tiles; b->d.cur = d.cur; b->d.has_prev = d.has_prev;
+  int rc = MOR_OK;
+  std::vector<float> cent;
+  for (int s = 0; s < B; ++s) {
+    const MorFrameInfo &f = d.h_info[s];
+    if (f.flags & 1u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than %d clusters", s, d.Kcap);
+    if (f.flags & 2u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: voxel key out of range in method 2", s);
+    const size_t ko = (size_t)s * d.Kcap;
+    cent.resize(3 * (size_t)f.K);
+    for (uint32_t k = 0; k < f.K; ++k) { cent[3 * k] = d.h_centroid[ko + k].x; cent[3 * k + 1] = d.h_centroid[ko + k].y; cent[3 * k + 2] = d.h_centroid[ko + k].z; }
+    b->trackers[s].push((int)f.K, cent.data(), d.h_det + ko, d.has_prev ? (int)f.n_pairs : -1, d.h_pair_q + ko, d.h_pair_m + ko);   // :608
+    b->prev_pose[s] = cur[s];
+  }
+  b->frame++; b->filtered = false;
+  return rc;
+}
+
+int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t *n_out) {
+  if (!b) return set_error(MOR_ERR_INVALID, "null batch");
+  if (b->frame == 0) return set_error(MOR_ERR_NOT_READY, "filterCloud before the first pushRawCloudAndPose");
+  HIP_TRY(hipSetDevice(b->device));
+  MorDev d = b->d; const int B = d.B;
+  // host: filterCloud's loop over mo_vec (:630-671) → clusters to remove
+  std::vector<int32_t> sizes;
+  for (int s = 0; s < B; ++s) {
+    const MorFrameInfo &f = d.h_info[s]; const int *off = d.h_cl_off + (size_t)s * (d.Kcap + 1);
+    sizes.resize(f.K);
+    for (uint32_t k = 0; k < f.K; ++k) sizes[k] = off[k + 1] - off[k];
+    if (b->filtered) continue;   // a repeated filter on the same frame re-emits the same cloud; the tracker advances once per frame
+    uint64_t n_idx = 0;
+    b->trackers[s].filter(sizes.data(), b->h_moving + (size_t)s * d.Kcap, &n_idx);
+    b->h_moving[(size_t)B * d.Kcap + s] = n_idx > f.M;   // ExtractIndices: more indices than points ⇒ error, empty output
+  }
+  b->filtered = true;
+  HIP_TRY(hipMemcpyAsync(b->d_moving, b->h_moving, (size_t)B * d.Kcap + B, hipMemcpyHostToDevice, b->st));
+  d.out_ptrs = nullptr;
+  if (out && out_on_device) {
+    for (int s = 0; s < B; ++s) b->h_outptrs[s] = (float4 *)out[s];
+    HIP_TRY(hipMemcpyAsync(b->d_outptrs, b->h_outptrs, sizeof(float4 *) * B, hipMemcpyHostToDevice, b->st));
+    d.out_ptrs = b->d_outptrs;
+  }
+  HIP_TRY(hipEventRecord(b->ev[2], b->st));
+  mor_launch_filter(d, b->st, &b->timer);
+  HIP_TRY(hipEventRecord(b->ev[3], b->st));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(b->st));
+  hipEventElapsedTime(&b->filter_ms, b->ev[2], b->ev[3]);
+  b->timer.collect();
+  for (int s = 0; s < B; ++s) if (n_out) n_out[s] = d.h_nout[s];
+  if (out && !out_on_device) {
+    for (int s = 0; s < B; ++s) if (out[s] && d.h_nout[s]) HIP_TRY(hipMemcpyAsync(out[s], d.out + (size_t)s * d.Nmax, d.h_nout[s] * sizeof(float4), hipMemcpyDeviceToHost, b->st));
+    HIP_TRY(hipStreamSynchronize(b->st));
+  }
+  return MOR_OK;
+}
+
+const void *mor_get_output_device(const mor_batch *b, int s, uint64_t *n_out) {
+  if (!b || s < 0 || s >= b->B) return nullptr;
+  if (n_out) *n_out = b->d.h_nout[s];
+  return b->d.out + (size_t)s * b->d.Nmax;
+}
+
+// ---- single-stream forms
+mor_ctx *mor_create(const mor_params *p, int n_bad, int n_good, uint64_t max_points, int device, int *err) { return mor_batch_create(p, n_bad, n_good, 1, max_points, device, err); }
+int mor_push(mor_ctx *c, const void *data, uint64_t n, uint32_t step, uint32_t ox, uint32_t oy, uint32_t oz, uint32_t oi, const double pose[7]) {
+  mor_cloud_view v; v.data = data; v.n_points = n; v.point_step = step; v.off_x = ox; v.off_y = oy; v.off_z = oz; v.off_intensity = oi; v.on_device = 0;
+  return mor_push_batch(c, &v, pose);
+}
+int mor_filter(mor_ctx *c, float *out, uint64_t *n_out) { void *o = out; return mor_filter_batch(c, out ? &o : nullptr, 0, n_out); }
+void mor_destroy(mor_ctx *c) { mor_batch_destroy(c); }
+
+// ---- read-backs
+#define CHECK_STREAM()                                                                     \
+  if (!b || s < 0 || s >= b->B) return set_error(MOR_ERR_INVALID, "bad batch/stream");      \
+  if (b->frame == 0) return set_error(MOR_ERR_NOT_READY, "no frame pushed yet");            \
+  HIP_TRY(hipSetDevice(b->device));                                                         \
+  const MorDev &d = b->d; const MorFrameInfo &f = d.h_info[s]; const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap; (void)so; (void)ko; (void)f
+
+int mor_get_counts(const mor_batch *b, int s, mor_counts *o) {
+  CHECK_STREAM();
+  o->n_in = f.N; o->n_trim = f.T; o->n_cloud = f.M; o->n_ground = f.G; o->n_clusters = f.K; o->n_clustered = f.C;
+  o->n_corr = f.n_pairs; o->n_tracks = (uint32_t)b->trackers[s].mo_vec.size();
+  return MOR_OK;
+}
+int mor_get_labels(const mor_batch *b, int s, int32_t *lab) {
+  CHECK_STREAM();
+  std::vector<int> pc(f.M), ti(f.M);
+  if (f.M) { HIP_TRY(hipMemcpy(pc.data(), d.pcid + so, f.M * sizeof(int), hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(ti.data(), d.cloud_tidx + so, f.M * sizeof(int), hipMemcpyDeviceToHost)); }
+  for (uint32_t i = 0; i < f.T; ++i) lab[i] = -2;
+  for (uint32_t i = 0; i < f.M; ++i) lab[ti[i]] = pc[i];
+  return MOR_OK;
+}
+int mor_get_ground_indices(const mor_batch *b, int s, int32_t *idx) {
+  CHECK_STREAM();
+  if (f.G) HIP_TRY(hipMemcpy(idx, d.gp_idx + so, f.G * sizeof(int), hipMemcpyDeviceToHost));
+  return MOR_OK;
+}
+int mor_get_clusters(const mor_batch *b, int s, int32_t *off, int32_t *idx) {
+  CHECK_STREAM();
+  memcpy(off, d.h_cl_off + (size_t)s * (d.Kcap + 1), (f.K + 1) * sizeof(int));
+  if (f.C) HIP_TRY(hipMemcpy(idx, d.cl_idx + so, f.C * sizeof(int), hipMemcpyDeviceToHost));
+  return MOR_OK;
+}
+int mor_get_centroids(const mor_batch *b, int s, float *xyz) {
+  CHECK_STREAM();
+  for (uint32_t k = 0; k < f.K; ++k) { xyz[3 * k] = d.h_centroid[ko + k].x; xyz[3 * k + 1] = d.h_centroid[ko + k].y; xyz[3 * k + 2] = d.h_centroid[ko + k].z; }
+  return MOR_OK;
+}
+int mor_get_detection(const mor_batch *b, int s, uint8_t *det) { CHECK_STREAM(); memcpy(det, d.h_det + ko, f.K); return MOR_OK; }
+int mor_get_correspondences(const mor_batch *b, int s, int32_t *q, int32_t *m, float *dist, double *score) {
+  CHECK_STREAM();
+  memcpy(q, d.h_pair_q + ko, f.n_pairs * sizeof(int)); memcpy(m, d.h_pair_m + ko, f.n_pairs * sizeof(int));
+  memcpy(dist, d.h_pair_d + ko, f.n_pairs * sizeof(float)); memcpy(score, d.h_score + ko, f.n_pairs * sizeof(double));
+  return MOR_OK;
+}
+int mor_get_tracks(const mor_batch *b, int s, float *xyz, int32_t *conf, int32_t *maxc) {
+  CHECK_STREAM();
+  mor_tracker_get(&b->trackers[s], xyz, conf, maxc, 1 << 30);
+  return MOR_OK;
+}
+int mor_get_cluster_collection(const mor_batch *b, int s, float *out) {
+  CHECK_STREAM();
+  if (f.C) HIP_TRY(hipMemcpy(out, d.cl_pts[d.cur] + so, f.C * sizeof(float4), hipMemcpyDeviceToHost));
+  return MOR_OK;
+}
+
+// ---- device memory helpers
+void *mor_device_alloc(int device, size_t bytes) { void *p = nullptr; if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) { set_error(MOR_ERR_HIP, "hipMalloc(%zu) failed", bytes); return nullptr; } return p; }
+void mor_device_free(int device, void *p) { if (hipSetDevice(device) == hipSuccess) hipFree(p); }
+int mor_device_upload(int device, void *dst, const void *src, size_t bytes) { HIP_TRY(hipSetDevice(device)); HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return MOR_OK; }
+int mor_device_download(int device, void *dst, const void *src, size_t bytes) { HIP_TRY(hipSetDevice(device)); HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return MOR_OK; }
+int mor_device_synchronize(int device) { HIP_TRY(hipSetDevice(device)); HIP_TRY(hipDeviceSynchronize()); return MOR_OK; }
+
+// ---- timing
+int mor_get_last_timing(const mor_batch *b, float *push_ms, float *filter_ms) {
+  if (!b) return MOR_ERR_INVALID;
+  if (push_ms) *push_ms = b->push_ms; if (filter_ms) *filter_ms = b->filter_ms; return MOR_OK;
+}
+int mor_kernel_timing_enable(mor_batch *b, int enable) { if (!b) return MOR_ERR_INVALID; b->timer.enabled = enable != 0; return MOR_OK; }
+int mor_kernel_timing_read(mor_batch *b, int reset, char *names, size_t names_cap, float *ms_total, uint32_t *launches, int max_kernels) {
+  if (!b) return MOR_ERR_INVALID;
+  std::string all;
+  int n = std::min<int>(MK_COUNT, max_kernels);
+  for (int i = 0; i < n; ++i) { if (ms_total) ms_total[i] = (float)b->timer.ms[i]; if (launches) launches[i] = b->timer.launches[i]; all += mor_kernel_names[i]; all += (i + 1 < n) ? "," : ""; }
+  if (names && names_cap) { strncpy(names, all.c_str(), names_cap - 1); names[names_cap - 1] = 0; }
+  if (reset) { memset(b->timer.ms, 0, sizeof b->timer.ms); memset(b->timer.launches, 0, sizeof b->timer.launches); }
+  return n;
+}
+
+}   // extern "C"

@@ -1,0 +1,862 @@
+// mor_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) for the hot path
+//   pushRawCloudAndPose (/root/reference/src/MovingObjectRemoval.cpp:516-611) and
+//   filterCloud (:613-696), batched over B independent streams.
+//
+// All of it is HBM / L2-bound integer, compare and scatter work — no MFMA.  Design rules applied:
+//   * 16-byte points (float4) on device, never PCL's 32-byte struct; every streaming pass reads
+//     1-KiB rows per wave instruction (64 lanes × 16 B).
+//   * order-preserving compactions use wave ballots + one LDS exchange per 2048-point tile.
+//   * the PCL kd-tree is replaced by a uniform grid keyed by linear cell id (a collision-free
+//     spatial hash), points counting-sorted by cell so a 3-cell x-run is one contiguous range.
+//   * Euclidean clustering = concurrent union-find with min-index hooking (atomicCAS on roots
+//     only), so the final root of a component is its smallest cloud index whatever the schedule.
+//   * one workgroup→(stream, tile) map that keeps all tiles of a stream on one XCD (blocks b and
+//     b+8 share an XCD), so a stream's grid, sorted points and forest stay in one 4-MiB L2.
+//     Correctness never depends on that placement: forest loads/stores are agent-scope relaxed
+//     atomics, hooks are device-scope CAS, and every cross-kernel hand-off is a kernel boundary.
+//   * fp32 predicates are evaluated exactly as the CPU reference does (individually rounded
+//     mul/add, no FMA contraction): the file is compiled with -ffp-contract=off.
+#include "mor_device.h"
+#include <cfloat>
+
+const char *const mor_kernel_names[MK_COUNT] = {
+    "classify", "scan_tiles", "scatter", "cell_reduce", "cell_scan", "cell_final", "fill", "hook", "flatten",
+    "select_count", "select_scan", "select_scatter", "rank", "offsets", "label", "rhist", "rscan", "rscatter",
+    "stats", "xform_prev", "nn_centroid", "pairs", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
+    "out_count", "out_scan", "out_scatter"};
+
+// ------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// (stream, tile) of this workgroup.  With B a multiple of 8, all tiles of stream s run on the
+// XCD group s % 8 (workgroups are dealt round-robin over the 8 XCDs): L2 locality only.
+__device__ __forceinline__ void map_block(int B, int tiles, int &s, int &t) {
+  int L = blockIdx.x;
+  if ((B & 7) == 0) { int x = L & 7, r = L >> 3; s = (r / tiles) * 8 + x; t = r % tiles; }
+  else { s = L / tiles; t = L % tiles; }
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(v, o, 64); if (lane_id() >= o) v += n; }
+  return v;
+}
+// exclusive scan over the 256 threads of a workgroup; *total = sum.  sh: ≥ 5 ints of LDS.
+__device__ __forceinline__ int block_excl_scan(int v, int *sh, int *total) {
+  int inc = wave_incl_scan(v);
+  if (lane_id() == 63) sh[wave_id()] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < MOR_BT / 64; ++w) { int x = sh[w]; if (w < wave_id()) base += x; tot += x; }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// fromPCLPointCloud2 (:523): named float32 fields of a blob record → (x,y,z,intensity)
+__device__ __forceinline__ float4 load_point(const MorStreamArgs &a, uint32_t i) {
+  if (a.step == 16 && a.off_x == 0 && a.off_y == 4 && a.off_z == 8 && a.off_i == 12)
+    return reinterpret_cast<const float4 *>(a.data)[i];
+  const char *r = reinterpret_cast<const char *>(a.data) + (size_t)i * a.step;
+  float4 p;
+  p.x = *reinterpret_cast<const float *>(r + a.off_x);
+  p.y = *reinterpret_cast<const float *>(r + a.off_y);
+  p.z = *reinterpret_cast<const float *>(r + a.off_z);
+  p.w = (a.off_i == 0xFFFFFFFFu) ? 0.0f : *reinterpret_cast<const float *>(r + a.off_i);
+  return p;
+}
+
+// groundPlaneRemoval(x,y,z) (:62-88): 0 = dropped by the x/y PassThrough pair (or non-finite),
+// 1 = removed by the CropBox (→ gp_indices), 2 = kept in `cloud`.
+__device__ __forceinline__ int classify(const MorDev &d, float4 p) {
+  bool fin = __builtin_isfinite(p.x) && __builtin_isfinite(p.y) && __builtin_isfinite(p.z);
+  if (!fin || p.x < -d.trim_x || p.x > d.trim_x || p.y < -d.trim_y || p.y > d.trim_y) return 0;
+  return (p.z < d.gp_limit || p.z > d.trim_z) ? 1 : 2;
+}
+
+__device__ __forceinline__ int cell_axis(float v, float o, float inv, int n) {
+  int c = (int)floorf((v - o) * inv);
+  return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+__device__ __forceinline__ int cell_axis_unclamped(float v, float o, float inv) { return (int)floorf((v - o) * inv); }
+
+// L2_Simple: ((dx·dx)+(dy·dy))+(dz·dz), each operation rounded (no contraction)
+__device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+  float dx = ax - bx, dy = ay - by, dz = az - bz;
+  float r = dx * dx; r = r + dy * dy; r = r + dz * dz;
+  return r;
+}
+
+// ------------------------------------------------------------------------------------ G1: trim + ground split
+// pass 1: per-tile counts of (non-ground, ground)
+__global__ __launch_bounds__(MOR_BT) void k_classify(MorDev d) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  const MorStreamArgs a = d.args[s];
+  uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
+  int c_ng = 0, c_g = 0;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    uint32_t i = base + it * 64 + lane_id();
+    int cls = (i < a.n) ? classify(d, load_point(a, i)) : 0;
+    c_ng += __popcll(__ballot(cls == 2));
+    c_g += __popcll(__ballot(cls == 1));
+  }
+  __shared__ int sh[8];
+  if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int *o = d.tile_cnt + ((size_t)s * d.tiles_max + t) * 2;
+    o[0] = sh[0] + sh[1] + sh[2] + sh[3];
+    o[1] = sh[4] + sh[5] + sh[6] + sh[7];
+  }
+}
+
+// one workgroup per stream: exclusive scan of the tile counts; publishes N, T, M, G
+__global__ __launch_bounds__(MOR_BT) void k_scan_tiles(MorDev d) {
+  int s = blockIdx.x;
+  __shared__ int sh[8];
+  int carry_ng = 0, carry_g = 0;
+  for (int b = 0; b < d.tiles; b += MOR_BT) {
+    int t = b + threadIdx.x;
+    const int *c = d.tile_cnt + ((size_t)s * d.tiles_max + t) * 2;
+    int v0 = t < d.tiles ? c[0] : 0, v1 = t < d.tiles ? c[1] : 0, t0, t1;
+    int e0 = block_excl_scan(v0, sh, &t0), e1 = block_excl_scan(v1, sh, &t1);
+    if (t < d.tiles) { int *o = d.tile_off + ((size_t)s * d.tiles_max + t) * 2; o[0] = carry_ng + e0; o[1] = carry_g + e1; }
+    carry_ng += t0; carry_g += t1;
+  }
+  if (threadIdx.x == 0) {
+    MorFrameInfo &f = d.info[s];
+    f.N = d.args[s].n; f.M = carry_ng; f.G = carry_g; f.T = carry_ng + carry_g; f.flags = 0; f.n_pairs = 0; f.K = 0; f.C = 0;
+    f.Kprev = d.has_prev ? f.Kprev : 0; f.Cprev = d.has_prev ? f.Cprev : 0;
+  }
+}
+
+// pass 2: order-preserving split into `cloud` / ground, cell histogram, forest init
+__global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  const MorStreamArgs a = d.args[s];
+  uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
+  if ((uint32_t)t * MOR_TILE >= a.n) return;
+  float4 p[8]; int cls[8]; unsigned long long m_ng[8], m_g[8];
+  int c_ng = 0, c_g = 0;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    uint32_t i = base + it * 64 + lane_id();
+    cls[it] = 0;
+    if (i < a.n) { p[it] = load_point(a, i); cls[it] = classify(d, p[it]); }
+    m_ng[it] = __ballot(cls[it] == 2); m_g[it] = __ballot(cls[it] == 1);
+    c_ng += __popcll(m_ng[it]); c_g += __popcll(m_g[it]);
+  }
+  __shared__ int sh[8];
+  if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
+  __syncthreads();
+  const int *to = d.tile_off + ((size_t)s * d.tiles_max + t) * 2;
+  int r_ng = to[0], r_g = to[1];
+  for (int w = 0; w < wave_id(); ++w) { r_ng += sh[w]; r_g += sh[4 + w]; }
+  const size_t so = (size_t)s * d.Nmax;
+  int *cell_cnt = d.cell_cnt + (size_t)s * d.g.ncells;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    int k_ng = r_ng + __popcll(m_ng[it] & lanemask_lt());
+    int k_g = r_g + __popcll(m_g[it] & lanemask_lt());
+    if (cls[it] == 2) {
+      int cx = cell_axis(p[it].x, d.g.ox, d.g.inv_cs, d.g.nx), cy = cell_axis(p[it].y, d.g.oy, d.g.inv_cs, d.g.ny), cz = cell_axis(p[it].z, d.g.oz, d.g.inv_cs, d.g.nz);
+      int c = (cz * d.g.ny + cy) * d.g.nx + cx;
+      d.cloud[so + k_ng] = p[it];
+      d.cloud_tidx[so + k_ng] = k_ng + k_g;   // index in the trimmed cloud (both ranks are exclusive counts of earlier kept points)
+      d.cell_of[so + k_ng] = c;
+      d.parent[so + k_ng] = k_ng;
+      d.csize[so + k_ng] = 0;
+      d.cid_of_root[so + k_ng] = -1;
+      atomicAdd(&cell_cnt[c], 1);
+    } else if (cls[it] == 1) {
+      d.ground[so + k_g] = p[it];
+      d.gp_idx[so + k_g] = k_ng + k_g;
+    }
+    r_ng += __popcll(m_ng[it]); r_g += __popcll(m_g[it]);
+  }
+}
+
+// ------------------------------------------------------------------------------------ grid: exclusive scan of the cell histogram
+__global__ __launch_bounds__(MOR_BT) void k_cell_reduce(MorDev d) {
+  int s, t; map_block(d.B, d.ctiles, s, t);
+  const int *c = d.cell_cnt + (size_t)s * d.g.ncells;
+  int base = t * MOR_TILE, sum = 0;
+  for (int i = base + threadIdx.x; i < min(base + MOR_TILE, d.g.ncells); i += MOR_BT) sum += c[i];
+  __shared__ int sh[8]; int tot;
+  block_excl_scan(sum, sh, &tot);
+  if (threadIdx.x == 0) d.ctile_sum[(size_t)s * d.ctiles + t] = tot;
+}
+__global__ __launch_bounds__(MOR_BT) void k_cell_scan(MorDev d) {
+  int s = blockIdx.x; __shared__ int sh[8]; int carry = 0;
+  int *c = d.ctile_sum + (size_t)s * d.ctiles;
+  for (int b = 0; b < d.ctiles; b += MOR_BT) {
+    int t = b + threadIdx.x, v = t < d.ctiles ? c[t] : 0, tot;
+    int e = block_excl_scan(v, sh, &tot);
+    if (t < d.ctiles) c[t] = carry + e;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) d.cell_start[(size_t)s * (d.g.ncells + 1) + d.g.ncells] = carry;
+}
+__global__ __launch_bounds__(MOR_BT) void k_cell_final(MorDev d) {
+  int s, t; map_block(d.B, d.ctiles, s, t);
+  int *cnt = d.cell_cnt + (size_t)s * d.g.ncells;
+  int *start = d.cell_start + (size_t)s * (d.g.ncells + 1);
+  int base = t * MOR_TILE + threadIdx.x * 8;   // 8 consecutive cells per thread
+  int v[8], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { v[k] = (base + k < d.g.ncells) ? cnt[base + k] : 0; sum += v[k]; }
+  __shared__ int sh[8]; int tot;
+  int e = block_excl_scan(sum, sh, &tot) + d.ctile_sum[(size_t)s * d.ctiles + t];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) if (base + k < d.g.ncells) { start[base + k] = e; e += v[k]; cnt[base + k] = 0; }
+}
+
+// counting-sort scatter: sorted[slot] = (x,y,z,bits(cloud index)); order inside a cell is arbitrary
+// (nothing downstream depends on it: roots are min indices, NN results are minima)
+__global__ __launch_bounds__(MOR_BT) void k_fill(MorDev d) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  int M = d.info[s].M, base = t * MOR_TILE;
+  if (base >= M) return;
+  const size_t so = (size_t)s * d.Nmax;
+  int *cnt = d.cell_cnt + (size_t)s * d.g.ncells;
+  const int *start = d.cell_start + (size_t)s * (d.g.ncells + 1);
+  for (int i = base + threadIdx.x; i < min(base + MOR_TILE, M); i += MOR_BT) {
+    int c = d.cell_of[so + i];
+    int slot = start[c] + atomicAdd(&cnt[c], 1);
+    float4 p = d.cloud[so + i];
+    p.w = __int_as_float(i);
+    d.sorted[so + slot] = p;
+  }
+}
+
+// ------------------------------------------------------------------------------------ C1: Euclidean clustering = connected components
+__device__ __forceinline__ int uf_find(int *P, int x) {
+  int p = ld_agent(P + x);
+  while (p != x) {
+    int gp = ld_agent(P + p);
+    if (gp == p) return p;
+    st_agent(P + x, gp);   // path halving: any smaller member of the same component keeps the forest valid
+    x = gp; p = ld_agent(P + x);
+  }
+  return x;
+}
+// returns the (current) root of the merged component.  Only true roots are ever re-pointed
+// (CAS expects parent[r] == r) and always to a smaller index, so parent ≤ child holds at all times.
+__device__ __forceinline__ int uf_unite(int *P, int a, int b) {
+  int ra = uf_find(P, a), rb = uf_find(P, b);
+  while (ra != rb) {
+    if (ra < rb) { int x = ra; ra = rb; rb = x; }
+    int old = atomicCAS(P + ra, ra, rb);
+    if (old == ra) return rb;
+    ra = uf_find(P, old);
+  }
+  return ra;
+}
+
+// one thread per point (cell order): test the 27-cell stencil as 9 contiguous x-runs, unite with
+// every smaller-index neighbour with d² < r² (EuclideanClusterExtraction's edge predicate, :213-218)
+__global__ __launch_bounds__(MOR_BT) void k_hook(MorDev d) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  int M = d.info[s].M, base = t * MOR_TILE;
+  if (base >= M) return;
+  const float4 *sp = d.sorted + (size_t)s * d.Nmax;
+  const int *start = d.cell_start + (size_t)s * (d.g.ncells + 1);
+  int *P = d.parent + (size_t)s * d.Nmax;
+  const float r2 = d.r2;
+  for (int js = base + threadIdx.x; js < min(base + MOR_TILE, M); js += MOR_BT) {
+    float4 q = sp[js];
+    int i = __float_as_int(q.w), ri = i;
+    int cx = cell_axis(q.x, d.g.ox, d.g.inv_cs, d.g.nx), cy = cell_axis(q.y, d.g.oy, d.g.inv_cs, d.g.ny), cz = cell_axis(q.z, d.g.oz, d.g.inv_cs, d.g.nz);
+    int x0 = max(cx - 1, 0), x1 = min(cx + 1, d.g.nx - 1);
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, d.g.nz - 1); ++z)
+      for (int y = max(cy - 1, 0); y <= min(cy + 1, d.g.ny - 1); ++y) {
+        int row = (z * d.g.ny + y) * d.g.nx;
+        int b = start[row + x0], e = start[row + x1 + 1];
+        for (int k = b; k < e; ++k) {
+          float4 p = sp[k];
+          int j = __float_as_int(p.w);
+          if (j >= i) continue;
+          if (sqdist(q.x, q.y, q.z, p.x, p.y, p.z) < r2) {
+            if (ld_agent(P + j) == ri) continue;   // already under my root
+            ri = uf_unite(P, ri, j);
+          }
+        }
+      }
+  }
+}
+
+// root of every point + component sizes
+__global__ __launch_bounds__(MOR_BT) void k_flatten(MorDev d) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  int M = d.info[s].M, base = t * MOR_TILE;
+  if (base >= M) return;
+  const size_t so = (size_t)s * d.Nmax;
+  for (int i = base + threadIdx.x; i < min(base + MOR_TILE, M); i += MOR_BT) {
+    int r = i, p = d.parent[so + r];
+    while (p != r) { r = p; p = d.parent[so + r]; }
+    d.label[so + i] = r;
+    atomicAdd(&d.csize[so + r], 1);
+  }
+}
+
+// kept components: min_cluster_size ≤ size ≤ max_cluster_size (:215-216), compacted in ascending root order
+__device__ __forceinline__ bool kept_root(const MorDev &d, size_t so, int i) {
+  if (d.label[so + i] != i) return false;
+  long long n = d.csize[so + i];
+  return n >= d.min_cs && n <= d.max_cs;
+}
+__global__ __launch_bounds__(MOR_BT) void k_select_count(MorDev d) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  int M = d.info[s].M, base = t * MOR_TILE, c = 0;
+  const size_t so = (size_t)s * d.Nmax;
+  for (int i = base + threadIdx.x; i < min(base + MOR_TILE, M); i += MOR_BT) c += kept_root(d, so, i);
+  __shared__ int sh[8]; int tot;
+  block_excl_scan(c, sh, &tot);
+  if (threadIdx.x == 0) d.ktile_cnt[(size_t)s * d.tiles_max + t] = tot;
+}
+__global__ __launch_bounds__(MOR_BT) void k_select_scan(MorDev d) {
+  int s = blockIdx.x; __shared__ int sh[8]; int carry = 0;
+  int *c = d.ktile_cnt + (size_t)s * d.tiles_max;
+  for (int b = 0; b < d.tiles; b += MOR_BT) {
+    int t = b + threadIdx.x, v = t < d.tiles ? c[t] : 0, tot;
+    int e = block_excl_scan(v, sh, &tot);
+    if (t < d.tiles) c[t] = carry + e;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    MorFrameInfo &f = d.info[s];
+    if (carry > d.Kcap) { f.flags |= 1u; carry = d.Kcap; }
+    f.K = carry;
+  }
+}
+__global__ __launch_bounds__(MOR_BT) void k_select_scatter(MorDev d) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  int M = d.info[s].M, base = t * MOR_TILE;
+  if (base >= M) return;
+  const size_t so = (size_t)s * d.Nmax;
+  int off = d.ktile_cnt[(size_t)s * d.tiles_max + t];
+  // 2048 items as 8 rows of 256: rows are consecutive, so row-major exclusive scan = index order
+  __shared__ int sh[8];
+  for (int row = 0; row < 8; ++row) {
+    int i = base + row * MOR_BT + threadIdx.x;
+    int k = (i < M) ? kept_root(d, so, i) : 0, tot;
+    int e = block_excl_scan(k, sh, &tot);
+    if (k && off + e < d.Kcap) { d.kroot[(size_t)s * d.Kcap + off + e] = i; d.ksize[(size_t)s * d.Kcap + off + e] = d.csize[so + i]; }
+    off += tot;
+  }
+}
+
+// cluster order: size descending, ties by smaller first (= root) index.  K is small: rank by counting.
+__global__ __launch_bounds__(MOR_BT) void k_rank(MorDev d) {
+  int s = blockIdx.y, K = d.info[s].K;
+  int k = blockIdx.x * MOR_BT + threadIdx.x;
+  if (blockIdx.x * MOR_BT >= K) return;
+  const int *kr = d.kroot + (size_t)s * d.Kcap, *ks = d.ksize + (size_t)s * d.Kcap;
+  __shared__ int s_sz[MOR_BT], s_rt[MOR_BT];
+  int my_sz = k < K ? ks[k] : 0, my_rt = k < K ? kr[k] : 0, rank = 0;
+  for (int b = 0; b < K; b += MOR_BT) {
+    int j = b + threadIdx.x;
+    s_sz[threadIdx.x] = j < K ? ks[j] : -1; s_rt[threadIdx.x] = j < K ? kr[j] : 0x7fffffff;
+    __syncthreads();
+    int lim = min(MOR_BT, K - b);
+    for (int u = 0; u < lim; ++u) rank += (s_sz[u] > my_sz) || (s_sz[u] == my_sz && s_rt[u] < my_rt);
+    __syncthreads();
+  }
+  if (k < K) {
+    d.cid_of_root[(size_t)s * d.Nmax + my_rt] = rank;
+    d.csz[(size_t)s * d.Kcap + rank] = my_sz;
+  }
+}
+// cluster offsets (exclusive scan of sizes in cluster order), C, clear detection_results (:250-254)
+__global__ __launch_bounds__(MOR_BT) void k_offsets(MorDev d) {
+  int s = blockIdx.x, K = d.info[s].K; __shared__ int sh[8]; int carry = 0;
+  int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1);
+  const int *sz = d.csz + (size_t)s * d.Kcap;
+  for (int b = 0; b < K; b += MOR_BT) {
+    int k = b + threadIdx.x, v = k < K ? sz[k] : 0, tot;
+    int e = block_excl_scan(v, sh, &tot);
+    if (k < K) { off[k] = carry + e; d.det[(size_t)s * d.Kcap + k] = 0; d.pair_of_cur[(size_t)s * d.Kcap + k] = -1; }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) { off[K] = carry; d.info[s].C = carry; }
+}
+// per sorted slot: cluster id of its point → label[cloud index] and sorted.w
+__global__ __launch_bounds__(MOR_BT) void k_label(MorDev d) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  int M = d.info[s].M, base = t * MOR_TILE;
+  if (base >= M) return;
+  const size_t so = (size_t)s * d.Nmax;
+  for (int js = base + threadIdx.x; js < min(base + MOR_TILE, M); js += MOR_BT) {
+    float4 q = d.sorted[so + js];
+    int i = __float_as_int(q.w);
+    int cid = d.cid_of_root[so + d.label[so + i]];
+    q.w = __int_as_float(cid);
+    d.sorted[so + js] = q;
+    d.pcid[so + i] = cid;   // `label` still serves other slots as root → cluster ids go to their own array
+  }
+}
+
+// ------------------------------------------------------------------------------------ stable partition of cloud indices by cluster id (LSD radix, 8-bit digits)
+// pass 0 reads (pcid = cluster id per cloud point, value = index) and drops unclustered points
+__device__ __forceinline__ void radix_item(const MorDev &d, int pass, size_t so, int count, int i, int &key, int &val, bool &valid) {
+  valid = i < count;
+  key = 0; val = 0;
+  if (!valid) return;
+  if (pass == 0) { key = d.pcid[so + i]; val = i; valid = key >= 0; }
+  else { key = d.rkeys[pass & 1][so + i]; val = d.rvals[pass & 1][so + i]; }
+}
+__device__ __forceinline__ int radix_count(const MorDev &d, int pass, int s) { return pass == 0 ? d.info[s].M : d.info[s].C; }
+
+__global__ __launch_bounds__(MOR_BT) void k_rhist(MorDev d, int pass) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  int count = radix_count(d, pass, s), base = t * MOR_TILE;
+  __shared__ int h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t so = (size_t)s * d.Nmax;
+  for (int i = base + threadIdx.x; i < min(base + MOR_TILE, count); i += MOR_BT) {
+    int key, val; bool valid; radix_item(d, pass, so, count, i, key, val, valid);
+    if (valid) atomicAdd(&h[(key >> (8 * pass)) & 255], 1);
+  }
+  __syncthreads();
+  d.rhist[((size_t)s * d.tiles_max + t) * 256 + threadIdx.x] = h[threadIdx.x];
+}
+// one workgroup per stream, one thread per digit: offsets[tile][digit] = Σ smaller digits + Σ earlier tiles
+__global__ __launch_bounds__(MOR_BT) void k_rscan(MorDev d) {
+  int s = blockIdx.x; __shared__ int sh[8];
+  int *h = d.rhist + (size_t)s * d.tiles_max * 256;
+  int run = 0;
+  for (int t = 0; t < d.tiles; ++t) { int v = h[t * 256 + threadIdx.x]; h[t * 256 + threadIdx.x] = run; run += v; }
+  int tot, base = block_excl_scan(run, sh, &tot);
+  for (int t = 0; t < d.tiles; ++t) h[t * 256 + threadIdx.x] += base;
+}
+__global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, int pass, int last) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  int count = radix_count(d, pass, s), tb = t * MOR_TILE;
+  if (tb >= count) return;
+  const size_t so = (size_t)s * d.Nmax;
+  __shared__ int wcnt[4][256];
+  for (int k = threadIdx.x; k < 4 * 256; k += MOR_BT) (&wcnt[0][0])[k] = 0;
+  __syncthreads();
+  int key[8], val[8], pre[8]; bool valid[8];
+  int base = tb + wave_id() * 512;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    int i = base + it * 64 + lane_id();
+    radix_item(d, pass, so, count, i, key[it], val[it], valid[it]);
+    int dg = (key[it] >> (8 * pass)) & 255;
+    unsigned long long peers = __ballot(valid[it]);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) { unsigned long long m = __ballot((dg >> b) & 1); peers &= ((dg >> b) & 1) ? m : ~m; }
+    pre[it] = 0;
+    if (valid[it]) {
+      int leader = __ffsll((long long)peers) - 1, rank = __popcll(peers & lanemask_lt()), basec = 0;
+      if (lane_id() == leader) basec = atomicAdd(&wcnt[wave_id()][dg], __popcll(peers));
+      basec = __shfl(basec, leader, 64);
+      pre[it] = basec + rank;
+    }
+  }
+  __syncthreads();
+  {  // exclusive prefix over the 4 waves per digit + global offset of (tile, digit)
+    int dg = threadIdx.x, run = d.rhist[((size_t)s * d.tiles_max + t) * 256 + dg];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { int v = wcnt[w][dg]; wcnt[w][dg] = run; run += v; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    if (!valid[it]) continue;
+    int dg = (key[it] >> (8 * pass)) & 255;
+    int pos = wcnt[wave_id()][dg] + pre[it];
+    if (last) d.cl_idx[so + pos] = val[it];
+    else { d.rkeys[(pass + 1) & 1][so + pos] = key[it]; d.rvals[(pass + 1) & 1][so + pos] = val[it]; }
+  }
+}
+
+// ------------------------------------------------------------------------------------ C2: per-cluster extraction + centroid + AABB
+struct Red6 { double sx, sy, sz; float mnx, mny, mnz, mxx, mxy, mxz; };
+__device__ __forceinline__ void red6_block(Red6 &r, Red6 *sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    r.sx += __shfl_down(r.sx, o, 64); r.sy += __shfl_down(r.sy, o, 64); r.sz += __shfl_down(r.sz, o, 64);
+    r.mnx = fminf(r.mnx, __shfl_down(r.mnx, o, 64)); r.mny = fminf(r.mny, __shfl_down(r.mny, o, 64)); r.mnz = fminf(r.mnz, __shfl_down(r.mnz, o, 64));
+    r.mxx = fmaxf(r.mxx, __shfl_down(r.mxx, o, 64)); r.mxy = fmaxf(r.mxy, __shfl_down(r.mxy, o, 64)); r.mxz = fmaxf(r.mxz, __shfl_down(r.mxz, o, 64));
+  }
+  if (lane_id() == 0) sh[wave_id()] = r;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < MOR_BT / 64; ++w) {
+      r.sx += sh[w].sx; r.sy += sh[w].sy; r.sz += sh[w].sz;
+      r.mnx = fminf(r.mnx, sh[w].mnx); r.mny = fminf(r.mny, sh[w].mny); r.mnz = fminf(r.mnz, sh[w].mnz);
+      r.mxx = fmaxf(r.mxx, sh[w].mxx); r.mxy = fmaxf(r.mxy, sh[w].mxy); r.mxz = fmaxf(r.mxz, sh[w].mxz);
+    }
+  }
+  __syncthreads();
+}
+// one workgroup per cluster (grid-stride): copy member points (:224-230), centroid = Σ(double)p / n
+// cast to fp32 (:239-243), AABB for the volume gate.  Fixed reduction tree ⇒ run-to-run identical.
+__global__ __launch_bounds__(MOR_BT) void k_stats(MorDev d) {
+  int s = blockIdx.y, K = d.info[s].K;
+  const size_t so = (size_t)s * d.Nmax;
+  const int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1);
+  __shared__ Red6 sh[MOR_BT / 64];
+  for (int k = blockIdx.x; k < K; k += gridDim.x) {
+    int b = off[k], e = off[k + 1];
+    Red6 r = {0, 0, 0, FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int j = b + threadIdx.x; j < e; j += MOR_BT) {
+      float4 p = d.cloud[so + d.cl_idx[so + j]];
+      d.cl_pts[d.cur][so + j] = p; d.cl_cid[d.cur][so + j] = k;
+      r.sx += (double)p.x; r.sy += (double)p.y; r.sz += (double)p.z;
+      r.mnx = fminf(r.mnx, p.x); r.mny = fminf(r.mny, p.y); r.mnz = fminf(r.mnz, p.z);
+      r.mxx = fmaxf(r.mxx, p.x); r.mxy = fmaxf(r.mxy, p.y); r.mxz = fmaxf(r.mxz, p.z);
+    }
+    red6_block(r, sh);
+    if (threadIdx.x == 0) {
+      double n = (double)(e - b);
+      d.centroid[d.cur][(size_t)s * d.Kcap + k] = make_float4((float)(r.sx / n), (float)(r.sy / n), (float)(r.sz / n), 0.f);
+      d.amin[d.cur][(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
+      d.amax[d.cur][(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ P1: previous frame → current pose (:536-551)
+__device__ __forceinline__ void xform(const float *m, float &x, float &y, float &z) {
+  float a = x, b = y, c = z;
+  x = ((m[0] * a + m[1] * b) + m[2] * c) + m[3];
+  y = ((m[4] * a + m[5] * b) + m[6] * c) + m[7];
+  z = ((m[8] * a + m[9] * b) + m[10] * c) + m[11];
+}
+__global__ __launch_bounds__(MOR_BT) void k_xform_prev(MorDev d) {
+  int s = blockIdx.y, pv = d.cur ^ 1, K = d.info[s].Kprev;
+  const size_t so = (size_t)s * d.Nmax;
+  const int *off = d.cl_off[pv] + (size_t)s * (d.Kcap + 1);
+  __shared__ Red6 sh[MOR_BT / 64];
+  __shared__ float m[12];
+  if (threadIdx.x < 12) m[threadIdx.x] = d.args[s].xf[threadIdx.x];
+  __syncthreads();
+  for (int k = blockIdx.x; k < K; k += gridDim.x) {
+    int b = off[k], e = off[k + 1];
+    Red6 r = {0, 0, 0, FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int j = b + threadIdx.x; j < e; j += MOR_BT) {
+      float4 p = d.cl_pts[pv][so + j];
+      xform(m, p.x, p.y, p.z);
+      d.cl_pts[pv][so + j] = p;
+      r.mnx = fminf(r.mnx, p.x); r.mny = fminf(r.mny, p.y); r.mnz = fminf(r.mnz, p.z);
+      r.mxx = fmaxf(r.mxx, p.x); r.mxy = fmaxf(r.mxy, p.y); r.mxz = fmaxf(r.mxz, p.z);
+    }
+    red6_block(r, sh);
+    if (threadIdx.x == 0) {
+      float4 c = d.centroid[pv][(size_t)s * d.Kcap + k];
+      xform(m, c.x, c.y, c.z);
+      d.centroid[pv][(size_t)s * d.Kcap + k] = c;
+      d.amin[pv][(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
+      d.amax[pv][(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
+      d.pair_of_prev[(size_t)s * d.Kcap + k] = -1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ P2: centroid correspondence (:285-307)
+// dir 0: nearest current centroid of every previous centroid; dir 1: the reverse.  Squared fp32
+// distance, ties → lowest index (ascending scan with strict <).
+__global__ __launch_bounds__(MOR_BT) void k_nn_centroid(MorDev d, int dir) {
+  int s = blockIdx.y, pv = d.cur ^ 1;
+  int Ksrc = dir == 0 ? d.info[s].Kprev : d.info[s].K, Kdst = dir == 0 ? d.info[s].K : d.info[s].Kprev;
+  if (blockIdx.x * MOR_BT >= Ksrc) return;
+  const float4 *src = d.centroid[dir == 0 ? pv : d.cur] + (size_t)s * d.Kcap, *dst = d.centroid[dir == 0 ? d.cur : pv] + (size_t)s * d.Kcap;
+  int i = blockIdx.x * MOR_BT + threadIdx.x;
+  float4 q = i < Ksrc ? src[i] : make_float4(0, 0, 0, 0);
+  __shared__ float4 tile[MOR_BT];
+  float best = INFINITY; int bi = -1;
+  for (int b = 0; b < Kdst; b += MOR_BT) {
+    if (b + threadIdx.x < Kdst) tile[threadIdx.x] = dst[b + threadIdx.x];
+    __syncthreads();
+    int lim = min(MOR_BT, Kdst - b);
+    for (int u = 0; u < lim; ++u) { float dd = sqdist(q.x, q.y, q.z, tile[u].x, tile[u].y, tile[u].z); if (dd < best) { best = dd; bi = b + u; } }
+    __syncthreads();
+  }
+  if (i < Ksrc) {
+    if (dir == 0) { d.nn_fwd[(size_t)s * d.Kcap + i] = bi; d.nn_fwd_d[(size_t)s * d.Kcap + i] = best; }
+    else d.nn_bwd[(size_t)s * d.Kcap + i] = bi;
+  }
+}
+// reciprocal test + volumeConstraint (:264-283), correspondences emitted in source-index order
+__global__ __launch_bounds__(MOR_BT) void k_pairs(MorDev d) {
+  int s = blockIdx.x, pv = d.cur ^ 1, Kp = d.info[s].Kprev, Kc = d.info[s].K;
+  __shared__ int sh[8]; int carry = 0;
+  const size_t ko = (size_t)s * d.Kcap;
+  for (int b = 0; b < Kp; b += MOR_BT) {
+    int i = b + threadIdx.x, ok = 0, j = -1;
+    if (i < Kp && Kc > 0) {
+      j = d.nn_fwd[ko + i];
+      if (j >= 0 && d.nn_bwd[ko + j] == i) {
+        float4 a0 = d.amin[pv][ko + i], a1 = d.amax[pv][ko + i], c0 = d.amin[d.cur][ko + j], c1 = d.amax[d.cur][ko + j];
+        float vp = (a1.x - a0.x) * (a1.y - a0.y); vp = vp * (a1.z - a0.z);
+        float vc = (c1.x - c0.x) * (c1.y - c0.y); vc = vc * (c1.z - c0.z);
+        double dp = (double)vp, dc = (double)vc;
+        ok = (fabs(dp - dc) / (dp + dc)) < d.vol_thr;   // NaN (0/0) compares false ⇒ rejected, as in the reference
+      }
+    }
+    int tot, e = block_excl_scan(ok, sh, &tot);
+    if (ok) {
+      int pr = carry + e;
+      d.pair_q[ko + pr] = i; d.pair_m[ko + pr] = j; d.pair_d[ko + pr] = d.nn_fwd_d[ko + i]; d.pair_cnt[ko + pr] = 0;
+      d.pair_of_prev[ko + i] = pr; d.pair_of_cur[ko + j] = pr;
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) d.info[s].n_pairs = carry;
+}
+
+// ------------------------------------------------------------------------------------ P3: method 1 (:336-366)
+// per point of a matched previous cluster: squared distance to the nearest point of the matched
+// current cluster, found in the current frame's grid inside a √ub stencil (a farther neighbour can
+// never satisfy d² < ub); count lb < d² < ub.
+__global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  int pv = d.cur ^ 1, Cp = d.info[s].Cprev, base = t * MOR_TILE;
+  if (base >= Cp) return;
+  const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
+  const float4 *sp = d.sorted + so;
+  const int *start = d.cell_start + (size_t)s * (d.g.ncells + 1);
+  const int R = d.score_R;
+  for (int j = base + threadIdx.x; j < min(base + MOR_TILE, Cp); j += MOR_BT) {
+    int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
+    if (pr < 0) continue;
+    int target = d.pair_m[ko + pr];
+    float4 q = d.cl_pts[pv][so + j];
+    int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.g.oz, d.g.inv_cs);
+    int x0 = min(max(cx - R, 0), d.g.nx - 1), x1 = min(max(cx + R, 0), d.g.nx - 1);
+    int y0 = min(max(cy - R, 0), d.g.ny - 1), y1 = min(max(cy + R, 0), d.g.ny - 1);
+    int z0 = min(max(cz - R, 0), d.g.nz - 1), z1 = min(max(cz + R, 0), d.g.nz - 1);
+    float best = INFINITY;
+    for (int z = z0; z <= z1; ++z)
+      for (int y = y0; y <= y1; ++y) {
+        int row = (z * d.g.ny + y) * d.g.nx;
+        int b = start[row + x0], e = start[row + x1 + 1];
+        for (int k = b; k < e; ++k) {
+          float4 p = sp[k];
+          if (__float_as_int(p.w) != target) continue;
+          best = fminf(best, sqdist(q.x, q.y, q.z, p.x, p.y, p.z));
+        }
+      }
+    if (best > d.pde_lb && best < d.pde_ub) atomicAdd(&d.pair_cnt[ko + pr], 1);
+  }
+}
+
+// ------------------------------------------------------------------------------------ P4: method 2 (:309-334)
+// OctreePointCloudChangeDetector as a voxel hash set.  PCL grows its octree from the first inserted
+// point p0 of the previous cluster: box = p0 ± res/2, which getKeyBitSize() widens to two voxels per
+// axis and re-centres (min = p0 − res); every later growth shifts min by a multiple of res.  So the
+// leaf lattice is {p0 − res + k·res}; keys by floor in fp64.
+#define VOX_EMPTY 0xFFFFFFFFFFFFFFFFull
+__device__ __forceinline__ int vox_table_size(const MorDev &d, int Cprev) { int h = 64; while (h < 2 * Cprev && h < d.Hcap) h <<= 1; return h; }
+__device__ __forceinline__ unsigned long long vox_hash(unsigned long long k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; }
+__device__ __forceinline__ bool vox_key(const MorDev &d, int s, int pr, float4 p, unsigned long long &key) {
+  int pv = d.cur ^ 1;
+  const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
+  int q = d.pair_q[ko + pr];
+  float4 p0 = d.cl_pts[pv][so + d.cl_off[pv][(size_t)s * (d.Kcap + 1) + q]];
+  const double res = d.opc_res, eps = (double)FLT_EPSILON;
+  long long kk[3]; const float pc[3] = {p.x, p.y, p.z}, p0c[3] = {p0.x, p0.y, p0.z};
+  bool ok = pr < 65535;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    double mn = (double)p0c[a] - res / 2, mx = (double)p0c[a] + res / 2;
+    double over = (2.0 * res - (mx - mn)) / 2.0;
+    if (over > eps) mn -= over;
+    kk[a] = (long long)floor(((double)pc[a] - mn) / res);
+    ok = ok && kk[a] >= -32768 && kk[a] < 32768;
+  }
+  key = ((unsigned long long)pr << 48) | ((unsigned long long)(kk[0] + 32768) << 32) | ((unsigned long long)(kk[1] + 32768) << 16) | (unsigned long long)(kk[2] + 32768);
+  return ok;
+}
+__global__ __launch_bounds__(MOR_BT) void k_vox_clear(MorDev d) {
+  int s = blockIdx.y, H = vox_table_size(d, d.info[s].Cprev);
+  unsigned long long *tab = d.vox + (size_t)s * d.Hcap;
+  for (int i = blockIdx.x * MOR_BT + threadIdx.x; i < H; i += gridDim.x * MOR_BT) tab[i] = VOX_EMPTY;
+}
+__global__ __launch_bounds__(MOR_BT) void k_vox_insert(MorDev d) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  int pv = d.cur ^ 1, Cp = d.info[s].Cprev, base = t * MOR_TILE;
+  if (base >= Cp) return;
+  const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
+  unsigned long long *tab = d.vox + (size_t)s * d.Hcap; int H = vox_table_size(d, Cp);
+  for (int j = base + threadIdx.x; j < min(base + MOR_TILE, Cp); j += MOR_BT) {
+    int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
+    if (pr < 0) continue;
+    unsigned long long key;
+    if (!vox_key(d, s, pr, d.cl_pts[pv][so + j], key)) { atomicOr(&d.info[s].flags, 2u); continue; }
+    unsigned h = (unsigned)vox_hash(key) & (H - 1);
+    for (;;) { unsigned long long old = atomicCAS(&tab[h], VOX_EMPTY, key); if (old == VOX_EMPTY || old == key) break; h = (h + 1) & (H - 1); }
+  }
+}
+__global__ __launch_bounds__(MOR_BT) void k_vox_probe(MorDev d) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  int C = d.info[s].C, base = t * MOR_TILE;
+  if (base >= C) return;
+  const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
+  const unsigned long long *tab = d.vox + (size_t)s * d.Hcap; int H = vox_table_size(d, d.info[s].Cprev);
+  for (int j = base + threadIdx.x; j < min(base + MOR_TILE, C); j += MOR_BT) {
+    int pr = d.pair_of_cur[ko + d.cl_cid[d.cur][so + j]];
+    if (pr < 0) continue;
+    unsigned long long key;
+    if (!vox_key(d, s, pr, d.cl_pts[d.cur][so + j], key)) { atomicOr(&d.info[s].flags, 2u); continue; }
+    unsigned h = (unsigned)vox_hash(key) & (H - 1); bool found = false;
+    for (;;) { unsigned long long v = tab[h]; if (v == key) { found = true; break; } if (v == VOX_EMPTY) break; h = (h + 1) & (H - 1); }
+    if (!found) atomicAdd(&d.pair_cnt[ko + pr], 1);
+  }
+}
+
+// ------------------------------------------------------------------------------------ P5 + summary to the host
+// scores → detection_results (:580-606); then everything the host tracker needs goes straight
+// into pinned host memory (a few KB per stream), so the push needs exactly one stream sync.
+__global__ __launch_bounds__(MOR_BT) void k_decide(MorDev d) {
+  int s = blockIdx.x, pv = d.cur ^ 1;
+  const size_t ko = (size_t)s * d.Kcap;
+  MorFrameInfo f = d.info[s];
+  int np = d.has_prev ? (int)f.n_pairs : 0;
+  const int *offc = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1), *offp = d.cl_off[pv] + (size_t)s * (d.Kcap + 1);
+  for (int pr = threadIdx.x; pr < np; pr += MOR_BT) {
+    int q = d.pair_q[ko + pr], m = d.pair_m[ko + pr];
+    unsigned long long n1 = (unsigned long long)(offp[q + 1] - offp[q]), n2 = (unsigned long long)(offc[m + 1] - offc[m]);
+    double cnt = (double)d.pair_cnt[ko + pr], score, thr;
+    if (d.method == 1) { score = cnt / (double)((n1 + n2) / 2ull); thr = d.pde_thr; }             // :361, :586
+    else if (d.method == 2) { score = cnt; thr = (double)((n1 + n2) / (unsigned long long)d.opc_norm); } // :330, :590
+    else { score = 0; thr = 0; }
+    d.det[ko + m] = score > thr;                                                                     // :593-604
+    d.h_pair_q[ko + pr] = q; d.h_pair_m[ko + pr] = m; d.h_pair_d[ko + pr] = d.pair_d[ko + pr]; d.h_score[ko + pr] = score;
+  }
+  __syncthreads();
+  int K = (int)f.K;
+  for (int k = threadIdx.x; k < K; k += MOR_BT) { d.h_centroid[ko + k] = d.centroid[d.cur][ko + k]; d.h_det[ko + k] = d.det[ko + k]; }
+  for (int k = threadIdx.x; k <= K; k += MOR_BT) d.h_cl_off[(size_t)s * (d.Kcap + 1) + k] = offc[k];
+  if (threadIdx.x == 0) {
+    f.n_pairs = np;
+    d.info[s].Kprev = f.K; d.info[s].Cprev = f.C;   // this frame is the next push's `ca`
+    d.info[s].n_pairs = np;
+    d.h_info[s] = f;
+  }
+}
+
+// ------------------------------------------------------------------------------------ F1: filtered cloud (:673-687)
+// keep = cloud points whose cluster is not flagged moving (ExtractIndices negative, set semantics;
+// the per-stream error flag reproduces "more indices than points ⇒ empty output"), then ground.
+__device__ __forceinline__ bool out_keep(const MorDev &d, int s, size_t so, int i) {
+  if (d.moving[(size_t)d.B * d.Kcap + s]) return false;
+  int cid = d.pcid[so + i];   // cluster id per cloud point (written by k_label)
+  return !(cid >= 0 && d.moving[(size_t)s * d.Kcap + cid]);
+}
+__global__ __launch_bounds__(MOR_BT) void k_out_count(MorDev d) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  int M = d.info[s].M, base = t * MOR_TILE + wave_id() * 512, c = 0;
+  const size_t so = (size_t)s * d.Nmax;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) { int i = base + it * 64 + lane_id(); c += __popcll(__ballot(i < M && out_keep(d, s, so, i))); }
+  __shared__ int sh[4];
+  if (lane_id() == 0) sh[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) d.otile_cnt[(size_t)s * d.tiles_max + t] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(MOR_BT) void k_out_scan(MorDev d) {
+  int s = blockIdx.x; __shared__ int sh[8]; int carry = 0;
+  int *c = d.otile_cnt + (size_t)s * d.tiles_max;
+  for (int b = 0; b < d.tiles; b += MOR_BT) {
+    int t = b + threadIdx.x, v = t < d.tiles ? c[t] : 0, tot;
+    int e = block_excl_scan(v, sh, &tot);
+    if (t < d.tiles) c[t] = carry + e;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) { d.info[s].n_keep = carry; d.h_nout[s] = (unsigned long long)carry + d.info[s].G; }
+}
+// tiles [0, tiles): kept cloud points; tiles [tiles, 2·tiles): ground points appended after them
+__global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
+  int s, t2; map_block(d.B, 2 * d.tiles, s, t2);
+  const size_t so = (size_t)s * d.Nmax;
+  float4 *out = d.out_ptrs ? d.out_ptrs[s] : d.out + so;
+  if (t2 >= d.tiles) {
+    int t = t2 - d.tiles, G = d.info[s].G, nk = d.info[s].n_keep, base = t * MOR_TILE;
+    for (int i = base + threadIdx.x; i < min(base + MOR_TILE, G); i += MOR_BT) out[nk + i] = d.ground[so + i];
+    return;
+  }
+  int t = t2, M = d.info[s].M;
+  if (t * MOR_TILE >= M) return;
+  int base = t * MOR_TILE + wave_id() * 512, c = 0;
+  unsigned long long mk[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) { int i = base + it * 64 + lane_id(); mk[it] = __ballot(i < M && out_keep(d, s, so, i)); c += __popcll(mk[it]); }
+  __shared__ int sh[4];
+  if (lane_id() == 0) sh[wave_id()] = c;
+  __syncthreads();
+  int r = d.otile_cnt[(size_t)s * d.tiles_max + t];
+  for (int w = 0; w < wave_id(); ++w) r += sh[w];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    int i = base + it * 64 + lane_id();
+    if ((mk[it] >> lane_id()) & 1ull) out[r + __popcll(mk[it] & lanemask_lt())] = d.cloud[so + i];
+    r += __popcll(mk[it]);
+  }
+}
+
+// ------------------------------------------------------------------------------------ launch sequences
+#define MOR_LAUNCH(id, kern, grid, ...)                                   \
+  do {                                                                    \
+    mor_timer_begin(tm, id, st);                                          \
+    hipLaunchKernelGGL(kern, grid, dim3(MOR_BT), 0, st, __VA_ARGS__);     \
+    mor_timer_end(tm, id, st);                                            \
+  } while (0)
+
+void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+  const dim3 gT(d.B * d.tiles), gB(d.B), gC(d.B * d.ctiles), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B);
+  hipMemsetAsync(d.cell_cnt, 0, (size_t)d.B * d.g.ncells * sizeof(int), st);
+  MOR_LAUNCH(MK_CLASSIFY, k_classify, gT, d);
+  MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
+  MOR_LAUNCH(MK_SCATTER, k_scatter, gT, d);
+  MOR_LAUNCH(MK_CELL_REDUCE, k_cell_reduce, gC, d);
+  MOR_LAUNCH(MK_CELL_SCAN, k_cell_scan, gB, d);
+  MOR_LAUNCH(MK_CELL_FINAL, k_cell_final, gC, d);
+  MOR_LAUNCH(MK_FILL, k_fill, gT, d);
+  MOR_LAUNCH(MK_HOOK, k_hook, gT, d);
+  MOR_LAUNCH(MK_FLATTEN, k_flatten, gT, d);
+  MOR_LAUNCH(MK_SELECT_COUNT, k_select_count, gT, d);
+  MOR_LAUNCH(MK_SELECT_SCAN, k_select_scan, gB, d);
+  MOR_LAUNCH(MK_SELECT_SCATTER, k_select_scatter, gT, d);
+  MOR_LAUNCH(MK_RANK, k_rank, gKt, d);
+  MOR_LAUNCH(MK_OFFSETS, k_offsets, gB, d);
+  MOR_LAUNCH(MK_LABEL, k_label, gT, d);
+  for (int pass = 0; pass < d.radix_passes; ++pass) {
+    MOR_LAUNCH(MK_RHIST, k_rhist, gT, d, pass);
+    MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d);
+    MOR_LAUNCH(MK_RSCATTER, k_rscatter, gT, d, pass, pass == d.radix_passes - 1 ? 1 : 0);
+  }
+  MOR_LAUNCH(MK_STATS, k_stats, gK, d);
+  if (d.has_prev) {
+    MOR_LAUNCH(MK_XFORM_PREV, k_xform_prev, gK, d);
+    MOR_LAUNCH(MK_NN, k_nn_centroid, gKt, d, 0);
+    MOR_LAUNCH(MK_NN, k_nn_centroid, gKt, d, 1);
+    MOR_LAUNCH(MK_PAIRS, k_pairs, gB, d);
+    if (d.method == 1) {
+      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) MOR_LAUNCH(MK_SCORE1, k_score_pde, gT, d);
+    } else if (d.method == 2) {
+      MOR_LAUNCH(MK_VOX_CLEAR, k_vox_clear, dim3(64, d.B), d);
+      MOR_LAUNCH(MK_VOX_INSERT, k_vox_insert, gT, d);
+      MOR_LAUNCH(MK_VOX_PROBE, k_vox_probe, gT, d);
+    }
+  }
+  MOR_LAUNCH(MK_DECIDE, k_decide, gB, d);
+}
+
+void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+  const dim3 gT(d.B * d.tiles), gB(d.B), gT2(d.B * 2 * d.tiles);
+  MOR_LAUNCH(MK_OUT_COUNT, k_out_count, gT, d);
+  MOR_LAUNCH(MK_OUT_SCAN, k_out_scan, gB, d);
+  MOR_LAUNCH(MK_OUT_SCATTER, k_out_scatter, gT2, d);
+}

@@ -1,0 +1,293 @@
+"""ctypes binding of libmor_hip.so (include/mor_hip.h).  No CPU fallback: if the library is missing
+or there is no HIP device, construction raises."""
+import ctypes as C
+import os
+import numpy as np
+
+from .params import MorParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmor_hip.so")
+_LIB = None
+MOR_NO_FIELD = 0xFFFFFFFF
+
+# every symbol include/mor_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "mor_sizeof_params", "mor_last_error", "mor_batch_create", "mor_batch_destroy", "mor_batch_streams", "mor_push_batch",
+    "mor_filter_batch", "mor_get_output_device", "mor_create", "mor_push", "mor_filter", "mor_destroy", "mor_get_counts",
+    "mor_get_labels", "mor_get_ground_indices", "mor_get_clusters", "mor_get_centroids", "mor_get_detection",
+    "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_device_alloc", "mor_device_free",
+    "mor_device_upload", "mor_device_download", "mor_device_synchronize", "mor_device_count", "mor_get_last_timing",
+    "mor_kernel_timing_enable", "mor_kernel_timing_read", "mor_tracker_create", "mor_tracker_destroy", "mor_tracker_push",
+    "mor_tracker_filter", "mor_tracker_get",
+]
+
+
+class CloudView(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("n_points", C.c_uint64), ("point_step", C.c_uint32), ("off_x", C.c_uint32),
+                ("off_y", C.c_uint32), ("off_z", C.c_uint32), ("off_intensity", C.c_uint32), ("on_device", C.c_int32)]
+
+
+class Counts(C.Structure):
+    _fields_ = [("n_in", C.c_uint64), ("n_trim", C.c_uint64), ("n_cloud", C.c_uint64), ("n_ground", C.c_uint64),
+                ("n_clusters", C.c_uint32), ("n_clustered", C.c_uint32), ("n_corr", C.c_uint32), ("n_tracks", C.c_uint32)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libmor_hip.so is not built (python -m dynamicslamtool_amd.build); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
+        L.mor_sizeof_params.restype = C.c_size_t
+        L.mor_last_error.restype = C.c_char_p
+        L.mor_batch_create.restype = vp
+        L.mor_batch_create.argtypes = [vp, i32, i32, i32, u64, i32, vp]
+        L.mor_batch_destroy.argtypes = [vp]
+        L.mor_batch_streams.argtypes = [vp]
+        L.mor_push_batch.argtypes = [vp, vp, vp]
+        L.mor_filter_batch.argtypes = [vp, vp, i32, vp]
+        L.mor_get_output_device.restype = vp
+        L.mor_get_output_device.argtypes = [vp, i32, vp]
+        L.mor_create.restype = vp
+        L.mor_create.argtypes = [vp, i32, i32, u64, i32, vp]
+        L.mor_push.argtypes = [vp, vp, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+        L.mor_filter.argtypes = [vp, vp, vp]
+        L.mor_destroy.argtypes = [vp]
+        for n in ("mor_get_counts", "mor_get_labels", "mor_get_ground_indices", "mor_get_centroids", "mor_get_detection", "mor_get_cluster_collection"):
+            getattr(L, n).argtypes = [vp, i32, vp]
+        L.mor_get_clusters.argtypes = [vp, i32, vp, vp]
+        L.mor_get_correspondences.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.mor_get_tracks.argtypes = [vp, i32, vp, vp, vp]
+        L.mor_device_alloc.restype = vp
+        L.mor_device_alloc.argtypes = [i32, C.c_size_t]
+        L.mor_device_free.argtypes = [i32, vp]
+        L.mor_device_upload.argtypes = [i32, vp, vp, C.c_size_t]
+        L.mor_device_download.argtypes = [i32, vp, vp, C.c_size_t]
+        L.mor_device_synchronize.argtypes = [i32]
+        L.mor_get_last_timing.argtypes = [vp, vp, vp]
+        L.mor_kernel_timing_enable.argtypes = [vp, i32]
+        L.mor_kernel_timing_read.argtypes = [vp, i32, vp, C.c_size_t, vp, vp, i32]
+        L.mor_tracker_create.restype = vp
+        L.mor_tracker_create.argtypes = [vp, i32, i32]
+        L.mor_tracker_destroy.argtypes = [vp]
+        L.mor_tracker_push.argtypes = [vp, i32, vp, vp, i32, vp, vp]
+        L.mor_tracker_filter.argtypes = [vp, vp, vp, vp]
+        L.mor_tracker_get.argtypes = [vp, vp, vp, vp, i32]
+        _LIB = L
+    return _LIB
+
+
+class MorError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise MorError("rc=%d: %s" % (rc, lib().mor_last_error().decode()))
+
+
+def device_count():
+    return int(lib().mor_device_count())
+
+
+class DeviceBuffer:
+    """A plain hipMalloc'd buffer (clouds kept resident in HBM for the bench / replay driver)."""
+
+    def __init__(self, nbytes, device=0):
+        self.device, self.nbytes = device, int(nbytes)
+        self.ptr = lib().mor_device_alloc(device, self.nbytes)
+        if not self.ptr:
+            raise MorError(lib().mor_last_error().decode())
+
+    def upload(self, arr, offset=0):
+        a = np.ascontiguousarray(arr)
+        assert offset + a.nbytes <= self.nbytes
+        _check(lib().mor_device_upload(self.device, self.ptr + offset, a.ctypes.data, a.nbytes))
+
+    def download(self, nbytes=None, offset=0, dtype=np.uint8):
+        nbytes = self.nbytes - offset if nbytes is None else int(nbytes)
+        out = np.empty(nbytes, np.uint8)
+        _check(lib().mor_device_download(self.device, out.ctypes.data, self.ptr + offset, nbytes))
+        return out.view(dtype)
+
+    def free(self):
+        if self.ptr:
+            lib().mor_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class MorBatch:
+    """B independent MovingObjectRemoval streams on one MI355X (mor_batch)."""
+
+    def __init__(self, params, n_streams=1, max_points=131072, n_bad=4, n_good=3, device=0):
+        L = lib()
+        assert L.mor_sizeof_params() == C.sizeof(MorParams)
+        self.params, self.B, self.max_points, self.device = params, int(n_streams), int(max_points), device
+        err = C.c_int(0)
+        self._h = L.mor_batch_create(C.addressof(params), n_bad, n_good, self.B, self.max_points, device, C.addressof(err))
+        if not self._h:
+            raise MorError("mor_batch_create failed (rc=%d): %s" % (err.value, L.mor_last_error().decode()))
+        self._views = (CloudView * self.B)()
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mor_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- pushRawCloudAndPose for all streams
+    def push(self, clouds, poses, point_step=16, offsets=(0, 4, 8, 12)):
+        """clouds: list of B float32 [N,4] arrays (host) — or of (DeviceBuffer|int ptr, n_points) tuples
+        for device-resident blobs.  poses: [B,7] float64."""
+        assert len(clouds) == self.B
+        keep = []
+        for s, c in enumerate(clouds):
+            v = self._views[s]
+            v.point_step, v.off_x, v.off_y, v.off_z, v.off_intensity = point_step, offsets[0], offsets[1], offsets[2], offsets[3]
+            if isinstance(c, tuple):
+                buf, n = c
+                v.data, v.n_points, v.on_device = (buf.ptr if isinstance(buf, DeviceBuffer) else int(buf)), int(n), 1
+            else:
+                a = np.ascontiguousarray(c)
+                keep.append(a)
+                v.data, v.n_points, v.on_device = a.ctypes.data, a.nbytes // point_step, 0
+        poses = np.ascontiguousarray(poses, np.float64).reshape(self.B, 7)
+        self._keep = keep
+        _check(lib().mor_push_batch(self._h, C.addressof(self._views), poses.ctypes.data))
+
+    # ---- filterCloud for all streams
+    def filter(self, to_host=True):
+        n_out = (C.c_uint64 * self.B)()
+        if not to_host:
+            _check(lib().mor_filter_batch(self._h, None, 0, C.addressof(n_out)))
+            return [int(x) for x in n_out]
+        outs = [np.empty((max(int(self._views[s].n_points), 1), 4), np.float32) for s in range(self.B)]
+        ptrs = (C.c_void_p * self.B)(*[o.ctypes.data for o in outs])
+        _check(lib().mor_filter_batch(self._h, C.addressof(ptrs), 0, C.addressof(n_out)))
+        return [outs[s][: int(n_out[s])] for s in range(self.B)]
+
+    # ---- read-backs
+    def counts(self, s=0):
+        c = Counts()
+        _check(lib().mor_get_counts(self._h, s, C.addressof(c)))
+        return c
+
+    def _get(self, fn, s, n, dtype, width=1):
+        a = np.empty((max(int(n), 1), width) if width > 1 else max(int(n), 1), dtype)
+        _check(fn(self._h, s, a.ctypes.data))
+        return a[: int(n)]
+
+    def labels(self, s=0):
+        return self._get(lib().mor_get_labels, s, self.counts(s).n_trim, np.int32)
+
+    def ground_indices(self, s=0):
+        return self._get(lib().mor_get_ground_indices, s, self.counts(s).n_ground, np.int32)
+
+    def clusters(self, s=0):
+        c = self.counts(s)
+        off = np.zeros(c.n_clusters + 1, np.int32)
+        idx = np.empty(max(int(c.n_clustered), 1), np.int32)
+        _check(lib().mor_get_clusters(self._h, s, off.ctypes.data, idx.ctypes.data))
+        return off, idx[: c.n_clustered]
+
+    def centroids(self, s=0):
+        return self._get(lib().mor_get_centroids, s, self.counts(s).n_clusters, np.float32, 3)
+
+    def detection(self, s=0):
+        return self._get(lib().mor_get_detection, s, self.counts(s).n_clusters, np.uint8)
+
+    def cluster_collection(self, s=0):
+        return self._get(lib().mor_get_cluster_collection, s, self.counts(s).n_clustered, np.float32, 4)
+
+    def correspondences(self, s=0):
+        k = int(self.counts(s).n_corr)
+        n = max(k, 1)
+        q, m, d, sc = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.float32), np.empty(n, np.float64)
+        _check(lib().mor_get_correspondences(self._h, s, q.ctypes.data, m.ctypes.data, d.ctypes.data, sc.ctypes.data))
+        return q[:k], m[:k], d[:k], sc[:k]
+
+    def tracks(self, s=0):
+        k = int(self.counts(s).n_tracks)
+        n = max(k, 1)
+        xyz, conf, mx = np.empty((n, 3), np.float32), np.empty(n, np.int32), np.empty(n, np.int32)
+        _check(lib().mor_get_tracks(self._h, s, xyz.ctypes.data, conf.ctypes.data, mx.ctypes.data))
+        return xyz[:k], conf[:k], mx[:k]
+
+    def output_device(self, s=0):
+        n = C.c_uint64(0)
+        p = lib().mor_get_output_device(self._h, s, C.addressof(n))
+        return p, int(n.value)
+
+    # ---- timing
+    def last_timing(self):
+        a, b = C.c_float(0), C.c_float(0)
+        lib().mor_get_last_timing(self._h, C.addressof(a), C.addressof(b))
+        return a.value, b.value
+
+    def kernel_timing_enable(self, on=True):
+        lib().mor_kernel_timing_enable(self._h, 1 if on else 0)
+
+    def kernel_timing(self, reset=True):
+        names = C.create_string_buffer(2048)
+        ms = (C.c_float * 64)()
+        ln = (C.c_uint32 * 64)()
+        n = lib().mor_kernel_timing_read(self._h, 1 if reset else 0, names, 2048, ms, ln, 64)
+        nm = names.value.decode().split(",")
+        return {nm[i]: (float(ms[i]), int(ln[i])) for i in range(n)}
+
+    def synchronize(self):
+        _check(lib().mor_device_synchronize(self.device))
+
+
+class HostTracker:
+    """mor_tracker alone — the T1/F1 state machine, usable without a GPU."""
+
+    def __init__(self, params, n_bad=4, n_good=3):
+        self._h = lib().mor_tracker_create(C.addressof(params), n_bad, n_good)
+        self._K = 0
+
+    def push(self, centroids, det, pairs=None):
+        c = np.ascontiguousarray(centroids, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(det, np.uint8)
+        self._K = len(d)
+        if pairs is None:
+            rc = lib().mor_tracker_push(self._h, len(d), c.ctypes.data, d.ctypes.data, -1, None, None)
+        else:
+            q = np.ascontiguousarray([p[0] for p in pairs], np.int32)
+            m = np.ascontiguousarray([p[1] for p in pairs], np.int32)
+            rc = lib().mor_tracker_push(self._h, len(d), c.ctypes.data, d.ctypes.data, len(q), q.ctypes.data, m.ctypes.data)
+        _check(rc)
+
+    def filter(self, sizes):
+        sz = np.ascontiguousarray(sizes, np.int32)
+        mv = np.zeros(max(self._K, 1), np.uint8)
+        n = C.c_uint64(0)
+        _check(lib().mor_tracker_filter(self._h, sz.ctypes.data, mv.ctypes.data, C.addressof(n)))
+        return mv[: self._K], int(n.value)
+
+    def tracks(self):
+        xyz, conf, mx = np.empty((4096, 3), np.float32), np.empty(4096, np.int32), np.empty(4096, np.int32)
+        k = lib().mor_tracker_get(self._h, xyz.ctypes.data, conf.ctypes.data, mx.ctypes.data, 4096)
+        return xyz[:k], conf[:k], mx[:k]
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().mor_tracker_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

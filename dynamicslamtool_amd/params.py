@@ -1,6 +1,6 @@
 """Parameter block + config-file grammar of the reference.
 
-`MorParams` mirrors include/mor_hip.h:mor_params (and oracle/mor_oracle.h:oracle_params — same
+`MorParams` mirrors include/mor_hip.h:mor_params (the test checker uses the same
 layout).  `parse_config` follows MovingObjectRemoval::setVariables
 (/root/reference/src/MovingObjectRemoval.cpp:698-864): `key:value` lines, `#` comments, lines
 shorter than 3 characters skipped, EVERY ':' stripped, no whitespace trimming, unknown key is an

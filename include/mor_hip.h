@@ -1,0 +1,154 @@
+/*
+ * mor_hip.h — C ABI of libmor_hip.so: the MI355X-native (HIP, gfx950) implementation of the
+ * reference hot path
+ *     MovingObjectRemoval::pushRawCloudAndPose()   /root/reference/src/MovingObjectRemoval.cpp:516-611
+ *     MovingObjectRemoval::filterCloud()           /root/reference/src/MovingObjectRemoval.cpp:613-696
+ * behind the reference's class (include/MOR/MovingObjectRemoval.h:96-168).  The reference has no
+ * FFI layer — the class *is* the boundary — so these are the entry points the header-level adapter
+ * (include/MOR/MovingObjectRemoval.h in this repo) binds; SURVEY.md §8(b) lists them.
+ *
+ * Plain pointers and sizes only.  Every function returns MOR_OK (0) or a negative error code;
+ * nothing here calls exit() (the reference exit(0)s on config errors, :703-707, :856-860 — that
+ * behaviour lives in the adapter).  There is NO CPU fallback: without a usable HIP device
+ * mor_batch_create() fails with MOR_ERR_HIP.
+ *
+ * Threading: like the reference (single-threaded ros::spin, external_sync_test.cpp:39) a batch is
+ * not thread-safe; calls on one batch must be strictly ordered push → filter → push → …
+ */
+#ifndef MOR_HIP_H
+#define MOR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOR_OK 0
+#define MOR_ERR_INVALID (-1)   /* bad argument / parameter */
+#define MOR_ERR_NOT_READY (-2) /* filter before the first push (the reference would crash, :618/:681) */
+#define MOR_ERR_HIP (-3)       /* HIP runtime error or no device; see mor_last_error() */
+#define MOR_ERR_CAPACITY (-4)  /* more points than max_points, or more clusters than the cluster capacity */
+#define MOR_NO_FIELD 0xFFFFFFFFu
+
+/* The 17 numeric members of MovingObjectRemoval (include/MOR/MovingObjectRemoval.h:103-105; keys of
+ * config/MOR_config.txt, parsed at MovingObjectRemoval.cpp:736-855) plus two values the reference
+ * fixes in source. */
+typedef struct mor_params {
+  float gp_limit, gp_leaf, bin_gap;
+  int64_t min_cluster_size, max_cluster_size; /* reference: long */
+  float volume_constraint, pde_lb, pde_ub;
+  float leave_off_distance, catch_up_distance;
+  float trim_x, trim_y, trim_z;
+  float ec_distance_threshold, pde_distance_threshold;
+  int32_t method_choice;            /* 1 = point-distance estimate (:336-366), 2 = octree change (:309-334) */
+  int32_t opc_normalization_factor; /* :843 */
+  int32_t ground_method;            /* 0 = crop box (:526, the active call), 1 = voxel covariance (:527, intended semantics) */
+  float opc_resolution;             /* 0.1f — literal at the call site :575 */
+} mor_params;
+
+/* One incoming cloud: a pcl::PCLPointCloud2-style blob (what fromPCLPointCloud2 consumes at :523).
+ * n_points records of point_step bytes; float32 fields at the given byte offsets;
+ * off_intensity = MOR_NO_FIELD when the blob has no "intensity" field (intensity stays 0). */
+typedef struct mor_cloud_view {
+  const void *data;
+  uint64_t n_points;
+  uint32_t point_step, off_x, off_y, off_z, off_intensity;
+  int32_t on_device; /* 0: host memory, staged by the library; 1: device memory on the batch's GPU */
+} mor_cloud_view;
+
+/* Sizes of the latest frame `cb` of one stream. */
+typedef struct mor_counts {
+  uint64_t n_in, n_trim, n_cloud, n_ground; /* N, T (after x/y trim), M (`cloud`), G (`gp_indices`) */
+  uint32_t n_clusters, n_clustered;          /* K, C */
+  uint32_t n_corr, n_tracks;                 /* |mp| of the last push (:564), |mo_vec| */
+} mor_counts;
+
+typedef struct mor_batch mor_batch; /* B independent sensor streams sharing one GPU and one set of launches */
+
+size_t mor_sizeof_params(void);
+const char *mor_last_error(void);
+
+/* MovingObjectRemoval::MovingObjectRemoval (:368-391) for n_streams independent instances:
+ * n_bad → moving_confidence, n_good → static_confidence.  max_points bounds the points per cloud
+ * (buffers are sized once for it; 288 GB of HBM3E makes that cheap).  device = HIP ordinal. */
+mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_streams, uint64_t max_points,
+                            int device, int *err);
+void mor_batch_destroy(mor_batch *b);
+int mor_batch_streams(const mor_batch *b);
+
+/* pushRawCloudAndPose (:516-611) for every stream of the batch at once: clouds[n_streams],
+ * poses = n_streams × (position xyz, quaternion xyzw) in fp64.  All device work is enqueued as one
+ * sequence of batched launches; returns after the per-stream cluster summaries reached the host
+ * and the host-side tracker (checkMovingClusterChain, :478-514) ran. */
+int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *poses_xyz_qxyzw);
+
+/* filterCloud (:613-696) for every stream.  out[i] receives stream i's filtered cloud as packed
+ * (x,y,z,intensity) float32 records — [cloud minus moving clusters, original order] ++ [ground
+ * points in index order] — and n_out[i] its point count.  out[i] must hold n_in points.
+ * out_on_device: 0 = host pointers, 1 = device pointers.  out may be NULL: results then stay in the
+ * batch's own device buffers (mor_get_output_device). */
+int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t *n_out);
+
+/* Device-resident result of the last filter for stream i (float4 records) */
+const void *mor_get_output_device(const mor_batch *b, int stream, uint64_t *n_out);
+
+/* Single-stream forms used by the class adapter (a batch with one stream). */
+typedef mor_batch mor_ctx;
+mor_ctx *mor_create(const mor_params *p, int n_bad, int n_good, uint64_t max_points, int device, int *err);
+int mor_push(mor_ctx *c, const void *data, uint64_t n_points, uint32_t point_step, uint32_t off_x, uint32_t off_y,
+             uint32_t off_z, uint32_t off_intensity, const double pose_xyz_qxyzw[7]);
+int mor_filter(mor_ctx *c, float *out_xyzi, uint64_t *n_out);
+void mor_destroy(mor_ctx *c);
+
+/* ---- read-backs of stream i's latest frame (parity tests, debugging, VISUALIZE side channel) ---- */
+int mor_get_counts(const mor_batch *b, int stream, mor_counts *out);
+/* per trimmed point: cluster id ≥ 0 (cluster_indices order, :221), -1 non-ground unclustered, -2 ground */
+int mor_get_labels(const mor_batch *b, int stream, int32_t *labels_T);
+/* gp_indices (:86): indices into the trimmed cloud, ascending */
+int mor_get_ground_indices(const mor_batch *b, int stream, int32_t *idx_G);
+/* cluster_indices (:218): offsets[K+1] and indices[C] into `cloud`, ascending inside a cluster;
+ * clusters ordered by size descending, ties by first index */
+int mor_get_clusters(const mor_batch *b, int stream, int32_t *offsets, int32_t *indices);
+int mor_get_centroids(const mor_batch *b, int stream, float *xyz_K3);  /* centroid_collection (:243) */
+int mor_get_detection(const mor_batch *b, int stream, uint8_t *det_K); /* detection_results (:593-604) */
+/* correspondence map mp (:564) + movement scores param_vec (:571/:575) of the last push */
+int mor_get_correspondences(const mor_batch *b, int stream, int32_t *query, int32_t *match, float *dist, double *score);
+/* mo_vec (header :109): centroid xyz, confidence, max_confidence */
+int mor_get_tracks(const mor_batch *b, int stream, float *xyz_n3, int32_t *conf, int32_t *max_conf);
+/* cluster_collection (:227, :258-260): the clustered points of `cb` concatenated in cluster order
+ * (what push writes back into the caller's cloud under VISUALIZE, :553-558); out holds C records */
+int mor_get_cluster_collection(const mor_batch *b, int stream, float *out_xyzi);
+
+/* ---- device-memory helpers so callers can keep clouds resident in HBM (bench, replay driver) ---- */
+void *mor_device_alloc(int device, size_t bytes);
+void mor_device_free(int device, void *p);
+int mor_device_upload(int device, void *dst, const void *src, size_t bytes);
+int mor_device_download(int device, void *dst, const void *src, size_t bytes);
+int mor_device_synchronize(int device);
+int mor_device_count(void);
+
+/* ---- timing hooks (HIP events on the batch's own stream) ---- */
+/* milliseconds spent in device work of the last push / filter (event-timed), and the accumulated
+ * time + launch count of the dominant kernel (cluster hook) since the last reset. */
+int mor_get_last_timing(const mor_batch *b, float *push_ms, float *filter_ms);
+int mor_kernel_timing_enable(mor_batch *b, int enable);
+int mor_kernel_timing_read(mor_batch *b, int reset, char *names, size_t names_cap, float *ms_total, uint32_t *launches, int max_kernels);
+
+/* ---- host-side tracker alone (T1/F1 state machine; lets CPU-only tests drive it) ---- */
+typedef struct mor_tracker mor_tracker;
+mor_tracker *mor_tracker_create(const mor_params *p, int n_bad, int n_good);
+void mor_tracker_destroy(mor_tracker *t);
+/* feed one frame's cluster summary: K centroids, detection flags, and the correspondence pairs to
+ * the previous frame (n_pairs < 0: first frame, no pair stage) — runs checkMovingClusterChain */
+int mor_tracker_push(mor_tracker *t, int K, const float *centroids_K3, const uint8_t *det_K, int n_pairs,
+                     const int32_t *query, const int32_t *match);
+/* filterCloud's tracking loop (:630-671): fills moving_K (1 = cluster removed) and *n_moving_idx =
+ * total indices pushed incl. duplicates (cluster sizes needed for the ExtractIndices size check) */
+int mor_tracker_filter(mor_tracker *t, const int32_t *cluster_sizes_K, uint8_t *moving_K, uint64_t *n_moving_idx);
+int mor_tracker_get(const mor_tracker *t, float *xyz_n3, int32_t *conf, int32_t *max_conf, int max_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

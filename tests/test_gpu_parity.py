@@ -1,0 +1,176 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+from dynamicslamtool_amd import kitti_params, synth
+from dynamicslamtool_amd.engine import DeviceBuffer, MorBatch, MorError
+from oracle.oracle import Oracle
+from parity import compare_frame, compare_output, compare_tracks
+from scenes import scene_params, small_stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_lockstep(p, streams, n_bad=4, n_good=3, max_points=None, check_tracks=True):
+    """streams: list (per stream) of lists of (pts, pose).  Returns stats."""
+    B = len(streams)
+    nf = len(streams[0])
+    max_points = max_points or max(len(f[0]) for st in streams for f in st)
+    b = MorBatch(p, B, max_points, n_bad, n_good)
+    os_ = [Oracle(p, n_bad, n_good) for _ in range(B)]
+    stats = dict(tracks=0, removed=0, centroid_bit_diffs=0, clusters=0, corr=0, moving=0)
+    for f in range(nf):
+        b.push([streams[s][f][0] for s in range(B)], np.stack([streams[s][f][1] for s in range(B)]))
+        for s in range(B):
+            os_[s].push(*streams[s][f])
+            stats["centroid_bit_diffs"] += compare_frame(os_[s], b, s, "stream %d frame %d" % (s, f))
+            c = os_[s].counts()
+            stats["clusters"] += c.n_clusters
+            stats["corr"] += c.n_corr
+            stats["moving"] += int(os_[s].detection().sum())
+        outs = b.filter()
+        for s in range(B):
+            c = os_[s].counts()
+            out_o = os_[s].filter()
+            compare_output(out_o, outs[s], "stream %d frame %d" % (s, f))
+            compare_tracks(os_[s], b, s, "stream %d frame %d after filter" % (s, f))
+            stats["tracks"] = max(stats["tracks"], os_[s].counts().n_tracks)
+            stats["removed"] = max(stats["removed"], int(c.n_trim) - len(out_o))
+    b.close()
+    return stats
+
+
+@pytest.mark.parametrize("method", [1, 2])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_small_streams_match_oracle(seed, method):
+    st = _run_lockstep(scene_params(method_choice=method), [small_stream(seed, n_frames=9)])
+    assert st["clusters"] > 0 and st["corr"] > 0
+
+
+def test_small_stream_exercises_removal():
+    st = _run_lockstep(scene_params(method_choice=2), [small_stream(1, n_frames=9)])
+    assert st["tracks"] >= 1 and st["removed"] > 0 and st["moving"] > 0
+
+
+@pytest.mark.parametrize("B", [3, 8])
+def test_batches_of_independent_streams(B):
+    """Streams in one batch share launches but nothing else; B=3 takes the generic workgroup map,
+    B=8 the XCD-grouped one."""
+    streams = [small_stream(10 + s, n_frames=6, n_objects=4 + s % 3) for s in range(B)]
+    _run_lockstep(scene_params(method_choice=1 + (B % 2)), streams)
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_hdl64_full_size_matches_oracle(method):
+    """120 000-point synthetic HDL-64 frames, KITTI profile, 6 consecutive frames."""
+    p = kitti_params(method)
+    frames = [synth.frame(1000, "hdl64", f) for f in range(6)]
+    st = _run_lockstep(p, [frames])
+    assert st["clusters"] >= 60 and st["corr"] >= 50 and st["moving"] > 0
+
+
+def test_hdl64_batch_of_8_matches_oracle():
+    p = kitti_params(1)
+    streams = [[synth.frame(2000 + s, "hdl64", f) for f in range(3)] for s in range(8)]
+    _run_lockstep(p, streams)
+
+
+def test_blob_layouts_and_device_resident_input():
+    """32-byte Velodyne-style records, 12-byte xyz-only records and a device-resident packed blob."""
+    p = scene_params()
+    pts, pose = small_stream(5, n_frames=1)[0]
+    o = Oracle(p)
+    o.push(pts, pose)
+    ref = o.filter()
+    blob = np.zeros((len(pts), 8), np.float32)
+    blob[:, 0:3] = pts[:, 0:3]
+    blob[:, 4] = pts[:, 3]
+    b = MorBatch(p, 1, len(pts))
+    b.push([blob], pose[None, :], point_step=32, offsets=(0, 4, 8, 16))
+    compare_output(ref, b.filter()[0], "32-byte records")
+    b.close()
+    b = MorBatch(p, 1, len(pts))
+    b.push([np.ascontiguousarray(pts[:, :3])], pose[None, :], point_step=12, offsets=(0, 4, 8, 0xFFFFFFFF))
+    out = b.filter()[0]
+    assert np.array_equal(out[:, :3].view(np.uint32), ref[:, :3].view(np.uint32)) and np.all(out[:, 3] == 0)
+    b.close()
+    b = MorBatch(p, 1, len(pts))
+    buf = DeviceBuffer(pts.nbytes)
+    buf.upload(pts)
+    b.push([(buf, len(pts))], pose[None, :])
+    compare_output(ref, b.filter()[0], "device-resident blob")
+    n = b.filter(to_host=False)[0]   # repeated filter on the same frame: same cloud, tracker not advanced twice
+    ptr, n2 = b.output_device(0)
+    assert n == n2 == len(ref)
+    b.close()
+
+
+def test_edge_cases():
+    p = scene_params()
+    pose = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    cases = {
+        "single point": np.array([[0.1, 0.2, 0.3, 0.5]], np.float32),
+        "all outside trim": np.full((100, 4), 10.0, np.float32),
+        "all ground": np.column_stack([np.random.default_rng(0).uniform(-2, 2, (500, 2)), np.full(500, -0.7), np.zeros(500)]).astype(np.float32),
+        "all nan": np.full((64, 4), np.nan, np.float32),
+        "identical points": np.tile(np.array([[0.5, 0.5, 0.5, 1.0]], np.float32), (300, 1)),
+        "ragged 2049": np.random.default_rng(1).uniform(-1, 1, (2049, 4)).astype(np.float32),
+    }
+    for name, pts in cases.items():
+        b, o = MorBatch(p, 1, 4096), Oracle(p)
+        for rep in range(2):   # two frames so the pair stage runs on the degenerate input too
+            b.push([pts], pose[None, :])
+            o.push(pts, pose)
+            compare_frame(o, b, 0, name)
+            compare_output(o.filter(), b.filter()[0], name)
+        b.close()
+    # empty cloud
+    b, o = MorBatch(p, 1, 4096), Oracle(p)
+    e = np.zeros((0, 4), np.float32)
+    b.push([e], pose[None, :])
+    o.push(e, pose)
+    compare_frame(o, b, 0, "empty")
+    assert len(b.filter()[0]) == 0
+    b.close()
+
+
+def test_errors_are_loud():
+    p = scene_params()
+    b = MorBatch(p, 1, 100)
+    with pytest.raises(MorError):
+        b.filter()                                         # filter before push
+    with pytest.raises(MorError):
+        b.push([np.zeros((101, 4), np.float32)], np.array([[0, 0, 0, 0, 0, 0, 1.0]]))   # over capacity
+    b.close()
+
+
+def test_known_answers():
+    """Hand-checkable scenes."""
+    p = scene_params(min_cluster_size=5)
+    pose = np.array([[0, 0, 0, 0, 0, 0, 1.0]])
+    r = np.float32(p.ec_distance_threshold)
+
+    def line(x0, n):   # n points spaced 0.05 along y at x = x0
+        return np.column_stack([np.full(n, x0), np.arange(n) * 0.05, np.zeros(n), np.zeros(n)]).astype(np.float32)
+    # two lines 0.12 apart at r = 0.11 → 2 clusters; 0.10 apart → 1
+    for gap, want in ((0.12, 2), (0.10, 1)):
+        b = MorBatch(p, 1, 1024)
+        b.push([np.concatenate([line(0.0, 10), line(gap, 10)])], pose)
+        assert b.counts().n_clusters == want, gap
+        b.close()
+    # strict '<': two points whose fp32 d² equals r² exactly are NOT connected
+    d = np.float32(np.sqrt(np.float64(np.float32(np.float64(r) * np.float64(r)))))
+    pts = np.concatenate([line(0.0, 6), line(0.0, 6)])
+    pts[6:, 1] += np.float32(1.0)
+    b = MorBatch(p, 1, 1024)
+    b.push([pts], pose)
+    assert b.counts().n_clusters == 2
+    b.close()
+    # min_cluster_size boundary: 4 points vs 5 points with min = 5
+    b = MorBatch(p, 1, 1024)
+    b.push([np.concatenate([line(0.0, 4), line(1.0, 5)])], pose)
+    assert b.counts().n_clusters == 1 and b.counts().n_clustered == 5
+    # first-frame output = [non-ground ‖ ground] permutation of the trimmed input
+    out = b.filter()[0]
+    assert len(out) == 9
+    b.close()
