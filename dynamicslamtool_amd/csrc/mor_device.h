@@ -9,12 +9,16 @@
 #define MOR_BT 256      // threads per workgroup
 #define MOR_KGRID 128   // workgroups per stream for per-cluster kernels (grid-stride over clusters)
 
-// Uniform grid over the trim box ("perfect spatial hash": key = linear cell id). Cell edge ≥ r so a
-// 3×3×3 stencil covers every neighbour within r; the cell map is monotone and clamped, so points
-// outside the nominal box land in border cells and are still found.
+// Uniform grid over the trim box, keyed by linear cell id (a collision-free spatial hash).
+// Cell edge s = 0.57·r, so the cell diagonal is < r and ALL points of one cell are mutually within
+// the cluster tolerance: a cell is a clique, and Euclidean clustering reduces to connected
+// components over occupied CELLS (two cells are adjacent iff some point pair across them has
+// d² < r²; only cells ≤ 2 apart per axis can be).  Occupancy is a bitmap (x fastest, rows padded to
+// 32-bit words); the compact id of an occupied cell = number of set bits before it (word prefix +
+// popcount), which is also its position in the cell-sorted point array.
 struct MorGrid {
-  float ox, oy, oz, inv_cs;
-  int nx, ny, nz, ncells;
+  float ox, oy, oz, inv_cs, cs;
+  int nx, ny, nz, wx, nwords;   // wx = words per x-row
 };
 
 struct MorStreamArgs {       // per stream, per push (host → device, one small copy)
@@ -25,17 +29,18 @@ struct MorStreamArgs {       // per stream, per push (host → device, one small
 
 struct MorFrameInfo {        // per stream, produced on device
   uint32_t N, T, M, G, K, C, n_pairs, flags;   // flags bit0: cluster capacity exceeded, bit1: voxel key overflow
-  uint32_t Kprev, Cprev, n_keep, pad;
+  uint32_t Kprev, Cprev, n_keep, n_occ;   // n_occ: occupied grid cells
 };
 
 struct MorDev {
   // ---- static configuration
-  int B, Nmax, Kcap, tiles_max, ctiles, radix_passes, Hcap;
+  int B, Nmax, Kcap, tiles_max, radix_passes, Hcap;
   float trim_x, trim_y, trim_z, gp_limit, r2;
   long long min_cs, max_cs;
   float pde_lb, pde_ub;
   double pde_thr, vol_thr, opc_res;
-  int method, opc_norm, score_R;
+  int method, opc_norm, score_R, n_rows;
+  const signed char *row_order; // [n_rows][2] (dy,dz) of the method-1 search stencil, nearest rows first
   MorGrid g;
   // ---- per call
   int tiles;                 // ceil(max n_points of this batch / MOR_TILE)
@@ -48,18 +53,21 @@ struct MorDev {
   int *cloud_tidx;           // [B][Nmax]  index of each cloud point in the trimmed cloud
   float4 *ground;            // [B][Nmax]  removed points in order (raw_cloud[gp_indices], :683)
   int *gp_idx;               // [B][Nmax]  gp_indices (:86)
-  int *cell_of;              // [B][Nmax]
-  int *cell_cnt;             // [B][ncells]   histogram, then fill cursor
-  int *cell_start;           // [B][ncells+1]
-  int *ctile_sum;            // [B][ctiles]
+  int *cell_of;              // [B][Nmax]  linear cell position (word·32 + bit) per cloud point, then compact cell id
+  unsigned *bitmap;          // [B][nwords]  occupancy
+  int *wprefix;              // [B][nwords]  exclusive prefix of popcounts
+  int *ccount, *cstart, *cfill; // [B][Nmax+1]  points per occupied cell, exclusive offsets, fill cursor
+  int *ccoord;               // [B][Nmax]  packed (cx | cy<<12 | cz<<24 … see pack_cell) per occupied cell
+  int *cmin;                 // [B][Nmax]  smallest cloud index in the cell
   float4 *sorted;            // [B][Nmax]  (x,y,z, bits(cloud index)) in cell order; .w becomes the cluster id after labelling
-  int *parent;               // [B][Nmax]  union-find forest over cloud indices (parent ≤ child)
-  int *csize;                // [B][Nmax]  component size at its root
-  int *cid_of_root;          // [B][Nmax]
-  int *label;                // [B][Nmax]  component root per cloud point
+  int *parent;               // [B][Nmax]  union-find forest over occupied cells (parent ≤ child)
+  int *croot;                // [B][Nmax]  flattened root per cell
+  int *csize;                // [B][Nmax]  component size (points) at its root cell
+  int *compmin;              // [B][Nmax]  smallest cloud index of the component, at its root cell
+  int *cid_of_root;          // [B][Nmax]  cluster id of a root cell (−1: not kept)
   int *pcid;                 // [B][Nmax]  cluster id (−1 none) per cloud point
   int *ktile_cnt;            // [B][tiles_max]
-  int *kroot, *ksize;        // [B][Kcap]  kept roots ascending, their sizes
+  int *kcell, *kroot, *ksize; // [B][Kcap]  kept components: root cell, smallest cloud index, size
   int *csz;                  // [B][Kcap]  sizes in final cluster order
   int *rkeys[2], *rvals[2];  // [B][Nmax]  radix ping-pong (cluster id, cloud index)
   int *rhist;                // [B][tiles_max][256]
@@ -97,7 +105,7 @@ struct MorDev {
 
 // kernel ids for optional per-kernel event timing
 enum MorKernelId {
-  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_CELL_REDUCE, MK_CELL_SCAN, MK_CELL_FINAL, MK_FILL, MK_HOOK, MK_FLATTEN,
+  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_WPREFIX, MK_CELLCOUNT, MK_CSTART, MK_FILL, MK_HOOK_NEAR, MK_HOOK_SHELL, MK_FLATTEN,
   MK_SELECT_COUNT, MK_SELECT_SCAN, MK_SELECT_SCATTER, MK_RANK, MK_OFFSETS, MK_LABEL, MK_RHIST, MK_RSCAN, MK_RSCATTER,
   MK_STATS, MK_XFORM_PREV, MK_NN, MK_PAIRS, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
   MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_COUNT

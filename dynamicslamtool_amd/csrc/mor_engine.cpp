@@ -108,17 +108,18 @@ static int configure(mor_batch *b) {
   d.min_cs = p.min_cluster_size; d.max_cs = p.max_cluster_size;
   d.pde_lb = p.pde_lb; d.pde_ub = p.pde_ub; d.pde_thr = (double)p.pde_distance_threshold; d.vol_thr = (double)p.volume_constraint;
   d.opc_res = (double)p.opc_resolution; d.method = p.method_choice; d.opc_norm = p.opc_normalization_factor;
-  // grid: cell edge ≥ r·1.001 (slack for the fp32 cell map), ≤ 2048 cells per axis, ≤ 4 Mi cells
-  float cs = p.ec_distance_threshold * 1.001f;
+  // grid: cell edge 0.57·r (cell diagonal 0.987·r < r ⇒ a cell is a clique; the 1.3 % margin dwarfs the
+  // fp32 rounding of the cell map, ≤ 1e-3 cell at ≤ 2048 cells per axis)
+  float cs = p.ec_distance_threshold * 0.57f;
   float zlo = p.gp_limit, zhi = std::max(p.trim_z, p.gp_limit);
-  for (;;) {
-    double nx = std::floor(2.0 * p.trim_x / cs) + 1, ny = std::floor(2.0 * p.trim_y / cs) + 1, nz = std::floor((double)(zhi - zlo) / cs) + 1;
-    if (nx <= 2048 && ny <= 2048 && nz <= 2048 && nx * ny * nz <= 4.0 * 1024 * 1024) { d.g.nx = (int)nx; d.g.ny = (int)ny; d.g.nz = (int)nz; break; }
-    cs *= 1.25f;
-  }
-  d.g.ox = -p.trim_x; d.g.oy = -p.trim_y; d.g.oz = zlo; d.g.inv_cs = 1.0f / cs; d.g.ncells = d.g.nx * d.g.ny * d.g.nz;
-  d.ctiles = (d.g.ncells + MOR_TILE - 1) / MOR_TILE;
+  double nx = std::floor(2.0 * p.trim_x / cs) + 1, ny = std::floor(2.0 * p.trim_y / cs) + 1, nz = std::floor((double)(zhi - zlo) / cs) + 1;
+  if (nx > 2048 || ny > 2048 || nz > 1024)
+    return set_error(MOR_ERR_INVALID, "grid %gx%gx%g cells exceeds 2048x2048x1024: trim box too large for ec_distance_threshold %g", nx, ny, nz, (double)p.ec_distance_threshold);
+  d.g.nx = (int)nx; d.g.ny = (int)ny; d.g.nz = (int)nz; d.g.wx = (d.g.nx + 31) / 32;
+  d.g.nwords = d.g.wx * d.g.ny * d.g.nz;
+  d.g.ox = -p.trim_x; d.g.oy = -p.trim_y; d.g.oz = zlo; d.g.cs = cs; d.g.inv_cs = 1.0f / cs;
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
+  if (d.score_R > 60) return set_error(MOR_ERR_INVALID, "pde_ub %g needs a %d-cell search radius (> 60)", (double)p.pde_ub, d.score_R);
   int bits = 1; while ((1 << bits) < d.Kcap) ++bits;
   d.radix_passes = (bits + 7) / 8;
   d.Hcap = 64; while (d.Hcap < 2 * d.Nmax) d.Hcap <<= 1;
@@ -162,9 +163,25 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, dargs, B) && dalloc(b, d.info, B) && dalloc(b, d.tile_cnt, B * T * 2) && dalloc(b, d.tile_off, B * T * 2);
   b->d_args = dargs; d.args = dargs;
   ok = ok && dalloc(b, d.cloud, B * N) && dalloc(b, d.cloud_tidx, B * N) && dalloc(b, d.ground, B * N) && dalloc(b, d.gp_idx, B * N) && dalloc(b, d.cell_of, B * N);
-  ok = ok && dalloc(b, d.cell_cnt, B * (size_t)d.g.ncells) && dalloc(b, d.cell_start, B * ((size_t)d.g.ncells + 1)) && dalloc(b, d.ctile_sum, B * (size_t)d.ctiles);
-  ok = ok && dalloc(b, d.sorted, B * N) && dalloc(b, d.parent, B * N) && dalloc(b, d.csize, B * N) && dalloc(b, d.cid_of_root, B * N) && dalloc(b, d.label, B * N) && dalloc(b, d.pcid, B * N);
-  ok = ok && dalloc(b, d.ktile_cnt, B * T) && dalloc(b, d.kroot, B * K) && dalloc(b, d.ksize, B * K) && dalloc(b, d.csz, B * K);
+  ok = ok && dalloc(b, d.bitmap, B * (size_t)d.g.nwords) && dalloc(b, d.wprefix, B * (size_t)d.g.nwords);
+  ok = ok && dalloc(b, d.ccount, B * (N + 1)) && dalloc(b, d.cstart, B * (N + 1)) && dalloc(b, d.cfill, B * (N + 1)) && dalloc(b, d.ccoord, B * N) && dalloc(b, d.cmin, B * N);
+  ok = ok && dalloc(b, d.sorted, B * N) && dalloc(b, d.parent, B * N) && dalloc(b, d.croot, B * N) && dalloc(b, d.csize, B * N) && dalloc(b, d.compmin, B * N) && dalloc(b, d.cid_of_root, B * N) && dalloc(b, d.pcid, B * N);
+  ok = ok && dalloc(b, d.ktile_cnt, B * T) && dalloc(b, d.kcell, B * K) && dalloc(b, d.kroot, B * K) && dalloc(b, d.ksize, B * K) && dalloc(b, d.csz, B * K);
+  {  // method-1 search stencil: (dy,dz) rows ordered by their distance lower bound, then by centre distance
+    const int R = d.score_R, side = 2 * R + 1;
+    std::vector<std::pair<std::pair<int, int>, std::pair<int, int>>> rows;
+    for (int dz = -R; dz <= R; ++dz) for (int dy = -R; dy <= R; ++dy) {
+      int ly = std::max(std::abs(dy) - 1, 0), lz = std::max(std::abs(dz) - 1, 0);
+      rows.push_back({{ly * ly + lz * lz, dy * dy + dz * dz}, {dy, dz}});
+    }
+    std::sort(rows.begin(), rows.end());
+    std::vector<signed char> tab(2 * (size_t)side * side);
+    for (size_t i = 0; i < rows.size(); ++i) { tab[2 * i] = (signed char)rows[i].second.first; tab[2 * i + 1] = (signed char)rows[i].second.second; }
+    signed char *dtab = nullptr;
+    ok = ok && dalloc(b, dtab, tab.size());
+    if (ok) ok = hipMemcpy(dtab, tab.data(), tab.size(), hipMemcpyHostToDevice) == hipSuccess;
+    d.row_order = dtab; d.n_rows = side * side;
+  }
   for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, d.rkeys[i], B * N) && dalloc(b, d.rvals[i], B * N);
   ok = ok && dalloc(b, d.rhist, B * T * 256) && dalloc(b, d.cl_idx, B * N);
   for (int i = 0; i < 2; ++i)

@@ -7,9 +7,14 @@
 //     1-KiB rows per wave instruction (64 lanes × 16 B).
 //   * order-preserving compactions use wave ballots + one LDS exchange per 2048-point tile.
 //   * the PCL kd-tree is replaced by a uniform grid keyed by linear cell id (a collision-free
-//     spatial hash), points counting-sorted by cell so a 3-cell x-run is one contiguous range.
-//   * Euclidean clustering = concurrent union-find with min-index hooking (atomicCAS on roots
-//     only), so the final root of a component is its smallest cloud index whatever the schedule.
+//     spatial hash): occupancy bitmap + popcount rank, points counting-sorted by cell so an x-run of
+//     cells is one contiguous range of the sorted array.
+//   * cell edge 0.57·r ⇒ each cell is a clique of the cluster graph, so Euclidean clustering is
+//     connected components over occupied CELLS: one wave per cell, lanes look up the neighbour
+//     cells in the bitmap, then test point pairs across two cells 64 at a time and stop at the
+//     first pair with d² < r².  Concurrent union-find with min-index hooking (atomicCAS on roots
+//     only); cluster identity/order comes from the smallest cloud index of each component, so the
+//     result does not depend on the schedule.
 //   * one workgroup→(stream, tile) map that keeps all tiles of a stream on one XCD (blocks b and
 //     b+8 share an XCD), so a stream's grid, sorted points and forest stay in one 4-MiB L2.
 //     Correctness never depends on that placement: forest loads/stores are agent-scope relaxed
@@ -20,7 +25,7 @@
 #include <cfloat>
 
 const char *const mor_kernel_names[MK_COUNT] = {
-    "classify", "scan_tiles", "scatter", "cell_reduce", "cell_scan", "cell_final", "fill", "hook", "flatten",
+    "classify", "scan_tiles", "scatter", "wprefix", "cellcount", "cstart", "fill", "hook_near", "hook_shell", "flatten",
     "select_count", "select_scan", "select_scatter", "rank", "offsets", "label", "rhist", "rscan", "rscatter",
     "stats", "xform_prev", "nn_centroid", "pairs", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
     "out_count", "out_scan", "out_scatter"};
@@ -85,6 +90,21 @@ __device__ __forceinline__ int cell_axis(float v, float o, float inv, int n) {
   return c < 0 ? 0 : (c >= n ? n - 1 : c);
 }
 __device__ __forceinline__ int cell_axis_unclamped(float v, float o, float inv) { return (int)floorf((v - o) * inv); }
+__device__ __forceinline__ int pack_cell(int cx, int cy, int cz) { return cx | (cy << 11) | (cz << 22); }   // nx,ny ≤ 2048, nz ≤ 1024
+// compact id of cell (cx,cy,cz) or −1 when empty / outside
+__device__ __forceinline__ int cell_lookup(const MorGrid &g, const unsigned *bm, const int *wp, int cx, int cy, int cz) {
+  if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cy >= (unsigned)g.ny || (unsigned)cz >= (unsigned)g.nz) return -1;
+  int w = (cz * g.ny + cy) * g.wx + (cx >> 5);
+  unsigned bits = bm[w], bit = 1u << (cx & 31);
+  return (bits & bit) ? wp[w] + __popc(bits & (bit - 1)) : -1;
+}
+// occupied cells with x in [x0,x1] of row (cy,cz) have the consecutive compact ids [lo, hi)
+__device__ __forceinline__ void row_cells(const MorGrid &g, const unsigned *bm, const int *wp, int x0, int x1, int cy, int cz, int &lo, int &hi) {
+  int rw = (cz * g.ny + cy) * g.wx, w0 = rw + (x0 >> 5), w1 = rw + (x1 >> 5);
+  lo = wp[w0] + __popc(bm[w0] & ((1u << (x0 & 31)) - 1u));
+  unsigned m1 = ((x1 & 31) == 31) ? 0xFFFFFFFFu : ((2u << (x1 & 31)) - 1u);
+  hi = wp[w1] + __popc(bm[w1] & m1);
+}
 
 // L2_Simple: ((dx·dx)+(dy·dy))+(dz·dz), each operation rounded (no contraction)
 __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
@@ -160,21 +180,21 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   int r_ng = to[0], r_g = to[1];
   for (int w = 0; w < wave_id(); ++w) { r_ng += sh[w]; r_g += sh[4 + w]; }
   const size_t so = (size_t)s * d.Nmax;
-  int *cell_cnt = d.cell_cnt + (size_t)s * d.g.ncells;
+  unsigned *bm = d.bitmap + (size_t)s * d.g.nwords;
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     int k_ng = r_ng + __popcll(m_ng[it] & lanemask_lt());
     int k_g = r_g + __popcll(m_g[it] & lanemask_lt());
     if (cls[it] == 2) {
       int cx = cell_axis(p[it].x, d.g.ox, d.g.inv_cs, d.g.nx), cy = cell_axis(p[it].y, d.g.oy, d.g.inv_cs, d.g.ny), cz = cell_axis(p[it].z, d.g.oz, d.g.inv_cs, d.g.nz);
-      int c = (cz * d.g.ny + cy) * d.g.nx + cx;
+      int pos = ((cz * d.g.ny + cy) * d.g.wx) * 32 + cx;
+      atomicOr(&bm[pos >> 5], 1u << (pos & 31));
       d.cloud[so + k_ng] = p[it];
       d.cloud_tidx[so + k_ng] = k_ng + k_g;   // index in the trimmed cloud (both ranks are exclusive counts of earlier kept points)
-      d.cell_of[so + k_ng] = c;
-      d.parent[so + k_ng] = k_ng;
-      d.csize[so + k_ng] = 0;
-      d.cid_of_root[so + k_ng] = -1;
-      atomicAdd(&cell_cnt[c], 1);
+      d.cell_of[so + k_ng] = pos;
+      // per-cell / per-component state lives in arrays indexed by compact cell id < n_occ ≤ M: initialise slot k_ng
+      d.ccount[so + k_ng] = 0; d.cfill[so + k_ng] = 0; d.cmin[so + k_ng] = 0x7fffffff;
+      d.parent[so + k_ng] = k_ng; d.csize[so + k_ng] = 0; d.compmin[so + k_ng] = 0x7fffffff; d.cid_of_root[so + k_ng] = -1;
     } else if (cls[it] == 1) {
       d.ground[so + k_g] = p[it];
       d.gp_idx[so + k_g] = k_ng + k_g;
@@ -183,60 +203,68 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   }
 }
 
-// ------------------------------------------------------------------------------------ grid: exclusive scan of the cell histogram
-__global__ __launch_bounds__(MOR_BT) void k_cell_reduce(MorDev d) {
-  int s, t; map_block(d.B, d.ctiles, s, t);
-  const int *c = d.cell_cnt + (size_t)s * d.g.ncells;
-  int base = t * MOR_TILE, sum = 0;
-  for (int i = base + threadIdx.x; i < min(base + MOR_TILE, d.g.ncells); i += MOR_BT) sum += c[i];
-  __shared__ int sh[8]; int tot;
-  block_excl_scan(sum, sh, &tot);
-  if (threadIdx.x == 0) d.ctile_sum[(size_t)s * d.ctiles + t] = tot;
-}
-__global__ __launch_bounds__(MOR_BT) void k_cell_scan(MorDev d) {
+// ------------------------------------------------------------------------------------ grid: bitmap rank, counting sort by cell
+// one workgroup per stream: exclusive prefix of the bitmap popcounts; publishes n_occ
+__global__ __launch_bounds__(MOR_BT) void k_wprefix(MorDev d) {
   int s = blockIdx.x; __shared__ int sh[8]; int carry = 0;
-  int *c = d.ctile_sum + (size_t)s * d.ctiles;
-  for (int b = 0; b < d.ctiles; b += MOR_BT) {
-    int t = b + threadIdx.x, v = t < d.ctiles ? c[t] : 0, tot;
+  const unsigned *bm = d.bitmap + (size_t)s * d.g.nwords; int *wp = d.wprefix + (size_t)s * d.g.nwords;
+  for (int b = 0; b < d.g.nwords; b += MOR_BT) {
+    int w = b + threadIdx.x, v = w < d.g.nwords ? __popc(bm[w]) : 0, tot;
     int e = block_excl_scan(v, sh, &tot);
-    if (t < d.ctiles) c[t] = carry + e;
+    if (w < d.g.nwords) wp[w] = carry + e;
     carry += tot;
   }
-  if (threadIdx.x == 0) d.cell_start[(size_t)s * (d.g.ncells + 1) + d.g.ncells] = carry;
+  if (threadIdx.x == 0) d.info[s].n_occ = carry;
 }
-__global__ __launch_bounds__(MOR_BT) void k_cell_final(MorDev d) {
-  int s, t; map_block(d.B, d.ctiles, s, t);
-  int *cnt = d.cell_cnt + (size_t)s * d.g.ncells;
-  int *start = d.cell_start + (size_t)s * (d.g.ncells + 1);
-  int base = t * MOR_TILE + threadIdx.x * 8;   // 8 consecutive cells per thread
-  int v[8], sum = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { v[k] = (base + k < d.g.ncells) ? cnt[base + k] : 0; sum += v[k]; }
-  __shared__ int sh[8]; int tot;
-  int e = block_excl_scan(sum, sh, &tot) + d.ctile_sum[(size_t)s * d.ctiles + t];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) if (base + k < d.g.ncells) { start[base + k] = e; e += v[k]; cnt[base + k] = 0; }
+// per cloud point: compact cell id; per cell: point count, smallest cloud index, coordinates
+__global__ __launch_bounds__(MOR_BT) void k_cellcount(MorDev d) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  int M = d.info[s].M, base = t * MOR_TILE;
+  if (base >= M) return;
+  const size_t so = (size_t)s * d.Nmax;
+  const unsigned *bm = d.bitmap + (size_t)s * d.g.nwords; const int *wp = d.wprefix + (size_t)s * d.g.nwords;
+  const int rowbits = d.g.wx * 32;
+  for (int i = base + threadIdx.x; i < min(base + MOR_TILE, M); i += MOR_BT) {
+    int pos = d.cell_of[so + i], w = pos >> 5;
+    int c = wp[w] + __popc(bm[w] & ((1u << (pos & 31)) - 1u));
+    d.cell_of[so + i] = c;
+    atomicAdd(&d.ccount[so + c], 1);
+    atomicMin(&d.cmin[so + c], i);
+    int row = pos / rowbits;
+    d.ccoord[so + c] = pack_cell(pos - row * rowbits, row % d.g.ny, row / d.g.ny);   // same value from every point of the cell
+  }
 }
-
+// one workgroup per stream: exclusive scan of the per-cell counts
+__global__ __launch_bounds__(MOR_BT) void k_cstart(MorDev d) {
+  int s = blockIdx.x, nocc = d.info[s].n_occ; __shared__ int sh[8]; int carry = 0;
+  const size_t so = (size_t)s * d.Nmax;
+  const int *cnt = d.ccount + so; int *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  for (int b = 0; b < nocc; b += MOR_BT) {
+    int c = b + threadIdx.x, v = c < nocc ? cnt[c] : 0, tot;
+    int e = block_excl_scan(v, sh, &tot);
+    if (c < nocc) st[c] = carry + e;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) st[nocc] = carry;
+}
 // counting-sort scatter: sorted[slot] = (x,y,z,bits(cloud index)); order inside a cell is arbitrary
-// (nothing downstream depends on it: roots are min indices, NN results are minima)
+// (nothing downstream depends on it: components are keyed by min indices, NN results are minima)
 __global__ __launch_bounds__(MOR_BT) void k_fill(MorDev d) {
   int s, t; map_block(d.B, d.tiles, s, t);
   int M = d.info[s].M, base = t * MOR_TILE;
   if (base >= M) return;
   const size_t so = (size_t)s * d.Nmax;
-  int *cnt = d.cell_cnt + (size_t)s * d.g.ncells;
-  const int *start = d.cell_start + (size_t)s * (d.g.ncells + 1);
+  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   for (int i = base + threadIdx.x; i < min(base + MOR_TILE, M); i += MOR_BT) {
     int c = d.cell_of[so + i];
-    int slot = start[c] + atomicAdd(&cnt[c], 1);
+    int slot = st[c] + atomicAdd(&d.cfill[so + c], 1);
     float4 p = d.cloud[so + i];
     p.w = __int_as_float(i);
     d.sorted[so + slot] = p;
   }
 }
 
-// ------------------------------------------------------------------------------------ C1: Euclidean clustering = connected components
+// ------------------------------------------------------------------------------------ C1: Euclidean clustering = connected components over cells
 __device__ __forceinline__ int uf_find(int *P, int x) {
   int p = ld_agent(P + x);
   while (p != x) {
@@ -248,7 +276,7 @@ __device__ __forceinline__ int uf_find(int *P, int x) {
   return x;
 }
 // returns the (current) root of the merged component.  Only true roots are ever re-pointed
-// (CAS expects parent[r] == r) and always to a smaller index, so parent ≤ child holds at all times.
+// (CAS expects parent[r] == r) and always to a smaller id, so parent ≤ child holds at all times.
 __device__ __forceinline__ int uf_unite(int *P, int a, int b) {
   int ra = uf_find(P, a), rb = uf_find(P, b);
   while (ra != rb) {
@@ -260,63 +288,73 @@ __device__ __forceinline__ int uf_unite(int *P, int a, int b) {
   return ra;
 }
 
-// one thread per point (cell order): test the 27-cell stencil as 9 contiguous x-runs, unite with
-// every smaller-index neighbour with d² < r² (EuclideanClusterExtraction's edge predicate, :213-218)
-__global__ __launch_bounds__(MOR_BT) void k_hook(MorDev d) {
-  int s, t; map_block(d.B, d.tiles, s, t);
-  int M = d.info[s].M, base = t * MOR_TILE;
-  if (base >= M) return;
-  const float4 *sp = d.sorted + (size_t)s * d.Nmax;
-  const int *start = d.cell_start + (size_t)s * (d.g.ncells + 1);
-  int *P = d.parent + (size_t)s * d.Nmax;
-  const float r2 = d.r2;
-  for (int js = base + threadIdx.x; js < min(base + MOR_TILE, M); js += MOR_BT) {
-    float4 q = sp[js];
-    int i = __float_as_int(q.w), ri = i;
-    int cx = cell_axis(q.x, d.g.ox, d.g.inv_cs, d.g.nx), cy = cell_axis(q.y, d.g.oy, d.g.inv_cs, d.g.ny), cz = cell_axis(q.z, d.g.oz, d.g.inv_cs, d.g.nz);
-    int x0 = max(cx - 1, 0), x1 = min(cx + 1, d.g.nx - 1);
-    for (int z = max(cz - 1, 0); z <= min(cz + 1, d.g.nz - 1); ++z)
-      for (int y = max(cy - 1, 0); y <= min(cy + 1, d.g.ny - 1); ++y) {
-        int row = (z * d.g.ny + y) * d.g.nx;
-        int b = start[row + x0], e = start[row + x1 + 1];
-        for (int k = b; k < e; ++k) {
-          float4 p = sp[k];
-          int j = __float_as_int(p.w);
-          if (j >= i) continue;
-          if (sqdist(q.x, q.y, q.z, p.x, p.y, p.z) < r2) {
-            if (ld_agent(P + j) == ri) continue;   // already under my root
-            ri = uf_unite(P, ri, j);
-          }
-        }
-      }
-  }
-}
-
-// root of every point + component sizes
-__global__ __launch_bounds__(MOR_BT) void k_flatten(MorDev d) {
-  int s, t; map_block(d.B, d.tiles, s, t);
-  int M = d.info[s].M, base = t * MOR_TILE;
-  if (base >= M) return;
+// One wave per occupied cell A.  shell = 0: the 13 "forward" cells of the 3×3×3 neighbourhood;
+// shell = 1: the 49 forward cells of the 5×5×5 shell (run as a second launch, when most of those
+// pairs are already in one component through the cell between them and are skipped by the root
+// test).  Each unordered cell pair is visited exactly once.  Lanes first look the neighbours up in
+// the bitmap, then the wave tests point pairs (a ∈ A, b ∈ B) 64 at a time — EuclideanCluster-
+// Extraction's edge predicate d² < r² (:213-218) — and unites the cells at the first hit.
+__global__ __launch_bounds__(MOR_BT) void k_hook_cells(MorDev d, int shell) {
+  int s = blockIdx.y, nocc = d.info[s].n_occ;
+  const int wv = blockIdx.x * (MOR_BT / 64) + wave_id(), nw = gridDim.x * (MOR_BT / 64), lane = lane_id();
   const size_t so = (size_t)s * d.Nmax;
-  for (int i = base + threadIdx.x; i < min(base + MOR_TILE, M); i += MOR_BT) {
-    int r = i, p = d.parent[so + r];
-    while (p != r) { r = p; p = d.parent[so + r]; }
-    d.label[so + i] = r;
-    atomicAdd(&d.csize[so + r], 1);
+  const unsigned *bm = d.bitmap + (size_t)s * d.g.nwords; const int *wp = d.wprefix + (size_t)s * d.g.nwords;
+  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  const float4 *sp = d.sorted + so;
+  int *P = d.parent + so;
+  int dx, dy, dz; bool lane_ok;
+  if (!shell) { int idx = 14 + lane; lane_ok = lane < 13; dx = idx % 3 - 1; dy = (idx / 3) % 3 - 1; dz = idx / 9 - 1; }
+  else { int idx = 63 + lane; dx = idx % 5 - 2; dy = (idx / 5) % 5 - 2; dz = idx / 25 - 2; lane_ok = lane < 62 && (abs(dx) == 2 || abs(dy) == 2 || abs(dz) == 2); }
+  const float r2 = d.r2;
+  for (int a = wv; a < nocc; a += nw) {
+    int cc = d.ccoord[so + a];
+    int nb = lane_ok ? cell_lookup(d.g, bm, wp, (cc & 2047) + dx, ((cc >> 11) & 2047) + dy, (cc >> 22) + dz) : -1;
+    unsigned long long mask = __ballot(nb >= 0);
+    if (!mask) continue;
+    int ra = uf_find(P, a);
+    const int a0 = st[a], na = st[a + 1] - a0;
+    while (mask) {
+      int l = __ffsll((long long)mask) - 1; mask &= mask - 1;
+      int b = __shfl(nb, l, 64);
+      int rb = uf_find(P, b);
+      if (rb == ra) continue;
+      const int b0 = st[b], nbp = st[b + 1] - b0;
+      const long long total = (long long)na * nbp;
+      bool hit = false;
+      for (long long base = 0; base < total; base += 64) {
+        long long k = base + lane; bool h = false;
+        if (k < total) { int ib = (int)(k / na), ia = (int)(k - (long long)ib * na); float4 pa = sp[a0 + ia], pb = sp[b0 + ib]; h = sqdist(pa.x, pa.y, pa.z, pb.x, pb.y, pb.z) < r2; }
+        if (__ballot(h)) { hit = true; break; }
+      }
+      if (hit) { int r = 0; if (lane == 0) r = uf_unite(P, ra, rb); ra = __shfl(r, 0, 64); }
+    }
   }
 }
 
-// kept components: min_cluster_size ≤ size ≤ max_cluster_size (:215-216), compacted in ascending root order
-__device__ __forceinline__ bool kept_root(const MorDev &d, size_t so, int i) {
-  if (d.label[so + i] != i) return false;
-  long long n = d.csize[so + i];
+// root of every cell; component size (points) and smallest cloud index accumulate at the root
+__global__ __launch_bounds__(MOR_BT) void k_flatten(MorDev d) {
+  int s = blockIdx.y, nocc = d.info[s].n_occ;
+  const size_t so = (size_t)s * d.Nmax;
+  for (int c = blockIdx.x * MOR_BT + threadIdx.x; c < nocc; c += gridDim.x * MOR_BT) {
+    int r = c, p = d.parent[so + r];
+    while (p != r) { r = p; p = d.parent[so + r]; }
+    d.croot[so + c] = r;
+    atomicAdd(&d.csize[so + r], d.ccount[so + c]);
+    atomicMin(&d.compmin[so + r], d.cmin[so + c]);
+  }
+}
+
+// kept components: min_cluster_size ≤ size ≤ max_cluster_size (:215-216)
+__device__ __forceinline__ bool kept_root(const MorDev &d, size_t so, int c) {
+  if (d.croot[so + c] != c) return false;
+  long long n = d.csize[so + c];
   return n >= d.min_cs && n <= d.max_cs;
 }
 __global__ __launch_bounds__(MOR_BT) void k_select_count(MorDev d) {
   int s, t; map_block(d.B, d.tiles, s, t);
-  int M = d.info[s].M, base = t * MOR_TILE, c = 0;
+  int nocc = d.info[s].n_occ, base = t * MOR_TILE, c = 0;
   const size_t so = (size_t)s * d.Nmax;
-  for (int i = base + threadIdx.x; i < min(base + MOR_TILE, M); i += MOR_BT) c += kept_root(d, so, i);
+  for (int i = base + threadIdx.x; i < min(base + MOR_TILE, nocc); i += MOR_BT) c += kept_root(d, so, i);
   __shared__ int sh[8]; int tot;
   block_excl_scan(c, sh, &tot);
   if (threadIdx.x == 0) d.ktile_cnt[(size_t)s * d.tiles_max + t] = tot;
@@ -338,22 +376,21 @@ __global__ __launch_bounds__(MOR_BT) void k_select_scan(MorDev d) {
 }
 __global__ __launch_bounds__(MOR_BT) void k_select_scatter(MorDev d) {
   int s, t; map_block(d.B, d.tiles, s, t);
-  int M = d.info[s].M, base = t * MOR_TILE;
-  if (base >= M) return;
-  const size_t so = (size_t)s * d.Nmax;
+  int nocc = d.info[s].n_occ, base = t * MOR_TILE;
+  if (base >= nocc) return;
+  const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   int off = d.ktile_cnt[(size_t)s * d.tiles_max + t];
-  // 2048 items as 8 rows of 256: rows are consecutive, so row-major exclusive scan = index order
   __shared__ int sh[8];
   for (int row = 0; row < 8; ++row) {
     int i = base + row * MOR_BT + threadIdx.x;
-    int k = (i < M) ? kept_root(d, so, i) : 0, tot;
+    int k = (i < nocc) ? kept_root(d, so, i) : 0, tot;
     int e = block_excl_scan(k, sh, &tot);
-    if (k && off + e < d.Kcap) { d.kroot[(size_t)s * d.Kcap + off + e] = i; d.ksize[(size_t)s * d.Kcap + off + e] = d.csize[so + i]; }
+    if (k && off + e < d.Kcap) { d.kcell[ko + off + e] = i; d.kroot[ko + off + e] = d.compmin[so + i]; d.ksize[ko + off + e] = d.csize[so + i]; }
     off += tot;
   }
 }
 
-// cluster order: size descending, ties by smaller first (= root) index.  K is small: rank by counting.
+// cluster order: size descending, ties by smaller first cloud index (kroot).  K is small: rank by counting.
 __global__ __launch_bounds__(MOR_BT) void k_rank(MorDev d) {
   int s = blockIdx.y, K = d.info[s].K;
   int k = blockIdx.x * MOR_BT + threadIdx.x;
@@ -370,7 +407,7 @@ __global__ __launch_bounds__(MOR_BT) void k_rank(MorDev d) {
     __syncthreads();
   }
   if (k < K) {
-    d.cid_of_root[(size_t)s * d.Nmax + my_rt] = rank;
+    d.cid_of_root[(size_t)s * d.Nmax + d.kcell[(size_t)s * d.Kcap + k]] = rank;
     d.csz[(size_t)s * d.Kcap + rank] = my_sz;
   }
 }
@@ -387,7 +424,7 @@ __global__ __launch_bounds__(MOR_BT) void k_offsets(MorDev d) {
   }
   if (threadIdx.x == 0) { off[K] = carry; d.info[s].C = carry; }
 }
-// per sorted slot: cluster id of its point → label[cloud index] and sorted.w
+// per sorted slot: cluster id of its point → pcid[cloud index] and sorted.w
 __global__ __launch_bounds__(MOR_BT) void k_label(MorDev d) {
   int s, t; map_block(d.B, d.tiles, s, t);
   int M = d.info[s].M, base = t * MOR_TILE;
@@ -396,10 +433,10 @@ __global__ __launch_bounds__(MOR_BT) void k_label(MorDev d) {
   for (int js = base + threadIdx.x; js < min(base + MOR_TILE, M); js += MOR_BT) {
     float4 q = d.sorted[so + js];
     int i = __float_as_int(q.w);
-    int cid = d.cid_of_root[so + d.label[so + i]];
+    int cid = d.cid_of_root[so + d.croot[so + d.cell_of[so + i]]];
     q.w = __int_as_float(cid);
     d.sorted[so + js] = q;
-    d.pcid[so + i] = cid;   // `label` still serves other slots as root → cluster ids go to their own array
+    d.pcid[so + i] = cid;
   }
 }
 
@@ -618,36 +655,44 @@ __global__ __launch_bounds__(MOR_BT) void k_pairs(MorDev d) {
 
 // ------------------------------------------------------------------------------------ P3: method 1 (:336-366)
 // per point of a matched previous cluster: squared distance to the nearest point of the matched
-// current cluster, found in the current frame's grid inside a √ub stencil (a farther neighbour can
-// never satisfy d² < ub); count lb < d² < ub.
+// current cluster; count lb < d² < ub (:356).  Search in the current frame's grid, rows of cells
+// visited nearest-first (row_order): a row whose lower bound is ≥ min(best, ub) ends the search
+// (a neighbour at d² ≥ ub can never be counted), and so does best ≤ lb.
 __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
   int s, t; map_block(d.B, d.tiles, s, t);
   int pv = d.cur ^ 1, Cp = d.info[s].Cprev, base = t * MOR_TILE;
   if (base >= Cp) return;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
-  const int *start = d.cell_start + (size_t)s * (d.g.ncells + 1);
+  const unsigned *bm = d.bitmap + (size_t)s * d.g.nwords; const int *wp = d.wprefix + (size_t)s * d.g.nwords;
+  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const int R = d.score_R;
+  const float cs = d.g.cs * 0.999f;
   for (int j = base + threadIdx.x; j < min(base + MOR_TILE, Cp); j += MOR_BT) {
     int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
     if (pr < 0) continue;
     int target = d.pair_m[ko + pr];
     float4 q = d.cl_pts[pv][so + j];
     int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.g.oz, d.g.inv_cs);
-    int x0 = min(max(cx - R, 0), d.g.nx - 1), x1 = min(max(cx + R, 0), d.g.nx - 1);
-    int y0 = min(max(cy - R, 0), d.g.ny - 1), y1 = min(max(cy + R, 0), d.g.ny - 1);
-    int z0 = min(max(cz - R, 0), d.g.nz - 1), z1 = min(max(cz + R, 0), d.g.nz - 1);
+    int x0 = max(cx - R, 0), x1 = min(cx + R, d.g.nx - 1);
     float best = INFINITY;
-    for (int z = z0; z <= z1; ++z)
-      for (int y = y0; y <= y1; ++y) {
-        int row = (z * d.g.ny + y) * d.g.nx;
-        int b = start[row + x0], e = start[row + x1 + 1];
-        for (int k = b; k < e; ++k) {
+    if (x0 <= x1) {
+      for (int ro = 0; ro < d.n_rows; ++ro) {
+        int dy = d.row_order[2 * ro], dz = d.row_order[2 * ro + 1];
+        float ly = (float)max(abs(dy) - 1, 0) * cs, lz = (float)max(abs(dz) - 1, 0) * cs;
+        if (ly * ly + lz * lz >= fminf(best, d.pde_ub)) break;   // rows are ordered by this bound
+        int y = cy + dy, z = cz + dz;
+        if ((unsigned)y >= (unsigned)d.g.ny || (unsigned)z >= (unsigned)d.g.nz) continue;
+        int lo, hi; row_cells(d.g, bm, wp, x0, x1, y, z, lo, hi);
+        if (lo >= hi) continue;
+        for (int k = st[lo], e = st[hi]; k < e; ++k) {
           float4 p = sp[k];
           if (__float_as_int(p.w) != target) continue;
           best = fminf(best, sqdist(q.x, q.y, q.z, p.x, p.y, p.z));
         }
+        if (best <= d.pde_lb) break;   // the minimum can only get smaller: never counted
       }
+    }
     if (best > d.pde_lb && best < d.pde_ub) atomicAdd(&d.pair_cnt[ko + pr], 1);
   }
 }
@@ -815,17 +860,18 @@ __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
   } while (0)
 
 void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  const dim3 gT(d.B * d.tiles), gB(d.B), gC(d.B * d.ctiles), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B);
-  hipMemsetAsync(d.cell_cnt, 0, (size_t)d.B * d.g.ncells * sizeof(int), st);
+  const dim3 gT(d.B * d.tiles), gB(d.B), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B), gW(64, d.B);
+  hipMemsetAsync(d.bitmap, 0, (size_t)d.B * d.g.nwords * sizeof(unsigned), st);
   MOR_LAUNCH(MK_CLASSIFY, k_classify, gT, d);
   MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
   MOR_LAUNCH(MK_SCATTER, k_scatter, gT, d);
-  MOR_LAUNCH(MK_CELL_REDUCE, k_cell_reduce, gC, d);
-  MOR_LAUNCH(MK_CELL_SCAN, k_cell_scan, gB, d);
-  MOR_LAUNCH(MK_CELL_FINAL, k_cell_final, gC, d);
+  MOR_LAUNCH(MK_WPREFIX, k_wprefix, gB, d);
+  MOR_LAUNCH(MK_CELLCOUNT, k_cellcount, gT, d);
+  MOR_LAUNCH(MK_CSTART, k_cstart, gB, d);
   MOR_LAUNCH(MK_FILL, k_fill, gT, d);
-  MOR_LAUNCH(MK_HOOK, k_hook, gT, d);
-  MOR_LAUNCH(MK_FLATTEN, k_flatten, gT, d);
+  MOR_LAUNCH(MK_HOOK_NEAR, k_hook_cells, gW, d, 0);
+  MOR_LAUNCH(MK_HOOK_SHELL, k_hook_cells, gW, d, 1);
+  MOR_LAUNCH(MK_FLATTEN, k_flatten, dim3(32, d.B), d);
   MOR_LAUNCH(MK_SELECT_COUNT, k_select_count, gT, d);
   MOR_LAUNCH(MK_SELECT_SCAN, k_select_scan, gB, d);
   MOR_LAUNCH(MK_SELECT_SCATTER, k_select_scatter, gT, d);
