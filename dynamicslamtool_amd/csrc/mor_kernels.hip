@@ -654,46 +654,65 @@ __global__ __launch_bounds__(MOR_BT) void k_pairs(MorDev d) {
 }
 
 // ------------------------------------------------------------------------------------ P3: method 1 (:336-366)
-// per point of a matched previous cluster: squared distance to the nearest point of the matched
-// current cluster; count lb < d² < ub (:356).  Search in the current frame's grid, rows of cells
-// visited nearest-first (row_order): a row whose lower bound is ≥ min(best, ub) ends the search
-// (a neighbour at d² ≥ ub can never be counted), and so does best ≤ lb.
+// per point q of a matched previous cluster: squared distance to the nearest point of the matched
+// current cluster; count lb < d² < ub (:356).  One WAVE per query: lanes first resolve the rows of
+// the search stencil to point ranges of the current frame's cell-sorted array (bitmap rank), then
+// the wave streams each range 64 candidates at a time (coalesced 1-KiB reads).  Rows are visited
+// nearest-first (row_order): a row whose lower bound is ≥ min(best, ub) ends the search (a
+// neighbour at d² ≥ ub can never be counted), and so does any candidate with d² ≤ lb (the minimum
+// can only get smaller ⇒ never counted).
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
 __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
-  int s, t; map_block(d.B, d.tiles, s, t);
-  int pv = d.cur ^ 1, Cp = d.info[s].Cprev, base = t * MOR_TILE;
-  if (base >= Cp) return;
+  int s = blockIdx.y, pv = d.cur ^ 1, Cp = d.info[s].Cprev;
+  const int wv = blockIdx.x * (MOR_BT / 64) + wave_id(), nw = gridDim.x * (MOR_BT / 64), lane = lane_id();
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
   const unsigned *bm = d.bitmap + (size_t)s * d.g.nwords; const int *wp = d.wprefix + (size_t)s * d.g.nwords;
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const int R = d.score_R;
-  const float cs = d.g.cs * 0.999f;
-  for (int j = base + threadIdx.x; j < min(base + MOR_TILE, Cp); j += MOR_BT) {
+  const float cs = d.g.cs * 0.999f;   // conservative cell edge for the row lower bounds
+  for (int j = wv; j < Cp; j += nw) {
     int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
     if (pr < 0) continue;
-    int target = d.pair_m[ko + pr];
-    float4 q = d.cl_pts[pv][so + j];
-    int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.g.oz, d.g.inv_cs);
-    int x0 = max(cx - R, 0), x1 = min(cx + R, d.g.nx - 1);
-    float best = INFINITY;
-    if (x0 <= x1) {
-      for (int ro = 0; ro < d.n_rows; ++ro) {
+    const int target = d.pair_m[ko + pr];
+    const float4 q = d.cl_pts[pv][so + j];
+    const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.g.oz, d.g.inv_cs);
+    float best = INFINITY; bool done = false;
+    for (int rb = 0; rb < d.n_rows && !done; rb += 64) {
+      // lanes: resolve up to 64 rows
+      int ro = rb + lane, kb = 0, ke = 0; float lbrow = INFINITY;
+      if (ro < d.n_rows) {
         int dy = d.row_order[2 * ro], dz = d.row_order[2 * ro + 1];
         float ly = (float)max(abs(dy) - 1, 0) * cs, lz = (float)max(abs(dz) - 1, 0) * cs;
-        if (ly * ly + lz * lz >= fminf(best, d.pde_ub)) break;   // rows are ordered by this bound
+        lbrow = ly * ly + lz * lz;
+        float budget = d.pde_ub - lbrow;
         int y = cy + dy, z = cz + dz;
-        if ((unsigned)y >= (unsigned)d.g.ny || (unsigned)z >= (unsigned)d.g.nz) continue;
-        int lo, hi; row_cells(d.g, bm, wp, x0, x1, y, z, lo, hi);
-        if (lo >= hi) continue;
-        for (int k = st[lo], e = st[hi]; k < e; ++k) {
-          float4 p = sp[k];
-          if (__float_as_int(p.w) != target) continue;
-          best = fminf(best, sqdist(q.x, q.y, q.z, p.x, p.y, p.z));
+        if (budget > 0.f && (unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) {
+          int rx = min(R, (int)(sqrtf(budget) * d.g.inv_cs * 1.001f) + 1);
+          int x0 = max(cx - rx, 0), x1 = min(cx + rx, d.g.nx - 1);
+          if (x0 <= x1) { int lo, hi; row_cells(d.g, bm, wp, x0, x1, y, z, lo, hi); if (lo < hi) { kb = st[lo]; ke = st[hi]; } }
         }
-        if (best <= d.pde_lb) break;   // the minimum can only get smaller: never counted
+      }
+      const int nr = min(64, d.n_rows - rb);
+      for (int r = 0; r < nr; ++r) {
+        float lbr = __shfl(lbrow, r, 64);
+        if (lbr >= fminf(best, d.pde_ub)) { done = true; break; }   // rows are ordered by this bound
+        int b0 = __shfl(kb, r, 64), e0 = __shfl(ke, r, 64);
+        float local = INFINITY;
+        for (int k0 = b0; k0 < e0; k0 += 64) {
+          int k = k0 + lane;
+          if (k < e0) { float4 p = sp[k]; if (__float_as_int(p.w) == target) local = fminf(local, sqdist(q.x, q.y, q.z, p.x, p.y, p.z)); }
+          if (__ballot(local <= d.pde_lb)) break;
+        }
+        best = fminf(best, wave_min(local));
+        if (best <= d.pde_lb) { done = true; break; }
       }
     }
-    if (best > d.pde_lb && best < d.pde_ub) atomicAdd(&d.pair_cnt[ko + pr], 1);
+    if (lane == 0 && best > d.pde_lb && best < d.pde_ub) atomicAdd(&d.pair_cnt[ko + pr], 1);
   }
 }
 
@@ -890,7 +909,7 @@ void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     MOR_LAUNCH(MK_NN, k_nn_centroid, gKt, d, 1);
     MOR_LAUNCH(MK_PAIRS, k_pairs, gB, d);
     if (d.method == 1) {
-      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) MOR_LAUNCH(MK_SCORE1, k_score_pde, gT, d);
+      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(128, d.B), d);
     } else if (d.method == 2) {
       MOR_LAUNCH(MK_VOX_CLEAR, k_vox_clear, dim3(64, d.B), d);
       MOR_LAUNCH(MK_VOX_INSERT, k_vox_insert, gT, d);
