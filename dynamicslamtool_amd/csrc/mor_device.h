@@ -59,6 +59,7 @@ struct MorDev {
   int *ccount, *cstart, *cfill; // [B][Nmax+1]  points per occupied cell, exclusive offsets, fill cursor
   int *ccoord;               // [B][Nmax]  packed (cx | cy<<12 | cz<<24 … see pack_cell) per occupied cell
   int *cmin;                 // [B][Nmax]  smallest cloud index in the cell
+  float4 *cbox_lo, *cbox_hi; // [B][Nmax]  bounding box of the cell's points
   float4 *sorted;            // [B][Nmax]  (x,y,z, bits(cloud index)) in cell order; .w becomes the cluster id after labelling
   int *parent;               // [B][Nmax]  union-find forest over occupied cells (parent ≤ child)
   int *croot;                // [B][Nmax]  flattened root per cell
@@ -105,7 +106,7 @@ struct MorDev {
 
 // kernel ids for optional per-kernel event timing
 enum MorKernelId {
-  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_WPREFIX, MK_CELLCOUNT, MK_CSTART, MK_FILL, MK_HOOK_NEAR, MK_HOOK_SHELL, MK_FLATTEN,
+  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_WPREFIX, MK_CELLCOUNT, MK_CSTART, MK_FILL, MK_CELLBOX, MK_HOOK_NEAR, MK_HOOK_SHELL, MK_FLATTEN,
   MK_SELECT_COUNT, MK_SELECT_SCAN, MK_SELECT_SCATTER, MK_RANK, MK_OFFSETS, MK_LABEL, MK_RHIST, MK_RSCAN, MK_RSCATTER,
   MK_STATS, MK_XFORM_PREV, MK_NN, MK_PAIRS, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
   MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_COUNT

@@ -23,9 +23,10 @@
 //     mul/add, no FMA contraction): the file is compiled with -ffp-contract=off.
 #include "mor_device.h"
 #include <cfloat>
+#include <cstdlib>
 
 const char *const mor_kernel_names[MK_COUNT] = {
-    "classify", "scan_tiles", "scatter", "wprefix", "cellcount", "cstart", "fill", "hook_near", "hook_shell", "flatten",
+    "classify", "scan_tiles", "scatter", "wprefix", "cellcount", "cstart", "fill", "cellbox", "hook_near", "hook_shell", "flatten",
     "select_count", "select_scan", "select_scatter", "rank", "offsets", "label", "rhist", "rscan", "rscatter",
     "stats", "xform_prev", "nn_centroid", "pairs", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
     "out_count", "out_scan", "out_scatter"};
@@ -61,8 +62,13 @@ __device__ __forceinline__ int block_excl_scan(int v, int *sh, int *total) {
   return base + inc - v;
 }
 
+#ifdef MOR_EXP_PLAIN_UF
+__device__ __forceinline__ int ld_agent(const int *p) { return *(const volatile int *)p; }
+__device__ __forceinline__ void st_agent(int *p, int v) { *(volatile int *)p = v; }
+#else
 __device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 
 // fromPCLPointCloud2 (:523): named float32 fields of a blob record → (x,y,z,intensity)
 __device__ __forceinline__ float4 load_point(const MorStreamArgs &a, uint32_t i) {
@@ -288,6 +294,25 @@ __device__ __forceinline__ int uf_unite(int *P, int a, int b) {
   return ra;
 }
 
+// bounding box of the points of every occupied cell (prunes cell-pair tests); one wave per cell
+__global__ __launch_bounds__(MOR_BT) void k_cellbox(MorDev d) {
+  int s = blockIdx.y, nocc = d.info[s].n_occ;
+  const int wv = blockIdx.x * (MOR_BT / 64) + wave_id(), nw = gridDim.x * (MOR_BT / 64), lane = lane_id();
+  const size_t so = (size_t)s * d.Nmax;
+  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  const float4 *sp = d.sorted + so;
+  for (int a = wv; a < nocc; a += nw) {
+    float lx = FLT_MAX, ly = FLT_MAX, lz = FLT_MAX, hx = -FLT_MAX, hy = -FLT_MAX, hz = -FLT_MAX;
+    for (int k = st[a] + lane, e = st[a + 1]; k < e; k += 64) { float4 p = sp[k]; lx = fminf(lx, p.x); ly = fminf(ly, p.y); lz = fminf(lz, p.z); hx = fmaxf(hx, p.x); hy = fmaxf(hy, p.y); hz = fmaxf(hz, p.z); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
+      hx = fmaxf(hx, __shfl_xor(hx, o, 64)); hy = fmaxf(hy, __shfl_xor(hy, o, 64)); hz = fmaxf(hz, __shfl_xor(hz, o, 64));
+    }
+    if (lane == 0) { d.cbox_lo[so + a] = make_float4(lx, ly, lz, 0.f); d.cbox_hi[so + a] = make_float4(hx, hy, hz, 0.f); }
+  }
+}
+
 // One wave per occupied cell A.  shell = 0: the 13 "forward" cells of the 3×3×3 neighbourhood;
 // shell = 1: the 49 forward cells of the 5×5×5 shell (run as a second launch, when most of those
 // pairs are already in one component through the cell between them and are skipped by the root
@@ -309,24 +334,43 @@ __global__ __launch_bounds__(MOR_BT) void k_hook_cells(MorDev d, int shell) {
   for (int a = wv; a < nocc; a += nw) {
     int cc = d.ccoord[so + a];
     int nb = lane_ok ? cell_lookup(d.g, bm, wp, (cc & 2047) + dx, ((cc >> 11) & 2047) + dy, (cc >> 22) + dz) : -1;
-    unsigned long long mask = __ballot(nb >= 0);
-    if (!mask) continue;
+    if (!__ballot(nb >= 0)) continue;
     int ra = uf_find(P, a);
     const int a0 = st[a], na = st[a + 1] - a0;
+    int sh = 0; while ((1 << sh) < na && sh < 6) ++sh;
+    const int at = 1 << sh, bt = 64 >> sh, la = lane & (at - 1), lb = lane >> sh;
+    const float4 alo = d.cbox_lo[so + a], ahi = d.cbox_hi[so + a];
+    // every lane resolves ITS neighbour in parallel: root differs from mine and the two cells' point boxes
+    // are closer than r (conservative, 0.999 slack) ⇒ candidate for a pair test
+    bool cand = false;
+    if (nb >= 0) {
+      const float4 blo = d.cbox_lo[so + nb], bhi = d.cbox_hi[so + nb];
+      float gx = fmaxf(fmaxf(blo.x - ahi.x, alo.x - bhi.x), 0.f), gy = fmaxf(fmaxf(blo.y - ahi.y, alo.y - bhi.y), 0.f), gz = fmaxf(fmaxf(blo.z - ahi.z, alo.z - bhi.z), 0.f);
+      cand = (gx * gx + gy * gy + gz * gz) * 0.999f < r2;
+    }
+    int rb = cand ? uf_find(P, nb) : -1;
+    unsigned long long mask = __ballot(cand && rb != ra);
     while (mask) {
-      int l = __ffsll((long long)mask) - 1; mask &= mask - 1;
+      int l = __ffsll((long long)mask) - 1;
       int b = __shfl(nb, l, 64);
-      int rb = uf_find(P, b);
-      if (rb == ra) continue;
       const int b0 = st[b], nbp = st[b + 1] - b0;
-      const long long total = (long long)na * nbp;
       bool hit = false;
-      for (long long base = 0; base < total; base += 64) {
-        long long k = base + lane; bool h = false;
-        if (k < total) { int ib = (int)(k / na), ia = (int)(k - (long long)ib * na); float4 pa = sp[a0 + ia], pb = sp[b0 + ib]; h = sqdist(pa.x, pa.y, pa.z, pb.x, pb.y, pb.z) < r2; }
-        if (__ballot(h)) { hit = true; break; }
+      for (int ia0 = 0; ia0 < na && !hit; ia0 += at) {   // lanes tile (A × B) as at × (64/at), at = power of two ≥ min(na, 64)
+        const int ia = ia0 + la;
+        float4 pa = sp[a0 + min(ia, na - 1)];
+        for (int ib0 = 0; ib0 < nbp; ib0 += bt) {
+          const int ib = ib0 + lb;
+          float4 pb = sp[b0 + min(ib, nbp - 1)];
+          bool h = ia < na && ib < nbp && sqdist(pa.x, pa.y, pa.z, pb.x, pb.y, pb.z) < r2;
+          if (__ballot(h)) { hit = true; break; }
+        }
       }
-      if (hit) { int r = 0; if (lane == 0) r = uf_unite(P, ra, rb); ra = __shfl(r, 0, 64); }
+      if (lane == l) cand = false;   // this pair is settled either way
+      if (hit) {
+        int r = 0; if (lane == 0) r = uf_unite(P, ra, b); ra = __shfl(r, 0, 64);
+        if (cand) rb = uf_find(P, nb);   // roots may have moved: refresh in parallel
+      }
+      mask = __ballot(cand && rb != ra);
     }
   }
 }
@@ -682,10 +726,28 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
     const float4 q = d.cl_pts[pv][so + j];
     const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.g.oz, d.g.inv_cs);
     float best = INFINITY; bool done = false;
+    // stage 1: the query's own row of cells (row_order[0] = (0,0)).  On a static surface some point of
+    // the matched cluster lies within √lb of q, almost always in this row: one lookup, one short scan.
+    if ((unsigned)cy < (unsigned)d.g.ny && (unsigned)cz < (unsigned)d.g.nz) {
+      int x0 = max(cx - R, 0), x1 = min(cx + R, d.g.nx - 1);
+      if (x0 <= x1) {
+        int lo, hi; row_cells(d.g, bm, wp, x0, x1, cy, cz, lo, hi);
+        if (lo < hi) {
+          float local = INFINITY;
+          for (int k0 = st[lo], e0 = st[hi]; k0 < e0; k0 += 64) {
+            int k = k0 + lane;
+            if (k < e0) { float4 p = sp[k]; if (__float_as_int(p.w) == target) local = fminf(local, sqdist(q.x, q.y, q.z, p.x, p.y, p.z)); }
+            if (__ballot(local <= d.pde_lb)) break;
+          }
+          best = wave_min(local);
+          done = best <= d.pde_lb;
+        }
+      }
+    }
     for (int rb = 0; rb < d.n_rows && !done; rb += 64) {
       // lanes: resolve up to 64 rows
       int ro = rb + lane, kb = 0, ke = 0; float lbrow = INFINITY;
-      if (ro < d.n_rows) {
+      if (ro < d.n_rows && ro > 0) {   // row 0 was stage 1
         int dy = d.row_order[2 * ro], dz = d.row_order[2 * ro + 1];
         float ly = (float)max(abs(dy) - 1, 0) * cs, lz = (float)max(abs(dz) - 1, 0) * cs;
         lbrow = ly * ly + lz * lz;
@@ -697,8 +759,10 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
           if (x0 <= x1) { int lo, hi; row_cells(d.g, bm, wp, x0, x1, y, z, lo, hi); if (lo < hi) { kb = st[lo]; ke = st[hi]; } }
         }
       }
-      const int nr = min(64, d.n_rows - rb);
-      for (int r = 0; r < nr; ++r) {
+      unsigned long long rows = __ballot(kb < ke);   // non-empty rows, lane order = nearest first
+      if (!rows && __shfl(lbrow, min(63, d.n_rows - rb - 1), 64) >= fminf(best, d.pde_ub)) done = true;
+      while (rows) {
+        int r = __ffsll((long long)rows) - 1; rows &= rows - 1;
         float lbr = __shfl(lbrow, r, 64);
         if (lbr >= fminf(best, d.pde_ub)) { done = true; break; }   // rows are ordered by this bound
         int b0 = __shfl(kb, r, 64), e0 = __shfl(ke, r, 64);
@@ -879,7 +943,7 @@ __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
   } while (0)
 
 void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  const dim3 gT(d.B * d.tiles), gB(d.B), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B), gW(64, d.B);
+  const dim3 gT(d.B * d.tiles), gB(d.B), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B), gW(getenv("MOR_GW") ? atoi(getenv("MOR_GW")) : 64, d.B);
   hipMemsetAsync(d.bitmap, 0, (size_t)d.B * d.g.nwords * sizeof(unsigned), st);
   MOR_LAUNCH(MK_CLASSIFY, k_classify, gT, d);
   MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
@@ -888,6 +952,7 @@ void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   MOR_LAUNCH(MK_CELLCOUNT, k_cellcount, gT, d);
   MOR_LAUNCH(MK_CSTART, k_cstart, gB, d);
   MOR_LAUNCH(MK_FILL, k_fill, gT, d);
+  MOR_LAUNCH(MK_CELLBOX, k_cellbox, gW, d);
   MOR_LAUNCH(MK_HOOK_NEAR, k_hook_cells, gW, d, 0);
   MOR_LAUNCH(MK_HOOK_SHELL, k_hook_cells, gW, d, 1);
   MOR_LAUNCH(MK_FLATTEN, k_flatten, dim3(32, d.B), d);

@@ -7,7 +7,7 @@ import numpy as np
 from .params import MorParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmor_hip.so")
+LIB_PATH = os.environ.get("MOR_HIP_LIB") or os.path.join(_HERE, "csrc", "libmor_hip.so")
 _LIB = None
 MOR_NO_FIELD = 0xFFFFFFFF
 
