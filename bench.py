@@ -41,17 +41,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--e2e", action="store_true", help="also time a few steps with host-resident clouds (PCIe-inclusive)")
+    ap.add_argument("--dry-run", action="store_true", help="exercise only the multi-rank plumbing (no GPU work, no measurement)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from dynamicslamtool_amd import shard
+    rank, local_rank, world = shard.env_rank()
+    dist = shard.init_distributed()
+
+    if args.dry_run:
+        B = args.streams or WORKLOADS[args.workload][1]
+        seeds = shard.stream_seeds(2, rank, B)
+        shard.barrier(dist)
+        fake_elapsed = 1.0 + 0.5 * rank          # the slowest rank defines the job time
+        rate = shard.whole_job_rate(dist, B * args.steps, fake_elapsed)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "value": rate, "first_seed": seeds[0], "last_seed_rank0": seeds[-1], "steps": args.steps}))
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from dynamicslamtool_amd import engine, kitti_params, synth
 
@@ -67,7 +75,7 @@ def main():
 
     # ---- synthetic streams, resident in HBM: frame f of stream s at offset ((f*B)+s)*npts*16
     n_frames = min(args.warmup + args.steps + 1, 24)
-    seeds = [1000 * 2 + rank * B + s for s in range(B)]   # seed = 1000·config + stream (config 2)
+    seeds = shard.stream_seeds(2, rank, B)   # seed = 1000·config + global stream (config 2)
     cloud_bytes = npts * 16
     buf = engine.DeviceBuffer(n_frames * B * cloud_bytes, device)
     poses = np.empty((n_frames, B, 7))
@@ -107,13 +115,7 @@ def main():
     batch.synchronize()
     if dist:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-
+    elapsed = shard.max_over_ranks(dist, time.perf_counter() - t0)
     value = world * B * args.steps / elapsed
 
     # ---- algorithmic bytes per frame-pair: 16·N + 16·C_prev + 16·N_out + 4·T + 32·K

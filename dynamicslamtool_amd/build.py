@@ -42,8 +42,20 @@ def build_synth(force=False):
     return out
 
 
+def build_replay(force=False):
+    """The drop-in class (include/MOR/MovingObjectRemoval.h over the C ABI) + the ROS-free replay driver."""
+    out = os.path.join(CSRC, "mor_replay")
+    srcs = [os.path.join(CSRC, "mor_adapter.cpp"), os.path.join(CSRC, "mor_replay.cpp")]
+    inc = os.path.join(HERE, "..", "include")
+    deps = srcs + [os.path.join(inc, "MOR", "MovingObjectRemoval.h"), os.path.join(inc, "MOR", "IncludeAll.h"), os.path.join(inc, "mor_hip.h"), os.path.join(CSRC, "libmor_hip.so")]
+    if not force and not _newer(out, deps):
+        return out
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I", inc, "-o", out] + srcs + ["-L", CSRC, "-lmor_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_synth(force)
+    return build_hip(force, verbose), build_synth(force), build_replay(force)
 
 
 if __name__ == "__main__":

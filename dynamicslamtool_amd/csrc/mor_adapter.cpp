@@ -1,0 +1,119 @@
+// mor_adapter.cpp — implementation of the drop-in class in include/MOR/MovingObjectRemoval.h on top
+// of the C ABI (include/mor_hip.h).  Host-only C++; link with libmor_hip.so.
+#include "MOR/MovingObjectRemoval.h"
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+namespace {
+// PointXYZI record as toPCLPointCloud2<PointXYZI> serialises it (reference .cpp:690): 32 bytes,
+// x@0 y@4 z@8 (pad 1.0f @12) intensity@16
+constexpr uint32_t kStep = 32, kOffI = 16;
+
+template <class Cloud, class Field> void describe_xyzi(Cloud &c, size_t n) {
+  c.fields.clear();
+  const char *names[4] = {"x", "y", "z", "intensity"}; const uint32_t offs[4] = {0, 4, 8, kOffI};
+  for (int i = 0; i < 4; ++i) { Field f; f.name = names[i]; f.offset = offs[i]; f.datatype = 7 /*FLOAT32*/; f.count = 1; c.fields.push_back(f); }
+  c.height = 1; c.width = (uint32_t)n; c.point_step = kStep; c.row_step = kStep * (uint32_t)n; c.is_bigendian = 0; c.is_dense = 1;
+}
+void expand(const float *xyzi, size_t n, std::vector<uint8_t> &blob) {
+  blob.assign(n * kStep, 0);
+  const float one = 1.0f;
+  for (size_t i = 0; i < n; ++i) {
+    uint8_t *r = blob.data() + i * kStep;
+    std::memcpy(r, xyzi + 4 * i, 12); std::memcpy(r + 12, &one, 4); std::memcpy(r + kOffI, xyzi + 4 * i + 3, 4);
+  }
+}
+}  // namespace
+
+MovingObjectRemoval::MovingObjectRemoval(ros::NodeHandle, std::string config_path, int n_bad, int n_good) {
+  std::memset(&params_, 0, sizeof params_);
+  params_.opc_resolution = 0.1f;   // literal at the reference call site (.cpp:575)
+  params_.ground_method = 0;       // .cpp:526 is the active call
+  setVariables(config_path);
+  const char *dev = std::getenv("MOR_DEVICE"), *cap = std::getenv("MOR_MAX_POINTS");
+  int err = 0;
+  ctx_ = mor_create(&params_, n_bad, n_good, cap ? std::strtoull(cap, nullptr, 10) : (1ull << 20), dev ? std::atoi(dev) : 0, &err);
+  if (!ctx_) { std::cerr << "MovingObjectRemoval: mor_create failed (" << err << "): " << mor_last_error() << std::endl; std::exit(1); }
+}
+
+MovingObjectRemoval::~MovingObjectRemoval() { mor_destroy(ctx_); }
+
+// same file format and the same echo as the reference's setVariables (.cpp:698-864): `key:value`,
+// '#' comment lines and lines shorter than 3 characters skipped, every ':' dropped, no trimming;
+// unreadable file or unknown key ⇒ message on stdout and exit(0).
+void MovingObjectRemoval::setVariables(const std::string &path) {
+  std::ifstream in(path);
+  if (!in.is_open()) { std::cout << "Couldnt open the file\n"; std::exit(0); }
+  struct FKey { const char *name; float mor_params::*field; };
+  static const FKey fkeys[] = {
+      {"gp_limit", &mor_params::gp_limit}, {"gp_leaf", &mor_params::gp_leaf}, {"bin_gap", &mor_params::bin_gap},
+      {"volume_constraint", &mor_params::volume_constraint}, {"pde_lb", &mor_params::pde_lb}, {"pde_ub", &mor_params::pde_ub},
+      {"leave_off_distance", &mor_params::leave_off_distance}, {"catch_up_distance", &mor_params::catch_up_distance},
+      {"trim_x", &mor_params::trim_x}, {"trim_y", &mor_params::trim_y}, {"trim_z", &mor_params::trim_z},
+      {"ec_distance_threshold", &mor_params::ec_distance_threshold}, {"pde_distance_threshold", &mor_params::pde_distance_threshold}};
+  struct SKey { const char *name; std::string MovingObjectRemoval::*field; };
+  static const SKey skeys[] = {
+      {"output_topic", &MovingObjectRemoval::output_topic_}, {"debug_topic", &MovingObjectRemoval::debug_topic_},
+      {"marker_topic", &MovingObjectRemoval::marker_topic_}, {"input_pointcloud_topic", &MovingObjectRemoval::input_pointcloud_topic_},
+      {"input_odometry_topic", &MovingObjectRemoval::input_odometry_topic_}, {"output_fid", &MovingObjectRemoval::output_fid_},
+      {"debug_fid", &MovingObjectRemoval::debug_fid_}};
+  std::string line;
+  while (std::getline(in, line)) {
+    if (line.empty() || line[0] == '#' || line.length() < 3) continue;
+    std::string key, val; bool in_key = true;
+    for (char ch : line) { if (ch == ':') { in_key = false; continue; } (in_key ? key : val).push_back(ch); }
+    std::cout << key << ":";
+    bool known = false;
+    for (const FKey &k : fkeys) if (key == k.name) { params_.*(k.field) = std::stof(val); std::cout << params_.*(k.field); known = true; }
+    for (const SKey &k : skeys) if (key == k.name) { this->*(k.field) = val; std::cout << val; known = true; }
+    if (key == "min_cluster_size") { params_.min_cluster_size = std::stol(val); std::cout << params_.min_cluster_size; known = true; }
+    else if (key == "max_cluster_size") { params_.max_cluster_size = std::stol(val); std::cout << params_.max_cluster_size; known = true; }
+    else if (key == "method_choice") { params_.method_choice = std::stoi(val); std::cout << params_.method_choice; known = true; }
+    else if (key == "opc_normalization_factor") { params_.opc_normalization_factor = (int)std::stof(val); std::cout << params_.opc_normalization_factor; known = true; }   // stof into an int (.cpp:843)
+    else if (key == "ground_method") { params_.ground_method = std::stoi(val); std::cout << params_.ground_method; known = true; }   // extension key: 0 crop box, 1 voxel covariance
+    if (!known) { std::cout << "Invalid parameter found in config file\n"; std::exit(0); }
+    std::cout << std::endl;
+  }
+}
+
+void MovingObjectRemoval::pushRawCloudAndPose(pcl::PCLPointCloud2 &cloud, geometry_msgs::Pose pose) {
+  // fromPCLPointCloud2 (.cpp:523): fields matched by name; a missing intensity stays 0
+  uint32_t off[4] = {MOR_NO_FIELD, MOR_NO_FIELD, MOR_NO_FIELD, MOR_NO_FIELD};
+  for (const auto &f : cloud.fields) {
+    if (f.datatype != 7 /*FLOAT32*/) continue;
+    if (f.name == "x") off[0] = f.offset; else if (f.name == "y") off[1] = f.offset; else if (f.name == "z") off[2] = f.offset; else if (f.name == "intensity") off[3] = f.offset;
+  }
+  const uint64_t n = (uint64_t)cloud.width * cloud.height;
+  if (off[0] == MOR_NO_FIELD || off[1] == MOR_NO_FIELD || off[2] == MOR_NO_FIELD) { std::cerr << "MovingObjectRemoval: cloud has no float32 x/y/z fields" << std::endl; return; }
+  const double p[7] = {pose.position.x, pose.position.y, pose.position.z, pose.orientation.x, pose.orientation.y, pose.orientation.z, pose.orientation.w};
+  int rc = mor_push(ctx_, cloud.data.data(), n, cloud.point_step, off[0], off[1], off[2], off[3], p);
+  if (rc != MOR_OK) { std::cerr << "MovingObjectRemoval: mor_push failed (" << rc << "): " << mor_last_error() << std::endl; return; }
+  last_n_ = n; ++pushes_;
+#ifdef MOR_VISUALIZE
+  if (pushes_ >= 2) {   // inside `if(ca->init && cb->init)` (.cpp:534, :553-558)
+    mor_counts c; mor_get_counts(ctx_, 0, &c);
+    scratch_.resize(4 * (size_t)c.n_clustered + 4);
+    mor_get_cluster_collection(ctx_, 0, scratch_.data());
+    expand(scratch_.data(), c.n_clustered, cloud.data);
+    describe_xyzi<pcl::PCLPointCloud2, pcl::PCLPointField>(cloud, c.n_clustered);
+    output.data = cloud.data;
+    describe_xyzi<sensor_msgs::PointCloud2, sensor_msgs::PointField>(output, c.n_clustered);
+    output.header.frame_id = debug_fid_;
+  }
+#endif
+}
+
+bool MovingObjectRemoval::filterCloud(pcl::PCLPointCloud2 &out_cloud, std::string f_id) {
+  scratch_.resize(4 * (size_t)last_n_ + 4);
+  uint64_t n = 0;
+  int rc = mor_filter(ctx_, scratch_.data(), &n);
+  if (rc != MOR_OK) { std::cerr << "MovingObjectRemoval: mor_filter failed (" << rc << "): " << mor_last_error() << std::endl; return false; }
+  expand(scratch_.data(), n, out_cloud.data);   // toPCLPointCloud2 (.cpp:690)
+  describe_xyzi<pcl::PCLPointCloud2, pcl::PCLPointField>(out_cloud, n);
+  output.data = out_cloud.data;                 // pcl_conversions::fromPCL (.cpp:691)
+  describe_xyzi<sensor_msgs::PointCloud2, sensor_msgs::PointField>(output, n);
+  output.header.frame_id = f_id;                // .cpp:692
+  return true;
+}

@@ -1,0 +1,53 @@
+// mor_replay.cpp — ROS-free replay driver: the counterpart of the reference's demo node
+// src/external_sync_test.cpp:7-22 (callback: toPCL → pushRawCloudAndPose → filterCloud → publish).
+// Reads a sequence of clouds (KITTI-style .bin: packed float32 x,y,z,intensity) and poses
+// (text, one "x y z qx qy qz qw" line per frame), drives the drop-in class exactly as the demo node
+// does, and writes every filtered cloud (`output`) next to the input as packed xyzi float32.
+//   mor_replay <config.txt> <poses.txt> <out_dir> <cloud0.bin> <cloud1.bin> ...
+#include "MOR/MovingObjectRemoval.h"
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+static bool read_file(const std::string &path, std::vector<uint8_t> &out) {
+  std::ifstream f(path, std::ios::binary | std::ios::ate);
+  if (!f) return false;
+  std::streamsize n = f.tellg(); f.seekg(0);
+  out.resize((size_t)n);
+  return (bool)f.read((char *)out.data(), n);
+}
+
+int main(int argc, char **argv) {
+  if (argc < 5) { std::fprintf(stderr, "usage: %s <config> <poses.txt> <out_dir> <cloud.bin>...\n", argv[0]); return 2; }
+  ros::NodeHandle nh;
+  MovingObjectRemoval mor(nh, argv[1], 4, 3);   // n_bad = 4, n_good = 3 as in external_sync_test.cpp:37
+  std::ifstream poses(argv[2]);
+  const std::string out_dir = argv[3];
+  for (int i = 4; i < argc; ++i) {
+    pcl::PCLPointCloud2 cloud;   // what pcl_conversions::toPCL would hand over for a packed xyzi cloud
+    if (!read_file(argv[i], cloud.data)) { std::fprintf(stderr, "cannot read %s\n", argv[i]); return 1; }
+    const char *names[4] = {"x", "y", "z", "intensity"};
+    for (int k = 0; k < 4; ++k) { pcl::PCLPointField f; f.name = names[k]; f.offset = 4 * k; f.datatype = pcl::PCLPointField::FLOAT32; f.count = 1; cloud.fields.push_back(f); }
+    cloud.point_step = 16; cloud.width = (uint32_t)(cloud.data.size() / 16); cloud.height = 1; cloud.row_step = 16 * cloud.width; cloud.is_dense = 1;
+    geometry_msgs::Pose pose; std::string line;
+    if (!std::getline(poses, line)) { std::fprintf(stderr, "poses file too short\n"); return 1; }
+    std::istringstream ls(line);
+    ls >> pose.position.x >> pose.position.y >> pose.position.z >> pose.orientation.x >> pose.orientation.y >> pose.orientation.z >> pose.orientation.w;
+    auto t0 = std::chrono::steady_clock::now();
+    mor.pushRawCloudAndPose(cloud, pose);
+    bool ok = mor.filterCloud(cloud, "/filtered");
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (!ok) return 1;
+    // "publish": unpack the 32-byte PointXYZI records of `output` back to packed xyzi
+    const size_t n = mor.output.width;
+    std::vector<float> packed(4 * n);
+    for (size_t k = 0; k < n; ++k) { const uint8_t *r = mor.output.data.data() + k * mor.output.point_step; std::memcpy(&packed[4 * k], r, 12); std::memcpy(&packed[4 * k + 3], r + 16, 4); }
+    char name[64]; std::snprintf(name, sizeof name, "/filtered_%04d.bin", i - 4);
+    std::ofstream o(out_dir + name, std::ios::binary); o.write((const char *)packed.data(), packed.size() * sizeof(float));
+    std::cout << "frame " << (i - 4) << ": " << cloud.width << " pts in filtered cloud, frame_id " << mor.output.header.frame_id << ", " << ms << " ms" << std::endl;
+  }
+  return 0;
+}

@@ -1,0 +1,46 @@
+// MovingObjectRemoval.h — the reference's public class, backed by libmor_hip.so (MI355X / HIP).
+//
+// Drop-in for /root/reference/include/MOR/MovingObjectRemoval.h:96-168: same class name, same
+// constructor and method signatures, same public member `output`, same call protocol
+// (README.md:16-29, src/external_sync_test.cpp:14-17).  All geometry runs on the GPU through the C
+// ABI in include/mor_hip.h; this class only parses the config file, maps the PCLPointCloud2 blob
+// fields and re-expands the 16-byte device points into PCL's 32-byte PointXYZI records.
+#pragma once
+#include "MOR/IncludeAll.h"
+#include "mor_hip.h"
+
+class MovingObjectRemoval {
+ public:
+  sensor_msgs::PointCloud2 output;   // filtered cloud of the last filterCloud() (reference header :159)
+
+  // config_path: key:value file, grammar of setVariables (reference .cpp:698-864); n_bad / n_good as
+  // in the reference (:368).  Extra knobs come from the environment so the signature stays intact:
+  // MOR_DEVICE (HIP ordinal, default 0), MOR_MAX_POINTS (capacity per cloud, default 2^20).
+  MovingObjectRemoval(ros::NodeHandle nh, std::string config_path, int n_bad, int n_good);
+  ~MovingObjectRemoval();
+  MovingObjectRemoval(const MovingObjectRemoval &) = delete;
+  MovingObjectRemoval &operator=(const MovingObjectRemoval &) = delete;
+
+  // Input (reference :163 / .cpp:516-611).  Under MOR_VISUALIZE the caller's cloud and `output` are
+  // overwritten with the clustered points of the new frame from the second call on (:553-558).
+  void pushRawCloudAndPose(pcl::PCLPointCloud2 &cloud, geometry_msgs::Pose pose);
+
+  // Output (reference :166 / .cpp:613-696): `cloud` and `output` receive the latest cloud minus the
+  // tracked moving clusters, ground points appended; PointXYZI layout (x@0,y@4,z@8,intensity@16,
+  // point_step 32), width = n, height = 1, is_dense = true, output.header.frame_id = f_id.
+  // Returns true (the reference cannot fail); false only if the GPU call failed.
+  bool filterCloud(pcl::PCLPointCloud2 &cloud, std::string f_id);
+
+  // not in the reference: parameters as parsed (for tools/tests) and the last error text
+  const mor_params &params() const { return params_; }
+  const std::string &debug_fid() const { return debug_fid_; }
+  const std::string &output_fid() const { return output_fid_; }
+
+ private:
+  void setVariables(const std::string &config_file_path);
+  mor_params params_;
+  std::string output_topic_, debug_topic_, marker_topic_, input_pointcloud_topic_, input_odometry_topic_, output_fid_, debug_fid_;
+  mor_ctx *ctx_ = nullptr;
+  uint64_t pushes_ = 0, last_n_ = 0;
+  std::vector<float> scratch_;
+};

@@ -1,0 +1,59 @@
+"""The drop-in C++ class (include/MOR/MovingObjectRemoval.h + csrc/mor_adapter.cpp) driven by the
+ROS-free replay driver (csrc/mor_replay.cpp), the counterpart of the reference's
+src/external_sync_test.cpp callback."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from dynamicslamtool_amd.params import REF_DEFAULT_CONFIG
+from scenes import scene_params, small_stream
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPLAY = os.path.join(ROOT, "dynamicslamtool_amd", "csrc", "mor_replay")
+
+
+def _config_text(min_cluster_size=25, method=2):
+    return REF_DEFAULT_CONFIG.replace("min_cluster_size:200", "min_cluster_size:%d" % min_cluster_size).replace("method_choice:2", "method_choice:%d" % method)
+
+
+def test_config_errors_follow_the_reference(tmp_path):
+    """Unknown key / unreadable file: message on stdout and exit(0), before any GPU work
+    (reference .cpp:703-707, :856-860)."""
+    assert os.path.exists(REPLAY), "build first: python -m dynamicslamtool_amd.build"
+    bad = tmp_path / "bad.txt"
+    bad.write_text("trim_x:3.0\nnot_a_key:1\n")
+    r = subprocess.run([REPLAY, str(bad), "/dev/null", str(tmp_path), "/dev/null"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Invalid parameter found in config file" in r.stdout and "trim_x:3" in r.stdout
+    r = subprocess.run([REPLAY, str(tmp_path / "missing.txt"), "/dev/null", str(tmp_path), "/dev/null"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Couldnt open the file" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", [1, 2])
+def test_replay_matches_oracle(tmp_path, method):
+    from oracle.oracle import Oracle
+    cfg = tmp_path / "MOR_config.txt"
+    cfg.write_text(_config_text(method=method))
+    frames = small_stream(1, n_frames=8, with_nan=True)
+    files = []
+    with open(tmp_path / "poses.txt", "w") as pf:
+        for i, (pts, pose) in enumerate(frames):
+            fn = tmp_path / ("cloud_%04d.bin" % i)
+            pts.astype(np.float32).tofile(fn)
+            files.append(str(fn))
+            pf.write(" ".join(repr(float(v)) for v in pose) + "\n")
+    r = subprocess.run([REPLAY, str(cfg), str(tmp_path / "poses.txt"), str(tmp_path)] + files, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "method_choice:%d" % method in r.stdout   # the echo of setVariables
+    o = Oracle(scene_params(method_choice=method), 4, 3)
+    removed = 0
+    for i, (pts, pose) in enumerate(frames):
+        o.push(pts, pose)
+        want = o.filter()
+        got = np.fromfile(tmp_path / ("filtered_%04d.bin" % i), np.float32).reshape(-1, 4)
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), "frame %d" % i
+        removed = max(removed, int(o.counts().n_trim) - len(want))
+    if method == 2:
+        assert removed > 0

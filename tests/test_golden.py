@@ -1,0 +1,65 @@
+"""Committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py): the oracle
+must reproduce them on CPU; the HIP path must reproduce them on the GPU."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from scenes import scene_params
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+
+
+def _check(g, f, eng, s=None):
+    """eng: Oracle (s None) or MorBatch (s = stream)."""
+    a = (lambda name: getattr(eng, name)()) if s is None else (lambda name: getattr(eng, name)(s))
+    pre = "f%d_" % f
+    assert np.array_equal(a("labels"), g[pre + "labels"])
+    assert np.array_equal(a("ground_indices"), g[pre + "ground"])
+    off, idx = a("clusters")
+    assert np.array_equal(off, g[pre + "cl_off"]) and np.array_equal(idx, g[pre + "cl_idx"])
+    cen = a("centroids")
+    assert cen.shape == g[pre + "centroids"].shape
+    if len(cen):
+        assert np.max(np.abs(cen.astype(np.float64) - g[pre + "centroids"])) <= 1e-5
+    q, m, d, sc = a("correspondences")
+    assert np.array_equal(q, g[pre + "corr_q"]) and np.array_equal(m, g[pre + "corr_m"]) and np.array_equal(sc, g[pre + "score"])
+    assert np.array_equal(a("detection"), g[pre + "detection"])
+    xyz, conf, _ = a("tracks")
+    assert np.array_equal(conf, g[pre + "conf_push"])
+
+
+def test_fixtures_exist():
+    assert len(FIXTURES) >= 2
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
+def test_oracle_reproduces_golden(path):
+    from oracle.oracle import Oracle
+    g = np.load(path)
+    p = scene_params(method_choice=int(g["method"]), min_cluster_size=int(g["min_cluster_size"]))
+    o = Oracle(p, int(g["n_bad"]), int(g["n_good"]))
+    for f in range(int(g["n_frames"])):
+        o.push(g["f%d_pts" % f], g["f%d_pose" % f])
+        _check(g, f, o)
+        out = o.filter()
+        assert np.array_equal(out.view(np.uint32), g["f%d_out" % f].view(np.uint32))
+        assert np.array_equal(o.tracks()[1], g["f%d_conf_filter" % f])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
+def test_hip_reproduces_golden(path):
+    from dynamicslamtool_amd.engine import MorBatch
+    g = np.load(path)
+    p = scene_params(method_choice=int(g["method"]), min_cluster_size=int(g["min_cluster_size"]))
+    b = MorBatch(p, 1, 4096, int(g["n_bad"]), int(g["n_good"]))
+    for f in range(int(g["n_frames"])):
+        b.push([g["f%d_pts" % f]], g["f%d_pose" % f][None, :])
+        _check(g, f, b, 0)
+        out = b.filter()[0]
+        assert np.array_equal(out.view(np.uint32), g["f%d_out" % f].view(np.uint32))
+        assert np.array_equal(b.tracks(0)[1], g["f%d_conf_filter" % f])
+    b.close()
