@@ -13,12 +13,21 @@
 // Cell edge s = 0.57·r, so the cell diagonal is < r and ALL points of one cell are mutually within
 // the cluster tolerance: a cell is a clique, and Euclidean clustering reduces to connected
 // components over occupied CELLS (two cells are adjacent iff some point pair across them has
-// d² < r²; only cells ≤ 2 apart per axis can be).  Occupancy is a bitmap (x fastest, rows padded to
-// 32-bit words); the compact id of an occupied cell = number of set bits before it (word prefix +
-// popcount), which is also its position in the cell-sorted point array.
+// d² < r²; only cells ≤ 2 apart per axis can be).  Points are radix-sorted by cell key
+// ((z·ny + y)·nx + x); the occupied cells are the distinct keys `ckey` (ascending), an occupied
+// cell's compact id is its rank in `ckey`, and `row_start` (dense over the ny·nz rows) finds a
+// row's cells with two loads — so an x-run of cells is one contiguous range of the sorted points.
 struct MorGrid {
   float ox, oy, oz, inv_cs, cs;
-  int nx, ny, nz, wx, nwords;   // wx = words per x-row
+  int nx, ny, nz, nrows, keybits;
+};
+
+// one LSD radix pass (8-bit digit) of the stable (key, value) sort
+struct MorRadix {
+  const int *kin, *vin;   // [B][Nmax]; vin == nullptr ⇒ value = element index
+  int *kout, *vout;       // kout may be nullptr on a last pass that only needs the values
+  int shift, count_sel;   // digit = (key >> shift) & 255; element count: 0 → M, 1 → C
+  int drop_negative;      // elements with key < 0 are dropped (unclustered points)
 };
 
 struct MorStreamArgs {       // per stream, per push (host → device, one small copy)
@@ -30,11 +39,12 @@ struct MorStreamArgs {       // per stream, per push (host → device, one small
 struct MorFrameInfo {        // per stream, produced on device
   uint32_t N, T, M, G, K, C, n_pairs, flags;   // flags bit0: cluster capacity exceeded, bit1: voxel key overflow
   uint32_t Kprev, Cprev, n_keep, n_occ;   // n_occ: occupied grid cells
+  uint32_t n_defer, pad0, pad1, pad2;     // n_defer: method-1 queries handed to the wave tier
 };
 
 struct MorDev {
   // ---- static configuration
-  int B, Nmax, Kcap, tiles_max, radix_passes, Hcap;
+  int B, Nmax, Kcap, tiles_max, radix_passes, cell_passes, Hcap;
   float trim_x, trim_y, trim_z, gp_limit, r2;
   long long min_cs, max_cs;
   float pde_lb, pde_ub;
@@ -53,11 +63,12 @@ struct MorDev {
   int *cloud_tidx;           // [B][Nmax]  index of each cloud point in the trimmed cloud
   float4 *ground;            // [B][Nmax]  removed points in order (raw_cloud[gp_indices], :683)
   int *gp_idx;               // [B][Nmax]  gp_indices (:86)
-  int *cell_of;              // [B][Nmax]  linear cell position (word·32 + bit) per cloud point, then compact cell id
-  unsigned *bitmap;          // [B][nwords]  occupancy
-  int *wprefix;              // [B][nwords]  exclusive prefix of popcounts
-  int *ccount, *cstart, *cfill; // [B][Nmax+1]  points per occupied cell, exclusive offsets, fill cursor
-  int *ccoord;               // [B][Nmax]  packed (cx | cy<<12 | cz<<24 … see pack_cell) per occupied cell
+  int *pkey;                 // [B][Nmax]  linear cell key per cloud point
+  int *cell_of;              // [B][Nmax]  compact cell id per cloud point
+  int *skey, *sidx;          // aliases of the radix buffers holding the cell-sorted (key, cloud index)
+  int *ckey;                 // [B][Nmax]  distinct cell keys, ascending (n_occ of them)
+  int *cstart;               // [B][Nmax+1]  first sorted position of each occupied cell
+  int *row_start;            // [B][nrows+1]  first occupied cell of each (y,z) row
   int *cmin;                 // [B][Nmax]  smallest cloud index in the cell
   float4 *cbox_lo, *cbox_hi; // [B][Nmax]  bounding box of the cell's points
   float4 *sorted;            // [B][Nmax]  (x,y,z, bits(cloud index)) in cell order; .w becomes the cluster id after labelling
@@ -67,6 +78,7 @@ struct MorDev {
   int *compmin;              // [B][Nmax]  smallest cloud index of the component, at its root cell
   int *cid_of_root;          // [B][Nmax]  cluster id of a root cell (−1: not kept)
   int *pcid;                 // [B][Nmax]  cluster id (−1 none) per cloud point
+  int *ccid;                 // [B][Nmax]  cluster id per occupied cell (a cell is a clique ⇒ one cluster)
   int *ktile_cnt;            // [B][tiles_max]
   int *kcell, *kroot, *ksize; // [B][Kcap]  kept components: root cell, smallest cloud index, size
   int *csz;                  // [B][Kcap]  sizes in final cluster order
@@ -86,6 +98,7 @@ struct MorDev {
   float *pair_d;             // [B][Kcap]
   int *pair_cnt;             // [B][Kcap]
   int *pair_of_prev, *pair_of_cur; // [B][Kcap]
+  int *wl, *wl_n;            // [B][Nmax], [B]  method-1 tier-2 worklist (query ids) and its length
   unsigned long long *vox;   // [B][Hcap]
   unsigned char *det;        // [B][Kcap]  detection_results of cb
   // filter stage
@@ -106,9 +119,9 @@ struct MorDev {
 
 // kernel ids for optional per-kernel event timing
 enum MorKernelId {
-  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_WPREFIX, MK_CELLCOUNT, MK_CSTART, MK_FILL, MK_CELLBOX, MK_HOOK_NEAR, MK_HOOK_SHELL, MK_FLATTEN,
+  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_ROWTABLE, MK_CELLBOX, MK_HOOK_NEAR, MK_HOOK_SHELL, MK_FLATTEN,
   MK_SELECT_COUNT, MK_SELECT_SCAN, MK_SELECT_SCATTER, MK_RANK, MK_OFFSETS, MK_LABEL, MK_RHIST, MK_RSCAN, MK_RSCATTER,
-  MK_STATS, MK_XFORM_PREV, MK_NN, MK_PAIRS, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
+  MK_STATS, MK_XFORM_PREV, MK_NN, MK_PAIRS, MK_SCORE_FAST, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
   MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_COUNT
 };
 extern const char *const mor_kernel_names[MK_COUNT];

@@ -113,10 +113,11 @@ static int configure(mor_batch *b) {
   float cs = p.ec_distance_threshold * 0.57f;
   float zlo = p.gp_limit, zhi = std::max(p.trim_z, p.gp_limit);
   double nx = std::floor(2.0 * p.trim_x / cs) + 1, ny = std::floor(2.0 * p.trim_y / cs) + 1, nz = std::floor((double)(zhi - zlo) / cs) + 1;
-  if (nx > 2048 || ny > 2048 || nz > 1024)
-    return set_error(MOR_ERR_INVALID, "grid %gx%gx%g cells exceeds 2048x2048x1024: trim box too large for ec_distance_threshold %g", nx, ny, nz, (double)p.ec_distance_threshold);
-  d.g.nx = (int)nx; d.g.ny = (int)ny; d.g.nz = (int)nz; d.g.wx = (d.g.nx + 31) / 32;
-  d.g.nwords = d.g.wx * d.g.ny * d.g.nz;
+  if (nx > 2048 || ny > 2048 || nz > 1024 || nx * ny * nz >= 2147483648.0 || ny * nz > 1048576.0)
+    return set_error(MOR_ERR_INVALID, "grid %gx%gx%g cells too large: trim box too big for ec_distance_threshold %g", nx, ny, nz, (double)p.ec_distance_threshold);
+  d.g.nx = (int)nx; d.g.ny = (int)ny; d.g.nz = (int)nz; d.g.nrows = d.g.ny * d.g.nz;
+  d.g.keybits = 1; while ((1ll << d.g.keybits) < (long long)(nx * ny * nz)) ++d.g.keybits;
+  d.cell_passes = (d.g.keybits + 7) / 8;
   d.g.ox = -p.trim_x; d.g.oy = -p.trim_y; d.g.oz = zlo; d.g.cs = cs; d.g.inv_cs = 1.0f / cs;
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
   if (d.score_R > 60) return set_error(MOR_ERR_INVALID, "pde_ub %g needs a %d-cell search radius (> 60)", (double)p.pde_ub, d.score_R);
@@ -163,9 +164,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, dargs, B) && dalloc(b, d.info, B) && dalloc(b, d.tile_cnt, B * T * 2) && dalloc(b, d.tile_off, B * T * 2);
   b->d_args = dargs; d.args = dargs;
   ok = ok && dalloc(b, d.cloud, B * N) && dalloc(b, d.cloud_tidx, B * N) && dalloc(b, d.ground, B * N) && dalloc(b, d.gp_idx, B * N) && dalloc(b, d.cell_of, B * N);
-  ok = ok && dalloc(b, d.bitmap, B * (size_t)d.g.nwords) && dalloc(b, d.wprefix, B * (size_t)d.g.nwords);
-  ok = ok && dalloc(b, d.ccount, B * (N + 1)) && dalloc(b, d.cstart, B * (N + 1)) && dalloc(b, d.cfill, B * (N + 1)) && dalloc(b, d.ccoord, B * N) && dalloc(b, d.cmin, B * N) && dalloc(b, d.cbox_lo, B * N) && dalloc(b, d.cbox_hi, B * N);
-  ok = ok && dalloc(b, d.sorted, B * N) && dalloc(b, d.parent, B * N) && dalloc(b, d.croot, B * N) && dalloc(b, d.csize, B * N) && dalloc(b, d.compmin, B * N) && dalloc(b, d.cid_of_root, B * N) && dalloc(b, d.pcid, B * N);
+  ok = ok && dalloc(b, d.pkey, B * N) && dalloc(b, d.ckey, B * N) && dalloc(b, d.cstart, B * (N + 1)) && dalloc(b, d.row_start, B * ((size_t)d.g.nrows + 1)) && dalloc(b, d.cmin, B * N) && dalloc(b, d.cbox_lo, B * N) && dalloc(b, d.cbox_hi, B * N);
+  ok = ok && dalloc(b, d.sorted, B * N) && dalloc(b, d.parent, B * N) && dalloc(b, d.croot, B * N) && dalloc(b, d.csize, B * N) && dalloc(b, d.compmin, B * N) && dalloc(b, d.cid_of_root, B * N) && dalloc(b, d.pcid, B * N) && dalloc(b, d.ccid, B * N);
   ok = ok && dalloc(b, d.ktile_cnt, B * T) && dalloc(b, d.kcell, B * K) && dalloc(b, d.kroot, B * K) && dalloc(b, d.ksize, B * K) && dalloc(b, d.csz, B * K);
   {  // method-1 search stencil: (dy,dz) rows ordered by their distance lower bound, then by centre distance
     const int R = d.score_R, side = 2 * R + 1;
@@ -184,11 +184,13 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   }
   for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, d.rkeys[i], B * N) && dalloc(b, d.rvals[i], B * N);
   ok = ok && dalloc(b, d.rhist, B * T * 256) && dalloc(b, d.cl_idx, B * N);
+  d.skey = d.rkeys[d.cell_passes & 1]; d.sidx = d.rvals[d.cell_passes & 1];
   for (int i = 0; i < 2; ++i)
     ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K);
   ok = ok && dalloc(b, d.nn_fwd, B * K) && dalloc(b, d.nn_bwd, B * K) && dalloc(b, d.nn_fwd_d, B * K) && dalloc(b, d.pair_q, B * K) && dalloc(b, d.pair_m, B * K) && dalloc(b, d.pair_d, B * K);
   ok = ok && dalloc(b, d.pair_cnt, B * K) && dalloc(b, d.pair_of_prev, B * K) && dalloc(b, d.pair_of_cur, B * K) && dalloc(b, d.det, B * K);
   if (p->method_choice == 2) ok = ok && dalloc(b, d.vox, B * (size_t)d.Hcap);
+  ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_n, B);
   ok = ok && dalloc(b, b->d_moving, B * K + B) && dalloc(b, d.otile_cnt, B * T) && dalloc(b, d.out, B * N) && dalloc(b, b->d_outptrs, B);
   d.moving = b->d_moving;
   ok = ok && halloc(b, b->h_args, B) && halloc(b, b->h_moving, B * K + B) && halloc(b, b->h_outptrs, B);
@@ -368,6 +370,13 @@ int mor_get_tracks(const mor_batch *b, int s, float *xyz, int32_t *conf, int32_t
 int mor_get_cluster_collection(const mor_batch *b, int s, float *out) {
   CHECK_STREAM();
   if (f.C) HIP_TRY(hipMemcpy(out, d.cl_pts[d.cur] + so, f.C * sizeof(float4), hipMemcpyDeviceToHost));
+  return MOR_OK;
+}
+
+int mor_get_stage_counts(const mor_batch *b, int s, uint32_t *out, int n) {
+  CHECK_STREAM();
+  const uint32_t v[4] = {f.n_occ, f.n_defer, f.Kprev, f.Cprev};
+  for (int i = 0; i < n && i < 4; ++i) out[i] = v[i];
   return MOR_OK;
 }
 

@@ -26,9 +26,9 @@
 #include <cstdlib>
 
 const char *const mor_kernel_names[MK_COUNT] = {
-    "classify", "scan_tiles", "scatter", "wprefix", "cellcount", "cstart", "fill", "cellbox", "hook_near", "hook_shell", "flatten",
+    "classify", "scan_tiles", "scatter", "heads_count", "heads_scan", "heads_scatter", "rowtable", "cellbox", "hook_near", "hook_shell", "flatten",
     "select_count", "select_scan", "select_scatter", "rank", "offsets", "label", "rhist", "rscan", "rscatter",
-    "stats", "xform_prev", "nn_centroid", "pairs", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
+    "stats", "xform_prev", "nn_centroid", "pairs", "score_fast", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
     "out_count", "out_scan", "out_scatter"};
 
 // ------------------------------------------------------------------------------------ helpers
@@ -96,20 +96,32 @@ __device__ __forceinline__ int cell_axis(float v, float o, float inv, int n) {
   return c < 0 ? 0 : (c >= n ? n - 1 : c);
 }
 __device__ __forceinline__ int cell_axis_unclamped(float v, float o, float inv) { return (int)floorf((v - o) * inv); }
-__device__ __forceinline__ int pack_cell(int cx, int cy, int cz) { return cx | (cy << 11) | (cz << 22); }   // nx,ny ≤ 2048, nz ≤ 1024
-// compact id of cell (cx,cy,cz) or −1 when empty / outside
-__device__ __forceinline__ int cell_lookup(const MorGrid &g, const unsigned *bm, const int *wp, int cx, int cy, int cz) {
-  if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cy >= (unsigned)g.ny || (unsigned)cz >= (unsigned)g.nz) return -1;
-  int w = (cz * g.ny + cy) * g.wx + (cx >> 5);
-  unsigned bits = bm[w], bit = 1u << (cx & 31);
-  return (bits & bit) ? wp[w] + __popc(bits & (bit - 1)) : -1;
-}
 // occupied cells with x in [x0,x1] of row (cy,cz) have the consecutive compact ids [lo, hi)
-__device__ __forceinline__ void row_cells(const MorGrid &g, const unsigned *bm, const int *wp, int x0, int x1, int cy, int cz, int &lo, int &hi) {
-  int rw = (cz * g.ny + cy) * g.wx, w0 = rw + (x0 >> 5), w1 = rw + (x1 >> 5);
-  lo = wp[w0] + __popc(bm[w0] & ((1u << (x0 & 31)) - 1u));
-  unsigned m1 = ((x1 & 31) == 31) ? 0xFFFFFFFFu : ((2u << (x1 & 31)) - 1u);
-  hi = wp[w1] + __popc(bm[w1] & m1);
+__device__ __forceinline__ void row_cells(const MorGrid &g, const int *ckey, const int *rs, int x0, int x1, int cy, int cz, int &lo, int &hi) {
+  const int r = cz * g.ny + cy, e = rs[r + 1], base = r * g.nx;
+  lo = rs[r];
+  if (e - lo > 8) {   // long row (a wall along x): binary search
+    int a = lo, b = e, k0 = base + x0;
+    while (a < b) { int m = (a + b) >> 1; if (ckey[m] < k0) a = m + 1; else b = m; }
+    lo = a; b = e; int k1 = base + x1;
+    while (a < b) { int m = (a + b) >> 1; if (ckey[m] <= k1) a = m + 1; else b = m; }
+    hi = a;
+    return;
+  }
+  // short row: fetch up to 8 keys with independent loads (one memory latency, not a chain of them)
+  const int n = e - lo, k0 = base + x0, k1 = base + x1;
+  int below = 0, within = 0;
+  if (n > 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { int k = ckey[lo + min(i, n - 1)]; bool v = i < n; below += v && k < k0; within += v && k >= k0 && k <= k1; }
+  }
+  lo += below; hi = lo + within;
+}
+// compact id of cell (cx,cy,cz) or −1 when empty / outside
+__device__ __forceinline__ int cell_lookup(const MorGrid &g, const int *ckey, const int *rs, int cx, int cy, int cz) {
+  if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cy >= (unsigned)g.ny || (unsigned)cz >= (unsigned)g.nz) return -1;
+  int lo, hi; row_cells(g, ckey, rs, cx, cx, cy, cz, lo, hi);
+  return lo < hi ? lo : -1;
 }
 
 // L2_Simple: ((dx·dx)+(dy·dy))+(dz·dz), each operation rounded (no contraction)
@@ -186,21 +198,15 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   int r_ng = to[0], r_g = to[1];
   for (int w = 0; w < wave_id(); ++w) { r_ng += sh[w]; r_g += sh[4 + w]; }
   const size_t so = (size_t)s * d.Nmax;
-  unsigned *bm = d.bitmap + (size_t)s * d.g.nwords;
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     int k_ng = r_ng + __popcll(m_ng[it] & lanemask_lt());
     int k_g = r_g + __popcll(m_g[it] & lanemask_lt());
     if (cls[it] == 2) {
       int cx = cell_axis(p[it].x, d.g.ox, d.g.inv_cs, d.g.nx), cy = cell_axis(p[it].y, d.g.oy, d.g.inv_cs, d.g.ny), cz = cell_axis(p[it].z, d.g.oz, d.g.inv_cs, d.g.nz);
-      int pos = ((cz * d.g.ny + cy) * d.g.wx) * 32 + cx;
-      atomicOr(&bm[pos >> 5], 1u << (pos & 31));
       d.cloud[so + k_ng] = p[it];
       d.cloud_tidx[so + k_ng] = k_ng + k_g;   // index in the trimmed cloud (both ranks are exclusive counts of earlier kept points)
-      d.cell_of[so + k_ng] = pos;
-      // per-cell / per-component state lives in arrays indexed by compact cell id < n_occ ≤ M: initialise slot k_ng
-      d.ccount[so + k_ng] = 0; d.cfill[so + k_ng] = 0; d.cmin[so + k_ng] = 0x7fffffff;
-      d.parent[so + k_ng] = k_ng; d.csize[so + k_ng] = 0; d.compmin[so + k_ng] = 0x7fffffff; d.cid_of_root[so + k_ng] = -1;
+      d.pkey[so + k_ng] = (cz * d.g.ny + cy) * d.g.nx + cx;
     } else if (cls[it] == 1) {
       d.ground[so + k_g] = p[it];
       d.gp_idx[so + k_g] = k_ng + k_g;
@@ -209,64 +215,74 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   }
 }
 
-// ------------------------------------------------------------------------------------ grid: bitmap rank, counting sort by cell
-// one workgroup per stream: exclusive prefix of the bitmap popcounts; publishes n_occ
-__global__ __launch_bounds__(MOR_BT) void k_wprefix(MorDev d) {
+// ------------------------------------------------------------------------------------ grid: distinct cells of the key-sorted points
+// (the sort itself is the generic radix below: k_rhist / k_rscan / k_rscatter)
+__device__ __forceinline__ bool is_head(const int *skey, int p) { return p == 0 || skey[p] != skey[p - 1]; }
+__global__ __launch_bounds__(MOR_BT) void k_heads_count(MorDev d) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  int M = d.info[s].M, base = t * MOR_TILE, c = 0;
+  const int *skey = d.skey + (size_t)s * d.Nmax;
+  for (int p = base + threadIdx.x; p < min(base + MOR_TILE, M); p += MOR_BT) c += is_head(skey, p);
+  __shared__ int sh[8]; int tot;
+  block_excl_scan(c, sh, &tot);
+  if (threadIdx.x == 0) d.ktile_cnt[(size_t)s * d.tiles_max + t] = tot;
+}
+__global__ __launch_bounds__(MOR_BT) void k_heads_scan(MorDev d) {
   int s = blockIdx.x; __shared__ int sh[8]; int carry = 0;
-  const unsigned *bm = d.bitmap + (size_t)s * d.g.nwords; int *wp = d.wprefix + (size_t)s * d.g.nwords;
-  for (int b = 0; b < d.g.nwords; b += MOR_BT) {
-    int w = b + threadIdx.x, v = w < d.g.nwords ? __popc(bm[w]) : 0, tot;
+  int *c = d.ktile_cnt + (size_t)s * d.tiles_max;
+  for (int b = 0; b < d.tiles; b += MOR_BT) {
+    int t = b + threadIdx.x, v = t < d.tiles ? c[t] : 0, tot;
     int e = block_excl_scan(v, sh, &tot);
-    if (w < d.g.nwords) wp[w] = carry + e;
+    if (t < d.tiles) c[t] = carry + e;
     carry += tot;
   }
-  if (threadIdx.x == 0) d.info[s].n_occ = carry;
+  if (threadIdx.x == 0) { d.info[s].n_occ = carry; d.cstart[(size_t)s * (d.Nmax + 1) + carry] = d.info[s].M; }
 }
-// per cloud point: compact cell id; per cell: point count, smallest cloud index, coordinates
-__global__ __launch_bounds__(MOR_BT) void k_cellcount(MorDev d) {
+// per sorted position: compact cell id; heads publish the cell; every point lands in `sorted`
+__global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
   int s, t; map_block(d.B, d.tiles, s, t);
-  int M = d.info[s].M, base = t * MOR_TILE;
-  if (base >= M) return;
+  int M = d.info[s].M, tb = t * MOR_TILE;
+  if (tb >= M) return;
   const size_t so = (size_t)s * d.Nmax;
-  const unsigned *bm = d.bitmap + (size_t)s * d.g.nwords; const int *wp = d.wprefix + (size_t)s * d.g.nwords;
-  const int rowbits = d.g.wx * 32;
-  for (int i = base + threadIdx.x; i < min(base + MOR_TILE, M); i += MOR_BT) {
-    int pos = d.cell_of[so + i], w = pos >> 5;
-    int c = wp[w] + __popc(bm[w] & ((1u << (pos & 31)) - 1u));
-    d.cell_of[so + i] = c;
-    atomicAdd(&d.ccount[so + c], 1);
-    atomicMin(&d.cmin[so + c], i);
-    int row = pos / rowbits;
-    d.ccoord[so + c] = pack_cell(pos - row * rowbits, row % d.g.ny, row / d.g.ny);   // same value from every point of the cell
+  const int *skey = d.skey + so, *sidx = d.sidx + so;
+  int *cstart = d.cstart + (size_t)s * (d.Nmax + 1);
+  const int base = tb + wave_id() * 512;
+  unsigned long long mh[8]; int cnt = 0;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) { int p = base + it * 64 + lane_id(); mh[it] = __ballot(p < M && is_head(skey, p)); cnt += __popcll(mh[it]); }
+  __shared__ int sh[4];
+  if (lane_id() == 0) sh[wave_id()] = cnt;
+  __syncthreads();
+  int r = d.ktile_cnt[(size_t)s * d.tiles_max + t];
+  for (int w = 0; w < wave_id(); ++w) r += sh[w];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    int p = base + it * 64 + lane_id();
+    if (p < M) {
+      bool head = (mh[it] >> lane_id()) & 1ull;
+      int c = r + __popcll(mh[it] & lanemask_lt()) + (head ? 1 : 0) - 1;
+      int i = sidx[p];
+      if (head) {
+        d.ckey[so + c] = skey[p]; cstart[c] = p; d.cmin[so + c] = i;   // stable sort ⇒ first of the cell = smallest cloud index
+        d.parent[so + c] = c; d.csize[so + c] = 0; d.compmin[so + c] = 0x7fffffff; d.cid_of_root[so + c] = -1;
+      }
+      d.cell_of[so + i] = c;
+      float4 q = d.cloud[so + i]; q.w = __int_as_float(i);
+      d.sorted[so + p] = q;
+    }
+    r += __popcll(mh[it]);
   }
 }
-// one workgroup per stream: exclusive scan of the per-cell counts
-__global__ __launch_bounds__(MOR_BT) void k_cstart(MorDev d) {
-  int s = blockIdx.x, nocc = d.info[s].n_occ; __shared__ int sh[8]; int carry = 0;
-  const size_t so = (size_t)s * d.Nmax;
-  const int *cnt = d.ccount + so; int *st = d.cstart + (size_t)s * (d.Nmax + 1);
-  for (int b = 0; b < nocc; b += MOR_BT) {
-    int c = b + threadIdx.x, v = c < nocc ? cnt[c] : 0, tot;
-    int e = block_excl_scan(v, sh, &tot);
-    if (c < nocc) st[c] = carry + e;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) st[nocc] = carry;
-}
-// counting-sort scatter: sorted[slot] = (x,y,z,bits(cloud index)); order inside a cell is arbitrary
-// (nothing downstream depends on it: components are keyed by min indices, NN results are minima)
-__global__ __launch_bounds__(MOR_BT) void k_fill(MorDev d) {
-  int s, t; map_block(d.B, d.tiles, s, t);
-  int M = d.info[s].M, base = t * MOR_TILE;
-  if (base >= M) return;
-  const size_t so = (size_t)s * d.Nmax;
-  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
-  for (int i = base + threadIdx.x; i < min(base + MOR_TILE, M); i += MOR_BT) {
-    int c = d.cell_of[so + i];
-    int slot = st[c] + atomicAdd(&d.cfill[so + c], 1);
-    float4 p = d.cloud[so + i];
-    p.w = __int_as_float(i);
-    d.sorted[so + slot] = p;
+// dense (y,z) row table: first occupied cell with key ≥ row·nx
+__global__ __launch_bounds__(MOR_BT) void k_rowtable(MorDev d) {
+  int s = blockIdx.y, nocc = d.info[s].n_occ;
+  const int *ckey = d.ckey + (size_t)s * d.Nmax;
+  int *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
+  for (int r = blockIdx.x * MOR_BT + threadIdx.x; r <= d.g.nrows; r += gridDim.x * MOR_BT) {
+    int a = 0, b = nocc; const int k = r * d.g.nx;
+    if (r == d.g.nrows) a = nocc;
+    else while (a < b) { int m = (a + b) >> 1; if (ckey[m] < k) a = m + 1; else b = m; }
+    rs[r] = a;
   }
 }
 
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(MOR_BT) void k_hook_cells(MorDev d, int shell) {
   int s = blockIdx.y, nocc = d.info[s].n_occ;
   const int wv = blockIdx.x * (MOR_BT / 64) + wave_id(), nw = gridDim.x * (MOR_BT / 64), lane = lane_id();
   const size_t so = (size_t)s * d.Nmax;
-  const unsigned *bm = d.bitmap + (size_t)s * d.g.nwords; const int *wp = d.wprefix + (size_t)s * d.g.nwords;
+  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
   int *P = d.parent + so;
@@ -332,8 +348,8 @@ __global__ __launch_bounds__(MOR_BT) void k_hook_cells(MorDev d, int shell) {
   else { int idx = 63 + lane; dx = idx % 5 - 2; dy = (idx / 5) % 5 - 2; dz = idx / 25 - 2; lane_ok = lane < 62 && (abs(dx) == 2 || abs(dy) == 2 || abs(dz) == 2); }
   const float r2 = d.r2;
   for (int a = wv; a < nocc; a += nw) {
-    int cc = d.ccoord[so + a];
-    int nb = lane_ok ? cell_lookup(d.g, bm, wp, (cc & 2047) + dx, ((cc >> 11) & 2047) + dy, (cc >> 22) + dz) : -1;
+    const int ka = ckey[a], rowa = ka / d.g.nx;
+    int nb = lane_ok ? cell_lookup(d.g, ckey, rs, ka - rowa * d.g.nx + dx, rowa % d.g.ny + dy, rowa / d.g.ny + dz) : -1;
     if (!__ballot(nb >= 0)) continue;
     int ra = uf_find(P, a);
     const int a0 = st[a], na = st[a + 1] - a0;
@@ -383,7 +399,7 @@ __global__ __launch_bounds__(MOR_BT) void k_flatten(MorDev d) {
     int r = c, p = d.parent[so + r];
     while (p != r) { r = p; p = d.parent[so + r]; }
     d.croot[so + c] = r;
-    atomicAdd(&d.csize[so + r], d.ccount[so + c]);
+    atomicAdd(&d.csize[so + r], d.cstart[(size_t)s * (d.Nmax + 1) + c + 1] - d.cstart[(size_t)s * (d.Nmax + 1) + c]);
     atomicMin(&d.compmin[so + r], d.cmin[so + c]);
   }
 }
@@ -481,30 +497,31 @@ __global__ __launch_bounds__(MOR_BT) void k_label(MorDev d) {
     q.w = __int_as_float(cid);
     d.sorted[so + js] = q;
     d.pcid[so + i] = cid;
+    const int c = d.cell_of[so + i];
+    if (d.cstart[(size_t)s * (d.Nmax + 1) + c] == js) d.ccid[so + c] = cid;   // one cluster per cell (clique)
   }
 }
 
-// ------------------------------------------------------------------------------------ stable partition of cloud indices by cluster id (LSD radix, 8-bit digits)
-// pass 0 reads (pcid = cluster id per cloud point, value = index) and drops unclustered points
-__device__ __forceinline__ void radix_item(const MorDev &d, int pass, size_t so, int count, int i, int &key, int &val, bool &valid) {
-  valid = i < count;
-  key = 0; val = 0;
+// ------------------------------------------------------------------------------------ stable LSD radix sort, 8-bit digits, batched over streams
+// used twice per frame: points by cell key (grid build) and clustered points by cluster id (C2).
+__device__ __forceinline__ void radix_item(const MorRadix &j, size_t so, int count, int i, int &key, int &val, bool &valid) {
+  valid = i < count; key = 0; val = 0;
   if (!valid) return;
-  if (pass == 0) { key = d.pcid[so + i]; val = i; valid = key >= 0; }
-  else { key = d.rkeys[pass & 1][so + i]; val = d.rvals[pass & 1][so + i]; }
+  key = j.kin[so + i]; val = j.vin ? j.vin[so + i] : i;
+  if (j.drop_negative) valid = key >= 0;
 }
-__device__ __forceinline__ int radix_count(const MorDev &d, int pass, int s) { return pass == 0 ? d.info[s].M : d.info[s].C; }
+__device__ __forceinline__ int radix_count(const MorDev &d, const MorRadix &j, int s) { return j.count_sel == 0 ? d.info[s].M : d.info[s].C; }
 
-__global__ __launch_bounds__(MOR_BT) void k_rhist(MorDev d, int pass) {
+__global__ __launch_bounds__(MOR_BT) void k_rhist(MorDev d, MorRadix j) {
   int s, t; map_block(d.B, d.tiles, s, t);
-  int count = radix_count(d, pass, s), base = t * MOR_TILE;
+  int count = radix_count(d, j, s), base = t * MOR_TILE;
   __shared__ int h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
   const size_t so = (size_t)s * d.Nmax;
   for (int i = base + threadIdx.x; i < min(base + MOR_TILE, count); i += MOR_BT) {
-    int key, val; bool valid; radix_item(d, pass, so, count, i, key, val, valid);
-    if (valid) atomicAdd(&h[(key >> (8 * pass)) & 255], 1);
+    int key, val; bool valid; radix_item(j, so, count, i, key, val, valid);
+    if (valid) atomicAdd(&h[(key >> j.shift) & 255], 1);
   }
   __syncthreads();
   d.rhist[((size_t)s * d.tiles_max + t) * 256 + threadIdx.x] = h[threadIdx.x];
@@ -518,9 +535,9 @@ __global__ __launch_bounds__(MOR_BT) void k_rscan(MorDev d) {
   int tot, base = block_excl_scan(run, sh, &tot);
   for (int t = 0; t < d.tiles; ++t) h[t * 256 + threadIdx.x] += base;
 }
-__global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, int pass, int last) {
+__global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, MorRadix j) {
   int s, t; map_block(d.B, d.tiles, s, t);
-  int count = radix_count(d, pass, s), tb = t * MOR_TILE;
+  int count = radix_count(d, j, s), tb = t * MOR_TILE;
   if (tb >= count) return;
   const size_t so = (size_t)s * d.Nmax;
   __shared__ int wcnt[4][256];
@@ -531,8 +548,8 @@ __global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, int pass, int las
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     int i = base + it * 64 + lane_id();
-    radix_item(d, pass, so, count, i, key[it], val[it], valid[it]);
-    int dg = (key[it] >> (8 * pass)) & 255;
+    radix_item(j, so, count, i, key[it], val[it], valid[it]);
+    int dg = (key[it] >> j.shift) & 255;
     unsigned long long peers = __ballot(valid[it]);
 #pragma unroll
     for (int b = 0; b < 8; ++b) { unsigned long long m = __ballot((dg >> b) & 1); peers &= ((dg >> b) & 1) ? m : ~m; }
@@ -554,10 +571,10 @@ __global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, int pass, int las
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     if (!valid[it]) continue;
-    int dg = (key[it] >> (8 * pass)) & 255;
+    int dg = (key[it] >> j.shift) & 255;
     int pos = wcnt[wave_id()][dg] + pre[it];
-    if (last) d.cl_idx[so + pos] = val[it];
-    else { d.rkeys[(pass + 1) & 1][so + pos] = key[it]; d.rvals[(pass + 1) & 1][so + pos] = val[it]; }
+    if (j.kout) j.kout[so + pos] = key[it];
+    j.vout[so + pos] = val[it];
   }
 }
 
@@ -694,7 +711,7 @@ __global__ __launch_bounds__(MOR_BT) void k_pairs(MorDev d) {
     }
     carry += tot;
   }
-  if (threadIdx.x == 0) d.info[s].n_pairs = carry;
+  if (threadIdx.x == 0) { d.info[s].n_pairs = carry; d.wl_n[s] = 0; }
 }
 
 // ------------------------------------------------------------------------------------ P3: method 1 (:336-366)
@@ -705,75 +722,174 @@ __global__ __launch_bounds__(MOR_BT) void k_pairs(MorDev d) {
 // nearest-first (row_order): a row whose lower bound is ≥ min(best, ub) ends the search (a
 // neighbour at d² ≥ ub can never be counted), and so does any candidate with d² ≤ lb (the minimum
 // can only get smaller ⇒ never counted).
+// Tier 1 — one THREAD per query, the 9 rows of cells around it (row_order[0..8], lower bound 0).
+// Static surfaces end here: either some matched point lies within √lb (never counted), or the
+// nearest one is closer than one cell edge, which already beats every farther row (bound ≥ cs²).
+// Anything else goes to the worklist of tier 2 (k_score_pde, one wave per query).
+// All points of a cell belong to one component (the cell is a clique), so the cluster id is a
+// per-CELL attribute (ccid): candidates are filtered cell by cell without touching their points,
+// and a cell's point box gives a lower bound that prunes it against the best distance so far.
+__device__ __forceinline__ float box_dist2(const float4 &q, const float4 &lo, const float4 &hi) {
+  float gx = fmaxf(fmaxf(lo.x - q.x, q.x - hi.x), 0.f), gy = fmaxf(fmaxf(lo.y - q.y, q.y - hi.y), 0.f), gz = fmaxf(fmaxf(lo.z - q.z, q.z - hi.z), 0.f);
+  return (gx * gx + gy * gy + gz * gz) * 0.999f;   // conservative
+}
+// scan sorted positions [b,e) (one cell of the matched cluster), four independent loads at a time; stops at d² ≤ lb
+__device__ __forceinline__ void scan4(const float4 *sp, int b, int e, const float4 &q, float lbv, float &best, int &budget) {
+  for (int k = b; k < e && budget > 0; k += 4, budget -= 4) {
+    float4 p0 = sp[k], p1 = sp[min(k + 1, e - 1)], p2 = sp[min(k + 2, e - 1)], p3 = sp[min(k + 3, e - 1)];
+    best = fminf(best, sqdist(q.x, q.y, q.z, p0.x, p0.y, p0.z));
+    best = fminf(best, sqdist(q.x, q.y, q.z, p1.x, p1.y, p1.z));
+    best = fminf(best, sqdist(q.x, q.y, q.z, p2.x, p2.y, p2.z));
+    best = fminf(best, sqdist(q.x, q.y, q.z, p3.x, p3.y, p3.z));
+    if (best <= lbv) return;
+  }
+}
+// the matched cells among compact ids [lo,hi): nearest box first, then the rest that can still improve `best`
+__device__ __forceinline__ void scan_cells(const MorDev &d, size_t so, const int *st, const float4 *sp, int lo, int hi, int target, const float4 &q, float &best, int &budget) {
+  int cfirst = -1; float bfirst = INFINITY;
+  for (int c = lo; c < hi; ++c) {
+    if (d.ccid[so + c] != target) continue;
+    float bd = box_dist2(q, d.cbox_lo[so + c], d.cbox_hi[so + c]);
+    if (bd < bfirst) { bfirst = bd; cfirst = c; }
+  }
+  if (cfirst < 0 || bfirst >= fminf(best, d.pde_ub)) return;
+  scan4(sp, st[cfirst], st[cfirst + 1], q, d.pde_lb, best, budget);
+  for (int c = lo; c < hi && best > d.pde_lb && budget > 0; ++c) {
+    if (c == cfirst || d.ccid[so + c] != target) continue;
+    if (box_dist2(q, d.cbox_lo[so + c], d.cbox_hi[so + c]) >= fminf(best, d.pde_ub)) continue;
+    scan4(sp, st[c], st[c + 1], q, d.pde_lb, best, budget);
+  }
+}
+
+// Tier 1 — one THREAD per query: its own cell, then the 9 rows of cells around it (row_order[0..8],
+// lower bound 0).  Static surfaces end here: either some matched point lies within √lb (never
+// counted), or the nearest one is closer than one cell edge, which already beats every farther row
+// (bound ≥ cs²).  Anything else — or a thread that has scanned its budget — goes to the worklist of
+// tier 2 (k_score_pde, one wave per query).
+__global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
+  int s, t; map_block(d.B, d.tiles * 8, s, t);
+  int pv = d.cur ^ 1, Cp = d.info[s].Cprev, base = t * MOR_BT;
+  if (base >= Cp) return;
+  const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
+  const float4 *sp = d.sorted + so;
+  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
+  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  const int R = d.score_R;
+  const float cs = d.g.cs * 0.999f, ring2 = cs * cs;   // lower bound of every row beyond the first 9
+  const int j = base + threadIdx.x;
+  bool defer = false;
+  if (j < Cp) {
+    int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
+    if (pr >= 0) {
+      const int target = d.pair_m[ko + pr];
+      const float4 q = d.cl_pts[pv][so + j];
+      const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.g.oz, d.g.inv_cs);
+      float best = INFINITY; int budget = 256;   // points this thread may scan before handing the query to a wave
+      {  // stage 0: the query's own cell — on a static surface a matched point within √lb is almost always here
+        int c = cell_lookup(d.g, ckey, rs, cx, cy, cz);
+        if (c >= 0 && d.ccid[so + c] == target) scan4(sp, st[c], st[c + 1], q, d.pde_lb, best, budget);
+      }
+      for (int ro = 0; ro < 9 && best > d.pde_lb && budget > 0; ++ro) {
+        int y = cy + d.row_order[2 * ro], z = cz + d.row_order[2 * ro + 1];
+        if ((unsigned)y >= (unsigned)d.g.ny || (unsigned)z >= (unsigned)d.g.nz) continue;
+        int rx = min(R, (int)(sqrtf(fminf(best, d.pde_ub)) * d.g.inv_cs * 1.001f) + 1);
+        int x0 = max(cx - rx, 0), x1 = min(cx + rx, d.g.nx - 1);
+        if (x0 > x1) continue;
+        int lo, hi; row_cells(d.g, ckey, rs, x0, x1, y, z, lo, hi);
+        if (lo < hi) scan_cells(d, so, st, sp, lo, hi, target, q, best, budget);
+      }
+      if (best > d.pde_lb) {
+        if (budget <= 0) defer = true;
+        else if (ring2 >= fminf(best, d.pde_ub) || d.n_rows <= 9) { if (best < d.pde_ub) atomicAdd(&d.pair_cnt[ko + pr], 1); }
+        else defer = true;
+      }
+    }
+  }
+  unsigned long long m = __ballot(defer);
+  if (m) {   // wave-aggregated push
+    int basew = 0, leader = __ffsll((long long)m) - 1;
+    if (lane_id() == leader) basew = atomicAdd(&d.wl_n[s], __popcll(m));
+    basew = __shfl(basew, leader, 64);
+    if (defer) d.wl[so + basew + __popcll(m & lanemask_lt())] = j;
+  }
+}
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// Tier 2 — one WAVE per deferred query.  Every lane owns one ROW of the search stencil (nearest rows
+// first, 64 rows per round) and walks that row's cells with a cursor: cell-level work (cluster id,
+// box distance) is lane-parallel; every surviving cell is then scanned by the whole wave, 128 points
+// per iteration, and `best` tightens the pruning of everything that follows.  Rows are ordered by
+// their lower bound, so a round in which no row can beat min(best, ub) ends the search (a neighbour
+// at d² ≥ ub is never counted), and so does best ≤ lb.
+__device__ __forceinline__ float wave_scan_cell(const float4 *sp, int b0, int e0, const float4 &q, float lbv, int lane) {
+  float local = INFINITY;
+  for (int k0 = b0; k0 < e0; k0 += 128) {
+    int k = k0 + lane, k2 = k + 64;
+    float4 p = sp[min(k, e0 - 1)], p2 = sp[min(k2, e0 - 1)];
+    local = fminf(local, fminf(sqdist(q.x, q.y, q.z, p.x, p.y, p.z), sqdist(q.x, q.y, q.z, p2.x, p2.y, p2.z)));
+    if (__ballot(local <= lbv)) break;
+  }
+  return wave_min(local);
+}
 __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
-  int s = blockIdx.y, pv = d.cur ^ 1, Cp = d.info[s].Cprev;
+  int s = blockIdx.y, pv = d.cur ^ 1, nq = d.wl_n[s];
   const int wv = blockIdx.x * (MOR_BT / 64) + wave_id(), nw = gridDim.x * (MOR_BT / 64), lane = lane_id();
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
-  const unsigned *bm = d.bitmap + (size_t)s * d.g.nwords; const int *wp = d.wprefix + (size_t)s * d.g.nwords;
+  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const int R = d.score_R;
   const float cs = d.g.cs * 0.999f;   // conservative cell edge for the row lower bounds
-  for (int j = wv; j < Cp; j += nw) {
+  for (int w = wv; w < nq; w += nw) {
+    const int j = d.wl[so + w];
     int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
     if (pr < 0) continue;
     const int target = d.pair_m[ko + pr];
     const float4 q = d.cl_pts[pv][so + j];
     const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.g.oz, d.g.inv_cs);
-    float best = INFINITY; bool done = false;
-    // stage 1: the query's own row of cells (row_order[0] = (0,0)).  On a static surface some point of
-    // the matched cluster lies within √lb of q, almost always in this row: one lookup, one short scan.
-    if ((unsigned)cy < (unsigned)d.g.ny && (unsigned)cz < (unsigned)d.g.nz) {
-      int x0 = max(cx - R, 0), x1 = min(cx + R, d.g.nx - 1);
-      if (x0 <= x1) {
-        int lo, hi; row_cells(d.g, bm, wp, x0, x1, cy, cz, lo, hi);
-        if (lo < hi) {
-          float local = INFINITY;
-          for (int k0 = st[lo], e0 = st[hi]; k0 < e0; k0 += 64) {
-            int k = k0 + lane;
-            if (k < e0) { float4 p = sp[k]; if (__float_as_int(p.w) == target) local = fminf(local, sqdist(q.x, q.y, q.z, p.x, p.y, p.z)); }
-            if (__ballot(local <= d.pde_lb)) break;
-          }
-          best = wave_min(local);
-          done = best <= d.pde_lb;
-        }
-      }
+    float best = INFINITY;
+    {  // the query's own cell first
+      int c = cell_lookup(d.g, ckey, rs, cx, cy, cz);
+      if (c >= 0 && d.ccid[so + c] == target) best = wave_scan_cell(sp, st[c], st[c + 1], q, d.pde_lb, lane);
     }
-    for (int rb = 0; rb < d.n_rows && !done; rb += 64) {
-      // lanes: resolve up to 64 rows
-      int ro = rb + lane, kb = 0, ke = 0; float lbrow = INFINITY;
-      if (ro < d.n_rows && ro > 0) {   // row 0 was stage 1
+    for (int rb = 0; rb < d.n_rows && best > d.pde_lb; rb += 64) {
+      // lanes: resolve one row each → cursor [cur, hi) over its cells
+      int ro = rb + lane, cur = 0, hi = 0; float lbrow = INFINITY;
+      if (ro < d.n_rows) {
         int dy = d.row_order[2 * ro], dz = d.row_order[2 * ro + 1];
         float ly = (float)max(abs(dy) - 1, 0) * cs, lz = (float)max(abs(dz) - 1, 0) * cs;
         lbrow = ly * ly + lz * lz;
-        float budget = d.pde_ub - lbrow;
+        float room = fminf(best, d.pde_ub) - lbrow;   // a useful neighbour in this row needs dx² < room
         int y = cy + dy, z = cz + dz;
-        if (budget > 0.f && (unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) {
-          int rx = min(R, (int)(sqrtf(budget) * d.g.inv_cs * 1.001f) + 1);
+        if (room > 0.f && (unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) {
+          int rx = min(R, (int)(sqrtf(room) * d.g.inv_cs * 1.001f) + 1);
           int x0 = max(cx - rx, 0), x1 = min(cx + rx, d.g.nx - 1);
-          if (x0 <= x1) { int lo, hi; row_cells(d.g, bm, wp, x0, x1, y, z, lo, hi); if (lo < hi) { kb = st[lo]; ke = st[hi]; } }
+          if (x0 <= x1) row_cells(d.g, ckey, rs, x0, x1, y, z, cur, hi);
         }
       }
-      unsigned long long rows = __ballot(kb < ke);   // non-empty rows, lane order = nearest first
-      if (!rows && __shfl(lbrow, min(63, d.n_rows - rb - 1), 64) >= fminf(best, d.pde_ub)) done = true;
-      while (rows) {
-        int r = __ffsll((long long)rows) - 1; rows &= rows - 1;
-        float lbr = __shfl(lbrow, r, 64);
-        if (lbr >= fminf(best, d.pde_ub)) { done = true; break; }   // rows are ordered by this bound
-        int b0 = __shfl(kb, r, 64), e0 = __shfl(ke, r, 64);
-        float local = INFINITY;
-        for (int k0 = b0; k0 < e0; k0 += 64) {
-          int k = k0 + lane;
-          if (k < e0) { float4 p = sp[k]; if (__float_as_int(p.w) == target) local = fminf(local, sqdist(q.x, q.y, q.z, p.x, p.y, p.z)); }
-          if (__ballot(local <= d.pde_lb)) break;
+      if (__shfl(lbrow, 0, 64) >= fminf(best, d.pde_ub)) break;   // rows are ordered by their lower bound
+      for (;;) {
+        // lane-parallel: advance the cursor to the next cell of the matched cluster whose box can still improve `best`
+        int cand = -1;
+        const float lim = fminf(best, d.pde_ub);
+        if (lbrow < lim) {
+          while (cur < hi) {
+            int c = cur++;
+            if (d.ccid[so + c] != target) continue;
+            if (box_dist2(q, d.cbox_lo[so + c], d.cbox_hi[so + c]) < lim) { cand = c; break; }
+          }
         }
-        best = fminf(best, wave_min(local));
-        if (best <= d.pde_lb) { done = true; break; }
+        unsigned long long m = __ballot(cand >= 0);
+        if (!m) break;
+        while (m && best > d.pde_lb) {   // whole wave scans each surviving cell
+          int l = __ffsll((long long)m) - 1; m &= m - 1;
+          int c = __shfl(cand, l, 64);
+          best = fminf(best, wave_scan_cell(sp, st[c], st[c + 1], q, d.pde_lb, lane));
+        }
+        if (best <= d.pde_lb) break;
       }
     }
     if (lane == 0 && best > d.pde_lb && best < d.pde_ub) atomicAdd(&d.pair_cnt[ko + pr], 1);
@@ -868,7 +984,7 @@ __global__ __launch_bounds__(MOR_BT) void k_decide(MorDev d) {
   for (int k = threadIdx.x; k < K; k += MOR_BT) { d.h_centroid[ko + k] = d.centroid[d.cur][ko + k]; d.h_det[ko + k] = d.det[ko + k]; }
   for (int k = threadIdx.x; k <= K; k += MOR_BT) d.h_cl_off[(size_t)s * (d.Kcap + 1) + k] = offc[k];
   if (threadIdx.x == 0) {
-    f.n_pairs = np;
+    f.n_pairs = np; f.n_defer = (d.has_prev && d.method == 1) ? (uint32_t)d.wl_n[s] : 0u;
     d.info[s].Kprev = f.K; d.info[s].Cprev = f.C;   // this frame is the next push's `ca`
     d.info[s].n_pairs = np;
     d.h_info[s] = f;
@@ -944,14 +1060,19 @@ __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
 
 void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gT(d.B * d.tiles), gB(d.B), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B), gW(getenv("MOR_GW") ? atoi(getenv("MOR_GW")) : 64, d.B);
-  hipMemsetAsync(d.bitmap, 0, (size_t)d.B * d.g.nwords * sizeof(unsigned), st);
   MOR_LAUNCH(MK_CLASSIFY, k_classify, gT, d);
   MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
   MOR_LAUNCH(MK_SCATTER, k_scatter, gT, d);
-  MOR_LAUNCH(MK_WPREFIX, k_wprefix, gB, d);
-  MOR_LAUNCH(MK_CELLCOUNT, k_cellcount, gT, d);
-  MOR_LAUNCH(MK_CSTART, k_cstart, gB, d);
-  MOR_LAUNCH(MK_FILL, k_fill, gT, d);
+  for (int pass = 0; pass < d.cell_passes; ++pass) {   // points sorted by cell key; result in (skey, sidx) = buffers [cell_passes & 1]
+    MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0};
+    MOR_LAUNCH(MK_RHIST, k_rhist, gT, d, j);
+    MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d);
+    MOR_LAUNCH(MK_RSCATTER, k_rscatter, gT, d, j);
+  }
+  MOR_LAUNCH(MK_HEADS_COUNT, k_heads_count, gT, d);
+  MOR_LAUNCH(MK_HEADS_SCAN, k_heads_scan, gB, d);
+  MOR_LAUNCH(MK_HEADS_SCATTER, k_heads_scatter, gT, d);
+  MOR_LAUNCH(MK_ROWTABLE, k_rowtable, dim3((d.g.nrows + MOR_BT) / MOR_BT > 32 ? 32 : (d.g.nrows + MOR_BT) / MOR_BT, d.B), d);
   MOR_LAUNCH(MK_CELLBOX, k_cellbox, gW, d);
   MOR_LAUNCH(MK_HOOK_NEAR, k_hook_cells, gW, d, 0);
   MOR_LAUNCH(MK_HOOK_SHELL, k_hook_cells, gW, d, 1);
@@ -962,10 +1083,12 @@ void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   MOR_LAUNCH(MK_RANK, k_rank, gKt, d);
   MOR_LAUNCH(MK_OFFSETS, k_offsets, gB, d);
   MOR_LAUNCH(MK_LABEL, k_label, gT, d);
-  for (int pass = 0; pass < d.radix_passes; ++pass) {
-    MOR_LAUNCH(MK_RHIST, k_rhist, gT, d, pass);
+  for (int pass = 0; pass < d.radix_passes; ++pass) {   // clustered points partitioned by cluster id, index order kept ⇒ cluster_indices
+    const bool last = pass == d.radix_passes - 1;
+    MorRadix j = {pass == 0 ? d.pcid : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], last ? nullptr : d.rkeys[(pass + 1) & 1], last ? d.cl_idx : d.rvals[(pass + 1) & 1], 8 * pass, pass == 0 ? 0 : 1, pass == 0 ? 1 : 0};
+    MOR_LAUNCH(MK_RHIST, k_rhist, gT, d, j);
     MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d);
-    MOR_LAUNCH(MK_RSCATTER, k_rscatter, gT, d, pass, pass == d.radix_passes - 1 ? 1 : 0);
+    MOR_LAUNCH(MK_RSCATTER, k_rscatter, gT, d, j);
   }
   MOR_LAUNCH(MK_STATS, k_stats, gK, d);
   if (d.has_prev) {
@@ -974,7 +1097,7 @@ void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     MOR_LAUNCH(MK_NN, k_nn_centroid, gKt, d, 1);
     MOR_LAUNCH(MK_PAIRS, k_pairs, gB, d);
     if (d.method == 1) {
-      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(128, d.B), d);
+      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles * 8), d); if (!getenv("MOR_EXP_SKIP_T2")) MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(getenv("MOR_T2G") ? atoi(getenv("MOR_T2G")) : 256, d.B), d); }
     } else if (d.method == 2) {
       MOR_LAUNCH(MK_VOX_CLEAR, k_vox_clear, dim3(64, d.B), d);
       MOR_LAUNCH(MK_VOX_INSERT, k_vox_insert, gT, d);

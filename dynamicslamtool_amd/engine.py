@@ -16,7 +16,7 @@ EXPORTS = [
     "mor_sizeof_params", "mor_last_error", "mor_batch_create", "mor_batch_destroy", "mor_batch_streams", "mor_push_batch",
     "mor_filter_batch", "mor_get_output_device", "mor_create", "mor_push", "mor_filter", "mor_destroy", "mor_get_counts",
     "mor_get_labels", "mor_get_ground_indices", "mor_get_clusters", "mor_get_centroids", "mor_get_detection",
-    "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_device_alloc", "mor_device_free",
+    "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_get_stage_counts", "mor_device_alloc", "mor_device_free",
     "mor_device_upload", "mor_device_download", "mor_device_synchronize", "mor_device_count", "mor_get_last_timing",
     "mor_kernel_timing_enable", "mor_kernel_timing_read", "mor_tracker_create", "mor_tracker_destroy", "mor_tracker_push",
     "mor_tracker_filter", "mor_tracker_get",
@@ -60,6 +60,7 @@ def lib():
         L.mor_get_clusters.argtypes = [vp, i32, vp, vp]
         L.mor_get_correspondences.argtypes = [vp, i32, vp, vp, vp, vp]
         L.mor_get_tracks.argtypes = [vp, i32, vp, vp, vp]
+        L.mor_get_stage_counts.argtypes = [vp, i32, vp, i32]
         L.mor_device_alloc.restype = vp
         L.mor_device_alloc.argtypes = [i32, C.c_size_t]
         L.mor_device_free.argtypes = [i32, vp]
@@ -226,6 +227,11 @@ class MorBatch:
         xyz, conf, mx = np.empty((n, 3), np.float32), np.empty(n, np.int32), np.empty(n, np.int32)
         _check(lib().mor_get_tracks(self._h, s, xyz.ctypes.data, conf.ctypes.data, mx.ctypes.data))
         return xyz[:k], conf[:k], mx[:k]
+
+    def stage_counts(self, s=0):
+        a = (C.c_uint32 * 4)()
+        _check(lib().mor_get_stage_counts(self._h, s, a, 4))
+        return {"n_occ": int(a[0]), "n_defer": int(a[1]), "K_prev": int(a[2]), "C_prev": int(a[3])}
 
     def output_device(self, s=0):
         n = C.c_uint64(0)
