@@ -44,7 +44,8 @@ struct MorFrameInfo {        // per stream, produced on device
 
 struct MorDev {
   // ---- static configuration
-  int B, Nmax, Kcap, tiles_max, radix_passes, cell_passes, Hcap;
+  int B, s0, Btot;           // streams in this launch, first stream, streams in the batch
+  int Nmax, Kcap, tiles_max, radix_passes, cell_passes, Hcap;
   float trim_x, trim_y, trim_z, gp_limit, r2;
   long long min_cs, max_cs;
   float pde_lb, pde_ub;
@@ -106,6 +107,7 @@ struct MorDev {
   int *otile_cnt;            // [B][tiles_max]
   float4 *out;               // [B][Nmax] (or caller-provided per-stream pointers through out_ptrs)
   float4 *const *out_ptrs;   // [B] or null
+  unsigned long long *dbg;   // [B][16] experiment stamps (MOR_EXP_STAMPS builds only)
   // ---- pinned host mirrors written by the device (zero-copy summaries)
   MorFrameInfo *h_info;      // [B]
   float4 *h_centroid;        // [B][Kcap]
@@ -119,7 +121,7 @@ struct MorDev {
 
 // kernel ids for optional per-kernel event timing
 enum MorKernelId {
-  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_ROWTABLE, MK_CELLBOX, MK_HOOK_NEAR, MK_HOOK_SHELL, MK_FLATTEN,
+  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_ROWTABLE, MK_CELLGRAPH, MK_CELLBOX, MK_HOOK_NEAR, MK_HOOK_SHELL, MK_FLATTEN, MK_CELLCID,
   MK_SELECT_COUNT, MK_SELECT_SCAN, MK_SELECT_SCATTER, MK_RANK, MK_OFFSETS, MK_LABEL, MK_RHIST, MK_RSCAN, MK_RSCATTER,
   MK_STATS, MK_XFORM_PREV, MK_NN, MK_PAIRS, MK_SCORE_FAST, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
   MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_COUNT

@@ -8,9 +8,14 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
+
+#define MOR_MAX_GROUPS 8
 
 static thread_local std::string g_last_error;
 static int set_error(int code, const char *fmt, ...) {
@@ -49,6 +54,14 @@ struct PoseTf { double R[3][3], o[3]; };
 struct mor_batch {
   mor_params p; int n_bad, n_good, B, device; uint64_t Nmax;
   hipStream_t st = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // stream groups: the B streams are split into G groups that run the same launch sequence on their own HIP
+  // streams, so the latency-bound stages of one group overlap the other groups' work (streams are independent)
+  int G = 1;
+  hipStream_t gst[MOR_MAX_GROUPS] = {};
+  hipEvent_t gev[MOR_MAX_GROUPS][2] = {};
+  bool use_graphs = true;
+  struct GraphKey { int kind, g, cur, has_prev, tiles, outp; bool operator<(const GraphKey &o) const { return std::tie(kind, g, cur, has_prev, tiles, outp) < std::tie(o.kind, o.g, o.cur, o.has_prev, o.tiles, o.outp); } };
+  std::map<GraphKey, hipGraphExec_t> graphs;
   MorDev d;                                  // template descriptor (static part + pointers)
   std::vector<void *> dev_allocs, host_allocs;
   MorStreamArgs *h_args = nullptr, *d_args = nullptr;
@@ -99,7 +112,7 @@ static int configure(mor_batch *b) {
   if (p.method_choice == 2 && p.opc_normalization_factor <= 0) return set_error(MOR_ERR_INVALID, "opc_normalization_factor must be > 0 for method 2");
   if (p.method_choice == 2 && !(p.opc_resolution > 0.f)) return set_error(MOR_ERR_INVALID, "opc_resolution must be > 0");
   if (p.ground_method != 0) return set_error(MOR_ERR_INVALID, "ground_method %d not available in this build (0 = crop box)", p.ground_method);
-  d.B = b->B; d.Nmax = (int)b->Nmax;
+  d.B = b->B; d.Btot = b->B; d.s0 = 0; d.Nmax = (int)b->Nmax;
   long long mn = std::max<long long>(p.min_cluster_size, 1);
   d.Kcap = (int)std::min<long long>((long long)b->Nmax / mn + 1, 16384);
   d.tiles_max = (int)((b->Nmax + MOR_TILE - 1) / MOR_TILE);
@@ -127,6 +140,43 @@ static int configure(mor_batch *b) {
   return MOR_OK;
 }
 
+// Runs one launch sequence (kind 0 = push, 1 = filter) for every stream group on its own HIP stream and waits for
+// all of them.  The sequence of a group is captured once per (frame slot, tile count, …) into a hipGraph and
+// replayed: ≈45 launches collapse into one host call per group.  `pre(g, stream)` enqueues the per-call copies.
+template <class Pre> static int run_groups(mor_batch *b, const MorDev &d, int kind, Pre pre, float *ms_out) {
+  const int G = b->G, Bg = d.Btot / G;
+  const bool graphs = b->use_graphs && !b->timer.enabled;
+  for (int g = 0; g < G; ++g) {
+    MorDev dg = d; dg.B = Bg; dg.s0 = g * Bg;
+    hipStream_t st = b->gst[g];
+    int rc = pre(g, st, dg); if (rc != MOR_OK) return rc;
+    HIP_TRY(hipEventRecord(b->gev[g][0], st));
+    if (graphs) {
+      mor_batch::GraphKey key{kind, g, d.cur, d.has_prev, d.tiles, d.out_ptrs ? 1 : 0};
+      auto it = b->graphs.find(key);
+      if (it == b->graphs.end()) {
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        if (kind == 0) mor_launch_push(dg, st, nullptr); else mor_launch_filter(dg, st, nullptr);
+        HIP_TRY(hipStreamEndCapture(st, &graph));
+        HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIP_TRY(hipGraphDestroy(graph));
+        it = b->graphs.emplace(key, exec).first;
+      }
+      HIP_TRY(hipGraphLaunch(it->second, st));
+    } else {
+      if (kind == 0) mor_launch_push(dg, st, &b->timer); else mor_launch_filter(dg, st, &b->timer);
+    }
+    HIP_TRY(hipEventRecord(b->gev[g][1], st));
+  }
+  HIP_TRY(hipGetLastError());
+  float mx = 0;
+  for (int g = 0; g < G; ++g) { HIP_TRY(hipStreamSynchronize(b->gst[g])); float t = 0; hipEventElapsedTime(&t, b->gev[g][0], b->gev[g][1]); mx = std::max(mx, t); }
+  if (ms_out) *ms_out = mx;
+  b->timer.collect();
+  return MOR_OK;
+}
+
 extern "C" {
 
 size_t mor_sizeof_params(void) { return sizeof(mor_params); }
@@ -137,6 +187,9 @@ void mor_batch_destroy(mor_batch *b) {
   if (!b) return;
   hipSetDevice(b->device);
   if (b->st) hipStreamSynchronize(b->st);
+  for (int g = 0; g < b->G; ++g) if (b->gst[g]) hipStreamSynchronize(b->gst[g]);
+  for (auto &kv : b->graphs) hipGraphExecDestroy(kv.second);
+  for (int g = 0; g < b->G; ++g) { if (b->gst[g]) hipStreamDestroy(b->gst[g]); for (auto &ev : b->gev[g]) if (ev) hipEventDestroy(ev); }
   for (void *p : b->dev_allocs) hipFree(p);
   for (void *p : b->host_allocs) hipHostFree(p);
   if (b->d_stage) hipFree(b->d_stage);
@@ -158,6 +211,16 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if ((rc = configure(b)) != MOR_OK) return fail(rc);
   if (hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
   for (auto &e : b->ev) if (hipEventCreate(&e) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+  {
+    const char *eg = getenv("MOR_GROUPS"), *egr = getenv("MOR_GRAPH");
+    int G = eg ? atoi(eg) : 1;   // measured on MI355X (B=64 hdl64): G>1 loses more to host-side launch/copy cost than overlap gains
+    if (G < 1 || G > MOR_MAX_GROUPS || n_streams % G != 0) G = 1;
+    b->G = G; b->use_graphs = !(egr && atoi(egr) == 0);
+    for (int g = 0; g < G; ++g) {
+      if (hipStreamCreateWithFlags(&b->gst[g], hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
+      for (auto &ev : b->gev[g]) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+    }
+  }
   MorDev &d = b->d; const size_t B = d.B, N = d.Nmax, K = d.Kcap, T = d.tiles_max;
   bool ok = true;
   MorStreamArgs *dargs = nullptr;
@@ -190,7 +253,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.nn_fwd, B * K) && dalloc(b, d.nn_bwd, B * K) && dalloc(b, d.nn_fwd_d, B * K) && dalloc(b, d.pair_q, B * K) && dalloc(b, d.pair_m, B * K) && dalloc(b, d.pair_d, B * K);
   ok = ok && dalloc(b, d.pair_cnt, B * K) && dalloc(b, d.pair_of_prev, B * K) && dalloc(b, d.pair_of_cur, B * K) && dalloc(b, d.det, B * K);
   if (p->method_choice == 2) ok = ok && dalloc(b, d.vox, B * (size_t)d.Hcap);
-  ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_n, B);
+  ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_n, B) && dalloc(b, d.dbg, B * 16);
   ok = ok && dalloc(b, b->d_moving, B * K + B) && dalloc(b, d.otile_cnt, B * T) && dalloc(b, d.out, B * N) && dalloc(b, b->d_outptrs, B);
   d.moving = b->d_moving;
   ok = ok && halloc(b, b->h_args, B) && halloc(b, b->h_moving, B * K + B) && halloc(b, b->h_outptrs, B);
@@ -224,7 +287,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     if (!c.on_device) max_host_bytes = std::max<size_t>(max_host_bytes, (size_t)c.n_points * c.point_step);
   }
   if (max_host_bytes > b->stage_stride) {   // (re)allocate the staging area for host-resident blobs
-    if (b->d_stage) { HIP_TRY(hipStreamSynchronize(b->st)); HIP_TRY(hipFree(b->d_stage)); b->d_stage = nullptr; }
+    if (b->d_stage) { for (int g = 0; g < b->G; ++g) HIP_TRY(hipStreamSynchronize(b->gst[g])); HIP_TRY(hipFree(b->d_stage)); b->d_stage = nullptr; }
     b->stage_stride = (max_host_bytes + 255) & ~(size_t)255;
     HIP_TRY(hipMalloc((void **)&b->d_stage, b->stage_stride * B));
   }
@@ -232,21 +295,22 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   for (int s = 0; s < B; ++s) {
     const mor_cloud_view &c = clouds[s]; MorStreamArgs &a = b->h_args[s];
     a.n = (uint32_t)c.n_points; a.step = c.point_step; a.off_x = c.off_x; a.off_y = c.off_y; a.off_z = c.off_z; a.off_i = c.off_intensity;
-    if (c.on_device || c.n_points == 0) a.data = c.data;
-    else { a.data = b->d_stage + b->stage_stride * s; HIP_TRY(hipMemcpyAsync((void *)a.data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, b->st)); }
+    a.data = (c.on_device || c.n_points == 0) ? c.data : (const void *)(b->d_stage + b->stage_stride * s);
     pose_to_tf(poses + 7 * s, cur[s]);
     if (b->frame > 0) relative_transform(cur[s], b->prev_pose[s], a.xf); else memset(a.xf, 0, sizeof a.xf);
   }
-  HIP_TRY(hipMemcpyAsync(b->d_args, b->h_args, sizeof(MorStreamArgs) * B, hipMemcpyHostToDevice, b->st));
   d.tiles = std::max<int>(1, (int)((maxn + MOR_TILE - 1) / MOR_TILE));
-  d.cur = (int)(b->frame & 1); d.has_prev = b->frame > 0;
-  HIP_TRY(hipEventRecord(b->ev[0], b->st));
-  mor_launch_push(d, b->st, &b->timer);
-  HIP_TRY(hipEventRecord(b->ev[1], b->st));
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(b->st));
-  hipEventElapsedTime(&b->push_ms, b->ev[0], b->ev[1]);
-  b->timer.collect();
+  d.cur = (int)(b->frame & 1); d.has_prev = b->frame > 0; d.out_ptrs = nullptr;
+  const int Bg = B / b->G;
+  auto pre = [&](int g, hipStream_t st, const MorDev &) -> int {
+    for (int s = g * Bg; s < (g + 1) * Bg; ++s) {   // host-resident blobs: stage on the group's stream
+      const mor_cloud_view &c = clouds[s];
+      if (!c.on_device && c.n_points) HIP_TRY(hipMemcpyAsync((void *)b->h_args[s].data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemcpyAsync(b->d_args + g * Bg, b->h_args + g * Bg, sizeof(MorStreamArgs) * Bg, hipMemcpyHostToDevice, st));
+    return MOR_OK;
+  };
+  { int rc0 = run_groups(b, d, 0, pre, &b->push_ms); if (rc0 != MOR_OK) return rc0; }
   b->d.tiles = d.tiles; b->d.cur = d.cur; b->d.has_prev = d.has_prev;
   int rc = MOR_OK;
   std::vector<float> cent;
@@ -281,20 +345,16 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
     b->h_moving[(size_t)B * d.Kcap + s] = n_idx > f.M;   // ExtractIndices: more indices than points ⇒ error, empty output
   }
   b->filtered = true;
-  HIP_TRY(hipMemcpyAsync(b->d_moving, b->h_moving, (size_t)B * d.Kcap + B, hipMemcpyHostToDevice, b->st));
   d.out_ptrs = nullptr;
-  if (out && out_on_device) {
-    for (int s = 0; s < B; ++s) b->h_outptrs[s] = (float4 *)out[s];
-    HIP_TRY(hipMemcpyAsync(b->d_outptrs, b->h_outptrs, sizeof(float4 *) * B, hipMemcpyHostToDevice, b->st));
-    d.out_ptrs = b->d_outptrs;
-  }
-  HIP_TRY(hipEventRecord(b->ev[2], b->st));
-  mor_launch_filter(d, b->st, &b->timer);
-  HIP_TRY(hipEventRecord(b->ev[3], b->st));
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(b->st));
-  hipEventElapsedTime(&b->filter_ms, b->ev[2], b->ev[3]);
-  b->timer.collect();
+  if (out && out_on_device) { for (int s = 0; s < B; ++s) b->h_outptrs[s] = (float4 *)out[s]; d.out_ptrs = b->d_outptrs; }
+  const int Bg = B / b->G;
+  auto pre = [&](int g, hipStream_t st, const MorDev &) -> int {
+    HIP_TRY(hipMemcpyAsync(b->d_moving + (size_t)g * Bg * d.Kcap, b->h_moving + (size_t)g * Bg * d.Kcap, (size_t)Bg * d.Kcap, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->d_moving + (size_t)B * d.Kcap + g * Bg, b->h_moving + (size_t)B * d.Kcap + g * Bg, Bg, hipMemcpyHostToDevice, st));
+    if (d.out_ptrs) HIP_TRY(hipMemcpyAsync(b->d_outptrs + g * Bg, b->h_outptrs + g * Bg, sizeof(float4 *) * Bg, hipMemcpyHostToDevice, st));
+    return MOR_OK;
+  };
+  { int rc0 = run_groups(b, d, 1, pre, &b->filter_ms); if (rc0 != MOR_OK) return rc0; }
   for (int s = 0; s < B; ++s) if (n_out) n_out[s] = d.h_nout[s];
   if (out && !out_on_device) {
     for (int s = 0; s < B; ++s) if (out[s] && d.h_nout[s]) HIP_TRY(hipMemcpyAsync(out[s], d.out + (size_t)s * d.Nmax, d.h_nout[s] * sizeof(float4), hipMemcpyDeviceToHost, b->st));
@@ -373,6 +433,11 @@ int mor_get_cluster_collection(const mor_batch *b, int s, float *out) {
   return MOR_OK;
 }
 
+int mor_exp_read_stamps(const mor_batch *b, unsigned long long *out) {
+  if (!b) return MOR_ERR_INVALID;
+  HIP_TRY(hipMemcpy(out, b->d.dbg, sizeof(unsigned long long) * 16 * b->B, hipMemcpyDeviceToHost));
+  return MOR_OK;
+}
 int mor_get_stage_counts(const mor_batch *b, int s, uint32_t *out, int n) {
   CHECK_STREAM();
   const uint32_t v[4] = {f.n_occ, f.n_defer, f.Kprev, f.Cprev};

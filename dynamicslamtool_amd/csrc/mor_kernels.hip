@@ -26,7 +26,7 @@
 #include <cstdlib>
 
 const char *const mor_kernel_names[MK_COUNT] = {
-    "classify", "scan_tiles", "scatter", "heads_count", "heads_scan", "heads_scatter", "rowtable", "cellbox", "hook_near", "hook_shell", "flatten",
+    "classify", "scan_tiles", "scatter", "heads_count", "heads_scan", "heads_scatter", "rowtable", "cellgraph", "cellbox", "hook_near", "hook_shell", "flatten", "cellcid",
     "select_count", "select_scan", "select_scatter", "rank", "offsets", "label", "rhist", "rscan", "rscatter",
     "stats", "xform_prev", "nn_centroid", "pairs", "score_fast", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
     "out_count", "out_scan", "out_scatter"};
@@ -38,11 +38,13 @@ __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << la
 
 // (stream, tile) of this workgroup.  With B a multiple of 8, all tiles of stream s run on the
 // XCD group s % 8 (workgroups are dealt round-robin over the 8 XCDs): L2 locality only.
-__device__ __forceinline__ void map_block(int B, int tiles, int &s, int &t) {
+__device__ __forceinline__ void map_block_local(int B, int tiles, int &s, int &t) {
   int L = blockIdx.x;
   if ((B & 7) == 0) { int x = L & 7, r = L >> 3; s = (r / tiles) * 8 + x; t = r % tiles; }
   else { s = L / tiles; t = L % tiles; }
 }
+// d.B streams of this launch start at stream d.s0 of the batch (stream groups run on their own HIP streams)
+#define map_block(B_, tiles_, s_, t_) do { map_block_local((B_), (tiles_), (s_), (t_)); (s_) += d.s0; } while (0)
 
 __device__ __forceinline__ int wave_incl_scan(int v) {
 #pragma unroll
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(MOR_BT) void k_classify(MorDev d) {
 
 // one workgroup per stream: exclusive scan of the tile counts; publishes N, T, M, G
 __global__ __launch_bounds__(MOR_BT) void k_scan_tiles(MorDev d) {
-  int s = blockIdx.x;
+  int s = blockIdx.x + d.s0;
   __shared__ int sh[8];
   int carry_ng = 0, carry_g = 0;
   for (int b = 0; b < d.tiles; b += MOR_BT) {
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_count(MorDev d) {
   if (threadIdx.x == 0) d.ktile_cnt[(size_t)s * d.tiles_max + t] = tot;
 }
 __global__ __launch_bounds__(MOR_BT) void k_heads_scan(MorDev d) {
-  int s = blockIdx.x; __shared__ int sh[8]; int carry = 0;
+  int s = blockIdx.x + d.s0; __shared__ int sh[8]; int carry = 0;
   int *c = d.ktile_cnt + (size_t)s * d.tiles_max;
   for (int b = 0; b < d.tiles; b += MOR_BT) {
     int t = b + threadIdx.x, v = t < d.tiles ? c[t] : 0, tot;
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
 }
 // dense (y,z) row table: first occupied cell with key ≥ row·nx
 __global__ __launch_bounds__(MOR_BT) void k_rowtable(MorDev d) {
-  int s = blockIdx.y, nocc = d.info[s].n_occ;
+  int s = blockIdx.y + d.s0, nocc = d.info[s].n_occ;
   const int *ckey = d.ckey + (size_t)s * d.Nmax;
   int *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
   for (int r = blockIdx.x * MOR_BT + threadIdx.x; r <= d.g.nrows; r += gridDim.x * MOR_BT) {
@@ -312,7 +314,7 @@ __device__ __forceinline__ int uf_unite(int *P, int a, int b) {
 
 // bounding box of the points of every occupied cell (prunes cell-pair tests); one wave per cell
 __global__ __launch_bounds__(MOR_BT) void k_cellbox(MorDev d) {
-  int s = blockIdx.y, nocc = d.info[s].n_occ;
+  int s = blockIdx.y + d.s0, nocc = d.info[s].n_occ;
   const int wv = blockIdx.x * (MOR_BT / 64) + wave_id(), nw = gridDim.x * (MOR_BT / 64), lane = lane_id();
   const size_t so = (size_t)s * d.Nmax;
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(MOR_BT) void k_cellbox(MorDev d) {
 // the bitmap, then the wave tests point pairs (a ∈ A, b ∈ B) 64 at a time — EuclideanCluster-
 // Extraction's edge predicate d² < r² (:213-218) — and unites the cells at the first hit.
 __global__ __launch_bounds__(MOR_BT) void k_hook_cells(MorDev d, int shell) {
-  int s = blockIdx.y, nocc = d.info[s].n_occ;
+  int s = blockIdx.y + d.s0, nocc = d.info[s].n_occ;
   const int wv = blockIdx.x * (MOR_BT / 64) + wave_id(), nw = gridDim.x * (MOR_BT / 64), lane = lane_id();
   const size_t so = (size_t)s * d.Nmax;
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(MOR_BT) void k_hook_cells(MorDev d, int shell) {
 
 // root of every cell; component size (points) and smallest cloud index accumulate at the root
 __global__ __launch_bounds__(MOR_BT) void k_flatten(MorDev d) {
-  int s = blockIdx.y, nocc = d.info[s].n_occ;
+  int s = blockIdx.y + d.s0, nocc = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
   for (int c = blockIdx.x * MOR_BT + threadIdx.x; c < nocc; c += gridDim.x * MOR_BT) {
     int r = c, p = d.parent[so + r];
@@ -404,6 +406,12 @@ __global__ __launch_bounds__(MOR_BT) void k_flatten(MorDev d) {
   }
 }
 
+// general path: per-cell cluster id from the root's id
+__global__ __launch_bounds__(MOR_BT) void k_cellcid(MorDev d) {
+  int s = blockIdx.y + d.s0, nocc = d.info[s].n_occ;
+  const size_t so = (size_t)s * d.Nmax;
+  for (int c = blockIdx.x * MOR_BT + threadIdx.x; c < nocc; c += gridDim.x * MOR_BT) d.ccid[so + c] = d.cid_of_root[so + d.croot[so + c]];
+}
 // kept components: min_cluster_size ≤ size ≤ max_cluster_size (:215-216)
 __device__ __forceinline__ bool kept_root(const MorDev &d, size_t so, int c) {
   if (d.croot[so + c] != c) return false;
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(MOR_BT) void k_select_count(MorDev d) {
   if (threadIdx.x == 0) d.ktile_cnt[(size_t)s * d.tiles_max + t] = tot;
 }
 __global__ __launch_bounds__(MOR_BT) void k_select_scan(MorDev d) {
-  int s = blockIdx.x; __shared__ int sh[8]; int carry = 0;
+  int s = blockIdx.x + d.s0; __shared__ int sh[8]; int carry = 0;
   int *c = d.ktile_cnt + (size_t)s * d.tiles_max;
   for (int b = 0; b < d.tiles; b += MOR_BT) {
     int t = b + threadIdx.x, v = t < d.tiles ? c[t] : 0, tot;
@@ -450,9 +458,284 @@ __global__ __launch_bounds__(MOR_BT) void k_select_scatter(MorDev d) {
   }
 }
 
+// ------------------------------------------------------------------------------------ C1 fast path: the whole cell graph of one stream in ONE workgroup
+// The per-cell kernels above are bound by chains of dependent global loads (key → row table → key →
+// parent → parent …, ≈1 µs a hop).  A stream's cell graph is small (a few thousand occupied cells):
+// one 1024-thread workgroup per stream keeps the distinct keys, cell offsets, row table and the
+// union-find forest in LDS (160 KiB per CU on CDNA4), so every hop of those chains is an LDS access and
+// all unions are LDS atomics; only the point coordinates of tested pairs come from L2/HBM.  The
+// kernel covers cell boxes, both hook passes, flattening, component sizes / min indices, cluster
+// selection, ordering and offsets — nine launches of the general path.  Streams whose cell count
+// exceeds the LDS capacity run the same code on their global-memory arrays.
+#define CG_T 1024
+#define CG_CAP 8192      // occupied cells held in LDS
+#define CG_ROWCAP 8192   // (y,z) rows held in LDS
+#define CG_LIST 2040     // deferred (cell | cell pair) entries
+
+template <bool LDS> __device__ __forceinline__ int cg_ld(const int *p) {
+  return LDS ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool LDS> __device__ __forceinline__ void cg_st(int *p, int v) {
+  if (LDS) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool LDS> __device__ __forceinline__ int cg_find(int *P, int x) {
+  int p = cg_ld<LDS>(P + x);
+  while (p != x) { int gp = cg_ld<LDS>(P + p); if (gp == p) return p; cg_st<LDS>(P + x, gp); x = gp; p = cg_ld<LDS>(P + x); }
+  return x;
+}
+template <bool LDS> __device__ __forceinline__ int cg_unite(int *P, int a, int b) {
+  int ra = cg_find<LDS>(P, a), rb = cg_find<LDS>(P, b);
+  while (ra != rb) {
+    if (ra < rb) { int x = ra; ra = rb; rb = x; }
+    int old = atomicCAS(P + ra, ra, rb);
+    if (old == ra) return rb;
+    ra = cg_find<LDS>(P, old);
+  }
+  return ra;
+}
+// any pair (a ∈ A, b ∈ B) with d² < r²?  one thread, B streamed four independent loads at a time
+__device__ __forceinline__ bool pair_hit_serial(const float4 *sp, int a0, int na, int b0, int nb, float r2) {
+  for (int ia = 0; ia < na; ++ia) {
+    const float4 pa = sp[a0 + ia];
+    for (int ib = 0; ib < nb; ib += 4) {
+      float4 q0 = sp[b0 + ib], q1 = sp[b0 + min(ib + 1, nb - 1)], q2 = sp[b0 + min(ib + 2, nb - 1)], q3 = sp[b0 + min(ib + 3, nb - 1)];
+      if (sqdist(pa.x, pa.y, pa.z, q0.x, q0.y, q0.z) < r2 || sqdist(pa.x, pa.y, pa.z, q1.x, q1.y, q1.z) < r2 ||
+          sqdist(pa.x, pa.y, pa.z, q2.x, q2.y, q2.z) < r2 || sqdist(pa.x, pa.y, pa.z, q3.x, q3.y, q3.z) < r2) return true;
+    }
+  }
+  return false;
+}
+// the same question answered by a whole wave: lanes tile A × B as at × (64/at)
+__device__ __forceinline__ bool pair_hit_wave(const float4 *sp, int a0, int na, int b0, int nb, float r2, int lane) {
+  int sh = 0; while ((1 << sh) < na && sh < 6) ++sh;
+  const int at = 1 << sh, bt = 64 >> sh, la = lane & (at - 1), lb = lane >> sh;
+  for (int ia0 = 0; ia0 < na; ia0 += at) {
+    const int ia = ia0 + la; const float4 pa = sp[a0 + min(ia, na - 1)];
+    for (int ib0 = 0; ib0 < nb; ib0 += bt) {
+      const int ib = ib0 + lb; const float4 pb = sp[b0 + min(ib, nb - 1)];
+      bool h = ia < na && ib < nb && sqdist(pa.x, pa.y, pa.z, pb.x, pb.y, pb.z) < r2;
+      if (__ballot(h)) return true;
+    }
+  }
+  return false;
+}
+__device__ __forceinline__ void wave_box(const float4 *sp, int b, int e, int lane, float4 &lo, float4 &hi) {
+  float lx = FLT_MAX, ly = FLT_MAX, lz = FLT_MAX, hx = -FLT_MAX, hy = -FLT_MAX, hz = -FLT_MAX;
+  for (int k = b + lane; k < e; k += 64) { float4 p = sp[k]; lx = fminf(lx, p.x); ly = fminf(ly, p.y); lz = fminf(lz, p.z); hx = fmaxf(hx, p.x); hy = fmaxf(hy, p.y); hz = fmaxf(hz, p.z); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
+    hx = fmaxf(hx, __shfl_xor(hx, o, 64)); hy = fmaxf(hy, __shfl_xor(hy, o, 64)); hz = fmaxf(hz, __shfl_xor(hz, o, 64));
+  }
+  lo = make_float4(lx, ly, lz, 0.f); hi = make_float4(hx, hy, hz, 0.f);
+}
+
+// one hook pass over the forward half of the (2·RING+1)³ neighbourhood, ring == RING only
+template <bool LDS> __device__ __forceinline__ void cg_hook_pass(const MorDev &d, int s, int nocc, int RING, const int *key, const int *start, const int *rows, int *par,
+                                                                   const float4 *sp, int *l_list, int *l_nlist) {
+  const float r2 = d.r2;
+  const size_t so_ = (size_t)s * d.Nmax;
+  for (int a = threadIdx.x; a < nocc; a += CG_T) {
+    const int ka = key[a], rowa = ka / d.g.nx, x = ka - rowa * d.g.nx, y = rowa % d.g.ny, z = rowa / d.g.ny;
+    const int a0 = start[a], na = start[a + 1] - a0;
+    int ra = cg_find<LDS>(par, a);
+    float4 alo, ahi; bool have_box = false;
+    for (int dz = 0; dz <= RING; ++dz) {
+      if (z + dz >= d.g.nz) break;
+      for (int dy = (dz == 0 ? 0 : -RING); dy <= RING; ++dy) {
+        if ((unsigned)(y + dy) >= (unsigned)d.g.ny) continue;
+        const bool edge_row = dz == RING || abs(dy) == RING;   // every cell of this row lies on the ring
+        int lo, hi; row_cells(d.g, key, rows, max(x - RING, 0), min(x + RING, d.g.nx - 1), y + dy, z + dz, lo, hi);
+        if (lo >= hi) continue;
+        // ≤ 2·RING+1 ≤ 5 cells in the run: filter on LDS data only, then fetch the survivors' boxes together
+        const int rowbase = ((z + dz) * d.g.ny + (y + dy)) * d.g.nx + x;
+        int cb[5]; float4 blo[5], bhi[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          int b = lo + u; cb[u] = -1;
+          if (b < hi) {
+            const int dx = key[b] - rowbase;
+            const bool fwd = !(dz == 0 && dy == 0 && dx <= 0);      // forward half: each unordered pair once
+            const bool ring = edge_row || abs(dx) == RING;           // inner cells belong to the previous pass
+            if (fwd && ring && cg_find<LDS>(par, b) != ra) cb[u] = b;
+          }
+        }
+        if (cb[0] < 0 && cb[1] < 0 && cb[2] < 0 && cb[3] < 0 && cb[4] < 0) continue;
+        if (!have_box) { alo = d.cbox_lo[so_ + a]; ahi = d.cbox_hi[so_ + a]; have_box = true; }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) if (cb[u] >= 0) { blo[u] = d.cbox_lo[so_ + cb[u]]; bhi[u] = d.cbox_hi[so_ + cb[u]]; }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int b = cb[u];
+          if (b < 0) continue;
+          // boxes of the two cells' points: gap ≥ r ⇒ no edge; farthest corners < r ⇒ every pair is an edge
+          float gx = fmaxf(fmaxf(blo[u].x - ahi.x, alo.x - bhi[u].x), 0.f), gy = fmaxf(fmaxf(blo[u].y - ahi.y, alo.y - bhi[u].y), 0.f), gz = fmaxf(fmaxf(blo[u].z - ahi.z, alo.z - bhi[u].z), 0.f);
+          if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) continue;
+          float sx = fmaxf(bhi[u].x - alo.x, ahi.x - blo[u].x), sy = fmaxf(bhi[u].y - alo.y, ahi.y - blo[u].y), sz = fmaxf(bhi[u].z - alo.z, ahi.z - blo[u].z);
+          bool edge = (sx * sx + sy * sy + sz * sz) * 1.001f < r2;
+          if (!edge) {
+            if (u > 0 && cg_find<LDS>(par, b) == ra) continue;         // an earlier union of this row may have merged it
+            const int b0 = start[b], nb = start[b + 1] - b0;
+            if ((long long)na * nb > 256) {                             // big × big: leave it to a whole wave
+              int slot = atomicAdd(l_nlist, 1);
+              if (slot < CG_LIST) { l_list[2 * slot] = a; l_list[2 * slot + 1] = b; continue; }
+            }
+            edge = pair_hit_serial(sp, a0, na, b0, nb, r2);
+          }
+          if (edge) ra = cg_unite<LDS>(par, ra, b);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // deferred pairs: one wave each — root re-check, box rejection, tiled exhaustive test
+  const int nl = min(*l_nlist, CG_LIST), lane = lane_id();
+  for (int h = wave_id(); h < nl; h += CG_T / 64) {
+    const int a = l_list[2 * h], b = l_list[2 * h + 1];
+    if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;
+    const size_t so = (size_t)s * d.Nmax;
+    const float4 alo = d.cbox_lo[so + a], ahi = d.cbox_hi[so + a], blo = d.cbox_lo[so + b], bhi = d.cbox_hi[so + b];
+    float gx = fmaxf(fmaxf(blo.x - ahi.x, alo.x - bhi.x), 0.f), gy = fmaxf(fmaxf(blo.y - ahi.y, alo.y - bhi.y), 0.f), gz = fmaxf(fmaxf(blo.z - ahi.z, alo.z - bhi.z), 0.f);
+    if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) continue;
+    if (pair_hit_wave(sp, start[a], start[a + 1] - start[a], start[b], start[b + 1] - start[b], r2, lane) && lane == 0) cg_unite<LDS>(par, a, b);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *l_nlist = 0;
+  __syncthreads();
+}
+
+#ifdef MOR_EXP_STAMPS
+#define CG_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) d.dbg[(size_t)s * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define CG_STAMP(i)
+#endif
+template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int s, int nocc, const int *key, const int *start, const int *rows, int *par,
+                                                              int *size, int *mn, int *cidr, int *l_list, int *l_nlist, int *l_misc) {
+  const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
+  const float4 *sp = d.sorted + so;
+  const int lane = lane_id();
+  CG_STAMP(1);
+  // ---- boxes of the cells' points: small cells by one thread, big ones by a wave
+  for (int c = threadIdx.x; c < nocc; c += CG_T) {
+    const int b = start[c], e = start[c + 1];
+    if (e - b > 16) { int slot = atomicAdd(l_nlist, 1); if (slot < 2 * CG_LIST) { l_list[slot] = c; continue; } }
+    float lx = FLT_MAX, ly = FLT_MAX, lz = FLT_MAX, hx = -FLT_MAX, hy = -FLT_MAX, hz = -FLT_MAX;
+    for (int k = b; k < e; k += 4) {
+      float4 p0 = sp[k], p1 = sp[min(k + 1, e - 1)], p2 = sp[min(k + 2, e - 1)], p3 = sp[min(k + 3, e - 1)];
+      lx = fminf(fminf(lx, p0.x), fminf(p1.x, fminf(p2.x, p3.x))); ly = fminf(fminf(ly, p0.y), fminf(p1.y, fminf(p2.y, p3.y))); lz = fminf(fminf(lz, p0.z), fminf(p1.z, fminf(p2.z, p3.z)));
+      hx = fmaxf(fmaxf(hx, p0.x), fmaxf(p1.x, fmaxf(p2.x, p3.x))); hy = fmaxf(fmaxf(hy, p0.y), fmaxf(p1.y, fmaxf(p2.y, p3.y))); hz = fmaxf(fmaxf(hz, p0.z), fmaxf(p1.z, fmaxf(p2.z, p3.z)));
+    }
+    d.cbox_lo[so + c] = make_float4(lx, ly, lz, 0.f); d.cbox_hi[so + c] = make_float4(hx, hy, hz, 0.f);
+  }
+  __syncthreads();
+  {
+    const int nl = min(*l_nlist, 2 * CG_LIST);
+    for (int h = wave_id(); h < nl; h += CG_T / 64) {
+      const int c = l_list[h]; float4 lo, hi; wave_box(sp, start[c], start[c + 1], lane, lo, hi);
+      if (lane == 0) { d.cbox_lo[so + c] = lo; d.cbox_hi[so + c] = hi; }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *l_nlist = 0;
+  __threadfence_block();
+  __syncthreads();
+  CG_STAMP(2);
+  // ---- hooks: 3×3×3 neighbourhood first, then the 5×5×5 shell (mostly skipped by the root test)
+  cg_hook_pass<LDS>(d, s, nocc, 1, key, start, rows, par, sp, l_list, l_nlist);
+  CG_STAMP(3);
+  cg_hook_pass<LDS>(d, s, nocc, 2, key, start, rows, par, sp, l_list, l_nlist);
+  CG_STAMP(4);
+  // ---- components: size (points) and smallest cloud index at the root; `size`/`mn` may alias key/start ⇒ read first
+  constexpr int PER = LDS ? CG_CAP / CG_T : 1;
+  int r_[PER], cnt_[PER];
+  if (LDS) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { int c = threadIdx.x + u * CG_T; r_[u] = -1; cnt_[u] = 0; if (c < nocc) { r_[u] = cg_find<LDS>(par, c); cnt_[u] = start[c + 1] - start[c]; } }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < nocc; c += CG_T) { size[c] = 0; mn[c] = 0x7fffffff; }
+  __syncthreads();
+  if (LDS) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { int c = threadIdx.x + u * CG_T; if (c < nocc) { atomicAdd(&size[r_[u]], cnt_[u]); atomicMin(&mn[r_[u]], d.cmin[so + c]); } }
+  } else {
+    for (int c = threadIdx.x; c < nocc; c += CG_T) { int r = cg_find<LDS>(par, c); atomicAdd(&size[r], start[c + 1] - start[c]); atomicMin(&mn[r], d.cmin[so + c]); }
+  }
+  __syncthreads();
+  CG_STAMP(5);
+  // ---- kept components (:215-216) → scratch list; K
+  if (threadIdx.x == 0) l_misc[0] = 0;
+  __syncthreads();
+  for (int c = threadIdx.x; c < nocc; c += CG_T) {
+    const bool root = LDS ? (cg_ld<LDS>(par + c) == c) : (cg_find<LDS>(par, c) == c);
+    long long n = size[c];
+    if (root && n >= d.min_cs && n <= d.max_cs) {
+      int k = atomicAdd(&l_misc[0], 1);
+      if (k < d.Kcap) { d.kcell[ko + k] = c; d.kroot[ko + k] = mn[c]; d.ksize[ko + k] = (int)n; }
+    }
+  }
+  __syncthreads();
+  int K = l_misc[0];
+  if (K > d.Kcap) { if (threadIdx.x == 0) atomicOr(&d.info[s].flags, 1u); K = d.Kcap; }
+  __syncthreads();
+  // ---- cluster order: size descending, ties by smaller first cloud index; rank by counting
+  for (int c = threadIdx.x; c < nocc; c += CG_T) cidr[c] = -1;
+  __threadfence_block();
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += CG_T) {
+    const int my_sz = d.ksize[ko + k], my_rt = d.kroot[ko + k]; int rank = 0;
+    for (int u = 0; u < K; ++u) { int sz = d.ksize[ko + u], rt = d.kroot[ko + u]; rank += (sz > my_sz) || (sz == my_sz && rt < my_rt); }
+    cidr[d.kcell[ko + k]] = rank;
+    d.csz[ko + rank] = my_sz;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- per-cell cluster id (a cell is a clique ⇒ one cluster) and root
+  for (int c = threadIdx.x; c < nocc; c += CG_T) { int r = cg_find<LDS>(par, c); d.croot[so + c] = r; d.ccid[so + c] = cidr[r]; }
+  // ---- cluster offsets (exclusive scan of sizes in cluster order), C, clear detection_results (:250-254)
+  int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1);
+  int carry = 0;
+  for (int b = 0; b < K; b += CG_T) {
+    int k = b + threadIdx.x, v = k < K ? d.csz[ko + k] : 0;
+    int inc = wave_incl_scan(v);
+    if (lane == 63) l_misc[1 + wave_id()] = inc;
+    __syncthreads();
+    int basew = 0, tot = 0;
+    for (int w = 0; w < CG_T / 64; ++w) { int xw = l_misc[1 + w]; if (w < wave_id()) basew += xw; tot += xw; }
+    __syncthreads();
+    if (k < K) { off[k] = carry + basew + inc - v; d.det[ko + k] = 0; d.pair_of_cur[ko + k] = -1; }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) { off[K] = carry; d.info[s].C = carry; d.info[s].K = K; }
+  CG_STAMP(6);
+}
+
+__global__ __launch_bounds__(CG_T) void k_cellgraph(MorDev d) {
+  const int s = blockIdx.x + d.s0, nocc = d.info[s].n_occ;
+#ifdef MOR_EXP_STAMPS
+  if (threadIdx.x == 0) d.dbg[(size_t)s * 16 + 0] = wall_clock64();
+#endif
+  __shared__ int l_key[CG_CAP], l_start[CG_CAP + 1], l_par[CG_CAP], l_rows[CG_ROWCAP + 1], l_list[2 * CG_LIST], l_nlist, l_misc[1 + CG_T / 64];
+  const size_t so = (size_t)s * d.Nmax;
+  const int *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1);
+  const int *rows = g_rows;
+  if (threadIdx.x == 0) l_nlist = 0;
+  if (d.g.nrows + 1 <= CG_ROWCAP + 1) { for (int i = threadIdx.x; i <= d.g.nrows; i += CG_T) l_rows[i] = g_rows[i]; rows = l_rows; }
+  if (nocc <= CG_CAP) {
+    const int *gk = d.ckey + so, *gs = d.cstart + (size_t)s * (d.Nmax + 1);
+    for (int i = threadIdx.x; i < nocc; i += CG_T) { l_key[i] = gk[i]; l_start[i] = gs[i]; l_par[i] = i; }
+    if (threadIdx.x == 0) l_start[nocc] = gs[nocc];
+    __syncthreads();
+    cg_body<true>(d, s, nocc, l_key, l_start, rows, l_par, l_key, l_start, l_key, l_list, &l_nlist, l_misc);
+  } else {
+    __syncthreads();
+    cg_body<false>(d, s, nocc, d.ckey + so, d.cstart + (size_t)s * (d.Nmax + 1), rows, d.parent + so, d.csize + so, d.compmin + so, d.cid_of_root + so, l_list, &l_nlist, l_misc);
+  }
+}
+
 // cluster order: size descending, ties by smaller first cloud index (kroot).  K is small: rank by counting.
 __global__ __launch_bounds__(MOR_BT) void k_rank(MorDev d) {
-  int s = blockIdx.y, K = d.info[s].K;
+  int s = blockIdx.y + d.s0, K = d.info[s].K;
   int k = blockIdx.x * MOR_BT + threadIdx.x;
   if (blockIdx.x * MOR_BT >= K) return;
   const int *kr = d.kroot + (size_t)s * d.Kcap, *ks = d.ksize + (size_t)s * d.Kcap;
@@ -473,7 +756,7 @@ __global__ __launch_bounds__(MOR_BT) void k_rank(MorDev d) {
 }
 // cluster offsets (exclusive scan of sizes in cluster order), C, clear detection_results (:250-254)
 __global__ __launch_bounds__(MOR_BT) void k_offsets(MorDev d) {
-  int s = blockIdx.x, K = d.info[s].K; __shared__ int sh[8]; int carry = 0;
+  int s = blockIdx.x + d.s0, K = d.info[s].K; __shared__ int sh[8]; int carry = 0;
   int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1);
   const int *sz = d.csz + (size_t)s * d.Kcap;
   for (int b = 0; b < K; b += MOR_BT) {
@@ -493,12 +776,10 @@ __global__ __launch_bounds__(MOR_BT) void k_label(MorDev d) {
   for (int js = base + threadIdx.x; js < min(base + MOR_TILE, M); js += MOR_BT) {
     float4 q = d.sorted[so + js];
     int i = __float_as_int(q.w);
-    int cid = d.cid_of_root[so + d.croot[so + d.cell_of[so + i]]];
+    int cid = d.ccid[so + d.cell_of[so + i]];   // one cluster per cell (clique)
     q.w = __int_as_float(cid);
     d.sorted[so + js] = q;
     d.pcid[so + i] = cid;
-    const int c = d.cell_of[so + i];
-    if (d.cstart[(size_t)s * (d.Nmax + 1) + c] == js) d.ccid[so + c] = cid;   // one cluster per cell (clique)
   }
 }
 
@@ -528,7 +809,7 @@ __global__ __launch_bounds__(MOR_BT) void k_rhist(MorDev d, MorRadix j) {
 }
 // one workgroup per stream, one thread per digit: offsets[tile][digit] = Σ smaller digits + Σ earlier tiles
 __global__ __launch_bounds__(MOR_BT) void k_rscan(MorDev d) {
-  int s = blockIdx.x; __shared__ int sh[8];
+  int s = blockIdx.x + d.s0; __shared__ int sh[8];
   int *h = d.rhist + (size_t)s * d.tiles_max * 256;
   int run = 0;
   for (int t = 0; t < d.tiles; ++t) { int v = h[t * 256 + threadIdx.x]; h[t * 256 + threadIdx.x] = run; run += v; }
@@ -601,7 +882,7 @@ __device__ __forceinline__ void red6_block(Red6 &r, Red6 *sh) {
 // one workgroup per cluster (grid-stride): copy member points (:224-230), centroid = Σ(double)p / n
 // cast to fp32 (:239-243), AABB for the volume gate.  Fixed reduction tree ⇒ run-to-run identical.
 __global__ __launch_bounds__(MOR_BT) void k_stats(MorDev d) {
-  int s = blockIdx.y, K = d.info[s].K;
+  int s = blockIdx.y + d.s0, K = d.info[s].K;
   const size_t so = (size_t)s * d.Nmax;
   const int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1);
   __shared__ Red6 sh[MOR_BT / 64];
@@ -633,7 +914,7 @@ __device__ __forceinline__ void xform(const float *m, float &x, float &y, float 
   z = ((m[8] * a + m[9] * b) + m[10] * c) + m[11];
 }
 __global__ __launch_bounds__(MOR_BT) void k_xform_prev(MorDev d) {
-  int s = blockIdx.y, pv = d.cur ^ 1, K = d.info[s].Kprev;
+  int s = blockIdx.y + d.s0, pv = d.cur ^ 1, K = d.info[s].Kprev;
   const size_t so = (size_t)s * d.Nmax;
   const int *off = d.cl_off[pv] + (size_t)s * (d.Kcap + 1);
   __shared__ Red6 sh[MOR_BT / 64];
@@ -666,7 +947,7 @@ __global__ __launch_bounds__(MOR_BT) void k_xform_prev(MorDev d) {
 // dir 0: nearest current centroid of every previous centroid; dir 1: the reverse.  Squared fp32
 // distance, ties → lowest index (ascending scan with strict <).
 __global__ __launch_bounds__(MOR_BT) void k_nn_centroid(MorDev d, int dir) {
-  int s = blockIdx.y, pv = d.cur ^ 1;
+  int s = blockIdx.y + d.s0, pv = d.cur ^ 1;
   int Ksrc = dir == 0 ? d.info[s].Kprev : d.info[s].K, Kdst = dir == 0 ? d.info[s].K : d.info[s].Kprev;
   if (blockIdx.x * MOR_BT >= Ksrc) return;
   const float4 *src = d.centroid[dir == 0 ? pv : d.cur] + (size_t)s * d.Kcap, *dst = d.centroid[dir == 0 ? d.cur : pv] + (size_t)s * d.Kcap;
@@ -688,7 +969,7 @@ __global__ __launch_bounds__(MOR_BT) void k_nn_centroid(MorDev d, int dir) {
 }
 // reciprocal test + volumeConstraint (:264-283), correspondences emitted in source-index order
 __global__ __launch_bounds__(MOR_BT) void k_pairs(MorDev d) {
-  int s = blockIdx.x, pv = d.cur ^ 1, Kp = d.info[s].Kprev, Kc = d.info[s].K;
+  int s = blockIdx.x + d.s0, pv = d.cur ^ 1, Kp = d.info[s].Kprev, Kc = d.info[s].K;
   __shared__ int sh[8]; int carry = 0;
   const size_t ko = (size_t)s * d.Kcap;
   for (int b = 0; b < Kp; b += MOR_BT) {
@@ -835,7 +1116,7 @@ __device__ __forceinline__ float wave_scan_cell(const float4 *sp, int b0, int e0
   return wave_min(local);
 }
 __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
-  int s = blockIdx.y, pv = d.cur ^ 1, nq = d.wl_n[s];
+  int s = blockIdx.y + d.s0, pv = d.cur ^ 1, nq = d.wl_n[s];
   const int wv = blockIdx.x * (MOR_BT / 64) + wave_id(), nw = gridDim.x * (MOR_BT / 64), lane = lane_id();
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
@@ -924,7 +1205,7 @@ __device__ __forceinline__ bool vox_key(const MorDev &d, int s, int pr, float4 p
   return ok;
 }
 __global__ __launch_bounds__(MOR_BT) void k_vox_clear(MorDev d) {
-  int s = blockIdx.y, H = vox_table_size(d, d.info[s].Cprev);
+  int s = blockIdx.y + d.s0, H = vox_table_size(d, d.info[s].Cprev);
   unsigned long long *tab = d.vox + (size_t)s * d.Hcap;
   for (int i = blockIdx.x * MOR_BT + threadIdx.x; i < H; i += gridDim.x * MOR_BT) tab[i] = VOX_EMPTY;
 }
@@ -964,7 +1245,7 @@ __global__ __launch_bounds__(MOR_BT) void k_vox_probe(MorDev d) {
 // scores → detection_results (:580-606); then everything the host tracker needs goes straight
 // into pinned host memory (a few KB per stream), so the push needs exactly one stream sync.
 __global__ __launch_bounds__(MOR_BT) void k_decide(MorDev d) {
-  int s = blockIdx.x, pv = d.cur ^ 1;
+  int s = blockIdx.x + d.s0, pv = d.cur ^ 1;
   const size_t ko = (size_t)s * d.Kcap;
   MorFrameInfo f = d.info[s];
   int np = d.has_prev ? (int)f.n_pairs : 0;
@@ -995,7 +1276,7 @@ __global__ __launch_bounds__(MOR_BT) void k_decide(MorDev d) {
 // keep = cloud points whose cluster is not flagged moving (ExtractIndices negative, set semantics;
 // the per-stream error flag reproduces "more indices than points ⇒ empty output"), then ground.
 __device__ __forceinline__ bool out_keep(const MorDev &d, int s, size_t so, int i) {
-  if (d.moving[(size_t)d.B * d.Kcap + s]) return false;
+  if (d.moving[(size_t)d.Btot * d.Kcap + s]) return false;
   int cid = d.pcid[so + i];   // cluster id per cloud point (written by k_label)
   return !(cid >= 0 && d.moving[(size_t)s * d.Kcap + cid]);
 }
@@ -1011,7 +1292,7 @@ __global__ __launch_bounds__(MOR_BT) void k_out_count(MorDev d) {
   if (threadIdx.x == 0) d.otile_cnt[(size_t)s * d.tiles_max + t] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 __global__ __launch_bounds__(MOR_BT) void k_out_scan(MorDev d) {
-  int s = blockIdx.x; __shared__ int sh[8]; int carry = 0;
+  int s = blockIdx.x + d.s0; __shared__ int sh[8]; int carry = 0;
   int *c = d.otile_cnt + (size_t)s * d.tiles_max;
   for (int b = 0; b < d.tiles; b += MOR_BT) {
     int t = b + threadIdx.x, v = t < d.tiles ? c[t] : 0, tot;
@@ -1073,15 +1354,22 @@ void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   MOR_LAUNCH(MK_HEADS_SCAN, k_heads_scan, gB, d);
   MOR_LAUNCH(MK_HEADS_SCATTER, k_heads_scatter, gT, d);
   MOR_LAUNCH(MK_ROWTABLE, k_rowtable, dim3((d.g.nrows + MOR_BT) / MOR_BT > 32 ? 32 : (d.g.nrows + MOR_BT) / MOR_BT, d.B), d);
-  MOR_LAUNCH(MK_CELLBOX, k_cellbox, gW, d);
-  MOR_LAUNCH(MK_HOOK_NEAR, k_hook_cells, gW, d, 0);
-  MOR_LAUNCH(MK_HOOK_SHELL, k_hook_cells, gW, d, 1);
-  MOR_LAUNCH(MK_FLATTEN, k_flatten, dim3(32, d.B), d);
-  MOR_LAUNCH(MK_SELECT_COUNT, k_select_count, gT, d);
-  MOR_LAUNCH(MK_SELECT_SCAN, k_select_scan, gB, d);
-  MOR_LAUNCH(MK_SELECT_SCATTER, k_select_scatter, gT, d);
-  MOR_LAUNCH(MK_RANK, k_rank, gKt, d);
-  MOR_LAUNCH(MK_OFFSETS, k_offsets, gB, d);
+  if (!getenv("MOR_EXP_GENERAL_CC")) {
+    mor_timer_begin(tm, MK_CELLGRAPH, st);
+    hipLaunchKernelGGL(k_cellgraph, gB, dim3(CG_T), 0, st, d);
+    mor_timer_end(tm, MK_CELLGRAPH, st);
+  } else {
+    MOR_LAUNCH(MK_CELLBOX, k_cellbox, gW, d);
+    MOR_LAUNCH(MK_HOOK_NEAR, k_hook_cells, gW, d, 0);
+    MOR_LAUNCH(MK_HOOK_SHELL, k_hook_cells, gW, d, 1);
+    MOR_LAUNCH(MK_FLATTEN, k_flatten, dim3(32, d.B), d);
+    MOR_LAUNCH(MK_SELECT_COUNT, k_select_count, gT, d);
+    MOR_LAUNCH(MK_SELECT_SCAN, k_select_scan, gB, d);
+    MOR_LAUNCH(MK_SELECT_SCATTER, k_select_scatter, gT, d);
+    MOR_LAUNCH(MK_RANK, k_rank, gKt, d);
+    MOR_LAUNCH(MK_OFFSETS, k_offsets, gB, d);
+    MOR_LAUNCH(MK_CELLCID, k_cellcid, dim3(32, d.B), d);
+  }
   MOR_LAUNCH(MK_LABEL, k_label, gT, d);
   for (int pass = 0; pass < d.radix_passes; ++pass) {   // clustered points partitioned by cluster id, index order kept ⇒ cluster_indices
     const bool last = pass == d.radix_passes - 1;

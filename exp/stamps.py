@@ -1,0 +1,17 @@
+import ctypes as C, os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["MOR_HIP_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmor_stamps.so")
+from dynamicslamtool_amd import engine, kitti_params, synth
+B = 64
+p = kitti_params(1)
+b = engine.MorBatch(p, B, 120000)
+for f in range(4):
+    xs, ps = synth.batch([2000 + s for s in range(B)], [f] * B)
+    b.push(list(xs), ps); b.filter(to_host=False)
+L = engine.lib(); L.mor_exp_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
+out = np.zeros((B, 16), np.uint64); L.mor_exp_read_stamps(b._h, out.ctypes.data)
+d = np.diff(out[:, :7].astype(np.int64), axis=1) / 100.0   # 100 MHz → µs
+names = ["load", "boxes", "near", "shell", "comp", "select+rank+off"]
+print("per-phase µs: mean / max over streams")
+for i, n in enumerate(names): print("  %-16s %8.1f %8.1f" % (n, d[:, i].mean(), d[:, i].max()))
+print("total mean %.1f max %.1f; kernel span %.1f" % (d.sum(1).mean(), d.sum(1).max(), (out[:, 6].max() - out[:, 0].min()) / 100.0))
