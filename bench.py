@@ -93,11 +93,13 @@ def main():
         k = step % period
         return k if k < n_frames else period - k
 
+    views = [batch.make_views([(buf.ptr + (f * B + s) * cloud_bytes, npts) for s in range(B)]) for f in range(n_frames)]
+    poses = np.ascontiguousarray(poses)
+
     def run_step(step):
         f = frame_of(step)
-        clouds = [(buf.ptr + (f * B + s) * cloud_bytes, npts) for s in range(B)]
-        batch.push(clouds, poses[f])
-        return batch.filter(to_host=False)
+        batch.push_views(views[f], poses[f])
+        return batch.filter_device()
 
     for i in range(args.warmup):
         run_step(i)
@@ -111,7 +113,7 @@ def main():
         n_out = run_step(args.warmup + i)
         a, b_ = batch.last_timing()
         dev_ms += a + b_
-        n_out_total += sum(n_out)
+        n_out_total += sum(n_out[s] for s in range(B))
     batch.synchronize()
     if dist:
         dist.barrier()

@@ -50,11 +50,13 @@ struct MorDev {
   long long min_cs, max_cs;
   float pde_lb, pde_ub;
   double pde_thr, vol_thr, opc_res;
-  int method, opc_norm, score_R, n_rows;
+  int method, opc_norm, score_R, n_rows, t1_budget;
   const signed char *row_order; // [n_rows][2] (dy,dz) of the method-1 search stencil, nearest rows first
   MorGrid g;
   // ---- per call
   int tiles;                 // ceil(max n_points of this batch / MOR_TILE)
+  int tiles_m;               // workgroups per stream for kernels over the non-ground cloud / clusters: an estimate from the
+                             // previous frame; those kernels grid-stride over the tiles a stream really has, so any value ≥ 1 is correct
   int cur, has_prev;         // frame slot of cb (ca = cur^1); whether ca exists (:534)
   // ---- device arrays (per-stream stride noted)
   const MorStreamArgs *args; // [B]

@@ -60,7 +60,7 @@ struct mor_batch {
   hipStream_t gst[MOR_MAX_GROUPS] = {};
   hipEvent_t gev[MOR_MAX_GROUPS][2] = {};
   bool use_graphs = true;
-  struct GraphKey { int kind, g, cur, has_prev, tiles, outp; bool operator<(const GraphKey &o) const { return std::tie(kind, g, cur, has_prev, tiles, outp) < std::tie(o.kind, o.g, o.cur, o.has_prev, o.tiles, o.outp); } };
+  struct GraphKey { int kind, g, cur, has_prev, tiles, tiles_m, outp; bool operator<(const GraphKey &o) const { return std::tie(kind, g, cur, has_prev, tiles, tiles_m, outp) < std::tie(o.kind, o.g, o.cur, o.has_prev, o.tiles, o.tiles_m, o.outp); } };
   std::map<GraphKey, hipGraphExec_t> graphs;
   MorDev d;                                  // template descriptor (static part + pointers)
   std::vector<void *> dev_allocs, host_allocs;
@@ -133,6 +133,7 @@ static int configure(mor_batch *b) {
   d.cell_passes = (d.g.keybits + 7) / 8;
   d.g.ox = -p.trim_x; d.g.oy = -p.trim_y; d.g.oz = zlo; d.g.cs = cs; d.g.inv_cs = 1.0f / cs;
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
+  d.t1_budget = getenv("MOR_T1_BUDGET") ? atoi(getenv("MOR_T1_BUDGET")) : 256;
   if (d.score_R > 60) return set_error(MOR_ERR_INVALID, "pde_ub %g needs a %d-cell search radius (> 60)", (double)p.pde_ub, d.score_R);
   int bits = 1; while ((1 << bits) < d.Kcap) ++bits;
   d.radix_passes = (bits + 7) / 8;
@@ -152,7 +153,7 @@ template <class Pre> static int run_groups(mor_batch *b, const MorDev &d, int ki
     int rc = pre(g, st, dg); if (rc != MOR_OK) return rc;
     HIP_TRY(hipEventRecord(b->gev[g][0], st));
     if (graphs) {
-      mor_batch::GraphKey key{kind, g, d.cur, d.has_prev, d.tiles, d.out_ptrs ? 1 : 0};
+      mor_batch::GraphKey key{kind, g, d.cur, d.has_prev, d.tiles, d.tiles_m, d.out_ptrs ? 1 : 0};
       auto it = b->graphs.find(key);
       if (it == b->graphs.end()) {
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
@@ -301,6 +302,11 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   }
   d.tiles = std::max<int>(1, (int)((maxn + MOR_TILE - 1) / MOR_TILE));
   d.cur = (int)(b->frame & 1); d.has_prev = b->frame > 0; d.out_ptrs = nullptr;
+  {  // workgroups for the cloud-sized kernels: 1.25 × the largest cloud / cluster set of the previous frame
+    uint32_t mx = 0;
+    if (b->frame > 0) for (int s = 0; s < B; ++s) mx = std::max(mx, std::max(d.h_info[s].M, d.h_info[s].C));
+    d.tiles_m = b->frame > 0 ? std::min<int>(d.tiles, (int)(((uint64_t)mx * 5 / 4 + MOR_TILE - 1) / MOR_TILE) + 1) : d.tiles;
+  }
   const int Bg = B / b->G;
   auto pre = [&](int g, hipStream_t st, const MorDev &) -> int {
     for (int s = g * Bg; s < (g + 1) * Bg; ++s) {   // host-resident blobs: stage on the group's stream
@@ -311,7 +317,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     return MOR_OK;
   };
   { int rc0 = run_groups(b, d, 0, pre, &b->push_ms); if (rc0 != MOR_OK) return rc0; }
-  b->d.tiles = d.tiles; b->d.cur = d.cur; b->d.has_prev = d.has_prev;
+  b->d.tiles = d.tiles; b->d.tiles_m = d.tiles_m; b->d.cur = d.cur; b->d.has_prev = d.has_prev;
   int rc = MOR_OK;
   std::vector<float> cent;
   for (int s = 0; s < B; ++s) {

@@ -221,58 +221,64 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
 // (the sort itself is the generic radix below: k_rhist / k_rscan / k_rscatter)
 __device__ __forceinline__ bool is_head(const int *skey, int p) { return p == 0 || skey[p] != skey[p - 1]; }
 __global__ __launch_bounds__(MOR_BT) void k_heads_count(MorDev d) {
-  int s, t; map_block(d.B, d.tiles, s, t);
-  int M = d.info[s].M, base = t * MOR_TILE, c = 0;
+  int s, t0; map_block(d.B, d.tiles_m, s, t0);
+  const int M = d.info[s].M;
   const int *skey = d.skey + (size_t)s * d.Nmax;
-  for (int p = base + threadIdx.x; p < min(base + MOR_TILE, M); p += MOR_BT) c += is_head(skey, p);
-  __shared__ int sh[8]; int tot;
-  block_excl_scan(c, sh, &tot);
-  if (threadIdx.x == 0) d.ktile_cnt[(size_t)s * d.tiles_max + t] = tot;
+  __shared__ int sh[8];
+  for (int t = t0; t * MOR_TILE < M; t += d.tiles_m) {   // grid-stride over the tiles this stream really has
+    int base = t * MOR_TILE, c = 0, tot;
+    for (int p = base + threadIdx.x; p < min(base + MOR_TILE, M); p += MOR_BT) c += is_head(skey, p);
+    block_excl_scan(c, sh, &tot);
+    if (threadIdx.x == 0) d.ktile_cnt[(size_t)s * d.tiles_max + t] = tot;
+  }
 }
 __global__ __launch_bounds__(MOR_BT) void k_heads_scan(MorDev d) {
   int s = blockIdx.x + d.s0; __shared__ int sh[8]; int carry = 0;
   int *c = d.ktile_cnt + (size_t)s * d.tiles_max;
-  for (int b = 0; b < d.tiles; b += MOR_BT) {
-    int t = b + threadIdx.x, v = t < d.tiles ? c[t] : 0, tot;
+  const int nt = (d.info[s].M + MOR_TILE - 1) / MOR_TILE;
+  for (int b = 0; b < nt; b += MOR_BT) {
+    int t = b + threadIdx.x, v = t < nt ? c[t] : 0, tot;
     int e = block_excl_scan(v, sh, &tot);
-    if (t < d.tiles) c[t] = carry + e;
+    if (t < nt) c[t] = carry + e;
     carry += tot;
   }
   if (threadIdx.x == 0) { d.info[s].n_occ = carry; d.cstart[(size_t)s * (d.Nmax + 1) + carry] = d.info[s].M; }
 }
 // per sorted position: compact cell id; heads publish the cell; every point lands in `sorted`
 __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
-  int s, t; map_block(d.B, d.tiles, s, t);
-  int M = d.info[s].M, tb = t * MOR_TILE;
-  if (tb >= M) return;
+  int s, t0; map_block(d.B, d.tiles_m, s, t0);
+  const int M = d.info[s].M;
   const size_t so = (size_t)s * d.Nmax;
   const int *skey = d.skey + so, *sidx = d.sidx + so;
   int *cstart = d.cstart + (size_t)s * (d.Nmax + 1);
-  const int base = tb + wave_id() * 512;
-  unsigned long long mh[8]; int cnt = 0;
-#pragma unroll
-  for (int it = 0; it < 8; ++it) { int p = base + it * 64 + lane_id(); mh[it] = __ballot(p < M && is_head(skey, p)); cnt += __popcll(mh[it]); }
   __shared__ int sh[4];
-  if (lane_id() == 0) sh[wave_id()] = cnt;
-  __syncthreads();
-  int r = d.ktile_cnt[(size_t)s * d.tiles_max + t];
-  for (int w = 0; w < wave_id(); ++w) r += sh[w];
+  for (int t = t0; t * MOR_TILE < M; t += d.tiles_m) {
+    const int base = t * MOR_TILE + wave_id() * 512;
+    unsigned long long mh[8]; int cnt = 0;
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    int p = base + it * 64 + lane_id();
-    if (p < M) {
-      bool head = (mh[it] >> lane_id()) & 1ull;
-      int c = r + __popcll(mh[it] & lanemask_lt()) + (head ? 1 : 0) - 1;
-      int i = sidx[p];
-      if (head) {
-        d.ckey[so + c] = skey[p]; cstart[c] = p; d.cmin[so + c] = i;   // stable sort ⇒ first of the cell = smallest cloud index
-        d.parent[so + c] = c; d.csize[so + c] = 0; d.compmin[so + c] = 0x7fffffff; d.cid_of_root[so + c] = -1;
+    for (int it = 0; it < 8; ++it) { int p = base + it * 64 + lane_id(); mh[it] = __ballot(p < M && is_head(skey, p)); cnt += __popcll(mh[it]); }
+    if (lane_id() == 0) sh[wave_id()] = cnt;
+    __syncthreads();
+    int r = d.ktile_cnt[(size_t)s * d.tiles_max + t];
+    for (int w = 0; w < wave_id(); ++w) r += sh[w];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      int p = base + it * 64 + lane_id();
+      if (p < M) {
+        bool head = (mh[it] >> lane_id()) & 1ull;
+        int c = r + __popcll(mh[it] & lanemask_lt()) + (head ? 1 : 0) - 1;
+        int i = sidx[p];
+        if (head) {
+          d.ckey[so + c] = skey[p]; cstart[c] = p; d.cmin[so + c] = i;   // stable sort ⇒ first of the cell = smallest cloud index
+          d.parent[so + c] = c; d.csize[so + c] = 0; d.compmin[so + c] = 0x7fffffff; d.cid_of_root[so + c] = -1;
+        }
+        d.cell_of[so + i] = c;
+        float4 q = d.cloud[so + i]; q.w = __int_as_float(i);
+        d.sorted[so + p] = q;
       }
-      d.cell_of[so + i] = c;
-      float4 q = d.cloud[so + i]; q.w = __int_as_float(i);
-      d.sorted[so + p] = q;
+      r += __popcll(mh[it]);
     }
-    r += __popcll(mh[it]);
   }
 }
 // dense (y,z) row table: first occupied cell with key ≥ row·nx
@@ -769,11 +775,10 @@ __global__ __launch_bounds__(MOR_BT) void k_offsets(MorDev d) {
 }
 // per sorted slot: cluster id of its point → pcid[cloud index] and sorted.w
 __global__ __launch_bounds__(MOR_BT) void k_label(MorDev d) {
-  int s, t; map_block(d.B, d.tiles, s, t);
-  int M = d.info[s].M, base = t * MOR_TILE;
-  if (base >= M) return;
+  int s, t0; map_block(d.B, d.tiles_m, s, t0);
+  const int M = d.info[s].M;
   const size_t so = (size_t)s * d.Nmax;
-  for (int js = base + threadIdx.x; js < min(base + MOR_TILE, M); js += MOR_BT) {
+  for (int js = t0 * MOR_BT + threadIdx.x; js < M; js += d.tiles_m * MOR_BT) {
     float4 q = d.sorted[so + js];
     int i = __float_as_int(q.w);
     int cid = d.ccid[so + d.cell_of[so + i]];   // one cluster per cell (clique)
@@ -794,68 +799,79 @@ __device__ __forceinline__ void radix_item(const MorRadix &j, size_t so, int cou
 __device__ __forceinline__ int radix_count(const MorDev &d, const MorRadix &j, int s) { return j.count_sel == 0 ? d.info[s].M : d.info[s].C; }
 
 __global__ __launch_bounds__(MOR_BT) void k_rhist(MorDev d, MorRadix j) {
-  int s, t; map_block(d.B, d.tiles, s, t);
-  int count = radix_count(d, j, s), base = t * MOR_TILE;
+  int s, t0; map_block(d.B, d.tiles_m, s, t0);
+  const int count = radix_count(d, j, s);
   __shared__ int h[256];
-  h[threadIdx.x] = 0;
-  __syncthreads();
   const size_t so = (size_t)s * d.Nmax;
-  for (int i = base + threadIdx.x; i < min(base + MOR_TILE, count); i += MOR_BT) {
-    int key, val; bool valid; radix_item(j, so, count, i, key, val, valid);
-    if (valid) atomicAdd(&h[(key >> j.shift) & 255], 1);
+  for (int t = t0; t * MOR_TILE < count; t += d.tiles_m) {
+    const int base = t * MOR_TILE;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = base + threadIdx.x; i < min(base + MOR_TILE, count); i += MOR_BT) {
+      int key, val; bool valid; radix_item(j, so, count, i, key, val, valid);
+      if (valid) atomicAdd(&h[(key >> j.shift) & 255], 1);
+    }
+    __syncthreads();
+    d.rhist[((size_t)s * d.tiles_max + t) * 256 + threadIdx.x] = h[threadIdx.x];
   }
-  __syncthreads();
-  d.rhist[((size_t)s * d.tiles_max + t) * 256 + threadIdx.x] = h[threadIdx.x];
 }
 // one workgroup per stream, one thread per digit: offsets[tile][digit] = Σ smaller digits + Σ earlier tiles
-__global__ __launch_bounds__(MOR_BT) void k_rscan(MorDev d) {
+__global__ __launch_bounds__(MOR_BT) void k_rscan(MorDev d, MorRadix j) {
   int s = blockIdx.x + d.s0; __shared__ int sh[8];
-  int *h = d.rhist + (size_t)s * d.tiles_max * 256;
-  int run = 0;
-  for (int t = 0; t < d.tiles; ++t) { int v = h[t * 256 + threadIdx.x]; h[t * 256 + threadIdx.x] = run; run += v; }
+  int *h = d.rhist + (size_t)s * d.tiles_max * 256 + threadIdx.x;
+  const int nt = (radix_count(d, j, s) + MOR_TILE - 1) / MOR_TILE;
+  int run = 0, t = 0;
+  for (; t + 4 <= nt; t += 4) {   // four independent loads per step
+    int v0 = h[t * 256], v1 = h[(t + 1) * 256], v2 = h[(t + 2) * 256], v3 = h[(t + 3) * 256];
+    h[t * 256] = run; run += v0; h[(t + 1) * 256] = run; run += v1; h[(t + 2) * 256] = run; run += v2; h[(t + 3) * 256] = run; run += v3;
+  }
+  for (; t < nt; ++t) { int v = h[t * 256]; h[t * 256] = run; run += v; }
   int tot, base = block_excl_scan(run, sh, &tot);
-  for (int t = 0; t < d.tiles; ++t) h[t * 256 + threadIdx.x] += base;
+  for (t = 0; t < nt; ++t) h[t * 256] += base;
 }
 __global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, MorRadix j) {
-  int s, t; map_block(d.B, d.tiles, s, t);
-  int count = radix_count(d, j, s), tb = t * MOR_TILE;
-  if (tb >= count) return;
+  int s, t0; map_block(d.B, d.tiles_m, s, t0);
+  const int count = radix_count(d, j, s);
   const size_t so = (size_t)s * d.Nmax;
   __shared__ int wcnt[4][256];
-  for (int k = threadIdx.x; k < 4 * 256; k += MOR_BT) (&wcnt[0][0])[k] = 0;
-  __syncthreads();
-  int key[8], val[8], pre[8]; bool valid[8];
-  int base = tb + wave_id() * 512;
+  for (int t = t0; t * MOR_TILE < count; t += d.tiles_m) {
+    const int tb = t * MOR_TILE;
+    for (int k = threadIdx.x; k < 4 * 256; k += MOR_BT) (&wcnt[0][0])[k] = 0;
+    __syncthreads();
+    int key[8], val[8], pre[8]; bool valid[8];
+    int base = tb + wave_id() * 512;
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    int i = base + it * 64 + lane_id();
-    radix_item(j, so, count, i, key[it], val[it], valid[it]);
-    int dg = (key[it] >> j.shift) & 255;
-    unsigned long long peers = __ballot(valid[it]);
+    for (int it = 0; it < 8; ++it) {
+      int i = base + it * 64 + lane_id();
+      radix_item(j, so, count, i, key[it], val[it], valid[it]);
+      int dg = (key[it] >> j.shift) & 255;
+      unsigned long long peers = __ballot(valid[it]);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) { unsigned long long m = __ballot((dg >> b) & 1); peers &= ((dg >> b) & 1) ? m : ~m; }
-    pre[it] = 0;
-    if (valid[it]) {
-      int leader = __ffsll((long long)peers) - 1, rank = __popcll(peers & lanemask_lt()), basec = 0;
-      if (lane_id() == leader) basec = atomicAdd(&wcnt[wave_id()][dg], __popcll(peers));
-      basec = __shfl(basec, leader, 64);
-      pre[it] = basec + rank;
+      for (int b = 0; b < 8; ++b) { unsigned long long m = __ballot((dg >> b) & 1); peers &= ((dg >> b) & 1) ? m : ~m; }
+      pre[it] = 0;
+      if (valid[it]) {
+        int leader = __ffsll((long long)peers) - 1, rank = __popcll(peers & lanemask_lt()), basec = 0;
+        if (lane_id() == leader) basec = atomicAdd(&wcnt[wave_id()][dg], __popcll(peers));
+        basec = __shfl(basec, leader, 64);
+        pre[it] = basec + rank;
+      }
     }
-  }
-  __syncthreads();
-  {  // exclusive prefix over the 4 waves per digit + global offset of (tile, digit)
-    int dg = threadIdx.x, run = d.rhist[((size_t)s * d.tiles_max + t) * 256 + dg];
+    __syncthreads();
+    {  // exclusive prefix over the 4 waves per digit + global offset of (tile, digit)
+      int dg = threadIdx.x, run = d.rhist[((size_t)s * d.tiles_max + t) * 256 + dg];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { int v = wcnt[w][dg]; wcnt[w][dg] = run; run += v; }
-  }
-  __syncthreads();
+      for (int w = 0; w < 4; ++w) { int v = wcnt[w][dg]; wcnt[w][dg] = run; run += v; }
+    }
+    __syncthreads();
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    if (!valid[it]) continue;
-    int dg = (key[it] >> j.shift) & 255;
-    int pos = wcnt[wave_id()][dg] + pre[it];
-    if (j.kout) j.kout[so + pos] = key[it];
-    j.vout[so + pos] = val[it];
+    for (int it = 0; it < 8; ++it) {
+      if (!valid[it]) continue;
+      int dg = (key[it] >> j.shift) & 255;
+      int pos = wcnt[wave_id()][dg] + pre[it];
+      if (j.kout) j.kout[so + pos] = key[it];
+      j.vout[so + pos] = val[it];
+    }
+    __syncthreads();
   }
 }
 
@@ -1048,9 +1064,9 @@ __device__ __forceinline__ void scan_cells(const MorDev &d, size_t so, const int
 // (bound ≥ cs²).  Anything else — or a thread that has scanned its budget — goes to the worklist of
 // tier 2 (k_score_pde, one wave per query).
 __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
-  int s, t; map_block(d.B, d.tiles * 8, s, t);
-  int pv = d.cur ^ 1, Cp = d.info[s].Cprev, base = t * MOR_BT;
-  if (base >= Cp) return;
+  int s, t0; map_block(d.B, d.tiles_m * 8, s, t0);
+  const int pv = d.cur ^ 1, Cp = d.info[s].Cprev;
+  for (int base = t0 * MOR_BT; base < Cp; base += d.tiles_m * 8 * MOR_BT) {
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
@@ -1065,7 +1081,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
       const int target = d.pair_m[ko + pr];
       const float4 q = d.cl_pts[pv][so + j];
       const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.g.oz, d.g.inv_cs);
-      float best = INFINITY; int budget = 256;   // points this thread may scan before handing the query to a wave
+      float best = INFINITY; int budget = d.t1_budget;   // points this thread may scan before handing the query to a wave
       {  // stage 0: the query's own cell — on a static surface a matched point within √lb is almost always here
         int c = cell_lookup(d.g, ckey, rs, cx, cy, cz);
         if (c >= 0 && d.ccid[so + c] == target) scan4(sp, st[c], st[c + 1], q, d.pde_lb, best, budget);
@@ -1092,6 +1108,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
     if (lane_id() == leader) basew = atomicAdd(&d.wl_n[s], __popcll(m));
     basew = __shfl(basew, leader, 64);
     if (defer) d.wl[so + basew + __popcll(m & lanemask_lt())] = j;
+  }
   }
 }
 __device__ __forceinline__ float wave_min(float v) {
@@ -1281,53 +1298,61 @@ __device__ __forceinline__ bool out_keep(const MorDev &d, int s, size_t so, int 
   return !(cid >= 0 && d.moving[(size_t)s * d.Kcap + cid]);
 }
 __global__ __launch_bounds__(MOR_BT) void k_out_count(MorDev d) {
-  int s, t; map_block(d.B, d.tiles, s, t);
-  int M = d.info[s].M, base = t * MOR_TILE + wave_id() * 512, c = 0;
+  int s, t0; map_block(d.B, d.tiles_m, s, t0);
+  const int M = d.info[s].M;
   const size_t so = (size_t)s * d.Nmax;
-#pragma unroll
-  for (int it = 0; it < 8; ++it) { int i = base + it * 64 + lane_id(); c += __popcll(__ballot(i < M && out_keep(d, s, so, i))); }
   __shared__ int sh[4];
-  if (lane_id() == 0) sh[wave_id()] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) d.otile_cnt[(size_t)s * d.tiles_max + t] = sh[0] + sh[1] + sh[2] + sh[3];
+  for (int t = t0; t * MOR_TILE < M; t += d.tiles_m) {
+    int base = t * MOR_TILE + wave_id() * 512, c = 0;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) { int i = base + it * 64 + lane_id(); c += __popcll(__ballot(i < M && out_keep(d, s, so, i))); }
+    if (lane_id() == 0) sh[wave_id()] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) d.otile_cnt[(size_t)s * d.tiles_max + t] = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+  }
 }
 __global__ __launch_bounds__(MOR_BT) void k_out_scan(MorDev d) {
   int s = blockIdx.x + d.s0; __shared__ int sh[8]; int carry = 0;
   int *c = d.otile_cnt + (size_t)s * d.tiles_max;
-  for (int b = 0; b < d.tiles; b += MOR_BT) {
-    int t = b + threadIdx.x, v = t < d.tiles ? c[t] : 0, tot;
+  const int nt = (d.info[s].M + MOR_TILE - 1) / MOR_TILE;
+  for (int b = 0; b < nt; b += MOR_BT) {
+    int t = b + threadIdx.x, v = t < nt ? c[t] : 0, tot;
     int e = block_excl_scan(v, sh, &tot);
-    if (t < d.tiles) c[t] = carry + e;
+    if (t < nt) c[t] = carry + e;
     carry += tot;
   }
   if (threadIdx.x == 0) { d.info[s].n_keep = carry; d.h_nout[s] = (unsigned long long)carry + d.info[s].G; }
 }
-// tiles [0, tiles): kept cloud points; tiles [tiles, 2·tiles): ground points appended after them
+// workgroups [0, tiles_m) per stream: kept cloud points (grid-stride over the cloud's tiles);
+// workgroups [tiles_m, tiles_m + tiles): ground points appended after them
 __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
-  int s, t2; map_block(d.B, 2 * d.tiles, s, t2);
+  int s, t2; map_block(d.B, d.tiles_m + d.tiles, s, t2);
   const size_t so = (size_t)s * d.Nmax;
   float4 *out = d.out_ptrs ? d.out_ptrs[s] : d.out + so;
-  if (t2 >= d.tiles) {
-    int t = t2 - d.tiles, G = d.info[s].G, nk = d.info[s].n_keep, base = t * MOR_TILE;
+  if (t2 >= d.tiles_m) {
+    int t = t2 - d.tiles_m, G = d.info[s].G, nk = d.info[s].n_keep, base = t * MOR_TILE;
     for (int i = base + threadIdx.x; i < min(base + MOR_TILE, G); i += MOR_BT) out[nk + i] = d.ground[so + i];
     return;
   }
-  int t = t2, M = d.info[s].M;
-  if (t * MOR_TILE >= M) return;
-  int base = t * MOR_TILE + wave_id() * 512, c = 0;
-  unsigned long long mk[8];
-#pragma unroll
-  for (int it = 0; it < 8; ++it) { int i = base + it * 64 + lane_id(); mk[it] = __ballot(i < M && out_keep(d, s, so, i)); c += __popcll(mk[it]); }
+  const int M = d.info[s].M;
   __shared__ int sh[4];
-  if (lane_id() == 0) sh[wave_id()] = c;
-  __syncthreads();
-  int r = d.otile_cnt[(size_t)s * d.tiles_max + t];
-  for (int w = 0; w < wave_id(); ++w) r += sh[w];
+  for (int t = t2; t * MOR_TILE < M; t += d.tiles_m) {
+    int base = t * MOR_TILE + wave_id() * 512, c = 0;
+    unsigned long long mk[8];
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    int i = base + it * 64 + lane_id();
-    if ((mk[it] >> lane_id()) & 1ull) out[r + __popcll(mk[it] & lanemask_lt())] = d.cloud[so + i];
-    r += __popcll(mk[it]);
+    for (int it = 0; it < 8; ++it) { int i = base + it * 64 + lane_id(); mk[it] = __ballot(i < M && out_keep(d, s, so, i)); c += __popcll(mk[it]); }
+    if (lane_id() == 0) sh[wave_id()] = c;
+    __syncthreads();
+    int r = d.otile_cnt[(size_t)s * d.tiles_max + t];
+    for (int w = 0; w < wave_id(); ++w) r += sh[w];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      int i = base + it * 64 + lane_id();
+      if ((mk[it] >> lane_id()) & 1ull) out[r + __popcll(mk[it] & lanemask_lt())] = d.cloud[so + i];
+      r += __popcll(mk[it]);
+    }
   }
 }
 
@@ -1340,19 +1365,19 @@ __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
   } while (0)
 
 void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  const dim3 gT(d.B * d.tiles), gB(d.B), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B), gW(getenv("MOR_GW") ? atoi(getenv("MOR_GW")) : 64, d.B);
+  const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B), gW(getenv("MOR_GW") ? atoi(getenv("MOR_GW")) : 64, d.B);
   MOR_LAUNCH(MK_CLASSIFY, k_classify, gT, d);
   MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
   MOR_LAUNCH(MK_SCATTER, k_scatter, gT, d);
   for (int pass = 0; pass < d.cell_passes; ++pass) {   // points sorted by cell key; result in (skey, sidx) = buffers [cell_passes & 1]
     MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0};
-    MOR_LAUNCH(MK_RHIST, k_rhist, gT, d, j);
-    MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d);
-    MOR_LAUNCH(MK_RSCATTER, k_rscatter, gT, d, j);
+    MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
+    MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
+    MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
   }
-  MOR_LAUNCH(MK_HEADS_COUNT, k_heads_count, gT, d);
+  MOR_LAUNCH(MK_HEADS_COUNT, k_heads_count, gM, d);
   MOR_LAUNCH(MK_HEADS_SCAN, k_heads_scan, gB, d);
-  MOR_LAUNCH(MK_HEADS_SCATTER, k_heads_scatter, gT, d);
+  MOR_LAUNCH(MK_HEADS_SCATTER, k_heads_scatter, gM, d);
   MOR_LAUNCH(MK_ROWTABLE, k_rowtable, dim3((d.g.nrows + MOR_BT) / MOR_BT > 32 ? 32 : (d.g.nrows + MOR_BT) / MOR_BT, d.B), d);
   if (!getenv("MOR_EXP_GENERAL_CC")) {
     mor_timer_begin(tm, MK_CELLGRAPH, st);
@@ -1370,13 +1395,13 @@ void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     MOR_LAUNCH(MK_OFFSETS, k_offsets, gB, d);
     MOR_LAUNCH(MK_CELLCID, k_cellcid, dim3(32, d.B), d);
   }
-  MOR_LAUNCH(MK_LABEL, k_label, gT, d);
+  MOR_LAUNCH(MK_LABEL, k_label, gM, d);
   for (int pass = 0; pass < d.radix_passes; ++pass) {   // clustered points partitioned by cluster id, index order kept ⇒ cluster_indices
     const bool last = pass == d.radix_passes - 1;
     MorRadix j = {pass == 0 ? d.pcid : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], last ? nullptr : d.rkeys[(pass + 1) & 1], last ? d.cl_idx : d.rvals[(pass + 1) & 1], 8 * pass, pass == 0 ? 0 : 1, pass == 0 ? 1 : 0};
-    MOR_LAUNCH(MK_RHIST, k_rhist, gT, d, j);
-    MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d);
-    MOR_LAUNCH(MK_RSCATTER, k_rscatter, gT, d, j);
+    MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
+    MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
+    MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
   }
   MOR_LAUNCH(MK_STATS, k_stats, gK, d);
   if (d.has_prev) {
@@ -1385,7 +1410,7 @@ void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     MOR_LAUNCH(MK_NN, k_nn_centroid, gKt, d, 1);
     MOR_LAUNCH(MK_PAIRS, k_pairs, gB, d);
     if (d.method == 1) {
-      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles * 8), d); if (!getenv("MOR_EXP_SKIP_T2")) MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(getenv("MOR_T2G") ? atoi(getenv("MOR_T2G")) : 256, d.B), d); }
+      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * 8), d); if (!getenv("MOR_EXP_SKIP_T2")) MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(getenv("MOR_T2G") ? atoi(getenv("MOR_T2G")) : 256, d.B), d); }
     } else if (d.method == 2) {
       MOR_LAUNCH(MK_VOX_CLEAR, k_vox_clear, dim3(64, d.B), d);
       MOR_LAUNCH(MK_VOX_INSERT, k_vox_insert, gT, d);
@@ -1396,8 +1421,8 @@ void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
 }
 
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  const dim3 gT(d.B * d.tiles), gB(d.B), gT2(d.B * 2 * d.tiles);
-  MOR_LAUNCH(MK_OUT_COUNT, k_out_count, gT, d);
+  const dim3 gM(d.B * d.tiles_m), gB(d.B), gT2(d.B * (d.tiles_m + d.tiles));
+  MOR_LAUNCH(MK_OUT_COUNT, k_out_count, gM, d);
   MOR_LAUNCH(MK_OUT_SCAN, k_out_scan, gB, d);
   MOR_LAUNCH(MK_OUT_SCATTER, k_out_scatter, gT2, d);
 }

@@ -170,6 +170,26 @@ class MorBatch:
         self._keep = keep
         _check(lib().mor_push_batch(self._h, C.addressof(self._views), poses.ctypes.data))
 
+    def make_views(self, clouds, point_step=16, offsets=(0, 4, 8, 12)):
+        """Pre-builds the mor_cloud_view array for device-resident clouds [(ptr|DeviceBuffer, n_points)] × B, so a
+        replay loop pays no per-step Python marshalling (push_views)."""
+        v = (CloudView * self.B)()
+        for s, (buf, n) in enumerate(clouds):
+            v[s].data, v[s].n_points, v[s].on_device = (buf.ptr if isinstance(buf, DeviceBuffer) else int(buf)), int(n), 1
+            v[s].point_step, v[s].off_x, v[s].off_y, v[s].off_z, v[s].off_intensity = point_step, offsets[0], offsets[1], offsets[2], offsets[3]
+        return v
+
+    def push_views(self, views, poses):
+        poses = np.ascontiguousarray(poses, np.float64)
+        _check(lib().mor_push_batch(self._h, C.addressof(views), poses.ctypes.data))
+
+    def filter_device(self):
+        """filterCloud for all streams, results left in the batch's device buffers; returns the n_out array."""
+        if not hasattr(self, "_nout"):
+            self._nout = (C.c_uint64 * self.B)()
+        _check(lib().mor_filter_batch(self._h, None, 0, C.addressof(self._nout)))
+        return self._nout
+
     # ---- filterCloud for all streams
     def filter(self, to_host=True):
         n_out = (C.c_uint64 * self.B)()
