@@ -7,6 +7,7 @@
 
 #define MOR_TILE 2048   // points per workgroup tile: 4 waves × 8 coalesced 1-KiB rows of float4
 #define MOR_BT 256      // threads per workgroup
+#define MOR_CHUNK 2048  // points per work item of the per-cluster reductions
 #define MOR_KGRID 128   // workgroups per stream for per-cluster kernels (grid-stride over clusters)
 
 // Uniform grid over the trim box, keyed by linear cell id (a collision-free spatial hash).
@@ -21,6 +22,8 @@ struct MorGrid {
   float ox, oy, oz, inv_cs, cs;
   int nx, ny, nz, nrows, keybits;
 };
+
+struct Red6 { double sx, sy, sz; float mnx, mny, mnz, mxx, mxy, mxz; };   // partial Σxyz (fp64) + AABB
 
 // one LSD radix pass (8-bit digit) of the stable (key, value) sort
 struct MorRadix {
@@ -92,6 +95,8 @@ struct MorDev {
   float4 *cl_pts[2];         // [B][Nmax]  clusters[k] points, (cluster, index) order (:229); ca's are transformed in place (:550)
   int *cl_cid[2];            // [B][Nmax]  cluster id per cl_pts entry
   int *cl_off[2];            // [B][Kcap+1]
+  int *chunk_off[2];         // [B][Kcap+1]  first reduction chunk of each cluster
+  Red6 *part; int Wcap;      // [B][Wcap]    per-chunk partials (scratch)
   float4 *centroid[2];       // [B][Kcap]  centroid_collection (:243)
   float4 *amin[2], *amax[2]; // [B][Kcap]  cluster AABBs (getMinMax3D, :272-274)
   // pair stage
@@ -125,7 +130,7 @@ struct MorDev {
 enum MorKernelId {
   MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_ROWTABLE, MK_CELLGRAPH, MK_CELLBOX, MK_HOOK_NEAR, MK_HOOK_SHELL, MK_FLATTEN, MK_CELLCID,
   MK_SELECT_COUNT, MK_SELECT_SCAN, MK_SELECT_SCATTER, MK_RANK, MK_OFFSETS, MK_LABEL, MK_RHIST, MK_RSCAN, MK_RSCATTER,
-  MK_STATS, MK_XFORM_PREV, MK_NN, MK_PAIRS, MK_SCORE_FAST, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
+  MK_STATS, MK_STATS_FIN, MK_XFORM_PREV, MK_XFORM_FIN, MK_NN, MK_PAIRS, MK_SCORE_FAST, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
   MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_COUNT
 };
 extern const char *const mor_kernel_names[MK_COUNT];

@@ -250,7 +250,9 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.rhist, B * T * 256) && dalloc(b, d.cl_idx, B * N);
   d.skey = d.rkeys[d.cell_passes & 1]; d.sidx = d.rvals[d.cell_passes & 1];
   for (int i = 0; i < 2; ++i)
-    ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K);
+    ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.chunk_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K);
+  d.Wcap = (int)(N / MOR_CHUNK + K + 2);
+  ok = ok && dalloc(b, d.part, B * (size_t)d.Wcap);
   ok = ok && dalloc(b, d.nn_fwd, B * K) && dalloc(b, d.nn_bwd, B * K) && dalloc(b, d.nn_fwd_d, B * K) && dalloc(b, d.pair_q, B * K) && dalloc(b, d.pair_m, B * K) && dalloc(b, d.pair_d, B * K);
   ok = ok && dalloc(b, d.pair_cnt, B * K) && dalloc(b, d.pair_of_prev, B * K) && dalloc(b, d.pair_of_cur, B * K) && dalloc(b, d.det, B * K);
   if (p->method_choice == 2) ok = ok && dalloc(b, d.vox, B * (size_t)d.Hcap);

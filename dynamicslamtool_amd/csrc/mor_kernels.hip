@@ -28,7 +28,7 @@
 const char *const mor_kernel_names[MK_COUNT] = {
     "classify", "scan_tiles", "scatter", "heads_count", "heads_scan", "heads_scatter", "rowtable", "cellgraph", "cellbox", "hook_near", "hook_shell", "flatten", "cellcid",
     "select_count", "select_scan", "select_scatter", "rank", "offsets", "label", "rhist", "rscan", "rscatter",
-    "stats", "xform_prev", "nn_centroid", "pairs", "score_fast", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
+    "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "pairs", "score_fast", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
     "out_count", "out_scan", "out_scatter"};
 
 // ------------------------------------------------------------------------------------ helpers
@@ -713,6 +713,22 @@ template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int
     carry += tot;
   }
   if (threadIdx.x == 0) { off[K] = carry; d.info[s].C = carry; d.info[s].K = K; }
+  // ---- work items of the per-cluster reductions: cluster k owns ceil(size/MOR_CHUNK) chunks
+  int *coff = d.chunk_off[d.cur] + (size_t)s * (d.Kcap + 1);
+  carry = 0;
+  __syncthreads();
+  for (int b = 0; b < K; b += CG_T) {
+    int k = b + threadIdx.x, v = k < K ? (d.csz[ko + k] + MOR_CHUNK - 1) / MOR_CHUNK : 0;
+    int inc = wave_incl_scan(v);
+    if (lane == 63) l_misc[1 + wave_id()] = inc;
+    __syncthreads();
+    int basew = 0, tot = 0;
+    for (int w = 0; w < CG_T / 64; ++w) { int xw = l_misc[1 + w]; if (w < wave_id()) basew += xw; tot += xw; }
+    __syncthreads();
+    if (k < K) coff[k] = carry + basew + inc - v;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) coff[K] = carry;
   CG_STAMP(6);
 }
 
@@ -772,6 +788,15 @@ __global__ __launch_bounds__(MOR_BT) void k_offsets(MorDev d) {
     carry += tot;
   }
   if (threadIdx.x == 0) { off[K] = carry; d.info[s].C = carry; }
+  int *coff = d.chunk_off[d.cur] + (size_t)s * (d.Kcap + 1);
+  carry = 0;
+  for (int b = 0; b < K; b += MOR_BT) {
+    int k = b + threadIdx.x, v = k < K ? (sz[k] + MOR_CHUNK - 1) / MOR_CHUNK : 0, tot;
+    int e = block_excl_scan(v, sh, &tot);
+    if (k < K) coff[k] = carry + e;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) coff[K] = carry;
 }
 // per sorted slot: cluster id of its point → pcid[cloud index] and sorted.w
 __global__ __launch_bounds__(MOR_BT) void k_label(MorDev d) {
@@ -876,7 +901,6 @@ __global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, MorRadix j) {
 }
 
 // ------------------------------------------------------------------------------------ C2: per-cluster extraction + centroid + AABB
-struct Red6 { double sx, sy, sz; float mnx, mny, mnz, mxx, mxy, mxz; };
 __device__ __forceinline__ void red6_block(Red6 &r, Red6 *sh) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -895,15 +919,24 @@ __device__ __forceinline__ void red6_block(Red6 &r, Red6 *sh) {
   }
   __syncthreads();
 }
-// one workgroup per cluster (grid-stride): copy member points (:224-230), centroid = Σ(double)p / n
-// cast to fp32 (:239-243), AABB for the volume gate.  Fixed reduction tree ⇒ run-to-run identical.
+// Per-cluster reductions are split into chunks of MOR_CHUNK points so a 35 000-point wall does not serialise on one
+// workgroup: work item w = (cluster k, chunk c) with chunk_off[k] ≤ w < chunk_off[k+1].  Partials are combined per
+// cluster in chunk order by one thread — a fixed reduction tree, so centroids are identical from run to run.
+__device__ __forceinline__ int chunk_cluster(const int *coff, int K, int w) {
+  int a = 0, b = K;   // last k with coff[k] ≤ w
+  while (b - a > 1) { int m = (a + b) >> 1; if (coff[m] <= w) a = m; else b = m; }
+  return a;
+}
+// copy member points (:224-230), partial Σ(double)p and AABB per chunk
 __global__ __launch_bounds__(MOR_BT) void k_stats(MorDev d) {
   int s = blockIdx.y + d.s0, K = d.info[s].K;
+  if (K == 0) return;
   const size_t so = (size_t)s * d.Nmax;
-  const int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1);
+  const int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1), *coff = d.chunk_off[d.cur] + (size_t)s * (d.Kcap + 1);
+  const int W = coff[K];
   __shared__ Red6 sh[MOR_BT / 64];
-  for (int k = blockIdx.x; k < K; k += gridDim.x) {
-    int b = off[k], e = off[k + 1];
+  for (int w = blockIdx.x; w < W; w += gridDim.x) {
+    const int k = chunk_cluster(coff, K, w), b = off[k] + (w - coff[k]) * MOR_CHUNK, e = min(off[k + 1], b + MOR_CHUNK);
     Red6 r = {0, 0, 0, FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int j = b + threadIdx.x; j < e; j += MOR_BT) {
       float4 p = d.cloud[so + d.cl_idx[so + j]];
@@ -913,13 +946,26 @@ __global__ __launch_bounds__(MOR_BT) void k_stats(MorDev d) {
       r.mxx = fmaxf(r.mxx, p.x); r.mxy = fmaxf(r.mxy, p.y); r.mxz = fmaxf(r.mxz, p.z);
     }
     red6_block(r, sh);
-    if (threadIdx.x == 0) {
-      double n = (double)(e - b);
-      d.centroid[d.cur][(size_t)s * d.Kcap + k] = make_float4((float)(r.sx / n), (float)(r.sy / n), (float)(r.sz / n), 0.f);
-      d.amin[d.cur][(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
-      d.amax[d.cur][(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
-    }
+    if (threadIdx.x == 0) d.part[(size_t)s * d.Wcap + w] = r;
   }
+}
+// centroid = Σ(double)p / n cast to fp32 (:239-243), AABB for the volume gate
+__global__ __launch_bounds__(MOR_BT) void k_stats_fin(MorDev d) {
+  int s = blockIdx.y + d.s0, K = d.info[s].K, k = blockIdx.x * MOR_BT + threadIdx.x;
+  if (k >= K) return;
+  const int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1), *coff = d.chunk_off[d.cur] + (size_t)s * (d.Kcap + 1);
+  const Red6 *pt = d.part + (size_t)s * d.Wcap;
+  Red6 r = pt[coff[k]];
+  for (int w = coff[k] + 1; w < coff[k + 1]; ++w) {
+    const Red6 q = pt[w];
+    r.sx += q.sx; r.sy += q.sy; r.sz += q.sz;
+    r.mnx = fminf(r.mnx, q.mnx); r.mny = fminf(r.mny, q.mny); r.mnz = fminf(r.mnz, q.mnz);
+    r.mxx = fmaxf(r.mxx, q.mxx); r.mxy = fmaxf(r.mxy, q.mxy); r.mxz = fmaxf(r.mxz, q.mxz);
+  }
+  const double n = (double)(off[k + 1] - off[k]);
+  d.centroid[d.cur][(size_t)s * d.Kcap + k] = make_float4((float)(r.sx / n), (float)(r.sy / n), (float)(r.sz / n), 0.f);
+  d.amin[d.cur][(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
+  d.amax[d.cur][(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
 }
 
 // ------------------------------------------------------------------------------------ P1: previous frame → current pose (:536-551)
@@ -931,14 +977,16 @@ __device__ __forceinline__ void xform(const float *m, float &x, float &y, float 
 }
 __global__ __launch_bounds__(MOR_BT) void k_xform_prev(MorDev d) {
   int s = blockIdx.y + d.s0, pv = d.cur ^ 1, K = d.info[s].Kprev;
+  if (K == 0) return;
   const size_t so = (size_t)s * d.Nmax;
-  const int *off = d.cl_off[pv] + (size_t)s * (d.Kcap + 1);
+  const int *off = d.cl_off[pv] + (size_t)s * (d.Kcap + 1), *coff = d.chunk_off[pv] + (size_t)s * (d.Kcap + 1);
+  const int W = coff[K];
   __shared__ Red6 sh[MOR_BT / 64];
   __shared__ float m[12];
   if (threadIdx.x < 12) m[threadIdx.x] = d.args[s].xf[threadIdx.x];
   __syncthreads();
-  for (int k = blockIdx.x; k < K; k += gridDim.x) {
-    int b = off[k], e = off[k + 1];
+  for (int w = blockIdx.x; w < W; w += gridDim.x) {
+    const int k = chunk_cluster(coff, K, w), b = off[k] + (w - coff[k]) * MOR_CHUNK, e = min(off[k + 1], b + MOR_CHUNK);
     Red6 r = {0, 0, 0, FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int j = b + threadIdx.x; j < e; j += MOR_BT) {
       float4 p = d.cl_pts[pv][so + j];
@@ -948,15 +996,28 @@ __global__ __launch_bounds__(MOR_BT) void k_xform_prev(MorDev d) {
       r.mxx = fmaxf(r.mxx, p.x); r.mxy = fmaxf(r.mxy, p.y); r.mxz = fmaxf(r.mxz, p.z);
     }
     red6_block(r, sh);
-    if (threadIdx.x == 0) {
-      float4 c = d.centroid[pv][(size_t)s * d.Kcap + k];
-      xform(m, c.x, c.y, c.z);
-      d.centroid[pv][(size_t)s * d.Kcap + k] = c;
-      d.amin[pv][(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
-      d.amax[pv][(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
-      d.pair_of_prev[(size_t)s * d.Kcap + k] = -1;
-    }
+    if (threadIdx.x == 0) d.part[(size_t)s * d.Wcap + w] = r;
   }
+}
+// AABBs of the transformed clusters (volume gate), transformed centroids (:540-541)
+__global__ __launch_bounds__(MOR_BT) void k_xform_fin(MorDev d) {
+  int s = blockIdx.y + d.s0, pv = d.cur ^ 1, K = d.info[s].Kprev, k = blockIdx.x * MOR_BT + threadIdx.x;
+  if (k >= K) return;
+  const int *coff = d.chunk_off[pv] + (size_t)s * (d.Kcap + 1);
+  const Red6 *pt = d.part + (size_t)s * d.Wcap;
+  Red6 r = pt[coff[k]];
+  for (int w = coff[k] + 1; w < coff[k + 1]; ++w) {
+    const Red6 q = pt[w];
+    r.mnx = fminf(r.mnx, q.mnx); r.mny = fminf(r.mny, q.mny); r.mnz = fminf(r.mnz, q.mnz);
+    r.mxx = fmaxf(r.mxx, q.mxx); r.mxy = fmaxf(r.mxy, q.mxy); r.mxz = fmaxf(r.mxz, q.mxz);
+  }
+  const float *m = d.args[s].xf;
+  float4 c = d.centroid[pv][(size_t)s * d.Kcap + k];
+  xform(m, c.x, c.y, c.z);
+  d.centroid[pv][(size_t)s * d.Kcap + k] = c;
+  d.amin[pv][(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
+  d.amax[pv][(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
+  d.pair_of_prev[(size_t)s * d.Kcap + k] = -1;
 }
 
 // ------------------------------------------------------------------------------------ P2: centroid correspondence (:285-307)
@@ -1403,9 +1464,11 @@ void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
     MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
   }
-  MOR_LAUNCH(MK_STATS, k_stats, gK, d);
+  MOR_LAUNCH(MK_STATS, k_stats, dim3(64, d.B), d);
+  MOR_LAUNCH(MK_STATS_FIN, k_stats_fin, gKt, d);
   if (d.has_prev) {
-    MOR_LAUNCH(MK_XFORM_PREV, k_xform_prev, gK, d);
+    MOR_LAUNCH(MK_XFORM_PREV, k_xform_prev, dim3(64, d.B), d);
+    MOR_LAUNCH(MK_XFORM_FIN, k_xform_fin, gKt, d);
     MOR_LAUNCH(MK_NN, k_nn_centroid, gKt, d, 0);
     MOR_LAUNCH(MK_NN, k_nn_centroid, gKt, d, 1);
     MOR_LAUNCH(MK_PAIRS, k_pairs, gB, d);
