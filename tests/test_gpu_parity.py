@@ -174,3 +174,78 @@ def test_known_answers():
     out = b.filter()[0]
     assert len(out) == 9
     b.close()
+
+
+def test_os128_dense_cloud_matches_oracle():
+    """BASELINE configs[2] shape: 262 144-point Ouster-128-style frames, KITTI profile (3 frames, 2 streams)."""
+    p = kitti_params(1)
+    streams = [[synth.frame(3000 + s, "os128", f) for f in range(3)] for s in range(2)]
+    st = _run_lockstep(p, streams)
+    assert st["clusters"] > 20 and st["corr"] > 10
+
+
+def test_agg10_million_point_cloud_matches_oracle():
+    """BASELINE configs[4] shape: 10 aggregated sweeps, 1 000 000 points; exercises the cell-graph path that
+    keeps its arrays in global memory (more occupied cells than fit in LDS) and 3-pass cluster partitions."""
+    from dynamicslamtool_amd.engine import MorBatch
+    from oracle.oracle import Oracle
+    p = kitti_params(2)
+    frames = [synth.frame(5000, "agg10", f) for f in range(2)]
+    b, o = MorBatch(p, 1, 1000000), Oracle(p)
+    for f, (x, pose) in enumerate(frames):
+        b.push([x], pose[None, :])
+        o.push(x, pose)
+        compare_frame(o, b, 0, "agg10 frame %d" % f)
+        compare_output(o.filter(), b.filter()[0], "agg10 frame %d" % f)
+    b.close()
+
+
+def test_fine_grid_takes_the_global_memory_cell_graph():
+    """A small cluster tolerance (r = 0.15 m → 8.6 cm cells) gives more occupied cells than the per-stream
+    workgroup can hold in LDS: the cell graph then runs on its global-memory arrays (same code)."""
+    from dynamicslamtool_amd.engine import MorBatch
+    from oracle.oracle import Oracle
+    p = kitti_params(1)
+    p.ec_distance_threshold = 0.15
+    p.min_cluster_size = 10
+    frames = [synth.frame(2033, "hdl64", f) for f in range(3)]
+    b, o = MorBatch(p, 1, 120000), Oracle(p)
+    for f, (x, pose) in enumerate(frames):
+        b.push([x], pose[None, :])
+        o.push(x, pose)
+        compare_frame(o, b, 0, "fine grid frame %d" % f)
+        compare_output(o.filter(), b.filter()[0], "fine grid frame %d" % f)
+    assert b.stage_counts(0)["n_occ"] > 8192
+    b.close()
+
+
+def test_full_size_batch_properties():
+    """BASELINE configs[1] at full size (B = 64 × 120 000 pts) through size-independent properties: the
+    filtered cloud is a sub-multiset of the trimmed input; |out| = T − removed; labels partition the cloud;
+    re-running the same stream in another batch slot gives identical bytes (streams are independent)."""
+    p = kitti_params(1)
+    B = 64
+    seeds = [2000 + s for s in range(B)]
+    seeds[37] = seeds[5]   # duplicate stream in a different slot / XCD group
+    b = MorBatch(p, B, 120000)
+    outs = None
+    for f in range(4):
+        xs, ps = synth.batch(seeds, [f] * B)
+        b.push(list(xs), ps)
+        outs = b.filter()
+        for s in (0, 5, 37, 63):
+            c = b.counts(s)
+            lab = b.labels(s)
+            assert len(lab) == c.n_trim and (lab == -2).sum() == c.n_ground and (lab >= 0).sum() == c.n_clustered
+            off, idx = b.clusters(s)
+            assert off[-1] == c.n_clustered and len(np.unique(idx)) == len(idx)
+            assert np.all(np.diff(np.diff(off)) <= 0)   # sizes descending
+            assert len(outs[s]) <= c.n_trim
+            x = xs[s]
+            keep = np.isfinite(x[:, :3]).all(1) & (np.abs(x[:, 0]) <= p.trim_x) & (np.abs(x[:, 1]) <= p.trim_y)
+            assert c.n_trim == keep.sum()
+            a = np.sort(outs[s].view([("", np.float32)] * 4).ravel())
+            t = np.sort(x[keep].view([("", np.float32)] * 4).ravel())
+            assert np.isin(a, t).all()
+    assert np.array_equal(outs[5].view(np.uint32), outs[37].view(np.uint32))
+    b.close()
