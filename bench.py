@@ -138,7 +138,7 @@ def main():
             run_step(args.warmup + args.steps + i)
         kt = batch.kernel_timing(reset=True)
         batch.kernel_timing_enable(False)
-        kernels = {k: {"ms_total": round(v[0], 4), "launches": v[1], "avg_us": round(1e3 * v[0] / max(v[1], 1), 2)} for k, v in kt.items() if v[1]}
+        kernels = {"k_" + k: {"ms_total": round(v[0], 4), "launches": v[1], "avg_us": round(1e3 * v[0] / max(v[1], 1), 2)} for k, v in kt.items() if v[1]}   # names = the __global__ functions rocprofv3 reports
         dom = max(kernels, key=lambda k: kernels[k]["ms_total"])
         avg_s = kernels[dom]["ms_total"] / kernels[dom]["launches"] * 1e-3
         achieved = B * b_alg / avg_s / 1e9
@@ -146,7 +146,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

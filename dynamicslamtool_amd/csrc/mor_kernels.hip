@@ -26,7 +26,7 @@
 #include <cstdlib>
 
 const char *const mor_kernel_names[MK_COUNT] = {
-    "classify", "scan_tiles", "scatter", "heads_count", "heads_scan", "heads_scatter", "rowtable", "cellgraph", "cellbox", "hook_near", "hook_shell", "flatten", "cellcid",
+    "classify", "scan_tiles", "scatter", "heads_count", "heads_scan", "heads_scatter", "rowtable", "cellgraph", "cellbox", "hook_cells", "hook_cells_shell", "flatten", "cellcid",
     "select_count", "select_scan", "select_scatter", "rank", "offsets", "label", "rhist", "rscan", "rscatter",
     "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "pairs", "score_fast", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
     "out_count", "out_scan", "out_scatter"};
@@ -582,11 +582,16 @@ template <bool LDS> __device__ __forceinline__ void cg_hook_pass(const MorDev &d
           if (!edge) {
             if (u > 0 && cg_find<LDS>(par, b) == ra) continue;         // an earlier union of this row may have merged it
             const int b0 = start[b], nb = start[b + 1] - b0;
-            if ((long long)na * nb > 256) {                             // big × big: leave it to a whole wave
-              int slot = atomicAdd(l_nlist, 1);
-              if (slot < CG_LIST) { l_list[2 * slot] = a; l_list[2 * slot + 1] = b; continue; }
-            }
-            edge = pair_hit_serial(sp, a0, na, b0, nb, r2);
+            if ((long long)na * nb > 256) {
+              // big × big: dense neighbouring cells nearly always show an edge within a small sample of pairs;
+              // what is left (mostly true non-edges) goes to a whole wave
+              edge = pair_hit_serial(sp, a0, min(na, 16), b0, min(nb, 16), r2);
+              if (!edge) {
+                int slot = atomicAdd(l_nlist, 1);
+                if (slot < CG_LIST) { l_list[2 * slot] = a; l_list[2 * slot + 1] = b; continue; }
+                edge = pair_hit_serial(sp, a0, na, b0, nb, r2);           // list full: settle it here
+              }
+            } else edge = pair_hit_serial(sp, a0, na, b0, nb, r2);
           }
           if (edge) ra = cg_unite<LDS>(par, ra, b);
         }
@@ -621,10 +626,10 @@ template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int
   const float4 *sp = d.sorted + so;
   const int lane = lane_id();
   CG_STAMP(1);
-  // ---- boxes of the cells' points: small cells by one thread, big ones by a wave
+  // ---- boxes of the cells' points: cells of ≤ 16 points by one thread each, bigger ones by a whole wave each
   for (int c = threadIdx.x; c < nocc; c += CG_T) {
     const int b = start[c], e = start[c + 1];
-    if (e - b > 16) { int slot = atomicAdd(l_nlist, 1); if (slot < 2 * CG_LIST) { l_list[slot] = c; continue; } }
+    if (e - b > 16) continue;
     float lx = FLT_MAX, ly = FLT_MAX, lz = FLT_MAX, hx = -FLT_MAX, hy = -FLT_MAX, hz = -FLT_MAX;
     for (int k = b; k < e; k += 4) {
       float4 p0 = sp[k], p1 = sp[min(k + 1, e - 1)], p2 = sp[min(k + 2, e - 1)], p3 = sp[min(k + 3, e - 1)];
@@ -633,16 +638,12 @@ template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int
     }
     d.cbox_lo[so + c] = make_float4(lx, ly, lz, 0.f); d.cbox_hi[so + c] = make_float4(hx, hy, hz, 0.f);
   }
-  __syncthreads();
-  {
-    const int nl = min(*l_nlist, 2 * CG_LIST);
-    for (int h = wave_id(); h < nl; h += CG_T / 64) {
-      const int c = l_list[h]; float4 lo, hi; wave_box(sp, start[c], start[c + 1], lane, lo, hi);
-      if (lane == 0) { d.cbox_lo[so + c] = lo; d.cbox_hi[so + c] = hi; }
-    }
+  for (int c = wave_id(); c < nocc; c += CG_T / 64) {
+    const int b = start[c], e = start[c + 1];
+    if (e - b <= 16) continue;
+    float4 lo, hi; wave_box(sp, b, e, lane, lo, hi);
+    if (lane == 0) { d.cbox_lo[so + c] = lo; d.cbox_hi[so + c] = hi; }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) *l_nlist = 0;
   __threadfence_block();
   __syncthreads();
   CG_STAMP(2);
