@@ -21,6 +21,7 @@
 struct MorGrid {
   float ox, oy, oz, inv_cs, cs;
   int nx, ny, nz, nrows, keybits;
+  int mode, ibx, iby;   // mode 1 (VoxelGrid lattice): cell = floor(v·inv_cs) − ib, absolute multiples of the leaf; z base per stream
 };
 
 struct Red6 { double sx, sy, sz; float mnx, mny, mnz, mxx, mxy, mxz; };   // partial Σxyz (fp64) + AABB
@@ -55,7 +56,10 @@ struct MorDev {
   double pde_thr, vol_thr, opc_res;
   int method, opc_norm, score_R, n_rows, t1_budget;
   const signed char *row_order; // [n_rows][2] (dy,dz) of the method-1 search stencil, nearest rows first
-  MorGrid g;
+  MorGrid g;                 // clustering grid (cell edge 0.57·r)
+  MorGrid gv;                // VoxelGrid lattice of the voxel-covariance ground removal (cell edge gp_leaf)
+  int gmode;                 // 0: crop-box ground removal; 1 / 2: passes A (trim) / B (split by ground flag) of the voxel variant
+  int voxel_passes; float leaf_r2;
   // ---- per call
   int tiles;                 // ceil(max n_points of this batch / MOR_TILE)
   int tiles_m;               // workgroups per stream for kernels over the non-ground cloud / clusters: an estimate from the
@@ -69,6 +73,12 @@ struct MorDev {
   int *cloud_tidx;           // [B][Nmax]  index of each cloud point in the trimmed cloud
   float4 *ground;            // [B][Nmax]  removed points in order (raw_cloud[gp_indices], :683)
   int *gp_idx;               // [B][Nmax]  gp_indices (:86)
+  float4 *rawbuf;            // [B][Nmax]  trimmed cloud (voxel ground variant only)
+  int *is_ground;            // [B][Nmax]  per trimmed point
+  float4 *vcent; int *vbin;  // [B][Nmax]  voxel centroids (dsc, :113) and bin id of accepted voxels
+  int *zmin_i, *zmax_i;      // [B]  ordered-int min / max z of the trimmed cloud
+  float *zorg; int *zbase;   // [B]  z origin of the clustering grid / z base of the voxel lattice
+  int *mode_bin;             // [B]  dominant z-bin (:169-178)
   int *pkey;                 // [B][Nmax]  linear cell key per cloud point
   int *cell_of;              // [B][Nmax]  compact cell id per cloud point
   int *skey, *sidx;          // aliases of the radix buffers holding the cell-sorted (key, cloud index)
@@ -131,7 +141,7 @@ enum MorKernelId {
   MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_ROWTABLE, MK_CELLGRAPH, MK_CELLBOX, MK_HOOK_NEAR, MK_HOOK_SHELL, MK_FLATTEN, MK_CELLCID,
   MK_SELECT_COUNT, MK_SELECT_SCAN, MK_SELECT_SCATTER, MK_RANK, MK_OFFSETS, MK_LABEL, MK_RHIST, MK_RSCAN, MK_RSCATTER,
   MK_STATS, MK_STATS_FIN, MK_XFORM_PREV, MK_XFORM_FIN, MK_NN, MK_PAIRS, MK_SCORE_FAST, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
-  MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_COUNT
+  MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_G2_CENTROID, MK_G2_COV, MK_G2_MODE, MK_G2_MARK, MK_COUNT
 };
 extern const char *const mor_kernel_names[MK_COUNT];
 

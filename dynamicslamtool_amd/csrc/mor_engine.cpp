@@ -111,7 +111,8 @@ static int configure(mor_batch *b) {
   if (!(p.ec_distance_threshold > 0.f) || !(p.trim_x > 0.f) || !(p.trim_y > 0.f)) return set_error(MOR_ERR_INVALID, "ec_distance_threshold, trim_x, trim_y must be > 0");
   if (p.method_choice == 2 && p.opc_normalization_factor <= 0) return set_error(MOR_ERR_INVALID, "opc_normalization_factor must be > 0 for method 2");
   if (p.method_choice == 2 && !(p.opc_resolution > 0.f)) return set_error(MOR_ERR_INVALID, "opc_resolution must be > 0");
-  if (p.ground_method != 0) return set_error(MOR_ERR_INVALID, "ground_method %d not available in this build (0 = crop box)", p.ground_method);
+  if (p.ground_method != 0 && p.ground_method != 1) return set_error(MOR_ERR_INVALID, "ground_method must be 0 (crop box) or 1 (voxel covariance)");
+  if (p.ground_method == 1 && !(p.gp_leaf > 0.f)) return set_error(MOR_ERR_INVALID, "gp_leaf must be > 0 for the voxel-covariance ground removal");
   d.B = b->B; d.Btot = b->B; d.s0 = 0; d.Nmax = (int)b->Nmax;
   long long mn = std::max<long long>(p.min_cluster_size, 1);
   d.Kcap = (int)std::min<long long>((long long)b->Nmax / mn + 1, 16384);
@@ -125,13 +126,29 @@ static int configure(mor_batch *b) {
   // fp32 rounding of the cell map, ≤ 1e-3 cell at ≤ 2048 cells per axis)
   float cs = p.ec_distance_threshold * 0.57f;
   float zlo = p.gp_limit, zhi = std::max(p.trim_z, p.gp_limit);
+  d.gmode = p.ground_method;
+  const double zspan_voxel_mode = 64.0;   // voxel variant: no z crop; grids hang on the lowest trimmed point and cover this span
   double nx = std::floor(2.0 * p.trim_x / cs) + 1, ny = std::floor(2.0 * p.trim_y / cs) + 1, nz = std::floor((double)(zhi - zlo) / cs) + 1;
+  if (d.gmode == 1) nz = std::min(1024.0, std::ceil(zspan_voxel_mode / cs) + 2);
   if (nx > 2048 || ny > 2048 || nz > 1024 || nx * ny * nz >= 2147483648.0 || ny * nz > 1048576.0)
     return set_error(MOR_ERR_INVALID, "grid %gx%gx%g cells too large: trim box too big for ec_distance_threshold %g", nx, ny, nz, (double)p.ec_distance_threshold);
   d.g.nx = (int)nx; d.g.ny = (int)ny; d.g.nz = (int)nz; d.g.nrows = d.g.ny * d.g.nz;
   d.g.keybits = 1; while ((1ll << d.g.keybits) < (long long)(nx * ny * nz)) ++d.g.keybits;
   d.cell_passes = (d.g.keybits + 7) / 8;
-  d.g.ox = -p.trim_x; d.g.oy = -p.trim_y; d.g.oz = zlo; d.g.cs = cs; d.g.inv_cs = 1.0f / cs;
+  d.g.ox = -p.trim_x; d.g.oy = -p.trim_y; d.g.oz = zlo; d.g.cs = cs; d.g.inv_cs = 1.0f / cs; d.g.mode = 0; d.g.ibx = d.g.iby = 0;
+  d.gv = d.g; d.voxel_passes = 0; d.leaf_r2 = 0.f;
+  if (d.gmode == 1) {   // VoxelGrid lattice: cells at absolute multiples of the leaf (pcl::VoxelGrid: floor(x·inv_leaf)), :110-113
+    MorGrid &v = d.gv; v.mode = 1; v.cs = p.gp_leaf; v.inv_cs = 1.0f / p.gp_leaf;
+    v.ibx = (int)std::floor(-p.trim_x * v.inv_cs); v.iby = (int)std::floor(-p.trim_y * v.inv_cs);
+    double vx = (double)((int)std::floor(p.trim_x * v.inv_cs) - v.ibx + 1), vy = (double)((int)std::floor(p.trim_y * v.inv_cs) - v.iby + 1);
+    double vz = std::min(1024.0, std::ceil(zspan_voxel_mode / p.gp_leaf) + 2);
+    if (vx > 2048 || vy > 2048 || vx * vy * vz >= 2147483648.0 || vy * vz > 1048576.0)
+      return set_error(MOR_ERR_INVALID, "voxel lattice %gx%gx%g too large: trim box too big for gp_leaf %g", vx, vy, vz, (double)p.gp_leaf);
+    v.nx = (int)vx; v.ny = (int)vy; v.nz = (int)vz; v.nrows = v.ny * v.nz;
+    v.keybits = 1; while ((1ll << v.keybits) < (long long)(vx * vy * vz)) ++v.keybits;
+    d.voxel_passes = (v.keybits + 7) / 8;
+    double lf = (double)p.gp_leaf; d.leaf_r2 = (float)(lf * lf);   // radiusSearch(…, gp_leaf): (float)(radius·radius)
+  }
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
   d.t1_budget = getenv("MOR_T1_BUDGET") ? atoi(getenv("MOR_T1_BUDGET")) : 256;
   if (d.score_R > 60) return set_error(MOR_ERR_INVALID, "pde_ub %g needs a %d-cell search radius (> 60)", (double)p.pde_ub, d.score_R);
@@ -228,7 +245,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, dargs, B) && dalloc(b, d.info, B) && dalloc(b, d.tile_cnt, B * T * 2) && dalloc(b, d.tile_off, B * T * 2);
   b->d_args = dargs; d.args = dargs;
   ok = ok && dalloc(b, d.cloud, B * N) && dalloc(b, d.cloud_tidx, B * N) && dalloc(b, d.ground, B * N) && dalloc(b, d.gp_idx, B * N) && dalloc(b, d.cell_of, B * N);
-  ok = ok && dalloc(b, d.pkey, B * N) && dalloc(b, d.ckey, B * N) && dalloc(b, d.cstart, B * (N + 1)) && dalloc(b, d.row_start, B * ((size_t)d.g.nrows + 1)) && dalloc(b, d.cmin, B * N) && dalloc(b, d.cbox_lo, B * N) && dalloc(b, d.cbox_hi, B * N);
+  ok = ok && dalloc(b, d.pkey, B * N) && dalloc(b, d.ckey, B * N) && dalloc(b, d.cstart, B * (N + 1)) && dalloc(b, d.row_start, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, d.cmin, B * N) && dalloc(b, d.cbox_lo, B * N) && dalloc(b, d.cbox_hi, B * N);
   ok = ok && dalloc(b, d.sorted, B * N) && dalloc(b, d.parent, B * N) && dalloc(b, d.croot, B * N) && dalloc(b, d.csize, B * N) && dalloc(b, d.compmin, B * N) && dalloc(b, d.cid_of_root, B * N) && dalloc(b, d.pcid, B * N) && dalloc(b, d.ccid, B * N);
   ok = ok && dalloc(b, d.ktile_cnt, B * T) && dalloc(b, d.kcell, B * K) && dalloc(b, d.kroot, B * K) && dalloc(b, d.ksize, B * K) && dalloc(b, d.csz, B * K);
   {  // method-1 search stencil: (dy,dz) rows ordered by their distance lower bound, then by centre distance
@@ -257,6 +274,12 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.pair_cnt, B * K) && dalloc(b, d.pair_of_prev, B * K) && dalloc(b, d.pair_of_cur, B * K) && dalloc(b, d.det, B * K);
   if (p->method_choice == 2) ok = ok && dalloc(b, d.vox, B * (size_t)d.Hcap);
   ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_n, B) && dalloc(b, d.dbg, B * 16);
+  ok = ok && dalloc(b, d.zmin_i, B) && dalloc(b, d.zmax_i, B) && dalloc(b, d.zorg, B) && dalloc(b, d.zbase, B) && dalloc(b, d.mode_bin, B);
+  if (d.gmode == 1) ok = ok && dalloc(b, d.rawbuf, B * N) && dalloc(b, d.is_ground, B * N) && dalloc(b, d.vcent, B * N) && dalloc(b, d.vbin, B * N);
+  if (ok) {   // crop-box variant: the clustering grid starts at gp_limit for every stream
+    std::vector<float> z0(B, p->gp_limit); std::vector<int> zb(B, 0);
+    ok = hipMemcpy(d.zorg, z0.data(), B * sizeof(float), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d.zbase, zb.data(), B * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+  }
   ok = ok && dalloc(b, b->d_moving, B * K + B) && dalloc(b, d.otile_cnt, B * T) && dalloc(b, d.out, B * N) && dalloc(b, b->d_outptrs, B);
   d.moving = b->d_moving;
   ok = ok && halloc(b, b->h_args, B) && halloc(b, b->h_moving, B * K + B) && halloc(b, b->h_outptrs, B);
@@ -326,6 +349,8 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     const MorFrameInfo &f = d.h_info[s];
     if (f.flags & 1u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than %d clusters", s, d.Kcap);
     if (f.flags & 2u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: voxel key out of range in method 2", s);
+    if (f.flags & 8u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: z extent of the trimmed cloud exceeds the 64 m the voxel ground variant covers", s);
+    if (f.flags & 16u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than 2048 points within gp_leaf of a voxel centroid", s);
     const size_t ko = (size_t)s * d.Kcap;
     cent.resize(3 * (size_t)f.K);
     for (uint32_t k = 0; k < f.K; ++k) { cent[3 * k] = d.h_centroid[ko + k].x; cent[3 * k + 1] = d.h_centroid[ko + k].y; cent[3 * k + 2] = d.h_centroid[ko + k].z; }

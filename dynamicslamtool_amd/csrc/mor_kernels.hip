@@ -29,7 +29,7 @@ const char *const mor_kernel_names[MK_COUNT] = {
     "classify", "scan_tiles", "scatter", "heads_count", "heads_scan", "heads_scatter", "rowtable", "cellgraph", "cellbox", "hook_cells", "hook_cells_shell", "flatten", "cellcid",
     "select_count", "select_scan", "select_scatter", "rank", "offsets", "label", "rhist", "rscan", "rscatter",
     "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "pairs", "score_fast", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
-    "out_count", "out_scan", "out_scatter"};
+    "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_mode", "g2_mark"};
 
 // ------------------------------------------------------------------------------------ helpers
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -90,7 +90,28 @@ __device__ __forceinline__ float4 load_point(const MorStreamArgs &a, uint32_t i)
 __device__ __forceinline__ int classify(const MorDev &d, float4 p) {
   bool fin = __builtin_isfinite(p.x) && __builtin_isfinite(p.y) && __builtin_isfinite(p.z);
   if (!fin || p.x < -d.trim_x || p.x > d.trim_x || p.y < -d.trim_y || p.y > d.trim_y) return 0;
+  if (d.gmode == 1) return 2;   // voxel variant, pass A: only the x/y PassThrough pair (:94-102)
   return (p.z < d.gp_limit || p.z > d.trim_z) ? 1 : 2;
+}
+// number of input records of stream s and record i for the current pass (pass B of the voxel variant re-reads the
+// trimmed cloud and splits it by the ground flag, :194-198)
+__device__ __forceinline__ uint32_t pass_count(const MorDev &d, const MorStreamArgs &a, int s) { return d.gmode == 2 ? d.info[s].T : a.n; }
+__device__ __forceinline__ int pass_item(const MorDev &d, const MorStreamArgs &a, int s, uint32_t i, float4 &p) {
+  if (d.gmode == 2) { p = d.rawbuf[(size_t)s * d.Nmax + i]; return d.is_ground[(size_t)s * d.Nmax + i] ? 1 : 2; }
+  p = load_point(a, i);
+  return classify(d, p);
+}
+__device__ __forceinline__ int float_ordered(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float ordered_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+// grid cell of a point: clustering grid (clamped, monotone map) or the VoxelGrid lattice (absolute multiples of the leaf)
+__device__ __forceinline__ void grid_cell(const MorGrid &g, float4 p, float zorg, int zbase, int &cx, int &cy, int &cz, bool &clamped) {
+  if (g.mode == 1) {
+    cx = (int)floorf(p.x * g.inv_cs) - g.ibx; cy = (int)floorf(p.y * g.inv_cs) - g.iby; cz = (int)floorf(p.z * g.inv_cs) - zbase;
+  } else {
+    cx = (int)floorf((p.x - g.ox) * g.inv_cs); cy = (int)floorf((p.y - g.oy) * g.inv_cs); cz = (int)floorf((p.z - zorg) * g.inv_cs);
+  }
+  clamped = cx < 0 || cy < 0 || cz < 0 || cx >= g.nx || cy >= g.ny || cz >= g.nz;
+  cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
 }
 
 __device__ __forceinline__ int cell_axis(float v, float o, float inv, int n) {
@@ -138,14 +159,22 @@ __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, 
 __global__ __launch_bounds__(MOR_BT) void k_classify(MorDev d) {
   int s, t; map_block(d.B, d.tiles, s, t);
   const MorStreamArgs a = d.args[s];
+  const uint32_t n_in = pass_count(d, a, s);
   uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
   int c_ng = 0, c_g = 0;
+  float zlo = INFINITY, zhi = -INFINITY;
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     uint32_t i = base + it * 64 + lane_id();
-    int cls = (i < a.n) ? classify(d, load_point(a, i)) : 0;
+    float4 p; int cls = (i < n_in) ? pass_item(d, a, s, i, p) : 0;
+    if (d.gmode == 1 && cls == 2) { zlo = fminf(zlo, p.z); zhi = fmaxf(zhi, p.z); }
     c_ng += __popcll(__ballot(cls == 2));
     c_g += __popcll(__ballot(cls == 1));
+  }
+  if (d.gmode == 1) {   // z extent of the trimmed cloud: the voxel variant does not crop in z
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { zlo = fminf(zlo, __shfl_xor(zlo, o, 64)); zhi = fmaxf(zhi, __shfl_xor(zhi, o, 64)); }
+    if (lane_id() == 0 && zlo <= zhi) { atomicMin(&d.zmin_i[s], float_ordered(zlo)); atomicMax(&d.zmax_i[s], float_ordered(zhi)); }
   }
   __shared__ int sh[8];
   if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
@@ -172,8 +201,15 @@ __global__ __launch_bounds__(MOR_BT) void k_scan_tiles(MorDev d) {
   }
   if (threadIdx.x == 0) {
     MorFrameInfo &f = d.info[s];
-    f.N = d.args[s].n; f.M = carry_ng; f.G = carry_g; f.T = carry_ng + carry_g; f.flags = 0; f.n_pairs = 0; f.K = 0; f.C = 0;
-    f.Kprev = d.has_prev ? f.Kprev : 0; f.Cprev = d.has_prev ? f.Cprev : 0;
+    f.M = carry_ng; f.G = carry_g; f.T = carry_ng + carry_g;
+    if (d.gmode != 2) {
+      f.N = d.args[s].n; f.flags = 0; f.n_pairs = 0; f.K = 0; f.C = 0;
+      f.Kprev = d.has_prev ? f.Kprev : 0; f.Cprev = d.has_prev ? f.Cprev : 0;
+    }
+    if (d.gmode == 1) {   // grids of the voxel variant hang on the lowest trimmed point
+      float zmin = f.T ? ordered_float(d.zmin_i[s]) : 0.f;
+      d.zorg[s] = zmin; d.zbase[s] = (int)floorf(zmin * d.gv.inv_cs);
+    }
   }
 }
 
@@ -181,15 +217,16 @@ __global__ __launch_bounds__(MOR_BT) void k_scan_tiles(MorDev d) {
 __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   int s, t; map_block(d.B, d.tiles, s, t);
   const MorStreamArgs a = d.args[s];
+  const uint32_t n_in = pass_count(d, a, s);
   uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
-  if ((uint32_t)t * MOR_TILE >= a.n) return;
+  if ((uint32_t)t * MOR_TILE >= n_in) return;
   float4 p[8]; int cls[8]; unsigned long long m_ng[8], m_g[8];
   int c_ng = 0, c_g = 0;
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     uint32_t i = base + it * 64 + lane_id();
     cls[it] = 0;
-    if (i < a.n) { p[it] = load_point(a, i); cls[it] = classify(d, p[it]); }
+    if (i < n_in) cls[it] = pass_item(d, a, s, i, p[it]);
     m_ng[it] = __ballot(cls[it] == 2); m_g[it] = __ballot(cls[it] == 1);
     c_ng += __popcll(m_ng[it]); c_g += __popcll(m_g[it]);
   }
@@ -205,7 +242,8 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
     int k_ng = r_ng + __popcll(m_ng[it] & lanemask_lt());
     int k_g = r_g + __popcll(m_g[it] & lanemask_lt());
     if (cls[it] == 2) {
-      int cx = cell_axis(p[it].x, d.g.ox, d.g.inv_cs, d.g.nx), cy = cell_axis(p[it].y, d.g.oy, d.g.inv_cs, d.g.ny), cz = cell_axis(p[it].z, d.g.oz, d.g.inv_cs, d.g.nz);
+      int cx, cy, cz; bool clamped; grid_cell(d.g, p[it], d.zorg[s], d.zbase[s], cx, cy, cz, clamped);
+      if (clamped && d.gmode != 0) atomicOr(&d.info[s].flags, 8u);   // z extent beyond the grid: cells would no longer be cliques / voxels
       d.cloud[so + k_ng] = p[it];
       d.cloud_tidx[so + k_ng] = k_ng + k_g;   // index in the trimmed cloud (both ranks are exclusive counts of earlier kept points)
       d.pkey[so + k_ng] = (cz * d.g.ny + cy) * d.g.nx + cx;
@@ -1142,7 +1180,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
     if (pr >= 0) {
       const int target = d.pair_m[ko + pr];
       const float4 q = d.cl_pts[pv][so + j];
-      const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.g.oz, d.g.inv_cs);
+      const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
       float best = INFINITY; int budget = d.t1_budget;   // points this thread may scan before handing the query to a wave
       {  // stage 0: the query's own cell — on a static surface a matched point within √lb is almost always here
         int c = cell_lookup(d.g, ckey, rs, cx, cy, cz);
@@ -1209,7 +1247,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
     if (pr < 0) continue;
     const int target = d.pair_m[ko + pr];
     const float4 q = d.cl_pts[pv][so + j];
-    const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.g.oz, d.g.inv_cs);
+    const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
     float best = INFINITY;
     {  // the query's own cell first
       int c = cell_lookup(d.g, ckey, rs, cx, cy, cz);
@@ -1418,6 +1456,129 @@ __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
   }
 }
 
+// ------------------------------------------------------------------------------------ G2: voxel-covariance ground removal (:90-200)
+// Dead code in the reference (the call is commented out at :527 and would crash at :188); implemented with the
+// intended semantics and the deterministic definitions of DESIGN.md §G2.  Pass A has trimmed the cloud in x/y
+// and sorted it by VoxelGrid cell (stable ⇒ ascending point index inside a voxel).
+// dsc (:110-113): per voxel, fp32 sums in ascending point index, divided by the count
+__global__ __launch_bounds__(MOR_BT) void k_g2_centroid(MorDev d) {
+  int s = blockIdx.y + d.s0, V = d.info[s].n_occ;
+  const size_t so = (size_t)s * d.Nmax;
+  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  for (int v = blockIdx.x * MOR_BT + threadIdx.x; v < V; v += gridDim.x * MOR_BT) {
+    float sx = 0.f, sy = 0.f, sz = 0.f; const int b = st[v], e = st[v + 1];
+    for (int k = b; k < e; ++k) { float4 p = d.sorted[so + k]; sx += p.x; sy += p.y; sz += p.z; }
+    const float n = (float)(e - b);
+    d.vcent[so + v] = make_float4(sx / n, sy / n, sz / n, 0.f);
+  }
+}
+#define G2_CAP 2048   // neighbours of one voxel centroid held in LDS
+// all trimmed points with d² < leaf² around q (radiusSearch, :125), appended to the LDS list in arbitrary order
+__device__ __forceinline__ void g2_gather(const MorDev &d, int s, float4 q, unsigned long long *key, float *px, float *py, float *pz, int *cnt, bool coords) {
+  const size_t so = (size_t)s * d.Nmax;
+  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  int cx, cy, cz; bool cl; grid_cell(d.g, q, 0.f, d.zbase[s], cx, cy, cz, cl);
+  for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
+    const int y = cy + dy, z = cz + dz;
+    if ((unsigned)y >= (unsigned)d.g.ny || (unsigned)z >= (unsigned)d.g.nz) continue;
+    int lo, hi; row_cells(d.g, ckey, rs, max(cx - 1, 0), min(cx + 1, d.g.nx - 1), y, z, lo, hi);
+    if (lo >= hi) continue;
+    for (int k = st[lo] + threadIdx.x, e = st[hi]; k < e; k += MOR_BT) {
+      const float4 p = d.sorted[so + k];
+      const float dd = sqdist(q.x, q.y, q.z, p.x, p.y, p.z);
+      if (dd < d.leaf_r2) {
+        int slot = atomicAdd(cnt, 1);
+        if (slot < G2_CAP) { key[slot] = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(p.w); if (coords) { px[slot] = p.x; py[slot] = p.y; pz[slot] = p.z; } }
+      }
+    }
+  }
+}
+// one workgroup per voxel: neighbours sorted by (d², index) as KdTreeFLANN::radiusSearch returns them; > 3 of them
+// (:131); fp32 centroid (:142) and un-normalised scatter terms xz, yz, zz (:144) summed in that order; accepted
+// voxels (:145) record their z-bin (:166)
+__global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
+  int s = blockIdx.y + d.s0, V = d.info[s].n_occ;
+  const size_t so = (size_t)s * d.Nmax;
+  __shared__ unsigned long long key[G2_CAP];
+  __shared__ unsigned short slot[G2_CAP];
+  __shared__ float px[G2_CAP], py[G2_CAP], pz[G2_CAP];
+  __shared__ int cnt;
+  for (int v = blockIdx.x; v < V; v += gridDim.x) {
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const float4 q = d.vcent[so + v];
+    g2_gather(d, s, q, key, px, py, pz, &cnt, true);
+    __syncthreads();
+    const int n = cnt;
+    int bin = 0x7fffffff;
+    if (n > G2_CAP) { if (threadIdx.x == 0) atomicOr(&d.info[s].flags, 16u); }
+    else if (n > 3) {
+      int P = 4; while (P < n) P <<= 1;
+      for (int i = threadIdx.x; i < P; i += MOR_BT) { slot[i] = (unsigned short)i; if (i >= n) key[i] = ~0ull; }
+      __syncthreads();
+      for (int k = 2; k <= P; k <<= 1) for (int j = k >> 1; j > 0; j >>= 1) {   // bitonic sort of (key, slot)
+        for (int i = threadIdx.x; i < P; i += MOR_BT) {
+          int l = i ^ j;
+          if (l > i) {
+            bool up = (i & k) == 0; unsigned long long a = key[i], b = key[l];
+            if ((a > b) == up) { key[i] = b; key[l] = a; unsigned short t = slot[i]; slot[i] = slot[l]; slot[l] = t; }
+          }
+        }
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) {
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        for (int i = 0; i < n; ++i) { int t = slot[i]; cx += px[t]; cy += py[t]; cz += pz[t]; }
+        const float fn = (float)n; cx /= fn; cy /= fn; cz /= fn;
+        float c02 = 0.f, c12 = 0.f, c22 = 0.f;
+        for (int i = 0; i < n; ++i) { int t = slot[i]; float dx = px[t] - cx, dy = py[t] - cy, dz = pz[t] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; }
+        if ((double)fabsf(c02) < 0.001 && (double)fabsf(c12) < 0.001 && (double)fabsf(c22) < 0.001) bin = (int)(q.z * 10);
+      }
+    }
+    if (threadIdx.x == 0) d.vbin[so + v] = bin;
+    __syncthreads();
+  }
+}
+// dominant bin (:169-178): most accepted voxels, ties → smallest key
+__global__ __launch_bounds__(MOR_BT) void k_g2_mode(MorDev d) {
+  int s = blockIdx.x + d.s0, V = d.info[s].n_occ;
+  const size_t so = (size_t)s * d.Nmax;
+  __shared__ int hist[4096], best_cnt, best_bin;
+  for (int i = threadIdx.x; i < 4096; i += MOR_BT) hist[i] = 0;
+  if (threadIdx.x == 0) { best_cnt = 0; best_bin = 0x7fffffff; }
+  __syncthreads();
+  for (int v = threadIdx.x; v < V; v += MOR_BT) {
+    int b = d.vbin[so + v];
+    if (b == 0x7fffffff) continue;
+    if (b < -2048 || b >= 2048) { atomicOr(&d.info[s].flags, 8u); continue; }
+    atomicAdd(&hist[b + 2048], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4096; i += MOR_BT) atomicMax(&best_cnt, hist[i]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4096; i += MOR_BT) if (best_cnt > 0 && hist[i] == best_cnt) atomicMin(&best_bin, i - 2048);
+  __syncthreads();
+  if (threadIdx.x == 0) d.mode_bin[s] = best_bin;
+}
+// ground = union of the neighbour lists of the dominant bin's voxels (:184-191, de-duplicated)
+__global__ __launch_bounds__(MOR_BT) void k_g2_mark(MorDev d) {
+  int s = blockIdx.y + d.s0, V = d.info[s].n_occ, mode = d.mode_bin[s];
+  if (mode == 0x7fffffff) return;
+  const size_t so = (size_t)s * d.Nmax;
+  __shared__ unsigned long long key[G2_CAP];
+  __shared__ int cnt;
+  for (int v = blockIdx.x; v < V; v += gridDim.x) {
+    if (d.vbin[so + v] != mode) continue;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    g2_gather(d, s, d.vcent[so + v], key, nullptr, nullptr, nullptr, &cnt, false);
+    __syncthreads();
+    const int n = min(cnt, G2_CAP);
+    for (int i = threadIdx.x; i < n; i += MOR_BT) d.is_ground[so + (int)(key[i] & 0xffffffffu)] = 1;
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------ launch sequences
 #define MOR_LAUNCH(id, kern, grid, ...)                                   \
   do {                                                                    \
@@ -1426,8 +1587,8 @@ __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
     mor_timer_end(tm, id, st);                                            \
   } while (0)
 
-void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B), gW(getenv("MOR_GW") ? atoi(getenv("MOR_GW")) : 64, d.B);
+static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+  const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B);
   MOR_LAUNCH(MK_CLASSIFY, k_classify, gT, d);
   MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
   MOR_LAUNCH(MK_SCATTER, k_scatter, gT, d);
@@ -1441,6 +1602,27 @@ void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   MOR_LAUNCH(MK_HEADS_SCAN, k_heads_scan, gB, d);
   MOR_LAUNCH(MK_HEADS_SCATTER, k_heads_scatter, gM, d);
   MOR_LAUNCH(MK_ROWTABLE, k_rowtable, dim3((d.g.nrows + MOR_BT) / MOR_BT > 32 ? 32 : (d.g.nrows + MOR_BT) / MOR_BT, d.B), d);
+}
+
+void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+  const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B), gW(getenv("MOR_GW") ? atoi(getenv("MOR_GW")) : 64, d.B);
+  if (d.gmode == 0) {
+    mor_launch_split_and_grid(d, st, tm);
+  } else {
+    // voxel-covariance ground removal: pass A (trim, VoxelGrid sort), voxel tests, pass B (split by ground flag)
+    hipMemsetD32Async((hipDeviceptr_t)(d.zmin_i + d.s0), 0x7fffffff, d.B, st);
+    hipMemsetD32Async((hipDeviceptr_t)(d.zmax_i + d.s0), (int)0x80000000, d.B, st);
+    hipMemsetAsync(d.is_ground + (size_t)d.s0 * d.Nmax, 0, (size_t)d.B * d.Nmax * sizeof(int), st);
+    MorDev da = d; da.gmode = 1; da.g = d.gv; da.cloud = d.rawbuf; da.cell_passes = d.voxel_passes; da.tiles_m = d.tiles;
+    da.skey = d.rkeys[da.cell_passes & 1]; da.sidx = d.rvals[da.cell_passes & 1];
+    mor_launch_split_and_grid(da, st, tm);
+    MOR_LAUNCH(MK_G2_CENTROID, k_g2_centroid, dim3(32, d.B), da);
+    MOR_LAUNCH(MK_G2_COV, k_g2_cov, dim3(512, d.B), da);
+    MOR_LAUNCH(MK_G2_MODE, k_g2_mode, gB, da);
+    MOR_LAUNCH(MK_G2_MARK, k_g2_mark, dim3(512, d.B), da);
+    MorDev db = d; db.gmode = 2;
+    mor_launch_split_and_grid(db, st, tm);
+  }
   if (!getenv("MOR_EXP_GENERAL_CC")) {
     mor_timer_begin(tm, MK_CELLGRAPH, st);
     hipLaunchKernelGGL(k_cellgraph, gB, dim3(CG_T), 0, st, d);

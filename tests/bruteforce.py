@@ -44,6 +44,63 @@ def ground_crop(xyzi, p):
     return raw, np.nonzero(~outside)[0], np.nonzero(outside)[0]
 
 
+def ground_voxel(xyzi, p):
+    """:90-200, intended semantics with the deterministic definitions of DESIGN.md §G2 — returns raw (T,4),
+    cloud_src, gp (sorted unique ground indices into raw).  Pure definition: voxels by integer floor
+    coordinates, fp32 sums in the stated orders, neighbours by the dense distance matrix."""
+    x, y, z = xyzi[:, 0], xyzi[:, 1], xyzi[:, 2]
+    X, Y = f32(p.trim_x), f32(p.trim_y)
+    fin = np.isfinite(x) & np.isfinite(y) & np.isfinite(z)
+    raw = xyzi[fin & (x >= -X) & (x <= X) & (y >= -Y) & (y <= Y)]
+    T = len(raw)
+    is_ground = np.zeros(T, bool)
+    if T:
+        leaf = f32(p.gp_leaf)
+        inv = f32(1.0) / leaf
+        ijk = np.floor(raw[:, :3].astype(f32) * inv).astype(np.int64)           # absolute voxel coordinates
+        order = np.lexsort((np.arange(T), ijk[:, 0], ijk[:, 1], ijk[:, 2]))     # (z, y, x, index)
+        keys = ijk[order]
+        starts = np.nonzero(np.r_[True, np.any(keys[1:] != keys[:-1], axis=1)])[0]
+        ends = np.r_[starts[1:], T]
+        rr = np.float64(leaf)
+        r2 = f32(rr * rr)
+        pts = raw[:, :3].astype(f32)
+        accepted = []   # (bin, neighbour indices)
+        for s0, e0 in zip(starts, ends):
+            idx = order[s0:e0]
+            sx = sy = sz = f32(0)
+            for i in idx:   # fp32 sequential, ascending point index
+                sx = f32(sx + pts[i, 0]); sy = f32(sy + pts[i, 1]); sz = f32(sz + pts[i, 2])
+            n = f32(len(idx))
+            c = np.array([sx / n, sy / n, sz / n], f32)
+            d = sqdist_matrix(c[None, :], pts)[0]
+            nb = np.nonzero(d < r2)[0]
+            if len(nb) <= 3:
+                continue
+            nb = nb[np.lexsort((nb, d[nb]))]   # (d², index)
+            cx = cy = cz = f32(0)
+            for i in nb:
+                cx = f32(cx + pts[i, 0]); cy = f32(cy + pts[i, 1]); cz = f32(cz + pts[i, 2])
+            fn = f32(len(nb))
+            cx, cy, cz = f32(cx / fn), f32(cy / fn), f32(cz / fn)
+            c02 = c12 = c22 = f32(0)
+            for i in nb:
+                dx, dy, dz = f32(pts[i, 0] - cx), f32(pts[i, 1] - cy), f32(pts[i, 2] - cz)
+                c12 = f32(c12 + f32(dy * dz)); c22 = f32(c22 + f32(dz * dz)); c02 = f32(c02 + f32(dz * dx))
+            if not (abs(np.float64(c02)) < 0.001 and abs(np.float64(c12)) < 0.001 and abs(np.float64(c22)) < 0.001):
+                continue
+            accepted.append((int(f32(c[2] * f32(10))), nb))   # truncation toward zero
+        if accepted:
+            bins = {}
+            for b, _ in accepted:
+                bins[b] = bins.get(b, 0) + 1
+            best = min(bins, key=lambda b: (-bins[b], b))   # mode, ties → smallest key
+            for b, nb in accepted:
+                if b == best:
+                    is_ground[nb] = True
+    return raw, np.nonzero(~is_ground)[0], np.nonzero(is_ground)[0]
+
+
 def clusters(cloud_xyz, p):
     """:202-262 — list of index arrays (ascending), ordered by (size desc, first index asc); centroids."""
     n = len(cloud_xyz)
@@ -160,7 +217,7 @@ class BruteMOR:
         p = self.p
         xyzi = np.asarray(xyzi, f32).reshape(-1, 4)
         self.ca = self.cb
-        raw, cloud_src, gp = ground_crop(xyzi, p)
+        raw, cloud_src, gp = (ground_voxel if p.ground_method == 1 else ground_crop)(xyzi, p)
         cloud = raw[cloud_src]
         comps, cents = clusters(cloud[:, :3], p)
         cb = dict(raw=raw, cloud=cloud, cloud_src=cloud_src, gp=gp, comps=comps, cents=cents,

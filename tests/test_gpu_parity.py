@@ -249,3 +249,28 @@ def test_full_size_batch_properties():
             assert np.isin(a, t).all()
     assert np.array_equal(outs[5].view(np.uint32), outs[37].view(np.uint32))
     b.close()
+
+
+@pytest.mark.parametrize("seed", [1, 4])
+def test_voxel_covariance_ground_small_streams(seed):
+    """G2 (reference :90-200): voxel-covariance ground removal, full pipeline on top of it."""
+    p = scene_params(method_choice=2)
+    p.ground_method = 1
+    p.gp_leaf = 0.1
+    frames = small_stream(seed, n_frames=5, n_floor=900)
+    st = _run_lockstep(p, [frames])
+    assert st["clusters"] > 0
+    o = Oracle(p)
+    o.push(*frames[0])
+    assert o.counts().n_ground > 100
+
+
+def test_voxel_covariance_ground_hdl64():
+    p = kitti_params(1)
+    p.ground_method = 1
+    frames = [synth.frame(1000, "hdl64", f) for f in range(3)]
+    streams = [frames, [synth.frame(1001, "hdl64", f) for f in range(3)]]
+    st = _run_lockstep(p, streams)
+    o = Oracle(p)
+    o.push(*frames[0])
+    assert o.counts().n_ground > 20000   # the ground plane is the dominant bin

@@ -90,3 +90,22 @@ def test_blob_layouts_equivalent():
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert np.array_equal(a[:, :3].view(np.uint32), c[:, :3].view(np.uint32))
     assert np.all(c[:, 3] == 0)
+
+
+@pytest.mark.parametrize("seed", [1, 4])
+def test_oracle_voxel_covariance_ground_matches_bruteforce(seed):
+    """G2 (reference :90-200, dead code there): intended semantics with the deterministic definitions of
+    DESIGN.md — oracle vs the definition-level numpy version, full pipeline on top of it."""
+    p = scene_params(method_choice=2)
+    p.ground_method = 1
+    p.gp_leaf = 0.1
+    o, b = Oracle(p, 4, 3), BruteMOR(p, 4, 3)
+    saw_ground = 0
+    for f, (pts, pose) in enumerate(small_stream(seed, n_frames=4, n_floor=900)):
+        o.push(pts, pose)
+        b.push(pts, pose)
+        _compare_frame(o, b, "G2 seed %d frame %d" % (seed, f))
+        out_o, out_b = o.filter(), b.filter()
+        assert np.array_equal(out_o.view(np.uint32), out_b.view(np.uint32))
+        saw_ground = max(saw_ground, int(o.counts().n_ground))
+    assert saw_ground > 100   # the floor plane was found
