@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--workload", default="hdl64_b64", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--method", type=int, default=1, choices=[1, 2])
+    ap.add_argument("--ground-method", type=int, default=0, choices=[0, 1], help="0 crop box (reference default), 1 voxel covariance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--e2e", action="store_true", help="also time a few steps with host-resident clouds (PCIe-inclusive)")
@@ -68,6 +69,7 @@ def main():
         B = args.streams
     npts = synth.n_points(sensor)
     p = kitti_params(args.method)
+    p.ground_method = args.ground_method
     ndev = engine.device_count()
     if ndev < 1:
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback in the product path)")

@@ -350,7 +350,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     if (f.flags & 1u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than %d clusters", s, d.Kcap);
     if (f.flags & 2u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: voxel key out of range in method 2", s);
     if (f.flags & 8u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: z extent of the trimmed cloud exceeds the 64 m the voxel ground variant covers", s);
-    if (f.flags & 16u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than 2048 points within gp_leaf of a voxel centroid", s);
+    if (f.flags & 16u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than 16384 points within gp_leaf of a voxel centroid", s);
     const size_t ko = (size_t)s * d.Kcap;
     cent.resize(3 * (size_t)f.K);
     for (uint32_t k = 0; k < f.K; ++k) { cent[3 * k] = d.h_centroid[ko + k].x; cent[3 * k + 1] = d.h_centroid[ko + k].y; cent[3 * k + 2] = d.h_centroid[ko + k].z; }

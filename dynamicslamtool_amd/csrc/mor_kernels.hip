@@ -1472,9 +1472,10 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_centroid(MorDev d) {
     d.vcent[so + v] = make_float4(sx / n, sy / n, sz / n, 0.f);
   }
 }
-#define G2_CAP 2048   // neighbours of one voxel centroid held in LDS
+#define G2_CAP 16384    // neighbours of one voxel centroid held in LDS as (d², index) keys (128 KiB of the CU's 160)
+#define G2_CHUNK 1024   // coordinates staged per step of the ordered fp32 sums
 // all trimmed points with d² < leaf² around q (radiusSearch, :125), appended to the LDS list in arbitrary order
-__device__ __forceinline__ void g2_gather(const MorDev &d, int s, float4 q, unsigned long long *key, float *px, float *py, float *pz, int *cnt, bool coords) {
+__device__ __forceinline__ void g2_gather(const MorDev &d, int s, float4 q, unsigned long long *key, int *cnt) {
   const size_t so = (size_t)s * d.Nmax;
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   int cx, cy, cz; bool cl; grid_cell(d.g, q, 0.f, d.zbase[s], cx, cy, cz, cl);
@@ -1488,52 +1489,59 @@ __device__ __forceinline__ void g2_gather(const MorDev &d, int s, float4 q, unsi
       const float dd = sqdist(q.x, q.y, q.z, p.x, p.y, p.z);
       if (dd < d.leaf_r2) {
         int slot = atomicAdd(cnt, 1);
-        if (slot < G2_CAP) { key[slot] = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(p.w); if (coords) { px[slot] = p.x; py[slot] = p.y; pz[slot] = p.z; } }
+        if (slot < G2_CAP) key[slot] = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(p.w);
       }
     }
   }
 }
 // one workgroup per voxel: neighbours sorted by (d², index) as KdTreeFLANN::radiusSearch returns them; > 3 of them
-// (:131); fp32 centroid (:142) and un-normalised scatter terms xz, yz, zz (:144) summed in that order; accepted
-// voxels (:145) record their z-bin (:166)
+// (:131); fp32 centroid (:142) and un-normalised scatter terms xz, yz, zz (:144) summed in that order (coordinates
+// staged through LDS in chunks, one thread adds them up); accepted voxels (:145) record their z-bin (:166)
 __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
   int s = blockIdx.y + d.s0, V = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
   __shared__ unsigned long long key[G2_CAP];
-  __shared__ unsigned short slot[G2_CAP];
-  __shared__ float px[G2_CAP], py[G2_CAP], pz[G2_CAP];
+  __shared__ float px[G2_CHUNK], py[G2_CHUNK], pz[G2_CHUNK];
   __shared__ int cnt;
+  __shared__ float acc[6];
   for (int v = blockIdx.x; v < V; v += gridDim.x) {
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     const float4 q = d.vcent[so + v];
-    g2_gather(d, s, q, key, px, py, pz, &cnt, true);
+    g2_gather(d, s, q, key, &cnt);
     __syncthreads();
     const int n = cnt;
     int bin = 0x7fffffff;
     if (n > G2_CAP) { if (threadIdx.x == 0) atomicOr(&d.info[s].flags, 16u); }
     else if (n > 3) {
       int P = 4; while (P < n) P <<= 1;
-      for (int i = threadIdx.x; i < P; i += MOR_BT) { slot[i] = (unsigned short)i; if (i >= n) key[i] = ~0ull; }
+      for (int i = n + threadIdx.x; i < P; i += MOR_BT) key[i] = ~0ull;
       __syncthreads();
-      for (int k = 2; k <= P; k <<= 1) for (int j = k >> 1; j > 0; j >>= 1) {   // bitonic sort of (key, slot)
+      for (int k = 2; k <= P; k <<= 1) for (int j = k >> 1; j > 0; j >>= 1) {   // bitonic sort of the keys
         for (int i = threadIdx.x; i < P; i += MOR_BT) {
           int l = i ^ j;
-          if (l > i) {
-            bool up = (i & k) == 0; unsigned long long a = key[i], b = key[l];
-            if ((a > b) == up) { key[i] = b; key[l] = a; unsigned short t = slot[i]; slot[i] = slot[l]; slot[l] = t; }
-          }
+          if (l > i) { bool up = (i & k) == 0; unsigned long long a = key[i], b = key[l]; if ((a > b) == up) { key[i] = b; key[l] = a; } }
         }
         __syncthreads();
       }
-      if (threadIdx.x == 0) {
-        float cx = 0.f, cy = 0.f, cz = 0.f;
-        for (int i = 0; i < n; ++i) { int t = slot[i]; cx += px[t]; cy += py[t]; cz += pz[t]; }
-        const float fn = (float)n; cx /= fn; cy /= fn; cz /= fn;
-        float c02 = 0.f, c12 = 0.f, c22 = 0.f;
-        for (int i = 0; i < n; ++i) { int t = slot[i]; float dx = px[t] - cx, dy = py[t] - cy, dz = pz[t] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; }
-        if ((double)fabsf(c02) < 0.001 && (double)fabsf(c12) < 0.001 && (double)fabsf(c22) < 0.001) bin = (int)(q.z * 10);
+      if (threadIdx.x == 0) { acc[0] = acc[1] = acc[2] = acc[3] = acc[4] = acc[5] = 0.f; }
+      for (int pass = 0; pass < 2; ++pass) {   // pass 0: Σ p (centroid); pass 1: Σ (p−c) terms
+        for (int c0 = 0; c0 < n; c0 += G2_CHUNK) {
+          const int m = min(G2_CHUNK, n - c0);
+          for (int i = threadIdx.x; i < m; i += MOR_BT) { float4 p = d.rawbuf[so + (int)(key[c0 + i] & 0xffffffffu)]; px[i] = p.x; py[i] = p.y; pz[i] = p.z; }
+          __syncthreads();
+          if (threadIdx.x == 0) {
+            if (pass == 0) { float cx = acc[0], cy = acc[1], cz = acc[2]; for (int i = 0; i < m; ++i) { cx += px[i]; cy += py[i]; cz += pz[i]; } acc[0] = cx; acc[1] = cy; acc[2] = cz; }
+            else { const float cx = acc[0], cy = acc[1], cz = acc[2]; float c02 = acc[3], c12 = acc[4], c22 = acc[5];
+              for (int i = 0; i < m; ++i) { float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; }
+              acc[3] = c02; acc[4] = c12; acc[5] = c22; }
+          }
+          __syncthreads();
+        }
+        if (pass == 0 && threadIdx.x == 0) { const float fn = (float)n; acc[0] /= fn; acc[1] /= fn; acc[2] /= fn; }
+        __syncthreads();
       }
+      if (threadIdx.x == 0 && (double)fabsf(acc[3]) < 0.001 && (double)fabsf(acc[4]) < 0.001 && (double)fabsf(acc[5]) < 0.001) bin = (int)(q.z * 10);
     }
     if (threadIdx.x == 0) d.vbin[so + v] = bin;
     __syncthreads();
@@ -1571,7 +1579,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mark(MorDev d) {
     if (d.vbin[so + v] != mode) continue;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
-    g2_gather(d, s, d.vcent[so + v], key, nullptr, nullptr, nullptr, &cnt, false);
+    g2_gather(d, s, d.vcent[so + v], key, &cnt);
     __syncthreads();
     const int n = min(cnt, G2_CAP);
     for (int i = threadIdx.x; i < n; i += MOR_BT) d.is_ground[so + (int)(key[i] & 0xffffffffu)] = 1;
