@@ -537,14 +537,23 @@ template <bool LDS> __device__ __forceinline__ int cg_unite(int *P, int a, int b
   }
   return ra;
 }
-// any pair (a ∈ A, b ∈ B) with d² < r²?  one thread, B streamed four independent loads at a time
+// any pair (a ∈ A, b ∈ B) with d² < r²?  one thread; points fetched in blocks of 8 (B) × 4 (A) independent loads so
+// a 16 × 16 test costs ≈10 memory round trips instead of 64
 __device__ __forceinline__ bool pair_hit_serial(const float4 *sp, int a0, int na, int b0, int nb, float r2) {
-  for (int ia = 0; ia < na; ++ia) {
-    const float4 pa = sp[a0 + ia];
-    for (int ib = 0; ib < nb; ib += 4) {
-      float4 q0 = sp[b0 + ib], q1 = sp[b0 + min(ib + 1, nb - 1)], q2 = sp[b0 + min(ib + 2, nb - 1)], q3 = sp[b0 + min(ib + 3, nb - 1)];
-      if (sqdist(pa.x, pa.y, pa.z, q0.x, q0.y, q0.z) < r2 || sqdist(pa.x, pa.y, pa.z, q1.x, q1.y, q1.z) < r2 ||
-          sqdist(pa.x, pa.y, pa.z, q2.x, q2.y, q2.z) < r2 || sqdist(pa.x, pa.y, pa.z, q3.x, q3.y, q3.z) < r2) return true;
+  for (int ib0 = 0; ib0 < nb; ib0 += 8) {
+    float4 q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = sp[b0 + min(ib0 + j, nb - 1)];
+    for (int ia0 = 0; ia0 < na; ia0 += 4) {
+      float4 pa[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pa[i] = sp[a0 + min(ia0 + i, na - 1)];
+      bool hit = false;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hit |= sqdist(pa[i].x, pa[i].y, pa[i].z, q[j].x, q[j].y, q[j].z) < r2;   // clamped duplicates repeat real pairs
+      if (hit) return true;
     }
   }
   return false;
