@@ -203,7 +203,7 @@ def main():
                        "profile": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in p.as_dict().items()}},
             "device_ms_per_step": round(dev_ms / args.steps, 4),
             "algorithmic_bytes_per_frame_pair": int(b_alg),
-            "stage_totals": {k: sum(batch.stage_counts(s)[k] for s in range(B)) for k in ("n_occ", "n_defer", "C_prev")},
+            "stage_totals": {k: sum(batch.stage_counts(s)[k] for s in range(B)) for k in ("n_occ", "n_tier1b", "n_defer", "C_prev")},
             "stream0": {"T": int(c0.n_trim), "M": int(c0.n_cloud), "G": int(c0.n_ground), "K": int(c0.n_clusters), "C": int(c0.n_clustered), "pairs": int(c0.n_corr), "tracks": int(c0.n_tracks)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
             "e2e_host_frame_pairs_per_s": None if e2e is None else round(e2e, 2),

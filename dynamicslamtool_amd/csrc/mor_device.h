@@ -116,7 +116,8 @@ struct MorDev {
   float *pair_d;             // [B][Kcap]
   int *pair_cnt;             // [B][Kcap]
   int *pair_of_prev, *pair_of_cur; // [B][Kcap]
-  int *wl, *wl_n;            // [B][Nmax], [B]  method-1 tier-2 worklist (query ids) and its length
+  int *wl, *wl_n; float *wl_best; // [B][Nmax], [B]  method-1 worklist after tier 1 (query ids, best d² so far)
+  int *wl2, *wl2_n;          // [B][Nmax], [B]  method-1 worklist of the wave tier
   unsigned long long *vox;   // [B][Hcap]
   unsigned char *det;        // [B][Kcap]  detection_results of cb
   // filter stage
@@ -140,7 +141,7 @@ struct MorDev {
 enum MorKernelId {
   MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_ROWTABLE, MK_CELLGRAPH, MK_CELLBOX, MK_HOOK_NEAR, MK_HOOK_SHELL, MK_FLATTEN, MK_CELLCID,
   MK_SELECT_COUNT, MK_SELECT_SCAN, MK_SELECT_SCATTER, MK_RANK, MK_OFFSETS, MK_LABEL, MK_RHIST, MK_RSCAN, MK_RSCATTER,
-  MK_STATS, MK_STATS_FIN, MK_XFORM_PREV, MK_XFORM_FIN, MK_NN, MK_PAIRS, MK_SCORE_FAST, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
+  MK_STATS, MK_STATS_FIN, MK_XFORM_PREV, MK_XFORM_FIN, MK_NN, MK_PAIRS, MK_SCORE_FAST, MK_SCORE_ROWS, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
   MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_G2_CENTROID, MK_G2_COV, MK_G2_MODE, MK_G2_MARK, MK_COUNT
 };
 extern const char *const mor_kernel_names[MK_COUNT];

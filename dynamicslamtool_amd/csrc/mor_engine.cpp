@@ -273,7 +273,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.nn_fwd, B * K) && dalloc(b, d.nn_bwd, B * K) && dalloc(b, d.nn_fwd_d, B * K) && dalloc(b, d.pair_q, B * K) && dalloc(b, d.pair_m, B * K) && dalloc(b, d.pair_d, B * K);
   ok = ok && dalloc(b, d.pair_cnt, B * K) && dalloc(b, d.pair_of_prev, B * K) && dalloc(b, d.pair_of_cur, B * K) && dalloc(b, d.det, B * K);
   if (p->method_choice == 2) ok = ok && dalloc(b, d.vox, B * (size_t)d.Hcap);
-  ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_n, B) && dalloc(b, d.dbg, B * 16);
+  ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_n, B) && dalloc(b, d.wl_best, B * N) && dalloc(b, d.wl2, B * N) && dalloc(b, d.wl2_n, B) && dalloc(b, d.dbg, B * 16);
   ok = ok && dalloc(b, d.zmin_i, B) && dalloc(b, d.zmax_i, B) && dalloc(b, d.zorg, B) && dalloc(b, d.zbase, B) && dalloc(b, d.mode_bin, B);
   if (d.gmode == 1) ok = ok && dalloc(b, d.rawbuf, B * N) && dalloc(b, d.is_ground, B * N) && dalloc(b, d.vcent, B * N) && dalloc(b, d.vbin, B * N);
   if (ok) {   // crop-box variant: the clustering grid starts at gp_limit for every stream
@@ -473,7 +473,7 @@ int mor_exp_read_stamps(const mor_batch *b, unsigned long long *out) {
 }
 int mor_get_stage_counts(const mor_batch *b, int s, uint32_t *out, int n) {
   CHECK_STREAM();
-  const uint32_t v[4] = {f.n_occ, f.n_defer, f.Kprev, f.Cprev};
+  const uint32_t v[4] = {f.n_occ, f.n_defer, f.pad0, f.Cprev};   // v[2] = queries left after tier 1
   for (int i = 0; i < n && i < 4; ++i) out[i] = v[i];
   return MOR_OK;
 }

@@ -28,7 +28,7 @@
 const char *const mor_kernel_names[MK_COUNT] = {
     "classify", "scan_tiles", "scatter", "heads_count", "heads_scan", "heads_scatter", "rowtable", "cellgraph", "cellbox", "hook_cells", "hook_cells_shell", "flatten", "cellcid",
     "select_count", "select_scan", "select_scatter", "rank", "offsets", "label", "rhist", "rscan", "rscatter",
-    "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "pairs", "score_fast", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
+    "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "pairs", "score_fast", "score_rows", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
     "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_mode", "g2_mark"};
 
 // ------------------------------------------------------------------------------------ helpers
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(MOR_BT) void k_pairs(MorDev d) {
     }
     carry += tot;
   }
-  if (threadIdx.x == 0) { d.info[s].n_pairs = carry; d.wl_n[s] = 0; }
+  if (threadIdx.x == 0) { d.info[s].n_pairs = carry; d.wl_n[s] = 0; d.wl2_n[s] = 0; }
 }
 
 // ------------------------------------------------------------------------------------ P3: method 1 (:336-366)
@@ -1167,34 +1167,63 @@ __device__ __forceinline__ void scan_cells(const MorDev &d, size_t so, const int
   }
 }
 
-// Tier 1 — one THREAD per query: its own cell, then the 9 rows of cells around it (row_order[0..8],
-// lower bound 0).  Static surfaces end here: either some matched point lies within √lb (never
-// counted), or the nearest one is closer than one cell edge, which already beats every farther row
-// (bound ≥ cs²).  Anything else — or a thread that has scanned its budget — goes to the worklist of
-// tier 2 (k_score_pde, one wave per query).
+// wave-aggregated append of (query, best-so-far) to a per-stream worklist
+__device__ __forceinline__ void wl_push(bool want, int *n, int *list, float *bests, int j, float best) {
+  unsigned long long m = __ballot(want);
+  if (!m) return;
+  int basew = 0, leader = __ffsll((long long)m) - 1;
+  if (lane_id() == leader) basew = atomicAdd(n, __popcll(m));
+  basew = __shfl(basew, leader, 64);
+  if (want) { int pos = basew + __popcll(m & lanemask_lt()); list[pos] = j; if (bests) bests[pos] = best; }
+}
+// Tier 1 — one THREAD per query, its OWN cell only.  On a static surface a point of the matched cluster lies
+// within √lb of q, almost always in q's own cell: ≈95 % of the queries end here (never counted).  The rest is
+// compacted into a worklist so the next tier runs full waves of hard queries instead of dragging every wave.
 __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
   int s, t0; map_block(d.B, d.tiles_m * 8, s, t0);
   const int pv = d.cur ^ 1, Cp = d.info[s].Cprev;
+  const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
+  const float4 *sp = d.sorted + so;
+  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
+  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   for (int base = t0 * MOR_BT; base < Cp; base += d.tiles_m * 8 * MOR_BT) {
+    const int j = base + threadIdx.x;
+    bool more = false; float best = INFINITY;
+    if (j < Cp) {
+      int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
+      if (pr >= 0) {
+        const int target = d.pair_m[ko + pr];
+        const float4 q = d.cl_pts[pv][so + j];
+        const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
+        int budget = 64;
+        int c = cell_lookup(d.g, ckey, rs, cx, cy, cz);
+        if (c >= 0 && d.ccid[so + c] == target) scan4(sp, st[c], st[c + 1], q, d.pde_lb, best, budget);
+        more = best > d.pde_lb;
+      }
+    }
+    wl_push(more, &d.wl_n[s], d.wl + so, d.wl_best + so, j, best);
+  }
+}
+// Tier 1b — one THREAD per remaining query: the 9 rows of cells around it (row_order[0..8], lower bound 0).  Ends
+// here when some matched point lies within √lb, or when the nearest one is closer than one cell edge, which beats
+// every farther row (bound ≥ cs²).  Anything else — or a thread that has scanned its budget — goes to tier 2.
+__global__ __launch_bounds__(MOR_BT) void k_score_rows(MorDev d) {
+  int s = blockIdx.y + d.s0, pv = d.cur ^ 1, nq = d.wl_n[s];
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const int R = d.score_R;
   const float cs = d.g.cs * 0.999f, ring2 = cs * cs;   // lower bound of every row beyond the first 9
-  const int j = base + threadIdx.x;
-  bool defer = false;
-  if (j < Cp) {
-    int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
-    if (pr >= 0) {
-      const int target = d.pair_m[ko + pr];
+  for (int w0 = blockIdx.x * MOR_BT; w0 < nq; w0 += gridDim.x * MOR_BT) {
+    const int w = w0 + threadIdx.x;
+    bool defer = false; int j = 0; float best = INFINITY;
+    if (w < nq) {
+      j = d.wl[so + w]; best = d.wl_best[so + w];
+      const int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]], target = d.pair_m[ko + pr];
       const float4 q = d.cl_pts[pv][so + j];
       const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
-      float best = INFINITY; int budget = d.t1_budget;   // points this thread may scan before handing the query to a wave
-      {  // stage 0: the query's own cell — on a static surface a matched point within √lb is almost always here
-        int c = cell_lookup(d.g, ckey, rs, cx, cy, cz);
-        if (c >= 0 && d.ccid[so + c] == target) scan4(sp, st[c], st[c + 1], q, d.pde_lb, best, budget);
-      }
+      int budget = d.t1_budget;   // points this thread may scan before handing the query to a wave
       for (int ro = 0; ro < 9 && best > d.pde_lb && budget > 0; ++ro) {
         int y = cy + d.row_order[2 * ro], z = cz + d.row_order[2 * ro + 1];
         if ((unsigned)y >= (unsigned)d.g.ny || (unsigned)z >= (unsigned)d.g.nz) continue;
@@ -1210,14 +1239,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
         else defer = true;
       }
     }
-  }
-  unsigned long long m = __ballot(defer);
-  if (m) {   // wave-aggregated push
-    int basew = 0, leader = __ffsll((long long)m) - 1;
-    if (lane_id() == leader) basew = atomicAdd(&d.wl_n[s], __popcll(m));
-    basew = __shfl(basew, leader, 64);
-    if (defer) d.wl[so + basew + __popcll(m & lanemask_lt())] = j;
-  }
+    wl_push(defer, &d.wl2_n[s], d.wl2 + so, nullptr, j, best);
   }
 }
 __device__ __forceinline__ float wave_min(float v) {
@@ -1242,7 +1264,7 @@ __device__ __forceinline__ float wave_scan_cell(const float4 *sp, int b0, int e0
   return wave_min(local);
 }
 __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
-  int s = blockIdx.y + d.s0, pv = d.cur ^ 1, nq = d.wl_n[s];
+  int s = blockIdx.y + d.s0, pv = d.cur ^ 1, nq = d.wl2_n[s];
   const int wv = blockIdx.x * (MOR_BT / 64) + wave_id(), nw = gridDim.x * (MOR_BT / 64), lane = lane_id();
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
@@ -1251,7 +1273,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
   const int R = d.score_R;
   const float cs = d.g.cs * 0.999f;   // conservative cell edge for the row lower bounds
   for (int w = wv; w < nq; w += nw) {
-    const int j = d.wl[so + w];
+    const int j = d.wl2[so + w];
     int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
     if (pr < 0) continue;
     const int target = d.pair_m[ko + pr];
@@ -1289,11 +1311,18 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
             if (box_dist2(q, d.cbox_lo[so + c], d.cbox_hi[so + c]) < lim) { cand = c; break; }
           }
         }
-        unsigned long long m = __ballot(cand >= 0);
-        if (!m) break;
-        while (m && best > d.pde_lb) {   // whole wave scans each surviving cell
+        if (!__ballot(cand >= 0)) break;
+        // small surviving cells are scanned by the lane that found them (all rows in parallel); big ones by the whole wave
+        const int cb = cand >= 0 ? st[cand] : 0, ce = cand >= 0 ? st[cand + 1] : 0;
+        const bool small = cand >= 0 && ce - cb <= 16;
+        float local = INFINITY;
+        if (small) { int budget = 0x7fffffff; scan4(sp, cb, ce, q, d.pde_lb, local, budget); }
+        best = fminf(best, wave_min(local));
+        unsigned long long m = __ballot(cand >= 0 && !small);
+        while (m && best > d.pde_lb) {
           int l = __ffsll((long long)m) - 1; m &= m - 1;
           int c = __shfl(cand, l, 64);
+          if (box_dist2(q, d.cbox_lo[so + c], d.cbox_hi[so + c]) >= fminf(best, d.pde_ub)) continue;   // best may have tightened since
           best = fminf(best, wave_scan_cell(sp, st[c], st[c + 1], q, d.pde_lb, lane));
         }
         if (best <= d.pde_lb) break;
@@ -1391,7 +1420,7 @@ __global__ __launch_bounds__(MOR_BT) void k_decide(MorDev d) {
   for (int k = threadIdx.x; k < K; k += MOR_BT) { d.h_centroid[ko + k] = d.centroid[d.cur][ko + k]; d.h_det[ko + k] = d.det[ko + k]; }
   for (int k = threadIdx.x; k <= K; k += MOR_BT) d.h_cl_off[(size_t)s * (d.Kcap + 1) + k] = offc[k];
   if (threadIdx.x == 0) {
-    f.n_pairs = np; f.n_defer = (d.has_prev && d.method == 1) ? (uint32_t)d.wl_n[s] : 0u;
+    f.n_pairs = np; f.n_defer = (d.has_prev && d.method == 1) ? (uint32_t)d.wl2_n[s] : 0u; f.pad0 = (d.has_prev && d.method == 1) ? (uint32_t)d.wl_n[s] : 0u;
     d.info[s].Kprev = f.K; d.info[s].Cprev = f.C;   // this frame is the next push's `ca`
     d.info[s].n_pairs = np;
     d.h_info[s] = f;
@@ -1673,7 +1702,7 @@ void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     MOR_LAUNCH(MK_NN, k_nn_centroid, gKt, d, 1);
     MOR_LAUNCH(MK_PAIRS, k_pairs, gB, d);
     if (d.method == 1) {
-      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * 8), d); if (!getenv("MOR_EXP_SKIP_T2")) MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(getenv("MOR_T2G") ? atoi(getenv("MOR_T2G")) : 256, d.B), d); }
+      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * 8), d); MOR_LAUNCH(MK_SCORE_ROWS, k_score_rows, dim3(getenv("MOR_T1B") ? atoi(getenv("MOR_T1B")) : 128, d.B), d); if (!getenv("MOR_EXP_SKIP_T2")) MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(getenv("MOR_T2G") ? atoi(getenv("MOR_T2G")) : 256, d.B), d); }
     } else if (d.method == 2) {
       MOR_LAUNCH(MK_VOX_CLEAR, k_vox_clear, dim3(64, d.B), d);
       MOR_LAUNCH(MK_VOX_INSERT, k_vox_insert, gT, d);

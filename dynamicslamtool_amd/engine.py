@@ -251,7 +251,7 @@ class MorBatch:
     def stage_counts(self, s=0):
         a = (C.c_uint32 * 4)()
         _check(lib().mor_get_stage_counts(self._h, s, a, 4))
-        return {"n_occ": int(a[0]), "n_defer": int(a[1]), "K_prev": int(a[2]), "C_prev": int(a[3])}
+        return {"n_occ": int(a[0]), "n_defer": int(a[1]), "n_tier1b": int(a[2]), "C_prev": int(a[3])}
 
     def output_device(self, s=0):
         n = C.c_uint64(0)
