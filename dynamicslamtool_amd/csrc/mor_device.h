@@ -32,6 +32,8 @@ struct MorRadix {
   int *kout, *vout;       // kout may be nullptr on a last pass that only needs the values
   int shift, count_sel;   // digit = (key >> shift) & 255; element count: 0 → M, 1 → C
   int drop_negative;      // elements with key < 0 are dropped (unclustered points)
+  int *vout2;             // optional second copy of the values (pass 0 of the cluster partition also writes cl_idx)
+  int skip_k_le;          // > 0: streams with K ≤ this need no further pass — the kernel returns at once for them
 };
 
 struct MorStreamArgs {       // per stream, per push (host → device, one small copy)

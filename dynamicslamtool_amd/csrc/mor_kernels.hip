@@ -869,7 +869,10 @@ __device__ __forceinline__ void radix_item(const MorRadix &j, size_t so, int cou
   key = j.kin[so + i]; val = j.vin ? j.vin[so + i] : i;
   if (j.drop_negative) valid = key >= 0;
 }
-__device__ __forceinline__ int radix_count(const MorDev &d, const MorRadix &j, int s) { return j.count_sel == 0 ? d.info[s].M : d.info[s].C; }
+__device__ __forceinline__ int radix_count(const MorDev &d, const MorRadix &j, int s) {
+  if (j.skip_k_le > 0 && (int)d.info[s].K <= j.skip_k_le) return 0;   // all higher digits are zero: the previous pass already produced the final order
+  return j.count_sel == 0 ? d.info[s].M : d.info[s].C;
+}
 
 __global__ __launch_bounds__(MOR_BT) void k_rhist(MorDev d, MorRadix j) {
   int s, t0; map_block(d.B, d.tiles_m, s, t0);
@@ -943,6 +946,7 @@ __global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, MorRadix j) {
       int pos = wcnt[wave_id()][dg] + pre[it];
       if (j.kout) j.kout[so + pos] = key[it];
       j.vout[so + pos] = val[it];
+      if (j.vout2) j.vout2[so + pos] = val[it];
     }
     __syncthreads();
   }
@@ -1639,7 +1643,7 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
   MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
   MOR_LAUNCH(MK_SCATTER, k_scatter, gT, d);
   for (int pass = 0; pass < d.cell_passes; ++pass) {   // points sorted by cell key; result in (skey, sidx) = buffers [cell_passes & 1]
-    MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0};
+    MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, 0};
     MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
     MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
     MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
@@ -1688,7 +1692,10 @@ void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   MOR_LAUNCH(MK_LABEL, k_label, gM, d);
   for (int pass = 0; pass < d.radix_passes; ++pass) {   // clustered points partitioned by cluster id, index order kept ⇒ cluster_indices
     const bool last = pass == d.radix_passes - 1;
-    MorRadix j = {pass == 0 ? d.pcid : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], last ? nullptr : d.rkeys[(pass + 1) & 1], last ? d.cl_idx : d.rvals[(pass + 1) & 1], 8 * pass, pass == 0 ? 0 : 1, pass == 0 ? 1 : 0};
+    // every pass also writes cl_idx: a stream with K ≤ 256^p has its final order after pass p−1 and later passes
+    // return at once for it (K ≤ 256 is the usual case: one effective pass)
+    MorRadix j = {pass == 0 ? d.pcid : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], last ? nullptr : d.rkeys[(pass + 1) & 1], last ? d.cl_idx : d.rvals[(pass + 1) & 1],
+                  8 * pass, pass == 0 ? 0 : 1, pass == 0 ? 1 : 0, last ? nullptr : d.cl_idx, pass == 0 ? 0 : (1 << (8 * pass))};
     MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
     MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
     MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
