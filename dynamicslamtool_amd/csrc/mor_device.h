@@ -88,7 +88,7 @@ struct MorDev {
   int *cstart;               // [B][Nmax+1]  first sorted position of each occupied cell
   int *row_start;            // [B][nrows+1]  first occupied cell of each (y,z) row
   int *cmin;                 // [B][Nmax]  smallest cloud index in the cell
-  float4 *cbox_lo, *cbox_hi; // [B][Nmax]  bounding box of the cell's points
+  float4 *cmeta;             // [B][2·Nmax]  per occupied cell: low corner of its point box (.w = cluster id bits), high corner
   float4 *sorted;            // [B][Nmax]  (x,y,z, bits(cloud index)) in cell order; .w becomes the cluster id after labelling
   int *parent;               // [B][Nmax]  union-find forest over occupied cells (parent ≤ child)
   int *croot;                // [B][Nmax]  flattened root per cell

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(MOR_BT) void k_cellbox(MorDev d) {
       lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
       hx = fmaxf(hx, __shfl_xor(hx, o, 64)); hy = fmaxf(hy, __shfl_xor(hy, o, 64)); hz = fmaxf(hz, __shfl_xor(hz, o, 64));
     }
-    if (lane == 0) { d.cbox_lo[so + a] = make_float4(lx, ly, lz, 0.f); d.cbox_hi[so + a] = make_float4(hx, hy, hz, 0.f); }
+    if (lane == 0) { d.cmeta[2 * (so + a)] = make_float4(lx, ly, lz, 0.f); d.cmeta[2 * (so + a) + 1] = make_float4(hx, hy, hz, 0.f); }
   }
 }
 
@@ -401,12 +401,12 @@ __global__ __launch_bounds__(MOR_BT) void k_hook_cells(MorDev d, int shell) {
     const int a0 = st[a], na = st[a + 1] - a0;
     int sh = 0; while ((1 << sh) < na && sh < 6) ++sh;
     const int at = 1 << sh, bt = 64 >> sh, la = lane & (at - 1), lb = lane >> sh;
-    const float4 alo = d.cbox_lo[so + a], ahi = d.cbox_hi[so + a];
+    const float4 alo = d.cmeta[2 * (so + a)], ahi = d.cmeta[2 * (so + a) + 1];
     // every lane resolves ITS neighbour in parallel: root differs from mine and the two cells' point boxes
     // are closer than r (conservative, 0.999 slack) ⇒ candidate for a pair test
     bool cand = false;
     if (nb >= 0) {
-      const float4 blo = d.cbox_lo[so + nb], bhi = d.cbox_hi[so + nb];
+      const float4 blo = d.cmeta[2 * (so + nb)], bhi = d.cmeta[2 * (so + nb) + 1];
       float gx = fmaxf(fmaxf(blo.x - ahi.x, alo.x - bhi.x), 0.f), gy = fmaxf(fmaxf(blo.y - ahi.y, alo.y - bhi.y), 0.f), gz = fmaxf(fmaxf(blo.z - ahi.z, alo.z - bhi.z), 0.f);
       cand = (gx * gx + gy * gy + gz * gz) * 0.999f < r2;
     }
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(MOR_BT) void k_flatten(MorDev d) {
 __global__ __launch_bounds__(MOR_BT) void k_cellcid(MorDev d) {
   int s = blockIdx.y + d.s0, nocc = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
-  for (int c = blockIdx.x * MOR_BT + threadIdx.x; c < nocc; c += gridDim.x * MOR_BT) d.ccid[so + c] = d.cid_of_root[so + d.croot[so + c]];
+  for (int c = blockIdx.x * MOR_BT + threadIdx.x; c < nocc; c += gridDim.x * MOR_BT) { int cid = d.cid_of_root[so + d.croot[so + c]]; d.ccid[so + c] = cid; reinterpret_cast<int *>(&d.cmeta[2 * (so + c)])[3] = cid; }
 }
 // kept components: min_cluster_size ≤ size ≤ max_cluster_size (:215-216)
 __device__ __forceinline__ bool kept_root(const MorDev &d, size_t so, int c) {
@@ -614,9 +614,9 @@ template <bool LDS> __device__ __forceinline__ void cg_hook_pass(const MorDev &d
           }
         }
         if (cb[0] < 0 && cb[1] < 0 && cb[2] < 0 && cb[3] < 0 && cb[4] < 0) continue;
-        if (!have_box) { alo = d.cbox_lo[so_ + a]; ahi = d.cbox_hi[so_ + a]; have_box = true; }
+        if (!have_box) { alo = d.cmeta[2 * (so_ + a)]; ahi = d.cmeta[2 * (so_ + a) + 1]; have_box = true; }
 #pragma unroll
-        for (int u = 0; u < 5; ++u) if (cb[u] >= 0) { blo[u] = d.cbox_lo[so_ + cb[u]]; bhi[u] = d.cbox_hi[so_ + cb[u]]; }
+        for (int u = 0; u < 5; ++u) if (cb[u] >= 0) { blo[u] = d.cmeta[2 * (so_ + cb[u])]; bhi[u] = d.cmeta[2 * (so_ + cb[u]) + 1]; }
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
           const int b = cb[u];
@@ -652,7 +652,7 @@ template <bool LDS> __device__ __forceinline__ void cg_hook_pass(const MorDev &d
     const int a = l_list[2 * h], b = l_list[2 * h + 1];
     if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;
     const size_t so = (size_t)s * d.Nmax;
-    const float4 alo = d.cbox_lo[so + a], ahi = d.cbox_hi[so + a], blo = d.cbox_lo[so + b], bhi = d.cbox_hi[so + b];
+    const float4 alo = d.cmeta[2 * (so + a)], ahi = d.cmeta[2 * (so + a) + 1], blo = d.cmeta[2 * (so + b)], bhi = d.cmeta[2 * (so + b) + 1];
     float gx = fmaxf(fmaxf(blo.x - ahi.x, alo.x - bhi.x), 0.f), gy = fmaxf(fmaxf(blo.y - ahi.y, alo.y - bhi.y), 0.f), gz = fmaxf(fmaxf(blo.z - ahi.z, alo.z - bhi.z), 0.f);
     if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) continue;
     if (pair_hit_wave(sp, start[a], start[a + 1] - start[a], start[b], start[b + 1] - start[b], r2, lane) && lane == 0) cg_unite<LDS>(par, a, b);
@@ -683,13 +683,13 @@ template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int
       lx = fminf(fminf(lx, p0.x), fminf(p1.x, fminf(p2.x, p3.x))); ly = fminf(fminf(ly, p0.y), fminf(p1.y, fminf(p2.y, p3.y))); lz = fminf(fminf(lz, p0.z), fminf(p1.z, fminf(p2.z, p3.z)));
       hx = fmaxf(fmaxf(hx, p0.x), fmaxf(p1.x, fmaxf(p2.x, p3.x))); hy = fmaxf(fmaxf(hy, p0.y), fmaxf(p1.y, fmaxf(p2.y, p3.y))); hz = fmaxf(fmaxf(hz, p0.z), fmaxf(p1.z, fmaxf(p2.z, p3.z)));
     }
-    d.cbox_lo[so + c] = make_float4(lx, ly, lz, 0.f); d.cbox_hi[so + c] = make_float4(hx, hy, hz, 0.f);
+    d.cmeta[2 * (so + c)] = make_float4(lx, ly, lz, 0.f); d.cmeta[2 * (so + c) + 1] = make_float4(hx, hy, hz, 0.f);
   }
   for (int c = wave_id(); c < nocc; c += CG_T / 64) {
     const int b = start[c], e = start[c + 1];
     if (e - b <= 16) continue;
     float4 lo, hi; wave_box(sp, b, e, lane, lo, hi);
-    if (lane == 0) { d.cbox_lo[so + c] = lo; d.cbox_hi[so + c] = hi; }
+    if (lane == 0) { d.cmeta[2 * (so + c)] = lo; d.cmeta[2 * (so + c) + 1] = hi; }
   }
   __threadfence_block();
   __syncthreads();
@@ -745,7 +745,7 @@ template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int
   __threadfence_block();
   __syncthreads();
   // ---- per-cell cluster id (a cell is a clique ⇒ one cluster) and root
-  for (int c = threadIdx.x; c < nocc; c += CG_T) { int r = cg_find<LDS>(par, c); d.croot[so + c] = r; d.ccid[so + c] = cidr[r]; }
+  for (int c = threadIdx.x; c < nocc; c += CG_T) { int r = cg_find<LDS>(par, c); d.croot[so + c] = r; d.ccid[so + c] = cidr[r]; reinterpret_cast<int *>(&d.cmeta[2 * (so + c)])[3] = cidr[r]; }
   // ---- cluster offsets (exclusive scan of sizes in cluster order), C, clear detection_results (:250-254)
   int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1);
   int carry = 0;
@@ -1154,19 +1154,21 @@ __device__ __forceinline__ void scan4(const float4 *sp, int b, int e, const floa
     if (best <= lbv) return;
   }
 }
-// the matched cells among compact ids [lo,hi): nearest box first, then the rest that can still improve `best`
+// the matched cells among compact ids [lo,hi): nearest box first, then the rest that can still improve `best`.
+// A cell's record (point box + cluster id in .w of the low corner) is one 32-byte line.
 __device__ __forceinline__ void scan_cells(const MorDev &d, size_t so, const int *st, const float4 *sp, int lo, int hi, int target, const float4 &q, float &best, int &budget) {
   int cfirst = -1; float bfirst = INFINITY;
-  for (int c = lo; c < hi; ++c) {
-    if (d.ccid[so + c] != target) continue;
-    float bd = box_dist2(q, d.cbox_lo[so + c], d.cbox_hi[so + c]);
-    if (bd < bfirst) { bfirst = bd; cfirst = c; }
+  for (int c = lo; c < hi; ++c) {   // no early exit: the record loads of a row are independent
+    const float4 blo = d.cmeta[2 * (so + c)], bhi = d.cmeta[2 * (so + c) + 1];
+    float bd = box_dist2(q, blo, bhi);
+    if (__float_as_int(blo.w) == target && bd < bfirst) { bfirst = bd; cfirst = c; }
   }
   if (cfirst < 0 || bfirst >= fminf(best, d.pde_ub)) return;
   scan4(sp, st[cfirst], st[cfirst + 1], q, d.pde_lb, best, budget);
   for (int c = lo; c < hi && best > d.pde_lb && budget > 0; ++c) {
-    if (c == cfirst || d.ccid[so + c] != target) continue;
-    if (box_dist2(q, d.cbox_lo[so + c], d.cbox_hi[so + c]) >= fminf(best, d.pde_ub)) continue;
+    if (c == cfirst) continue;
+    const float4 blo = d.cmeta[2 * (so + c)], bhi = d.cmeta[2 * (so + c) + 1];
+    if (__float_as_int(blo.w) != target || box_dist2(q, blo, bhi) >= fminf(best, d.pde_ub)) continue;
     scan4(sp, st[c], st[c + 1], q, d.pde_lb, best, budget);
   }
 }
@@ -1192,20 +1194,25 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   for (int base = t0 * MOR_BT; base < Cp; base += d.tiles_m * 8 * MOR_BT) {
     const int j = base + threadIdx.x;
-    bool more = false; float best = INFINITY;
+    bool more = false, big = false; float best = INFINITY;
     if (j < Cp) {
       int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
       if (pr >= 0) {
         const int target = d.pair_m[ko + pr];
         const float4 q = d.cl_pts[pv][so + j];
         const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
-        int budget = 64;
+        int budget = 64;   // a big own cell that shows no close point within its first 64 goes to the wave tier
         int c = cell_lookup(d.g, ckey, rs, cx, cy, cz);
-        if (c >= 0 && d.ccid[so + c] == target) scan4(sp, st[c], st[c + 1], q, d.pde_lb, best, budget);
-        more = best > d.pde_lb;
+        if (c >= 0 && d.ccid[so + c] == target) {
+          const int b0 = st[c], e0 = st[c + 1];
+          scan4(sp, b0, e0, q, d.pde_lb, best, budget);
+          big = best > d.pde_lb && e0 - b0 > 64;
+        }
+        more = best > d.pde_lb && !big;
       }
     }
     wl_push(more, &d.wl_n[s], d.wl + so, d.wl_best + so, j, best);
+    wl_push(big, &d.wl2_n[s], d.wl2 + so, nullptr, j, best);
   }
 }
 // Tier 1b — one THREAD per remaining query: the 9 rows of cells around it (row_order[0..8], lower bound 0).  Ends
@@ -1228,15 +1235,38 @@ __global__ __launch_bounds__(MOR_BT) void k_score_rows(MorDev d) {
       const float4 q = d.cl_pts[pv][so + j];
       const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
       int budget = d.t1_budget;   // points this thread may scan before handing the query to a wave
-      for (int ro = 0; ro < 9 && best > d.pde_lb && budget > 0; ++ro) {
+      // the 9 row lookups do not depend on each other (x half-width from the incoming best): all their loads overlap
+      int lo9[9], hi9[9];
+      const int rx = min(R, (int)(sqrtf(fminf(best, d.pde_ub)) * d.g.inv_cs * 1.001f) + 1);
+      const int x0 = max(cx - rx, 0), x1 = min(cx + rx, d.g.nx - 1);
+#pragma unroll
+      for (int ro = 0; ro < 9; ++ro) {
         int y = cy + d.row_order[2 * ro], z = cz + d.row_order[2 * ro + 1];
-        if ((unsigned)y >= (unsigned)d.g.ny || (unsigned)z >= (unsigned)d.g.nz) continue;
-        int rx = min(R, (int)(sqrtf(fminf(best, d.pde_ub)) * d.g.inv_cs * 1.001f) + 1);
-        int x0 = max(cx - rx, 0), x1 = min(cx + rx, d.g.nx - 1);
-        if (x0 > x1) continue;
-        int lo, hi; row_cells(d.g, ckey, rs, x0, x1, y, z, lo, hi);
-        if (lo < hi) scan_cells(d, so, st, sp, lo, hi, target, q, best, budget);
+        lo9[ro] = hi9[ro] = 0;
+        if (x0 <= x1 && (unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) row_cells(d.g, ckey, rs, x0, x1, y, z, lo9[ro], hi9[ro]);
       }
+      // all matched cells of the 9 rows, the 8 nearest by box distance kept sorted in registers; scanning them
+      // nearest-first tightens `best` at once, so usually one or two cells are read at all
+      float bd[8]; int cc[8]; int ncand = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { bd[i] = INFINITY; cc[i] = -1; }
+      const float lim0 = fminf(best, d.pde_ub);
+#pragma unroll
+      for (int ro = 0; ro < 9; ++ro)
+        for (int c = lo9[ro]; c < hi9[ro]; ++c) {
+          const float4 blo = d.cmeta[2 * (so + c)], bhi = d.cmeta[2 * (so + c) + 1];
+          float nb = box_dist2(q, blo, bhi); int nc = c;
+          if (__float_as_int(blo.w) != target || nb >= lim0) continue;
+          ++ncand;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) if (nb < bd[i]) { float tb = bd[i]; int tc = cc[i]; bd[i] = nb; cc[i] = nc; nb = tb; nc = tc; }
+        }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (cc[i] >= 0 && best > d.pde_lb && budget > 0 && bd[i] < fminf(best, d.pde_ub)) {
+          scan4(sp, st[cc[i]], st[cc[i] + 1], q, d.pde_lb, best, budget);
+        }
+      if (ncand > 8 && best > d.pde_lb && bd[7] < fminf(best, d.pde_ub)) budget = 0;   // more candidates than kept: let the wave tier finish it
       if (best > d.pde_lb) {
         if (budget <= 0) defer = true;
         else if (ring2 >= fminf(best, d.pde_ub) || d.n_rows <= 9) { if (best < d.pde_ub) atomicAdd(&d.pair_cnt[ko + pr], 1); }
@@ -1311,8 +1341,8 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
         if (lbrow < lim) {
           while (cur < hi) {
             int c = cur++;
-            if (d.ccid[so + c] != target) continue;
-            if (box_dist2(q, d.cbox_lo[so + c], d.cbox_hi[so + c]) < lim) { cand = c; break; }
+            const float4 blo = d.cmeta[2 * (so + c)], bhi = d.cmeta[2 * (so + c) + 1];
+            if (__float_as_int(blo.w) == target && box_dist2(q, blo, bhi) < lim) { cand = c; break; }
           }
         }
         if (!__ballot(cand >= 0)) break;
@@ -1326,7 +1356,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
         while (m && best > d.pde_lb) {
           int l = __ffsll((long long)m) - 1; m &= m - 1;
           int c = __shfl(cand, l, 64);
-          if (box_dist2(q, d.cbox_lo[so + c], d.cbox_hi[so + c]) >= fminf(best, d.pde_ub)) continue;   // best may have tightened since
+          if (box_dist2(q, d.cmeta[2 * (so + c)], d.cmeta[2 * (so + c) + 1]) >= fminf(best, d.pde_ub)) continue;   // best may have tightened since
           best = fminf(best, wave_scan_cell(sp, st[c], st[c + 1], q, d.pde_lb, lane));
         }
         if (best <= d.pde_lb) break;
