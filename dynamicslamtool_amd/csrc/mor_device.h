@@ -48,6 +48,18 @@ struct MorFrameInfo {        // per stream, produced on device
   uint32_t n_defer, pad0, pad1, pad2;     // n_defer: method-1 queries handed to the wave tier
 };
 
+// Temporal logic (T1 + the tracking loop of F1) as device state, one instance per stream.  O(clusters) sequential work
+// per frame: it runs in a one-workgroup-per-stream kernel right behind the geometry so that push + filter need no
+// host round trip in between.  Mirrors csrc/mor_tracker.cpp (the host version behind the mor_tracker_* C ABI).
+#define MOR_TR_MAXT 512   // tracked moving centroids per stream (mo_vec)
+#define MOR_TR_NB 8       // longest supported window (n_bad)
+struct MorTrackDev {
+  int n_mo, n_corr, n_res, has_cur, K_last, overflow, pad0, pad1;
+  int corr_n[MOR_TR_NB], res_n[MOR_TR_NB + 1];
+  float mo_c[MOR_TR_MAXT][3];
+  int mo_conf[MOR_TR_MAXT], mo_max[MOR_TR_MAXT];
+};
+
 struct MorDev {
   // ---- static configuration
   int B, s0, Btot;           // streams in this launch, first stream, streams in the batch
@@ -67,6 +79,7 @@ struct MorDev {
   int tiles_m;               // workgroups per stream for kernels over the non-ground cloud / clusters: an estimate from the
                              // previous frame; those kernels grid-stride over the tiles a stream really has, so any value ≥ 1 is correct
   int cur, has_prev;         // frame slot of cb (ca = cur^1); whether ca exists (:534)
+  int run_tracker;           // filter: advance the tracking loop (first filterCloud of this frame)
   // ---- device arrays (per-stream stride noted)
   const MorStreamArgs *args; // [B]
   MorFrameInfo *info;        // [B]
@@ -123,7 +136,12 @@ struct MorDev {
   unsigned long long *vox;   // [B][Hcap]
   unsigned char *det;        // [B][Kcap]  detection_results of cb
   // filter stage
-  const unsigned char *moving; // [B][Kcap] + [B] extract-error flags at the end
+  unsigned char *moving;     // [B][Kcap] + [B] extract-error flags at the end (written by k_track_filter)
+  MorTrackDev *tr;           // [B]
+  int2 *tr_corr;             // [B][MOR_TR_NB][Kcap]   corrs_vec (query, match), oldest first
+  unsigned char *tr_res;     // [B][MOR_TR_NB+1][Kcap] res_vec, oldest first
+  unsigned char *tr_lastdet; // [B][Kcap]  detection_results of the previous frame (ca)
+  int moving_confidence, static_confidence; float leave_off, catch_up;
   int *otile_cnt;            // [B][tiles_max]
   float4 *out;               // [B][Nmax] (or caller-provided per-stream pointers through out_ptrs)
   float4 *const *out_ptrs;   // [B] or null
@@ -144,7 +162,7 @@ enum MorKernelId {
   MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_ROWTABLE, MK_CELLGRAPH, MK_CELLBOX, MK_HOOK_NEAR, MK_HOOK_SHELL, MK_FLATTEN, MK_CELLCID,
   MK_SELECT_COUNT, MK_SELECT_SCAN, MK_SELECT_SCATTER, MK_RANK, MK_OFFSETS, MK_LABEL, MK_RHIST, MK_RSCAN, MK_RSCATTER,
   MK_STATS, MK_STATS_FIN, MK_XFORM_PREV, MK_XFORM_FIN, MK_NN, MK_PAIRS, MK_SCORE_FAST, MK_SCORE_ROWS, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
-  MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_G2_CENTROID, MK_G2_COV, MK_G2_MODE, MK_G2_MARK, MK_COUNT
+  MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_G2_CENTROID, MK_G2_COV, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_COUNT
 };
 extern const char *const mor_kernel_names[MK_COUNT];
 

@@ -16,6 +16,7 @@
 #include <vector>
 
 #define MOR_MAX_GROUPS 8
+#define MOR_ARGS_RING 8
 
 static thread_local std::string g_last_error;
 static int set_error(int code, const char *fmt, ...) {
@@ -64,11 +65,12 @@ struct mor_batch {
   std::map<GraphKey, hipGraphExec_t> graphs;
   MorDev d;                                  // template descriptor (static part + pointers)
   std::vector<void *> dev_allocs, host_allocs;
-  MorStreamArgs *h_args = nullptr, *d_args = nullptr;
-  unsigned char *h_moving = nullptr, *d_moving = nullptr;
+  MorStreamArgs *h_args_ring = nullptr, *h_args = nullptr, *d_args = nullptr;   // pinned ring of MOR_ARGS_RING slots (async pushes), current slot
+  hipEvent_t args_ev[MOR_ARGS_RING] = {};
+  bool async = false, pending = false;   // async: push/filter only enqueue; pending: work enqueued since the last wait
+  unsigned char *d_moving = nullptr;
   float4 **h_outptrs = nullptr, **d_outptrs = nullptr;
   unsigned char *d_stage = nullptr; size_t stage_stride = 0;   // staging for host-resident input blobs
-  std::vector<mor_tracker> trackers;
   std::vector<PoseTf> prev_pose;
   uint64_t frame = 0;
   bool filtered = false;
@@ -161,7 +163,7 @@ static int configure(mor_batch *b) {
 // Runs one launch sequence (kind 0 = push, 1 = filter) for every stream group on its own HIP stream and waits for
 // all of them.  The sequence of a group is captured once per (frame slot, tile count, …) into a hipGraph and
 // replayed: ≈45 launches collapse into one host call per group.  `pre(g, stream)` enqueues the per-call copies.
-template <class Pre> static int run_groups(mor_batch *b, const MorDev &d, int kind, Pre pre, float *ms_out) {
+template <class Pre> static int run_groups(mor_batch *b, const MorDev &d, int kind, Pre pre, float *ms_out, bool sync) {
   const int G = b->G, Bg = d.Btot / G;
   const bool graphs = b->use_graphs && !b->timer.enabled;
   for (int g = 0; g < G; ++g) {
@@ -188,11 +190,32 @@ template <class Pre> static int run_groups(mor_batch *b, const MorDev &d, int ki
     HIP_TRY(hipEventRecord(b->gev[g][1], st));
   }
   HIP_TRY(hipGetLastError());
+  b->pending = true;
+  if (!sync) return MOR_OK;
   float mx = 0;
   for (int g = 0; g < G; ++g) { HIP_TRY(hipStreamSynchronize(b->gst[g])); float t = 0; hipEventElapsedTime(&t, b->gev[g][0], b->gev[g][1]); mx = std::max(mx, t); }
   if (ms_out) *ms_out = mx;
   b->timer.collect();
   return MOR_OK;
+}
+
+// waits for everything enqueued on the batch and turns the device-side flags of the last push into an error code
+static int wait_all_checked(mor_batch *b) {
+  if (!b->pending) return MOR_OK;
+  for (int g = 0; g < b->G; ++g) HIP_TRY(hipStreamSynchronize(b->gst[g]));
+  b->pending = false;
+  b->timer.collect();
+  int rc = MOR_OK;
+  const MorDev &d = b->d;
+  for (int s = 0; s < d.B; ++s) {
+    const MorFrameInfo &f = d.h_info[s];
+    if (f.flags & 1u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than %d clusters", s, d.Kcap);
+    if (f.flags & 2u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: voxel key out of range in method 2", s);
+    if (f.flags & 8u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: z extent of the trimmed cloud exceeds the 64 m the voxel ground variant covers", s);
+    if (f.flags & 16u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than 16384 points within gp_leaf of a voxel centroid", s);
+    if (f.flags & 32u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than %d tracked moving centroids", s, MOR_TR_MAXT);
+  }
+  return rc;
 }
 
 extern "C" {
@@ -207,6 +230,7 @@ void mor_batch_destroy(mor_batch *b) {
   if (b->st) hipStreamSynchronize(b->st);
   for (int g = 0; g < b->G; ++g) if (b->gst[g]) hipStreamSynchronize(b->gst[g]);
   for (auto &kv : b->graphs) hipGraphExecDestroy(kv.second);
+  for (auto &ev : b->args_ev) if (ev) hipEventDestroy(ev);
   for (int g = 0; g < b->G; ++g) { if (b->gst[g]) hipStreamDestroy(b->gst[g]); for (auto &ev : b->gev[g]) if (ev) hipEventDestroy(ev); }
   for (void *p : b->dev_allocs) hipFree(p);
   for (void *p : b->host_allocs) hipHostFree(p);
@@ -227,6 +251,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   b = new mor_batch(); memset(&b->d, 0, sizeof b->d);
   b->p = *p; b->n_bad = n_bad; b->n_good = n_good; b->B = n_streams; b->device = device; b->Nmax = max_points;
   if ((rc = configure(b)) != MOR_OK) return fail(rc);
+  if (n_bad > MOR_TR_NB) return fail(set_error(MOR_ERR_INVALID, "n_bad = %d: windows longer than %d frames are not supported", n_bad, MOR_TR_NB));
+  for (auto &ev : b->args_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   if (hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
   for (auto &e : b->ev) if (hipEventCreate(&e) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   {
@@ -282,14 +308,16 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   }
   ok = ok && dalloc(b, b->d_moving, B * K + B) && dalloc(b, d.otile_cnt, B * T) && dalloc(b, d.out, B * N) && dalloc(b, b->d_outptrs, B);
   d.moving = b->d_moving;
-  ok = ok && halloc(b, b->h_args, B) && halloc(b, b->h_moving, B * K + B) && halloc(b, b->h_outptrs, B);
+  ok = ok && dalloc(b, d.tr, B) && dalloc(b, d.tr_corr, B * MOR_TR_NB * K) && dalloc(b, d.tr_res, B * (MOR_TR_NB + 1) * K) && dalloc(b, d.tr_lastdet, B * K);
+  if (ok) ok = hipMemset(d.tr, 0, B * sizeof(MorTrackDev)) == hipSuccess && hipMemset(b->d_moving, 0, B * K + B) == hipSuccess;
+  d.moving_confidence = n_bad; d.static_confidence = n_good; d.leave_off = p->leave_off_distance; d.catch_up = p->catch_up_distance;
+  ok = ok && halloc(b, b->h_args_ring, B * MOR_ARGS_RING) && halloc(b, b->h_outptrs, B);
+  b->h_args = b->h_args_ring;
   ok = ok && halloc(b, d.h_info, B) && halloc(b, d.h_centroid, B * K) && halloc(b, d.h_cl_off, B * (K + 1)) && halloc(b, d.h_det, B * K);
   ok = ok && halloc(b, d.h_pair_q, B * K) && halloc(b, d.h_pair_m, B * K) && halloc(b, d.h_pair_d, B * K) && halloc(b, d.h_score, B * K) && halloc(b, d.h_nout, B);
   if (!ok) return fail(set_error(MOR_ERR_HIP, "device/host allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
   if (hipMemsetAsync(d.info, 0, B * sizeof(MorFrameInfo), b->st) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "memset failed"));
   hipStreamSynchronize(b->st);
-  b->trackers.reserve(B);
-  for (size_t s = 0; s < B; ++s) b->trackers.emplace_back(*p, n_bad, n_good);
   b->prev_pose.resize(B);
   if (err) *err = MOR_OK;
   return b;
@@ -317,6 +345,10 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     b->stage_stride = (max_host_bytes + 255) & ~(size_t)255;
     HIP_TRY(hipMalloc((void **)&b->d_stage, b->stage_stride * B));
   }
+  // pinned argument slot of this push (a ring, so asynchronous pushes never overwrite a slot the GPU still has to copy)
+  const int slot = (int)(b->frame % MOR_ARGS_RING);
+  HIP_TRY(hipEventSynchronize(b->args_ev[slot]));
+  b->h_args = b->h_args_ring + (size_t)slot * B;
   std::vector<PoseTf> cur(B);
   for (int s = 0; s < B; ++s) {
     const mor_cloud_view &c = clouds[s]; MorStreamArgs &a = b->h_args[s];
@@ -324,13 +356,14 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     a.data = (c.on_device || c.n_points == 0) ? c.data : (const void *)(b->d_stage + b->stage_stride * s);
     pose_to_tf(poses + 7 * s, cur[s]);
     if (b->frame > 0) relative_transform(cur[s], b->prev_pose[s], a.xf); else memset(a.xf, 0, sizeof a.xf);
+    b->prev_pose[s] = cur[s];
   }
   d.tiles = std::max<int>(1, (int)((maxn + MOR_TILE - 1) / MOR_TILE));
-  d.cur = (int)(b->frame & 1); d.has_prev = b->frame > 0; d.out_ptrs = nullptr;
-  {  // workgroups for the cloud-sized kernels: 1.25 × the largest cloud / cluster set of the previous frame
+  d.cur = (int)(b->frame & 1); d.has_prev = b->frame > 0; d.out_ptrs = nullptr; d.run_tracker = 0;
+  {  // workgroups for the cloud-sized kernels: 1.25 × the largest cloud / cluster set the device last reported
     uint32_t mx = 0;
-    if (b->frame > 0) for (int s = 0; s < B; ++s) mx = std::max(mx, std::max(d.h_info[s].M, d.h_info[s].C));
-    d.tiles_m = b->frame > 0 ? std::min<int>(d.tiles, (int)(((uint64_t)mx * 5 / 4 + MOR_TILE - 1) / MOR_TILE) + 1) : d.tiles;
+    for (int s = 0; s < B; ++s) mx = std::max(mx, std::max(d.h_info[s].M, d.h_info[s].C));
+    d.tiles_m = (b->frame > 0 && mx > 0) ? std::min<int>(d.tiles, (int)(((uint64_t)mx * 5 / 4 + MOR_TILE - 1) / MOR_TILE) + 1) : d.tiles;
   }
   const int Bg = B / b->G;
   auto pre = [&](int g, hipStream_t st, const MorDev &) -> int {
@@ -339,26 +372,13 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
       if (!c.on_device && c.n_points) HIP_TRY(hipMemcpyAsync((void *)b->h_args[s].data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, st));
     }
     HIP_TRY(hipMemcpyAsync(b->d_args + g * Bg, b->h_args + g * Bg, sizeof(MorStreamArgs) * Bg, hipMemcpyHostToDevice, st));
+    if (g == b->G - 1) HIP_TRY(hipEventRecord(b->args_ev[slot], st));
     return MOR_OK;
   };
-  { int rc0 = run_groups(b, d, 0, pre, &b->push_ms); if (rc0 != MOR_OK) return rc0; }
   b->d.tiles = d.tiles; b->d.tiles_m = d.tiles_m; b->d.cur = d.cur; b->d.has_prev = d.has_prev;
-  int rc = MOR_OK;
-  std::vector<float> cent;
-  for (int s = 0; s < B; ++s) {
-    const MorFrameInfo &f = d.h_info[s];
-    if (f.flags & 1u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than %d clusters", s, d.Kcap);
-    if (f.flags & 2u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: voxel key out of range in method 2", s);
-    if (f.flags & 8u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: z extent of the trimmed cloud exceeds the 64 m the voxel ground variant covers", s);
-    if (f.flags & 16u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than 16384 points within gp_leaf of a voxel centroid", s);
-    const size_t ko = (size_t)s * d.Kcap;
-    cent.resize(3 * (size_t)f.K);
-    for (uint32_t k = 0; k < f.K; ++k) { cent[3 * k] = d.h_centroid[ko + k].x; cent[3 * k + 1] = d.h_centroid[ko + k].y; cent[3 * k + 2] = d.h_centroid[ko + k].z; }
-    b->trackers[s].push((int)f.K, cent.data(), d.h_det + ko, d.has_prev ? (int)f.n_pairs : -1, d.h_pair_q + ko, d.h_pair_m + ko);   // :608
-    b->prev_pose[s] = cur[s];
-  }
   b->frame++; b->filtered = false;
-  return rc;
+  { int rc0 = run_groups(b, d, 0, pre, &b->push_ms, !b->async); if (rc0 != MOR_OK) return rc0; }
+  return b->async ? MOR_OK : wait_all_checked(b);
 }
 
 int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t *n_out) {
@@ -366,35 +386,29 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
   if (b->frame == 0) return set_error(MOR_ERR_NOT_READY, "filterCloud before the first pushRawCloudAndPose");
   HIP_TRY(hipSetDevice(b->device));
   MorDev d = b->d; const int B = d.B;
-  // host: filterCloud's loop over mo_vec (:630-671) → clusters to remove
-  std::vector<int32_t> sizes;
-  for (int s = 0; s < B; ++s) {
-    const MorFrameInfo &f = d.h_info[s]; const int *off = d.h_cl_off + (size_t)s * (d.Kcap + 1);
-    sizes.resize(f.K);
-    for (uint32_t k = 0; k < f.K; ++k) sizes[k] = off[k + 1] - off[k];
-    if (b->filtered) continue;   // a repeated filter on the same frame re-emits the same cloud; the tracker advances once per frame
-    uint64_t n_idx = 0;
-    b->trackers[s].filter(sizes.data(), b->h_moving + (size_t)s * d.Kcap, &n_idx);
-    b->h_moving[(size_t)B * d.Kcap + s] = n_idx > f.M;   // ExtractIndices: more indices than points ⇒ error, empty output
-  }
+  d.run_tracker = b->filtered ? 0 : 1;   // the tracking loop of filterCloud (:630-671) runs on the device, once per frame
   b->filtered = true;
   d.out_ptrs = nullptr;
   if (out && out_on_device) { for (int s = 0; s < B; ++s) b->h_outptrs[s] = (float4 *)out[s]; d.out_ptrs = b->d_outptrs; }
   const int Bg = B / b->G;
   auto pre = [&](int g, hipStream_t st, const MorDev &) -> int {
-    HIP_TRY(hipMemcpyAsync(b->d_moving + (size_t)g * Bg * d.Kcap, b->h_moving + (size_t)g * Bg * d.Kcap, (size_t)Bg * d.Kcap, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b->d_moving + (size_t)B * d.Kcap + g * Bg, b->h_moving + (size_t)B * d.Kcap + g * Bg, Bg, hipMemcpyHostToDevice, st));
     if (d.out_ptrs) HIP_TRY(hipMemcpyAsync(b->d_outptrs + g * Bg, b->h_outptrs + g * Bg, sizeof(float4 *) * Bg, hipMemcpyHostToDevice, st));
     return MOR_OK;
   };
-  { int rc0 = run_groups(b, d, 1, pre, &b->filter_ms); if (rc0 != MOR_OK) return rc0; }
+  const bool need_host = n_out != nullptr || (out && !out_on_device);
+  { int rc0 = run_groups(b, d, 1, pre, &b->filter_ms, !b->async || need_host); if (rc0 != MOR_OK) return rc0; }
+  if (b->async && !need_host) return MOR_OK;
+  int rc = wait_all_checked(b);
   for (int s = 0; s < B; ++s) if (n_out) n_out[s] = d.h_nout[s];
   if (out && !out_on_device) {
     for (int s = 0; s < B; ++s) if (out[s] && d.h_nout[s]) HIP_TRY(hipMemcpyAsync(out[s], d.out + (size_t)s * d.Nmax, d.h_nout[s] * sizeof(float4), hipMemcpyDeviceToHost, b->st));
     HIP_TRY(hipStreamSynchronize(b->st));
   }
-  return MOR_OK;
+  return rc;
 }
+
+int mor_batch_set_async(mor_batch *b, int on) { if (!b) return MOR_ERR_INVALID; int rc = wait_all_checked(b); b->async = on != 0; return rc; }
+int mor_batch_wait(mor_batch *b) { if (!b) return MOR_ERR_INVALID; HIP_TRY(hipSetDevice(b->device)); return wait_all_checked(b); }
 
 const void *mor_get_output_device(const mor_batch *b, int s, uint64_t *n_out) {
   if (!b || s < 0 || s >= b->B) return nullptr;
@@ -416,12 +430,14 @@ void mor_destroy(mor_ctx *c) { mor_batch_destroy(c); }
   if (!b || s < 0 || s >= b->B) return set_error(MOR_ERR_INVALID, "bad batch/stream");      \
   if (b->frame == 0) return set_error(MOR_ERR_NOT_READY, "no frame pushed yet");            \
   HIP_TRY(hipSetDevice(b->device));                                                         \
+  if (b->pending) wait_all_checked(const_cast<mor_batch *>(b));                                                         \
   const MorDev &d = b->d; const MorFrameInfo &f = d.h_info[s]; const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap; (void)so; (void)ko; (void)f
 
 int mor_get_counts(const mor_batch *b, int s, mor_counts *o) {
   CHECK_STREAM();
   o->n_in = f.N; o->n_trim = f.T; o->n_cloud = f.M; o->n_ground = f.G; o->n_clusters = f.K; o->n_clustered = f.C;
-  o->n_corr = f.n_pairs; o->n_tracks = (uint32_t)b->trackers[s].mo_vec.size();
+  o->n_corr = f.n_pairs;
+  { int n_mo = 0; HIP_TRY(hipMemcpy(&n_mo, &d.tr[s].n_mo, sizeof(int), hipMemcpyDeviceToHost)); o->n_tracks = (uint32_t)n_mo; }
   return MOR_OK;
 }
 int mor_get_labels(const mor_batch *b, int s, int32_t *lab) {
@@ -457,7 +473,9 @@ int mor_get_correspondences(const mor_batch *b, int s, int32_t *q, int32_t *m, f
 }
 int mor_get_tracks(const mor_batch *b, int s, float *xyz, int32_t *conf, int32_t *maxc) {
   CHECK_STREAM();
-  mor_tracker_get(&b->trackers[s], xyz, conf, maxc, 1 << 30);
+  std::vector<MorTrackDev> t(1);
+  HIP_TRY(hipMemcpy(t.data(), &d.tr[s], sizeof(MorTrackDev), hipMemcpyDeviceToHost));
+  for (int i = 0; i < t[0].n_mo; ++i) { if (xyz) memcpy(xyz + 3 * i, t[0].mo_c[i], 3 * sizeof(float)); if (conf) conf[i] = t[0].mo_conf[i]; if (maxc) maxc[i] = t[0].mo_max[i]; }
   return MOR_OK;
 }
 int mor_get_cluster_collection(const mor_batch *b, int s, float *out) {
@@ -488,7 +506,9 @@ int mor_device_synchronize(int device) { HIP_TRY(hipSetDevice(device)); HIP_TRY(
 // ---- timing
 int mor_get_last_timing(const mor_batch *b, float *push_ms, float *filter_ms) {
   if (!b) return MOR_ERR_INVALID;
-  if (push_ms) *push_ms = b->push_ms; if (filter_ms) *filter_ms = b->filter_ms; return MOR_OK;
+  if (push_ms) *push_ms = b->push_ms;
+  if (filter_ms) *filter_ms = b->filter_ms;
+  return MOR_OK;
 }
 int mor_kernel_timing_enable(mor_batch *b, int enable) { if (!b) return MOR_ERR_INVALID; b->timer.enabled = enable != 0; return MOR_OK; }
 int mor_kernel_timing_read(mor_batch *b, int reset, char *names, size_t names_cap, float *ms_total, uint32_t *launches, int max_kernels) {

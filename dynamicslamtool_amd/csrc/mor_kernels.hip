@@ -23,13 +23,14 @@
 //     mul/add, no FMA contraction): the file is compiled with -ffp-contract=off.
 #include "mor_device.h"
 #include <cfloat>
+#include <cstddef>
 #include <cstdlib>
 
 const char *const mor_kernel_names[MK_COUNT] = {
     "classify", "scan_tiles", "scatter", "heads_count", "heads_scan", "heads_scatter", "rowtable", "cellgraph", "cellbox", "hook_cells", "hook_cells_shell", "flatten", "cellcid",
     "select_count", "select_scan", "select_scatter", "rank", "offsets", "label", "rhist", "rscan", "rscatter",
     "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "pairs", "score_fast", "score_rows", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
-    "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_mode", "g2_mark"};
+    "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_mode", "g2_mark", "track_push", "track_filter"};
 
 // ------------------------------------------------------------------------------------ helpers
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -1659,6 +1660,178 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mark(MorDev d) {
   }
 }
 
+// ------------------------------------------------------------------------------------ T1 + F1 tracking, on the device
+// One workgroup (one wave) per stream.  The state is tiny (a few dozen clusters, pairs and tracked centroids) but the
+// logic is sequential, so it is staged into LDS, run there (no chain of global-memory round trips) and written back.
+// Streams whose vectors exceed the LDS slots run the same code on the global arrays.
+#define TRK 512   // clusters / pairs per window slot held in LDS
+__device__ __forceinline__ void tr_load_state(const MorTrackDev &g, MorTrackDev &l, int lane) {
+  const int *gs = reinterpret_cast<const int *>(&g); int *ls = reinterpret_cast<int *>(&l);
+  const int head = (int)(offsetof(MorTrackDev, mo_c) / sizeof(int));
+  for (int i = lane; i < head; i += 64) ls[i] = gs[i];
+  __syncthreads();
+  const int n = l.n_mo;
+  for (int i = lane; i < n * 3; i += 64) (&l.mo_c[0][0])[i] = (&g.mo_c[0][0])[i];
+  for (int i = lane; i < n; i += 64) { l.mo_conf[i] = g.mo_conf[i]; l.mo_max[i] = g.mo_max[i]; }
+  __syncthreads();
+}
+__device__ __forceinline__ void tr_store_state(MorTrackDev &g, const MorTrackDev &l, int lane) {
+  __syncthreads();
+  int *gs = reinterpret_cast<int *>(&g); const int *ls = reinterpret_cast<const int *>(&l);
+  const int head = (int)(offsetof(MorTrackDev, mo_c) / sizeof(int));
+  for (int i = lane; i < head; i += 64) gs[i] = ls[i];
+  const int n = l.n_mo;
+  for (int i = lane; i < n * 3; i += 64) (&g.mo_c[0][0])[i] = (&l.mo_c[0][0])[i];
+  for (int i = lane; i < n; i += 64) { g.mo_conf[i] = l.mo_conf[i]; g.mo_max[i] = l.mo_max[i]; }
+}
+// checkMovingClusterChain (:478-514) with recurseFindClusterChain (:415-453) and pushCentroid (:455-476)
+__global__ __launch_bounds__(64) void k_track_push(MorDev d) {
+  const int s = blockIdx.x + d.s0, K = d.info[s].K, np = d.has_prev ? (int)d.info[s].n_pairs : -1, lane = threadIdx.x;
+  const size_t ko = (size_t)s * d.Kcap;
+  __shared__ MorTrackDev t;
+  __shared__ int2 l_corr[MOR_TR_NB][TRK];
+  __shared__ unsigned char l_res[MOR_TR_NB + 1][TRK];
+  tr_load_state(d.tr[s], t, lane);
+  int2 *g_corr = d.tr_corr + (size_t)s * MOR_TR_NB * d.Kcap;
+  unsigned char *g_res = d.tr_res + (size_t)s * (MOR_TR_NB + 1) * d.Kcap, *last = d.tr_lastdet + ko;
+  bool fits = K <= TRK && t.K_last <= TRK && np <= TRK;
+  for (int c = 0; c < t.n_corr; ++c) fits = fits && t.corr_n[c] <= TRK;
+  for (int r = 0; r < t.n_res; ++r) fits = fits && t.res_n[r] <= TRK;
+  int2 *corr = g_corr; unsigned char *res = g_res; int stride = d.Kcap;
+  if (fits) {   // stage the window
+    for (int c = 0; c < t.n_corr; ++c) for (int j = lane; j < t.corr_n[c]; j += 64) l_corr[c][j] = g_corr[(size_t)c * d.Kcap + j];
+    for (int r = 0; r < t.n_res; ++r) for (int k = lane; k < t.res_n[r]; k += 64) l_res[r][k] = g_res[(size_t)r * d.Kcap + k];
+    corr = &l_corr[0][0]; res = &l_res[0][0]; stride = TRK;
+    __syncthreads();
+  }
+  const bool chain = np >= 0 && t.has_cur;
+  if (chain) {
+    const int cs_ = t.n_corr, rs0 = t.n_res;
+    for (int j = lane; j < np; j += 64) corr[(size_t)cs_ * stride + j] = make_int2(d.pair_q[ko + j], d.pair_m[ko + j]);   // corrs_vec.push_back(mp) :483
+    if (rs0 == 0) for (int k = lane; k < t.K_last; k += 64) res[k] = last[k];                                              // res_vec.push_back(res_ca) :484-488
+    const int rs1 = rs0 == 0 ? 1 : rs0;
+    for (int k = lane; k < K; k += 64) res[(size_t)rs1 * stride + k] = d.det[ko + k];                                     // res_vec.push_back(res_cb) :490
+    __syncthreads();
+    if (lane == 0) {
+      t.corr_n[cs_] = np; t.n_corr = cs_ + 1;
+      if (rs0 == 0) t.res_n[0] = t.K_last;
+      t.res_n[rs1] = K; t.n_res = rs1 + 1;
+    }
+    __syncthreads();
+    if (t.n_res >= d.moving_confidence) {                                                                                  // :492
+      // the outer loop (clusters flagged in the oldest frame, in index order) is sequential — the order decides which
+      // centroid wins inside catch_up_distance — but every inner search runs across the 64 lanes
+      const int n0 = t.res_n[0], ncol = t.n_corr;
+      for (int i = 0; i < n0; ++i) {
+        if (!res[i]) continue;
+        int track = i; bool ok = true;
+        for (int col = 0; col < ncol && ok; ++col) {                                                                       // recurseFindClusterChain
+          const int2 *c = corr + (size_t)col * stride; const int n = t.corr_n[col]; int match = -1;
+          for (int j0 = 0; j0 < n && match < 0; j0 += 64) {
+            const int j = j0 + lane; const int2 pr = j < n ? c[j] : make_int2(-1, -1);
+            unsigned long long m = __ballot(pr.x == track);
+            if (m) match = __shfl(pr.y, __ffsll((long long)m) - 1, 64);   // first pair whose query is `track`
+          }
+          if (match < 0 || !res[(size_t)(col + 1) * stride + match]) ok = false; else track = match;
+        }
+        if (!ok) continue;
+        const float4 pt = d.centroid[d.cur][ko + track];                                                                   // pushCentroid(cb->centroid_collection[found])
+        bool near = false; const int nm = t.n_mo;
+        for (int m0 = 0; m0 < nm && !near; m0 += 64) {
+          const int m = m0 + lane; bool hit = false;
+          if (m < nm) { double dx = (double)(pt.x - t.mo_c[m][0]), dy = (double)(pt.y - t.mo_c[m][1]), dz = (double)(pt.z - t.mo_c[m][2]); hit = sqrt(dx * dx + dy * dy + dz * dz) < (double)d.catch_up; }
+          near = __ballot(hit) != 0ull;
+        }
+        if (near) continue;
+        if (lane == 0) {
+          if (nm >= MOR_TR_MAXT) { t.overflow = 1; atomicOr(&d.info[s].flags, 32u); }
+          else { t.mo_c[nm][0] = pt.x; t.mo_c[nm][1] = pt.y; t.mo_c[nm][2] = pt.z; t.mo_conf[nm] = t.mo_max[nm] = d.static_confidence + 1; t.n_mo = nm + 1; }   // header :91
+        }
+        __syncthreads();
+      }
+    }
+    __syncthreads();
+    if (t.n_res >= d.moving_confidence) {   // pop_front of both deques (:511-512): shift the slots down
+      const int nc = t.n_corr, nr = t.n_res;
+      for (int col = 1; col < nc; ++col) { for (int j = lane; j < t.corr_n[col]; j += 64) corr[(size_t)(col - 1) * stride + j] = corr[(size_t)col * stride + j]; __syncthreads(); }
+      for (int r = 1; r < nr; ++r) { for (int k = lane; k < t.res_n[r]; k += 64) res[(size_t)(r - 1) * stride + k] = res[(size_t)r * stride + k]; __syncthreads(); }
+      if (lane == 0) {
+        for (int col = 1; col < nc; ++col) t.corr_n[col - 1] = t.corr_n[col];
+        for (int r = 1; r < nr; ++r) t.res_n[r - 1] = t.res_n[r];
+        t.n_corr = nc - 1; t.n_res = nr - 1;
+      }
+    }
+    __syncthreads();
+    if (fits) {   // write the window back
+      for (int c = 0; c < t.n_corr; ++c) for (int j = lane; j < t.corr_n[c]; j += 64) g_corr[(size_t)c * d.Kcap + j] = l_corr[c][j];
+      for (int r = 0; r < t.n_res; ++r) for (int k = lane; k < t.res_n[r]; k += 64) g_res[(size_t)r * d.Kcap + k] = l_res[r][k];
+    }
+  }
+  __syncthreads();
+  for (int k = lane; k < K; k += 64) last[k] = d.det[ko + k];
+  if (lane == 0) { t.K_last = K; t.has_cur = 1; }
+  tr_store_state(d.tr[s], t, lane);
+}
+// filterCloud's loop over mo_vec (:630-671): nearest current centroid of every tracked one (squared fp32 distance, ties →
+// lowest index), its whole cluster queued for removal before any test, confidence bookkeeping.  Writes the per-cluster
+// removal flags and the ExtractIndices size-check flag the output kernels read.
+__global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
+  const int s = blockIdx.x + d.s0, K = d.info[s].K, lane = threadIdx.x;
+  const size_t ko = (size_t)s * d.Kcap;
+  const int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1);
+  __shared__ MorTrackDev t;
+  __shared__ float4 l_cen[TRK];
+  __shared__ int l_size[TRK];
+  __shared__ unsigned char l_det[TRK], l_mov[TRK];
+  tr_load_state(d.tr[s], t, lane);
+  const bool fits = K <= TRK;
+  unsigned char *moving = d.moving + ko;
+  for (int k = lane; k < K; k += 64) {
+    if (fits) { l_cen[k] = d.centroid[d.cur][ko + k]; l_size[k] = off[k + 1] - off[k]; l_det[k] = d.det[ko + k]; l_mov[k] = 0; }
+    else moving[k] = 0;
+  }
+  __syncthreads();
+  // Every tracked centroid is handled independently of the others (its nearest cluster, its confidence, its own new
+  // position); erasing only compacts the vector, order kept.  So: one lane per track, 64 tracks per round, survivors
+  // compacted in place with a ballot prefix (reads of a round happen before its writes, and writes never pass reads).
+  unsigned long long total = 0;
+  const int n_mo = t.n_mo; int n_keep = 0;
+  if (K > 0) {
+    for (int i0 = 0; i0 < n_mo; i0 += 64) {
+      const int i = i0 + lane; const bool v = i < n_mo;
+      float c0 = 0, c1 = 0, c2 = 0; int conf = 0, mx = 0; bool keep = false; unsigned long long mine = 0;
+      if (v) {
+        c0 = t.mo_c[i][0]; c1 = t.mo_c[i][1]; c2 = t.mo_c[i][2]; conf = t.mo_conf[i]; mx = t.mo_max[i];
+        float bd = INFINITY; int bi = 0;
+        for (int k = 0; k < K; ++k) { const float4 c = fits ? l_cen[k] : d.centroid[d.cur][ko + k]; float dd = sqdist(c0, c1, c2, c.x, c.y, c.z); if (dd < bd) { bd = dd; bi = k; } }   // ties → lowest index
+        if (fits) l_mov[bi] = 1; else moving[bi] = 1;                      // whole cluster queued for removal before any test (:644-648)
+        mine = (unsigned long long)(fits ? l_size[bi] : off[bi + 1] - off[bi]);
+        if (!(fits ? l_det[bi] : d.det[ko + bi]) || bd > d.leave_off) {    // squared vs un-squared: reference quirk kept (:650)
+          keep = --conf != 0;                                              // erased at confidence 0 (:655-660)
+        } else {
+          const float4 c = fits ? l_cen[bi] : d.centroid[d.cur][ko + bi];
+          c0 = c.x; c1 = c.y; c2 = c.z;                                    // :664
+          if (conf < mx) ++conf;                                           // :667
+          keep = true;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+      total += mine;
+      const unsigned long long km = __ballot(keep);
+      __syncthreads();
+      if (keep) { const int o = n_keep + __popcll(km & lanemask_lt()); t.mo_c[o][0] = c0; t.mo_c[o][1] = c1; t.mo_c[o][2] = c2; t.mo_conf[o] = conf; t.mo_max[o] = mx; }
+      n_keep += __popcll(km);
+      __syncthreads();
+    }
+    if (lane == 0) t.n_mo = n_keep;
+  }
+  __syncthreads();
+  if (fits) for (int k = lane; k < K; k += 64) moving[k] = l_mov[k];
+  if (lane == 0) d.moving[(size_t)d.Btot * d.Kcap + s] = total > (unsigned long long)d.info[s].M;   // ExtractIndices: more indices than points ⇒ error, empty output
+  tr_store_state(d.tr[s], t, lane);
+}
+
 // ------------------------------------------------------------------------------------ launch sequences
 #define MOR_LAUNCH(id, kern, grid, ...)                                   \
   do {                                                                    \
@@ -1747,10 +1920,18 @@ void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     }
   }
   MOR_LAUNCH(MK_DECIDE, k_decide, gB, d);
+  mor_timer_begin(tm, MK_TRACK_PUSH, st);
+  hipLaunchKernelGGL(k_track_push, gB, dim3(64), 0, st, d);
+  mor_timer_end(tm, MK_TRACK_PUSH, st);
 }
 
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gM(d.B * d.tiles_m), gB(d.B), gT2(d.B * (d.tiles_m + d.tiles));
+  if (d.run_tracker) {   // once per frame: a repeated filterCloud on the same frame re-emits the same cloud
+    mor_timer_begin(tm, MK_TRACK_FILTER, st);
+    hipLaunchKernelGGL(k_track_filter, gB, dim3(64), 0, st, d);
+    mor_timer_end(tm, MK_TRACK_FILTER, st);
+  }
   MOR_LAUNCH(MK_OUT_COUNT, k_out_count, gM, d);
   MOR_LAUNCH(MK_OUT_SCAN, k_out_scan, gB, d);
   MOR_LAUNCH(MK_OUT_SCATTER, k_out_scatter, gT2, d);

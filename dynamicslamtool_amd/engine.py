@@ -14,7 +14,7 @@ MOR_NO_FIELD = 0xFFFFFFFF
 # every symbol include/mor_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "mor_sizeof_params", "mor_last_error", "mor_batch_create", "mor_batch_destroy", "mor_batch_streams", "mor_push_batch",
-    "mor_filter_batch", "mor_get_output_device", "mor_create", "mor_push", "mor_filter", "mor_destroy", "mor_get_counts",
+    "mor_filter_batch", "mor_batch_set_async", "mor_batch_wait", "mor_get_output_device", "mor_create", "mor_push", "mor_filter", "mor_destroy", "mor_get_counts",
     "mor_get_labels", "mor_get_ground_indices", "mor_get_clusters", "mor_get_centroids", "mor_get_detection",
     "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_get_stage_counts", "mor_device_alloc", "mor_device_free",
     "mor_device_upload", "mor_device_download", "mor_device_synchronize", "mor_device_count", "mor_get_last_timing",
@@ -48,6 +48,8 @@ def lib():
         L.mor_batch_streams.argtypes = [vp]
         L.mor_push_batch.argtypes = [vp, vp, vp]
         L.mor_filter_batch.argtypes = [vp, vp, i32, vp]
+        L.mor_batch_set_async.argtypes = [vp, i32]
+        L.mor_batch_wait.argtypes = [vp]
         L.mor_get_output_device.restype = vp
         L.mor_get_output_device.argtypes = [vp, i32, vp]
         L.mor_create.restype = vp
@@ -182,6 +184,16 @@ class MorBatch:
     def push_views(self, views, poses):
         poses = np.ascontiguousarray(poses, np.float64)
         _check(lib().mor_push_batch(self._h, C.addressof(views), poses.ctypes.data))
+
+    def set_async(self, on=True):
+        _check(lib().mor_batch_set_async(self._h, 1 if on else 0))
+
+    def wait(self):
+        _check(lib().mor_batch_wait(self._h))
+
+    def filter_async(self):
+        """filterCloud for all streams, enqueue only (async mode): results stay in the batch's device buffers."""
+        _check(lib().mor_filter_batch(self._h, None, 0, None))
 
     def filter_device(self):
         """filterCloud for all streams, results left in the batch's device buffers; returns the n_out array."""

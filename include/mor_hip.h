@@ -90,6 +90,13 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
  * batch's own device buffers (mor_get_output_device). */
 int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t *n_out);
 
+/* Asynchronous mode (off by default).  With it on, mor_push_batch and mor_filter_batch (called with n_out == NULL
+ * and no host output) only enqueue their launches — the tracking state lives on the device, so a push + filter
+ * pair needs no host round trip — and return at once; mor_batch_wait blocks until everything enqueued has
+ * finished and reports the first error of the last push.  Every read-back waits by itself. */
+int mor_batch_set_async(mor_batch *b, int on);
+int mor_batch_wait(mor_batch *b);
+
 /* Device-resident result of the last filter for stream i (float4 records) */
 const void *mor_get_output_device(const mor_batch *b, int stream, uint64_t *n_out);
 
