@@ -78,11 +78,13 @@ struct MorDev {
   int tiles;                 // ceil(max n_points of this batch / MOR_TILE)
   int tiles_m;               // workgroups per stream for kernels over the non-ground cloud / clusters: an estimate from the
                              // previous frame; those kernels grid-stride over the tiles a stream really has, so any value ≥ 1 is correct
-  int cur, has_prev;         // frame slot of cb (ca = cur^1); whether ca exists (:534)
+  int cur, prev, has_prev;   // cluster-array slots of cb and ca (three slots rotate so frame k+1's front stage can run beside
+                             // frame k's pair stage); whether ca exists (:534)
   int run_tracker;           // filter: advance the tracking loop (first filterCloud of this frame)
   // ---- device arrays (per-stream stride noted)
   const MorStreamArgs *args; // [B]
-  MorFrameInfo *info;        // [B]
+  MorFrameInfo *info;        // [B]  this frame (the engine double-buffers it and every array the pair / filter stage reads)
+  const MorFrameInfo *info_prev; // [B]  previous frame (its K, C)
   int *tile_cnt, *tile_off;  // [B][tiles_max][2]   (non-ground, ground) counts / exclusive offsets
   float4 *cloud;             // [B][Nmax]  non-ground points, input order (`cloud`, :85)
   int *cloud_tidx;           // [B][Nmax]  index of each cloud point in the trimmed cloud
@@ -117,13 +119,13 @@ struct MorDev {
   int *rhist;                // [B][tiles_max][256]
   int *cl_idx;               // [B][Nmax]  cluster_indices flattened (:218)
   // frame-slotted (cb / ca)
-  float4 *cl_pts[2];         // [B][Nmax]  clusters[k] points, (cluster, index) order (:229); ca's are transformed in place (:550)
-  int *cl_cid[2];            // [B][Nmax]  cluster id per cl_pts entry
-  int *cl_off[2];            // [B][Kcap+1]
-  int *chunk_off[2];         // [B][Kcap+1]  first reduction chunk of each cluster
-  Red6 *part; int Wcap;      // [B][Wcap]    per-chunk partials (scratch)
-  float4 *centroid[2];       // [B][Kcap]  centroid_collection (:243)
-  float4 *amin[2], *amax[2]; // [B][Kcap]  cluster AABBs (getMinMax3D, :272-274)
+  float4 *cl_pts[3];         // [B][Nmax]  clusters[k] points, (cluster, index) order (:229); ca's are transformed in place (:550)
+  int *cl_cid[3];            // [B][Nmax]  cluster id per cl_pts entry
+  int *cl_off[3];            // [B][Kcap+1]
+  int *chunk_off[3];         // [B][Kcap+1]  first reduction chunk of each cluster
+  Red6 *part, *part_back; int Wcap; // [B][Wcap]  per-chunk partials: scratch of k_stats (front stage) / k_xform_prev (pair stage)
+  float4 *centroid[3];       // [B][Kcap]  centroid_collection (:243)
+  float4 *amin[3], *amax[3]; // [B][Kcap]  cluster AABBs (getMinMax3D, :272-274)
   // pair stage
   int *nn_fwd, *nn_bwd;      // [B][Kcap]
   float *nn_fwd_d;           // [B][Kcap]
@@ -167,7 +169,8 @@ enum MorKernelId {
 extern const char *const mor_kernel_names[MK_COUNT];
 
 struct MorLaunchTimer;   // engine-owned; records event pairs when enabled
-void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);
+void mor_launch_front(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);   // ingest … clusters + centroids of the new frame
+void mor_launch_back(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);    // pair stage with the previous frame, scores, tracking
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);
 void mor_timer_begin(MorLaunchTimer *tm, int kernel_id, hipStream_t st);
 void mor_timer_end(MorLaunchTimer *tm, int kernel_id, hipStream_t st);

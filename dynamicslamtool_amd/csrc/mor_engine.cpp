@@ -54,18 +54,18 @@ struct PoseTf { double R[3][3], o[3]; };
 
 struct mor_batch {
   mor_params p; int n_bad, n_good, B, device; uint64_t Nmax;
-  hipStream_t st = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  // stream groups: the B streams are split into G groups that run the same launch sequence on their own HIP
-  // streams, so the latency-bound stages of one group overlap the other groups' work (streams are independent)
-  int G = 1;
-  hipStream_t gst[MOR_MAX_GROUPS] = {};
-  hipEvent_t gev[MOR_MAX_GROUPS][2] = {};
-  bool use_graphs = true;
-  struct GraphKey { int kind, g, cur, has_prev, tiles, tiles_m, outp; bool operator<(const GraphKey &o) const { return std::tie(kind, g, cur, has_prev, tiles, tiles_m, outp) < std::tie(o.kind, o.g, o.cur, o.has_prev, o.tiles, o.tiles_m, o.outp); } };
-  std::map<GraphKey, hipGraphExec_t> graphs;
-  MorDev d;                                  // template descriptor (static part + pointers)
+  hipStream_t st = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // st: copies of read-backs; ev: push/filter timing
+  // Two in-order HIP streams form a software pipeline over frames: `sf` runs the front stage of frame k (ingest …
+  // clusters), `sb` its pair stage, tracking and filterCloud.  Every array the back stage reads is double-buffered by
+  // frame parity and the cluster arrays rotate through three slots, so front(k+1) runs beside back(k); front(k) only
+  // waits for back(k−2), back(k) for front(k).
+  hipStream_t sf = nullptr, sb = nullptr;
+  hipEvent_t ev_front[3] = {}, ev_back[3] = {};
+  MorDev dtemp[2];                           // descriptor templates for even / odd frames (static part + pointers)
+  MorDev d;                                  // descriptor of the latest pushed frame
+  MorStreamArgs *d_args_s[2] = {nullptr, nullptr};
   std::vector<void *> dev_allocs, host_allocs;
-  MorStreamArgs *h_args_ring = nullptr, *h_args = nullptr, *d_args = nullptr;   // pinned ring of MOR_ARGS_RING slots (async pushes), current slot
+  MorStreamArgs *h_args_ring = nullptr, *h_args = nullptr;   // pinned ring of MOR_ARGS_RING slots (async pushes), current slot
   hipEvent_t args_ev[MOR_ARGS_RING] = {};
   bool async = false, pending = false;   // async: push/filter only enqueue; pending: work enqueued since the last wait
   unsigned char *d_moving = nullptr;
@@ -160,49 +160,10 @@ static int configure(mor_batch *b) {
   return MOR_OK;
 }
 
-// Runs one launch sequence (kind 0 = push, 1 = filter) for every stream group on its own HIP stream and waits for
-// all of them.  The sequence of a group is captured once per (frame slot, tile count, …) into a hipGraph and
-// replayed: ≈45 launches collapse into one host call per group.  `pre(g, stream)` enqueues the per-call copies.
-template <class Pre> static int run_groups(mor_batch *b, const MorDev &d, int kind, Pre pre, float *ms_out, bool sync) {
-  const int G = b->G, Bg = d.Btot / G;
-  const bool graphs = b->use_graphs && !b->timer.enabled;
-  for (int g = 0; g < G; ++g) {
-    MorDev dg = d; dg.B = Bg; dg.s0 = g * Bg;
-    hipStream_t st = b->gst[g];
-    int rc = pre(g, st, dg); if (rc != MOR_OK) return rc;
-    HIP_TRY(hipEventRecord(b->gev[g][0], st));
-    if (graphs) {
-      mor_batch::GraphKey key{kind, g, d.cur, d.has_prev, d.tiles, d.tiles_m, d.out_ptrs ? 1 : 0};
-      auto it = b->graphs.find(key);
-      if (it == b->graphs.end()) {
-        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-        HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        if (kind == 0) mor_launch_push(dg, st, nullptr); else mor_launch_filter(dg, st, nullptr);
-        HIP_TRY(hipStreamEndCapture(st, &graph));
-        HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        HIP_TRY(hipGraphDestroy(graph));
-        it = b->graphs.emplace(key, exec).first;
-      }
-      HIP_TRY(hipGraphLaunch(it->second, st));
-    } else {
-      if (kind == 0) mor_launch_push(dg, st, &b->timer); else mor_launch_filter(dg, st, &b->timer);
-    }
-    HIP_TRY(hipEventRecord(b->gev[g][1], st));
-  }
-  HIP_TRY(hipGetLastError());
-  b->pending = true;
-  if (!sync) return MOR_OK;
-  float mx = 0;
-  for (int g = 0; g < G; ++g) { HIP_TRY(hipStreamSynchronize(b->gst[g])); float t = 0; hipEventElapsedTime(&t, b->gev[g][0], b->gev[g][1]); mx = std::max(mx, t); }
-  if (ms_out) *ms_out = mx;
-  b->timer.collect();
-  return MOR_OK;
-}
-
 // waits for everything enqueued on the batch and turns the device-side flags of the last push into an error code
 static int wait_all_checked(mor_batch *b) {
   if (!b->pending) return MOR_OK;
-  for (int g = 0; g < b->G; ++g) HIP_TRY(hipStreamSynchronize(b->gst[g]));
+  HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sb));
   b->pending = false;
   b->timer.collect();
   int rc = MOR_OK;
@@ -228,10 +189,13 @@ void mor_batch_destroy(mor_batch *b) {
   if (!b) return;
   hipSetDevice(b->device);
   if (b->st) hipStreamSynchronize(b->st);
-  for (int g = 0; g < b->G; ++g) if (b->gst[g]) hipStreamSynchronize(b->gst[g]);
-  for (auto &kv : b->graphs) hipGraphExecDestroy(kv.second);
+  if (b->sf) hipStreamSynchronize(b->sf);
+  if (b->sb) hipStreamSynchronize(b->sb);
   for (auto &ev : b->args_ev) if (ev) hipEventDestroy(ev);
-  for (int g = 0; g < b->G; ++g) { if (b->gst[g]) hipStreamDestroy(b->gst[g]); for (auto &ev : b->gev[g]) if (ev) hipEventDestroy(ev); }
+  for (auto &ev : b->ev_front) if (ev) hipEventDestroy(ev);
+  for (auto &ev : b->ev_back) if (ev) hipEventDestroy(ev);
+  if (b->sf) hipStreamDestroy(b->sf);
+  if (b->sb) hipStreamDestroy(b->sb);
   for (void *p : b->dev_allocs) hipFree(p);
   for (void *p : b->host_allocs) hipHostFree(p);
   if (b->d_stage) hipFree(b->d_stage);
@@ -255,21 +219,14 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   for (auto &ev : b->args_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   if (hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
   for (auto &e : b->ev) if (hipEventCreate(&e) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
-  {
-    const char *eg = getenv("MOR_GROUPS"), *egr = getenv("MOR_GRAPH");
-    int G = eg ? atoi(eg) : 1;   // measured on MI355X (B=64 hdl64): G>1 loses more to host-side launch/copy cost than overlap gains
-    if (G < 1 || G > MOR_MAX_GROUPS || n_streams % G != 0) G = 1;
-    b->G = G; b->use_graphs = !(egr && atoi(egr) == 0);
-    for (int g = 0; g < G; ++g) {
-      if (hipStreamCreateWithFlags(&b->gst[g], hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
-      for (auto &ev : b->gev[g]) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
-    }
-  }
+  if (hipStreamCreateWithFlags(&b->sf, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sb, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
+  for (auto &ev : b->ev_front) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+  for (auto &ev : b->ev_back) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   MorDev &d = b->d; const size_t B = d.B, N = d.Nmax, K = d.Kcap, T = d.tiles_max;
   bool ok = true;
   MorStreamArgs *dargs = nullptr;
   ok = ok && dalloc(b, dargs, B) && dalloc(b, d.info, B) && dalloc(b, d.tile_cnt, B * T * 2) && dalloc(b, d.tile_off, B * T * 2);
-  b->d_args = dargs; d.args = dargs;
+  b->d_args_s[0] = dargs; d.args = dargs;
   ok = ok && dalloc(b, d.cloud, B * N) && dalloc(b, d.cloud_tidx, B * N) && dalloc(b, d.ground, B * N) && dalloc(b, d.gp_idx, B * N) && dalloc(b, d.cell_of, B * N);
   ok = ok && dalloc(b, d.pkey, B * N) && dalloc(b, d.ckey, B * N) && dalloc(b, d.cstart, B * (N + 1)) && dalloc(b, d.row_start, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, d.cmin, B * N) && dalloc(b, d.cmeta, 2 * B * N);
   ok = ok && dalloc(b, d.sorted, B * N) && dalloc(b, d.parent, B * N) && dalloc(b, d.croot, B * N) && dalloc(b, d.csize, B * N) && dalloc(b, d.compmin, B * N) && dalloc(b, d.cid_of_root, B * N) && dalloc(b, d.pcid, B * N) && dalloc(b, d.ccid, B * N);
@@ -292,10 +249,10 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, d.rkeys[i], B * N) && dalloc(b, d.rvals[i], B * N);
   ok = ok && dalloc(b, d.rhist, B * T * 256) && dalloc(b, d.cl_idx, B * N);
   d.skey = d.rkeys[d.cell_passes & 1]; d.sidx = d.rvals[d.cell_passes & 1];
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 3; ++i)
     ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.chunk_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K);
   d.Wcap = (int)(N / MOR_CHUNK + K + 2);
-  ok = ok && dalloc(b, d.part, B * (size_t)d.Wcap);
+  ok = ok && dalloc(b, d.part, B * (size_t)d.Wcap) && dalloc(b, d.part_back, B * (size_t)d.Wcap);
   ok = ok && dalloc(b, d.nn_fwd, B * K) && dalloc(b, d.nn_bwd, B * K) && dalloc(b, d.nn_fwd_d, B * K) && dalloc(b, d.pair_q, B * K) && dalloc(b, d.pair_m, B * K) && dalloc(b, d.pair_d, B * K);
   ok = ok && dalloc(b, d.pair_cnt, B * K) && dalloc(b, d.pair_of_prev, B * K) && dalloc(b, d.pair_of_cur, B * K) && dalloc(b, d.det, B * K);
   if (p->method_choice == 2) ok = ok && dalloc(b, d.vox, B * (size_t)d.Hcap);
@@ -316,8 +273,20 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && halloc(b, d.h_info, B) && halloc(b, d.h_centroid, B * K) && halloc(b, d.h_cl_off, B * (K + 1)) && halloc(b, d.h_det, B * K);
   ok = ok && halloc(b, d.h_pair_q, B * K) && halloc(b, d.h_pair_m, B * K) && halloc(b, d.h_pair_d, B * K) && halloc(b, d.h_score, B * K) && halloc(b, d.h_nout, B);
   if (!ok) return fail(set_error(MOR_ERR_HIP, "device/host allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
-  if (hipMemsetAsync(d.info, 0, B * sizeof(MorFrameInfo), b->st) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "memset failed"));
-  hipStreamSynchronize(b->st);
+  // second copy of everything the back stage (pair stage, tracking, filterCloud) reads of a frame
+  b->dtemp[0] = d; b->dtemp[1] = d;
+  {
+    MorDev &o = b->dtemp[1]; MorStreamArgs *dargs1 = nullptr;
+    ok = dalloc(b, dargs1, B) && dalloc(b, o.info, B) && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, B * N) && dalloc(b, o.gp_idx, B * N);
+    ok = ok && dalloc(b, o.sorted, B * N) && dalloc(b, o.ckey, B * N) && dalloc(b, o.cstart, B * (N + 1)) && dalloc(b, o.row_start, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, o.cmeta, 2 * B * N);
+    ok = ok && dalloc(b, o.pcid, B * N) && dalloc(b, o.ccid, B * N) && dalloc(b, o.cl_idx, B * N) && dalloc(b, o.det, B * K) && dalloc(b, o.zorg, B);
+    b->d_args_s[1] = dargs1; o.args = dargs1;
+    if (ok) ok = hipMemcpy(o.zorg, d.zorg, B * sizeof(float), hipMemcpyDeviceToDevice) == hipSuccess;
+    if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
+  }
+  for (int i = 0; i < 2; ++i) if (hipMemset(b->dtemp[i].info, 0, B * sizeof(MorFrameInfo)) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "memset failed"));
+  b->dtemp[0].info_prev = b->dtemp[1].info; b->dtemp[1].info_prev = b->dtemp[0].info;
+  b->d = b->dtemp[0];
   b->prev_pose.resize(B);
   if (err) *err = MOR_OK;
   return b;
@@ -328,7 +297,8 @@ int mor_batch_streams(const mor_batch *b) { return b ? b->B : 0; }
 int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *poses) {
   if (!b || !clouds || !poses) return set_error(MOR_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(b->device));
-  MorDev d = b->d; const int B = d.B;
+  const uint64_t k = b->frame;
+  MorDev d = b->dtemp[k & 1]; const int B = d.B;
   uint64_t maxn = 0; size_t max_host_bytes = 0;
   for (int s = 0; s < B; ++s) {
     const mor_cloud_view &c = clouds[s];
@@ -341,12 +311,12 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     if (!c.on_device) max_host_bytes = std::max<size_t>(max_host_bytes, (size_t)c.n_points * c.point_step);
   }
   if (max_host_bytes > b->stage_stride) {   // (re)allocate the staging area for host-resident blobs
-    if (b->d_stage) { for (int g = 0; g < b->G; ++g) HIP_TRY(hipStreamSynchronize(b->gst[g])); HIP_TRY(hipFree(b->d_stage)); b->d_stage = nullptr; }
+    if (b->d_stage) { HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sb)); HIP_TRY(hipFree(b->d_stage)); b->d_stage = nullptr; }
     b->stage_stride = (max_host_bytes + 255) & ~(size_t)255;
     HIP_TRY(hipMalloc((void **)&b->d_stage, b->stage_stride * B));
   }
   // pinned argument slot of this push (a ring, so asynchronous pushes never overwrite a slot the GPU still has to copy)
-  const int slot = (int)(b->frame % MOR_ARGS_RING);
+  const int slot = (int)(k % MOR_ARGS_RING);
   HIP_TRY(hipEventSynchronize(b->args_ev[slot]));
   b->h_args = b->h_args_ring + (size_t)slot * B;
   std::vector<PoseTf> cur(B);
@@ -355,30 +325,39 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     a.n = (uint32_t)c.n_points; a.step = c.point_step; a.off_x = c.off_x; a.off_y = c.off_y; a.off_z = c.off_z; a.off_i = c.off_intensity;
     a.data = (c.on_device || c.n_points == 0) ? c.data : (const void *)(b->d_stage + b->stage_stride * s);
     pose_to_tf(poses + 7 * s, cur[s]);
-    if (b->frame > 0) relative_transform(cur[s], b->prev_pose[s], a.xf); else memset(a.xf, 0, sizeof a.xf);
+    if (k > 0) relative_transform(cur[s], b->prev_pose[s], a.xf); else memset(a.xf, 0, sizeof a.xf);
     b->prev_pose[s] = cur[s];
   }
   d.tiles = std::max<int>(1, (int)((maxn + MOR_TILE - 1) / MOR_TILE));
-  d.cur = (int)(b->frame & 1); d.has_prev = b->frame > 0; d.out_ptrs = nullptr; d.run_tracker = 0;
+  d.cur = (int)(k % 3); d.prev = (int)((k + 2) % 3); d.has_prev = k > 0; d.out_ptrs = nullptr; d.run_tracker = 0;
+  d.info_prev = b->dtemp[(k + 1) & 1].info;
   {  // workgroups for the cloud-sized kernels: 1.25 × the largest cloud / cluster set the device last reported
     uint32_t mx = 0;
     for (int s = 0; s < B; ++s) mx = std::max(mx, std::max(d.h_info[s].M, d.h_info[s].C));
-    d.tiles_m = (b->frame > 0 && mx > 0) ? std::min<int>(d.tiles, (int)(((uint64_t)mx * 5 / 4 + MOR_TILE - 1) / MOR_TILE) + 1) : d.tiles;
+    d.tiles_m = (k > 0 && mx > 0) ? std::min<int>(d.tiles, (int)(((uint64_t)mx * 5 / 4 + MOR_TILE - 1) / MOR_TILE) + 1) : d.tiles;
   }
-  const int Bg = B / b->G;
-  auto pre = [&](int g, hipStream_t st, const MorDev &) -> int {
-    for (int s = g * Bg; s < (g + 1) * Bg; ++s) {   // host-resident blobs: stage on the group's stream
-      const mor_cloud_view &c = clouds[s];
-      if (!c.on_device && c.n_points) HIP_TRY(hipMemcpyAsync((void *)b->h_args[s].data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, st));
-    }
-    HIP_TRY(hipMemcpyAsync(b->d_args + g * Bg, b->h_args + g * Bg, sizeof(MorStreamArgs) * Bg, hipMemcpyHostToDevice, st));
-    if (g == b->G - 1) HIP_TRY(hipEventRecord(b->args_ev[slot], st));
-    return MOR_OK;
-  };
-  b->d.tiles = d.tiles; b->d.tiles_m = d.tiles_m; b->d.cur = d.cur; b->d.has_prev = d.has_prev;
-  b->frame++; b->filtered = false;
-  { int rc0 = run_groups(b, d, 0, pre, &b->push_ms, !b->async); if (rc0 != MOR_OK) return rc0; }
-  return b->async ? MOR_OK : wait_all_checked(b);
+  // ---- front stage on sf: must not overwrite what back(k−2) still reads (same parity buffers, same cluster slot)
+  if (k >= 2) HIP_TRY(hipStreamWaitEvent(b->sf, b->ev_back[(k - 2) % 3], 0));
+  for (int s = 0; s < B; ++s) {   // host-resident blobs are staged through device memory
+    const mor_cloud_view &c = clouds[s];
+    if (!c.on_device && c.n_points) HIP_TRY(hipMemcpyAsync((void *)b->h_args[s].data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, b->sf));
+  }
+  HIP_TRY(hipMemcpyAsync(b->d_args_s[k & 1], b->h_args, sizeof(MorStreamArgs) * B, hipMemcpyHostToDevice, b->sf));
+  HIP_TRY(hipEventRecord(b->args_ev[slot], b->sf));
+  HIP_TRY(hipEventRecord(b->ev[0], b->sf));
+  mor_launch_front(d, b->sf, &b->timer);
+  HIP_TRY(hipEventRecord(b->ev_front[k % 3], b->sf));
+  // ---- pair stage + tracking on sb (in order behind back(k−1)), once the front stage of this frame is done
+  HIP_TRY(hipStreamWaitEvent(b->sb, b->ev_front[k % 3], 0));
+  mor_launch_back(d, b->sb, &b->timer);
+  HIP_TRY(hipEventRecord(b->ev[1], b->sb));
+  HIP_TRY(hipEventRecord(b->ev_back[k % 3], b->sb));
+  HIP_TRY(hipGetLastError());
+  b->d = d; b->frame++; b->filtered = false; b->pending = true;
+  if (b->async) return MOR_OK;
+  int rc = wait_all_checked(b);
+  hipEventElapsedTime(&b->push_ms, b->ev[0], b->ev[1]);
+  return rc;
 }
 
 int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t *n_out) {
@@ -386,19 +365,26 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
   if (b->frame == 0) return set_error(MOR_ERR_NOT_READY, "filterCloud before the first pushRawCloudAndPose");
   HIP_TRY(hipSetDevice(b->device));
   MorDev d = b->d; const int B = d.B;
+  const uint64_t k = b->frame - 1;
   d.run_tracker = b->filtered ? 0 : 1;   // the tracking loop of filterCloud (:630-671) runs on the device, once per frame
   b->filtered = true;
   d.out_ptrs = nullptr;
-  if (out && out_on_device) { for (int s = 0; s < B; ++s) b->h_outptrs[s] = (float4 *)out[s]; d.out_ptrs = b->d_outptrs; }
-  const int Bg = B / b->G;
-  auto pre = [&](int g, hipStream_t st, const MorDev &) -> int {
-    if (d.out_ptrs) HIP_TRY(hipMemcpyAsync(b->d_outptrs + g * Bg, b->h_outptrs + g * Bg, sizeof(float4 *) * Bg, hipMemcpyHostToDevice, st));
-    return MOR_OK;
-  };
+  if (out && out_on_device) {
+    if (b->async) HIP_TRY(hipStreamSynchronize(b->sb));   // the pinned pointer table may still be in flight
+    for (int s = 0; s < B; ++s) b->h_outptrs[s] = (float4 *)out[s];
+    HIP_TRY(hipMemcpyAsync(b->d_outptrs, b->h_outptrs, sizeof(float4 *) * B, hipMemcpyHostToDevice, b->sb));
+    d.out_ptrs = b->d_outptrs;
+  }
+  HIP_TRY(hipEventRecord(b->ev[2], b->sb));
+  mor_launch_filter(d, b->sb, &b->timer);
+  HIP_TRY(hipEventRecord(b->ev[3], b->sb));
+  HIP_TRY(hipEventRecord(b->ev_back[k % 3], b->sb));
+  HIP_TRY(hipGetLastError());
+  b->pending = true;
   const bool need_host = n_out != nullptr || (out && !out_on_device);
-  { int rc0 = run_groups(b, d, 1, pre, &b->filter_ms, !b->async || need_host); if (rc0 != MOR_OK) return rc0; }
   if (b->async && !need_host) return MOR_OK;
   int rc = wait_all_checked(b);
+  hipEventElapsedTime(&b->filter_ms, b->ev[2], b->ev[3]);
   for (int s = 0; s < B; ++s) if (n_out) n_out[s] = d.h_nout[s];
   if (out && !out_on_device) {
     for (int s = 0; s < B; ++s) if (out[s] && d.h_nout[s]) HIP_TRY(hipMemcpyAsync(out[s], d.out + (size_t)s * d.Nmax, d.h_nout[s] * sizeof(float4), hipMemcpyDeviceToHost, b->st));

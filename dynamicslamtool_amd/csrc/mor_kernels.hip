@@ -205,7 +205,6 @@ __global__ __launch_bounds__(MOR_BT) void k_scan_tiles(MorDev d) {
     f.M = carry_ng; f.G = carry_g; f.T = carry_ng + carry_g;
     if (d.gmode != 2) {
       f.N = d.args[s].n; f.flags = 0; f.n_pairs = 0; f.K = 0; f.C = 0;
-      f.Kprev = d.has_prev ? f.Kprev : 0; f.Cprev = d.has_prev ? f.Cprev : 0;
     }
     if (d.gmode == 1) {   // grids of the voxel variant hang on the lowest trimmed point
       float zmin = f.T ? ordered_float(d.zmin_i[s]) : 0.f;
@@ -758,7 +757,7 @@ template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int
     int basew = 0, tot = 0;
     for (int w = 0; w < CG_T / 64; ++w) { int xw = l_misc[1 + w]; if (w < wave_id()) basew += xw; tot += xw; }
     __syncthreads();
-    if (k < K) { off[k] = carry + basew + inc - v; d.det[ko + k] = 0; d.pair_of_cur[ko + k] = -1; }
+    if (k < K) { off[k] = carry + basew + inc - v; d.det[ko + k] = 0; }
     carry += tot;
   }
   if (threadIdx.x == 0) { off[K] = carry; d.info[s].C = carry; d.info[s].K = K; }
@@ -833,7 +832,7 @@ __global__ __launch_bounds__(MOR_BT) void k_offsets(MorDev d) {
   for (int b = 0; b < K; b += MOR_BT) {
     int k = b + threadIdx.x, v = k < K ? sz[k] : 0, tot;
     int e = block_excl_scan(v, sh, &tot);
-    if (k < K) { off[k] = carry + e; d.det[(size_t)s * d.Kcap + k] = 0; d.pair_of_cur[(size_t)s * d.Kcap + k] = -1; }
+    if (k < K) { off[k] = carry + e; d.det[(size_t)s * d.Kcap + k] = 0; }
     carry += tot;
   }
   if (threadIdx.x == 0) { off[K] = carry; d.info[s].C = carry; }
@@ -1029,7 +1028,7 @@ __device__ __forceinline__ void xform(const float *m, float &x, float &y, float 
   z = ((m[8] * a + m[9] * b) + m[10] * c) + m[11];
 }
 __global__ __launch_bounds__(MOR_BT) void k_xform_prev(MorDev d) {
-  int s = blockIdx.y + d.s0, pv = d.cur ^ 1, K = d.info[s].Kprev;
+  int s = blockIdx.y + d.s0, pv = d.prev, K = d.info_prev[s].K;
   if (K == 0) return;
   const size_t so = (size_t)s * d.Nmax;
   const int *off = d.cl_off[pv] + (size_t)s * (d.Kcap + 1), *coff = d.chunk_off[pv] + (size_t)s * (d.Kcap + 1);
@@ -1049,15 +1048,15 @@ __global__ __launch_bounds__(MOR_BT) void k_xform_prev(MorDev d) {
       r.mxx = fmaxf(r.mxx, p.x); r.mxy = fmaxf(r.mxy, p.y); r.mxz = fmaxf(r.mxz, p.z);
     }
     red6_block(r, sh);
-    if (threadIdx.x == 0) d.part[(size_t)s * d.Wcap + w] = r;
+    if (threadIdx.x == 0) d.part_back[(size_t)s * d.Wcap + w] = r;
   }
 }
 // AABBs of the transformed clusters (volume gate), transformed centroids (:540-541)
 __global__ __launch_bounds__(MOR_BT) void k_xform_fin(MorDev d) {
-  int s = blockIdx.y + d.s0, pv = d.cur ^ 1, K = d.info[s].Kprev, k = blockIdx.x * MOR_BT + threadIdx.x;
+  int s = blockIdx.y + d.s0, pv = d.prev, K = d.info_prev[s].K, k = blockIdx.x * MOR_BT + threadIdx.x;
   if (k >= K) return;
   const int *coff = d.chunk_off[pv] + (size_t)s * (d.Kcap + 1);
-  const Red6 *pt = d.part + (size_t)s * d.Wcap;
+  const Red6 *pt = d.part_back + (size_t)s * d.Wcap;
   Red6 r = pt[coff[k]];
   for (int w = coff[k] + 1; w < coff[k + 1]; ++w) {
     const Red6 q = pt[w];
@@ -1077,8 +1076,8 @@ __global__ __launch_bounds__(MOR_BT) void k_xform_fin(MorDev d) {
 // dir 0: nearest current centroid of every previous centroid; dir 1: the reverse.  Squared fp32
 // distance, ties → lowest index (ascending scan with strict <).
 __global__ __launch_bounds__(MOR_BT) void k_nn_centroid(MorDev d, int dir) {
-  int s = blockIdx.y + d.s0, pv = d.cur ^ 1;
-  int Ksrc = dir == 0 ? d.info[s].Kprev : d.info[s].K, Kdst = dir == 0 ? d.info[s].K : d.info[s].Kprev;
+  int s = blockIdx.y + d.s0, pv = d.prev;
+  int Ksrc = dir == 0 ? d.info_prev[s].K : d.info[s].K, Kdst = dir == 0 ? d.info[s].K : d.info_prev[s].K;
   if (blockIdx.x * MOR_BT >= Ksrc) return;
   const float4 *src = d.centroid[dir == 0 ? pv : d.cur] + (size_t)s * d.Kcap, *dst = d.centroid[dir == 0 ? d.cur : pv] + (size_t)s * d.Kcap;
   int i = blockIdx.x * MOR_BT + threadIdx.x;
@@ -1094,12 +1093,12 @@ __global__ __launch_bounds__(MOR_BT) void k_nn_centroid(MorDev d, int dir) {
   }
   if (i < Ksrc) {
     if (dir == 0) { d.nn_fwd[(size_t)s * d.Kcap + i] = bi; d.nn_fwd_d[(size_t)s * d.Kcap + i] = best; }
-    else d.nn_bwd[(size_t)s * d.Kcap + i] = bi;
+    else { d.nn_bwd[(size_t)s * d.Kcap + i] = bi; d.pair_of_cur[(size_t)s * d.Kcap + i] = -1; }
   }
 }
 // reciprocal test + volumeConstraint (:264-283), correspondences emitted in source-index order
 __global__ __launch_bounds__(MOR_BT) void k_pairs(MorDev d) {
-  int s = blockIdx.x + d.s0, pv = d.cur ^ 1, Kp = d.info[s].Kprev, Kc = d.info[s].K;
+  int s = blockIdx.x + d.s0, pv = d.prev, Kp = d.info_prev[s].K, Kc = d.info[s].K;
   __shared__ int sh[8]; int carry = 0;
   const size_t ko = (size_t)s * d.Kcap;
   for (int b = 0; b < Kp; b += MOR_BT) {
@@ -1188,7 +1187,7 @@ __device__ __forceinline__ void wl_push(bool want, int *n, int *list, float *bes
 // compacted into a worklist so the next tier runs full waves of hard queries instead of dragging every wave.
 __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
   int s, t0; map_block(d.B, d.tiles_m * 8, s, t0);
-  const int pv = d.cur ^ 1, Cp = d.info[s].Cprev;
+  const int pv = d.prev, Cp = d.info_prev[s].C;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
@@ -1220,7 +1219,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
 // here when some matched point lies within √lb, or when the nearest one is closer than one cell edge, which beats
 // every farther row (bound ≥ cs²).  Anything else — or a thread that has scanned its budget — goes to tier 2.
 __global__ __launch_bounds__(MOR_BT) void k_score_rows(MorDev d) {
-  int s = blockIdx.y + d.s0, pv = d.cur ^ 1, nq = d.wl_n[s];
+  int s = blockIdx.y + d.s0, pv = d.prev, nq = d.wl_n[s];
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
@@ -1299,7 +1298,7 @@ __device__ __forceinline__ float wave_scan_cell(const float4 *sp, int b0, int e0
   return wave_min(local);
 }
 __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
-  int s = blockIdx.y + d.s0, pv = d.cur ^ 1, nq = d.wl2_n[s];
+  int s = blockIdx.y + d.s0, pv = d.prev, nq = d.wl2_n[s];
   const int wv = blockIdx.x * (MOR_BT / 64) + wave_id(), nw = gridDim.x * (MOR_BT / 64), lane = lane_id();
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
@@ -1376,7 +1375,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
 __device__ __forceinline__ int vox_table_size(const MorDev &d, int Cprev) { int h = 64; while (h < 2 * Cprev && h < d.Hcap) h <<= 1; return h; }
 __device__ __forceinline__ unsigned long long vox_hash(unsigned long long k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; }
 __device__ __forceinline__ bool vox_key(const MorDev &d, int s, int pr, float4 p, unsigned long long &key) {
-  int pv = d.cur ^ 1;
+  int pv = d.prev;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   int q = d.pair_q[ko + pr];
   float4 p0 = d.cl_pts[pv][so + d.cl_off[pv][(size_t)s * (d.Kcap + 1) + q]];
@@ -1395,13 +1394,13 @@ __device__ __forceinline__ bool vox_key(const MorDev &d, int s, int pr, float4 p
   return ok;
 }
 __global__ __launch_bounds__(MOR_BT) void k_vox_clear(MorDev d) {
-  int s = blockIdx.y + d.s0, H = vox_table_size(d, d.info[s].Cprev);
+  int s = blockIdx.y + d.s0, H = vox_table_size(d, d.info_prev[s].C);
   unsigned long long *tab = d.vox + (size_t)s * d.Hcap;
   for (int i = blockIdx.x * MOR_BT + threadIdx.x; i < H; i += gridDim.x * MOR_BT) tab[i] = VOX_EMPTY;
 }
 __global__ __launch_bounds__(MOR_BT) void k_vox_insert(MorDev d) {
   int s, t; map_block(d.B, d.tiles, s, t);
-  int pv = d.cur ^ 1, Cp = d.info[s].Cprev, base = t * MOR_TILE;
+  int pv = d.prev, Cp = d.info_prev[s].C, base = t * MOR_TILE;
   if (base >= Cp) return;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   unsigned long long *tab = d.vox + (size_t)s * d.Hcap; int H = vox_table_size(d, Cp);
@@ -1419,7 +1418,7 @@ __global__ __launch_bounds__(MOR_BT) void k_vox_probe(MorDev d) {
   int C = d.info[s].C, base = t * MOR_TILE;
   if (base >= C) return;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
-  const unsigned long long *tab = d.vox + (size_t)s * d.Hcap; int H = vox_table_size(d, d.info[s].Cprev);
+  const unsigned long long *tab = d.vox + (size_t)s * d.Hcap; int H = vox_table_size(d, d.info_prev[s].C);
   for (int j = base + threadIdx.x; j < min(base + MOR_TILE, C); j += MOR_BT) {
     int pr = d.pair_of_cur[ko + d.cl_cid[d.cur][so + j]];
     if (pr < 0) continue;
@@ -1435,7 +1434,7 @@ __global__ __launch_bounds__(MOR_BT) void k_vox_probe(MorDev d) {
 // scores → detection_results (:580-606); then everything the host tracker needs goes straight
 // into pinned host memory (a few KB per stream), so the push needs exactly one stream sync.
 __global__ __launch_bounds__(MOR_BT) void k_decide(MorDev d) {
-  int s = blockIdx.x + d.s0, pv = d.cur ^ 1;
+  int s = blockIdx.x + d.s0, pv = d.prev;
   const size_t ko = (size_t)s * d.Kcap;
   MorFrameInfo f = d.info[s];
   int np = d.has_prev ? (int)f.n_pairs : 0;
@@ -1456,7 +1455,7 @@ __global__ __launch_bounds__(MOR_BT) void k_decide(MorDev d) {
   for (int k = threadIdx.x; k <= K; k += MOR_BT) d.h_cl_off[(size_t)s * (d.Kcap + 1) + k] = offc[k];
   if (threadIdx.x == 0) {
     f.n_pairs = np; f.n_defer = (d.has_prev && d.method == 1) ? (uint32_t)d.wl2_n[s] : 0u; f.pad0 = (d.has_prev && d.method == 1) ? (uint32_t)d.wl_n[s] : 0u;
-    d.info[s].Kprev = f.K; d.info[s].Cprev = f.C;   // this frame is the next push's `ca`
+    f.Kprev = d.has_prev ? d.info_prev[s].K : 0; f.Cprev = d.has_prev ? d.info_prev[s].C : 0;   // for the host mirror
     d.info[s].n_pairs = np;
     d.h_info[s] = f;
   }
@@ -1857,7 +1856,7 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
   MOR_LAUNCH(MK_ROWTABLE, k_rowtable, dim3((d.g.nrows + MOR_BT) / MOR_BT > 32 ? 32 : (d.g.nrows + MOR_BT) / MOR_BT, d.B), d);
 }
 
-void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+void mor_launch_front(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B), gW(getenv("MOR_GW") ? atoi(getenv("MOR_GW")) : 64, d.B);
   if (d.gmode == 0) {
     mor_launch_split_and_grid(d, st, tm);
@@ -1905,6 +1904,10 @@ void mor_launch_push(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   }
   MOR_LAUNCH(MK_STATS, k_stats, dim3(64, d.B), d);
   MOR_LAUNCH(MK_STATS_FIN, k_stats_fin, gKt, d);
+}
+
+void mor_launch_back(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+  const dim3 gT(d.B * d.tiles), gB(d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B);
   if (d.has_prev) {
     MOR_LAUNCH(MK_XFORM_PREV, k_xform_prev, dim3(64, d.B), d);
     MOR_LAUNCH(MK_XFORM_FIN, k_xform_fin, gKt, d);
