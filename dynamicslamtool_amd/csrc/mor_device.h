@@ -33,6 +33,7 @@ struct MorRadix {
   int shift, count_sel;   // digit = (key >> shift) & 255; element count: 0 → M, 1 → C
   int drop_negative;      // elements with key < 0 are dropped (unclustered points)
   int *vout2;             // optional second copy of the values (pass 0 of the cluster partition also writes cl_idx)
+  int *hist;              // [B][tiles_max][256] histogram / offset scratch of this sort
   int skip_k_le;          // > 0: streams with K ≤ this need no further pass — the kernel returns at once for them
 };
 
@@ -115,8 +116,9 @@ struct MorDev {
   int *ktile_cnt;            // [B][tiles_max]
   int *kcell, *kroot, *ksize; // [B][Kcap]  kept components: root cell, smallest cloud index, size
   int *csz;                  // [B][Kcap]  sizes in final cluster order
-  int *rkeys[2], *rvals[2];  // [B][Nmax]  radix ping-pong (cluster id, cloud index)
+  int *rkeys[2], *rvals[2];  // [B][Nmax]  radix ping-pong of the cell sort (grid stage)
   int *rhist;                // [B][tiles_max][256]
+  int *rkeys2[2], *rvals2[2], *rhist2; // the same for the cluster partition (cluster stage runs beside the next frame's grid stage)
   int *cl_idx;               // [B][Nmax]  cluster_indices flattened (:218)
   // frame-slotted (cb / ca)
   float4 *cl_pts[3];         // [B][Nmax]  clusters[k] points, (cluster, index) order (:229); ca's are transformed in place (:550)
@@ -169,7 +171,8 @@ enum MorKernelId {
 extern const char *const mor_kernel_names[MK_COUNT];
 
 struct MorLaunchTimer;   // engine-owned; records event pairs when enabled
-void mor_launch_front(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);   // ingest … clusters + centroids of the new frame
+void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);     // ingest, ground split, cell-sorted cloud, cell table
+void mor_launch_cluster(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);  // cell graph, labels, cluster_indices, centroids
 void mor_launch_back(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);    // pair stage with the previous frame, scores, tracking
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);
 void mor_timer_begin(MorLaunchTimer *tm, int kernel_id, hipStream_t st);

@@ -55,12 +55,12 @@ struct PoseTf { double R[3][3], o[3]; };
 struct mor_batch {
   mor_params p; int n_bad, n_good, B, device; uint64_t Nmax;
   hipStream_t st = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // st: copies of read-backs; ev: push/filter timing
-  // Two in-order HIP streams form a software pipeline over frames: `sf` runs the front stage of frame k (ingest …
-  // clusters), `sb` its pair stage, tracking and filterCloud.  Every array the back stage reads is double-buffered by
-  // frame parity and the cluster arrays rotate through three slots, so front(k+1) runs beside back(k); front(k) only
-  // waits for back(k−2), back(k) for front(k).
-  hipStream_t sf = nullptr, sb = nullptr;
-  hipEvent_t ev_front[3] = {}, ev_back[3] = {};
+  // Three in-order HIP streams form a software pipeline over frames: `sf` runs the grid stage of frame k (ingest, ground
+  // split, cell sort), `sc` its cluster stage (cell graph … centroids), `sb` its pair stage, tracking and filterCloud.  Every array the back stage reads is double-buffered by
+  // frame parity and the cluster arrays rotate through three slots, so the three stages of consecutive frames overlap;
+  // grid(k) only waits for back(k−2), cluster(k) for grid(k), back(k) for cluster(k).
+  hipStream_t sf = nullptr, sc = nullptr, sb = nullptr;   // grid stage, cluster stage, pair/filter stage
+  hipEvent_t ev_grid[3] = {}, ev_front[3] = {}, ev_back[3] = {};
   MorDev dtemp[2];                           // descriptor templates for even / odd frames (static part + pointers)
   MorDev d;                                  // descriptor of the latest pushed frame
   MorStreamArgs *d_args_s[2] = {nullptr, nullptr};
@@ -163,7 +163,7 @@ static int configure(mor_batch *b) {
 // waits for everything enqueued on the batch and turns the device-side flags of the last push into an error code
 static int wait_all_checked(mor_batch *b) {
   if (!b->pending) return MOR_OK;
-  HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sb));
+  HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sc)); HIP_TRY(hipStreamSynchronize(b->sb));
   b->pending = false;
   b->timer.collect();
   int rc = MOR_OK;
@@ -190,11 +190,14 @@ void mor_batch_destroy(mor_batch *b) {
   hipSetDevice(b->device);
   if (b->st) hipStreamSynchronize(b->st);
   if (b->sf) hipStreamSynchronize(b->sf);
+  if (b->sc) hipStreamSynchronize(b->sc);
   if (b->sb) hipStreamSynchronize(b->sb);
   for (auto &ev : b->args_ev) if (ev) hipEventDestroy(ev);
+  for (auto &ev : b->ev_grid) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->ev_front) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->ev_back) if (ev) hipEventDestroy(ev);
   if (b->sf) hipStreamDestroy(b->sf);
+  if (b->sc) hipStreamDestroy(b->sc);
   if (b->sb) hipStreamDestroy(b->sb);
   for (void *p : b->dev_allocs) hipFree(p);
   for (void *p : b->host_allocs) hipHostFree(p);
@@ -219,7 +222,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   for (auto &ev : b->args_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   if (hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
   for (auto &e : b->ev) if (hipEventCreate(&e) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
-  if (hipStreamCreateWithFlags(&b->sf, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sb, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
+  if (hipStreamCreateWithFlags(&b->sf, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sc, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sb, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
+  for (auto &ev : b->ev_grid) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_front) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_back) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   MorDev &d = b->d; const size_t B = d.B, N = d.Nmax, K = d.Kcap, T = d.tiles_max;
@@ -246,8 +250,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     if (ok) ok = hipMemcpy(dtab, tab.data(), tab.size(), hipMemcpyHostToDevice) == hipSuccess;
     d.row_order = dtab; d.n_rows = side * side;
   }
-  for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, d.rkeys[i], B * N) && dalloc(b, d.rvals[i], B * N);
-  ok = ok && dalloc(b, d.rhist, B * T * 256) && dalloc(b, d.cl_idx, B * N);
+  for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, d.rkeys[i], B * N) && dalloc(b, d.rvals[i], B * N) && dalloc(b, d.rkeys2[i], B * N) && dalloc(b, d.rvals2[i], B * N);
+  ok = ok && dalloc(b, d.rhist, B * T * 256) && dalloc(b, d.rhist2, B * T * 256) && dalloc(b, d.cl_idx, B * N);
   d.skey = d.rkeys[d.cell_passes & 1]; d.sidx = d.rvals[d.cell_passes & 1];
   for (int i = 0; i < 3; ++i)
     ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.chunk_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K);
@@ -280,6 +284,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = dalloc(b, dargs1, B) && dalloc(b, o.info, B) && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, B * N) && dalloc(b, o.gp_idx, B * N);
     ok = ok && dalloc(b, o.sorted, B * N) && dalloc(b, o.ckey, B * N) && dalloc(b, o.cstart, B * (N + 1)) && dalloc(b, o.row_start, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, o.cmeta, 2 * B * N);
     ok = ok && dalloc(b, o.pcid, B * N) && dalloc(b, o.ccid, B * N) && dalloc(b, o.cl_idx, B * N) && dalloc(b, o.det, B * K) && dalloc(b, o.zorg, B);
+    ok = ok && dalloc(b, o.cell_of, B * N) && dalloc(b, o.cmin, B * N) && dalloc(b, o.parent, B * N) && dalloc(b, o.csize, B * N) && dalloc(b, o.compmin, B * N) && dalloc(b, o.cid_of_root, B * N);
     b->d_args_s[1] = dargs1; o.args = dargs1;
     if (ok) ok = hipMemcpy(o.zorg, d.zorg, B * sizeof(float), hipMemcpyDeviceToDevice) == hipSuccess;
     if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
@@ -311,7 +316,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     if (!c.on_device) max_host_bytes = std::max<size_t>(max_host_bytes, (size_t)c.n_points * c.point_step);
   }
   if (max_host_bytes > b->stage_stride) {   // (re)allocate the staging area for host-resident blobs
-    if (b->d_stage) { HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sb)); HIP_TRY(hipFree(b->d_stage)); b->d_stage = nullptr; }
+    if (b->d_stage) { HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sc)); HIP_TRY(hipStreamSynchronize(b->sb)); HIP_TRY(hipFree(b->d_stage)); b->d_stage = nullptr; }
     b->stage_stride = (max_host_bytes + 255) & ~(size_t)255;
     HIP_TRY(hipMalloc((void **)&b->d_stage, b->stage_stride * B));
   }
@@ -336,7 +341,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     for (int s = 0; s < B; ++s) mx = std::max(mx, std::max(d.h_info[s].M, d.h_info[s].C));
     d.tiles_m = (k > 0 && mx > 0) ? std::min<int>(d.tiles, (int)(((uint64_t)mx * 5 / 4 + MOR_TILE - 1) / MOR_TILE) + 1) : d.tiles;
   }
-  // ---- front stage on sf: must not overwrite what back(k−2) still reads (same parity buffers, same cluster slot)
+  // ---- grid stage on sf: must not overwrite what back(k−2) still reads (same parity buffers, same cluster slot)
   if (k >= 2) HIP_TRY(hipStreamWaitEvent(b->sf, b->ev_back[(k - 2) % 3], 0));
   for (int s = 0; s < B; ++s) {   // host-resident blobs are staged through device memory
     const mor_cloud_view &c = clouds[s];
@@ -345,8 +350,13 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   HIP_TRY(hipMemcpyAsync(b->d_args_s[k & 1], b->h_args, sizeof(MorStreamArgs) * B, hipMemcpyHostToDevice, b->sf));
   HIP_TRY(hipEventRecord(b->args_ev[slot], b->sf));
   HIP_TRY(hipEventRecord(b->ev[0], b->sf));
-  mor_launch_front(d, b->sf, &b->timer);
-  HIP_TRY(hipEventRecord(b->ev_front[k % 3], b->sf));
+  mor_launch_grid(d, b->sf, &b->timer);
+  HIP_TRY(hipEventRecord(b->ev_grid[k % 3], b->sf));
+  // ---- cluster stage on sc (in order behind cluster(k−1)), beside the grid stage of the next frame
+  hipStream_t sc = getenv("MOR_EXP_GENERAL_CC") ? b->sf : b->sc;   // the experimental multi-workgroup cell-graph path shares scratch with the grid stage
+  HIP_TRY(hipStreamWaitEvent(sc, b->ev_grid[k % 3], 0));
+  mor_launch_cluster(d, sc, &b->timer);
+  HIP_TRY(hipEventRecord(b->ev_front[k % 3], sc));
   // ---- pair stage + tracking on sb (in order behind back(k−1)), once the front stage of this frame is done
   HIP_TRY(hipStreamWaitEvent(b->sb, b->ev_front[k % 3], 0));
   mor_launch_back(d, b->sb, &b->timer);

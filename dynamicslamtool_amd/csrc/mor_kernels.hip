@@ -888,13 +888,13 @@ __global__ __launch_bounds__(MOR_BT) void k_rhist(MorDev d, MorRadix j) {
       if (valid) atomicAdd(&h[(key >> j.shift) & 255], 1);
     }
     __syncthreads();
-    d.rhist[((size_t)s * d.tiles_max + t) * 256 + threadIdx.x] = h[threadIdx.x];
+    j.hist[((size_t)s * d.tiles_max + t) * 256 + threadIdx.x] = h[threadIdx.x];
   }
 }
 // one workgroup per stream, one thread per digit: offsets[tile][digit] = Σ smaller digits + Σ earlier tiles
 __global__ __launch_bounds__(MOR_BT) void k_rscan(MorDev d, MorRadix j) {
   int s = blockIdx.x + d.s0; __shared__ int sh[8];
-  int *h = d.rhist + (size_t)s * d.tiles_max * 256 + threadIdx.x;
+  int *h = j.hist + (size_t)s * d.tiles_max * 256 + threadIdx.x;
   const int nt = (radix_count(d, j, s) + MOR_TILE - 1) / MOR_TILE;
   int run = 0, t = 0;
   for (; t + 4 <= nt; t += 4) {   // four independent loads per step
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, MorRadix j) {
     }
     __syncthreads();
     {  // exclusive prefix over the 4 waves per digit + global offset of (tile, digit)
-      int dg = threadIdx.x, run = d.rhist[((size_t)s * d.tiles_max + t) * 256 + dg];
+      int dg = threadIdx.x, run = j.hist[((size_t)s * d.tiles_max + t) * 256 + dg];
 #pragma unroll
       for (int w = 0; w < 4; ++w) { int v = wcnt[w][dg]; wcnt[w][dg] = run; run += v; }
     }
@@ -1845,7 +1845,7 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
   MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
   MOR_LAUNCH(MK_SCATTER, k_scatter, gT, d);
   for (int pass = 0; pass < d.cell_passes; ++pass) {   // points sorted by cell key; result in (skey, sidx) = buffers [cell_passes & 1]
-    MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, 0};
+    MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0};
     MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
     MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
     MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
@@ -1856,7 +1856,7 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
   MOR_LAUNCH(MK_ROWTABLE, k_rowtable, dim3((d.g.nrows + MOR_BT) / MOR_BT > 32 ? 32 : (d.g.nrows + MOR_BT) / MOR_BT, d.B), d);
 }
 
-void mor_launch_front(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B), gW(getenv("MOR_GW") ? atoi(getenv("MOR_GW")) : 64, d.B);
   if (d.gmode == 0) {
     mor_launch_split_and_grid(d, st, tm);
@@ -1875,6 +1875,10 @@ void mor_launch_front(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     MorDev db = d; db.gmode = 2;
     mor_launch_split_and_grid(db, st, tm);
   }
+}
+
+void mor_launch_cluster(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+  const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B), gW(getenv("MOR_GW") ? atoi(getenv("MOR_GW")) : 64, d.B);
   if (!getenv("MOR_EXP_GENERAL_CC")) {
     mor_timer_begin(tm, MK_CELLGRAPH, st);
     hipLaunchKernelGGL(k_cellgraph, gB, dim3(CG_T), 0, st, d);
@@ -1896,8 +1900,8 @@ void mor_launch_front(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     const bool last = pass == d.radix_passes - 1;
     // every pass also writes cl_idx: a stream with K ≤ 256^p has its final order after pass p−1 and later passes
     // return at once for it (K ≤ 256 is the usual case: one effective pass)
-    MorRadix j = {pass == 0 ? d.pcid : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], last ? nullptr : d.rkeys[(pass + 1) & 1], last ? d.cl_idx : d.rvals[(pass + 1) & 1],
-                  8 * pass, pass == 0 ? 0 : 1, pass == 0 ? 1 : 0, last ? nullptr : d.cl_idx, pass == 0 ? 0 : (1 << (8 * pass))};
+    MorRadix j = {pass == 0 ? d.pcid : d.rkeys2[pass & 1], pass == 0 ? nullptr : d.rvals2[pass & 1], last ? nullptr : d.rkeys2[(pass + 1) & 1], last ? d.cl_idx : d.rvals2[(pass + 1) & 1],
+                  8 * pass, pass == 0 ? 0 : 1, pass == 0 ? 1 : 0, last ? nullptr : d.cl_idx, d.rhist2, pass == 0 ? 0 : (1 << (8 * pass))};
     MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
     MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
     MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
