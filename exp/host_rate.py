@@ -1,0 +1,21 @@
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dynamicslamtool_amd import engine, kitti_params, synth
+B, npts, nf = 64, 120000, 12
+p = kitti_params(1)
+seeds = [2000 + s for s in range(B)]
+buf = engine.DeviceBuffer(nf * B * npts * 16); poses = np.empty((nf, B, 7))
+for f in range(nf):
+    xs, ps = synth.batch(seeds, [f] * B); buf.upload(xs, f * B * npts * 16); poses[f] = ps
+b = engine.MorBatch(p, B, npts)
+views = [b.make_views([(buf.ptr + (f * B + s) * npts * 16, npts) for s in range(B)]) for f in range(nf)]
+def fr(i):
+    k = i % (2 * (nf - 1)); return k if k < nf else 2 * (nf - 1) - k
+for i in range(4): b.push_views(views[fr(i)], poses[fr(i)]); b.filter_device()
+b.set_async(True)
+for n in (10, 40):
+    t0 = time.perf_counter()
+    for i in range(4, 4 + n): b.push_views(views[fr(i)], poses[fr(i)]); b.filter_async()
+    t1 = time.perf_counter(); b.wait(); t2 = time.perf_counter()
+    print("steps", n, "host enqueue per step %.1f us" % (1e6 * (t1 - t0) / n), "total per step %.1f us" % (1e6 * (t2 - t0) / n))

@@ -274,3 +274,47 @@ def test_voxel_covariance_ground_hdl64():
     o = Oracle(p)
     o.push(*frames[0])
     assert o.counts().n_ground > 20000   # the ground plane is the dominant bin
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_async_pipeline_matches_oracle(method):
+    """Asynchronous mode: pushes and filters are only enqueued (three-stage frame pipeline on three HIP streams, state
+    double/triple-buffered); the host waits every few frames and the state it then reads must equal the oracle's."""
+    p = kitti_params(method)
+    B, nf = 8, 10
+    streams = [[synth.frame(2100 + s, "hdl64", f) for f in range(nf)] for s in range(B)]
+    b = MorBatch(p, B, 120000)
+    b.set_async(True)
+    oracles = [Oracle(p) for _ in range(B)]
+    bufs = []
+    for f in range(nf):
+        db = DeviceBuffer(B * 120000 * 16)
+        for s in range(B):
+            db.upload(streams[s][f][0], s * 120000 * 16)
+        bufs.append(db)
+    outs_o = [None] * B
+    for f in range(nf):
+        views = b.make_views([(bufs[f].ptr + s * 120000 * 16, 120000) for s in range(B)])
+        b.push_views(views, np.stack([streams[s][f][1] for s in range(B)]))
+        b.filter_async()
+        for s in range(B):
+            oracles[s].push(*streams[s][f])
+            outs_o[s] = oracles[s].filter()
+        if f % 3 == 2 or f == nf - 1:
+            b.wait()
+            for s in range(B):
+                # after the filter: clusters/correspondences of this frame and the tracker state after filterCloud
+                co, cb = oracles[s].counts(), b.counts(s)
+                assert (co.n_trim, co.n_cloud, co.n_ground, co.n_clusters, co.n_clustered, co.n_corr, co.n_tracks) == \
+                       (cb.n_trim, cb.n_cloud, cb.n_ground, cb.n_clusters, cb.n_clustered, cb.n_corr, cb.n_tracks), (f, s)
+                assert np.array_equal(oracles[s].labels(), b.labels(s)), (f, s)
+                assert np.array_equal(oracles[s].detection(), b.detection(s)), (f, s)
+                assert np.array_equal(oracles[s].correspondences()[3], b.correspondences(s)[3]), (f, s)
+                compare_tracks(oracles[s], b, s, "async frame %d stream %d" % (f, s))
+                ptr, n = b.output_device(s)
+                got = np.empty((n, 4), np.float32)
+                from dynamicslamtool_amd.engine import lib, _check
+                _check(lib().mor_device_download(0, got.ctypes.data, ptr, n * 16))
+                compare_output(outs_o[s], got, "async frame %d stream %d" % (f, s))
+    b.set_async(False)
+    b.close()
