@@ -18,6 +18,11 @@
 #define MOR_MAX_GROUPS 8
 #define MOR_ARGS_RING 8
 
+// The frame pipeline needs its three HIP streams on three different hardware queues; the ROCm runtime multiplexes
+// streams onto GPU_MAX_HW_QUEUES (default 4) queues, and with the null stream and a copy stream two stages would share
+// one.  Ask for more queues before the runtime initialises (no effect if the process has already initialised HIP).
+namespace { struct MorEnvInit { MorEnvInit() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_mor_env_init; }
+
 static thread_local std::string g_last_error;
 static int set_error(int code, const char *fmt, ...) {
   char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);

@@ -23,8 +23,10 @@ def frame_of(step):
 def run(e, n0, n):
     b, views, poses, _ = engs[e]
     for i in range(n0, n0 + n):
-        f = frame_of(i); b.push_views(views[f], poses[f]); b.filter_device()
+        f = frame_of(i); b.push_views(views[f], poses[f]); b.filter_async()
+    b.wait()
 for e in range(E): run(e, 0, warm)
+for e in range(E): engs[e][0].set_async(True)
 bar = threading.Barrier(E + 1)
 def worker(e):
     bar.wait(); run(e, warm, steps); bar.wait()
