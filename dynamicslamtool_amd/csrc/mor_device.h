@@ -79,8 +79,7 @@ struct MorDev {
   int tiles;                 // ceil(max n_points of this batch / MOR_TILE)
   int tiles_m;               // workgroups per stream for kernels over the non-ground cloud / clusters: an estimate from the
                              // previous frame; those kernels grid-stride over the tiles a stream really has, so any value ≥ 1 is correct
-  int cur, prev, has_prev;   // cluster-array slots of cb and ca (three slots rotate so frame k+1's front stage can run beside
-                             // frame k's pair stage); whether ca exists (:534)
+  int cur, prev, has_prev;   // cluster-array slots of cb and ca (four slots rotate: up to three frames are in flight in the stage pipeline); whether ca exists (:534)
   int run_tracker;           // filter: advance the tracking loop (first filterCloud of this frame)
   // ---- device arrays (per-stream stride noted)
   const MorStreamArgs *args; // [B]
@@ -121,13 +120,14 @@ struct MorDev {
   int *rkeys2[2], *rvals2[2], *rhist2; // the same for the cluster partition (cluster stage runs beside the next frame's grid stage)
   int *cl_idx;               // [B][Nmax]  cluster_indices flattened (:218)
   // frame-slotted (cb / ca)
-  float4 *cl_pts[3];         // [B][Nmax]  clusters[k] points, (cluster, index) order (:229); ca's are transformed in place (:550)
-  int *cl_cid[3];            // [B][Nmax]  cluster id per cl_pts entry
-  int *cl_off[3];            // [B][Kcap+1]
-  int *chunk_off[3];         // [B][Kcap+1]  first reduction chunk of each cluster
+  float4 *cl_pts[4];         // [B][Nmax]  clusters[k] points, (cluster, index) order (:229); ca's are transformed in place (:550)
+  int *cl_cid[4];            // [B][Nmax]  cluster id per cl_pts entry
+  int *cl_off[4];            // [B][Kcap+1]
+  int *chunk_off[4];         // [B][Kcap+1]  first reduction chunk of each cluster
   Red6 *part, *part_back; int Wcap; // [B][Wcap]  per-chunk partials: scratch of k_stats (front stage) / k_xform_prev (pair stage)
-  float4 *centroid[3];       // [B][Kcap]  centroid_collection (:243)
-  float4 *amin[3], *amax[3]; // [B][Kcap]  cluster AABBs (getMinMax3D, :272-274)
+  float4 *centroid[4];       // [B][Kcap]  centroid_collection (:243)
+  float4 *amin[4], *amax[4]; // [B][Kcap]  cluster AABBs (getMinMax3D, :272-274)
+  float4 *xcent, *xamin, *xamax; // [B][Kcap]  ca's centroids and AABBs after the transform into cb's frame (:540-550)
   // pair stage
   int *nn_fwd, *nn_bwd;      // [B][Kcap]
   float *nn_fwd_d;           // [B][Kcap]
@@ -172,8 +172,9 @@ extern const char *const mor_kernel_names[MK_COUNT];
 
 struct MorLaunchTimer;   // engine-owned; records event pairs when enabled
 void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);     // ingest, ground split, cell-sorted cloud, cell table
-void mor_launch_cluster(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);  // cell graph, labels, cluster_indices, centroids
-void mor_launch_back(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);    // pair stage with the previous frame, scores, tracking
+void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);  // connected components over cells, cluster order
+void mor_launch_mid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);   // labels, cluster_indices, centroids; transform of ca, correspondences, thread tiers of the scores
+void mor_launch_tail(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);  // wave tier of the scores, thresholds, host summary, tracking
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);
 void mor_timer_begin(MorLaunchTimer *tm, int kernel_id, hipStream_t st);
 void mor_timer_end(MorLaunchTimer *tm, int kernel_id, hipStream_t st);

@@ -64,11 +64,11 @@ struct mor_batch {
   // split, cell sort), `sc` its cluster stage (cell graph … centroids), `sb` its pair stage, tracking and filterCloud.  Every array the back stage reads is double-buffered by
   // frame parity and the cluster arrays rotate through three slots, so the three stages of consecutive frames overlap;
   // grid(k) only waits for back(k−2), cluster(k) for grid(k), back(k) for cluster(k).
-  hipStream_t sf = nullptr, sc = nullptr, sb = nullptr;   // grid stage, cluster stage, pair/filter stage
-  hipEvent_t ev_grid[3] = {}, ev_front[3] = {}, ev_back[3] = {};
-  MorDev dtemp[2];                           // descriptor templates for even / odd frames (static part + pointers)
+  hipStream_t sf = nullptr, sc = nullptr, sm = nullptr, sb = nullptr;   // grid, cell graph, mid (clusters + pair stage), tail (scores wave tier, tracking, filterCloud)
+  hipEvent_t ev_grid[4] = {}, ev_cg[4] = {}, ev_front[4] = {}, ev_back[4] = {};
+  MorDev dtemp[3];                           // descriptor templates, frame k uses dtemp[k % 3] (static part + pointers)
   MorDev d;                                  // descriptor of the latest pushed frame
-  MorStreamArgs *d_args_s[2] = {nullptr, nullptr};
+  MorStreamArgs *d_args_s[3] = {nullptr, nullptr, nullptr};
   std::vector<void *> dev_allocs, host_allocs;
   MorStreamArgs *h_args_ring = nullptr, *h_args = nullptr;   // pinned ring of MOR_ARGS_RING slots (async pushes), current slot
   hipEvent_t args_ev[MOR_ARGS_RING] = {};
@@ -168,7 +168,7 @@ static int configure(mor_batch *b) {
 // waits for everything enqueued on the batch and turns the device-side flags of the last push into an error code
 static int wait_all_checked(mor_batch *b) {
   if (!b->pending) return MOR_OK;
-  HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sc)); HIP_TRY(hipStreamSynchronize(b->sb));
+  HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sc)); HIP_TRY(hipStreamSynchronize(b->sm)); HIP_TRY(hipStreamSynchronize(b->sb));
   b->pending = false;
   b->timer.collect();
   int rc = MOR_OK;
@@ -196,13 +196,16 @@ void mor_batch_destroy(mor_batch *b) {
   if (b->st) hipStreamSynchronize(b->st);
   if (b->sf) hipStreamSynchronize(b->sf);
   if (b->sc) hipStreamSynchronize(b->sc);
+  if (b->sm) hipStreamSynchronize(b->sm);
   if (b->sb) hipStreamSynchronize(b->sb);
   for (auto &ev : b->args_ev) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->ev_grid) if (ev) hipEventDestroy(ev);
+  for (auto &ev : b->ev_cg) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->ev_front) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->ev_back) if (ev) hipEventDestroy(ev);
   if (b->sf) hipStreamDestroy(b->sf);
   if (b->sc) hipStreamDestroy(b->sc);
+  if (b->sm) hipStreamDestroy(b->sm);
   if (b->sb) hipStreamDestroy(b->sb);
   for (void *p : b->dev_allocs) hipFree(p);
   for (void *p : b->host_allocs) hipHostFree(p);
@@ -227,8 +230,9 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   for (auto &ev : b->args_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   if (hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
   for (auto &e : b->ev) if (hipEventCreate(&e) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
-  if (hipStreamCreateWithFlags(&b->sf, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sc, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sb, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
+  if (hipStreamCreateWithFlags(&b->sf, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sc, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sm, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sb, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
   for (auto &ev : b->ev_grid) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+  for (auto &ev : b->ev_cg) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_front) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_back) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   MorDev &d = b->d; const size_t B = d.B, N = d.Nmax, K = d.Kcap, T = d.tiles_max;
@@ -258,7 +262,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, d.rkeys[i], B * N) && dalloc(b, d.rvals[i], B * N) && dalloc(b, d.rkeys2[i], B * N) && dalloc(b, d.rvals2[i], B * N);
   ok = ok && dalloc(b, d.rhist, B * T * 256) && dalloc(b, d.rhist2, B * T * 256) && dalloc(b, d.cl_idx, B * N);
   d.skey = d.rkeys[d.cell_passes & 1]; d.sidx = d.rvals[d.cell_passes & 1];
-  for (int i = 0; i < 3; ++i)
+  ok = ok && dalloc(b, d.xcent, B * K) && dalloc(b, d.xamin, B * K) && dalloc(b, d.xamax, B * K);
+  for (int i = 0; i < 4; ++i)
     ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.chunk_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K);
   d.Wcap = (int)(N / MOR_CHUNK + K + 2);
   ok = ok && dalloc(b, d.part, B * (size_t)d.Wcap) && dalloc(b, d.part_back, B * (size_t)d.Wcap);
@@ -282,20 +287,23 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && halloc(b, d.h_info, B) && halloc(b, d.h_centroid, B * K) && halloc(b, d.h_cl_off, B * (K + 1)) && halloc(b, d.h_det, B * K);
   ok = ok && halloc(b, d.h_pair_q, B * K) && halloc(b, d.h_pair_m, B * K) && halloc(b, d.h_pair_d, B * K) && halloc(b, d.h_score, B * K) && halloc(b, d.h_nout, B);
   if (!ok) return fail(set_error(MOR_ERR_HIP, "device/host allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
-  // second copy of everything the back stage (pair stage, tracking, filterCloud) reads of a frame
-  b->dtemp[0] = d; b->dtemp[1] = d;
-  {
-    MorDev &o = b->dtemp[1]; MorStreamArgs *dargs1 = nullptr;
+  // two more copies of every per-frame array that crosses a stage boundary (frame k uses copy k % 3)
+  b->dtemp[0] = d;
+  for (int c = 1; c < 3; ++c) {
+    b->dtemp[c] = d;
+    MorDev &o = b->dtemp[c]; MorStreamArgs *dargs1 = nullptr;
     ok = dalloc(b, dargs1, B) && dalloc(b, o.info, B) && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, B * N) && dalloc(b, o.gp_idx, B * N);
     ok = ok && dalloc(b, o.sorted, B * N) && dalloc(b, o.ckey, B * N) && dalloc(b, o.cstart, B * (N + 1)) && dalloc(b, o.row_start, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, o.cmeta, 2 * B * N);
     ok = ok && dalloc(b, o.pcid, B * N) && dalloc(b, o.ccid, B * N) && dalloc(b, o.cl_idx, B * N) && dalloc(b, o.det, B * K) && dalloc(b, o.zorg, B);
     ok = ok && dalloc(b, o.cell_of, B * N) && dalloc(b, o.cmin, B * N) && dalloc(b, o.parent, B * N) && dalloc(b, o.csize, B * N) && dalloc(b, o.compmin, B * N) && dalloc(b, o.cid_of_root, B * N);
-    b->d_args_s[1] = dargs1; o.args = dargs1;
+    ok = ok && dalloc(b, o.pair_q, B * K) && dalloc(b, o.pair_m, B * K) && dalloc(b, o.pair_d, B * K) && dalloc(b, o.pair_cnt, B * K) && dalloc(b, o.pair_of_prev, B * K) && dalloc(b, o.pair_of_cur, B * K);
+    ok = ok && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B) && dalloc(b, o.wl_n, B);
+    b->d_args_s[c] = dargs1; o.args = dargs1;
     if (ok) ok = hipMemcpy(o.zorg, d.zorg, B * sizeof(float), hipMemcpyDeviceToDevice) == hipSuccess;
     if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
   }
-  for (int i = 0; i < 2; ++i) if (hipMemset(b->dtemp[i].info, 0, B * sizeof(MorFrameInfo)) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "memset failed"));
-  b->dtemp[0].info_prev = b->dtemp[1].info; b->dtemp[1].info_prev = b->dtemp[0].info;
+  for (int i = 0; i < 3; ++i) if (hipMemset(b->dtemp[i].info, 0, B * sizeof(MorFrameInfo)) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "memset failed"));
+  for (int c = 0; c < 3; ++c) b->dtemp[c].info_prev = b->dtemp[(c + 2) % 3].info;
   b->d = b->dtemp[0];
   b->prev_pose.resize(B);
   if (err) *err = MOR_OK;
@@ -308,7 +316,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   if (!b || !clouds || !poses) return set_error(MOR_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(b->device));
   const uint64_t k = b->frame;
-  MorDev d = b->dtemp[k & 1]; const int B = d.B;
+  MorDev d = b->dtemp[k % 3]; const int B = d.B;
   uint64_t maxn = 0; size_t max_host_bytes = 0;
   for (int s = 0; s < B; ++s) {
     const mor_cloud_view &c = clouds[s];
@@ -321,7 +329,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     if (!c.on_device) max_host_bytes = std::max<size_t>(max_host_bytes, (size_t)c.n_points * c.point_step);
   }
   if (max_host_bytes > b->stage_stride) {   // (re)allocate the staging area for host-resident blobs
-    if (b->d_stage) { HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sc)); HIP_TRY(hipStreamSynchronize(b->sb)); HIP_TRY(hipFree(b->d_stage)); b->d_stage = nullptr; }
+    if (b->d_stage) { HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sc)); HIP_TRY(hipStreamSynchronize(b->sm)); HIP_TRY(hipStreamSynchronize(b->sb)); HIP_TRY(hipFree(b->d_stage)); b->d_stage = nullptr; }
     b->stage_stride = (max_host_bytes + 255) & ~(size_t)255;
     HIP_TRY(hipMalloc((void **)&b->d_stage, b->stage_stride * B));
   }
@@ -339,34 +347,38 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     b->prev_pose[s] = cur[s];
   }
   d.tiles = std::max<int>(1, (int)((maxn + MOR_TILE - 1) / MOR_TILE));
-  d.cur = (int)(k % 3); d.prev = (int)((k + 2) % 3); d.has_prev = k > 0; d.out_ptrs = nullptr; d.run_tracker = 0;
-  d.info_prev = b->dtemp[(k + 1) & 1].info;
+  d.cur = (int)(k % 4); d.prev = (int)((k + 3) % 4); d.has_prev = k > 0; d.out_ptrs = nullptr; d.run_tracker = 0;
   {  // workgroups for the cloud-sized kernels: 1.25 × the largest cloud / cluster set the device last reported
     uint32_t mx = 0;
     for (int s = 0; s < B; ++s) mx = std::max(mx, std::max(d.h_info[s].M, d.h_info[s].C));
     d.tiles_m = (k > 0 && mx > 0) ? std::min<int>(d.tiles, (int)(((uint64_t)mx * 5 / 4 + MOR_TILE - 1) / MOR_TILE) + 1) : d.tiles;
   }
-  // ---- grid stage on sf: must not overwrite what back(k−2) still reads (same parity buffers, same cluster slot)
-  if (k >= 2) HIP_TRY(hipStreamWaitEvent(b->sf, b->ev_back[(k - 2) % 3], 0));
+  // ---- grid stage on sf: must not overwrite what frame k−3 still uses (same buffer copy; its cluster slot doubles as
+  //      the `ca` slot of frame k−3... and the `cb` slot of frame k−4)
+  if (k >= 3) HIP_TRY(hipStreamWaitEvent(b->sf, b->ev_back[(k - 3) % 4], 0));
   for (int s = 0; s < B; ++s) {   // host-resident blobs are staged through device memory
     const mor_cloud_view &c = clouds[s];
     if (!c.on_device && c.n_points) HIP_TRY(hipMemcpyAsync((void *)b->h_args[s].data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, b->sf));
   }
-  HIP_TRY(hipMemcpyAsync(b->d_args_s[k & 1], b->h_args, sizeof(MorStreamArgs) * B, hipMemcpyHostToDevice, b->sf));
+  HIP_TRY(hipMemcpyAsync(b->d_args_s[k % 3], b->h_args, sizeof(MorStreamArgs) * B, hipMemcpyHostToDevice, b->sf));
   HIP_TRY(hipEventRecord(b->args_ev[slot], b->sf));
   HIP_TRY(hipEventRecord(b->ev[0], b->sf));
   mor_launch_grid(d, b->sf, &b->timer);
-  HIP_TRY(hipEventRecord(b->ev_grid[k % 3], b->sf));
-  // ---- cluster stage on sc (in order behind cluster(k−1)), beside the grid stage of the next frame
+  HIP_TRY(hipEventRecord(b->ev_grid[k % 4], b->sf));
+  // ---- cell graph on sc (in order behind the cell graph of frame k−1)
   hipStream_t sc = getenv("MOR_EXP_GENERAL_CC") ? b->sf : b->sc;   // the experimental multi-workgroup cell-graph path shares scratch with the grid stage
-  HIP_TRY(hipStreamWaitEvent(sc, b->ev_grid[k % 3], 0));
-  mor_launch_cluster(d, sc, &b->timer);
-  HIP_TRY(hipEventRecord(b->ev_front[k % 3], sc));
-  // ---- pair stage + tracking on sb (in order behind back(k−1)), once the front stage of this frame is done
-  HIP_TRY(hipStreamWaitEvent(b->sb, b->ev_front[k % 3], 0));
-  mor_launch_back(d, b->sb, &b->timer);
+  HIP_TRY(hipStreamWaitEvent(sc, b->ev_grid[k % 4], 0));
+  mor_launch_cellgraph(d, sc, &b->timer);
+  HIP_TRY(hipEventRecord(b->ev_cg[k % 4], sc));
+  // ---- mid stage on sm: labels … centroids, then the pair stage with frame k−1 up to the thread tiers of the scores
+  HIP_TRY(hipStreamWaitEvent(b->sm, b->ev_cg[k % 4], 0));
+  mor_launch_mid(d, b->sm, &b->timer);
+  HIP_TRY(hipEventRecord(b->ev_front[k % 4], b->sm));
+  // ---- tail stage on sb: wave tier of the scores, thresholds, host summary, tracking (then filterCloud)
+  HIP_TRY(hipStreamWaitEvent(b->sb, b->ev_front[k % 4], 0));
+  mor_launch_tail(d, b->sb, &b->timer);
   HIP_TRY(hipEventRecord(b->ev[1], b->sb));
-  HIP_TRY(hipEventRecord(b->ev_back[k % 3], b->sb));
+  HIP_TRY(hipEventRecord(b->ev_back[k % 4], b->sb));
   HIP_TRY(hipGetLastError());
   b->d = d; b->frame++; b->filtered = false; b->pending = true;
   if (b->async) return MOR_OK;
@@ -393,7 +405,7 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
   HIP_TRY(hipEventRecord(b->ev[2], b->sb));
   mor_launch_filter(d, b->sb, &b->timer);
   HIP_TRY(hipEventRecord(b->ev[3], b->sb));
-  HIP_TRY(hipEventRecord(b->ev_back[k % 3], b->sb));
+  HIP_TRY(hipEventRecord(b->ev_back[k % 4], b->sb));
   HIP_TRY(hipGetLastError());
   b->pending = true;
   const bool need_host = n_out != nullptr || (out && !out_on_device);

@@ -1066,9 +1066,9 @@ __global__ __launch_bounds__(MOR_BT) void k_xform_fin(MorDev d) {
   const float *m = d.args[s].xf;
   float4 c = d.centroid[pv][(size_t)s * d.Kcap + k];
   xform(m, c.x, c.y, c.z);
-  d.centroid[pv][(size_t)s * d.Kcap + k] = c;
-  d.amin[pv][(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
-  d.amax[pv][(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
+  d.xcent[(size_t)s * d.Kcap + k] = c;     // ca's own centroids stay as they are: the tail stage of frame k−1 may still be reading them
+  d.xamin[(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
+  d.xamax[(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
   d.pair_of_prev[(size_t)s * d.Kcap + k] = -1;
 }
 
@@ -1076,10 +1076,11 @@ __global__ __launch_bounds__(MOR_BT) void k_xform_fin(MorDev d) {
 // dir 0: nearest current centroid of every previous centroid; dir 1: the reverse.  Squared fp32
 // distance, ties → lowest index (ascending scan with strict <).
 __global__ __launch_bounds__(MOR_BT) void k_nn_centroid(MorDev d, int dir) {
-  int s = blockIdx.y + d.s0, pv = d.prev;
+  int s = blockIdx.y + d.s0;
   int Ksrc = dir == 0 ? d.info_prev[s].K : d.info[s].K, Kdst = dir == 0 ? d.info[s].K : d.info_prev[s].K;
   if (blockIdx.x * MOR_BT >= Ksrc) return;
-  const float4 *src = d.centroid[dir == 0 ? pv : d.cur] + (size_t)s * d.Kcap, *dst = d.centroid[dir == 0 ? d.cur : pv] + (size_t)s * d.Kcap;
+  const float4 *cp = d.xcent + (size_t)s * d.Kcap, *cc = d.centroid[d.cur] + (size_t)s * d.Kcap;
+  const float4 *src = dir == 0 ? cp : cc, *dst = dir == 0 ? cc : cp;
   int i = blockIdx.x * MOR_BT + threadIdx.x;
   float4 q = i < Ksrc ? src[i] : make_float4(0, 0, 0, 0);
   __shared__ float4 tile[MOR_BT];
@@ -1098,7 +1099,7 @@ __global__ __launch_bounds__(MOR_BT) void k_nn_centroid(MorDev d, int dir) {
 }
 // reciprocal test + volumeConstraint (:264-283), correspondences emitted in source-index order
 __global__ __launch_bounds__(MOR_BT) void k_pairs(MorDev d) {
-  int s = blockIdx.x + d.s0, pv = d.prev, Kp = d.info_prev[s].K, Kc = d.info[s].K;
+  int s = blockIdx.x + d.s0, Kp = d.info_prev[s].K, Kc = d.info[s].K;
   __shared__ int sh[8]; int carry = 0;
   const size_t ko = (size_t)s * d.Kcap;
   for (int b = 0; b < Kp; b += MOR_BT) {
@@ -1106,7 +1107,7 @@ __global__ __launch_bounds__(MOR_BT) void k_pairs(MorDev d) {
     if (i < Kp && Kc > 0) {
       j = d.nn_fwd[ko + i];
       if (j >= 0 && d.nn_bwd[ko + j] == i) {
-        float4 a0 = d.amin[pv][ko + i], a1 = d.amax[pv][ko + i], c0 = d.amin[d.cur][ko + j], c1 = d.amax[d.cur][ko + j];
+        float4 a0 = d.xamin[ko + i], a1 = d.xamax[ko + i], c0 = d.amin[d.cur][ko + j], c1 = d.amax[d.cur][ko + j];
         float vp = (a1.x - a0.x) * (a1.y - a0.y); vp = vp * (a1.z - a0.z);
         float vc = (c1.x - c0.x) * (c1.y - c0.y); vc = vc * (c1.z - c0.z);
         double dp = (double)vp, dc = (double)vc;
@@ -1877,7 +1878,7 @@ void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   }
 }
 
-void mor_launch_cluster(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B), gW(getenv("MOR_GW") ? atoi(getenv("MOR_GW")) : 64, d.B);
   if (!getenv("MOR_EXP_GENERAL_CC")) {
     mor_timer_begin(tm, MK_CELLGRAPH, st);
@@ -1895,6 +1896,10 @@ void mor_launch_cluster(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     MOR_LAUNCH(MK_OFFSETS, k_offsets, gB, d);
     MOR_LAUNCH(MK_CELLCID, k_cellcid, dim3(32, d.B), d);
   }
+}
+
+void mor_launch_mid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+  const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B);
   MOR_LAUNCH(MK_LABEL, k_label, gM, d);
   for (int pass = 0; pass < d.radix_passes; ++pass) {   // clustered points partitioned by cluster id, index order kept ⇒ cluster_indices
     const bool last = pass == d.radix_passes - 1;
@@ -1908,10 +1913,6 @@ void mor_launch_cluster(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   }
   MOR_LAUNCH(MK_STATS, k_stats, dim3(64, d.B), d);
   MOR_LAUNCH(MK_STATS_FIN, k_stats_fin, gKt, d);
-}
-
-void mor_launch_back(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  const dim3 gT(d.B * d.tiles), gB(d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B);
   if (d.has_prev) {
     MOR_LAUNCH(MK_XFORM_PREV, k_xform_prev, dim3(64, d.B), d);
     MOR_LAUNCH(MK_XFORM_FIN, k_xform_fin, gKt, d);
@@ -1919,13 +1920,18 @@ void mor_launch_back(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     MOR_LAUNCH(MK_NN, k_nn_centroid, gKt, d, 1);
     MOR_LAUNCH(MK_PAIRS, k_pairs, gB, d);
     if (d.method == 1) {
-      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * 8), d); MOR_LAUNCH(MK_SCORE_ROWS, k_score_rows, dim3(getenv("MOR_T1B") ? atoi(getenv("MOR_T1B")) : 128, d.B), d); if (!getenv("MOR_EXP_SKIP_T2")) MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(getenv("MOR_T2G") ? atoi(getenv("MOR_T2G")) : 256, d.B), d); }
+      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * 8), d); MOR_LAUNCH(MK_SCORE_ROWS, k_score_rows, dim3(getenv("MOR_T1B") ? atoi(getenv("MOR_T1B")) : 128, d.B), d); }
     } else if (d.method == 2) {
       MOR_LAUNCH(MK_VOX_CLEAR, k_vox_clear, dim3(64, d.B), d);
       MOR_LAUNCH(MK_VOX_INSERT, k_vox_insert, gT, d);
       MOR_LAUNCH(MK_VOX_PROBE, k_vox_probe, gT, d);
     }
   }
+}
+
+void mor_launch_tail(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+  const dim3 gB(d.B);
+  if (d.has_prev && d.method == 1 && d.pde_ub > 0.f && d.pde_ub > d.pde_lb) MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(getenv("MOR_T2G") ? atoi(getenv("MOR_T2G")) : 256, d.B), d);
   MOR_LAUNCH(MK_DECIDE, k_decide, gB, d);
   mor_timer_begin(tm, MK_TRACK_PUSH, st);
   hipLaunchKernelGGL(k_track_push, gB, dim3(64), 0, st, d);
