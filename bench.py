@@ -33,8 +33,8 @@ HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measure
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="hdl64_b64", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--method", type=int, default=1, choices=[1, 2])

@@ -46,7 +46,7 @@ struct MorStreamArgs {       // per stream, per push (host → device, one small
 struct MorFrameInfo {        // per stream, produced on device
   uint32_t N, T, M, G, K, C, n_pairs, flags;   // flags bit0: cluster capacity exceeded, bit1: voxel key overflow
   uint32_t Kprev, Cprev, n_keep, n_occ;   // n_occ: occupied grid cells
-  uint32_t n_defer, pad0, pad1, pad2;     // n_defer: method-1 queries handed to the wave tier
+  uint32_t n_defer, pad0, hshift, pad2;   // n_defer: method-1 queries handed to the wave tier; hshift: 32 − log2(size of the stream's cell hash table)
 };
 
 // Temporal logic (T1 + the tracking loop of F1) as device state, one instance per stream.  O(clusters) sequential work
@@ -102,6 +102,8 @@ struct MorDev {
   int *ckey;                 // [B][Nmax]  distinct cell keys, ascending (n_occ of them)
   int *cstart;               // [B][Nmax+1]  first sorted position of each occupied cell
   int *row_start;            // [B][nrows+1]  first occupied cell of each (y,z) row
+  unsigned long long *chash; // [B][Hcell]  open-addressing hash set of the occupied cells: (key+1) << 32 | compact id, 0 = empty (method 1 only)
+  int Hcell, use_hash;       // table capacity per stream (power of two ≥ 4·Nmax); whether this pass builds it
   int *cmin;                 // [B][Nmax]  smallest cloud index in the cell
   float4 *cmeta;             // [B][2·Nmax]  per occupied cell: low corner of its point box (.w = cluster id bits), high corner
   float4 *sorted;            // [B][Nmax]  (x,y,z, bits(cloud index)) in cell order; .w becomes the cluster id after labelling
@@ -135,8 +137,8 @@ struct MorDev {
   float *pair_d;             // [B][Kcap]
   int *pair_cnt;             // [B][Kcap]
   int *pair_of_prev, *pair_of_cur; // [B][Kcap]
-  int *wl, *wl_n; float *wl_best; // [B][Nmax], [B]  method-1 worklist after tier 1 (query ids, best d² so far)
-  int *wl2, *wl2_n;          // [B][Nmax], [B]  method-1 worklist of the wave tier
+  int4 *wl; int *wl_n, *wlb_n; // [B][Nmax], [B], [B]  method-1 worklists after tier 1 (query, pair, matched cluster, –): E2-known queries from the front, block queries from the back
+  int4 *wl2; int *wl2_n;          // [B][Nmax], [B]  method-1 worklist of the wave tier
   unsigned long long *vox;   // [B][Hcap]
   unsigned char *det;        // [B][Kcap]  detection_results of cb
   // filter stage
@@ -163,9 +165,9 @@ struct MorDev {
 
 // kernel ids for optional per-kernel event timing
 enum MorKernelId {
-  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_ROWTABLE, MK_CELLGRAPH, MK_CELLBOX, MK_HOOK_NEAR, MK_HOOK_SHELL, MK_FLATTEN, MK_CELLCID,
+  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_HASH_CLEAR, MK_ROWTABLE, MK_CELLBOXES, MK_CELLGRAPH, MK_CELLBOX, MK_HOOK_NEAR, MK_HOOK_SHELL, MK_FLATTEN, MK_CELLCID,
   MK_SELECT_COUNT, MK_SELECT_SCAN, MK_SELECT_SCATTER, MK_RANK, MK_OFFSETS, MK_LABEL, MK_RHIST, MK_RSCAN, MK_RSCATTER,
-  MK_STATS, MK_STATS_FIN, MK_XFORM_PREV, MK_XFORM_FIN, MK_NN, MK_PAIRS, MK_SCORE_FAST, MK_SCORE_ROWS, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
+  MK_STATS, MK_STATS_FIN, MK_XFORM_PREV, MK_XFORM_FIN, MK_NN, MK_PAIRS, MK_SCORE_FAST, MK_SCORE_NEAR, MK_SCORE_BLOCK, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
   MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_G2_CENTROID, MK_G2_COV, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_COUNT
 };
 extern const char *const mor_kernel_names[MK_COUNT];

@@ -18,9 +18,13 @@
 #define MOR_MAX_GROUPS 8
 #define MOR_ARGS_RING 8
 
-// The frame pipeline needs its three HIP streams on three different hardware queues; the ROCm runtime multiplexes
-// streams onto GPU_MAX_HW_QUEUES (default 4) queues, and with the null stream and a copy stream two stages would share
-// one.  Ask for more queues before the runtime initialises (no effect if the process has already initialised HIP).
+// The frame pipeline needs its four stage streams on four different hardware queues; the ROCm runtime multiplexes
+// streams onto GPU_MAX_HW_QUEUES (default 4) queues in creation order, so with the batch's main stream two stages would
+// share one.  Ask for more queues before the runtime initialises (no effect if the process has already initialised HIP).
+// Measured on MI355X: hardware queue i is served by compute pipe i % 4 and queues of one pipe do not overlap, so four
+// is also the useful maximum of concurrently busy streams — a fifth stage stream (tried: alternating the cell-graph
+// kernel of even / odd frames) lands on a busy pipe and halves the throughput.  Stream creation order below is
+// st, sf, sc, sm, sb ⇒ queues 0…4 ⇒ pipes 0,1,2,3,0 with `st` idle during pushes.
 namespace { struct MorEnvInit { MorEnvInit() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_mor_env_init; }
 
 static thread_local std::string g_last_error;
@@ -157,6 +161,8 @@ static int configure(mor_batch *b) {
     double lf = (double)p.gp_leaf; d.leaf_r2 = (float)(lf * lf);   // radiusSearch(…, gp_leaf): (float)(radius·radius)
   }
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
+  d.use_hash = d.method == 1;
+  { size_t hc = 1024; while (hc < 4 * (size_t)d.Nmax) hc <<= 1; d.Hcell = (int)hc; }
   d.t1_budget = getenv("MOR_T1_BUDGET") ? atoi(getenv("MOR_T1_BUDGET")) : 256;
   if (d.score_R > 60) return set_error(MOR_ERR_INVALID, "pde_ub %g needs a %d-cell search radius (> 60)", (double)p.pde_ub, d.score_R);
   int bits = 1; while ((1 << bits) < d.Kcap) ++bits;
@@ -262,6 +268,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, d.rkeys[i], B * N) && dalloc(b, d.rvals[i], B * N) && dalloc(b, d.rkeys2[i], B * N) && dalloc(b, d.rvals2[i], B * N);
   ok = ok && dalloc(b, d.rhist, B * T * 256) && dalloc(b, d.rhist2, B * T * 256) && dalloc(b, d.cl_idx, B * N);
   d.skey = d.rkeys[d.cell_passes & 1]; d.sidx = d.rvals[d.cell_passes & 1];
+  if (d.use_hash) ok = ok && dalloc(b, d.chash, B * (size_t)d.Hcell); else d.chash = nullptr;
   ok = ok && dalloc(b, d.xcent, B * K) && dalloc(b, d.xamin, B * K) && dalloc(b, d.xamax, B * K);
   for (int i = 0; i < 4; ++i)
     ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.chunk_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K);
@@ -270,7 +277,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.nn_fwd, B * K) && dalloc(b, d.nn_bwd, B * K) && dalloc(b, d.nn_fwd_d, B * K) && dalloc(b, d.pair_q, B * K) && dalloc(b, d.pair_m, B * K) && dalloc(b, d.pair_d, B * K);
   ok = ok && dalloc(b, d.pair_cnt, B * K) && dalloc(b, d.pair_of_prev, B * K) && dalloc(b, d.pair_of_cur, B * K) && dalloc(b, d.det, B * K);
   if (p->method_choice == 2) ok = ok && dalloc(b, d.vox, B * (size_t)d.Hcap);
-  ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_n, B) && dalloc(b, d.wl_best, B * N) && dalloc(b, d.wl2, B * N) && dalloc(b, d.wl2_n, B) && dalloc(b, d.dbg, B * 16);
+  ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_n, B) && dalloc(b, d.wlb_n, B) && dalloc(b, d.wl2, B * N) && dalloc(b, d.wl2_n, B) && dalloc(b, d.dbg, B * 16);
   ok = ok && dalloc(b, d.zmin_i, B) && dalloc(b, d.zmax_i, B) && dalloc(b, d.zorg, B) && dalloc(b, d.zbase, B) && dalloc(b, d.mode_bin, B);
   if (d.gmode == 1) ok = ok && dalloc(b, d.rawbuf, B * N) && dalloc(b, d.is_ground, B * N) && dalloc(b, d.vcent, B * N) && dalloc(b, d.vbin, B * N);
   if (ok) {   // crop-box variant: the clustering grid starts at gp_limit for every stream
@@ -297,7 +304,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = ok && dalloc(b, o.pcid, B * N) && dalloc(b, o.ccid, B * N) && dalloc(b, o.cl_idx, B * N) && dalloc(b, o.det, B * K) && dalloc(b, o.zorg, B);
     ok = ok && dalloc(b, o.cell_of, B * N) && dalloc(b, o.cmin, B * N) && dalloc(b, o.parent, B * N) && dalloc(b, o.csize, B * N) && dalloc(b, o.compmin, B * N) && dalloc(b, o.cid_of_root, B * N);
     ok = ok && dalloc(b, o.pair_q, B * K) && dalloc(b, o.pair_m, B * K) && dalloc(b, o.pair_d, B * K) && dalloc(b, o.pair_cnt, B * K) && dalloc(b, o.pair_of_prev, B * K) && dalloc(b, o.pair_of_cur, B * K);
-    ok = ok && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B) && dalloc(b, o.wl_n, B);
+    ok = ok && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B) && dalloc(b, o.wl_n, B) && dalloc(b, o.wlb_n, B) && dalloc(b, o.wl, B * N);
+    if (d.use_hash) ok = ok && dalloc(b, o.chash, B * (size_t)d.Hcell);
     b->d_args_s[c] = dargs1; o.args = dargs1;
     if (ok) ok = hipMemcpy(o.zorg, d.zorg, B * sizeof(float), hipMemcpyDeviceToDevice) == hipSuccess;
     if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
@@ -500,6 +508,7 @@ int mor_get_cluster_collection(const mor_batch *b, int s, float *out) {
 int mor_exp_read_stamps(const mor_batch *b, unsigned long long *out) {
   if (!b) return MOR_ERR_INVALID;
   HIP_TRY(hipMemcpy(out, b->d.dbg, sizeof(unsigned long long) * 16 * b->B, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(b->d.dbg, 0, sizeof(unsigned long long) * 16 * b->B));   // counters restart
   return MOR_OK;
 }
 int mor_get_stage_counts(const mor_batch *b, int s, uint32_t *out, int n) {

@@ -27,9 +27,9 @@
 #include <cstdlib>
 
 const char *const mor_kernel_names[MK_COUNT] = {
-    "classify", "scan_tiles", "scatter", "heads_count", "heads_scan", "heads_scatter", "rowtable", "cellgraph", "cellbox", "hook_cells", "hook_cells_shell", "flatten", "cellcid",
+    "classify", "scan_tiles", "scatter", "heads_count", "heads_scan", "heads_scatter", "hash_clear", "rowtable", "cellboxes", "cellgraph", "cellbox", "hook_cells", "hook_cells_shell", "flatten", "cellcid",
     "select_count", "select_scan", "select_scatter", "rank", "offsets", "label", "rhist", "rscan", "rscatter",
-    "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "pairs", "score_fast", "score_rows", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
+    "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "pairs", "score_fast", "score_near", "score_block", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
     "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_mode", "g2_mark", "track_push", "track_filter"};
 
 // ------------------------------------------------------------------------------------ helpers
@@ -120,11 +120,14 @@ __device__ __forceinline__ int cell_axis(float v, float o, float inv, int n) {
   return c < 0 ? 0 : (c >= n ? n - 1 : c);
 }
 __device__ __forceinline__ int cell_axis_unclamped(float v, float o, float inv) { return (int)floorf((v - o) * inv); }
+#ifndef ROW_BATCH
+#define ROW_BATCH 8
+#endif
 // occupied cells with x in [x0,x1] of row (cy,cz) have the consecutive compact ids [lo, hi)
 __device__ __forceinline__ void row_cells(const MorGrid &g, const int *ckey, const int *rs, int x0, int x1, int cy, int cz, int &lo, int &hi) {
   const int r = cz * g.ny + cy, e = rs[r + 1], base = r * g.nx;
   lo = rs[r];
-  if (e - lo > 8) {   // long row (a wall along x): binary search
+  if (e - lo > ROW_BATCH) {   // long row (a wall along x): binary search
     int a = lo, b = e, k0 = base + x0;
     while (a < b) { int m = (a + b) >> 1; if (ckey[m] < k0) a = m + 1; else b = m; }
     lo = a; b = e; int k1 = base + x1;
@@ -137,7 +140,7 @@ __device__ __forceinline__ void row_cells(const MorGrid &g, const int *ckey, con
   int below = 0, within = 0;
   if (n > 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { int k = ckey[lo + min(i, n - 1)]; bool v = i < n; below += v && k < k0; within += v && k >= k0 && k <= k1; }
+    for (int i = 0; i < ROW_BATCH; ++i) { int k = ckey[lo + min(i, n - 1)]; bool v = i < n; below += v && k < k0; within += v && k >= k0 && k <= k1; }
   }
   lo += below; hi = lo + within;
 }
@@ -280,7 +283,37 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scan(MorDev d) {
     if (t < nt) c[t] = carry + e;
     carry += tot;
   }
-  if (threadIdx.x == 0) { d.info[s].n_occ = carry; d.cstart[(size_t)s * (d.Nmax + 1) + carry] = d.info[s].M; }
+  if (threadIdx.x == 0) {
+    d.info[s].n_occ = carry; d.cstart[(size_t)s * (d.Nmax + 1) + carry] = d.info[s].M;
+    int bits = 10; while ((1 << bits) < 4 * carry && (1 << bits) < d.Hcell) ++bits;   // load factor ≤ 1/4
+    d.info[s].hshift = 32 - bits;
+  }
+}
+// ------------------------------------------------------------------------------------ cell hash (method-1 scoring)
+// The scoring tiers look cells up by coordinates a few million times per batch.  Through the row table that is a chain
+// of dependent loads (row bounds → keys → …); a hash probe is one.  Open addressing, linear probing, load ≤ 1/4.
+__device__ __forceinline__ unsigned hash_slot(int key, unsigned hshift) { return ((unsigned)key * 0x9E3779B1u) >> hshift; }
+__device__ __forceinline__ int hash_resolve(const unsigned long long *tab, unsigned hshift, int key, unsigned sl, unsigned long long e) {
+  const unsigned mask = (1u << (32 - hshift)) - 1u;
+  for (;;) {   // e = tab[sl] was fetched by the caller (first probes of a batch are independent loads)
+    if (e == 0ull) return -1;
+    if ((unsigned)(e >> 32) == (unsigned)key + 1u) return (int)(unsigned)e;
+    sl = (sl + 1) & mask; e = tab[sl];
+  }
+}
+__device__ __forceinline__ int hash_find(const unsigned long long *tab, unsigned hshift, int key) {
+  const unsigned sl = hash_slot(key, hshift);
+  return hash_resolve(tab, hshift, key, sl, tab[sl]);
+}
+// linear key of cell (cx,cy,cz), −1 outside the grid
+__device__ __forceinline__ int cell_key(const MorGrid &g, int cx, int cy, int cz) {
+  if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cy >= (unsigned)g.ny || (unsigned)cz >= (unsigned)g.nz) return -1;
+  return (cz * g.ny + cy) * g.nx + cx;
+}
+__global__ __launch_bounds__(MOR_BT) void k_hash_clear(MorDev d) {
+  const int s = blockIdx.y + d.s0, n = 1 << (32 - d.info[s].hshift);
+  unsigned long long *tab = d.chash + (size_t)s * d.Hcell;
+  for (int i = blockIdx.x * MOR_BT + threadIdx.x; i < n; i += gridDim.x * MOR_BT) tab[i] = 0ull;
 }
 // per sorted position: compact cell id; heads publish the cell; every point lands in `sorted`
 __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
@@ -290,6 +323,8 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
   const int *skey = d.skey + so, *sidx = d.sidx + so;
   int *cstart = d.cstart + (size_t)s * (d.Nmax + 1);
   __shared__ int sh[4];
+  unsigned long long *tab = d.use_hash ? d.chash + (size_t)s * d.Hcell : nullptr;
+  const unsigned hshift = d.info[s].hshift, hmask = (1u << (32 - hshift)) - 1u;
   for (int t = t0; t * MOR_TILE < M; t += d.tiles_m) {
     const int base = t * MOR_TILE + wave_id() * 512;
     unsigned long long mh[8]; int cnt = 0;
@@ -310,6 +345,11 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
         if (head) {
           d.ckey[so + c] = skey[p]; cstart[c] = p; d.cmin[so + c] = i;   // stable sort ⇒ first of the cell = smallest cloud index
           d.parent[so + c] = c; d.csize[so + c] = 0; d.compmin[so + c] = 0x7fffffff; d.cid_of_root[so + c] = -1;
+          if (tab) {
+            const int key = skey[p]; unsigned sl = hash_slot(key, hshift);
+            const unsigned long long ent = ((unsigned long long)((unsigned)key + 1u) << 32) | (unsigned)c;
+            while (atomicCAS(&tab[sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
+          }
         }
         d.cell_of[so + i] = c;
         float4 q = d.cloud[so + i]; q.w = __int_as_float(i);
@@ -574,7 +614,11 @@ __device__ __forceinline__ bool pair_hit_wave(const float4 *sp, int a0, int na, 
 }
 __device__ __forceinline__ void wave_box(const float4 *sp, int b, int e, int lane, float4 &lo, float4 &hi) {
   float lx = FLT_MAX, ly = FLT_MAX, lz = FLT_MAX, hx = -FLT_MAX, hy = -FLT_MAX, hz = -FLT_MAX;
-  for (int k = b + lane; k < e; k += 64) { float4 p = sp[k]; lx = fminf(lx, p.x); ly = fminf(ly, p.y); lz = fminf(lz, p.z); hx = fmaxf(hx, p.x); hy = fmaxf(hy, p.y); hz = fmaxf(hz, p.z); }
+  for (int k = b + lane; k < e; k += 256) {   // four independent loads per lane and step
+    const float4 p0 = sp[k], p1 = sp[min(k + 64, e - 1)], p2 = sp[min(k + 128, e - 1)], p3 = sp[min(k + 192, e - 1)];
+    lx = fminf(fminf(lx, p0.x), fminf(p1.x, fminf(p2.x, p3.x))); ly = fminf(fminf(ly, p0.y), fminf(p1.y, fminf(p2.y, p3.y))); lz = fminf(fminf(lz, p0.z), fminf(p1.z, fminf(p2.z, p3.z)));
+    hx = fmaxf(fmaxf(hx, p0.x), fmaxf(p1.x, fmaxf(p2.x, p3.x))); hy = fmaxf(fmaxf(hy, p0.y), fmaxf(p1.y, fmaxf(p2.y, p3.y))); hz = fmaxf(fmaxf(hz, p0.z), fmaxf(p1.z, fmaxf(p2.z, p3.z)));
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
@@ -667,32 +711,52 @@ template <bool LDS> __device__ __forceinline__ void cg_hook_pass(const MorDev &d
 #else
 #define CG_STAMP(i)
 #endif
+#define MOR_BOX_G 32      // workgroups per stream of k_cellboxes
+// Boxes of the cells' points (cmeta), for every stream at once at the end of the grid stage: 16 lanes per cell (most
+// cells hold a handful of points), four cells per wave-iteration.  (Used to be the first phase of k_cellgraph, where
+// one workgroup per stream walked its cells alone.)
+__global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
+  int s, bx; map_block(d.B, MOR_BOX_G, s, bx);
+  const int nocc = d.info[s].n_occ, sub = lane_id() & 15, grp = lane_id() >> 4;
+  const size_t so = (size_t)s * d.Nmax;
+  const int *start = d.cstart + (size_t)s * (d.Nmax + 1);
+  const float4 *sp = d.sorted + so;
+  // four cells per 16-lane group and pass: their ranges, then their first 32 points each, as two batches of independent loads
+  for (int c0 = ((bx * (MOR_BT / 64) + wave_id()) * 4 + grp) * 4; c0 < nocc; c0 += MOR_BOX_G * (MOR_BT / 64) * 16) {
+    int b[4], e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int c = min(c0 + u, nocc - 1); b[u] = start[c]; e[u] = start[c + 1]; }
+    float4 p[4], p2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { p[u] = sp[min(b[u] + sub, e[u] - 1)]; p2[u] = sp[min(b[u] + sub + 16, e[u] - 1)]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float lx = fminf(p[u].x, p2[u].x), ly = fminf(p[u].y, p2[u].y), lz = fminf(p[u].z, p2[u].z), hx = fmaxf(p[u].x, p2[u].x), hy = fmaxf(p[u].y, p2[u].y), hz = fmaxf(p[u].z, p2[u].z);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
+        hx = fmaxf(hx, __shfl_xor(hx, o, 64)); hy = fmaxf(hy, __shfl_xor(hy, o, 64)); hz = fmaxf(hz, __shfl_xor(hz, o, 64));
+      }
+      const bool bigc = e[u] - b[u] > 32 && c0 + u < nocc;
+      if (sub == 0 && c0 + u < nocc && !bigc) { d.cmeta[2 * (so + c0 + u)] = make_float4(lx, ly, lz, 0.f); d.cmeta[2 * (so + c0 + u) + 1] = make_float4(hx, hy, hz, 0.f); }
+      // cells of more than 32 points (dense surfaces close to the sensor hold hundreds): the whole wave, 256 points per step
+      unsigned long long m = __ballot(bigc && sub == 0);
+      while (m) {
+        const int l = __ffsll((long long)m) - 1; m &= m - 1;
+        const int cb = __shfl(b[u], l, 64), ce = __shfl(e[u], l, 64), cc = __shfl(c0 + u, l, 64);
+        float4 lo, hi; wave_box(sp, cb, ce, lane_id(), lo, hi);
+        if (lane_id() == 0) { d.cmeta[2 * (so + cc)] = lo; d.cmeta[2 * (so + cc) + 1] = hi; }
+      }
+    }
+  }
+}
 template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int s, int nocc, const int *key, const int *start, const int *rows, int *par,
                                                               int *size, int *mn, int *cidr, int *l_list, int *l_nlist, int *l_misc) {
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
   const int lane = lane_id();
   CG_STAMP(1);
-  // ---- boxes of the cells' points: cells of ≤ 16 points by one thread each, bigger ones by a whole wave each
-  for (int c = threadIdx.x; c < nocc; c += CG_T) {
-    const int b = start[c], e = start[c + 1];
-    if (e - b > 16) continue;
-    float lx = FLT_MAX, ly = FLT_MAX, lz = FLT_MAX, hx = -FLT_MAX, hy = -FLT_MAX, hz = -FLT_MAX;
-    for (int k = b; k < e; k += 4) {
-      float4 p0 = sp[k], p1 = sp[min(k + 1, e - 1)], p2 = sp[min(k + 2, e - 1)], p3 = sp[min(k + 3, e - 1)];
-      lx = fminf(fminf(lx, p0.x), fminf(p1.x, fminf(p2.x, p3.x))); ly = fminf(fminf(ly, p0.y), fminf(p1.y, fminf(p2.y, p3.y))); lz = fminf(fminf(lz, p0.z), fminf(p1.z, fminf(p2.z, p3.z)));
-      hx = fmaxf(fmaxf(hx, p0.x), fmaxf(p1.x, fmaxf(p2.x, p3.x))); hy = fmaxf(fmaxf(hy, p0.y), fmaxf(p1.y, fmaxf(p2.y, p3.y))); hz = fmaxf(fmaxf(hz, p0.z), fmaxf(p1.z, fmaxf(p2.z, p3.z)));
-    }
-    d.cmeta[2 * (so + c)] = make_float4(lx, ly, lz, 0.f); d.cmeta[2 * (so + c) + 1] = make_float4(hx, hy, hz, 0.f);
-  }
-  for (int c = wave_id(); c < nocc; c += CG_T / 64) {
-    const int b = start[c], e = start[c + 1];
-    if (e - b <= 16) continue;
-    float4 lo, hi; wave_box(sp, b, e, lane, lo, hi);
-    if (lane == 0) { d.cmeta[2 * (so + c)] = lo; d.cmeta[2 * (so + c) + 1] = hi; }
-  }
-  __threadfence_block();
-  __syncthreads();
+  // (the boxes of the cells' points were written by k_cellboxes at the end of the grid stage)
   CG_STAMP(2);
   // ---- hooks: 3×3×3 neighbourhood first, then the 5×5×5 shell (mostly skipped by the root test)
   cg_hook_pass<LDS>(d, s, nocc, 1, key, start, rows, par, sp, l_list, l_nlist);
@@ -1122,159 +1186,241 @@ __global__ __launch_bounds__(MOR_BT) void k_pairs(MorDev d) {
     }
     carry += tot;
   }
-  if (threadIdx.x == 0) { d.info[s].n_pairs = carry; d.wl_n[s] = 0; d.wl2_n[s] = 0; }
+  if (threadIdx.x == 0) { d.info[s].n_pairs = carry; d.wl_n[s] = 0; d.wlb_n[s] = 0; d.wl2_n[s] = 0; }
 }
 
+#define MOR_SCORE_G 64    // workgroups per stream of the worklist tiers
+#define MOR_PDE_G 256
 // ------------------------------------------------------------------------------------ P3: method 1 (:336-366)
-// per point q of a matched previous cluster: squared distance to the nearest point of the matched
-// current cluster; count lb < d² < ub (:356).  One WAVE per query: lanes first resolve the rows of
-// the search stencil to point ranges of the current frame's cell-sorted array (bitmap rank), then
-// the wave streams each range 64 candidates at a time (coalesced 1-KiB reads).  Rows are visited
-// nearest-first (row_order): a row whose lower bound is ≥ min(best, ub) ends the search (a
-// neighbour at d² ≥ ub can never be counted), and so does any candidate with d² ≤ lb (the minimum
-// can only get smaller ⇒ never counted).
-// Tier 1 — one THREAD per query, the 9 rows of cells around it (row_order[0..8], lower bound 0).
-// Static surfaces end here: either some matched point lies within √lb (never counted), or the
-// nearest one is closer than one cell edge, which already beats every farther row (bound ≥ cs²).
-// Anything else goes to the worklist of tier 2 (k_score_pde, one wave per query).
-// All points of a cell belong to one component (the cell is a clique), so the cluster id is a
-// per-CELL attribute (ccid): candidates are filtered cell by cell without touching their points,
-// and a cell's point box gives a lower bound that prunes it against the best distance so far.
+// Per point q of a matched previous cluster: squared distance to the nearest point of the matched current cluster;
+// count lb < d² < ub (:356).  Only the CLASS of that distance matters (≤ lb, inside (lb, ub), ≥ ub), so the search is
+// two existence tests: E2 "some matched point closer than √ub" and E1 "some matched point within √lb"; q is counted
+// iff E2 ∧ ¬E1.  All points of a grid cell belong to one component (the cell is a clique), so the cluster id is a
+// per-CELL attribute (ccid, also in .w of the cell's box record): candidates are filtered cell by cell without
+// touching their points, and a cell's point box gives a lower bound that prunes it.
+//   tier 1  k_score_fast   thread per query, its own cell (hash probe → cell → points): static surfaces end here
+//   tier 1a k_score_near   thread per query with E2 known: the ≤ 7 neighbour cells across the walls q is close to
+//   tier 1b k_score_block  thread per query whose own cell has no matched point: E2 (then E1) in the 3×3×3 block
+//   tier 2  k_score_pde    wave per query for what is left: big cells, matches farther than one cell
+// Lesson of the profile: a thread's time is the NUMBER of dependent load levels (≈ 2 µs each under load), not bytes;
+// every tier is written as a few levels of batched independent loads.
+// Threshold T for the wave tier: a region with lower bound ≥ T can be skipped — ub while E2 is open; once best < ub
+// only regions that could hold a point within lb matter (`best` then need not be the true minimum).
+__device__ __forceinline__ float score_lim(float best, float lbn /* smallest float > lb */, float ub) { return best < ub ? fminf(best, lbn) : ub; }
 __device__ __forceinline__ float box_dist2(const float4 &q, const float4 &lo, const float4 &hi) {
   float gx = fmaxf(fmaxf(lo.x - q.x, q.x - hi.x), 0.f), gy = fmaxf(fmaxf(lo.y - q.y, q.y - hi.y), 0.f), gz = fmaxf(fmaxf(lo.z - q.z, q.z - hi.z), 0.f);
   return (gx * gx + gy * gy + gz * gz) * 0.999f;   // conservative
 }
-// scan sorted positions [b,e) (one cell of the matched cluster), four independent loads at a time; stops at d² ≤ lb
-__device__ __forceinline__ void scan4(const float4 *sp, int b, int e, const float4 &q, float lbv, float &best, int &budget) {
+// scan sorted positions [b,e) (one cell of the matched cluster), four independent loads at a time; returns as soon as best < stopv
+__device__ __forceinline__ void scan4s(const float4 *sp, int b, int e, const float4 &q, float stopv, float &best, int &budget) {
   for (int k = b; k < e && budget > 0; k += 4, budget -= 4) {
     float4 p0 = sp[k], p1 = sp[min(k + 1, e - 1)], p2 = sp[min(k + 2, e - 1)], p3 = sp[min(k + 3, e - 1)];
     best = fminf(best, sqdist(q.x, q.y, q.z, p0.x, p0.y, p0.z));
     best = fminf(best, sqdist(q.x, q.y, q.z, p1.x, p1.y, p1.z));
     best = fminf(best, sqdist(q.x, q.y, q.z, p2.x, p2.y, p2.z));
     best = fminf(best, sqdist(q.x, q.y, q.z, p3.x, p3.y, p3.z));
-    if (best <= lbv) return;
+    if (best < stopv) return;
   }
 }
-// the matched cells among compact ids [lo,hi): nearest box first, then the rest that can still improve `best`.
-// A cell's record (point box + cluster id in .w of the low corner) is one 32-byte line.
-__device__ __forceinline__ void scan_cells(const MorDev &d, size_t so, const int *st, const float4 *sp, int lo, int hi, int target, const float4 &q, float &best, int &budget) {
-  int cfirst = -1; float bfirst = INFINITY;
-  for (int c = lo; c < hi; ++c) {   // no early exit: the record loads of a row are independent
-    const float4 blo = d.cmeta[2 * (so + c)], bhi = d.cmeta[2 * (so + c) + 1];
-    float bd = box_dist2(q, blo, bhi);
-    if (__float_as_int(blo.w) == target && bd < bfirst) { bfirst = bd; cfirst = c; }
-  }
-  if (cfirst < 0 || bfirst >= fminf(best, d.pde_ub)) return;
-  scan4(sp, st[cfirst], st[cfirst + 1], q, d.pde_lb, best, budget);
-  for (int c = lo; c < hi && best > d.pde_lb && budget > 0; ++c) {
-    if (c == cfirst) continue;
-    const float4 blo = d.cmeta[2 * (so + c)], bhi = d.cmeta[2 * (so + c) + 1];
-    if (__float_as_int(blo.w) != target || box_dist2(q, blo, bhi) >= fminf(best, d.pde_ub)) continue;
-    scan4(sp, st[c], st[c + 1], q, d.pde_lb, best, budget);
-  }
+// Which neighbour cells can hold a point within √lb of q: per axis −1 / +1 when q lies within `slb` (√lb, padded for
+// the rounding of the cell map) of the low / high wall of its cell, else 0.  Valid when 2·slb < cell edge.
+__device__ __forceinline__ int near_side(float v, float o, float inv, float cs, int c, float slb) {
+  const float f = ((v - o) * inv - (float)c) * cs;   // distance to the low wall
+  return f <= slb ? -1 : (cs - f <= slb ? 1 : 0);
 }
-
-// wave-aggregated append of (query, best-so-far) to a per-stream worklist
-__device__ __forceinline__ void wl_push(bool want, int *n, int *list, float *bests, int j, float best) {
+// wave-aggregated append of a query to a per-stream worklist; `back`: the list grows downwards from list[cap−1]
+// An entry is (query, pair, matched cluster) so the next tier starts without the chain query → cluster → pair → match.
+__device__ __forceinline__ void wl_push(bool want, int *n, int4 *list, int j, int pr, int target, bool back = false, int cap = 0) {
   unsigned long long m = __ballot(want);
   if (!m) return;
   int basew = 0, leader = __ffsll((long long)m) - 1;
   if (lane_id() == leader) basew = atomicAdd(n, __popcll(m));
   basew = __shfl(basew, leader, 64);
-  if (want) { int pos = basew + __popcll(m & lanemask_lt()); list[pos] = j; if (bests) bests[pos] = best; }
+  if (want) { int pos = basew + __popcll(m & lanemask_lt()); list[back ? cap - 1 - pos : pos] = make_int4(j, pr, target, 0); }
+}
+// wave-aggregated count: all counted queries of a pair add to ONE address (a few dozen addresses per stream), and
+// same-address atomics serialise in L2 — thousands of them per stream were the real cost of these kernels.  Lanes
+// with the same pair are combined first (worklist order is cluster order, so usually one atomic per wave).
+__device__ __forceinline__ void count_push(bool want, int *cnt, int pr) {
+  unsigned long long m = __ballot(want);
+  while (m) {
+    const int l = __ffsll((long long)m) - 1, p = __shfl(pr, l, 64);
+    const unsigned long long same = __ballot(want && pr == p);
+    if (lane_id() == l) atomicAdd(&cnt[p], __popcll(same));
+    m &= ~same;
+  }
 }
 // Tier 1 — one THREAD per query, its OWN cell only.  On a static surface a point of the matched cluster lies
-// within √lb of q, almost always in q's own cell: ≈95 % of the queries end here (never counted).  The rest is
-// compacted into a worklist so the next tier runs full waves of hard queries instead of dragging every wave.
+// within √lb of q, almost always in q's own cell: ≈ 85 % of the queries end here (never counted).  The rest is
+// compacted into worklists so the next tiers run full waves of like queries: `wl` front = E2 known (a matched point of
+// the own cell closer than √ub), `wl` back = own cell without a matched point, `wl2` = big own cell (wave tier).
 __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
   int s, t0; map_block(d.B, d.tiles_m * 8, s, t0);
   const int pv = d.prev, Cp = d.info_prev[s].C;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
-  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
+  const unsigned long long *tab = d.chash + (size_t)s * d.Hcell; const unsigned hshift = d.info[s].hshift;
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  const float lbn = nextafterf(d.pde_lb, INFINITY);
+  const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + d.g.cs * 1e-3f;
+  const bool e1_local = 2.f * slb < d.g.cs;
   for (int base = t0 * MOR_BT; base < Cp; base += d.tiles_m * 8 * MOR_BT) {
     const int j = base + threadIdx.x;
-    bool more = false, big = false; float best = INFINITY;
+    bool nearq = false, blockq = false, big = false, counted = false; float best = INFINITY; int pr = -1, target = -1;
     if (j < Cp) {
-      int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
+      pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
       if (pr >= 0) {
-        const int target = d.pair_m[ko + pr];
+        target = d.pair_m[ko + pr];
         const float4 q = d.cl_pts[pv][so + j];
         const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
         int budget = 64;   // a big own cell that shows no close point within its first 64 goes to the wave tier
-        int c = cell_lookup(d.g, ckey, rs, cx, cy, cz);
-        if (c >= 0 && d.ccid[so + c] == target) {
-          const int b0 = st[c], e0 = st[c + 1];
-          scan4(sp, b0, e0, q, d.pde_lb, best, budget);
-          big = best > d.pde_lb && e0 - b0 > 64;
+        const int key = cell_key(d.g, cx, cy, cz);
+        const int c = key >= 0 ? hash_find(tab, hshift, key) : -1;
+        const bool reach = box_dist2(q, d.amin[d.cur][ko + target], d.amax[d.cur][ko + target]) < d.pde_ub;   // farther than √ub from the whole matched cluster: never counted
+        if (reach && c >= 0) {
+          const int cid = d.ccid[so + c], b0 = st[c], e0 = st[c + 1];   // one level of independent loads
+          if (cid == target) { scan4s(sp, b0, e0, q, lbn, best, budget); big = best > d.pde_lb && e0 - b0 > 64; }
         }
-        more = best > d.pde_lb && !big;
+        if (reach && best > d.pde_lb && !big) {
+          if (!e1_local) big = true;   // √lb reaches beyond the adjacent half-cells in this configuration: wave tier
+          else if (best < d.pde_ub) {
+            if (near_side(q.x, d.g.ox, d.g.inv_cs, d.g.cs, cx, slb) == 0 && near_side(q.y, d.g.oy, d.g.inv_cs, d.g.cs, cy, slb) == 0 && near_side(q.z, d.zorg[s], d.g.inv_cs, d.g.cs, cz, slb) == 0)
+              counted = true;   // deep inside its cell: no other cell can hold a point within √lb ⇒ counted
+            else nearq = true;
+          } else blockq = true;
+        }
       }
     }
-    wl_push(more, &d.wl_n[s], d.wl + so, d.wl_best + so, j, best);
-    wl_push(big, &d.wl2_n[s], d.wl2 + so, nullptr, j, best);
+    count_push(counted, d.pair_cnt + ko, pr);
+    wl_push(nearq, &d.wl_n[s], d.wl + so, j, pr, target);
+    wl_push(blockq, &d.wlb_n[s], d.wl + so, j, pr, target, true, d.Nmax);
+    wl_push(big, &d.wl2_n[s], d.wl2 + so, j, pr, target);
   }
 }
-// Tier 1b — one THREAD per remaining query: the 9 rows of cells around it (row_order[0..8], lower bound 0).  Ends
-// here when some matched point lies within √lb, or when the nearest one is closer than one cell edge, which beats
-// every farther row (bound ≥ cs²).  Anything else — or a thread that has scanned its budget — goes to tier 2.
-__global__ __launch_bounds__(MOR_BT) void k_score_rows(MorDev d) {
-  int s = blockIdx.y + d.s0, pv = d.prev, nq = d.wl_n[s];
+// one batch of four cells: box records and point ranges with independent loads, then the scans.  A cell is scanned up
+// to the first point within lb when its box allows one (E1); while E2 is open also when its box allows a point < ub.
+__device__ __forceinline__ void scan_batch4(const MorDev &d, size_t so, const int *st, const float4 *sp, const int (&c4)[4], int target, bool check_target, const float4 &q,
+                                            float lbn, float &best, int &budget) {
+  float4 blo[4], bhi[4]; int b0[4], e0[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int c = max(c4[i], 0); blo[i] = d.cmeta[2 * (so + c)]; bhi[i] = d.cmeta[2 * (so + c) + 1]; b0[i] = st[c]; e0[i] = st[c + 1]; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (c4[i] < 0 || (check_target && __float_as_int(blo[i].w) != target) || !(best > d.pde_lb) || budget <= 0) continue;
+    const float bd = box_dist2(q, blo[i], bhi[i]);
+    if (bd < lbn) scan4s(sp, b0[i], e0[i], q, lbn, best, budget);
+    else if (!(best < d.pde_ub) && bd < d.pde_ub) scan4s(sp, b0[i], e0[i], q, d.pde_ub, best, budget);
+  }
+}
+// Tier 1a — one THREAD per query with E2 known (worklist front).  E1: only the ≤ 7 neighbour cells across the walls q
+// is close to can hold a point within √lb (the own cell was scanned by tier 1).  Three levels of loads: hash probes →
+// box records + ranges → points.  No such point ⇒ counted.
+__global__ __launch_bounds__(MOR_BT) void k_score_near(MorDev d) {
+  int s, bx; map_block(d.B, MOR_SCORE_G, s, bx);   // a stream's workgroups share an XCD (its cell tables stay in that L2)
+  const int pv = d.prev, nq = d.wl_n[s];
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
-  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
+  const unsigned long long *tab = d.chash + (size_t)s * d.Hcell; const unsigned hshift = d.info[s].hshift;
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
-  const int R = d.score_R;
-  const float cs = d.g.cs * 0.999f, ring2 = cs * cs;   // lower bound of every row beyond the first 9
-  for (int w0 = blockIdx.x * MOR_BT; w0 < nq; w0 += gridDim.x * MOR_BT) {
+  const float lbn = nextafterf(d.pde_lb, INFINITY);
+  const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + d.g.cs * 1e-3f;
+  for (int w0 = bx * MOR_BT; w0 < nq; w0 += MOR_SCORE_G * MOR_BT) {
     const int w = w0 + threadIdx.x;
-    bool defer = false; int j = 0; float best = INFINITY;
+    bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
     if (w < nq) {
-      j = d.wl[so + w]; best = d.wl_best[so + w];
-      const int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]], target = d.pair_m[ko + pr];
+      const int4 we = d.wl[so + w]; j = we.x; pr = we.y; target = we.z;
       const float4 q = d.cl_pts[pv][so + j];
       const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
-      int budget = d.t1_budget;   // points this thread may scan before handing the query to a wave
-      // the 9 row lookups do not depend on each other (x half-width from the incoming best): all their loads overlap
-      int lo9[9], hi9[9];
-      const int rx = min(R, (int)(sqrtf(fminf(best, d.pde_ub)) * d.g.inv_cs * 1.001f) + 1);
-      const int x0 = max(cx - rx, 0), x1 = min(cx + rx, d.g.nx - 1);
+      const int sx = near_side(q.x, d.g.ox, d.g.inv_cs, d.g.cs, cx, slb), sy = near_side(q.y, d.g.oy, d.g.inv_cs, d.g.cs, cy, slb), sz = near_side(q.z, d.zorg[s], d.g.inv_cs, d.g.cs, cz, slb);
+      int budget = d.t1_budget; float best = 0.5f * (d.pde_lb + d.pde_ub) ;   // any value inside (lb, ub): E2 holds
+      if (!(best > d.pde_lb && best < d.pde_ub)) best = d.pde_ub * 0.999f;
+      int key[8]; unsigned sl[8]; unsigned long long ent[8]; int id[8];
 #pragma unroll
-      for (int ro = 0; ro < 9; ++ro) {
-        int y = cy + d.row_order[2 * ro], z = cz + d.row_order[2 * ro + 1];
-        lo9[ro] = hi9[ro] = 0;
-        if (x0 <= x1 && (unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) row_cells(d.g, ckey, rs, x0, x1, y, z, lo9[ro], hi9[ro]);
+      for (int i = 1; i < 8; ++i) {
+        const int ax = i & 1, ay = (i >> 1) & 1, az = i >> 2;
+        const bool valid = !(ax && sx == 0) && !(ay && sy == 0) && !(az && sz == 0);
+        key[i] = valid ? cell_key(d.g, cx + ax * sx, cy + ay * sy, cz + az * sz) : -1;
+        sl[i] = hash_slot(max(key[i], 0), hshift); ent[i] = tab[sl[i]];
       }
-      // all matched cells of the 9 rows, the 8 nearest by box distance kept sorted in registers; scanning them
-      // nearest-first tightens `best` at once, so usually one or two cells are read at all
-      float bd[8]; int cc[8]; int ncand = 0;
+      id[0] = -1;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { bd[i] = INFINITY; cc[i] = -1; }
-      const float lim0 = fminf(best, d.pde_ub);
+      for (int i = 1; i < 8; ++i) id[i] = key[i] >= 0 ? hash_resolve(tab, hshift, key[i], sl[i], ent[i]) : -1;
+      const int ca[4] = {id[1], id[2], id[4], id[3]}, cb2[4] = {id[5], id[6], id[7], -1};   // face neighbours first
+      scan_batch4(d, so, st, sp, ca, target, true, q, lbn, best, budget);
+      if ((cb2[0] >= 0 || cb2[1] >= 0 || cb2[2] >= 0) && best > d.pde_lb) scan_batch4(d, so, st, sp, cb2, target, true, q, lbn, best, budget);
+      if (best > d.pde_lb) { if (budget <= 0) defer = true; else counted = true; }
+    }
+    count_push(counted, d.pair_cnt + ko, pr);
+    wl_push(defer, &d.wl2_n[s], d.wl2 + so, j, pr, target);
+  }
+}
+// Tier 1b — one THREAD per query whose own cell holds no matched point (worklist back).  The 26 other cells of the
+// 3×3×3 block: hash probes → cluster ids → up to 8 matched cells (those that can hold a point within √lb first) →
+// box records + ranges → points.  E2 hit ⇒ E1 is decided by the same cells; no hit ⇒ the wider stencil is the wave tier's job.
+__global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
+  int s, bx; map_block(d.B, MOR_SCORE_G, s, bx);
+  const int pv = d.prev, nq = d.wlb_n[s];
+  const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
+  const float4 *sp = d.sorted + so;
+  const unsigned long long *tab = d.chash + (size_t)s * d.Hcell; const unsigned hshift = d.info[s].hshift;
+  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  const int *cid_c = d.ccid + so;
+  const float lbn = nextafterf(d.pde_lb, INFINITY);
+  const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + d.g.cs * 1e-3f;
+  const bool stencil27 = d.n_rows <= 9 && d.score_R <= 1;   // the whole search stencil is the 3×3×3 block
+  for (int w0 = bx * MOR_BT; w0 < nq; w0 += MOR_SCORE_G * MOR_BT) {
+    const int w = w0 + threadIdx.x;
+    bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
+    if (w < nq) {
+      const int4 we = d.wl[so + d.Nmax - 1 - w]; j = we.x; pr = we.y; target = we.z;
+      const float4 q = d.cl_pts[pv][so + j];
+      const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
+      const int sx = near_side(q.x, d.g.ox, d.g.inv_cs, d.g.cs, cx, slb), sy = near_side(q.y, d.g.oy, d.g.inv_cs, d.g.cs, cy, slb), sz = near_side(q.z, d.zorg[s], d.g.inv_cs, d.g.cs, cz, slb);
+      int budget = d.t1_budget; float best = INFINITY;
+      int id[27];
+      {
+        int key[27]; unsigned long long ent[27];
 #pragma unroll
-      for (int ro = 0; ro < 9; ++ro)
-        for (int c = lo9[ro]; c < hi9[ro]; ++c) {
-          const float4 blo = d.cmeta[2 * (so + c)], bhi = d.cmeta[2 * (so + c) + 1];
-          float nb = box_dist2(q, blo, bhi); int nc = c;
-          if (__float_as_int(blo.w) != target || nb >= lim0) continue;
-          ++ncand;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) if (nb < bd[i]) { float tb = bd[i]; int tc = cc[i]; bd[i] = nb; cc[i] = nc; nb = tb; nc = tc; }
+        for (int i = 0; i < 27; ++i) {
+          key[i] = i == 13 ? -1 : cell_key(d.g, cx + i % 3 - 1, cy + (i / 3) % 3 - 1, cz + i / 9 - 1);
+          ent[i] = tab[hash_slot(max(key[i], 0), hshift)];
         }
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (cc[i] >= 0 && best > d.pde_lb && budget > 0 && bd[i] < fminf(best, d.pde_ub)) {
-          scan4(sp, st[cc[i]], st[cc[i] + 1], q, d.pde_lb, best, budget);
-        }
-      if (ncand > 8 && best > d.pde_lb && bd[7] < fminf(best, d.pde_ub)) budget = 0;   // more candidates than kept: let the wave tier finish it
+        for (int i = 0; i < 27; ++i) id[i] = key[i] >= 0 ? hash_resolve(tab, hshift, key[i], hash_slot(key[i], hshift), ent[i]) : -1;
+      }
+      int mc[8]; int ncand = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mc[i] = -1;
+      {
+        int cidv[27];
+#pragma unroll
+        for (int i = 0; i < 27; ++i) cidv[i] = cid_c[max(id[i], 0)];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass)   // pass 0: cells that can hold a point within √lb (≤ 7), pass 1: the others
+#pragma unroll
+          for (int i = 0; i < 27; ++i) {
+            const int dx = i % 3 - 1, dy = (i / 3) % 3 - 1, dz = i / 9 - 1;
+            const bool nearc = (dx == 0 || dx == sx) && (dy == 0 || dy == sy) && (dz == 0 || dz == sz);
+            if (id[i] >= 0 && cidv[i] == target && nearc == (pass == 0)) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) if (ncand == k) mc[k] = id[i];
+              ++ncand;
+            }
+          }
+      }
+      if (ncand > 0) {
+        const int ca[4] = {mc[0], mc[1], mc[2], mc[3]}, cb2[4] = {mc[4], mc[5], mc[6], mc[7]};
+        scan_batch4(d, so, st, sp, ca, target, false, q, lbn, best, budget);
+        if (ncand > 4 && best > d.pde_lb) scan_batch4(d, so, st, sp, cb2, target, false, q, lbn, best, budget);
+      }
       if (best > d.pde_lb) {
         if (budget <= 0) defer = true;
-        else if (ring2 >= fminf(best, d.pde_ub) || d.n_rows <= 9) { if (best < d.pde_ub) atomicAdd(&d.pair_cnt[ko + pr], 1); }
-        else defer = true;
+        else if (best < d.pde_ub) counted = true;   // all cells that can hold a point within √lb were among the slots
+        else if (!(stencil27 && ncand <= 8)) defer = true;              // E2 still open: wider search
       }
     }
-    wl_push(defer, &d.wl2_n[s], d.wl2 + so, nullptr, j, best);
+    count_push(counted, d.pair_cnt + ko, pr);
+    wl_push(defer, &d.wl2_n[s], d.wl2 + so, j, pr, target);
   }
 }
 __device__ __forceinline__ float wave_min(float v) {
@@ -1299,24 +1445,27 @@ __device__ __forceinline__ float wave_scan_cell(const float4 *sp, int b0, int e0
   return wave_min(local);
 }
 __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
-  int s = blockIdx.y + d.s0, pv = d.prev, nq = d.wl2_n[s];
-  const int wv = blockIdx.x * (MOR_BT / 64) + wave_id(), nw = gridDim.x * (MOR_BT / 64), lane = lane_id();
+  const int s = blockIdx.y + d.s0, bx = blockIdx.x;   // a stream's waves spread over all XCDs: the deferred queries are few and uneven across streams
+  const int pv = d.prev, nq = d.wl2_n[s];
+  const int wv = bx * (MOR_BT / 64) + wave_id(), nw = MOR_PDE_G * (MOR_BT / 64), lane = lane_id();
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const int R = d.score_R;
+  const int *cid_c = d.ccid + so;
+  const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float cs = d.g.cs * 0.999f;   // conservative cell edge for the row lower bounds
+  int acc_pr = -1, acc = 0;   // counts of consecutive queries of one pair are flushed together
   for (int w = wv; w < nq; w += nw) {
-    const int j = d.wl2[so + w];
-    int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
-    if (pr < 0) continue;
-    const int target = d.pair_m[ko + pr];
+    const int4 we = d.wl2[so + w];
+    const int j = we.x, pr = we.y, target = we.z;
     const float4 q = d.cl_pts[pv][so + j];
     const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
     float best = INFINITY;
     {  // the query's own cell first
-      int c = cell_lookup(d.g, ckey, rs, cx, cy, cz);
+      const int key = cell_key(d.g, cx, cy, cz);
+      const int c = key >= 0 && d.use_hash ? hash_find(d.chash + (size_t)s * d.Hcell, d.info[s].hshift, key) : cell_lookup(d.g, ckey, rs, cx, cy, cz);
       if (c >= 0 && d.ccid[so + c] == target) best = wave_scan_cell(sp, st[c], st[c + 1], q, d.pde_lb, lane);
     }
     for (int rb = 0; rb < d.n_rows && best > d.pde_lb; rb += 64) {
@@ -1326,7 +1475,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
         int dy = d.row_order[2 * ro], dz = d.row_order[2 * ro + 1];
         float ly = (float)max(abs(dy) - 1, 0) * cs, lz = (float)max(abs(dz) - 1, 0) * cs;
         lbrow = ly * ly + lz * lz;
-        float room = fminf(best, d.pde_ub) - lbrow;   // a useful neighbour in this row needs dx² < room
+        float room = score_lim(best, lbn, d.pde_ub) - lbrow;   // a useful neighbour in this row needs dx² < room
         int y = cy + dy, z = cz + dz;
         if (room > 0.f && (unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) {
           int rx = min(R, (int)(sqrtf(room) * d.g.inv_cs * 1.001f) + 1);
@@ -1334,13 +1483,27 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
           if (x0 <= x1) row_cells(d.g, ckey, rs, x0, x1, y, z, cur, hi);
         }
       }
-      if (__shfl(lbrow, 0, 64) >= fminf(best, d.pde_ub)) break;   // rows are ordered by their lower bound
+      if (__shfl(lbrow, 0, 64) >= score_lim(best, lbn, d.pde_ub)) break;   // rows are ordered by their lower bound
+      // cluster ids of the first 8 cells of the lane's row as one batch of independent loads → bit mask of matched cells
+      unsigned rowmask = 0; const int base = cur;
+      {
+        int idv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) idv[u] = cid_c[min(base + u, d.Nmax - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (base + u < hi && idv[u] == target) rowmask |= 1u << u;
+      }
+      cur = min(base + 8, hi);   // cells beyond the batch are walked one by one
       for (;;) {
-        // lane-parallel: advance the cursor to the next cell of the matched cluster whose box can still improve `best`
+        // lane-parallel: advance to the next cell of the matched cluster whose box can still improve the class of `best`
         int cand = -1;
-        const float lim = fminf(best, d.pde_ub);
+        const float lim = score_lim(best, lbn, d.pde_ub);
         if (lbrow < lim) {
-          while (cur < hi) {
+          while (rowmask) {
+            const int c = base + __ffs(rowmask) - 1; rowmask &= rowmask - 1;
+            if (box_dist2(q, d.cmeta[2 * (so + c)], d.cmeta[2 * (so + c) + 1]) < lim) { cand = c; break; }
+          }
+          while (cand < 0 && cur < hi) {
             int c = cur++;
             const float4 blo = d.cmeta[2 * (so + c)], bhi = d.cmeta[2 * (so + c) + 1];
             if (__float_as_int(blo.w) == target && box_dist2(q, blo, bhi) < lim) { cand = c; break; }
@@ -1351,20 +1514,24 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
         const int cb = cand >= 0 ? st[cand] : 0, ce = cand >= 0 ? st[cand + 1] : 0;
         const bool small = cand >= 0 && ce - cb <= 16;
         float local = INFINITY;
-        if (small) { int budget = 0x7fffffff; scan4(sp, cb, ce, q, d.pde_lb, local, budget); }
+        if (small) { int budget = 0x7fffffff; scan4s(sp, cb, ce, q, lbn, local, budget); }
         best = fminf(best, wave_min(local));
         unsigned long long m = __ballot(cand >= 0 && !small);
         while (m && best > d.pde_lb) {
           int l = __ffsll((long long)m) - 1; m &= m - 1;
           int c = __shfl(cand, l, 64);
-          if (box_dist2(q, d.cmeta[2 * (so + c)], d.cmeta[2 * (so + c) + 1]) >= fminf(best, d.pde_ub)) continue;   // best may have tightened since
+          if (box_dist2(q, d.cmeta[2 * (so + c)], d.cmeta[2 * (so + c) + 1]) >= score_lim(best, lbn, d.pde_ub)) continue;   // best may have tightened since
           best = fminf(best, wave_scan_cell(sp, st[c], st[c + 1], q, d.pde_lb, lane));
         }
         if (best <= d.pde_lb) break;
       }
     }
-    if (lane == 0 && best > d.pde_lb && best < d.pde_ub) atomicAdd(&d.pair_cnt[ko + pr], 1);
+    if (best > d.pde_lb && best < d.pde_ub) {
+      if (pr != acc_pr) { if (lane == 0 && acc) atomicAdd(&d.pair_cnt[ko + acc_pr], acc); acc_pr = pr; acc = 0; }
+      ++acc;
+    }
   }
+  if (lane == 0 && acc) atomicAdd(&d.pair_cnt[ko + acc_pr], acc);
 }
 
 // ------------------------------------------------------------------------------------ P4: method 2 (:309-334)
@@ -1455,7 +1622,7 @@ __global__ __launch_bounds__(MOR_BT) void k_decide(MorDev d) {
   for (int k = threadIdx.x; k < K; k += MOR_BT) { d.h_centroid[ko + k] = d.centroid[d.cur][ko + k]; d.h_det[ko + k] = d.det[ko + k]; }
   for (int k = threadIdx.x; k <= K; k += MOR_BT) d.h_cl_off[(size_t)s * (d.Kcap + 1) + k] = offc[k];
   if (threadIdx.x == 0) {
-    f.n_pairs = np; f.n_defer = (d.has_prev && d.method == 1) ? (uint32_t)d.wl2_n[s] : 0u; f.pad0 = (d.has_prev && d.method == 1) ? (uint32_t)d.wl_n[s] : 0u;
+    f.n_pairs = np; f.n_defer = (d.has_prev && d.method == 1) ? (uint32_t)d.wl2_n[s] : 0u; f.pad0 = (d.has_prev && d.method == 1) ? (uint32_t)(d.wl_n[s] + d.wlb_n[s]) : 0u;
     f.Kprev = d.has_prev ? d.info_prev[s].K : 0; f.Cprev = d.has_prev ? d.info_prev[s].C : 0;   // for the host mirror
     d.info[s].n_pairs = np;
     d.h_info[s] = f;
@@ -1853,8 +2020,10 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
   }
   MOR_LAUNCH(MK_HEADS_COUNT, k_heads_count, gM, d);
   MOR_LAUNCH(MK_HEADS_SCAN, k_heads_scan, gB, d);
+  if (d.use_hash) MOR_LAUNCH(MK_HASH_CLEAR, k_hash_clear, dim3(64, d.B), d);
   MOR_LAUNCH(MK_HEADS_SCATTER, k_heads_scatter, gM, d);
   MOR_LAUNCH(MK_ROWTABLE, k_rowtable, dim3((d.g.nrows + MOR_BT) / MOR_BT > 32 ? 32 : (d.g.nrows + MOR_BT) / MOR_BT, d.B), d);
+  if (d.gmode != 1) MOR_LAUNCH(MK_CELLBOXES, k_cellboxes, dim3(MOR_BOX_G * d.B), d);
 }
 
 void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
@@ -1866,7 +2035,7 @@ void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     hipMemsetD32Async((hipDeviceptr_t)(d.zmin_i + d.s0), 0x7fffffff, d.B, st);
     hipMemsetD32Async((hipDeviceptr_t)(d.zmax_i + d.s0), (int)0x80000000, d.B, st);
     hipMemsetAsync(d.is_ground + (size_t)d.s0 * d.Nmax, 0, (size_t)d.B * d.Nmax * sizeof(int), st);
-    MorDev da = d; da.gmode = 1; da.g = d.gv; da.cloud = d.rawbuf; da.cell_passes = d.voxel_passes; da.tiles_m = d.tiles;
+    MorDev da = d; da.gmode = 1; da.g = d.gv; da.cloud = d.rawbuf; da.cell_passes = d.voxel_passes; da.tiles_m = d.tiles; da.use_hash = 0;
     da.skey = d.rkeys[da.cell_passes & 1]; da.sidx = d.rvals[da.cell_passes & 1];
     mor_launch_split_and_grid(da, st, tm);
     MOR_LAUNCH(MK_G2_CENTROID, k_g2_centroid, dim3(32, d.B), da);
@@ -1920,7 +2089,7 @@ void mor_launch_mid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     MOR_LAUNCH(MK_NN, k_nn_centroid, gKt, d, 1);
     MOR_LAUNCH(MK_PAIRS, k_pairs, gB, d);
     if (d.method == 1) {
-      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * 8), d); MOR_LAUNCH(MK_SCORE_ROWS, k_score_rows, dim3(getenv("MOR_T1B") ? atoi(getenv("MOR_T1B")) : 128, d.B), d); }
+      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * 8), d); MOR_LAUNCH(MK_SCORE_NEAR, k_score_near, dim3(MOR_SCORE_G * d.B), d); }
     } else if (d.method == 2) {
       MOR_LAUNCH(MK_VOX_CLEAR, k_vox_clear, dim3(64, d.B), d);
       MOR_LAUNCH(MK_VOX_INSERT, k_vox_insert, gT, d);
@@ -1931,7 +2100,10 @@ void mor_launch_mid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
 
 void mor_launch_tail(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gB(d.B);
-  if (d.has_prev && d.method == 1 && d.pde_ub > 0.f && d.pde_ub > d.pde_lb) MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(getenv("MOR_T2G") ? atoi(getenv("MOR_T2G")) : 256, d.B), d);
+  if (d.has_prev && d.method == 1 && d.pde_ub > 0.f && d.pde_ub > d.pde_lb) {
+    MOR_LAUNCH(MK_SCORE_BLOCK, k_score_block, dim3(MOR_SCORE_G * d.B), d);
+    MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(MOR_PDE_G, d.B), d);
+  }
   MOR_LAUNCH(MK_DECIDE, k_decide, gB, d);
   mor_timer_begin(tm, MK_TRACK_PUSH, st);
   hipLaunchKernelGGL(k_track_push, gB, dim3(64), 0, st, d);
