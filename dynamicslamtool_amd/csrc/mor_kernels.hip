@@ -32,6 +32,15 @@ const char *const mor_kernel_names[MK_COUNT] = {
     "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "pairs", "score_fast", "score_near", "score_block", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
     "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_mode", "g2_mark", "track_push", "track_filter"};
 
+#ifdef MOR_EXP_STAMPS
+#define RS_T(v) const unsigned long long v = wall_clock64()
+#define RS_ADD(i, x) atomicAdd(&d.dbg[(size_t)s * 16 + (i)], (unsigned long long)(x))
+#define RS_MAX(i, x) atomicMax(&d.dbg[(size_t)s * 16 + (i)], (unsigned long long)(x))
+#else
+#define RS_T(v)
+#define RS_ADD(i, x)
+#define RS_MAX(i, x)
+#endif
 // ------------------------------------------------------------------------------------ helpers
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
@@ -717,6 +726,7 @@ template <bool LDS> __device__ __forceinline__ void cg_hook_pass(const MorDev &d
 // one workgroup per stream walked its cells alone.)
 __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
   int s, bx; map_block(d.B, MOR_BOX_G, s, bx);
+  RS_T(tb0);
   const int nocc = d.info[s].n_occ, sub = lane_id() & 15, grp = lane_id() >> 4;
   const size_t so = (size_t)s * d.Nmax;
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1);
@@ -749,6 +759,9 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
       }
     }
   }
+#ifdef MOR_EXP_STAMPS
+  if (lane_id() == 0) { RS_T(tb1); RS_MAX(8, ~tb0); RS_MAX(9, tb1); RS_ADD(10, tb1 - tb0); RS_ADD(11, 1); RS_MAX(12, tb1 - tb0); }
+#endif
 }
 template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int s, int nocc, const int *key, const int *start, const int *rows, int *par,
                                                               int *size, int *mn, int *cidr, int *l_list, int *l_nlist, int *l_misc) {
