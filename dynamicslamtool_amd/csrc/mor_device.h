@@ -35,6 +35,7 @@ struct MorRadix {
   int *vout2;             // optional second copy of the values (pass 0 of the cluster partition also writes cl_idx)
   int *hist;              // [B][tiles_max][256] histogram / offset scratch of this sort
   int skip_k_le;          // > 0: streams with K ≤ this need no further pass — the kernel returns at once for them
+  int fuse;               // k_rscatter derives the offsets from the raw histograms itself (no k_rscan launch; ≤ 64 tiles)
 };
 
 struct MorStreamArgs {       // per stream, per push (host → device, one small copy)
@@ -79,6 +80,7 @@ struct MorDev {
   int tiles;                 // ceil(max n_points of this batch / MOR_TILE)
   int tiles_m;               // workgroups per stream for kernels over the non-ground cloud / clusters: an estimate from the
                              // previous frame; those kernels grid-stride over the tiles a stream really has, so any value ≥ 1 is correct
+  int fuse_scans;            // tile-count scans re-derived inside the consuming kernels instead of one-workgroup scan launches (tables of ≤ 2048 tiles)
   int cur, prev, has_prev;   // cluster-array slots of cb and ca (four slots rotate: up to three frames are in flight in the stage pipeline); whether ca exists (:534)
   int run_tracker;           // filter: advance the tracking loop (first filterCloud of this frame)
   // ---- device arrays (per-stream stride noted)

@@ -74,6 +74,21 @@ __device__ __forceinline__ int block_excl_scan(int v, int *sh, int *total) {
   return base + inc - v;
 }
 
+// Σ c[i·stride] over i < t (prefix) and over i < nt (total), by the whole workgroup.  The per-tile count tables are a few
+// hundred ints, so every workgroup re-derives its own offset instead of waiting for a separate one-workgroup scan
+// kernel (a launch of ≈ 10 µs in the middle of each stage).  sh: ≥ 8 ints of LDS.
+__device__ __forceinline__ void wg_prefix_total(const int *c, int stride, int t, int nt, int *sh, int &prefix, int &total) {
+  int p = 0, a = 0;
+  for (int i = threadIdx.x; i < nt; i += MOR_BT) { const int v = c[(size_t)i * stride]; a += v; p += i < t ? v : 0; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { p += __shfl_xor(p, o, 64); a += __shfl_xor(a, o, 64); }
+  __syncthreads();
+  if (lane_id() == 0) { sh[wave_id()] = p; sh[4 + wave_id()] = a; }
+  __syncthreads();
+  prefix = sh[0] + sh[1] + sh[2] + sh[3]; total = sh[4] + sh[5] + sh[6] + sh[7];
+  __syncthreads();
+}
+
 #ifdef MOR_EXP_PLAIN_UF
 __device__ __forceinline__ int ld_agent(const int *p) { return *(const volatile int *)p; }
 __device__ __forceinline__ void st_agent(int *p, int v) { *(volatile int *)p = v; }
@@ -199,7 +214,17 @@ __global__ __launch_bounds__(MOR_BT) void k_classify(MorDev d) {
   }
 }
 
-// one workgroup per stream: exclusive scan of the tile counts; publishes N, T, M, G
+// N, T, M, G of the frame (and, for pass A of the voxel variant, the z origin of its grids)
+__device__ __forceinline__ void publish_split(const MorDev &d, int s, int n_ng, int n_g) {
+  MorFrameInfo &f = d.info[s];
+  f.M = n_ng; f.G = n_g; f.T = n_ng + n_g;
+  if (d.gmode != 2) { f.N = d.args[s].n; f.flags = 0; f.n_pairs = 0; f.K = 0; f.C = 0; }
+  if (d.gmode == 1) {   // grids of the voxel variant hang on the lowest trimmed point
+    float zmin = f.T ? ordered_float(d.zmin_i[s]) : 0.f;
+    d.zorg[s] = zmin; d.zbase[s] = (int)floorf(zmin * d.gv.inv_cs);
+  }
+}
+// one workgroup per stream: exclusive scan of the tile counts; publishes N, T, M, G  (only when fuse_scans is off)
 __global__ __launch_bounds__(MOR_BT) void k_scan_tiles(MorDev d) {
   int s = blockIdx.x + d.s0;
   __shared__ int sh[8];
@@ -212,17 +237,7 @@ __global__ __launch_bounds__(MOR_BT) void k_scan_tiles(MorDev d) {
     if (t < d.tiles) { int *o = d.tile_off + ((size_t)s * d.tiles_max + t) * 2; o[0] = carry_ng + e0; o[1] = carry_g + e1; }
     carry_ng += t0; carry_g += t1;
   }
-  if (threadIdx.x == 0) {
-    MorFrameInfo &f = d.info[s];
-    f.M = carry_ng; f.G = carry_g; f.T = carry_ng + carry_g;
-    if (d.gmode != 2) {
-      f.N = d.args[s].n; f.flags = 0; f.n_pairs = 0; f.K = 0; f.C = 0;
-    }
-    if (d.gmode == 1) {   // grids of the voxel variant hang on the lowest trimmed point
-      float zmin = f.T ? ordered_float(d.zmin_i[s]) : 0.f;
-      d.zorg[s] = zmin; d.zbase[s] = (int)floorf(zmin * d.gv.inv_cs);
-    }
-  }
+  if (threadIdx.x == 0) publish_split(d, s, carry_ng, carry_g);
 }
 
 // pass 2: order-preserving split into `cloud` / ground, cell histogram, forest init
@@ -231,6 +246,15 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   const MorStreamArgs a = d.args[s];
   const uint32_t n_in = pass_count(d, a, s);
   uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
+  __shared__ int sh[8];
+  int r_ng = 0, r_g = 0; float zorg = d.zorg[s]; int zbase = d.zbase[s];
+  if (d.fuse_scans) {   // own offsets from the per-tile counts of k_classify; tile 0 publishes the totals
+    const int *tc = d.tile_cnt + (size_t)s * d.tiles_max * 2; int tot_ng, tot_g;
+    wg_prefix_total(tc, 2, t, d.tiles, sh, r_ng, tot_ng);
+    wg_prefix_total(tc + 1, 2, t, d.tiles, sh, r_g, tot_g);
+    if (d.gmode == 1) { zorg = (tot_ng + tot_g) ? ordered_float(d.zmin_i[s]) : 0.f; zbase = (int)floorf(zorg * d.gv.inv_cs); }
+    if (t == 0 && threadIdx.x == 0) publish_split(d, s, tot_ng, tot_g);
+  }
   if ((uint32_t)t * MOR_TILE >= n_in) return;
   float4 p[8]; int cls[8]; unsigned long long m_ng[8], m_g[8];
   int c_ng = 0, c_g = 0;
@@ -242,11 +266,9 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
     m_ng[it] = __ballot(cls[it] == 2); m_g[it] = __ballot(cls[it] == 1);
     c_ng += __popcll(m_ng[it]); c_g += __popcll(m_g[it]);
   }
-  __shared__ int sh[8];
   if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
   __syncthreads();
-  const int *to = d.tile_off + ((size_t)s * d.tiles_max + t) * 2;
-  int r_ng = to[0], r_g = to[1];
+  if (!d.fuse_scans) { const int *to = d.tile_off + ((size_t)s * d.tiles_max + t) * 2; r_ng = to[0]; r_g = to[1]; }
   for (int w = 0; w < wave_id(); ++w) { r_ng += sh[w]; r_g += sh[4 + w]; }
   const size_t so = (size_t)s * d.Nmax;
 #pragma unroll
@@ -254,7 +276,7 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
     int k_ng = r_ng + __popcll(m_ng[it] & lanemask_lt());
     int k_g = r_g + __popcll(m_g[it] & lanemask_lt());
     if (cls[it] == 2) {
-      int cx, cy, cz; bool clamped; grid_cell(d.g, p[it], d.zorg[s], d.zbase[s], cx, cy, cz, clamped);
+      int cx, cy, cz; bool clamped; grid_cell(d.g, p[it], zorg, zbase, cx, cy, cz, clamped);
       if (clamped && d.gmode != 0) atomicOr(&d.info[s].flags, 8u);   // z extent beyond the grid: cells would no longer be cliques / voxels
       d.cloud[so + k_ng] = p[it];
       d.cloud_tidx[so + k_ng] = k_ng + k_g;   // index in the trimmed cloud (both ranks are exclusive counts of earlier kept points)
@@ -331,9 +353,17 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
   const size_t so = (size_t)s * d.Nmax;
   const int *skey = d.skey + so, *sidx = d.sidx + so;
   int *cstart = d.cstart + (size_t)s * (d.Nmax + 1);
-  __shared__ int sh[4];
-  unsigned long long *tab = d.use_hash ? d.chash + (size_t)s * d.Hcell : nullptr;
-  const unsigned hshift = d.info[s].hshift, hmask = (1u << (32 - hshift)) - 1u;
+  __shared__ int sh[12];
+  const int nt = (M + MOR_TILE - 1) / MOR_TILE;
+  if (d.fuse_scans) {   // number of occupied cells: every workgroup sums the tile counts itself (no separate scan launch)
+    int pre, nocc; wg_prefix_total(d.ktile_cnt + (size_t)s * d.tiles_max, 1, 0, nt, sh, pre, nocc);
+    int bits = 10; while ((1 << bits) < 4 * nocc && (1 << bits) < d.Hcell) ++bits;   // cell hash: load factor ≤ 1/4
+    if (t0 == 0 && threadIdx.x == 0) { d.info[s].n_occ = nocc; cstart[nocc] = M; d.info[s].hshift = 32 - bits; }
+    if (d.use_hash) {   // the stream's workgroups clear its table; k_rowtable inserts the cells
+      unsigned long long *tab = d.chash + (size_t)s * d.Hcell;
+      for (int i = t0 * MOR_BT + threadIdx.x; i < (1 << bits); i += d.tiles_m * MOR_BT) tab[i] = 0ull;
+    }
+  }
   for (int t = t0; t * MOR_TILE < M; t += d.tiles_m) {
     const int base = t * MOR_TILE + wave_id() * 512;
     unsigned long long mh[8]; int cnt = 0;
@@ -341,7 +371,9 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
     for (int it = 0; it < 8; ++it) { int p = base + it * 64 + lane_id(); mh[it] = __ballot(p < M && is_head(skey, p)); cnt += __popcll(mh[it]); }
     if (lane_id() == 0) sh[wave_id()] = cnt;
     __syncthreads();
-    int r = d.ktile_cnt[(size_t)s * d.tiles_max + t];
+    int r;
+    if (d.fuse_scans) { int tot; wg_prefix_total(d.ktile_cnt + (size_t)s * d.tiles_max, 1, t, nt, sh + 4, r, tot); }
+    else r = d.ktile_cnt[(size_t)s * d.tiles_max + t];
     for (int w = 0; w < wave_id(); ++w) r += sh[w];
     __syncthreads();
 #pragma unroll
@@ -354,11 +386,6 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
         if (head) {
           d.ckey[so + c] = skey[p]; cstart[c] = p; d.cmin[so + c] = i;   // stable sort ⇒ first of the cell = smallest cloud index
           d.parent[so + c] = c; d.csize[so + c] = 0; d.compmin[so + c] = 0x7fffffff; d.cid_of_root[so + c] = -1;
-          if (tab) {
-            const int key = skey[p]; unsigned sl = hash_slot(key, hshift);
-            const unsigned long long ent = ((unsigned long long)((unsigned)key + 1u) << 32) | (unsigned)c;
-            while (atomicCAS(&tab[sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
-          }
         }
         d.cell_of[so + i] = c;
         float4 q = d.cloud[so + i]; q.w = __int_as_float(i);
@@ -378,6 +405,15 @@ __global__ __launch_bounds__(MOR_BT) void k_rowtable(MorDev d) {
     if (r == d.g.nrows) a = nocc;
     else while (a < b) { int m = (a + b) >> 1; if (ckey[m] < k) a = m + 1; else b = m; }
     rs[r] = a;
+  }
+  if (d.use_hash) {   // cell hash: (key+1, compact id); the table was cleared by the previous kernel
+    unsigned long long *tab = d.chash + (size_t)s * d.Hcell;
+    const unsigned hshift = d.info[s].hshift, hmask = (1u << (32 - hshift)) - 1u;
+    for (int c = blockIdx.x * MOR_BT + threadIdx.x; c < nocc; c += gridDim.x * MOR_BT) {
+      const int key = ckey[c]; unsigned sl = hash_slot(key, hshift);
+      const unsigned long long ent = ((unsigned long long)((unsigned)key + 1u) << 32) | (unsigned)c;
+      while (atomicCAS(&tab[sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
+    }
   }
 }
 
@@ -636,6 +672,11 @@ __device__ __forceinline__ void wave_box(const float4 *sp, int b, int e, int lan
   lo = make_float4(lx, ly, lz, 0.f); hi = make_float4(hx, hy, hz, 0.f);
 }
 
+#ifdef MOR_EXP_STAMPS
+#define CG_CNT(i, x) atomicAdd(&d.dbg[(size_t)s * 16 + 8 + (RING - 1) * 4 + (i)], (unsigned long long)(x))
+#else
+#define CG_CNT(i, x)
+#endif
 // one hook pass over the forward half of the (2·RING+1)³ neighbourhood, ring == RING only
 template <bool LDS> __device__ __forceinline__ void cg_hook_pass(const MorDev &d, int s, int nocc, int RING, const int *key, const int *start, const int *rows, int *par,
                                                                    const float4 *sp, int *l_list, int *l_nlist) {
@@ -667,6 +708,7 @@ template <bool LDS> __device__ __forceinline__ void cg_hook_pass(const MorDev &d
           }
         }
         if (cb[0] < 0 && cb[1] < 0 && cb[2] < 0 && cb[3] < 0 && cb[4] < 0) continue;
+        CG_CNT(0, (cb[0] >= 0) + (cb[1] >= 0) + (cb[2] >= 0) + (cb[3] >= 0) + (cb[4] >= 0)); CG_CNT(3, 1);
         if (!have_box) { alo = d.cmeta[2 * (so_ + a)]; ahi = d.cmeta[2 * (so_ + a) + 1]; have_box = true; }
 #pragma unroll
         for (int u = 0; u < 5; ++u) if (cb[u] >= 0) { blo[u] = d.cmeta[2 * (so_ + cb[u])]; bhi[u] = d.cmeta[2 * (so_ + cb[u]) + 1]; }
@@ -676,12 +718,13 @@ template <bool LDS> __device__ __forceinline__ void cg_hook_pass(const MorDev &d
           if (b < 0) continue;
           // boxes of the two cells' points: gap ≥ r ⇒ no edge; farthest corners < r ⇒ every pair is an edge
           float gx = fmaxf(fmaxf(blo[u].x - ahi.x, alo.x - bhi[u].x), 0.f), gy = fmaxf(fmaxf(blo[u].y - ahi.y, alo.y - bhi[u].y), 0.f), gz = fmaxf(fmaxf(blo[u].z - ahi.z, alo.z - bhi[u].z), 0.f);
-          if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) continue;
+          if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) { CG_CNT(1, 1); continue; }
           float sx = fmaxf(bhi[u].x - alo.x, ahi.x - blo[u].x), sy = fmaxf(bhi[u].y - alo.y, ahi.y - blo[u].y), sz = fmaxf(bhi[u].z - alo.z, ahi.z - blo[u].z);
           bool edge = (sx * sx + sy * sy + sz * sz) * 1.001f < r2;
           if (!edge) {
             if (u > 0 && cg_find<LDS>(par, b) == ra) continue;         // an earlier union of this row may have merged it
             const int b0 = start[b], nb = start[b + 1] - b0;
+            CG_CNT(2, 1);
             if ((long long)na * nb > 256) {
               // big × big: dense neighbouring cells nearly always show an edge within a small sample of pairs;
               // what is left (mostly true non-edges) goes to a whole wave
@@ -760,7 +803,7 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
     }
   }
 #ifdef MOR_EXP_STAMPS
-  if (lane_id() == 0) { RS_T(tb1); RS_MAX(8, ~tb0); RS_MAX(9, tb1); RS_ADD(10, tb1 - tb0); RS_ADD(11, 1); RS_MAX(12, tb1 - tb0); }
+
 #endif
 }
 template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int s, int nocc, const int *key, const int *start, const int *rows, int *par,
@@ -986,7 +1029,7 @@ __global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, MorRadix j) {
   int s, t0; map_block(d.B, d.tiles_m, s, t0);
   const int count = radix_count(d, j, s);
   const size_t so = (size_t)s * d.Nmax;
-  __shared__ int wcnt[4][256];
+  __shared__ int wcnt[4][256]; __shared__ int shs[8];
   for (int t = t0; t * MOR_TILE < count; t += d.tiles_m) {
     const int tb = t * MOR_TILE;
     for (int k = threadIdx.x; k < 4 * 256; k += MOR_BT) (&wcnt[0][0])[k] = 0;
@@ -1011,7 +1054,17 @@ __global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, MorRadix j) {
     }
     __syncthreads();
     {  // exclusive prefix over the 4 waves per digit + global offset of (tile, digit)
-      int dg = threadIdx.x, run = j.hist[((size_t)s * d.tiles_max + t) * 256 + dg];
+      int dg = threadIdx.x, run;
+      if (j.fuse) {   // raw per-tile histograms: Σ smaller digits (all tiles) + Σ earlier tiles (this digit), re-derived per workgroup
+        const int *hh = j.hist + (size_t)s * d.tiles_max * 256 + dg; const int nt = (count + MOR_TILE - 1) / MOR_TILE;
+        int before = 0, all = 0, u = 0;
+        for (; u + 4 <= nt; u += 4) {
+          const int v0 = hh[u * 256], v1 = hh[(u + 1) * 256], v2 = hh[(u + 2) * 256], v3 = hh[(u + 3) * 256];
+          all += v0 + v1 + v2 + v3; before += (u < t ? v0 : 0) + (u + 1 < t ? v1 : 0) + (u + 2 < t ? v2 : 0) + (u + 3 < t ? v3 : 0);
+        }
+        for (; u < nt; ++u) { const int v = hh[u * 256]; all += v; before += u < t ? v : 0; }
+        int tot; run = block_excl_scan(all, shs, &tot) + before;
+      } else run = j.hist[((size_t)s * d.tiles_max + t) * 256 + dg];
 #pragma unroll
       for (int w = 0; w < 4; ++w) { int v = wcnt[w][dg]; wcnt[w][dg] = run; run += v; }
     }
@@ -1683,13 +1736,19 @@ __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
   int s, t2; map_block(d.B, d.tiles_m + d.tiles, s, t2);
   const size_t so = (size_t)s * d.Nmax;
   float4 *out = d.out_ptrs ? d.out_ptrs[s] : d.out + so;
+  const int M = d.info[s].M;
+  __shared__ int sh[12];
+  const int nto = (M + MOR_TILE - 1) / MOR_TILE;
+  int n_keep = 0;
+  if (d.fuse_scans) {   // kept points in total: every workgroup sums the per-tile counts of k_out_count itself
+    int pre; wg_prefix_total(d.otile_cnt + (size_t)s * d.tiles_max, 1, 0, nto, sh, pre, n_keep);
+    if (t2 == 0 && threadIdx.x == 0) { d.info[s].n_keep = n_keep; d.h_nout[s] = (unsigned long long)n_keep + d.info[s].G; }
+  } else n_keep = d.info[s].n_keep;
   if (t2 >= d.tiles_m) {
-    int t = t2 - d.tiles_m, G = d.info[s].G, nk = d.info[s].n_keep, base = t * MOR_TILE;
+    int t = t2 - d.tiles_m, G = d.info[s].G, nk = n_keep, base = t * MOR_TILE;
     for (int i = base + threadIdx.x; i < min(base + MOR_TILE, G); i += MOR_BT) out[nk + i] = d.ground[so + i];
     return;
   }
-  const int M = d.info[s].M;
-  __shared__ int sh[4];
   for (int t = t2; t * MOR_TILE < M; t += d.tiles_m) {
     int base = t * MOR_TILE + wave_id() * 512, c = 0;
     unsigned long long mk[8];
@@ -1697,7 +1756,9 @@ __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
     for (int it = 0; it < 8; ++it) { int i = base + it * 64 + lane_id(); mk[it] = __ballot(i < M && out_keep(d, s, so, i)); c += __popcll(mk[it]); }
     if (lane_id() == 0) sh[wave_id()] = c;
     __syncthreads();
-    int r = d.otile_cnt[(size_t)s * d.tiles_max + t];
+    int r;
+    if (d.fuse_scans) { int tot; wg_prefix_total(d.otile_cnt + (size_t)s * d.tiles_max, 1, t, nto, sh + 4, r, tot); }
+    else r = d.otile_cnt[(size_t)s * d.tiles_max + t];
     for (int w = 0; w < wave_id(); ++w) r += sh[w];
     __syncthreads();
 #pragma unroll
@@ -2023,17 +2084,19 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
 static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B);
   MOR_LAUNCH(MK_CLASSIFY, k_classify, gT, d);
-  MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
+  if (!d.fuse_scans) MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
   MOR_LAUNCH(MK_SCATTER, k_scatter, gT, d);
   for (int pass = 0; pass < d.cell_passes; ++pass) {   // points sorted by cell key; result in (skey, sidx) = buffers [cell_passes & 1]
-    MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0};
+    MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0, d.fuse_scans && d.tiles_m <= 64};
     MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
-    MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
+    if (!j.fuse) MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
     MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
   }
   MOR_LAUNCH(MK_HEADS_COUNT, k_heads_count, gM, d);
-  MOR_LAUNCH(MK_HEADS_SCAN, k_heads_scan, gB, d);
-  if (d.use_hash) MOR_LAUNCH(MK_HASH_CLEAR, k_hash_clear, dim3(64, d.B), d);
+  if (!d.fuse_scans) {
+    MOR_LAUNCH(MK_HEADS_SCAN, k_heads_scan, gB, d);
+    if (d.use_hash) MOR_LAUNCH(MK_HASH_CLEAR, k_hash_clear, dim3(64, d.B), d);
+  }
   MOR_LAUNCH(MK_HEADS_SCATTER, k_heads_scatter, gM, d);
   MOR_LAUNCH(MK_ROWTABLE, k_rowtable, dim3((d.g.nrows + MOR_BT) / MOR_BT > 32 ? 32 : (d.g.nrows + MOR_BT) / MOR_BT, d.B), d);
   if (d.gmode != 1) MOR_LAUNCH(MK_CELLBOXES, k_cellboxes, dim3(MOR_BOX_G * d.B), d);
@@ -2088,9 +2151,9 @@ void mor_launch_mid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     // every pass also writes cl_idx: a stream with K ≤ 256^p has its final order after pass p−1 and later passes
     // return at once for it (K ≤ 256 is the usual case: one effective pass)
     MorRadix j = {pass == 0 ? d.pcid : d.rkeys2[pass & 1], pass == 0 ? nullptr : d.rvals2[pass & 1], last ? nullptr : d.rkeys2[(pass + 1) & 1], last ? d.cl_idx : d.rvals2[(pass + 1) & 1],
-                  8 * pass, pass == 0 ? 0 : 1, pass == 0 ? 1 : 0, last ? nullptr : d.cl_idx, d.rhist2, pass == 0 ? 0 : (1 << (8 * pass))};
+                  8 * pass, pass == 0 ? 0 : 1, pass == 0 ? 1 : 0, last ? nullptr : d.cl_idx, d.rhist2, pass == 0 ? 0 : (1 << (8 * pass)), d.fuse_scans && d.tiles_m <= 64};
     MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
-    MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
+    if (!j.fuse) MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
     MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
   }
   MOR_LAUNCH(MK_STATS, k_stats, dim3(64, d.B), d);
@@ -2131,6 +2194,6 @@ void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     mor_timer_end(tm, MK_TRACK_FILTER, st);
   }
   MOR_LAUNCH(MK_OUT_COUNT, k_out_count, gM, d);
-  MOR_LAUNCH(MK_OUT_SCAN, k_out_scan, gB, d);
+  if (!d.fuse_scans) MOR_LAUNCH(MK_OUT_SCAN, k_out_scan, gB, d);
   MOR_LAUNCH(MK_OUT_SCATTER, k_out_scatter, gT2, d);
 }

@@ -5,13 +5,21 @@ from dynamicslamtool_amd import engine, kitti_params, synth
 B = 64
 p = kitti_params(1)
 b = engine.MorBatch(p, B, 120000)
+L = engine.lib(); L.mor_exp_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
+out = np.zeros((B, 16), np.uint64)
 for f in range(4):
     xs, ps = synth.batch([2000 + s for s in range(B)], [f] * B)
+    if f == 3: L.mor_exp_read_stamps(b._h, out.ctypes.data)
     b.push(list(xs), ps); b.filter(to_host=False)
-L = engine.lib(); L.mor_exp_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
-out = np.zeros((B, 16), np.uint64); L.mor_exp_read_stamps(b._h, out.ctypes.data)
+L.mor_exp_read_stamps(b._h, out.ctypes.data)
 d = np.diff(out[:, :7].astype(np.int64), axis=1) / 100.0   # 100 MHz → µs
 names = ["load", "boxes", "near", "shell", "comp", "select+rank+off"]
 print("per-phase µs: mean / max over streams")
 for i, n in enumerate(names): print("  %-16s %8.1f %8.1f" % (n, d[:, i].mean(), d[:, i].max()))
 print("total mean %.1f max %.1f; kernel span %.1f" % (d.sum(1).mean(), d.sum(1).max(), (out[:, 6].max() - out[:, 0].min()) / 100.0))
+
+c = out[:, 8:16].astype(np.float64)
+tot = d.sum(1); hv = np.argsort(-tot)[:5]
+print("counters per stream (mean | five slowest streams): near cand / boxrej / pointtests / rows-with-cand ; shell same")
+print(np.round(c.mean(0)), "nocc?")
+for s_ in hv: print(int(s_), "total %.0f near %.0f shell %.0f" % (tot[s_], d[s_, 2], d[s_, 3]), c[s_].astype(int))
