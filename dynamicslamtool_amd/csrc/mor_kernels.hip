@@ -678,7 +678,7 @@ __device__ __forceinline__ void wave_box(const float4 *sp, int b, int e, int lan
 #define CG_CNT(i, x)
 #endif
 // one hook pass over the forward half of the (2·RING+1)³ neighbourhood, ring == RING only
-template <bool LDS> __device__ __forceinline__ void cg_hook_pass(const MorDev &d, int s, int nocc, int RING, const int *key, const int *start, const int *rows, int *par,
+template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const MorDev &d, int s, int nocc, const int *key, const int *start, const int *rows, int *par,
                                                                    const float4 *sp, int *l_list, int *l_nlist) {
   const float r2 = d.r2;
   const size_t so_ = (size_t)s * d.Nmax;
@@ -692,23 +692,30 @@ template <bool LDS> __device__ __forceinline__ void cg_hook_pass(const MorDev &d
       for (int dy = (dz == 0 ? 0 : -RING); dy <= RING; ++dy) {
         if ((unsigned)(y + dy) >= (unsigned)d.g.ny) continue;
         const bool edge_row = dz == RING || abs(dy) == RING;   // every cell of this row lies on the ring
-        int lo, hi; row_cells(d.g, key, rows, max(x - RING, 0), min(x + RING, d.g.nx - 1), y + dy, z + dz, lo, hi);
-        if (lo >= hi) continue;
-        // ≤ 2·RING+1 ≤ 5 cells in the run: filter on LDS data only, then fetch the survivors' boxes together
-        const int rowbase = ((z + dz) * d.g.ny + (y + dy)) * d.g.nx + x;
-        int cb[5]; float4 blo[5], bhi[5];
+        const int rr = (z + dz) * d.g.ny + (y + dy), rlo = rows[rr], rn = rows[rr + 1] - rlo;
+        if (rn == 0) continue;
+        // ≤ 2·RING+1 ≤ 5 cells of the row lie within RING of x.  A short row is walked with a plain loop over its real
+        // cell count (a few instructions and two LDS loads per cell; a fixed 8-wide batch cost every wave its full
+        // width); a cell whose parent is a's root is skipped on the first load (the forest is flattened between passes)
+        const int rowbase = rr * d.g.nx + x;
+        int cb[5]; float4 blo[5], bhi[5]; int nc = 0;
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-          int b = lo + u; cb[u] = -1;
-          if (b < hi) {
-            const int dx = key[b] - rowbase;
-            const bool fwd = !(dz == 0 && dy == 0 && dx <= 0);      // forward half: each unordered pair once
-            const bool ring = edge_row || abs(dx) == RING;           // inner cells belong to the previous pass
-            if (fwd && ring && cg_find<LDS>(par, b) != ra) cb[u] = b;
-          }
+        for (int u = 0; u < 5; ++u) cb[u] = -1;
+        int lo = rlo, hi = rlo + rn;
+        if (rn > 8) row_cells(d.g, key, rows, max(x - RING, 0), min(x + RING, d.g.nx - 1), y + dy, z + dz, lo, hi);
+        for (int b = lo; b < hi; ++b) {
+          const int dx = key[b] - rowbase;
+          if (abs(dx) > RING) continue;
+          const bool fwd = !(dz == 0 && dy == 0 && dx <= 0);      // forward half: each unordered pair once
+          const bool ring = edge_row || abs(dx) == RING;           // inner cells belong to the previous pass
+          if (!fwd || !ring) continue;
+          const int pb = cg_ld<LDS>(par + b);
+          if (pb == ra || cg_find<LDS>(par, b) == ra) continue;
+#pragma unroll
+          for (int u = 0; u < 5; ++u) if (nc == u) cb[u] = b;
+          ++nc;
         }
-        if (cb[0] < 0 && cb[1] < 0 && cb[2] < 0 && cb[3] < 0 && cb[4] < 0) continue;
-        CG_CNT(0, (cb[0] >= 0) + (cb[1] >= 0) + (cb[2] >= 0) + (cb[3] >= 0) + (cb[4] >= 0)); CG_CNT(3, 1);
+        if (nc == 0) continue;
         if (!have_box) { alo = d.cmeta[2 * (so_ + a)]; ahi = d.cmeta[2 * (so_ + a) + 1]; have_box = true; }
 #pragma unroll
         for (int u = 0; u < 5; ++u) if (cb[u] >= 0) { blo[u] = d.cmeta[2 * (so_ + cb[u])]; bhi[u] = d.cmeta[2 * (so_ + cb[u]) + 1]; }
@@ -718,13 +725,12 @@ template <bool LDS> __device__ __forceinline__ void cg_hook_pass(const MorDev &d
           if (b < 0) continue;
           // boxes of the two cells' points: gap ≥ r ⇒ no edge; farthest corners < r ⇒ every pair is an edge
           float gx = fmaxf(fmaxf(blo[u].x - ahi.x, alo.x - bhi[u].x), 0.f), gy = fmaxf(fmaxf(blo[u].y - ahi.y, alo.y - bhi[u].y), 0.f), gz = fmaxf(fmaxf(blo[u].z - ahi.z, alo.z - bhi[u].z), 0.f);
-          if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) { CG_CNT(1, 1); continue; }
+          if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) continue;
           float sx = fmaxf(bhi[u].x - alo.x, ahi.x - blo[u].x), sy = fmaxf(bhi[u].y - alo.y, ahi.y - blo[u].y), sz = fmaxf(bhi[u].z - alo.z, ahi.z - blo[u].z);
           bool edge = (sx * sx + sy * sy + sz * sz) * 1.001f < r2;
           if (!edge) {
             if (u > 0 && cg_find<LDS>(par, b) == ra) continue;         // an earlier union of this row may have merged it
             const int b0 = start[b], nb = start[b + 1] - b0;
-            CG_CNT(2, 1);
             if ((long long)na * nb > 256) {
               // big × big: dense neighbouring cells nearly always show an edge within a small sample of pairs;
               // what is left (mostly true non-edges) goes to a whole wave
@@ -815,9 +821,11 @@ template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int
   // (the boxes of the cells' points were written by k_cellboxes at the end of the grid stage)
   CG_STAMP(2);
   // ---- hooks: 3×3×3 neighbourhood first, then the 5×5×5 shell (mostly skipped by the root test)
-  cg_hook_pass<LDS>(d, s, nocc, 1, key, start, rows, par, sp, l_list, l_nlist);
+  cg_hook_pass<LDS, 1>(d, s, nocc, key, start, rows, par, sp, l_list, l_nlist);
   CG_STAMP(3);
-  cg_hook_pass<LDS>(d, s, nocc, 2, key, start, rows, par, sp, l_list, l_nlist);
+  for (int c = threadIdx.x; c < nocc; c += CG_T) { const int r = cg_find<LDS>(par, c); if (r != c) cg_st<LDS>(par + c, r); }   // flat forest: the shell pass compares parents directly
+  __syncthreads();
+  cg_hook_pass<LDS, 2>(d, s, nocc, key, start, rows, par, sp, l_list, l_nlist);
   CG_STAMP(4);
   // ---- components: size (points) and smallest cloud index at the root; `size`/`mn` may alias key/start ⇒ read first
   constexpr int PER = LDS ? CG_CAP / CG_T : 1;

@@ -19,7 +19,6 @@ for i, n in enumerate(names): print("  %-16s %8.1f %8.1f" % (n, d[:, i].mean(), 
 print("total mean %.1f max %.1f; kernel span %.1f" % (d.sum(1).mean(), d.sum(1).max(), (out[:, 6].max() - out[:, 0].min()) / 100.0))
 
 c = out[:, 8:16].astype(np.float64)
-tot = d.sum(1); hv = np.argsort(-tot)[:5]
-print("counters per stream (mean | five slowest streams): near cand / boxrej / pointtests / rows-with-cand ; shell same")
-print(np.round(c.mean(0)), "nocc?")
-for s_ in hv: print(int(s_), "total %.0f near %.0f shell %.0f" % (tot[s_], d[s_, 2], d[s_, 3]), c[s_].astype(int))
+for nm, o in (("near", 0), ("shell", 4)):
+    print("%s: non-empty (cell,row) visits per stream mean %.0f, of them rows > 8 cells %.0f, > 32 cells %.0f" % (nm, c[:, o].mean(), c[:, o + 1].mean(), c[:, o + 2].mean()))
+print("n_occ mean", np.mean([b.stage_counts(s_)["n_occ"] for s_ in range(B)]))
