@@ -76,6 +76,7 @@ struct mor_batch {
   std::vector<void *> dev_allocs, host_allocs;
   MorStreamArgs *h_args_ring = nullptr, *h_args = nullptr;   // pinned ring of MOR_ARGS_RING slots (async pushes), current slot
   hipEvent_t args_ev[MOR_ARGS_RING] = {};
+  uint64_t pipe_depth = 3;
   bool async = false, pending = false;   // async: push/filter only enqueue; pending: work enqueued since the last wait
   unsigned char *d_moving = nullptr;
   float4 **h_outptrs = nullptr, **d_outptrs = nullptr;
@@ -232,11 +233,14 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (hipSetDevice(device) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipSetDevice(%d) failed", device));
   b = new mor_batch(); memset(&b->d, 0, sizeof b->d);
   b->p = *p; b->n_bad = n_bad; b->n_good = n_good; b->B = n_streams; b->device = device; b->Nmax = max_points;
+  if (getenv("MOR_PIPE_DEPTH")) b->pipe_depth = std::min(3, std::max(1, atoi(getenv("MOR_PIPE_DEPTH"))));
   if ((rc = configure(b)) != MOR_OK) return fail(rc);
   if (n_bad > MOR_TR_NB) return fail(set_error(MOR_ERR_INVALID, "n_bad = %d: windows longer than %d frames are not supported", n_bad, MOR_TR_NB));
   for (auto &ev : b->args_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   if (hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
   for (auto &e : b->ev) if (hipEventCreate(&e) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+  // (Tried and measured without effect on the pipeline: highest stream priority for the cell-graph stream, and CU masks
+  //  that give it 32-96 CUs of its own.)
   if (hipStreamCreateWithFlags(&b->sf, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sc, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sm, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sb, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
   for (auto &ev : b->ev_grid) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_cg) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
@@ -365,7 +369,10 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   }
   // ---- grid stage on sf: must not overwrite what frame k−3 still uses (same buffer copy; its cluster slot doubles as
   //      the `ca` slot of frame k−3... and the `cb` slot of frame k−4)
-  if (k >= 3) HIP_TRY(hipStreamWaitEvent(b->sf, b->ev_back[(k - 3) % 4], 0));
+  {
+    const uint64_t depth = b->pipe_depth;   // frames in flight: 3 = what the buffers allow; fewer = less overlap
+    if (k >= depth) HIP_TRY(hipStreamWaitEvent(b->sf, b->ev_back[(k - depth) % 4], 0));
+  }
   for (int s = 0; s < B; ++s) {   // host-resident blobs are staged through device memory
     const mor_cloud_view &c = clouds[s];
     if (!c.on_device && c.n_points) HIP_TRY(hipMemcpyAsync((void *)b->h_args[s].data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, b->sf));
