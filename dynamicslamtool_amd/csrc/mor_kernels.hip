@@ -597,7 +597,7 @@ __global__ __launch_bounds__(MOR_BT) void k_select_scatter(MorDev d) {
 // selection, ordering and offsets — nine launches of the general path.  Streams whose cell count
 // exceeds the LDS capacity run the same code on their global-memory arrays.
 #define CG_T 1024
-#define CG_CAP 8192      // occupied cells held in LDS
+#define CG_CAP 12288     // occupied cells held in LDS (keys + union-find forest; point ranges stay in global memory)
 #define CG_ROWCAP 8192   // (y,z) rows held in LDS
 #define CG_LIST 2040     // deferred (cell | cell pair) entries
 
@@ -644,15 +644,31 @@ __device__ __forceinline__ bool pair_hit_serial(const float4 *sp, int a0, int na
   return false;
 }
 // the same question answered by a whole wave: lanes tile A × B as at × (64/at)
-__device__ __forceinline__ bool pair_hit_wave(const float4 *sp, int a0, int na, int b0, int nb, float r2, int lane) {
-  int sh = 0; while ((1 << sh) < na && sh < 6) ++sh;
-  const int at = 1 << sh, bt = 64 >> sh, la = lane & (at - 1), lb = lane >> sh;
-  for (int ia0 = 0; ia0 < na; ia0 += at) {
-    const int ia = ia0 + la; const float4 pa = sp[a0 + min(ia, na - 1)];
-    for (int ib0 = 0; ib0 < nb; ib0 += bt) {
-      const int ib = ib0 + lb; const float4 pb = sp[b0 + min(ib, nb - 1)];
-      bool h = ia < na && ib < nb && sqdist(pa.x, pa.y, pa.z, pb.x, pb.y, pb.z) < r2;
-      if (__ballot(h)) return true;
+// squared distance from p to the box [lo, hi], scaled down a hair: ≥ r² ⇒ no point of the box is within r of p
+__device__ __forceinline__ float point_box_gap2(const float4 &p, const float4 &lo, const float4 &hi) {
+  float gx = fmaxf(fmaxf(lo.x - p.x, p.x - hi.x), 0.f), gy = fmaxf(fmaxf(lo.y - p.y, p.y - hi.y), 0.f), gz = fmaxf(fmaxf(lo.z - p.z, p.z - hi.z), 0.f);
+  return (gx * gx + gy * gy + gz * gz) * 0.999f;
+}
+// any pair (a ∈ A, b ∈ B) with d² < r²?  One wave, for the pairs of big cells the thread-level sample could not decide
+// (mostly true non-edges: two dense surfaces a cell apart).  A and B are read in coalesced chunks of 64 points; a point
+// takes part only if it lies within r of the OTHER cell's point box, which removes nearly everything when the cells
+// are two apart; the surviving B points of a chunk are broadcast by shuffles — no memory access in the inner loop.
+__device__ __forceinline__ bool pair_hit_wave(const float4 *sp, int a0, int na, int b0, int nb, float r2, int lane,
+                                              const float4 &alo, const float4 &ahi, const float4 &blo, const float4 &bhi) {
+  for (int ia0 = 0; ia0 < na; ia0 += 64) {
+    const int ia = ia0 + lane; const float4 pa = sp[a0 + min(ia, na - 1)];
+    const bool a_act = ia < na && point_box_gap2(pa, blo, bhi) < r2;
+    if (!__ballot(a_act)) continue;
+    for (int ib0 = 0; ib0 < nb; ib0 += 64) {
+      const int ib = ib0 + lane; const float4 pb = sp[b0 + min(ib, nb - 1)];
+      unsigned long long mb = __ballot(ib < nb && point_box_gap2(pb, alo, ahi) < r2);
+      bool hit = false;
+      while (mb) {
+        const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
+        const float bx = __shfl(pb.x, l, 64), by = __shfl(pb.y, l, 64), bz = __shfl(pb.z, l, 64);
+        hit |= a_act && sqdist(pa.x, pa.y, pa.z, bx, by, bz) < r2;
+      }
+      if (__ballot(hit)) return true;
     }
   }
   return false;
@@ -682,9 +698,10 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
                                                                    const float4 *sp, int *l_list, int *l_nlist) {
   const float r2 = d.r2;
   const size_t so_ = (size_t)s * d.Nmax;
+  for (bool again = true; again;) {
   for (int a = threadIdx.x; a < nocc; a += CG_T) {
     const int ka = key[a], rowa = ka / d.g.nx, x = ka - rowa * d.g.nx, y = rowa % d.g.ny, z = rowa / d.g.ny;
-    const int a0 = start[a], na = start[a + 1] - a0;
+    int a0 = -1, na = 0;   // point range of a: fetched from global memory when the first point test needs it
     int ra = cg_find<LDS>(par, a);
     float4 alo, ahi; bool have_box = false;
     for (int dz = 0; dz <= RING; ++dz) {
@@ -730,6 +747,7 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
           bool edge = (sx * sx + sy * sy + sz * sz) * 1.001f < r2;
           if (!edge) {
             if (u > 0 && cg_find<LDS>(par, b) == ra) continue;         // an earlier union of this row may have merged it
+            if (a0 < 0) { a0 = start[a]; na = start[a + 1] - a0; }
             const int b0 = start[b], nb = start[b + 1] - b0;
             if ((long long)na * nb > 256) {
               // big × big: dense neighbouring cells nearly always show an edge within a small sample of pairs;
@@ -737,8 +755,8 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
               edge = pair_hit_serial(sp, a0, min(na, 16), b0, min(nb, 16), r2);
               if (!edge) {
                 int slot = atomicAdd(l_nlist, 1);
-                if (slot < CG_LIST) { l_list[2 * slot] = a; l_list[2 * slot + 1] = b; continue; }
-                edge = pair_hit_serial(sp, a0, na, b0, nb, r2);           // list full: settle it here
+                if (slot < CG_LIST) { l_list[2 * slot] = a; l_list[2 * slot + 1] = b; }
+                continue;   // list full: the pair stays open and the pass is repeated (settled pairs are skipped by the root test)
               }
             } else edge = pair_hit_serial(sp, a0, na, b0, nb, r2);
           }
@@ -757,11 +775,14 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
     const float4 alo = d.cmeta[2 * (so + a)], ahi = d.cmeta[2 * (so + a) + 1], blo = d.cmeta[2 * (so + b)], bhi = d.cmeta[2 * (so + b) + 1];
     float gx = fmaxf(fmaxf(blo.x - ahi.x, alo.x - bhi.x), 0.f), gy = fmaxf(fmaxf(blo.y - ahi.y, alo.y - bhi.y), 0.f), gz = fmaxf(fmaxf(blo.z - ahi.z, alo.z - bhi.z), 0.f);
     if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) continue;
-    if (pair_hit_wave(sp, start[a], start[a + 1] - start[a], start[b], start[b + 1] - start[b], r2, lane) && lane == 0) cg_unite<LDS>(par, a, b);
+    if (pair_hit_wave(sp, start[a], start[a + 1] - start[a], start[b], start[b + 1] - start[b], r2, lane, alo, ahi, blo, bhi) && lane == 0) cg_unite<LDS>(par, a, b);
   }
+  __syncthreads();
+  again = *l_nlist > CG_LIST;   // more undecided big pairs than list slots
   __syncthreads();
   if (threadIdx.x == 0) *l_nlist = 0;
   __syncthreads();
+  }
 }
 
 #ifdef MOR_EXP_STAMPS
@@ -827,20 +848,29 @@ template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int
   __syncthreads();
   cg_hook_pass<LDS, 2>(d, s, nocc, key, start, rows, par, sp, l_list, l_nlist);
   CG_STAMP(4);
-  // ---- components: size (points) and smallest cloud index at the root; `size`/`mn` may alias key/start ⇒ read first
+  // ---- components: size (points) and smallest cloud index at the root.  LDS mode has one scratch array left (`mn`
+  //      aliases the keys): sizes are accumulated in it first and parked in the global `size` array, then the minima
   constexpr int PER = LDS ? CG_CAP / CG_T : 1;
-  int r_[PER], cnt_[PER];
   if (LDS) {
+    int r_[PER], cnt_[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) { int c = threadIdx.x + u * CG_T; r_[u] = -1; cnt_[u] = 0; if (c < nocc) { r_[u] = cg_find<LDS>(par, c); cnt_[u] = start[c + 1] - start[c]; } }
     __syncthreads();
-  }
-  for (int c = threadIdx.x; c < nocc; c += CG_T) { size[c] = 0; mn[c] = 0x7fffffff; }
-  __syncthreads();
-  if (LDS) {
+    for (int c = threadIdx.x; c < nocc; c += CG_T) mn[c] = 0;
+    __syncthreads();
 #pragma unroll
-    for (int u = 0; u < PER; ++u) { int c = threadIdx.x + u * CG_T; if (c < nocc) { atomicAdd(&size[r_[u]], cnt_[u]); atomicMin(&mn[r_[u]], d.cmin[so + c]); } }
+    for (int u = 0; u < PER; ++u) { int c = threadIdx.x + u * CG_T; if (c < nocc) atomicAdd(&mn[r_[u]], cnt_[u]); }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { int c = threadIdx.x + u * CG_T; if (c < nocc && r_[u] == c) cg_st<false>(size + c, mn[c]); }
+    __syncthreads();
+    for (int c = threadIdx.x; c < nocc; c += CG_T) mn[c] = 0x7fffffff;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { int c = threadIdx.x + u * CG_T; if (c < nocc) atomicMin(&mn[r_[u]], d.cmin[so + c]); }
   } else {
+    for (int c = threadIdx.x; c < nocc; c += CG_T) { size[c] = 0; mn[c] = 0x7fffffff; }
+    __syncthreads();
     for (int c = threadIdx.x; c < nocc; c += CG_T) { int r = cg_find<LDS>(par, c); atomicAdd(&size[r], start[c + 1] - start[c]); atomicMin(&mn[r], d.cmin[so + c]); }
   }
   __syncthreads();
@@ -850,7 +880,7 @@ template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int
   __syncthreads();
   for (int c = threadIdx.x; c < nocc; c += CG_T) {
     const bool root = LDS ? (cg_ld<LDS>(par + c) == c) : (cg_find<LDS>(par, c) == c);
-    long long n = size[c];
+    long long n = root ? (long long)cg_ld<false>(size + c) : 0;
     if (root && n >= d.min_cs && n <= d.max_cs) {
       int k = atomicAdd(&l_misc[0], 1);
       if (k < d.Kcap) { d.kcell[ko + k] = c; d.kroot[ko + k] = mn[c]; d.ksize[ko + k] = (int)n; }
@@ -913,18 +943,17 @@ __global__ __launch_bounds__(CG_T) void k_cellgraph(MorDev d) {
 #ifdef MOR_EXP_STAMPS
   if (threadIdx.x == 0) d.dbg[(size_t)s * 16 + 0] = wall_clock64();
 #endif
-  __shared__ int l_key[CG_CAP], l_start[CG_CAP + 1], l_par[CG_CAP], l_rows[CG_ROWCAP + 1], l_list[2 * CG_LIST], l_nlist, l_misc[1 + CG_T / 64];
+  __shared__ int l_key[CG_CAP], l_par[CG_CAP], l_rows[CG_ROWCAP + 1], l_list[2 * CG_LIST], l_nlist, l_misc[1 + CG_T / 64];
   const size_t so = (size_t)s * d.Nmax;
   const int *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1);
   const int *rows = g_rows;
   if (threadIdx.x == 0) l_nlist = 0;
   if (d.g.nrows + 1 <= CG_ROWCAP + 1) { for (int i = threadIdx.x; i <= d.g.nrows; i += CG_T) l_rows[i] = g_rows[i]; rows = l_rows; }
   if (nocc <= CG_CAP) {
-    const int *gk = d.ckey + so, *gs = d.cstart + (size_t)s * (d.Nmax + 1);
-    for (int i = threadIdx.x; i < nocc; i += CG_T) { l_key[i] = gk[i]; l_start[i] = gs[i]; l_par[i] = i; }
-    if (threadIdx.x == 0) l_start[nocc] = gs[nocc];
+    const int *gk = d.ckey + so;
+    for (int i = threadIdx.x; i < nocc; i += CG_T) { l_key[i] = gk[i]; l_par[i] = i; }
     __syncthreads();
-    cg_body<true>(d, s, nocc, l_key, l_start, rows, l_par, l_key, l_start, l_key, l_list, &l_nlist, l_misc);
+    cg_body<true>(d, s, nocc, l_key, d.cstart + (size_t)s * (d.Nmax + 1), rows, l_par, d.csize + so, l_key, l_key, l_list, &l_nlist, l_misc);
   } else {
     __syncthreads();
     cg_body<false>(d, s, nocc, d.ckey + so, d.cstart + (size_t)s * (d.Nmax + 1), rows, d.parent + so, d.csize + so, d.compmin + so, d.cid_of_root + so, l_list, &l_nlist, l_misc);
