@@ -53,6 +53,7 @@ struct MorFrameInfo {        // per stream, produced on device
 // Temporal logic (T1 + the tracking loop of F1) as device state, one instance per stream.  O(clusters) sequential work
 // per frame: it runs in a one-workgroup-per-stream kernel right behind the geometry so that push + filter need no
 // host round trip in between.  Mirrors csrc/mor_tracker.cpp (the host version behind the mor_tracker_* C ABI).
+#define MOR_CG_OVF 65536   // overflow entries per stream of the cell graph's deferred-pair list
 #define MOR_TR_MAXT 512   // tracked moving centroids per stream (mo_vec)
 #define MOR_TR_NB 8       // longest supported window (n_bad)
 struct MorTrackDev {
@@ -110,6 +111,7 @@ struct MorDev {
   float4 *cmeta;             // [B][2·Nmax]  per occupied cell: low corner of its point box (.w = cluster id bits), high corner
   float4 *sorted;            // [B][Nmax]  (x,y,z, bits(cloud index)) in cell order; .w becomes the cluster id after labelling
   int *parent;               // [B][Nmax]  union-find forest over occupied cells (parent ≤ child)
+  int *cg_ovf;               // [B][MOR_CG_OVF][2]  k_cellgraph: undecided big cell pairs beyond its LDS list
   int *croot;                // [B][Nmax]  flattened root per cell
   int *csize;                // [B][Nmax]  component size (points) at its root cell
   int *compmin;              // [B][Nmax]  smallest cloud index of the component, at its root cell

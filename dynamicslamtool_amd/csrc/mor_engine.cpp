@@ -274,6 +274,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.rhist, B * T * 256) && dalloc(b, d.rhist2, B * T * 256) && dalloc(b, d.cl_idx, B * N);
   d.skey = d.rkeys[d.cell_passes & 1]; d.sidx = d.rvals[d.cell_passes & 1];
   if (d.use_hash) ok = ok && dalloc(b, d.chash, B * (size_t)d.Hcell); else d.chash = nullptr;
+  ok = ok && dalloc(b, d.cg_ovf, B * (size_t)MOR_CG_OVF * 2);
   ok = ok && dalloc(b, d.xcent, B * K) && dalloc(b, d.xamin, B * K) && dalloc(b, d.xamax, B * K);
   for (int i = 0; i < 4; ++i)
     ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.chunk_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K);

@@ -599,7 +599,9 @@ __global__ __launch_bounds__(MOR_BT) void k_select_scatter(MorDev d) {
 #define CG_T 1024
 #define CG_CAP 12288     // occupied cells held in LDS (keys + union-find forest; point ranges stay in global memory)
 #define CG_ROWCAP 8192   // (y,z) rows held in LDS
+#ifndef CG_LIST
 #define CG_LIST 2040     // deferred (cell | cell pair) entries
+#endif
 
 template <bool LDS> __device__ __forceinline__ int cg_ld(const int *p) {
   return LDS ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -698,7 +700,6 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
                                                                    const float4 *sp, int *l_list, int *l_nlist) {
   const float r2 = d.r2;
   const size_t so_ = (size_t)s * d.Nmax;
-  for (bool again = true; again;) {
   for (int a = threadIdx.x; a < nocc; a += CG_T) {
     const int ka = key[a], rowa = ka / d.g.nx, x = ka - rowa * d.g.nx, y = rowa % d.g.ny, z = rowa / d.g.ny;
     int a0 = -1, na = 0;   // point range of a: fetched from global memory when the first point test needs it
@@ -755,8 +756,12 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
               edge = pair_hit_serial(sp, a0, min(na, 16), b0, min(nb, 16), r2);
               if (!edge) {
                 int slot = atomicAdd(l_nlist, 1);
-                if (slot < CG_LIST) { l_list[2 * slot] = a; l_list[2 * slot + 1] = b; }
-                continue;   // list full: the pair stays open and the pass is repeated (settled pairs are skipped by the root test)
+                if (slot < CG_LIST) { l_list[2 * slot] = a; l_list[2 * slot + 1] = b; continue; }
+                if (slot < CG_LIST + MOR_CG_OVF) {   // LDS list full: overflow list in global memory
+                  int *ov = d.cg_ovf + ((size_t)s * MOR_CG_OVF + (slot - CG_LIST)) * 2;
+                  cg_st<false>(ov, a); cg_st<false>(ov + 1, b); continue;
+                }
+                edge = pair_hit_serial(sp, a0, na, b0, nb, r2);           // both lists full: settle it here
               }
             } else edge = pair_hit_serial(sp, a0, na, b0, nb, r2);
           }
@@ -767,9 +772,11 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
   }
   __syncthreads();
   // deferred pairs: one wave each — root re-check, box rejection, tiled exhaustive test
-  const int nl = min(*l_nlist, CG_LIST), lane = lane_id();
+  __threadfence_block();
+  const int nl = min(*l_nlist, CG_LIST + MOR_CG_OVF), lane = lane_id();
   for (int h = wave_id(); h < nl; h += CG_T / 64) {
-    const int a = l_list[2 * h], b = l_list[2 * h + 1];
+    const int *ov = d.cg_ovf + ((size_t)s * MOR_CG_OVF + max(h - CG_LIST, 0)) * 2;
+    const int a = h < CG_LIST ? l_list[2 * h] : cg_ld<false>(ov), b = h < CG_LIST ? l_list[2 * h + 1] : cg_ld<false>(ov + 1);
     if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;
     const size_t so = (size_t)s * d.Nmax;
     const float4 alo = d.cmeta[2 * (so + a)], ahi = d.cmeta[2 * (so + a) + 1], blo = d.cmeta[2 * (so + b)], bhi = d.cmeta[2 * (so + b) + 1];
@@ -778,11 +785,8 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
     if (pair_hit_wave(sp, start[a], start[a + 1] - start[a], start[b], start[b + 1] - start[b], r2, lane, alo, ahi, blo, bhi) && lane == 0) cg_unite<LDS>(par, a, b);
   }
   __syncthreads();
-  again = *l_nlist > CG_LIST;   // more undecided big pairs than list slots
-  __syncthreads();
   if (threadIdx.x == 0) *l_nlist = 0;
   __syncthreads();
-  }
 }
 
 #ifdef MOR_EXP_STAMPS

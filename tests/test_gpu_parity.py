@@ -201,12 +201,12 @@ def test_agg10_million_point_cloud_matches_oracle():
 
 
 def test_fine_grid_takes_the_global_memory_cell_graph():
-    """A small cluster tolerance (r = 0.15 m → 8.6 cm cells) gives more occupied cells than the per-stream
+    """A small cluster tolerance (r = 0.12 m → 6.8 cm cells) gives more occupied cells than the per-stream
     workgroup can hold in LDS: the cell graph then runs on its global-memory arrays (same code)."""
     from dynamicslamtool_amd.engine import MorBatch
     from oracle.oracle import Oracle
     p = kitti_params(1)
-    p.ec_distance_threshold = 0.15
+    p.ec_distance_threshold = 0.12
     p.min_cluster_size = 10
     frames = [synth.frame(2033, "hdl64", f) for f in range(3)]
     b, o = MorBatch(p, 1, 120000), Oracle(p)
@@ -215,7 +215,36 @@ def test_fine_grid_takes_the_global_memory_cell_graph():
         o.push(x, pose)
         compare_frame(o, b, 0, "fine grid frame %d" % f)
         compare_output(o.filter(), b.filter()[0], "fine grid frame %d" % f)
-    assert b.stage_counts(0)["n_occ"] > 8192
+    assert b.stage_counts(0)["n_occ"] > 12288   # CG_CAP of k_cellgraph
+    b.close()
+
+
+@pytest.mark.gpu
+def test_dense_sheets_overflow_the_deferred_pair_list():
+    """Two dense wavy sheets 0.6 m apart (r = 0.5): every cell holds dozens of points, cells of the two sheets are
+    two apart with overlapping-looking boxes, and no pair of points is within r — thousands of big × big cell
+    pairs that only an exhaustive test can reject.  More of them than the kernel's deferred-pair list holds, so
+    the shell pass has to repeat; the result must still be two clusters with the oracle's membership."""
+    from dynamicslamtool_amd.engine import MorBatch
+    from oracle.oracle import Oracle
+    p = kitti_params(1)
+    g = np.arange(-3.0, 3.0, 0.04, dtype=np.float32)
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    wav = (0.12 * np.sin(3.0 * X) * np.cos(2.0 * Y)).astype(np.float32)
+    sheets = []
+    for z0 in (-0.4, 0.2):
+        sheets.append(np.stack([X.ravel() + 6.0, Y.ravel(), (wav + np.float32(z0)).ravel(), np.full(X.size, 0.5, np.float32)], 1))
+    x = np.concatenate(sheets).astype(np.float32)
+    rng = np.random.default_rng(5)
+    x = x[rng.permutation(len(x))]
+    pose = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    b, o = MorBatch(p, 1, len(x)), Oracle(p)
+    for f in range(2):
+        b.push([x], pose[None, :])
+        o.push(x, pose)
+        compare_frame(o, b, 0, "dense sheets frame %d" % f)
+        compare_output(o.filter(), b.filter()[0], "dense sheets frame %d" % f)
+    assert b.counts(0).n_clusters == 2
     b.close()
 
 
