@@ -33,6 +33,19 @@ def build_hip(force=False, verbose=False):
     return out
 
 
+def build_hip_smalllist(force=False):
+    """Test-only variant of the library with an 8-entry deferred-pair list in k_cellgraph, so that small scenes
+    exercise the global overflow list (tests/test_gpu_parity.py::test_deferred_pair_overflow_list)."""
+    out = os.path.join(CSRC, "libmor_hip_smalllist.so")
+    deps = [os.path.join(CSRC, f) for f in HIP_SOURCES + HIP_HEADERS]
+    if not force and not _newer(out, deps):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-DCG_LIST=8",
+                           "-x", "hip"] + [os.path.join(CSRC, f) for f in HIP_SOURCES] + ["-o", out])
+    return out
+
+
 def build_synth(force=False):
     out = os.path.join(CSRC, "libmor_synth.so")
     src = os.path.join(CSRC, "mor_synth.c")
@@ -55,7 +68,7 @@ def build_replay(force=False):
 
 
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_synth(force), build_replay(force)
+    return build_hip(force, verbose), build_synth(force), build_replay(force), build_hip_smalllist(force)
 
 
 if __name__ == "__main__":

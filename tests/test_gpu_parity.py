@@ -1,4 +1,6 @@
 """-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -246,6 +248,40 @@ def test_dense_sheets_overflow_the_deferred_pair_list():
         compare_output(o.filter(), b.filter()[0], "dense sheets frame %d" % f)
     assert b.counts(0).n_clusters == 2
     b.close()
+
+
+_OVERFLOW_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from dynamicslamtool_amd import kitti_params, synth
+from dynamicslamtool_amd.engine import MorBatch
+from oracle.oracle import Oracle
+from parity import compare_frame, compare_output
+p = kitti_params(1)
+for seed in (2001, 2005):
+    b, o = MorBatch(p, 1, 120000), Oracle(p)
+    for f in range(3):
+        x, pose = synth.frame(seed, "hdl64", f)
+        b.push([x], pose[None, :]); o.push(x, pose)
+        compare_frame(o, b, 0, "overflow variant seed %%d frame %%d" %% (seed, f))
+        compare_output(o.filter(), b.filter()[0], "overflow variant seed %%d frame %%d" %% (seed, f))
+    b.close(); o.close()
+print("OK")
+"""
+
+
+@pytest.mark.gpu
+def test_deferred_pair_overflow_list():
+    """k_cellgraph keeps undecided big cell pairs in an LDS list and spills into a global list beyond it.  A library
+    variant built with an 8-entry LDS list (dynamicslamtool_amd/build.py) makes ordinary hdl64 frames spill; results
+    must not change.  Runs in a child process because the library is chosen at import time."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "dynamicslamtool_amd", "csrc", "libmor_hip_smalllist.so")
+    assert os.path.exists(lib), "build the test variant first: python -m dynamicslamtool_amd.build"
+    env = dict(os.environ, MOR_HIP_LIB=lib)
+    r = subprocess.run([sys.executable, "-c", _OVERFLOW_SCRIPT % (root, os.path.join(root, "tests"))], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_full_size_batch_properties():
