@@ -91,7 +91,7 @@ struct MorDev {
   int *tile_cnt, *tile_off;  // [B][tiles_max][2]   (non-ground, ground) counts / exclusive offsets
   float4 *cloud;             // [B][Nmax]  non-ground points, input order (`cloud`, :85)
   int *cloud_tidx;           // [B][Nmax]  index of each cloud point in the trimmed cloud
-  float4 *ground;            // [B][Nmax]  removed points in order (raw_cloud[gp_indices], :683)
+  float4 *ground;            // [B][Nmax]  slots [M, M+G): removed points in order (raw_cloud[gp_indices], :683); slots [M − n_keep, M): the kept cloud points after filterCloud — together the filtered cloud, assembled in place
   int *gp_idx;               // [B][Nmax]  gp_indices (:86)
   float4 *rawbuf;            // [B][Nmax]  trimmed cloud (voxel ground variant only)
   int *is_ground;            // [B][Nmax]  per trimmed point
@@ -153,7 +153,6 @@ struct MorDev {
   unsigned char *tr_lastdet; // [B][Kcap]  detection_results of the previous frame (ca)
   int moving_confidence, static_confidence; float leave_off, catch_up;
   int *otile_cnt;            // [B][tiles_max]
-  float4 *out;               // [B][Nmax] (or caller-provided per-stream pointers through out_ptrs)
   float4 *const *out_ptrs;   // [B] or null
   unsigned long long *dbg;   // [B][16] experiment stamps (MOR_EXP_STAMPS builds only)
   // ---- pinned host mirrors written by the device (zero-copy summaries)
@@ -164,7 +163,8 @@ struct MorDev {
   int *h_pair_q, *h_pair_m;  // [B][Kcap]
   float *h_pair_d;           // [B][Kcap]
   double *h_score;           // [B][Kcap]
-  unsigned long long *h_nout;// [B]
+  unsigned long long *h_nout;// [B]  points in the filtered cloud
+  int *h_noff;               // [B]  first slot of the filtered cloud in `ground` (M − n_keep)
 };
 
 // kernel ids for optional per-kernel event timing

@@ -290,7 +290,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     std::vector<float> z0(B, p->gp_limit); std::vector<int> zb(B, 0);
     ok = hipMemcpy(d.zorg, z0.data(), B * sizeof(float), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d.zbase, zb.data(), B * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
   }
-  ok = ok && dalloc(b, b->d_moving, B * K + B) && dalloc(b, d.otile_cnt, B * T) && dalloc(b, d.out, B * N) && dalloc(b, b->d_outptrs, B);
+  ok = ok && dalloc(b, b->d_moving, B * K + B) && dalloc(b, d.otile_cnt, B * T) && dalloc(b, b->d_outptrs, B);
   d.moving = b->d_moving;
   ok = ok && dalloc(b, d.tr, B) && dalloc(b, d.tr_corr, B * MOR_TR_NB * K) && dalloc(b, d.tr_res, B * (MOR_TR_NB + 1) * K) && dalloc(b, d.tr_lastdet, B * K);
   if (ok) ok = hipMemset(d.tr, 0, B * sizeof(MorTrackDev)) == hipSuccess && hipMemset(b->d_moving, 0, B * K + B) == hipSuccess;
@@ -298,7 +298,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && halloc(b, b->h_args_ring, B * MOR_ARGS_RING) && halloc(b, b->h_outptrs, B);
   b->h_args = b->h_args_ring;
   ok = ok && halloc(b, d.h_info, B) && halloc(b, d.h_centroid, B * K) && halloc(b, d.h_cl_off, B * (K + 1)) && halloc(b, d.h_det, B * K);
-  ok = ok && halloc(b, d.h_pair_q, B * K) && halloc(b, d.h_pair_m, B * K) && halloc(b, d.h_pair_d, B * K) && halloc(b, d.h_score, B * K) && halloc(b, d.h_nout, B);
+  ok = ok && halloc(b, d.h_pair_q, B * K) && halloc(b, d.h_pair_m, B * K) && halloc(b, d.h_pair_d, B * K) && halloc(b, d.h_score, B * K) && halloc(b, d.h_nout, B) && halloc(b, d.h_noff, B);
   if (!ok) return fail(set_error(MOR_ERR_HIP, "device/host allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
   // two more copies of every per-frame array that crosses a stage boundary (frame k uses copy k % 3)
   b->dtemp[0] = d;
@@ -432,7 +432,7 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
   hipEventElapsedTime(&b->filter_ms, b->ev[2], b->ev[3]);
   for (int s = 0; s < B; ++s) if (n_out) n_out[s] = d.h_nout[s];
   if (out && !out_on_device) {
-    for (int s = 0; s < B; ++s) if (out[s] && d.h_nout[s]) HIP_TRY(hipMemcpyAsync(out[s], d.out + (size_t)s * d.Nmax, d.h_nout[s] * sizeof(float4), hipMemcpyDeviceToHost, b->st));
+    for (int s = 0; s < B; ++s) if (out[s] && d.h_nout[s]) HIP_TRY(hipMemcpyAsync(out[s], d.ground + (size_t)s * d.Nmax + d.h_noff[s], d.h_nout[s] * sizeof(float4), hipMemcpyDeviceToHost, b->st));
     HIP_TRY(hipStreamSynchronize(b->st));
   }
   return rc;
@@ -444,7 +444,7 @@ int mor_batch_wait(mor_batch *b) { if (!b) return MOR_ERR_INVALID; HIP_TRY(hipSe
 const void *mor_get_output_device(const mor_batch *b, int s, uint64_t *n_out) {
   if (!b || s < 0 || s >= b->B) return nullptr;
   if (n_out) *n_out = b->d.h_nout[s];
-  return b->d.out + (size_t)s * b->d.Nmax;
+  return b->d.ground + (size_t)s * b->d.Nmax + b->d.h_noff[s];   // assembled in place in the frame's ground buffer (valid until three more frames have been pushed)
 }
 
 // ---- single-stream forms

@@ -247,14 +247,15 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   const uint32_t n_in = pass_count(d, a, s);
   uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
   __shared__ int sh[8];
-  int r_ng = 0, r_g = 0; float zorg = d.zorg[s]; int zbase = d.zbase[s];
+  int r_ng = 0, r_g = 0, m_total = 0; float zorg = d.zorg[s]; int zbase = d.zbase[s];
   if (d.fuse_scans) {   // own offsets from the per-tile counts of k_classify; tile 0 publishes the totals
     const int *tc = d.tile_cnt + (size_t)s * d.tiles_max * 2; int tot_ng, tot_g;
     wg_prefix_total(tc, 2, t, d.tiles, sh, r_ng, tot_ng);
     wg_prefix_total(tc + 1, 2, t, d.tiles, sh, r_g, tot_g);
     if (d.gmode == 1) { zorg = (tot_ng + tot_g) ? ordered_float(d.zmin_i[s]) : 0.f; zbase = (int)floorf(zorg * d.gv.inv_cs); }
     if (t == 0 && threadIdx.x == 0) publish_split(d, s, tot_ng, tot_g);
-  }
+    m_total = tot_ng;
+  } else m_total = (int)d.info[s].M;
   if ((uint32_t)t * MOR_TILE >= n_in) return;
   float4 p[8]; int cls[8]; unsigned long long m_ng[8], m_g[8];
   int c_ng = 0, c_g = 0;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
       d.cloud_tidx[so + k_ng] = k_ng + k_g;   // index in the trimmed cloud (both ranks are exclusive counts of earlier kept points)
       d.pkey[so + k_ng] = (cz * d.g.ny + cy) * d.g.nx + cx;
     } else if (cls[it] == 1) {
-      d.ground[so + k_g] = p[it];
+      d.ground[so + m_total + k_g] = p[it];   // final place of filterCloud's output: [kept cloud, right-aligned to M | ground]
       d.gp_idx[so + k_g] = k_ng + k_g;
     }
     r_ng += __popcll(m_ng[it]); r_g += __popcll(m_g[it]);
@@ -1769,27 +1770,33 @@ __global__ __launch_bounds__(MOR_BT) void k_out_scan(MorDev d) {
     if (t < nt) c[t] = carry + e;
     carry += tot;
   }
-  if (threadIdx.x == 0) { d.info[s].n_keep = carry; d.h_nout[s] = (unsigned long long)carry + d.info[s].G; }
+  if (threadIdx.x == 0) { d.info[s].n_keep = carry; d.h_nout[s] = (unsigned long long)carry + d.info[s].G; d.h_noff[s] = d.info[s].M - carry; }
 }
-// workgroups [0, tiles_m) per stream: kept cloud points (grid-stride over the cloud's tiles);
-// workgroups [tiles_m, tiles_m + tiles): ground points appended after them
+// filterCloud's output (:673-684) = [cloud minus moving clusters, original order] ++ [ground points].  The ground points
+// were written to their final place by k_scatter (behind the M cloud slots of the `ground` buffer), so the result is
+// assembled in place: the kept cloud points go right-aligned in front of them and the result starts at slot M − n_keep —
+// the bulk of the frame (the ground, ≈ 90 % of a LiDAR sweep) is not copied again.  With caller-provided device
+// pointers both parts are copied out: workgroups [0, tiles_m) per stream the kept cloud points (grid-stride over the
+// cloud's tiles), workgroups [tiles_m, tiles_m + tiles) the ground points.
 __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
-  int s, t2; map_block(d.B, d.tiles_m + d.tiles, s, t2);
+  int s, t2; map_block(d.B, d.tiles_m + (d.out_ptrs ? d.tiles : 0), s, t2);
   const size_t so = (size_t)s * d.Nmax;
-  float4 *out = d.out_ptrs ? d.out_ptrs[s] : d.out + so;
+  float4 *og = d.ground + so;
   const int M = d.info[s].M;
   __shared__ int sh[12];
   const int nto = (M + MOR_TILE - 1) / MOR_TILE;
   int n_keep = 0;
   if (d.fuse_scans) {   // kept points in total: every workgroup sums the per-tile counts of k_out_count itself
     int pre; wg_prefix_total(d.otile_cnt + (size_t)s * d.tiles_max, 1, 0, nto, sh, pre, n_keep);
-    if (t2 == 0 && threadIdx.x == 0) { d.info[s].n_keep = n_keep; d.h_nout[s] = (unsigned long long)n_keep + d.info[s].G; }
+    if (t2 == 0 && threadIdx.x == 0) { d.info[s].n_keep = n_keep; d.h_nout[s] = (unsigned long long)n_keep + d.info[s].G; d.h_noff[s] = M - n_keep; }
   } else n_keep = d.info[s].n_keep;
   if (t2 >= d.tiles_m) {
     int t = t2 - d.tiles_m, G = d.info[s].G, nk = n_keep, base = t * MOR_TILE;
-    for (int i = base + threadIdx.x; i < min(base + MOR_TILE, G); i += MOR_BT) out[nk + i] = d.ground[so + i];
+    float4 *out = d.out_ptrs[s];
+    for (int i = base + threadIdx.x; i < min(base + MOR_TILE, G); i += MOR_BT) out[nk + i] = og[M + i];
     return;
   }
+  float4 *dst = d.out_ptrs ? d.out_ptrs[s] : og + (M - n_keep);
   for (int t = t2; t * MOR_TILE < M; t += d.tiles_m) {
     int base = t * MOR_TILE + wave_id() * 512, c = 0;
     unsigned long long mk[8];
@@ -1805,7 +1812,7 @@ __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       int i = base + it * 64 + lane_id();
-      if ((mk[it] >> lane_id()) & 1ull) out[r + __popcll(mk[it] & lanemask_lt())] = d.cloud[so + i];
+      if ((mk[it] >> lane_id()) & 1ull) dst[r + __popcll(mk[it] & lanemask_lt())] = d.cloud[so + i];
       r += __popcll(mk[it]);
     }
   }
@@ -2228,7 +2235,7 @@ void mor_launch_tail(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
 }
 
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  const dim3 gM(d.B * d.tiles_m), gB(d.B), gT2(d.B * (d.tiles_m + d.tiles));
+  const dim3 gM(d.B * d.tiles_m), gB(d.B), gT2(d.B * (d.tiles_m + (d.out_ptrs ? d.tiles : 0)));
   if (d.run_tracker) {   // once per frame: a repeated filterCloud on the same frame re-emits the same cloud
     mor_timer_begin(tm, MK_TRACK_FILTER, st);
     hipLaunchKernelGGL(k_track_filter, gB, dim3(64), 0, st, d);
