@@ -89,9 +89,10 @@ struct MorDev {
   MorFrameInfo *info;        // [B]  this frame (the engine double-buffers it and every array the pair / filter stage reads)
   const MorFrameInfo *info_prev; // [B]  previous frame (its K, C)
   int *tile_cnt, *tile_off;  // [B][tiles_max][2]   (non-ground, ground) counts / exclusive offsets
+  unsigned long long *split_desc; // [B][tiles_max]  look-back descriptors of the single-pass split (status | non-ground | ground)
   float4 *cloud;             // [B][Nmax]  non-ground points, input order (`cloud`, :85)
   int *cloud_tidx;           // [B][Nmax]  index of each cloud point in the trimmed cloud
-  float4 *ground;            // [B][Nmax]  slots [M, M+G): removed points in order (raw_cloud[gp_indices], :683); slots [M − n_keep, M): the kept cloud points after filterCloud — together the filtered cloud, assembled in place
+  float4 *ground;            // [B][2·Nmax]  slots [Nmax, Nmax+G): removed points in order (raw_cloud[gp_indices], :683); slots [Nmax − n_keep, Nmax): the kept cloud points after filterCloud — together the filtered cloud, assembled in place
   int *gp_idx;               // [B][Nmax]  gp_indices (:86)
   float4 *rawbuf;            // [B][Nmax]  trimmed cloud (voxel ground variant only)
   int *is_ground;            // [B][Nmax]  per trimmed point
@@ -164,12 +165,12 @@ struct MorDev {
   float *h_pair_d;           // [B][Kcap]
   double *h_score;           // [B][Kcap]
   unsigned long long *h_nout;// [B]  points in the filtered cloud
-  int *h_noff;               // [B]  first slot of the filtered cloud in `ground` (M − n_keep)
+  int *h_noff;               // [B]  first slot of the filtered cloud in the stream's `ground` buffer (Nmax − n_keep)
 };
 
 // kernel ids for optional per-kernel event timing
 enum MorKernelId {
-  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_HASH_CLEAR, MK_ROWTABLE, MK_CELLBOXES, MK_CELLGRAPH, MK_CELLBOX, MK_HOOK_NEAR, MK_HOOK_SHELL, MK_FLATTEN, MK_CELLCID,
+  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_SPLIT, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_HASH_CLEAR, MK_ROWTABLE, MK_CELLBOXES, MK_CELLGRAPH, MK_CELLBOX, MK_HOOK_NEAR, MK_HOOK_SHELL, MK_FLATTEN, MK_CELLCID,
   MK_SELECT_COUNT, MK_SELECT_SCAN, MK_SELECT_SCATTER, MK_RANK, MK_OFFSETS, MK_LABEL, MK_RHIST, MK_RSCAN, MK_RSCATTER,
   MK_STATS, MK_STATS_FIN, MK_XFORM_PREV, MK_XFORM_FIN, MK_NN, MK_PAIRS, MK_SCORE_FAST, MK_SCORE_NEAR, MK_SCORE_BLOCK, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
   MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_G2_CENTROID, MK_G2_COV, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_COUNT

@@ -187,6 +187,7 @@ static int wait_all_checked(mor_batch *b) {
     if (f.flags & 2u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: voxel key out of range in method 2", s);
     if (f.flags & 8u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: z extent of the trimmed cloud exceeds the 64 m the voxel ground variant covers", s);
     if (f.flags & 16u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than 16384 points within gp_leaf of a voxel centroid", s);
+    if (f.flags & 64u) rc = set_error(MOR_ERR_HIP, "stream %d: look-back of the single-pass split stalled", s);
     if (f.flags & 32u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than %d tracked moving centroids", s, MOR_TR_MAXT);
   }
   return rc;
@@ -251,7 +252,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   MorStreamArgs *dargs = nullptr;
   ok = ok && dalloc(b, dargs, B) && dalloc(b, d.info, B) && dalloc(b, d.tile_cnt, B * T * 2) && dalloc(b, d.tile_off, B * T * 2);
   b->d_args_s[0] = dargs; d.args = dargs;
-  ok = ok && dalloc(b, d.cloud, B * N) && dalloc(b, d.cloud_tidx, B * N) && dalloc(b, d.ground, B * N) && dalloc(b, d.gp_idx, B * N) && dalloc(b, d.cell_of, B * N);
+  ok = ok && dalloc(b, d.cloud, B * N) && dalloc(b, d.cloud_tidx, B * N) && dalloc(b, d.ground, 2 * B * N) && dalloc(b, d.gp_idx, B * N) && dalloc(b, d.cell_of, B * N);
   ok = ok && dalloc(b, d.pkey, B * N) && dalloc(b, d.ckey, B * N) && dalloc(b, d.cstart, B * (N + 1)) && dalloc(b, d.row_start, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, d.cmin, B * N) && dalloc(b, d.cmeta, 2 * B * N);
   ok = ok && dalloc(b, d.sorted, B * N) && dalloc(b, d.parent, B * N) && dalloc(b, d.croot, B * N) && dalloc(b, d.csize, B * N) && dalloc(b, d.compmin, B * N) && dalloc(b, d.cid_of_root, B * N) && dalloc(b, d.pcid, B * N) && dalloc(b, d.ccid, B * N);
   ok = ok && dalloc(b, d.ktile_cnt, B * T) && dalloc(b, d.kcell, B * K) && dalloc(b, d.kroot, B * K) && dalloc(b, d.ksize, B * K) && dalloc(b, d.csz, B * K);
@@ -274,6 +275,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.rhist, B * T * 256) && dalloc(b, d.rhist2, B * T * 256) && dalloc(b, d.cl_idx, B * N);
   d.skey = d.rkeys[d.cell_passes & 1]; d.sidx = d.rvals[d.cell_passes & 1];
   if (d.use_hash) ok = ok && dalloc(b, d.chash, B * (size_t)d.Hcell); else d.chash = nullptr;
+  ok = ok && dalloc(b, d.split_desc, B * T);
   ok = ok && dalloc(b, d.cg_ovf, B * (size_t)MOR_CG_OVF * 2);
   ok = ok && dalloc(b, d.xcent, B * K) && dalloc(b, d.xamin, B * K) && dalloc(b, d.xamax, B * K);
   for (int i = 0; i < 4; ++i)
@@ -305,7 +307,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   for (int c = 1; c < 3; ++c) {
     b->dtemp[c] = d;
     MorDev &o = b->dtemp[c]; MorStreamArgs *dargs1 = nullptr;
-    ok = dalloc(b, dargs1, B) && dalloc(b, o.info, B) && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, B * N) && dalloc(b, o.gp_idx, B * N);
+    ok = dalloc(b, dargs1, B) && dalloc(b, o.info, B) && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, 2 * B * N) && dalloc(b, o.gp_idx, B * N);
     ok = ok && dalloc(b, o.sorted, B * N) && dalloc(b, o.ckey, B * N) && dalloc(b, o.cstart, B * (N + 1)) && dalloc(b, o.row_start, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, o.cmeta, 2 * B * N);
     ok = ok && dalloc(b, o.pcid, B * N) && dalloc(b, o.ccid, B * N) && dalloc(b, o.cl_idx, B * N) && dalloc(b, o.det, B * K) && dalloc(b, o.zorg, B);
     ok = ok && dalloc(b, o.cell_of, B * N) && dalloc(b, o.cmin, B * N) && dalloc(b, o.parent, B * N) && dalloc(b, o.csize, B * N) && dalloc(b, o.compmin, B * N) && dalloc(b, o.cid_of_root, B * N);
@@ -432,7 +434,7 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
   hipEventElapsedTime(&b->filter_ms, b->ev[2], b->ev[3]);
   for (int s = 0; s < B; ++s) if (n_out) n_out[s] = d.h_nout[s];
   if (out && !out_on_device) {
-    for (int s = 0; s < B; ++s) if (out[s] && d.h_nout[s]) HIP_TRY(hipMemcpyAsync(out[s], d.ground + (size_t)s * d.Nmax + d.h_noff[s], d.h_nout[s] * sizeof(float4), hipMemcpyDeviceToHost, b->st));
+    for (int s = 0; s < B; ++s) if (out[s] && d.h_nout[s]) HIP_TRY(hipMemcpyAsync(out[s], d.ground + 2 * (size_t)s * d.Nmax + d.h_noff[s], d.h_nout[s] * sizeof(float4), hipMemcpyDeviceToHost, b->st));
     HIP_TRY(hipStreamSynchronize(b->st));
   }
   return rc;
@@ -444,7 +446,7 @@ int mor_batch_wait(mor_batch *b) { if (!b) return MOR_ERR_INVALID; HIP_TRY(hipSe
 const void *mor_get_output_device(const mor_batch *b, int s, uint64_t *n_out) {
   if (!b || s < 0 || s >= b->B) return nullptr;
   if (n_out) *n_out = b->d.h_nout[s];
-  return b->d.ground + (size_t)s * b->d.Nmax + b->d.h_noff[s];   // assembled in place in the frame's ground buffer (valid until three more frames have been pushed)
+  return b->d.ground + 2 * (size_t)s * b->d.Nmax + b->d.h_noff[s];   // assembled in place in the frame's ground buffer (valid until three more frames have been pushed)
 }
 
 // ---- single-stream forms

@@ -27,7 +27,7 @@
 #include <cstdlib>
 
 const char *const mor_kernel_names[MK_COUNT] = {
-    "classify", "scan_tiles", "scatter", "heads_count", "heads_scan", "heads_scatter", "hash_clear", "rowtable", "cellboxes", "cellgraph", "cellbox", "hook_cells", "hook_cells_shell", "flatten", "cellcid",
+    "classify", "scan_tiles", "scatter", "split", "heads_count", "heads_scan", "heads_scatter", "hash_clear", "rowtable", "cellboxes", "cellgraph", "cellbox", "hook_cells", "hook_cells_shell", "flatten", "cellcid",
     "select_count", "select_scan", "select_scatter", "rank", "offsets", "label", "rhist", "rscan", "rscatter",
     "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "pairs", "score_fast", "score_near", "score_block", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
     "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_mode", "g2_mark", "track_push", "track_filter"};
@@ -182,6 +182,13 @@ __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, 
   return r;
 }
 
+// start of a frame: input size, error flags and cluster counts of the stream's info record (not in pass B of the voxel
+// variant, which continues the frame).  Runs in the first kernel of the frame, before any kernel that raises a flag.
+__device__ __forceinline__ void reset_frame_info(const MorDev &d, int s) {
+  if (d.gmode == 2) return;
+  MorFrameInfo &f = d.info[s];
+  f.N = d.args[s].n; f.flags = 0; f.n_pairs = 0; f.K = 0; f.C = 0;
+}
 // ------------------------------------------------------------------------------------ G1: trim + ground split
 // pass 1: per-tile counts of (non-ground, ground)
 __global__ __launch_bounds__(MOR_BT) void k_classify(MorDev d) {
@@ -208,17 +215,17 @@ __global__ __launch_bounds__(MOR_BT) void k_classify(MorDev d) {
   if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
   __syncthreads();
   if (threadIdx.x == 0) {
+    if (t == 0) reset_frame_info(d, s);
     int *o = d.tile_cnt + ((size_t)s * d.tiles_max + t) * 2;
     o[0] = sh[0] + sh[1] + sh[2] + sh[3];
     o[1] = sh[4] + sh[5] + sh[6] + sh[7];
   }
 }
 
-// N, T, M, G of the frame (and, for pass A of the voxel variant, the z origin of its grids)
+// T, M, G of the frame (and, for pass A of the voxel variant, the z origin of its grids)
 __device__ __forceinline__ void publish_split(const MorDev &d, int s, int n_ng, int n_g) {
   MorFrameInfo &f = d.info[s];
   f.M = n_ng; f.G = n_g; f.T = n_ng + n_g;
-  if (d.gmode != 2) { f.N = d.args[s].n; f.flags = 0; f.n_pairs = 0; f.K = 0; f.C = 0; }
   if (d.gmode == 1) {   // grids of the voxel variant hang on the lowest trimmed point
     float zmin = f.T ? ordered_float(d.zmin_i[s]) : 0.f;
     d.zorg[s] = zmin; d.zbase[s] = (int)floorf(zmin * d.gv.inv_cs);
@@ -247,15 +254,14 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   const uint32_t n_in = pass_count(d, a, s);
   uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
   __shared__ int sh[8];
-  int r_ng = 0, r_g = 0, m_total = 0; float zorg = d.zorg[s]; int zbase = d.zbase[s];
+  int r_ng = 0, r_g = 0; float zorg = d.zorg[s]; int zbase = d.zbase[s];
   if (d.fuse_scans) {   // own offsets from the per-tile counts of k_classify; tile 0 publishes the totals
     const int *tc = d.tile_cnt + (size_t)s * d.tiles_max * 2; int tot_ng, tot_g;
     wg_prefix_total(tc, 2, t, d.tiles, sh, r_ng, tot_ng);
     wg_prefix_total(tc + 1, 2, t, d.tiles, sh, r_g, tot_g);
     if (d.gmode == 1) { zorg = (tot_ng + tot_g) ? ordered_float(d.zmin_i[s]) : 0.f; zbase = (int)floorf(zorg * d.gv.inv_cs); }
     if (t == 0 && threadIdx.x == 0) publish_split(d, s, tot_ng, tot_g);
-    m_total = tot_ng;
-  } else m_total = (int)d.info[s].M;
+  }
   if ((uint32_t)t * MOR_TILE >= n_in) return;
   float4 p[8]; int cls[8]; unsigned long long m_ng[8], m_g[8];
   int c_ng = 0, c_g = 0;
@@ -283,7 +289,96 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
       d.cloud_tidx[so + k_ng] = k_ng + k_g;   // index in the trimmed cloud (both ranks are exclusive counts of earlier kept points)
       d.pkey[so + k_ng] = (cz * d.g.ny + cy) * d.g.nx + cx;
     } else if (cls[it] == 1) {
-      d.ground[so + m_total + k_g] = p[it];   // final place of filterCloud's output: [kept cloud, right-aligned to M | ground]
+      d.ground[2 * so + d.Nmax + k_g] = p[it];   // final place in filterCloud's output: [kept cloud, right-aligned to slot Nmax | ground from slot Nmax]
+      d.gp_idx[so + k_g] = k_ng + k_g;
+    }
+    r_ng += __popcll(m_ng[it]); r_g += __popcll(m_g[it]);
+  }
+}
+
+// Single-pass variant of k_classify + k_scatter (crop-box variant and pass B of the voxel variant): the cloud is read
+// ONCE.  Every tile counts its (non-ground, ground) points, publishes the pair in a 64-bit descriptor and obtains its
+// exclusive prefix by decoupled look-back over the descriptors of the earlier tiles of its stream (status A = tile
+// aggregate, P = inclusive prefix; Merrill & Garland).  Workgroups of a stream are dispatched in tile order
+// (map_block), so a tile only ever waits for workgroups that are already running.  Descriptors are zeroed by a
+// memset in front of the kernel; they are polled and published with agent-scope read-modify-write atomics (coherent
+// across the XCDs' L2s).  The last tile publishes N, T, M, G.
+#define SPLIT_A 1ull
+#define SPLIT_P 2ull
+#define SPLIT_SPIN_LIMIT (1u << 22)
+__device__ __forceinline__ unsigned long long split_pack(unsigned long long st, int ng, int g) { return (st << 62) | ((unsigned long long)(unsigned)ng << 31) | (unsigned long long)(unsigned)g; }
+__global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
+  int s, t; map_block(d.B, d.tiles, s, t);
+  const MorStreamArgs a = d.args[s];
+  const uint32_t n_in = pass_count(d, a, s);
+  const uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
+  float4 p[8]; int cls[8]; unsigned long long m_ng[8], m_g[8];
+  int c_ng = 0, c_g = 0;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    uint32_t i = base + it * 64 + lane_id();
+    cls[it] = 0;
+    if (i < n_in) cls[it] = pass_item(d, a, s, i, p[it]);
+    m_ng[it] = __ballot(cls[it] == 2); m_g[it] = __ballot(cls[it] == 1);
+    c_ng += __popcll(m_ng[it]); c_g += __popcll(m_g[it]);
+  }
+  __shared__ int sh[8], s_ex[2];
+  if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
+  __syncthreads();
+  if (wave_id() == 0) {
+    const int tng = sh[0] + sh[1] + sh[2] + sh[3], tg = sh[4] + sh[5] + sh[6] + sh[7], lane = lane_id();
+    unsigned long long *desc = d.split_desc + (size_t)s * d.tiles_max;
+    if (lane == 0) {
+      if (t == 0) { reset_frame_info(d, s); __threadfence(); }   // every other tile raises flags only after its look-back has seen this tile's descriptor
+      atomicExch(&desc[t], split_pack(t == 0 ? SPLIT_P : SPLIT_A, tng, tg));
+    }
+    int ex_ng = 0, ex_g = 0;
+    if (t > 0) {
+      int back = t - 1; unsigned spins = 0;
+      for (;;) {
+        const int j = back - lane;
+        const unsigned long long v = j >= 0 ? atomicAdd(&desc[j], 0ull) : split_pack(SPLIT_P, 0, 0);   // "tile −1": prefix 0
+        const unsigned long long st = v >> 62;
+        const unsigned long long mP = __ballot(st == SPLIT_P), mX = __ballot(st == 0ull);
+        const int fp = mP ? __ffsll((long long)mP) - 1 : 64;                                 // nearest tile with a full prefix
+        const unsigned long long need = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);          // lanes 0 … fp
+        if (mX & need) {                                                                     // a needed tile has not published yet
+          if (++spins > SPLIT_SPIN_LIMIT) { if (lane == 0) atomicOr(&d.info[s].flags, 64u); break; }
+          __builtin_amdgcn_s_sleep(2);
+          continue;
+        }
+        int cn = lane <= fp ? (int)((v >> 31) & 0x7fffffffu) : 0, cg = lane <= fp ? (int)(v & 0x7fffffffu) : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { cn += __shfl_xor(cn, o, 64); cg += __shfl_xor(cg, o, 64); }
+        ex_ng += cn; ex_g += cg;
+        if (fp < 64) break;
+        back -= 64;
+      }
+      if (lane == 0) atomicExch(&desc[t], split_pack(SPLIT_P, ex_ng + tng, ex_g + tg));
+    }
+    if (lane == 0) {
+      s_ex[0] = ex_ng; s_ex[1] = ex_g;
+      if (t == d.tiles - 1) publish_split(d, s, ex_ng + tng, ex_g + tg);
+    }
+  }
+  __syncthreads();
+  if ((uint32_t)t * MOR_TILE >= n_in) return;
+  int r_ng = s_ex[0], r_g = s_ex[1];
+  for (int w = 0; w < wave_id(); ++w) { r_ng += sh[w]; r_g += sh[4 + w]; }
+  const size_t so = (size_t)s * d.Nmax;
+  const float zorg = d.zorg[s]; const int zbase = d.zbase[s];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    int k_ng = r_ng + __popcll(m_ng[it] & lanemask_lt());
+    int k_g = r_g + __popcll(m_g[it] & lanemask_lt());
+    if (cls[it] == 2) {
+      int cx, cy, cz; bool clamped; grid_cell(d.g, p[it], zorg, zbase, cx, cy, cz, clamped);
+      if (clamped && d.gmode != 0) atomicOr(&d.info[s].flags, 8u);
+      d.cloud[so + k_ng] = p[it];
+      d.cloud_tidx[so + k_ng] = k_ng + k_g;
+      d.pkey[so + k_ng] = (cz * d.g.ny + cy) * d.g.nx + cx;
+    } else if (cls[it] == 1) {
+      d.ground[2 * so + d.Nmax + k_g] = p[it];
       d.gp_idx[so + k_g] = k_ng + k_g;
     }
     r_ng += __popcll(m_ng[it]); r_g += __popcll(m_g[it]);
@@ -1770,33 +1865,34 @@ __global__ __launch_bounds__(MOR_BT) void k_out_scan(MorDev d) {
     if (t < nt) c[t] = carry + e;
     carry += tot;
   }
-  if (threadIdx.x == 0) { d.info[s].n_keep = carry; d.h_nout[s] = (unsigned long long)carry + d.info[s].G; d.h_noff[s] = d.info[s].M - carry; }
+  if (threadIdx.x == 0) { d.info[s].n_keep = carry; d.h_nout[s] = (unsigned long long)carry + d.info[s].G; d.h_noff[s] = d.Nmax - carry; }
 }
 // filterCloud's output (:673-684) = [cloud minus moving clusters, original order] ++ [ground points].  The ground points
-// were written to their final place by k_scatter (behind the M cloud slots of the `ground` buffer), so the result is
-// assembled in place: the kept cloud points go right-aligned in front of them and the result starts at slot M − n_keep —
+// were written to their final place by the split kernel (from slot Nmax of the stream's 2·Nmax-slot `ground` buffer), so the
+// result is assembled in place: the kept cloud points go right-aligned in front of them and the result starts at slot
+// Nmax − n_keep —
 // the bulk of the frame (the ground, ≈ 90 % of a LiDAR sweep) is not copied again.  With caller-provided device
 // pointers both parts are copied out: workgroups [0, tiles_m) per stream the kept cloud points (grid-stride over the
 // cloud's tiles), workgroups [tiles_m, tiles_m + tiles) the ground points.
 __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
   int s, t2; map_block(d.B, d.tiles_m + (d.out_ptrs ? d.tiles : 0), s, t2);
   const size_t so = (size_t)s * d.Nmax;
-  float4 *og = d.ground + so;
+  float4 *og = d.ground + 2 * so;
   const int M = d.info[s].M;
   __shared__ int sh[12];
   const int nto = (M + MOR_TILE - 1) / MOR_TILE;
   int n_keep = 0;
   if (d.fuse_scans) {   // kept points in total: every workgroup sums the per-tile counts of k_out_count itself
     int pre; wg_prefix_total(d.otile_cnt + (size_t)s * d.tiles_max, 1, 0, nto, sh, pre, n_keep);
-    if (t2 == 0 && threadIdx.x == 0) { d.info[s].n_keep = n_keep; d.h_nout[s] = (unsigned long long)n_keep + d.info[s].G; d.h_noff[s] = M - n_keep; }
+    if (t2 == 0 && threadIdx.x == 0) { d.info[s].n_keep = n_keep; d.h_nout[s] = (unsigned long long)n_keep + d.info[s].G; d.h_noff[s] = d.Nmax - n_keep; }
   } else n_keep = d.info[s].n_keep;
   if (t2 >= d.tiles_m) {
     int t = t2 - d.tiles_m, G = d.info[s].G, nk = n_keep, base = t * MOR_TILE;
     float4 *out = d.out_ptrs[s];
-    for (int i = base + threadIdx.x; i < min(base + MOR_TILE, G); i += MOR_BT) out[nk + i] = og[M + i];
+    for (int i = base + threadIdx.x; i < min(base + MOR_TILE, G); i += MOR_BT) out[nk + i] = og[d.Nmax + i];
     return;
   }
-  float4 *dst = d.out_ptrs ? d.out_ptrs[s] : og + (M - n_keep);
+  float4 *dst = d.out_ptrs ? d.out_ptrs[s] : og + (d.Nmax - n_keep);
   for (int t = t2; t * MOR_TILE < M; t += d.tiles_m) {
     int base = t * MOR_TILE + wave_id() * 512, c = 0;
     unsigned long long mk[8];
@@ -2131,9 +2227,14 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
 
 static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B);
-  MOR_LAUNCH(MK_CLASSIFY, k_classify, gT, d);
-  if (!d.fuse_scans) MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
-  MOR_LAUNCH(MK_SCATTER, k_scatter, gT, d);
+  if (d.fuse_scans && d.gmode != 1 && !getenv("MOR_TWO_PASS_SPLIT")) {
+    (void)hipMemsetAsync(d.split_desc + (size_t)d.s0 * d.tiles_max, 0, (size_t)d.B * d.tiles_max * sizeof(unsigned long long), st);
+    MOR_LAUNCH(MK_SPLIT, k_split, gT, d);
+  } else {
+    MOR_LAUNCH(MK_CLASSIFY, k_classify, gT, d);
+    if (!d.fuse_scans) MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
+    MOR_LAUNCH(MK_SCATTER, k_scatter, gT, d);
+  }
   for (int pass = 0; pass < d.cell_passes; ++pass) {   // points sorted by cell key; result in (skey, sidx) = buffers [cell_passes & 1]
     MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0, d.fuse_scans && d.tiles_m <= 64};
     MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
