@@ -184,18 +184,25 @@ def main():
 
     e2e = None
     if args.e2e and rank == 0:
-        xs, ps = synth.batch(seeds, [0] * B, sensor)
-        xs1, ps1 = synth.batch(seeds, [1] * B, sensor)
+        # PCIe-inclusive: clouds start in page-locked host memory, filtered clouds end there (synchronous push + filter)
+        hin = [engine.HostBuffer((B, npts, 4)) for _ in range(2)]
+        hout = engine.HostBuffer((B, npts, 4))
+        for f in range(2):
+            xs, ps_ = synth.batch(seeds, [f] * B, sensor)
+            hin[f].array[...] = np.asarray(xs).reshape(B, npts, 4)
+        pp = [np.ascontiguousarray(poses[0]), np.ascontiguousarray(poses[1])]
         hb = engine.MorBatch(p, B, npts, 4, 3, device)
-        hb.push(list(xs), ps)
-        hb.filter()
+        hb.push([hin[0].array[s] for s in range(B)], pp[0])
+        hb.filter_into([hout.array[s] for s in range(B)])
         t1 = time.perf_counter()
-        reps = 3
+        reps = 6
         for r in range(reps):
-            hb.push(list(xs1 if r % 2 == 0 else xs), ps1 if r % 2 == 0 else ps)
-            hb.filter()
+            hb.push([hin[(r + 1) % 2].array[s] for s in range(B)], pp[(r + 1) % 2])
+            hb.filter_into([hout.array[s] for s in range(B)])
         e2e = B * reps / (time.perf_counter() - t1)
         hb.close()
+        for x in hin + [hout]:
+            x.free()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

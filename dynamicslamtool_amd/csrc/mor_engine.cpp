@@ -533,6 +533,8 @@ int mor_get_stage_counts(const mor_batch *b, int s, uint32_t *out, int n) {
 // ---- device memory helpers
 void *mor_device_alloc(int device, size_t bytes) { void *p = nullptr; if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) { set_error(MOR_ERR_HIP, "hipMalloc(%zu) failed", bytes); return nullptr; } return p; }
 void mor_device_free(int device, void *p) { if (hipSetDevice(device) == hipSuccess) hipFree(p); }
+void *mor_host_alloc(size_t bytes) { void *p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { set_error(MOR_ERR_HIP, "hipHostMalloc(%zu) failed", bytes); return nullptr; } return p; }
+void mor_host_free(void *p) { if (p) hipHostFree(p); }
 int mor_device_upload(int device, void *dst, const void *src, size_t bytes) { HIP_TRY(hipSetDevice(device)); HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return MOR_OK; }
 int mor_device_download(int device, void *dst, const void *src, size_t bytes) { HIP_TRY(hipSetDevice(device)); HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return MOR_OK; }
 int mor_device_synchronize(int device) { HIP_TRY(hipSetDevice(device)); HIP_TRY(hipDeviceSynchronize()); return MOR_OK; }

@@ -16,7 +16,7 @@ EXPORTS = [
     "mor_sizeof_params", "mor_last_error", "mor_batch_create", "mor_batch_destroy", "mor_batch_streams", "mor_push_batch",
     "mor_filter_batch", "mor_batch_set_async", "mor_batch_wait", "mor_get_output_device", "mor_create", "mor_push", "mor_filter", "mor_destroy", "mor_get_counts",
     "mor_get_labels", "mor_get_ground_indices", "mor_get_clusters", "mor_get_centroids", "mor_get_detection",
-    "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_get_stage_counts", "mor_device_alloc", "mor_device_free",
+    "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_get_stage_counts", "mor_device_alloc", "mor_device_free", "mor_host_alloc", "mor_host_free",
     "mor_device_upload", "mor_device_download", "mor_device_synchronize", "mor_device_count", "mor_get_last_timing",
     "mor_kernel_timing_enable", "mor_kernel_timing_read", "mor_tracker_create", "mor_tracker_destroy", "mor_tracker_push",
     "mor_tracker_filter", "mor_tracker_get",
@@ -66,6 +66,9 @@ def lib():
         L.mor_device_alloc.restype = vp
         L.mor_device_alloc.argtypes = [i32, C.c_size_t]
         L.mor_device_free.argtypes = [i32, vp]
+        L.mor_host_alloc.restype = vp
+        L.mor_host_alloc.argtypes = [C.c_size_t]
+        L.mor_host_free.argtypes = [vp]
         L.mor_device_upload.argtypes = [i32, vp, vp, C.c_size_t]
         L.mor_device_download.argtypes = [i32, vp, vp, C.c_size_t]
         L.mor_device_synchronize.argtypes = [i32]
@@ -118,6 +121,29 @@ class DeviceBuffer:
     def free(self):
         if self.ptr:
             lib().mor_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class HostBuffer:
+    """Page-locked host memory viewed as a numpy array (PCIe transfers to and from it run at DMA rate)."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = lib().mor_host_alloc(max(self.nbytes, 1))
+        if not self.ptr:
+            raise MorError(lib().mor_last_error().decode())
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr))[: self.nbytes].view(dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().mor_host_free(self.ptr)
             self.ptr = None
 
     def __del__(self):
@@ -212,6 +238,14 @@ class MorBatch:
         ptrs = (C.c_void_p * self.B)(*[o.ctypes.data for o in outs])
         _check(lib().mor_filter_batch(self._h, C.addressof(ptrs), 0, C.addressof(n_out)))
         return [outs[s][: int(n_out[s])] for s in range(self.B)]
+
+    def filter_into(self, outs):
+        """filterCloud into caller-provided host arrays (e.g. HostBuffer.array), one per stream, each with room for the
+        stream's input point count; returns the point counts."""
+        n_out = (C.c_uint64 * self.B)()
+        ptrs = (C.c_void_p * self.B)(*[o.ctypes.data for o in outs])
+        _check(lib().mor_filter_batch(self._h, C.addressof(ptrs), 0, C.addressof(n_out)))
+        return [int(x) for x in n_out]
 
     # ---- read-backs
     def counts(self, s=0):

@@ -134,6 +134,10 @@ int mor_get_stage_counts(const mor_batch *b, int stream, uint32_t *out, int n);
 /* ---- device-memory helpers so callers can keep clouds resident in HBM (bench, replay driver) ---- */
 void *mor_device_alloc(int device, size_t bytes);
 void mor_device_free(int device, void *p);
+/* page-locked host memory: clouds handed over (and outputs received) in it cross PCIe by DMA at full rate; pageable
+ * memory works too but is staged by the driver at a fraction of it */
+void *mor_host_alloc(size_t bytes);
+void mor_host_free(void *p);
 int mor_device_upload(int device, void *dst, const void *src, size_t bytes);
 int mor_device_download(int device, void *dst, const void *src, size_t bytes);
 int mor_device_synchronize(int device);
