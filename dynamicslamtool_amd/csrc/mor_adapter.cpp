@@ -105,6 +105,26 @@ void MovingObjectRemoval::pushRawCloudAndPose(pcl::PCLPointCloud2 &cloud, geomet
 #endif
 }
 
+std::vector<MovingObjectRemoval::BoxMarker> MovingObjectRemoval::clusterMarkers() const {
+  std::vector<BoxMarker> out;
+  mor_counts c;
+  if (!ctx_ || mor_get_counts(ctx_, 0, &c) != MOR_OK || c.n_clusters == 0) return out;
+  std::vector<float> cen(3 * (size_t)c.n_clusters), lo(3 * (size_t)c.n_clusters), hi(3 * (size_t)c.n_clusters);
+  std::vector<uint8_t> det(c.n_clusters);
+  if (mor_get_centroids(ctx_, 0, cen.data()) != MOR_OK || mor_get_boxes(ctx_, 0, lo.data(), hi.data()) != MOR_OK || mor_get_detection(ctx_, 0, det.data()) != MOR_OK) return out;
+  out.resize(c.n_clusters);
+  for (uint32_t k = 0; k < c.n_clusters; ++k) {
+    BoxMarker &m = out[k];
+    m.id = (int)k; m.moving = det[k] != 0;
+    for (int a = 0; a < 3; ++a) {
+      m.position[a] = cen[3 * k + a];
+      m.scale[a] = hi[3 * k + a] - lo[3 * k + a];
+      if (m.scale[a] == 0) m.scale[a] = 0.1f;   // .cpp:40-47
+    }
+  }
+  return out;
+}
+
 bool MovingObjectRemoval::filterCloud(pcl::PCLPointCloud2 &out_cloud, std::string f_id) {
   scratch_.resize(4 * (size_t)last_n_ + 4);
   uint64_t n = 0;

@@ -517,6 +517,19 @@ int mor_get_cluster_collection(const mor_batch *b, int s, float *out) {
   return MOR_OK;
 }
 
+int mor_get_boxes(const mor_batch *b, int s, float *min_K3, float *max_K3) {
+  CHECK_STREAM();
+  if (!f.K) return MOR_OK;
+  std::vector<float4> lo(f.K), hi(f.K);
+  HIP_TRY(hipMemcpy(lo.data(), d.amin[d.cur] + ko, f.K * sizeof(float4), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(hi.data(), d.amax[d.cur] + ko, f.K * sizeof(float4), hipMemcpyDeviceToHost));
+  for (uint32_t k = 0; k < f.K; ++k) {
+    min_K3[3 * k] = lo[k].x; min_K3[3 * k + 1] = lo[k].y; min_K3[3 * k + 2] = lo[k].z;
+    max_K3[3 * k] = hi[k].x; max_K3[3 * k + 1] = hi[k].y; max_K3[3 * k + 2] = hi[k].z;
+  }
+  return MOR_OK;
+}
+
 int mor_exp_read_stamps(const mor_batch *b, unsigned long long *out) {
   if (!b) return MOR_ERR_INVALID;
   HIP_TRY(hipMemcpy(out, b->d.dbg, sizeof(unsigned long long) * 16 * b->B, hipMemcpyDeviceToHost));

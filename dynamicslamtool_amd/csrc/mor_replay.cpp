@@ -47,7 +47,12 @@ int main(int argc, char **argv) {
     for (size_t k = 0; k < n; ++k) { const uint8_t *r = mor.output.data.data() + k * mor.output.point_step; std::memcpy(&packed[4 * k], r, 12); std::memcpy(&packed[4 * k + 3], r + 16, 4); }
     char name[64]; std::snprintf(name, sizeof name, "/filtered_%04d.bin", i - 4);
     std::ofstream o(out_dir + name, std::ios::binary); o.write((const char *)packed.data(), packed.size() * sizeof(float));
-    std::cout << "frame " << (i - 4) << ": " << cloud.width << " pts in filtered cloud, frame_id " << mor.output.header.frame_id << ", " << ms << " ms" << std::endl;
+    // the debug bounding boxes (what the reference publishes as markers under VISUALIZE): id px py pz sx sy sz moving
+    std::snprintf(name, sizeof name, "/markers_%04d.txt", i - 4);
+    std::ofstream mk(out_dir + name);
+    const auto markers = mor.clusterMarkers();
+    for (const auto &m : markers) mk << m.id << ' ' << m.position[0] << ' ' << m.position[1] << ' ' << m.position[2] << ' ' << m.scale[0] << ' ' << m.scale[1] << ' ' << m.scale[2] << ' ' << (m.moving ? 1 : 0) << '\n';
+    std::cout << "frame " << (i - 4) << ": " << cloud.width << " pts in filtered cloud, " << markers.size() << " cluster boxes, frame_id " << mor.output.header.frame_id << ", " << ms << " ms" << std::endl;
   }
   return 0;
 }

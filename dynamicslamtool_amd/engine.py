@@ -15,7 +15,7 @@ MOR_NO_FIELD = 0xFFFFFFFF
 EXPORTS = [
     "mor_sizeof_params", "mor_last_error", "mor_batch_create", "mor_batch_destroy", "mor_batch_streams", "mor_push_batch",
     "mor_filter_batch", "mor_batch_set_async", "mor_batch_wait", "mor_get_output_device", "mor_create", "mor_push", "mor_filter", "mor_destroy", "mor_get_counts",
-    "mor_get_labels", "mor_get_ground_indices", "mor_get_clusters", "mor_get_centroids", "mor_get_detection",
+    "mor_get_labels", "mor_get_ground_indices", "mor_get_clusters", "mor_get_centroids", "mor_get_detection", "mor_get_boxes",
     "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_get_stage_counts", "mor_device_alloc", "mor_device_free", "mor_host_alloc", "mor_host_free",
     "mor_device_upload", "mor_device_download", "mor_device_synchronize", "mor_device_count", "mor_get_last_timing",
     "mor_kernel_timing_enable", "mor_kernel_timing_read", "mor_tracker_create", "mor_tracker_destroy", "mor_tracker_push",
@@ -57,12 +57,13 @@ def lib():
         L.mor_push.argtypes = [vp, vp, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
         L.mor_filter.argtypes = [vp, vp, vp]
         L.mor_destroy.argtypes = [vp]
-        for n in ("mor_get_counts", "mor_get_labels", "mor_get_ground_indices", "mor_get_centroids", "mor_get_detection", "mor_get_cluster_collection"):
+        for n in ("mor_get_counts", "mor_get_labels", "mor_get_ground_indices", "mor_get_centroids", "mor_get_detection", "mor_get_boxes", "mor_get_cluster_collection"):
             getattr(L, n).argtypes = [vp, i32, vp]
         L.mor_get_clusters.argtypes = [vp, i32, vp, vp]
         L.mor_get_correspondences.argtypes = [vp, i32, vp, vp, vp, vp]
         L.mor_get_tracks.argtypes = [vp, i32, vp, vp, vp]
         L.mor_get_stage_counts.argtypes = [vp, i32, vp, i32]
+        L.mor_get_boxes.argtypes = [vp, i32, vp, vp]
         L.mor_device_alloc.restype = vp
         L.mor_device_alloc.argtypes = [i32, C.c_size_t]
         L.mor_device_free.argtypes = [i32, vp]
@@ -273,6 +274,20 @@ class MorBatch:
 
     def centroids(self, s=0):
         return self._get(lib().mor_get_centroids, s, self.counts(s).n_clusters, np.float32, 3)
+
+    def boxes(self, s=0):
+        """(min[K,3], max[K,3]) of the clusters' points (getMinMax3D)."""
+        K = self.counts(s).n_clusters
+        lo, hi = np.empty((max(K, 1), 3), np.float32), np.empty((max(K, 1), 3), np.float32)
+        _check(lib().mor_get_boxes(self._h, s, lo.ctypes.data, hi.ctypes.data))
+        return lo[:K], hi[:K]
+
+    def markers(self, s=0):
+        """Data of the reference's debug markers (mark_cluster, :7-58): per cluster (position xyz, scale xyz); zero extents become 0.1."""
+        lo, hi = self.boxes(s)
+        scale = hi - lo
+        scale[scale == 0] = 0.1
+        return self.centroids(s), scale
 
     def detection(self, s=0):
         return self._get(lib().mor_get_detection, s, self.counts(s).n_clusters, np.uint8)

@@ -31,6 +31,13 @@ class MovingObjectRemoval {
   // Returns true (the reference cannot fail); false only if the GPU call failed.
   bool filterCloud(pcl::PCLPointCloud2 &cloud, std::string f_id);
 
+  // not in the reference's public interface: the data of its debug bounding-box markers (mark_cluster, .cpp:7-58 —
+  // a CUBE at the cluster centroid, scale = max − min of its points, zero extents replaced by 0.1), one entry per
+  // cluster of the latest frame in cluster order; `moving` = detection_results of that cluster.  A ROS build turns
+  // them into visualization_msgs::Marker with header.frame_id = debug_fid(), ns "bounding_box", lifetime 2 s.
+  struct BoxMarker { int id; float position[3], scale[3]; bool moving; };
+  std::vector<BoxMarker> clusterMarkers() const;
+
   // not in the reference: parameters as parsed (for tools/tests) and the last error text
   const mor_params &params() const { return params_; }
   const std::string &debug_fid() const { return debug_fid_; }

@@ -119,6 +119,9 @@ int mor_get_ground_indices(const mor_batch *b, int stream, int32_t *idx_G);
 int mor_get_clusters(const mor_batch *b, int stream, int32_t *offsets, int32_t *indices);
 int mor_get_centroids(const mor_batch *b, int stream, float *xyz_K3);  /* centroid_collection (:243) */
 int mor_get_detection(const mor_batch *b, int stream, uint8_t *det_K); /* detection_results (:593-604) */
+/* axis-aligned boxes of the clusters (getMinMax3D, :16 / :272-274): with the centroids they are the data of the
+ * reference's debug markers (mark_cluster, :7-58: CUBE at the centroid, scale = max − min, zero extent → 0.1) */
+int mor_get_boxes(const mor_batch *b, int stream, float *min_K3, float *max_K3);
 /* correspondence map mp (:564) + movement scores param_vec (:571/:575) of the last push */
 int mor_get_correspondences(const mor_batch *b, int stream, int32_t *query, int32_t *match, float *dist, double *score);
 /* mo_vec (header :109): centroid xyz, confidence, max_confidence */

@@ -55,5 +55,11 @@ def test_replay_matches_oracle(tmp_path, method):
         got = np.fromfile(tmp_path / ("filtered_%04d.bin" % i), np.float32).reshape(-1, 4)
         assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), "frame %d" % i
         removed = max(removed, int(o.counts().n_trim) - len(want))
+        # debug bounding boxes (mark_cluster, reference .cpp:7-58): one per cluster, centred on its centroid
+        mk = np.loadtxt(tmp_path / ("markers_%04d.txt" % i), ndmin=2)
+        cen = o.centroids()
+        assert len(mk) == len(cen), "frame %d" % i
+        if len(cen):
+            assert np.allclose(mk[:, 1:4], cen, atol=1e-4) and (mk[:, 4:7] > 0).all(), "frame %d" % i
     if method == 2:
         assert removed > 0

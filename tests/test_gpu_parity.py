@@ -250,6 +250,28 @@ def test_dense_sheets_overflow_the_deferred_pair_list():
     b.close()
 
 
+def test_cluster_boxes_are_the_min_max_of_their_points():
+    """mor_get_boxes = getMinMax3D of every cluster (the data of the reference's bounding-box markers, :7-58): exact
+    fp32 min / max over the cluster's points as listed by cluster_indices."""
+    p = kitti_params(1)
+    b = MorBatch(p, 2, 120000)
+    for f in range(2):
+        xs, ps = synth.batch([2003, 2011], [f, f])
+        b.push(list(xs), ps)
+        b.filter(to_host=False)
+    for s in range(2):
+        off, idx = b.clusters(s)
+        pts = b.cluster_collection(s)[:, :3]
+        lo, hi = b.boxes(s)
+        assert len(lo) == b.counts(s).n_clusters > 0
+        for k in range(len(lo)):
+            q = pts[off[k]:off[k + 1]]
+            assert np.array_equal(lo[k], q.min(0)) and np.array_equal(hi[k], q.max(0)), (s, k)
+        pos, scale = b.markers(s)
+        assert pos.shape == scale.shape and (scale > 0).all()
+    b.close()
+
+
 _OVERFLOW_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
