@@ -287,7 +287,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (p->method_choice == 2) ok = ok && dalloc(b, d.vox, B * (size_t)d.Hcap);
   ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_n, B) && dalloc(b, d.wlb_n, B) && dalloc(b, d.wl2, B * N) && dalloc(b, d.wl2_n, B) && dalloc(b, d.dbg, B * 16);
   ok = ok && dalloc(b, d.zmin_i, B) && dalloc(b, d.zmax_i, B) && dalloc(b, d.zorg, B) && dalloc(b, d.zbase, B) && dalloc(b, d.mode_bin, B);
-  if (d.gmode == 1) ok = ok && dalloc(b, d.rawbuf, B * N) && dalloc(b, d.is_ground, B * N) && dalloc(b, d.vcent, B * N) && dalloc(b, d.vbin, B * N);
+  if (d.gmode == 1) ok = ok && dalloc(b, d.rawbuf, B * N) && dalloc(b, d.is_ground, B * N) && dalloc(b, d.vcent, B * N) && dalloc(b, d.vbin, B * N) && dalloc(b, d.g2_big, B * N) && dalloc(b, d.g2_nbig, B);
   if (ok) {   // crop-box variant: the clustering grid starts at gp_limit for every stream
     std::vector<float> z0(B, p->gp_limit); std::vector<int> zb(B, 0);
     ok = hipMemcpy(d.zorg, z0.data(), B * sizeof(float), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d.zbase, zb.data(), B * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;

@@ -30,7 +30,7 @@ const char *const mor_kernel_names[MK_COUNT] = {
     "classify", "scan_tiles", "scatter", "split", "heads_count", "heads_scan", "heads_scatter", "hash_clear", "rowtable", "cellboxes", "cellgraph", "cellbox", "hook_cells", "hook_cells_shell", "flatten", "cellcid",
     "select_count", "select_scan", "select_scatter", "rank", "offsets", "label", "rhist", "rscan", "rscatter",
     "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "pairs", "score_fast", "score_near", "score_block", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
-    "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_mode", "g2_mark", "track_push", "track_filter"};
+    "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter"};
 
 #ifdef MOR_EXP_STAMPS
 #define RS_T(v) const unsigned long long v = wall_clock64()
@@ -693,7 +693,9 @@ __global__ __launch_bounds__(MOR_BT) void k_select_scatter(MorDev d) {
 // selection, ordering and offsets — nine launches of the general path.  Streams whose cell count
 // exceeds the LDS capacity run the same code on their global-memory arrays.
 #define CG_T 1024
+#ifndef CG_CAP
 #define CG_CAP 12288     // occupied cells held in LDS (keys + union-find forest; point ranges stay in global memory)
+#endif
 #define CG_ROWCAP 8192   // (y,z) rows held in LDS
 #ifndef CG_LIST
 #define CG_LIST 2040     // deferred (cell | cell pair) entries
@@ -1930,10 +1932,12 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_centroid(MorDev d) {
     d.vcent[so + v] = make_float4(sx / n, sy / n, sz / n, 0.f);
   }
 }
-#define G2_CAP 16384    // neighbours of one voxel centroid held in LDS as (d², index) keys (128 KiB of the CU's 160)
+#define G2_CAP 16384    // neighbours of one voxel centroid held in LDS as (d², index) keys (128 KiB of the CU's 160): big-voxel kernel
+#define G2_SMALL 512    // … in the one-wave-per-voxel kernel (4 KiB: many workgroups per CU)
 #define G2_CHUNK 1024   // coordinates staged per step of the ordered fp32 sums
-// all trimmed points with d² < leaf² around q (radiusSearch, :125), appended to the LDS list in arbitrary order
-__device__ __forceinline__ void g2_gather(const MorDev &d, int s, float4 q, unsigned long long *key, int *cnt) {
+// all trimmed points with d² < leaf² around q (radiusSearch, :125), appended to the LDS list in arbitrary order;
+// the count keeps running beyond `cap` so the caller sees the overflow
+__device__ __forceinline__ void g2_gather(const MorDev &d, int s, float4 q, unsigned long long *key, int *cnt, int cap) {
   const size_t so = (size_t)s * d.Nmax;
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   int cx, cy, cz; bool cl; grid_cell(d.g, q, 0.f, d.zbase[s], cx, cy, cz, cl);
@@ -1942,70 +1946,95 @@ __device__ __forceinline__ void g2_gather(const MorDev &d, int s, float4 q, unsi
     if ((unsigned)y >= (unsigned)d.g.ny || (unsigned)z >= (unsigned)d.g.nz) continue;
     int lo, hi; row_cells(d.g, ckey, rs, max(cx - 1, 0), min(cx + 1, d.g.nx - 1), y, z, lo, hi);
     if (lo >= hi) continue;
-    for (int k = st[lo] + threadIdx.x, e = st[hi]; k < e; k += MOR_BT) {
+    for (int k = st[lo] + threadIdx.x, e = st[hi]; k < e; k += blockDim.x) {
       const float4 p = d.sorted[so + k];
       const float dd = sqdist(q.x, q.y, q.z, p.x, p.y, p.z);
       if (dd < d.leaf_r2) {
         int slot = atomicAdd(cnt, 1);
-        if (slot < G2_CAP) key[slot] = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(p.w);
+        if (slot < cap) key[slot] = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(p.w);
       }
     }
   }
 }
-// one workgroup per voxel: neighbours sorted by (d², index) as KdTreeFLANN::radiusSearch returns them; > 3 of them
-// (:131); fp32 centroid (:142) and un-normalised scatter terms xz, yz, zz (:144) summed in that order (coordinates
-// staged through LDS in chunks, one thread adds them up); accepted voxels (:145) record their z-bin (:166)
-__global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
+// Neighbours sorted by (d², index) as KdTreeFLANN::radiusSearch returns them; > 3 of them (:131); fp32 centroid (:142)
+// and un-normalised scatter terms xz, yz, zz (:144) summed in that order (coordinates staged through LDS in chunks,
+// one thread adds them up); an accepted voxel (:145) gets its z-bin (:166).  n = neighbours held in `key`.
+template <int CHUNK> __device__ __forceinline__ int g2_voxel_bin(const MorDev &d, size_t so, const float4 &q, unsigned long long *key, int n, float *px, float *py, float *pz, float *acc) {
+  int P = 4; while (P < n) P <<= 1;
+  for (int i = n + threadIdx.x; i < P; i += blockDim.x) key[i] = ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1) for (int j = k >> 1; j > 0; j >>= 1) {   // bitonic sort of the keys
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+      int l = i ^ j;
+      if (l > i) { bool up = (i & k) == 0; unsigned long long a = key[i], b = key[l]; if ((a > b) == up) { key[i] = b; key[l] = a; } }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { acc[0] = acc[1] = acc[2] = acc[3] = acc[4] = acc[5] = 0.f; }
+  for (int pass = 0; pass < 2; ++pass) {   // pass 0: Σ p (centroid); pass 1: Σ (p−c) terms
+    for (int c0 = 0; c0 < n; c0 += CHUNK) {
+      const int m = min(CHUNK, n - c0);
+      for (int i = threadIdx.x; i < m; i += blockDim.x) { float4 p = d.rawbuf[so + (int)(key[c0 + i] & 0xffffffffu)]; px[i] = p.x; py[i] = p.y; pz[i] = p.z; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        if (pass == 0) { float cx = acc[0], cy = acc[1], cz = acc[2]; for (int i = 0; i < m; ++i) { cx += px[i]; cy += py[i]; cz += pz[i]; } acc[0] = cx; acc[1] = cy; acc[2] = cz; }
+        else { const float cx = acc[0], cy = acc[1], cz = acc[2]; float c02 = acc[3], c12 = acc[4], c22 = acc[5];
+          for (int i = 0; i < m; ++i) { float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; }
+          acc[3] = c02; acc[4] = c12; acc[5] = c22; }
+      }
+      __syncthreads();
+    }
+    if (pass == 0 && threadIdx.x == 0) { const float fn = (float)n; acc[0] /= fn; acc[1] /= fn; acc[2] /= fn; }
+    __syncthreads();
+  }
+  return ((double)fabsf(acc[3]) < 0.001 && (double)fabsf(acc[4]) < 0.001 && (double)fabsf(acc[5]) < 0.001) ? (int)(q.z * 10) : 0x7fffffff;
+}
+// One WAVE per voxel (64-thread workgroups, 10 KiB of LDS ⇒ a dozen voxels in flight per CU): the usual case of at most
+// G2_SMALL neighbours.  Voxels with more (a dense surface next to the sensor) are queued for k_g2_cov_big.
+__global__ __launch_bounds__(64) void k_g2_cov(MorDev d) {
   int s = blockIdx.y + d.s0, V = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
-  __shared__ unsigned long long key[G2_CAP];
-  __shared__ float px[G2_CHUNK], py[G2_CHUNK], pz[G2_CHUNK];
+  __shared__ unsigned long long key[G2_SMALL];
+  __shared__ float px[G2_SMALL], py[G2_SMALL], pz[G2_SMALL];
   __shared__ int cnt;
   __shared__ float acc[6];
   for (int v = blockIdx.x; v < V; v += gridDim.x) {
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     const float4 q = d.vcent[so + v];
-    g2_gather(d, s, q, key, &cnt);
+    g2_gather(d, s, q, key, &cnt, G2_SMALL);
     __syncthreads();
     const int n = cnt;
     int bin = 0x7fffffff;
-    if (n > G2_CAP) { if (threadIdx.x == 0) atomicOr(&d.info[s].flags, 16u); }
-    else if (n > 3) {
-      int P = 4; while (P < n) P <<= 1;
-      for (int i = n + threadIdx.x; i < P; i += MOR_BT) key[i] = ~0ull;
-      __syncthreads();
-      for (int k = 2; k <= P; k <<= 1) for (int j = k >> 1; j > 0; j >>= 1) {   // bitonic sort of the keys
-        for (int i = threadIdx.x; i < P; i += MOR_BT) {
-          int l = i ^ j;
-          if (l > i) { bool up = (i & k) == 0; unsigned long long a = key[i], b = key[l]; if ((a > b) == up) { key[i] = b; key[l] = a; } }
-        }
-        __syncthreads();
-      }
-      if (threadIdx.x == 0) { acc[0] = acc[1] = acc[2] = acc[3] = acc[4] = acc[5] = 0.f; }
-      for (int pass = 0; pass < 2; ++pass) {   // pass 0: Σ p (centroid); pass 1: Σ (p−c) terms
-        for (int c0 = 0; c0 < n; c0 += G2_CHUNK) {
-          const int m = min(G2_CHUNK, n - c0);
-          for (int i = threadIdx.x; i < m; i += MOR_BT) { float4 p = d.rawbuf[so + (int)(key[c0 + i] & 0xffffffffu)]; px[i] = p.x; py[i] = p.y; pz[i] = p.z; }
-          __syncthreads();
-          if (threadIdx.x == 0) {
-            if (pass == 0) { float cx = acc[0], cy = acc[1], cz = acc[2]; for (int i = 0; i < m; ++i) { cx += px[i]; cy += py[i]; cz += pz[i]; } acc[0] = cx; acc[1] = cy; acc[2] = cz; }
-            else { const float cx = acc[0], cy = acc[1], cz = acc[2]; float c02 = acc[3], c12 = acc[4], c22 = acc[5];
-              for (int i = 0; i < m; ++i) { float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; }
-              acc[3] = c02; acc[4] = c12; acc[5] = c22; }
-          }
-          __syncthreads();
-        }
-        if (pass == 0 && threadIdx.x == 0) { const float fn = (float)n; acc[0] /= fn; acc[1] /= fn; acc[2] /= fn; }
-        __syncthreads();
-      }
-      if (threadIdx.x == 0 && (double)fabsf(acc[3]) < 0.001 && (double)fabsf(acc[4]) < 0.001 && (double)fabsf(acc[5]) < 0.001) bin = (int)(q.z * 10);
-    }
+    if (n > G2_SMALL) { if (threadIdx.x == 0) { int slot = atomicAdd(&d.g2_nbig[s], 1); d.g2_big[so + slot] = v; } }
+    else if (n > 3) bin = g2_voxel_bin<G2_SMALL>(d, so, q, key, n, px, py, pz, acc);
     if (threadIdx.x == 0) d.vbin[so + v] = bin;
     __syncthreads();
   }
 }
-// dominant bin (:169-178): most accepted voxels, ties → smallest key
+// the queued voxels: one 256-thread workgroup each, up to G2_CAP neighbours in 128 KiB of LDS
+__global__ __launch_bounds__(MOR_BT) void k_g2_cov_big(MorDev d) {
+  int s = blockIdx.y + d.s0; const int nbig = d.g2_nbig[s];
+  const size_t so = (size_t)s * d.Nmax;
+  __shared__ unsigned long long key[G2_CAP];
+  __shared__ float px[G2_CHUNK], py[G2_CHUNK], pz[G2_CHUNK];
+  __shared__ int cnt;
+  __shared__ float acc[6];
+  for (int w = blockIdx.x; w < nbig; w += gridDim.x) {
+    const int v = d.g2_big[so + w];
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const float4 q = d.vcent[so + v];
+    g2_gather(d, s, q, key, &cnt, G2_CAP);
+    __syncthreads();
+    const int n = cnt;
+    int bin = 0x7fffffff;
+    if (n > G2_CAP) { if (threadIdx.x == 0) atomicOr(&d.info[s].flags, 16u); }
+    else if (n > 3) bin = g2_voxel_bin<G2_CHUNK>(d, so, q, key, n, px, py, pz, acc);
+    if (threadIdx.x == 0) d.vbin[so + v] = bin;
+    __syncthreads();
+  }
+}
 __global__ __launch_bounds__(MOR_BT) void k_g2_mode(MorDev d) {
   int s = blockIdx.x + d.s0, V = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
@@ -2026,22 +2055,27 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mode(MorDev d) {
   __syncthreads();
   if (threadIdx.x == 0) d.mode_bin[s] = best_bin;
 }
-// ground = union of the neighbour lists of the dominant bin's voxels (:184-191, de-duplicated)
-__global__ __launch_bounds__(MOR_BT) void k_g2_mark(MorDev d) {
+// ground = union of the neighbour lists of the dominant bin's voxels (:184-191, de-duplicated): one wave per such
+// voxel marks every trimmed point within the radius (no list, no sort needed here)
+__global__ __launch_bounds__(64) void k_g2_mark(MorDev d) {
   int s = blockIdx.y + d.s0, V = d.info[s].n_occ, mode = d.mode_bin[s];
   if (mode == 0x7fffffff) return;
   const size_t so = (size_t)s * d.Nmax;
-  __shared__ unsigned long long key[G2_CAP];
-  __shared__ int cnt;
+  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   for (int v = blockIdx.x; v < V; v += gridDim.x) {
     if (d.vbin[so + v] != mode) continue;
-    if (threadIdx.x == 0) cnt = 0;
-    __syncthreads();
-    g2_gather(d, s, d.vcent[so + v], key, &cnt);
-    __syncthreads();
-    const int n = min(cnt, G2_CAP);
-    for (int i = threadIdx.x; i < n; i += MOR_BT) d.is_ground[so + (int)(key[i] & 0xffffffffu)] = 1;
-    __syncthreads();
+    const float4 q = d.vcent[so + v];
+    int cx, cy, cz; bool cl; grid_cell(d.g, q, 0.f, d.zbase[s], cx, cy, cz, cl);
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
+      const int y = cy + dy, z = cz + dz;
+      if ((unsigned)y >= (unsigned)d.g.ny || (unsigned)z >= (unsigned)d.g.nz) continue;
+      int lo, hi; row_cells(d.g, ckey, rs, max(cx - 1, 0), min(cx + 1, d.g.nx - 1), y, z, lo, hi);
+      if (lo >= hi) continue;
+      for (int k = st[lo] + threadIdx.x, e = st[hi]; k < e; k += 64) {
+        const float4 p = d.sorted[so + k];
+        if (sqdist(q.x, q.y, q.z, p.x, p.y, p.z) < d.leaf_r2) d.is_ground[so + __float_as_int(p.w)] = 1;
+      }
+    }
   }
 }
 
@@ -2264,9 +2298,15 @@ void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
     da.skey = d.rkeys[da.cell_passes & 1]; da.sidx = d.rvals[da.cell_passes & 1];
     mor_launch_split_and_grid(da, st, tm);
     MOR_LAUNCH(MK_G2_CENTROID, k_g2_centroid, dim3(32, d.B), da);
-    MOR_LAUNCH(MK_G2_COV, k_g2_cov, dim3(512, d.B), da);
+    (void)hipMemsetAsync(d.g2_nbig + d.s0, 0, (size_t)d.B * sizeof(int), st);
+    mor_timer_begin(tm, MK_G2_COV, st);
+    hipLaunchKernelGGL(k_g2_cov, dim3(4096, d.B), dim3(64), 0, st, da);
+    mor_timer_end(tm, MK_G2_COV, st);
+    MOR_LAUNCH(MK_G2_COV_BIG, k_g2_cov_big, dim3(64, d.B), da);
     MOR_LAUNCH(MK_G2_MODE, k_g2_mode, gB, da);
-    MOR_LAUNCH(MK_G2_MARK, k_g2_mark, dim3(512, d.B), da);
+    mor_timer_begin(tm, MK_G2_MARK, st);
+    hipLaunchKernelGGL(k_g2_mark, dim3(4096, d.B), dim3(64), 0, st, da);
+    mor_timer_end(tm, MK_G2_MARK, st);
     MorDev db = d; db.gmode = 2;
     mor_launch_split_and_grid(db, st, tm);
   }
