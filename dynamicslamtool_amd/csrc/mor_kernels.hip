@@ -1956,6 +1956,34 @@ __device__ __forceinline__ void g2_gather(const MorDev &d, int s, float4 q, unsi
     }
   }
 }
+// Wave version (64-thread workgroups): lanes 0 … 8 resolve the nine (y,z) rows of the 3×3×3 voxel block in parallel —
+// each row's three x-cells are one contiguous range of `sorted` — then the wave walks the concatenated candidates 64 at
+// a time.  f(k, point) is called for every candidate within the radius.
+template <class F> __device__ __forceinline__ void g2_for_neighbours(const MorDev &d, int s, const float4 &q, F f) {
+  const size_t so = (size_t)s * d.Nmax;
+  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  const int lane = threadIdx.x & 63;
+  int cx, cy, cz; bool cl; grid_cell(d.g, q, 0.f, d.zbase[s], cx, cy, cz, cl);
+  int b0 = 0, len = 0;
+  if (lane < 9) {
+    const int y = cy + lane % 3 - 1, z = cz + lane / 3 - 1;
+    if ((unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) {
+      int lo, hi; row_cells(d.g, ckey, rs, max(cx - 1, 0), min(cx + 1, d.g.nx - 1), y, z, lo, hi);
+      if (lo < hi) { b0 = st[lo]; len = st[hi] - b0; }
+    }
+  }
+  int rb[9], rp[10]; rp[0] = 0;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) { rb[r] = __shfl(b0, r, 64); rp[r + 1] = rp[r] + __shfl(len, r, 64); }
+  for (int c = lane; c < rp[9]; c += 64) {
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) if (c >= rp[r] && c < rp[r + 1]) k = rb[r] + (c - rp[r]);
+    const float4 p = d.sorted[so + k];
+    const float dd = sqdist(q.x, q.y, q.z, p.x, p.y, p.z);
+    if (dd < d.leaf_r2) f(dd, p);
+  }
+}
 // Neighbours sorted by (d², index) as KdTreeFLANN::radiusSearch returns them; > 3 of them (:131); fp32 centroid (:142)
 // and un-normalised scatter terms xz, yz, zz (:144) summed in that order (coordinates staged through LDS in chunks,
 // one thread adds them up); an accepted voxel (:145) gets its z-bin (:166).  n = neighbours held in `key`.
@@ -2002,7 +2030,10 @@ __global__ __launch_bounds__(64) void k_g2_cov(MorDev d) {
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     const float4 q = d.vcent[so + v];
-    g2_gather(d, s, q, key, &cnt, G2_SMALL);
+    g2_for_neighbours(d, s, q, [&](float dd, const float4 &p) {
+      int slot = atomicAdd(&cnt, 1);
+      if (slot < G2_SMALL) key[slot] = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(p.w);
+    });
     __syncthreads();
     const int n = cnt;
     int bin = 0x7fffffff;
@@ -2061,21 +2092,10 @@ __global__ __launch_bounds__(64) void k_g2_mark(MorDev d) {
   int s = blockIdx.y + d.s0, V = d.info[s].n_occ, mode = d.mode_bin[s];
   if (mode == 0x7fffffff) return;
   const size_t so = (size_t)s * d.Nmax;
-  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   for (int v = blockIdx.x; v < V; v += gridDim.x) {
     if (d.vbin[so + v] != mode) continue;
     const float4 q = d.vcent[so + v];
-    int cx, cy, cz; bool cl; grid_cell(d.g, q, 0.f, d.zbase[s], cx, cy, cz, cl);
-    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
-      const int y = cy + dy, z = cz + dz;
-      if ((unsigned)y >= (unsigned)d.g.ny || (unsigned)z >= (unsigned)d.g.nz) continue;
-      int lo, hi; row_cells(d.g, ckey, rs, max(cx - 1, 0), min(cx + 1, d.g.nx - 1), y, z, lo, hi);
-      if (lo >= hi) continue;
-      for (int k = st[lo] + threadIdx.x, e = st[hi]; k < e; k += 64) {
-        const float4 p = d.sorted[so + k];
-        if (sqdist(q.x, q.y, q.z, p.x, p.y, p.z) < d.leaf_r2) d.is_ground[so + __float_as_int(p.w)] = 1;
-      }
-    }
+    g2_for_neighbours(d, s, q, [&](float, const float4 &p) { d.is_ground[so + __float_as_int(p.w)] = 1; });
   }
 }
 
