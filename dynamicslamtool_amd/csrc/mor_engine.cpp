@@ -386,7 +386,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   mor_launch_grid(d, b->sf, &b->timer);
   HIP_TRY(hipEventRecord(b->ev_grid[k % 4], b->sf));
   // ---- cell graph on sc (in order behind the cell graph of frame k−1)
-  hipStream_t sc = getenv("MOR_EXP_GENERAL_CC") ? b->sf : b->sc;   // the experimental multi-workgroup cell-graph path shares scratch with the grid stage
+  hipStream_t sc = b->sc;
   HIP_TRY(hipStreamWaitEvent(sc, b->ev_grid[k % 4], 0));
   mor_launch_cellgraph(d, sc, &b->timer);
   HIP_TRY(hipEventRecord(b->ev_cg[k % 4], sc));

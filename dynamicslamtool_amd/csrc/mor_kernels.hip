@@ -27,8 +27,8 @@
 #include <cstdlib>
 
 const char *const mor_kernel_names[MK_COUNT] = {
-    "classify", "scan_tiles", "scatter", "split", "heads_count", "heads_scan", "heads_scatter", "hash_clear", "rowtable", "cellboxes", "cellgraph", "cellbox", "hook_cells", "hook_cells_shell", "flatten", "cellcid",
-    "select_count", "select_scan", "select_scatter", "rank", "offsets", "label", "rhist", "rscan", "rscatter",
+    "classify", "scan_tiles", "scatter", "split", "heads_count", "heads_scan", "heads_scatter", "hash_clear", "rowtable", "cellboxes", "cellgraph", 
+    "label", "rhist", "rscan", "rscatter",
     "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "pairs", "score_fast", "score_near", "score_block", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
     "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter"};
 
@@ -89,13 +89,8 @@ __device__ __forceinline__ void wg_prefix_total(const int *c, int stride, int t,
   __syncthreads();
 }
 
-#ifdef MOR_EXP_PLAIN_UF
-__device__ __forceinline__ int ld_agent(const int *p) { return *(const volatile int *)p; }
-__device__ __forceinline__ void st_agent(int *p, int v) { *(volatile int *)p = v; }
-#else
 __device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#endif
 
 // fromPCLPointCloud2 (:523): named float32 fields of a blob record → (x,y,z,intensity)
 __device__ __forceinline__ float4 load_point(const MorStreamArgs &a, uint32_t i) {
@@ -513,185 +508,15 @@ __global__ __launch_bounds__(MOR_BT) void k_rowtable(MorDev d) {
   }
 }
 
-// ------------------------------------------------------------------------------------ C1: Euclidean clustering = connected components over cells
-__device__ __forceinline__ int uf_find(int *P, int x) {
-  int p = ld_agent(P + x);
-  while (p != x) {
-    int gp = ld_agent(P + p);
-    if (gp == p) return p;
-    st_agent(P + x, gp);   // path halving: any smaller member of the same component keeps the forest valid
-    x = gp; p = ld_agent(P + x);
-  }
-  return x;
-}
-// returns the (current) root of the merged component.  Only true roots are ever re-pointed
-// (CAS expects parent[r] == r) and always to a smaller id, so parent ≤ child holds at all times.
-__device__ __forceinline__ int uf_unite(int *P, int a, int b) {
-  int ra = uf_find(P, a), rb = uf_find(P, b);
-  while (ra != rb) {
-    if (ra < rb) { int x = ra; ra = rb; rb = x; }
-    int old = atomicCAS(P + ra, ra, rb);
-    if (old == ra) return rb;
-    ra = uf_find(P, old);
-  }
-  return ra;
-}
-
-// bounding box of the points of every occupied cell (prunes cell-pair tests); one wave per cell
-__global__ __launch_bounds__(MOR_BT) void k_cellbox(MorDev d) {
-  int s = blockIdx.y + d.s0, nocc = d.info[s].n_occ;
-  const int wv = blockIdx.x * (MOR_BT / 64) + wave_id(), nw = gridDim.x * (MOR_BT / 64), lane = lane_id();
-  const size_t so = (size_t)s * d.Nmax;
-  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
-  const float4 *sp = d.sorted + so;
-  for (int a = wv; a < nocc; a += nw) {
-    float lx = FLT_MAX, ly = FLT_MAX, lz = FLT_MAX, hx = -FLT_MAX, hy = -FLT_MAX, hz = -FLT_MAX;
-    for (int k = st[a] + lane, e = st[a + 1]; k < e; k += 64) { float4 p = sp[k]; lx = fminf(lx, p.x); ly = fminf(ly, p.y); lz = fminf(lz, p.z); hx = fmaxf(hx, p.x); hy = fmaxf(hy, p.y); hz = fmaxf(hz, p.z); }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
-      hx = fmaxf(hx, __shfl_xor(hx, o, 64)); hy = fmaxf(hy, __shfl_xor(hy, o, 64)); hz = fmaxf(hz, __shfl_xor(hz, o, 64));
-    }
-    if (lane == 0) { d.cmeta[2 * (so + a)] = make_float4(lx, ly, lz, 0.f); d.cmeta[2 * (so + a) + 1] = make_float4(hx, hy, hz, 0.f); }
-  }
-}
-
-// One wave per occupied cell A.  shell = 0: the 13 "forward" cells of the 3×3×3 neighbourhood;
-// shell = 1: the 49 forward cells of the 5×5×5 shell (run as a second launch, when most of those
-// pairs are already in one component through the cell between them and are skipped by the root
-// test).  Each unordered cell pair is visited exactly once.  Lanes first look the neighbours up in
-// the bitmap, then the wave tests point pairs (a ∈ A, b ∈ B) 64 at a time — EuclideanCluster-
-// Extraction's edge predicate d² < r² (:213-218) — and unites the cells at the first hit.
-__global__ __launch_bounds__(MOR_BT) void k_hook_cells(MorDev d, int shell) {
-  int s = blockIdx.y + d.s0, nocc = d.info[s].n_occ;
-  const int wv = blockIdx.x * (MOR_BT / 64) + wave_id(), nw = gridDim.x * (MOR_BT / 64), lane = lane_id();
-  const size_t so = (size_t)s * d.Nmax;
-  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
-  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
-  const float4 *sp = d.sorted + so;
-  int *P = d.parent + so;
-  int dx, dy, dz; bool lane_ok;
-  if (!shell) { int idx = 14 + lane; lane_ok = lane < 13; dx = idx % 3 - 1; dy = (idx / 3) % 3 - 1; dz = idx / 9 - 1; }
-  else { int idx = 63 + lane; dx = idx % 5 - 2; dy = (idx / 5) % 5 - 2; dz = idx / 25 - 2; lane_ok = lane < 62 && (abs(dx) == 2 || abs(dy) == 2 || abs(dz) == 2); }
-  const float r2 = d.r2;
-  for (int a = wv; a < nocc; a += nw) {
-    const int ka = ckey[a], rowa = ka / d.g.nx;
-    int nb = lane_ok ? cell_lookup(d.g, ckey, rs, ka - rowa * d.g.nx + dx, rowa % d.g.ny + dy, rowa / d.g.ny + dz) : -1;
-    if (!__ballot(nb >= 0)) continue;
-    int ra = uf_find(P, a);
-    const int a0 = st[a], na = st[a + 1] - a0;
-    int sh = 0; while ((1 << sh) < na && sh < 6) ++sh;
-    const int at = 1 << sh, bt = 64 >> sh, la = lane & (at - 1), lb = lane >> sh;
-    const float4 alo = d.cmeta[2 * (so + a)], ahi = d.cmeta[2 * (so + a) + 1];
-    // every lane resolves ITS neighbour in parallel: root differs from mine and the two cells' point boxes
-    // are closer than r (conservative, 0.999 slack) ⇒ candidate for a pair test
-    bool cand = false;
-    if (nb >= 0) {
-      const float4 blo = d.cmeta[2 * (so + nb)], bhi = d.cmeta[2 * (so + nb) + 1];
-      float gx = fmaxf(fmaxf(blo.x - ahi.x, alo.x - bhi.x), 0.f), gy = fmaxf(fmaxf(blo.y - ahi.y, alo.y - bhi.y), 0.f), gz = fmaxf(fmaxf(blo.z - ahi.z, alo.z - bhi.z), 0.f);
-      cand = (gx * gx + gy * gy + gz * gz) * 0.999f < r2;
-    }
-    int rb = cand ? uf_find(P, nb) : -1;
-    unsigned long long mask = __ballot(cand && rb != ra);
-    while (mask) {
-      int l = __ffsll((long long)mask) - 1;
-      int b = __shfl(nb, l, 64);
-      const int b0 = st[b], nbp = st[b + 1] - b0;
-      bool hit = false;
-      for (int ia0 = 0; ia0 < na && !hit; ia0 += at) {   // lanes tile (A × B) as at × (64/at), at = power of two ≥ min(na, 64)
-        const int ia = ia0 + la;
-        float4 pa = sp[a0 + min(ia, na - 1)];
-        for (int ib0 = 0; ib0 < nbp; ib0 += bt) {
-          const int ib = ib0 + lb;
-          float4 pb = sp[b0 + min(ib, nbp - 1)];
-          bool h = ia < na && ib < nbp && sqdist(pa.x, pa.y, pa.z, pb.x, pb.y, pb.z) < r2;
-          if (__ballot(h)) { hit = true; break; }
-        }
-      }
-      if (lane == l) cand = false;   // this pair is settled either way
-      if (hit) {
-        int r = 0; if (lane == 0) r = uf_unite(P, ra, b); ra = __shfl(r, 0, 64);
-        if (cand) rb = uf_find(P, nb);   // roots may have moved: refresh in parallel
-      }
-      mask = __ballot(cand && rb != ra);
-    }
-  }
-}
-
-// root of every cell; component size (points) and smallest cloud index accumulate at the root
-__global__ __launch_bounds__(MOR_BT) void k_flatten(MorDev d) {
-  int s = blockIdx.y + d.s0, nocc = d.info[s].n_occ;
-  const size_t so = (size_t)s * d.Nmax;
-  for (int c = blockIdx.x * MOR_BT + threadIdx.x; c < nocc; c += gridDim.x * MOR_BT) {
-    int r = c, p = d.parent[so + r];
-    while (p != r) { r = p; p = d.parent[so + r]; }
-    d.croot[so + c] = r;
-    atomicAdd(&d.csize[so + r], d.cstart[(size_t)s * (d.Nmax + 1) + c + 1] - d.cstart[(size_t)s * (d.Nmax + 1) + c]);
-    atomicMin(&d.compmin[so + r], d.cmin[so + c]);
-  }
-}
-
-// general path: per-cell cluster id from the root's id
-__global__ __launch_bounds__(MOR_BT) void k_cellcid(MorDev d) {
-  int s = blockIdx.y + d.s0, nocc = d.info[s].n_occ;
-  const size_t so = (size_t)s * d.Nmax;
-  for (int c = blockIdx.x * MOR_BT + threadIdx.x; c < nocc; c += gridDim.x * MOR_BT) { int cid = d.cid_of_root[so + d.croot[so + c]]; d.ccid[so + c] = cid; reinterpret_cast<int *>(&d.cmeta[2 * (so + c)])[3] = cid; }
-}
-// kept components: min_cluster_size ≤ size ≤ max_cluster_size (:215-216)
-__device__ __forceinline__ bool kept_root(const MorDev &d, size_t so, int c) {
-  if (d.croot[so + c] != c) return false;
-  long long n = d.csize[so + c];
-  return n >= d.min_cs && n <= d.max_cs;
-}
-__global__ __launch_bounds__(MOR_BT) void k_select_count(MorDev d) {
-  int s, t; map_block(d.B, d.tiles, s, t);
-  int nocc = d.info[s].n_occ, base = t * MOR_TILE, c = 0;
-  const size_t so = (size_t)s * d.Nmax;
-  for (int i = base + threadIdx.x; i < min(base + MOR_TILE, nocc); i += MOR_BT) c += kept_root(d, so, i);
-  __shared__ int sh[8]; int tot;
-  block_excl_scan(c, sh, &tot);
-  if (threadIdx.x == 0) d.ktile_cnt[(size_t)s * d.tiles_max + t] = tot;
-}
-__global__ __launch_bounds__(MOR_BT) void k_select_scan(MorDev d) {
-  int s = blockIdx.x + d.s0; __shared__ int sh[8]; int carry = 0;
-  int *c = d.ktile_cnt + (size_t)s * d.tiles_max;
-  for (int b = 0; b < d.tiles; b += MOR_BT) {
-    int t = b + threadIdx.x, v = t < d.tiles ? c[t] : 0, tot;
-    int e = block_excl_scan(v, sh, &tot);
-    if (t < d.tiles) c[t] = carry + e;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) {
-    MorFrameInfo &f = d.info[s];
-    if (carry > d.Kcap) { f.flags |= 1u; carry = d.Kcap; }
-    f.K = carry;
-  }
-}
-__global__ __launch_bounds__(MOR_BT) void k_select_scatter(MorDev d) {
-  int s, t; map_block(d.B, d.tiles, s, t);
-  int nocc = d.info[s].n_occ, base = t * MOR_TILE;
-  if (base >= nocc) return;
-  const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
-  int off = d.ktile_cnt[(size_t)s * d.tiles_max + t];
-  __shared__ int sh[8];
-  for (int row = 0; row < 8; ++row) {
-    int i = base + row * MOR_BT + threadIdx.x;
-    int k = (i < nocc) ? kept_root(d, so, i) : 0, tot;
-    int e = block_excl_scan(k, sh, &tot);
-    if (k && off + e < d.Kcap) { d.kcell[ko + off + e] = i; d.kroot[ko + off + e] = d.compmin[so + i]; d.ksize[ko + off + e] = d.csize[so + i]; }
-    off += tot;
-  }
-}
-
-// ------------------------------------------------------------------------------------ C1 fast path: the whole cell graph of one stream in ONE workgroup
-// The per-cell kernels above are bound by chains of dependent global loads (key → row table → key →
-// parent → parent …, ≈1 µs a hop).  A stream's cell graph is small (a few thousand occupied cells):
-// one 1024-thread workgroup per stream keeps the distinct keys, cell offsets, row table and the
-// union-find forest in LDS (160 KiB per CU on CDNA4), so every hop of those chains is an LDS access and
-// all unions are LDS atomics; only the point coordinates of tested pairs come from L2/HBM.  The
-// kernel covers cell boxes, both hook passes, flattening, component sizes / min indices, cluster
-// selection, ordering and offsets — nine launches of the general path.  Streams whose cell count
-// exceeds the LDS capacity run the same code on their global-memory arrays.
+// ------------------------------------------------------------------------------------ C1: Euclidean clustering = connected components over cells,
+// the whole cell graph of one stream in ONE workgroup.
+// Per-cell kernels over global memory are bound by chains of dependent loads (key → row table → key → parent →
+// parent …, ≈ 1–2 µs a hop).  A stream's cell graph is small (a few thousand occupied cells): one 1024-thread
+// workgroup per stream keeps the distinct keys, the row table and the union-find forest in LDS (160 KiB per CU on
+// CDNA4), so every hop of those chains is an LDS access and all unions are LDS atomics; only the point boxes and the
+// point coordinates of tested pairs come from L2/HBM.  The kernel covers both hook passes, flattening, component
+// sizes / min indices, cluster selection, ordering and offsets.  Streams whose cell count exceeds the LDS capacity
+// run the same code on their global-memory arrays (≈ 3× slower at equal size).
 #define CG_T 1024
 #ifndef CG_CAP
 #define CG_CAP 12288     // occupied cells held in LDS (keys + union-find forest; point ranges stay in global memory)
@@ -1062,49 +887,6 @@ __global__ __launch_bounds__(CG_T) void k_cellgraph(MorDev d) {
   }
 }
 
-// cluster order: size descending, ties by smaller first cloud index (kroot).  K is small: rank by counting.
-__global__ __launch_bounds__(MOR_BT) void k_rank(MorDev d) {
-  int s = blockIdx.y + d.s0, K = d.info[s].K;
-  int k = blockIdx.x * MOR_BT + threadIdx.x;
-  if (blockIdx.x * MOR_BT >= K) return;
-  const int *kr = d.kroot + (size_t)s * d.Kcap, *ks = d.ksize + (size_t)s * d.Kcap;
-  __shared__ int s_sz[MOR_BT], s_rt[MOR_BT];
-  int my_sz = k < K ? ks[k] : 0, my_rt = k < K ? kr[k] : 0, rank = 0;
-  for (int b = 0; b < K; b += MOR_BT) {
-    int j = b + threadIdx.x;
-    s_sz[threadIdx.x] = j < K ? ks[j] : -1; s_rt[threadIdx.x] = j < K ? kr[j] : 0x7fffffff;
-    __syncthreads();
-    int lim = min(MOR_BT, K - b);
-    for (int u = 0; u < lim; ++u) rank += (s_sz[u] > my_sz) || (s_sz[u] == my_sz && s_rt[u] < my_rt);
-    __syncthreads();
-  }
-  if (k < K) {
-    d.cid_of_root[(size_t)s * d.Nmax + d.kcell[(size_t)s * d.Kcap + k]] = rank;
-    d.csz[(size_t)s * d.Kcap + rank] = my_sz;
-  }
-}
-// cluster offsets (exclusive scan of sizes in cluster order), C, clear detection_results (:250-254)
-__global__ __launch_bounds__(MOR_BT) void k_offsets(MorDev d) {
-  int s = blockIdx.x + d.s0, K = d.info[s].K; __shared__ int sh[8]; int carry = 0;
-  int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1);
-  const int *sz = d.csz + (size_t)s * d.Kcap;
-  for (int b = 0; b < K; b += MOR_BT) {
-    int k = b + threadIdx.x, v = k < K ? sz[k] : 0, tot;
-    int e = block_excl_scan(v, sh, &tot);
-    if (k < K) { off[k] = carry + e; d.det[(size_t)s * d.Kcap + k] = 0; }
-    carry += tot;
-  }
-  if (threadIdx.x == 0) { off[K] = carry; d.info[s].C = carry; }
-  int *coff = d.chunk_off[d.cur] + (size_t)s * (d.Kcap + 1);
-  carry = 0;
-  for (int b = 0; b < K; b += MOR_BT) {
-    int k = b + threadIdx.x, v = k < K ? (sz[k] + MOR_CHUNK - 1) / MOR_CHUNK : 0, tot;
-    int e = block_excl_scan(v, sh, &tot);
-    if (k < K) coff[k] = carry + e;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) coff[K] = carry;
-}
 // per sorted slot: cluster id of its point → pcid[cloud index] and sorted.w
 __global__ __launch_bounds__(MOR_BT) void k_label(MorDev d) {
   int s, t0; map_block(d.B, d.tiles_m, s, t0);
@@ -2306,7 +2088,7 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
 }
 
 void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B), gW(getenv("MOR_GW") ? atoi(getenv("MOR_GW")) : 64, d.B);
+  const dim3 gB(d.B);
   if (d.gmode == 0) {
     mor_launch_split_and_grid(d, st, tm);
   } else {
@@ -2333,23 +2115,10 @@ void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
 }
 
 void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B), gK(MOR_KGRID, d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B), gW(getenv("MOR_GW") ? atoi(getenv("MOR_GW")) : 64, d.B);
-  if (!getenv("MOR_EXP_GENERAL_CC")) {
-    mor_timer_begin(tm, MK_CELLGRAPH, st);
-    hipLaunchKernelGGL(k_cellgraph, gB, dim3(CG_T), 0, st, d);
-    mor_timer_end(tm, MK_CELLGRAPH, st);
-  } else {
-    MOR_LAUNCH(MK_CELLBOX, k_cellbox, gW, d);
-    MOR_LAUNCH(MK_HOOK_NEAR, k_hook_cells, gW, d, 0);
-    MOR_LAUNCH(MK_HOOK_SHELL, k_hook_cells, gW, d, 1);
-    MOR_LAUNCH(MK_FLATTEN, k_flatten, dim3(32, d.B), d);
-    MOR_LAUNCH(MK_SELECT_COUNT, k_select_count, gT, d);
-    MOR_LAUNCH(MK_SELECT_SCAN, k_select_scan, gB, d);
-    MOR_LAUNCH(MK_SELECT_SCATTER, k_select_scatter, gT, d);
-    MOR_LAUNCH(MK_RANK, k_rank, gKt, d);
-    MOR_LAUNCH(MK_OFFSETS, k_offsets, gB, d);
-    MOR_LAUNCH(MK_CELLCID, k_cellcid, dim3(32, d.B), d);
-  }
+  const dim3 gB(d.B);
+  mor_timer_begin(tm, MK_CELLGRAPH, st);
+  hipLaunchKernelGGL(k_cellgraph, gB, dim3(CG_T), 0, st, d);
+  mor_timer_end(tm, MK_CELLGRAPH, st);
 }
 
 void mor_launch_mid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
