@@ -30,6 +30,59 @@ WORKLOADS = {
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4-copy ceiling)
 
 
+_CPU_BARRIER = None
+
+
+def _cpu_stream(job):
+    """One independent stream through the CPU oracle (a worker of the all-cores baseline): returns (frame-pairs, seconds)."""
+    seed, sensor, method, ground_method, pairs = job
+    from dynamicslamtool_amd import kitti_params, synth
+    from oracle.oracle import Oracle
+    p = kitti_params(method)
+    p.ground_method = ground_method
+    o = Oracle(p, 4, 3)
+    x, ps = synth.frame(seed, sensor, 0)
+    o.push(x, ps)
+    o.filter()
+    frames = [synth.frame(seed, sensor, f) for f in range(1, pairs + 1)]
+    if _CPU_BARRIER is not None:
+        _CPU_BARRIER.wait()   # every worker has its inputs: the timed parts run side by side, nothing else on the cores
+    t0 = time.perf_counter()
+    for x, ps in frames:
+        o.push(x, ps)
+        o.filter()
+    dt = time.perf_counter() - t0
+    o.close()
+    return pairs, dt
+
+
+def cpu_all_cores(seeds, sensor, method, ground_method, pairs=3, max_workers=64):
+    """'all cores' = one independent stream per core.  Runs before anything touches the GPU (forked workers)."""
+    import multiprocessing as mp
+    n = max(1, min(os.cpu_count() or 1, max_workers, len(seeds)))
+    global _CPU_BARRIER
+    jobs = [(seeds[i], sensor, method, ground_method, pairs) for i in range(n)]
+    t0 = time.perf_counter()
+    ctx = mp.get_context("fork")
+    _CPU_BARRIER = ctx.Barrier(n)
+    omp = os.environ.get("OMP_NUM_THREADS")
+    os.environ["OMP_NUM_THREADS"] = "1"   # the synthetic-cloud generator is OpenMP-parallel: one thread per worker here
+    try:
+        with ctx.Pool(n) as pool:
+            res = pool.map(_cpu_stream, jobs, chunksize=1)
+    finally:
+        _CPU_BARRIER = None
+        if omp is None:
+            os.environ.pop("OMP_NUM_THREADS", None)
+        else:
+            os.environ["OMP_NUM_THREADS"] = omp
+    wall = time.perf_counter() - t0
+    rates = [r[0] / r[1] for r in res]
+    return {"value": round(sum(rates), 2), "unit": "frame-pairs/s", "cores": n, "kind": "port",
+            "sample": "%d independent streams x %d steady-state frame-pairs, one oracle process per core, all running side by side; value = sum of the per-core rates" % (n, pairs),
+            "per_core_min_max": [round(min(rates), 3), round(max(rates), 3)], "wall_s": round(wall, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,6 +114,11 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+
+    cpu_all = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from dynamicslamtool_amd import shard as _sh
+        cpu_all = cpu_all_cores(_sh.stream_seeds(2, 0, WORKLOADS[args.workload][1]), WORKLOADS[args.workload][0], args.method, args.ground_method)
 
     from dynamicslamtool_amd import engine, kitti_params, synth
 
@@ -238,7 +296,7 @@ def main():
             "algorithmic_bytes_per_frame_pair": int(b_alg),
             "stage_totals": {k: sum(batch.stage_counts(s)[k] for s in range(B)) for k in ("n_occ", "n_tier1b", "n_defer", "C_prev")},
             "stream0": {"T": int(c0.n_trim), "M": int(c0.n_cloud), "G": int(c0.n_ground), "K": int(c0.n_clusters), "C": int(c0.n_clustered), "pairs": int(c0.n_corr), "tracks": int(c0.n_tracks)},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "kernels_alone_avg_us": kernels_alone,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "kernels": kernels, "kernels_alone_avg_us": kernels_alone,
             "e2e_host_frame_pairs_per_s": None if e2e is None else round(e2e, 2),
             "setup_s": round(t_gen, 2),
         }
