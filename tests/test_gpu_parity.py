@@ -54,6 +54,50 @@ def test_small_stream_exercises_removal():
     assert st["tracks"] >= 1 and st["removed"] > 0 and st["moving"] > 0
 
 
+@pytest.mark.parametrize("case", range(14))
+def test_parameter_sweep_on_small_streams(case):
+    """Randomised parameter profiles (cluster tolerance, size limits, trim box, both scoring methods with bounds that
+    exercise every scoring tier — √lb wider than half a cell, lb ≥ ub, negative lb, a search stencil of one cell,
+    a wide one —, window lengths) on small streams, everything compared with the oracle frame by frame."""
+    rng = np.random.default_rng(1000 + case)
+    p = scene_params(method_choice=int(rng.integers(1, 3)))
+    p.ec_distance_threshold = float(rng.choice([0.06, 0.11, 0.18, 0.3]))
+    p.min_cluster_size = int(rng.choice([5, 25, 60]))
+    p.max_cluster_size = int(rng.choice([150, 400, 20000]))
+    p.trim_x, p.trim_y = float(rng.choice([2.0, 3.0, 5.0])), float(rng.choice([2.0, 3.0, 5.0]))
+    p.trim_z = float(rng.choice([0.8, 2.0]))
+    p.gp_limit = float(rng.choice([-0.6, -0.55, -0.3]))
+    p.volume_constraint = float(rng.choice([0.1, 0.3, 0.9]))
+    lb, ub = [(0.0001, 0.003), (0.002, 0.02), (0.01, 0.5), (0.05, 0.01), (-1.0, 0.004), (0.0, 0.0002), (0.0005, 2.5)][case % 7]
+    p.pde_lb, p.pde_ub = lb, ub
+    p.pde_distance_threshold = float(rng.choice([0.05, 0.15, 0.5]))
+    p.opc_normalization_factor = int(rng.choice([5, 15, 40]))
+    p.leave_off_distance, p.catch_up_distance = float(rng.choice([0.05, 0.4])), float(rng.choice([0.1, 0.3]))
+    n_bad, n_good = int(rng.integers(2, 6)), int(rng.integers(1, 5))
+    streams = [small_stream(100 + 3 * case + i, n_frames=8, n_objects=int(rng.integers(3, 9))) for i in range(2)]
+    st = _run_lockstep(p, streams, n_bad=n_bad, n_good=n_good)
+    assert st["clusters"] >= 0
+
+
+@pytest.mark.parametrize("lb,ub", [(0.05, 0.5), (0.005, 0.05), (0.0004, 0.9), (0.3, 0.2), (0.005, 3.0)])
+def test_hdl64_scoring_bound_variants(lb, ub):
+    """Method 1 at full size with bounds that steer the queries through different tiers: √lb wider than half a cell
+    (thread tiers off, wave tier only), a one-cell search stencil, a tiny lb, lb ≥ ub (nothing counted), a stencil of
+    several cells."""
+    p = kitti_params(1)
+    p.pde_lb, p.pde_ub = lb, ub
+    b, o = MorBatch(p, 2, 120000), [Oracle(p), Oracle(p)]
+    for f in range(3):
+        fr = [synth.frame(2005, "hdl64", f), synth.frame(2017, "hdl64", f)]
+        b.push([fr[0][0], fr[1][0]], np.stack([fr[0][1], fr[1][1]]))
+        outs = b.filter()
+        for s in range(2):
+            o[s].push(*fr[s])
+            compare_frame(o[s], b, s, "bounds (%g, %g) stream %d frame %d" % (lb, ub, s, f))
+            compare_output(o[s].filter(), outs[s], "bounds (%g, %g) stream %d frame %d" % (lb, ub, s, f))
+    b.close()
+
+
 @pytest.mark.parametrize("B", [3, 8])
 def test_batches_of_independent_streams(B):
     """Streams in one batch share launches but nothing else; B=3 takes the generic workgroup map,
