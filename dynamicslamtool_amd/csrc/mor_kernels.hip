@@ -618,6 +618,22 @@ __device__ __forceinline__ void wave_box(const float4 *sp, int b, int e, int lan
 #else
 #define CG_CNT(i, x)
 #endif
+// first index in [lo, lo+n) whose key is ≥ k0, by 8-ary search: every step fetches its seven pivots with independent
+// loads, so a row of 500 cells costs three load latencies instead of the nine dependent ones of a binary search (the
+// wave pays the latency of its longest row in every iteration of the hook passes)
+__device__ __forceinline__ int cg_lower_bound8(const int *key, int lo, int n, int k0) {
+  while (n > 8) {
+    const int step = (n + 7) >> 3;
+    int c = 0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) c += (j * step < n) && key[min(lo + j * step, lo + n - 1)] < k0;
+    lo += c * step; n = min(step, n - c * step);
+  }
+  int below = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) below += (i < n) && key[lo + min(i, n - 1)] < k0;
+  return lo + below;
+}
 // one hook pass over the forward half of the (2·RING+1)³ neighbourhood, ring == RING only
 template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const MorDev &d, int s, int nocc, const int *key, const int *start, const int *rows, int *par,
                                                                    const float4 *sp, int *l_list, int *l_nlist) {
@@ -642,11 +658,12 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
         int cb[5]; float4 blo[5], bhi[5]; int nc = 0;
 #pragma unroll
         for (int u = 0; u < 5; ++u) cb[u] = -1;
-        int lo = rlo, hi = rlo + rn;
-        if (rn > 8) row_cells(d.g, key, rows, max(x - RING, 0), min(x + RING, d.g.nx - 1), y + dy, z + dz, lo, hi);
+        int lo = rlo; const int hi = rlo + rn;
+        if (rn > 8) lo = cg_lower_bound8(key, rlo, rn, rowbase - RING);   // long row: skip to x − RING in log8 steps of independent loads
         for (int b = lo; b < hi; ++b) {
           const int dx = key[b] - rowbase;
-          if (abs(dx) > RING) continue;
+          if (dx > RING) break;        // keys ascend along the row: nothing further can be in range
+          if (dx < -RING) continue;
           const bool fwd = !(dz == 0 && dy == 0 && dx <= 0);      // forward half: each unordered pair once
           const bool ring = edge_row || abs(dx) == RING;           // inner cells belong to the previous pass
           if (!fwd || !ring) continue;
