@@ -111,9 +111,10 @@ struct MorDev {
   int Hcell, use_hash;       // table capacity per stream (power of two ≥ 4·Nmax); whether this pass builds it
   int *cmin;                 // [B][Nmax]  smallest cloud index in the cell
   float4 *cmeta;             // [B][2·Nmax]  per occupied cell: low corner of its point box (.w = cluster id bits), high corner
+  float4 *crep;              // [B][Nmax]  per occupied cell: its first point (sample for the quick edge test of the cell graph)
   float4 *sorted;            // [B][Nmax]  (x,y,z, bits(cloud index)) in cell order; .w becomes the cluster id after labelling
   int *parent;               // [B][Nmax]  union-find forest over occupied cells (parent ≤ child)
-  int *cg_ovf;               // [B][MOR_CG_OVF][2]  k_cellgraph: undecided big cell pairs beyond its LDS list
+  int *cg_ovf;               // [B][2][MOR_CG_OVF][2]  k_cellgraph: candidate cell pairs beyond its LDS list; undecided big cell pairs
   int *croot;                // [B][Nmax]  flattened root per cell
   int *csize;                // [B][Nmax]  component size (points) at its root cell
   int *compmin;              // [B][Nmax]  smallest cloud index of the component, at its root cell

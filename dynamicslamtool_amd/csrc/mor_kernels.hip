@@ -634,16 +634,50 @@ __device__ __forceinline__ int cg_lower_bound8(const int *key, int lo, int n, in
   for (int i = 0; i < 8; ++i) below += (i < n) && key[lo + min(i, n - 1)] < k0;
   return lo + below;
 }
-// one hook pass over the forward half of the (2·RING+1)³ neighbourhood, ring == RING only
+// One hook pass over the forward half of the (2·RING+1)³ neighbourhood, ring == RING only, in three phases:
+//  A  enumeration, LDS only: every thread walks the neighbour rows of its cells and appends each neighbour cell that
+//     is not yet in its component to a pair list (LDS, spilling to global memory).  No global load, no divergent
+//     heavy code: before this split the whole wave executed box loads and point tests whenever one lane needed them
+//     (VALU utilisation of the tests ≈ 15 %).
+//  B1 one THREAD per listed pair, all lanes busy: roots re-checked (earlier unions settle most pairs), the two point
+//     boxes (gap ≥ r ⇒ no edge; farthest corners < r ⇒ edge), else the points — exhaustively for small cells, a
+//     16 × 16 sample for big × big ones, whose undecided rest (mostly true non-edges) goes to a second list.
+//  B2 one WAVE per pair of the second list: pruned exhaustive test (pair_hit_wave).
+// Pair lists: entries [0, CG_LIST) in LDS, the rest in the stream's global overflow area; second list global only.
+template <bool LDS> __device__ __forceinline__ void cg_list_put(const MorDev &d, int s, int *l_list, int slot, int region, int a, int b) {
+  if (region == 0 && slot < CG_LIST) { l_list[2 * slot] = a; l_list[2 * slot + 1] = b; return; }
+  int *ov = d.cg_ovf + (((size_t)s * 2 + region) * MOR_CG_OVF + (region == 0 ? slot - CG_LIST : slot)) * 2;
+  cg_st<false>(ov, a); cg_st<false>(ov + 1, b);
+}
+template <bool LDS> __device__ __forceinline__ void cg_list_get(const MorDev &d, int s, const int *l_list, int slot, int region, int &a, int &b) {
+  if (region == 0 && slot < CG_LIST) { a = l_list[2 * slot]; b = l_list[2 * slot + 1]; return; }
+  const int *ov = d.cg_ovf + (((size_t)s * 2 + region) * MOR_CG_OVF + (region == 0 ? slot - CG_LIST : slot)) * 2;
+  a = cg_ld<false>(ov); b = cg_ld<false>(ov + 1);
+}
+// decides one pair: returns 1 = edge, 0 = no edge, −1 = big × big and undecided by the sample
+__device__ __forceinline__ int cg_pair_test(const MorDev &d, size_t so, const int *start, const float4 *sp, int a, int b, float r2) {
+  const float4 alo = d.cmeta[2 * (so + a)], ahi = d.cmeta[2 * (so + a) + 1], blo = d.cmeta[2 * (so + b)], bhi = d.cmeta[2 * (so + b) + 1];
+  const float4 pa = d.crep[so + a], pb = d.crep[so + b];                            // one point of each cell
+  const int a0 = start[a], a1 = start[a + 1], b0 = start[b], b1 = start[b + 1];   // issued with the boxes: one level of loads
+  // boxes of the two cells' points: gap ≥ r ⇒ no edge; farthest corners < r ⇒ every pair is an edge
+  float gx = fmaxf(fmaxf(blo.x - ahi.x, alo.x - bhi.x), 0.f), gy = fmaxf(fmaxf(blo.y - ahi.y, alo.y - bhi.y), 0.f), gz = fmaxf(fmaxf(blo.z - ahi.z, alo.z - bhi.z), 0.f);
+  if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) return 0;
+  float sx = fmaxf(bhi.x - alo.x, ahi.x - blo.x), sy = fmaxf(bhi.y - alo.y, ahi.y - blo.y), sz = fmaxf(bhi.z - alo.z, ahi.z - blo.z);
+  if ((sx * sx + sy * sy + sz * sz) * 1.001f < r2) return 1;
+  if (sqdist(pa.x, pa.y, pa.z, pb.x, pb.y, pb.z) < r2) return 1;   // the two sample points are an edge already (most neighbouring cells of one surface)
+  const int na = a1 - a0, nb = b1 - b0;
+  if ((long long)na * nb > 256) return pair_hit_serial(sp, a0, min(na, 16), b0, min(nb, 16), r2) ? 1 : -1;   // dense neighbours nearly always show an edge within a small sample
+  return pair_hit_serial(sp, a0, na, b0, nb, r2) ? 1 : 0;
+}
 template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const MorDev &d, int s, int nocc, const int *key, const int *start, const int *rows, int *par,
-                                                                   const float4 *sp, int *l_list, int *l_nlist) {
+                                                                   const float4 *sp, int *l_list, int *l_nlist, int *l_n2) {
   const float r2 = d.r2;
-  const size_t so_ = (size_t)s * d.Nmax;
+  const size_t so = (size_t)s * d.Nmax;
+  RS_T(tp0);
+  // ---- A: candidate pairs
   for (int a = threadIdx.x; a < nocc; a += CG_T) {
     const int ka = key[a], rowa = ka / d.g.nx, x = ka - rowa * d.g.nx, y = rowa % d.g.ny, z = rowa / d.g.ny;
-    int a0 = -1, na = 0;   // point range of a: fetched from global memory when the first point test needs it
-    int ra = cg_find<LDS>(par, a);
-    float4 alo, ahi; bool have_box = false;
+    const int ra = cg_find<LDS>(par, a);
     for (int dz = 0; dz <= RING; ++dz) {
       if (z + dz >= d.g.nz) break;
       for (int dy = (dz == 0 ? 0 : -RING); dy <= RING; ++dy) {
@@ -651,81 +685,69 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
         const bool edge_row = dz == RING || abs(dy) == RING;   // every cell of this row lies on the ring
         const int rr = (z + dz) * d.g.ny + (y + dy), rlo = rows[rr], rn = rows[rr + 1] - rlo;
         if (rn == 0) continue;
-        // ≤ 2·RING+1 ≤ 5 cells of the row lie within RING of x.  A short row is walked with a plain loop over its real
-        // cell count (a few instructions and two LDS loads per cell; a fixed 8-wide batch cost every wave its full
-        // width); a cell whose parent is a's root is skipped on the first load (the forest is flattened between passes)
+        // ≤ 2·RING+1 ≤ 5 cells of the row lie within RING of x: a plain walk over the row's real cell count (a long row
+        // is entered at x − RING by an 8-ary search); a cell whose parent is a's root is skipped on the first load
         const int rowbase = rr * d.g.nx + x;
-        int cb[5]; float4 blo[5], bhi[5]; int nc = 0;
-#pragma unroll
-        for (int u = 0; u < 5; ++u) cb[u] = -1;
         int lo = rlo; const int hi = rlo + rn;
-        if (rn > 8) lo = cg_lower_bound8(key, rlo, rn, rowbase - RING);   // long row: skip to x − RING in log8 steps of independent loads
+        if (rn > 8) lo = cg_lower_bound8(key, rlo, rn, rowbase - RING);
         for (int b = lo; b < hi; ++b) {
           const int dx = key[b] - rowbase;
           if (dx > RING) break;        // keys ascend along the row: nothing further can be in range
-          if (dx < -RING) continue;
           const bool fwd = !(dz == 0 && dy == 0 && dx <= 0);      // forward half: each unordered pair once
           const bool ring = edge_row || abs(dx) == RING;           // inner cells belong to the previous pass
-          if (!fwd || !ring) continue;
-          const int pb = cg_ld<LDS>(par + b);
-          if (pb == ra || cg_find<LDS>(par, b) == ra) continue;
-#pragma unroll
-          for (int u = 0; u < 5; ++u) if (nc == u) cb[u] = b;
-          ++nc;
-        }
-        if (nc == 0) continue;
-        if (!have_box) { alo = d.cmeta[2 * (so_ + a)]; ahi = d.cmeta[2 * (so_ + a) + 1]; have_box = true; }
-#pragma unroll
-        for (int u = 0; u < 5; ++u) if (cb[u] >= 0) { blo[u] = d.cmeta[2 * (so_ + cb[u])]; bhi[u] = d.cmeta[2 * (so_ + cb[u]) + 1]; }
-#pragma unroll
-        for (int u = 0; u < 5; ++u) {
-          const int b = cb[u];
-          if (b < 0) continue;
-          // boxes of the two cells' points: gap ≥ r ⇒ no edge; farthest corners < r ⇒ every pair is an edge
-          float gx = fmaxf(fmaxf(blo[u].x - ahi.x, alo.x - bhi[u].x), 0.f), gy = fmaxf(fmaxf(blo[u].y - ahi.y, alo.y - bhi[u].y), 0.f), gz = fmaxf(fmaxf(blo[u].z - ahi.z, alo.z - bhi[u].z), 0.f);
-          if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) continue;
-          float sx = fmaxf(bhi[u].x - alo.x, ahi.x - blo[u].x), sy = fmaxf(bhi[u].y - alo.y, ahi.y - blo[u].y), sz = fmaxf(bhi[u].z - alo.z, ahi.z - blo[u].z);
-          bool edge = (sx * sx + sy * sy + sz * sz) * 1.001f < r2;
-          if (!edge) {
-            if (u > 0 && cg_find<LDS>(par, b) == ra) continue;         // an earlier union of this row may have merged it
-            if (a0 < 0) { a0 = start[a]; na = start[a + 1] - a0; }
-            const int b0 = start[b], nb = start[b + 1] - b0;
-            if ((long long)na * nb > 256) {
-              // big × big: dense neighbouring cells nearly always show an edge within a small sample of pairs;
-              // what is left (mostly true non-edges) goes to a whole wave
-              edge = pair_hit_serial(sp, a0, min(na, 16), b0, min(nb, 16), r2);
-              if (!edge) {
-                int slot = atomicAdd(l_nlist, 1);
-                if (slot < CG_LIST) { l_list[2 * slot] = a; l_list[2 * slot + 1] = b; continue; }
-                if (slot < CG_LIST + MOR_CG_OVF) {   // LDS list full: overflow list in global memory
-                  int *ov = d.cg_ovf + ((size_t)s * MOR_CG_OVF + (slot - CG_LIST)) * 2;
-                  cg_st<false>(ov, a); cg_st<false>(ov + 1, b); continue;
-                }
-                edge = pair_hit_serial(sp, a0, na, b0, nb, r2);           // both lists full: settle it here
+          bool want = dx >= -RING && fwd && ring;
+          if (want) { const int pb = cg_ld<LDS>(par + b); want = pb != ra && cg_find<LDS>(par, b) != ra; }
+          // append (a, b): one LDS atomic per wave and iteration instead of one per pair (they all hit one counter)
+          const unsigned long long m = __ballot(want);
+          if (m) {
+            const int leader = __ffsll((long long)m) - 1; int base = 0;
+            if (lane_id() == leader) base = atomicAdd(l_nlist, __popcll(m));
+            base = __shfl(base, leader, 64);
+            if (want) {
+              const int slot = base + __popcll(m & lanemask_lt());
+              if (slot < CG_LIST + MOR_CG_OVF) cg_list_put<LDS>(d, s, l_list, slot, 0, a, b);
+              else {   // both lists full (never seen): settle it here, exhaustively
+                const int a0 = start[a], b0 = start[b];
+                if (pair_hit_serial(sp, a0, start[a + 1] - a0, b0, start[b + 1] - b0, r2)) cg_unite<LDS>(par, a, b);
               }
-            } else edge = pair_hit_serial(sp, a0, na, b0, nb, r2);
+            }
           }
-          if (edge) ra = cg_unite<LDS>(par, ra, b);
         }
       }
     }
   }
-  __syncthreads();
-  // deferred pairs: one wave each — root re-check, box rejection, tiled exhaustive test
   __threadfence_block();
-  const int nl = min(*l_nlist, CG_LIST + MOR_CG_OVF), lane = lane_id();
-  for (int h = wave_id(); h < nl; h += CG_T / 64) {
-    const int *ov = d.cg_ovf + ((size_t)s * MOR_CG_OVF + max(h - CG_LIST, 0)) * 2;
-    const int a = h < CG_LIST ? l_list[2 * h] : cg_ld<false>(ov), b = h < CG_LIST ? l_list[2 * h + 1] : cg_ld<false>(ov + 1);
+  __syncthreads();
+  RS_T(tp1);
+  // ---- B1: one thread per candidate pair
+  const int n1 = min(*l_nlist, CG_LIST + MOR_CG_OVF);
+  for (int h = threadIdx.x; h < n1; h += CG_T) {
+    int a, b; cg_list_get<LDS>(d, s, l_list, h, 0, a, b);
+    if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;   // an earlier union has connected them
+    const int verdict = cg_pair_test(d, so, start, sp, a, b, r2);
+    if (verdict > 0) cg_unite<LDS>(par, a, b);
+    else if (verdict < 0) {
+      const int slot = atomicAdd(l_n2, 1);
+      if (slot < MOR_CG_OVF) cg_list_put<LDS>(d, s, l_list, slot, 1, a, b);
+      else { const int a0 = start[a], b0 = start[b]; if (pair_hit_serial(sp, a0, start[a + 1] - a0, b0, start[b + 1] - b0, r2)) cg_unite<LDS>(par, a, b); }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  RS_T(tp2);
+  // ---- B2: one wave per undecided big pair — root re-check, pruned exhaustive test
+  const int n2 = min(*l_n2, MOR_CG_OVF), lane = lane_id();
+  for (int h = wave_id(); h < n2; h += CG_T / 64) {
+    int a, b; cg_list_get<LDS>(d, s, l_list, h, 1, a, b);
     if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;
-    const size_t so = (size_t)s * d.Nmax;
     const float4 alo = d.cmeta[2 * (so + a)], ahi = d.cmeta[2 * (so + a) + 1], blo = d.cmeta[2 * (so + b)], bhi = d.cmeta[2 * (so + b) + 1];
-    float gx = fmaxf(fmaxf(blo.x - ahi.x, alo.x - bhi.x), 0.f), gy = fmaxf(fmaxf(blo.y - ahi.y, alo.y - bhi.y), 0.f), gz = fmaxf(fmaxf(blo.z - ahi.z, alo.z - bhi.z), 0.f);
-    if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) continue;
     if (pair_hit_wave(sp, start[a], start[a + 1] - start[a], start[b], start[b + 1] - start[b], r2, lane, alo, ahi, blo, bhi) && lane == 0) cg_unite<LDS>(par, a, b);
   }
   __syncthreads();
-  if (threadIdx.x == 0) *l_nlist = 0;
+#ifdef MOR_EXP_STAMPS
+  if (threadIdx.x == 0) { RS_T(tp3); unsigned long long *g = d.dbg + (size_t)s * 16 + 8 + (RING - 1) * 4; g[0] = tp1 - tp0; g[1] = tp2 - tp1; g[2] = tp3 - tp2; g[3] = ((unsigned long long)n1 << 32) | (unsigned)n2; }
+#endif
+  if (threadIdx.x == 0) { *l_nlist = 0; *l_n2 = 0; }
   __syncthreads();
 }
 
@@ -762,6 +784,7 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
         hx = fmaxf(hx, __shfl_xor(hx, o, 64)); hy = fmaxf(hy, __shfl_xor(hy, o, 64)); hz = fmaxf(hz, __shfl_xor(hz, o, 64));
       }
       const bool bigc = e[u] - b[u] > 32 && c0 + u < nocc;
+      if (sub == 0 && c0 + u < nocc) d.crep[so + c0 + u] = p[u];   // the cell's first point: sample for the quick edge test of k_cellgraph
       if (sub == 0 && c0 + u < nocc && !bigc) { d.cmeta[2 * (so + c0 + u)] = make_float4(lx, ly, lz, 0.f); d.cmeta[2 * (so + c0 + u) + 1] = make_float4(hx, hy, hz, 0.f); }
       // cells of more than 32 points (dense surfaces close to the sensor hold hundreds): the whole wave, 256 points per step
       unsigned long long m = __ballot(bigc && sub == 0);
@@ -786,11 +809,11 @@ template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int
   // (the boxes of the cells' points were written by k_cellboxes at the end of the grid stage)
   CG_STAMP(2);
   // ---- hooks: 3×3×3 neighbourhood first, then the 5×5×5 shell (mostly skipped by the root test)
-  cg_hook_pass<LDS, 1>(d, s, nocc, key, start, rows, par, sp, l_list, l_nlist);
+  cg_hook_pass<LDS, 1>(d, s, nocc, key, start, rows, par, sp, l_list, l_nlist, l_misc);
   CG_STAMP(3);
   for (int c = threadIdx.x; c < nocc; c += CG_T) { const int r = cg_find<LDS>(par, c); if (r != c) cg_st<LDS>(par + c, r); }   // flat forest: the shell pass compares parents directly
   __syncthreads();
-  cg_hook_pass<LDS, 2>(d, s, nocc, key, start, rows, par, sp, l_list, l_nlist);
+  cg_hook_pass<LDS, 2>(d, s, nocc, key, start, rows, par, sp, l_list, l_nlist, l_misc);
   CG_STAMP(4);
   // ---- components: size (points) and smallest cloud index at the root.  LDS mode has one scratch array left (`mn`
   //      aliases the keys): sizes are accumulated in it first and parked in the global `size` array, then the minima
@@ -891,7 +914,7 @@ __global__ __launch_bounds__(CG_T) void k_cellgraph(MorDev d) {
   const size_t so = (size_t)s * d.Nmax;
   const int *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1);
   const int *rows = g_rows;
-  if (threadIdx.x == 0) l_nlist = 0;
+  if (threadIdx.x == 0) { l_nlist = 0; l_misc[0] = 0; }
   if (d.g.nrows + 1 <= CG_ROWCAP + 1) { for (int i = threadIdx.x; i <= d.g.nrows; i += CG_T) l_rows[i] = g_rows[i]; rows = l_rows; }
   if (nocc <= CG_CAP) {
     const int *gk = d.ckey + so;

@@ -18,7 +18,9 @@ print("per-phase µs: mean / max over streams")
 for i, n in enumerate(names): print("  %-16s %8.1f %8.1f" % (n, d[:, i].mean(), d[:, i].max()))
 print("total mean %.1f max %.1f; kernel span %.1f" % (d.sum(1).mean(), d.sum(1).max(), (out[:, 6].max() - out[:, 0].min()) / 100.0))
 
-c = out[:, 8:16].astype(np.float64)
+c = out[:, 8:16]
 for nm, o in (("near", 0), ("shell", 4)):
-    print("%s: non-empty (cell,row) visits per stream mean %.0f, of them rows > 8 cells %.0f, > 32 cells %.0f" % (nm, c[:, o].mean(), c[:, o + 1].mean(), c[:, o + 2].mean()))
-print("n_occ mean", np.mean([b.stage_counts(s_)["n_occ"] for s_ in range(B)]))
+    A, B1, B2 = c[:, o].astype(np.float64) / 100, c[:, o + 1].astype(np.float64) / 100, c[:, o + 2].astype(np.float64) / 100
+    n1, n2 = (c[:, o + 3] >> np.uint64(32)).astype(np.int64), (c[:, o + 3] & np.uint64(0xffffffff)).astype(np.int64)
+    print("%s: A enumeration us mean %.1f max %.1f | B1 thread tests us mean %.1f max %.1f | B2 wave tests us mean %.1f max %.1f | pairs listed mean %.0f max %d | big undecided mean %.1f max %d" % (
+        nm, A.mean(), A.max(), B1.mean(), B1.max(), B2.mean(), B2.max(), n1.mean(), n1.max(), n2.mean(), n2.max()))
