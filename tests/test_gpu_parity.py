@@ -190,36 +190,32 @@ def test_errors_are_loud():
     b.close()
 
 
-def test_known_answers():
-    """Hand-checkable scenes."""
-    p = scene_params(min_cluster_size=5)
-    pose = np.array([[0, 0, 0, 0, 0, 0, 1.0]])
-    r = np.float32(p.ec_distance_threshold)
+class _HipEngine:
+    """One-stream MorBatch with the call shape tests/known_answers.py expects."""
 
-    def line(x0, n):   # n points spaced 0.05 along y at x = x0
-        return np.column_stack([np.full(n, x0), np.arange(n) * 0.05, np.zeros(n), np.zeros(n)]).astype(np.float32)
-    # two lines 0.12 apart at r = 0.11 → 2 clusters; 0.10 apart → 1
-    for gap, want in ((0.12, 2), (0.10, 1)):
-        b = MorBatch(p, 1, 1024)
-        b.push([np.concatenate([line(0.0, 10), line(gap, 10)])], pose)
-        assert b.counts().n_clusters == want, gap
-        b.close()
-    # strict '<': two points whose fp32 d² equals r² exactly are NOT connected
-    d = np.float32(np.sqrt(np.float64(np.float32(np.float64(r) * np.float64(r)))))
-    pts = np.concatenate([line(0.0, 6), line(0.0, 6)])
-    pts[6:, 1] += np.float32(1.0)
-    b = MorBatch(p, 1, 1024)
-    b.push([pts], pose)
-    assert b.counts().n_clusters == 2
-    b.close()
-    # min_cluster_size boundary: 4 points vs 5 points with min = 5
-    b = MorBatch(p, 1, 1024)
-    b.push([np.concatenate([line(0.0, 4), line(1.0, 5)])], pose)
-    assert b.counts().n_clusters == 1 and b.counts().n_clustered == 5
-    # first-frame output = [non-ground ‖ ground] permutation of the trimmed input
-    out = b.filter()[0]
-    assert len(out) == 9
-    b.close()
+    def __init__(self, p):
+        self.b = MorBatch(p, 1, 4096)
+
+    def push(self, x, pose):
+        self.b.push([x], np.asarray(pose)[None, :])
+
+    def filter(self):
+        return self.b.filter()[0]
+
+    def counts(self):
+        return self.b.counts(0)
+
+    def correspondences(self):
+        return self.b.correspondences(0)
+
+    def close(self):
+        self.b.close()
+
+
+def test_known_answers():
+    """Hand-checkable scenes; the same checks pin the oracle in tests/test_oracle_bruteforce.py."""
+    from known_answers import check_all
+    check_all(_HipEngine, scene_params)
 
 
 def test_os128_dense_cloud_matches_oracle():

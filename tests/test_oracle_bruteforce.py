@@ -109,3 +109,29 @@ def test_oracle_voxel_covariance_ground_matches_bruteforce(seed):
         assert np.array_equal(out_o.view(np.uint32), out_b.view(np.uint32))
         saw_ground = max(saw_ground, int(o.counts().n_ground))
     assert saw_ground > 100   # the floor plane was found
+
+
+class _OracleEngine:
+    def __init__(self, p):
+        self.o = Oracle(p)
+
+    def push(self, x, pose):
+        self.o.push(x, pose)
+
+    def filter(self):
+        return self.o.filter()
+
+    def counts(self):
+        return self.o.counts()
+
+    def correspondences(self):
+        return self.o.correspondences()
+
+    def close(self):
+        self.o.close()
+
+
+def test_oracle_known_answers():
+    """hand-checkable scenes pin the oracle without any reference binary (tests/known_answers.py)."""
+    from known_answers import check_all
+    check_all(_OracleEngine, scene_params)
