@@ -97,7 +97,9 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
 int mor_batch_set_async(mor_batch *b, int on);
 int mor_batch_wait(mor_batch *b);
 
-/* Device-resident result of the last filter for stream i (float4 records) */
+/* Device-resident result of the last filter for stream i (float4 records).  The filtered cloud is assembled in place in
+ * one of the batch's three per-frame buffers (the ground points are written there once, at the split): the pointer stays
+ * valid until three more frames have been pushed. */
 const void *mor_get_output_device(const mor_batch *b, int stream, uint64_t *n_out);
 
 /* Single-stream forms used by the class adapter (a batch with one stream). */
