@@ -172,7 +172,7 @@ struct MorDev {
 
 // kernel ids for optional per-kernel event timing
 enum MorKernelId {
-  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_SPLIT, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_HASH_CLEAR, MK_ROWTABLE, MK_CELLBOXES, MK_CELLGRAPH,
+  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_SPLIT, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_HASH_CLEAR, MK_CELLBOXES, MK_CELLGRAPH,
   MK_LABEL, MK_RHIST, MK_RSCAN, MK_RSCATTER,
   MK_STATS, MK_STATS_FIN, MK_XFORM_PREV, MK_XFORM_FIN, MK_NN, MK_PAIRS, MK_SCORE_FAST, MK_SCORE_NEAR, MK_SCORE_BLOCK, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
   MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_G2_CENTROID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_COUNT

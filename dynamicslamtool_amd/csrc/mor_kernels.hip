@@ -27,7 +27,7 @@
 #include <cstdlib>
 
 const char *const mor_kernel_names[MK_COUNT] = {
-    "classify", "scan_tiles", "scatter", "split", "heads_count", "heads_scan", "heads_scatter", "hash_clear", "rowtable", "cellboxes", "cellgraph", 
+    "classify", "scan_tiles", "scatter", "split", "heads_count", "heads_scan", "heads_scatter", "hash_clear", "cellboxes", "cellgraph", 
     "label", "rhist", "rscan", "rscatter",
     "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "pairs", "score_fast", "score_near", "score_block", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
     "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter"};
@@ -444,13 +444,16 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
   const size_t so = (size_t)s * d.Nmax;
   const int *skey = d.skey + so, *sidx = d.sidx + so;
   int *cstart = d.cstart + (size_t)s * (d.Nmax + 1);
-  __shared__ int sh[12];
+  __shared__ int sh[12], l_gap[3 * 64], l_ng;
+  int *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
   const int nt = (M + MOR_TILE - 1) / MOR_TILE;
+  if (threadIdx.x == 0) l_ng = 0;
+  if (M == 0 && t0 == 0) for (int r = threadIdx.x; r <= d.g.nrows; r += MOR_BT) rs[r] = 0;   // no cells: every row starts (and ends) at 0
   if (d.fuse_scans) {   // number of occupied cells: every workgroup sums the tile counts itself (no separate scan launch)
     int pre, nocc; wg_prefix_total(d.ktile_cnt + (size_t)s * d.tiles_max, 1, 0, nt, sh, pre, nocc);
     int bits = 10; while ((1 << bits) < 4 * nocc && (1 << bits) < d.Hcell) ++bits;   // cell hash: load factor ≤ 1/4
     if (t0 == 0 && threadIdx.x == 0) { d.info[s].n_occ = nocc; cstart[nocc] = M; d.info[s].hshift = 32 - bits; }
-    if (d.use_hash) {   // the stream's workgroups clear its table; k_rowtable inserts the cells
+    if (d.use_hash) {   // the stream's workgroups clear its table; k_cellboxes inserts the cells
       unsigned long long *tab = d.chash + (size_t)s * d.Hcell;
       for (int i = t0 * MOR_BT + threadIdx.x; i < (1 << bits); i += d.tiles_m * MOR_BT) tab[i] = 0ull;
     }
@@ -475,8 +478,18 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
         int c = r + __popcll(mh[it] & lanemask_lt()) + (head ? 1 : 0) - 1;
         int i = sidx[p];
         if (head) {
-          d.ckey[so + c] = skey[p]; cstart[c] = p; d.cmin[so + c] = i;   // stable sort ⇒ first of the cell = smallest cloud index
+          const int kc = skey[p];
+          d.ckey[so + c] = kc; cstart[c] = p; d.cmin[so + c] = i;   // stable sort ⇒ first of the cell = smallest cloud index
           d.parent[so + c] = c; d.csize[so + c] = 0; d.compmin[so + c] = 0x7fffffff; d.cid_of_root[so + c] = -1;
+          // dense (y,z) row table: rs[r] = first cell with key ≥ r·nx.  The head of cell c owns the rows after its
+          // predecessor's row up to its own (keys ascend), so the table is written without any search
+          const int rc = kc / d.g.nx, rp = p > 0 ? skey[p - 1] / d.g.nx : -1;
+          if (rc - rp > 16) { const int g = atomicAdd(&l_ng, 1); if (g < 64) { l_gap[3 * g] = rp; l_gap[3 * g + 1] = rc; l_gap[3 * g + 2] = c; } else for (int r = rp + 1; r <= rc; ++r) rs[r] = c; }
+          else for (int r = rp + 1; r <= rc; ++r) rs[r] = c;
+        }
+        if (p == M - 1) {   // rows behind the last cell (and the end sentinel) start at n_occ
+          const int rl = skey[p] / d.g.nx;
+          const int g = atomicAdd(&l_ng, 1); if (g < 64) { l_gap[3 * g] = rl; l_gap[3 * g + 1] = d.g.nrows; l_gap[3 * g + 2] = c + 1; } else for (int r = rl + 1; r <= d.g.nrows; ++r) rs[r] = c + 1;
         }
         d.cell_of[so + i] = c;
         float4 q = d.cloud[so + i]; q.w = __int_as_float(i);
@@ -484,30 +497,14 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
       }
       r += __popcll(mh[it]);
     }
+    __syncthreads();
+    for (int g = 0, ng = min(l_ng, 64); g < ng; ++g)   // long runs of empty rows (between z layers, before the first and after the last cell): the whole workgroup fills them
+      for (int r = l_gap[3 * g] + 1 + threadIdx.x; r <= l_gap[3 * g + 1]; r += MOR_BT) rs[r] = l_gap[3 * g + 2];
+    __syncthreads();
+    if (threadIdx.x == 0) l_ng = 0;
+    __syncthreads();
   }
 }
-// dense (y,z) row table: first occupied cell with key ≥ row·nx
-__global__ __launch_bounds__(MOR_BT) void k_rowtable(MorDev d) {
-  int s = blockIdx.y + d.s0, nocc = d.info[s].n_occ;
-  const int *ckey = d.ckey + (size_t)s * d.Nmax;
-  int *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
-  for (int r = blockIdx.x * MOR_BT + threadIdx.x; r <= d.g.nrows; r += gridDim.x * MOR_BT) {
-    int a = 0, b = nocc; const int k = r * d.g.nx;
-    if (r == d.g.nrows) a = nocc;
-    else while (a < b) { int m = (a + b) >> 1; if (ckey[m] < k) a = m + 1; else b = m; }
-    rs[r] = a;
-  }
-  if (d.use_hash) {   // cell hash: (key+1, compact id); the table was cleared by the previous kernel
-    unsigned long long *tab = d.chash + (size_t)s * d.Hcell;
-    const unsigned hshift = d.info[s].hshift, hmask = (1u << (32 - hshift)) - 1u;
-    for (int c = blockIdx.x * MOR_BT + threadIdx.x; c < nocc; c += gridDim.x * MOR_BT) {
-      const int key = ckey[c]; unsigned sl = hash_slot(key, hshift);
-      const unsigned long long ent = ((unsigned long long)((unsigned)key + 1u) << 32) | (unsigned)c;
-      while (atomicCAS(&tab[sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------ C1: Euclidean clustering = connected components over cells,
 // the whole cell graph of one stream in ONE workgroup.
 // Per-cell kernels over global memory are bound by chains of dependent loads (key → row table → key → parent →
@@ -767,6 +764,15 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
   const size_t so = (size_t)s * d.Nmax;
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
+  if (d.use_hash) {   // cell hash: (key+1, compact id); the table was cleared by k_heads_scatter
+    unsigned long long *tab = d.chash + (size_t)s * d.Hcell; const int *ckey = d.ckey + so;
+    const unsigned hshift = d.info[s].hshift, hmask = (1u << (32 - hshift)) - 1u;
+    for (int c = bx * MOR_BT + threadIdx.x; c < nocc; c += MOR_BOX_G * MOR_BT) {
+      const int key = ckey[c]; unsigned sl = hash_slot(key, hshift);
+      const unsigned long long ent = ((unsigned long long)((unsigned)key + 1u) << 32) | (unsigned)c;
+      while (atomicCAS(&tab[sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
+    }
+  }
   // four cells per 16-lane group and pass: their ranges, then their first 32 points each, as two batches of independent loads
   for (int c0 = ((bx * (MOR_BT / 64) + wave_id()) * 4 + grp) * 4; c0 < nocc; c0 += MOR_BOX_G * (MOR_BT / 64) * 16) {
     int b[4], e[4];
@@ -2123,8 +2129,7 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
     if (d.use_hash) MOR_LAUNCH(MK_HASH_CLEAR, k_hash_clear, dim3(64, d.B), d);
   }
   MOR_LAUNCH(MK_HEADS_SCATTER, k_heads_scatter, gM, d);
-  MOR_LAUNCH(MK_ROWTABLE, k_rowtable, dim3((d.g.nrows + MOR_BT) / MOR_BT > 32 ? 32 : (d.g.nrows + MOR_BT) / MOR_BT, d.B), d);
-  if (d.gmode != 1) MOR_LAUNCH(MK_CELLBOXES, k_cellboxes, dim3(MOR_BOX_G * d.B), d);
+  if (d.gmode != 1) MOR_LAUNCH(MK_CELLBOXES, k_cellboxes, dim3(MOR_BOX_G * d.B), d);   // + cell hash (the row table is written by k_heads_scatter)
 }
 
 void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
