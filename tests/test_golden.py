@@ -63,3 +63,54 @@ def test_hip_reproduces_golden(path):
         assert np.array_equal(out.view(np.uint32), g["f%d_out" % f].view(np.uint32))
         assert np.array_equal(b.tracks(0)[1], g["f%d_conf_filter" % f])
     b.close()
+
+
+# ---- full-size digests (tests/golden/fullsize_digests.json, made by tests/golden/make_golden_fullsize.py): the synthetic
+# generator is deterministic and part of the repo, so the fixture holds only counts and CRC-32 digests of the results
+def _fullsize():
+    import json
+    sys_path = os.path.join(HERE, "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_fullsize", os.path.join(sys_path, "make_golden_fullsize.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, json.load(open(os.path.join(sys_path, "fullsize_digests.json")))
+
+
+def _fullsize_params(method, gm):
+    from dynamicslamtool_amd import kitti_params
+    p = kitti_params(method)
+    p.ground_method = gm
+    return p
+
+
+@pytest.mark.parametrize("name,seed", [("hdl64_m1", 2000), ("hdl64_m1", 2005), ("hdl64_m2", 2003)])
+def test_oracle_reproduces_fullsize_digests(name, seed):
+    from dynamicslamtool_amd import synth
+    from oracle.oracle import Oracle
+    mod, fx = _fullsize()
+    case = [c for c in fx["cases"] if c[0] == name][0]
+    o = Oracle(_fullsize_params(case[2], case[3]), 4, 3)
+    for f in range(case[5]):
+        x, pose = synth.frame(seed, case[1], f)
+        o.push(x, pose)
+        out = o.filter()
+        assert mod.digest(o, out) == fx["digests"]["%s/%d/%d" % (name, seed, f)], (name, seed, f)
+    o.close()
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_fullsize_digests():
+    """Every case of the fixture (120 000- and 262 144-point clouds, both methods, both ground variants), one batch per case."""
+    from dynamicslamtool_amd import synth
+    from dynamicslamtool_amd.engine import MorBatch
+    mod, fx = _fullsize()
+    for name, sensor, method, gm, seeds, nf in fx["cases"]:
+        b = MorBatch(_fullsize_params(method, gm), len(seeds), synth.n_points(sensor), 4, 3)
+        for f in range(nf):
+            xs, ps = synth.batch(seeds, [f] * len(seeds), sensor)
+            b.push(list(xs), ps)
+            outs = b.filter()
+            for s, seed in enumerate(seeds):
+                assert mod.digest(b, outs[s], s) == fx["digests"]["%s/%d/%d" % (name, seed, f)], (name, seed, f)
+        b.close()
