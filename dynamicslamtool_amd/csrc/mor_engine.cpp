@@ -64,10 +64,8 @@ struct PoseTf { double R[3][3], o[3]; };
 struct mor_batch {
   mor_params p; int n_bad, n_good, B, device; uint64_t Nmax;
   hipStream_t st = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // st: copies of read-backs; ev: push/filter timing
-  // Three in-order HIP streams form a software pipeline over frames: `sf` runs the grid stage of frame k (ingest, ground
-  // split, cell sort), `sc` its cluster stage (cell graph … centroids), `sb` its pair stage, tracking and filterCloud.  Every array the back stage reads is double-buffered by
-  // frame parity and the cluster arrays rotate through three slots, so the three stages of consecutive frames overlap;
-  // grid(k) only waits for back(k−2), cluster(k) for grid(k), back(k) for cluster(k).
+  // Four in-order HIP streams form a software pipeline over frames (see mor_push_batch): grid stage on `sf`, cell graph on
+  // `sc`, cluster extraction + pair stage on `sm`, wave-tier scores + tracking + filterCloud on `sb`.
   hipStream_t sf = nullptr, sc = nullptr, sm = nullptr, sb = nullptr;   // grid, cell graph, mid (clusters + pair stage), tail (scores wave tier, tracking, filterCloud)
   hipEvent_t ev_grid[4] = {}, ev_cg[4] = {}, ev_front[4] = {}, ev_back[4] = {};
   MorDev dtemp[3];                           // descriptor templates, frame k uses dtemp[k % 3] (static part + pointers)

@@ -78,9 +78,9 @@ void mor_batch_destroy(mor_batch *b);
 int mor_batch_streams(const mor_batch *b);
 
 /* pushRawCloudAndPose (:516-611) for every stream of the batch at once: clouds[n_streams],
- * poses = n_streams × (position xyz, quaternion xyzw) in fp64.  All device work is enqueued as one
- * sequence of batched launches; returns after the per-stream cluster summaries reached the host
- * and the host-side tracker (checkMovingClusterChain, :478-514) ran. */
+ * poses = n_streams × (position xyz, quaternion xyzw) in fp64.  All device work — including the temporal logic
+ * (checkMovingClusterChain, :478-514), whose state lives on the device — is enqueued as batched launches; in the
+ * default synchronous mode the call returns when they have finished and the per-stream summaries are on the host. */
 int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *poses_xyz_qxyzw);
 
 /* filterCloud (:613-696) for every stream.  out[i] receives stream i's filtered cloud as packed
@@ -155,7 +155,8 @@ int mor_get_last_timing(const mor_batch *b, float *push_ms, float *filter_ms);
 int mor_kernel_timing_enable(mor_batch *b, int enable);
 int mor_kernel_timing_read(mor_batch *b, int reset, char *names, size_t names_cap, float *ms_total, uint32_t *launches, int max_kernels);
 
-/* ---- host-side tracker alone (T1/F1 state machine; lets CPU-only tests drive it) ---- */
+/* ---- the temporal logic alone as host C++ (T1/F1 state machine, the same rules as the device kernels; lets CPU-only
+ * tests drive it) ---- */
 typedef struct mor_tracker mor_tracker;
 mor_tracker *mor_tracker_create(const mor_params *p, int n_bad, int n_good);
 void mor_tracker_destroy(mor_tracker *t);
