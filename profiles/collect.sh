@@ -38,6 +38,7 @@ rows = list(csv.DictReader(open(OUT + "/trace/t_kernel_stats.csv")))
 with open("profiles/%s_summary.md" % R, "w") as o:
     o.write("# %s — rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu-baseline --no-kernel-timing` (frames pipelined over four HIP streams: kernels overlap, so the averages are those of the pipelined regime)\n\n" % R)
     o.write("bench line of the traced run: `%s`\n\n" % open(OUT + "/bench_trace.json").read().strip()[:600])
+    o.write("Note: under the tracer the four pipeline stages overlap less (the traced run reaches about half the untraced throughput), so the\naverages below lie between the `kernels_alone_avg_us` and the pipelined `kernels` figures that bench.py measures with HIP events\n(e.g. k_cellgraph: ≈ 305 µs alone, ≈ 340 µs here, ≈ 340–400 µs fully pipelined).\n\n")
     o.write("| kernel | calls | avg µs | % | HBM KB/launch (2·FETCH+WRITE) |\n|---|---|---|---|---|\n")
     for r in rows[:32]:
         k = r["Name"].split("(")[0]
