@@ -641,16 +641,23 @@ __device__ __forceinline__ int cg_lower_bound8(const int *key, int lo, int n, in
 //     16 × 16 sample for big × big ones, whose undecided rest (mostly true non-edges) goes to a second list.
 //  B2 one WAVE per pair of the second list: pruned exhaustive test (pair_hit_wave).
 // Pair lists: entries [0, CG_LIST) in LDS, the rest in the stream's global overflow area; second list global only.
+// LDS mode: compact ids are < 16384, a pair is one word (a << 14 | b) — the LDS part of the list holds 2·CG_LIST of
+// them and the spill to global memory is one 4-byte store per pair; global mode: two words per pair.
 template <bool LDS> __device__ __forceinline__ void cg_list_put(const MorDev &d, int s, int *l_list, int slot, int region, int a, int b) {
-  if (region == 0 && slot < CG_LIST) { l_list[2 * slot] = a; l_list[2 * slot + 1] = b; return; }
-  int *ov = d.cg_ovf + (((size_t)s * 2 + region) * MOR_CG_OVF + (region == 0 ? slot - CG_LIST : slot)) * 2;
-  cg_st<false>(ov, a); cg_st<false>(ov + 1, b);
+  constexpr int W = LDS ? 1 : 2, NL = 2 * CG_LIST / W;   // words per pair, pairs in the LDS part (region 0 only)
+  if (region == 0 && slot < NL) { if (LDS) l_list[slot] = (a << 14) | b; else { l_list[2 * slot] = a; l_list[2 * slot + 1] = b; } return; }
+  int *ov = d.cg_ovf + ((size_t)s * 2 + region) * MOR_CG_OVF * 2 + (size_t)(region == 0 ? slot - NL : slot) * W;
+  if (LDS) cg_st<false>(ov, (a << 14) | b); else { cg_st<false>(ov, a); cg_st<false>(ov + 1, b); }
 }
 template <bool LDS> __device__ __forceinline__ void cg_list_get(const MorDev &d, int s, const int *l_list, int slot, int region, int &a, int &b) {
-  if (region == 0 && slot < CG_LIST) { a = l_list[2 * slot]; b = l_list[2 * slot + 1]; return; }
-  const int *ov = d.cg_ovf + (((size_t)s * 2 + region) * MOR_CG_OVF + (region == 0 ? slot - CG_LIST : slot)) * 2;
-  a = cg_ld<false>(ov); b = cg_ld<false>(ov + 1);
+  constexpr int W = LDS ? 1 : 2, NL = 2 * CG_LIST / W;
+  if (region == 0 && slot < NL) { if (LDS) { const int c = l_list[slot]; a = c >> 14; b = c & 16383; } else { a = l_list[2 * slot]; b = l_list[2 * slot + 1]; } return; }
+  const int *ov = d.cg_ovf + ((size_t)s * 2 + region) * MOR_CG_OVF * 2 + (size_t)(region == 0 ? slot - NL : slot) * W;
+  if (LDS) { const int c = cg_ld<false>(ov); a = c >> 14; b = c & 16383; } else { a = cg_ld<false>(ov); b = cg_ld<false>(ov + 1); }
 }
+static_assert(CG_CAP <= 16384, "pair lists pack two compact cell ids into 28 bits");
+// capacity of list `region` in pairs
+template <bool LDS> __device__ __forceinline__ int cg_list_cap(int region) { return (region == 0 ? 2 * CG_LIST / (LDS ? 1 : 2) : 0) + MOR_CG_OVF * (LDS ? 2 : 1); }
 // decides one pair: returns 1 = edge, 0 = no edge, −1 = big × big and undecided by the sample
 __device__ __forceinline__ int cg_pair_test(const MorDev &d, size_t so, const int *start, const float4 *sp, int a, int b, float r2) {
   const float4 alo = d.cmeta[2 * (so + a)], ahi = d.cmeta[2 * (so + a) + 1], blo = d.cmeta[2 * (so + b)], bhi = d.cmeta[2 * (so + b) + 1];
@@ -702,7 +709,7 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
             base = __shfl(base, leader, 64);
             if (want) {
               const int slot = base + __popcll(m & lanemask_lt());
-              if (slot < CG_LIST + MOR_CG_OVF) cg_list_put<LDS>(d, s, l_list, slot, 0, a, b);
+              if (slot < cg_list_cap<LDS>(0)) cg_list_put<LDS>(d, s, l_list, slot, 0, a, b);
               else {   // both lists full (never seen): settle it here, exhaustively
                 const int a0 = start[a], b0 = start[b];
                 if (pair_hit_serial(sp, a0, start[a + 1] - a0, b0, start[b + 1] - b0, r2)) cg_unite<LDS>(par, a, b);
@@ -717,7 +724,7 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
   __syncthreads();
   RS_T(tp1);
   // ---- B1: one thread per candidate pair
-  const int n1 = min(*l_nlist, CG_LIST + MOR_CG_OVF);
+  const int n1 = min(*l_nlist, cg_list_cap<LDS>(0));
   for (int h = threadIdx.x; h < n1; h += CG_T) {
     int a, b; cg_list_get<LDS>(d, s, l_list, h, 0, a, b);
     if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;   // an earlier union has connected them
@@ -725,7 +732,7 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
     if (verdict > 0) cg_unite<LDS>(par, a, b);
     else if (verdict < 0) {
       const int slot = atomicAdd(l_n2, 1);
-      if (slot < MOR_CG_OVF) cg_list_put<LDS>(d, s, l_list, slot, 1, a, b);
+      if (slot < cg_list_cap<LDS>(1)) cg_list_put<LDS>(d, s, l_list, slot, 1, a, b);
       else { const int a0 = start[a], b0 = start[b]; if (pair_hit_serial(sp, a0, start[a + 1] - a0, b0, start[b + 1] - b0, r2)) cg_unite<LDS>(par, a, b); }
     }
   }
@@ -733,7 +740,7 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
   __syncthreads();
   RS_T(tp2);
   // ---- B2: one wave per undecided big pair — root re-check, pruned exhaustive test
-  const int n2 = min(*l_n2, MOR_CG_OVF), lane = lane_id();
+  const int n2 = min(*l_n2, cg_list_cap<LDS>(1)), lane = lane_id();
   for (int h = wave_id(); h < n2; h += CG_T / 64) {
     int a, b; cg_list_get<LDS>(d, s, l_list, h, 1, a, b);
     if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;
