@@ -53,6 +53,7 @@ struct MorFrameInfo {        // per stream, produced on device
 // Temporal logic (T1 + the tracking loop of F1) as device state, one instance per stream.  O(clusters) sequential work
 // per frame: it runs in a one-workgroup-per-stream kernel right behind the geometry so that push + filter need no
 // host round trip in between.  Mirrors csrc/mor_tracker.cpp (the host version behind the mor_tracker_* C ABI).
+#define MOR_CG_EXT 262144  // entries per stream of the helper workgroup's shell-pair list
 #define MOR_CG_OVF 65536   // overflow entries per stream of the cell graph's deferred-pair list
 #define MOR_TR_MAXT 512   // tracked moving centroids per stream (mo_vec)
 #define MOR_TR_NB 8       // longest supported window (n_bad)
@@ -114,6 +115,7 @@ struct MorDev {
   float4 *crep;              // [B][Nmax]  per occupied cell: its first point (sample for the quick edge test of the cell graph)
   float4 *sorted;            // [B][Nmax]  (x,y,z, bits(cloud index)) in cell order; .w becomes the cluster id after labelling
   int *parent;               // [B][Nmax]  union-find forest over occupied cells (parent ≤ child)
+  int *cg_ext, *cg_help; int cg_help_min; // [B][MOR_CG_EXT], [B][4]  k_cellgraph: shell-pass candidate pairs listed by a heavy stream's helper workgroup ((a << 14) | b), its flag + count; cell count from which a stream gets a helper (0: none)
   int *cg_ovf;               // [B][2][MOR_CG_OVF][2]  k_cellgraph: candidate cell pairs beyond its LDS list; undecided big cell pairs
   int *croot;                // [B][Nmax]  flattened root per cell
   int *csize;                // [B][Nmax]  component size (points) at its root cell

@@ -275,6 +275,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (d.use_hash) ok = ok && dalloc(b, d.chash, B * (size_t)d.Hcell); else d.chash = nullptr;
   ok = ok && dalloc(b, d.split_desc, B * T);
   ok = ok && dalloc(b, d.crep, B * N);
+  ok = ok && dalloc(b, d.cg_ext, B * (size_t)MOR_CG_EXT) && dalloc(b, d.cg_help, B * 4);
   ok = ok && dalloc(b, d.cg_ovf, B * (size_t)MOR_CG_OVF * 4);
   ok = ok && dalloc(b, d.xcent, B * K) && dalloc(b, d.xamin, B * K) && dalloc(b, d.xamax, B * K);
   for (int i = 0; i < 4; ++i)
@@ -363,6 +364,16 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   }
   d.tiles = std::max<int>(1, (int)((maxn + MOR_TILE - 1) / MOR_TILE));
   d.fuse_scans = d.fuse_scans && d.tiles <= 2048;
+  {  // helper workgroups of the cell graph: for the streams with the most cells (they decide the kernel's duration)
+    d.cg_help_min = 0;
+    const int frac = getenv("MOR_CG_HELP_PCT") ? atoi(getenv("MOR_CG_HELP_PCT")) : 15;   // share of the streams, in percent
+    if (k > 0 && B >= 8 && frac > 0) {
+      std::vector<uint32_t> occ(B);
+      for (int s = 0; s < B; ++s) occ[s] = d.h_info[s].n_occ;
+      std::sort(occ.begin(), occ.end());
+      d.cg_help_min = (int)std::max<uint32_t>(occ[std::min(B - 1, B - 1 - B * frac / 100 + 1)], 1024u);
+    }
+  }
   d.cur = (int)(k % 4); d.prev = (int)((k + 3) % 4); d.has_prev = k > 0; d.out_ptrs = nullptr; d.run_tracker = 0;
   {  // workgroups for the cloud-sized kernels: 1.25 × the largest cloud / cluster set the device last reported
     uint32_t mx = 0;

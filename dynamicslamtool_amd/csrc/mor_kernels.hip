@@ -674,11 +674,14 @@ __device__ __forceinline__ int cg_pair_test(const MorDev &d, size_t so, const in
   return pair_hit_serial(sp, a0, na, b0, nb, r2) ? 1 : 0;
 }
 template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const MorDev &d, int s, int nocc, const int *key, const int *start, const int *rows, int *par,
-                                                                   const float4 *sp, int *l_list, int *l_nlist, int *l_n2) {
+                                                                   const float4 *sp, int *l_list, int *l_nlist, int *l_n2, int n_ext) {
   const float r2 = d.r2;
   const size_t so = (size_t)s * d.Nmax;
+  const bool listed = n_ext >= 0;                                   // the helper workgroup has listed this pass's candidate pairs
+  const int *ext = d.cg_ext + (size_t)s * MOR_CG_EXT;
   RS_T(tp0);
-  // ---- A: candidate pairs
+  // ---- A: candidate pairs (unless the stream's helper workgroup has listed them)
+  if (!listed)
   for (int a = threadIdx.x; a < nocc; a += CG_T) {
     const int ka = key[a], rowa = ka / d.g.nx, x = ka - rowa * d.g.nx, y = rowa % d.g.ny, z = rowa / d.g.ny;
     const int ra = cg_find<LDS>(par, a);
@@ -724,9 +727,10 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
   __syncthreads();
   RS_T(tp1);
   // ---- B1: one thread per candidate pair
-  const int n1 = min(*l_nlist, cg_list_cap<LDS>(0));
+  const int n1 = listed ? n_ext : min(*l_nlist, cg_list_cap<LDS>(0));
   for (int h = threadIdx.x; h < n1; h += CG_T) {
-    int a, b; cg_list_get<LDS>(d, s, l_list, h, 0, a, b);
+    int a, b;
+    if (listed) { const int code = cg_ld<false>(ext + h); a = code >> 14; b = code & 16383; } else cg_list_get<LDS>(d, s, l_list, h, 0, a, b);
     if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;   // an earlier union has connected them
     const int verdict = cg_pair_test(d, so, start, sp, a, b, r2);
     if (verdict > 0) cg_unite<LDS>(par, a, b);
@@ -832,11 +836,25 @@ template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int
   // (the boxes of the cells' points were written by k_cellboxes at the end of the grid stage)
   CG_STAMP(2);
   // ---- hooks: 3×3×3 neighbourhood first, then the 5×5×5 shell (mostly skipped by the root test)
-  cg_hook_pass<LDS, 1>(d, s, nocc, key, start, rows, par, sp, l_list, l_nlist, l_misc);
+  cg_hook_pass<LDS, 1>(d, s, nocc, key, start, rows, par, sp, l_list, l_nlist, l_misc, -1);
   CG_STAMP(3);
   for (int c = threadIdx.x; c < nocc; c += CG_T) { const int r = cg_find<LDS>(par, c); if (r != c) cg_st<LDS>(par + c, r); }   // flat forest: the shell pass compares parents directly
   __syncthreads();
-  cg_hook_pass<LDS, 2>(d, s, nocc, key, start, rows, par, sp, l_list, l_nlist, l_misc);
+  // A heavy stream (many cells: the ones this kernel's duration hangs on) has a helper workgroup that has meanwhile
+  // listed the shell pass's candidate pairs — all of them, it has no forest to filter with; the root re-check of
+  // phase B1 drops nearly all at two LDS loads each.  Bounded wait; no list ⇒ this workgroup enumerates itself.
+  int n_ext = -1;
+  if (LDS && d.cg_help_min > 0 && nocc >= d.cg_help_min) {
+    if (threadIdx.x == 0) {
+      int *hf = d.cg_help + (size_t)s * 4; unsigned spins = 0;
+      while (atomicAdd(hf, 0) == 0 && ++spins < 2048u) __builtin_amdgcn_s_sleep(8);
+      l_misc[1] = atomicAdd(hf, 0) != 0 ? atomicAdd(hf + 1, 0) : -1;
+    }
+    __syncthreads();
+    n_ext = l_misc[1];
+    __syncthreads();
+  }
+  cg_hook_pass<LDS, 2>(d, s, nocc, key, start, rows, par, sp, l_list, l_nlist, l_misc, n_ext);
   CG_STAMP(4);
   // ---- components: size (points) and smallest cloud index at the root.  LDS mode has one scratch array left (`mn`
   //      aliases the keys): sizes are accumulated in it first and parked in the global `size` array, then the minima
@@ -928,12 +946,65 @@ template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int
   CG_STAMP(6);
 }
 
+// Helper workgroup of a heavy stream: candidate pairs of the SHELL pass — every forward pair at ring distance 2, no
+// forest filter — written to the stream's external list as (a << 14 | b) while the main workgroup runs the 3×3×3 pass.
+// It is the list's only writer: positions come from an LDS counter and the stores are fire-and-forget; count and flag
+// are published at the end (release at agent scope).
+__device__ __forceinline__ void cg_helper(const MorDev &d, int s, int nocc, int *l_key, int *l_rows, int *l_cnt) {
+  int *hf = d.cg_help + (size_t)s * 4;
+  if (nocc < d.cg_help_min) return;                                   // light stream: its main workgroup does not wait
+  if (nocc > CG_CAP || d.g.nrows > CG_ROWCAP) { if (threadIdx.x == 0) { atomicExch(hf + 1, -1); __threadfence(); atomicExch(hf, 1); } return; }
+  const size_t so = (size_t)s * d.Nmax;
+  const int *gk = d.ckey + so, *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1);
+  for (int i = threadIdx.x; i < nocc; i += CG_T) l_key[i] = gk[i];
+  for (int i = threadIdx.x; i <= d.g.nrows; i += CG_T) l_rows[i] = g_rows[i];
+  if (threadIdx.x == 0) *l_cnt = 0;
+  __syncthreads();
+  const int *key = l_key, *rows = l_rows;
+  int *ext = d.cg_ext + (size_t)s * MOR_CG_EXT;
+  constexpr int RING = 2;
+  for (int a = threadIdx.x; a < nocc; a += CG_T) {
+    const int ka = key[a], rowa = ka / d.g.nx, x = ka - rowa * d.g.nx, y = rowa % d.g.ny, z = rowa / d.g.ny;
+    for (int dz = 0; dz <= RING; ++dz) {
+      if (z + dz >= d.g.nz) break;
+      for (int dy = (dz == 0 ? 0 : -RING); dy <= RING; ++dy) {
+        if ((unsigned)(y + dy) >= (unsigned)d.g.ny) continue;
+        const bool edge_row = dz == RING || abs(dy) == RING;
+        const int rr = (z + dz) * d.g.ny + (y + dy), rlo = rows[rr], rn = rows[rr + 1] - rlo;
+        if (rn == 0) continue;
+        const int rowbase = rr * d.g.nx + x;
+        int lo = rlo; const int hi = rlo + rn;
+        if (rn > 8) lo = cg_lower_bound8(key, rlo, rn, rowbase - RING);
+        for (int b = lo; b < hi; ++b) {
+          const int dx = key[b] - rowbase;
+          if (dx > RING) break;
+          const bool want = dx >= -RING && !(dz == 0 && dy == 0 && dx <= 0) && (edge_row || abs(dx) == RING);
+          const unsigned long long m = __ballot(want);
+          if (m) {
+            const int leader = __ffsll((long long)m) - 1; int base = 0;
+            if (lane_id() == leader) base = atomicAdd(l_cnt, __popcll(m));
+            base = __shfl(base, leader, 64);
+            if (want) { const int slot = base + __popcll(m & lanemask_lt()); if (slot < MOR_CG_EXT) ext[slot] = (a << 14) | b; }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { const int n = *l_cnt; atomicExch(hf + 1, n <= MOR_CG_EXT ? n : -1); }
+  __threadfence();      // every thread's list stores are performed at agent scope before …
+  __syncthreads();
+  if (threadIdx.x == 0) atomicExch(hf, 1);   // … the flag goes up
+}
 __global__ __launch_bounds__(CG_T) void k_cellgraph(MorDev d) {
-  const int s = blockIdx.x + d.s0, nocc = d.info[s].n_occ;
+  // blocks [0, B): helper workgroups (when enabled; they return at once for light streams), the next B: main workgroups
+  // (on the XCD of their helper when B is a multiple of 8)
+  const int s = blockIdx.x % d.B + d.s0, nocc = d.info[s].n_occ;
 #ifdef MOR_EXP_STAMPS
   if (threadIdx.x == 0) d.dbg[(size_t)s * 16 + 0] = wall_clock64();
 #endif
   __shared__ int l_key[CG_CAP], l_par[CG_CAP], l_rows[CG_ROWCAP + 1], l_list[2 * CG_LIST], l_nlist, l_misc[1 + CG_T / 64];
+  if (d.cg_help_min > 0 && (int)blockIdx.x < d.B) { cg_helper(d, s, nocc, l_key, l_rows, &l_nlist); return; }
   const size_t so = (size_t)s * d.Nmax;
   const int *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1);
   const int *rows = g_rows;
@@ -2177,7 +2248,8 @@ void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
 }
 
 void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  const dim3 gB(d.B);
+  const dim3 gB(d.cg_help_min > 0 ? 2 * d.B : d.B);
+  if (d.cg_help_min > 0) (void)hipMemsetAsync(d.cg_help + (size_t)d.s0 * 4, 0, (size_t)d.B * 4 * sizeof(int), st);
   mor_timer_begin(tm, MK_CELLGRAPH, st);
   hipLaunchKernelGGL(k_cellgraph, gB, dim3(CG_T), 0, st, d);
   mor_timer_end(tm, MK_CELLGRAPH, st);

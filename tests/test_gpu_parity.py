@@ -312,6 +312,25 @@ def test_cluster_boxes_are_the_min_max_of_their_points():
     b.close()
 
 
+def test_cell_graph_helper_workgroups(monkeypatch):
+    """k_cellgraph gives the streams with the most cells a second, helper workgroup that lists the shell pass's candidate
+    pairs while the main one runs the 3×3×3 pass (by default the top 15 % of a batch of ≥ 8 streams).  Here every stream
+    of a batch of 8 gets one; results must not change."""
+    monkeypatch.setenv("MOR_CG_HELP_PCT", "100")
+    p = kitti_params(1)
+    seeds = [2000, 2001, 2005, 2017, 2033, 2040, 2041, 2042]
+    b, os_ = MorBatch(p, 8, 120000), [Oracle(p) for _ in seeds]
+    for f in range(3):
+        xs, ps = synth.batch(seeds, [f] * 8)
+        b.push(list(xs), ps)
+        outs = b.filter()
+        for s in (0, 2, 5, 7):   # the oracle is the slow side: four of the eight streams
+            os_[s].push(xs[s], ps[s])
+            compare_frame(os_[s], b, s, "helper stream %d frame %d" % (s, f))
+            compare_output(os_[s].filter(), outs[s], "helper stream %d frame %d" % (s, f))
+    b.close()
+
+
 _OVERFLOW_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
