@@ -163,7 +163,7 @@ static int configure(mor_batch *b) {
   d.fuse_scans = getenv("MOR_NO_FUSE") ? 0 : 1;   // refined per push (tile count)
   d.use_hash = d.method == 1;
   { size_t hc = 1024; while (hc < 4 * (size_t)d.Nmax) hc <<= 1; d.Hcell = (int)hc; }
-  d.t1_budget = getenv("MOR_T1_BUDGET") ? atoi(getenv("MOR_T1_BUDGET")) : 256;
+  d.t1_budget = getenv("MOR_T1_BUDGET") ? atoi(getenv("MOR_T1_BUDGET")) : 64;
   if (d.score_R > 60) return set_error(MOR_ERR_INVALID, "pde_ub %g needs a %d-cell search radius (> 60)", (double)p.pde_ub, d.score_R);
   int bits = 1; while ((1 << bits) < d.Kcap) ++bits;
   d.radix_passes = (bits + 7) / 8;
