@@ -1,7 +1,7 @@
 import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dynamicslamtool_amd import engine, kitti_params, synth
-B, npts, nf = 64, 120000, 8
+B, npts, nf = 64, 120000, 20
 p = kitti_params(1)
 seeds = [2000 + s for s in range(B)]
 frames = [synth.batch(seeds, [f] * B) for f in range(nf)]

@@ -331,6 +331,34 @@ def test_cell_graph_helper_workgroups(monkeypatch):
     b.close()
 
 
+def test_async_pipeline_equals_synchronous_use_at_full_batch_size():
+    """BASELINE configs[1] shape (B = 64 × 120 000 pts), 12 frames: the asynchronous four-stage pipeline (three frames
+    in flight, helper workgroups on the heavy streams) must leave exactly the results of synchronous push / filter
+    calls — correspondences, scores, tracks and filtered-cloud sizes of every stream."""
+    p = kitti_params(1)
+    B, nf = 64, 12
+    seeds = [2000 + s for s in range(B)]
+    frames = [synth.batch(seeds, [f] * B) for f in range(nf)]
+    a, b = MorBatch(p, B, 120000), MorBatch(p, B, 120000)
+    for xs, ps in frames:
+        a.push(list(xs), ps)
+        a.filter(to_host=False)
+    b.set_async(True)
+    for xs, ps in frames:
+        b.push(list(xs), ps)
+        b.filter_async()
+    b.wait()
+    for s in range(B):
+        for x, y in zip(a.correspondences(s), b.correspondences(s)):
+            assert np.array_equal(np.asarray(x), np.asarray(y)), s
+        for x, y in zip(a.tracks(s), b.tracks(s)):
+            assert np.array_equal(np.asarray(x), np.asarray(y)), s
+        assert a.output_device(s)[1] == b.output_device(s)[1], s
+        assert np.array_equal(a.labels(s), b.labels(s)), s
+    a.close()
+    b.close()
+
+
 _OVERFLOW_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
