@@ -103,7 +103,7 @@ struct MorDev {
   float *zorg; int *zbase;   // [B]  z origin of the clustering grid / z base of the voxel lattice
   int *mode_bin;             // [B]  dominant z-bin (:169-178)
   int *pkey;                 // [B][Nmax]  linear cell key per cloud point
-  int *cell_of;              // [B][Nmax]  compact cell id per cloud point
+  int *cell_of;              // [B][Nmax]  compact cell id per position of `sorted`
   int *skey, *sidx;          // aliases of the radix buffers holding the cell-sorted (key, cloud index)
   int *ckey;                 // [B][Nmax]  distinct cell keys, ascending (n_occ of them)
   int *cstart;               // [B][Nmax+1]  first sorted position of each occupied cell

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
           const int rl = skey[p] / d.g.nx;
           const int g = atomicAdd(&l_ng, 1); if (g < 64) { l_gap[3 * g] = rl; l_gap[3 * g + 1] = d.g.nrows; l_gap[3 * g + 2] = c + 1; } else for (int r = rl + 1; r <= d.g.nrows; ++r) rs[r] = c + 1;
         }
-        d.cell_of[so + i] = c;
+        d.cell_of[so + p] = c;   // per sorted position (coalesced; k_label reads it the same way)
         float4 q = d.cloud[so + i]; q.w = __int_as_float(i);
         d.sorted[so + p] = q;
       }
@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(MOR_BT) void k_label(MorDev d) {
   for (int js = t0 * MOR_BT + threadIdx.x; js < M; js += d.tiles_m * MOR_BT) {
     float4 q = d.sorted[so + js];
     int i = __float_as_int(q.w);
-    int cid = d.ccid[so + d.cell_of[so + i]];   // one cluster per cell (clique)
+    int cid = d.ccid[so + d.cell_of[so + js]];   // one cluster per cell (clique)
     q.w = __int_as_float(cid);
     d.sorted[so + js] = q;
     d.pcid[so + i] = cid;
@@ -1260,7 +1260,8 @@ __global__ __launch_bounds__(MOR_BT) void k_xform_fin(MorDev d) {
 // ------------------------------------------------------------------------------------ P2: centroid correspondence (:285-307)
 // dir 0: nearest current centroid of every previous centroid; dir 1: the reverse.  Squared fp32
 // distance, ties → lowest index (ascending scan with strict <).
-__global__ __launch_bounds__(MOR_BT) void k_nn_centroid(MorDev d, int dir) {
+__global__ __launch_bounds__(MOR_BT) void k_nn_centroid(MorDev d) {
+  const int dir = blockIdx.z;   // both directions in one launch
   int s = blockIdx.y + d.s0;
   int Ksrc = dir == 0 ? d.info_prev[s].K : d.info[s].K, Kdst = dir == 0 ? d.info[s].K : d.info_prev[s].K;
   if (blockIdx.x * MOR_BT >= Ksrc) return;
@@ -2273,8 +2274,7 @@ void mor_launch_mid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   if (d.has_prev) {
     MOR_LAUNCH(MK_XFORM_PREV, k_xform_prev, dim3(64, d.B), d);
     MOR_LAUNCH(MK_XFORM_FIN, k_xform_fin, gKt, d);
-    MOR_LAUNCH(MK_NN, k_nn_centroid, gKt, d, 0);
-    MOR_LAUNCH(MK_NN, k_nn_centroid, gKt, d, 1);
+    MOR_LAUNCH(MK_NN, k_nn_centroid, dim3(gKt.x, gKt.y, 2), d);
     MOR_LAUNCH(MK_PAIRS, k_pairs, gB, d);
     if (d.method == 1) {
       if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * 8), d); MOR_LAUNCH(MK_SCORE_NEAR, k_score_near, dim3(MOR_SCORE_G * d.B), d); }
