@@ -79,6 +79,7 @@ void MovingObjectRemoval::setVariables(const std::string &path) {
 }
 
 void MovingObjectRemoval::pushRawCloudAndPose(pcl::PCLPointCloud2 &cloud, geometry_msgs::Pose pose) {
+  push_ok_ = false;
   // fromPCLPointCloud2 (.cpp:523): fields matched by name; a missing intensity stays 0
   uint32_t off[4] = {MOR_NO_FIELD, MOR_NO_FIELD, MOR_NO_FIELD, MOR_NO_FIELD};
   for (const auto &f : cloud.fields) {
@@ -87,9 +88,23 @@ void MovingObjectRemoval::pushRawCloudAndPose(pcl::PCLPointCloud2 &cloud, geomet
   }
   const uint64_t n = (uint64_t)cloud.width * cloud.height;
   if (off[0] == MOR_NO_FIELD || off[1] == MOR_NO_FIELD || off[2] == MOR_NO_FIELD) { std::cerr << "MovingObjectRemoval: cloud has no float32 x/y/z fields" << std::endl; return; }
+  // the blob must hold what its header promises (fromPCLPointCloud2 would read past the end otherwise); rows of an
+  // organised cloud may be padded (row_step > width·point_step): the records are then gathered row by row
+  const uint64_t row_bytes = (uint64_t)cloud.width * cloud.point_step;
+  const uint64_t row_step = (cloud.height > 1 && cloud.row_step > row_bytes) ? cloud.row_step : row_bytes;
+  const uint64_t need = cloud.height ? (uint64_t)(cloud.height - 1) * row_step + row_bytes : 0;
+  if (cloud.data.size() < need) { std::cerr << "MovingObjectRemoval: cloud.data holds " << cloud.data.size() << " bytes, header needs " << need << std::endl; return; }
+  const uint8_t *records = cloud.data.data();
+  if (row_step != row_bytes) {
+    rows_.resize((size_t)(n * cloud.point_step));
+    for (uint32_t r = 0; r < cloud.height; ++r) std::memcpy(rows_.data() + (size_t)r * row_bytes, cloud.data.data() + (size_t)r * row_step, (size_t)row_bytes);
+    records = rows_.data();
+  }
   const double p[7] = {pose.position.x, pose.position.y, pose.position.z, pose.orientation.x, pose.orientation.y, pose.orientation.z, pose.orientation.w};
-  int rc = mor_push(ctx_, cloud.data.data(), n, cloud.point_step, off[0], off[1], off[2], off[3], p);
+  int rc = mor_push(ctx_, records, n, cloud.point_step, off[0], off[1], off[2], off[3], p);
   if (rc != MOR_OK) { std::cerr << "MovingObjectRemoval: mor_push failed (" << rc << "): " << mor_last_error() << std::endl; return; }
+  push_ok_ = true;
+  in_header_ = cloud.header;   // raw_cloud->header (fromPCLPointCloud2 copies it, .cpp:523); filterCloud's outputs carry it (.cpp:690-691)
   last_n_ = n; ++pushes_;
 #ifdef MOR_VISUALIZE
   if (pushes_ >= 2) {   // inside `if(ca->init && cb->init)` (.cpp:534, :553-558)
@@ -98,9 +113,11 @@ void MovingObjectRemoval::pushRawCloudAndPose(pcl::PCLPointCloud2 &cloud, geomet
     mor_get_cluster_collection(ctx_, 0, scratch_.data());
     expand(scratch_.data(), c.n_clustered, cloud.data);
     describe_xyzi<pcl::PCLPointCloud2, pcl::PCLPointField>(cloud, c.n_clustered);
+    cloud.header = pcl::PCLHeader();   // cluster_collection is a fresh PointCloud: default header (.cpp:554)
     output.data = cloud.data;
     describe_xyzi<sensor_msgs::PointCloud2, sensor_msgs::PointField>(output, c.n_clustered);
-    output.header.frame_id = debug_fid_;
+    output.header = std_msgs::Header();   // fromPCL copies the (default) header (.cpp:555) …
+    output.header.frame_id = debug_fid_;  // … then .cpp:556
   }
 #endif
 }
@@ -126,14 +143,23 @@ std::vector<MovingObjectRemoval::BoxMarker> MovingObjectRemoval::clusterMarkers(
 }
 
 bool MovingObjectRemoval::filterCloud(pcl::PCLPointCloud2 &out_cloud, std::string f_id) {
+  // the reference cannot fail here (.cpp:695); this implementation can when the preceding push was refused (capacity,
+  // malformed blob, GPU error): the frame never reached the device, so there is nothing to filter — report it
+  // instead of re-emitting the previous frame's cloud
+  if (!push_ok_) { std::cerr << "MovingObjectRemoval: filterCloud without a successful pushRawCloudAndPose" << std::endl; return false; }
   scratch_.resize(4 * (size_t)last_n_ + 4);
   uint64_t n = 0;
   int rc = mor_filter(ctx_, scratch_.data(), &n);
   if (rc != MOR_OK) { std::cerr << "MovingObjectRemoval: mor_filter failed (" << rc << "): " << mor_last_error() << std::endl; return false; }
   expand(scratch_.data(), n, out_cloud.data);   // toPCLPointCloud2 (.cpp:690)
   describe_xyzi<pcl::PCLPointCloud2, pcl::PCLPointField>(out_cloud, n);
+  // f_cloud is created empty and filled by ExtractIndices::filter(f_cloud), which copies the header of its input cloud
+  // cb->cloud (= the incoming cloud's header, carried through fromPCLPointCloud2 and the filters); toPCLPointCloud2
+  // (.cpp:690) and fromPCL (.cpp:691) pass it on, .cpp:692 then overwrites frame_id
+  out_cloud.header = in_header_;
   output.data = out_cloud.data;                 // pcl_conversions::fromPCL (.cpp:691)
   describe_xyzi<sensor_msgs::PointCloud2, sensor_msgs::PointField>(output, n);
+  output.header.seq = in_header_.seq; output.header.stamp = (double)in_header_.stamp * 1e-6;   // pcl stamps are microseconds
   output.header.frame_id = f_id;                // .cpp:692
   return true;
 }

@@ -64,6 +64,10 @@ struct MorTrackDev {
   int mo_conf[MOR_TR_MAXT], mo_max[MOR_TR_MAXT];
 };
 
+// per-frame, per-stream summary written into pinned host memory by the tail / filter kernels
+#define MOR_LOG_CAP 64
+struct MorFrameLog { int frame, K, C, n_pairs; unsigned cnt_sum, det_sum; int n_mo_push, n_mo_filter; unsigned long long n_out; int flags, pad; };
+
 struct MorDev {
   // ---- static configuration
   int B, s0, Btot;           // streams in this launch, first stream, streams in the batch
@@ -87,8 +91,14 @@ struct MorDev {
   int run_tracker;           // filter: advance the tracking loop (first filterCloud of this frame)
   // ---- device arrays (per-stream stride noted)
   const MorStreamArgs *args; // [B]
-  MorFrameInfo *info;        // [B]  this frame (the engine double-buffers it and every array the pair / filter stage reads)
-  const MorFrameInfo *info_prev; // [B]  previous frame (its K, C)
+  MorFrameInfo *info;        // [B]  this frame (one copy per frame in flight, like every array that crosses a stage boundary)
+  int2 *slot_kc[4];          // [B]  (K, C) of the frame that owns the cluster slot: written by the cell graph of that frame, read by the
+                             //      next frame's pair stage as ca's K and C (never through another frame's `info` copy, which the grid
+                             //      stage of a later frame resets while the pair stage may still be running)
+  unsigned *err;             // [B]  sticky error word per stream: every raised flag is OR-ed in and stays until the host has reported it
+  unsigned *h_err;           // [B]  pinned host mirror of `err`, refreshed by the last kernel of every push and filter
+  int frame_no;              // index of this frame since the batch was created
+  struct MorFrameLog *h_log; // [MOR_LOG_CAP][B]  pinned per-frame summaries (frame k in row k % MOR_LOG_CAP): lets tests compare every frame of an asynchronous run
   int *tile_cnt, *tile_off;  // [B][tiles_max][2]   (non-ground, ground) counts / exclusive offsets
   unsigned long long *split_desc; // [B][tiles_max]  look-back descriptors of the single-pass split (status | non-ground | ground)
   float4 *cloud;             // [B][Nmax]  non-ground points, input order (`cloud`, :85)

@@ -15,17 +15,15 @@
 #include <tuple>
 #include <vector>
 
-#define MOR_MAX_GROUPS 8
 #define MOR_ARGS_RING 8
 
-// The frame pipeline needs its four stage streams on four different hardware queues; the ROCm runtime multiplexes
-// streams onto GPU_MAX_HW_QUEUES (default 4) queues in creation order, so with the batch's main stream two stages would
-// share one.  Ask for more queues before the runtime initialises (no effect if the process has already initialised HIP).
-// Measured on MI355X: hardware queue i is served by compute pipe i % 4 and queues of one pipe do not overlap, so four
-// is also the useful maximum of concurrently busy streams — a fifth stage stream (tried: alternating the cell-graph
-// kernel of even / odd frames) lands on a busy pipe and halves the throughput.  Stream creation order below is
-// st, sf, sc, sm, sb ⇒ queues 0…4 ⇒ pipes 0,1,2,3,0 with `st` idle during pushes.
-namespace { struct MorEnvInit { MorEnvInit() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_mor_env_init; }
+// The frame pipeline wants its four stage streams on four different hardware queues.  The ROCm runtime multiplexes
+// streams onto GPU_MAX_HW_QUEUES (default 4) queues in creation order, so with the batch's main stream two stages share
+// one unless the PROCESS sets GPU_MAX_HW_QUEUES=8 (or more) before HIP initialises — the integrator's decision, this
+// library never touches the environment (the Python binding and the replay driver set it).  Measured on
+// MI355X: hardware queue i is served by compute pipe i % 4 and queues of one pipe do not overlap, so four is also the
+// useful maximum of concurrently busy streams.  Stream creation order below is st, sf, sc, sm, sb ⇒ queues 0…4 ⇒
+// pipes 0,1,2,3,0 with `st` idle during pushes.
 
 static thread_local std::string g_last_error;
 static int set_error(int code, const char *fmt, ...) {
@@ -171,7 +169,8 @@ static int configure(mor_batch *b) {
   return MOR_OK;
 }
 
-// waits for everything enqueued on the batch and turns the device-side flags of the last push into an error code
+// waits for everything enqueued on the batch and turns the sticky per-stream error words (every flag any kernel has
+// raised since the last report, whichever frame it belonged to) into an error code; reporting clears them
 static int wait_all_checked(mor_batch *b) {
   if (!b->pending) return MOR_OK;
   HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sc)); HIP_TRY(hipStreamSynchronize(b->sm)); HIP_TRY(hipStreamSynchronize(b->sb));
@@ -179,15 +178,21 @@ static int wait_all_checked(mor_batch *b) {
   b->timer.collect();
   int rc = MOR_OK;
   const MorDev &d = b->d;
+  bool any = false;
   for (int s = 0; s < d.B; ++s) {
-    const MorFrameInfo &f = d.h_info[s];
-    if (f.flags & 1u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than %d clusters", s, d.Kcap);
-    if (f.flags & 2u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: voxel key out of range in method 2", s);
-    if (f.flags & 8u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: z extent of the trimmed cloud exceeds the 64 m the voxel ground variant covers", s);
-    if (f.flags & 16u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than 16384 points within gp_leaf of a voxel centroid", s);
-    if (f.flags & 64u) rc = set_error(MOR_ERR_HIP, "stream %d: look-back of the single-pass split stalled", s);
-    if (f.flags & 32u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than %d tracked moving centroids", s, MOR_TR_MAXT);
+    const unsigned f = d.h_err[s];
+    if (!f) continue;
+    any = true;
+    if (f & 1u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than %d clusters", s, d.Kcap);
+    if (f & 2u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: voxel key out of range in method 2", s);
+    if (f & 8u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: z extent of the trimmed cloud exceeds the 64 m the voxel ground variant covers", s);
+    if (f & 16u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than 16384 points within gp_leaf of a voxel centroid", s);
+    if (f & 64u) rc = set_error(MOR_ERR_HIP, "stream %d: look-back of the single-pass split stalled", s);
+    if (f & 32u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than %d tracked moving centroids", s, MOR_TR_MAXT);
+    if (f & 128u) rc = set_error(MOR_ERR_HIP, "stream %d: an in-kernel hand-off timed out", s);
+    d.h_err[s] = 0;
   }
+  if (any) HIP_TRY(hipMemset(d.err, 0, sizeof(unsigned) * d.B));
   return rc;
 }
 
@@ -293,6 +298,9 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = hipMemcpy(d.zorg, z0.data(), B * sizeof(float), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d.zbase, zb.data(), B * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
   }
   ok = ok && dalloc(b, b->d_moving, B * K + B) && dalloc(b, d.otile_cnt, B * T) && dalloc(b, b->d_outptrs, B);
+  for (int i = 0; i < 4; ++i) ok = ok && dalloc(b, d.slot_kc[i], B);
+  ok = ok && dalloc(b, d.err, B) && halloc(b, d.h_err, B) && halloc(b, d.h_log, B * (size_t)MOR_LOG_CAP);
+  if (ok) { ok = hipMemset(d.err, 0, B * sizeof(unsigned)) == hipSuccess; for (int i = 0; i < 4; ++i) ok = ok && hipMemset(d.slot_kc[i], 0, B * sizeof(int2)) == hipSuccess; }
   d.moving = b->d_moving;
   ok = ok && dalloc(b, d.tr, B) && dalloc(b, d.tr_corr, B * MOR_TR_NB * K) && dalloc(b, d.tr_res, B * (MOR_TR_NB + 1) * K) && dalloc(b, d.tr_lastdet, B * K);
   if (ok) ok = hipMemset(d.tr, 0, B * sizeof(MorTrackDev)) == hipSuccess && hipMemset(b->d_moving, 0, B * K + B) == hipSuccess;
@@ -319,7 +327,6 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
   }
   for (int i = 0; i < 3; ++i) if (hipMemset(b->dtemp[i].info, 0, B * sizeof(MorFrameInfo)) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "memset failed"));
-  for (int c = 0; c < 3; ++c) b->dtemp[c].info_prev = b->dtemp[(c + 2) % 3].info;
   b->d = b->dtemp[0];
   b->prev_pose.resize(B);
   if (err) *err = MOR_OK;
@@ -338,8 +345,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     const mor_cloud_view &c = clouds[s];
     if (c.n_points > b->Nmax) return set_error(MOR_ERR_CAPACITY, "stream %d: %llu points > max_points %llu", s, (unsigned long long)c.n_points, (unsigned long long)b->Nmax);
     if (c.n_points && (!c.data || c.point_step < 12 || c.off_x + 4 > c.point_step || c.off_y + 4 > c.point_step || c.off_z + 4 > c.point_step ||
-                       (c.off_intensity != MOR_NO_FIELD && c.off_intensity + 4 > c.point_step) || ((c.off_x | c.off_y | c.off_z | c.point_step) & 3) ||
-                       (c.off_intensity != MOR_NO_FIELD && (c.off_intensity & 3))))
+                       (c.off_intensity != MOR_NO_FIELD && c.off_intensity + 4 > c.point_step)))
       return set_error(MOR_ERR_INVALID, "stream %d: bad blob layout", s);
     maxn = std::max<uint64_t>(maxn, c.n_points);
     if (!c.on_device) max_host_bytes = std::max<size_t>(max_host_bytes, (size_t)c.n_points * c.point_step);
@@ -374,7 +380,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
       d.cg_help_min = (int)std::max<uint32_t>(occ[std::min(B - 1, B - 1 - B * frac / 100 + 1)], 1024u);
     }
   }
-  d.cur = (int)(k % 4); d.prev = (int)((k + 3) % 4); d.has_prev = k > 0; d.out_ptrs = nullptr; d.run_tracker = 0;
+  d.cur = (int)(k % 4); d.prev = (int)((k + 3) % 4); d.has_prev = k > 0; d.out_ptrs = nullptr; d.run_tracker = 0; d.frame_no = (int)k;
   {  // workgroups for the cloud-sized kernels: 1.25 × the largest cloud / cluster set the device last reported
     uint32_t mx = 0;
     for (int s = 0; s < B; ++s) mx = std::max(mx, std::max(d.h_info[s].M, d.h_info[s].C));
@@ -537,6 +543,16 @@ int mor_get_boxes(const mor_batch *b, int s, float *min_K3, float *max_K3) {
     min_K3[3 * k] = lo[k].x; min_K3[3 * k + 1] = lo[k].y; min_K3[3 * k + 2] = lo[k].z;
     max_K3[3 * k] = hi[k].x; max_K3[3 * k + 1] = hi[k].y; max_K3[3 * k + 2] = hi[k].z;
   }
+  return MOR_OK;
+}
+
+int mor_get_frame_log(const mor_batch *b, uint64_t frame, int s, int64_t *out) {
+  if (!b || s < 0 || s >= b->B || !out) return set_error(MOR_ERR_INVALID, "bad batch/stream");
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->pending) wait_all_checked(const_cast<mor_batch *>(b));
+  if (frame >= b->frame || frame + MOR_LOG_CAP < b->frame) return set_error(MOR_ERR_NOT_READY, "frame %llu is not in the log (frames pushed: %llu, log depth %d)", (unsigned long long)frame, (unsigned long long)b->frame, MOR_LOG_CAP);
+  const MorFrameLog &L = b->d.h_log[(size_t)(frame % MOR_LOG_CAP) * b->B + s];
+  out[0] = L.frame; out[1] = L.K; out[2] = L.C; out[3] = L.n_pairs; out[4] = L.cnt_sum; out[5] = L.det_sum; out[6] = L.n_mo_push; out[7] = L.n_mo_filter; out[8] = (int64_t)L.n_out; out[9] = L.flags;
   return MOR_OK;
 }
 

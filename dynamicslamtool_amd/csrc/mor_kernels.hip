@@ -92,16 +92,33 @@ __device__ __forceinline__ void wg_prefix_total(const int *c, int stride, int t,
 __device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Error flags: into the frame's info record (reset at the start of every frame) and into the stream's sticky error word,
+// which the host reports and clears at its next wait — so an error of ANY frame of an asynchronous run is reported, and
+// flags raised after k_decide has copied the info record to the host are too.
+__device__ __forceinline__ void mor_raise(const MorDev &d, int s, unsigned bit) { atomicOr(&d.info[s].flags, bit); atomicOr(&d.err[s], bit); }
+// last kernel of a push / filter: refresh the pinned mirror of the sticky error word (one thread per stream)
+__device__ __forceinline__ void mor_publish_err(const MorDev &d, int s) { d.h_err[s] = __hip_atomic_load(&d.err[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // fromPCLPointCloud2 (:523): named float32 fields of a blob record → (x,y,z,intensity)
+__device__ __forceinline__ float ld_f32_bytes(const char *p) {   // a float32 field at any byte address
+  const unsigned char *u = reinterpret_cast<const unsigned char *>(p);
+  return __uint_as_float((unsigned)u[0] | ((unsigned)u[1] << 8) | ((unsigned)u[2] << 16) | ((unsigned)u[3] << 24));
+}
 __device__ __forceinline__ float4 load_point(const MorStreamArgs &a, uint32_t i) {
-  if (a.step == 16 && a.off_x == 0 && a.off_y == 4 && a.off_z == 8 && a.off_i == 12)
+  if (a.step == 16 && a.off_x == 0 && a.off_y == 4 && a.off_z == 8 && a.off_i == 12 && (reinterpret_cast<uintptr_t>(a.data) & 15) == 0)
     return reinterpret_cast<const float4 *>(a.data)[i];
   const char *r = reinterpret_cast<const char *>(a.data) + (size_t)i * a.step;
   float4 p;
-  p.x = *reinterpret_cast<const float *>(r + a.off_x);
-  p.y = *reinterpret_cast<const float *>(r + a.off_y);
-  p.z = *reinterpret_cast<const float *>(r + a.off_z);
-  p.w = (a.off_i == 0xFFFFFFFFu) ? 0.0f : *reinterpret_cast<const float *>(r + a.off_i);
+  const uint32_t oi = a.off_i == 0xFFFFFFFFu ? 0u : a.off_i;
+  if (((a.step | a.off_x | a.off_y | a.off_z | oi) & 3u) == 0 && (reinterpret_cast<uintptr_t>(a.data) & 3) == 0) {
+    p.x = *reinterpret_cast<const float *>(r + a.off_x);
+    p.y = *reinterpret_cast<const float *>(r + a.off_y);
+    p.z = *reinterpret_cast<const float *>(r + a.off_z);
+    p.w = (a.off_i == 0xFFFFFFFFu) ? 0.0f : *reinterpret_cast<const float *>(r + a.off_i);
+  } else {   // packed records such as the Velodyne driver's 22-byte PointXYZIRT: fromPCLPointCloud2 memcpy's the fields, so do we
+    p.x = ld_f32_bytes(r + a.off_x); p.y = ld_f32_bytes(r + a.off_y); p.z = ld_f32_bytes(r + a.off_z);
+    p.w = (a.off_i == 0xFFFFFFFFu) ? 0.0f : ld_f32_bytes(r + a.off_i);
+  }
   return p;
 }
 
@@ -279,7 +296,7 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
     int k_g = r_g + __popcll(m_g[it] & lanemask_lt());
     if (cls[it] == 2) {
       int cx, cy, cz; bool clamped; grid_cell(d.g, p[it], zorg, zbase, cx, cy, cz, clamped);
-      if (clamped && d.gmode != 0) atomicOr(&d.info[s].flags, 8u);   // z extent beyond the grid: cells would no longer be cliques / voxels
+      if (clamped && d.gmode != 0) mor_raise(d, s, 8u);   // z extent beyond the grid: cells would no longer be cliques / voxels
       d.cloud[so + k_ng] = p[it];
       d.cloud_tidx[so + k_ng] = k_ng + k_g;   // index in the trimmed cloud (both ranks are exclusive counts of earlier kept points)
       d.pkey[so + k_ng] = (cz * d.g.ny + cy) * d.g.nx + cx;
@@ -338,7 +355,7 @@ __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
         const int fp = mP ? __ffsll((long long)mP) - 1 : 64;                                 // nearest tile with a full prefix
         const unsigned long long need = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);          // lanes 0 … fp
         if (mX & need) {                                                                     // a needed tile has not published yet
-          if (++spins > SPLIT_SPIN_LIMIT) { if (lane == 0) atomicOr(&d.info[s].flags, 64u); break; }
+          if (++spins > SPLIT_SPIN_LIMIT) { if (lane == 0) mor_raise(d, s, 64u); break; }
           __builtin_amdgcn_s_sleep(2);
           continue;
         }
@@ -368,7 +385,7 @@ __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
     int k_g = r_g + __popcll(m_g[it] & lanemask_lt());
     if (cls[it] == 2) {
       int cx, cy, cz; bool clamped; grid_cell(d.g, p[it], zorg, zbase, cx, cy, cz, clamped);
-      if (clamped && d.gmode != 0) atomicOr(&d.info[s].flags, 8u);
+      if (clamped && d.gmode != 0) mor_raise(d, s, 8u);
       d.cloud[so + k_ng] = p[it];
       d.cloud_tidx[so + k_ng] = k_ng + k_g;
       d.pkey[so + k_ng] = (cz * d.g.ny + cy) * d.g.nx + cx;
@@ -896,7 +913,7 @@ template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int
   }
   __syncthreads();
   int K = l_misc[0];
-  if (K > d.Kcap) { if (threadIdx.x == 0) atomicOr(&d.info[s].flags, 1u); K = d.Kcap; }
+  if (K > d.Kcap) { if (threadIdx.x == 0) mor_raise(d, s, 1u); K = d.Kcap; }
   __syncthreads();
   // ---- cluster order: size descending, ties by smaller first cloud index; rank by counting
   for (int c = threadIdx.x; c < nocc; c += CG_T) cidr[c] = -1;
@@ -926,7 +943,7 @@ template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int
     if (k < K) { off[k] = carry + basew + inc - v; d.det[ko + k] = 0; }
     carry += tot;
   }
-  if (threadIdx.x == 0) { off[K] = carry; d.info[s].C = carry; d.info[s].K = K; }
+  if (threadIdx.x == 0) { off[K] = carry; d.info[s].C = carry; d.info[s].K = K; d.slot_kc[d.cur][s] = make_int2(K, carry); }
   // ---- work items of the per-cluster reductions: cluster k owns ceil(size/MOR_CHUNK) chunks
   int *coff = d.chunk_off[d.cur] + (size_t)s * (d.Kcap + 1);
   carry = 0;
@@ -1213,7 +1230,7 @@ __device__ __forceinline__ void xform(const float *m, float &x, float &y, float 
   z = ((m[8] * a + m[9] * b) + m[10] * c) + m[11];
 }
 __global__ __launch_bounds__(MOR_BT) void k_xform_prev(MorDev d) {
-  int s = blockIdx.y + d.s0, pv = d.prev, K = d.info_prev[s].K;
+  int s = blockIdx.y + d.s0, pv = d.prev, K = d.slot_kc[d.prev][s].x;
   if (K == 0) return;
   const size_t so = (size_t)s * d.Nmax;
   const int *off = d.cl_off[pv] + (size_t)s * (d.Kcap + 1), *coff = d.chunk_off[pv] + (size_t)s * (d.Kcap + 1);
@@ -1238,7 +1255,7 @@ __global__ __launch_bounds__(MOR_BT) void k_xform_prev(MorDev d) {
 }
 // AABBs of the transformed clusters (volume gate), transformed centroids (:540-541)
 __global__ __launch_bounds__(MOR_BT) void k_xform_fin(MorDev d) {
-  int s = blockIdx.y + d.s0, pv = d.prev, K = d.info_prev[s].K, k = blockIdx.x * MOR_BT + threadIdx.x;
+  int s = blockIdx.y + d.s0, pv = d.prev, K = d.slot_kc[d.prev][s].x, k = blockIdx.x * MOR_BT + threadIdx.x;
   if (k >= K) return;
   const int *coff = d.chunk_off[pv] + (size_t)s * (d.Kcap + 1);
   const Red6 *pt = d.part_back + (size_t)s * d.Wcap;
@@ -1263,7 +1280,7 @@ __global__ __launch_bounds__(MOR_BT) void k_xform_fin(MorDev d) {
 __global__ __launch_bounds__(MOR_BT) void k_nn_centroid(MorDev d) {
   const int dir = blockIdx.z;   // both directions in one launch
   int s = blockIdx.y + d.s0;
-  int Ksrc = dir == 0 ? d.info_prev[s].K : d.info[s].K, Kdst = dir == 0 ? d.info[s].K : d.info_prev[s].K;
+  int Ksrc = dir == 0 ? d.slot_kc[d.prev][s].x : d.info[s].K, Kdst = dir == 0 ? d.info[s].K : d.slot_kc[d.prev][s].x;
   if (blockIdx.x * MOR_BT >= Ksrc) return;
   const float4 *cp = d.xcent + (size_t)s * d.Kcap, *cc = d.centroid[d.cur] + (size_t)s * d.Kcap;
   const float4 *src = dir == 0 ? cp : cc, *dst = dir == 0 ? cc : cp;
@@ -1285,7 +1302,7 @@ __global__ __launch_bounds__(MOR_BT) void k_nn_centroid(MorDev d) {
 }
 // reciprocal test + volumeConstraint (:264-283), correspondences emitted in source-index order
 __global__ __launch_bounds__(MOR_BT) void k_pairs(MorDev d) {
-  int s = blockIdx.x + d.s0, Kp = d.info_prev[s].K, Kc = d.info[s].K;
+  int s = blockIdx.x + d.s0, Kp = d.slot_kc[d.prev][s].x, Kc = d.info[s].K;
   __shared__ int sh[8]; int carry = 0;
   const size_t ko = (size_t)s * d.Kcap;
   for (int b = 0; b < Kp; b += MOR_BT) {
@@ -1378,7 +1395,7 @@ __device__ __forceinline__ void count_push(bool want, int *cnt, int pr) {
 // the own cell closer than √ub), `wl` back = own cell without a matched point, `wl2` = big own cell (wave tier).
 __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
   int s, t0; map_block(d.B, d.tiles_m * 8, s, t0);
-  const int pv = d.prev, Cp = d.info_prev[s].C;
+  const int pv = d.prev, Cp = d.slot_kc[d.prev][s].y;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
   const unsigned long long *tab = d.chash + (size_t)s * d.Hcell; const unsigned hshift = d.info[s].hshift;
@@ -1684,13 +1701,13 @@ __device__ __forceinline__ bool vox_key(const MorDev &d, int s, int pr, float4 p
   return ok;
 }
 __global__ __launch_bounds__(MOR_BT) void k_vox_clear(MorDev d) {
-  int s = blockIdx.y + d.s0, H = vox_table_size(d, d.info_prev[s].C);
+  int s = blockIdx.y + d.s0, H = vox_table_size(d, d.slot_kc[d.prev][s].y);
   unsigned long long *tab = d.vox + (size_t)s * d.Hcap;
   for (int i = blockIdx.x * MOR_BT + threadIdx.x; i < H; i += gridDim.x * MOR_BT) tab[i] = VOX_EMPTY;
 }
 __global__ __launch_bounds__(MOR_BT) void k_vox_insert(MorDev d) {
   int s, t; map_block(d.B, d.tiles, s, t);
-  int pv = d.prev, Cp = d.info_prev[s].C, base = t * MOR_TILE;
+  int pv = d.prev, Cp = d.slot_kc[d.prev][s].y, base = t * MOR_TILE;
   if (base >= Cp) return;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   unsigned long long *tab = d.vox + (size_t)s * d.Hcap; int H = vox_table_size(d, Cp);
@@ -1698,7 +1715,7 @@ __global__ __launch_bounds__(MOR_BT) void k_vox_insert(MorDev d) {
     int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
     if (pr < 0) continue;
     unsigned long long key;
-    if (!vox_key(d, s, pr, d.cl_pts[pv][so + j], key)) { atomicOr(&d.info[s].flags, 2u); continue; }
+    if (!vox_key(d, s, pr, d.cl_pts[pv][so + j], key)) { mor_raise(d, s, 2u); continue; }
     unsigned h = (unsigned)vox_hash(key) & (H - 1);
     for (;;) { unsigned long long old = atomicCAS(&tab[h], VOX_EMPTY, key); if (old == VOX_EMPTY || old == key) break; h = (h + 1) & (H - 1); }
   }
@@ -1708,12 +1725,12 @@ __global__ __launch_bounds__(MOR_BT) void k_vox_probe(MorDev d) {
   int C = d.info[s].C, base = t * MOR_TILE;
   if (base >= C) return;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
-  const unsigned long long *tab = d.vox + (size_t)s * d.Hcap; int H = vox_table_size(d, d.info_prev[s].C);
+  const unsigned long long *tab = d.vox + (size_t)s * d.Hcap; int H = vox_table_size(d, d.slot_kc[d.prev][s].y);
   for (int j = base + threadIdx.x; j < min(base + MOR_TILE, C); j += MOR_BT) {
     int pr = d.pair_of_cur[ko + d.cl_cid[d.cur][so + j]];
     if (pr < 0) continue;
     unsigned long long key;
-    if (!vox_key(d, s, pr, d.cl_pts[d.cur][so + j], key)) { atomicOr(&d.info[s].flags, 2u); continue; }
+    if (!vox_key(d, s, pr, d.cl_pts[d.cur][so + j], key)) { mor_raise(d, s, 2u); continue; }
     unsigned h = (unsigned)vox_hash(key) & (H - 1); bool found = false;
     for (;;) { unsigned long long v = tab[h]; if (v == key) { found = true; break; } if (v == VOX_EMPTY) break; h = (h + 1) & (H - 1); }
     if (!found) atomicAdd(&d.pair_cnt[ko + pr], 1);
@@ -1745,9 +1762,23 @@ __global__ __launch_bounds__(MOR_BT) void k_decide(MorDev d) {
   for (int k = threadIdx.x; k <= K; k += MOR_BT) d.h_cl_off[(size_t)s * (d.Kcap + 1) + k] = offc[k];
   if (threadIdx.x == 0) {
     f.n_pairs = np; f.n_defer = (d.has_prev && d.method == 1) ? (uint32_t)d.wl2_n[s] : 0u; f.pad0 = (d.has_prev && d.method == 1) ? (uint32_t)(d.wl_n[s] + d.wlb_n[s]) : 0u;
-    f.Kprev = d.has_prev ? d.info_prev[s].K : 0; f.Cprev = d.has_prev ? d.info_prev[s].C : 0;   // for the host mirror
+    f.Kprev = d.has_prev ? d.slot_kc[d.prev][s].x : 0; f.Cprev = d.has_prev ? d.slot_kc[d.prev][s].y : 0;   // for the host mirror
     d.info[s].n_pairs = np;
     d.h_info[s] = f;
+  }
+  {  // per-frame summary for the host (tests compare every frame of an asynchronous run through it)
+    __shared__ unsigned l_sum[2];
+    if (threadIdx.x == 0) { l_sum[0] = 0; l_sum[1] = 0; }
+    __syncthreads();
+    unsigned cs = 0, ds = 0;
+    for (int pr = threadIdx.x; pr < np; pr += MOR_BT) cs += (unsigned)d.pair_cnt[ko + pr] * (unsigned)(2 * pr + 1) + (unsigned)d.pair_m[ko + pr];
+    for (int k = threadIdx.x; k < K; k += MOR_BT) ds += d.det[ko + k] ? (unsigned)(k + 1) : 0u;
+    atomicAdd(&l_sum[0], cs); atomicAdd(&l_sum[1], ds);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      MorFrameLog &L = d.h_log[(size_t)(d.frame_no % MOR_LOG_CAP) * d.Btot + s];
+      L.frame = d.frame_no; L.K = K; L.C = (int)f.C; L.n_pairs = np; L.cnt_sum = l_sum[0]; L.det_sum = l_sum[1]; L.flags = (int)d.info[s].flags;
+    }
   }
 }
 
@@ -1805,6 +1836,7 @@ __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
     int pre; wg_prefix_total(d.otile_cnt + (size_t)s * d.tiles_max, 1, 0, nto, sh, pre, n_keep);
     if (t2 == 0 && threadIdx.x == 0) { d.info[s].n_keep = n_keep; d.h_nout[s] = (unsigned long long)n_keep + d.info[s].G; d.h_noff[s] = d.Nmax - n_keep; }
   } else n_keep = d.info[s].n_keep;
+  if (t2 == 0 && threadIdx.x == 0) { d.h_log[(size_t)(d.frame_no % MOR_LOG_CAP) * d.Btot + s].n_out = (unsigned long long)n_keep + d.info[s].G; mor_publish_err(d, s); }
   if (t2 >= d.tiles_m) {
     int t = t2 - d.tiles_m, G = d.info[s].G, nk = n_keep, base = t * MOR_TILE;
     float4 *out = d.out_ptrs[s];
@@ -1977,7 +2009,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_big(MorDev d) {
     __syncthreads();
     const int n = cnt;
     int bin = 0x7fffffff;
-    if (n > G2_CAP) { if (threadIdx.x == 0) atomicOr(&d.info[s].flags, 16u); }
+    if (n > G2_CAP) { if (threadIdx.x == 0) mor_raise(d, s, 16u); }
     else if (n > 3) bin = g2_voxel_bin<G2_CHUNK>(d, so, q, key, n, px, py, pz, acc);
     if (threadIdx.x == 0) d.vbin[so + v] = bin;
     __syncthreads();
@@ -1993,7 +2025,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mode(MorDev d) {
   for (int v = threadIdx.x; v < V; v += MOR_BT) {
     int b = d.vbin[so + v];
     if (b == 0x7fffffff) continue;
-    if (b < -2048 || b >= 2048) { atomicOr(&d.info[s].flags, 8u); continue; }
+    if (b < -2048 || b >= 2048) { mor_raise(d, s, 8u); continue; }
     atomicAdd(&hist[b + 2048], 1);
   }
   __syncthreads();
@@ -2100,7 +2132,7 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
         }
         if (near) continue;
         if (lane == 0) {
-          if (nm >= MOR_TR_MAXT) { t.overflow = 1; atomicOr(&d.info[s].flags, 32u); }
+          if (nm >= MOR_TR_MAXT) { t.overflow = 1; mor_raise(d, s, 32u); }
           else { t.mo_c[nm][0] = pt.x; t.mo_c[nm][1] = pt.y; t.mo_c[nm][2] = pt.z; t.mo_conf[nm] = t.mo_max[nm] = d.static_confidence + 1; t.n_mo = nm + 1; }   // header :91
         }
         __syncthreads();
@@ -2125,8 +2157,9 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
   }
   __syncthreads();
   for (int k = lane; k < K; k += 64) last[k] = d.det[ko + k];
-  if (lane == 0) { t.K_last = K; t.has_cur = 1; }
+  if (lane == 0) { t.K_last = K; t.has_cur = 1; d.h_log[(size_t)(d.frame_no % MOR_LOG_CAP) * d.Btot + s].n_mo_push = t.n_mo; }
   tr_store_state(d.tr[s], t, lane);
+  if (lane == 0) mor_publish_err(d, s);
 }
 // filterCloud's loop over mo_vec (:630-671): nearest current centroid of every tracked one (squared fp32 distance, ties →
 // lowest index), its whole cluster queued for removal before any test, confidence bookkeeping.  Writes the per-cluster
@@ -2185,6 +2218,7 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
   __syncthreads();
   if (fits) for (int k = lane; k < K; k += 64) moving[k] = l_mov[k];
   if (lane == 0) d.moving[(size_t)d.Btot * d.Kcap + s] = total > (unsigned long long)d.info[s].M;   // ExtractIndices: more indices than points ⇒ error, empty output
+  if (lane == 0) d.h_log[(size_t)(d.frame_no % MOR_LOG_CAP) * d.Btot + s].n_mo_filter = t.n_mo;
   tr_store_state(d.tr[s], t, lane);
 }
 

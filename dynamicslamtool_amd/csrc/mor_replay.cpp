@@ -10,6 +10,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <cstdlib>
 #include <sstream>
 
 static bool read_file(const std::string &path, std::vector<uint8_t> &out) {
@@ -22,6 +23,7 @@ static bool read_file(const std::string &path, std::vector<uint8_t> &out) {
 
 int main(int argc, char **argv) {
   if (argc < 5) { std::fprintf(stderr, "usage: %s <config> <poses.txt> <out_dir> <cloud.bin>...\n", argv[0]); return 2; }
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);   // the application's choice: one hardware queue per stage stream of the library's frame pipeline
   ros::NodeHandle nh;
   MovingObjectRemoval mor(nh, argv[1], 4, 3);   // n_bad = 4, n_good = 3 as in external_sync_test.cpp:37
   std::ifstream poses(argv[2]);

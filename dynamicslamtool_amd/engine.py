@@ -19,7 +19,7 @@ EXPORTS = [
     "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_get_stage_counts", "mor_device_alloc", "mor_device_free", "mor_host_alloc", "mor_host_free",
     "mor_device_upload", "mor_device_download", "mor_device_synchronize", "mor_device_count", "mor_get_last_timing",
     "mor_kernel_timing_enable", "mor_kernel_timing_read", "mor_tracker_create", "mor_tracker_destroy", "mor_tracker_push",
-    "mor_tracker_filter", "mor_tracker_get",
+    "mor_tracker_filter", "mor_tracker_get", "mor_get_frame_log",
 ]
 
 
@@ -38,6 +38,9 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libmor_hip.so is not built (python -m dynamicslamtool_amd.build); there is no CPU fallback")
+        # one hardware queue per stage stream of the frame pipeline (csrc/mor_engine.cpp): the application's choice, made
+        # here for the test / bench processes before HIP initialises; a value the caller has set is left alone
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         L = C.CDLL(LIB_PATH)
         vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
         L.mor_sizeof_params.restype = C.c_size_t
@@ -82,6 +85,7 @@ def lib():
         L.mor_tracker_push.argtypes = [vp, i32, vp, vp, i32, vp, vp]
         L.mor_tracker_filter.argtypes = [vp, vp, vp, vp]
         L.mor_tracker_get.argtypes = [vp, vp, vp, vp, i32]
+        L.mor_get_frame_log.argtypes = [vp, u64, i32, vp]
         _LIB = L
     return _LIB
 
@@ -308,6 +312,12 @@ class MorBatch:
         xyz, conf, mx = np.empty((n, 3), np.float32), np.empty(n, np.int32), np.empty(n, np.int32)
         _check(lib().mor_get_tracks(self._h, s, xyz.ctypes.data, conf.ctypes.data, mx.ctypes.data))
         return xyz[:k], conf[:k], mx[:k]
+
+    def frame_log(self, frame, s=0):
+        """Summary of frame `frame` (0-based push index) of stream s: dict of the mor_get_frame_log fields."""
+        a = (C.c_int64 * 10)()
+        _check(lib().mor_get_frame_log(self._h, int(frame), s, a))
+        return dict(zip(("frame", "K", "C", "n_pairs", "cnt_sum", "det_sum", "n_mo_push", "n_mo_filter", "n_out", "flags"), [int(x) for x in a]))
 
     def stage_counts(self, s=0):
         a = (C.c_uint32 * 4)()

@@ -28,7 +28,7 @@ class MovingObjectRemoval {
   // Output (reference :166 / .cpp:613-696): `cloud` and `output` receive the latest cloud minus the
   // tracked moving clusters, ground points appended; PointXYZI layout (x@0,y@4,z@8,intensity@16,
   // point_step 32), width = n, height = 1, is_dense = true, output.header.frame_id = f_id.
-  // Returns true (the reference cannot fail); false only if the GPU call failed.
+  // Returns true (the reference cannot fail); false only if the GPU call failed or the preceding push was refused.
   bool filterCloud(pcl::PCLPointCloud2 &cloud, std::string f_id);
 
   // not in the reference's public interface: the data of its debug bounding-box markers (mark_cluster, .cpp:7-58 —
@@ -49,5 +49,8 @@ class MovingObjectRemoval {
   std::string output_topic_, debug_topic_, marker_topic_, input_pointcloud_topic_, input_odometry_topic_, output_fid_, debug_fid_;
   mor_ctx *ctx_ = nullptr;
   uint64_t pushes_ = 0, last_n_ = 0;
+  bool push_ok_ = false;            // the latest pushRawCloudAndPose reached the device
+  pcl::PCLHeader in_header_;        // header of the latest incoming cloud
   std::vector<float> scratch_;
+  std::vector<uint8_t> rows_;       // de-padded rows of an organised cloud
 };

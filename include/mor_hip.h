@@ -93,7 +93,8 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
 /* Asynchronous mode (off by default).  With it on, mor_push_batch and mor_filter_batch (called with n_out == NULL
  * and no host output) only enqueue their launches — the tracking state lives on the device, so a push + filter
  * pair needs no host round trip — and return at once; mor_batch_wait blocks until everything enqueued has
- * finished and reports the first error of the last push.  Every read-back waits by itself. */
+ * finished and reports the errors any frame has raised since the last report (a sticky error word per stream; reporting
+ * clears it).  Every read-back waits by itself. */
 int mor_batch_set_async(mor_batch *b, int on);
 int mor_batch_wait(mor_batch *b);
 
@@ -135,6 +136,11 @@ int mor_get_cluster_collection(const mor_batch *b, int stream, float *out_xyzi);
 /* diagnostics of the last push of stream i: out[0] = occupied grid cells, out[1] = method-1 queries that
  * needed the wave tier, out[2] = method-1 queries left after the own-cell tier, out[3] = clustered points of the previous frame */
 int mor_get_stage_counts(const mor_batch *b, int stream, uint32_t *out, int n);
+
+/* Per-frame summary log (the last 64 frames): lets a caller of the asynchronous mode inspect EVERY frame after one wait.
+ * out[10] = frame, K, C, |mp|, checksum of the per-pair movement counts, checksum of detection_results, |mo_vec| after
+ * the push, |mo_vec| after filterCloud, points in the filtered cloud, device flags of the frame. */
+int mor_get_frame_log(const mor_batch *b, uint64_t frame, int stream, int64_t *out10);
 
 /* ---- device-memory helpers so callers can keep clouds resident in HBM (bench, replay driver) ---- */
 void *mor_device_alloc(int device, size_t bytes);
