@@ -53,6 +53,8 @@ struct MorFrameInfo {        // per stream, produced on device
 // Temporal logic (T1 + the tracking loop of F1) as device state, one instance per stream.  O(clusters) sequential work
 // per frame: it runs in a one-workgroup-per-stream kernel right behind the geometry so that push + filter need no
 // host round trip in between.  Mirrors csrc/mor_tracker.cpp (the host version behind the mor_tracker_* C ABI).
+#define MOR_MAXP 32        // slabs per stream of the cell graph (k_cg_slab), at most
+#define MOR_CGS_OVF 8192   // overflow entries per slab of its candidate-pair lists (beyond them a pair is settled on the spot)
 #define MOR_CG_EXT 262144  // entries per stream of the helper workgroup's shell-pair list
 #define MOR_CG_OVF 65536   // overflow entries per stream of the cell graph's deferred-pair list
 #define MOR_TR_MAXT 512   // tracked moving centroids per stream (mo_vec)
@@ -113,7 +115,15 @@ struct MorDev {
   float *zorg; int *zbase;   // [B]  z origin of the clustering grid / z base of the voxel lattice
   int *mode_bin;             // [B]  dominant z-bin (:169-178)
   int *pkey;                 // [B][Nmax]  linear cell key per cloud point
-  int *cell_of;              // [B][Nmax]  compact cell id per position of `sorted`
+  int *pcell;                // [B][Nmax]  compact cell id per cloud point
+  int *ppos, *pslot;         // [B][Nmax]  hash path of the grid: position of each cloud point in `sorted`; its slot in the cell table
+  int2 *gh_rowlist;          // [B][Nmax]  hash path: (slot, x) of the cells of every row, unordered inside the row
+  int *gh_key, *gh_val;      // [B][Hcell] hash path: the cell table of streams with more cells than the LDS table holds
+  int grid_mode, gh_force_global;   // grid_mode 0: points radix-sorted by cell key; 1: cells counted in a hash table (k_gridhash); test knob: always the global-memory table
+  int *slab_y, *slab_c, *slab_e;    // [B][MOR_MAXP+1]  slabs of the cell graph: first y-slice, first compact cell id, end of the look-ahead (cells of the next two y-slices)
+  int P, cg_mode, cg_force_global;  // slabs per stream this frame; cg_mode 0: one workgroup per stream (k_cellgraph), 1: slabs (k_cg_slab + k_cg_final); test knob: forests in global memory
+  int *lroot_a, *lroot_b;    // [B][Nmax]  per cell: its local root in its own slab / in the previous slab's look-ahead (compact ids)
+  int *parent2;              // [B][Nmax]  second global forest (odd slabs when they do not fit LDS)
   int *skey, *sidx;          // aliases of the radix buffers holding the cell-sorted (key, cloud index)
   int *ckey;                 // [B][Nmax]  distinct cell keys, ascending (n_occ of them)
   int *cstart;               // [B][Nmax+1]  first sorted position of each occupied cell
@@ -187,7 +197,7 @@ enum MorKernelId {
   MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_SPLIT, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_HASH_CLEAR, MK_CELLBOXES, MK_CELLGRAPH,
   MK_LABEL, MK_RHIST, MK_RSCAN, MK_RSCATTER,
   MK_STATS, MK_STATS_FIN, MK_XFORM_PREV, MK_XFORM_FIN, MK_NN, MK_PAIRS, MK_SCORE_FAST, MK_SCORE_NEAR, MK_SCORE_BLOCK, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
-  MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_G2_CENTROID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_COUNT
+  MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_G2_CENTROID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_GRIDHASH, MK_GRIDFILL, MK_CG_SLAB, MK_CG_FINAL, MK_COUNT
 };
 extern const char *const mor_kernel_names[MK_COUNT];
 

@@ -73,6 +73,7 @@ struct mor_batch {
   MorStreamArgs *h_args_ring = nullptr, *h_args = nullptr;   // pinned ring of MOR_ARGS_RING slots (async pushes), current slot
   hipEvent_t args_ev[MOR_ARGS_RING] = {};
   uint64_t pipe_depth = 3;
+  int env_cg_p = 0, env_help_pct = 15;       // tuning knobs from the environment, read once at creation
   bool async = false, pending = false;   // async: push/filter only enqueue; pending: work enqueued since the last wait
   unsigned char *d_moving = nullptr;
   float4 **h_outptrs = nullptr, **d_outptrs = nullptr;
@@ -162,6 +163,13 @@ static int configure(mor_batch *b) {
   d.use_hash = d.method == 1;
   { size_t hc = 1024; while (hc < 4 * (size_t)d.Nmax) hc <<= 1; d.Hcell = (int)hc; }
   d.t1_budget = getenv("MOR_T1_BUDGET") ? atoi(getenv("MOR_T1_BUDGET")) : 64;
+  // development / test switches (defaults: the fast paths): MOR_GRID=radix sorts the points by cell key instead of counting
+  // cells in a hash table; MOR_CG=wg runs the cell graph as one workgroup per stream instead of over y-slabs;
+  // MOR_GH_GLOBAL / MOR_CG_GLOBAL force the global-memory variants of the hash table / the forests
+  d.grid_mode = (getenv("MOR_GRID") && !strcmp(getenv("MOR_GRID"), "radix")) ? 0 : 1;
+  d.cg_mode = (getenv("MOR_CG") && !strcmp(getenv("MOR_CG"), "wg")) ? 0 : 1;
+  d.gh_force_global = getenv("MOR_GH_GLOBAL") ? 1 : 0; d.cg_force_global = getenv("MOR_CG_GLOBAL") ? 1 : 0;
+  d.P = 1;
   if (d.score_R > 60) return set_error(MOR_ERR_INVALID, "pde_ub %g needs a %d-cell search radius (> 60)", (double)p.pde_ub, d.score_R);
   int bits = 1; while ((1 << bits) < d.Kcap) ++bits;
   d.radix_passes = (bits + 7) / 8;
@@ -238,6 +246,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   b = new mor_batch(); memset(&b->d, 0, sizeof b->d);
   b->p = *p; b->n_bad = n_bad; b->n_good = n_good; b->B = n_streams; b->device = device; b->Nmax = max_points;
   if (getenv("MOR_PIPE_DEPTH")) b->pipe_depth = std::min(3, std::max(1, atoi(getenv("MOR_PIPE_DEPTH"))));
+  if (getenv("MOR_CG_P")) b->env_cg_p = atoi(getenv("MOR_CG_P"));
+  if (getenv("MOR_CG_HELP_PCT")) b->env_help_pct = atoi(getenv("MOR_CG_HELP_PCT"));
   if ((rc = configure(b)) != MOR_OK) return fail(rc);
   if (n_bad > MOR_TR_NB) return fail(set_error(MOR_ERR_INVALID, "n_bad = %d: windows longer than %d frames are not supported", n_bad, MOR_TR_NB));
   for (auto &ev : b->args_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
@@ -255,7 +265,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   MorStreamArgs *dargs = nullptr;
   ok = ok && dalloc(b, dargs, B) && dalloc(b, d.info, B) && dalloc(b, d.tile_cnt, B * T * 2) && dalloc(b, d.tile_off, B * T * 2);
   b->d_args_s[0] = dargs; d.args = dargs;
-  ok = ok && dalloc(b, d.cloud, B * N) && dalloc(b, d.cloud_tidx, B * N) && dalloc(b, d.ground, 2 * B * N) && dalloc(b, d.gp_idx, B * N) && dalloc(b, d.cell_of, B * N);
+  ok = ok && dalloc(b, d.cloud, B * N) && dalloc(b, d.cloud_tidx, B * N) && dalloc(b, d.ground, 2 * B * N) && dalloc(b, d.gp_idx, B * N) && dalloc(b, d.pcell, B * N);
   ok = ok && dalloc(b, d.pkey, B * N) && dalloc(b, d.ckey, B * N) && dalloc(b, d.cstart, B * (N + 1)) && dalloc(b, d.row_start, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, d.cmin, B * N) && dalloc(b, d.cmeta, 2 * B * N);
   ok = ok && dalloc(b, d.sorted, B * N) && dalloc(b, d.parent, B * N) && dalloc(b, d.croot, B * N) && dalloc(b, d.csize, B * N) && dalloc(b, d.compmin, B * N) && dalloc(b, d.cid_of_root, B * N) && dalloc(b, d.pcid, B * N) && dalloc(b, d.ccid, B * N);
   ok = ok && dalloc(b, d.ktile_cnt, B * T) && dalloc(b, d.kcell, B * K) && dalloc(b, d.kroot, B * K) && dalloc(b, d.ksize, B * K) && dalloc(b, d.csz, B * K);
@@ -281,7 +291,9 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.split_desc, B * T);
   ok = ok && dalloc(b, d.crep, B * N);
   ok = ok && dalloc(b, d.cg_ext, B * (size_t)MOR_CG_EXT) && dalloc(b, d.cg_help, B * 4);
-  ok = ok && dalloc(b, d.cg_ovf, B * (size_t)MOR_CG_OVF * 4);
+  ok = ok && dalloc(b, d.cg_ovf, B * std::max((size_t)MOR_CG_OVF * 4, (size_t)MOR_MAXP * MOR_CGS_OVF * 4));
+  ok = ok && dalloc(b, d.ppos, B * N) && dalloc(b, d.pslot, B * N) && dalloc(b, d.gh_rowlist, B * N) && dalloc(b, d.gh_key, B * (size_t)d.Hcell) && dalloc(b, d.gh_val, B * (size_t)d.Hcell);
+  ok = ok && dalloc(b, d.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, d.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, d.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, d.lroot_a, B * N) && dalloc(b, d.lroot_b, B * N) && dalloc(b, d.parent2, B * N);
   ok = ok && dalloc(b, d.xcent, B * K) && dalloc(b, d.xamin, B * K) && dalloc(b, d.xamax, B * K);
   for (int i = 0; i < 4; ++i)
     ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.chunk_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K);
@@ -318,7 +330,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = dalloc(b, dargs1, B) && dalloc(b, o.info, B) && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, 2 * B * N) && dalloc(b, o.gp_idx, B * N);
     ok = ok && dalloc(b, o.sorted, B * N) && dalloc(b, o.ckey, B * N) && dalloc(b, o.cstart, B * (N + 1)) && dalloc(b, o.row_start, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, o.cmeta, 2 * B * N) && dalloc(b, o.crep, B * N);
     ok = ok && dalloc(b, o.pcid, B * N) && dalloc(b, o.ccid, B * N) && dalloc(b, o.cl_idx, B * N) && dalloc(b, o.det, B * K) && dalloc(b, o.zorg, B);
-    ok = ok && dalloc(b, o.cell_of, B * N) && dalloc(b, o.cmin, B * N) && dalloc(b, o.parent, B * N) && dalloc(b, o.csize, B * N) && dalloc(b, o.compmin, B * N) && dalloc(b, o.cid_of_root, B * N);
+    ok = ok && dalloc(b, o.pcell, B * N) && dalloc(b, o.ppos, B * N) && dalloc(b, o.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, o.lroot_a, B * N) && dalloc(b, o.lroot_b, B * N) && dalloc(b, o.cmin, B * N) && dalloc(b, o.parent, B * N) && dalloc(b, o.csize, B * N) && dalloc(b, o.compmin, B * N) && dalloc(b, o.cid_of_root, B * N);
     ok = ok && dalloc(b, o.pair_q, B * K) && dalloc(b, o.pair_m, B * K) && dalloc(b, o.pair_d, B * K) && dalloc(b, o.pair_cnt, B * K) && dalloc(b, o.pair_of_prev, B * K) && dalloc(b, o.pair_of_cur, B * K);
     ok = ok && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B) && dalloc(b, o.wl_n, B) && dalloc(b, o.wlb_n, B) && dalloc(b, o.wl, B * N);
     if (d.use_hash) ok = ok && dalloc(b, o.chash, B * (size_t)d.Hcell);
@@ -370,12 +382,17 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   }
   d.tiles = std::max<int>(1, (int)((maxn + MOR_TILE - 1) / MOR_TILE));
   d.fuse_scans = d.fuse_scans && d.tiles <= 2048;
-  {  // helper workgroups of the cell graph: for the streams with the most cells (they decide the kernel's duration)
+  {  // cell graph: slabs per stream (k_cg_slab) — enough that a slab's cells fit its LDS with room for imbalance, and that
+     // the launch fills the GPU (two 256-thread workgroups per CU); the one-workgroup variant gets its helper threshold
+    uint32_t maxocc = 0;
+    std::vector<uint32_t> occ(B);
+    for (int s = 0; s < B; ++s) { occ[s] = k > 0 ? d.h_info[s].n_occ : 0; maxocc = std::max(maxocc, occ[s]); }
+    const int p_fit = (int)((maxocc * 3ull / 2 + 3275) / 3276), p_par = (512 + B - 1) / B;
+    d.P = b->env_cg_p > 0 ? b->env_cg_p : std::max(p_fit, p_par);
+    d.P = std::max(1, std::min(d.P, std::min(MOR_MAXP, std::max(1, d.g.ny / 2))));
     d.cg_help_min = 0;
-    const int frac = getenv("MOR_CG_HELP_PCT") ? atoi(getenv("MOR_CG_HELP_PCT")) : 15;   // share of the streams, in percent
-    if (k > 0 && B >= 8 && frac > 0) {
-      std::vector<uint32_t> occ(B);
-      for (int s = 0; s < B; ++s) occ[s] = d.h_info[s].n_occ;
+    const int frac = b->env_help_pct;   // share of the streams, in percent
+    if (d.cg_mode == 0 && k > 0 && B >= 8 && frac > 0) {
       std::sort(occ.begin(), occ.end());
       d.cg_help_min = (int)std::max<uint32_t>(occ[std::min(B - 1, B - 1 - B * frac / 100 + 1)], 1024u);
     }
@@ -553,6 +570,36 @@ int mor_get_frame_log(const mor_batch *b, uint64_t frame, int s, int64_t *out) {
   if (frame >= b->frame || frame + MOR_LOG_CAP < b->frame) return set_error(MOR_ERR_NOT_READY, "frame %llu is not in the log (frames pushed: %llu, log depth %d)", (unsigned long long)frame, (unsigned long long)b->frame, MOR_LOG_CAP);
   const MorFrameLog &L = b->d.h_log[(size_t)(frame % MOR_LOG_CAP) * b->B + s];
   out[0] = L.frame; out[1] = L.K; out[2] = L.C; out[3] = L.n_pairs; out[4] = L.cnt_sum; out[5] = L.det_sum; out[6] = L.n_mo_push; out[7] = L.n_mo_filter; out[8] = (int64_t)L.n_out; out[9] = L.flags;
+  return MOR_OK;
+}
+
+// Development read-back of a named intermediate device array of stream s (latest frame): copies min(bytes, size of the stream's
+// slice) bytes and returns the number copied, or a negative error.  Not part of the product interface (exp/, tests).
+long long mor_debug_read(const mor_batch *b, const char *name, int s, void *out, size_t bytes) {
+  if (!b || s < 0 || s >= b->B || !name || !out) return set_error(MOR_ERR_INVALID, "bad arguments");
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->pending) wait_all_checked(const_cast<mor_batch *>(b));
+  const MorDev &d = b->d; const size_t N = d.Nmax, K = d.Kcap, S = MOR_MAXP + 1;
+  struct Ent { const char *n; const void *p; size_t stride; };
+  const Ent tab[] = {
+      {"ckey", d.ckey, N * 4}, {"cstart", d.cstart, (N + 1) * 4}, {"row_start", d.row_start, ((size_t)d.g.nrows + 1) * 4}, {"pcell", d.pcell, N * 4}, {"ppos", d.ppos, N * 4},
+      {"pkey", d.pkey, N * 4}, {"sorted", d.sorted, N * 16}, {"cloud", d.cloud, N * 16}, {"cmin", d.cmin, N * 4}, {"cmeta", d.cmeta, 2 * N * 16}, {"crep", d.crep, N * 16},
+      {"slab_y", d.slab_y, S * 4}, {"slab_c", d.slab_c, S * 4}, {"slab_e", d.slab_e, S * 4}, {"lroot_a", d.lroot_a, N * 4}, {"lroot_b", d.lroot_b, N * 4},
+      {"ccid", d.ccid, N * 4}, {"pcid", d.pcid, N * 4}, {"chash", d.chash, (size_t)d.Hcell * 8}, {"info", d.info, sizeof(MorFrameInfo)},
+      {"xcent", d.xcent, K * 16}, {"xamin", d.xamin, K * 16}, {"xamax", d.xamax, K * 16}, {"cl_pts_prev", d.cl_pts[d.prev], N * 16}, {"cl_pts", d.cl_pts[d.cur], N * 16}};
+  for (const Ent &e : tab) if (!strcmp(e.n, name)) {
+    if (!e.p) return set_error(MOR_ERR_INVALID, "array %s is not allocated in this configuration", name);
+    const size_t n = std::min(bytes, e.stride);
+    HIP_TRY(hipMemcpy(out, (const char *)e.p + (size_t)s * e.stride, n, hipMemcpyDeviceToHost));
+    return (long long)n;
+  }
+  return set_error(MOR_ERR_INVALID, "unknown array %s", name);
+}
+int mor_debug_config(const mor_batch *b, int *out, int n) {   // grid geometry and launch configuration of the latest push
+  if (!b || !out) return MOR_ERR_INVALID;
+  const MorDev &d = b->d;
+  const int v[12] = {d.g.nx, d.g.ny, d.g.nz, d.g.nrows, d.P, d.grid_mode, d.cg_mode, d.Hcell, d.Kcap, d.tiles_m, d.cur, d.prev};
+  for (int i = 0; i < n && i < 12; ++i) out[i] = v[i];
   return MOR_OK;
 }
 

@@ -30,7 +30,7 @@ const char *const mor_kernel_names[MK_COUNT] = {
     "classify", "scan_tiles", "scatter", "split", "heads_count", "heads_scan", "heads_scatter", "hash_clear", "cellboxes", "cellgraph", 
     "label", "rhist", "rscan", "rscatter",
     "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "pairs", "score_fast", "score_near", "score_block", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
-    "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter"};
+    "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridfill", "cg_slab", "cg_final"};
 
 #ifdef MOR_EXP_STAMPS
 #define RS_T(v) const unsigned long long v = wall_clock64()
@@ -151,6 +151,11 @@ __device__ __forceinline__ void grid_cell(const MorGrid &g, float4 p, float zorg
   cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
 }
 
+// Linear cell key, y-major: (cy·nz + cz)·nx + cx.  A (y,z) ROW is nx consecutive keys; a y-SLICE (all rows of one y) is
+// nz·nx consecutive keys, so a contiguous range of the key-sorted cells is a slab of space between two y planes — the
+// unit the cell graph is split over (k_cg_slab).
+__device__ __forceinline__ int grid_row(const MorGrid &g, int cy, int cz) { return cy * g.nz + cz; }
+__device__ __forceinline__ int grid_key(const MorGrid &g, int cx, int cy, int cz) { return grid_row(g, cy, cz) * g.nx + cx; }
 __device__ __forceinline__ int cell_axis(float v, float o, float inv, int n) {
   int c = (int)floorf((v - o) * inv);
   return c < 0 ? 0 : (c >= n ? n - 1 : c);
@@ -161,7 +166,7 @@ __device__ __forceinline__ int cell_axis_unclamped(float v, float o, float inv) 
 #endif
 // occupied cells with x in [x0,x1] of row (cy,cz) have the consecutive compact ids [lo, hi)
 __device__ __forceinline__ void row_cells(const MorGrid &g, const int *ckey, const int *rs, int x0, int x1, int cy, int cz, int &lo, int &hi) {
-  const int r = cz * g.ny + cy, e = rs[r + 1], base = r * g.nx;
+  const int r = grid_row(g, cy, cz), e = rs[r + 1], base = r * g.nx;
   lo = rs[r];
   if (e - lo > ROW_BATCH) {   // long row (a wall along x): binary search
     int a = lo, b = e, k0 = base + x0;
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
       if (clamped && d.gmode != 0) mor_raise(d, s, 8u);   // z extent beyond the grid: cells would no longer be cliques / voxels
       d.cloud[so + k_ng] = p[it];
       d.cloud_tidx[so + k_ng] = k_ng + k_g;   // index in the trimmed cloud (both ranks are exclusive counts of earlier kept points)
-      d.pkey[so + k_ng] = (cz * d.g.ny + cy) * d.g.nx + cx;
+      d.pkey[so + k_ng] = grid_key(d.g, cx, cy, cz);
     } else if (cls[it] == 1) {
       d.ground[2 * so + d.Nmax + k_g] = p[it];   // final place in filterCloud's output: [kept cloud, right-aligned to slot Nmax | ground from slot Nmax]
       d.gp_idx[so + k_g] = k_ng + k_g;
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
       if (clamped && d.gmode != 0) mor_raise(d, s, 8u);
       d.cloud[so + k_ng] = p[it];
       d.cloud_tidx[so + k_ng] = k_ng + k_g;
-      d.pkey[so + k_ng] = (cz * d.g.ny + cy) * d.g.nx + cx;
+      d.pkey[so + k_ng] = grid_key(d.g, cx, cy, cz);
     } else if (cls[it] == 1) {
       d.ground[2 * so + d.Nmax + k_g] = p[it];
       d.gp_idx[so + k_g] = k_ng + k_g;
@@ -447,7 +452,7 @@ __device__ __forceinline__ int hash_find(const unsigned long long *tab, unsigned
 // linear key of cell (cx,cy,cz), −1 outside the grid
 __device__ __forceinline__ int cell_key(const MorGrid &g, int cx, int cy, int cz) {
   if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cy >= (unsigned)g.ny || (unsigned)cz >= (unsigned)g.nz) return -1;
-  return (cz * g.ny + cy) * g.nx + cx;
+  return grid_key(g, cx, cy, cz);
 }
 __global__ __launch_bounds__(MOR_BT) void k_hash_clear(MorDev d) {
   const int s = blockIdx.y + d.s0, n = 1 << (32 - d.info[s].hshift);
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
         int i = sidx[p];
         if (head) {
           const int kc = skey[p];
-          d.ckey[so + c] = kc; cstart[c] = p; d.cmin[so + c] = i;   // stable sort ⇒ first of the cell = smallest cloud index
+          d.ckey[so + c] = kc; cstart[c] = p;
           d.parent[so + c] = c; d.csize[so + c] = 0; d.compmin[so + c] = 0x7fffffff; d.cid_of_root[so + c] = -1;
           // dense (y,z) row table: rs[r] = first cell with key ≥ r·nx.  The head of cell c owns the rows after its
           // predecessor's row up to its own (keys ascend), so the table is written without any search
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
           const int rl = skey[p] / d.g.nx;
           const int g = atomicAdd(&l_ng, 1); if (g < 64) { l_gap[3 * g] = rl; l_gap[3 * g + 1] = d.g.nrows; l_gap[3 * g + 2] = c + 1; } else for (int r = rl + 1; r <= d.g.nrows; ++r) rs[r] = c + 1;
         }
-        d.cell_of[so + p] = c;   // per sorted position (coalesced; k_label reads it the same way)
+        d.pcell[so + i] = c;     // compact cell id per cloud point (k_label)
         float4 q = d.cloud[so + i]; q.w = __int_as_float(i);
         d.sorted[so + p] = q;
       }
@@ -520,6 +525,188 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
     __syncthreads();
     if (threadIdx.x == 0) l_ng = 0;
     __syncthreads();
+  }
+}
+// ------------------------------------------------------------------------------------ grid, hash path: cells by counting, not by sorting points
+// A stream's non-ground cloud has FEW occupied cells (a few thousand) but a heavy-tailed number of points per cell
+// (a wall two metres from the sensor puts thousands of returns into one 28-cm cell; M ranges 5 k … 60 k over the
+// streams of one batch).  Sorting all points by key moves every point three times; what the later stages need is only:
+// the distinct keys in ascending order (compact cell ids), the points grouped by cell (any order inside a cell — every
+// consumer tests existence, takes a min / max or counts), and the (y,z) row table.  So one workgroup per stream
+//   1. counts the points of every cell in an LDS hash table (open addressing; LDS atomics digest the hot cells),
+//   2. orders the distinct cells through the row table: a cell's compact id is its row's first id plus the number of
+//      cells of the row with a smaller x (rows are short) — no sort,
+//   3. turns the counts into ranges of `sorted` and hands every point its position (LDS cursor per cell),
+// and a wide kernel (k_gridfill) moves the points.  The table doubles as the cell hash of the method-1 scoring tiers.
+// Streams with more cells than the LDS table holds run the same code on a table in global memory.
+#define GH_T 1024
+#define GH_H 16384       // slots of the LDS table (cells ≤ 3/4 of it)
+#define GH_ROWS 7167     // (y,z) rows the LDS copy of the row table holds
+template <int NT> __device__ __forceinline__ int block_excl_scan_n(int v, int *sh, int *total) {   // sh: ≥ NT/64 ints
+  const int inc = wave_incl_scan(v);
+  __syncthreads();
+  if (lane_id() == 63) sh[wave_id()] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) { const int x = sh[w]; if (w < wave_id()) base += x; tot += x; }
+  *total = tot;
+  return base + inc - v;
+}
+template <bool L> __device__ __forceinline__ int gh_ld(const int *p) {
+  return L ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool L> __device__ __forceinline__ void gh_st(int *p, int v) {
+  if (L) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// in-place exclusive scan of a[0, n) by the whole workgroup (contiguous chunk per thread); returns the total
+template <bool L> __device__ __forceinline__ int gh_scan(int *a, int n, int *sh) {
+  const int chunk = (n + GH_T - 1) / GH_T, b = min((int)threadIdx.x * chunk, n), e = min(b + chunk, n);
+  int sum = 0;
+  for (int i = b; i < e; ++i) sum += gh_ld<L>(a + i);
+  int total; int run = block_excl_scan_n<GH_T>(sum, sh, &total);
+  for (int i = b; i < e; ++i) { const int v = gh_ld<L>(a + i); gh_st<L>(a + i, run); run += v; }
+  __syncthreads();
+  return total;
+}
+// Slab boundaries of the cell graph (k_cg_slab): P slabs of whole y-slices with about equal cell counts, each at least
+// two slices thick so that the two-slice look-ahead of a slab stays inside its successor.  rows = exclusive row table
+// (rows[r] = first compact id of row r, rows[nrows] = n_occ); threads 0 … P of the calling workgroup take part; sh: ≥ 40 ints.
+template <bool L> __device__ __forceinline__ void slab_bounds(const MorDev &d, int s, const int *rows, int nocc, int *sh) {
+  const int P = d.P, ny = d.g.ny, nz = d.g.nz, j = threadIdx.x;
+  if (j <= P) {
+    int y = j == 0 ? 0 : ny;
+    if (j > 0 && j < P) {   // smallest y whose first cell id reaches the j-th share of the cells
+      const int target = (int)((long long)nocc * j / P);
+      int a = 0, b = ny;
+      while (a < b) { const int m = (a + b) >> 1; if (gh_ld<L>(rows + m * nz) >= target) b = m; else a = m + 1; }
+      y = a;
+    }
+    sh[j] = y;
+  }
+  __syncthreads();
+  if (j == 0) for (int k = 1; k < P; ++k) sh[k] = min(max(sh[k], sh[k - 1] + 2), ny);
+  __syncthreads();
+  if (j <= P) {
+    int *sy = d.slab_y + (size_t)s * (MOR_MAXP + 1), *sc = d.slab_c + (size_t)s * (MOR_MAXP + 1), *se = d.slab_e + (size_t)s * (MOR_MAXP + 1);
+    sy[j] = sh[j]; sc[j] = gh_ld<L>(rows + sh[j] * nz);
+    se[j] = j < P ? gh_ld<L>(rows + min(sh[j + 1] + 2, ny) * nz) : nocc;   // end of slab j's look-ahead (cells of the next two y-slices)
+  }
+  __syncthreads();
+}
+// TL / RL: hash table / row table in LDS (else global memory).  Returns false when the table overflowed (nothing
+// published yet: the caller re-runs with a bigger table).
+template <bool TL, bool RL> __device__ __forceinline__ bool gh_run(const MorDev &d, int s, int M, int *tkey, int *tval, int H, int cell_cap, int *rows, int *l_misc, int *l_sh) {
+  const size_t so = (size_t)s * d.Nmax;
+  const int *pkey = d.pkey + so; int *pslot = d.pslot + so, *ppos = d.ppos + so, *pcell = d.pcell + so;
+  int *cstart = d.cstart + (size_t)s * (d.Nmax + 1), *ckey = d.ckey + so;
+  int2 *rowlist = d.gh_rowlist + so;
+  const int nrows = d.g.nrows, nx = d.g.nx, tid = threadIdx.x;
+  int hbits = 0; while ((1 << hbits) < H) ++hbits;
+  const unsigned hshift = 32 - hbits, mask = (unsigned)H - 1u;
+  for (int i = tid; i < H; i += GH_T) { gh_st<TL>(tkey + i, 0); gh_st<TL>(tval + i, 0); }
+  if (tid == 0) { l_misc[0] = 0; l_misc[1] = 0; }
+  __syncthreads();
+  // ---- sweep 1: every point finds (or claims) the slot of its cell and counts itself; slot kept for sweep 2
+  for (int i0 = 0; i0 < M; i0 += 4 * GH_T) {
+    int key[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + u * GH_T + tid; key[u] = i < M ? pkey[i] : -1; }
+    if (gh_ld<true>(&l_misc[1])) break;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (key[u] < 0) continue;
+      const int want = key[u] + 1; unsigned h = hash_slot(key[u], hshift); bool ok = false;
+      for (int probes = 0; probes < H; ++probes) {
+        int k = gh_ld<TL>(tkey + h);
+        if (k == 0) {
+          k = atomicCAS(tkey + h, 0, want);
+          if (k == 0) { k = want; if (atomicAdd(&l_misc[0], 1) >= cell_cap) gh_st<true>(&l_misc[1], 1); }
+        }
+        if (k == want) { ok = true; break; }
+        h = (h + 1) & mask;
+      }
+      if (ok) { atomicAdd(tval + h, 1); pslot[i0 + u * GH_T + tid] = (int)h; } else gh_st<true>(&l_misc[1], 1);
+    }
+  }
+  __syncthreads();
+  if (l_misc[1]) { __syncthreads(); return false; }
+  const int nocc = l_misc[0];
+  // ---- cells per row → row table
+  for (int r = tid; r <= nrows; r += GH_T) gh_st<RL>(rows + r, 0);
+  __syncthreads();
+  for (int sl = tid; sl < H; sl += GH_T) { const int k = gh_ld<TL>(tkey + sl); if (k) atomicAdd(rows + (k - 1) / nx, 1); }
+  __syncthreads();
+  gh_scan<RL>(rows, nrows, l_sh);
+  if (tid == 0) gh_st<RL>(rows + nrows, nocc);
+  __syncthreads();
+  if (RL) { int *grs = d.row_start + (size_t)s * (nrows + 1); for (int r = tid; r <= nrows; r += GH_T) grs[r] = rows[r]; }
+  slab_bounds<RL>(d, s, rows, nocc, l_sh);
+  // ---- the cells of every row, listed (unordered) behind the row's first id; rows[r] becomes the END of row r
+  for (int sl = tid; sl < H; sl += GH_T) {
+    const int k = gh_ld<TL>(tkey + sl);
+    if (k) { const int key = k - 1, r = key / nx; const int pos = atomicAdd(rows + r, 1); rowlist[pos] = make_int2(sl, key - r * nx); }
+  }
+  __syncthreads();
+  // ---- compact id = first id of the row + cells of the row with a smaller x; counts in id order; slot → id
+  unsigned long long *chash = d.use_hash ? d.chash + (size_t)s * d.Hcell : nullptr;
+  for (int sl = tid; sl < H; sl += GH_T) {
+    const int k = gh_ld<TL>(tkey + sl);
+    if (k) {
+      const int key = k - 1, r = key / nx, x = key - r * nx;
+      const int b = r ? gh_ld<RL>(rows + r - 1) : 0, e = gh_ld<RL>(rows + r);
+      int c = b;
+      for (int q = b; q < e; ++q) c += rowlist[q].y < x;
+      ckey[c] = key; cstart[c] = gh_ld<TL>(tval + sl);
+      gh_st<TL>(tkey + sl, c + 1);
+      if (chash) chash[sl] = ((unsigned long long)(unsigned)k << 32) | (unsigned)c;
+    } else if (chash) chash[sl] = 0ull;
+  }
+  __syncthreads();
+  gh_scan<false>(cstart, nocc, l_sh);   // counts → first position of every cell
+  if (tid == 0) { cstart[nocc] = M; d.info[s].n_occ = nocc; d.info[s].hshift = hshift; }
+  __syncthreads();
+  for (int sl = tid; sl < H; sl += GH_T) { const int c1 = gh_ld<TL>(tkey + sl); if (c1) gh_st<TL>(tval + sl, gh_ld<false>(cstart + c1 - 1)); }
+  __syncthreads();
+  // ---- sweep 2: position of every point inside its cell's range
+  for (int i0 = 0; i0 < M; i0 += 4 * GH_T) {
+    int sl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + u * GH_T + tid; sl[u] = i < M ? pslot[i] : -1; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (sl[u] < 0) continue;
+      const int i = i0 + u * GH_T + tid;
+      pcell[i] = gh_ld<TL>(tkey + sl[u]) - 1;
+      ppos[i] = atomicAdd(tval + sl[u], 1);
+    }
+  }
+  return true;
+}
+__global__ __launch_bounds__(GH_T) void k_gridhash(MorDev d) {
+  const int s = blockIdx.x + d.s0, M = d.info[s].M;
+  __shared__ int l_tab[2 * GH_H], l_rows[GH_ROWS + 1], l_misc[4], l_sh[48];
+  const bool rows_lds = d.g.nrows <= GH_ROWS;
+  int *grows = d.row_start + (size_t)s * (d.g.nrows + 1);
+  const int Hl = min(GH_H, d.Hcell);
+  bool done = false;
+  if (!d.gh_force_global) {
+    if (rows_lds) done = gh_run<true, true>(d, s, M, l_tab, l_tab + Hl, Hl, Hl / 4 * 3, l_rows, l_misc, l_sh);
+    else done = gh_run<true, false>(d, s, M, l_tab, l_tab + Hl, Hl, Hl / 4 * 3, grows, l_misc, l_sh);
+  }
+  if (!done) {   // more cells than the LDS table holds: table in global memory, sized for the cloud (cells ≤ M ≤ H/2)
+    int H = 1024; while (H < 2 * M && H < d.Hcell) H <<= 1;
+    gh_run<false, false>(d, s, M, d.gh_key + (size_t)s * d.Hcell, d.gh_val + (size_t)s * d.Hcell, H, H, grows, l_misc, l_sh);
+  }
+}
+// the points into cell order: sorted[position] = (x, y, z, bits(cloud index))
+__global__ __launch_bounds__(MOR_BT) void k_gridfill(MorDev d) {
+  int s, t0; map_block(d.B, d.tiles_m, s, t0);
+  const int M = d.info[s].M;
+  const size_t so = (size_t)s * d.Nmax;
+  for (int i = t0 * MOR_BT + threadIdx.x; i < M; i += d.tiles_m * MOR_BT) {
+    float4 q = d.cloud[so + i]; q.w = __int_as_float(i);
+    d.sorted[so + d.ppos[so + i]] = q;
   }
 }
 // ------------------------------------------------------------------------------------ C1: Euclidean clustering = connected components over cells,
@@ -612,15 +799,18 @@ __device__ __forceinline__ bool pair_hit_wave(const float4 *sp, int a0, int na, 
   }
   return false;
 }
-__device__ __forceinline__ void wave_box(const float4 *sp, int b, int e, int lane, float4 &lo, float4 &hi) {
+__device__ __forceinline__ void wave_box(const float4 *sp, int b, int e, int lane, float4 &lo, float4 &hi, int &mi) {
+  mi = 0x7fffffff;
   float lx = FLT_MAX, ly = FLT_MAX, lz = FLT_MAX, hx = -FLT_MAX, hy = -FLT_MAX, hz = -FLT_MAX;
   for (int k = b + lane; k < e; k += 256) {   // four independent loads per lane and step
     const float4 p0 = sp[k], p1 = sp[min(k + 64, e - 1)], p2 = sp[min(k + 128, e - 1)], p3 = sp[min(k + 192, e - 1)];
     lx = fminf(fminf(lx, p0.x), fminf(p1.x, fminf(p2.x, p3.x))); ly = fminf(fminf(ly, p0.y), fminf(p1.y, fminf(p2.y, p3.y))); lz = fminf(fminf(lz, p0.z), fminf(p1.z, fminf(p2.z, p3.z)));
     hx = fmaxf(fmaxf(hx, p0.x), fmaxf(p1.x, fmaxf(p2.x, p3.x))); hy = fmaxf(fmaxf(hy, p0.y), fmaxf(p1.y, fmaxf(p2.y, p3.y))); hz = fmaxf(fmaxf(hz, p0.z), fmaxf(p1.z, fmaxf(p2.z, p3.z)));
+    mi = min(min(mi, __float_as_int(p0.w)), min(__float_as_int(p1.w), min(__float_as_int(p2.w), __float_as_int(p3.w))));
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
+    mi = min(mi, __shfl_xor(mi, o, 64));
     lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
     hx = fmaxf(hx, __shfl_xor(hx, o, 64)); hy = fmaxf(hy, __shfl_xor(hy, o, 64)); hz = fmaxf(hz, __shfl_xor(hz, o, 64));
   }
@@ -700,14 +890,14 @@ template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const
   // ---- A: candidate pairs (unless the stream's helper workgroup has listed them)
   if (!listed)
   for (int a = threadIdx.x; a < nocc; a += CG_T) {
-    const int ka = key[a], rowa = ka / d.g.nx, x = ka - rowa * d.g.nx, y = rowa % d.g.ny, z = rowa / d.g.ny;
+    const int ka = key[a], rowa = ka / d.g.nx, x = ka - rowa * d.g.nx, z = rowa % d.g.nz, y = rowa / d.g.nz;
     const int ra = cg_find<LDS>(par, a);
     for (int dz = 0; dz <= RING; ++dz) {
       if (z + dz >= d.g.nz) break;
       for (int dy = (dz == 0 ? 0 : -RING); dy <= RING; ++dy) {
         if ((unsigned)(y + dy) >= (unsigned)d.g.ny) continue;
         const bool edge_row = dz == RING || abs(dy) == RING;   // every cell of this row lies on the ring
-        const int rr = (z + dz) * d.g.ny + (y + dy), rlo = rows[rr], rn = rows[rr + 1] - rlo;
+        const int rr = grid_row(d.g, y + dy, z + dz), rlo = rows[rr], rn = rows[rr + 1] - rlo;
         if (rn == 0) continue;
         // ≤ 2·RING+1 ≤ 5 cells of the row lie within RING of x: a plain walk over the row's real cell count (a long row
         // is entered at x − RING by an 8-ary search); a cell whose parent is a's root is skipped on the first load
@@ -792,7 +982,8 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
   const size_t so = (size_t)s * d.Nmax;
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
-  if (d.use_hash) {   // cell hash: (key+1, compact id); the table was cleared by k_heads_scatter
+  if (bx == 0 && d.grid_mode == 0) { __shared__ int l_sb[48]; slab_bounds<false>(d, s, d.row_start + (size_t)s * (d.g.nrows + 1), nocc, l_sb); }   // (the hash path computes them in k_gridhash)
+  if (d.use_hash && d.grid_mode == 0) {   // cell hash: (key+1, compact id); the table was cleared by k_heads_scatter
     unsigned long long *tab = d.chash + (size_t)s * d.Hcell; const int *ckey = d.ckey + so;
     const unsigned hshift = d.info[s].hshift, hmask = (1u << (32 - hshift)) - 1u;
     for (int c = bx * MOR_BT + threadIdx.x; c < nocc; c += MOR_BOX_G * MOR_BT) {
@@ -812,6 +1003,7 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float lx = fminf(p[u].x, p2[u].x), ly = fminf(p[u].y, p2[u].y), lz = fminf(p[u].z, p2[u].z), hx = fmaxf(p[u].x, p2[u].x), hy = fmaxf(p[u].y, p2[u].y), hz = fmaxf(p[u].z, p2[u].z);
+      int mi = min(__float_as_int(p[u].w), __float_as_int(p2[u].w));   // smallest cloud index of the cell (identity / order of its component)
       // cells of 33 … 512 points stay with their 16 lanes: 64 more points per step, four independent loads per lane
       // (handing each of them to the whole wave, one after the other, cost half of this kernel's time)
       const int nu = e[u] - b[u];
@@ -820,23 +1012,25 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
           const float4 q0 = sp[k], q1 = sp[min(k + 16, e[u] - 1)], q2 = sp[min(k + 32, e[u] - 1)], q3 = sp[min(k + 48, e[u] - 1)];
           lx = fminf(fminf(lx, q0.x), fminf(q1.x, fminf(q2.x, q3.x))); ly = fminf(fminf(ly, q0.y), fminf(q1.y, fminf(q2.y, q3.y))); lz = fminf(fminf(lz, q0.z), fminf(q1.z, fminf(q2.z, q3.z)));
           hx = fmaxf(fmaxf(hx, q0.x), fmaxf(q1.x, fmaxf(q2.x, q3.x))); hy = fmaxf(fmaxf(hy, q0.y), fmaxf(q1.y, fmaxf(q2.y, q3.y))); hz = fmaxf(fmaxf(hz, q0.z), fmaxf(q1.z, fmaxf(q2.z, q3.z)));
+          mi = min(min(mi, __float_as_int(q0.w)), min(__float_as_int(q1.w), min(__float_as_int(q2.w), __float_as_int(q3.w))));
         }
       }
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) {
+        mi = min(mi, __shfl_xor(mi, o, 64));
         lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
         hx = fmaxf(hx, __shfl_xor(hx, o, 64)); hy = fmaxf(hy, __shfl_xor(hy, o, 64)); hz = fmaxf(hz, __shfl_xor(hz, o, 64));
       }
       const bool bigc = nu > 512 && c0 + u < nocc;
       if (sub == 0 && c0 + u < nocc) d.crep[so + c0 + u] = p[u];   // the cell's first point: sample for the quick edge test of k_cellgraph
-      if (sub == 0 && c0 + u < nocc && !bigc) { d.cmeta[2 * (so + c0 + u)] = make_float4(lx, ly, lz, 0.f); d.cmeta[2 * (so + c0 + u) + 1] = make_float4(hx, hy, hz, 0.f); }
+      if (sub == 0 && c0 + u < nocc && !bigc) { d.cmeta[2 * (so + c0 + u)] = make_float4(lx, ly, lz, 0.f); d.cmeta[2 * (so + c0 + u) + 1] = make_float4(hx, hy, hz, 0.f); d.cmin[so + c0 + u] = mi; }
       // cells of more than 512 points (a dense surface next to the sensor): the whole wave, 256 points per step
       unsigned long long m = __ballot(bigc && sub == 0);
       while (m) {
         const int l = __ffsll((long long)m) - 1; m &= m - 1;
         const int cb = __shfl(b[u], l, 64), ce = __shfl(e[u], l, 64), cc = __shfl(c0 + u, l, 64);
-        float4 lo, hi; wave_box(sp, cb, ce, lane_id(), lo, hi);
-        if (lane_id() == 0) { d.cmeta[2 * (so + cc)] = lo; d.cmeta[2 * (so + cc) + 1] = hi; }
+        float4 lo, hi; int wmi; wave_box(sp, cb, ce, lane_id(), lo, hi, wmi);
+        if (lane_id() == 0) { d.cmeta[2 * (so + cc)] = lo; d.cmeta[2 * (so + cc) + 1] = hi; d.cmin[so + cc] = wmi; }
       }
     }
   }
@@ -981,13 +1175,13 @@ __device__ __forceinline__ void cg_helper(const MorDev &d, int s, int nocc, int 
   int *ext = d.cg_ext + (size_t)s * MOR_CG_EXT;
   constexpr int RING = 2;
   for (int a = threadIdx.x; a < nocc; a += CG_T) {
-    const int ka = key[a], rowa = ka / d.g.nx, x = ka - rowa * d.g.nx, y = rowa % d.g.ny, z = rowa / d.g.ny;
+    const int ka = key[a], rowa = ka / d.g.nx, x = ka - rowa * d.g.nx, z = rowa % d.g.nz, y = rowa / d.g.nz;
     for (int dz = 0; dz <= RING; ++dz) {
       if (z + dz >= d.g.nz) break;
       for (int dy = (dz == 0 ? 0 : -RING); dy <= RING; ++dy) {
         if ((unsigned)(y + dy) >= (unsigned)d.g.ny) continue;
         const bool edge_row = dz == RING || abs(dy) == RING;
-        const int rr = (z + dz) * d.g.ny + (y + dy), rlo = rows[rr], rn = rows[rr + 1] - rlo;
+        const int rr = grid_row(d.g, y + dy, z + dz), rlo = rows[rr], rn = rows[rr + 1] - rlo;
         if (rn == 0) continue;
         const int rowbase = rr * d.g.nx + x;
         int lo = rlo; const int hi = rlo + rn;
@@ -1038,19 +1232,258 @@ __global__ __launch_bounds__(CG_T) void k_cellgraph(MorDev d) {
   }
 }
 
-// per sorted slot: cluster id of its point → pcid[cloud index] and sorted.w
+// ------------------------------------------------------------------------------------ C1, spread over the GPU: the cell graph over y-SLABS
+// One 1024-thread workgroup per stream (k_cellgraph above) keeps 64 of the 256 CUs busy and ends with its slowest stream.
+// Cell keys are y-major, so a contiguous range of compact ids is the slab of space between two y planes: every stream's
+// cells are cut into P slabs of about equal cell count (k_gridhash / k_cellboxes: slab_bounds), and one small workgroup
+// per (stream, slab) runs both hook passes for the cells it OWNS over the forward half of the neighbourhood
+// (dy ≥ 0), i.e. against its own cells and the cells of the next two y-slices (its look-ahead, owned by the next slab).
+// Its union-find forest lives in its own LDS and covers own + look-ahead cells only; what it publishes is, per cell of
+// that range, the LOCAL root.  A forest is equivalent to the edge set {(c, root(c))}, so k_cg_final re-unites
+// (c, root_own(c)) and (c, root_lookahead-of-the-previous-slab(c)) in one forest per stream and gets exactly the
+// components of the full edge set — every edge was found by the slab owning its lower-y cell.
+#define CGS_T 256
+#ifndef CGS_CAP
+#define CGS_CAP 4096      // local cells (own + look-ahead) held in LDS
+#endif
+#define CGS_ROWCAP 4096   // local (y,z) rows held in LDS
+static_assert(CGS_CAP <= 16384, "pair lists pack two local cell ids into 28 bits");
+template <bool LDS> __device__ __forceinline__ void cgs_list_put(int *ovf, int *l_list, int slot, int region, int a, int b) {
+  constexpr int W = LDS ? 1 : 2, NL = 2 * CG_LIST / W;
+  if (region == 0 && slot < NL) { if (LDS) l_list[slot] = (a << 14) | b; else { l_list[2 * slot] = a; l_list[2 * slot + 1] = b; } return; }
+  int *ov = ovf + (size_t)region * MOR_CGS_OVF * 2 + (size_t)(region == 0 ? slot - NL : slot) * W;
+  if (LDS) cg_st<false>(ov, (a << 14) | b); else { cg_st<false>(ov, a); cg_st<false>(ov + 1, b); }
+}
+template <bool LDS> __device__ __forceinline__ void cgs_list_get(const int *ovf, const int *l_list, int slot, int region, int &a, int &b) {
+  constexpr int W = LDS ? 1 : 2, NL = 2 * CG_LIST / W;
+  if (region == 0 && slot < NL) { if (LDS) { const int c = l_list[slot]; a = c >> 14; b = c & 16383; } else { a = l_list[2 * slot]; b = l_list[2 * slot + 1]; } return; }
+  const int *ov = ovf + (size_t)region * MOR_CGS_OVF * 2 + (size_t)(region == 0 ? slot - NL : slot) * W;
+  if (LDS) { const int c = cg_ld<false>(ov); a = c >> 14; b = c & 16383; } else { a = cg_ld<false>(ov); b = cg_ld<false>(ov + 1); }
+}
+template <bool LDS> __device__ __forceinline__ int cgs_list_cap(int region) { return (region == 0 ? 2 * CG_LIST / (LDS ? 1 : 2) : 0) + MOR_CGS_OVF * (LDS ? 2 : 1); }
+// One hook pass of a slab.  Local ids: own cells [0, n_own), look-ahead [n_own, n_loc).  key[] = keys of the local cells,
+// rows[] = row table of the slab's rows (row r0 first) holding LOCAL ids minus `rsub` (0 for the LDS copy, the slab's first
+// compact id when the global table is read in place); soc = first slot of the slab's cells in the per-cell global arrays.
+template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(const MorDev &d, size_t soc, int n_own, const int *key, const int *start, const int *rows, int rsub, int r0, int nlrows,
+                                                                            int *par, const float4 *sp, int *ovf, int *l_list, int *l_nlist, int *l_n2) {
+  const float r2 = d.r2;
+  // ---- A: candidate pairs (own cell a, forward neighbour b in another component), LDS only
+  for (int a = threadIdx.x; a < n_own; a += CGS_T) {
+    const int ka = key[a], rowa = ka / d.g.nx, x = ka - rowa * d.g.nx, z = rowa % d.g.nz, y = rowa / d.g.nz;
+    const int ra = cg_find<LDS>(par, a);
+    for (int dy = 0; dy <= RING; ++dy) {
+      if (y + dy >= d.g.ny) break;
+      for (int dz = (dy == 0 ? 0 : -RING); dz <= RING; ++dz) {
+        if ((unsigned)(z + dz) >= (unsigned)d.g.nz) continue;
+        const bool edge_row = dy == RING || abs(dz) == RING;   // every cell of this row lies on the ring
+        const int rr = grid_row(d.g, y + dy, z + dz), rl = rr - r0;
+        if (rl < 0 || rl >= nlrows) continue;                  // (cannot happen: the slab's rows cover y … y+2)
+        const int rlo = rows[rl] - rsub, rn = rows[rl + 1] - rsub - rlo;
+        if (rn == 0) continue;
+        const int rowbase = rr * d.g.nx + x;
+        int lo = rlo; const int hi = rlo + rn;
+        if (rn > 8) lo = cg_lower_bound8(key, rlo, rn, rowbase - RING);
+        for (int b = lo; b < hi; ++b) {
+          const int dx = key[b] - rowbase;
+          if (dx > RING) break;
+          const bool fwd = !(dy == 0 && dz == 0 && dx <= 0);      // forward half: each unordered pair once
+          const bool ring = edge_row || abs(dx) == RING;           // inner cells belong to the previous pass
+          bool want = dx >= -RING && fwd && ring;
+          if (want) { const int pb = cg_ld<LDS>(par + b); want = pb != ra && cg_find<LDS>(par, b) != ra; }
+          const unsigned long long m = __ballot(want);
+          if (m) {
+            const int leader = __ffsll((long long)m) - 1; int base = 0;
+            if (lane_id() == leader) base = atomicAdd(l_nlist, __popcll(m));
+            base = __shfl(base, leader, 64);
+            if (want) {
+              const int slot = base + __popcll(m & lanemask_lt());
+              if (slot < cgs_list_cap<LDS>(0)) cgs_list_put<LDS>(ovf, l_list, slot, 0, a, b);
+              else { const int a0 = start[a], b0 = start[b]; if (pair_hit_serial(sp, a0, start[a + 1] - a0, b0, start[b + 1] - b0, r2)) cg_unite<LDS>(par, a, b); }
+            }
+          }
+        }
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- B1: one thread per candidate pair
+  const int n1 = min(*l_nlist, cgs_list_cap<LDS>(0));
+  for (int h = threadIdx.x; h < n1; h += CGS_T) {
+    int a, b; cgs_list_get<LDS>(ovf, l_list, h, 0, a, b);
+    if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;
+    const int verdict = cg_pair_test(d, soc, start, sp, a, b, r2);
+    if (verdict > 0) cg_unite<LDS>(par, a, b);
+    else if (verdict < 0) {
+      const int slot = atomicAdd(l_n2, 1);
+      if (slot < cgs_list_cap<LDS>(1)) cgs_list_put<LDS>(ovf, l_list, slot, 1, a, b);
+      else { const int a0 = start[a], b0 = start[b]; if (pair_hit_serial(sp, a0, start[a + 1] - a0, b0, start[b + 1] - b0, r2)) cg_unite<LDS>(par, a, b); }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- B2: one wave per undecided big pair
+  const int n2 = min(*l_n2, cgs_list_cap<LDS>(1)), lane = lane_id();
+  for (int h = wave_id(); h < n2; h += CGS_T / 64) {
+    int a, b; cgs_list_get<LDS>(ovf, l_list, h, 1, a, b);
+    if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;
+    const float4 alo = d.cmeta[2 * (soc + a)], ahi = d.cmeta[2 * (soc + a) + 1], blo = d.cmeta[2 * (soc + b)], bhi = d.cmeta[2 * (soc + b) + 1];
+    if (pair_hit_wave(sp, start[a], start[a + 1] - start[a], start[b], start[b + 1] - start[b], r2, lane, alo, ahi, blo, bhi) && lane == 0) cg_unite<LDS>(par, a, b);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { *l_nlist = 0; *l_n2 = 0; }
+  __syncthreads();
+}
+template <bool LDS> __device__ __forceinline__ void cgs_body(const MorDev &d, int s, size_t so, int c0, int n_own, int n_loc, const int *key, const int *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_nlist, int *l_n2) {
+  const int *start = d.cstart + (size_t)s * (d.Nmax + 1) + c0;   // start[local id]: first position of the cell in `sorted`
+  const float4 *sp = d.sorted + so;
+  cgs_hook_pass<LDS, 1>(d, so + c0, n_own, key, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_nlist, l_n2);
+  for (int c = threadIdx.x; c < n_loc; c += CGS_T) { const int r = cg_find<LDS>(par, c); if (r != c) cg_st<LDS>(par + c, r); }   // flat forest: the shell pass compares parents directly
+  __syncthreads();
+  cgs_hook_pass<LDS, 2>(d, so + c0, n_own, key, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_nlist, l_n2);
+  // local roots as global compact ids: own cells → lroot_a, look-ahead cells → lroot_b
+  for (int c = threadIdx.x; c < n_loc; c += CGS_T) {
+    const int r = c0 + cg_find<LDS>(par, c);
+    if (c < n_own) d.lroot_a[so + c0 + c] = r; else d.lroot_b[so + c0 + c] = r;
+  }
+}
+__global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {
+  int s, j; map_block(d.B, d.P, s, j);
+  const size_t so = (size_t)s * d.Nmax;
+  const int *sy = d.slab_y + (size_t)s * (MOR_MAXP + 1), *sc = d.slab_c + (size_t)s * (MOR_MAXP + 1), *se = d.slab_e + (size_t)s * (MOR_MAXP + 1);
+  const int c0 = sc[j], c1 = sc[j + 1], c2 = se[j], n_own = c1 - c0, n_loc = c2 - c0;
+  if (n_own <= 0) return;
+  const int y0 = sy[j], y2 = min(sy[j + 1] + 2, d.g.ny), r0 = y0 * d.g.nz, nlrows = (y2 - y0) * d.g.nz;
+  __shared__ int l_key[CGS_CAP], l_par[CGS_CAP], l_rows[CGS_ROWCAP + 1], l_list[2 * CG_LIST], l_nlist, l_n2;
+  int *ovf = d.cg_ovf + (size_t)(s * MOR_MAXP + j) * MOR_CGS_OVF * 4;
+  const int *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1) + r0;
+  if (threadIdx.x == 0) { l_nlist = 0; l_n2 = 0; }
+  if (n_loc <= CGS_CAP && nlrows <= CGS_ROWCAP && !d.cg_force_global) {
+    const int *gk = d.ckey + so + c0;
+    for (int i = threadIdx.x; i < n_loc; i += CGS_T) { l_key[i] = gk[i]; l_par[i] = i; }
+    for (int i = threadIdx.x; i <= nlrows; i += CGS_T) l_rows[i] = g_rows[i] - c0;
+    __syncthreads();
+    cgs_body<true>(d, s, so, c0, n_own, n_loc, l_key, l_rows, 0, r0, nlrows, l_par, ovf, l_list, &l_nlist, &l_n2);
+  } else {   // slab too big for LDS: the same code on global arrays (even and odd slabs use different forests: look-aheads overlap the next slab)
+    int *par = ((j & 1) ? d.parent2 : d.parent) + so + c0;
+    for (int i = threadIdx.x; i < n_loc; i += CGS_T) cg_st<false>(par + i, i);
+    __threadfence();
+    __syncthreads();
+    cgs_body<false>(d, s, so, c0, n_own, n_loc, d.ckey + so + c0, g_rows, c0, r0, nlrows, par, ovf, l_list, &l_nlist, &l_n2);
+  }
+}
+// One workgroup per stream: merges the slab forests, then components (size, smallest cloud index), the kept clusters
+// (:215-216), their order, per-cell cluster ids, offsets — the tail of the former one-workgroup kernel.
+#define CGF_T 1024
+#define CGF_CAP 12288
+template <bool LDS> __device__ __forceinline__ void cgf_body(const MorDev &d, int s, int nocc, int *par, int *size, int *mn, int *cidr, int *l_misc, const int *l_sc, const int *l_se) {
+  const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
+  const int *start = d.cstart + (size_t)s * (d.Nmax + 1);
+  const int lane = lane_id(), P = d.P;
+  // ---- merge: (c, local root in its own slab) and, for the look-ahead cells of the previous slab, (c, local root there)
+  for (int c = threadIdx.x; c < nocc; c += CGF_T) {
+    cg_unite<LDS>(par, c, d.lroot_a[so + c]);
+    int j = 0;
+    for (int k = 1; k < P; ++k) j += l_sc[k] <= c;            // slab owning c
+    if (j > 0 && c < l_se[j - 1] && l_sc[j] > l_sc[j - 1]) cg_unite<LDS>(par, c, d.lroot_b[so + c]);   // (an empty slab publishes nothing)
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int c = threadIdx.x; c < nocc; c += CGF_T) { const int r = cg_find<LDS>(par, c); if (r != c) cg_st<LDS>(par + c, r); }
+  __syncthreads();
+  // ---- components: size (points) and smallest cloud index at the root
+  for (int c = threadIdx.x; c < nocc; c += CGF_T) { cg_st<LDS>(size + c, 0); cg_st<LDS>(mn + c, 0x7fffffff); }
+  __threadfence_block();
+  __syncthreads();
+  for (int c = threadIdx.x; c < nocc; c += CGF_T) { const int r = cg_ld<LDS>(par + c); atomicAdd(&size[r], start[c + 1] - start[c]); atomicMin(&mn[r], d.cmin[so + c]); }
+  __threadfence_block();
+  __syncthreads();
+  // ---- kept components (:215-216) → scratch list; K
+  if (threadIdx.x == 0) l_misc[0] = 0;
+  __syncthreads();
+  for (int c = threadIdx.x; c < nocc; c += CGF_T) {
+    const bool root = cg_ld<LDS>(par + c) == c;
+    const long long n = root ? (long long)cg_ld<LDS>(size + c) : 0;
+    if (root && n >= d.min_cs && n <= d.max_cs) {
+      const int k = atomicAdd(&l_misc[0], 1);
+      if (k < d.Kcap) { d.kcell[ko + k] = c; d.kroot[ko + k] = cg_ld<LDS>(mn + c); d.ksize[ko + k] = (int)n; }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  int K = l_misc[0];
+  if (K > d.Kcap) { if (threadIdx.x == 0) mor_raise(d, s, 1u); K = d.Kcap; }
+  __syncthreads();
+  // ---- cluster order: size descending, ties by smaller first cloud index; rank by counting (cidr may alias `size`: sizes were copied to ksize)
+  for (int c = threadIdx.x; c < nocc; c += CGF_T) cg_st<LDS>(cidr + c, -1);
+  __threadfence_block();
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += CGF_T) {
+    const int my_sz = d.ksize[ko + k], my_rt = d.kroot[ko + k]; int rank = 0;
+    for (int u = 0; u < K; ++u) { const int sz = d.ksize[ko + u], rt = d.kroot[ko + u]; rank += (sz > my_sz) || (sz == my_sz && rt < my_rt); }
+    cg_st<LDS>(cidr + d.kcell[ko + k], rank);
+    d.csz[ko + rank] = my_sz;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- per-cell cluster id (a cell is a clique ⇒ one cluster)
+  for (int c = threadIdx.x; c < nocc; c += CGF_T) { const int r = cg_ld<LDS>(par + c), id = cg_ld<LDS>(cidr + r); d.ccid[so + c] = id; reinterpret_cast<int *>(&d.cmeta[2 * (so + c)])[3] = id; }
+  // ---- cluster offsets (exclusive scan of sizes in cluster order), C, clear detection_results (:250-254)
+  int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1);
+  int carry = 0;
+  for (int b = 0; b < K; b += CGF_T) {
+    const int k = b + threadIdx.x, v = k < K ? d.csz[ko + k] : 0;
+    const int inc = wave_incl_scan(v);
+    if (lane == 63) l_misc[1 + wave_id()] = inc;
+    __syncthreads();
+    int basew = 0, tot = 0;
+    for (int w = 0; w < CGF_T / 64; ++w) { const int xw = l_misc[1 + w]; if (w < wave_id()) basew += xw; tot += xw; }
+    __syncthreads();
+    if (k < K) { off[k] = carry + basew + inc - v; d.det[ko + k] = 0; }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) { off[K] = carry; d.info[s].C = carry; d.info[s].K = K; d.slot_kc[d.cur][s] = make_int2(K, carry); }
+  // ---- work items of the per-cluster reductions: cluster k owns ceil(size/MOR_CHUNK) chunks
+  int *coff = d.chunk_off[d.cur] + (size_t)s * (d.Kcap + 1);
+  carry = 0;
+  __syncthreads();
+  for (int b = 0; b < K; b += CGF_T) {
+    const int k = b + threadIdx.x, v = k < K ? (d.csz[ko + k] + MOR_CHUNK - 1) / MOR_CHUNK : 0;
+    const int inc = wave_incl_scan(v);
+    if (lane == 63) l_misc[1 + wave_id()] = inc;
+    __syncthreads();
+    int basew = 0, tot = 0;
+    for (int w = 0; w < CGF_T / 64; ++w) { const int xw = l_misc[1 + w]; if (w < wave_id()) basew += xw; tot += xw; }
+    __syncthreads();
+    if (k < K) coff[k] = carry + basew + inc - v;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) coff[K] = carry;
+}
+__global__ __launch_bounds__(CGF_T) void k_cg_final(MorDev d) {
+  const int s = blockIdx.x + d.s0, nocc = d.info[s].n_occ;
+  const size_t so = (size_t)s * d.Nmax;
+  __shared__ int l_par[CGF_CAP], l_a[CGF_CAP], l_b[CGF_CAP], l_misc[1 + CGF_T / 64], l_sc[MOR_MAXP + 1], l_se[MOR_MAXP + 1];
+  if (threadIdx.x <= d.P) { l_sc[threadIdx.x] = d.slab_c[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; l_se[threadIdx.x] = d.slab_e[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; }
+  if (nocc <= CGF_CAP && !d.cg_force_global) {          // forest, sizes (then cluster ids), minima: three LDS arrays
+    for (int i = threadIdx.x; i < nocc; i += CGF_T) l_par[i] = i;
+    __syncthreads();
+    cgf_body<true>(d, s, nocc, l_par, l_a, l_b, l_a, l_misc, l_sc, l_se);
+  } else {
+    int *par = d.parent + so;
+    for (int i = threadIdx.x; i < nocc; i += CGF_T) cg_st<false>(par + i, i);
+    __threadfence();
+    __syncthreads();
+    cgf_body<false>(d, s, nocc, par, d.csize + so, d.compmin + so, d.cid_of_root + so, l_misc, l_sc, l_se);
+  }
+}
+
+// per cloud point: cluster id of its cell (a cell is a clique ⇒ one cluster per cell)
 __global__ __launch_bounds__(MOR_BT) void k_label(MorDev d) {
   int s, t0; map_block(d.B, d.tiles_m, s, t0);
   const int M = d.info[s].M;
   const size_t so = (size_t)s * d.Nmax;
-  for (int js = t0 * MOR_BT + threadIdx.x; js < M; js += d.tiles_m * MOR_BT) {
-    float4 q = d.sorted[so + js];
-    int i = __float_as_int(q.w);
-    int cid = d.ccid[so + d.cell_of[so + js]];   // one cluster per cell (clique)
-    q.w = __int_as_float(cid);
-    d.sorted[so + js] = q;
-    d.pcid[so + i] = cid;
-  }
+  for (int i = t0 * MOR_BT + threadIdx.x; i < M; i += d.tiles_m * MOR_BT) d.pcid[so + i] = d.ccid[so + d.pcell[so + i]];
 }
 
 // ------------------------------------------------------------------------------------ stable LSD radix sort, 8-bit digits, batched over streams
@@ -2240,19 +2673,26 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
     if (!d.fuse_scans) MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
     MOR_LAUNCH(MK_SCATTER, k_scatter, gT, d);
   }
-  for (int pass = 0; pass < d.cell_passes; ++pass) {   // points sorted by cell key; result in (skey, sidx) = buffers [cell_passes & 1]
-    MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0, d.fuse_scans && d.tiles_m <= 64};
-    MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
-    if (!j.fuse) MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
-    MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
+  if (d.grid_mode == 1 && d.gmode != 1) {   // clustering grid by counting (k_gridhash); the VoxelGrid pass of the voxel ground variant needs the points of a voxel in index order: sort
+    mor_timer_begin(tm, MK_GRIDHASH, st);
+    hipLaunchKernelGGL(k_gridhash, gB, dim3(GH_T), 0, st, d);
+    mor_timer_end(tm, MK_GRIDHASH, st);
+    MOR_LAUNCH(MK_GRIDFILL, k_gridfill, gM, d);
+  } else {
+    for (int pass = 0; pass < d.cell_passes; ++pass) {   // points sorted by cell key; result in (skey, sidx) = buffers [cell_passes & 1]
+      MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0, d.fuse_scans && d.tiles_m <= 64};
+      MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
+      if (!j.fuse) MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
+      MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
+    }
+    MOR_LAUNCH(MK_HEADS_COUNT, k_heads_count, gM, d);
+    if (!d.fuse_scans) {
+      MOR_LAUNCH(MK_HEADS_SCAN, k_heads_scan, gB, d);
+      if (d.use_hash) MOR_LAUNCH(MK_HASH_CLEAR, k_hash_clear, dim3(64, d.B), d);
+    }
+    MOR_LAUNCH(MK_HEADS_SCATTER, k_heads_scatter, gM, d);
   }
-  MOR_LAUNCH(MK_HEADS_COUNT, k_heads_count, gM, d);
-  if (!d.fuse_scans) {
-    MOR_LAUNCH(MK_HEADS_SCAN, k_heads_scan, gB, d);
-    if (d.use_hash) MOR_LAUNCH(MK_HASH_CLEAR, k_hash_clear, dim3(64, d.B), d);
-  }
-  MOR_LAUNCH(MK_HEADS_SCATTER, k_heads_scatter, gM, d);
-  if (d.gmode != 1) MOR_LAUNCH(MK_CELLBOXES, k_cellboxes, dim3(MOR_BOX_G * d.B), d);   // + cell hash (the row table is written by k_heads_scatter)
+  if (d.gmode != 1) MOR_LAUNCH(MK_CELLBOXES, k_cellboxes, dim3(MOR_BOX_G * d.B), d);   // point boxes, smallest index, slabs (+ cell hash on the sort path)
 }
 
 void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
@@ -2283,6 +2723,15 @@ void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
 }
 
 void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+  if (d.cg_mode == 1) {
+    mor_timer_begin(tm, MK_CG_SLAB, st);
+    hipLaunchKernelGGL(k_cg_slab, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
+    mor_timer_end(tm, MK_CG_SLAB, st);
+    mor_timer_begin(tm, MK_CG_FINAL, st);
+    hipLaunchKernelGGL(k_cg_final, dim3(d.B), dim3(CGF_T), 0, st, d);
+    mor_timer_end(tm, MK_CG_FINAL, st);
+    return;
+  }
   const dim3 gB(d.cg_help_min > 0 ? 2 * d.B : d.B);
   if (d.cg_help_min > 0) (void)hipMemsetAsync(d.cg_help + (size_t)d.s0 * 4, 0, (size_t)d.B * 4 * sizeof(int), st);
   mor_timer_begin(tm, MK_CELLGRAPH, st);

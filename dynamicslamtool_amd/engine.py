@@ -19,7 +19,7 @@ EXPORTS = [
     "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_get_stage_counts", "mor_device_alloc", "mor_device_free", "mor_host_alloc", "mor_host_free",
     "mor_device_upload", "mor_device_download", "mor_device_synchronize", "mor_device_count", "mor_get_last_timing",
     "mor_kernel_timing_enable", "mor_kernel_timing_read", "mor_tracker_create", "mor_tracker_destroy", "mor_tracker_push",
-    "mor_tracker_filter", "mor_tracker_get", "mor_get_frame_log",
+    "mor_tracker_filter", "mor_tracker_get", "mor_get_frame_log", "mor_debug_read", "mor_debug_config",
 ]
 
 
@@ -318,6 +318,24 @@ class MorBatch:
         a = (C.c_int64 * 10)()
         _check(lib().mor_get_frame_log(self._h, int(frame), s, a))
         return dict(zip(("frame", "K", "C", "n_pairs", "cnt_sum", "det_sum", "n_mo_push", "n_mo_filter", "n_out", "flags"), [int(x) for x in a]))
+
+    def debug_read(self, name, s=0, dtype=np.int32, count=None):
+        """Development read-back of an intermediate device array (mor_debug_read): `count` elements of dtype."""
+        L = lib()
+        L.mor_debug_read.restype = C.c_longlong
+        L.mor_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]
+        n = int(count if count is not None else self.max_points)
+        out = np.zeros(max(n, 1), dtype)
+        got = L.mor_debug_read(self._h, name.encode(), s, out.ctypes.data, out.nbytes)
+        if got < 0:
+            raise MorError(L.mor_last_error().decode())
+        return out[:n]
+
+    def debug_config(self):
+        a = (C.c_int * 12)()
+        lib().mor_debug_config.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib().mor_debug_config(self._h, a, 12)
+        return dict(zip(("nx", "ny", "nz", "nrows", "P", "grid_mode", "cg_mode", "Hcell", "Kcap", "tiles_m", "cur", "prev"), [int(x) for x in a]))
 
     def stage_counts(self, s=0):
         a = (C.c_uint32 * 4)()

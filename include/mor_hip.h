@@ -142,6 +142,11 @@ int mor_get_stage_counts(const mor_batch *b, int stream, uint32_t *out, int n);
  * the push, |mo_vec| after filterCloud, points in the filtered cloud, device flags of the frame. */
 int mor_get_frame_log(const mor_batch *b, uint64_t frame, int stream, int64_t *out10);
 
+/* Development hooks (exp/, tests): raw copy of a named intermediate device array of one stream (returns bytes copied or
+ * a negative error), and the grid geometry / launch configuration of the latest push. */
+long long mor_debug_read(const mor_batch *b, const char *name, int stream, void *out, size_t bytes);
+int mor_debug_config(const mor_batch *b, int *out, int n);
+
 /* ---- device-memory helpers so callers can keep clouds resident in HBM (bench, replay driver) ---- */
 void *mor_device_alloc(int device, size_t bytes);
 void mor_device_free(int device, void *p);

@@ -492,3 +492,93 @@ def test_async_pipeline_matches_oracle(method):
                 compare_output(outs_o[s], got, "async frame %d stream %d" % (f, s))
     b.set_async(False)
     b.close()
+
+
+def test_async_without_waits_matches_synchronous_use_frame_by_frame():
+    """BASELINE configs[1] shape with the clouds resident in HBM and NO wait between frames: the four stage streams
+    really overlap three frames here (pushing pageable host arrays blocks on the copies and hides races between
+    frames).  Every frame's summary (K, C, correspondences, checksum of the movement counts, detections, tracked
+    centroids after push and after filterCloud, filtered-cloud size) must equal the one of a run that waits after
+    every call.  The streams produce tracks from frame 4 on, so wrong scores in any frame change later frames too."""
+    p = kitti_params(1)
+    B, nf, npts = 64, 10, 120000
+    seeds = [2000 + s for s in range(B)]
+    buf = DeviceBuffer(nf * B * npts * 16)
+    poses = []
+    for f in range(nf):
+        xs, ps = synth.batch(seeds, [f] * B)
+        buf.upload(xs, f * B * npts * 16)
+        poses.append(ps)
+    logs = []
+    for mode in ("async", "sync"):
+        b = MorBatch(p, B, npts)
+        views = [b.make_views([(buf.ptr + (f * B + s) * npts * 16, npts) for s in range(B)]) for f in range(nf)]
+        if mode == "async":
+            b.set_async(True)
+        for f in range(nf):
+            b.push_views(views[f], poses[f])
+            if mode == "async":
+                b.filter_async()
+            else:
+                b.filter_device()
+        b.wait()
+        logs.append([[b.frame_log(f, s) for s in range(B)] for f in range(nf)])
+        b.close()
+    buf.free()
+    tracks = 0
+    for f in range(nf):
+        for s in range(B):
+            assert logs[0][f][s] == logs[1][f][s], (f, s, logs[0][f][s], logs[1][f][s])
+            tracks = max(tracks, logs[0][f][s]["n_mo_filter"])
+    assert tracks > 0 and any(logs[0][nf - 1][s]["n_pairs"] > 0 for s in range(B))
+
+
+def test_unaligned_blob_records():
+    """Packed sensor records whose float32 fields sit at odd addresses (the Velodyne driver's PointXYZIRT: x y z
+    intensity float32, ring uint16, time float32 → point_step 22): fromPCLPointCloud2 memcpy's the named fields, so the
+    blob is valid input."""
+    p = scene_params()
+    frames = small_stream(6, n_frames=3)
+    b, o = MorBatch(p, 1, len(frames[0][0]) + 64), Oracle(p)
+    for pts, pose in frames:
+        rec = np.zeros((len(pts), 22), np.uint8)
+        rec[:, 0:16] = pts.view(np.uint8).reshape(len(pts), 16)
+        rec[:, 16:18] = 7
+        blob = np.concatenate([np.zeros(1, np.uint8), rec.reshape(-1)])[1:]   # record 0 starts at an odd host address too
+        b.push([blob], pose[None, :], point_step=22, offsets=(0, 4, 8, 12))
+        o.push(pts, pose)
+        compare_frame(o, b, 0, "22-byte records")
+        compare_output(o.filter(), b.filter()[0], "22-byte records")
+    # x at byte 1 of a 17-byte record: nothing is 4-byte aligned
+    pts, pose = frames[0]
+    rec = np.zeros((len(pts), 17), np.uint8)
+    rec[:, 1:17] = pts.view(np.uint8).reshape(len(pts), 16)
+    b2, o2 = MorBatch(p, 1, len(pts)), Oracle(p)
+    b2.push([rec.reshape(-1)], pose[None, :], point_step=17, offsets=(1, 5, 9, 13))
+    o2.push(pts, pose)
+    compare_output(o2.filter(), b2.filter()[0], "17-byte records")
+    b.close()
+    b2.close()
+
+
+def test_error_of_an_intermediate_frame_is_reported_once():
+    """Device-side error flags are sticky until the host has reported them: in asynchronous mode an error raised by an
+    intermediate frame (here: the voxel ground variant meets a cloud whose z extent exceeds its 64 m grid) must surface
+    at the next wait even though later frames were fine, and must not be reported twice."""
+    p = scene_params(method_choice=2)
+    p.ground_method = 1
+    p.gp_leaf = 0.1
+    frames = small_stream(2, n_frames=5, with_nan=False)
+    bad = frames[2][0].copy()
+    bad[5] = (0.5, 0.5, 150.0, 0.0)
+    b = MorBatch(p, 1, len(bad) + 16)
+    b.set_async(True)
+    for f, (pts, pose) in enumerate(frames):
+        b.push([bad if f == 2 else pts], pose[None, :])
+        b.filter_async()
+    with pytest.raises(MorError, match="z extent"):
+        b.wait()
+    b.push([frames[0][0]], frames[0][1][None, :])
+    b.filter_async()
+    b.wait()   # reported and cleared: the next wait is clean
+    b.close()
