@@ -118,6 +118,7 @@ struct MorDev {
   int *pcell;                // [B][Nmax]  compact cell id per cloud point
   int *ppos, *pslot;         // [B][Nmax]  hash path of the grid: position of each cloud point in `sorted`; its slot in the cell table
   int2 *gh_rowlist;          // [B][Nmax]  hash path: (slot, x) of the cells of every row, unordered inside the row
+  int *gh_rowfill;           // [B][nrows+1]  hash path: per-row fill cursors when the row table does not fit the LDS copy
   int *gh_key, *gh_val;      // [B][Hcell] hash path: the cell table of streams with more cells than the LDS table holds
   int grid_mode, gh_force_global;   // grid_mode 0: points radix-sorted by cell key; 1: cells counted in a hash table (k_gridhash); test knob: always the global-memory table
   int *slab_y, *slab_c, *slab_e;    // [B][MOR_MAXP+1]  slabs of the cell graph: first y-slice, first compact cell id, end of the look-ahead (cells of the next two y-slices)
@@ -180,6 +181,7 @@ struct MorDev {
   int *otile_cnt;            // [B][tiles_max]
   float4 *const *out_ptrs;   // [B] or null
   unsigned long long *dbg;   // [B][16] experiment stamps (MOR_EXP_STAMPS builds only)
+  unsigned long long *dbg2;  // [B][MOR_MAXP+2][16] experiment stamps of the slab workgroups, k_gridhash, k_cg_final
   // ---- pinned host mirrors written by the device (zero-copy summaries)
   MorFrameInfo *h_info;      // [B]
   float4 *h_centroid;        // [B][Kcap]

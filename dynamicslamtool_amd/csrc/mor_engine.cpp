@@ -292,7 +292,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.crep, B * N);
   ok = ok && dalloc(b, d.cg_ext, B * (size_t)MOR_CG_EXT) && dalloc(b, d.cg_help, B * 4);
   ok = ok && dalloc(b, d.cg_ovf, B * std::max((size_t)MOR_CG_OVF * 4, (size_t)MOR_MAXP * MOR_CGS_OVF * 4));
-  ok = ok && dalloc(b, d.ppos, B * N) && dalloc(b, d.pslot, B * N) && dalloc(b, d.gh_rowlist, B * N) && dalloc(b, d.gh_key, B * (size_t)d.Hcell) && dalloc(b, d.gh_val, B * (size_t)d.Hcell);
+  ok = ok && dalloc(b, d.ppos, B * N) && dalloc(b, d.pslot, B * N) && dalloc(b, d.gh_rowlist, B * N) && dalloc(b, d.gh_rowfill, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, d.gh_key, B * (size_t)d.Hcell) && dalloc(b, d.gh_val, B * (size_t)d.Hcell);
   ok = ok && dalloc(b, d.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, d.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, d.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, d.lroot_a, B * N) && dalloc(b, d.lroot_b, B * N) && dalloc(b, d.parent2, B * N);
   ok = ok && dalloc(b, d.xcent, B * K) && dalloc(b, d.xamin, B * K) && dalloc(b, d.xamax, B * K);
   for (int i = 0; i < 4; ++i)
@@ -302,7 +302,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.nn_fwd, B * K) && dalloc(b, d.nn_bwd, B * K) && dalloc(b, d.nn_fwd_d, B * K) && dalloc(b, d.pair_q, B * K) && dalloc(b, d.pair_m, B * K) && dalloc(b, d.pair_d, B * K);
   ok = ok && dalloc(b, d.pair_cnt, B * K) && dalloc(b, d.pair_of_prev, B * K) && dalloc(b, d.pair_of_cur, B * K) && dalloc(b, d.det, B * K);
   if (p->method_choice == 2) ok = ok && dalloc(b, d.vox, B * (size_t)d.Hcap);
-  ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_n, B) && dalloc(b, d.wlb_n, B) && dalloc(b, d.wl2, B * N) && dalloc(b, d.wl2_n, B) && dalloc(b, d.dbg, B * 16);
+  ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_n, B) && dalloc(b, d.wlb_n, B) && dalloc(b, d.wl2, B * N) && dalloc(b, d.wl2_n, B) && dalloc(b, d.dbg, B * 16) && dalloc(b, d.dbg2, B * (MOR_MAXP + 2) * 16);
   ok = ok && dalloc(b, d.zmin_i, B) && dalloc(b, d.zmax_i, B) && dalloc(b, d.zorg, B) && dalloc(b, d.zbase, B) && dalloc(b, d.mode_bin, B);
   if (d.gmode == 1) ok = ok && dalloc(b, d.rawbuf, B * N) && dalloc(b, d.is_ground, B * N) && dalloc(b, d.vcent, B * N) && dalloc(b, d.vbin, B * N) && dalloc(b, d.g2_big, B * N) && dalloc(b, d.g2_nbig, B);
   if (ok) {   // crop-box variant: the clustering grid starts at gp_limit for every stream
@@ -607,6 +607,13 @@ int mor_exp_read_stamps(const mor_batch *b, unsigned long long *out) {
   if (!b) return MOR_ERR_INVALID;
   HIP_TRY(hipMemcpy(out, b->d.dbg, sizeof(unsigned long long) * 16 * b->B, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(b->d.dbg, 0, sizeof(unsigned long long) * 16 * b->B));   // counters restart
+  return MOR_OK;
+}
+int mor_exp_read_stamps2(const mor_batch *b, unsigned long long *out) {
+  if (!b) return MOR_ERR_INVALID;
+  const size_t n = sizeof(unsigned long long) * 16 * (MOR_MAXP + 2) * b->B;
+  HIP_TRY(hipMemcpy(out, b->d.dbg2, n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(b->d.dbg2, 0, n));
   return MOR_OK;
 }
 int mor_get_stage_counts(const mor_batch *b, int s, uint32_t *out, int n) {

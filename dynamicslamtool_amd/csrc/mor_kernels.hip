@@ -41,6 +41,13 @@ const char *const mor_kernel_names[MK_COUNT] = {
 #define RS_ADD(i, x)
 #define RS_MAX(i, x)
 #endif
+#ifdef MOR_EXP_STAMPS
+#define ST2(w, i) do { __syncthreads(); if (threadIdx.x == 0) d.dbg2[(size_t)(w) * 16 + (i)] = wall_clock64(); } while (0)
+#define ST2V(w, i, v) do { if (threadIdx.x == 0) d.dbg2[(size_t)(w) * 16 + (i)] = (unsigned long long)(v); } while (0)
+#else
+#define ST2(w, i)
+#define ST2V(w, i, v)
+#endif
 // ------------------------------------------------------------------------------------ helpers
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
@@ -604,6 +611,8 @@ template <bool TL, bool RL> __device__ __forceinline__ bool gh_run(const MorDev 
   const int nrows = d.g.nrows, nx = d.g.nx, tid = threadIdx.x;
   int hbits = 0; while ((1 << hbits) < H) ++hbits;
   const unsigned hshift = 32 - hbits, mask = (unsigned)H - 1u;
+  const size_t stw = (size_t)s * (MOR_MAXP + 2) + MOR_MAXP; (void)stw;
+  ST2(stw, 0);
   for (int i = tid; i < H; i += GH_T) { gh_st<TL>(tkey + i, 0); gh_st<TL>(tval + i, 0); }
   if (tid == 0) { l_misc[0] = 0; l_misc[1] = 0; }
   __syncthreads();
@@ -632,6 +641,7 @@ template <bool TL, bool RL> __device__ __forceinline__ bool gh_run(const MorDev 
   __syncthreads();
   if (l_misc[1]) { __syncthreads(); return false; }
   const int nocc = l_misc[0];
+  ST2(stw, 1);
   // ---- cells per row → row table
   for (int r = tid; r <= nrows; r += GH_T) gh_st<RL>(rows + r, 0);
   __syncthreads();
@@ -642,10 +652,18 @@ template <bool TL, bool RL> __device__ __forceinline__ bool gh_run(const MorDev 
   __syncthreads();
   if (RL) { int *grs = d.row_start + (size_t)s * (nrows + 1); for (int r = tid; r <= nrows; r += GH_T) grs[r] = rows[r]; }
   slab_bounds<RL>(d, s, rows, nocc, l_sh);
-  // ---- the cells of every row, listed (unordered) behind the row's first id; rows[r] becomes the END of row r
+  // ---- the cells of every row, listed (unordered) behind the row's first id.  The LDS copy of the row table serves as the
+  //      fill cursor itself (rows[r] becomes the END of row r; the table proper is in global memory by now); a row table
+  //      that lives in global memory stays intact and a scratch copy is the cursor
+  int *fill = rows;
+  if (!RL) {
+    fill = d.gh_rowfill + (size_t)s * (nrows + 1);
+    for (int r = tid; r < nrows; r += GH_T) gh_st<false>(fill + r, gh_ld<false>(rows + r));
+    __syncthreads();
+  }
   for (int sl = tid; sl < H; sl += GH_T) {
     const int k = gh_ld<TL>(tkey + sl);
-    if (k) { const int key = k - 1, r = key / nx; const int pos = atomicAdd(rows + r, 1); rowlist[pos] = make_int2(sl, key - r * nx); }
+    if (k) { const int key = k - 1, r = key / nx; const int pos = atomicAdd(fill + r, 1); rowlist[pos] = make_int2(sl, key - r * nx); }
   }
   __syncthreads();
   // ---- compact id = first id of the row + cells of the row with a smaller x; counts in id order; slot → id
@@ -654,7 +672,7 @@ template <bool TL, bool RL> __device__ __forceinline__ bool gh_run(const MorDev 
     const int k = gh_ld<TL>(tkey + sl);
     if (k) {
       const int key = k - 1, r = key / nx, x = key - r * nx;
-      const int b = r ? gh_ld<RL>(rows + r - 1) : 0, e = gh_ld<RL>(rows + r);
+      const int b = RL ? (r ? gh_ld<RL>(rows + r - 1) : 0) : gh_ld<RL>(rows + r), e = RL ? gh_ld<RL>(rows + r) : gh_ld<RL>(rows + r + 1);
       int c = b;
       for (int q = b; q < e; ++q) c += rowlist[q].y < x;
       ckey[c] = key; cstart[c] = gh_ld<TL>(tval + sl);
@@ -668,6 +686,7 @@ template <bool TL, bool RL> __device__ __forceinline__ bool gh_run(const MorDev 
   __syncthreads();
   for (int sl = tid; sl < H; sl += GH_T) { const int c1 = gh_ld<TL>(tkey + sl); if (c1) gh_st<TL>(tval + sl, gh_ld<false>(cstart + c1 - 1)); }
   __syncthreads();
+  ST2(stw, 2);
   // ---- sweep 2: position of every point inside its cell's range
   for (int i0 = 0; i0 < M; i0 += 4 * GH_T) {
     int sl[4];
@@ -681,6 +700,7 @@ template <bool TL, bool RL> __device__ __forceinline__ bool gh_run(const MorDev 
       ppos[i] = atomicAdd(tval + sl[u], 1);
     }
   }
+  ST2(stw, 3); ST2V(stw, 4, M); ST2V(stw, 5, nocc);
   return true;
 }
 __global__ __launch_bounds__(GH_T) void k_gridhash(MorDev d) {
@@ -1265,8 +1285,9 @@ template <bool LDS> __device__ __forceinline__ int cgs_list_cap(int region) { re
 // rows[] = row table of the slab's rows (row r0 first) holding LOCAL ids minus `rsub` (0 for the LDS copy, the slab's first
 // compact id when the global table is read in place); soc = first slot of the slab's cells in the per-cell global arrays.
 template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(const MorDev &d, size_t soc, int n_own, const int *key, const int *start, const int *rows, int rsub, int r0, int nlrows,
-                                                                            int *par, const float4 *sp, int *ovf, int *l_list, int *l_nlist, int *l_n2) {
+                                                                            int *par, const float4 *sp, int *ovf, int *l_list, int *l_nlist, int *l_n2, size_t stw) {
   const float r2 = d.r2;
+  ST2(stw, (RING - 1) * 4 + 1);
   // ---- A: candidate pairs (own cell a, forward neighbour b in another component), LDS only
   for (int a = threadIdx.x; a < n_own; a += CGS_T) {
     const int ka = key[a], rowa = ka / d.g.nx, x = ka - rowa * d.g.nx, z = rowa % d.g.nz, y = rowa / d.g.nz;
@@ -1307,6 +1328,7 @@ template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(cons
   }
   __threadfence_block();
   __syncthreads();
+  ST2(stw, (RING - 1) * 4 + 2);
   // ---- B1: one thread per candidate pair
   const int n1 = min(*l_nlist, cgs_list_cap<LDS>(0));
   for (int h = threadIdx.x; h < n1; h += CGS_T) {
@@ -1322,6 +1344,7 @@ template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(cons
   }
   __threadfence_block();
   __syncthreads();
+  ST2(stw, (RING - 1) * 4 + 3);
   // ---- B2: one wave per undecided big pair
   const int n2 = min(*l_n2, cgs_list_cap<LDS>(1)), lane = lane_id();
   for (int h = wave_id(); h < n2; h += CGS_T / 64) {
@@ -1330,22 +1353,25 @@ template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(cons
     const float4 alo = d.cmeta[2 * (soc + a)], ahi = d.cmeta[2 * (soc + a) + 1], blo = d.cmeta[2 * (soc + b)], bhi = d.cmeta[2 * (soc + b) + 1];
     if (pair_hit_wave(sp, start[a], start[a + 1] - start[a], start[b], start[b + 1] - start[b], r2, lane, alo, ahi, blo, bhi) && lane == 0) cg_unite<LDS>(par, a, b);
   }
+  ST2(stw, (RING - 1) * 4 + 4);
+  ST2V(stw, 10 + (RING - 1) * 2, n1); ST2V(stw, 11 + (RING - 1) * 2, n2);
   __syncthreads();
   if (threadIdx.x == 0) { *l_nlist = 0; *l_n2 = 0; }
   __syncthreads();
 }
-template <bool LDS> __device__ __forceinline__ void cgs_body(const MorDev &d, int s, size_t so, int c0, int n_own, int n_loc, const int *key, const int *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_nlist, int *l_n2) {
+template <bool LDS> __device__ __forceinline__ void cgs_body(const MorDev &d, int s, size_t so, int c0, int n_own, int n_loc, const int *key, const int *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_nlist, int *l_n2, size_t stwj) {
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1) + c0;   // start[local id]: first position of the cell in `sorted`
   const float4 *sp = d.sorted + so;
-  cgs_hook_pass<LDS, 1>(d, so + c0, n_own, key, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_nlist, l_n2);
+  cgs_hook_pass<LDS, 1>(d, so + c0, n_own, key, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_nlist, l_n2, stwj);
   for (int c = threadIdx.x; c < n_loc; c += CGS_T) { const int r = cg_find<LDS>(par, c); if (r != c) cg_st<LDS>(par + c, r); }   // flat forest: the shell pass compares parents directly
   __syncthreads();
-  cgs_hook_pass<LDS, 2>(d, so + c0, n_own, key, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_nlist, l_n2);
+  cgs_hook_pass<LDS, 2>(d, so + c0, n_own, key, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_nlist, l_n2, stwj);
   // local roots as global compact ids: own cells → lroot_a, look-ahead cells → lroot_b
   for (int c = threadIdx.x; c < n_loc; c += CGS_T) {
     const int r = c0 + cg_find<LDS>(par, c);
     if (c < n_own) d.lroot_a[so + c0 + c] = r; else d.lroot_b[so + c0 + c] = r;
   }
+  ST2(stwj, 9); ST2V(stwj, 14, n_own); ST2V(stwj, 15, n_loc);
 }
 __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {
   int s, j; map_block(d.B, d.P, s, j);
@@ -1353,6 +1379,8 @@ __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {
   const int *sy = d.slab_y + (size_t)s * (MOR_MAXP + 1), *sc = d.slab_c + (size_t)s * (MOR_MAXP + 1), *se = d.slab_e + (size_t)s * (MOR_MAXP + 1);
   const int c0 = sc[j], c1 = sc[j + 1], c2 = se[j], n_own = c1 - c0, n_loc = c2 - c0;
   if (n_own <= 0) return;
+  const size_t stwj = (size_t)s * (MOR_MAXP + 2) + j; (void)stwj;
+  ST2(stwj, 0);
   const int y0 = sy[j], y2 = min(sy[j + 1] + 2, d.g.ny), r0 = y0 * d.g.nz, nlrows = (y2 - y0) * d.g.nz;
   __shared__ int l_key[CGS_CAP], l_par[CGS_CAP], l_rows[CGS_ROWCAP + 1], l_list[2 * CG_LIST], l_nlist, l_n2;
   int *ovf = d.cg_ovf + (size_t)(s * MOR_MAXP + j) * MOR_CGS_OVF * 4;
@@ -1363,13 +1391,13 @@ __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) { l_key[i] = gk[i]; l_par[i] = i; }
     for (int i = threadIdx.x; i <= nlrows; i += CGS_T) l_rows[i] = g_rows[i] - c0;
     __syncthreads();
-    cgs_body<true>(d, s, so, c0, n_own, n_loc, l_key, l_rows, 0, r0, nlrows, l_par, ovf, l_list, &l_nlist, &l_n2);
+    cgs_body<true>(d, s, so, c0, n_own, n_loc, l_key, l_rows, 0, r0, nlrows, l_par, ovf, l_list, &l_nlist, &l_n2, stwj);
   } else {   // slab too big for LDS: the same code on global arrays (even and odd slabs use different forests: look-aheads overlap the next slab)
     int *par = ((j & 1) ? d.parent2 : d.parent) + so + c0;
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) cg_st<false>(par + i, i);
     __threadfence();
     __syncthreads();
-    cgs_body<false>(d, s, so, c0, n_own, n_loc, d.ckey + so + c0, g_rows, c0, r0, nlrows, par, ovf, l_list, &l_nlist, &l_n2);
+    cgs_body<false>(d, s, so, c0, n_own, n_loc, d.ckey + so + c0, g_rows, c0, r0, nlrows, par, ovf, l_list, &l_nlist, &l_n2, stwj);
   }
 }
 // One workgroup per stream: merges the slab forests, then components (size, smallest cloud index), the kept clusters

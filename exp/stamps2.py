@@ -1,0 +1,40 @@
+"""Phase times inside k_gridhash and k_cg_slab (library built with -DMOR_EXP_STAMPS as exp/libmor_stamps.so)."""
+import ctypes as C, os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["MOR_HIP_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmor_stamps.so")
+from dynamicslamtool_amd import engine, kitti_params, synth
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+sensor = sys.argv[2] if len(sys.argv) > 2 else "hdl64"
+MAXP = 32
+p = kitti_params(1)
+b = engine.MorBatch(p, B, synth.n_points(sensor))
+L = engine.lib(); L.mor_exp_read_stamps2.argtypes = [C.c_void_p, C.c_void_p]
+out = np.zeros((B, MAXP + 2, 16), np.uint64)
+seeds = [2000 + s for s in range(B)]
+for f in range(4):
+    xs, ps = synth.batch(seeds, [f] * B, sensor)
+    if f == 3: L.mor_exp_read_stamps2(b._h, out.ctypes.data)
+    b.push(list(xs), ps); b.filter(to_host=False)
+L.mor_exp_read_stamps2(b._h, out.ctypes.data)
+P = b.debug_config()["P"]
+print("P =", P)
+g = out[:, MAXP, :].astype(np.int64)
+t = np.diff(g[:, 0:4], axis=1) / 100.0
+print("k_gridhash per stream (us): sweep1 mean %.1f max %.1f | cells/rank/scan mean %.1f max %.1f | sweep2 mean %.1f max %.1f | total mean %.1f max %.1f" % (
+    t[:, 0].mean(), t[:, 0].max(), t[:, 1].mean(), t[:, 1].max(), t[:, 2].mean(), t[:, 2].max(), t.sum(1).mean(), t.sum(1).max()))
+i = int(np.argmax(t.sum(1)))
+print("   slowest stream %d: M %d n_occ %d phases %s; kernel span %.1f us" % (i, g[i, 4], g[i, 5], np.round(t[i], 1).tolist(), (g[:, 3].max() - g[:, 0].min()) / 100.0))
+order = np.argsort(-t.sum(1))[:6]
+print("   six slowest: " + ", ".join("s%d M=%d %.0fus" % (k, g[k, 4], t[k].sum()) for k in order))
+w = out[:, :P, :].astype(np.int64).reshape(-1, 16)
+w = w[w[:, 0] > 0]
+tot = (w[:, 9] - w[:, 0]) / 100.0
+ph = {"load": w[:, 1] - w[:, 0], "A1": w[:, 2] - w[:, 1], "B1_1": w[:, 3] - w[:, 2], "B2_1": w[:, 4] - w[:, 3], "flat": w[:, 5] - w[:, 4], "A2": w[:, 6] - w[:, 5], "B1_2": w[:, 7] - w[:, 6], "B2_2": w[:, 8] - w[:, 7], "out": w[:, 9] - w[:, 8]}
+print("k_cg_slab workgroups: %d, total us mean %.1f p50 %.1f p90 %.1f max %.1f; kernel span %.1f" % (len(w), tot.mean(), np.median(tot), np.percentile(tot, 90), tot.max(), (w[:, 9].max() - w[:, 0].min()) / 100.0))
+for k, v in ph.items():
+    v = v / 100.0
+    print("   %-5s mean %7.1f p90 %7.1f max %7.1f" % (k, v.mean(), np.percentile(v, 90), v.max()))
+print("   pairs listed pass1 mean %.0f max %d | undecided big pass1 mean %.1f max %d | listed pass2 mean %.0f max %d | big pass2 mean %.1f max %d | n_own mean %.0f max %d n_loc max %d" % (
+    w[:, 10].mean(), w[:, 10].max(), w[:, 11].mean(), w[:, 11].max(), w[:, 12].mean(), w[:, 12].max(), w[:, 13].mean(), w[:, 13].max(), w[:, 14].mean(), w[:, 14].max(), w[:, 15].max()))
+for k in np.argsort(-tot)[:8]:
+    print("   slow wg: total %.0f us  " % tot[k] + " ".join("%s=%.0f" % (n, v[k] / 100.0) for n, v in ph.items()) + "  n1=%d n2=%d | n1'=%d n2'=%d own=%d loc=%d" % (w[k, 10], w[k, 11], w[k, 12], w[k, 13], w[k, 14], w[k, 15]))
