@@ -117,10 +117,10 @@ struct MorDev {
   int *pkey;                 // [B][Nmax]  linear cell key per cloud point
   int *pcell;                // [B][Nmax]  compact cell id per cloud point
   int *ppos, *pslot;         // [B][Nmax]  hash path of the grid: position of each cloud point in `sorted`; its slot in the cell table
-  int2 *gh_rowlist;          // [B][Nmax]  hash path: (slot, x) of the cells of every row, unordered inside the row
+  int *gh_rowlist, *gh_cells; // [B][Nmax]  hash path, streams beyond the LDS lists: x of the cells of every row (unordered inside the row) then point counts per cell; claimed slots in discovery order
   int *gh_rowfill;           // [B][nrows+1]  hash path: per-row fill cursors when the row table does not fit the LDS copy
   int *gh_key, *gh_val;      // [B][Hcell] hash path: the cell table of streams with more cells than the LDS table holds
-  int grid_mode, gh_force_global;   // grid_mode 0: points radix-sorted by cell key; 1: cells counted in a hash table (k_gridhash); test knob: always the global-memory table
+  int grid_mode, gh_tier;   // grid_mode 0: points radix-sorted by cell key; 1: cells counted in a hash table (k_gridhash); gh_tier: table tier k_gridhash starts with (0 small LDS table, 1 big LDS table, 2 global memory)
   int *slab_y, *slab_c, *slab_e;    // [B][MOR_MAXP+1]  slabs of the cell graph: first y-slice, first compact cell id, end of the look-ahead (cells of the next two y-slices)
   int P, cg_mode, cg_force_global;  // slabs per stream this frame; cg_mode 0: one workgroup per stream (k_cellgraph), 1: slabs (k_cg_slab + k_cg_final); test knob: forests in global memory
   int *lroot_a, *lroot_b;    // [B][Nmax]  per cell: its local root in its own slab / in the previous slab's look-ahead (compact ids)

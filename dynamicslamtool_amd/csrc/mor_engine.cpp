@@ -165,10 +165,10 @@ static int configure(mor_batch *b) {
   d.t1_budget = getenv("MOR_T1_BUDGET") ? atoi(getenv("MOR_T1_BUDGET")) : 64;
   // development / test switches (defaults: the fast paths): MOR_GRID=radix sorts the points by cell key instead of counting
   // cells in a hash table; MOR_CG=wg runs the cell graph as one workgroup per stream instead of over y-slabs;
-  // MOR_GH_GLOBAL / MOR_CG_GLOBAL force the global-memory variants of the hash table / the forests
+  // MOR_GH_TIER=1|2 starts k_gridhash with its big LDS table / its global-memory table; MOR_CG_GLOBAL forces the global-memory forests
   d.grid_mode = (getenv("MOR_GRID") && !strcmp(getenv("MOR_GRID"), "radix")) ? 0 : 1;
   d.cg_mode = (getenv("MOR_CG") && !strcmp(getenv("MOR_CG"), "wg")) ? 0 : 1;
-  d.gh_force_global = getenv("MOR_GH_GLOBAL") ? 1 : 0; d.cg_force_global = getenv("MOR_CG_GLOBAL") ? 1 : 0;
+  d.gh_tier = getenv("MOR_GH_TIER") ? atoi(getenv("MOR_GH_TIER")) : 0; d.cg_force_global = getenv("MOR_CG_GLOBAL") ? 1 : 0;
   d.P = 1;
   if (d.score_R > 60) return set_error(MOR_ERR_INVALID, "pde_ub %g needs a %d-cell search radius (> 60)", (double)p.pde_ub, d.score_R);
   int bits = 1; while ((1 << bits) < d.Kcap) ++bits;
@@ -292,7 +292,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.crep, B * N);
   ok = ok && dalloc(b, d.cg_ext, B * (size_t)MOR_CG_EXT) && dalloc(b, d.cg_help, B * 4);
   ok = ok && dalloc(b, d.cg_ovf, B * std::max((size_t)MOR_CG_OVF * 4, (size_t)MOR_MAXP * MOR_CGS_OVF * 4));
-  ok = ok && dalloc(b, d.ppos, B * N) && dalloc(b, d.pslot, B * N) && dalloc(b, d.gh_rowlist, B * N) && dalloc(b, d.gh_rowfill, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, d.gh_key, B * (size_t)d.Hcell) && dalloc(b, d.gh_val, B * (size_t)d.Hcell);
+  ok = ok && dalloc(b, d.ppos, B * N) && dalloc(b, d.pslot, B * N) && dalloc(b, d.gh_rowlist, B * N) && dalloc(b, d.gh_cells, B * N) && dalloc(b, d.gh_rowfill, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, d.gh_key, B * (size_t)d.Hcell) && dalloc(b, d.gh_val, B * (size_t)d.Hcell);
   ok = ok && dalloc(b, d.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, d.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, d.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, d.lroot_a, B * N) && dalloc(b, d.lroot_b, B * N) && dalloc(b, d.parent2, B * N);
   ok = ok && dalloc(b, d.xcent, B * K) && dalloc(b, d.xamin, B * K) && dalloc(b, d.xamax, B * K);
   for (int i = 0; i < 4; ++i)
@@ -387,9 +387,10 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     uint32_t maxocc = 0;
     std::vector<uint32_t> occ(B);
     for (int s = 0; s < B; ++s) { occ[s] = k > 0 ? d.h_info[s].n_occ : 0; maxocc = std::max(maxocc, occ[s]); }
-    const int p_fit = (int)((maxocc * 3ull / 2 + 3275) / 3276), p_par = (512 + B - 1) / B;
+    const int p_fit = (int)((maxocc * 3ull / 2 + 1637) / 1638), p_par = (512 + B - 1) / B;   // a slab's LDS holds 2048 cells
     d.P = b->env_cg_p > 0 ? b->env_cg_p : std::max(p_fit, p_par);
     d.P = std::max(1, std::min(d.P, std::min(MOR_MAXP, std::max(1, d.g.ny / 2))));
+    if (!getenv("MOR_GH_TIER")) d.gh_tier = maxocc * 5ull / 4 > 6144 ? (maxocc * 5ull / 4 > 12288 ? 2 : 1) : 0;   // table tier k_gridhash starts with (a stream whose table overflows moves up by itself)
     d.cg_help_min = 0;
     const int frac = b->env_help_pct;   // share of the streams, in percent
     if (d.cg_mode == 0 && k > 0 && B >= 8 && frac > 0) {

@@ -601,16 +601,18 @@ template <bool L> __device__ __forceinline__ void slab_bounds(const MorDev &d, i
   }
   __syncthreads();
 }
-// TL / RL: hash table / row table in LDS (else global memory).  Returns false when the table overflowed (nothing
-// published yet: the caller re-runs with a bigger table).
-template <bool TL, bool RL> __device__ __forceinline__ bool gh_run(const MorDev &d, int s, int M, int *tkey, int *tval, int H, int cell_cap, int *rows, int *l_misc, int *l_sh) {
+// TL / RL / CL: hash table / row table / per-cell lists in LDS (else global memory).  Returns false when the table
+// overflowed (nothing published yet: the caller re-runs with a bigger table).  `cells` lists the claimed slots in
+// discovery order — every per-cell phase walks it (a few entries per thread) instead of the whole table; `rowlist`
+// first holds the x of the cells of every row, then (same memory) the point counts in compact-id order.
+template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(const MorDev &d, int s, int M, int *tkey, int *tval, int H, int cell_cap, int *rows, int *cells, int *rowlist, int *l_misc, int *l_sh) {
   const size_t so = (size_t)s * d.Nmax;
   const int *pkey = d.pkey + so; int *pslot = d.pslot + so, *ppos = d.ppos + so, *pcell = d.pcell + so;
   int *cstart = d.cstart + (size_t)s * (d.Nmax + 1), *ckey = d.ckey + so;
-  int2 *rowlist = d.gh_rowlist + so;
   const int nrows = d.g.nrows, nx = d.g.nx, tid = threadIdx.x;
   int hbits = 0; while ((1 << hbits) < H) ++hbits;
   const unsigned hshift = 32 - hbits, mask = (unsigned)H - 1u;
+  unsigned long long *chash = d.use_hash ? d.chash + (size_t)s * d.Hcell : nullptr;
   const size_t stw = (size_t)s * (MOR_MAXP + 2) + MOR_MAXP; (void)stw;
   ST2(stw, 0);
   for (int i = tid; i < H; i += GH_T) { gh_st<TL>(tkey + i, 0); gh_st<TL>(tval + i, 0); }
@@ -630,7 +632,7 @@ template <bool TL, bool RL> __device__ __forceinline__ bool gh_run(const MorDev 
         int k = gh_ld<TL>(tkey + h);
         if (k == 0) {
           k = atomicCAS(tkey + h, 0, want);
-          if (k == 0) { k = want; if (atomicAdd(&l_misc[0], 1) >= cell_cap) gh_st<true>(&l_misc[1], 1); }
+          if (k == 0) { k = want; const int n = atomicAdd(&l_misc[0], 1); if (n < cell_cap) gh_st<CL>(cells + n, (int)h); else gh_st<true>(&l_misc[1], 1); }
         }
         if (k == want) { ok = true; break; }
         h = (h + 1) & mask;
@@ -642,49 +644,50 @@ template <bool TL, bool RL> __device__ __forceinline__ bool gh_run(const MorDev 
   if (l_misc[1]) { __syncthreads(); return false; }
   const int nocc = l_misc[0];
   ST2(stw, 1);
+  if (chash) for (int i = tid; i < H; i += GH_T) chash[i] = 0ull;   // the scoring tiers' cell hash = this table with compact ids (entries follow below)
   // ---- cells per row → row table
   for (int r = tid; r <= nrows; r += GH_T) gh_st<RL>(rows + r, 0);
   __syncthreads();
-  for (int sl = tid; sl < H; sl += GH_T) { const int k = gh_ld<TL>(tkey + sl); if (k) atomicAdd(rows + (k - 1) / nx, 1); }
+  for (int e = tid; e < nocc; e += GH_T) { const int key = gh_ld<TL>(tkey + gh_ld<CL>(cells + e)) - 1; atomicAdd(rows + key / nx, 1); }
   __syncthreads();
   gh_scan<RL>(rows, nrows, l_sh);
   if (tid == 0) gh_st<RL>(rows + nrows, nocc);
   __syncthreads();
   if (RL) { int *grs = d.row_start + (size_t)s * (nrows + 1); for (int r = tid; r <= nrows; r += GH_T) grs[r] = rows[r]; }
   slab_bounds<RL>(d, s, rows, nocc, l_sh);
-  // ---- the cells of every row, listed (unordered) behind the row's first id.  The LDS copy of the row table serves as the
-  //      fill cursor itself (rows[r] becomes the END of row r; the table proper is in global memory by now); a row table
-  //      that lives in global memory stays intact and a scratch copy is the cursor
+  // ---- the x of the cells of every row, listed (unordered) behind the row's first id.  The LDS copy of the row table
+  //      serves as the fill cursor itself (rows[r] becomes the END of row r; the table proper is in global memory by now);
+  //      a row table that lives in global memory stays intact and a scratch copy is the cursor
   int *fill = rows;
   if (!RL) {
     fill = d.gh_rowfill + (size_t)s * (nrows + 1);
     for (int r = tid; r < nrows; r += GH_T) gh_st<false>(fill + r, gh_ld<false>(rows + r));
     __syncthreads();
   }
-  for (int sl = tid; sl < H; sl += GH_T) {
-    const int k = gh_ld<TL>(tkey + sl);
-    if (k) { const int key = k - 1, r = key / nx; const int pos = atomicAdd(fill + r, 1); rowlist[pos] = make_int2(sl, key - r * nx); }
+  for (int e = tid; e < nocc; e += GH_T) {
+    const int key = gh_ld<TL>(tkey + gh_ld<CL>(cells + e)) - 1, r = key / nx;
+    gh_st<CL>(rowlist + atomicAdd(fill + r, 1), key - r * nx);
   }
   __syncthreads();
-  // ---- compact id = first id of the row + cells of the row with a smaller x; counts in id order; slot → id
-  unsigned long long *chash = d.use_hash ? d.chash + (size_t)s * d.Hcell : nullptr;
-  for (int sl = tid; sl < H; sl += GH_T) {
-    const int k = gh_ld<TL>(tkey + sl);
-    if (k) {
-      const int key = k - 1, r = key / nx, x = key - r * nx;
-      const int b = RL ? (r ? gh_ld<RL>(rows + r - 1) : 0) : gh_ld<RL>(rows + r), e = RL ? gh_ld<RL>(rows + r) : gh_ld<RL>(rows + r + 1);
-      int c = b;
-      for (int q = b; q < e; ++q) c += rowlist[q].y < x;
-      ckey[c] = key; cstart[c] = gh_ld<TL>(tval + sl);
-      gh_st<TL>(tkey + sl, c + 1);
-      if (chash) chash[sl] = ((unsigned long long)(unsigned)k << 32) | (unsigned)c;
-    } else if (chash) chash[sl] = 0ull;
+  // ---- compact id = first id of the row + cells of the row with a smaller x; slot → id
+  for (int e = tid; e < nocc; e += GH_T) {
+    const int sl = gh_ld<CL>(cells + e), k = gh_ld<TL>(tkey + sl), key = k - 1, r = key / nx, x = key - r * nx;
+    const int b = RL ? (r ? gh_ld<RL>(rows + r - 1) : 0) : gh_ld<RL>(rows + r), e2 = RL ? gh_ld<RL>(rows + r) : gh_ld<RL>(rows + r + 1);
+    int c = b;
+    for (int q = b; q < e2; ++q) c += gh_ld<CL>(rowlist + q) < x;
+    ckey[c] = key;
+    gh_st<TL>(tkey + sl, c + 1);
+    if (chash) chash[sl] = ((unsigned long long)(unsigned)k << 32) | (unsigned)c;
   }
   __syncthreads();
-  gh_scan<false>(cstart, nocc, l_sh);   // counts → first position of every cell
+  // ---- point counts in id order (same memory as the row lists) → first position of every cell
+  int *cnt = rowlist;
+  for (int e = tid; e < nocc; e += GH_T) { const int sl = gh_ld<CL>(cells + e); gh_st<CL>(cnt + gh_ld<TL>(tkey + sl) - 1, gh_ld<TL>(tval + sl)); }
+  __syncthreads();
+  gh_scan<CL>(cnt, nocc, l_sh);
+  for (int c = tid; c < nocc; c += GH_T) cstart[c] = gh_ld<CL>(cnt + c);
   if (tid == 0) { cstart[nocc] = M; d.info[s].n_occ = nocc; d.info[s].hshift = hshift; }
-  __syncthreads();
-  for (int sl = tid; sl < H; sl += GH_T) { const int c1 = gh_ld<TL>(tkey + sl); if (c1) gh_st<TL>(tval + sl, gh_ld<false>(cstart + c1 - 1)); }
+  for (int e = tid; e < nocc; e += GH_T) { const int sl = gh_ld<CL>(cells + e); gh_st<TL>(tval + sl, gh_ld<CL>(cnt + gh_ld<TL>(tkey + sl) - 1)); }
   __syncthreads();
   ST2(stw, 2);
   // ---- sweep 2: position of every point inside its cell's range
@@ -703,20 +706,36 @@ template <bool TL, bool RL> __device__ __forceinline__ bool gh_run(const MorDev 
   ST2(stw, 3); ST2V(stw, 4, M); ST2V(stw, 5, nocc);
   return true;
 }
+// LDS layouts of k_gridhash (ints): tier 0 — table of GH_H0 slots, row table, cell list and row lists all in LDS
+// (≤ GH_C0 cells); tier 1 — table of GH_H slots and the row table in LDS, the per-cell lists in global scratch (≤ 3/4·GH_H
+// cells); tier 2 — everything in global memory.  A stream starts at the tier the previous frame's cell counts suggest
+// (d.gh_tier) and moves up when its table overflows.
+#define GH_H0 8192
+#define GH_C0 6144
+#define GH_LDS_INTS (2 * GH_H + GH_ROWS + 1)
+static_assert(2 * GH_H0 + GH_ROWS + 1 + 2 * GH_C0 <= GH_LDS_INTS, "tier-0 layout must fit the tier-1 arena");
 __global__ __launch_bounds__(GH_T) void k_gridhash(MorDev d) {
   const int s = blockIdx.x + d.s0, M = d.info[s].M;
-  __shared__ int l_tab[2 * GH_H], l_rows[GH_ROWS + 1], l_misc[4], l_sh[48];
+  __shared__ int l_mem[GH_LDS_INTS], l_misc[4], l_sh[48];
   const bool rows_lds = d.g.nrows <= GH_ROWS;
   int *grows = d.row_start + (size_t)s * (d.g.nrows + 1);
-  const int Hl = min(GH_H, d.Hcell);
+  const size_t so = (size_t)s * d.Nmax;
+  int *g_cells = d.gh_cells + so, *g_rowlist = d.gh_rowlist + so;
   bool done = false;
-  if (!d.gh_force_global) {
-    if (rows_lds) done = gh_run<true, true>(d, s, M, l_tab, l_tab + Hl, Hl, Hl / 4 * 3, l_rows, l_misc, l_sh);
-    else done = gh_run<true, false>(d, s, M, l_tab, l_tab + Hl, Hl, Hl / 4 * 3, grows, l_misc, l_sh);
+  if (d.gh_tier <= 0) {
+    const int H = min(GH_H0, d.Hcell);
+    int *rows = l_mem + 2 * GH_H0, *cells = rows + GH_ROWS + 1, *rl = cells + GH_C0;
+    if (rows_lds) done = gh_run<true, true, true>(d, s, M, l_mem, l_mem + H, H, min(GH_C0, H / 4 * 3), rows, cells, rl, l_misc, l_sh);
+    else done = gh_run<true, false, true>(d, s, M, l_mem, l_mem + H, H, min(GH_C0, H / 4 * 3), grows, cells, rl, l_misc, l_sh);
   }
-  if (!done) {   // more cells than the LDS table holds: table in global memory, sized for the cloud (cells ≤ M ≤ H/2)
+  if (!done && d.gh_tier <= 1) {
+    const int H = min(GH_H, d.Hcell);
+    if (rows_lds) done = gh_run<true, true, false>(d, s, M, l_mem, l_mem + H, H, H / 4 * 3, l_mem + 2 * GH_H, g_cells, g_rowlist, l_misc, l_sh);
+    else done = gh_run<true, false, false>(d, s, M, l_mem, l_mem + H, H, H / 4 * 3, grows, g_cells, g_rowlist, l_misc, l_sh);
+  }
+  if (!done) {   // table in global memory, sized for the cloud (cells ≤ M ≤ H/2)
     int H = 1024; while (H < 2 * M && H < d.Hcell) H <<= 1;
-    gh_run<false, false>(d, s, M, d.gh_key + (size_t)s * d.Hcell, d.gh_val + (size_t)s * d.Hcell, H, H, grows, l_misc, l_sh);
+    gh_run<false, false, false>(d, s, M, d.gh_key + (size_t)s * d.Hcell, d.gh_val + (size_t)s * d.Hcell, H, H, grows, g_cells, g_rowlist, l_misc, l_sh);
   }
 }
 // the points into cell order: sorted[position] = (x, y, z, bits(cloud index))
@@ -1262,93 +1281,141 @@ __global__ __launch_bounds__(CG_T) void k_cellgraph(MorDev d) {
 // that range, the LOCAL root.  A forest is equivalent to the edge set {(c, root(c))}, so k_cg_final re-unites
 // (c, root_own(c)) and (c, root_lookahead-of-the-previous-slab(c)) in one forest per stream and gets exactly the
 // components of the full edge set — every edge was found by the slab owning its lower-y cell.
-#define CGS_T 256
+#define CGS_T 512
 #ifndef CGS_CAP
-#define CGS_CAP 4096      // local cells (own + look-ahead) held in LDS
+#define CGS_CAP 2048      // local cells (own + look-ahead) held in LDS
 #endif
-#define CGS_ROWCAP 4096   // local (y,z) rows held in LDS
+#define CGS_ROWCAP 3840   // local (y,z) rows held in LDS (with the rest: just under half a CU's LDS, two workgroups per CU)
+#define CGS_NW (CGS_T / 64)
+#define CGS_WLIST (2 * CG_LIST / CGS_NW)      // LDS list entries per wave (one packed pair each)
+#define CGS_WOVF (MOR_CGS_OVF / CGS_NW)       // global overflow entries per wave
 static_assert(CGS_CAP <= 16384, "pair lists pack two local cell ids into 28 bits");
-template <bool LDS> __device__ __forceinline__ void cgs_list_put(int *ovf, int *l_list, int slot, int region, int a, int b) {
-  constexpr int W = LDS ? 1 : 2, NL = 2 * CG_LIST / W;
-  if (region == 0 && slot < NL) { if (LDS) l_list[slot] = (a << 14) | b; else { l_list[2 * slot] = a; l_list[2 * slot + 1] = b; } return; }
-  int *ov = ovf + (size_t)region * MOR_CGS_OVF * 2 + (size_t)(region == 0 ? slot - NL : slot) * W;
-  if (LDS) cg_st<false>(ov, (a << 14) | b); else { cg_st<false>(ov, a); cg_st<false>(ov + 1, b); }
+// Candidate pairs are appended by the wave that finds them to ITS OWN list (LDS part + global overflow part): the
+// position comes from a wave-uniform counter in a register, so enumeration needs no atomic and no round trip per append.
+// (LDS mode: local ids < 16384, a pair is one word a << 14 | b; global mode: two words per pair, half the capacity.)
+template <bool LDS> __device__ __forceinline__ int cgs_wlist_cap() { return (CGS_WLIST + CGS_WOVF) / (LDS ? 1 : 2); }
+template <bool LDS> __device__ __forceinline__ void cgs_wlist_put(int *ovf, int *l_list, int w, int slot, int a, int b) {
+  if (LDS) {
+    if (slot < CGS_WLIST) l_list[w * CGS_WLIST + slot] = (a << 14) | b;
+    else cg_st<false>(ovf + (size_t)w * CGS_WOVF + (slot - CGS_WLIST), (a << 14) | b);
+  } else {
+    if (2 * slot + 1 < CGS_WLIST) { l_list[w * CGS_WLIST + 2 * slot] = a; l_list[w * CGS_WLIST + 2 * slot + 1] = b; }
+    else { int *o = ovf + (size_t)w * CGS_WOVF + (2 * slot - CGS_WLIST / 2 * 2); cg_st<false>(o, a); cg_st<false>(o + 1, b); }
+  }
 }
-template <bool LDS> __device__ __forceinline__ void cgs_list_get(const int *ovf, const int *l_list, int slot, int region, int &a, int &b) {
-  constexpr int W = LDS ? 1 : 2, NL = 2 * CG_LIST / W;
-  if (region == 0 && slot < NL) { if (LDS) { const int c = l_list[slot]; a = c >> 14; b = c & 16383; } else { a = l_list[2 * slot]; b = l_list[2 * slot + 1]; } return; }
-  const int *ov = ovf + (size_t)region * MOR_CGS_OVF * 2 + (size_t)(region == 0 ? slot - NL : slot) * W;
-  if (LDS) { const int c = cg_ld<false>(ov); a = c >> 14; b = c & 16383; } else { a = cg_ld<false>(ov); b = cg_ld<false>(ov + 1); }
+template <bool LDS> __device__ __forceinline__ void cgs_wlist_get(const int *ovf, const int *l_list, int w, int slot, int &a, int &b) {
+  if (LDS) {
+    const int c = slot < CGS_WLIST ? l_list[w * CGS_WLIST + slot] : cg_ld<false>(ovf + (size_t)w * CGS_WOVF + (slot - CGS_WLIST));
+    a = c >> 14; b = c & 16383;
+  } else {
+    if (2 * slot + 1 < CGS_WLIST) { a = l_list[w * CGS_WLIST + 2 * slot]; b = l_list[w * CGS_WLIST + 2 * slot + 1]; }
+    else { const int *o = ovf + (size_t)w * CGS_WOVF + (2 * slot - CGS_WLIST / 2 * 2); a = cg_ld<false>(o); b = cg_ld<false>(o + 1); }
+  }
 }
-template <bool LDS> __device__ __forceinline__ int cgs_list_cap(int region) { return (region == 0 ? 2 * CG_LIST / (LDS ? 1 : 2) : 0) + MOR_CGS_OVF * (LDS ? 2 : 1); }
+// second list (undecided big pairs), global only
+template <bool LDS> __device__ __forceinline__ int cgs_list2_cap() { return MOR_CGS_OVF / (LDS ? 1 : 2); }
+template <bool LDS> __device__ __forceinline__ void cgs_list2_put(int *ovf, int slot, int a, int b) {
+  if (LDS) cg_st<false>(ovf + MOR_CGS_OVF + slot, (a << 14) | b); else { cg_st<false>(ovf + MOR_CGS_OVF + 2 * slot, a); cg_st<false>(ovf + MOR_CGS_OVF + 2 * slot + 1, b); }
+}
+template <bool LDS> __device__ __forceinline__ void cgs_list2_get(const int *ovf, int slot, int &a, int &b) {
+  if (LDS) { const int c = cg_ld<false>(ovf + MOR_CGS_OVF + slot); a = c >> 14; b = c & 16383; } else { a = cg_ld<false>(ovf + MOR_CGS_OVF + 2 * slot); b = cg_ld<false>(ovf + MOR_CGS_OVF + 2 * slot + 1); }
+}
 // One hook pass of a slab.  Local ids: own cells [0, n_own), look-ahead [n_own, n_loc).  key[] = keys of the local cells,
-// rows[] = row table of the slab's rows (row r0 first) holding LOCAL ids minus `rsub` (0 for the LDS copy, the slab's first
+// rows[] = row table of the slab's rows (row r0 first) holding LOCAL ids plus `rsub` (0 for the LDS copy, the slab's first
 // compact id when the global table is read in place); soc = first slot of the slab's cells in the per-cell global arrays.
-template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(const MorDev &d, size_t soc, int n_own, const int *key, const int *start, const int *rows, int rsub, int r0, int nlrows,
-                                                                            int *par, const float4 *sp, int *ovf, int *l_list, int *l_nlist, int *l_n2, size_t stw) {
+// LDS mode also has pc[] (the cells' coordinates, packed) and rep[] (one point per cell).
+//  A   one lane per (own cell, neighbour row) — rows are short, so a lane's walk is a couple of LDS loads: every forward
+//      neighbour in another component whose SAMPLE point lies within r of the cell's sample is united on the spot (most
+//      neighbouring cells of one surface); the others go to the wave's candidate list.
+//  B1  one thread per listed pair: roots re-checked, point boxes, then the points; big × big undecided → second list.
+//  B2  one wave per pair of the second list: pruned exhaustive test.
+template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(const MorDev &d, size_t soc, int n_own, const int *key, const int *pc, const float *rx, const float *ry, const float *rz, const int *start, const int *rows, int rsub, int r0, int nlrows,
+                                                                            int *par, const float4 *sp, int *ovf, int *l_list, int *l_wcnt, int *l_n2, size_t stw) {
   const float r2 = d.r2;
+  constexpr int NR = (RING + 1) + RING * (2 * RING + 1);   // rows of the forward half: dy = 0: dz 0…RING; dy = 1…RING: dz −RING…RING
+  const int w = wave_id(), lane = lane_id();
+  int wcount = 0;
   ST2(stw, (RING - 1) * 4 + 1);
-  // ---- A: candidate pairs (own cell a, forward neighbour b in another component), LDS only
-  for (int a = threadIdx.x; a < n_own; a += CGS_T) {
-    const int ka = key[a], rowa = ka / d.g.nx, x = ka - rowa * d.g.nx, z = rowa % d.g.nz, y = rowa / d.g.nz;
-    const int ra = cg_find<LDS>(par, a);
-    for (int dy = 0; dy <= RING; ++dy) {
-      if (y + dy >= d.g.ny) break;
-      for (int dz = (dy == 0 ? 0 : -RING); dz <= RING; ++dz) {
-        if ((unsigned)(z + dz) >= (unsigned)d.g.nz) continue;
-        const bool edge_row = dy == RING || abs(dz) == RING;   // every cell of this row lies on the ring
+  for (int it0 = 0; it0 < n_own * NR; it0 += CGS_T) {
+    const int it = it0 + threadIdx.x;
+    int a = 0, x = 0, rowbase = 0, b = 0, hi = 0, ra = -1; bool edge_row = false, same_row = false;
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (it < n_own * NR) {
+      a = it / NR; const int ri = it - a * NR;
+      const int dy = ri <= RING ? 0 : 1 + (ri - RING - 1) / (2 * RING + 1), dz = ri <= RING ? ri : (ri - RING - 1) % (2 * RING + 1) - RING;
+      int y, z;
+      if (LDS) { const unsigned q = (unsigned)pc[a]; x = (int)(q & 2047u); z = (int)((q >> 11) & 1023u); y = (int)(q >> 21); }
+      else { const int ka = key[a], rowa = ka / d.g.nx; x = ka - rowa * d.g.nx; z = rowa % d.g.nz; y = rowa / d.g.nz; }
+      if (y + dy < d.g.ny && (unsigned)(z + dz) < (unsigned)d.g.nz) {
         const int rr = grid_row(d.g, y + dy, z + dz), rl = rr - r0;
-        if (rl < 0 || rl >= nlrows) continue;                  // (cannot happen: the slab's rows cover y … y+2)
-        const int rlo = rows[rl] - rsub, rn = rows[rl + 1] - rsub - rlo;
-        if (rn == 0) continue;
-        const int rowbase = rr * d.g.nx + x;
-        int lo = rlo; const int hi = rlo + rn;
-        if (rn > 8) lo = cg_lower_bound8(key, rlo, rn, rowbase - RING);
-        for (int b = lo; b < hi; ++b) {
-          const int dx = key[b] - rowbase;
-          if (dx > RING) break;
-          const bool fwd = !(dy == 0 && dz == 0 && dx <= 0);      // forward half: each unordered pair once
-          const bool ring = edge_row || abs(dx) == RING;           // inner cells belong to the previous pass
-          bool want = dx >= -RING && fwd && ring;
-          if (want) { const int pb = cg_ld<LDS>(par + b); want = pb != ra && cg_find<LDS>(par, b) != ra; }
-          const unsigned long long m = __ballot(want);
-          if (m) {
-            const int leader = __ffsll((long long)m) - 1; int base = 0;
-            if (lane_id() == leader) base = atomicAdd(l_nlist, __popcll(m));
-            base = __shfl(base, leader, 64);
-            if (want) {
-              const int slot = base + __popcll(m & lanemask_lt());
-              if (slot < cgs_list_cap<LDS>(0)) cgs_list_put<LDS>(ovf, l_list, slot, 0, a, b);
-              else { const int a0 = start[a], b0 = start[b]; if (pair_hit_serial(sp, a0, start[a + 1] - a0, b0, start[b + 1] - b0, r2)) cg_unite<LDS>(par, a, b); }
-            }
-          }
+        if (rl >= 0 && rl < nlrows) {
+          const int rlo = rows[rl] - rsub, rn = rows[rl + 1] - rsub - rlo;
+          rowbase = rr * d.g.nx + x; b = rlo; hi = rlo + rn;
+          if (rn > 8) b = cg_lower_bound8(key, rlo, rn, rowbase - RING);
+          edge_row = dy == RING || abs(dz) == RING; same_row = dy == 0 && dz == 0;
+          if (b < hi) { ra = cg_find<LDS>(par, a); if (LDS) pa = make_float4(rx[a], ry[a], rz[a], 0.f); else pa = d.crep[soc + a]; }
         }
       }
     }
+    // walk the (≤ 2·RING+1 relevant) cells of the row; lanes of the wave step together so the list append stays wave-uniform
+    for (;;) {
+      bool want = false; int bb = b;
+      if (b < hi) {
+        const int dx = key[b] - rowbase;
+        if (dx > RING) b = hi;
+        else {
+          const bool fwd = !(same_row && dx <= 0), ring = edge_row || abs(dx) == RING;
+          want = dx >= -RING && fwd && ring;
+          if (want) { const int pb = cg_ld<LDS>(par + b); want = pb != ra && cg_find<LDS>(par, b) != ra; }
+          if (want) {   // sample points of the two cells within r: an edge, no need to look at boxes or points
+            float4 pq; if (LDS) pq = make_float4(rx[b], ry[b], rz[b], 0.f); else pq = d.crep[soc + b];
+            if (sqdist(pa.x, pa.y, pa.z, pq.x, pq.y, pq.z) < r2) { cg_unite<LDS>(par, a, b); want = false; }
+          }
+          ++b;
+        }
+      }
+      const unsigned long long m = __ballot(want);
+      if (m) {
+        if (want) {
+          const int slot = wcount + __popcll(m & lanemask_lt());
+          if (slot < cgs_wlist_cap<LDS>()) cgs_wlist_put<LDS>(ovf, l_list, w, slot, a, bb);
+          else { const int a0 = start[a], b0 = start[bb]; if (pair_hit_serial(sp, a0, start[a + 1] - a0, b0, start[bb + 1] - b0, r2)) cg_unite<LDS>(par, a, bb); }   // lists full (never seen): settle it here
+        }
+        wcount += __popcll(m);
+      }
+      if (!__ballot(b < hi)) break;
+    }
   }
+  if (lane == 0) l_wcnt[w] = min(wcount, cgs_wlist_cap<LDS>());
   __threadfence_block();
   __syncthreads();
   ST2(stw, (RING - 1) * 4 + 2);
-  // ---- B1: one thread per candidate pair
-  const int n1 = min(*l_nlist, cgs_list_cap<LDS>(0));
+  // ---- B1: one thread per candidate pair (the waves' lists, back to back)
+  int pre[CGS_NW + 1]; pre[0] = 0;
+#pragma unroll
+  for (int u = 0; u < CGS_NW; ++u) pre[u + 1] = pre[u] + l_wcnt[u];
+  const int n1 = pre[CGS_NW];
   for (int h = threadIdx.x; h < n1; h += CGS_T) {
-    int a, b; cgs_list_get<LDS>(ovf, l_list, h, 0, a, b);
+    int lw = 0;
+#pragma unroll
+    for (int u = 1; u < CGS_NW; ++u) lw += h >= pre[u];
+    int a, b; cgs_wlist_get<LDS>(ovf, l_list, lw, h - pre[lw], a, b);
     if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;
     const int verdict = cg_pair_test(d, soc, start, sp, a, b, r2);
     if (verdict > 0) cg_unite<LDS>(par, a, b);
     else if (verdict < 0) {
       const int slot = atomicAdd(l_n2, 1);
-      if (slot < cgs_list_cap<LDS>(1)) cgs_list_put<LDS>(ovf, l_list, slot, 1, a, b);
+      if (slot < cgs_list2_cap<LDS>()) cgs_list2_put<LDS>(ovf, slot, a, b);
       else { const int a0 = start[a], b0 = start[b]; if (pair_hit_serial(sp, a0, start[a + 1] - a0, b0, start[b + 1] - b0, r2)) cg_unite<LDS>(par, a, b); }
     }
   }
-  __threadfence_block();
+  __threadfence();
   __syncthreads();
   ST2(stw, (RING - 1) * 4 + 3);
   // ---- B2: one wave per undecided big pair
-  const int n2 = min(*l_n2, cgs_list_cap<LDS>(1)), lane = lane_id();
-  for (int h = wave_id(); h < n2; h += CGS_T / 64) {
-    int a, b; cgs_list_get<LDS>(ovf, l_list, h, 1, a, b);
+  const int n2 = min(*l_n2, cgs_list2_cap<LDS>());
+  for (int h = w; h < n2; h += CGS_NW) {
+    int a, b; cgs_list2_get<LDS>(ovf, h, a, b);
     if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;
     const float4 alo = d.cmeta[2 * (soc + a)], ahi = d.cmeta[2 * (soc + a) + 1], blo = d.cmeta[2 * (soc + b)], bhi = d.cmeta[2 * (soc + b) + 1];
     if (pair_hit_wave(sp, start[a], start[a + 1] - start[a], start[b], start[b + 1] - start[b], r2, lane, alo, ahi, blo, bhi) && lane == 0) cg_unite<LDS>(par, a, b);
@@ -1356,16 +1423,16 @@ template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(cons
   ST2(stw, (RING - 1) * 4 + 4);
   ST2V(stw, 10 + (RING - 1) * 2, n1); ST2V(stw, 11 + (RING - 1) * 2, n2);
   __syncthreads();
-  if (threadIdx.x == 0) { *l_nlist = 0; *l_n2 = 0; }
+  if (threadIdx.x == 0) *l_n2 = 0;
   __syncthreads();
 }
-template <bool LDS> __device__ __forceinline__ void cgs_body(const MorDev &d, int s, size_t so, int c0, int n_own, int n_loc, const int *key, const int *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_nlist, int *l_n2, size_t stwj) {
+template <bool LDS> __device__ __forceinline__ void cgs_body(const MorDev &d, int s, size_t so, int c0, int n_own, int n_loc, const int *key, const int *pc, const float *rx, const float *ry, const float *rz, const int *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_wcnt, int *l_n2, size_t stwj) {
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1) + c0;   // start[local id]: first position of the cell in `sorted`
   const float4 *sp = d.sorted + so;
-  cgs_hook_pass<LDS, 1>(d, so + c0, n_own, key, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_nlist, l_n2, stwj);
+  cgs_hook_pass<LDS, 1>(d, so + c0, n_own, key, pc, rx, ry, rz, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_wcnt, l_n2, stwj);
   for (int c = threadIdx.x; c < n_loc; c += CGS_T) { const int r = cg_find<LDS>(par, c); if (r != c) cg_st<LDS>(par + c, r); }   // flat forest: the shell pass compares parents directly
   __syncthreads();
-  cgs_hook_pass<LDS, 2>(d, so + c0, n_own, key, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_nlist, l_n2, stwj);
+  cgs_hook_pass<LDS, 2>(d, so + c0, n_own, key, pc, rx, ry, rz, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_wcnt, l_n2, stwj);
   // local roots as global compact ids: own cells → lroot_a, look-ahead cells → lroot_b
   for (int c = threadIdx.x; c < n_loc; c += CGS_T) {
     const int r = c0 + cg_find<LDS>(par, c);
@@ -1382,22 +1449,27 @@ __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {
   const size_t stwj = (size_t)s * (MOR_MAXP + 2) + j; (void)stwj;
   ST2(stwj, 0);
   const int y0 = sy[j], y2 = min(sy[j + 1] + 2, d.g.ny), r0 = y0 * d.g.nz, nlrows = (y2 - y0) * d.g.nz;
-  __shared__ int l_key[CGS_CAP], l_par[CGS_CAP], l_rows[CGS_ROWCAP + 1], l_list[2 * CG_LIST], l_nlist, l_n2;
-  int *ovf = d.cg_ovf + (size_t)(s * MOR_MAXP + j) * MOR_CGS_OVF * 4;
+  __shared__ float l_rx[CGS_CAP], l_ry[CGS_CAP], l_rz[CGS_CAP];
+  __shared__ int l_key[CGS_CAP], l_par[CGS_CAP], l_pc[CGS_CAP], l_rows[CGS_ROWCAP + 1], l_list[2 * CG_LIST], l_wcnt[CGS_NW], l_n2;
+  int *ovf = d.cg_ovf + (size_t)(s * MOR_MAXP + j) * MOR_CGS_OVF * 2;   // [0, MOR_CGS_OVF): the waves' candidate lists, [MOR_CGS_OVF, 2·MOR_CGS_OVF): undecided big pairs
   const int *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1) + r0;
-  if (threadIdx.x == 0) { l_nlist = 0; l_n2 = 0; }
+  if (threadIdx.x == 0) l_n2 = 0;
   if (n_loc <= CGS_CAP && nlrows <= CGS_ROWCAP && !d.cg_force_global) {
-    const int *gk = d.ckey + so + c0;
-    for (int i = threadIdx.x; i < n_loc; i += CGS_T) { l_key[i] = gk[i]; l_par[i] = i; }
+    const int *gk = d.ckey + so + c0; const float4 *grep = d.crep + so + c0;
+    for (int i = threadIdx.x; i < n_loc; i += CGS_T) {
+      const int k = gk[i], row = k / d.g.nx;
+      l_key[i] = k; l_par[i] = i; l_pc[i] = (int)((unsigned)(k - row * d.g.nx) | ((unsigned)(row % d.g.nz) << 11) | ((unsigned)(row / d.g.nz) << 21));
+      const float4 q = grep[i]; l_rx[i] = q.x; l_ry[i] = q.y; l_rz[i] = q.z;
+    }
     for (int i = threadIdx.x; i <= nlrows; i += CGS_T) l_rows[i] = g_rows[i] - c0;
     __syncthreads();
-    cgs_body<true>(d, s, so, c0, n_own, n_loc, l_key, l_rows, 0, r0, nlrows, l_par, ovf, l_list, &l_nlist, &l_n2, stwj);
+    cgs_body<true>(d, s, so, c0, n_own, n_loc, l_key, l_pc, l_rx, l_ry, l_rz, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_wcnt, &l_n2, stwj);
   } else {   // slab too big for LDS: the same code on global arrays (even and odd slabs use different forests: look-aheads overlap the next slab)
     int *par = ((j & 1) ? d.parent2 : d.parent) + so + c0;
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) cg_st<false>(par + i, i);
     __threadfence();
     __syncthreads();
-    cgs_body<false>(d, s, so, c0, n_own, n_loc, d.ckey + so + c0, g_rows, c0, r0, nlrows, par, ovf, l_list, &l_nlist, &l_n2, stwj);
+    cgs_body<false>(d, s, so, c0, n_own, n_loc, d.ckey + so + c0, nullptr, nullptr, nullptr, nullptr, g_rows, c0, r0, nlrows, par, ovf, l_list, l_wcnt, &l_n2, stwj);
   }
 }
 // One workgroup per stream: merges the slab forests, then components (size, smallest cloud index), the kept clusters

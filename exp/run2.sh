@@ -2,9 +2,19 @@
 set -u
 O=gpurun_out/r2c2; mkdir -p $O
 export TMPDIR=/tmp
-echo "== check_grid global-memory table"; MOR_GH_GLOBAL=1 MOR_CG_GLOBAL=1 timeout 300 python exp/check_grid.py hdl64 2000 2 > $O/check_global.log 2>&1; echo rc=$?; grep -c "^ok" $O/check_global.log; grep FAIL $O/check_global.log
+echo "== check_grid global-memory table"; MOR_GH_TIER=2 MOR_CG_GLOBAL=1 timeout 300 python exp/check_grid.py hdl64 2000 2 > $O/check_global.log 2>&1; echo rc=$?; grep -c "^ok" $O/check_global.log; grep FAIL $O/check_global.log
 echo "== pytest default"; timeout 900 python -m pytest tests -m gpu -q > $O/pytest_new.log 2>&1; echo rc=$?; tail -12 $O/pytest_new.log
-echo "== pytest global variants"; MOR_GH_GLOBAL=1 MOR_CG_GLOBAL=1 timeout 900 python -m pytest tests -m gpu -q -x -k "hdl64_full or small_streams or known or edge or batch_of_8" > $O/pytest_global.log 2>&1; echo rc=$?; tail -5 $O/pytest_global.log
+echo "== pytest global variants"; MOR_GH_TIER=2 MOR_CG_GLOBAL=1 timeout 900 python -m pytest tests -m gpu -q -x -k "hdl64_full or small_streams or known or edge or batch_of_8" > $O/pytest_global.log 2>&1; echo rc=$?; tail -5 $O/pytest_global.log
 echo "== stamps P default"; timeout 300 python exp/stamps2.py 64 > $O/stamps_default.log 2>&1; cat $O/stamps_default.log
 echo "== stamps P=4"; MOR_CG_P=4 timeout 300 python exp/stamps2.py 64 > $O/stamps_p4.log 2>&1; grep -E "k_cg_slab|  (load|A1|B1_1|B2_1|A2|B1_2|B2_2) " $O/stamps_p4.log
 echo "== stamps P=16"; MOR_CG_P=16 timeout 300 python exp/stamps2.py 64 > $O/stamps_p16.log 2>&1; grep -E "k_cg_slab|  (load|A1|B1_1|B2_1|A2|B1_2|B2_2) " $O/stamps_p16.log
+echo "== pytest tier1"; MOR_GH_TIER=1 timeout 900 python -m pytest tests -m gpu -q -x -k "hdl64_full or small_streams or known or edge or batch_of_8" > $O/pytest_tier1.log 2>&1; echo rc=$?; tail -3 $O/pytest_tier1.log
+echo "== bench default"; timeout 600 python bench.py --steps 100 --warmup 5 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; echo rc=$?
+python - <<PY
+import json
+try:
+    d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
+    print("value", d["value"], "ms/step", d["ms_per_step"], "dev_ms", d["device_ms_per_step"])
+    for k,v in sorted(d["kernels"].items(), key=lambda kv:-kv[1]["ms_total"]): print("   %-18s %8.1f us x%d   alone %s" % (k, v["avg_us"], v["launches"], d["kernels_alone_avg_us"].get(k)))
+except Exception as e: print("bench parse failed", e); print(open("$O/bench.err").read()[-2000:])
+PY
