@@ -41,7 +41,7 @@ def build_hip_smalllist(force=False):
     if not force and not _newer(out, deps):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-DCG_LIST=8",
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-DCG_LIST=8", "-DCGS_LISTW=16",
                            "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-x", "hip"] + [os.path.join(CSRC, f) for f in HIP_SOURCES] + ["-o", out])
     return out
 

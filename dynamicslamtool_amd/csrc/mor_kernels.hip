@@ -1283,11 +1283,14 @@ __global__ __launch_bounds__(CG_T) void k_cellgraph(MorDev d) {
 // components of the full edge set — every edge was found by the slab owning its lower-y cell.
 #define CGS_T 512
 #ifndef CGS_CAP
-#define CGS_CAP 2048      // local cells (own + look-ahead) held in LDS
+#define CGS_CAP 1024      // local cells (own + look-ahead) held in LDS
 #endif
-#define CGS_ROWCAP 3840   // local (y,z) rows held in LDS (with the rest: just under half a CU's LDS, two workgroups per CU)
+#define CGS_ROWCAP 3584   // local (y,z) rows held in LDS
+#ifndef CGS_LISTW
+#define CGS_LISTW 2048    // LDS words of the candidate-pair lists
+#endif
 #define CGS_NW (CGS_T / 64)
-#define CGS_WLIST (2 * CG_LIST / CGS_NW)      // LDS list entries per wave (one packed pair each)
+#define CGS_WLIST (CGS_LISTW / CGS_NW)        // LDS list entries per wave (one packed pair each)
 #define CGS_WOVF (MOR_CGS_OVF / CGS_NW)       // global overflow entries per wave
 static_assert(CGS_CAP <= 16384, "pair lists pack two local cell ids into 28 bits");
 // Candidate pairs are appended by the wave that finds them to ITS OWN list (LDS part + global overflow part): the
@@ -1312,7 +1315,7 @@ template <bool LDS> __device__ __forceinline__ void cgs_wlist_get(const int *ovf
     else { const int *o = ovf + (size_t)w * CGS_WOVF + (2 * slot - CGS_WLIST / 2 * 2); a = cg_ld<false>(o); b = cg_ld<false>(o + 1); }
   }
 }
-// second list (undecided big pairs), global only
+// second list (pairs for a whole wave), global only
 template <bool LDS> __device__ __forceinline__ int cgs_list2_cap() { return MOR_CGS_OVF / (LDS ? 1 : 2); }
 template <bool LDS> __device__ __forceinline__ void cgs_list2_put(int *ovf, int slot, int a, int b) {
   if (LDS) cg_st<false>(ovf + MOR_CGS_OVF + slot, (a << 14) | b); else { cg_st<false>(ovf + MOR_CGS_OVF + 2 * slot, a); cg_st<false>(ovf + MOR_CGS_OVF + 2 * slot + 1, b); }
@@ -1320,18 +1323,45 @@ template <bool LDS> __device__ __forceinline__ void cgs_list2_put(int *ovf, int 
 template <bool LDS> __device__ __forceinline__ void cgs_list2_get(const int *ovf, int slot, int &a, int &b) {
   if (LDS) { const int c = cg_ld<false>(ovf + MOR_CGS_OVF + slot); a = c >> 14; b = c & 16383; } else { a = cg_ld<false>(ovf + MOR_CGS_OVF + 2 * slot); b = cg_ld<false>(ovf + MOR_CGS_OVF + 2 * slot + 1); }
 }
+// Point test of one pair by one thread, as few levels of dependent loads as possible: up to 8 points of the smaller
+// cell in registers, the other cell streamed eight independent loads at a time (at most 64 of its points).
+// Returns 1 = edge, 0 = no edge (every pair was looked at), −1 = undecided (a sample only: the pair goes to a wave).
+__device__ __forceinline__ int pair_points_thread(const float4 *sp, int a0, int na, int b0, int nb, float r2) {
+  if (na > nb) { int t = a0; a0 = b0; b0 = t; t = na; na = nb; nb = t; }
+  float ax[8], ay[8], az[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const float4 p = sp[a0 + min(i, na - 1)]; ax[i] = p.x; ay[i] = p.y; az[i] = p.z; }   // clamped duplicates repeat real points
+  const int lim = min(nb, 64);
+  for (int j0 = 0; j0 < lim; j0 += 8) {
+    float4 q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = sp[b0 + min(j0 + j, nb - 1)];
+    bool hit = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) hit |= sqdist(ax[i], ay[i], az[i], q[j].x, q[j].y, q[j].z) < r2;
+    if (hit) return 1;
+  }
+  return (na <= 8 && nb <= 64) ? 0 : -1;
+}
 // One hook pass of a slab.  Local ids: own cells [0, n_own), look-ahead [n_own, n_loc).  key[] = keys of the local cells,
 // rows[] = row table of the slab's rows (row r0 first) holding LOCAL ids plus `rsub` (0 for the LDS copy, the slab's first
 // compact id when the global table is read in place); soc = first slot of the slab's cells in the per-cell global arrays.
-// LDS mode also has pc[] (the cells' coordinates, packed) and rep[] (one point per cell).
-//  A   one lane per (own cell, neighbour row) — rows are short, so a lane's walk is a couple of LDS loads: every forward
-//      neighbour in another component whose SAMPLE point lies within r of the cell's sample is united on the spot (most
-//      neighbouring cells of one surface); the others go to the wave's candidate list.
-//  B1  one thread per listed pair: roots re-checked, point boxes, then the points; big × big undecided → second list.
-//  B2  one wave per pair of the second list: pruned exhaustive test.
-template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(const MorDev &d, size_t soc, int n_own, const int *key, const int *pc, const float *rx, const float *ry, const float *rz, const int *start, const int *rows, int rsub, int r0, int nlrows,
+// LDS mode also holds, per local cell: pc[] (its coordinates, packed), one sample point (rx, ry, rz), its point box
+// (bx[0..5]: low corner, high corner) and cs[] = first position of its points (cs[n_loc] = end) — so the enumeration
+// decides most pairs without a single global load:
+//  A   one lane per (own cell, neighbour row) — rows are short, a lane's walk is a couple of LDS loads.  A forward
+//      neighbour in another component is an edge when the two SAMPLE points lie within r (most neighbouring cells of one
+//      surface) or when the farthest corners of the two point boxes do; it is no edge when the boxes are ≥ r apart;
+//      only what is left goes to the wave's candidate list.
+//  B1  one thread per listed pair: roots re-checked, then the points (pair_points_thread).
+//  B2  one wave per pair the thread test could not finish (big cells): pruned exhaustive test.
+template <bool LDS> struct CgsCells { const int *key, *pc, *cs; const float *rx, *ry, *rz, *bx; };
+template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(const MorDev &d, size_t soc, int n_own, int n_loc, const CgsCells<LDS> &L, const int *start, const int *rows, int rsub, int r0, int nlrows,
                                                                             int *par, const float4 *sp, int *ovf, int *l_list, int *l_wcnt, int *l_n2, size_t stw) {
   const float r2 = d.r2;
+  const int *key = L.key;
   constexpr int NR = (RING + 1) + RING * (2 * RING + 1);   // rows of the forward half: dy = 0: dz 0…RING; dy = 1…RING: dz −RING…RING
   const int w = wave_id(), lane = lane_id();
   int wcount = 0;
@@ -1339,12 +1369,12 @@ template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(cons
   for (int it0 = 0; it0 < n_own * NR; it0 += CGS_T) {
     const int it = it0 + threadIdx.x;
     int a = 0, x = 0, rowbase = 0, b = 0, hi = 0, ra = -1; bool edge_row = false, same_row = false;
-    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pax = 0.f, pay = 0.f, paz = 0.f, alx = 0.f, aly = 0.f, alz = 0.f, ahx = 0.f, ahy = 0.f, ahz = 0.f;
     if (it < n_own * NR) {
       a = it / NR; const int ri = it - a * NR;
       const int dy = ri <= RING ? 0 : 1 + (ri - RING - 1) / (2 * RING + 1), dz = ri <= RING ? ri : (ri - RING - 1) % (2 * RING + 1) - RING;
       int y, z;
-      if (LDS) { const unsigned q = (unsigned)pc[a]; x = (int)(q & 2047u); z = (int)((q >> 11) & 1023u); y = (int)(q >> 21); }
+      if (LDS) { const unsigned q = (unsigned)L.pc[a]; x = (int)(q & 2047u); z = (int)((q >> 11) & 1023u); y = (int)(q >> 21); }
       else { const int ka = key[a], rowa = ka / d.g.nx; x = ka - rowa * d.g.nx; z = rowa % d.g.nz; y = rowa / d.g.nz; }
       if (y + dy < d.g.ny && (unsigned)(z + dz) < (unsigned)d.g.nz) {
         const int rr = grid_row(d.g, y + dy, z + dz), rl = rr - r0;
@@ -1353,13 +1383,17 @@ template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(cons
           rowbase = rr * d.g.nx + x; b = rlo; hi = rlo + rn;
           if (rn > 8) b = cg_lower_bound8(key, rlo, rn, rowbase - RING);
           edge_row = dy == RING || abs(dz) == RING; same_row = dy == 0 && dz == 0;
-          if (b < hi) { ra = cg_find<LDS>(par, a); if (LDS) pa = make_float4(rx[a], ry[a], rz[a], 0.f); else pa = d.crep[soc + a]; }
+          if (b < hi) {
+            ra = cg_find<LDS>(par, a);
+            if (LDS) { pax = L.rx[a]; pay = L.ry[a]; paz = L.rz[a]; alx = L.bx[a]; aly = L.bx[CGS_CAP + a]; alz = L.bx[2 * CGS_CAP + a]; ahx = L.bx[3 * CGS_CAP + a]; ahy = L.bx[4 * CGS_CAP + a]; ahz = L.bx[5 * CGS_CAP + a]; }
+            else { const float4 q = d.crep[soc + a], lo = d.cmeta[2 * (soc + a)], h4 = d.cmeta[2 * (soc + a) + 1]; pax = q.x; pay = q.y; paz = q.z; alx = lo.x; aly = lo.y; alz = lo.z; ahx = h4.x; ahy = h4.y; ahz = h4.z; }
+          }
         }
       }
     }
     // walk the (≤ 2·RING+1 relevant) cells of the row; lanes of the wave step together so the list append stays wave-uniform
     for (;;) {
-      bool want = false; int bb = b;
+      bool want = false; const int bb = b;
       if (b < hi) {
         const int dx = key[b] - rowbase;
         if (dx > RING) b = hi;
@@ -1367,9 +1401,17 @@ template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(cons
           const bool fwd = !(same_row && dx <= 0), ring = edge_row || abs(dx) == RING;
           want = dx >= -RING && fwd && ring;
           if (want) { const int pb = cg_ld<LDS>(par + b); want = pb != ra && cg_find<LDS>(par, b) != ra; }
-          if (want) {   // sample points of the two cells within r: an edge, no need to look at boxes or points
-            float4 pq; if (LDS) pq = make_float4(rx[b], ry[b], rz[b], 0.f); else pq = d.crep[soc + b];
-            if (sqdist(pa.x, pa.y, pa.z, pq.x, pq.y, pq.z) < r2) { cg_unite<LDS>(par, a, b); want = false; }
+          if (want) {
+            float qx, qy, qz, blx, bly, blz, bhx, bhy, bhz;
+            if (LDS) { qx = L.rx[b]; qy = L.ry[b]; qz = L.rz[b]; blx = L.bx[b]; bly = L.bx[CGS_CAP + b]; blz = L.bx[2 * CGS_CAP + b]; bhx = L.bx[3 * CGS_CAP + b]; bhy = L.bx[4 * CGS_CAP + b]; bhz = L.bx[5 * CGS_CAP + b]; }
+            else { const float4 q = d.crep[soc + b], lo = d.cmeta[2 * (soc + b)], h4 = d.cmeta[2 * (soc + b) + 1]; qx = q.x; qy = q.y; qz = q.z; blx = lo.x; bly = lo.y; blz = lo.z; bhx = h4.x; bhy = h4.y; bhz = h4.z; }
+            bool edge = sqdist(pax, pay, paz, qx, qy, qz) < r2;   // the two sample points are within r
+            if (!edge) {
+              const float gx = fmaxf(fmaxf(blx - ahx, alx - bhx), 0.f), gy = fmaxf(fmaxf(bly - ahy, aly - bhy), 0.f), gz = fmaxf(fmaxf(blz - ahz, alz - bhz), 0.f);
+              if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) want = false;   // boxes ≥ r apart: no edge
+              else { const float sx = fmaxf(bhx - alx, ahx - blx), sy = fmaxf(bhy - aly, ahy - bly), sz = fmaxf(bhz - alz, ahz - blz); edge = (sx * sx + sy * sy + sz * sz) * 1.001f < r2; }   // farthest corners within r: every pair is an edge
+            }
+            if (edge) { cg_unite<LDS>(par, a, b); want = false; }
           }
           ++b;
         }
@@ -1401,18 +1443,20 @@ template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(cons
     for (int u = 1; u < CGS_NW; ++u) lw += h >= pre[u];
     int a, b; cgs_wlist_get<LDS>(ovf, l_list, lw, h - pre[lw], a, b);
     if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;
-    const int verdict = cg_pair_test(d, soc, start, sp, a, b, r2);
+    int a0, a1, b0, b1;
+    if (LDS) { a0 = L.cs[a]; a1 = L.cs[a + 1]; b0 = L.cs[b]; b1 = L.cs[b + 1]; } else { a0 = start[a]; a1 = start[a + 1]; b0 = start[b]; b1 = start[b + 1]; }
+    const int verdict = pair_points_thread(sp, a0, a1 - a0, b0, b1 - b0, r2);
     if (verdict > 0) cg_unite<LDS>(par, a, b);
     else if (verdict < 0) {
       const int slot = atomicAdd(l_n2, 1);
       if (slot < cgs_list2_cap<LDS>()) cgs_list2_put<LDS>(ovf, slot, a, b);
-      else { const int a0 = start[a], b0 = start[b]; if (pair_hit_serial(sp, a0, start[a + 1] - a0, b0, start[b + 1] - b0, r2)) cg_unite<LDS>(par, a, b); }
+      else if (pair_hit_serial(sp, a0, a1 - a0, b0, b1 - b0, r2)) cg_unite<LDS>(par, a, b);
     }
   }
   __threadfence();
   __syncthreads();
   ST2(stw, (RING - 1) * 4 + 3);
-  // ---- B2: one wave per undecided big pair
+  // ---- B2: one wave per pair left over
   const int n2 = min(*l_n2, cgs_list2_cap<LDS>());
   for (int h = w; h < n2; h += CGS_NW) {
     int a, b; cgs_list2_get<LDS>(ovf, h, a, b);
@@ -1426,13 +1470,13 @@ template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(cons
   if (threadIdx.x == 0) *l_n2 = 0;
   __syncthreads();
 }
-template <bool LDS> __device__ __forceinline__ void cgs_body(const MorDev &d, int s, size_t so, int c0, int n_own, int n_loc, const int *key, const int *pc, const float *rx, const float *ry, const float *rz, const int *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_wcnt, int *l_n2, size_t stwj) {
+template <bool LDS> __device__ __forceinline__ void cgs_body(const MorDev &d, int s, size_t so, int c0, int n_own, int n_loc, const CgsCells<LDS> &L, const int *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_wcnt, int *l_n2, size_t stwj) {
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1) + c0;   // start[local id]: first position of the cell in `sorted`
   const float4 *sp = d.sorted + so;
-  cgs_hook_pass<LDS, 1>(d, so + c0, n_own, key, pc, rx, ry, rz, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_wcnt, l_n2, stwj);
+  cgs_hook_pass<LDS, 1>(d, so + c0, n_own, n_loc, L, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_wcnt, l_n2, stwj);
   for (int c = threadIdx.x; c < n_loc; c += CGS_T) { const int r = cg_find<LDS>(par, c); if (r != c) cg_st<LDS>(par + c, r); }   // flat forest: the shell pass compares parents directly
   __syncthreads();
-  cgs_hook_pass<LDS, 2>(d, so + c0, n_own, key, pc, rx, ry, rz, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_wcnt, l_n2, stwj);
+  cgs_hook_pass<LDS, 2>(d, so + c0, n_own, n_loc, L, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_wcnt, l_n2, stwj);
   // local roots as global compact ids: own cells → lroot_a, look-ahead cells → lroot_b
   for (int c = threadIdx.x; c < n_loc; c += CGS_T) {
     const int r = c0 + cg_find<LDS>(par, c);
@@ -1449,27 +1493,33 @@ __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {
   const size_t stwj = (size_t)s * (MOR_MAXP + 2) + j; (void)stwj;
   ST2(stwj, 0);
   const int y0 = sy[j], y2 = min(sy[j + 1] + 2, d.g.ny), r0 = y0 * d.g.nz, nlrows = (y2 - y0) * d.g.nz;
-  __shared__ float l_rx[CGS_CAP], l_ry[CGS_CAP], l_rz[CGS_CAP];
-  __shared__ int l_key[CGS_CAP], l_par[CGS_CAP], l_pc[CGS_CAP], l_rows[CGS_ROWCAP + 1], l_list[2 * CG_LIST], l_wcnt[CGS_NW], l_n2;
-  int *ovf = d.cg_ovf + (size_t)(s * MOR_MAXP + j) * MOR_CGS_OVF * 2;   // [0, MOR_CGS_OVF): the waves' candidate lists, [MOR_CGS_OVF, 2·MOR_CGS_OVF): undecided big pairs
+  __shared__ float l_rx[CGS_CAP], l_ry[CGS_CAP], l_rz[CGS_CAP], l_bx[6 * CGS_CAP];
+  __shared__ int l_key[CGS_CAP], l_par[CGS_CAP], l_pc[CGS_CAP], l_cs[CGS_CAP + 1], l_rows[CGS_ROWCAP + 1], l_list[CGS_LISTW], l_wcnt[CGS_NW], l_n2;
+  int *ovf = d.cg_ovf + (size_t)(s * MOR_MAXP + j) * MOR_CGS_OVF * 2;   // [0, MOR_CGS_OVF): the waves' candidate lists, [MOR_CGS_OVF, 2·MOR_CGS_OVF): pairs for whole waves
   const int *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1) + r0;
   if (threadIdx.x == 0) l_n2 = 0;
   if (n_loc <= CGS_CAP && nlrows <= CGS_ROWCAP && !d.cg_force_global) {
-    const int *gk = d.ckey + so + c0; const float4 *grep = d.crep + so + c0;
+    const int *gk = d.ckey + so + c0, *gs = d.cstart + (size_t)s * (d.Nmax + 1) + c0; const float4 *grep = d.crep + so + c0, *gm = d.cmeta + 2 * (so + c0);
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) {
       const int k = gk[i], row = k / d.g.nx;
       l_key[i] = k; l_par[i] = i; l_pc[i] = (int)((unsigned)(k - row * d.g.nx) | ((unsigned)(row % d.g.nz) << 11) | ((unsigned)(row / d.g.nz) << 21));
-      const float4 q = grep[i]; l_rx[i] = q.x; l_ry[i] = q.y; l_rz[i] = q.z;
+      const float4 q = grep[i], lo = gm[2 * i], hi4 = gm[2 * i + 1];
+      l_rx[i] = q.x; l_ry[i] = q.y; l_rz[i] = q.z;
+      l_bx[i] = lo.x; l_bx[CGS_CAP + i] = lo.y; l_bx[2 * CGS_CAP + i] = lo.z; l_bx[3 * CGS_CAP + i] = hi4.x; l_bx[4 * CGS_CAP + i] = hi4.y; l_bx[5 * CGS_CAP + i] = hi4.z;
+      l_cs[i] = gs[i];
     }
+    if (threadIdx.x == 0) l_cs[n_loc] = gs[n_loc];
     for (int i = threadIdx.x; i <= nlrows; i += CGS_T) l_rows[i] = g_rows[i] - c0;
     __syncthreads();
-    cgs_body<true>(d, s, so, c0, n_own, n_loc, l_key, l_pc, l_rx, l_ry, l_rz, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_wcnt, &l_n2, stwj);
+    const CgsCells<true> L = {l_key, l_pc, l_cs, l_rx, l_ry, l_rz, l_bx};
+    cgs_body<true>(d, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_wcnt, &l_n2, stwj);
   } else {   // slab too big for LDS: the same code on global arrays (even and odd slabs use different forests: look-aheads overlap the next slab)
     int *par = ((j & 1) ? d.parent2 : d.parent) + so + c0;
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) cg_st<false>(par + i, i);
     __threadfence();
     __syncthreads();
-    cgs_body<false>(d, s, so, c0, n_own, n_loc, d.ckey + so + c0, nullptr, nullptr, nullptr, nullptr, g_rows, c0, r0, nlrows, par, ovf, l_list, l_wcnt, &l_n2, stwj);
+    const CgsCells<false> L = {d.ckey + so + c0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    cgs_body<false>(d, s, so, c0, n_own, n_loc, L, g_rows, c0, r0, nlrows, par, ovf, l_list, l_wcnt, &l_n2, stwj);
   }
 }
 // One workgroup per stream: merges the slab forests, then components (size, smallest cloud index), the kept clusters
