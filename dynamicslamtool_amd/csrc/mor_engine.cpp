@@ -387,7 +387,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     uint32_t maxocc = 0;
     std::vector<uint32_t> occ(B);
     for (int s = 0; s < B; ++s) { occ[s] = k > 0 ? d.h_info[s].n_occ : 0; maxocc = std::max(maxocc, occ[s]); }
-    const int p_fit = (int)((maxocc * 3ull / 2 + 818) / 819), p_par = (512 + B - 1) / B;   // a slab's LDS holds 1024 cells (own + look-ahead)
+    const int p_fit = (int)((maxocc * 3ull / 2 + 409) / 410), p_par = (1024 + B - 1) / B;   // a slab's LDS holds 512 cells (own + look-ahead); four 256-thread workgroups per CU
     d.P = b->env_cg_p > 0 ? b->env_cg_p : std::max(p_fit, p_par);
     d.P = std::max(1, std::min(d.P, std::min(MOR_MAXP, std::max(1, d.g.ny / 2))));
     if (!getenv("MOR_GH_TIER")) d.gh_tier = maxocc * 5ull / 4 > 6144 ? (maxocc * 5ull / 4 > 12288 ? 2 : 1) : 0;   // table tier k_gridhash starts with (a stream whose table overflows moves up by itself)

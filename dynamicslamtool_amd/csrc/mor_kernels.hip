@@ -1281,13 +1281,13 @@ __global__ __launch_bounds__(CG_T) void k_cellgraph(MorDev d) {
 // that range, the LOCAL root.  A forest is equivalent to the edge set {(c, root(c))}, so k_cg_final re-unites
 // (c, root_own(c)) and (c, root_lookahead-of-the-previous-slab(c)) in one forest per stream and gets exactly the
 // components of the full edge set — every edge was found by the slab owning its lower-y cell.
-#define CGS_T 512
+#define CGS_T 256
 #ifndef CGS_CAP
-#define CGS_CAP 1024      // local cells (own + look-ahead) held in LDS
+#define CGS_CAP 512       // local cells (own + look-ahead) held in LDS
 #endif
-#define CGS_ROWCAP 3584   // local (y,z) rows held in LDS
+#define CGS_ROWCAP 3072   // local (y,z) rows held in LDS
 #ifndef CGS_LISTW
-#define CGS_LISTW 2048    // LDS words of the candidate-pair lists
+#define CGS_LISTW 1024    // LDS words of the candidate-pair lists
 #endif
 #define CGS_NW (CGS_T / 64)
 #define CGS_WLIST (CGS_LISTW / CGS_NW)        // LDS list entries per wave (one packed pair each)
@@ -1324,14 +1324,14 @@ template <bool LDS> __device__ __forceinline__ void cgs_list2_get(const int *ovf
   if (LDS) { const int c = cg_ld<false>(ovf + MOR_CGS_OVF + slot); a = c >> 14; b = c & 16383; } else { a = cg_ld<false>(ovf + MOR_CGS_OVF + 2 * slot); b = cg_ld<false>(ovf + MOR_CGS_OVF + 2 * slot + 1); }
 }
 // Point test of one pair by one thread, as few levels of dependent loads as possible: up to 8 points of the smaller
-// cell in registers, the other cell streamed eight independent loads at a time (at most 64 of its points).
+// cell in registers, the other cell streamed eight independent loads at a time (at most 24 of its points).
 // Returns 1 = edge, 0 = no edge (every pair was looked at), −1 = undecided (a sample only: the pair goes to a wave).
 __device__ __forceinline__ int pair_points_thread(const float4 *sp, int a0, int na, int b0, int nb, float r2) {
   if (na > nb) { int t = a0; a0 = b0; b0 = t; t = na; na = nb; nb = t; }
   float ax[8], ay[8], az[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { const float4 p = sp[a0 + min(i, na - 1)]; ax[i] = p.x; ay[i] = p.y; az[i] = p.z; }   // clamped duplicates repeat real points
-  const int lim = min(nb, 64);
+  const int lim = min(nb, 24);
   for (int j0 = 0; j0 < lim; j0 += 8) {
     float4 q[8];
 #pragma unroll
@@ -1343,37 +1343,40 @@ __device__ __forceinline__ int pair_points_thread(const float4 *sp, int a0, int 
       for (int i = 0; i < 8; ++i) hit |= sqdist(ax[i], ay[i], az[i], q[j].x, q[j].y, q[j].z) < r2;
     if (hit) return 1;
   }
-  return (na <= 8 && nb <= 64) ? 0 : -1;
+  return (na <= 8 && nb <= 24) ? 0 : -1;
 }
-// One hook pass of a slab.  Local ids: own cells [0, n_own), look-ahead [n_own, n_loc).  key[] = keys of the local cells,
+// The hook pass of a slab.  Local ids: own cells [0, n_own), look-ahead [n_own, n_loc).  key[] = keys of the local cells,
 // rows[] = row table of the slab's rows (row r0 first) holding LOCAL ids plus `rsub` (0 for the LDS copy, the slab's first
 // compact id when the global table is read in place); soc = first slot of the slab's cells in the per-cell global arrays.
 // LDS mode also holds, per local cell: pc[] (its coordinates, packed), one sample point (rx, ry, rz), its point box
 // (bx[0..5]: low corner, high corner) and cs[] = first position of its points (cs[n_loc] = end) — so the enumeration
 // decides most pairs without a single global load:
-//  A   one lane per (own cell, neighbour row) — rows are short, a lane's walk is a couple of LDS loads.  A forward
-//      neighbour in another component is an edge when the two SAMPLE points lie within r (most neighbouring cells of one
-//      surface) or when the farthest corners of the two point boxes do; it is no edge when the boxes are ≥ r apart;
-//      only what is left goes to the wave's candidate list.
+//  A   one lane per (own cell, neighbour row) over the forward half of the 5×5×5 neighbourhood (dy ≥ 0; 13 rows), the
+//      five rows of the 3×3×3 block first.  The ≤ 5 cells of the row's window come as one batch of independent LDS
+//      loads.  A neighbour in another component is an edge when the two SAMPLE points lie within r (most neighbouring
+//      cells of one surface) or when the farthest corners of the two point boxes do; it is no edge when the boxes are
+//      ≥ r apart; only what is left goes to the wave's candidate list.
 //  B1  one thread per listed pair: roots re-checked, then the points (pair_points_thread).
 //  B2  one wave per pair the thread test could not finish (big cells): pruned exhaustive test.
 template <bool LDS> struct CgsCells { const int *key, *pc, *cs; const float *rx, *ry, *rz, *bx; };
-template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(const MorDev &d, size_t soc, int n_own, int n_loc, const CgsCells<LDS> &L, const int *start, const int *rows, int rsub, int r0, int nlrows,
-                                                                            int *par, const float4 *sp, int *ovf, int *l_list, int *l_wcnt, int *l_n2, size_t stw) {
+template <bool LDS> __device__ __forceinline__ void cgs_hooks(const MorDev &d, size_t soc, int n_own, int n_loc, const CgsCells<LDS> &L, const int *start, const int *rows, int rsub, int r0, int nlrows,
+                                                              int *par, const float4 *sp, int *ovf, int *l_list, int *l_wcnt, int *l_n2, size_t stw) {
   const float r2 = d.r2;
   const int *key = L.key;
-  constexpr int NR = (RING + 1) + RING * (2 * RING + 1);   // rows of the forward half: dy = 0: dz 0…RING; dy = 1…RING: dz −RING…RING
+  constexpr int NR = 13;   // rows of the forward half: (dy,dz) = (0,0) (0,1) (1,−1) (1,0) (1,1) — the 3×3×3 block — then (0,2), (1,±2), (2,−2…2)
   const int w = wave_id(), lane = lane_id();
   int wcount = 0;
-  ST2(stw, (RING - 1) * 4 + 1);
+  ST2(stw, 1);
   for (int it0 = 0; it0 < n_own * NR; it0 += CGS_T) {
     const int it = it0 + threadIdx.x;
-    int a = 0, x = 0, rowbase = 0, b = 0, hi = 0, ra = -1; bool edge_row = false, same_row = false;
+    int a = 0, rowbase = 0, b = 0, hi = 0, ra = -1; bool same_row = false;
     float pax = 0.f, pay = 0.f, paz = 0.f, alx = 0.f, aly = 0.f, alz = 0.f, ahx = 0.f, ahy = 0.f, ahz = 0.f;
     if (it < n_own * NR) {
-      a = it / NR; const int ri = it - a * NR;
-      const int dy = ri <= RING ? 0 : 1 + (ri - RING - 1) / (2 * RING + 1), dz = ri <= RING ? ri : (ri - RING - 1) % (2 * RING + 1) - RING;
-      int y, z;
+      const int ri = it / n_own; a = it - ri * n_own;   // row-major over the rows: all cells' near rows come first
+      int dy, dz;
+      if (ri < 5) { dy = ri >= 2; dz = ri < 2 ? ri : ri - 3; } else if (ri == 5) { dy = 0; dz = 2; } else if (ri < 8) { dy = 1; dz = ri == 6 ? -2 : 2; } else { dy = 2; dz = ri - 10; }
+      same_row = dy == 0 && dz == 0;
+      int x, y, z;
       if (LDS) { const unsigned q = (unsigned)L.pc[a]; x = (int)(q & 2047u); z = (int)((q >> 11) & 1023u); y = (int)(q >> 21); }
       else { const int ka = key[a], rowa = ka / d.g.nx; x = ka - rowa * d.g.nx; z = rowa % d.g.nz; y = rowa / d.g.nz; }
       if (y + dy < d.g.ny && (unsigned)(z + dz) < (unsigned)d.g.nz) {
@@ -1381,8 +1384,7 @@ template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(cons
         if (rl >= 0 && rl < nlrows) {
           const int rlo = rows[rl] - rsub, rn = rows[rl + 1] - rsub - rlo;
           rowbase = rr * d.g.nx + x; b = rlo; hi = rlo + rn;
-          if (rn > 8) b = cg_lower_bound8(key, rlo, rn, rowbase - RING);
-          edge_row = dy == RING || abs(dz) == RING; same_row = dy == 0 && dz == 0;
+          if (rn > 5) b = cg_lower_bound8(key, rlo, rn, rowbase - 2);
           if (b < hi) {
             ra = cg_find<LDS>(par, a);
             if (LDS) { pax = L.rx[a]; pay = L.ry[a]; paz = L.rz[a]; alx = L.bx[a]; aly = L.bx[CGS_CAP + a]; alz = L.bx[2 * CGS_CAP + a]; ahx = L.bx[3 * CGS_CAP + a]; ahy = L.bx[4 * CGS_CAP + a]; ahz = L.bx[5 * CGS_CAP + a]; }
@@ -1391,47 +1393,44 @@ template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(cons
         }
       }
     }
-    // walk the (≤ 2·RING+1 relevant) cells of the row; lanes of the wave step together so the list append stays wave-uniform
-    for (;;) {
-      bool want = false; const int bb = b;
-      if (b < hi) {
-        const int dx = key[b] - rowbase;
-        if (dx > RING) b = hi;
-        else {
-          const bool fwd = !(same_row && dx <= 0), ring = edge_row || abs(dx) == RING;
-          want = dx >= -RING && fwd && ring;
-          if (want) { const int pb = cg_ld<LDS>(par + b); want = pb != ra && cg_find<LDS>(par, b) != ra; }
-          if (want) {
-            float qx, qy, qz, blx, bly, blz, bhx, bhy, bhz;
-            if (LDS) { qx = L.rx[b]; qy = L.ry[b]; qz = L.rz[b]; blx = L.bx[b]; bly = L.bx[CGS_CAP + b]; blz = L.bx[2 * CGS_CAP + b]; bhx = L.bx[3 * CGS_CAP + b]; bhy = L.bx[4 * CGS_CAP + b]; bhz = L.bx[5 * CGS_CAP + b]; }
-            else { const float4 q = d.crep[soc + b], lo = d.cmeta[2 * (soc + b)], h4 = d.cmeta[2 * (soc + b) + 1]; qx = q.x; qy = q.y; qz = q.z; blx = lo.x; bly = lo.y; blz = lo.z; bhx = h4.x; bhy = h4.y; bhz = h4.z; }
-            bool edge = sqdist(pax, pay, paz, qx, qy, qz) < r2;   // the two sample points are within r
-            if (!edge) {
-              const float gx = fmaxf(fmaxf(blx - ahx, alx - bhx), 0.f), gy = fmaxf(fmaxf(bly - ahy, aly - bhy), 0.f), gz = fmaxf(fmaxf(blz - ahz, alz - bhz), 0.f);
-              if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) want = false;   // boxes ≥ r apart: no edge
-              else { const float sx = fmaxf(bhx - alx, ahx - blx), sy = fmaxf(bhy - aly, ahy - bly), sz = fmaxf(bhz - alz, ahz - blz); edge = (sx * sx + sy * sy + sz * sz) * 1.001f < r2; }   // farthest corners within r: every pair is an edge
-            }
-            if (edge) { cg_unite<LDS>(par, a, b); want = false; }
-          }
-          ++b;
-        }
-      }
-      const unsigned long long m = __ballot(want);
-      if (m) {
+    // the window holds at most five cells (x−2 … x+2): keys and parents as one batch of independent loads
+    int kb[5], pb[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) { const int bi = min(b + u, max(hi - 1, 0)); kb[u] = key[bi]; pb[u] = cg_ld<LDS>(par + bi); }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int bb = b + u, dx = kb[u] - rowbase;
+      bool want = bb < hi && dx >= -2 && dx <= 2 && !(same_row && dx <= 0) && pb[u] != ra;
+      if (__ballot(want)) {
+        if (want) want = cg_find<LDS>(par, bb) != cg_find<LDS>(par, a);
         if (want) {
-          const int slot = wcount + __popcll(m & lanemask_lt());
-          if (slot < cgs_wlist_cap<LDS>()) cgs_wlist_put<LDS>(ovf, l_list, w, slot, a, bb);
-          else { const int a0 = start[a], b0 = start[bb]; if (pair_hit_serial(sp, a0, start[a + 1] - a0, b0, start[bb + 1] - b0, r2)) cg_unite<LDS>(par, a, bb); }   // lists full (never seen): settle it here
+          float qx, qy, qz, blx, bly, blz, bhx, bhy, bhz;
+          if (LDS) { qx = L.rx[bb]; qy = L.ry[bb]; qz = L.rz[bb]; blx = L.bx[bb]; bly = L.bx[CGS_CAP + bb]; blz = L.bx[2 * CGS_CAP + bb]; bhx = L.bx[3 * CGS_CAP + bb]; bhy = L.bx[4 * CGS_CAP + bb]; bhz = L.bx[5 * CGS_CAP + bb]; }
+          else { const float4 q = d.crep[soc + bb], lo = d.cmeta[2 * (soc + bb)], h4 = d.cmeta[2 * (soc + bb) + 1]; qx = q.x; qy = q.y; qz = q.z; blx = lo.x; bly = lo.y; blz = lo.z; bhx = h4.x; bhy = h4.y; bhz = h4.z; }
+          bool edge = sqdist(pax, pay, paz, qx, qy, qz) < r2;   // the two sample points are within r
+          if (!edge) {
+            const float gx = fmaxf(fmaxf(blx - ahx, alx - bhx), 0.f), gy = fmaxf(fmaxf(bly - ahy, aly - bhy), 0.f), gz = fmaxf(fmaxf(blz - ahz, alz - bhz), 0.f);
+            if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) want = false;   // boxes ≥ r apart: no edge
+            else { const float sx = fmaxf(bhx - alx, ahx - blx), sy = fmaxf(bhy - aly, ahy - bly), sz = fmaxf(bhz - alz, ahz - blz); edge = (sx * sx + sy * sy + sz * sz) * 1.001f < r2; }   // farthest corners within r: every pair is an edge
+          }
+          if (edge) { cg_unite<LDS>(par, a, bb); want = false; }
         }
-        wcount += __popcll(m);
+        const unsigned long long m = __ballot(want);
+        if (m) {
+          if (want) {
+            const int slot = wcount + __popcll(m & lanemask_lt());
+            if (slot < cgs_wlist_cap<LDS>()) cgs_wlist_put<LDS>(ovf, l_list, w, slot, a, bb);
+            else { const int a0 = start[a], b0 = start[bb]; if (pair_hit_serial(sp, a0, start[a + 1] - a0, b0, start[bb + 1] - b0, r2)) cg_unite<LDS>(par, a, bb); }   // lists full (never seen): settle it here
+          }
+          wcount += __popcll(m);
+        }
       }
-      if (!__ballot(b < hi)) break;
     }
   }
   if (lane == 0) l_wcnt[w] = min(wcount, cgs_wlist_cap<LDS>());
   __threadfence_block();
   __syncthreads();
-  ST2(stw, (RING - 1) * 4 + 2);
+  ST2(stw, 2);
   // ---- B1: one thread per candidate pair (the waves' lists, back to back)
   int pre[CGS_NW + 1]; pre[0] = 0;
 #pragma unroll
@@ -1453,9 +1452,9 @@ template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(cons
       else if (pair_hit_serial(sp, a0, a1 - a0, b0, b1 - b0, r2)) cg_unite<LDS>(par, a, b);
     }
   }
-  __threadfence();
+  __threadfence_block();
   __syncthreads();
-  ST2(stw, (RING - 1) * 4 + 3);
+  ST2(stw, 3);
   // ---- B2: one wave per pair left over
   const int n2 = min(*l_n2, cgs_list2_cap<LDS>());
   for (int h = w; h < n2; h += CGS_NW) {
@@ -1464,19 +1463,14 @@ template <bool LDS, int RING> __device__ __forceinline__ void cgs_hook_pass(cons
     const float4 alo = d.cmeta[2 * (soc + a)], ahi = d.cmeta[2 * (soc + a) + 1], blo = d.cmeta[2 * (soc + b)], bhi = d.cmeta[2 * (soc + b) + 1];
     if (pair_hit_wave(sp, start[a], start[a + 1] - start[a], start[b], start[b + 1] - start[b], r2, lane, alo, ahi, blo, bhi) && lane == 0) cg_unite<LDS>(par, a, b);
   }
-  ST2(stw, (RING - 1) * 4 + 4);
-  ST2V(stw, 10 + (RING - 1) * 2, n1); ST2V(stw, 11 + (RING - 1) * 2, n2);
-  __syncthreads();
-  if (threadIdx.x == 0) *l_n2 = 0;
+  ST2(stw, 4);
+  ST2V(stw, 10, n1); ST2V(stw, 11, n2);
   __syncthreads();
 }
 template <bool LDS> __device__ __forceinline__ void cgs_body(const MorDev &d, int s, size_t so, int c0, int n_own, int n_loc, const CgsCells<LDS> &L, const int *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_wcnt, int *l_n2, size_t stwj) {
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1) + c0;   // start[local id]: first position of the cell in `sorted`
   const float4 *sp = d.sorted + so;
-  cgs_hook_pass<LDS, 1>(d, so + c0, n_own, n_loc, L, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_wcnt, l_n2, stwj);
-  for (int c = threadIdx.x; c < n_loc; c += CGS_T) { const int r = cg_find<LDS>(par, c); if (r != c) cg_st<LDS>(par + c, r); }   // flat forest: the shell pass compares parents directly
-  __syncthreads();
-  cgs_hook_pass<LDS, 2>(d, so + c0, n_own, n_loc, L, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_wcnt, l_n2, stwj);
+  cgs_hooks<LDS>(d, so + c0, n_own, n_loc, L, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_wcnt, l_n2, stwj);
   // local roots as global compact ids: own cells → lroot_a, look-ahead cells → lroot_b
   for (int c = threadIdx.x; c < n_loc; c += CGS_T) {
     const int r = c0 + cg_find<LDS>(par, c);

@@ -29,12 +29,11 @@ print("   six slowest: " + ", ".join("s%d M=%d %.0fus" % (k, g[k, 4], t[k].sum()
 w = out[:, :P, :].astype(np.int64).reshape(-1, 16)
 w = w[w[:, 0] > 0]
 tot = (w[:, 9] - w[:, 0]) / 100.0
-ph = {"load": w[:, 1] - w[:, 0], "A1": w[:, 2] - w[:, 1], "B1_1": w[:, 3] - w[:, 2], "B2_1": w[:, 4] - w[:, 3], "flat": w[:, 5] - w[:, 4], "A2": w[:, 6] - w[:, 5], "B1_2": w[:, 7] - w[:, 6], "B2_2": w[:, 8] - w[:, 7], "out": w[:, 9] - w[:, 8]}
+ph = {"load": w[:, 1] - w[:, 0], "A": w[:, 2] - w[:, 1], "B1": w[:, 3] - w[:, 2], "B2": w[:, 4] - w[:, 3], "out": w[:, 9] - w[:, 4]}
 print("k_cg_slab workgroups: %d, total us mean %.1f p50 %.1f p90 %.1f max %.1f; kernel span %.1f" % (len(w), tot.mean(), np.median(tot), np.percentile(tot, 90), tot.max(), (w[:, 9].max() - w[:, 0].min()) / 100.0))
 for k, v in ph.items():
     v = v / 100.0
     print("   %-5s mean %7.1f p90 %7.1f max %7.1f" % (k, v.mean(), np.percentile(v, 90), v.max()))
-print("   pairs listed pass1 mean %.0f max %d | undecided big pass1 mean %.1f max %d | listed pass2 mean %.0f max %d | big pass2 mean %.1f max %d | n_own mean %.0f max %d n_loc max %d" % (
-    w[:, 10].mean(), w[:, 10].max(), w[:, 11].mean(), w[:, 11].max(), w[:, 12].mean(), w[:, 12].max(), w[:, 13].mean(), w[:, 13].max(), w[:, 14].mean(), w[:, 14].max(), w[:, 15].max()))
+print("   pairs listed mean %.0f max %d | for waves mean %.1f max %d | n_own mean %.0f max %d n_loc max %d" % (w[:, 10].mean(), w[:, 10].max(), w[:, 11].mean(), w[:, 11].max(), w[:, 14].mean(), w[:, 14].max(), w[:, 15].max()))
 for k in np.argsort(-tot)[:8]:
-    print("   slow wg: total %.0f us  " % tot[k] + " ".join("%s=%.0f" % (n, v[k] / 100.0) for n, v in ph.items()) + "  n1=%d n2=%d | n1'=%d n2'=%d own=%d loc=%d" % (w[k, 10], w[k, 11], w[k, 12], w[k, 13], w[k, 14], w[k, 15]))
+    print("   slow wg: total %.0f us  " % tot[k] + " ".join("%s=%.0f" % (n, v[k] / 100.0) for n, v in ph.items()) + "  n1=%d n2=%d own=%d loc=%d" % (w[k, 10], w[k, 11], w[k, 14], w[k, 15]))
