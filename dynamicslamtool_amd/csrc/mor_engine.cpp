@@ -238,7 +238,7 @@ void mor_batch_destroy(mor_batch *b) {
 mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_streams, uint64_t max_points, int device, int *err) {
   int rc = MOR_OK; mor_batch *b = nullptr;
   auto fail = [&](int code) -> mor_batch * { if (err) *err = code; if (b) mor_batch_destroy(b); return nullptr; };
-  if (!p || n_streams < 1 || max_points < 1 || max_points > (1ull << 27)) return fail(set_error(MOR_ERR_INVALID, "bad arguments to mor_batch_create"));
+  if (!p || n_streams < 1 || max_points < 1 || max_points > (1ull << 26)) return fail(set_error(MOR_ERR_INVALID, "bad arguments to mor_batch_create"));
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(set_error(MOR_ERR_HIP, "no HIP device available (this library has no CPU fallback)"));
   if (device < 0 || device >= ndev) return fail(set_error(MOR_ERR_INVALID, "device %d out of range (%d devices)", device, ndev));
@@ -387,7 +387,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     uint32_t maxocc = 0;
     std::vector<uint32_t> occ(B);
     for (int s = 0; s < B; ++s) { occ[s] = k > 0 ? d.h_info[s].n_occ : 0; maxocc = std::max(maxocc, occ[s]); }
-    const int p_fit = (int)((maxocc * 3ull / 2 + 409) / 410), p_par = (1024 + B - 1) / B;   // a slab's LDS holds 512 cells (own + look-ahead); four 256-thread workgroups per CU
+    const int p_fit = (int)((maxocc * 3ull / 2 + 818) / 819), p_par = (512 + B - 1) / B;   // a slab's LDS holds 1024 cells (own + look-ahead); two 512-thread workgroups per CU
     d.P = b->env_cg_p > 0 ? b->env_cg_p : std::max(p_fit, p_par);
     d.P = std::max(1, std::min(d.P, std::min(MOR_MAXP, std::max(1, d.g.ny / 2))));
     if (!getenv("MOR_GH_TIER")) d.gh_tier = maxocc * 5ull / 4 > 6144 ? (maxocc * 5ull / 4 > 12288 ? 2 : 1) : 0;   // table tier k_gridhash starts with (a stream whose table overflows moves up by itself)

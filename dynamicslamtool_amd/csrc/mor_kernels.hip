@@ -1281,17 +1281,18 @@ __global__ __launch_bounds__(CG_T) void k_cellgraph(MorDev d) {
 // that range, the LOCAL root.  A forest is equivalent to the edge set {(c, root(c))}, so k_cg_final re-unites
 // (c, root_own(c)) and (c, root_lookahead-of-the-previous-slab(c)) in one forest per stream and gets exactly the
 // components of the full edge set — every edge was found by the slab owning its lower-y cell.
-#define CGS_T 256
+#define CGS_T 512
 #ifndef CGS_CAP
-#define CGS_CAP 512       // local cells (own + look-ahead) held in LDS
+#define CGS_CAP 1024      // local cells (own + look-ahead) held in LDS
 #endif
-#define CGS_ROWCAP 3072   // local (y,z) rows held in LDS
+#define CGS_ROWCAP 2048   // local (y,z) rows held in LDS
 #ifndef CGS_LISTW
-#define CGS_LISTW 1024    // LDS words of the candidate-pair lists
+#define CGS_LISTW 2048    // LDS words of the candidate-pair lists
 #endif
 #define CGS_NW (CGS_T / 64)
 #define CGS_WLIST (CGS_LISTW / CGS_NW)        // LDS list entries per wave (one packed pair each)
 #define CGS_WOVF (MOR_CGS_OVF / CGS_NW)       // global overflow entries per wave
+#define CGS_QW 320                            // a wave's queue of neighbour pairs found by one batch of 64 (cell, row) items (≤ 5 each)
 static_assert(CGS_CAP <= 16384, "pair lists pack two local cell ids into 28 bits");
 // Candidate pairs are appended by the wave that finds them to ITS OWN list (LDS part + global overflow part): the
 // position comes from a wave-uniform counter in a register, so enumeration needs no atomic and no round trip per append.
@@ -1348,29 +1349,32 @@ __device__ __forceinline__ int pair_points_thread(const float4 *sp, int a0, int 
 // The hook pass of a slab.  Local ids: own cells [0, n_own), look-ahead [n_own, n_loc).  key[] = keys of the local cells,
 // rows[] = row table of the slab's rows (row r0 first) holding LOCAL ids plus `rsub` (0 for the LDS copy, the slab's first
 // compact id when the global table is read in place); soc = first slot of the slab's cells in the per-cell global arrays.
-// LDS mode also holds, per local cell: pc[] (its coordinates, packed), one sample point (rx, ry, rz), its point box
-// (bx[0..5]: low corner, high corner) and cs[] = first position of its points (cs[n_loc] = end) — so the enumeration
-// decides most pairs without a single global load:
-//  A   one lane per (own cell, neighbour row) over the forward half of the 5×5×5 neighbourhood (dy ≥ 0; 13 rows), the
-//      five rows of the 3×3×3 block first.  The ≤ 5 cells of the row's window come as one batch of independent LDS
-//      loads.  A neighbour in another component is an edge when the two SAMPLE points lie within r (most neighbouring
-//      cells of one surface) or when the farthest corners of the two point boxes do; it is no edge when the boxes are
-//      ≥ r apart; only what is left goes to the wave's candidate list.
+// LDS mode also holds, per local cell: pc[] (its coordinates, packed), one sample point (rx, ry, rz) and its point box
+// (bx[0..5]: low corner, high corner) — so most pairs are decided without a single global load.  Every wave works
+// on its own, in steps of 64 (own cell, neighbour row) items over the forward half of the 5×5×5 neighbourhood (dy ≥ 0;
+// 13 rows, the five rows of the 3×3×3 block first):
+//  A1  one lane per item: the ≤ 5 cells of the row's window come as one batch of independent LDS loads; those whose
+//      parent differs from the cell's root go to the wave's queue.
+//  A2  one lane per queued pair, all lanes busy: roots; an edge when the two SAMPLE points lie within r (most
+//      neighbouring cells of one surface) or when the farthest corners of the two point boxes do; no edge when the
+//      boxes are ≥ r apart; only what is left goes to the wave's candidate list.
+// then, for the whole workgroup:
 //  B1  one thread per listed pair: roots re-checked, then the points (pair_points_thread).
 //  B2  one wave per pair the thread test could not finish (big cells): pruned exhaustive test.
-template <bool LDS> struct CgsCells { const int *key, *pc, *cs; const float *rx, *ry, *rz, *bx; };
+template <bool LDS> struct CgsCells { const int *key, *pc; const float *rx, *ry, *rz, *bx; };
 template <bool LDS> __device__ __forceinline__ void cgs_hooks(const MorDev &d, size_t soc, int n_own, int n_loc, const CgsCells<LDS> &L, const int *start, const int *rows, int rsub, int r0, int nlrows,
-                                                              int *par, const float4 *sp, int *ovf, int *l_list, int *l_wcnt, int *l_n2, size_t stw) {
+                                                              int *par, const float4 *sp, int *ovf, int *l_list, int *l_queue, int *l_wcnt, int *l_n2, size_t stw) {
   const float r2 = d.r2;
   const int *key = L.key;
   constexpr int NR = 13;   // rows of the forward half: (dy,dz) = (0,0) (0,1) (1,−1) (1,0) (1,1) — the 3×3×3 block — then (0,2), (1,±2), (2,−2…2)
   const int w = wave_id(), lane = lane_id();
+  int *queue = l_queue + w * CGS_QW;
   int wcount = 0;
   ST2(stw, 1);
-  for (int it0 = 0; it0 < n_own * NR; it0 += CGS_T) {
-    const int it = it0 + threadIdx.x;
+  for (int it0 = w * 64; it0 < n_own * NR; it0 += CGS_T) {
+    // ---- A1
+    const int it = it0 + lane;
     int a = 0, rowbase = 0, b = 0, hi = 0, ra = -1; bool same_row = false;
-    float pax = 0.f, pay = 0.f, paz = 0.f, alx = 0.f, aly = 0.f, alz = 0.f, ahx = 0.f, ahy = 0.f, ahz = 0.f;
     if (it < n_own * NR) {
       const int ri = it / n_own; a = it - ri * n_own;   // row-major over the rows: all cells' near rows come first
       int dy, dz;
@@ -1385,45 +1389,53 @@ template <bool LDS> __device__ __forceinline__ void cgs_hooks(const MorDev &d, s
           const int rlo = rows[rl] - rsub, rn = rows[rl + 1] - rsub - rlo;
           rowbase = rr * d.g.nx + x; b = rlo; hi = rlo + rn;
           if (rn > 5) b = cg_lower_bound8(key, rlo, rn, rowbase - 2);
-          if (b < hi) {
-            ra = cg_find<LDS>(par, a);
-            if (LDS) { pax = L.rx[a]; pay = L.ry[a]; paz = L.rz[a]; alx = L.bx[a]; aly = L.bx[CGS_CAP + a]; alz = L.bx[2 * CGS_CAP + a]; ahx = L.bx[3 * CGS_CAP + a]; ahy = L.bx[4 * CGS_CAP + a]; ahz = L.bx[5 * CGS_CAP + a]; }
-            else { const float4 q = d.crep[soc + a], lo = d.cmeta[2 * (soc + a)], h4 = d.cmeta[2 * (soc + a) + 1]; pax = q.x; pay = q.y; paz = q.z; alx = lo.x; aly = lo.y; alz = lo.z; ahx = h4.x; ahy = h4.y; ahz = h4.z; }
-          }
+          if (b < hi) ra = cg_find<LDS>(par, a);
         }
       }
     }
-    // the window holds at most five cells (x−2 … x+2): keys and parents as one batch of independent loads
-    int kb[5], pb[5];
+    int kb[5], pb[5];   // the window holds at most five cells (x−2 … x+2): keys and parents as one batch of independent loads
 #pragma unroll
     for (int u = 0; u < 5; ++u) { const int bi = min(b + u, max(hi - 1, 0)); kb[u] = key[bi]; pb[u] = cg_ld<LDS>(par + bi); }
+    int qn = 0;
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
       const int bb = b + u, dx = kb[u] - rowbase;
-      bool want = bb < hi && dx >= -2 && dx <= 2 && !(same_row && dx <= 0) && pb[u] != ra;
-      if (__ballot(want)) {
-        if (want) want = cg_find<LDS>(par, bb) != cg_find<LDS>(par, a);
+      const bool want = bb < hi && dx >= -2 && dx <= 2 && !(same_row && dx <= 0) && pb[u] != ra;
+      const unsigned long long m = __ballot(want);
+      if (want) queue[qn + __popcll(m & lanemask_lt())] = (lane << 26) | bb;   // (enumerating lane, neighbour): the cell is that lane's `a` (local ids < 2²⁶: mor_batch_create bounds max_points)
+      qn += __popcll(m);
+    }
+    // ---- A2
+    for (int q0 = 0; q0 < qn; q0 += 64) {
+      const bool act = q0 + lane < qn;
+      const int qc = act ? queue[q0 + lane] : 0;
+      const int qa = __shfl(a, (qc >> 26) & 63, 64), qb = qc & ((1 << 26) - 1);
+      bool want = act && cg_find<LDS>(par, qa) != cg_find<LDS>(par, qb);
+      if (want) {
+        float pax, pay, paz, alx, aly, alz, ahx, ahy, ahz, qx, qy, qz, blx, bly, blz, bhx, bhy, bhz;
+        if (LDS) {
+          pax = L.rx[qa]; pay = L.ry[qa]; paz = L.rz[qa]; alx = L.bx[qa]; aly = L.bx[CGS_CAP + qa]; alz = L.bx[2 * CGS_CAP + qa]; ahx = L.bx[3 * CGS_CAP + qa]; ahy = L.bx[4 * CGS_CAP + qa]; ahz = L.bx[5 * CGS_CAP + qa];
+          qx = L.rx[qb]; qy = L.ry[qb]; qz = L.rz[qb]; blx = L.bx[qb]; bly = L.bx[CGS_CAP + qb]; blz = L.bx[2 * CGS_CAP + qb]; bhx = L.bx[3 * CGS_CAP + qb]; bhy = L.bx[4 * CGS_CAP + qb]; bhz = L.bx[5 * CGS_CAP + qb];
+        } else {
+          const float4 q = d.crep[soc + qa], lo = d.cmeta[2 * (soc + qa)], h4 = d.cmeta[2 * (soc + qa) + 1]; pax = q.x; pay = q.y; paz = q.z; alx = lo.x; aly = lo.y; alz = lo.z; ahx = h4.x; ahy = h4.y; ahz = h4.z;
+          const float4 q2 = d.crep[soc + qb], lo2 = d.cmeta[2 * (soc + qb)], h42 = d.cmeta[2 * (soc + qb) + 1]; qx = q2.x; qy = q2.y; qz = q2.z; blx = lo2.x; bly = lo2.y; blz = lo2.z; bhx = h42.x; bhy = h42.y; bhz = h42.z;
+        }
+        bool edge = sqdist(pax, pay, paz, qx, qy, qz) < r2;   // the two sample points are within r
+        if (!edge) {
+          const float gx = fmaxf(fmaxf(blx - ahx, alx - bhx), 0.f), gy = fmaxf(fmaxf(bly - ahy, aly - bhy), 0.f), gz = fmaxf(fmaxf(blz - ahz, alz - bhz), 0.f);
+          if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) want = false;   // boxes ≥ r apart: no edge
+          else { const float sx = fmaxf(bhx - alx, ahx - blx), sy = fmaxf(bhy - aly, ahy - bly), sz = fmaxf(bhz - alz, ahz - blz); edge = (sx * sx + sy * sy + sz * sz) * 1.001f < r2; }   // farthest corners within r: every pair is an edge
+        }
+        if (edge) { cg_unite<LDS>(par, qa, qb); want = false; }
+      }
+      const unsigned long long m = __ballot(want);
+      if (m) {
         if (want) {
-          float qx, qy, qz, blx, bly, blz, bhx, bhy, bhz;
-          if (LDS) { qx = L.rx[bb]; qy = L.ry[bb]; qz = L.rz[bb]; blx = L.bx[bb]; bly = L.bx[CGS_CAP + bb]; blz = L.bx[2 * CGS_CAP + bb]; bhx = L.bx[3 * CGS_CAP + bb]; bhy = L.bx[4 * CGS_CAP + bb]; bhz = L.bx[5 * CGS_CAP + bb]; }
-          else { const float4 q = d.crep[soc + bb], lo = d.cmeta[2 * (soc + bb)], h4 = d.cmeta[2 * (soc + bb) + 1]; qx = q.x; qy = q.y; qz = q.z; blx = lo.x; bly = lo.y; blz = lo.z; bhx = h4.x; bhy = h4.y; bhz = h4.z; }
-          bool edge = sqdist(pax, pay, paz, qx, qy, qz) < r2;   // the two sample points are within r
-          if (!edge) {
-            const float gx = fmaxf(fmaxf(blx - ahx, alx - bhx), 0.f), gy = fmaxf(fmaxf(bly - ahy, aly - bhy), 0.f), gz = fmaxf(fmaxf(blz - ahz, alz - bhz), 0.f);
-            if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) want = false;   // boxes ≥ r apart: no edge
-            else { const float sx = fmaxf(bhx - alx, ahx - blx), sy = fmaxf(bhy - aly, ahy - bly), sz = fmaxf(bhz - alz, ahz - blz); edge = (sx * sx + sy * sy + sz * sz) * 1.001f < r2; }   // farthest corners within r: every pair is an edge
-          }
-          if (edge) { cg_unite<LDS>(par, a, bb); want = false; }
+          const int slot = wcount + __popcll(m & lanemask_lt());
+          if (slot < cgs_wlist_cap<LDS>()) cgs_wlist_put<LDS>(ovf, l_list, w, slot, qa, qb);
+          else { const int a0 = start[qa], b0 = start[qb]; if (pair_hit_serial(sp, a0, start[qa + 1] - a0, b0, start[qb + 1] - b0, r2)) cg_unite<LDS>(par, qa, qb); }   // lists full (never seen): settle it here
         }
-        const unsigned long long m = __ballot(want);
-        if (m) {
-          if (want) {
-            const int slot = wcount + __popcll(m & lanemask_lt());
-            if (slot < cgs_wlist_cap<LDS>()) cgs_wlist_put<LDS>(ovf, l_list, w, slot, a, bb);
-            else { const int a0 = start[a], b0 = start[bb]; if (pair_hit_serial(sp, a0, start[a + 1] - a0, b0, start[bb + 1] - b0, r2)) cg_unite<LDS>(par, a, bb); }   // lists full (never seen): settle it here
-          }
-          wcount += __popcll(m);
-        }
+        wcount += __popcll(m);
       }
     }
   }
@@ -1442,8 +1454,7 @@ template <bool LDS> __device__ __forceinline__ void cgs_hooks(const MorDev &d, s
     for (int u = 1; u < CGS_NW; ++u) lw += h >= pre[u];
     int a, b; cgs_wlist_get<LDS>(ovf, l_list, lw, h - pre[lw], a, b);
     if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;
-    int a0, a1, b0, b1;
-    if (LDS) { a0 = L.cs[a]; a1 = L.cs[a + 1]; b0 = L.cs[b]; b1 = L.cs[b + 1]; } else { a0 = start[a]; a1 = start[a + 1]; b0 = start[b]; b1 = start[b + 1]; }
+    const int a0 = start[a], a1 = start[a + 1], b0 = start[b], b1 = start[b + 1];
     const int verdict = pair_points_thread(sp, a0, a1 - a0, b0, b1 - b0, r2);
     if (verdict > 0) cg_unite<LDS>(par, a, b);
     else if (verdict < 0) {
@@ -1467,10 +1478,10 @@ template <bool LDS> __device__ __forceinline__ void cgs_hooks(const MorDev &d, s
   ST2V(stw, 10, n1); ST2V(stw, 11, n2);
   __syncthreads();
 }
-template <bool LDS> __device__ __forceinline__ void cgs_body(const MorDev &d, int s, size_t so, int c0, int n_own, int n_loc, const CgsCells<LDS> &L, const int *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_wcnt, int *l_n2, size_t stwj) {
+template <bool LDS> __device__ __forceinline__ void cgs_body(const MorDev &d, int s, size_t so, int c0, int n_own, int n_loc, const CgsCells<LDS> &L, const int *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_queue, int *l_wcnt, int *l_n2, size_t stwj) {
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1) + c0;   // start[local id]: first position of the cell in `sorted`
   const float4 *sp = d.sorted + so;
-  cgs_hooks<LDS>(d, so + c0, n_own, n_loc, L, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_wcnt, l_n2, stwj);
+  cgs_hooks<LDS>(d, so + c0, n_own, n_loc, L, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_queue, l_wcnt, l_n2, stwj);
   // local roots as global compact ids: own cells → lroot_a, look-ahead cells → lroot_b
   for (int c = threadIdx.x; c < n_loc; c += CGS_T) {
     const int r = c0 + cg_find<LDS>(par, c);
@@ -1488,32 +1499,30 @@ __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {
   ST2(stwj, 0);
   const int y0 = sy[j], y2 = min(sy[j + 1] + 2, d.g.ny), r0 = y0 * d.g.nz, nlrows = (y2 - y0) * d.g.nz;
   __shared__ float l_rx[CGS_CAP], l_ry[CGS_CAP], l_rz[CGS_CAP], l_bx[6 * CGS_CAP];
-  __shared__ int l_key[CGS_CAP], l_par[CGS_CAP], l_pc[CGS_CAP], l_cs[CGS_CAP + 1], l_rows[CGS_ROWCAP + 1], l_list[CGS_LISTW], l_wcnt[CGS_NW], l_n2;
+  __shared__ int l_key[CGS_CAP], l_par[CGS_CAP], l_pc[CGS_CAP], l_rows[CGS_ROWCAP + 1], l_list[CGS_LISTW], l_queue[CGS_NW * CGS_QW], l_wcnt[CGS_NW], l_n2;
   int *ovf = d.cg_ovf + (size_t)(s * MOR_MAXP + j) * MOR_CGS_OVF * 2;   // [0, MOR_CGS_OVF): the waves' candidate lists, [MOR_CGS_OVF, 2·MOR_CGS_OVF): pairs for whole waves
   const int *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1) + r0;
   if (threadIdx.x == 0) l_n2 = 0;
   if (n_loc <= CGS_CAP && nlrows <= CGS_ROWCAP && !d.cg_force_global) {
-    const int *gk = d.ckey + so + c0, *gs = d.cstart + (size_t)s * (d.Nmax + 1) + c0; const float4 *grep = d.crep + so + c0, *gm = d.cmeta + 2 * (so + c0);
+    const int *gk = d.ckey + so + c0; const float4 *grep = d.crep + so + c0, *gm = d.cmeta + 2 * (so + c0);
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) {
       const int k = gk[i], row = k / d.g.nx;
       l_key[i] = k; l_par[i] = i; l_pc[i] = (int)((unsigned)(k - row * d.g.nx) | ((unsigned)(row % d.g.nz) << 11) | ((unsigned)(row / d.g.nz) << 21));
       const float4 q = grep[i], lo = gm[2 * i], hi4 = gm[2 * i + 1];
       l_rx[i] = q.x; l_ry[i] = q.y; l_rz[i] = q.z;
       l_bx[i] = lo.x; l_bx[CGS_CAP + i] = lo.y; l_bx[2 * CGS_CAP + i] = lo.z; l_bx[3 * CGS_CAP + i] = hi4.x; l_bx[4 * CGS_CAP + i] = hi4.y; l_bx[5 * CGS_CAP + i] = hi4.z;
-      l_cs[i] = gs[i];
     }
-    if (threadIdx.x == 0) l_cs[n_loc] = gs[n_loc];
     for (int i = threadIdx.x; i <= nlrows; i += CGS_T) l_rows[i] = g_rows[i] - c0;
     __syncthreads();
-    const CgsCells<true> L = {l_key, l_pc, l_cs, l_rx, l_ry, l_rz, l_bx};
-    cgs_body<true>(d, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_wcnt, &l_n2, stwj);
+    const CgsCells<true> L = {l_key, l_pc, l_rx, l_ry, l_rz, l_bx};
+    cgs_body<true>(d, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
   } else {   // slab too big for LDS: the same code on global arrays (even and odd slabs use different forests: look-aheads overlap the next slab)
     int *par = ((j & 1) ? d.parent2 : d.parent) + so + c0;
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) cg_st<false>(par + i, i);
     __threadfence();
     __syncthreads();
-    const CgsCells<false> L = {d.ckey + so + c0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    cgs_body<false>(d, s, so, c0, n_own, n_loc, L, g_rows, c0, r0, nlrows, par, ovf, l_list, l_wcnt, &l_n2, stwj);
+    const CgsCells<false> L = {d.ckey + so + c0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    cgs_body<false>(d, s, so, c0, n_own, n_loc, L, g_rows, c0, r0, nlrows, par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
   }
 }
 // One workgroup per stream: merges the slab forests, then components (size, smallest cloud index), the kept clusters

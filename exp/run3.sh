@@ -1,10 +1,10 @@
 #!/bin/bash
 set -u
-O=gpurun_out/r2c4; mkdir -p $O
+O=gpurun_out/r2c5; mkdir -p $O
 export TMPDIR=/tmp
 echo "== pytest default"; timeout 900 python -m pytest tests -m gpu -q > $O/pytest_new.log 2>&1; echo rc=$?; tail -8 $O/pytest_new.log
 echo "== pytest global variants"; MOR_GH_TIER=2 MOR_CG_GLOBAL=1 timeout 900 python -m pytest tests -m gpu -q -x -k "hdl64_full or small_streams or known or edge or batch_of_8" > $O/pytest_global.log 2>&1; echo rc=$?; tail -3 $O/pytest_global.log
-for P in 0 12 32; do
+for P in 0 6 16; do
 echo "== stamps P=$P"; MOR_CG_P=$P timeout 300 python exp/stamps2.py 64 > $O/stamps_p$P.log 2>&1; grep -vE "slow wg" $O/stamps_p$P.log; grep "slow wg" $O/stamps_p$P.log | head -3
 done
 echo "== bench default"; timeout 600 python bench.py --steps 100 --warmup 5 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; echo rc=$?
