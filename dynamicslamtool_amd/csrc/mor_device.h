@@ -88,6 +88,8 @@ struct MorDev {
   int tiles;                 // ceil(max n_points of this batch / MOR_TILE)
   int tiles_m;               // workgroups per stream for kernels over the non-ground cloud / clusters: an estimate from the
                              // previous frame; those kernels grid-stride over the tiles a stream really has, so any value ≥ 1 is correct
+  int split_variant;         // experiment bits of k_split: 1 = poll the look-back descriptors with agent-scope loads instead of read-modify-write atomics
+  int two_pass_split;        // development switch: count pass + scatter pass instead of the single-pass split
   int fuse_scans;            // tile-count scans re-derived inside the consuming kernels instead of one-workgroup scan launches (tables of ≤ 2048 tiles)
   int cur, prev, has_prev;   // cluster-array slots of cb and ca (four slots rotate: up to three frames are in flight in the stage pipeline); whether ca exists (:534)
   int run_tracker;           // filter: advance the tracking loop (first filterCloud of this frame)
@@ -204,10 +206,8 @@ enum MorKernelId {
 extern const char *const mor_kernel_names[MK_COUNT];
 
 struct MorLaunchTimer;   // engine-owned; records event pairs when enabled
-void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);     // ingest, ground split, cell-sorted cloud, cell table
-void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);  // connected components over cells, cluster order
-void mor_launch_mid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);   // labels, cluster_indices, centroids; transform of ca, correspondences, thread tiers of the scores
-void mor_launch_tail(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);  // wave tier of the scores, thresholds, host summary, tracking
+#define MOR_N_PIECES 7
+void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer *tm);   // 0 split + grid, 1 cell boxes, 2 cell graph, 3 labels … centroids, 4 transform of ca … first score tiers, 5 last score tiers, 6 thresholds + tracking
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);
 void mor_timer_begin(MorLaunchTimer *tm, int kernel_id, hipStream_t st);
 void mor_timer_end(MorLaunchTimer *tm, int kernel_id, hipStream_t st);

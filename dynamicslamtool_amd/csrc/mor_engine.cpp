@@ -65,7 +65,8 @@ struct mor_batch {
   // Four in-order HIP streams form a software pipeline over frames (see mor_push_batch): grid stage on `sf`, cell graph on
   // `sc`, cluster extraction + pair stage on `sm`, wave-tier scores + tracking + filterCloud on `sb`.
   hipStream_t sf = nullptr, sc = nullptr, sm = nullptr, sb = nullptr;   // grid, cell graph, mid (clusters + pair stage), tail (scores wave tier, tracking, filterCloud)
-  hipEvent_t ev_grid[4] = {}, ev_cg[4] = {}, ev_front[4] = {}, ev_back[4] = {};
+  hipEvent_t ev_piece[MOR_N_PIECES][4] = {}, ev_back[4] = {};
+  int stage_of[MOR_N_PIECES] = {0, 0, 1, 2, 2, 3, 3};   // stage stream of every launch piece (mor_device.h); the last piece and filterCloud run on stage 3
   MorDev dtemp[3];                           // descriptor templates, frame k uses dtemp[k % 3] (static part + pointers)
   MorDev d;                                  // descriptor of the latest pushed frame
   MorStreamArgs *d_args_s[3] = {nullptr, nullptr, nullptr};
@@ -160,6 +161,8 @@ static int configure(mor_batch *b) {
   }
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
   d.fuse_scans = getenv("MOR_NO_FUSE") ? 0 : 1;   // refined per push (tile count)
+  d.two_pass_split = getenv("MOR_TWO_PASS_SPLIT") ? 1 : 0;
+  d.split_variant = getenv("MOR_SPLIT_VARIANT") ? atoi(getenv("MOR_SPLIT_VARIANT")) : 0;
   d.use_hash = d.method == 1;
   { size_t hc = 1024; while (hc < 4 * (size_t)d.Nmax) hc <<= 1; d.Hcell = (int)hc; }
   d.t1_budget = getenv("MOR_T1_BUDGET") ? atoi(getenv("MOR_T1_BUDGET")) : 64;
@@ -219,9 +222,7 @@ void mor_batch_destroy(mor_batch *b) {
   if (b->sm) hipStreamSynchronize(b->sm);
   if (b->sb) hipStreamSynchronize(b->sb);
   for (auto &ev : b->args_ev) if (ev) hipEventDestroy(ev);
-  for (auto &ev : b->ev_grid) if (ev) hipEventDestroy(ev);
-  for (auto &ev : b->ev_cg) if (ev) hipEventDestroy(ev);
-  for (auto &ev : b->ev_front) if (ev) hipEventDestroy(ev);
+  for (auto &pe : b->ev_piece) for (auto &ev : pe) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->ev_back) if (ev) hipEventDestroy(ev);
   if (b->sf) hipStreamDestroy(b->sf);
   if (b->sc) hipStreamDestroy(b->sc);
@@ -247,6 +248,11 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   b->p = *p; b->n_bad = n_bad; b->n_good = n_good; b->B = n_streams; b->device = device; b->Nmax = max_points;
   if (getenv("MOR_PIPE_DEPTH")) b->pipe_depth = std::min(3, std::max(1, atoi(getenv("MOR_PIPE_DEPTH"))));
   if (getenv("MOR_CG_P")) b->env_cg_p = atoi(getenv("MOR_CG_P"));
+  if (const char *st = getenv("MOR_STAGES")) {   // tuning: stage stream (0…3) of each launch piece, e.g. 0012233; non-decreasing, last piece on stage 3
+    bool okc = strlen(st) == MOR_N_PIECES;
+    for (int i = 0; okc && i < MOR_N_PIECES; ++i) okc = st[i] >= '0' && st[i] <= '3' && (i == 0 || st[i] >= st[i - 1]);
+    if (okc && st[MOR_N_PIECES - 1] == '3') for (int i = 0; i < MOR_N_PIECES; ++i) b->stage_of[i] = st[i] - '0';
+  }
   if (getenv("MOR_CG_HELP_PCT")) b->env_help_pct = atoi(getenv("MOR_CG_HELP_PCT"));
   if ((rc = configure(b)) != MOR_OK) return fail(rc);
   if (n_bad > MOR_TR_NB) return fail(set_error(MOR_ERR_INVALID, "n_bad = %d: windows longer than %d frames are not supported", n_bad, MOR_TR_NB));
@@ -256,9 +262,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   // (Tried and measured without effect on the pipeline: highest stream priority for the cell-graph stream, and CU masks
   //  that give it 32-96 CUs of its own.)
   if (hipStreamCreateWithFlags(&b->sf, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sc, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sm, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sb, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
-  for (auto &ev : b->ev_grid) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
-  for (auto &ev : b->ev_cg) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
-  for (auto &ev : b->ev_front) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+  for (auto &pe : b->ev_piece) for (auto &ev : pe) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_back) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   MorDev &d = b->d; const size_t B = d.B, N = d.Nmax, K = d.Kcap, T = d.tiles_max;
   bool ok = true;
@@ -404,33 +408,30 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     for (int s = 0; s < B; ++s) mx = std::max(mx, std::max(d.h_info[s].M, d.h_info[s].C));
     d.tiles_m = (k > 0 && mx > 0) ? std::min<int>(d.tiles, (int)(((uint64_t)mx * 5 / 4 + MOR_TILE - 1) / MOR_TILE) + 1) : d.tiles;
   }
-  // ---- grid stage on sf: must not overwrite what frame k−3 still uses (same buffer copy; its cluster slot doubles as
-  //      the `ca` slot of frame k−3... and the `cb` slot of frame k−4)
+  // ---- the launches of the push, piece by piece, on the stage streams (frames overlap as a software pipeline: piece p of
+  //      frame k runs beside later pieces of frames k−1, k−2).  The first piece must not overwrite what frame k−depth still
+  //      uses (same buffer copy; its cluster slot doubles as the `ca` slot of frame k−depth+1)
+  hipStream_t S[4] = {b->sf, b->sc, b->sm, b->sb};
   {
     const uint64_t depth = b->pipe_depth;   // frames in flight: 3 = what the buffers allow; fewer = less overlap
-    if (k >= depth) HIP_TRY(hipStreamWaitEvent(b->sf, b->ev_back[(k - depth) % 4], 0));
+    if (k >= depth) HIP_TRY(hipStreamWaitEvent(S[b->stage_of[0]], b->ev_back[(k - depth) % 4], 0));
   }
+  hipStream_t s0 = S[b->stage_of[0]];
   for (int s = 0; s < B; ++s) {   // host-resident blobs are staged through device memory
     const mor_cloud_view &c = clouds[s];
-    if (!c.on_device && c.n_points) HIP_TRY(hipMemcpyAsync((void *)b->h_args[s].data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, b->sf));
+    if (!c.on_device && c.n_points) HIP_TRY(hipMemcpyAsync((void *)b->h_args[s].data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, s0));
   }
-  HIP_TRY(hipMemcpyAsync(b->d_args_s[k % 3], b->h_args, sizeof(MorStreamArgs) * B, hipMemcpyHostToDevice, b->sf));
-  HIP_TRY(hipEventRecord(b->args_ev[slot], b->sf));
-  HIP_TRY(hipEventRecord(b->ev[0], b->sf));
-  mor_launch_grid(d, b->sf, &b->timer);
-  HIP_TRY(hipEventRecord(b->ev_grid[k % 4], b->sf));
-  // ---- cell graph on sc (in order behind the cell graph of frame k−1)
-  hipStream_t sc = b->sc;
-  HIP_TRY(hipStreamWaitEvent(sc, b->ev_grid[k % 4], 0));
-  mor_launch_cellgraph(d, sc, &b->timer);
-  HIP_TRY(hipEventRecord(b->ev_cg[k % 4], sc));
-  // ---- mid stage on sm: labels … centroids, then the pair stage with frame k−1 up to the thread tiers of the scores
-  HIP_TRY(hipStreamWaitEvent(b->sm, b->ev_cg[k % 4], 0));
-  mor_launch_mid(d, b->sm, &b->timer);
-  HIP_TRY(hipEventRecord(b->ev_front[k % 4], b->sm));
-  // ---- tail stage on sb: wave tier of the scores, thresholds, host summary, tracking (then filterCloud)
-  HIP_TRY(hipStreamWaitEvent(b->sb, b->ev_front[k % 4], 0));
-  mor_launch_tail(d, b->sb, &b->timer);
+  HIP_TRY(hipMemcpyAsync(b->d_args_s[k % 3], b->h_args, sizeof(MorStreamArgs) * B, hipMemcpyHostToDevice, s0));
+  HIP_TRY(hipEventRecord(b->args_ev[slot], s0));
+  HIP_TRY(hipEventRecord(b->ev[0], s0));
+  for (int pc = 0; pc < MOR_N_PIECES; ++pc) {
+    hipStream_t st = S[b->stage_of[pc]];
+    if (pc > 0 && b->stage_of[pc] != b->stage_of[pc - 1]) {
+      HIP_TRY(hipEventRecord(b->ev_piece[pc - 1][k % 4], S[b->stage_of[pc - 1]]));
+      HIP_TRY(hipStreamWaitEvent(st, b->ev_piece[pc - 1][k % 4], 0));
+    }
+    mor_launch_piece(d, pc, st, &b->timer);
+  }
   HIP_TRY(hipEventRecord(b->ev[1], b->sb));
   HIP_TRY(hipEventRecord(b->ev_back[k % 4], b->sb));
   HIP_TRY(hipGetLastError());

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
       int back = t - 1; unsigned spins = 0;
       for (;;) {
         const int j = back - lane;
-        const unsigned long long v = j >= 0 ? atomicAdd(&desc[j], 0ull) : split_pack(SPLIT_P, 0, 0);   // "tile −1": prefix 0
+        const unsigned long long v = j >= 0 ? ((d.split_variant & 1) ? __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : atomicAdd(&desc[j], 0ull)) : split_pack(SPLIT_P, 0, 0);   // "tile −1": prefix 0
         const unsigned long long st = v >> 62;
         const unsigned long long mP = __ballot(st == SPLIT_P), mX = __ballot(st == 0ull);
         const int fp = mP ? __ffsll((long long)mP) - 1 : 64;                                 // nearest tile with a full prefix
@@ -624,11 +624,14 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int i = i0 + u * GH_T + tid; key[u] = i < M ? pkey[i] : -1; }
     if (gh_ld<true>(&l_misc[1])) break;
+    unsigned h0[4]; int k0[4];   // first probe of the four points as one batch of independent loads: nearly every point finds its cell's slot there
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { h0[u] = hash_slot(max(key[u], 0), hshift); k0[u] = gh_ld<TL>(tkey + h0[u]); }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (key[u] < 0) continue;
-      const int want = key[u] + 1; unsigned h = hash_slot(key[u], hshift); bool ok = false;
-      for (int probes = 0; probes < H; ++probes) {
+      const int want = key[u] + 1; unsigned h = h0[u]; bool ok = k0[u] == want;
+      for (int probes = 0; !ok && probes < H; ++probes) {
         int k = gh_ld<TL>(tkey + h);
         if (k == 0) {
           k = atomicCAS(tkey + h, 0, want);
@@ -2102,37 +2105,39 @@ __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
       const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
       const int sx = near_side(q.x, d.g.ox, d.g.inv_cs, d.g.cs, cx, slb), sy = near_side(q.y, d.g.oy, d.g.inv_cs, d.g.cs, cy, slb), sz = near_side(q.z, d.zorg[s], d.g.inv_cs, d.g.cs, cz, slb);
       int budget = d.t1_budget; float best = INFINITY;
-      int id[27];
-      {
-        int key[27]; unsigned long long ent[27];
-#pragma unroll
-        for (int i = 0; i < 27; ++i) {
-          key[i] = i == 13 ? -1 : cell_key(d.g, cx + i % 3 - 1, cy + (i / 3) % 3 - 1, cz + i / 9 - 1);
-          ent[i] = tab[hash_slot(max(key[i], 0), hshift)];
-        }
-#pragma unroll
-        for (int i = 0; i < 27; ++i) id[i] = key[i] >= 0 ? hash_resolve(tab, hshift, key[i], hash_slot(key[i], hshift), ent[i]) : -1;
-      }
+      // matched cells of the 3×3×3 block, at most eight kept: first those that can hold a point within √lb (the ≤ 7 cells across
+      // the walls q is close to), then the others in index order; ncand counts all of them.  One z-layer (nine probes, then
+      // nine cluster ids: two levels of independent loads) at a time keeps the live registers low — this kernel used to need
+      // 131 VGPRs and, with three waves per SIMD, fell apart whenever it shared the GPU with the other stages
       int mc[8]; int ncand = 0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) mc[i] = -1;
-      {
-        int cidv[27];
 #pragma unroll
-        for (int i = 0; i < 27; ++i) cidv[i] = cid_c[max(id[i], 0)];
+      for (int pass = 0; pass < 2; ++pass)
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass)   // pass 0: cells that can hold a point within √lb (≤ 7), pass 1: the others
+        for (int lz = 0; lz < 3; ++lz) {
+          const int dz = lz - 1;
+          if (pass == 0 && !(dz == 0 || dz == sz)) continue;   // no near cell in this layer
+          int key[9], id9[9], cid9[9]; unsigned long long ent[9];
 #pragma unroll
-          for (int i = 0; i < 27; ++i) {
-            const int dx = i % 3 - 1, dy = (i / 3) % 3 - 1, dz = i / 9 - 1;
+          for (int i = 0; i < 9; ++i) {
+            const int dx = i % 3 - 1, dy = i / 3 - 1;
             const bool nearc = (dx == 0 || dx == sx) && (dy == 0 || dy == sy) && (dz == 0 || dz == sz);
-            if (id[i] >= 0 && cidv[i] == target && nearc == (pass == 0)) {
+            key[i] = ((dx == 0 && dy == 0 && dz == 0) || nearc != (pass == 0)) ? -1 : cell_key(d.g, cx + dx, cy + dy, cz + dz);
+            ent[i] = key[i] >= 0 ? tab[hash_slot(key[i], hshift)] : 0ull;
+          }
 #pragma unroll
-              for (int k = 0; k < 8; ++k) if (ncand == k) mc[k] = id[i];
+          for (int i = 0; i < 9; ++i) id9[i] = key[i] >= 0 ? hash_resolve(tab, hshift, key[i], hash_slot(key[i], hshift), ent[i]) : -1;
+#pragma unroll
+          for (int i = 0; i < 9; ++i) cid9[i] = id9[i] >= 0 ? cid_c[id9[i]] : -1;
+#pragma unroll
+          for (int i = 0; i < 9; ++i)
+            if (id9[i] >= 0 && cid9[i] == target) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) if (ncand == k) mc[k] = id9[i];
               ++ncand;
             }
-          }
-      }
+        }
       if (ncand > 0) {
         const int ca[4] = {mc[0], mc[1], mc[2], mc[3]}, cb2[4] = {mc[4], mc[5], mc[6], mc[7]};
         scan_batch4(d, so, st, sp, ca, target, false, q, lbn, best, budget);
@@ -2818,7 +2823,7 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
 
 static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B);
-  if (d.fuse_scans && d.gmode != 1 && !getenv("MOR_TWO_PASS_SPLIT")) {
+  if (d.fuse_scans && d.gmode != 1 && !d.two_pass_split) {
     (void)hipMemsetAsync(d.split_desc + (size_t)d.s0 * d.tiles_max, 0, (size_t)d.B * d.tiles_max * sizeof(unsigned long long), st);
     MOR_LAUNCH(MK_SPLIT, k_split, gT, d);
   } else {
@@ -2845,10 +2850,12 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
     }
     MOR_LAUNCH(MK_HEADS_SCATTER, k_heads_scatter, gM, d);
   }
-  if (d.gmode != 1) MOR_LAUNCH(MK_CELLBOXES, k_cellboxes, dim3(MOR_BOX_G * d.B), d);   // point boxes, smallest index, slabs (+ cell hash on the sort path)
+}
+static void mor_launch_boxes(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+  MOR_LAUNCH(MK_CELLBOXES, k_cellboxes, dim3(MOR_BOX_G * d.B), d);   // point boxes, smallest index, slabs (+ cell hash on the sort path)
 }
 
-void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+static void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gB(d.B);
   if (d.gmode == 0) {
     mor_launch_split_and_grid(d, st, tm);
@@ -2875,7 +2882,7 @@ void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   }
 }
 
-void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+static void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   if (d.cg_mode == 1) {
     mor_timer_begin(tm, MK_CG_SLAB, st);
     hipLaunchKernelGGL(k_cg_slab, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
@@ -2892,8 +2899,8 @@ void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   mor_timer_end(tm, MK_CELLGRAPH, st);
 }
 
-void mor_launch_mid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B);
+static void mor_launch_clusters(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // labels, cluster_indices, cluster points, centroids
+  const dim3 gM(d.B * d.tiles_m), gB(d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B);
   MOR_LAUNCH(MK_LABEL, k_label, gM, d);
   for (int pass = 0; pass < d.radix_passes; ++pass) {   // clustered points partitioned by cluster id, index order kept ⇒ cluster_indices
     const bool last = pass == d.radix_passes - 1;
@@ -2907,6 +2914,9 @@ void mor_launch_mid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   }
   MOR_LAUNCH(MK_STATS, k_stats, dim3(64, d.B), d);
   MOR_LAUNCH(MK_STATS_FIN, k_stats_fin, gKt, d);
+}
+static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // transform of ca, correspondences, first tiers of the scores
+  const dim3 gT(d.B * d.tiles), gB(d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B);
   if (d.has_prev) {
     MOR_LAUNCH(MK_XFORM_PREV, k_xform_prev, dim3(64, d.B), d);
     MOR_LAUNCH(MK_XFORM_FIN, k_xform_fin, gKt, d);
@@ -2922,16 +2932,34 @@ void mor_launch_mid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   }
 }
 
-void mor_launch_tail(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  const dim3 gB(d.B);
+static void mor_launch_scores2(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   if (d.has_prev && d.method == 1 && d.pde_ub > 0.f && d.pde_ub > d.pde_lb) {
     MOR_LAUNCH(MK_SCORE_BLOCK, k_score_block, dim3(MOR_SCORE_G * d.B), d);
     MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(MOR_PDE_G, d.B), d);
   }
+}
+static void mor_launch_decide(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+  const dim3 gB(d.B);
   MOR_LAUNCH(MK_DECIDE, k_decide, gB, d);
   mor_timer_begin(tm, MK_TRACK_PUSH, st);
   hipLaunchKernelGGL(k_track_push, gB, dim3(64), 0, st, d);
   mor_timer_end(tm, MK_TRACK_PUSH, st);
+}
+
+// The launches of one push, in dependency order, as MOR_N_PIECES pieces; the engine assigns consecutive pieces to its
+// stage streams.  Arrays written by one piece and read by a later one exist once per frame in flight; pieces 4's kernels
+// (transform of ca … first score tiers) stay together because they mutate / read the previous frame's cluster points.
+void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer *tm) {
+  switch (piece) {
+    case 0: mor_launch_grid(d, st, tm); break;
+    case 1: mor_launch_boxes(d, st, tm); break;
+    case 2: mor_launch_cellgraph(d, st, tm); break;
+    case 3: mor_launch_clusters(d, st, tm); break;
+    case 4: mor_launch_pairs(d, st, tm); break;
+    case 5: mor_launch_scores2(d, st, tm); break;
+    case 6: mor_launch_decide(d, st, tm); break;
+    default: break;
+  }
 }
 
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
