@@ -53,6 +53,8 @@ struct MorFrameInfo {        // per stream, produced on device
 // Temporal logic (T1 + the tracking loop of F1) as device state, one instance per stream.  O(clusters) sequential work
 // per frame: it runs in a one-workgroup-per-stream kernel right behind the geometry so that push + filter need no
 // host round trip in between.  Mirrors csrc/mor_tracker.cpp (the host version behind the mor_tracker_* C ABI).
+#define MOR_MAX_DEPTH 6     // frames in flight in the stage pipeline, at most (one copy of every per-frame array each)
+#define MOR_MAX_SLOTS 8     // cluster-array slots (depth + 1 are in use)
 #define MOR_MAXP 32        // slabs per stream of the cell graph (k_cg_slab), at most
 #define MOR_CGS_OVF 8192   // overflow entries per slab of its candidate-pair lists (beyond them a pair is settled on the spot)
 #define MOR_CG_EXT 262144  // entries per stream of the helper workgroup's shell-pair list
@@ -96,7 +98,7 @@ struct MorDev {
   // ---- device arrays (per-stream stride noted)
   const MorStreamArgs *args; // [B]
   MorFrameInfo *info;        // [B]  this frame (one copy per frame in flight, like every array that crosses a stage boundary)
-  int2 *slot_kc[4];          // [B]  (K, C) of the frame that owns the cluster slot: written by the cell graph of that frame, read by the
+  int2 *slot_kc[MOR_MAX_SLOTS];          // [B]  (K, C) of the frame that owns the cluster slot: written by the cell graph of that frame, read by the
                              //      next frame's pair stage as ca's K and C (never through another frame's `info` copy, which the grid
                              //      stage of a later frame resets while the pair stage may still be running)
   unsigned *err;             // [B]  sticky error word per stream: every raised flag is OR-ed in and stays until the host has reported it
@@ -154,13 +156,13 @@ struct MorDev {
   int *rkeys2[2], *rvals2[2], *rhist2; // the same for the cluster partition (cluster stage runs beside the next frame's grid stage)
   int *cl_idx;               // [B][Nmax]  cluster_indices flattened (:218)
   // frame-slotted (cb / ca)
-  float4 *cl_pts[4];         // [B][Nmax]  clusters[k] points, (cluster, index) order (:229); ca's are transformed in place (:550)
-  int *cl_cid[4];            // [B][Nmax]  cluster id per cl_pts entry
-  int *cl_off[4];            // [B][Kcap+1]
-  int *chunk_off[4];         // [B][Kcap+1]  first reduction chunk of each cluster
+  float4 *cl_pts[MOR_MAX_SLOTS];         // [B][Nmax]  clusters[k] points, (cluster, index) order (:229); ca's are transformed in place (:550)
+  int *cl_cid[MOR_MAX_SLOTS];            // [B][Nmax]  cluster id per cl_pts entry
+  int *cl_off[MOR_MAX_SLOTS];            // [B][Kcap+1]
+  int *chunk_off[MOR_MAX_SLOTS];         // [B][Kcap+1]  first reduction chunk of each cluster
   Red6 *part, *part_back; int Wcap; // [B][Wcap]  per-chunk partials: scratch of k_stats (front stage) / k_xform_prev (pair stage)
-  float4 *centroid[4];       // [B][Kcap]  centroid_collection (:243)
-  float4 *amin[4], *amax[4]; // [B][Kcap]  cluster AABBs (getMinMax3D, :272-274)
+  float4 *centroid[MOR_MAX_SLOTS];       // [B][Kcap]  centroid_collection (:243)
+  float4 *amin[MOR_MAX_SLOTS], *amax[MOR_MAX_SLOTS]; // [B][Kcap]  cluster AABBs (getMinMax3D, :272-274)
   float4 *xcent, *xamin, *xamax; // [B][Kcap]  ca's centroids and AABBs after the transform into cb's frame (:540-550)
   // pair stage
   int *nn_fwd, *nn_bwd;      // [B][Kcap]

@@ -65,15 +65,15 @@ struct mor_batch {
   // Four in-order HIP streams form a software pipeline over frames (see mor_push_batch): grid stage on `sf`, cell graph on
   // `sc`, cluster extraction + pair stage on `sm`, wave-tier scores + tracking + filterCloud on `sb`.
   hipStream_t sf = nullptr, sc = nullptr, sm = nullptr, sb = nullptr;   // grid, cell graph, mid (clusters + pair stage), tail (scores wave tier, tracking, filterCloud)
-  hipEvent_t ev_piece[MOR_N_PIECES][4] = {}, ev_back[4] = {};
+  hipEvent_t ev_piece[MOR_N_PIECES][MOR_MAX_SLOTS] = {}, ev_back[MOR_MAX_SLOTS] = {};
   int stage_of[MOR_N_PIECES] = {0, 0, 1, 2, 2, 3, 3};   // stage stream of every launch piece (mor_device.h); the last piece and filterCloud run on stage 3
-  MorDev dtemp[3];                           // descriptor templates, frame k uses dtemp[k % 3] (static part + pointers)
+  MorDev dtemp[MOR_MAX_DEPTH];               // descriptor templates, frame k uses dtemp[k % depth] (static part + pointers)
   MorDev d;                                  // descriptor of the latest pushed frame
-  MorStreamArgs *d_args_s[3] = {nullptr, nullptr, nullptr};
+  MorStreamArgs *d_args_s[MOR_MAX_DEPTH] = {};
   std::vector<void *> dev_allocs, host_allocs;
   MorStreamArgs *h_args_ring = nullptr, *h_args = nullptr;   // pinned ring of MOR_ARGS_RING slots (async pushes), current slot
   hipEvent_t args_ev[MOR_ARGS_RING] = {};
-  uint64_t pipe_depth = 3;
+  uint64_t pipe_depth = 4, n_slots = 5;       // frames in flight (= copies of the per-frame arrays); cluster-array slots = depth + 1
   int env_cg_p = 0, env_help_pct = 15;       // tuning knobs from the environment, read once at creation
   bool async = false, pending = false;   // async: push/filter only enqueue; pending: work enqueued since the last wait
   unsigned char *d_moving = nullptr;
@@ -246,7 +246,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (hipSetDevice(device) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipSetDevice(%d) failed", device));
   b = new mor_batch(); memset(&b->d, 0, sizeof b->d);
   b->p = *p; b->n_bad = n_bad; b->n_good = n_good; b->B = n_streams; b->device = device; b->Nmax = max_points;
-  if (getenv("MOR_PIPE_DEPTH")) b->pipe_depth = std::min(3, std::max(1, atoi(getenv("MOR_PIPE_DEPTH"))));
+  if (getenv("MOR_PIPE_DEPTH")) b->pipe_depth = std::min(MOR_MAX_DEPTH, std::max(1, atoi(getenv("MOR_PIPE_DEPTH"))));
+  b->n_slots = b->pipe_depth + 1;
   if (getenv("MOR_CG_P")) b->env_cg_p = atoi(getenv("MOR_CG_P"));
   if (const char *st = getenv("MOR_STAGES")) {   // tuning: stage stream (0…3) of each launch piece, e.g. 0012233; non-decreasing, last piece on stage 3
     bool okc = strlen(st) == MOR_N_PIECES;
@@ -299,7 +300,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.ppos, B * N) && dalloc(b, d.pslot, B * N) && dalloc(b, d.gh_rowlist, B * N) && dalloc(b, d.gh_cells, B * N) && dalloc(b, d.gh_rowfill, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, d.gh_key, B * (size_t)d.Hcell) && dalloc(b, d.gh_val, B * (size_t)d.Hcell);
   ok = ok && dalloc(b, d.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, d.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, d.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, d.lroot_a, B * N) && dalloc(b, d.lroot_b, B * N) && dalloc(b, d.parent2, B * N);
   ok = ok && dalloc(b, d.xcent, B * K) && dalloc(b, d.xamin, B * K) && dalloc(b, d.xamax, B * K);
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < (int)b->n_slots; ++i)
     ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.chunk_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K);
   d.Wcap = (int)(N / MOR_CHUNK + K + 2);
   ok = ok && dalloc(b, d.part, B * (size_t)d.Wcap) && dalloc(b, d.part_back, B * (size_t)d.Wcap);
@@ -314,9 +315,9 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = hipMemcpy(d.zorg, z0.data(), B * sizeof(float), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d.zbase, zb.data(), B * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
   }
   ok = ok && dalloc(b, b->d_moving, B * K + B) && dalloc(b, d.otile_cnt, B * T) && dalloc(b, b->d_outptrs, B);
-  for (int i = 0; i < 4; ++i) ok = ok && dalloc(b, d.slot_kc[i], B);
+  for (int i = 0; i < (int)b->n_slots; ++i) ok = ok && dalloc(b, d.slot_kc[i], B);
   ok = ok && dalloc(b, d.err, B) && halloc(b, d.h_err, B) && halloc(b, d.h_log, B * (size_t)MOR_LOG_CAP);
-  if (ok) { ok = hipMemset(d.err, 0, B * sizeof(unsigned)) == hipSuccess; for (int i = 0; i < 4; ++i) ok = ok && hipMemset(d.slot_kc[i], 0, B * sizeof(int2)) == hipSuccess; }
+  if (ok) { ok = hipMemset(d.err, 0, B * sizeof(unsigned)) == hipSuccess; for (int i = 0; i < (int)b->n_slots; ++i) ok = ok && hipMemset(d.slot_kc[i], 0, B * sizeof(int2)) == hipSuccess; }
   d.moving = b->d_moving;
   ok = ok && dalloc(b, d.tr, B) && dalloc(b, d.tr_corr, B * MOR_TR_NB * K) && dalloc(b, d.tr_res, B * (MOR_TR_NB + 1) * K) && dalloc(b, d.tr_lastdet, B * K);
   if (ok) ok = hipMemset(d.tr, 0, B * sizeof(MorTrackDev)) == hipSuccess && hipMemset(b->d_moving, 0, B * K + B) == hipSuccess;
@@ -328,7 +329,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (!ok) return fail(set_error(MOR_ERR_HIP, "device/host allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
   // two more copies of every per-frame array that crosses a stage boundary (frame k uses copy k % 3)
   b->dtemp[0] = d;
-  for (int c = 1; c < 3; ++c) {
+  for (int c = 1; c < (int)b->pipe_depth; ++c) {
     b->dtemp[c] = d;
     MorDev &o = b->dtemp[c]; MorStreamArgs *dargs1 = nullptr;
     ok = dalloc(b, dargs1, B) && dalloc(b, o.info, B) && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, 2 * B * N) && dalloc(b, o.gp_idx, B * N);
@@ -342,7 +343,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     if (ok) ok = hipMemcpy(o.zorg, d.zorg, B * sizeof(float), hipMemcpyDeviceToDevice) == hipSuccess;
     if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
   }
-  for (int i = 0; i < 3; ++i) if (hipMemset(b->dtemp[i].info, 0, B * sizeof(MorFrameInfo)) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "memset failed"));
+  for (int i = 0; i < (int)b->pipe_depth; ++i) if (hipMemset(b->dtemp[i].info, 0, B * sizeof(MorFrameInfo)) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "memset failed"));
   b->d = b->dtemp[0];
   b->prev_pose.resize(B);
   if (err) *err = MOR_OK;
@@ -355,7 +356,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   if (!b || !clouds || !poses) return set_error(MOR_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(b->device));
   const uint64_t k = b->frame;
-  MorDev d = b->dtemp[k % 3]; const int B = d.B;
+  MorDev d = b->dtemp[k % b->pipe_depth]; const int B = d.B;
   uint64_t maxn = 0; size_t max_host_bytes = 0;
   for (int s = 0; s < B; ++s) {
     const mor_cloud_view &c = clouds[s];
@@ -402,7 +403,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
       d.cg_help_min = (int)std::max<uint32_t>(occ[std::min(B - 1, B - 1 - B * frac / 100 + 1)], 1024u);
     }
   }
-  d.cur = (int)(k % 4); d.prev = (int)((k + 3) % 4); d.has_prev = k > 0; d.out_ptrs = nullptr; d.run_tracker = 0; d.frame_no = (int)k;
+  d.cur = (int)(k % b->n_slots); d.prev = (int)((k + b->n_slots - 1) % b->n_slots); d.has_prev = k > 0; d.out_ptrs = nullptr; d.run_tracker = 0; d.frame_no = (int)k;
   {  // workgroups for the cloud-sized kernels: 1.25 × the largest cloud / cluster set the device last reported
     uint32_t mx = 0;
     for (int s = 0; s < B; ++s) mx = std::max(mx, std::max(d.h_info[s].M, d.h_info[s].C));
@@ -413,27 +414,27 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   //      uses (same buffer copy; its cluster slot doubles as the `ca` slot of frame k−depth+1)
   hipStream_t S[4] = {b->sf, b->sc, b->sm, b->sb};
   {
-    const uint64_t depth = b->pipe_depth;   // frames in flight: 3 = what the buffers allow; fewer = less overlap
-    if (k >= depth) HIP_TRY(hipStreamWaitEvent(S[b->stage_of[0]], b->ev_back[(k - depth) % 4], 0));
+    const uint64_t depth = b->pipe_depth;   // frames in flight = copies of the per-frame arrays
+    if (k >= depth) HIP_TRY(hipStreamWaitEvent(S[b->stage_of[0]], b->ev_back[(k - depth) % MOR_MAX_SLOTS], 0));
   }
   hipStream_t s0 = S[b->stage_of[0]];
   for (int s = 0; s < B; ++s) {   // host-resident blobs are staged through device memory
     const mor_cloud_view &c = clouds[s];
     if (!c.on_device && c.n_points) HIP_TRY(hipMemcpyAsync((void *)b->h_args[s].data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, s0));
   }
-  HIP_TRY(hipMemcpyAsync(b->d_args_s[k % 3], b->h_args, sizeof(MorStreamArgs) * B, hipMemcpyHostToDevice, s0));
+  HIP_TRY(hipMemcpyAsync(b->d_args_s[k % b->pipe_depth], b->h_args, sizeof(MorStreamArgs) * B, hipMemcpyHostToDevice, s0));
   HIP_TRY(hipEventRecord(b->args_ev[slot], s0));
   HIP_TRY(hipEventRecord(b->ev[0], s0));
   for (int pc = 0; pc < MOR_N_PIECES; ++pc) {
     hipStream_t st = S[b->stage_of[pc]];
     if (pc > 0 && b->stage_of[pc] != b->stage_of[pc - 1]) {
-      HIP_TRY(hipEventRecord(b->ev_piece[pc - 1][k % 4], S[b->stage_of[pc - 1]]));
-      HIP_TRY(hipStreamWaitEvent(st, b->ev_piece[pc - 1][k % 4], 0));
+      HIP_TRY(hipEventRecord(b->ev_piece[pc - 1][k % MOR_MAX_SLOTS], S[b->stage_of[pc - 1]]));
+      HIP_TRY(hipStreamWaitEvent(st, b->ev_piece[pc - 1][k % MOR_MAX_SLOTS], 0));
     }
     mor_launch_piece(d, pc, st, &b->timer);
   }
   HIP_TRY(hipEventRecord(b->ev[1], b->sb));
-  HIP_TRY(hipEventRecord(b->ev_back[k % 4], b->sb));
+  HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], b->sb));
   HIP_TRY(hipGetLastError());
   b->d = d; b->frame++; b->filtered = false; b->pending = true;
   if (b->async) return MOR_OK;
@@ -460,7 +461,7 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
   HIP_TRY(hipEventRecord(b->ev[2], b->sb));
   mor_launch_filter(d, b->sb, &b->timer);
   HIP_TRY(hipEventRecord(b->ev[3], b->sb));
-  HIP_TRY(hipEventRecord(b->ev_back[k % 4], b->sb));
+  HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], b->sb));
   HIP_TRY(hipGetLastError());
   b->pending = true;
   const bool need_host = n_out != nullptr || (out && !out_on_device);
