@@ -34,14 +34,14 @@ def build_hip(force=False, verbose=False):
 
 
 def build_hip_smalllist(force=False):
-    """Test-only variant of the library with an 8-entry deferred-pair list in k_cellgraph, so that small scenes
+    """Test-only variant of the library with two-entry per-wave candidate lists in k_cg_slab, so that small scenes
     exercise the global overflow list (tests/test_gpu_parity.py::test_deferred_pair_overflow_list)."""
     out = os.path.join(CSRC, "libmor_hip_smalllist.so")
     deps = [os.path.join(CSRC, f) for f in HIP_SOURCES + HIP_HEADERS]
     if not force and not _newer(out, deps):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-DCG_LIST=8", "-DCGS_LISTW=16",
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-DCGS_LISTW=16",
                            "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-x", "hip"] + [os.path.join(CSRC, f) for f in HIP_SOURCES] + ["-o", out])
     return out
 

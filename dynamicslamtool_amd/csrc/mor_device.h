@@ -57,8 +57,6 @@ struct MorFrameInfo {        // per stream, produced on device
 #define MOR_MAX_SLOTS 8     // cluster-array slots (depth + 1 are in use)
 #define MOR_MAXP 32        // slabs per stream of the cell graph (k_cg_slab), at most
 #define MOR_CGS_OVF 8192   // overflow entries per slab of its candidate-pair lists (beyond them a pair is settled on the spot)
-#define MOR_CG_EXT 262144  // entries per stream of the helper workgroup's shell-pair list
-#define MOR_CG_OVF 65536   // overflow entries per stream of the cell graph's deferred-pair list
 #define MOR_TR_MAXT 512   // tracked moving centroids per stream (mo_vec)
 #define MOR_TR_NB 8       // longest supported window (n_bad)
 struct MorTrackDev {
@@ -126,7 +124,7 @@ struct MorDev {
   int *gh_key, *gh_val;      // [B][Hcell] hash path: the cell table of streams with more cells than the LDS table holds
   int grid_mode, gh_tier;   // grid_mode 0: points radix-sorted by cell key; 1: cells counted in a hash table (k_gridhash); gh_tier: table tier k_gridhash starts with (0 small LDS table, 1 big LDS table, 2 global memory)
   int *slab_y, *slab_c, *slab_e;    // [B][MOR_MAXP+1]  slabs of the cell graph: first y-slice, first compact cell id, end of the look-ahead (cells of the next two y-slices)
-  int P, cg_mode, cg_force_global;  // slabs per stream this frame; cg_mode 0: one workgroup per stream (k_cellgraph), 1: slabs (k_cg_slab + k_cg_final); test knob: forests in global memory
+  int P, cg_force_global;    // slabs per stream this frame; test knob: forests in global memory
   int *lroot_a, *lroot_b;    // [B][Nmax]  per cell: its local root in its own slab / in the previous slab's look-ahead (compact ids)
   int *parent2;              // [B][Nmax]  second global forest (odd slabs when they do not fit LDS)
   int *skey, *sidx;          // aliases of the radix buffers holding the cell-sorted (key, cloud index)
@@ -140,7 +138,6 @@ struct MorDev {
   float4 *crep;              // [B][Nmax]  per occupied cell: its first point (sample for the quick edge test of the cell graph)
   float4 *sorted;            // [B][Nmax]  (x,y,z, bits(cloud index)) in cell order; .w becomes the cluster id after labelling
   int *parent;               // [B][Nmax]  union-find forest over occupied cells (parent ≤ child)
-  int *cg_ext, *cg_help; int cg_help_min; // [B][MOR_CG_EXT], [B][4]  k_cellgraph: shell-pass candidate pairs listed by a heavy stream's helper workgroup ((a << 14) | b), its flag + count; cell count from which a stream gets a helper (0: none)
   int *cg_ovf;               // [B][2][MOR_CG_OVF][2]  k_cellgraph: candidate cell pairs beyond its LDS list; undecided big cell pairs
   int *croot;                // [B][Nmax]  flattened root per cell
   int *csize;                // [B][Nmax]  component size (points) at its root cell

@@ -74,7 +74,7 @@ struct mor_batch {
   MorStreamArgs *h_args_ring = nullptr, *h_args = nullptr;   // pinned ring of MOR_ARGS_RING slots (async pushes), current slot
   hipEvent_t args_ev[MOR_ARGS_RING] = {};
   uint64_t pipe_depth = 4, n_slots = 5;       // frames in flight (= copies of the per-frame arrays); cluster-array slots = depth + 1
-  int env_cg_p = 0, env_help_pct = 15;       // tuning knobs from the environment, read once at creation
+  int env_cg_p = 0;                          // tuning knob from the environment, read once at creation
   bool async = false, pending = false;   // async: push/filter only enqueue; pending: work enqueued since the last wait
   unsigned char *d_moving = nullptr;
   float4 **h_outptrs = nullptr, **d_outptrs = nullptr;
@@ -161,16 +161,15 @@ static int configure(mor_batch *b) {
   }
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
   d.fuse_scans = getenv("MOR_NO_FUSE") ? 0 : 1;   // refined per push (tile count)
-  d.two_pass_split = getenv("MOR_TWO_PASS_SPLIT") ? 1 : 0;
+  d.two_pass_split = getenv("MOR_SINGLE_PASS_SPLIT") ? 0 : 1;   // count pass + scatter pass (the second read comes from the Infinity Cache); the single-pass split with decoupled look-back measured 5 % slower in the pipeline
   d.split_variant = getenv("MOR_SPLIT_VARIANT") ? atoi(getenv("MOR_SPLIT_VARIANT")) : 0;
   d.use_hash = d.method == 1;
   { size_t hc = 1024; while (hc < 4 * (size_t)d.Nmax) hc <<= 1; d.Hcell = (int)hc; }
   d.t1_budget = getenv("MOR_T1_BUDGET") ? atoi(getenv("MOR_T1_BUDGET")) : 64;
   // development / test switches (defaults: the fast paths): MOR_GRID=radix sorts the points by cell key instead of counting
-  // cells in a hash table; MOR_CG=wg runs the cell graph as one workgroup per stream instead of over y-slabs;
+  // cells in a hash table;
   // MOR_GH_TIER=1|2 starts k_gridhash with its big LDS table / its global-memory table; MOR_CG_GLOBAL forces the global-memory forests
   d.grid_mode = (getenv("MOR_GRID") && !strcmp(getenv("MOR_GRID"), "radix")) ? 0 : 1;
-  d.cg_mode = (getenv("MOR_CG") && !strcmp(getenv("MOR_CG"), "wg")) ? 0 : 1;
   d.gh_tier = getenv("MOR_GH_TIER") ? atoi(getenv("MOR_GH_TIER")) : 0; d.cg_force_global = getenv("MOR_CG_GLOBAL") ? 1 : 0;
   d.P = 1;
   if (d.score_R > 60) return set_error(MOR_ERR_INVALID, "pde_ub %g needs a %d-cell search radius (> 60)", (double)p.pde_ub, d.score_R);
@@ -254,7 +253,6 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     for (int i = 0; okc && i < MOR_N_PIECES; ++i) okc = st[i] >= '0' && st[i] <= '3' && (i == 0 || st[i] >= st[i - 1]);
     if (okc && st[MOR_N_PIECES - 1] == '3') for (int i = 0; i < MOR_N_PIECES; ++i) b->stage_of[i] = st[i] - '0';
   }
-  if (getenv("MOR_CG_HELP_PCT")) b->env_help_pct = atoi(getenv("MOR_CG_HELP_PCT"));
   if ((rc = configure(b)) != MOR_OK) return fail(rc);
   if (n_bad > MOR_TR_NB) return fail(set_error(MOR_ERR_INVALID, "n_bad = %d: windows longer than %d frames are not supported", n_bad, MOR_TR_NB));
   for (auto &ev : b->args_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
@@ -295,8 +293,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (d.use_hash) ok = ok && dalloc(b, d.chash, B * (size_t)d.Hcell); else d.chash = nullptr;
   ok = ok && dalloc(b, d.split_desc, B * T);
   ok = ok && dalloc(b, d.crep, B * N);
-  ok = ok && dalloc(b, d.cg_ext, B * (size_t)MOR_CG_EXT) && dalloc(b, d.cg_help, B * 4);
-  ok = ok && dalloc(b, d.cg_ovf, B * std::max((size_t)MOR_CG_OVF * 4, (size_t)MOR_MAXP * MOR_CGS_OVF * 4));
+  ok = ok && dalloc(b, d.cg_ovf, B * (size_t)MOR_MAXP * MOR_CGS_OVF * 2);
   ok = ok && dalloc(b, d.ppos, B * N) && dalloc(b, d.pslot, B * N) && dalloc(b, d.gh_rowlist, B * N) && dalloc(b, d.gh_cells, B * N) && dalloc(b, d.gh_rowfill, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, d.gh_key, B * (size_t)d.Hcell) && dalloc(b, d.gh_val, B * (size_t)d.Hcell);
   ok = ok && dalloc(b, d.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, d.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, d.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, d.lroot_a, B * N) && dalloc(b, d.lroot_b, B * N) && dalloc(b, d.parent2, B * N);
   ok = ok && dalloc(b, d.xcent, B * K) && dalloc(b, d.xamin, B * K) && dalloc(b, d.xamax, B * K);
@@ -388,20 +385,13 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   d.tiles = std::max<int>(1, (int)((maxn + MOR_TILE - 1) / MOR_TILE));
   d.fuse_scans = d.fuse_scans && d.tiles <= 2048;
   {  // cell graph: slabs per stream (k_cg_slab) — enough that a slab's cells fit its LDS with room for imbalance, and that
-     // the launch fills the GPU (two 256-thread workgroups per CU); the one-workgroup variant gets its helper threshold
+     // the launch fills the GPU (two 512-thread workgroups per CU)
     uint32_t maxocc = 0;
-    std::vector<uint32_t> occ(B);
-    for (int s = 0; s < B; ++s) { occ[s] = k > 0 ? d.h_info[s].n_occ : 0; maxocc = std::max(maxocc, occ[s]); }
+    for (int s = 0; s < B; ++s) maxocc = std::max(maxocc, k > 0 ? d.h_info[s].n_occ : 0u);
     const int p_fit = (int)((maxocc * 3ull / 2 + 818) / 819), p_par = (512 + B - 1) / B;   // a slab's LDS holds 1024 cells (own + look-ahead); two 512-thread workgroups per CU
     d.P = b->env_cg_p > 0 ? b->env_cg_p : std::max(p_fit, p_par);
     d.P = std::max(1, std::min(d.P, std::min(MOR_MAXP, std::max(1, d.g.ny / 2))));
     if (!getenv("MOR_GH_TIER")) d.gh_tier = maxocc * 5ull / 4 > 6144 ? (maxocc * 5ull / 4 > 12288 ? 2 : 1) : 0;   // table tier k_gridhash starts with (a stream whose table overflows moves up by itself)
-    d.cg_help_min = 0;
-    const int frac = b->env_help_pct;   // share of the streams, in percent
-    if (d.cg_mode == 0 && k > 0 && B >= 8 && frac > 0) {
-      std::sort(occ.begin(), occ.end());
-      d.cg_help_min = (int)std::max<uint32_t>(occ[std::min(B - 1, B - 1 - B * frac / 100 + 1)], 1024u);
-    }
   }
   d.cur = (int)(k % b->n_slots); d.prev = (int)((k + b->n_slots - 1) % b->n_slots); d.has_prev = k > 0; d.out_ptrs = nullptr; d.run_tracker = 0; d.frame_no = (int)k;
   {  // workgroups for the cloud-sized kernels: 1.25 × the largest cloud / cluster set the device last reported
@@ -601,7 +591,7 @@ long long mor_debug_read(const mor_batch *b, const char *name, int s, void *out,
 int mor_debug_config(const mor_batch *b, int *out, int n) {   // grid geometry and launch configuration of the latest push
   if (!b || !out) return MOR_ERR_INVALID;
   const MorDev &d = b->d;
-  const int v[12] = {d.g.nx, d.g.ny, d.g.nz, d.g.nrows, d.P, d.grid_mode, d.cg_mode, d.Hcell, d.Kcap, d.tiles_m, d.cur, d.prev};
+  const int v[12] = {d.g.nx, d.g.ny, d.g.nz, d.g.nrows, d.P, d.grid_mode, 1, d.Hcell, d.Kcap, d.tiles_m, d.cur, d.prev};
   for (int i = 0; i < n && i < 12; ++i) out[i] = v[i];
   return MOR_OK;
 }

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
       atomicExch(&desc[t], split_pack(t == 0 ? SPLIT_P : SPLIT_A, tng, tg));
     }
     int ex_ng = 0, ex_g = 0;
-    if (t > 0) {
+    if (t > 0 && !(d.split_variant & 4)) {
       int back = t - 1; unsigned spins = 0;
       for (;;) {
         const int j = back - lane;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
     }
   }
   __syncthreads();
-  if ((uint32_t)t * MOR_TILE >= n_in) return;
+  if ((uint32_t)t * MOR_TILE >= n_in || (d.split_variant & 2)) return;
   int r_ng = s_ex[0], r_g = s_ex[1];
   for (int w = 0; w < wave_id(); ++w) { r_ng += sh[w]; r_g += sh[4 + w]; }
   const size_t so = (size_t)s * d.Nmax;
@@ -399,11 +399,10 @@ __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
       int cx, cy, cz; bool clamped; grid_cell(d.g, p[it], zorg, zbase, cx, cy, cz, clamped);
       if (clamped && d.gmode != 0) mor_raise(d, s, 8u);
       d.cloud[so + k_ng] = p[it];
-      d.cloud_tidx[so + k_ng] = k_ng + k_g;
-      d.pkey[so + k_ng] = grid_key(d.g, cx, cy, cz);
+      if (!(d.split_variant & 8)) { d.cloud_tidx[so + k_ng] = k_ng + k_g; d.pkey[so + k_ng] = grid_key(d.g, cx, cy, cz); }
     } else if (cls[it] == 1) {
-      d.ground[2 * so + d.Nmax + k_g] = p[it];
-      d.gp_idx[so + k_g] = k_ng + k_g;
+      if (!(d.split_variant & 16)) d.ground[2 * so + d.Nmax + k_g] = p[it];
+      if (!(d.split_variant & 8)) d.gp_idx[so + k_g] = k_ng + k_g;
     }
     r_ng += __popcll(m_ng[it]); r_g += __popcll(m_g[it]);
   }
@@ -751,24 +750,11 @@ __global__ __launch_bounds__(MOR_BT) void k_gridfill(MorDev d) {
     d.sorted[so + d.ppos[so + i]] = q;
   }
 }
-// ------------------------------------------------------------------------------------ C1: Euclidean clustering = connected components over cells,
-// the whole cell graph of one stream in ONE workgroup.
+// ------------------------------------------------------------------------------------ C1: Euclidean clustering = connected components over cells
 // Per-cell kernels over global memory are bound by chains of dependent loads (key → row table → key → parent →
-// parent …, ≈ 1–2 µs a hop).  A stream's cell graph is small (a few thousand occupied cells): one 1024-thread
-// workgroup per stream keeps the distinct keys, the row table and the union-find forest in LDS (160 KiB per CU on
-// CDNA4), so every hop of those chains is an LDS access and all unions are LDS atomics; only the point boxes and the
-// point coordinates of tested pairs come from L2/HBM.  The kernel covers both hook passes, flattening, component
-// sizes / min indices, cluster selection, ordering and offsets.  Streams whose cell count exceeds the LDS capacity
-// run the same code on their global-memory arrays (≈ 3× slower at equal size).
-#define CG_T 1024
-#ifndef CG_CAP
-#define CG_CAP 12288     // occupied cells held in LDS (keys + union-find forest; point ranges stay in global memory)
-#endif
-#define CG_ROWCAP 8192   // (y,z) rows held in LDS
-#ifndef CG_LIST
-#define CG_LIST 2040     // deferred (cell | cell pair) entries
-#endif
-
+// parent …, ≈ 1–2 µs a hop), so the cell graph is worked on in LDS: union-find forests with LDS atomics (cg_find /
+// cg_unite below, also usable on global arrays with agent-scope accesses), distinct keys and row tables staged per
+// workgroup; only the point coordinates of the few pairs nothing cheaper decides come from L2 / HBM.
 template <bool LDS> __device__ __forceinline__ int cg_ld(const int *p) {
   return LDS ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -859,11 +845,6 @@ __device__ __forceinline__ void wave_box(const float4 *sp, int b, int e, int lan
   lo = make_float4(lx, ly, lz, 0.f); hi = make_float4(hx, hy, hz, 0.f);
 }
 
-#ifdef MOR_EXP_STAMPS
-#define CG_CNT(i, x) atomicAdd(&d.dbg[(size_t)s * 16 + 8 + (RING - 1) * 4 + (i)], (unsigned long long)(x))
-#else
-#define CG_CNT(i, x)
-#endif
 // first index in [lo, lo+n) whose key is ≥ k0, by 8-ary search: every step fetches its seven pivots with independent
 // loads, so a row of 500 cells costs three load latencies instead of the nine dependent ones of a binary search (the
 // wave pays the latency of its longest row in every iteration of the hook passes)
@@ -880,139 +861,6 @@ __device__ __forceinline__ int cg_lower_bound8(const int *key, int lo, int n, in
   for (int i = 0; i < 8; ++i) below += (i < n) && key[lo + min(i, n - 1)] < k0;
   return lo + below;
 }
-// One hook pass over the forward half of the (2·RING+1)³ neighbourhood, ring == RING only, in three phases:
-//  A  enumeration, LDS only: every thread walks the neighbour rows of its cells and appends each neighbour cell that
-//     is not yet in its component to a pair list (LDS, spilling to global memory).  No global load, no divergent
-//     heavy code: before this split the whole wave executed box loads and point tests whenever one lane needed them
-//     (VALU utilisation of the tests ≈ 15 %).
-//  B1 one THREAD per listed pair, all lanes busy: roots re-checked (earlier unions settle most pairs), the two point
-//     boxes (gap ≥ r ⇒ no edge; farthest corners < r ⇒ edge), else the points — exhaustively for small cells, a
-//     16 × 16 sample for big × big ones, whose undecided rest (mostly true non-edges) goes to a second list.
-//  B2 one WAVE per pair of the second list: pruned exhaustive test (pair_hit_wave).
-// Pair lists: entries [0, CG_LIST) in LDS, the rest in the stream's global overflow area; second list global only.
-// LDS mode: compact ids are < 16384, a pair is one word (a << 14 | b) — the LDS part of the list holds 2·CG_LIST of
-// them and the spill to global memory is one 4-byte store per pair; global mode: two words per pair.
-template <bool LDS> __device__ __forceinline__ void cg_list_put(const MorDev &d, int s, int *l_list, int slot, int region, int a, int b) {
-  constexpr int W = LDS ? 1 : 2, NL = 2 * CG_LIST / W;   // words per pair, pairs in the LDS part (region 0 only)
-  if (region == 0 && slot < NL) { if (LDS) l_list[slot] = (a << 14) | b; else { l_list[2 * slot] = a; l_list[2 * slot + 1] = b; } return; }
-  int *ov = d.cg_ovf + ((size_t)s * 2 + region) * MOR_CG_OVF * 2 + (size_t)(region == 0 ? slot - NL : slot) * W;
-  if (LDS) cg_st<false>(ov, (a << 14) | b); else { cg_st<false>(ov, a); cg_st<false>(ov + 1, b); }
-}
-template <bool LDS> __device__ __forceinline__ void cg_list_get(const MorDev &d, int s, const int *l_list, int slot, int region, int &a, int &b) {
-  constexpr int W = LDS ? 1 : 2, NL = 2 * CG_LIST / W;
-  if (region == 0 && slot < NL) { if (LDS) { const int c = l_list[slot]; a = c >> 14; b = c & 16383; } else { a = l_list[2 * slot]; b = l_list[2 * slot + 1]; } return; }
-  const int *ov = d.cg_ovf + ((size_t)s * 2 + region) * MOR_CG_OVF * 2 + (size_t)(region == 0 ? slot - NL : slot) * W;
-  if (LDS) { const int c = cg_ld<false>(ov); a = c >> 14; b = c & 16383; } else { a = cg_ld<false>(ov); b = cg_ld<false>(ov + 1); }
-}
-static_assert(CG_CAP <= 16384, "pair lists pack two compact cell ids into 28 bits");
-// capacity of list `region` in pairs
-template <bool LDS> __device__ __forceinline__ int cg_list_cap(int region) { return (region == 0 ? 2 * CG_LIST / (LDS ? 1 : 2) : 0) + MOR_CG_OVF * (LDS ? 2 : 1); }
-// decides one pair: returns 1 = edge, 0 = no edge, −1 = big × big and undecided by the sample
-__device__ __forceinline__ int cg_pair_test(const MorDev &d, size_t so, const int *start, const float4 *sp, int a, int b, float r2) {
-  const float4 alo = d.cmeta[2 * (so + a)], ahi = d.cmeta[2 * (so + a) + 1], blo = d.cmeta[2 * (so + b)], bhi = d.cmeta[2 * (so + b) + 1];
-  const float4 pa = d.crep[so + a], pb = d.crep[so + b];                            // one point of each cell
-  const int a0 = start[a], a1 = start[a + 1], b0 = start[b], b1 = start[b + 1];   // issued with the boxes: one level of loads
-  // boxes of the two cells' points: gap ≥ r ⇒ no edge; farthest corners < r ⇒ every pair is an edge
-  float gx = fmaxf(fmaxf(blo.x - ahi.x, alo.x - bhi.x), 0.f), gy = fmaxf(fmaxf(blo.y - ahi.y, alo.y - bhi.y), 0.f), gz = fmaxf(fmaxf(blo.z - ahi.z, alo.z - bhi.z), 0.f);
-  if ((gx * gx + gy * gy + gz * gz) * 0.999f >= r2) return 0;
-  float sx = fmaxf(bhi.x - alo.x, ahi.x - blo.x), sy = fmaxf(bhi.y - alo.y, ahi.y - blo.y), sz = fmaxf(bhi.z - alo.z, ahi.z - blo.z);
-  if ((sx * sx + sy * sy + sz * sz) * 1.001f < r2) return 1;
-  if (sqdist(pa.x, pa.y, pa.z, pb.x, pb.y, pb.z) < r2) return 1;   // the two sample points are an edge already (most neighbouring cells of one surface)
-  const int na = a1 - a0, nb = b1 - b0;
-  if ((long long)na * nb > 256) return pair_hit_serial(sp, a0, min(na, 16), b0, min(nb, 16), r2) ? 1 : -1;   // dense neighbours nearly always show an edge within a small sample
-  return pair_hit_serial(sp, a0, na, b0, nb, r2) ? 1 : 0;
-}
-template <bool LDS, int RING> __device__ __forceinline__ void cg_hook_pass(const MorDev &d, int s, int nocc, const int *key, const int *start, const int *rows, int *par,
-                                                                   const float4 *sp, int *l_list, int *l_nlist, int *l_n2, int n_ext) {
-  const float r2 = d.r2;
-  const size_t so = (size_t)s * d.Nmax;
-  const bool listed = n_ext >= 0;                                   // the helper workgroup has listed this pass's candidate pairs
-  const int *ext = d.cg_ext + (size_t)s * MOR_CG_EXT;
-  RS_T(tp0);
-  // ---- A: candidate pairs (unless the stream's helper workgroup has listed them)
-  if (!listed)
-  for (int a = threadIdx.x; a < nocc; a += CG_T) {
-    const int ka = key[a], rowa = ka / d.g.nx, x = ka - rowa * d.g.nx, z = rowa % d.g.nz, y = rowa / d.g.nz;
-    const int ra = cg_find<LDS>(par, a);
-    for (int dz = 0; dz <= RING; ++dz) {
-      if (z + dz >= d.g.nz) break;
-      for (int dy = (dz == 0 ? 0 : -RING); dy <= RING; ++dy) {
-        if ((unsigned)(y + dy) >= (unsigned)d.g.ny) continue;
-        const bool edge_row = dz == RING || abs(dy) == RING;   // every cell of this row lies on the ring
-        const int rr = grid_row(d.g, y + dy, z + dz), rlo = rows[rr], rn = rows[rr + 1] - rlo;
-        if (rn == 0) continue;
-        // ≤ 2·RING+1 ≤ 5 cells of the row lie within RING of x: a plain walk over the row's real cell count (a long row
-        // is entered at x − RING by an 8-ary search); a cell whose parent is a's root is skipped on the first load
-        const int rowbase = rr * d.g.nx + x;
-        int lo = rlo; const int hi = rlo + rn;
-        if (rn > 8) lo = cg_lower_bound8(key, rlo, rn, rowbase - RING);
-        for (int b = lo; b < hi; ++b) {
-          const int dx = key[b] - rowbase;
-          if (dx > RING) break;        // keys ascend along the row: nothing further can be in range
-          const bool fwd = !(dz == 0 && dy == 0 && dx <= 0);      // forward half: each unordered pair once
-          const bool ring = edge_row || abs(dx) == RING;           // inner cells belong to the previous pass
-          bool want = dx >= -RING && fwd && ring;
-          if (want) { const int pb = cg_ld<LDS>(par + b); want = pb != ra && cg_find<LDS>(par, b) != ra; }
-          // append (a, b): one LDS atomic per wave and iteration instead of one per pair (they all hit one counter)
-          const unsigned long long m = __ballot(want);
-          if (m) {
-            const int leader = __ffsll((long long)m) - 1; int base = 0;
-            if (lane_id() == leader) base = atomicAdd(l_nlist, __popcll(m));
-            base = __shfl(base, leader, 64);
-            if (want) {
-              const int slot = base + __popcll(m & lanemask_lt());
-              if (slot < cg_list_cap<LDS>(0)) cg_list_put<LDS>(d, s, l_list, slot, 0, a, b);
-              else {   // both lists full (never seen): settle it here, exhaustively
-                const int a0 = start[a], b0 = start[b];
-                if (pair_hit_serial(sp, a0, start[a + 1] - a0, b0, start[b + 1] - b0, r2)) cg_unite<LDS>(par, a, b);
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-  __threadfence_block();
-  __syncthreads();
-  RS_T(tp1);
-  // ---- B1: one thread per candidate pair
-  const int n1 = listed ? n_ext : min(*l_nlist, cg_list_cap<LDS>(0));
-  for (int h = threadIdx.x; h < n1; h += CG_T) {
-    int a, b;
-    if (listed) { const int code = cg_ld<false>(ext + h); a = code >> 14; b = code & 16383; } else cg_list_get<LDS>(d, s, l_list, h, 0, a, b);
-    if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;   // an earlier union has connected them
-    const int verdict = cg_pair_test(d, so, start, sp, a, b, r2);
-    if (verdict > 0) cg_unite<LDS>(par, a, b);
-    else if (verdict < 0) {
-      const int slot = atomicAdd(l_n2, 1);
-      if (slot < cg_list_cap<LDS>(1)) cg_list_put<LDS>(d, s, l_list, slot, 1, a, b);
-      else { const int a0 = start[a], b0 = start[b]; if (pair_hit_serial(sp, a0, start[a + 1] - a0, b0, start[b + 1] - b0, r2)) cg_unite<LDS>(par, a, b); }
-    }
-  }
-  __threadfence_block();
-  __syncthreads();
-  RS_T(tp2);
-  // ---- B2: one wave per undecided big pair — root re-check, pruned exhaustive test
-  const int n2 = min(*l_n2, cg_list_cap<LDS>(1)), lane = lane_id();
-  for (int h = wave_id(); h < n2; h += CG_T / 64) {
-    int a, b; cg_list_get<LDS>(d, s, l_list, h, 1, a, b);
-    if (cg_find<LDS>(par, a) == cg_find<LDS>(par, b)) continue;
-    const float4 alo = d.cmeta[2 * (so + a)], ahi = d.cmeta[2 * (so + a) + 1], blo = d.cmeta[2 * (so + b)], bhi = d.cmeta[2 * (so + b) + 1];
-    if (pair_hit_wave(sp, start[a], start[a + 1] - start[a], start[b], start[b + 1] - start[b], r2, lane, alo, ahi, blo, bhi) && lane == 0) cg_unite<LDS>(par, a, b);
-  }
-  __syncthreads();
-#ifdef MOR_EXP_STAMPS
-  if (threadIdx.x == 0) { RS_T(tp3); unsigned long long *g = d.dbg + (size_t)s * 16 + 8 + (RING - 1) * 4; g[0] = tp1 - tp0; g[1] = tp2 - tp1; g[2] = tp3 - tp2; g[3] = ((unsigned long long)n1 << 32) | (unsigned)n2; }
-#endif
-  if (threadIdx.x == 0) { *l_nlist = 0; *l_n2 = 0; }
-  __syncthreads();
-}
-
-#ifdef MOR_EXP_STAMPS
-#define CG_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) d.dbg[(size_t)s * 16 + (i)] = wall_clock64(); } while (0)
-#else
-#define CG_STAMP(i)
-#endif
 #define MOR_BOX_G 32      // workgroups per stream of k_cellboxes
 // Boxes of the cells' points (cmeta), for every stream at once at the end of the grid stage: 16 lanes per cell (most
 // cells hold a handful of points), four cells per wave-iteration.  (Used to be the first phase of k_cellgraph, where
@@ -1076,206 +924,9 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
       }
     }
   }
-#ifdef MOR_EXP_STAMPS
-
-#endif
 }
-template <bool LDS> __device__ __forceinline__ void cg_body(const MorDev &d, int s, int nocc, const int *key, const int *start, const int *rows, int *par,
-                                                              int *size, int *mn, int *cidr, int *l_list, int *l_nlist, int *l_misc) {
-  const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
-  const float4 *sp = d.sorted + so;
-  const int lane = lane_id();
-  CG_STAMP(1);
-  // (the boxes of the cells' points were written by k_cellboxes at the end of the grid stage)
-  CG_STAMP(2);
-  // ---- hooks: 3×3×3 neighbourhood first, then the 5×5×5 shell (mostly skipped by the root test)
-  cg_hook_pass<LDS, 1>(d, s, nocc, key, start, rows, par, sp, l_list, l_nlist, l_misc, -1);
-  CG_STAMP(3);
-  for (int c = threadIdx.x; c < nocc; c += CG_T) { const int r = cg_find<LDS>(par, c); if (r != c) cg_st<LDS>(par + c, r); }   // flat forest: the shell pass compares parents directly
-  __syncthreads();
-  // A heavy stream (many cells: the ones this kernel's duration hangs on) has a helper workgroup that has meanwhile
-  // listed the shell pass's candidate pairs — all of them, it has no forest to filter with; the root re-check of
-  // phase B1 drops nearly all at two LDS loads each.  Bounded wait; no list ⇒ this workgroup enumerates itself.
-  int n_ext = -1;
-  if (LDS && d.cg_help_min > 0 && nocc >= d.cg_help_min) {
-    if (threadIdx.x == 0) {
-      int *hf = d.cg_help + (size_t)s * 4; unsigned spins = 0;
-      while (atomicAdd(hf, 0) == 0 && ++spins < 2048u) __builtin_amdgcn_s_sleep(8);
-      l_misc[1] = atomicAdd(hf, 0) != 0 ? atomicAdd(hf + 1, 0) : -1;
-    }
-    __syncthreads();
-    n_ext = l_misc[1];
-    __syncthreads();
-  }
-  cg_hook_pass<LDS, 2>(d, s, nocc, key, start, rows, par, sp, l_list, l_nlist, l_misc, n_ext);
-  CG_STAMP(4);
-  // ---- components: size (points) and smallest cloud index at the root.  LDS mode has one scratch array left (`mn`
-  //      aliases the keys): sizes are accumulated in it first and parked in the global `size` array, then the minima
-  constexpr int PER = LDS ? CG_CAP / CG_T : 1;
-  if (LDS) {
-    int r_[PER], cnt_[PER];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) { int c = threadIdx.x + u * CG_T; r_[u] = -1; cnt_[u] = 0; if (c < nocc) { r_[u] = cg_find<LDS>(par, c); cnt_[u] = start[c + 1] - start[c]; } }
-    __syncthreads();
-    for (int c = threadIdx.x; c < nocc; c += CG_T) mn[c] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < PER; ++u) { int c = threadIdx.x + u * CG_T; if (c < nocc) atomicAdd(&mn[r_[u]], cnt_[u]); }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < PER; ++u) { int c = threadIdx.x + u * CG_T; if (c < nocc && r_[u] == c) cg_st<false>(size + c, mn[c]); }
-    __syncthreads();
-    for (int c = threadIdx.x; c < nocc; c += CG_T) mn[c] = 0x7fffffff;
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < PER; ++u) { int c = threadIdx.x + u * CG_T; if (c < nocc) atomicMin(&mn[r_[u]], d.cmin[so + c]); }
-  } else {
-    for (int c = threadIdx.x; c < nocc; c += CG_T) { size[c] = 0; mn[c] = 0x7fffffff; }
-    __syncthreads();
-    for (int c = threadIdx.x; c < nocc; c += CG_T) { int r = cg_find<LDS>(par, c); atomicAdd(&size[r], start[c + 1] - start[c]); atomicMin(&mn[r], d.cmin[so + c]); }
-  }
-  __syncthreads();
-  CG_STAMP(5);
-  // ---- kept components (:215-216) → scratch list; K
-  if (threadIdx.x == 0) l_misc[0] = 0;
-  __syncthreads();
-  for (int c = threadIdx.x; c < nocc; c += CG_T) {
-    const bool root = LDS ? (cg_ld<LDS>(par + c) == c) : (cg_find<LDS>(par, c) == c);
-    long long n = root ? (long long)cg_ld<false>(size + c) : 0;
-    if (root && n >= d.min_cs && n <= d.max_cs) {
-      int k = atomicAdd(&l_misc[0], 1);
-      if (k < d.Kcap) { d.kcell[ko + k] = c; d.kroot[ko + k] = mn[c]; d.ksize[ko + k] = (int)n; }
-    }
-  }
-  __syncthreads();
-  int K = l_misc[0];
-  if (K > d.Kcap) { if (threadIdx.x == 0) mor_raise(d, s, 1u); K = d.Kcap; }
-  __syncthreads();
-  // ---- cluster order: size descending, ties by smaller first cloud index; rank by counting
-  for (int c = threadIdx.x; c < nocc; c += CG_T) cidr[c] = -1;
-  __threadfence_block();
-  __syncthreads();
-  for (int k = threadIdx.x; k < K; k += CG_T) {
-    const int my_sz = d.ksize[ko + k], my_rt = d.kroot[ko + k]; int rank = 0;
-    for (int u = 0; u < K; ++u) { int sz = d.ksize[ko + u], rt = d.kroot[ko + u]; rank += (sz > my_sz) || (sz == my_sz && rt < my_rt); }
-    cidr[d.kcell[ko + k]] = rank;
-    d.csz[ko + rank] = my_sz;
-  }
-  __threadfence_block();
-  __syncthreads();
-  // ---- per-cell cluster id (a cell is a clique ⇒ one cluster) and root
-  for (int c = threadIdx.x; c < nocc; c += CG_T) { int r = cg_find<LDS>(par, c); d.croot[so + c] = r; d.ccid[so + c] = cidr[r]; reinterpret_cast<int *>(&d.cmeta[2 * (so + c)])[3] = cidr[r]; }
-  // ---- cluster offsets (exclusive scan of sizes in cluster order), C, clear detection_results (:250-254)
-  int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1);
-  int carry = 0;
-  for (int b = 0; b < K; b += CG_T) {
-    int k = b + threadIdx.x, v = k < K ? d.csz[ko + k] : 0;
-    int inc = wave_incl_scan(v);
-    if (lane == 63) l_misc[1 + wave_id()] = inc;
-    __syncthreads();
-    int basew = 0, tot = 0;
-    for (int w = 0; w < CG_T / 64; ++w) { int xw = l_misc[1 + w]; if (w < wave_id()) basew += xw; tot += xw; }
-    __syncthreads();
-    if (k < K) { off[k] = carry + basew + inc - v; d.det[ko + k] = 0; }
-    carry += tot;
-  }
-  if (threadIdx.x == 0) { off[K] = carry; d.info[s].C = carry; d.info[s].K = K; d.slot_kc[d.cur][s] = make_int2(K, carry); }
-  // ---- work items of the per-cluster reductions: cluster k owns ceil(size/MOR_CHUNK) chunks
-  int *coff = d.chunk_off[d.cur] + (size_t)s * (d.Kcap + 1);
-  carry = 0;
-  __syncthreads();
-  for (int b = 0; b < K; b += CG_T) {
-    int k = b + threadIdx.x, v = k < K ? (d.csz[ko + k] + MOR_CHUNK - 1) / MOR_CHUNK : 0;
-    int inc = wave_incl_scan(v);
-    if (lane == 63) l_misc[1 + wave_id()] = inc;
-    __syncthreads();
-    int basew = 0, tot = 0;
-    for (int w = 0; w < CG_T / 64; ++w) { int xw = l_misc[1 + w]; if (w < wave_id()) basew += xw; tot += xw; }
-    __syncthreads();
-    if (k < K) coff[k] = carry + basew + inc - v;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) coff[K] = carry;
-  CG_STAMP(6);
-}
-
-// Helper workgroup of a heavy stream: candidate pairs of the SHELL pass — every forward pair at ring distance 2, no
-// forest filter — written to the stream's external list as (a << 14 | b) while the main workgroup runs the 3×3×3 pass.
-// It is the list's only writer: positions come from an LDS counter and the stores are fire-and-forget; count and flag
-// are published at the end (release at agent scope).
-__device__ __forceinline__ void cg_helper(const MorDev &d, int s, int nocc, int *l_key, int *l_rows, int *l_cnt) {
-  int *hf = d.cg_help + (size_t)s * 4;
-  if (nocc < d.cg_help_min) return;                                   // light stream: its main workgroup does not wait
-  if (nocc > CG_CAP || d.g.nrows > CG_ROWCAP) { if (threadIdx.x == 0) { atomicExch(hf + 1, -1); __threadfence(); atomicExch(hf, 1); } return; }
-  const size_t so = (size_t)s * d.Nmax;
-  const int *gk = d.ckey + so, *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1);
-  for (int i = threadIdx.x; i < nocc; i += CG_T) l_key[i] = gk[i];
-  for (int i = threadIdx.x; i <= d.g.nrows; i += CG_T) l_rows[i] = g_rows[i];
-  if (threadIdx.x == 0) *l_cnt = 0;
-  __syncthreads();
-  const int *key = l_key, *rows = l_rows;
-  int *ext = d.cg_ext + (size_t)s * MOR_CG_EXT;
-  constexpr int RING = 2;
-  for (int a = threadIdx.x; a < nocc; a += CG_T) {
-    const int ka = key[a], rowa = ka / d.g.nx, x = ka - rowa * d.g.nx, z = rowa % d.g.nz, y = rowa / d.g.nz;
-    for (int dz = 0; dz <= RING; ++dz) {
-      if (z + dz >= d.g.nz) break;
-      for (int dy = (dz == 0 ? 0 : -RING); dy <= RING; ++dy) {
-        if ((unsigned)(y + dy) >= (unsigned)d.g.ny) continue;
-        const bool edge_row = dz == RING || abs(dy) == RING;
-        const int rr = grid_row(d.g, y + dy, z + dz), rlo = rows[rr], rn = rows[rr + 1] - rlo;
-        if (rn == 0) continue;
-        const int rowbase = rr * d.g.nx + x;
-        int lo = rlo; const int hi = rlo + rn;
-        if (rn > 8) lo = cg_lower_bound8(key, rlo, rn, rowbase - RING);
-        for (int b = lo; b < hi; ++b) {
-          const int dx = key[b] - rowbase;
-          if (dx > RING) break;
-          const bool want = dx >= -RING && !(dz == 0 && dy == 0 && dx <= 0) && (edge_row || abs(dx) == RING);
-          const unsigned long long m = __ballot(want);
-          if (m) {
-            const int leader = __ffsll((long long)m) - 1; int base = 0;
-            if (lane_id() == leader) base = atomicAdd(l_cnt, __popcll(m));
-            base = __shfl(base, leader, 64);
-            if (want) { const int slot = base + __popcll(m & lanemask_lt()); if (slot < MOR_CG_EXT) ext[slot] = (a << 14) | b; }
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) { const int n = *l_cnt; atomicExch(hf + 1, n <= MOR_CG_EXT ? n : -1); }
-  __threadfence();      // every thread's list stores are performed at agent scope before …
-  __syncthreads();
-  if (threadIdx.x == 0) atomicExch(hf, 1);   // … the flag goes up
-}
-__global__ __launch_bounds__(CG_T) void k_cellgraph(MorDev d) {
-  // blocks [0, B): helper workgroups (when enabled; they return at once for light streams), the next B: main workgroups
-  // (on the XCD of their helper when B is a multiple of 8)
-  const int s = blockIdx.x % d.B + d.s0, nocc = d.info[s].n_occ;
-#ifdef MOR_EXP_STAMPS
-  if (threadIdx.x == 0) d.dbg[(size_t)s * 16 + 0] = wall_clock64();
-#endif
-  __shared__ int l_key[CG_CAP], l_par[CG_CAP], l_rows[CG_ROWCAP + 1], l_list[2 * CG_LIST], l_nlist, l_misc[1 + CG_T / 64];
-  if (d.cg_help_min > 0 && (int)blockIdx.x < d.B) { cg_helper(d, s, nocc, l_key, l_rows, &l_nlist); return; }
-  const size_t so = (size_t)s * d.Nmax;
-  const int *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1);
-  const int *rows = g_rows;
-  if (threadIdx.x == 0) { l_nlist = 0; l_misc[0] = 0; }
-  if (d.g.nrows + 1 <= CG_ROWCAP + 1) { for (int i = threadIdx.x; i <= d.g.nrows; i += CG_T) l_rows[i] = g_rows[i]; rows = l_rows; }
-  if (nocc <= CG_CAP) {
-    const int *gk = d.ckey + so;
-    for (int i = threadIdx.x; i < nocc; i += CG_T) { l_key[i] = gk[i]; l_par[i] = i; }
-    __syncthreads();
-    cg_body<true>(d, s, nocc, l_key, d.cstart + (size_t)s * (d.Nmax + 1), rows, l_par, d.csize + so, l_key, l_key, l_list, &l_nlist, l_misc);
-  } else {
-    __syncthreads();
-    cg_body<false>(d, s, nocc, d.ckey + so, d.cstart + (size_t)s * (d.Nmax + 1), rows, d.parent + so, d.csize + so, d.compmin + so, d.cid_of_root + so, l_list, &l_nlist, l_misc);
-  }
-}
-
-// ------------------------------------------------------------------------------------ C1, spread over the GPU: the cell graph over y-SLABS
-// One 1024-thread workgroup per stream (k_cellgraph above) keeps 64 of the 256 CUs busy and ends with its slowest stream.
+// ------------------------------------------------------------------------------------ the cell graph over y-SLABS
+// (One 1024-thread workgroup per stream — round 1 — kept 64 of the 256 CUs busy for 250–330 µs and ended with its slowest stream.)
 // Cell keys are y-major, so a contiguous range of compact ids is the slab of space between two y planes: every stream's
 // cells are cut into P slabs of about equal cell count (k_gridhash / k_cellboxes: slab_bounds), and one small workgroup
 // per (stream, slab) runs both hook passes for the cells it OWNS over the forward half of the neighbourhood
@@ -2105,39 +1756,37 @@ __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
       const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
       const int sx = near_side(q.x, d.g.ox, d.g.inv_cs, d.g.cs, cx, slb), sy = near_side(q.y, d.g.oy, d.g.inv_cs, d.g.cs, cy, slb), sz = near_side(q.z, d.zorg[s], d.g.inv_cs, d.g.cs, cz, slb);
       int budget = d.t1_budget; float best = INFINITY;
-      // matched cells of the 3×3×3 block, at most eight kept: first those that can hold a point within √lb (the ≤ 7 cells across
-      // the walls q is close to), then the others in index order; ncand counts all of them.  One z-layer (nine probes, then
-      // nine cluster ids: two levels of independent loads) at a time keeps the live registers low — this kernel used to need
-      // 131 VGPRs and, with three waves per SIMD, fell apart whenever it shared the GPU with the other stages
+      int id[27];
+      {
+        int key[27]; unsigned long long ent[27];
+#pragma unroll
+        for (int i = 0; i < 27; ++i) {
+          key[i] = i == 13 ? -1 : cell_key(d.g, cx + i % 3 - 1, cy + (i / 3) % 3 - 1, cz + i / 9 - 1);
+          ent[i] = tab[hash_slot(max(key[i], 0), hshift)];
+        }
+#pragma unroll
+        for (int i = 0; i < 27; ++i) id[i] = key[i] >= 0 ? hash_resolve(tab, hshift, key[i], hash_slot(key[i], hshift), ent[i]) : -1;
+      }
       int mc[8]; int ncand = 0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) mc[i] = -1;
+      {
+        int cidv[27];
 #pragma unroll
-      for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < 27; ++i) cidv[i] = cid_c[max(id[i], 0)];
 #pragma unroll
-        for (int lz = 0; lz < 3; ++lz) {
-          const int dz = lz - 1;
-          if (pass == 0 && !(dz == 0 || dz == sz)) continue;   // no near cell in this layer
-          int key[9], id9[9], cid9[9]; unsigned long long ent[9];
+        for (int pass = 0; pass < 2; ++pass)   // pass 0: cells that can hold a point within √lb (≤ 7), pass 1: the others
 #pragma unroll
-          for (int i = 0; i < 9; ++i) {
-            const int dx = i % 3 - 1, dy = i / 3 - 1;
+          for (int i = 0; i < 27; ++i) {
+            const int dx = i % 3 - 1, dy = (i / 3) % 3 - 1, dz = i / 9 - 1;
             const bool nearc = (dx == 0 || dx == sx) && (dy == 0 || dy == sy) && (dz == 0 || dz == sz);
-            key[i] = ((dx == 0 && dy == 0 && dz == 0) || nearc != (pass == 0)) ? -1 : cell_key(d.g, cx + dx, cy + dy, cz + dz);
-            ent[i] = key[i] >= 0 ? tab[hash_slot(key[i], hshift)] : 0ull;
-          }
+            if (id[i] >= 0 && cidv[i] == target && nearc == (pass == 0)) {
 #pragma unroll
-          for (int i = 0; i < 9; ++i) id9[i] = key[i] >= 0 ? hash_resolve(tab, hshift, key[i], hash_slot(key[i], hshift), ent[i]) : -1;
-#pragma unroll
-          for (int i = 0; i < 9; ++i) cid9[i] = id9[i] >= 0 ? cid_c[id9[i]] : -1;
-#pragma unroll
-          for (int i = 0; i < 9; ++i)
-            if (id9[i] >= 0 && cid9[i] == target) {
-#pragma unroll
-              for (int k = 0; k < 8; ++k) if (ncand == k) mc[k] = id9[i];
+              for (int k = 0; k < 8; ++k) if (ncand == k) mc[k] = id[i];
               ++ncand;
             }
-        }
+          }
+      }
       if (ncand > 0) {
         const int ca[4] = {mc[0], mc[1], mc[2], mc[3]}, cb2[4] = {mc[4], mc[5], mc[6], mc[7]};
         scan_batch4(d, so, st, sp, ca, target, false, q, lbn, best, budget);
@@ -2883,20 +2532,12 @@ static void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm)
 }
 
 static void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  if (d.cg_mode == 1) {
-    mor_timer_begin(tm, MK_CG_SLAB, st);
-    hipLaunchKernelGGL(k_cg_slab, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
-    mor_timer_end(tm, MK_CG_SLAB, st);
-    mor_timer_begin(tm, MK_CG_FINAL, st);
-    hipLaunchKernelGGL(k_cg_final, dim3(d.B), dim3(CGF_T), 0, st, d);
-    mor_timer_end(tm, MK_CG_FINAL, st);
-    return;
-  }
-  const dim3 gB(d.cg_help_min > 0 ? 2 * d.B : d.B);
-  if (d.cg_help_min > 0) (void)hipMemsetAsync(d.cg_help + (size_t)d.s0 * 4, 0, (size_t)d.B * 4 * sizeof(int), st);
-  mor_timer_begin(tm, MK_CELLGRAPH, st);
-  hipLaunchKernelGGL(k_cellgraph, gB, dim3(CG_T), 0, st, d);
-  mor_timer_end(tm, MK_CELLGRAPH, st);
+  mor_timer_begin(tm, MK_CG_SLAB, st);
+  hipLaunchKernelGGL(k_cg_slab, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
+  mor_timer_end(tm, MK_CG_SLAB, st);
+  mor_timer_begin(tm, MK_CG_FINAL, st);
+  hipLaunchKernelGGL(k_cg_final, dim3(d.B), dim3(CGF_T), 0, st, d);
+  mor_timer_end(tm, MK_CG_FINAL, st);
 }
 
 static void mor_launch_clusters(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // labels, cluster_indices, cluster points, centroids

@@ -53,3 +53,15 @@ def sum_over_ranks(dist, value):
 def whole_job_rate(dist, units_this_rank, elapsed_this_rank):
     """units of ALL ranks ÷ the slowest rank's time."""
     return sum_over_ranks(dist, units_this_rank) / max_over_ranks(dist, elapsed_this_rank)
+
+
+def gather_floats(dist, value):
+    """One float per rank, on every rank (the per-rank rates of a multi-GPU run show imbalance between the GPUs)."""
+    if dist is None:
+        return [float(value)]
+    import torch
+    world = dist.get_world_size()
+    t = torch.zeros(world, dtype=torch.float64)
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t]

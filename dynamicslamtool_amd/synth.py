@@ -5,7 +5,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-SENSORS = {"hdl64": 0, "os128": 1, "agg10": 2}
+SENSORS = {"hdl64": 0, "os128": 1, "agg10": 2, "hdl64_urban": 3}
 
 
 def lib():

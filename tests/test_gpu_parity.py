@@ -226,12 +226,13 @@ def test_os128_dense_cloud_matches_oracle():
     assert st["clusters"] > 20 and st["corr"] > 10
 
 
-def test_agg10_million_point_cloud_matches_oracle():
-    """BASELINE configs[4] shape: 10 aggregated sweeps, 1 000 000 points; exercises the cell-graph path that
-    keeps its arrays in global memory (more occupied cells than fit in LDS) and 3-pass cluster partitions."""
+@pytest.mark.parametrize("method", [1, 2])
+def test_agg10_million_point_cloud_matches_oracle(method):
+    """BASELINE configs[4] shape: 10 aggregated sweeps, 1 000 000 points (hundreds of thousands of non-ground points,
+    cells of thousands of points), both scoring methods."""
     from dynamicslamtool_amd.engine import MorBatch
     from oracle.oracle import Oracle
-    p = kitti_params(2)
+    p = kitti_params(method)
     frames = [synth.frame(5000, "agg10", f) for f in range(2)]
     b, o = MorBatch(p, 1, 1000000), Oracle(p)
     for f, (x, pose) in enumerate(frames):
@@ -243,8 +244,8 @@ def test_agg10_million_point_cloud_matches_oracle():
 
 
 def test_fine_grid_takes_the_global_memory_cell_graph():
-    """A small cluster tolerance (r = 0.12 m → 6.8 cm cells) gives more occupied cells than the per-stream
-    workgroup can hold in LDS: the cell graph then runs on its global-memory arrays (same code)."""
+    """A small cluster tolerance (r = 0.12 m → 6.8 cm cells) gives more occupied cells than the per-stream workgroups can
+    hold in LDS: k_gridhash moves to its global-memory table and k_cg_final merges the slab forests in global memory (same code)."""
     from dynamicslamtool_amd.engine import MorBatch
     from oracle.oracle import Oracle
     p = kitti_params(1)
@@ -257,7 +258,7 @@ def test_fine_grid_takes_the_global_memory_cell_graph():
         o.push(x, pose)
         compare_frame(o, b, 0, "fine grid frame %d" % f)
         compare_output(o.filter(), b.filter()[0], "fine grid frame %d" % f)
-    assert b.stage_counts(0)["n_occ"] > 12288   # CG_CAP of k_cellgraph
+    assert b.stage_counts(0)["n_occ"] > 12288   # more than k_gridhash's LDS tables and k_cg_final's LDS forest hold
     b.close()
 
 
@@ -312,23 +313,67 @@ def test_cluster_boxes_are_the_min_max_of_their_points():
     b.close()
 
 
-def test_cell_graph_helper_workgroups(monkeypatch):
-    """k_cellgraph gives the streams with the most cells a second, helper workgroup that lists the shell pass's candidate
-    pairs while the main one runs the 3×3×3 pass (by default the top 15 % of a batch of ≥ 8 streams).  Here every stream
-    of a batch of 8 gets one; results must not change."""
-    monkeypatch.setenv("MOR_CG_HELP_PCT", "100")
+@pytest.mark.parametrize("P", [1, 3, 32])
+def test_cell_graph_slab_counts(monkeypatch, P):
+    """k_cg_slab cuts every stream's cells into P slabs of y-slices (by default enough to fill the GPU and to fit a slab's
+    LDS); the merged forests must give the same clusters for any P.  P = 1 puts all cells of a stream into one slab, far
+    more than its LDS holds: the slab then runs on global-memory arrays.  P = 32 makes slabs two or three slices thin."""
+    monkeypatch.setenv("MOR_CG_P", str(P))
     p = kitti_params(1)
     seeds = [2000, 2001, 2005, 2017, 2033, 2040, 2041, 2042]
     b, os_ = MorBatch(p, 8, 120000), [Oracle(p) for _ in seeds]
+    assert b.debug_config()["P"] == 1   # before the first push
     for f in range(3):
         xs, ps = synth.batch(seeds, [f] * 8)
         b.push(list(xs), ps)
+        assert b.debug_config()["P"] == P
         outs = b.filter()
-        for s in (0, 2, 5, 7):   # the oracle is the slow side: four of the eight streams
+        for s in (0, 1, 5):   # the oracle is the slow side: three of the eight streams
             os_[s].push(xs[s], ps[s])
-            compare_frame(os_[s], b, s, "helper stream %d frame %d" % (s, f))
-            compare_output(os_[s].filter(), outs[s], "helper stream %d frame %d" % (s, f))
+            compare_frame(os_[s], b, s, "P=%d stream %d frame %d" % (P, s, f))
+            compare_output(os_[s].filter(), outs[s], "P=%d stream %d frame %d" % (P, s, f))
     b.close()
+
+
+_VARIANT_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from dynamicslamtool_amd import kitti_params, synth
+from dynamicslamtool_amd.engine import MorBatch
+from oracle.oracle import Oracle
+from parity import compare_frame, compare_output
+from scenes import scene_params, small_stream
+p = kitti_params(1)
+b, o = MorBatch(p, 1, 120000), Oracle(p)
+for f in range(3):
+    x, pose = synth.frame(2005, "hdl64", f)
+    b.push([x], pose[None, :]); o.push(x, pose)
+    compare_frame(o, b, 0, "variant hdl64 frame %%d" %% f)
+    compare_output(o.filter(), b.filter()[0], "variant hdl64 frame %%d" %% f)
+b.close(); o.close()
+for method in (1, 2):
+    p = scene_params(method_choice=method)
+    frames = small_stream(3, n_frames=6)
+    b, o = MorBatch(p, 1, max(len(fr[0]) for fr in frames)), Oracle(p)
+    for f, (x, pose) in enumerate(frames):
+        b.push([x], pose[None, :]); o.push(x, pose)
+        compare_frame(o, b, 0, "variant small m%%d frame %%d" %% (method, f))
+        compare_output(o.filter(), b.filter()[0], "variant small m%%d frame %%d" %% (method, f))
+    b.close(); o.close()
+print("OK")
+"""
+
+
+@pytest.mark.parametrize("env", [{"MOR_GH_TIER": "1"}, {"MOR_GH_TIER": "2", "MOR_CG_GLOBAL": "1"}, {"MOR_GRID": "radix"}, {"MOR_SINGLE_PASS_SPLIT": "1"},
+                                 {"MOR_STAGES": "0123333", "MOR_PIPE_DEPTH": "2"}, {"MOR_STAGES": "0001123", "MOR_PIPE_DEPTH": "6"}])
+def test_kernel_variants(env):
+    """The slower variants behind the fast paths must give the same results: k_gridhash with its big LDS table / its
+    global-memory table, slab and merge forests in global memory, the radix-sort grid build, the single-pass ground split, and
+    other stage assignments / pipeline depths.  The variant is chosen when the batch is created, from the environment: child process."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT % (root, os.path.join(root, "tests"))], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_async_pipeline_equals_synchronous_use_at_full_batch_size():
@@ -381,8 +426,8 @@ print("OK")
 
 @pytest.mark.gpu
 def test_deferred_pair_overflow_list():
-    """k_cellgraph keeps undecided big cell pairs in an LDS list and spills into a global list beyond it.  A library
-    variant built with an 8-entry LDS list (dynamicslamtool_amd/build.py) makes ordinary hdl64 frames spill; results
+    """k_cg_slab keeps each wave's candidate pairs in an LDS list and spills into a global list beyond it.  A library
+    variant built with two-entry LDS lists (dynamicslamtool_amd/build.py) makes ordinary hdl64 frames spill; results
     must not change.  Runs in a child process because the library is chosen at import time."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -423,6 +468,75 @@ def test_full_size_batch_properties():
             assert np.isin(a, t).all()
     assert np.array_equal(outs[5].view(np.uint32), outs[37].view(np.uint32))
     b.close()
+
+
+def _full_batch_properties(sensor, B, seed0, n_frames=3):
+    """Size-independent properties at a BASELINE configuration's full batch size: the filtered cloud is a sub-multiset of the
+    trimmed input, labels partition the cloud, cluster lists are disjoint and size-descending, a stream repeated in another
+    batch slot gives identical bytes, and the asynchronous pipeline leaves the same per-frame summaries as synchronous use."""
+    p = kitti_params(1)
+    npts = synth.n_points(sensor)
+    seeds = [seed0 + s for s in range(B)]
+    seeds[B // 2 + 3] = seeds[1]   # duplicate stream in a different slot / XCD group
+    b = MorBatch(p, B, npts)
+    buf = DeviceBuffer(n_frames * B * npts * 16)
+    poses, outs, xs_last = [], None, None
+    for f in range(n_frames):
+        xs, ps = synth.batch(seeds, [f] * B, sensor)
+        buf.upload(xs, f * B * npts * 16)
+        poses.append(ps)
+        b.push(list(xs), ps)
+        outs = b.filter()
+        xs_last = xs
+        for s in (0, 1, B // 2 + 3, B - 1):
+            c = b.counts(s)
+            lab = b.labels(s)
+            assert len(lab) == c.n_trim and (lab == -2).sum() == c.n_ground and (lab >= 0).sum() == c.n_clustered
+            off, idx = b.clusters(s)
+            assert off[-1] == c.n_clustered and len(np.unique(idx)) == len(idx)
+            assert np.all(np.diff(np.diff(off)) <= 0)   # sizes descending
+            x = xs[s]
+            keep = np.isfinite(x[:, :3]).all(1) & (np.abs(x[:, 0]) <= p.trim_x) & (np.abs(x[:, 1]) <= p.trim_y)
+            assert c.n_trim == keep.sum() and len(outs[s]) <= c.n_trim
+            a = np.sort(outs[s].view([("", np.float32)] * 4).ravel())
+            t = np.sort(x[keep].view([("", np.float32)] * 4).ravel())
+            assert np.isin(a, t).all()
+    assert np.array_equal(outs[1].view(np.uint32), outs[B // 2 + 3].view(np.uint32))
+    assert sum(b.counts(s).n_clusters for s in range(B)) > B and sum(b.counts(s).n_corr for s in range(B)) > 0
+    sync_logs = [[b.frame_log(f, s) for s in range(B)] for f in range(n_frames)]
+    b.close()
+    del xs_last
+    a = MorBatch(p, B, npts)   # the same frames, device-resident, enqueued without a wait in between
+    a.set_async(True)
+    for f in range(n_frames):
+        a.push_views(a.make_views([(buf.ptr + (f * B + s) * npts * 16, npts) for s in range(B)]), poses[f])
+        a.filter_async()
+    a.wait()
+    for f in range(n_frames):
+        for s in range(B):
+            assert a.frame_log(f, s) == sync_logs[f][s], (sensor, f, s)
+    a.close()
+    buf.free()
+
+
+def test_full_size_batch_properties_os128_b64():
+    """BASELINE configs[2]: B = 64 Ouster-128-style streams of 262 144 points."""
+    _full_batch_properties("os128", 64, 3000)
+
+
+def test_full_size_batch_properties_agg10_b32():
+    """BASELINE configs[4]: B = 32 aggregated 10-sweep clouds of 1 000 000 points."""
+    _full_batch_properties("agg10", 32, 5000)
+
+
+def test_hdl64_urban_matches_oracle():
+    """Street scene of realistic density (façades, vegetation, kerbs, parked cars: about half of the sweep is non-ground),
+    both scoring methods, lock-step against the oracle."""
+    for method in (1, 2):
+        p = kitti_params(method)
+        streams = [[synth.frame(6000 + s, "hdl64_urban", f) for f in range(4)] for s in range(2)]
+        st = _run_lockstep(p, streams)
+        assert st["clusters"] > 40 and st["corr"] > 20
 
 
 @pytest.mark.parametrize("seed", [1, 4])

@@ -27,6 +27,8 @@ def test_two_rank_dry_run():
     # 2 ranks x 8 streams x 4 steps over the slowest rank's 1.5 s
     assert d["n_gpus"] == 2 and abs(d["value"] - (2 * 8 * 4) / 1.5) < 1e-9
     assert d["first_seed"] == 2000 and d["last_seed_rank0"] == 2007
+    # per-rank rates (rank 0: 32 / 1.0 s, rank 1: 32 / 1.5 s) are gathered so a scaling run shows imbalance
+    assert abs(d["per_rank_min_max"][0] - 32 / 1.5) < 1e-9 and abs(d["per_rank_min_max"][1] - 32.0) < 1e-9
 
 
 def test_stream_seeds_are_disjoint_across_ranks():
