@@ -73,6 +73,7 @@ void MovingObjectRemoval::setVariables(const std::string &path) {
     else if (key == "method_choice") { params_.method_choice = std::stoi(val); std::cout << params_.method_choice; known = true; }
     else if (key == "opc_normalization_factor") { params_.opc_normalization_factor = (int)std::stof(val); std::cout << params_.opc_normalization_factor; known = true; }   // stof into an int (.cpp:843)
     else if (key == "ground_method") { params_.ground_method = std::stoi(val); std::cout << params_.ground_method; known = true; }   // extension key: 0 crop box, 1 voxel covariance
+    else if (key == "volume_abs_int") { params_.volume_abs_int = std::stoi(val); std::cout << params_.volume_abs_int; known = true; }   // extension key: 1 = the abs() of .cpp:277 truncates to int first (old libstdc++)
     if (!known) { std::cout << "Invalid parameter found in config file\n"; std::exit(0); }
     std::cout << std::endl;
   }
@@ -126,18 +127,14 @@ std::vector<MovingObjectRemoval::BoxMarker> MovingObjectRemoval::clusterMarkers(
   std::vector<BoxMarker> out;
   mor_counts c;
   if (!ctx_ || mor_get_counts(ctx_, 0, &c) != MOR_OK || c.n_clusters == 0) return out;
-  std::vector<float> cen(3 * (size_t)c.n_clusters), lo(3 * (size_t)c.n_clusters), hi(3 * (size_t)c.n_clusters);
+  std::vector<float> pos(3 * (size_t)c.n_clusters), scale(3 * (size_t)c.n_clusters);
   std::vector<uint8_t> det(c.n_clusters);
-  if (mor_get_centroids(ctx_, 0, cen.data()) != MOR_OK || mor_get_boxes(ctx_, 0, lo.data(), hi.data()) != MOR_OK || mor_get_detection(ctx_, 0, det.data()) != MOR_OK) return out;
+  if (mor_get_markers(ctx_, 0, pos.data(), scale.data()) != MOR_OK || mor_get_detection(ctx_, 0, det.data()) != MOR_OK) return out;
   out.resize(c.n_clusters);
   for (uint32_t k = 0; k < c.n_clusters; ++k) {
     BoxMarker &m = out[k];
     m.id = (int)k; m.moving = det[k] != 0;
-    for (int a = 0; a < 3; ++a) {
-      m.position[a] = cen[3 * k + a];
-      m.scale[a] = hi[3 * k + a] - lo[3 * k + a];
-      if (m.scale[a] == 0) m.scale[a] = 0.1f;   // .cpp:40-47
-    }
+    for (int a = 0; a < 3; ++a) { m.position[a] = pos[3 * k + a]; m.scale[a] = scale[3 * k + a]; }   // float-accumulated centroid (.cpp:15), extent with 0 → 0.1 (.cpp:36-47)
   }
   return out;
 }

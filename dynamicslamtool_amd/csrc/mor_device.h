@@ -78,7 +78,7 @@ struct MorDev {
   long long min_cs, max_cs;
   float pde_lb, pde_ub;
   double pde_thr, vol_thr, opc_res;
-  int method, opc_norm, score_R, n_rows, t1_budget;
+  int method, opc_norm, score_R, n_rows, t1_budget, vol_abs_int;
   const signed char *row_order; // [n_rows][2] (dy,dz) of the method-1 search stencil, nearest rows first
   MorGrid g;                 // clustering grid (cell edge 0.57·r)
   MorGrid gv;                // VoxelGrid lattice of the voxel-covariance ground removal (cell edge gp_leaf)

@@ -131,7 +131,7 @@ static int configure(mor_batch *b) {
   double tol = (double)p.ec_distance_threshold; d.r2 = (float)(tol * tol);   // KdTreeFLANN::radiusSearch: (float)(radius·radius)
   d.min_cs = p.min_cluster_size; d.max_cs = p.max_cluster_size;
   d.pde_lb = p.pde_lb; d.pde_ub = p.pde_ub; d.pde_thr = (double)p.pde_distance_threshold; d.vol_thr = (double)p.volume_constraint;
-  d.opc_res = (double)p.opc_resolution; d.method = p.method_choice; d.opc_norm = p.opc_normalization_factor;
+  d.opc_res = (double)p.opc_resolution; d.method = p.method_choice; d.opc_norm = p.opc_normalization_factor; d.vol_abs_int = p.volume_abs_int ? 1 : 0;
   // grid: cell edge 0.57·r (cell diagonal 0.987·r < r ⇒ a cell is a clique; the 1.3 % margin dwarfs the
   // fp32 rounding of the cell map, ≤ 1e-3 cell at ≤ 2048 cells per axis)
   float cs = p.ec_distance_threshold * 0.57f;
@@ -439,7 +439,8 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
   HIP_TRY(hipSetDevice(b->device));
   MorDev d = b->d; const int B = d.B;
   const uint64_t k = b->frame - 1;
-  d.run_tracker = b->filtered ? 0 : 1;   // the tracking loop of filterCloud (:630-671) runs on the device, once per frame
+  d.run_tracker = 1;   // the tracking loop of filterCloud (:630-671) runs on the device — on EVERY call, as in the reference: a second
+                       // filterCloud on the same frame walks mo_vec again and moves the confidences again
   b->filtered = true;
   d.out_ptrs = nullptr;
   if (out && out_on_device) {
@@ -540,6 +541,32 @@ int mor_get_tracks(const mor_batch *b, int s, float *xyz, int32_t *conf, int32_t
 int mor_get_cluster_collection(const mor_batch *b, int s, float *out) {
   CHECK_STREAM();
   if (f.C) HIP_TRY(hipMemcpy(out, d.cl_pts[d.cur] + so, f.C * sizeof(float4), hipMemcpyDeviceToHost));
+  return MOR_OK;
+}
+
+// mark_cluster (:7-58) for every cluster of the latest frame: position = compute3DCentroid into an Eigen::Vector4f, i.e. a
+// sequential FLOAT sum over the cluster's points in order divided by n (:15) — not the fp64 centroid of :239-243 —,
+// scale = extent of getMinMax3D (:16, :36-38) with zero extents replaced by 0.1 (:40-47).  A debug read-back (the
+// reference builds markers only under VISUALIZE, for tracked clusters): the points come to the host and are summed there
+// in the reference's order.
+int mor_get_markers(const mor_batch *b, int s, float *pos_K3, float *scale_K3) {
+  CHECK_STREAM();
+  if (!f.K) return MOR_OK;
+  std::vector<float4> pts(f.C);
+  std::vector<int> off(f.K + 1);
+  memcpy(off.data(), d.h_cl_off + (size_t)s * (d.Kcap + 1), (f.K + 1) * sizeof(int));
+  if (f.C) HIP_TRY(hipMemcpy(pts.data(), d.cl_pts[d.cur] + so, f.C * sizeof(float4), hipMemcpyDeviceToHost));
+  for (uint32_t k = 0; k < f.K; ++k) {
+    float sx = 0.f, sy = 0.f, sz = 0.f, mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const int n = off[k + 1] - off[k];
+    for (int j = off[k]; j < off[k + 1]; ++j) {
+      const float q[3] = {pts[j].x, pts[j].y, pts[j].z};
+      sx += q[0]; sy += q[1]; sz += q[2];
+      for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], q[a]); mx[a] = std::max(mx[a], q[a]); }
+    }
+    pos_K3[3 * k] = sx / (float)n; pos_K3[3 * k + 1] = sy / (float)n; pos_K3[3 * k + 2] = sz / (float)n;
+    for (int a = 0; a < 3; ++a) { const float e = mx[a] - mn[a]; scale_K3[3 * k + a] = e == 0.f ? 0.1f : e; }
+  }
   return MOR_OK;
 }
 

@@ -1554,7 +1554,8 @@ __global__ __launch_bounds__(MOR_BT) void k_pairs(MorDev d) {
         float vp = (a1.x - a0.x) * (a1.y - a0.y); vp = vp * (a1.z - a0.z);
         float vc = (c1.x - c0.x) * (c1.y - c0.y); vc = vc * (c1.z - c0.z);
         double dp = (double)vp, dc = (double)vc;
-        ok = (fabs(dp - dc) / (dp + dc)) < d.vol_thr;   // NaN (0/0) compares false ⇒ rejected, as in the reference
+        const double diff = dp - dc, ad = d.vol_abs_int ? (double)abs((int)diff) : fabs(diff);   // :277 unqualified abs: fabs (libstdc++ ≥ 6, default) or int abs(int)
+        ok = (ad / (dp + dc)) < d.vol_thr;   // NaN (0/0) compares false ⇒ rejected, as in the reference
       }
     }
     int tot, e = block_excl_scan(ok, sh, &tot);

@@ -34,12 +34,20 @@ int main(int argc, char **argv) {
     const char *names[4] = {"x", "y", "z", "intensity"};
     for (int k = 0; k < 4; ++k) { pcl::PCLPointField f; f.name = names[k]; f.offset = 4 * k; f.datatype = pcl::PCLPointField::FLOAT32; f.count = 1; cloud.fields.push_back(f); }
     cloud.point_step = 16; cloud.width = (uint32_t)(cloud.data.size() / 16); cloud.height = 1; cloud.row_step = 16 * cloud.width; cloud.is_dense = 1;
+    cloud.header.seq = (uint32_t)(i - 4); cloud.header.stamp = 1000000ull * (uint64_t)(100 + i - 4); cloud.header.frame_id = "/velodyne";   // what toPCL copies from the sensor message
     geometry_msgs::Pose pose; std::string line;
     if (!std::getline(poses, line)) { std::fprintf(stderr, "poses file too short\n"); return 1; }
     std::istringstream ls(line);
     ls >> pose.position.x >> pose.position.y >> pose.position.z >> pose.orientation.x >> pose.orientation.y >> pose.orientation.z >> pose.orientation.w;
     auto t0 = std::chrono::steady_clock::now();
     mor.pushRawCloudAndPose(cloud, pose);
+#ifdef MOR_VISUALIZE
+    {  // under VISUALIZE the push overwrites the caller's cloud and `output` with the clustered points (.cpp:553-558): dump what the caller now holds
+      char pn[64]; std::snprintf(pn, sizeof pn, "/pushed_%04d.bin", i - 4);
+      std::ofstream po(out_dir + pn, std::ios::binary); po.write((const char *)cloud.data.data(), (std::streamsize)cloud.data.size());
+      std::cout << "pushed " << (i - 4) << ": caller cloud width " << cloud.width << " point_step " << cloud.point_step << " output.width " << mor.output.width << " output.frame_id " << mor.output.header.frame_id << std::endl;
+    }
+#endif
     bool ok = mor.filterCloud(cloud, "/filtered");
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (!ok) return 1;
@@ -51,7 +59,7 @@ int main(int argc, char **argv) {
     std::ofstream o(out_dir + name, std::ios::binary); o.write((const char *)packed.data(), packed.size() * sizeof(float));
     // the debug bounding boxes (what the reference publishes as markers under VISUALIZE): id px py pz sx sy sz moving
     std::snprintf(name, sizeof name, "/markers_%04d.txt", i - 4);
-    std::ofstream mk(out_dir + name);
+    std::ofstream mk(out_dir + name); mk.precision(9);
     const auto markers = mor.clusterMarkers();
     for (const auto &m : markers) mk << m.id << ' ' << m.position[0] << ' ' << m.position[1] << ' ' << m.position[2] << ' ' << m.scale[0] << ' ' << m.scale[1] << ' ' << m.scale[2] << ' ' << (m.moving ? 1 : 0) << '\n';
     std::cout << "frame " << (i - 4) << ": " << cloud.width << " pts in filtered cloud, " << markers.size() << " cluster boxes, frame_id " << mor.output.header.frame_id << ", " << ms << " ms" << std::endl;

@@ -19,7 +19,7 @@ EXPORTS = [
     "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_get_stage_counts", "mor_device_alloc", "mor_device_free", "mor_host_alloc", "mor_host_free",
     "mor_device_upload", "mor_device_download", "mor_device_synchronize", "mor_device_count", "mor_get_last_timing",
     "mor_kernel_timing_enable", "mor_kernel_timing_read", "mor_tracker_create", "mor_tracker_destroy", "mor_tracker_push",
-    "mor_tracker_filter", "mor_tracker_get", "mor_get_frame_log", "mor_debug_read", "mor_debug_config",
+    "mor_tracker_filter", "mor_tracker_get", "mor_get_frame_log", "mor_debug_read", "mor_debug_config", "mor_get_markers",
 ]
 
 
@@ -67,6 +67,7 @@ def lib():
         L.mor_get_tracks.argtypes = [vp, i32, vp, vp, vp]
         L.mor_get_stage_counts.argtypes = [vp, i32, vp, i32]
         L.mor_get_boxes.argtypes = [vp, i32, vp, vp]
+        L.mor_get_markers.argtypes = [vp, i32, vp, vp]
         L.mor_device_alloc.restype = vp
         L.mor_device_alloc.argtypes = [i32, C.c_size_t]
         L.mor_device_free.argtypes = [i32, vp]
@@ -287,11 +288,12 @@ class MorBatch:
         return lo[:K], hi[:K]
 
     def markers(self, s=0):
-        """Data of the reference's debug markers (mark_cluster, :7-58): per cluster (position xyz, scale xyz); zero extents become 0.1."""
-        lo, hi = self.boxes(s)
-        scale = hi - lo
-        scale[scale == 0] = 0.1
-        return self.centroids(s), scale
+        """Data of the reference's debug markers (mark_cluster, :7-58) per cluster: (position xyz = float-accumulated
+        centroid, scale xyz = box extent, zero extents 0.1)."""
+        K = self.counts(s).n_clusters
+        pos, scale = np.empty((max(K, 1), 3), np.float32), np.empty((max(K, 1), 3), np.float32)
+        _check(lib().mor_get_markers(self._h, s, pos.ctypes.data, scale.ctypes.data))
+        return pos[:K], scale[:K]
 
     def detection(self, s=0):
         return self._get(lib().mor_get_detection, s, self.counts(s).n_clusters, np.uint8)

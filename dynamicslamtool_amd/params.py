@@ -18,7 +18,7 @@ class MorParams(C.Structure):
         ("trim_x", C.c_float), ("trim_y", C.c_float), ("trim_z", C.c_float),
         ("ec_distance_threshold", C.c_float), ("pde_distance_threshold", C.c_float),
         ("method_choice", C.c_int32), ("opc_normalization_factor", C.c_int32),
-        ("ground_method", C.c_int32), ("opc_resolution", C.c_float),
+        ("ground_method", C.c_int32), ("opc_resolution", C.c_float), ("volume_abs_int", C.c_int32),
     ]
 
     def as_dict(self):
@@ -61,6 +61,8 @@ def parse_config_text(text):
             p.opc_normalization_factor = int(float(val))  # stof into an int, :843
         elif key == "ground_method":  # extension key: 0 crop, 1 voxel covariance
             p.ground_method = int(val)
+        elif key == "volume_abs_int":  # extension key: 1 = the unqualified abs() of :277 truncates to int first (old libstdc++)
+            p.volume_abs_int = int(val)
         elif key in _STRING_KEYS:
             strings[key] = val
         else:

@@ -45,6 +45,8 @@ typedef struct mor_params {
   int32_t opc_normalization_factor; /* :843 */
   int32_t ground_method;            /* 0 = crop box (:526, the active call), 1 = voxel covariance (:527, intended semantics) */
   float opc_resolution;             /* 0.1f — literal at the call site :575 */
+  int32_t volume_abs_int;           /* 0 (default): the unqualified abs(volp-volc) of :277 is fabs, as with libstdc++ >= 6; 1: it is C's int abs(int) — the
+                                       difference is truncated towards zero first (what an older libstdc++ can pick); DESIGN.md §2 */
 } mor_params;
 
 /* One incoming cloud: a pcl::PCLPointCloud2-style blob (what fromPCLPointCloud2 consumes at :523).
@@ -125,6 +127,9 @@ int mor_get_detection(const mor_batch *b, int stream, uint8_t *det_K); /* detect
 /* axis-aligned boxes of the clusters (getMinMax3D, :16 / :272-274): with the centroids they are the data of the
  * reference's debug markers (mark_cluster, :7-58: CUBE at the centroid, scale = max − min, zero extent → 0.1) */
 int mor_get_boxes(const mor_batch *b, int stream, float *min_K3, float *max_K3);
+/* the marker data itself, as mark_cluster computes it: position = FLOAT-accumulated centroid of the cluster's points (:15 — not
+ * the fp64 centroid of :239-243), scale = box extent with zero extents replaced by 0.1 */
+int mor_get_markers(const mor_batch *b, int stream, float *pos_K3, float *scale_K3);
 /* correspondence map mp (:564) + movement scores param_vec (:571/:575) of the last push */
 int mor_get_correspondences(const mor_batch *b, int stream, int32_t *query, int32_t *match, float *dist, double *score);
 /* mo_vec (header :109): centroid xyz, confidence, max_confidence */

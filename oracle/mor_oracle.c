@@ -394,17 +394,23 @@ static inline void xform3(const float m[12], float *x, float *y, float *z) {
 /* ------------------------------------------------------------------ P2
  * MovingObjectDetectionMethods::volumeConstraint — :264-283 (getMinMax3D fp32, product in
  * fp32, ratio in fp64; NaN when both volumes are 0 ⇒ rejected) */
-static int volume_constraint(const opoint *fp, int np, const opoint *fc, int nc, double threshold) {
+static int volume_constraint(const opoint *fp, int np, const opoint *fc, int nc, double threshold, int abs_int) {
   float mn[3], mx[3]; double vol[2];
   for (int w = 0; w < 2; ++w) { const opoint *c = w ? fc : fp; int n = w ? nc : np;
     for (int d = 0; d < 3; ++d) { mn[d] = FLT_MAX; mx[d] = -FLT_MAX; }
     for (int i = 0; i < n; ++i) { const float *q = &c[i].x; for (int d = 0; d < 3; ++d) { if (q[d] < mn[d]) mn[d] = q[d]; if (q[d] > mx[d]) mx[d] = q[d]; } }
     float v = (mx[0] - mn[0]) * (mx[1] - mn[1]); v = v * (mx[2] - mn[2]); vol[w] = (double)v; }
-  return (fabs(vol[0] - vol[1]) / (vol[0] + vol[1])) < threshold; /* :277 (abs → fabs) */
+  /* :277 is an UNQUALIFIED abs(volp-volc) on doubles.  With libstdc++ >= 6 (<cstdlib>/<stdlib.h> export the floating overloads
+   * into the global namespace; Ubuntu 18.04 / GCC 7, the toolchain of PCL 1.8) it is fabs — the default here.  An older
+   * libstdc++ can resolve it to C's int abs(int): the difference is truncated towards zero first, so volumes less than 1 m3
+   * apart always pass the gate.  volume_abs_int = 1 restates that reading (tested both ways). */
+  double diff = vol[0] - vol[1];
+  double ad = abs_int ? (double)abs((int)diff) : fabs(diff);
+  return (ad / (vol[0] + vol[1])) < threshold;
 }
 /* calculateCorrespondenceCentroid — :285-307.  determineReciprocalCorrespondences [PCL-1.8]:
  * per source index in order: 1-NN in target, 1-NN of that in source, keep iff same index. */
-static corr_list correspondence_centroid(const frame *ca, const frame *cb, double vc) {
+static corr_list correspondence_centroid(const frame *ca, const frame *cb, double vc, int abs_int) {
   corr_list out = { NULL, 0 };
   if (ca->K == 0 || cb->K == 0) return out; /* empty kd-tree: defined as no correspondences */
   kdtree tp, tc; kd_build(&tp, ca->centroid, 3, ca->K); kd_build(&tc, cb->centroid, 3, cb->K);
@@ -414,7 +420,7 @@ static corr_list correspondence_centroid(const frame *ca, const frame *cb, doubl
     int back = kd_nn(&tp, cb->centroid + 3 * j, &dr);
     if (back != i) continue;
     int np = ca->cl_off[i + 1] - ca->cl_off[i], nc = cb->cl_off[j + 1] - cb->cl_off[j];
-    if (!volume_constraint(ca->clusters[i], np, cb->clusters[j], nc, vc)) continue; /* :300 */
+    if (!volume_constraint(ca->clusters[i], np, cb->clusters[j], nc, vc, abs_int)) continue; /* :300 */
     out.c[out.n].query = i; out.c[out.n].match = j; out.c[out.n].dist = d; ++out.n;
   }
   kd_free(&tp); kd_free(&tc); return out;
@@ -550,7 +556,7 @@ int oracle_push(oracle_ctx *c, const void *data, uint64_t n_points, uint32_t poi
     float m[12]; relative_transform(cb, ca, m); /* :536 */
     for (int k = 0; k < ca->K; ++k) xform3(m, &ca->centroid[3 * k], &ca->centroid[3 * k + 1], &ca->centroid[3 * k + 2]); /* :540-541 */
     for (int k = 0; k < ca->K; ++k) { int n = ca->cl_off[k + 1] - ca->cl_off[k]; for (int j = 0; j < n; ++j) { opoint *q = &ca->clusters[k][j]; xform3(m, &q->x, &q->y, &q->z); } } /* :544-551 */
-    corr_list mp = correspondence_centroid(ca, cb, (double)c->p.volume_constraint); /* :564 */
+    corr_list mp = correspondence_centroid(ca, cb, (double)c->p.volume_constraint, c->p.volume_abs_int); /* :564 */
     double *score = (double *)malloc((mp.n ? mp.n : 1) * sizeof(double));
     for (int j = 0; j < mp.n; ++j) {
       int q = mp.c[j].query, mt = mp.c[j].match; int n1 = ca->cl_off[q + 1] - ca->cl_off[q], n2 = cb->cl_off[mt + 1] - cb->cl_off[mt];
@@ -629,4 +635,24 @@ void oracle_get_tracks(const oracle_ctx *c, float *xyz, int32_t *conf, int32_t *
   for (int i = 0; i < c->n_mo; ++i) { memcpy(xyz + 3 * i, c->mo[i].c, 3 * sizeof(float)); conf[i] = c->mo[i].confidence; maxc[i] = c->mo[i].max_confidence; }
 }
 uint32_t oracle_get_prev_cluster_count(const oracle_ctx *c) { return (uint32_t)c->ca->K; }
+/* P1 read-back: `ca` after the in-place transform of :540-551 — centroids (K_prev × 3) and the cluster points in cluster
+ * order (C_prev × xyzi), as pcl_ros::transformPointCloud left them */
+void oracle_get_prev_transformed(const oracle_ctx *c, float *cent_K3, float *pts_C4) {
+  const frame *f = c->ca; if (!f || !f->init) return;
+  if (cent_K3 && f->K) memcpy(cent_K3, f->centroid, (size_t)f->K * 3 * sizeof(float));
+  if (pts_C4) { size_t o = 0; for (int k = 0; k < f->K; ++k) { int n = f->cl_off[k + 1] - f->cl_off[k]; for (int j = 0; j < n; ++j, ++o) { const opoint *q = &f->clusters[k][j]; pts_C4[4 * o] = q->x; pts_C4[4 * o + 1] = q->y; pts_C4[4 * o + 2] = q->z; pts_C4[4 * o + 3] = q->intensity; } } }
+}
+uint32_t oracle_get_prev_clustered(const oracle_ctx *c) { const frame *f = c->ca; return (f && f->init && f->K) ? (uint32_t)f->cl_off[f->K] : 0u; }
+/* mark_cluster (:7-58) for every cluster of `cb`: position = compute3DCentroid into an Eigen::Vector4f — a sequential FLOAT
+ * sum over the cluster's points in order, divided by n (:15) —, scale = getMinMax3D extent (:16, :36-38), zero extents
+ * replaced by 0.1 (:40-47).  (The reference builds the marker only for tracked clusters inside filterCloud, :641.) */
+void oracle_get_markers(const oracle_ctx *c, float *pos_K3, float *scale_K3) {
+  const frame *f = c->cb;
+  for (int k = 0; k < f->K; ++k) {
+    int n = f->cl_off[k + 1] - f->cl_off[k]; float sx = 0.f, sy = 0.f, sz = 0.f, mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (int j = 0; j < n; ++j) { const float *q = &f->clusters[k][j].x; sx += q[0]; sy += q[1]; sz += q[2]; for (int d = 0; d < 3; ++d) { if (q[d] < mn[d]) mn[d] = q[d]; if (q[d] > mx[d]) mx[d] = q[d]; } }
+    pos_K3[3 * k] = sx / (float)n; pos_K3[3 * k + 1] = sy / (float)n; pos_K3[3 * k + 2] = sz / (float)n;
+    for (int d = 0; d < 3; ++d) { float e = mx[d] - mn[d]; scale_K3[3 * k + d] = e == 0.f ? 0.1f : e; }
+  }
+}
 double oracle_get_busy_seconds(const oracle_ctx *c) { return c->busy; }

@@ -42,6 +42,7 @@ typedef struct oracle_params {
   int32_t opc_normalization_factor; /* reference parses with stof into an int (:843) */
   int32_t ground_method;            /* 0 = crop (:526, active), 1 = voxel covariance (:527, intended) */
   float opc_resolution;             /* 0.1f, hard-coded at the call site :575 */
+  int32_t volume_abs_int;           /* 0: abs(volp-volc) at :277 is fabs (libstdc++ >= 6); 1: it is C's int abs(int) (truncates first) */
 } oracle_params;
 
 typedef struct oracle_ctx oracle_ctx;
@@ -88,6 +89,10 @@ void oracle_get_correspondences(const oracle_ctx *c, int32_t *query, int32_t *ma
 void oracle_get_tracks(const oracle_ctx *c, float *xyz_n3, int32_t *conf, int32_t *max_conf);
 /* clusters of the PREVIOUS frame after the in-place transform (:540-551): offsets + xyzi */
 uint32_t oracle_get_prev_cluster_count(const oracle_ctx *c);
+uint32_t oracle_get_prev_clustered(const oracle_ctx *c);
+void oracle_get_prev_transformed(const oracle_ctx *c, float *cent_K3, float *pts_C4);
+/* mark_cluster (:7-58) of every cluster of `cb`: fp32-centroid position and box extent (zero extent -> 0.1) */
+void oracle_get_markers(const oracle_ctx *c, float *pos_K3, float *scale_K3);
 
 /* wall-clock seconds spent inside oracle_push + oracle_filter since creation */
 double oracle_get_busy_seconds(const oracle_ctx *c);

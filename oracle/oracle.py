@@ -35,6 +35,10 @@ def lib():
         L.oracle_get_correspondences.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.oracle_get_tracks.argtypes = [C.c_void_p] + [C.c_void_p] * 3
         L.oracle_get_prev_cluster_count.restype = C.c_uint32
+        L.oracle_get_prev_clustered.restype = C.c_uint32
+        L.oracle_get_prev_clustered.argtypes = [C.c_void_p]
+        L.oracle_get_prev_transformed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_get_markers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_get_prev_cluster_count.argtypes = [C.c_void_p]
         L.oracle_get_busy_seconds.restype = C.c_double
         L.oracle_get_busy_seconds.argtypes = [C.c_void_p]
@@ -142,6 +146,20 @@ class Oracle:
         lib().oracle_get_tracks(self._h, xyz.ctypes.data, conf.ctypes.data, mx.ctypes.data)
         k = c.n_tracks
         return xyz[:k], conf[:k], mx[:k]
+
+    def markers(self):
+        """mark_cluster (:7-58) of every cluster of cb: (position K×3 float-accumulated centroid, scale K×3 with 0 → 0.1)."""
+        K = int(self.counts().n_clusters)
+        pos, scale = np.empty((max(K, 1), 3), np.float32), np.empty((max(K, 1), 3), np.float32)
+        lib().oracle_get_markers(self._h, pos.ctypes.data, scale.ctypes.data)
+        return pos[:K], scale[:K]
+
+    def prev_transformed(self):
+        """ca after the in-place transform of :540-551: (centroids K_prev×3, cluster points C_prev×4 in cluster order)."""
+        K, Cn = int(lib().oracle_get_prev_cluster_count(self._h)), int(lib().oracle_get_prev_clustered(self._h))
+        cen, pts = np.empty((max(K, 1), 3), np.float32), np.empty((max(Cn, 1), 4), np.float32)
+        lib().oracle_get_prev_transformed(self._h, cen.ctypes.data, pts.ctypes.data)
+        return cen[:K], pts[:Cn]
 
     def busy_seconds(self):
         return float(lib().oracle_get_busy_seconds(self._h))

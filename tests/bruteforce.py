@@ -174,7 +174,9 @@ def correspondences(prev_cents, prev_clusters, cur_cents, cur_clusters, p):
             continue
         vp, vc = volume(prev_clusters[i]), volume(cur_clusters[j])
         with np.errstate(invalid="ignore", divide="ignore"):
-            ok = (abs(vp - vc) / (vp + vc)) < np.float64(f32(p.volume_constraint))
+            diff = vp - vc
+            ad = np.float64(abs(int(diff))) if (getattr(p, "volume_abs_int", 0) and np.isfinite(diff)) else abs(diff)   # :277 int abs(int) reading vs fabs
+            ok = (ad / (vp + vc)) < np.float64(f32(p.volume_constraint))
         if not ok:
             continue
         out.append((i, int(j), dfwd[i]))

@@ -57,7 +57,10 @@ def main():
                 res["%s/%d/%d" % (name, seed, f)] = d
             o.close()
     path = os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")
-    json.dump({"cases": [list(c[:4]) + [c[4], c[5]] for c in CASES], "digests": res}, open(path, "w"), indent=0, sort_keys=True)
+    provenance = ("digests of oracle/mor_oracle.c outputs (this script); the cases hdl64_m1/2000, hdl64_m1/2005, hdl64_m2/2003 and os128_m1/3001 are "
+                  "reproduced without the oracle by the independent full-size implementation tests/independent_fullsize.py "
+                  "(tests/test_oracle_independent_fullsize.py); no output of the real reference (PCL/ROS, unbuildable here) backs any of them")
+    json.dump({"cases": [list(c[:4]) + [c[4], c[5]] for c in CASES], "digests": res, "provenance": provenance}, open(path, "w"), indent=0, sort_keys=True)
     print("wrote", path, len(res), "frames")
 
 

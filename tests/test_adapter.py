@@ -47,10 +47,13 @@ def test_replay_matches_oracle(tmp_path, method):
     r = subprocess.run([REPLAY, str(cfg), str(tmp_path / "poses.txt"), str(tmp_path)] + files, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "method_choice:%d" % method in r.stdout   # the echo of setVariables
-    o = Oracle(scene_params(method_choice=method), 4, 3)
+    p_ = scene_params(method_choice=method)
+    o = Oracle(p_, 4, 3)
     removed = 0
     for i, (pts, pose) in enumerate(frames):
         o.push(pts, pose)
+        raw = pts[np.isfinite(pts[:, :3]).all(1) & (np.abs(pts[:, 0]) <= p_.trim_x) & (np.abs(pts[:, 1]) <= p_.trim_y)]
+        o_cloud = raw[(raw[:, 2] >= p_.gp_limit) & (raw[:, 2] <= p_.trim_z)]   # `cloud` (.cpp:85): indices of cluster_indices refer to it
         want = o.filter()
         got = np.fromfile(tmp_path / ("filtered_%04d.bin" % i), np.float32).reshape(-1, 4)
         assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), "frame %d" % i
@@ -60,6 +63,24 @@ def test_replay_matches_oracle(tmp_path, method):
         cen = o.centroids()
         assert len(mk) == len(cen), "frame %d" % i
         if len(cen):
-            assert np.allclose(mk[:, 1:4], cen, atol=1e-4) and (mk[:, 4:7] > 0).all(), "frame %d" % i
+            pos, scale = o.markers()   # mark_cluster (.cpp:7-58): float-accumulated centroid, extent with 0 → 0.1
+            assert np.allclose(mk[:, 1:4], pos, rtol=0, atol=2e-6) and np.allclose(mk[:, 4:7], scale, rtol=0, atol=2e-6), "frame %d" % i
+            assert np.array_equal(mk[:, 7].astype(bool), o.detection().astype(bool)), "frame %d" % i
+        # VISUALIZE (on by default, as in the reference's IncludeAll.h:32): from the second push on the caller's cloud and `output`
+        # hold the clustered points of the new frame as 32-byte PointXYZI records (.cpp:553-558)
+        pushed = np.fromfile(tmp_path / ("pushed_%04d.bin" % i), np.uint8)
+        if i == 0:
+            assert np.array_equal(pushed, pts.astype(np.float32).view(np.uint8).reshape(-1)), "first push leaves the caller's cloud alone (ca not initialised, .cpp:534)"
+        else:
+            off, idx = o.clusters()
+            cc = o_cloud[idx]   # cluster_collection: the clustered points in cluster order
+            rec = pushed.reshape(-1, 32)
+            assert len(rec) == len(cc), "frame %d" % i
+            got_xyz = rec[:, 0:12].copy().view(np.float32).reshape(-1, 3)
+            got_i = rec[:, 16:20].copy().view(np.float32).reshape(-1)
+            assert np.array_equal(got_xyz.view(np.uint32), cc[:, :3].view(np.uint32)) and np.array_equal(got_i.view(np.uint32), cc[:, 3].view(np.uint32)), "frame %d" % i
+            assert ("pushed %d: caller cloud width %d point_step 32 output.width %d output.frame_id %s" % (i, len(cc), len(cc), "/debug")) in r.stdout, r.stdout
+        # filterCloud: the incoming cloud's header travels through to out_cloud and `output` (.cpp:690-691), frame_id replaced (.cpp:692)
+        assert ("frame %d:" % i) in r.stdout and ("frame_id /filtered, seq %d, stamp %d, cloud seq %d stamp %d" % (i, 100 + i, i, 1000000 * (100 + i))) in r.stdout, r.stdout
     if method == 2:
         assert removed > 0

@@ -145,7 +145,7 @@ def test_blob_layouts_and_device_resident_input():
     buf.upload(pts)
     b.push([(buf, len(pts))], pose[None, :])
     compare_output(ref, b.filter()[0], "device-resident blob")
-    n = b.filter(to_host=False)[0]   # repeated filter on the same frame: same cloud, tracker not advanced twice
+    n = b.filter(to_host=False)[0]   # repeated filter on the same frame (no tracked centroid yet: same cloud)
     ptr, n2 = b.output_device(0)
     assert n == n2 == len(ref)
     b.close()
@@ -696,3 +696,111 @@ def test_error_of_an_intermediate_frame_is_reported_once():
     b.filter_async()
     b.wait()   # reported and cleared: the next wait is clean
     b.close()
+
+
+def test_filter_cloud_called_twice_walks_the_tracks_twice():
+    """The reference's filterCloud has no "once per frame" guard: a second call on the same frame runs :630-671 again, so
+    confidences move again and the second output may differ.  HIP and oracle must agree call by call."""
+    p = scene_params(method_choice=2)
+    frames = small_stream(1, n_frames=9)
+    b, o = MorBatch(p, 1, max(len(f[0]) for f in frames)), Oracle(p)
+    changed = False
+    for f, (pts, pose) in enumerate(frames):
+        b.push([pts], pose[None, :])
+        o.push(pts, pose)
+        for rep in range(3 if f >= 5 else 1):
+            before = o.tracks()[1].copy()
+            compare_output(o.filter(), b.filter()[0], "frame %d call %d" % (f, rep))
+            compare_tracks(o, b, 0, "frame %d call %d" % (f, rep))
+            changed = changed or (rep > 0 and not np.array_equal(before, o.tracks()[1]))
+    assert changed, "the scene must have tracked centroids whose confidence a repeated call moves"
+    b.close()
+
+
+def test_markers_match_oracle_including_zero_extent():
+    """mark_cluster (:7-58): position = FLOAT-accumulated centroid of the cluster's points (not the fp64 centroid of :239-243),
+    scale = box extent, zero extents → 0.1.  Compared with the oracle's restatement; one cluster is a flat patch (all z
+    equal ⇒ zero z extent), one a line along x (two zero extents)."""
+    p = scene_params(method_choice=1, min_cluster_size=20)
+    rng = np.random.default_rng(3)
+    g = np.arange(0, 0.5, 0.05, dtype=np.float32)
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    flat = np.stack([X.ravel() + 1.0, Y.ravel() - 1.0, np.full(X.size, 0.25, np.float32), np.full(X.size, 0.5, np.float32)], 1)
+    line = np.stack([np.arange(40, dtype=np.float32) * np.float32(0.04) - 2.0, np.full(40, 1.5, np.float32), np.full(40, 0.75, np.float32), np.zeros(40, np.float32)], 1)
+    blob = np.column_stack([rng.normal(0.0, 0.08, (300, 3)) + [0.0, 0.0, 0.8], rng.random(300)]).astype(np.float32)
+    pts = np.concatenate([flat, line, blob]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    pose = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    b, o = MorBatch(p, 1, len(pts)), Oracle(p)
+    b.push([pts], pose[None, :])
+    o.push(pts, pose)
+    compare_frame(o, b, 0, "marker scene")
+    assert o.counts().n_clusters == 3
+    (pos_o, sc_o), (pos_b, sc_b) = o.markers(), b.markers(0)
+    assert np.array_equal(pos_o.view(np.uint32), pos_b.view(np.uint32)) and np.array_equal(sc_o.view(np.uint32), sc_b.view(np.uint32))
+    assert (sc_o == np.float32(0.1)).sum() == 3          # flat patch: z; line: y and z
+    lo, hi = b.boxes(0)
+    ext = hi - lo
+    assert np.array_equal(np.where(ext == 0, np.float32(0.1), ext), sc_b)
+    # the marker position is NOT the fp64-accumulated centroid in general
+    assert np.max(np.abs(pos_b.astype(np.float64) - b.centroids(0).astype(np.float64))) <= 1e-5
+    b.close()
+    # and at full size
+    p = kitti_params(1)
+    b, o = MorBatch(p, 1, 120000), Oracle(p)
+    x, pose = synth.frame(2005, "hdl64", 0)
+    b.push([x], pose[None, :])
+    o.push(x, pose)
+    (pos_o, sc_o), (pos_b, sc_b) = o.markers(), b.markers(0)
+    assert len(pos_o) > 10 and np.array_equal(pos_o.view(np.uint32), pos_b.view(np.uint32)) and np.array_equal(sc_o.view(np.uint32), sc_b.view(np.uint32))
+    b.close()
+
+
+@pytest.mark.parametrize("sensor,seed", [("hdl64", 2005), ("hdl64_urban", 6001)])
+def test_transformed_previous_frame_matches_oracle(sensor, seed):
+    """P1 (:536-551) read back directly: after a push the previous frame's centroids, cluster points and cluster boxes in the
+    new frame's coordinates must be bit-equal to the oracle's (individually rounded fp32 operations in the reference's order)."""
+    p = kitti_params(1)
+    n = synth.n_points(sensor)
+    b, o = MorBatch(p, 1, n), Oracle(p)
+    prev_off = None
+    for f in range(3):
+        x, pose = synth.frame(seed, sensor, f)
+        b.push([x], pose[None, :])
+        o.push(x, pose)
+        if prev_off is not None:
+            cen_o, pts_o = o.prev_transformed()
+            K, Cn = len(cen_o), len(pts_o)
+            assert K > 5 and Cn > 1000 and K == len(prev_off) - 1 and Cn == prev_off[-1]
+            cen_b = b.debug_read("xcent", 0, np.float32, 4 * K).reshape(K, 4)[:, :3]
+            pts_b = b.debug_read("cl_pts_prev", 0, np.float32, 4 * Cn).reshape(Cn, 4)
+            assert np.array_equal(cen_o.view(np.uint32), cen_b.view(np.uint32)), "frame %d transformed centroids" % f
+            assert np.array_equal(pts_o.view(np.uint32), pts_b.view(np.uint32)), "frame %d transformed cluster points" % f
+            lo_b = b.debug_read("xamin", 0, np.float32, 4 * K).reshape(K, 4)[:, :3]
+            hi_b = b.debug_read("xamax", 0, np.float32, 4 * K).reshape(K, 4)[:, :3]
+            for k in range(K):
+                q = pts_o[prev_off[k]:prev_off[k + 1], :3]
+                assert np.array_equal(lo_b[k], q.min(0)) and np.array_equal(hi_b[k], q.max(0)), (f, k)
+        compare_frame(o, b, 0, "frame %d" % f)
+        prev_off = o.clusters()[0].copy()
+        b.filter(to_host=False)
+        o.filter()
+    b.close()
+
+
+def test_volume_gate_with_integer_abs():
+    """The unqualified abs() of :277 may resolve to C's int abs(int) with an old libstdc++ (the difference of the two volumes is
+    truncated first): mor_params.volume_abs_int = 1 restates that reading.  HIP, oracle and brute force agree on it, and it is
+    observably different from the default (fabs) on these scenes."""
+    diffs = 0
+    for seed in (1, 2, 3):
+        frames = small_stream(seed, n_frames=6)
+        corr = {}
+        for flag in (0, 1):
+            p = scene_params(method_choice=1)
+            p.volume_abs_int = flag
+            p.volume_constraint = 0.05
+            st = _run_lockstep(p, [frames])
+            corr[flag] = st["corr"]
+        diffs += corr[0] != corr[1]
+    assert diffs > 0

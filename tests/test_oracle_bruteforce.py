@@ -135,3 +135,28 @@ def test_oracle_known_answers():
     """hand-checkable scenes pin the oracle without any reference binary (tests/known_answers.py)."""
     from known_answers import check_all
     check_all(_OracleEngine, scene_params)
+
+
+def test_volume_gate_integer_abs_reading():
+    """:277 `abs(volp-volc)` is unqualified.  Default: fabs (libstdc++ >= 6).  volume_abs_int = 1: C's int abs(int) — the
+    difference is truncated towards zero first, so clusters whose box volumes differ by less than 1 m³ always pass.
+    Oracle and brute force agree on both readings, and the readings differ on these scenes."""
+    differ = 0
+    for seed in (1, 2, 3):
+        corr = {}
+        for flag in (0, 1):
+            p = scene_params(method_choice=1)
+            p.volume_abs_int = flag
+            p.volume_constraint = 0.05
+            o, b = Oracle(p, 4, 3), BruteMOR(p, 4, 3)
+            n = 0
+            for f, (pts, pose) in enumerate(small_stream(seed, n_frames=6)):
+                o.push(pts, pose)
+                b.push(pts, pose)
+                _compare_frame(o, b, "abs_int %d seed %d frame %d" % (flag, seed, f))
+                assert np.array_equal(o.filter().view(np.uint32), b.filter().view(np.uint32))
+                n += o.counts().n_corr
+            corr[flag] = n
+        assert corr[1] >= corr[0]   # the truncating reading only ever lets more pairs through
+        differ += corr[1] > corr[0]
+    assert differ > 0
