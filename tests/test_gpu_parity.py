@@ -804,3 +804,36 @@ def test_volume_gate_with_integer_abs():
             corr[flag] = st["corr"]
         diffs += corr[0] != corr[1]
     assert diffs > 0
+
+
+def test_two_batches_in_one_process_interleaved():
+    """SURVEY §8e single-process form: two mor_batch objects (device ordinals 0 and min(1, n_devices − 1) — both on device 0 on a
+    one-GPU box) with interleaved pushes and filters, different parameter profiles, one of them asynchronous: nothing may leak
+    between them (stage streams, pinned rings, the thread-local error text)."""
+    from dynamicslamtool_amd import engine
+    dev1 = min(1, engine.device_count() - 1)
+    pa, pb = scene_params(method_choice=1), scene_params(method_choice=2)
+    fa, fb = small_stream(21, n_frames=7), small_stream(22, n_frames=7, n_objects=4)
+    a, b = MorBatch(pa, 1, max(len(f[0]) for f in fa), device=0), MorBatch(pb, 1, max(len(f[0]) for f in fb), 3, 2, device=dev1)
+    oa, ob = Oracle(pa), Oracle(pb, 3, 2)
+    b.set_async(True)
+    for f in range(7):
+        a.push([fa[f][0]], fa[f][1][None, :])
+        b.push([fb[f][0]], fb[f][1][None, :])
+        oa.push(*fa[f])
+        ob.push(*fb[f])
+        with pytest.raises(MorError):
+            a.push([np.zeros((a.max_points + 1, 4), np.float32)], fa[f][1][None, :])   # an error on one batch …
+        b.filter_async()
+        compare_frame(oa, a, 0, "batch a frame %d" % f)
+        compare_output(oa.filter(), a.filter()[0], "batch a frame %d" % f)
+        want_b = ob.filter()
+        if f % 2 == 1:
+            b.wait()                                                                    # … does not show up on the other
+            ptr, n = b.output_device(0)
+            got = np.empty((n, 4), np.float32)
+            engine._check(engine.lib().mor_device_download(dev1, got.ctypes.data, ptr, n * 16))
+            compare_output(want_b, got, "batch b frame %d" % f)
+            compare_tracks(ob, b, 0, "batch b frame %d" % f)
+    a.close()
+    b.close()
