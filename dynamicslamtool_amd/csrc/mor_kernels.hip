@@ -565,13 +565,36 @@ template <bool L> __device__ __forceinline__ int gh_ld(const int *p) {
 template <bool L> __device__ __forceinline__ void gh_st(int *p, int v) {
   if (L) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// in-place exclusive scan of a[0, n) by the whole workgroup (contiguous chunk per thread); returns the total
+// in-place exclusive scan of a[0, n) by the whole workgroup; returns the total.  LDS arrays: a contiguous chunk per thread.
+// Global arrays (long row tables, big cell lists): every wave owns a contiguous segment and walks it 64 elements at a time —
+// coalesced accesses, one wave scan per step — instead of a chain of dependent single loads per thread.
 template <bool L> __device__ __forceinline__ int gh_scan(int *a, int n, int *sh) {
-  const int chunk = (n + GH_T - 1) / GH_T, b = min((int)threadIdx.x * chunk, n), e = min(b + chunk, n);
+  if (L) {
+    const int chunk = (n + GH_T - 1) / GH_T, b = min((int)threadIdx.x * chunk, n), e = min(b + chunk, n);
+    int sum = 0;
+    for (int i = b; i < e; ++i) sum += gh_ld<L>(a + i);
+    int total; int run = block_excl_scan_n<GH_T>(sum, sh, &total);
+    for (int i = b; i < e; ++i) { const int v = gh_ld<L>(a + i); gh_st<L>(a + i, run); run += v; }
+    __syncthreads();
+    return total;
+  }
+  constexpr int NW = GH_T / 64;
+  const int seg = ((n + NW - 1) / NW + 63) / 64 * 64, b = min(wave_id() * seg, n), e = min(b + seg, n), lane = lane_id();
   int sum = 0;
-  for (int i = b; i < e; ++i) sum += gh_ld<L>(a + i);
-  int total; int run = block_excl_scan_n<GH_T>(sum, sh, &total);
-  for (int i = b; i < e; ++i) { const int v = gh_ld<L>(a + i); gh_st<L>(a + i, run); run += v; }
+  for (int i = b + lane; i < e; i += 64) sum += gh_ld<L>(a + i);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  __syncthreads();
+  if (lane == 0) sh[wave_id()] = sum;
+  __syncthreads();
+  int run = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { const int x = sh[w]; if (w < wave_id()) run += x; total += x; }
+  for (int i0 = b; i0 < e; i0 += 64) {
+    const int i = i0 + lane, v = i < e ? gh_ld<L>(a + i) : 0, inc = wave_incl_scan(v);
+    if (i < e) gh_st<L>(a + i, run + inc - v);
+    run += __shfl(inc, 63, 64);
+  }
   __syncthreads();
   return total;
 }
@@ -2207,29 +2230,101 @@ template <int CHUNK> __device__ __forceinline__ int g2_voxel_bin(const MorDev &d
   }
   return ((double)fabsf(acc[3]) < 0.001 && (double)fabsf(acc[4]) < 0.001 && (double)fabsf(acc[5]) < 0.001) ? (int)(q.z * 10) : 0x7fffffff;
 }
-// One WAVE per voxel (64-thread workgroups, 10 KiB of LDS ⇒ a dozen voxels in flight per CU): the usual case of at most
-// G2_SMALL neighbours.  Voxels with more (a dense surface next to the sensor) are queued for k_g2_cov_big.
-__global__ __launch_bounds__(64) void k_g2_cov(MorDev d) {
-  int s = blockIdx.y + d.s0, V = d.info[s].n_occ;
+// Sixteen lanes per voxel, sixteen voxels per 256-thread workgroup (a voxel centroid has a dozen neighbours on average, 96 %
+// have ≤ 64): the group computes the voxel's centroid (dsc, :110-113 — fp32 sums in ascending point index, one lane), gathers
+// the points within the radius from the 3×3×3 voxel block into its slice of LDS (lanes 0–8 resolve the nine rows, ballot
+// compaction inside the group: no atomics), ranks the (d², index) keys by counting (they are unique), lays the
+// coordinates out in rank order and lets one lane add up the ordered sums — four groups of a wave do that side by side.
+// Voxels with more than G2_GROUP_CAP neighbours (a dense surface next to the sensor) are queued for k_g2_cov_big.
+#define G2_GROUP_CAP 128
+__global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
+  const int s = blockIdx.y + d.s0, V = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
-  __shared__ unsigned long long key[G2_SMALL];
-  __shared__ float px[G2_SMALL], py[G2_SMALL], pz[G2_SMALL];
-  __shared__ int cnt;
-  __shared__ float acc[6];
-  for (int v = blockIdx.x; v < V; v += gridDim.x) {
-    if (threadIdx.x == 0) cnt = 0;
+  const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15, lane = lane_id(), gsh = lane & 48;   // group in the workgroup, lane in the group, shift of the group's bits in a wave ballot
+  __shared__ unsigned long long l_key[MOR_BT / 16][G2_GROUP_CAP];
+  __shared__ float l_x[MOR_BT / 16][G2_GROUP_CAP], l_y[MOR_BT / 16][G2_GROUP_CAP], l_z[MOR_BT / 16][G2_GROUP_CAP];
+  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  const float4 *sp = d.sorted + so;
+  const int zbase = d.zbase[s];
+  for (int v0 = blockIdx.x * (MOR_BT / 16); v0 < V; v0 += gridDim.x * (MOR_BT / 16)) {
+    const int v = v0 + grp; const bool act = v < V;
+    // ---- voxel centroid: sequential fp32 sums over the voxel's points in ascending index (stable sort ⇒ storage order)
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act && sub == 0) {
+      float sx = 0.f, sy = 0.f, sz = 0.f; const int b0 = st[v], e0 = st[v + 1];
+      for (int k = b0; k < e0; ++k) { const float4 p = sp[k]; sx += p.x; sy += p.y; sz += p.z; }
+      const float n = (float)(e0 - b0);
+      q = make_float4(sx / n, sy / n, sz / n, 0.f);
+      d.vcent[so + v] = q;
+    }
+    q.x = __shfl(q.x, lane & 48, 64); q.y = __shfl(q.y, lane & 48, 64); q.z = __shfl(q.z, lane & 48, 64);
+    // ---- the nine (y,z) rows of the 3×3×3 block: lanes 0 … 8 of the group, each row's three x-cells are one range of `sorted`
+    int rb0 = 0, rlen = 0;
+    if (act && sub < 9) {
+      int cx, cy, cz; bool cl; grid_cell(d.g, q, 0.f, zbase, cx, cy, cz, cl);
+      const int y = cy + sub % 3 - 1, z = cz + sub / 3 - 1;
+      if ((unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) {
+        int lo, hi; row_cells(d.g, ckey, rs, max(cx - 1, 0), min(cx + 1, d.g.nx - 1), y, z, lo, hi);
+        if (lo < hi) { rb0 = st[lo]; rlen = st[hi] - rb0; }
+      }
+    }
+    int rb[9], rp[10]; rp[0] = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { rb[r] = __shfl(rb0, (lane & 48) + r, 64); rp[r + 1] = rp[r] + __shfl(rlen, (lane & 48) + r, 64); }
+    // ---- gather: candidates sixteen at a time, hits compacted into the group's list
+    int n = 0;
+    const int ncand_max = __shfl(rp[9], lane & 48, 64);   // (uniform in the group anyway)
+    int wave_max = ncand_max;
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) wave_max = max(wave_max, __shfl_xor(wave_max, o, 64));
+    for (int c0 = 0; c0 < wave_max; c0 += 16) {
+      const int c = c0 + sub; bool hit = false; float dd = 0.f; float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < rp[9]) {
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) if (c >= rp[r] && c < rp[r + 1]) k = rb[r] + (c - rp[r]);
+        p = sp[k];
+        dd = sqdist(q.x, q.y, q.z, p.x, p.y, p.z);
+        hit = dd < d.leaf_r2;
+      }
+      const unsigned m16 = (unsigned)((__ballot(hit) >> gsh) & 0xffffull);
+      if (hit) {
+        const int slot = n + __popc(m16 & ((1u << sub) - 1u));
+        if (slot < G2_GROUP_CAP) { l_key[grp][slot] = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(p.w); l_x[grp][slot] = p.x; l_y[grp][slot] = p.y; l_z[grp][slot] = p.z; }
+      }
+      n += __popc(m16);
+    }
     __syncthreads();
-    const float4 q = d.vcent[so + v];
-    g2_for_neighbours(d, s, q, [&](float dd, const float4 &p) {
-      int slot = atomicAdd(&cnt, 1);
-      if (slot < G2_SMALL) key[slot] = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(p.w);
-    });
-    __syncthreads();
-    const int n = cnt;
+    // ---- rank by counting (keys are unique: the index is part of them), coordinates to their rank
     int bin = 0x7fffffff;
-    if (n > G2_SMALL) { if (threadIdx.x == 0) { int slot = atomicAdd(&d.g2_nbig[s], 1); d.g2_big[so + slot] = v; } }
-    else if (n > 3) bin = g2_voxel_bin<G2_SMALL>(d, so, q, key, n, px, py, pz, acc);
-    if (threadIdx.x == 0) d.vbin[so + v] = bin;
+    const bool small = act && n > 3 && n <= G2_GROUP_CAP;
+    float ex[G2_GROUP_CAP / 16], ey[G2_GROUP_CAP / 16], ez[G2_GROUP_CAP / 16]; int er[G2_GROUP_CAP / 16];
+#pragma unroll
+    for (int u = 0; u < G2_GROUP_CAP / 16; ++u) {
+      const int e = sub + 16 * u; er[u] = -1;
+      if (small && e < n) {
+        const unsigned long long ke = l_key[grp][e]; int r = 0;
+        for (int j = 0; j < n; ++j) r += l_key[grp][j] < ke;
+        er[u] = r; ex[u] = l_x[grp][e]; ey[u] = l_y[grp][e]; ez[u] = l_z[grp][e];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < G2_GROUP_CAP / 16; ++u) if (er[u] >= 0) { l_x[grp][er[u]] = ex[u]; l_y[grp][er[u]] = ey[u]; l_z[grp][er[u]] = ez[u]; }
+    __syncthreads();
+    // ---- ordered fp32 sums (:142, :144) by one lane of the group
+    if (small && sub == 0) {
+      float cx = 0.f, cy = 0.f, cz = 0.f;
+      for (int i = 0; i < n; ++i) { cx += l_x[grp][i]; cy += l_y[grp][i]; cz += l_z[grp][i]; }
+      const float fn = (float)n; cx /= fn; cy /= fn; cz /= fn;
+      float c02 = 0.f, c12 = 0.f, c22 = 0.f;
+      for (int i = 0; i < n; ++i) { const float dx = l_x[grp][i] - cx, dy = l_y[grp][i] - cy, dz = l_z[grp][i] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; }
+      if ((double)fabsf(c02) < 0.001 && (double)fabsf(c12) < 0.001 && (double)fabsf(c22) < 0.001) bin = (int)(q.z * 10);
+    }
+    if (act && sub == 0) {
+      if (n > G2_GROUP_CAP) { const int slot = atomicAdd(&d.g2_nbig[s], 1); d.g2_big[so + slot] = v; }
+      else d.vbin[so + v] = bin;
+    }
     __syncthreads();
   }
 }
@@ -2517,10 +2612,9 @@ static void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm)
     MorDev da = d; da.gmode = 1; da.g = d.gv; da.cloud = d.rawbuf; da.cell_passes = d.voxel_passes; da.tiles_m = d.tiles; da.use_hash = 0;
     da.skey = d.rkeys[da.cell_passes & 1]; da.sidx = d.rvals[da.cell_passes & 1];
     mor_launch_split_and_grid(da, st, tm);
-    MOR_LAUNCH(MK_G2_CENTROID, k_g2_centroid, dim3(32, d.B), da);
     (void)hipMemsetAsync(d.g2_nbig + d.s0, 0, (size_t)d.B * sizeof(int), st);
     mor_timer_begin(tm, MK_G2_COV, st);
-    hipLaunchKernelGGL(k_g2_cov, dim3(4096, d.B), dim3(64), 0, st, da);
+    hipLaunchKernelGGL(k_g2_cov, dim3(256, d.B), dim3(MOR_BT), 0, st, da);
     mor_timer_end(tm, MK_G2_COV, st);
     MOR_LAUNCH(MK_G2_COV_BIG, k_g2_cov_big, dim3(64, d.B), da);
     MOR_LAUNCH(MK_G2_MODE, k_g2_mode, gB, da);
