@@ -39,8 +39,18 @@ struct MorLaunchTimer {
   struct Rec { int id; hipEvent_t a, b; };
   std::vector<Rec> recs; size_t used = 0;
   double ms[MK_COUNT] = {0}; uint32_t launches[MK_COUNT] = {0};
+  struct Span { int id; float t0, t1; };
+  std::vector<Span> timeline;   // kernels of the last collected leg, milliseconds since its first recorded event (all streams on one clock)
   void collect() {
-    for (size_t i = 0; i < used; ++i) { float t = 0; if (hipEventElapsedTime(&t, recs[i].a, recs[i].b) == hipSuccess) { ms[recs[i].id] += t; launches[recs[i].id]++; } }
+    if (used) timeline.clear();
+    for (size_t i = 0; i < used; ++i) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, recs[i].a, recs[i].b) == hipSuccess) {
+        ms[recs[i].id] += t; launches[recs[i].id]++;
+        float s0 = 0;
+        if (hipEventElapsedTime(&s0, recs[0].a, recs[i].a) == hipSuccess) timeline.push_back({recs[i].id, s0, s0 + t});
+      }
+    }
     used = 0;
   }
   ~MorLaunchTimer() { for (auto &r : recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); } }
@@ -660,6 +670,13 @@ int mor_get_last_timing(const mor_batch *b, float *push_ms, float *filter_ms) {
   return MOR_OK;
 }
 int mor_kernel_timing_enable(mor_batch *b, int enable) { if (!b) return MOR_ERR_INVALID; b->timer.enabled = enable != 0; return MOR_OK; }
+// the kernels of the last timed leg as (kernel id, start ms, end ms) triples on one clock: shows how the stage streams overlap
+int mor_kernel_timeline_read(mor_batch *b, int *ids, float *t0_ms, float *t1_ms, int max_n) {
+  if (!b) return MOR_ERR_INVALID;
+  const int n = std::min<int>((int)b->timer.timeline.size(), max_n);
+  for (int i = 0; i < n; ++i) { ids[i] = b->timer.timeline[i].id; t0_ms[i] = b->timer.timeline[i].t0; t1_ms[i] = b->timer.timeline[i].t1; }
+  return n;
+}
 int mor_kernel_timing_read(mor_batch *b, int reset, char *names, size_t names_cap, float *ms_total, uint32_t *launches, int max_kernels) {
   if (!b) return MOR_ERR_INVALID;
   std::string all;

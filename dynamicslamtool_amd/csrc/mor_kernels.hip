@@ -29,7 +29,7 @@
 const char *const mor_kernel_names[MK_COUNT] = {
     "classify", "scan_tiles", "scatter", "split", "heads_count", "heads_scan", "heads_scatter", "hash_clear", "cellboxes", "cellgraph", 
     "label", "rhist", "rscan", "rscatter",
-    "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "pairs", "score_fast", "score_near", "score_block", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
+    "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "cluster_pairs", "score_fast", "score_near", "score_block", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
     "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridfill", "cg_slab", "cg_final"};
 
 #ifdef MOR_EXP_STAMPS
@@ -1466,23 +1466,25 @@ __global__ __launch_bounds__(MOR_BT) void k_stats(MorDev d) {
     if (threadIdx.x == 0) d.part[(size_t)s * d.Wcap + w] = r;
   }
 }
-// centroid = Σ(double)p / n cast to fp32 (:239-243), AABB for the volume gate
-__global__ __launch_bounds__(MOR_BT) void k_stats_fin(MorDev d) {
-  int s = blockIdx.y + d.s0, K = d.info[s].K, k = blockIdx.x * MOR_BT + threadIdx.x;
-  if (k >= K) return;
+// centroid = Σ(double)p / n cast to fp32 (:239-243), AABB for the volume gate — one workgroup per stream (part of k_cluster_pairs)
+__device__ __forceinline__ void stats_fin_body(const MorDev &d, int s) {
+  const int K = d.info[s].K;
   const int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1), *coff = d.chunk_off[d.cur] + (size_t)s * (d.Kcap + 1);
   const Red6 *pt = d.part + (size_t)s * d.Wcap;
-  Red6 r = pt[coff[k]];
-  for (int w = coff[k] + 1; w < coff[k + 1]; ++w) {
-    const Red6 q = pt[w];
-    r.sx += q.sx; r.sy += q.sy; r.sz += q.sz;
-    r.mnx = fminf(r.mnx, q.mnx); r.mny = fminf(r.mny, q.mny); r.mnz = fminf(r.mnz, q.mnz);
-    r.mxx = fmaxf(r.mxx, q.mxx); r.mxy = fmaxf(r.mxy, q.mxy); r.mxz = fmaxf(r.mxz, q.mxz);
+  for (int k = threadIdx.x; k < K; k += MOR_BT) {
+    Red6 r = pt[coff[k]];
+    for (int w = coff[k] + 1; w < coff[k + 1]; ++w) {
+      const Red6 q = pt[w];
+      r.sx += q.sx; r.sy += q.sy; r.sz += q.sz;
+      r.mnx = fminf(r.mnx, q.mnx); r.mny = fminf(r.mny, q.mny); r.mnz = fminf(r.mnz, q.mnz);
+      r.mxx = fmaxf(r.mxx, q.mxx); r.mxy = fmaxf(r.mxy, q.mxy); r.mxz = fmaxf(r.mxz, q.mxz);
+    }
+    const double n = (double)(off[k + 1] - off[k]);
+    d.centroid[d.cur][(size_t)s * d.Kcap + k] = make_float4((float)(r.sx / n), (float)(r.sy / n), (float)(r.sz / n), 0.f);
+    d.amin[d.cur][(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
+    d.amax[d.cur][(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
+    d.pair_of_cur[(size_t)s * d.Kcap + k] = -1;
   }
-  const double n = (double)(off[k + 1] - off[k]);
-  d.centroid[d.cur][(size_t)s * d.Kcap + k] = make_float4((float)(r.sx / n), (float)(r.sy / n), (float)(r.sz / n), 0.f);
-  d.amin[d.cur][(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
-  d.amax[d.cur][(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
 }
 
 // ------------------------------------------------------------------------------------ P1: previous frame → current pose (:536-551)
@@ -1517,56 +1519,56 @@ __global__ __launch_bounds__(MOR_BT) void k_xform_prev(MorDev d) {
   }
 }
 // AABBs of the transformed clusters (volume gate), transformed centroids (:540-541)
-__global__ __launch_bounds__(MOR_BT) void k_xform_fin(MorDev d) {
-  int s = blockIdx.y + d.s0, pv = d.prev, K = d.slot_kc[d.prev][s].x, k = blockIdx.x * MOR_BT + threadIdx.x;
-  if (k >= K) return;
+__device__ __forceinline__ void xform_fin_body(const MorDev &d, int s) {
+  const int pv = d.prev, K = d.slot_kc[d.prev][s].x;
   const int *coff = d.chunk_off[pv] + (size_t)s * (d.Kcap + 1);
   const Red6 *pt = d.part_back + (size_t)s * d.Wcap;
-  Red6 r = pt[coff[k]];
-  for (int w = coff[k] + 1; w < coff[k + 1]; ++w) {
-    const Red6 q = pt[w];
-    r.mnx = fminf(r.mnx, q.mnx); r.mny = fminf(r.mny, q.mny); r.mnz = fminf(r.mnz, q.mnz);
-    r.mxx = fmaxf(r.mxx, q.mxx); r.mxy = fmaxf(r.mxy, q.mxy); r.mxz = fmaxf(r.mxz, q.mxz);
-  }
   const float *m = d.args[s].xf;
-  float4 c = d.centroid[pv][(size_t)s * d.Kcap + k];
-  xform(m, c.x, c.y, c.z);
-  d.xcent[(size_t)s * d.Kcap + k] = c;     // ca's own centroids stay as they are: the tail stage of frame k−1 may still be reading them
-  d.xamin[(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
-  d.xamax[(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
-  d.pair_of_prev[(size_t)s * d.Kcap + k] = -1;
+  for (int k = threadIdx.x; k < K; k += MOR_BT) {
+    Red6 r = pt[coff[k]];
+    for (int w = coff[k] + 1; w < coff[k + 1]; ++w) {
+      const Red6 q = pt[w];
+      r.mnx = fminf(r.mnx, q.mnx); r.mny = fminf(r.mny, q.mny); r.mnz = fminf(r.mnz, q.mnz);
+      r.mxx = fmaxf(r.mxx, q.mxx); r.mxy = fmaxf(r.mxy, q.mxy); r.mxz = fmaxf(r.mxz, q.mxz);
+    }
+    float4 c = d.centroid[pv][(size_t)s * d.Kcap + k];
+    xform(m, c.x, c.y, c.z);
+    d.xcent[(size_t)s * d.Kcap + k] = c;     // ca's own centroids stay as they are: the tail stage of frame k−1 may still be reading them
+    d.xamin[(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
+    d.xamax[(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
+    d.pair_of_prev[(size_t)s * d.Kcap + k] = -1;
+  }
 }
 
 // ------------------------------------------------------------------------------------ P2: centroid correspondence (:285-307)
 // dir 0: nearest current centroid of every previous centroid; dir 1: the reverse.  Squared fp32
 // distance, ties → lowest index (ascending scan with strict <).
-__global__ __launch_bounds__(MOR_BT) void k_nn_centroid(MorDev d) {
-  const int dir = blockIdx.z;   // both directions in one launch
-  int s = blockIdx.y + d.s0;
-  int Ksrc = dir == 0 ? d.slot_kc[d.prev][s].x : d.info[s].K, Kdst = dir == 0 ? d.info[s].K : d.slot_kc[d.prev][s].x;
-  if (blockIdx.x * MOR_BT >= Ksrc) return;
+__device__ __forceinline__ void nn_centroid_body(const MorDev &d, int s, int dir, float4 *tile) {
+  const int Kp = d.slot_kc[d.prev][s].x, Kc = d.info[s].K;
+  const int Ksrc = dir == 0 ? Kp : Kc, Kdst = dir == 0 ? Kc : Kp;
   const float4 *cp = d.xcent + (size_t)s * d.Kcap, *cc = d.centroid[d.cur] + (size_t)s * d.Kcap;
   const float4 *src = dir == 0 ? cp : cc, *dst = dir == 0 ? cc : cp;
-  int i = blockIdx.x * MOR_BT + threadIdx.x;
-  float4 q = i < Ksrc ? src[i] : make_float4(0, 0, 0, 0);
-  __shared__ float4 tile[MOR_BT];
-  float best = INFINITY; int bi = -1;
-  for (int b = 0; b < Kdst; b += MOR_BT) {
-    if (b + threadIdx.x < Kdst) tile[threadIdx.x] = dst[b + threadIdx.x];
-    __syncthreads();
-    int lim = min(MOR_BT, Kdst - b);
-    for (int u = 0; u < lim; ++u) { float dd = sqdist(q.x, q.y, q.z, tile[u].x, tile[u].y, tile[u].z); if (dd < best) { best = dd; bi = b + u; } }
-    __syncthreads();
-  }
-  if (i < Ksrc) {
-    if (dir == 0) { d.nn_fwd[(size_t)s * d.Kcap + i] = bi; d.nn_fwd_d[(size_t)s * d.Kcap + i] = best; }
-    else { d.nn_bwd[(size_t)s * d.Kcap + i] = bi; d.pair_of_cur[(size_t)s * d.Kcap + i] = -1; }
+  for (int i0 = 0; i0 < Ksrc; i0 += MOR_BT) {
+    const int i = i0 + threadIdx.x;
+    const float4 q = i < Ksrc ? src[i] : make_float4(0, 0, 0, 0);
+    float best = INFINITY; int bi = -1;
+    for (int b = 0; b < Kdst; b += MOR_BT) {
+      __syncthreads();
+      if (b + threadIdx.x < Kdst) tile[threadIdx.x] = dst[b + threadIdx.x];
+      __syncthreads();
+      const int lim = min(MOR_BT, Kdst - b);
+      for (int u = 0; u < lim; ++u) { const float dd = sqdist(q.x, q.y, q.z, tile[u].x, tile[u].y, tile[u].z); if (dd < best) { best = dd; bi = b + u; } }
+    }
+    if (i < Ksrc) {
+      if (dir == 0) { d.nn_fwd[(size_t)s * d.Kcap + i] = bi; d.nn_fwd_d[(size_t)s * d.Kcap + i] = best; }
+      else d.nn_bwd[(size_t)s * d.Kcap + i] = bi;
+    }
   }
 }
 // reciprocal test + volumeConstraint (:264-283), correspondences emitted in source-index order
-__global__ __launch_bounds__(MOR_BT) void k_pairs(MorDev d) {
-  int s = blockIdx.x + d.s0, Kp = d.slot_kc[d.prev][s].x, Kc = d.info[s].K;
-  __shared__ int sh[8]; int carry = 0;
+__device__ __forceinline__ void pairs_body(const MorDev &d, int s, int *sh) {
+  const int Kp = d.slot_kc[d.prev][s].x, Kc = d.info[s].K;
+  int carry = 0;
   const size_t ko = (size_t)s * d.Kcap;
   for (int b = 0; b < Kp; b += MOR_BT) {
     int i = b + threadIdx.x, ok = 0, j = -1;
@@ -1590,6 +1592,24 @@ __global__ __launch_bounds__(MOR_BT) void k_pairs(MorDev d) {
     carry += tot;
   }
   if (threadIdx.x == 0) { d.info[s].n_pairs = carry; d.wl_n[s] = 0; d.wlb_n[s] = 0; d.wl2_n[s] = 0; }
+}
+// One workgroup per stream: everything per CLUSTER between the point kernels — centroids and boxes of cb (from k_stats'
+// partials), boxes and centroids of the transformed ca (from k_xform_prev's), both nearest-centroid directions, the
+// correspondences.  (Four launches of a few dozen threads' work each before.)
+__global__ __launch_bounds__(MOR_BT) void k_cluster_pairs(MorDev d) {
+  const int s = blockIdx.x + d.s0;
+  __shared__ float4 tile[MOR_BT];
+  __shared__ int sh[8];
+  stats_fin_body(d, s);
+  if (!d.has_prev) return;
+  xform_fin_body(d, s);
+  __threadfence_block();
+  __syncthreads();
+  nn_centroid_body(d, s, 0, tile);
+  nn_centroid_body(d, s, 1, tile);
+  __threadfence_block();
+  __syncthreads();
+  pairs_body(d, s, sh);
 }
 
 #define MOR_SCORE_G 64    // workgroups per stream of the worklist tiers
@@ -1671,19 +1691,23 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
     const int j = base + threadIdx.x;
     bool nearq = false, blockq = false, big = false, counted = false; float best = INFINITY; int pr = -1, target = -1;
     if (j < Cp) {
-      pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
+      // two chains of dependent loads, issued side by side (no branch between them): cluster → pair → matched cluster → its box,
+      // and point → cell → hash probe → cell record → points.  (One after the other they were seven levels deep.)
+      const int cidj = d.cl_cid[pv][so + j];
+      const float4 q = d.cl_pts[pv][so + j];
+      const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
+      const int key = cell_key(d.g, cx, cy, cz);
+      const unsigned sl = hash_slot(max(key, 0), hshift);
+      const unsigned long long ent = tab[sl];
+      pr = d.pair_of_prev[ko + cidj];
+      const int c = key >= 0 ? hash_resolve(tab, hshift, key, sl, ent) : -1;
+      const int cc = max(c, 0), cid = d.ccid[so + cc], b0 = st[cc], e0 = st[cc + 1];
+      target = min(max(d.pair_m[ko + max(pr, 0)], 0), d.Kcap - 1);   // (pr < 0: a stale entry, clamped — its box is loaded but not used)
+      const float4 tlo = d.amin[d.cur][ko + target], thi = d.amax[d.cur][ko + target];
       if (pr >= 0) {
-        target = d.pair_m[ko + pr];
-        const float4 q = d.cl_pts[pv][so + j];
-        const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
         int budget = 64;   // a big own cell that shows no close point within its first 64 goes to the wave tier
-        const int key = cell_key(d.g, cx, cy, cz);
-        const int c = key >= 0 ? hash_find(tab, hshift, key) : -1;
-        const bool reach = box_dist2(q, d.amin[d.cur][ko + target], d.amax[d.cur][ko + target]) < d.pde_ub;   // farther than √ub from the whole matched cluster: never counted
-        if (reach && c >= 0) {
-          const int cid = d.ccid[so + c], b0 = st[c], e0 = st[c + 1];   // one level of independent loads
-          if (cid == target) { scan4s(sp, b0, e0, q, lbn, best, budget); big = best > d.pde_lb && e0 - b0 > 64; }
-        }
+        const bool reach = box_dist2(q, tlo, thi) < d.pde_ub;   // farther than √ub from the whole matched cluster: never counted
+        if (reach && c >= 0 && cid == target) { scan4s(sp, b0, e0, q, lbn, best, budget); big = best > d.pde_lb && e0 - b0 > 64; }
         if (reach && best > d.pde_lb && !big) {
           if (!e1_local) big = true;   // √lb reaches beyond the adjacent half-cells in this configuration: wave tier
           else if (best < d.pde_ub) {
@@ -1692,7 +1716,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
             else nearq = true;
           } else blockq = true;
         }
-      }
+      } else target = -1;
     }
     count_push(counted, d.pair_cnt + ko, pr);
     wl_push(nearq, &d.wl_n[s], d.wl + so, j, pr, target);
@@ -2004,13 +2028,14 @@ __global__ __launch_bounds__(MOR_BT) void k_vox_probe(MorDev d) {
 // ------------------------------------------------------------------------------------ P5 + summary to the host
 // scores → detection_results (:580-606); then everything the host tracker needs goes straight
 // into pinned host memory (a few KB per stream), so the push needs exactly one stream sync.
-__global__ __launch_bounds__(MOR_BT) void k_decide(MorDev d) {
-  int s = blockIdx.x + d.s0, pv = d.prev;
+// (runs at the head of k_track_push: one workgroup per stream, NT threads)
+template <int NT> __device__ __forceinline__ void decide_body(const MorDev &d, int s) {
+  const int pv = d.prev;
   const size_t ko = (size_t)s * d.Kcap;
   MorFrameInfo f = d.info[s];
   int np = d.has_prev ? (int)f.n_pairs : 0;
   const int *offc = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1), *offp = d.cl_off[pv] + (size_t)s * (d.Kcap + 1);
-  for (int pr = threadIdx.x; pr < np; pr += MOR_BT) {
+  for (int pr = threadIdx.x; pr < np; pr += NT) {
     int q = d.pair_q[ko + pr], m = d.pair_m[ko + pr];
     unsigned long long n1 = (unsigned long long)(offp[q + 1] - offp[q]), n2 = (unsigned long long)(offc[m + 1] - offc[m]);
     double cnt = (double)d.pair_cnt[ko + pr], score, thr;
@@ -2022,8 +2047,8 @@ __global__ __launch_bounds__(MOR_BT) void k_decide(MorDev d) {
   }
   __syncthreads();
   int K = (int)f.K;
-  for (int k = threadIdx.x; k < K; k += MOR_BT) { d.h_centroid[ko + k] = d.centroid[d.cur][ko + k]; d.h_det[ko + k] = d.det[ko + k]; }
-  for (int k = threadIdx.x; k <= K; k += MOR_BT) d.h_cl_off[(size_t)s * (d.Kcap + 1) + k] = offc[k];
+  for (int k = threadIdx.x; k < K; k += NT) { d.h_centroid[ko + k] = d.centroid[d.cur][ko + k]; d.h_det[ko + k] = d.det[ko + k]; }
+  for (int k = threadIdx.x; k <= K; k += NT) d.h_cl_off[(size_t)s * (d.Kcap + 1) + k] = offc[k];
   if (threadIdx.x == 0) {
     f.n_pairs = np; f.n_defer = (d.has_prev && d.method == 1) ? (uint32_t)d.wl2_n[s] : 0u; f.pad0 = (d.has_prev && d.method == 1) ? (uint32_t)(d.wl_n[s] + d.wlb_n[s]) : 0u;
     f.Kprev = d.has_prev ? d.slot_kc[d.prev][s].x : 0; f.Cprev = d.has_prev ? d.slot_kc[d.prev][s].y : 0;   // for the host mirror
@@ -2035,8 +2060,8 @@ __global__ __launch_bounds__(MOR_BT) void k_decide(MorDev d) {
     if (threadIdx.x == 0) { l_sum[0] = 0; l_sum[1] = 0; }
     __syncthreads();
     unsigned cs = 0, ds = 0;
-    for (int pr = threadIdx.x; pr < np; pr += MOR_BT) cs += (unsigned)d.pair_cnt[ko + pr] * (unsigned)(2 * pr + 1) + (unsigned)d.pair_m[ko + pr];
-    for (int k = threadIdx.x; k < K; k += MOR_BT) ds += d.det[ko + k] ? (unsigned)(k + 1) : 0u;
+    for (int pr = threadIdx.x; pr < np; pr += NT) cs += (unsigned)d.pair_cnt[ko + pr] * (unsigned)(2 * pr + 1) + (unsigned)d.pair_m[ko + pr];
+    for (int k = threadIdx.x; k < K; k += NT) ds += d.det[ko + k] ? (unsigned)(k + 1) : 0u;
     atomicAdd(&l_sum[0], cs); atomicAdd(&l_sum[1], ds);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -2410,7 +2435,11 @@ __device__ __forceinline__ void tr_store_state(MorTrackDev &g, const MorTrackDev
 }
 // checkMovingClusterChain (:478-514) with recurseFindClusterChain (:415-453) and pushCentroid (:455-476)
 __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
-  const int s = blockIdx.x + d.s0, K = d.info[s].K, np = d.has_prev ? (int)d.info[s].n_pairs : -1, lane = threadIdx.x;
+  const int s = blockIdx.x + d.s0, lane = threadIdx.x;
+  decide_body<64>(d, s);   // P5: thresholds, detection_results, host summary
+  __threadfence_block();
+  __syncthreads();
+  const int K = d.info[s].K, np = d.has_prev ? (int)d.info[s].n_pairs : -1;
   const size_t ko = (size_t)s * d.Kcap;
   __shared__ MorTrackDev t;
   __shared__ int2 l_corr[MOR_TR_NB][TRK];
@@ -2649,15 +2678,12 @@ static void mor_launch_clusters(const MorDev &d, hipStream_t st, MorLaunchTimer 
     MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
   }
   MOR_LAUNCH(MK_STATS, k_stats, dim3(64, d.B), d);
-  MOR_LAUNCH(MK_STATS_FIN, k_stats_fin, gKt, d);
 }
 static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // transform of ca, correspondences, first tiers of the scores
   const dim3 gT(d.B * d.tiles), gB(d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B);
+  if (d.has_prev) MOR_LAUNCH(MK_XFORM_PREV, k_xform_prev, dim3(64, d.B), d);
+  MOR_LAUNCH(MK_PAIRS, k_cluster_pairs, gB, d);
   if (d.has_prev) {
-    MOR_LAUNCH(MK_XFORM_PREV, k_xform_prev, dim3(64, d.B), d);
-    MOR_LAUNCH(MK_XFORM_FIN, k_xform_fin, gKt, d);
-    MOR_LAUNCH(MK_NN, k_nn_centroid, dim3(gKt.x, gKt.y, 2), d);
-    MOR_LAUNCH(MK_PAIRS, k_pairs, gB, d);
     if (d.method == 1) {
       if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * 8), d); MOR_LAUNCH(MK_SCORE_NEAR, k_score_near, dim3(MOR_SCORE_G * d.B), d); }
     } else if (d.method == 2) {
@@ -2676,7 +2702,6 @@ static void mor_launch_scores2(const MorDev &d, hipStream_t st, MorLaunchTimer *
 }
 static void mor_launch_decide(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gB(d.B);
-  MOR_LAUNCH(MK_DECIDE, k_decide, gB, d);
   mor_timer_begin(tm, MK_TRACK_PUSH, st);
   hipLaunchKernelGGL(k_track_push, gB, dim3(64), 0, st, d);
   mor_timer_end(tm, MK_TRACK_PUSH, st);

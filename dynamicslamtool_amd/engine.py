@@ -19,7 +19,7 @@ EXPORTS = [
     "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_get_stage_counts", "mor_device_alloc", "mor_device_free", "mor_host_alloc", "mor_host_free",
     "mor_device_upload", "mor_device_download", "mor_device_synchronize", "mor_device_count", "mor_get_last_timing",
     "mor_kernel_timing_enable", "mor_kernel_timing_read", "mor_tracker_create", "mor_tracker_destroy", "mor_tracker_push",
-    "mor_tracker_filter", "mor_tracker_get", "mor_get_frame_log", "mor_debug_read", "mor_debug_config", "mor_get_markers",
+    "mor_tracker_filter", "mor_tracker_get", "mor_get_frame_log", "mor_debug_read", "mor_debug_config", "mor_get_markers", "mor_kernel_timeline_read",
 ]
 
 
@@ -365,6 +365,16 @@ class MorBatch:
         n = lib().mor_kernel_timing_read(self._h, 1 if reset else 0, names, 2048, ms, ln, 64)
         nm = names.value.decode().split(",")
         return {nm[i]: (float(ms[i]), int(ln[i])) for i in range(n)}
+
+    def kernel_timeline(self, max_n=200000):
+        """[(kernel name, start ms, end ms)] of the last timed leg (call after kernel_timing())."""
+        names = C.create_string_buffer(2048)
+        lib().mor_kernel_timing_read(self._h, 0, names, 2048, None, None, 64)
+        nm = names.value.decode().split(",")
+        ids, t0, t1 = (C.c_int * max_n)(), (C.c_float * max_n)(), (C.c_float * max_n)()
+        lib().mor_kernel_timeline_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        n = lib().mor_kernel_timeline_read(self._h, ids, t0, t1, max_n)
+        return [(nm[ids[i]], float(t0[i]), float(t1[i])) for i in range(n)]
 
     def synchronize(self):
         _check(lib().mor_device_synchronize(self.device))

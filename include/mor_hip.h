@@ -170,6 +170,8 @@ int mor_device_count(void);
 int mor_get_last_timing(const mor_batch *b, float *push_ms, float *filter_ms);
 int mor_kernel_timing_enable(mor_batch *b, int enable);
 int mor_kernel_timing_read(mor_batch *b, int reset, char *names, size_t names_cap, float *ms_total, uint32_t *launches, int max_kernels);
+/* the launches of the last timed leg as (index into the names of mor_kernel_timing_read, start ms, end ms) on one clock */
+int mor_kernel_timeline_read(mor_batch *b, int *ids, float *t0_ms, float *t1_ms, int max_n);
 
 /* ---- the temporal logic alone as host C++ (T1/F1 state machine, the same rules as the device kernels; lets CPU-only
  * tests drive it) ---- */
