@@ -88,6 +88,8 @@ struct MorDev {
   int tiles;                 // ceil(max n_points of this batch / MOR_TILE)
   int tiles_m;               // workgroups per stream for kernels over the non-ground cloud / clusters: an estimate from the
                              // previous frame; those kernels grid-stride over the tiles a stream really has, so any value ≥ 1 is correct
+  int g_fast, g_score, g_pde, g_box;   // launch widths: k_score_fast workgroups per cloud tile, workgroups per stream of the worklist tiers / the wave tier / k_cellboxes (MOR_TUNE)
+  int xcd_map;               // 1: the workgroups of a stream share an XCD (its tables stay in that L2); 0: streams spread over all XCDs
   int split_variant;         // experiment bits of k_split: 1 = poll the look-back descriptors with agent-scope loads instead of read-modify-write atomics
   int two_pass_split;        // development switch: count pass + scatter pass instead of the single-pass split
   int fuse_scans;            // tile-count scans re-derived inside the consuming kernels instead of one-workgroup scan launches (tables of ≤ 2048 tiles)

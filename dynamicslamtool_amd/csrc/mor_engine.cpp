@@ -172,6 +172,9 @@ static int configure(mor_batch *b) {
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
   d.fuse_scans = getenv("MOR_NO_FUSE") ? 0 : 1;   // refined per push (tile count)
   d.two_pass_split = getenv("MOR_SINGLE_PASS_SPLIT") ? 0 : 1;   // count pass + scatter pass (the second read comes from the Infinity Cache); the single-pass split with decoupled look-back measured 5 % slower in the pipeline
+  d.xcd_map = getenv("MOR_NO_XCD_MAP") ? 0 : 1;
+  d.g_fast = 8; d.g_score = 64; d.g_pde = 256; d.g_box = 32;
+  if (const char *tn = getenv("MOR_TUNE")) { int a, b2, c, e; if (sscanf(tn, "%d,%d,%d,%d", &a, &b2, &c, &e) == 4 && a > 0 && b2 > 0 && c > 0 && e > 0) { d.g_fast = a; d.g_score = b2; d.g_pde = c; d.g_box = e; } }
   d.split_variant = getenv("MOR_SPLIT_VARIANT") ? atoi(getenv("MOR_SPLIT_VARIANT")) : 0;
   d.use_hash = d.method == 1;
   { size_t hc = 1024; while (hc < 4 * (size_t)d.Nmax) hc <<= 1; d.Hcell = (int)hc; }

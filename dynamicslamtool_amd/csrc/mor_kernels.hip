@@ -55,13 +55,13 @@ __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << la
 
 // (stream, tile) of this workgroup.  With B a multiple of 8, all tiles of stream s run on the
 // XCD group s % 8 (workgroups are dealt round-robin over the 8 XCDs): L2 locality only.
-__device__ __forceinline__ void map_block_local(int B, int tiles, int &s, int &t) {
+__device__ __forceinline__ void map_block_local(int B, int tiles, int &s, int &t, int xcd) {
   int L = blockIdx.x;
-  if ((B & 7) == 0) { int x = L & 7, r = L >> 3; s = (r / tiles) * 8 + x; t = r % tiles; }
+  if ((B & 7) == 0 && xcd) { int x = L & 7, r = L >> 3; s = (r / tiles) * 8 + x; t = r % tiles; }
   else { s = L / tiles; t = L % tiles; }
 }
 // d.B streams of this launch start at stream d.s0 of the batch (stream groups run on their own HIP streams)
-#define map_block(B_, tiles_, s_, t_) do { map_block_local((B_), (tiles_), (s_), (t_)); (s_) += d.s0; } while (0)
+#define map_block(B_, tiles_, s_, t_) do { map_block_local((B_), (tiles_), (s_), (t_), d.xcd_map); (s_) += d.s0; } while (0)
 
 __device__ __forceinline__ int wave_incl_scan(int v) {
 #pragma unroll
@@ -889,7 +889,7 @@ __device__ __forceinline__ int cg_lower_bound8(const int *key, int lo, int n, in
 // cells hold a handful of points), four cells per wave-iteration.  (Used to be the first phase of k_cellgraph, where
 // one workgroup per stream walked its cells alone.)
 __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
-  int s, bx; map_block(d.B, MOR_BOX_G, s, bx);
+  int s, bx; map_block(d.B, d.g_box, s, bx);
   RS_T(tb0);
   const int nocc = d.info[s].n_occ, sub = lane_id() & 15, grp = lane_id() >> 4;
   const size_t so = (size_t)s * d.Nmax;
@@ -899,14 +899,14 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
   if (d.use_hash && d.grid_mode == 0) {   // cell hash: (key+1, compact id); the table was cleared by k_heads_scatter
     unsigned long long *tab = d.chash + (size_t)s * d.Hcell; const int *ckey = d.ckey + so;
     const unsigned hshift = d.info[s].hshift, hmask = (1u << (32 - hshift)) - 1u;
-    for (int c = bx * MOR_BT + threadIdx.x; c < nocc; c += MOR_BOX_G * MOR_BT) {
+    for (int c = bx * MOR_BT + threadIdx.x; c < nocc; c += d.g_box * MOR_BT) {
       const int key = ckey[c]; unsigned sl = hash_slot(key, hshift);
       const unsigned long long ent = ((unsigned long long)((unsigned)key + 1u) << 32) | (unsigned)c;
       while (atomicCAS(&tab[sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
     }
   }
   // four cells per 16-lane group and pass: their ranges, then their first 32 points each, as two batches of independent loads
-  for (int c0 = ((bx * (MOR_BT / 64) + wave_id()) * 4 + grp) * 4; c0 < nocc; c0 += MOR_BOX_G * (MOR_BT / 64) * 16) {
+  for (int c0 = ((bx * (MOR_BT / 64) + wave_id()) * 4 + grp) * 4; c0 < nocc; c0 += d.g_box * (MOR_BT / 64) * 16) {
     int b[4], e[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int c = min(c0 + u, nocc - 1); b[u] = start[c]; e[u] = start[c + 1]; }
@@ -1678,7 +1678,7 @@ __device__ __forceinline__ void count_push(bool want, int *cnt, int pr) {
 // compacted into worklists so the next tiers run full waves of like queries: `wl` front = E2 known (a matched point of
 // the own cell closer than √ub), `wl` back = own cell without a matched point, `wl2` = big own cell (wave tier).
 __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
-  int s, t0; map_block(d.B, d.tiles_m * 8, s, t0);
+  int s, t0; map_block(d.B, d.tiles_m * d.g_fast, s, t0);
   const int pv = d.prev, Cp = d.slot_kc[d.prev][s].y;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
@@ -1687,7 +1687,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
   const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + d.g.cs * 1e-3f;
   const bool e1_local = 2.f * slb < d.g.cs;
-  for (int base = t0 * MOR_BT; base < Cp; base += d.tiles_m * 8 * MOR_BT) {
+  for (int base = t0 * MOR_BT; base < Cp; base += d.tiles_m * d.g_fast * MOR_BT) {
     const int j = base + threadIdx.x;
     bool nearq = false, blockq = false, big = false, counted = false; float best = INFINITY; int pr = -1, target = -1;
     if (j < Cp) {
@@ -1743,7 +1743,7 @@ __device__ __forceinline__ void scan_batch4(const MorDev &d, size_t so, const in
 // is close to can hold a point within √lb (the own cell was scanned by tier 1).  Three levels of loads: hash probes →
 // box records + ranges → points.  No such point ⇒ counted.
 __global__ __launch_bounds__(MOR_BT) void k_score_near(MorDev d) {
-  int s, bx; map_block(d.B, MOR_SCORE_G, s, bx);   // a stream's workgroups share an XCD (its cell tables stay in that L2)
+  int s, bx; map_block(d.B, d.g_score, s, bx);   // a stream's workgroups share an XCD (its cell tables stay in that L2)
   const int pv = d.prev, nq = d.wl_n[s];
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
@@ -1751,7 +1751,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_near(MorDev d) {
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + d.g.cs * 1e-3f;
-  for (int w0 = bx * MOR_BT; w0 < nq; w0 += MOR_SCORE_G * MOR_BT) {
+  for (int w0 = bx * MOR_BT; w0 < nq; w0 += d.g_score * MOR_BT) {
     const int w = w0 + threadIdx.x;
     bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
     if (w < nq) {
@@ -1785,7 +1785,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_near(MorDev d) {
 // 3×3×3 block: hash probes → cluster ids → up to 8 matched cells (those that can hold a point within √lb first) →
 // box records + ranges → points.  E2 hit ⇒ E1 is decided by the same cells; no hit ⇒ the wider stencil is the wave tier's job.
 __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
-  int s, bx; map_block(d.B, MOR_SCORE_G, s, bx);
+  int s, bx; map_block(d.B, d.g_score, s, bx);
   const int pv = d.prev, nq = d.wlb_n[s];
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
@@ -1795,7 +1795,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
   const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + d.g.cs * 1e-3f;
   const bool stencil27 = d.n_rows <= 9 && d.score_R <= 1;   // the whole search stencil is the 3×3×3 block
-  for (int w0 = bx * MOR_BT; w0 < nq; w0 += MOR_SCORE_G * MOR_BT) {
+  for (int w0 = bx * MOR_BT; w0 < nq; w0 += d.g_score * MOR_BT) {
     const int w = w0 + threadIdx.x;
     bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
     if (w < nq) {
@@ -1874,7 +1874,7 @@ __device__ __forceinline__ float wave_scan_cell(const float4 *sp, int b0, int e0
 __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
   const int s = blockIdx.y + d.s0, bx = blockIdx.x;   // a stream's waves spread over all XCDs: the deferred queries are few and uneven across streams
   const int pv = d.prev, nq = d.wl2_n[s];
-  const int wv = bx * (MOR_BT / 64) + wave_id(), nw = MOR_PDE_G * (MOR_BT / 64), lane = lane_id();
+  const int wv = bx * (MOR_BT / 64) + wave_id(), nw = d.g_pde * (MOR_BT / 64), lane = lane_id();
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
@@ -2626,7 +2626,7 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
   }
 }
 static void mor_launch_boxes(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  MOR_LAUNCH(MK_CELLBOXES, k_cellboxes, dim3(MOR_BOX_G * d.B), d);   // point boxes, smallest index, slabs (+ cell hash on the sort path)
+  MOR_LAUNCH(MK_CELLBOXES, k_cellboxes, dim3(d.g_box * d.B), d);   // point boxes, smallest index, slabs (+ cell hash on the sort path)
 }
 
 static void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
@@ -2685,7 +2685,7 @@ static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
   MOR_LAUNCH(MK_PAIRS, k_cluster_pairs, gB, d);
   if (d.has_prev) {
     if (d.method == 1) {
-      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * 8), d); MOR_LAUNCH(MK_SCORE_NEAR, k_score_near, dim3(MOR_SCORE_G * d.B), d); }
+      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * d.g_fast), d); MOR_LAUNCH(MK_SCORE_NEAR, k_score_near, dim3(d.g_score * d.B), d); }
     } else if (d.method == 2) {
       MOR_LAUNCH(MK_VOX_CLEAR, k_vox_clear, dim3(64, d.B), d);
       MOR_LAUNCH(MK_VOX_INSERT, k_vox_insert, gT, d);
@@ -2696,8 +2696,8 @@ static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
 
 static void mor_launch_scores2(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   if (d.has_prev && d.method == 1 && d.pde_ub > 0.f && d.pde_ub > d.pde_lb) {
-    MOR_LAUNCH(MK_SCORE_BLOCK, k_score_block, dim3(MOR_SCORE_G * d.B), d);
-    MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(MOR_PDE_G, d.B), d);
+    MOR_LAUNCH(MK_SCORE_BLOCK, k_score_block, dim3(d.g_score * d.B), d);
+    MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(d.g_pde, d.B), d);
   }
 }
 static void mor_launch_decide(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {

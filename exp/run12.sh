@@ -1,8 +1,8 @@
 #!/bin/bash
 set -u
-O=gpurun_out/r2c14; mkdir -p $O
+O=gpurun_out/r2c15; mkdir -p $O
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -q -x -k "hdl64 or small_streams or bound_variants or sweep" 2>&1 | tail -3
+timeout 900 python -m pytest tests -m gpu -q -x  2>&1 | tail -3
 for i in 1 2; do timeout 600 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-extras > $O/bench$i.json 2> $O/bench$i.err; python - <<PY
 import json
 d=json.loads(open("$O/bench$i.json").read().strip().splitlines()[-1])
