@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-O=gpurun_out/r2c9; mkdir -p $O
+O=gpurun_out/r2c18; mkdir -p $O
 export TMPDIR=/tmp
 echo skip pytest
 echo "== bench full default"; SECONDS=0; timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo rc=$? wall=${SECONDS}s
