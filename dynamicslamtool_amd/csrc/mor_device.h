@@ -138,7 +138,12 @@ struct MorDev {
   int *cmin;                 // [B][Nmax]  smallest cloud index in the cell
   float4 *cmeta;             // [B][2·Nmax]  per occupied cell: low corner of its point box (.w = cluster id bits), high corner
   float4 *crep;              // [B][Nmax]  per occupied cell: its first point (sample for the quick edge test of the cell graph)
-  float4 *sorted;            // [B][Nmax]  (x,y,z, bits(cloud index)) in cell order; .w becomes the cluster id after labelling
+  float4 *sorted;            // [B][Nmax]  (x,y,z, bits(cloud index)) in cell order
+  int *scell;                // [B][Nmax]  compact cell id per position of `sorted`
+  struct MorCellSum *csum;   // [B][Nmax]  per occupied cell: exact fixed-point coordinate sums of its points (cluster centroids are sums over cells)
+  int4 *cgat;                // [B][Nmax]  per occupied cell, written by k_cg_final: (first slot in cl_pts − first position in `sorted`, cluster id or −1, cloud index of the cluster's first point if it lies in this cell else −1, –)
+  int *clist;                // [B][Nmax]  occupied cells grouped by cluster (any order inside a cluster)
+  int *cl_coff;              // [B][Kcap+1]  first entry of each cluster in clist
   int *parent;               // [B][Nmax]  union-find forest over occupied cells (parent ≤ child)
   int *cg_ovf;               // [B][2][MOR_CG_OVF][2]  k_cellgraph: candidate cell pairs beyond its LDS list; undecided big cell pairs
   int *croot;                // [B][Nmax]  flattened root per cell
@@ -150,19 +155,20 @@ struct MorDev {
   int *ktile_cnt;            // [B][tiles_max]
   int *kcell, *kroot, *ksize; // [B][Kcap]  kept components: root cell, smallest cloud index, size
   int *csz;                  // [B][Kcap]  sizes in final cluster order
+  int *krank_inv;            // [B][Kcap]  final cluster id → entry of the kept-component list
   int *rkeys[2], *rvals[2];  // [B][Nmax]  radix ping-pong of the cell sort (grid stage)
   int *rhist;                // [B][tiles_max][256]
-  int *rkeys2[2], *rvals2[2], *rhist2; // the same for the cluster partition (cluster stage runs beside the next frame's grid stage)
-  int *cl_idx;               // [B][Nmax]  cluster_indices flattened (:218)
   // frame-slotted (cb / ca)
-  float4 *cl_pts[MOR_MAX_SLOTS];         // [B][Nmax]  clusters[k] points, (cluster, index) order (:229); ca's are transformed in place (:550)
+  float4 *cl_pts[MOR_MAX_SLOTS];         // [B][Nmax]  clusters[k] points (:229), cluster after cluster, cell by cell inside a cluster (.w = bits of the cloud index); ca's are transformed in place (:550)
   int *cl_cid[MOR_MAX_SLOTS];            // [B][Nmax]  cluster id per cl_pts entry
   int *cl_off[MOR_MAX_SLOTS];            // [B][Kcap+1]
   int *chunk_off[MOR_MAX_SLOTS];         // [B][Kcap+1]  first reduction chunk of each cluster
-  Red6 *part, *part_back; int Wcap; // [B][Wcap]  per-chunk partials: scratch of k_stats (front stage) / k_xform_prev (pair stage)
+  Red6 *part_back; int Wcap; // [B][Wcap]  per-chunk partials of k_xform_prev (pair stage)
   float4 *centroid[MOR_MAX_SLOTS];       // [B][Kcap]  centroid_collection (:243)
   float4 *amin[MOR_MAX_SLOTS], *amax[MOR_MAX_SLOTS]; // [B][Kcap]  cluster AABBs (getMinMax3D, :272-274)
   float4 *xcent, *xamin, *xamax; // [B][Kcap]  ca's centroids and AABBs after the transform into cb's frame (:540-550)
+  float4 *cl_first[MOR_MAX_SLOTS];       // [B][Kcap]  the point with the smallest cloud index of every cluster (clusters[k][0], the octree anchor of method 2)
+  float4 *xfirst;                        // [B][Kcap]  ca's first points after the transform
   // pair stage
   int *nn_fwd, *nn_bwd;      // [B][Kcap]
   float *nn_fwd_d;           // [B][Kcap]
@@ -197,12 +203,16 @@ struct MorDev {
   int *h_noff;               // [B]  first slot of the filtered cloud in the stream's `ground` buffer (Nmax − n_keep)
 };
 
+// Σ of the coordinates of a set of points as exact integers: x = a·2^-24 + b·2^-64 with a = ⌊x·2^24⌋ (|a| < 2^39 for |x| < 32 km)
+// and 0 ≤ b < 2^40, summed separately in 64-bit integers (no carries needed up to 2^20 points).  Integer sums commute, so
+// a centroid does not depend on the order in which cells, waves or atomics deliver the points.
+struct MorCellSum { long long a[3], b[3]; };
 // kernel ids for optional per-kernel event timing
 enum MorKernelId {
   MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_SPLIT, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_HASH_CLEAR, MK_CELLBOXES, MK_CELLGRAPH,
   MK_LABEL, MK_RHIST, MK_RSCAN, MK_RSCATTER,
   MK_STATS, MK_STATS_FIN, MK_XFORM_PREV, MK_XFORM_FIN, MK_NN, MK_PAIRS, MK_SCORE_FAST, MK_SCORE_NEAR, MK_SCORE_BLOCK, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
-  MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_G2_CENTROID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_GRIDHASH, MK_GRIDFILL, MK_CG_SLAB, MK_CG_FINAL, MK_COUNT
+  MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_G2_CENTROID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_GRIDHASH, MK_GRIDFILL, MK_CG_SLAB, MK_CG_FINAL, MK_CLUSTERS, MK_COUNT
 };
 extern const char *const mor_kernel_names[MK_COUNT];
 

@@ -76,6 +76,16 @@ struct mor_batch {
   // `sc`, cluster extraction + pair stage on `sm`, wave-tier scores + tracking + filterCloud on `sb`.
   hipStream_t sf = nullptr, sc = nullptr, sm = nullptr, sb = nullptr;   // grid, cell graph, mid (clusters + pair stage), tail (scores wave tier, tracking, filterCloud)
   hipEvent_t ev_piece[MOR_N_PIECES][MOR_MAX_SLOTS] = {}, ev_back[MOR_MAX_SLOTS] = {};
+  // Default schedule ("lanes"): frame k runs ALL its pieces, then its filterCloud, on stream k % n_lanes, so every stream
+  // carries the same work whatever the pieces cost; piece p of frame k waits for piece p of frame k−1 (which keeps every
+  // guarantee of the stage schedule: scratch arrays of a piece are never used by two frames at once, the pair stage of
+  // frame k sees frame k−1's clusters), and the tracking steps (last piece, filterCloud) wait for the previous tracking step.
+  // (The stage schedule — pieces on fixed streams — made the stream with the scoring tiers + tracking + filterCloud the
+  // bottleneck: its kernels add up to 0.44 ms of a 0.45 ms period while the cell-graph stream idled half the time.)
+  bool lanes = true; int n_lanes = 4;
+  hipEvent_t ev_track[MOR_MAX_SLOTS] = {};      // recorded after the tracking step of a push / a filterCloud
+  hipEvent_t *last_track = nullptr;             // the latest of them
+  hipStream_t last_filter_stream = nullptr;
   int stage_of[MOR_N_PIECES] = {0, 0, 1, 2, 2, 3, 3};   // stage stream of every launch piece (mor_device.h); the last piece and filterCloud run on stage 3
   MorDev dtemp[MOR_MAX_DEPTH];               // descriptor templates, frame k uses dtemp[k % depth] (static part + pointers)
   MorDev d;                                  // descriptor of the latest pushed frame
@@ -236,6 +246,7 @@ void mor_batch_destroy(mor_batch *b) {
   for (auto &ev : b->args_ev) if (ev) hipEventDestroy(ev);
   for (auto &pe : b->ev_piece) for (auto &ev : pe) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->ev_back) if (ev) hipEventDestroy(ev);
+  for (auto &ev : b->ev_track) if (ev) hipEventDestroy(ev);
   if (b->sf) hipStreamDestroy(b->sf);
   if (b->sc) hipStreamDestroy(b->sc);
   if (b->sm) hipStreamDestroy(b->sm);
@@ -276,6 +287,10 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (hipStreamCreateWithFlags(&b->sf, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sc, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sm, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sb, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
   for (auto &pe : b->ev_piece) for (auto &ev : pe) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_back) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+  for (auto &ev : b->ev_track) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+  if (getenv("MOR_SCHED") && !strcmp(getenv("MOR_SCHED"), "stages")) b->lanes = false;
+  b->n_lanes = (int)std::min<uint64_t>(4, b->pipe_depth);
+  if (getenv("MOR_LANES")) b->n_lanes = std::max(1, std::min(b->n_lanes, atoi(getenv("MOR_LANES"))));
   MorDev &d = b->d; const size_t B = d.B, N = d.Nmax, K = d.Kcap, T = d.tiles_max;
   bool ok = true;
   MorStreamArgs *dargs = nullptr;
@@ -284,7 +299,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.cloud, B * N) && dalloc(b, d.cloud_tidx, B * N) && dalloc(b, d.ground, 2 * B * N) && dalloc(b, d.gp_idx, B * N) && dalloc(b, d.pcell, B * N);
   ok = ok && dalloc(b, d.pkey, B * N) && dalloc(b, d.ckey, B * N) && dalloc(b, d.cstart, B * (N + 1)) && dalloc(b, d.row_start, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, d.cmin, B * N) && dalloc(b, d.cmeta, 2 * B * N);
   ok = ok && dalloc(b, d.sorted, B * N) && dalloc(b, d.parent, B * N) && dalloc(b, d.croot, B * N) && dalloc(b, d.csize, B * N) && dalloc(b, d.compmin, B * N) && dalloc(b, d.cid_of_root, B * N) && dalloc(b, d.pcid, B * N) && dalloc(b, d.ccid, B * N);
-  ok = ok && dalloc(b, d.ktile_cnt, B * T) && dalloc(b, d.kcell, B * K) && dalloc(b, d.kroot, B * K) && dalloc(b, d.ksize, B * K) && dalloc(b, d.csz, B * K);
+  ok = ok && dalloc(b, d.ktile_cnt, B * T) && dalloc(b, d.kcell, B * K) && dalloc(b, d.kroot, B * K) && dalloc(b, d.ksize, B * K) && dalloc(b, d.csz, B * K) && dalloc(b, d.krank_inv, B * K);
   {  // method-1 search stencil: (dy,dz) rows ordered by their distance lower bound, then by centre distance
     const int R = d.score_R, side = 2 * R + 1;
     std::vector<std::pair<std::pair<int, int>, std::pair<int, int>>> rows;
@@ -300,8 +315,9 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     if (ok) ok = hipMemcpy(dtab, tab.data(), tab.size(), hipMemcpyHostToDevice) == hipSuccess;
     d.row_order = dtab; d.n_rows = side * side;
   }
-  for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, d.rkeys[i], B * N) && dalloc(b, d.rvals[i], B * N) && dalloc(b, d.rkeys2[i], B * N) && dalloc(b, d.rvals2[i], B * N);
-  ok = ok && dalloc(b, d.rhist, B * T * 256) && dalloc(b, d.rhist2, B * T * 256) && dalloc(b, d.cl_idx, B * N);
+  for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, d.rkeys[i], B * N) && dalloc(b, d.rvals[i], B * N);
+  ok = ok && dalloc(b, d.rhist, B * T * 256);
+  ok = ok && dalloc(b, d.scell, B * N) && dalloc(b, d.csum, B * N) && dalloc(b, d.cgat, B * N) && dalloc(b, d.clist, B * N) && dalloc(b, d.cl_coff, B * (K + 1));
   d.skey = d.rkeys[d.cell_passes & 1]; d.sidx = d.rvals[d.cell_passes & 1];
   if (d.use_hash) ok = ok && dalloc(b, d.chash, B * (size_t)d.Hcell); else d.chash = nullptr;
   ok = ok && dalloc(b, d.split_desc, B * T);
@@ -309,11 +325,11 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.cg_ovf, B * (size_t)MOR_MAXP * MOR_CGS_OVF * 2);
   ok = ok && dalloc(b, d.ppos, B * N) && dalloc(b, d.pslot, B * N) && dalloc(b, d.gh_rowlist, B * N) && dalloc(b, d.gh_cells, B * N) && dalloc(b, d.gh_rowfill, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, d.gh_key, B * (size_t)d.Hcell) && dalloc(b, d.gh_val, B * (size_t)d.Hcell);
   ok = ok && dalloc(b, d.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, d.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, d.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, d.lroot_a, B * N) && dalloc(b, d.lroot_b, B * N) && dalloc(b, d.parent2, B * N);
-  ok = ok && dalloc(b, d.xcent, B * K) && dalloc(b, d.xamin, B * K) && dalloc(b, d.xamax, B * K);
+  ok = ok && dalloc(b, d.xcent, B * K) && dalloc(b, d.xamin, B * K) && dalloc(b, d.xamax, B * K) && dalloc(b, d.xfirst, B * K);
   for (int i = 0; i < (int)b->n_slots; ++i)
-    ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.chunk_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K);
+    ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.chunk_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K) && dalloc(b, d.cl_first[i], B * K);
   d.Wcap = (int)(N / MOR_CHUNK + K + 2);
-  ok = ok && dalloc(b, d.part, B * (size_t)d.Wcap) && dalloc(b, d.part_back, B * (size_t)d.Wcap);
+  ok = ok && dalloc(b, d.part_back, B * (size_t)d.Wcap);
   ok = ok && dalloc(b, d.nn_fwd, B * K) && dalloc(b, d.nn_bwd, B * K) && dalloc(b, d.nn_fwd_d, B * K) && dalloc(b, d.pair_q, B * K) && dalloc(b, d.pair_m, B * K) && dalloc(b, d.pair_d, B * K);
   ok = ok && dalloc(b, d.pair_cnt, B * K) && dalloc(b, d.pair_of_prev, B * K) && dalloc(b, d.pair_of_cur, B * K) && dalloc(b, d.det, B * K);
   if (p->method_choice == 2) ok = ok && dalloc(b, d.vox, B * (size_t)d.Hcap);
@@ -344,7 +360,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     MorDev &o = b->dtemp[c]; MorStreamArgs *dargs1 = nullptr;
     ok = dalloc(b, dargs1, B) && dalloc(b, o.info, B) && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, 2 * B * N) && dalloc(b, o.gp_idx, B * N);
     ok = ok && dalloc(b, o.sorted, B * N) && dalloc(b, o.ckey, B * N) && dalloc(b, o.cstart, B * (N + 1)) && dalloc(b, o.row_start, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, o.cmeta, 2 * B * N) && dalloc(b, o.crep, B * N);
-    ok = ok && dalloc(b, o.pcid, B * N) && dalloc(b, o.ccid, B * N) && dalloc(b, o.cl_idx, B * N) && dalloc(b, o.det, B * K) && dalloc(b, o.zorg, B);
+    ok = ok && dalloc(b, o.pcid, B * N) && dalloc(b, o.ccid, B * N) && dalloc(b, o.det, B * K) && dalloc(b, o.zorg, B);
+    ok = ok && dalloc(b, o.scell, B * N) && dalloc(b, o.csum, B * N) && dalloc(b, o.cgat, B * N) && dalloc(b, o.clist, B * N) && dalloc(b, o.cl_coff, B * (K + 1));
     ok = ok && dalloc(b, o.pcell, B * N) && dalloc(b, o.ppos, B * N) && dalloc(b, o.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, o.lroot_a, B * N) && dalloc(b, o.lroot_b, B * N) && dalloc(b, o.cmin, B * N) && dalloc(b, o.parent, B * N) && dalloc(b, o.csize, B * N) && dalloc(b, o.compmin, B * N) && dalloc(b, o.cid_of_root, B * N);
     ok = ok && dalloc(b, o.pair_q, B * K) && dalloc(b, o.pair_m, B * K) && dalloc(b, o.pair_d, B * K) && dalloc(b, o.pair_cnt, B * K) && dalloc(b, o.pair_of_prev, B * K) && dalloc(b, o.pair_of_cur, B * K);
     ok = ok && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B) && dalloc(b, o.wl_n, B) && dalloc(b, o.wlb_n, B) && dalloc(b, o.wl, B * N);
@@ -416,11 +433,13 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   //      frame k runs beside later pieces of frames k−1, k−2).  The first piece must not overwrite what frame k−depth still
   //      uses (same buffer copy; its cluster slot doubles as the `ca` slot of frame k−depth+1)
   hipStream_t S[4] = {b->sf, b->sc, b->sm, b->sb};
+  hipStream_t lane = S[k % b->n_lanes];
+  hipStream_t s0 = b->lanes ? lane : S[b->stage_of[0]];
   {
     const uint64_t depth = b->pipe_depth;   // frames in flight = copies of the per-frame arrays
-    if (k >= depth) HIP_TRY(hipStreamWaitEvent(S[b->stage_of[0]], b->ev_back[(k - depth) % MOR_MAX_SLOTS], 0));
+    if (k >= depth) HIP_TRY(hipStreamWaitEvent(s0, b->ev_back[(k - depth) % MOR_MAX_SLOTS], 0));
+    if (b->lanes && k > 0) HIP_TRY(hipStreamWaitEvent(s0, b->ev_piece[0][(k - 1) % MOR_MAX_SLOTS], 0));   // (also: the staging area of host blobs is free)
   }
-  hipStream_t s0 = S[b->stage_of[0]];
   for (int s = 0; s < B; ++s) {   // host-resident blobs are staged through device memory
     const mor_cloud_view &c = clouds[s];
     if (!c.on_device && c.n_points) HIP_TRY(hipMemcpyAsync((void *)b->h_args[s].data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, s0));
@@ -428,16 +447,27 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   HIP_TRY(hipMemcpyAsync(b->d_args_s[k % b->pipe_depth], b->h_args, sizeof(MorStreamArgs) * B, hipMemcpyHostToDevice, s0));
   HIP_TRY(hipEventRecord(b->args_ev[slot], s0));
   HIP_TRY(hipEventRecord(b->ev[0], s0));
-  for (int pc = 0; pc < MOR_N_PIECES; ++pc) {
-    hipStream_t st = S[b->stage_of[pc]];
-    if (pc > 0 && b->stage_of[pc] != b->stage_of[pc - 1]) {
-      HIP_TRY(hipEventRecord(b->ev_piece[pc - 1][k % MOR_MAX_SLOTS], S[b->stage_of[pc - 1]]));
-      HIP_TRY(hipStreamWaitEvent(st, b->ev_piece[pc - 1][k % MOR_MAX_SLOTS], 0));
+  hipStream_t tail = b->lanes ? lane : b->sb;
+  if (b->lanes) {
+    for (int pc = 0; pc < MOR_N_PIECES; ++pc) {
+      if (pc > 0 && k > 0) HIP_TRY(hipStreamWaitEvent(lane, b->ev_piece[pc][(k - 1) % MOR_MAX_SLOTS], 0));
+      if (pc == MOR_N_PIECES - 1 && b->last_track) HIP_TRY(hipStreamWaitEvent(lane, *b->last_track, 0));   // tracking state: after the previous frame's filterCloud
+      mor_launch_piece(d, pc, lane, &b->timer);
+      HIP_TRY(hipEventRecord(b->ev_piece[pc][k % MOR_MAX_SLOTS], lane));
     }
-    mor_launch_piece(d, pc, st, &b->timer);
+    b->last_track = &b->ev_piece[MOR_N_PIECES - 1][k % MOR_MAX_SLOTS];
+  } else {
+    for (int pc = 0; pc < MOR_N_PIECES; ++pc) {
+      hipStream_t st = S[b->stage_of[pc]];
+      if (pc > 0 && b->stage_of[pc] != b->stage_of[pc - 1]) {
+        HIP_TRY(hipEventRecord(b->ev_piece[pc - 1][k % MOR_MAX_SLOTS], S[b->stage_of[pc - 1]]));
+        HIP_TRY(hipStreamWaitEvent(st, b->ev_piece[pc - 1][k % MOR_MAX_SLOTS], 0));
+      }
+      mor_launch_piece(d, pc, st, &b->timer);
+    }
   }
-  HIP_TRY(hipEventRecord(b->ev[1], b->sb));
-  HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], b->sb));
+  HIP_TRY(hipEventRecord(b->ev[1], tail));
+  HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], tail));
   HIP_TRY(hipGetLastError());
   b->d = d; b->frame++; b->filtered = false; b->pending = true;
   if (b->async) return MOR_OK;
@@ -456,16 +486,21 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
                        // filterCloud on the same frame walks mo_vec again and moves the confidences again
   b->filtered = true;
   d.out_ptrs = nullptr;
+  hipStream_t S[4] = {b->sf, b->sc, b->sm, b->sb};
+  hipStream_t fs = b->lanes ? S[k % b->n_lanes] : b->sb;   // behind the frame's push
+  if (b->lanes && b->last_track) HIP_TRY(hipStreamWaitEvent(fs, *b->last_track, 0));   // a second filterCloud of a frame, or the frame's own tracking step (same stream: free)
   if (out && out_on_device) {
-    if (b->async) HIP_TRY(hipStreamSynchronize(b->sb));   // the pinned pointer table may still be in flight
+    if (b->async && b->last_filter_stream) HIP_TRY(hipStreamSynchronize(b->last_filter_stream));   // the pinned pointer table may still be in flight
     for (int s = 0; s < B; ++s) b->h_outptrs[s] = (float4 *)out[s];
-    HIP_TRY(hipMemcpyAsync(b->d_outptrs, b->h_outptrs, sizeof(float4 *) * B, hipMemcpyHostToDevice, b->sb));
+    HIP_TRY(hipMemcpyAsync(b->d_outptrs, b->h_outptrs, sizeof(float4 *) * B, hipMemcpyHostToDevice, fs));
     d.out_ptrs = b->d_outptrs;
+    b->last_filter_stream = fs;
   }
-  HIP_TRY(hipEventRecord(b->ev[2], b->sb));
-  mor_launch_filter(d, b->sb, &b->timer);
-  HIP_TRY(hipEventRecord(b->ev[3], b->sb));
-  HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], b->sb));
+  HIP_TRY(hipEventRecord(b->ev[2], fs));
+  mor_launch_filter(d, fs, &b->timer);
+  HIP_TRY(hipEventRecord(b->ev[3], fs));
+  HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], fs));
+  if (b->lanes) { HIP_TRY(hipEventRecord(b->ev_track[k % MOR_MAX_SLOTS], fs)); b->last_track = &b->ev_track[k % MOR_MAX_SLOTS]; }
   HIP_TRY(hipGetLastError());
   b->pending = true;
   const bool need_host = n_out != nullptr || (out && !out_on_device);
@@ -526,10 +561,22 @@ int mor_get_ground_indices(const mor_batch *b, int s, int32_t *idx) {
   if (f.G) HIP_TRY(hipMemcpy(idx, d.gp_idx + so, f.G * sizeof(int), hipMemcpyDeviceToHost));
   return MOR_OK;
 }
-int mor_get_clusters(const mor_batch *b, int s, int32_t *off, int32_t *idx) {
+// cluster_indices (:218) in the reference's order — cluster after cluster, ascending cloud index inside a cluster —
+// rebuilt from the labels (the device keeps the points of a cluster cell by cell)
+static int cluster_lists(const mor_batch *b, int s, std::vector<int> &off, std::vector<int> &idx) {
   CHECK_STREAM();
-  memcpy(off, d.h_cl_off + (size_t)s * (d.Kcap + 1), (f.K + 1) * sizeof(int));
-  if (f.C) HIP_TRY(hipMemcpy(idx, d.cl_idx + so, f.C * sizeof(int), hipMemcpyDeviceToHost));
+  off.assign(d.h_cl_off + (size_t)s * (d.Kcap + 1), d.h_cl_off + (size_t)s * (d.Kcap + 1) + f.K + 1);
+  idx.assign(f.C, 0);
+  std::vector<int> pc(f.M), fill(off.begin(), off.end());
+  if (f.M) HIP_TRY(hipMemcpy(pc.data(), d.pcid + so, f.M * sizeof(int), hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < f.M; ++i) if (pc[i] >= 0) idx[fill[pc[i]]++] = (int)i;
+  return MOR_OK;
+}
+int mor_get_clusters(const mor_batch *b, int s, int32_t *off, int32_t *idx) {
+  std::vector<int> o, ix;
+  const int rc = cluster_lists(b, s, o, ix);
+  if (rc != MOR_OK) return rc;
+  memcpy(off, o.data(), o.size() * sizeof(int)); if (!ix.empty()) memcpy(idx, ix.data(), ix.size() * sizeof(int));
   return MOR_OK;
 }
 int mor_get_centroids(const mor_batch *b, int s, float *xyz) {
@@ -551,9 +598,23 @@ int mor_get_tracks(const mor_batch *b, int s, float *xyz, int32_t *conf, int32_t
   for (int i = 0; i < t[0].n_mo; ++i) { if (xyz) memcpy(xyz + 3 * i, t[0].mo_c[i], 3 * sizeof(float)); if (conf) conf[i] = t[0].mo_conf[i]; if (maxc) maxc[i] = t[0].mo_max[i]; }
   return MOR_OK;
 }
+// cluster_collection (:229): the clustered points (x, y, z, intensity) in the reference's order
+static int cluster_points(const mor_batch *b, int s, std::vector<int> &off, std::vector<float4> &pts) {
+  std::vector<int> idx;
+  const int rc = cluster_lists(b, s, off, idx);
+  if (rc != MOR_OK) return rc;
+  const MorDev &d = b->d; const uint32_t M = d.h_info[s].M;
+  std::vector<float4> cloud(M);
+  if (M) HIP_TRY(hipMemcpy(cloud.data(), d.cloud + (size_t)s * d.Nmax, M * sizeof(float4), hipMemcpyDeviceToHost));
+  pts.resize(idx.size());
+  for (size_t j = 0; j < idx.size(); ++j) pts[j] = cloud[idx[j]];
+  return MOR_OK;
+}
 int mor_get_cluster_collection(const mor_batch *b, int s, float *out) {
-  CHECK_STREAM();
-  if (f.C) HIP_TRY(hipMemcpy(out, d.cl_pts[d.cur] + so, f.C * sizeof(float4), hipMemcpyDeviceToHost));
+  std::vector<int> off; std::vector<float4> pts;
+  const int rc = cluster_points(b, s, off, pts);
+  if (rc != MOR_OK) return rc;
+  if (!pts.empty()) memcpy(out, pts.data(), pts.size() * sizeof(float4));
   return MOR_OK;
 }
 
@@ -563,13 +624,10 @@ int mor_get_cluster_collection(const mor_batch *b, int s, float *out) {
 // reference builds markers only under VISUALIZE, for tracked clusters): the points come to the host and are summed there
 // in the reference's order.
 int mor_get_markers(const mor_batch *b, int s, float *pos_K3, float *scale_K3) {
-  CHECK_STREAM();
-  if (!f.K) return MOR_OK;
-  std::vector<float4> pts(f.C);
-  std::vector<int> off(f.K + 1);
-  memcpy(off.data(), d.h_cl_off + (size_t)s * (d.Kcap + 1), (f.K + 1) * sizeof(int));
-  if (f.C) HIP_TRY(hipMemcpy(pts.data(), d.cl_pts[d.cur] + so, f.C * sizeof(float4), hipMemcpyDeviceToHost));
-  for (uint32_t k = 0; k < f.K; ++k) {
+  std::vector<int> off; std::vector<float4> pts;
+  const int rc = cluster_points(b, s, off, pts);
+  if (rc != MOR_OK) return rc;
+  for (size_t k = 0; k + 1 < off.size(); ++k) {
     float sx = 0.f, sy = 0.f, sz = 0.f, mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     const int n = off[k + 1] - off[k];
     for (int j = off[k]; j < off[k + 1]; ++j) {
@@ -619,7 +677,7 @@ long long mor_debug_read(const mor_batch *b, const char *name, int s, void *out,
       {"pkey", d.pkey, N * 4}, {"sorted", d.sorted, N * 16}, {"cloud", d.cloud, N * 16}, {"cmin", d.cmin, N * 4}, {"cmeta", d.cmeta, 2 * N * 16}, {"crep", d.crep, N * 16},
       {"slab_y", d.slab_y, S * 4}, {"slab_c", d.slab_c, S * 4}, {"slab_e", d.slab_e, S * 4}, {"lroot_a", d.lroot_a, N * 4}, {"lroot_b", d.lroot_b, N * 4},
       {"ccid", d.ccid, N * 4}, {"pcid", d.pcid, N * 4}, {"chash", d.chash, (size_t)d.Hcell * 8}, {"info", d.info, sizeof(MorFrameInfo)},
-      {"xcent", d.xcent, K * 16}, {"xamin", d.xamin, K * 16}, {"xamax", d.xamax, K * 16}, {"cl_pts_prev", d.cl_pts[d.prev], N * 16}, {"cl_pts", d.cl_pts[d.cur], N * 16}};
+      {"xcent", d.xcent, K * 16}, {"xamin", d.xamin, K * 16}, {"xamax", d.xamax, K * 16}, {"xfirst", d.xfirst, K * 16}, {"scell", d.scell, N * 4}, {"cgat", d.cgat, N * 16}, {"csum", d.csum, N * 48}, {"clist", d.clist, N * 4}, {"cl_pts_prev", d.cl_pts[d.prev], N * 16}, {"cl_pts", d.cl_pts[d.cur], N * 16}};
   for (const Ent &e : tab) if (!strcmp(e.n, name)) {
     if (!e.p) return set_error(MOR_ERR_INVALID, "array %s is not allocated in this configuration", name);
     const size_t n = std::min(bytes, e.stride);

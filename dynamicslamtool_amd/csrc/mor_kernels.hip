@@ -30,7 +30,7 @@ const char *const mor_kernel_names[MK_COUNT] = {
     "classify", "scan_tiles", "scatter", "split", "heads_count", "heads_scan", "heads_scatter", "hash_clear", "cellboxes", "cellgraph", 
     "label", "rhist", "rscan", "rscatter",
     "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "cluster_pairs", "score_fast", "score_near", "score_block", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
-    "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridfill", "cg_slab", "cg_final"};
+    "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridfill", "cg_slab", "cg_final", "clusters"};
 
 #ifdef MOR_EXP_STAMPS
 #define RS_T(v) const unsigned long long v = wall_clock64()
@@ -519,9 +519,9 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
           const int rl = skey[p] / d.g.nx;
           const int g = atomicAdd(&l_ng, 1); if (g < 64) { l_gap[3 * g] = rl; l_gap[3 * g + 1] = d.g.nrows; l_gap[3 * g + 2] = c + 1; } else for (int r = rl + 1; r <= d.g.nrows; ++r) rs[r] = c + 1;
         }
-        d.pcell[so + i] = c;     // compact cell id per cloud point (k_label)
+        d.pcell[so + i] = c;     // compact cell id per cloud point
         float4 q = d.cloud[so + i]; q.w = __int_as_float(i);
-        d.sorted[so + p] = q;
+        d.sorted[so + p] = q; if (d.scell) d.scell[so + p] = c;
       }
       r += __popcll(mh[it]);
     }
@@ -763,15 +763,86 @@ __global__ __launch_bounds__(GH_T) void k_gridhash(MorDev d) {
     gh_run<false, false, false>(d, s, M, d.gh_key + (size_t)s * d.Hcell, d.gh_val + (size_t)s * d.Hcell, H, H, grows, g_cells, g_rowlist, l_misc, l_sh);
   }
 }
-// the points into cell order: sorted[position] = (x, y, z, bits(cloud index))
+// ---- per-cell accumulators of the streaming cell pass (k_cellboxes): point box, smallest cloud index, exact coordinate sums
+#define CB_WTILE 256      // positions of `sorted` one wave handles per step (four consecutive ones per lane)
+struct CellAcc { float lx, ly, lz, hx, hy, hz; int mi; long long a[3], b[3]; };
+__device__ __forceinline__ void fx_split(float x, long long &a, long long &b) {   // x = a·2^-24 + b·2^-64 (MorCellSum); every step is exact
+  const double xd = (double)x, fa = floor(xd * 16777216.0);
+  a = (long long)fa;
+  b = (long long)((xd - fa * (1.0 / 16777216.0)) * 18446744073709551616.0);
+}
+__device__ __forceinline__ double fx_value(long long a, long long b) { return (double)a * (1.0 / 16777216.0) + (double)b * (1.0 / 18446744073709551616.0); }
+__device__ __forceinline__ void acc_clear(CellAcc &r) { r.lx = r.ly = r.lz = FLT_MAX; r.hx = r.hy = r.hz = -FLT_MAX; r.mi = 0x7fffffff; r.a[0] = r.a[1] = r.a[2] = 0; r.b[0] = r.b[1] = r.b[2] = 0; }
+__device__ __forceinline__ void acc_point(CellAcc &r, const float4 &p) {
+  r.lx = fminf(r.lx, p.x); r.ly = fminf(r.ly, p.y); r.lz = fminf(r.lz, p.z); r.hx = fmaxf(r.hx, p.x); r.hy = fmaxf(r.hy, p.y); r.hz = fmaxf(r.hz, p.z);
+  r.mi = min(r.mi, __float_as_int(p.w));
+  long long a, b;
+  fx_split(p.x, a, b); r.a[0] += a; r.b[0] += b; fx_split(p.y, a, b); r.a[1] += a; r.b[1] += b; fx_split(p.z, a, b); r.a[2] += a; r.b[2] += b;
+}
+__device__ __forceinline__ void acc_merge(CellAcc &r, const CellAcc &o) {
+  r.lx = fminf(r.lx, o.lx); r.ly = fminf(r.ly, o.ly); r.lz = fminf(r.lz, o.lz); r.hx = fmaxf(r.hx, o.hx); r.hy = fmaxf(r.hy, o.hy); r.hz = fmaxf(r.hz, o.hz);
+  r.mi = min(r.mi, o.mi);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { r.a[k] += o.a[k]; r.b[k] += o.b[k]; }
+}
+__device__ __forceinline__ long long shfl_up_ll(long long v, int o) {
+  int lo = __shfl_up((int)(unsigned)v, o, 64), hi = __shfl_up((int)(v >> 32), o, 64);
+  return ((long long)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ CellAcc acc_shfl_up(const CellAcc &r, int o) {
+  CellAcc t;
+  t.lx = __shfl_up(r.lx, o, 64); t.ly = __shfl_up(r.ly, o, 64); t.lz = __shfl_up(r.lz, o, 64); t.hx = __shfl_up(r.hx, o, 64); t.hy = __shfl_up(r.hy, o, 64); t.hz = __shfl_up(r.hz, o, 64);
+  t.mi = __shfl_up(r.mi, o, 64);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { t.a[k] = shfl_up_ll(r.a[k], o); t.b[k] = shfl_up_ll(r.b[k], o); }
+  return t;
+}
+// float min / max through integer atomics (no NaNs here; −0 is folded into +0 first)
+__device__ __forceinline__ void atomic_fmin(float *p, float v) { v += 0.f; if (v >= 0.f) atomicMin((int *)p, __float_as_int(v)); else atomicMax((unsigned *)p, __float_as_uint(v)); }
+__device__ __forceinline__ void atomic_fmax(float *p, float v) { v += 0.f; if (v >= 0.f) atomicMax((int *)p, __float_as_int(v)); else atomicMin((unsigned *)p, __float_as_uint(v)); }
+// the record of cell c: alone (the cell lies inside one wave tile) or merged into what other waves deliver (k_gridfill /
+// k_cellinit initialised the records of the cells that span tiles)
+__device__ __forceinline__ void acc_emit(const MorDev &d, size_t so, int c, const CellAcc &r, bool shared) {
+  float *lo = reinterpret_cast<float *>(&d.cmeta[2 * (so + c)]), *hi = lo + 4;
+  MorCellSum *cs = d.csum + so + c;
+  if (!shared) {
+    d.cmeta[2 * (so + c)] = make_float4(r.lx, r.ly, r.lz, 0.f); d.cmeta[2 * (so + c) + 1] = make_float4(r.hx, r.hy, r.hz, 0.f);
+    d.cmin[so + c] = r.mi;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { cs->a[k] = r.a[k]; cs->b[k] = r.b[k]; }
+  } else {
+    atomic_fmin(lo, r.lx); atomic_fmin(lo + 1, r.ly); atomic_fmin(lo + 2, r.lz); atomic_fmax(hi, r.hx); atomic_fmax(hi + 1, r.hy); atomic_fmax(hi + 2, r.hz);
+    atomicMin(&d.cmin[so + c], r.mi);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { atomicAdd((unsigned long long *)&cs->a[k], (unsigned long long)r.a[k]); atomicAdd((unsigned long long *)&cs->b[k], (unsigned long long)r.b[k]); }
+  }
+}
+__device__ __forceinline__ void cell_init_if_spanning(const MorDev &d, size_t so, const int *cstart, int c) {
+  const int b = cstart[c], e = cstart[c + 1];
+  if (b / CB_WTILE == (e - 1) / CB_WTILE) return;
+  d.cmeta[2 * (so + c)] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f); d.cmeta[2 * (so + c) + 1] = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.f);
+  d.cmin[so + c] = 0x7fffffff;
+  MorCellSum z = {{0, 0, 0}, {0, 0, 0}}; d.csum[so + c] = z;
+}
+// the points into cell order: sorted[position] = (x, y, z, bits(cloud index)), scell[position] = compact cell id
 __global__ __launch_bounds__(MOR_BT) void k_gridfill(MorDev d) {
   int s, t0; map_block(d.B, d.tiles_m, s, t0);
-  const int M = d.info[s].M;
+  const int M = d.info[s].M, nocc = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
   for (int i = t0 * MOR_BT + threadIdx.x; i < M; i += d.tiles_m * MOR_BT) {
     float4 q = d.cloud[so + i]; q.w = __int_as_float(i);
-    d.sorted[so + d.ppos[so + i]] = q;
+    const int pos = d.ppos[so + i];
+    d.sorted[so + pos] = q; d.scell[so + pos] = d.pcell[so + i];
   }
+  const int *cstart = d.cstart + (size_t)s * (d.Nmax + 1);
+  for (int c = t0 * MOR_BT + threadIdx.x; c < nocc; c += d.tiles_m * MOR_BT) cell_init_if_spanning(d, so, cstart, c);
+}
+// (sort path of the grid: the same initialisation as its own small launch)
+__global__ __launch_bounds__(MOR_BT) void k_cellinit(MorDev d) {
+  int s, t0; map_block(d.B, d.tiles_m, s, t0);
+  const int nocc = d.info[s].n_occ;
+  const int *cstart = d.cstart + (size_t)s * (d.Nmax + 1);
+  for (int c = t0 * MOR_BT + threadIdx.x; c < nocc; c += d.tiles_m * MOR_BT) cell_init_if_spanning(d, (size_t)s * d.Nmax, cstart, c);
 }
 // ------------------------------------------------------------------------------------ C1: Euclidean clustering = connected components over cells
 // Per-cell kernels over global memory are bound by chains of dependent loads (key → row table → key → parent →
@@ -884,17 +955,18 @@ __device__ __forceinline__ int cg_lower_bound8(const int *key, int lo, int n, in
   for (int i = 0; i < 8; ++i) below += (i < n) && key[lo + min(i, n - 1)] < k0;
   return lo + below;
 }
-#define MOR_BOX_G 32      // workgroups per stream of k_cellboxes
-// Boxes of the cells' points (cmeta), for every stream at once at the end of the grid stage: 16 lanes per cell (most
-// cells hold a handful of points), four cells per wave-iteration.  (Used to be the first phase of k_cellgraph, where
-// one workgroup per stream walked its cells alone.)
+// Per occupied cell: the box of its points, its first point (sample for the quick edge test of the cell graph), its
+// smallest cloud index and the exact sums of its coordinates — ONE streaming pass over `sorted`, balanced whatever the
+// cell sizes are (a thread group per cell — round 1/2 — ended with the cells of thousands of points): a wave takes 256
+// consecutive positions, four per lane; a lane folds its four points serially, the open runs at lane boundaries go
+// through a segmented scan over the lanes (19 words × 6 shuffles per 256 points), and whoever holds the last point of a
+// cell writes its record.  Cells that continue into another wave tile are merged with atomics (min / max / integer
+// add: order-free), their records were initialised by k_gridfill.
 __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
   int s, bx; map_block(d.B, d.g_box, s, bx);
-  RS_T(tb0);
-  const int nocc = d.info[s].n_occ, sub = lane_id() & 15, grp = lane_id() >> 4;
+  const int nocc = d.info[s].n_occ, M = d.info[s].M, lane = lane_id();
   const size_t so = (size_t)s * d.Nmax;
-  const int *start = d.cstart + (size_t)s * (d.Nmax + 1);
-  const float4 *sp = d.sorted + so;
+  const float4 *sp = d.sorted + so; const int *sc = d.scell + so;
   if (bx == 0 && d.grid_mode == 0) { __shared__ int l_sb[48]; slab_bounds<false>(d, s, d.row_start + (size_t)s * (d.g.nrows + 1), nocc, l_sb); }   // (the hash path computes them in k_gridhash)
   if (d.use_hash && d.grid_mode == 0) {   // cell hash: (key+1, compact id); the table was cleared by k_heads_scatter
     unsigned long long *tab = d.chash + (size_t)s * d.Hcell; const int *ckey = d.ckey + so;
@@ -905,45 +977,43 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
       while (atomicCAS(&tab[sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
     }
   }
-  // four cells per 16-lane group and pass: their ranges, then their first 32 points each, as two batches of independent loads
-  for (int c0 = ((bx * (MOR_BT / 64) + wave_id()) * 4 + grp) * 4; c0 < nocc; c0 += d.g_box * (MOR_BT / 64) * 16) {
-    int b[4], e[4];
+  for (int base = (bx * (MOR_BT / 64) + wave_id()) * CB_WTILE; base < M; base += d.g_box * (MOR_BT / 64) * CB_WTILE) {
+    const int j0 = base + 4 * lane;
+    int c[4]; float4 p[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int c = min(c0 + u, nocc - 1); b[u] = start[c]; e[u] = start[c + 1]; }
-    float4 p[4], p2[4];
+    for (int u = 0; u < 4; ++u) { const int j = min(j0 + u, M - 1); c[u] = sc[j]; p[u] = sp[j]; }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { p[u] = sp[min(b[u] + sub, e[u] - 1)]; p2[u] = sp[min(b[u] + sub + 16, e[u] - 1)]; }
+    for (int u = 0; u < 4; ++u) if (j0 + u >= M) c[u] = -1;
+    int left = -2, right = -3;   // cells of the positions just outside the tile
+    if (lane == 0 && base > 0) left = sc[base - 1];
+    if (lane == 63 && base + CB_WTILE < M) right = sc[base + CB_WTILE];
+    const int cw0 = __shfl(c[0], 0, 64), cwl = __shfl(c[3], 63, 64);
+    const bool open_l = __shfl(left, 0, 64) == cw0, open_r = __shfl(right, 63, 64) == cwl;
+    int prevc = __shfl_up(c[3], 1, 64), nextc = __shfl_down(c[0], 1, 64);
+    if (lane == 0) prevc = left;
+    if (lane == 63) nextc = right;
+    // the lane's tail run (the run holding its last position) and whether it began in an earlier lane
+    int ts = 3;
+    if (c[2] == c[3]) { ts = 2; if (c[1] == c[3]) { ts = 1; if (c[0] == c[3]) ts = 0; } }
+    CellAcc S; acc_clear(S);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (u >= ts) acc_point(S, p[u]);
+    const bool head = !(ts == 0 && c[0] == prevc) || lane == 0;
+    const unsigned long long heads = __ballot(head);
+    const int hl = 63 - __clzll((long long)(heads & (lanemask_lt() | (1ull << lane))));
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const CellAcc t = acc_shfl_up(S, o); if (lane - o >= hl) acc_merge(S, t); }
+    CellAcc acc = acc_shfl_up(S, 1);   // the run reaching this lane from the left, up to the previous lane
+    if (lane == 0 || c[0] != prevc) acc_clear(acc);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      float lx = fminf(p[u].x, p2[u].x), ly = fminf(p[u].y, p2[u].y), lz = fminf(p[u].z, p2[u].z), hx = fmaxf(p[u].x, p2[u].x), hy = fmaxf(p[u].y, p2[u].y), hz = fmaxf(p[u].z, p2[u].z);
-      int mi = min(__float_as_int(p[u].w), __float_as_int(p2[u].w));   // smallest cloud index of the cell (identity / order of its component)
-      // cells of 33 … 512 points stay with their 16 lanes: 64 more points per step, four independent loads per lane
-      // (handing each of them to the whole wave, one after the other, cost half of this kernel's time)
-      const int nu = e[u] - b[u];
-      if (nu > 32 && nu <= 512) {
-        for (int k = b[u] + 32 + sub; k < e[u]; k += 64) {
-          const float4 q0 = sp[k], q1 = sp[min(k + 16, e[u] - 1)], q2 = sp[min(k + 32, e[u] - 1)], q3 = sp[min(k + 48, e[u] - 1)];
-          lx = fminf(fminf(lx, q0.x), fminf(q1.x, fminf(q2.x, q3.x))); ly = fminf(fminf(ly, q0.y), fminf(q1.y, fminf(q2.y, q3.y))); lz = fminf(fminf(lz, q0.z), fminf(q1.z, fminf(q2.z, q3.z)));
-          hx = fmaxf(fmaxf(hx, q0.x), fmaxf(q1.x, fmaxf(q2.x, q3.x))); hy = fmaxf(fmaxf(hy, q0.y), fmaxf(q1.y, fmaxf(q2.y, q3.y))); hz = fmaxf(fmaxf(hz, q0.z), fmaxf(q1.z, fmaxf(q2.z, q3.z)));
-          mi = min(min(mi, __float_as_int(q0.w)), min(__float_as_int(q1.w), min(__float_as_int(q2.w), __float_as_int(q3.w))));
-        }
-      }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        mi = min(mi, __shfl_xor(mi, o, 64));
-        lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
-        hx = fmaxf(hx, __shfl_xor(hx, o, 64)); hy = fmaxf(hy, __shfl_xor(hy, o, 64)); hz = fmaxf(hz, __shfl_xor(hz, o, 64));
-      }
-      const bool bigc = nu > 512 && c0 + u < nocc;
-      if (sub == 0 && c0 + u < nocc) d.crep[so + c0 + u] = p[u];   // the cell's first point: sample for the quick edge test of k_cellgraph
-      if (sub == 0 && c0 + u < nocc && !bigc) { d.cmeta[2 * (so + c0 + u)] = make_float4(lx, ly, lz, 0.f); d.cmeta[2 * (so + c0 + u) + 1] = make_float4(hx, hy, hz, 0.f); d.cmin[so + c0 + u] = mi; }
-      // cells of more than 512 points (a dense surface next to the sensor): the whole wave, 256 points per step
-      unsigned long long m = __ballot(bigc && sub == 0);
-      while (m) {
-        const int l = __ffsll((long long)m) - 1; m &= m - 1;
-        const int cb = __shfl(b[u], l, 64), ce = __shfl(e[u], l, 64), cc = __shfl(c0 + u, l, 64);
-        float4 lo, hi; int wmi; wave_box(sp, cb, ce, lane_id(), lo, hi, wmi);
-        if (lane_id() == 0) { d.cmeta[2 * (so + cc)] = lo; d.cmeta[2 * (so + cc) + 1] = hi; d.cmin[so + cc] = wmi; }
+      if (c[u] < 0) break;
+      if (c[u] != (u ? c[u - 1] : prevc)) d.crep[so + c[u]] = p[u];   // first position of the cell
+      acc_point(acc, p[u]);
+      const int nxt = u < 3 ? c[u + 1] : nextc;
+      if (c[u] != nxt || (u == 3 && lane == 63)) {
+        acc_emit(d, so, c[u], acc, (c[u] == cw0 && open_l) || (c[u] == cwl && open_r));
+        acc_clear(acc);
       }
     }
   }
@@ -1252,12 +1322,14 @@ template <bool LDS> __device__ __forceinline__ void cgf_body(const MorDev &d, in
     const int my_sz = d.ksize[ko + k], my_rt = d.kroot[ko + k]; int rank = 0;
     for (int u = 0; u < K; ++u) { const int sz = d.ksize[ko + u], rt = d.kroot[ko + u]; rank += (sz > my_sz) || (sz == my_sz && rt < my_rt); }
     cg_st<LDS>(cidr + d.kcell[ko + k], rank);
-    d.csz[ko + rank] = my_sz;
+    d.csz[ko + rank] = my_sz; d.krank_inv[ko + rank] = k;
   }
   __threadfence_block();
   __syncthreads();
-  // ---- per-cell cluster id (a cell is a clique ⇒ one cluster)
-  for (int c = threadIdx.x; c < nocc; c += CGF_T) { const int r = cg_ld<LDS>(par + c), id = cg_ld<LDS>(cidr + r); d.ccid[so + c] = id; reinterpret_cast<int *>(&d.cmeta[2 * (so + c)])[3] = id; }
+  // ---- per-cell cluster id (a cell is a clique ⇒ one cluster); kept in place of the parent from here on
+  for (int c = threadIdx.x; c < nocc; c += CGF_T) { const int r = cg_ld<LDS>(par + c), id = cg_ld<LDS>(cidr + r); d.ccid[so + c] = id; reinterpret_cast<int *>(&d.cmeta[2 * (so + c)])[3] = id; cg_st<LDS>(par + c, id); }
+  __threadfence_block();
+  __syncthreads();
   // ---- cluster offsets (exclusive scan of sizes in cluster order), C, clear detection_results (:250-254)
   int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1);
   int carry = 0;
@@ -1289,6 +1361,54 @@ template <bool LDS> __device__ __forceinline__ void cgf_body(const MorDev &d, in
     carry += tot;
   }
   if (threadIdx.x == 0) coff[K] = carry;
+  // ---- the cells of every cluster as a list, and every cell's place in the cluster's range of cl_pts: cluster k owns
+  //      cl_pts[off[k], off[k+1]); its cells take consecutive pieces of it in the order their atomics arrive, except the
+  //      cell holding the cluster's first point (smallest cloud index), which takes the first piece.  (Any order will do:
+  //      what is computed from cluster points — counts, existence tests, min / max, exact integer sums — does not depend
+  //      on it; read-backs that promise the reference's order rebuild it from the labels.)
+  int *ncell = size, *cur = mn;   // both free by now: [K] cells per cluster → first list entry; next free slot of the cluster's range
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += CGF_T) cg_st<LDS>(ncell + k, 0);
+  __threadfence_block();
+  __syncthreads();
+  for (int c = threadIdx.x; c < nocc; c += CGF_T) { const int k = cg_ld<LDS>(par + c); if (k >= 0) atomicAdd(&ncell[k], 1); }
+  __threadfence_block();
+  __syncthreads();
+  int *lcoff = d.cl_coff + (size_t)s * (d.Kcap + 1);
+  carry = 0;
+  for (int b = 0; b < K; b += CGF_T) {
+    const int k = b + threadIdx.x, v = k < K ? cg_ld<LDS>(ncell + k) : 0;
+    const int inc = wave_incl_scan(v);
+    if (lane == 63) l_misc[1 + wave_id()] = inc;
+    __syncthreads();
+    int basew = 0, tot = 0;
+    for (int w = 0; w < CGF_T / 64; ++w) { const int xw = l_misc[1 + w]; if (w < wave_id()) basew += xw; tot += xw; }
+    __syncthreads();
+    if (k < K) { const int e = carry + basew + inc - v; lcoff[k] = e; cg_st<LDS>(ncell + k, e); }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) lcoff[K] = carry;
+  __threadfence_block();
+  __syncthreads();
+  // the cell with the cluster's first point opens the range
+  for (int c = threadIdx.x; c < nocc; c += CGF_T) {
+    const int k = cg_ld<LDS>(par + c);
+    if (k >= 0 && d.cmin[so + c] == d.kroot[ko + d.krank_inv[ko + k]]) cg_st<LDS>(cur + k, off[k] + (start[c + 1] - start[c]));
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int c = threadIdx.x; c < nocc; c += CGF_T) {
+    const int k = cg_ld<LDS>(par + c);
+    int4 g = make_int4(0, -1, -1, 0);
+    if (k >= 0) {
+      const int first = d.kroot[ko + d.krank_inv[ko + k]], n = start[c + 1] - start[c];
+      const bool opens = d.cmin[so + c] == first;
+      const int dst = opens ? off[k] : atomicAdd(&cur[k], n);
+      g = make_int4(dst - start[c], k, opens ? first : -1, 0);
+      d.clist[so + atomicAdd(&ncell[k], 1)] = c;
+    }
+    d.cgat[so + c] = g;
+  }
 }
 __global__ __launch_bounds__(CGF_T) void k_cg_final(MorDev d) {
   const int s = blockIdx.x + d.s0, nocc = d.info[s].n_occ;
@@ -1308,16 +1428,8 @@ __global__ __launch_bounds__(CGF_T) void k_cg_final(MorDev d) {
   }
 }
 
-// per cloud point: cluster id of its cell (a cell is a clique ⇒ one cluster per cell)
-__global__ __launch_bounds__(MOR_BT) void k_label(MorDev d) {
-  int s, t0; map_block(d.B, d.tiles_m, s, t0);
-  const int M = d.info[s].M;
-  const size_t so = (size_t)s * d.Nmax;
-  for (int i = t0 * MOR_BT + threadIdx.x; i < M; i += d.tiles_m * MOR_BT) d.pcid[so + i] = d.ccid[so + d.pcell[so + i]];
-}
-
 // ------------------------------------------------------------------------------------ stable LSD radix sort, 8-bit digits, batched over streams
-// used twice per frame: points by cell key (grid build) and clustered points by cluster id (C2).
+// used by the sort path of the grid (MOR_GRID=radix) and by the VoxelGrid pass of the voxel ground variant.
 __device__ __forceinline__ void radix_item(const MorRadix &j, size_t so, int count, int i, int &key, int &val, bool &valid) {
   valid = i < count; key = 0; val = 0;
   if (!valid) return;
@@ -1444,46 +1556,57 @@ __device__ __forceinline__ int chunk_cluster(const int *coff, int K, int w) {
   while (b - a > 1) { int m = (a + b) >> 1; if (coff[m] <= w) a = m; else b = m; }
   return a;
 }
-// copy member points (:224-230), partial Σ(double)p and AABB per chunk
-__global__ __launch_bounds__(MOR_BT) void k_stats(MorDev d) {
-  int s = blockIdx.y + d.s0, K = d.info[s].K;
-  if (K == 0) return;
-  const size_t so = (size_t)s * d.Nmax;
-  const int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1), *coff = d.chunk_off[d.cur] + (size_t)s * (d.Kcap + 1);
-  const int W = coff[K];
-  __shared__ Red6 sh[MOR_BT / 64];
-  for (int w = blockIdx.x; w < W; w += gridDim.x) {
-    const int k = chunk_cluster(coff, K, w), b = off[k] + (w - coff[k]) * MOR_CHUNK, e = min(off[k + 1], b + MOR_CHUNK);
-    Red6 r = {0, 0, 0, FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int j = b + threadIdx.x; j < e; j += MOR_BT) {
-      float4 p = d.cloud[so + d.cl_idx[so + j]];
-      d.cl_pts[d.cur][so + j] = p; d.cl_cid[d.cur][so + j] = k;
-      r.sx += (double)p.x; r.sy += (double)p.y; r.sz += (double)p.z;
-      r.mnx = fminf(r.mnx, p.x); r.mny = fminf(r.mny, p.y); r.mnz = fminf(r.mnz, p.z);
-      r.mxx = fmaxf(r.mxx, p.x); r.mxy = fmaxf(r.mxy, p.y); r.mxz = fmaxf(r.mxz, p.z);
+// C2 in one launch (labels, cluster points, centroids, boxes) — no partition of the points by cluster id: the points are
+// already grouped by cell, a cluster is a set of whole cells, and k_cg_final gave every cell its piece of the cluster's
+// range of cl_pts.  Workgroups [0, tiles_m) of a stream move points: position j of `sorted` → slot j + shift(cell) —
+// pieces of consecutive positions, coalesced on both sides — and write the label of cloud point j; workgroups
+// [tiles_m, tiles_m + MOR_CLS_G) reduce the cell records (boxes, exact coordinate sums) of every cluster with one wave
+// per cluster: centroid = Σ(double)p / n cast to fp32 (:239-243) from the exact sum, AABB for the volume gate.
+#define MOR_CLS_G 8
+__global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
+  int s, t; map_block(d.B, d.tiles_m + MOR_CLS_G, s, t);
+  const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
+  if (t < d.tiles_m) {
+    const int M = d.info[s].M;
+    float4 *dst = d.cl_pts[d.cur] + so; int *dcid = d.cl_cid[d.cur] + so;
+    for (int j = t * MOR_BT + threadIdx.x; j < M; j += d.tiles_m * MOR_BT) {
+      d.pcid[so + j] = d.ccid[so + d.pcell[so + j]];
+      const int4 g = d.cgat[so + d.scell[so + j]];
+      if (g.y < 0) continue;
+      const float4 p = d.sorted[so + j];
+      dst[j + g.x] = p; dcid[j + g.x] = g.y;
+      if (__float_as_int(p.w) == g.z) d.cl_first[d.cur][ko + g.y] = p;
     }
-    red6_block(r, sh);
-    if (threadIdx.x == 0) d.part[(size_t)s * d.Wcap + w] = r;
+    return;
   }
-}
-// centroid = Σ(double)p / n cast to fp32 (:239-243), AABB for the volume gate — one workgroup per stream (part of k_cluster_pairs)
-__device__ __forceinline__ void stats_fin_body(const MorDev &d, int s) {
-  const int K = d.info[s].K;
-  const int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1), *coff = d.chunk_off[d.cur] + (size_t)s * (d.Kcap + 1);
-  const Red6 *pt = d.part + (size_t)s * d.Wcap;
-  for (int k = threadIdx.x; k < K; k += MOR_BT) {
-    Red6 r = pt[coff[k]];
-    for (int w = coff[k] + 1; w < coff[k + 1]; ++w) {
-      const Red6 q = pt[w];
-      r.sx += q.sx; r.sy += q.sy; r.sz += q.sz;
-      r.mnx = fminf(r.mnx, q.mnx); r.mny = fminf(r.mny, q.mny); r.mnz = fminf(r.mnz, q.mnz);
-      r.mxx = fmaxf(r.mxx, q.mxx); r.mxy = fmaxf(r.mxy, q.mxy); r.mxz = fmaxf(r.mxz, q.mxz);
+  const int K = d.info[s].K, lane = lane_id();
+  const int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1), *lcoff = d.cl_coff + (size_t)s * (d.Kcap + 1);
+  for (int k = (t - d.tiles_m) * (MOR_BT / 64) + wave_id(); k < K; k += MOR_CLS_G * (MOR_BT / 64)) {
+    CellAcc r; acc_clear(r);
+    for (int e = lcoff[k] + lane; e < lcoff[k + 1]; e += 64) {
+      const int c = d.clist[so + e];
+      const float4 lo = d.cmeta[2 * (so + c)], hi = d.cmeta[2 * (so + c) + 1]; const MorCellSum cs = d.csum[so + c];
+      r.lx = fminf(r.lx, lo.x); r.ly = fminf(r.ly, lo.y); r.lz = fminf(r.lz, lo.z); r.hx = fmaxf(r.hx, hi.x); r.hy = fmaxf(r.hy, hi.y); r.hz = fmaxf(r.hz, hi.z);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { r.a[a] += cs.a[a]; r.b[a] += cs.b[a]; }
     }
-    const double n = (double)(off[k + 1] - off[k]);
-    d.centroid[d.cur][(size_t)s * d.Kcap + k] = make_float4((float)(r.sx / n), (float)(r.sy / n), (float)(r.sz / n), 0.f);
-    d.amin[d.cur][(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
-    d.amax[d.cur][(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
-    d.pair_of_cur[(size_t)s * d.Kcap + k] = -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      r.lx = fminf(r.lx, __shfl_xor(r.lx, o, 64)); r.ly = fminf(r.ly, __shfl_xor(r.ly, o, 64)); r.lz = fminf(r.lz, __shfl_xor(r.lz, o, 64));
+      r.hx = fmaxf(r.hx, __shfl_xor(r.hx, o, 64)); r.hy = fmaxf(r.hy, __shfl_xor(r.hy, o, 64)); r.hz = fmaxf(r.hz, __shfl_xor(r.hz, o, 64));
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        r.a[a] += ((long long)__shfl_xor((int)(r.a[a] >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)r.a[a], o, 64);
+        r.b[a] += ((long long)__shfl_xor((int)(r.b[a] >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)r.b[a], o, 64);
+      }
+    }
+    if (lane == 0) {
+      const double n = (double)(off[k + 1] - off[k]);
+      d.centroid[d.cur][ko + k] = make_float4((float)(fx_value(r.a[0], r.b[0]) / n), (float)(fx_value(r.a[1], r.b[1]) / n), (float)(fx_value(r.a[2], r.b[2]) / n), 0.f);
+      d.amin[d.cur][ko + k] = make_float4(r.lx, r.ly, r.lz, 0.f);
+      d.amax[d.cur][ko + k] = make_float4(r.hx, r.hy, r.hz, 0.f);
+      d.pair_of_cur[ko + k] = -1;
+    }
   }
 }
 
@@ -1534,6 +1657,9 @@ __device__ __forceinline__ void xform_fin_body(const MorDev &d, int s) {
     float4 c = d.centroid[pv][(size_t)s * d.Kcap + k];
     xform(m, c.x, c.y, c.z);
     d.xcent[(size_t)s * d.Kcap + k] = c;     // ca's own centroids stay as they are: the tail stage of frame k−1 may still be reading them
+    float4 p0 = d.cl_first[pv][(size_t)s * d.Kcap + k];
+    xform(m, p0.x, p0.y, p0.z);
+    d.xfirst[(size_t)s * d.Kcap + k] = p0;
     d.xamin[(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
     d.xamax[(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
     d.pair_of_prev[(size_t)s * d.Kcap + k] = -1;
@@ -1593,14 +1719,12 @@ __device__ __forceinline__ void pairs_body(const MorDev &d, int s, int *sh) {
   }
   if (threadIdx.x == 0) { d.info[s].n_pairs = carry; d.wl_n[s] = 0; d.wlb_n[s] = 0; d.wl2_n[s] = 0; }
 }
-// One workgroup per stream: everything per CLUSTER between the point kernels — centroids and boxes of cb (from k_stats'
-// partials), boxes and centroids of the transformed ca (from k_xform_prev's), both nearest-centroid directions, the
-// correspondences.  (Four launches of a few dozen threads' work each before.)
+// One workgroup per stream: everything per CLUSTER between the point kernels — boxes, centroids and first points of the
+// transformed ca (from k_xform_prev's partials), both nearest-centroid directions, the correspondences.
 __global__ __launch_bounds__(MOR_BT) void k_cluster_pairs(MorDev d) {
   const int s = blockIdx.x + d.s0;
   __shared__ float4 tile[MOR_BT];
   __shared__ int sh[8];
-  stats_fin_body(d, s);
   if (!d.has_prev) return;
   xform_fin_body(d, s);
   __threadfence_block();
@@ -1739,6 +1863,17 @@ __device__ __forceinline__ void scan_batch4(const MorDev &d, size_t so, const in
     else if (!(best < d.pde_ub) && bd < d.pde_ub) scan4s(sp, b0[i], e0[i], q, d.pde_ub, best, budget);
   }
 }
+// Which worklist entry a thread of the worklist tiers takes in the pass starting at w0 (= pass·G·256 + bx·256).  A stream's
+// list holds a few thousand entries — a few workgroups' worth if handed out 256 at a time, and those few CUs then carry
+// all the divergent gathers of the tier (measured: 112 µs → 73 µs for k_score_block alone).  So the entries of a pass are
+// dealt over ALL G workgroups: entry e → workgroup e % G (default), or in chunks of 64 (variant 64: waves keep
+// neighbouring queries).
+__device__ __forceinline__ int wl_entry(const MorDev &d, int w0, int bx) {
+  const int p0 = w0 - bx * MOR_BT;
+  if (d.split_variant & 32) return w0 + threadIdx.x;
+  if (d.split_variant & 64) return p0 + ((threadIdx.x >> 6) * d.g_score + bx) * 64 + (threadIdx.x & 63);
+  return p0 + threadIdx.x * d.g_score + bx;
+}
 // Tier 1a — one THREAD per query with E2 known (worklist front).  E1: only the ≤ 7 neighbour cells across the walls q
 // is close to can hold a point within √lb (the own cell was scanned by tier 1).  Three levels of loads: hash probes →
 // box records + ranges → points.  No such point ⇒ counted.
@@ -1752,7 +1887,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_near(MorDev d) {
   const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + d.g.cs * 1e-3f;
   for (int w0 = bx * MOR_BT; w0 < nq; w0 += d.g_score * MOR_BT) {
-    const int w = w0 + threadIdx.x;
+    const int w = (d.split_variant & 128) ? w0 + threadIdx.x : wl_entry(d, w0, bx);
     bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
     if (w < nq) {
       const int4 we = d.wl[so + w]; j = we.x; pr = we.y; target = we.z;
@@ -1796,7 +1931,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + d.g.cs * 1e-3f;
   const bool stencil27 = d.n_rows <= 9 && d.score_R <= 1;   // the whole search stencil is the 3×3×3 block
   for (int w0 = bx * MOR_BT; w0 < nq; w0 += d.g_score * MOR_BT) {
-    const int w = w0 + threadIdx.x;
+    const int w = wl_entry(d, w0, bx);
     bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
     if (w < nq) {
       const int4 we = d.wl[so + d.Nmax - 1 - w]; j = we.x; pr = we.y; target = we.z;
@@ -1970,10 +2105,9 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
 __device__ __forceinline__ int vox_table_size(const MorDev &d, int Cprev) { int h = 64; while (h < 2 * Cprev && h < d.Hcap) h <<= 1; return h; }
 __device__ __forceinline__ unsigned long long vox_hash(unsigned long long k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; }
 __device__ __forceinline__ bool vox_key(const MorDev &d, int s, int pr, float4 p, unsigned long long &key) {
-  int pv = d.prev;
-  const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
+  const size_t ko = (size_t)s * d.Kcap;
   int q = d.pair_q[ko + pr];
-  float4 p0 = d.cl_pts[pv][so + d.cl_off[pv][(size_t)s * (d.Kcap + 1) + q]];
+  const float4 p0 = d.xfirst[ko + q];   // clusters[q][0] of ca after the transform: the first point the octree sees
   const double res = d.opc_res, eps = (double)FLT_EPSILON;
   long long kk[3]; const float pc[3] = {p.x, p.y, p.z}, p0c[3] = {p0.x, p0.y, p0.z};
   bool ok = pr < 65535;
@@ -2076,7 +2210,7 @@ template <int NT> __device__ __forceinline__ void decide_body(const MorDev &d, i
 // the per-stream error flag reproduces "more indices than points ⇒ empty output"), then ground.
 __device__ __forceinline__ bool out_keep(const MorDev &d, int s, size_t so, int i) {
   if (d.moving[(size_t)d.Btot * d.Kcap + s]) return false;
-  int cid = d.pcid[so + i];   // cluster id per cloud point (written by k_label)
+  int cid = d.pcid[so + i];   // cluster id per cloud point (written by k_clusters)
   return !(cid >= 0 && d.moving[(size_t)s * d.Kcap + cid]);
 }
 __global__ __launch_bounds__(MOR_BT) void k_out_count(MorDev d) {
@@ -2623,6 +2757,7 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
       if (d.use_hash) MOR_LAUNCH(MK_HASH_CLEAR, k_hash_clear, dim3(64, d.B), d);
     }
     MOR_LAUNCH(MK_HEADS_SCATTER, k_heads_scatter, gM, d);
+    if (d.gmode != 1) MOR_LAUNCH(MK_GRIDFILL, k_cellinit, gM, d);
   }
 }
 static void mor_launch_boxes(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
@@ -2664,20 +2799,8 @@ static void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer
   mor_timer_end(tm, MK_CG_FINAL, st);
 }
 
-static void mor_launch_clusters(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // labels, cluster_indices, cluster points, centroids
-  const dim3 gM(d.B * d.tiles_m), gB(d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B);
-  MOR_LAUNCH(MK_LABEL, k_label, gM, d);
-  for (int pass = 0; pass < d.radix_passes; ++pass) {   // clustered points partitioned by cluster id, index order kept ⇒ cluster_indices
-    const bool last = pass == d.radix_passes - 1;
-    // every pass also writes cl_idx: a stream with K ≤ 256^p has its final order after pass p−1 and later passes
-    // return at once for it (K ≤ 256 is the usual case: one effective pass)
-    MorRadix j = {pass == 0 ? d.pcid : d.rkeys2[pass & 1], pass == 0 ? nullptr : d.rvals2[pass & 1], last ? nullptr : d.rkeys2[(pass + 1) & 1], last ? d.cl_idx : d.rvals2[(pass + 1) & 1],
-                  8 * pass, pass == 0 ? 0 : 1, pass == 0 ? 1 : 0, last ? nullptr : d.cl_idx, d.rhist2, pass == 0 ? 0 : (1 << (8 * pass)), d.fuse_scans && d.tiles_m <= 64};
-    MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
-    if (!j.fuse) MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
-    MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
-  }
-  MOR_LAUNCH(MK_STATS, k_stats, dim3(64, d.B), d);
+static void mor_launch_clusters(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // labels, cluster points, centroids, boxes
+  MOR_LAUNCH(MK_CLUSTERS, k_clusters, dim3(d.B * (d.tiles_m + MOR_CLS_G)), d);
 }
 static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // transform of ca, correspondences, first tiers of the scores
   const dim3 gT(d.B * d.tiles), gB(d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B);

@@ -775,14 +775,19 @@ def test_transformed_previous_frame_matches_oracle(sensor, seed):
             cen_b = b.debug_read("xcent", 0, np.float32, 4 * K).reshape(K, 4)[:, :3]
             pts_b = b.debug_read("cl_pts_prev", 0, np.float32, 4 * Cn).reshape(Cn, 4)
             assert np.array_equal(cen_o.view(np.uint32), cen_b.view(np.uint32)), "frame %d transformed centroids" % f
-            assert np.array_equal(pts_o.view(np.uint32), pts_b.view(np.uint32)), "frame %d transformed cluster points" % f
+            # the device keeps a cluster's points cell by cell, .w = bits of the cloud index: put them into the reference's order
+            # (ascending index inside a cluster) before comparing
+            idx_b = pts_b[:, 3].copy().view(np.int32)
+            order = np.concatenate([prev_off[k] + np.argsort(idx_b[prev_off[k]:prev_off[k + 1]], kind="stable") for k in range(K)])
+            assert np.array_equal(idx_b[order], prev_idx), "frame %d cluster membership of the transformed points" % f
+            assert np.array_equal(pts_o[:, :3].view(np.uint32), pts_b[order, :3].view(np.uint32)), "frame %d transformed cluster points" % f
             lo_b = b.debug_read("xamin", 0, np.float32, 4 * K).reshape(K, 4)[:, :3]
             hi_b = b.debug_read("xamax", 0, np.float32, 4 * K).reshape(K, 4)[:, :3]
             for k in range(K):
                 q = pts_o[prev_off[k]:prev_off[k + 1], :3]
                 assert np.array_equal(lo_b[k], q.min(0)) and np.array_equal(hi_b[k], q.max(0)), (f, k)
         compare_frame(o, b, 0, "frame %d" % f)
-        prev_off = o.clusters()[0].copy()
+        prev_off, prev_idx = (a.copy() for a in o.clusters())
         b.filter(to_host=False)
         o.filter()
     b.close()
