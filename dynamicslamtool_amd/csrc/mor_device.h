@@ -47,14 +47,14 @@ struct MorStreamArgs {       // per stream, per push (host → device, one small
 struct MorFrameInfo {        // per stream, produced on device
   uint32_t N, T, M, G, K, C, n_pairs, flags;   // flags bit0: cluster capacity exceeded, bit1: voxel key overflow
   uint32_t Kprev, Cprev, n_keep, n_occ;   // n_occ: occupied grid cells
-  uint32_t n_defer, pad0, hshift, pad2;   // n_defer: method-1 queries handed to the wave tier; hshift: 32 − log2(size of the stream's cell hash table)
+  uint32_t n_defer, pad0, hshift, max_loc;   // n_defer: method-1 queries handed to the wave tier; hshift: 32 − log2(size of the stream's cell hash table); max_loc: cells (own + look-ahead) of the largest slab of the cell graph
 };
 
 // Temporal logic (T1 + the tracking loop of F1) as device state, one instance per stream.  O(clusters) sequential work
 // per frame: it runs in a one-workgroup-per-stream kernel right behind the geometry so that push + filter need no
 // host round trip in between.  Mirrors csrc/mor_tracker.cpp (the host version behind the mor_tracker_* C ABI).
-#define MOR_MAX_DEPTH 6     // frames in flight in the stage pipeline, at most (one copy of every per-frame array each)
-#define MOR_MAX_SLOTS 8     // cluster-array slots (depth + 1 are in use)
+#define MOR_MAX_DEPTH 8     // frames in flight in the stage pipeline, at most (one copy of every per-frame array each)
+#define MOR_MAX_SLOTS 10     // cluster-array slots (depth + 1 are in use)
 #define MOR_MAXP 32        // slabs per stream of the cell graph (k_cg_slab), at most
 #define MOR_CGS_OVF 8192   // overflow entries per slab of its candidate-pair lists (beyond them a pair is settled on the spot)
 #define MOR_TR_MAXT 4096  // tracked moving centroids per stream (mo_vec); the reference has no bound — beyond this one the push reports MOR_ERR_CAPACITY
@@ -88,6 +88,7 @@ struct MorDev {
   int tiles;                 // ceil(max n_points of this batch / MOR_TILE)
   int tiles_m;               // workgroups per stream for kernels over the non-ground cloud / clusters: an estimate from the
                              // previous frame; those kernels grid-stride over the tiles a stream really has, so any value ≥ 1 is correct
+  int split_g;   // workgroups per stream of the two split passes (each walks tiles split_g apart)
   int g_fast, g_score, g_pde, g_box;   // launch widths: k_score_fast workgroups per cloud tile, workgroups per stream of the worklist tiers / the wave tier / k_cellboxes (MOR_TUNE)
   int xcd_map;               // 1: the workgroups of a stream share an XCD (its tables stay in that L2); 0: streams spread over all XCDs
   int split_variant;         // experiment bits of k_split: 1 = poll the look-back descriptors with agent-scope loads instead of read-modify-write atomics
@@ -126,7 +127,7 @@ struct MorDev {
   int *gh_key, *gh_val;      // [B][Hcell] hash path: the cell table of streams with more cells than the LDS table holds
   int grid_mode, gh_tier;   // grid_mode 0: points radix-sorted by cell key; 1: cells counted in a hash table (k_gridhash); gh_tier: table tier k_gridhash starts with (0 small LDS table, 1 big LDS table, 2 global memory)
   int *slab_y, *slab_c, *slab_e;    // [B][MOR_MAXP+1]  slabs of the cell graph: first y-slice, first compact cell id, end of the look-ahead (cells of the next two y-slices)
-  int P, cg_force_global;    // slabs per stream this frame; test knob: forests in global memory
+  int P, cg_force_global, cg_big;    // slabs per stream this frame; test knob: forests in global memory; big-slab variant of k_cg_slab
   int *lroot_a, *lroot_b;    // [B][Nmax]  per cell: its local root in its own slab / in the previous slab's look-ahead (compact ids)
   int *parent2;              // [B][Nmax]  second global forest (odd slabs when they do not fit LDS)
   int *skey, *sidx;          // aliases of the radix buffers holding the cell-sorted (key, cloud index)

@@ -83,6 +83,8 @@ struct mor_batch {
   // (The stage schedule — pieces on fixed streams — made the stream with the scoring tiers + tracking + filterCloud the
   // bottleneck: its kernels add up to 0.44 ms of a 0.45 ms period while the cell-graph stream idled half the time.)
   bool lanes = true; int n_lanes = 4;
+  hipStream_t extra[4] = {nullptr, nullptr, nullptr, nullptr};   // lanes 5 … 8 (MOR_LANES)
+  hipStream_t lane_stream(uint64_t k) const { const int i = (int)(k % (uint64_t)n_lanes); return i == 0 ? sf : i == 1 ? sc : i == 2 ? sm : i == 3 ? sb : extra[i - 4]; }
   hipEvent_t ev_track[MOR_MAX_SLOTS] = {};      // recorded after the tracking step of a push / a filterCloud
   hipEvent_t *last_track = nullptr;             // the latest of them
   hipStream_t last_filter_stream = nullptr;
@@ -94,7 +96,7 @@ struct mor_batch {
   MorStreamArgs *h_args_ring = nullptr, *h_args = nullptr;   // pinned ring of MOR_ARGS_RING slots (async pushes), current slot
   hipEvent_t args_ev[MOR_ARGS_RING] = {};
   uint64_t pipe_depth = 4, n_slots = 5;       // frames in flight (= copies of the per-frame arrays); cluster-array slots = depth + 1
-  int env_cg_p = 0;                          // tuning knob from the environment, read once at creation
+  int env_cg_p = 0, env_cg_big = -1, env_split_g = 0;         // tuning knobs from the environment, read once at creation
   bool async = false, pending = false;   // async: push/filter only enqueue; pending: work enqueued since the last wait
   unsigned char *d_moving = nullptr;
   float4 **h_outptrs = nullptr, **d_outptrs = nullptr;
@@ -207,6 +209,7 @@ static int configure(mor_batch *b) {
 static int wait_all_checked(mor_batch *b) {
   if (!b->pending) return MOR_OK;
   HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sc)); HIP_TRY(hipStreamSynchronize(b->sm)); HIP_TRY(hipStreamSynchronize(b->sb));
+  for (auto &x : b->extra) if (x) HIP_TRY(hipStreamSynchronize(x));
   b->pending = false;
   b->timer.collect();
   int rc = MOR_OK;
@@ -243,6 +246,7 @@ void mor_batch_destroy(mor_batch *b) {
   if (b->sc) hipStreamSynchronize(b->sc);
   if (b->sm) hipStreamSynchronize(b->sm);
   if (b->sb) hipStreamSynchronize(b->sb);
+  for (auto &x : b->extra) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
   for (auto &ev : b->args_ev) if (ev) hipEventDestroy(ev);
   for (auto &pe : b->ev_piece) for (auto &ev : pe) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->ev_back) if (ev) hipEventDestroy(ev);
@@ -272,6 +276,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (getenv("MOR_PIPE_DEPTH")) b->pipe_depth = std::min(MOR_MAX_DEPTH, std::max(1, atoi(getenv("MOR_PIPE_DEPTH"))));
   b->n_slots = b->pipe_depth + 1;
   if (getenv("MOR_CG_P")) b->env_cg_p = atoi(getenv("MOR_CG_P"));
+  if (getenv("MOR_SPLIT_G")) b->env_split_g = atoi(getenv("MOR_SPLIT_G"));
+  if (getenv("MOR_CG_BIG")) b->env_cg_big = atoi(getenv("MOR_CG_BIG")) != 0;
   if (const char *st = getenv("MOR_STAGES")) {   // tuning: stage stream (0…3) of each launch piece, e.g. 0012233; non-decreasing, last piece on stage 3
     bool okc = strlen(st) == MOR_N_PIECES;
     for (int i = 0; okc && i < MOR_N_PIECES; ++i) okc = st[i] >= '0' && st[i] <= '3' && (i == 0 || st[i] >= st[i - 1]);
@@ -290,7 +296,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   for (auto &ev : b->ev_track) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   if (getenv("MOR_SCHED") && !strcmp(getenv("MOR_SCHED"), "stages")) b->lanes = false;
   b->n_lanes = (int)std::min<uint64_t>(4, b->pipe_depth);
-  if (getenv("MOR_LANES")) b->n_lanes = std::max(1, std::min(b->n_lanes, atoi(getenv("MOR_LANES"))));
+  if (getenv("MOR_LANES")) b->n_lanes = std::max(1, std::min<int>((int)std::min<uint64_t>(8, b->pipe_depth), atoi(getenv("MOR_LANES"))));
+  for (int i = 4; i < b->n_lanes; ++i) if (hipStreamCreateWithFlags(&b->extra[i - 4], hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
   MorDev &d = b->d; const size_t B = d.B, N = d.Nmax, K = d.Kcap, T = d.tiles_max;
   bool ok = true;
   MorStreamArgs *dargs = nullptr;
@@ -395,7 +402,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     if (!c.on_device) max_host_bytes = std::max<size_t>(max_host_bytes, (size_t)c.n_points * c.point_step);
   }
   if (max_host_bytes > b->stage_stride) {   // (re)allocate the staging area for host-resident blobs
-    if (b->d_stage) { HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sc)); HIP_TRY(hipStreamSynchronize(b->sm)); HIP_TRY(hipStreamSynchronize(b->sb)); HIP_TRY(hipFree(b->d_stage)); b->d_stage = nullptr; }
+    if (b->d_stage) { b->pending = true; int rcw = wait_all_checked(b); if (rcw != MOR_OK) return rcw; HIP_TRY(hipFree(b->d_stage)); b->d_stage = nullptr; }
     b->stage_stride = (max_host_bytes + 255) & ~(size_t)255;
     HIP_TRY(hipMalloc((void **)&b->d_stage, b->stage_stride * B));
   }
@@ -413,11 +420,13 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     b->prev_pose[s] = cur[s];
   }
   d.tiles = std::max<int>(1, (int)((maxn + MOR_TILE - 1) / MOR_TILE));
+  d.split_g = b->env_split_g > 0 ? std::min(b->env_split_g, d.tiles) : d.tiles;
   d.fuse_scans = d.fuse_scans && d.tiles <= 2048;
   {  // cell graph: slabs per stream (k_cg_slab) — enough that a slab's cells fit its LDS with room for imbalance, and that
      // the launch fills the GPU (two 512-thread workgroups per CU)
-    uint32_t maxocc = 0;
-    for (int s = 0; s < B; ++s) maxocc = std::max(maxocc, k > 0 ? d.h_info[s].n_occ : 0u);
+    uint32_t maxocc = 0, maxloc = 0;
+    for (int s = 0; s < B; ++s) { maxocc = std::max(maxocc, k > 0 ? d.h_info[s].n_occ : 0u); maxloc = std::max(maxloc, k > 0 ? d.h_info[s].max_loc : 0u); }
+    d.cg_big = b->env_cg_big >= 0 ? b->env_cg_big : (maxloc > 1024u * 15 / 16);   // slabs near or beyond the LDS of the small variant last frame: the big one
     const int p_fit = (int)((maxocc * 3ull / 2 + 818) / 819), p_par = (512 + B - 1) / B;   // a slab's LDS holds 1024 cells (own + look-ahead); two 512-thread workgroups per CU
     d.P = b->env_cg_p > 0 ? b->env_cg_p : std::max(p_fit, p_par);
     d.P = std::max(1, std::min(d.P, std::min(MOR_MAXP, std::max(1, d.g.ny / 2))));
@@ -433,7 +442,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   //      frame k runs beside later pieces of frames k−1, k−2).  The first piece must not overwrite what frame k−depth still
   //      uses (same buffer copy; its cluster slot doubles as the `ca` slot of frame k−depth+1)
   hipStream_t S[4] = {b->sf, b->sc, b->sm, b->sb};
-  hipStream_t lane = S[k % b->n_lanes];
+  hipStream_t lane = b->lane_stream(k);
   hipStream_t s0 = b->lanes ? lane : S[b->stage_of[0]];
   {
     const uint64_t depth = b->pipe_depth;   // frames in flight = copies of the per-frame arrays
@@ -486,8 +495,7 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
                        // filterCloud on the same frame walks mo_vec again and moves the confidences again
   b->filtered = true;
   d.out_ptrs = nullptr;
-  hipStream_t S[4] = {b->sf, b->sc, b->sm, b->sb};
-  hipStream_t fs = b->lanes ? S[k % b->n_lanes] : b->sb;   // behind the frame's push
+  hipStream_t fs = b->lanes ? b->lane_stream(k) : b->sb;   // behind the frame's push
   if (b->lanes && b->last_track) HIP_TRY(hipStreamWaitEvent(fs, *b->last_track, 0));   // a second filterCloud of a frame, or the frame's own tracking step (same stream: free)
   if (out && out_on_device) {
     if (b->async && b->last_filter_stream) HIP_TRY(hipStreamSynchronize(b->last_filter_stream));   // the pinned pointer table may still be in flight

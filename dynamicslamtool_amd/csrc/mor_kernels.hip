@@ -211,14 +211,16 @@ __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, 
 __device__ __forceinline__ void reset_frame_info(const MorDev &d, int s) {
   if (d.gmode == 2) return;
   MorFrameInfo &f = d.info[s];
-  f.N = d.args[s].n; f.flags = 0; f.n_pairs = 0; f.K = 0; f.C = 0;
+  f.N = d.args[s].n; f.flags = 0; f.n_pairs = 0; f.K = 0; f.C = 0; f.max_loc = 0;
 }
 // ------------------------------------------------------------------------------------ G1: trim + ground split
 // pass 1: per-tile counts of (non-ground, ground)
 __global__ __launch_bounds__(MOR_BT) void k_classify(MorDev d) {
-  int s, t; map_block(d.B, d.tiles, s, t);
+  int s, t0; map_block(d.B, d.split_g, s, t0);
   const MorStreamArgs a = d.args[s];
   const uint32_t n_in = pass_count(d, a, s);
+  __shared__ int sh[8];
+  for (int t = t0; t < d.tiles; t += d.split_g) {   // split_g workgroups per stream walk its tiles: enough loads in flight for the HBM without holding every wave slot of the GPU
   uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
   int c_ng = 0, c_g = 0;
   float zlo = INFINITY, zhi = -INFINITY;
@@ -235,7 +237,6 @@ __global__ __launch_bounds__(MOR_BT) void k_classify(MorDev d) {
     for (int o = 32; o > 0; o >>= 1) { zlo = fminf(zlo, __shfl_xor(zlo, o, 64)); zhi = fmaxf(zhi, __shfl_xor(zhi, o, 64)); }
     if (lane_id() == 0 && zlo <= zhi) { atomicMin(&d.zmin_i[s], float_ordered(zlo)); atomicMax(&d.zmax_i[s], float_ordered(zhi)); }
   }
-  __shared__ int sh[8];
   if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -243,6 +244,8 @@ __global__ __launch_bounds__(MOR_BT) void k_classify(MorDev d) {
     int *o = d.tile_cnt + ((size_t)s * d.tiles_max + t) * 2;
     o[0] = sh[0] + sh[1] + sh[2] + sh[3];
     o[1] = sh[4] + sh[5] + sh[6] + sh[7];
+  }
+  __syncthreads();
   }
 }
 
@@ -273,11 +276,12 @@ __global__ __launch_bounds__(MOR_BT) void k_scan_tiles(MorDev d) {
 
 // pass 2: order-preserving split into `cloud` / ground, cell histogram, forest init
 __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
-  int s, t; map_block(d.B, d.tiles, s, t);
+  int s, t0; map_block(d.B, d.split_g, s, t0);
   const MorStreamArgs a = d.args[s];
   const uint32_t n_in = pass_count(d, a, s);
-  uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
   __shared__ int sh[8];
+  for (int t = t0; t < d.tiles; t += d.split_g) {
+  uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
   int r_ng = 0, r_g = 0; float zorg = d.zorg[s]; int zbase = d.zbase[s];
   if (d.fuse_scans) {   // own offsets from the per-tile counts of k_classify; tile 0 publishes the totals
     const int *tc = d.tile_cnt + (size_t)s * d.tiles_max * 2; int tot_ng, tot_g;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
     if (d.gmode == 1) { zorg = (tot_ng + tot_g) ? ordered_float(d.zmin_i[s]) : 0.f; zbase = (int)floorf(zorg * d.gv.inv_cs); }
     if (t == 0 && threadIdx.x == 0) publish_split(d, s, tot_ng, tot_g);
   }
-  if ((uint32_t)t * MOR_TILE >= n_in) return;
+  if ((uint32_t)t * MOR_TILE >= n_in) break;
   float4 p[8]; int cls[8]; unsigned long long m_ng[8], m_g[8];
   int c_ng = 0, c_g = 0;
 #pragma unroll
@@ -317,6 +321,8 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
       d.gp_idx[so + k_g] = k_ng + k_g;
     }
     r_ng += __popcll(m_ng[it]); r_g += __popcll(m_g[it]);
+  }
+  __syncthreads();
   }
 }
 
@@ -620,6 +626,7 @@ template <bool L> __device__ __forceinline__ void slab_bounds(const MorDev &d, i
     int *sy = d.slab_y + (size_t)s * (MOR_MAXP + 1), *sc = d.slab_c + (size_t)s * (MOR_MAXP + 1), *se = d.slab_e + (size_t)s * (MOR_MAXP + 1);
     sy[j] = sh[j]; sc[j] = gh_ld<L>(rows + sh[j] * nz);
     se[j] = j < P ? gh_ld<L>(rows + min(sh[j + 1] + 2, ny) * nz) : nocc;   // end of slab j's look-ahead (cells of the next two y-slices)
+    if (j < P) atomicMax(&d.info[s].max_loc, (unsigned)(se[j] - sc[j]));   // the host picks the kernel variant of the next frames by it
   }
   __syncthreads();
 }
@@ -1032,6 +1039,7 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
 #ifndef CGS_CAP
 #define CGS_CAP 1024      // local cells (own + look-ahead) held in LDS
 #endif
+#define CGS_CAP_BIG 2560  // the same for the big-slab variant of the kernel
 #define CGS_ROWCAP 2048   // local (y,z) rows held in LDS
 #ifndef CGS_LISTW
 #define CGS_LISTW 2048    // LDS words of the candidate-pair lists
@@ -1108,7 +1116,7 @@ __device__ __forceinline__ int pair_points_thread(const float4 *sp, int a0, int 
 // then, for the whole workgroup:
 //  B1  one thread per listed pair: roots re-checked, then the points (pair_points_thread).
 //  B2  one wave per pair the thread test could not finish (big cells): pruned exhaustive test.
-template <bool LDS> struct CgsCells { const int *key, *pc; const float *rx, *ry, *rz, *bx; };
+template <bool LDS> struct CgsCells { const int *key, *pc; const float *rx, *ry, *rz, *bx; int cap; };   // bx: six planes of `cap` floats
 template <bool LDS> __device__ __forceinline__ void cgs_hooks(const MorDev &d, size_t soc, int n_own, int n_loc, const CgsCells<LDS> &L, const int *start, const int *rows, int rsub, int r0, int nlrows,
                                                               int *par, const float4 *sp, int *ovf, int *l_list, int *l_queue, int *l_wcnt, int *l_n2, size_t stw) {
   const float r2 = d.r2;
@@ -1161,8 +1169,8 @@ template <bool LDS> __device__ __forceinline__ void cgs_hooks(const MorDev &d, s
       if (want) {
         float pax, pay, paz, alx, aly, alz, ahx, ahy, ahz, qx, qy, qz, blx, bly, blz, bhx, bhy, bhz;
         if (LDS) {
-          pax = L.rx[qa]; pay = L.ry[qa]; paz = L.rz[qa]; alx = L.bx[qa]; aly = L.bx[CGS_CAP + qa]; alz = L.bx[2 * CGS_CAP + qa]; ahx = L.bx[3 * CGS_CAP + qa]; ahy = L.bx[4 * CGS_CAP + qa]; ahz = L.bx[5 * CGS_CAP + qa];
-          qx = L.rx[qb]; qy = L.ry[qb]; qz = L.rz[qb]; blx = L.bx[qb]; bly = L.bx[CGS_CAP + qb]; blz = L.bx[2 * CGS_CAP + qb]; bhx = L.bx[3 * CGS_CAP + qb]; bhy = L.bx[4 * CGS_CAP + qb]; bhz = L.bx[5 * CGS_CAP + qb];
+          pax = L.rx[qa]; pay = L.ry[qa]; paz = L.rz[qa]; alx = L.bx[qa]; aly = L.bx[L.cap + qa]; alz = L.bx[2 * L.cap + qa]; ahx = L.bx[3 * L.cap + qa]; ahy = L.bx[4 * L.cap + qa]; ahz = L.bx[5 * L.cap + qa];
+          qx = L.rx[qb]; qy = L.ry[qb]; qz = L.rz[qb]; blx = L.bx[qb]; bly = L.bx[L.cap + qb]; blz = L.bx[2 * L.cap + qb]; bhx = L.bx[3 * L.cap + qb]; bhy = L.bx[4 * L.cap + qb]; bhz = L.bx[5 * L.cap + qb];
         } else {
           const float4 q = d.crep[soc + qa], lo = d.cmeta[2 * (soc + qa)], h4 = d.cmeta[2 * (soc + qa) + 1]; pax = q.x; pay = q.y; paz = q.z; alx = lo.x; aly = lo.y; alz = lo.z; ahx = h4.x; ahy = h4.y; ahz = h4.z;
           const float4 q2 = d.crep[soc + qb], lo2 = d.cmeta[2 * (soc + qb)], h42 = d.cmeta[2 * (soc + qb) + 1]; qx = q2.x; qy = q2.y; qz = q2.z; blx = lo2.x; bly = lo2.y; blz = lo2.z; bhx = h42.x; bhy = h42.y; bhz = h42.z;
@@ -1236,7 +1244,9 @@ template <bool LDS> __device__ __forceinline__ void cgs_body(const MorDev &d, in
   }
   ST2(stwj, 9); ST2V(stwj, 14, n_own); ST2V(stwj, 15, n_loc);
 }
-__global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {
+// CAP: local cells (own + look-ahead) the workgroup holds in LDS — CGS_CAP (76 KB, two workgroups per CU) for open scenes,
+// CGS_CAP_BIG (146 KB) when the previous frame had slabs beyond it (a façade across a y-slice puts > 1000 cells into it).
+template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {
   int s, j; map_block(d.B, d.P, s, j);
   const size_t so = (size_t)s * d.Nmax;
   const int *sy = d.slab_y + (size_t)s * (MOR_MAXP + 1), *sc = d.slab_c + (size_t)s * (MOR_MAXP + 1), *se = d.slab_e + (size_t)s * (MOR_MAXP + 1);
@@ -1245,30 +1255,30 @@ __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {
   const size_t stwj = (size_t)s * (MOR_MAXP + 2) + j; (void)stwj;
   ST2(stwj, 0);
   const int y0 = sy[j], y2 = min(sy[j + 1] + 2, d.g.ny), r0 = y0 * d.g.nz, nlrows = (y2 - y0) * d.g.nz;
-  __shared__ float l_rx[CGS_CAP], l_ry[CGS_CAP], l_rz[CGS_CAP], l_bx[6 * CGS_CAP];
-  __shared__ int l_key[CGS_CAP], l_par[CGS_CAP], l_pc[CGS_CAP], l_rows[CGS_ROWCAP + 1], l_list[CGS_LISTW], l_queue[CGS_NW * CGS_QW], l_wcnt[CGS_NW], l_n2;
+  __shared__ float l_rx[CAP], l_ry[CAP], l_rz[CAP], l_bx[6 * CAP];
+  __shared__ int l_key[CAP], l_par[CAP], l_pc[CAP], l_rows[CGS_ROWCAP + 1], l_list[CGS_LISTW], l_queue[CGS_NW * CGS_QW], l_wcnt[CGS_NW], l_n2;
   int *ovf = d.cg_ovf + (size_t)(s * MOR_MAXP + j) * MOR_CGS_OVF * 2;   // [0, MOR_CGS_OVF): the waves' candidate lists, [MOR_CGS_OVF, 2·MOR_CGS_OVF): pairs for whole waves
   const int *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1) + r0;
   if (threadIdx.x == 0) l_n2 = 0;
-  if (n_loc <= CGS_CAP && nlrows <= CGS_ROWCAP && !d.cg_force_global) {
+  if (n_loc <= CAP && nlrows <= CGS_ROWCAP && !d.cg_force_global) {
     const int *gk = d.ckey + so + c0; const float4 *grep = d.crep + so + c0, *gm = d.cmeta + 2 * (so + c0);
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) {
       const int k = gk[i], row = k / d.g.nx;
       l_key[i] = k; l_par[i] = i; l_pc[i] = (int)((unsigned)(k - row * d.g.nx) | ((unsigned)(row % d.g.nz) << 11) | ((unsigned)(row / d.g.nz) << 21));
       const float4 q = grep[i], lo = gm[2 * i], hi4 = gm[2 * i + 1];
       l_rx[i] = q.x; l_ry[i] = q.y; l_rz[i] = q.z;
-      l_bx[i] = lo.x; l_bx[CGS_CAP + i] = lo.y; l_bx[2 * CGS_CAP + i] = lo.z; l_bx[3 * CGS_CAP + i] = hi4.x; l_bx[4 * CGS_CAP + i] = hi4.y; l_bx[5 * CGS_CAP + i] = hi4.z;
+      l_bx[i] = lo.x; l_bx[CAP + i] = lo.y; l_bx[2 * CAP + i] = lo.z; l_bx[3 * CAP + i] = hi4.x; l_bx[4 * CAP + i] = hi4.y; l_bx[5 * CAP + i] = hi4.z;
     }
     for (int i = threadIdx.x; i <= nlrows; i += CGS_T) l_rows[i] = g_rows[i] - c0;
     __syncthreads();
-    const CgsCells<true> L = {l_key, l_pc, l_rx, l_ry, l_rz, l_bx};
+    const CgsCells<true> L = {l_key, l_pc, l_rx, l_ry, l_rz, l_bx, CAP};
     cgs_body<true>(d, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
   } else {   // slab too big for LDS: the same code on global arrays (even and odd slabs use different forests: look-aheads overlap the next slab)
     int *par = ((j & 1) ? d.parent2 : d.parent) + so + c0;
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) cg_st<false>(par + i, i);
     __threadfence();
     __syncthreads();
-    const CgsCells<false> L = {d.ckey + so + c0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const CgsCells<false> L = {d.ckey + so + c0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     cgs_body<false>(d, s, so, c0, n_own, n_loc, L, g_rows, c0, r0, nlrows, par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
   }
 }
@@ -1769,6 +1779,21 @@ __device__ __forceinline__ void scan4s(const float4 *sp, int b, int e, const flo
     if (best < stopv) return;
   }
 }
+// The same over a cell of more than `budget` points, sampled evenly: positions b, b+step, b+2·step, …  Points arrive in a
+// cell in scan order, so the first 64 of a 1000-point cell all come from one corner of it; an even sample of the whole
+// cell finds a point within √lb of q (if there is one: on a dense static surface ≈ 6 % of the cell's points qualify)
+// nearly always, and only genuine misses go on to the wave tier, which scans the whole cell.
+__device__ __forceinline__ void scan4_sampled(const float4 *sp, int b, int e, const float4 &q, float stopv, float &best, int &budget) {
+  const int n = e - b, step = max(n / budget, 1);
+  for (int k = 0; k < n && budget > 0; k += 4 * step, budget -= 4) {
+    float4 p0 = sp[b + k], p1 = sp[b + min(k + step, n - 1)], p2 = sp[b + min(k + 2 * step, n - 1)], p3 = sp[b + min(k + 3 * step, n - 1)];
+    best = fminf(best, sqdist(q.x, q.y, q.z, p0.x, p0.y, p0.z));
+    best = fminf(best, sqdist(q.x, q.y, q.z, p1.x, p1.y, p1.z));
+    best = fminf(best, sqdist(q.x, q.y, q.z, p2.x, p2.y, p2.z));
+    best = fminf(best, sqdist(q.x, q.y, q.z, p3.x, p3.y, p3.z));
+    if (best < stopv) return;
+  }
+}
 // Which neighbour cells can hold a point within √lb of q: per axis −1 / +1 when q lies within `slb` (√lb, padded for
 // the rounding of the cell map) of the low / high wall of its cell, else 0.  Valid when 2·slb < cell edge.
 __device__ __forceinline__ int near_side(float v, float o, float inv, float cs, int c, float slb) {
@@ -1814,6 +1839,10 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
   for (int base = t0 * MOR_BT; base < Cp; base += d.tiles_m * d.g_fast * MOR_BT) {
     const int j = base + threadIdx.x;
     bool nearq = false, blockq = false, big = false, counted = false; float best = INFINITY; int pr = -1, target = -1;
+    RS_T(f0);
+#ifdef MOR_EXP_STAMPS
+    unsigned long long f1 = f0, f2 = f0;
+#endif
     if (j < Cp) {
       // two chains of dependent loads, issued side by side (no branch between them): cluster → pair → matched cluster → its box,
       // and point → cell → hash probe → cell record → points.  (One after the other they were seven levels deep.)
@@ -1828,10 +1857,13 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
       const int cc = max(c, 0), cid = d.ccid[so + cc], b0 = st[cc], e0 = st[cc + 1];
       target = min(max(d.pair_m[ko + max(pr, 0)], 0), d.Kcap - 1);   // (pr < 0: a stale entry, clamped — its box is loaded but not used)
       const float4 tlo = d.amin[d.cur][ko + target], thi = d.amax[d.cur][ko + target];
+#ifdef MOR_EXP_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f1 = wall_clock64();
+#endif
       if (pr >= 0) {
-        int budget = 64;   // a big own cell that shows no close point within its first 64 goes to the wave tier
+        int budget = (d.split_variant & 256) ? 8 : (d.split_variant & 512) ? 0 : 64;   // a big own cell that shows no close point within its first 64 goes to the wave tier (experiment bits: timing only, wrong scores)
         const bool reach = box_dist2(q, tlo, thi) < d.pde_ub;   // farther than √ub from the whole matched cluster: never counted
-        if (reach && c >= 0 && cid == target) { scan4s(sp, b0, e0, q, lbn, best, budget); big = best > d.pde_lb && e0 - b0 > 64; }
+        if (reach && c >= 0 && cid == target) { if (d.split_variant & 1024) scan4s(sp, b0, e0, q, lbn, best, budget); else scan4_sampled(sp, b0, e0, q, lbn, best, budget); big = best > d.pde_lb && e0 - b0 > 64; }
         if (reach && best > d.pde_lb && !big) {
           if (!e1_local) big = true;   // √lb reaches beyond the adjacent half-cells in this configuration: wave tier
           else if (best < d.pde_ub) {
@@ -1841,11 +1873,19 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
           } else blockq = true;
         }
       } else target = -1;
+#ifdef MOR_EXP_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f2 = wall_clock64();
+#endif
     }
     count_push(counted, d.pair_cnt + ko, pr);
     wl_push(nearq, &d.wl_n[s], d.wl + so, j, pr, target);
     wl_push(blockq, &d.wlb_n[s], d.wl + so, j, pr, target, true, d.Nmax);
     wl_push(big, &d.wl2_n[s], d.wl2 + so, j, pr, target);
+#ifdef MOR_EXP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    { const int n_near = __popcll(__ballot(nearq)), n_block = __popcll(__ballot(blockq)), n_big = __popcll(__ballot(big));
+      if (lane_id() == 0 && base < Cp) { const unsigned long long f3 = wall_clock64(); RS_ADD(8, 1); RS_ADD(9, f1 - f0); RS_ADD(10, f2 - f1); RS_ADD(11, f3 - f2); RS_MAX(12, f3 - f0); RS_ADD(13, n_near); RS_ADD(14, n_block); RS_ADD(15, n_big); } }
+#endif
   }
 }
 // one batch of four cells: box records and point ranges with independent loads, then the scans.  A cell is scanned up
@@ -1863,16 +1903,15 @@ __device__ __forceinline__ void scan_batch4(const MorDev &d, size_t so, const in
     else if (!(best < d.pde_ub) && bd < d.pde_ub) scan4s(sp, b0[i], e0[i], q, d.pde_ub, best, budget);
   }
 }
-// Which worklist entry a thread of the worklist tiers takes in the pass starting at w0 (= pass·G·256 + bx·256).  A stream's
-// list holds a few thousand entries — a few workgroups' worth if handed out 256 at a time, and those few CUs then carry
-// all the divergent gathers of the tier (measured: 112 µs → 73 µs for k_score_block alone).  So the entries of a pass are
-// dealt over ALL G workgroups: entry e → workgroup e % G (default), or in chunks of 64 (variant 64: waves keep
-// neighbouring queries).
-__device__ __forceinline__ int wl_entry(const MorDev &d, int w0, int bx) {
-  const int p0 = w0 - bx * MOR_BT;
-  if (d.split_variant & 32) return w0 + threadIdx.x;
+// Which worklist entry a thread of the worklist tiers takes in the pass starting at entry p0 (a pass = G·256 entries, nq
+// entries in all).  Default: 256 consecutive entries per workgroup.  (Measured alternatives, MOR_SPLIT_VARIANT 32 / 64 / 128:
+// entry e → workgroup e % G; chunks of 64 dealt over the workgroups; lanes of a wave nrows apart.)
+__device__ __forceinline__ int wl_entry(const MorDev &d, int p0, int bx, int nq) {
+  if (d.split_variant & 32) return p0 + threadIdx.x * d.g_score + bx;
   if (d.split_variant & 64) return p0 + ((threadIdx.x >> 6) * d.g_score + bx) * 64 + (threadIdx.x & 63);
-  return p0 + threadIdx.x * d.g_score + bx;
+  const int w = p0 + bx * MOR_BT + threadIdx.x;
+  if (d.split_variant & 128) { const int nrows = (nq + 63) >> 6; return w < nrows * 64 ? (w & 63) * nrows + (w >> 6) : nq; }
+  return w;
 }
 // Tier 1a — one THREAD per query with E2 known (worklist front).  E1: only the ≤ 7 neighbour cells across the walls q
 // is close to can hold a point within √lb (the own cell was scanned by tier 1).  Three levels of loads: hash probes →
@@ -1886,8 +1925,8 @@ __global__ __launch_bounds__(MOR_BT) void k_score_near(MorDev d) {
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + d.g.cs * 1e-3f;
-  for (int w0 = bx * MOR_BT; w0 < nq; w0 += d.g_score * MOR_BT) {
-    const int w = (d.split_variant & 128) ? w0 + threadIdx.x : wl_entry(d, w0, bx);
+  for (int p0 = 0; p0 < ((nq + 63) & ~63); p0 += d.g_score * MOR_BT) {
+    const int w = wl_entry(d, p0, bx, nq);
     bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
     if (w < nq) {
       const int4 we = d.wl[so + w]; j = we.x; pr = we.y; target = we.z;
@@ -1912,6 +1951,9 @@ __global__ __launch_bounds__(MOR_BT) void k_score_near(MorDev d) {
       if ((cb2[0] >= 0 || cb2[1] >= 0 || cb2[2] >= 0) && best > d.pde_lb) scan_batch4(d, so, st, sp, cb2, target, true, q, lbn, best, budget);
       if (best > d.pde_lb) { if (budget <= 0) defer = true; else counted = true; }
     }
+#ifdef MOR_EXP_STAMPS
+    { const int nd = __popcll(__ballot(defer)); if (lane_id() == 0 && nd) RS_ADD(0, nd); }
+#endif
     count_push(counted, d.pair_cnt + ko, pr);
     wl_push(defer, &d.wl2_n[s], d.wl2 + so, j, pr, target);
   }
@@ -1930,9 +1972,12 @@ __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
   const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + d.g.cs * 1e-3f;
   const bool stencil27 = d.n_rows <= 9 && d.score_R <= 1;   // the whole search stencil is the 3×3×3 block
-  for (int w0 = bx * MOR_BT; w0 < nq; w0 += d.g_score * MOR_BT) {
-    const int w = wl_entry(d, w0, bx);
+  for (int p0 = 0; p0 < ((nq + 63) & ~63); p0 += d.g_score * MOR_BT) {
+    const int w = wl_entry(d, p0, bx, nq);
     bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
+#ifdef MOR_EXP_STAMPS
+    bool dbg_budget = false, dbg_nocand = false;
+#endif
     if (w < nq) {
       const int4 we = d.wl[so + d.Nmax - 1 - w]; j = we.x; pr = we.y; target = we.z;
       const float4 q = d.cl_pts[pv][so + j];
@@ -1980,7 +2025,13 @@ __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
         else if (best < d.pde_ub) counted = true;   // all cells that can hold a point within √lb were among the slots
         else if (!(stencil27 && ncand <= 8)) defer = true;              // E2 still open: wider search
       }
+#ifdef MOR_EXP_STAMPS
+      dbg_budget = defer && budget <= 0; dbg_nocand = defer && ncand == 0;
+#endif
     }
+#ifdef MOR_EXP_STAMPS
+    { const int n1 = __popcll(__ballot(dbg_budget)), n2 = __popcll(__ballot(defer && !dbg_budget)), n3 = __popcll(__ballot(dbg_nocand)); if (lane_id() == 0) { RS_ADD(1, n1); RS_ADD(2, n2); RS_ADD(3, n3); } }
+#endif
     count_push(counted, d.pair_cnt + ko, pr);
     wl_push(defer, &d.wl2_n[s], d.wl2 + so, j, pr, target);
   }
@@ -2735,9 +2786,10 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
     (void)hipMemsetAsync(d.split_desc + (size_t)d.s0 * d.tiles_max, 0, (size_t)d.B * d.tiles_max * sizeof(unsigned long long), st);
     MOR_LAUNCH(MK_SPLIT, k_split, gT, d);
   } else {
-    MOR_LAUNCH(MK_CLASSIFY, k_classify, gT, d);
+    const dim3 gS(d.B * d.split_g);
+    MOR_LAUNCH(MK_CLASSIFY, k_classify, gS, d);
     if (!d.fuse_scans) MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
-    MOR_LAUNCH(MK_SCATTER, k_scatter, gT, d);
+    MOR_LAUNCH(MK_SCATTER, k_scatter, gS, d);
   }
   if (d.grid_mode == 1 && d.gmode != 1) {   // clustering grid by counting (k_gridhash); the VoxelGrid pass of the voxel ground variant needs the points of a voxel in index order: sort
     mor_timer_begin(tm, MK_GRIDHASH, st);
@@ -2792,7 +2844,8 @@ static void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm)
 
 static void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   mor_timer_begin(tm, MK_CG_SLAB, st);
-  hipLaunchKernelGGL(k_cg_slab, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
+  if (d.cg_big) hipLaunchKernelGGL(k_cg_slab<CGS_CAP_BIG>, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
+  else hipLaunchKernelGGL(k_cg_slab<CGS_CAP>, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
   mor_timer_end(tm, MK_CG_SLAB, st);
   mor_timer_begin(tm, MK_CG_FINAL, st);
   hipLaunchKernelGGL(k_cg_final, dim3(d.B), dim3(CGF_T), 0, st, d);
