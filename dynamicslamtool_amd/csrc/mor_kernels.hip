@@ -457,6 +457,29 @@ __device__ __forceinline__ int hash_resolve(const unsigned long long *tab, unsig
     sl = (sl + 1) & mask; e = tab[sl];
   }
 }
+// N lookups of one thread resolved in LOCK-STEP: round r loads probe r of every lookup still open (independent loads), so
+// a thread waits max-over-lookups round trips, not their sum.  (Resolved one after the other — N while-loops in program
+// order — the 26 neighbour lookups of k_score_block cost a wave 30 µs: most of them are unsuccessful searches, ≈ 1.7 probes
+// each at load 1/3 and a long tail; the wave pays the sum for its unluckiest lane.)  key < 0: no lookup; ent = first probes.
+template <int N> __device__ __forceinline__ void hash_resolve_all(const unsigned long long *tab, unsigned hshift, const int (&key)[N], int (&id)[N]) {
+  const unsigned mask = (1u << (32 - hshift)) - 1u;
+  const unsigned *t32 = reinterpret_cast<const unsigned *>(tab);   // entry = (low word: compact id, high word: key + 1)
+  unsigned open = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) { id[i] = -1; if (key[i] >= 0) open |= 1u << i; }
+  for (unsigned r = 0; open; ++r) {   // every open lookup is at its r-th probe
+    unsigned kw[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) kw[i] = t32[2 * ((hash_slot(max(key[i], 0), hshift) + r) & mask) + 1];   // (closed lookups re-read their last slot: no branch around the loads)
+#pragma unroll
+    for (int i = 0; i < N; ++i) if ((open >> i) & 1u) {
+      if (kw[i] == 0u) open &= ~(1u << i);
+      else if (kw[i] == (unsigned)key[i] + 1u) { id[i] = (int)((hash_slot(key[i], hshift) + r) & mask); open &= ~(1u << i); }   // slot for now; its id is fetched below
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) if (id[i] >= 0) id[i] = (int)t32[2 * id[i]];
+}
 __device__ __forceinline__ int hash_find(const unsigned long long *tab, unsigned hshift, int key) {
   const unsigned sl = hash_slot(key, hshift);
   return hash_resolve(tab, hshift, key, sl, tab[sl]);
@@ -676,7 +699,11 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
   if (l_misc[1]) { __syncthreads(); return false; }
   const int nocc = l_misc[0];
   ST2(stw, 1);
-  if (chash) for (int i = tid; i < H; i += GH_T) chash[i] = 0ull;   // the scoring tiers' cell hash = this table with compact ids (entries follow below)
+  // the scoring tiers' cell hash: a table of its own in global memory, eight slots per cell (neighbour lookups are mostly
+  // UNSUCCESSFUL searches — ≈ 4 probes each at the load of this workgroup's LDS table, ≈ 1.1 at 1/8 — and a wave waits for the
+  // longest of its 64 × 26); cleared here, filled by k_gridfill
+  int xbits = 12; while ((1 << xbits) < 8 * nocc && (1 << xbits) < d.Hcell) ++xbits;
+  if (chash) for (int i = tid; i < (1 << xbits); i += GH_T) chash[i] = 0ull;
   // ---- cells per row → row table
   for (int r = tid; r <= nrows; r += GH_T) gh_st<RL>(rows + r, 0);
   __syncthreads();
@@ -709,7 +736,6 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
     for (int q = b; q < e2; ++q) c += gh_ld<CL>(rowlist + q) < x;
     ckey[c] = key;
     gh_st<TL>(tkey + sl, c + 1);
-    if (chash) chash[sl] = ((unsigned long long)(unsigned)k << 32) | (unsigned)c;
   }
   __syncthreads();
   // ---- point counts in id order (same memory as the row lists) → first position of every cell
@@ -718,7 +744,7 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
   __syncthreads();
   gh_scan<CL>(cnt, nocc, l_sh);
   for (int c = tid; c < nocc; c += GH_T) cstart[c] = gh_ld<CL>(cnt + c);
-  if (tid == 0) { cstart[nocc] = M; d.info[s].n_occ = nocc; d.info[s].hshift = hshift; }
+  if (tid == 0) { cstart[nocc] = M; d.info[s].n_occ = nocc; d.info[s].hshift = 32 - xbits; }
   for (int e = tid; e < nocc; e += GH_T) { const int sl = gh_ld<CL>(cells + e); gh_st<TL>(tval + sl, gh_ld<CL>(cnt + gh_ld<TL>(tkey + sl) - 1)); }
   __syncthreads();
   ST2(stw, 2);
@@ -842,7 +868,16 @@ __global__ __launch_bounds__(MOR_BT) void k_gridfill(MorDev d) {
     d.sorted[so + pos] = q; d.scell[so + pos] = d.pcell[so + i];
   }
   const int *cstart = d.cstart + (size_t)s * (d.Nmax + 1);
-  for (int c = t0 * MOR_BT + threadIdx.x; c < nocc; c += d.tiles_m * MOR_BT) cell_init_if_spanning(d, so, cstart, c);
+  unsigned long long *tab = d.use_hash ? d.chash + (size_t)s * d.Hcell : nullptr;
+  const unsigned hshift = d.info[s].hshift, hmask = (1u << (32 - hshift)) - 1u;
+  for (int c = t0 * MOR_BT + threadIdx.x; c < nocc; c += d.tiles_m * MOR_BT) {
+    cell_init_if_spanning(d, so, cstart, c);
+    if (tab) {   // cell hash entry: (key + 1, compact id); the table was cleared by k_gridhash
+      const int key = d.ckey[so + c]; unsigned sl = hash_slot(key, hshift);
+      const unsigned long long ent = ((unsigned long long)((unsigned)key + 1u) << 32) | (unsigned)c;
+      while (atomicCAS(&tab[sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
+    }
+  }
 }
 // (sort path of the grid: the same initialisation as its own small launch)
 __global__ __launch_bounds__(MOR_BT) void k_cellinit(MorDev d) {
@@ -1035,12 +1070,16 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
 // that range, the LOCAL root.  A forest is equivalent to the edge set {(c, root(c))}, so k_cg_final re-unites
 // (c, root_own(c)) and (c, root_lookahead-of-the-previous-slab(c)) in one forest per stream and gets exactly the
 // components of the full edge set — every edge was found by the slab owning its lower-y cell.
+#ifndef CGS_T
 #define CGS_T 512
+#endif
 #ifndef CGS_CAP
 #define CGS_CAP 1024      // local cells (own + look-ahead) held in LDS
 #endif
 #define CGS_CAP_BIG 2560  // the same for the big-slab variant of the kernel
+#ifndef CGS_ROWCAP
 #define CGS_ROWCAP 2048   // local (y,z) rows held in LDS
+#endif
 #ifndef CGS_LISTW
 #define CGS_LISTW 2048    // LDS words of the candidate-pair lists
 #endif
@@ -1285,7 +1324,9 @@ template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) 
 // One workgroup per stream: merges the slab forests, then components (size, smallest cloud index), the kept clusters
 // (:215-216), their order, per-cell cluster ids, offsets — the tail of the former one-workgroup kernel.
 #define CGF_T 1024
+#ifndef CGF_CAP
 #define CGF_CAP 12288
+#endif
 template <bool LDS> __device__ __forceinline__ void cgf_body(const MorDev &d, int s, int nocc, int *par, int *size, int *mn, int *cidr, int *l_misc, const int *l_sc, const int *l_se) {
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1);
@@ -1769,28 +1810,32 @@ __device__ __forceinline__ float box_dist2(const float4 &q, const float4 &lo, co
   return (gx * gx + gy * gy + gz * gz) * 0.999f;   // conservative
 }
 // scan sorted positions [b,e) (one cell of the matched cluster), four independent loads at a time; returns as soon as best < stopv
-__device__ __forceinline__ void scan4s(const float4 *sp, int b, int e, const float4 &q, float stopv, float &best, int &budget) {
-  for (int k = b; k < e && budget > 0; k += 4, budget -= 4) {
-    float4 p0 = sp[k], p1 = sp[min(k + 1, e - 1)], p2 = sp[min(k + 2, e - 1)], p3 = sp[min(k + 3, e - 1)];
-    best = fminf(best, sqdist(q.x, q.y, q.z, p0.x, p0.y, p0.z));
-    best = fminf(best, sqdist(q.x, q.y, q.z, p1.x, p1.y, p1.z));
-    best = fminf(best, sqdist(q.x, q.y, q.z, p2.x, p2.y, p2.z));
-    best = fminf(best, sqdist(q.x, q.y, q.z, p3.x, p3.y, p3.z));
+template <int W> __device__ __forceinline__ void scan_ws(const float4 *sp, int b, int e, const float4 &q, float stopv, float &best, int &budget) {
+  for (int k = b; k < e && budget > 0; k += W, budget -= W) {
+    float4 p[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) p[u] = sp[min(k + u, e - 1)];
+#pragma unroll
+    for (int u = 0; u < W; ++u) best = fminf(best, sqdist(q.x, q.y, q.z, p[u].x, p[u].y, p[u].z));
     if (best < stopv) return;
   }
 }
+__device__ __forceinline__ void scan4s(const float4 *sp, int b, int e, const float4 &q, float stopv, float &best, int &budget) { scan_ws<4>(sp, b, e, q, stopv, best, budget); }
+// (a wave pays for its slowest lane, and nearly every wave has a lane that goes through its whole budget: eight loads per
+//  round trip halve the dependent levels of that lane)
+__device__ __forceinline__ void scan8s(const float4 *sp, int b, int e, const float4 &q, float stopv, float &best, int &budget) { scan_ws<8>(sp, b, e, q, stopv, best, budget); }
 // The same over a cell of more than `budget` points, sampled evenly: positions b, b+step, b+2·step, …  Points arrive in a
 // cell in scan order, so the first 64 of a 1000-point cell all come from one corner of it; an even sample of the whole
 // cell finds a point within √lb of q (if there is one: on a dense static surface ≈ 6 % of the cell's points qualify)
 // nearly always, and only genuine misses go on to the wave tier, which scans the whole cell.
-__device__ __forceinline__ void scan4_sampled(const float4 *sp, int b, int e, const float4 &q, float stopv, float &best, int &budget) {
+__device__ __forceinline__ void scan_sampled(const float4 *sp, int b, int e, const float4 &q, float stopv, float &best, int &budget) {
   const int n = e - b, step = max(n / budget, 1);
-  for (int k = 0; k < n && budget > 0; k += 4 * step, budget -= 4) {
-    float4 p0 = sp[b + k], p1 = sp[b + min(k + step, n - 1)], p2 = sp[b + min(k + 2 * step, n - 1)], p3 = sp[b + min(k + 3 * step, n - 1)];
-    best = fminf(best, sqdist(q.x, q.y, q.z, p0.x, p0.y, p0.z));
-    best = fminf(best, sqdist(q.x, q.y, q.z, p1.x, p1.y, p1.z));
-    best = fminf(best, sqdist(q.x, q.y, q.z, p2.x, p2.y, p2.z));
-    best = fminf(best, sqdist(q.x, q.y, q.z, p3.x, p3.y, p3.z));
+  for (int k = 0; k < n && budget > 0; k += 8 * step, budget -= 8) {
+    float4 p[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] = sp[b + min(k + u * step, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) best = fminf(best, sqdist(q.x, q.y, q.z, p[u].x, p[u].y, p[u].z));
     if (best < stopv) return;
   }
 }
@@ -1863,7 +1908,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
       if (pr >= 0) {
         int budget = (d.split_variant & 256) ? 8 : (d.split_variant & 512) ? 0 : 64;   // a big own cell that shows no close point within its first 64 goes to the wave tier (experiment bits: timing only, wrong scores)
         const bool reach = box_dist2(q, tlo, thi) < d.pde_ub;   // farther than √ub from the whole matched cluster: never counted
-        if (reach && c >= 0 && cid == target) { if (d.split_variant & 1024) scan4s(sp, b0, e0, q, lbn, best, budget); else scan4_sampled(sp, b0, e0, q, lbn, best, budget); big = best > d.pde_lb && e0 - b0 > 64; }
+        if (reach && c >= 0 && cid == target) { if (d.split_variant & 1024) scan4s(sp, b0, e0, q, lbn, best, budget); else scan_sampled(sp, b0, e0, q, lbn, best, budget); big = best > d.pde_lb && e0 - b0 > 64; }
         if (reach && best > d.pde_lb && !big) {
           if (!e1_local) big = true;   // √lb reaches beyond the adjacent half-cells in this configuration: wave tier
           else if (best < d.pde_ub) {
@@ -1899,8 +1944,8 @@ __device__ __forceinline__ void scan_batch4(const MorDev &d, size_t so, const in
   for (int i = 0; i < 4; ++i) {
     if (c4[i] < 0 || (check_target && __float_as_int(blo[i].w) != target) || !(best > d.pde_lb) || budget <= 0) continue;
     const float bd = box_dist2(q, blo[i], bhi[i]);
-    if (bd < lbn) scan4s(sp, b0[i], e0[i], q, lbn, best, budget);
-    else if (!(best < d.pde_ub) && bd < d.pde_ub) scan4s(sp, b0[i], e0[i], q, d.pde_ub, best, budget);
+    if (bd < lbn) scan8s(sp, b0[i], e0[i], q, lbn, best, budget);
+    else if (!(best < d.pde_ub) && bd < d.pde_ub) scan8s(sp, b0[i], e0[i], q, d.pde_ub, best, budget);
   }
 }
 // Which worklist entry a thread of the worklist tiers takes in the pass starting at entry p0 (a pass = G·256 entries, nq
@@ -1935,17 +1980,15 @@ __global__ __launch_bounds__(MOR_BT) void k_score_near(MorDev d) {
       const int sx = near_side(q.x, d.g.ox, d.g.inv_cs, d.g.cs, cx, slb), sy = near_side(q.y, d.g.oy, d.g.inv_cs, d.g.cs, cy, slb), sz = near_side(q.z, d.zorg[s], d.g.inv_cs, d.g.cs, cz, slb);
       int budget = d.t1_budget; float best = 0.5f * (d.pde_lb + d.pde_ub) ;   // any value inside (lb, ub): E2 holds
       if (!(best > d.pde_lb && best < d.pde_ub)) best = d.pde_ub * 0.999f;
-      int key[8]; unsigned sl[8]; unsigned long long ent[8]; int id[8];
+      int key[8]; int id[8];
+      key[0] = -1;
 #pragma unroll
       for (int i = 1; i < 8; ++i) {
         const int ax = i & 1, ay = (i >> 1) & 1, az = i >> 2;
         const bool valid = !(ax && sx == 0) && !(ay && sy == 0) && !(az && sz == 0);
         key[i] = valid ? cell_key(d.g, cx + ax * sx, cy + ay * sy, cz + az * sz) : -1;
-        sl[i] = hash_slot(max(key[i], 0), hshift); ent[i] = tab[sl[i]];
       }
-      id[0] = -1;
-#pragma unroll
-      for (int i = 1; i < 8; ++i) id[i] = key[i] >= 0 ? hash_resolve(tab, hshift, key[i], sl[i], ent[i]) : -1;
+      hash_resolve_all<8>(tab, hshift, key, id);
       const int ca[4] = {id[1], id[2], id[4], id[3]}, cb2[4] = {id[5], id[6], id[7], -1};   // face neighbours first
       scan_batch4(d, so, st, sp, ca, target, true, q, lbn, best, budget);
       if ((cb2[0] >= 0 || cb2[1] >= 0 || cb2[2] >= 0) && best > d.pde_lb) scan_batch4(d, so, st, sp, cb2, target, true, q, lbn, best, budget);
@@ -1977,6 +2020,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
     bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
 #ifdef MOR_EXP_STAMPS
     bool dbg_budget = false, dbg_nocand = false;
+    const unsigned long long g0 = wall_clock64(); unsigned long long g1 = g0, g2 = g0, g3 = g0, g4 = g0;
 #endif
     if (w < nq) {
       const int4 we = d.wl[so + d.Nmax - 1 - w]; j = we.x; pr = we.y; target = we.z;
@@ -1986,15 +2030,14 @@ __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
       int budget = d.t1_budget; float best = INFINITY;
       int id[27];
       {
-        int key[27]; unsigned long long ent[27];
+        int key[27];
 #pragma unroll
-        for (int i = 0; i < 27; ++i) {
-          key[i] = i == 13 ? -1 : cell_key(d.g, cx + i % 3 - 1, cy + (i / 3) % 3 - 1, cz + i / 9 - 1);
-          ent[i] = tab[hash_slot(max(key[i], 0), hshift)];
-        }
-#pragma unroll
-        for (int i = 0; i < 27; ++i) id[i] = key[i] >= 0 ? hash_resolve(tab, hshift, key[i], hash_slot(key[i], hshift), ent[i]) : -1;
+        for (int i = 0; i < 27; ++i) key[i] = i == 13 ? -1 : cell_key(d.g, cx + i % 3 - 1, cy + (i / 3) % 3 - 1, cz + i / 9 - 1);
+        hash_resolve_all<27>(tab, hshift, key, id);
       }
+#ifdef MOR_EXP_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g1 = wall_clock64();
+#endif
       int mc[8]; int ncand = 0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) mc[i] = -1;
@@ -2015,11 +2058,17 @@ __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
             }
           }
       }
+#ifdef MOR_EXP_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g2 = wall_clock64();
+#endif
       if (ncand > 0) {
         const int ca[4] = {mc[0], mc[1], mc[2], mc[3]}, cb2[4] = {mc[4], mc[5], mc[6], mc[7]};
         scan_batch4(d, so, st, sp, ca, target, false, q, lbn, best, budget);
         if (ncand > 4 && best > d.pde_lb) scan_batch4(d, so, st, sp, cb2, target, false, q, lbn, best, budget);
       }
+#ifdef MOR_EXP_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g3 = wall_clock64();
+#endif
       if (best > d.pde_lb) {
         if (budget <= 0) defer = true;
         else if (best < d.pde_ub) counted = true;   // all cells that can hold a point within √lb were among the slots
@@ -2034,6 +2083,11 @@ __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
 #endif
     count_push(counted, d.pair_cnt + ko, pr);
     wl_push(defer, &d.wl2_n[s], d.wl2 + so, j, pr, target);
+#ifdef MOR_EXP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); g4 = wall_clock64();
+    if (lane_id() == 0 && __ballot(w < nq)) { RS_ADD(4, 1); RS_ADD(5, g1 - g0); RS_ADD(6, g2 - g1); RS_ADD(7, g3 - g2); }
+    (void)g4;
+#endif
   }
 }
 __device__ __forceinline__ float wave_min(float v) {
@@ -2049,10 +2103,10 @@ __device__ __forceinline__ float wave_min(float v) {
 // at d² ≥ ub is never counted), and so does best ≤ lb.
 __device__ __forceinline__ float wave_scan_cell(const float4 *sp, int b0, int e0, const float4 &q, float lbv, int lane) {
   float local = INFINITY;
-  for (int k0 = b0; k0 < e0; k0 += 128) {
-    int k = k0 + lane, k2 = k + 64;
-    float4 p = sp[min(k, e0 - 1)], p2 = sp[min(k2, e0 - 1)];
-    local = fminf(local, fminf(sqdist(q.x, q.y, q.z, p.x, p.y, p.z), sqdist(q.x, q.y, q.z, p2.x, p2.y, p2.z)));
+  for (int k0 = b0; k0 < e0; k0 += 256) {   // four loads per lane and round trip: a cell of 3000 points is 12 dependent levels, not 24
+    const int k = k0 + lane;
+    const float4 p = sp[min(k, e0 - 1)], p2 = sp[min(k + 64, e0 - 1)], p3 = sp[min(k + 128, e0 - 1)], p4 = sp[min(k + 192, e0 - 1)];
+    local = fminf(fminf(local, fminf(sqdist(q.x, q.y, q.z, p.x, p.y, p.z), sqdist(q.x, q.y, q.z, p2.x, p2.y, p2.z))), fminf(sqdist(q.x, q.y, q.z, p3.x, p3.y, p3.z), sqdist(q.x, q.y, q.z, p4.x, p4.y, p4.z)));
     if (__ballot(local <= lbv)) break;
   }
   return wave_min(local);

@@ -20,3 +20,5 @@ print("waves with queries %d; per wave us: chain to cell record %.2f | scan + cl
 print("tier 1 → near %d block %d big(wave tier) %d" % (c[:, 5].sum(), c[:, 6].sum(), c[:, 7].sum()))
 z = out[:, 0:4].astype(np.float64)
 print("near → wave tier (budget) %d | block → wave tier: budget %d, E2 open %d (of which no matched cell in the block %d)" % (z[:, 0].sum(), z[:, 1].sum(), z[:, 2].sum(), z[:, 3].sum()))
+z = out[:, 4:8].astype(np.float64); nb = z[:, 0].sum()
+print("block tier: waves %d; per wave us: entry + q + 27 probes + resolves %.2f | cluster ids + selection %.2f | boxes + ranges + point scans %.2f" % (nb, z[:, 1].sum() / nb / 100, z[:, 2].sum() / nb / 100, z[:, 3].sum() / nb / 100))
