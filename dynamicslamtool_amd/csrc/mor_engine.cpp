@@ -326,7 +326,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.rhist, B * T * 256);
   ok = ok && dalloc(b, d.scell, B * N) && dalloc(b, d.csum, B * N) && dalloc(b, d.cgat, B * N) && dalloc(b, d.clist, B * N) && dalloc(b, d.cl_coff, B * (K + 1));
   d.skey = d.rkeys[d.cell_passes & 1]; d.sidx = d.rvals[d.cell_passes & 1];
-  if (d.use_hash) ok = ok && dalloc(b, d.chash, B * (size_t)d.Hcell); else d.chash = nullptr;
+  if (d.use_hash) ok = ok && dalloc(b, d.chash, 2 * B * (size_t)d.Hcell); else d.chash = nullptr;
   ok = ok && dalloc(b, d.split_desc, B * T);
   ok = ok && dalloc(b, d.crep, B * N);
   ok = ok && dalloc(b, d.cg_ovf, B * (size_t)MOR_MAXP * MOR_CGS_OVF * 2);
@@ -340,7 +340,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   ok = ok && dalloc(b, d.nn_fwd, B * K) && dalloc(b, d.nn_bwd, B * K) && dalloc(b, d.nn_fwd_d, B * K) && dalloc(b, d.pair_q, B * K) && dalloc(b, d.pair_m, B * K) && dalloc(b, d.pair_d, B * K);
   ok = ok && dalloc(b, d.pair_cnt, B * K) && dalloc(b, d.pair_of_prev, B * K) && dalloc(b, d.pair_of_cur, B * K) && dalloc(b, d.det, B * K);
   if (p->method_choice == 2) ok = ok && dalloc(b, d.vox, B * (size_t)d.Hcap);
-  ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_n, B) && dalloc(b, d.wlb_n, B) && dalloc(b, d.wl2, B * N) && dalloc(b, d.wl2_n, B) && dalloc(b, d.dbg, B * 16) && dalloc(b, d.dbg2, B * (MOR_MAXP + 2) * 16);
+  ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_nb, B) && dalloc(b, d.wl2, B * N) && dalloc(b, d.wl2_n, B) && dalloc(b, d.dbg, B * 16) && dalloc(b, d.dbg2, B * (MOR_MAXP + 2) * 16);
   ok = ok && dalloc(b, d.zmin_i, B) && dalloc(b, d.zmax_i, B) && dalloc(b, d.zorg, B) && dalloc(b, d.zbase, B) && dalloc(b, d.mode_bin, B);
   if (d.gmode == 1) ok = ok && dalloc(b, d.rawbuf, B * N) && dalloc(b, d.is_ground, B * N) && dalloc(b, d.vcent, B * N) && dalloc(b, d.vbin, B * N) && dalloc(b, d.g2_big, B * N) && dalloc(b, d.g2_nbig, B);
   if (ok) {   // crop-box variant: the clustering grid starts at gp_limit for every stream
@@ -371,8 +371,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = ok && dalloc(b, o.scell, B * N) && dalloc(b, o.csum, B * N) && dalloc(b, o.cgat, B * N) && dalloc(b, o.clist, B * N) && dalloc(b, o.cl_coff, B * (K + 1));
     ok = ok && dalloc(b, o.pcell, B * N) && dalloc(b, o.ppos, B * N) && dalloc(b, o.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, o.lroot_a, B * N) && dalloc(b, o.lroot_b, B * N) && dalloc(b, o.cmin, B * N) && dalloc(b, o.parent, B * N) && dalloc(b, o.csize, B * N) && dalloc(b, o.compmin, B * N) && dalloc(b, o.cid_of_root, B * N);
     ok = ok && dalloc(b, o.pair_q, B * K) && dalloc(b, o.pair_m, B * K) && dalloc(b, o.pair_d, B * K) && dalloc(b, o.pair_cnt, B * K) && dalloc(b, o.pair_of_prev, B * K) && dalloc(b, o.pair_of_cur, B * K);
-    ok = ok && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B) && dalloc(b, o.wl_n, B) && dalloc(b, o.wlb_n, B) && dalloc(b, o.wl, B * N);
-    if (d.use_hash) ok = ok && dalloc(b, o.chash, B * (size_t)d.Hcell);
+    ok = ok && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B) && dalloc(b, o.wl_nb, B) && dalloc(b, o.wl, B * N);
+    if (d.use_hash) ok = ok && dalloc(b, o.chash, 2 * B * (size_t)d.Hcell);
     b->d_args_s[c] = dargs1; o.args = dargs1;
     if (ok) ok = hipMemcpy(o.zorg, d.zorg, B * sizeof(float), hipMemcpyDeviceToDevice) == hipSuccess;
     if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
@@ -684,7 +684,7 @@ long long mor_debug_read(const mor_batch *b, const char *name, int s, void *out,
       {"ckey", d.ckey, N * 4}, {"cstart", d.cstart, (N + 1) * 4}, {"row_start", d.row_start, ((size_t)d.g.nrows + 1) * 4}, {"pcell", d.pcell, N * 4}, {"ppos", d.ppos, N * 4},
       {"pkey", d.pkey, N * 4}, {"sorted", d.sorted, N * 16}, {"cloud", d.cloud, N * 16}, {"cmin", d.cmin, N * 4}, {"cmeta", d.cmeta, 2 * N * 16}, {"crep", d.crep, N * 16},
       {"slab_y", d.slab_y, S * 4}, {"slab_c", d.slab_c, S * 4}, {"slab_e", d.slab_e, S * 4}, {"lroot_a", d.lroot_a, N * 4}, {"lroot_b", d.lroot_b, N * 4},
-      {"ccid", d.ccid, N * 4}, {"pcid", d.pcid, N * 4}, {"chash", d.chash, (size_t)d.Hcell * 8}, {"info", d.info, sizeof(MorFrameInfo)},
+      {"ccid", d.ccid, N * 4}, {"pcid", d.pcid, N * 4}, {"chash", d.chash, (size_t)d.Hcell * 16}, {"info", d.info, sizeof(MorFrameInfo)},
       {"xcent", d.xcent, K * 16}, {"xamin", d.xamin, K * 16}, {"xamax", d.xamax, K * 16}, {"xfirst", d.xfirst, K * 16}, {"scell", d.scell, N * 4}, {"cgat", d.cgat, N * 16}, {"csum", d.csum, N * 48}, {"clist", d.clist, N * 4}, {"cl_pts_prev", d.cl_pts[d.prev], N * 16}, {"cl_pts", d.cl_pts[d.cur], N * 16}};
   for (const Ent &e : tab) if (!strcmp(e.n, name)) {
     if (!e.p) return set_error(MOR_ERR_INVALID, "array %s is not allocated in this configuration", name);

@@ -449,12 +449,14 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scan(MorDev d) {
 // The scoring tiers look cells up by coordinates a few million times per batch.  Through the row table that is a chain
 // of dependent loads (row bounds → keys → …); a hash probe is one.  Open addressing, linear probing, load ≤ 1/4.
 __device__ __forceinline__ unsigned hash_slot(int key, unsigned hshift) { return ((unsigned)key * 0x9E3779B1u) >> hshift; }
+// A slot of the cell hash is two 64-bit words: (key + 1) << 32 | compact id (0 = empty), and n << 32 | b0 — the cell's range
+// of `sorted`, so a probe that is loaded as one 16-byte entry brings what the first tier needs without another round trip.
 __device__ __forceinline__ int hash_resolve(const unsigned long long *tab, unsigned hshift, int key, unsigned sl, unsigned long long e) {
   const unsigned mask = (1u << (32 - hshift)) - 1u;
-  for (;;) {   // e = tab[sl] was fetched by the caller (first probes of a batch are independent loads)
+  for (;;) {   // e = tab[2·sl] was fetched by the caller (first probes of a batch are independent loads)
     if (e == 0ull) return -1;
     if ((unsigned)(e >> 32) == (unsigned)key + 1u) return (int)(unsigned)e;
-    sl = (sl + 1) & mask; e = tab[sl];
+    sl = (sl + 1) & mask; e = tab[2 * sl];
   }
 }
 // N lookups of one thread resolved in LOCK-STEP: round r loads probe r of every lookup still open (independent loads), so
@@ -463,14 +465,14 @@ __device__ __forceinline__ int hash_resolve(const unsigned long long *tab, unsig
 // each at load 1/3 and a long tail; the wave pays the sum for its unluckiest lane.)  key < 0: no lookup; ent = first probes.
 template <int N> __device__ __forceinline__ void hash_resolve_all(const unsigned long long *tab, unsigned hshift, const int (&key)[N], int (&id)[N]) {
   const unsigned mask = (1u << (32 - hshift)) - 1u;
-  const unsigned *t32 = reinterpret_cast<const unsigned *>(tab);   // entry = (low word: compact id, high word: key + 1)
+  const unsigned *t32 = reinterpret_cast<const unsigned *>(tab);   // slot = four 32-bit words: compact id, key + 1, b0, n
   unsigned open = 0;
 #pragma unroll
   for (int i = 0; i < N; ++i) { id[i] = -1; if (key[i] >= 0) open |= 1u << i; }
   for (unsigned r = 0; open; ++r) {   // every open lookup is at its r-th probe
     unsigned kw[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) kw[i] = t32[2 * ((hash_slot(max(key[i], 0), hshift) + r) & mask) + 1];   // (closed lookups re-read their last slot: no branch around the loads)
+    for (int i = 0; i < N; ++i) kw[i] = t32[4 * ((hash_slot(max(key[i], 0), hshift) + r) & mask) + 1];   // (closed lookups re-read their last slot: no branch around the loads)
 #pragma unroll
     for (int i = 0; i < N; ++i) if ((open >> i) & 1u) {
       if (kw[i] == 0u) open &= ~(1u << i);
@@ -478,11 +480,11 @@ template <int N> __device__ __forceinline__ void hash_resolve_all(const unsigned
     }
   }
 #pragma unroll
-  for (int i = 0; i < N; ++i) if (id[i] >= 0) id[i] = (int)t32[2 * id[i]];
+  for (int i = 0; i < N; ++i) if (id[i] >= 0) id[i] = (int)t32[4 * id[i]];
 }
 __device__ __forceinline__ int hash_find(const unsigned long long *tab, unsigned hshift, int key) {
   const unsigned sl = hash_slot(key, hshift);
-  return hash_resolve(tab, hshift, key, sl, tab[sl]);
+  return hash_resolve(tab, hshift, key, sl, tab[2 * sl]);
 }
 // linear key of cell (cx,cy,cz), −1 outside the grid
 __device__ __forceinline__ int cell_key(const MorGrid &g, int cx, int cy, int cz) {
@@ -491,8 +493,8 @@ __device__ __forceinline__ int cell_key(const MorGrid &g, int cx, int cy, int cz
 }
 __global__ __launch_bounds__(MOR_BT) void k_hash_clear(MorDev d) {
   const int s = blockIdx.y + d.s0, n = 1 << (32 - d.info[s].hshift);
-  unsigned long long *tab = d.chash + (size_t)s * d.Hcell;
-  for (int i = blockIdx.x * MOR_BT + threadIdx.x; i < n; i += gridDim.x * MOR_BT) tab[i] = 0ull;
+  unsigned long long *tab = d.chash + 2 * (size_t)s * d.Hcell;
+  for (int i = blockIdx.x * MOR_BT + threadIdx.x; i < 2 * n; i += gridDim.x * MOR_BT) tab[i] = 0ull;
 }
 // per sorted position: compact cell id; heads publish the cell; every point lands in `sorted`
 __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
@@ -511,8 +513,8 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
     int bits = 10; while ((1 << bits) < 4 * nocc && (1 << bits) < d.Hcell) ++bits;   // cell hash: load factor ≤ 1/4
     if (t0 == 0 && threadIdx.x == 0) { d.info[s].n_occ = nocc; cstart[nocc] = M; d.info[s].hshift = 32 - bits; }
     if (d.use_hash) {   // the stream's workgroups clear its table; k_cellboxes inserts the cells
-      unsigned long long *tab = d.chash + (size_t)s * d.Hcell;
-      for (int i = t0 * MOR_BT + threadIdx.x; i < (1 << bits); i += d.tiles_m * MOR_BT) tab[i] = 0ull;
+      unsigned long long *tab = d.chash + 2 * (size_t)s * d.Hcell;
+      for (int i = t0 * MOR_BT + threadIdx.x; i < (2 << bits); i += d.tiles_m * MOR_BT) tab[i] = 0ull;
     }
   }
   for (int t = t0; t * MOR_TILE < M; t += d.tiles_m) {
@@ -664,7 +666,7 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
   const int nrows = d.g.nrows, nx = d.g.nx, tid = threadIdx.x;
   int hbits = 0; while ((1 << hbits) < H) ++hbits;
   const unsigned hshift = 32 - hbits, mask = (unsigned)H - 1u;
-  unsigned long long *chash = d.use_hash ? d.chash + (size_t)s * d.Hcell : nullptr;
+  unsigned long long *chash = d.use_hash ? d.chash + 2 * (size_t)s * d.Hcell : nullptr;
   const size_t stw = (size_t)s * (MOR_MAXP + 2) + MOR_MAXP; (void)stw;
   ST2(stw, 0);
   for (int i = tid; i < H; i += GH_T) { gh_st<TL>(tkey + i, 0); gh_st<TL>(tval + i, 0); }
@@ -703,7 +705,7 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
   // UNSUCCESSFUL searches — ≈ 4 probes each at the load of this workgroup's LDS table, ≈ 1.1 at 1/8 — and a wave waits for the
   // longest of its 64 × 26); cleared here, filled by k_gridfill
   int xbits = 12; while ((1 << xbits) < 8 * nocc && (1 << xbits) < d.Hcell) ++xbits;
-  if (chash) for (int i = tid; i < (1 << xbits); i += GH_T) chash[i] = 0ull;
+  if (chash) for (int i = tid; i < (2 << xbits); i += GH_T) chash[i] = 0ull;
   // ---- cells per row → row table
   for (int r = tid; r <= nrows; r += GH_T) gh_st<RL>(rows + r, 0);
   __syncthreads();
@@ -868,14 +870,15 @@ __global__ __launch_bounds__(MOR_BT) void k_gridfill(MorDev d) {
     d.sorted[so + pos] = q; d.scell[so + pos] = d.pcell[so + i];
   }
   const int *cstart = d.cstart + (size_t)s * (d.Nmax + 1);
-  unsigned long long *tab = d.use_hash ? d.chash + (size_t)s * d.Hcell : nullptr;
+  unsigned long long *tab = d.use_hash ? d.chash + 2 * (size_t)s * d.Hcell : nullptr;
   const unsigned hshift = d.info[s].hshift, hmask = (1u << (32 - hshift)) - 1u;
   for (int c = t0 * MOR_BT + threadIdx.x; c < nocc; c += d.tiles_m * MOR_BT) {
     cell_init_if_spanning(d, so, cstart, c);
     if (tab) {   // cell hash entry: (key + 1, compact id); the table was cleared by k_gridhash
       const int key = d.ckey[so + c]; unsigned sl = hash_slot(key, hshift);
       const unsigned long long ent = ((unsigned long long)((unsigned)key + 1u) << 32) | (unsigned)c;
-      while (atomicCAS(&tab[sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
+      while (atomicCAS(&tab[2 * sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
+      tab[2 * sl + 1] = ((unsigned long long)(unsigned)(cstart[c + 1] - cstart[c]) << 32) | (unsigned)cstart[c];
     }
   }
 }
@@ -1011,12 +1014,14 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
   const float4 *sp = d.sorted + so; const int *sc = d.scell + so;
   if (bx == 0 && d.grid_mode == 0) { __shared__ int l_sb[48]; slab_bounds<false>(d, s, d.row_start + (size_t)s * (d.g.nrows + 1), nocc, l_sb); }   // (the hash path computes them in k_gridhash)
   if (d.use_hash && d.grid_mode == 0) {   // cell hash: (key+1, compact id); the table was cleared by k_heads_scatter
-    unsigned long long *tab = d.chash + (size_t)s * d.Hcell; const int *ckey = d.ckey + so;
+    unsigned long long *tab = d.chash + 2 * (size_t)s * d.Hcell; const int *ckey = d.ckey + so;
     const unsigned hshift = d.info[s].hshift, hmask = (1u << (32 - hshift)) - 1u;
     for (int c = bx * MOR_BT + threadIdx.x; c < nocc; c += d.g_box * MOR_BT) {
       const int key = ckey[c]; unsigned sl = hash_slot(key, hshift);
       const unsigned long long ent = ((unsigned long long)((unsigned)key + 1u) << 32) | (unsigned)c;
-      while (atomicCAS(&tab[sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
+      while (atomicCAS(&tab[2 * sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
+      const int *cst = d.cstart + (size_t)s * (d.Nmax + 1);
+      tab[2 * sl + 1] = ((unsigned long long)(unsigned)(cst[c + 1] - cst[c]) << 32) | (unsigned)cst[c];
     }
   }
   for (int base = (bx * (MOR_BT / 64) + wave_id()) * CB_WTILE; base < M; base += d.g_box * (MOR_BT / 64) * CB_WTILE) {
@@ -1768,7 +1773,7 @@ __device__ __forceinline__ void pairs_body(const MorDev &d, int s, int *sh) {
     }
     carry += tot;
   }
-  if (threadIdx.x == 0) { d.info[s].n_pairs = carry; d.wl_n[s] = 0; d.wlb_n[s] = 0; d.wl2_n[s] = 0; }
+  if (threadIdx.x == 0) { d.info[s].n_pairs = carry; d.wl_nb[s] = 0ull; d.wl2_n[s] = 0; }
 }
 // One workgroup per stream: everything per CLUSTER between the point kernels — boxes, centroids and first points of the
 // transformed ca (from k_xform_prev's partials), both nearest-centroid directions, the correspondences.
@@ -1876,8 +1881,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
   const int pv = d.prev, Cp = d.slot_kc[d.prev][s].y;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
-  const unsigned long long *tab = d.chash + (size_t)s * d.Hcell; const unsigned hshift = d.info[s].hshift;
-  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  const unsigned long long *tab = d.chash + 2 * (size_t)s * d.Hcell; const unsigned hshift = d.info[s].hshift;
   const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + d.g.cs * 1e-3f;
   const bool e1_local = 2.f * slb < d.g.cs;
@@ -1895,11 +1899,16 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
       const float4 q = d.cl_pts[pv][so + j];
       const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
       const int key = cell_key(d.g, cx, cy, cz);
-      const unsigned sl = hash_slot(max(key, 0), hshift);
-      const unsigned long long ent = tab[sl];
+      unsigned sl = hash_slot(max(key, 0), hshift);
+      ulonglong2 ent = reinterpret_cast<const ulonglong2 *>(tab)[sl];   // (key + 1, id), (n, b0): the whole slot in one load
       pr = d.pair_of_prev[ko + cidj];
-      const int c = key >= 0 ? hash_resolve(tab, hshift, key, sl, ent) : -1;
-      const int cc = max(c, 0), cid = d.ccid[so + cc], b0 = st[cc], e0 = st[cc + 1];
+      int c = -1;
+      if (key >= 0) {
+        const unsigned hmask = (1u << (32 - hshift)) - 1u;
+        while (ent.x != 0ull && (unsigned)(ent.x >> 32) != (unsigned)key + 1u) { sl = (sl + 1) & hmask; ent = reinterpret_cast<const ulonglong2 *>(tab)[sl]; }
+        if (ent.x != 0ull) c = (int)(unsigned)ent.x;
+      }
+      const int cc = max(c, 0), cid = d.ccid[so + cc], b0 = c >= 0 ? (int)(unsigned)ent.y : 0, e0 = c >= 0 ? b0 + (int)(ent.y >> 32) : 0;
       target = min(max(d.pair_m[ko + max(pr, 0)], 0), d.Kcap - 1);   // (pr < 0: a stale entry, clamped — its box is loaded but not used)
       const float4 tlo = d.amin[d.cur][ko + target], thi = d.amax[d.cur][ko + target];
 #ifdef MOR_EXP_STAMPS
@@ -1923,8 +1932,17 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
 #endif
     }
     count_push(counted, d.pair_cnt + ko, pr);
-    wl_push(nearq, &d.wl_n[s], d.wl + so, j, pr, target);
-    wl_push(blockq, &d.wlb_n[s], d.wl + so, j, pr, target, true, d.Nmax);
+    {  // both ends of `wl` with ONE returning atomic per wave (the two counters share a 64-bit word)
+      const unsigned long long mn = __ballot(nearq), mb = __ballot(blockq);
+      if (mn | mb) {
+        const int leader = __ffsll((long long)(mn | mb)) - 1;
+        unsigned long long base = 0ull;
+        if (lane_id() == leader) base = atomicAdd(&d.wl_nb[s], (unsigned long long)__popcll(mn) | ((unsigned long long)__popcll(mb) << 32));
+        const int bn = __shfl((int)(unsigned)base, leader, 64), bb = __shfl((int)(base >> 32), leader, 64);
+        if (nearq) d.wl[so + bn + __popcll(mn & lanemask_lt())] = make_int4(j, pr, target, 0);
+        if (blockq) d.wl[so + d.Nmax - 1 - (bb + __popcll(mb & lanemask_lt()))] = make_int4(j, pr, target, 0);
+      }
+    }
     wl_push(big, &d.wl2_n[s], d.wl2 + so, j, pr, target);
 #ifdef MOR_EXP_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1963,10 +1981,10 @@ __device__ __forceinline__ int wl_entry(const MorDev &d, int p0, int bx, int nq)
 // box records + ranges → points.  No such point ⇒ counted.
 __global__ __launch_bounds__(MOR_BT) void k_score_near(MorDev d) {
   int s, bx; map_block(d.B, d.g_score, s, bx);   // a stream's workgroups share an XCD (its cell tables stay in that L2)
-  const int pv = d.prev, nq = d.wl_n[s];
+  const int pv = d.prev, nq = (int)(unsigned)d.wl_nb[s];
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
-  const unsigned long long *tab = d.chash + (size_t)s * d.Hcell; const unsigned hshift = d.info[s].hshift;
+  const unsigned long long *tab = d.chash + 2 * (size_t)s * d.Hcell; const unsigned hshift = d.info[s].hshift;
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + d.g.cs * 1e-3f;
@@ -2006,10 +2024,10 @@ __global__ __launch_bounds__(MOR_BT) void k_score_near(MorDev d) {
 // box records + ranges → points.  E2 hit ⇒ E1 is decided by the same cells; no hit ⇒ the wider stencil is the wave tier's job.
 __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
   int s, bx; map_block(d.B, d.g_score, s, bx);
-  const int pv = d.prev, nq = d.wlb_n[s];
+  const int pv = d.prev, nq = (int)(d.wl_nb[s] >> 32);
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
-  const unsigned long long *tab = d.chash + (size_t)s * d.Hcell; const unsigned hshift = d.info[s].hshift;
+  const unsigned long long *tab = d.chash + 2 * (size_t)s * d.Hcell; const unsigned hshift = d.info[s].hshift;
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const int *cid_c = d.ccid + so;
   const float lbn = nextafterf(d.pde_lb, INFINITY);
@@ -2132,7 +2150,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
     float best = INFINITY;
     {  // the query's own cell first
       const int key = cell_key(d.g, cx, cy, cz);
-      const int c = key >= 0 && d.use_hash ? hash_find(d.chash + (size_t)s * d.Hcell, d.info[s].hshift, key) : cell_lookup(d.g, ckey, rs, cx, cy, cz);
+      const int c = key >= 0 && d.use_hash ? hash_find(d.chash + 2 * (size_t)s * d.Hcell, d.info[s].hshift, key) : cell_lookup(d.g, ckey, rs, cx, cy, cz);
       if (c >= 0 && d.ccid[so + c] == target) best = wave_scan_cell(sp, st[c], st[c + 1], q, d.pde_lb, lane);
     }
     for (int rb = 0; rb < d.n_rows && best > d.pde_lb; rb += 64) {
@@ -2289,7 +2307,7 @@ template <int NT> __device__ __forceinline__ void decide_body(const MorDev &d, i
   for (int k = threadIdx.x; k < K; k += NT) { d.h_centroid[ko + k] = d.centroid[d.cur][ko + k]; d.h_det[ko + k] = d.det[ko + k]; }
   for (int k = threadIdx.x; k <= K; k += NT) d.h_cl_off[(size_t)s * (d.Kcap + 1) + k] = offc[k];
   if (threadIdx.x == 0) {
-    f.n_pairs = np; f.n_defer = (d.has_prev && d.method == 1) ? (uint32_t)d.wl2_n[s] : 0u; f.pad0 = (d.has_prev && d.method == 1) ? (uint32_t)(d.wl_n[s] + d.wlb_n[s]) : 0u;
+    f.n_pairs = np; f.n_defer = (d.has_prev && d.method == 1) ? (uint32_t)d.wl2_n[s] : 0u; f.pad0 = (d.has_prev && d.method == 1) ? (uint32_t)((unsigned)d.wl_nb[s] + (unsigned)(d.wl_nb[s] >> 32)) : 0u;
     f.Kprev = d.has_prev ? d.slot_kc[d.prev][s].x : 0; f.Cprev = d.has_prev ? d.slot_kc[d.prev][s].y : 0;   // for the host mirror
     d.info[s].n_pairs = np;
     d.h_info[s] = f;
