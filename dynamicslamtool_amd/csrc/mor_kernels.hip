@@ -801,12 +801,12 @@ __global__ __launch_bounds__(GH_T) void k_gridhash(MorDev d) {
 // ---- per-cell accumulators of the streaming cell pass (k_cellboxes): point box, smallest cloud index, exact coordinate sums
 #define CB_WTILE 256      // positions of `sorted` one wave handles per step (four consecutive ones per lane)
 struct CellAcc { float lx, ly, lz, hx, hy, hz; int mi; long long a[3], b[3]; };
-__device__ __forceinline__ void fx_split(float x, long long &a, long long &b) {   // x = a·2^-24 + b·2^-64 (MorCellSum); every step is exact
+__device__ __forceinline__ void fx_split(float x, long long &a, long long &b) {   // x = a·2^-24 + b·2^-56 (MorCellSum); every step is exact for |x| ≥ 2^-32 (below: truncated at 2^-56)
   const double xd = (double)x, fa = floor(xd * 16777216.0);
   a = (long long)fa;
-  b = (long long)((xd - fa * (1.0 / 16777216.0)) * 18446744073709551616.0);
+  b = (long long)((xd - fa * (1.0 / 16777216.0)) * 72057594037927936.0);
 }
-__device__ __forceinline__ double fx_value(long long a, long long b) { return (double)a * (1.0 / 16777216.0) + (double)b * (1.0 / 18446744073709551616.0); }
+__device__ __forceinline__ double fx_value(long long a, long long b) { return (double)a * (1.0 / 16777216.0) + (double)b * (1.0 / 72057594037927936.0); }
 __device__ __forceinline__ void acc_clear(CellAcc &r) { r.lx = r.ly = r.lz = FLT_MAX; r.hx = r.hy = r.hz = -FLT_MAX; r.mi = 0x7fffffff; r.a[0] = r.a[1] = r.a[2] = 0; r.b[0] = r.b[1] = r.b[2] = 0; }
 __device__ __forceinline__ void acc_point(CellAcc &r, const float4 &p) {
   r.lx = fminf(r.lx, p.x); r.ly = fminf(r.ly, p.y); r.lz = fminf(r.lz, p.z); r.hx = fmaxf(r.hx, p.x); r.hy = fmaxf(r.hy, p.y); r.hz = fmaxf(r.hz, p.z);

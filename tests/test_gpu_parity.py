@@ -360,16 +360,44 @@ for method in (1, 2):
         compare_frame(o, b, 0, "variant small m%%d frame %%d" %% (method, f))
         compare_output(o.filter(), b.filter()[0], "variant small m%%d frame %%d" %% (method, f))
     b.close(); o.close()
+# asynchronous use without waits against synchronous use, frame by frame (schedules, depths, lanes)
+from dynamicslamtool_amd.engine import DeviceBuffer
+p = kitti_params(1)
+B, nf, npts = 16, 8, 120000
+seeds = [2000 + s for s in range(B)]
+buf = DeviceBuffer(nf * B * npts * 16); poses = []
+for f in range(nf):
+    xs, ps = synth.batch(seeds, [f] * B); buf.upload(xs, f * B * npts * 16); poses.append(ps)
+logs = []
+for mode in ("async", "sync"):
+    b = MorBatch(p, B, npts)
+    views = [b.make_views([(buf.ptr + (f * B + s) * npts * 16, npts) for s in range(B)]) for f in range(nf)]
+    if mode == "async": b.set_async(True)
+    for f in range(nf):
+        b.push_views(views[f], poses[f])
+        if mode == "async": b.filter_async()
+        else: b.filter_device()
+    b.wait()
+    logs.append([[b.frame_log(f, s) for s in range(B)] for f in range(nf)])
+    b.close()
+buf.free()
+assert logs[0] == logs[1], "asynchronous run differs from the synchronous one"
+assert sum(L["n_pairs"] for L in logs[0][-1]) > 100
 print("OK")
 """
 
 
 @pytest.mark.parametrize("env", [{"MOR_GH_TIER": "1"}, {"MOR_GH_TIER": "2", "MOR_CG_GLOBAL": "1"}, {"MOR_GRID": "radix"}, {"MOR_SINGLE_PASS_SPLIT": "1"},
-                                 {"MOR_STAGES": "0123333", "MOR_PIPE_DEPTH": "2"}, {"MOR_STAGES": "0001123", "MOR_PIPE_DEPTH": "6"}])
+                                 {"MOR_SCHED": "stages", "MOR_STAGES": "0123333", "MOR_PIPE_DEPTH": "2"}, {"MOR_SCHED": "stages", "MOR_STAGES": "0001123", "MOR_PIPE_DEPTH": "6"},
+                                 {"MOR_LANES": "2"}, {"MOR_PIPE_DEPTH": "8", "MOR_LANES": "6"}, {"MOR_PIPE_DEPTH": "1"},
+                                 {"MOR_CG_BIG": "1", "MOR_SPLIT_G": "8"}, {"MOR_SPLIT_VARIANT": "32"}, {"MOR_SPLIT_VARIANT": "1216"}])
 def test_kernel_variants(env):
-    """The slower variants behind the fast paths must give the same results: k_gridhash with its big LDS table / its
-    global-memory table, slab and merge forests in global memory, the radix-sort grid build, the single-pass ground split, and
-    other stage assignments / pipeline depths.  The variant is chosen when the batch is created, from the environment: child process."""
+    """The variants behind the default paths must give the same results: k_gridhash with its big LDS table / its
+    global-memory table, slab and merge forests in global memory, the radix-sort grid build, the single-pass ground split, the
+    stage schedule with other stage assignments, other numbers of lanes / pipeline depths, the big-slab kernel of the cell graph,
+    strided tile loops in the split, other worklist mappings and the unsampled own-cell scan of tier 1.  The variant is chosen
+    when the batch is created, from the environment: child process (synchronous frames against the oracle, then an asynchronous
+    run without waits against a synchronous one)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT % (root, os.path.join(root, "tests"))], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
