@@ -219,6 +219,7 @@ extern const char *const mor_kernel_names[MK_COUNT];
 
 struct MorLaunchTimer;   // engine-owned; records event pairs when enabled
 #define MOR_N_PIECES 7
+#define MOR_MAX_PIECES 13   // with the grid piece of the voxel ground variant as six (pieces 10 … 15 instead of 0)
 void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer *tm);   // 0 split + grid, 1 cell boxes, 2 cell graph, 3 labels … centroids, 4 transform of ca … first score tiers, 5 last score tiers, 6 thresholds + tracking
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);
 void mor_timer_begin(MorLaunchTimer *tm, int kernel_id, hipStream_t st);

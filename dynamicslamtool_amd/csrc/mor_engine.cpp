@@ -75,7 +75,8 @@ struct mor_batch {
   // Four in-order HIP streams form a software pipeline over frames (see mor_push_batch): grid stage on `sf`, cell graph on
   // `sc`, cluster extraction + pair stage on `sm`, wave-tier scores + tracking + filterCloud on `sb`.
   hipStream_t sf = nullptr, sc = nullptr, sm = nullptr, sb = nullptr;   // grid, cell graph, mid (clusters + pair stage), tail (scores wave tier, tracking, filterCloud)
-  hipEvent_t ev_piece[MOR_N_PIECES][MOR_MAX_SLOTS] = {}, ev_back[MOR_MAX_SLOTS] = {};
+  hipEvent_t ev_piece[MOR_MAX_PIECES][MOR_MAX_SLOTS] = {}, ev_back[MOR_MAX_SLOTS] = {};
+  int n_pieces = MOR_N_PIECES, piece_id[MOR_MAX_PIECES] = {0, 1, 2, 3, 4, 5, 6, 0, 0, 0, 0, 0, 0};   // lane schedule: the pieces of a push in order
   // Default schedule ("lanes"): frame k runs ALL its pieces, then its filterCloud, on stream k % n_lanes, so every stream
   // carries the same work whatever the pieces cost; piece p of frame k waits for piece p of frame k−1 (which keeps every
   // guarantee of the stage schedule: scratch arrays of a piece are never used by two frames at once, the pair stage of
@@ -295,6 +296,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   for (auto &ev : b->ev_back) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_track) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   if (getenv("MOR_SCHED") && !strcmp(getenv("MOR_SCHED"), "stages")) b->lanes = false;
+  if (b->lanes && p->ground_method == 0 && !getenv("MOR_ONE_GRID_PIECE")) { const int ids[9] = {7, 8, 1, 16, 17, 3, 4, 5, 6}; b->n_pieces = 9; for (int i = 0; i < 9; ++i) b->piece_id[i] = ids[i]; }
+  if (b->lanes && p->ground_method == 1) { const int ids[MOR_MAX_PIECES] = {10, 11, 12, 13, 14, 15, 1, 16, 17, 3, 4, 5, 6}; b->n_pieces = MOR_MAX_PIECES; for (int i = 0; i < MOR_MAX_PIECES; ++i) b->piece_id[i] = ids[i]; }
   b->n_lanes = (int)std::min<uint64_t>(4, b->pipe_depth);
   if (getenv("MOR_LANES")) b->n_lanes = std::max(1, std::min<int>((int)std::min<uint64_t>(8, b->pipe_depth), atoi(getenv("MOR_LANES"))));
   for (int i = 4; i < b->n_lanes; ++i) if (hipStreamCreateWithFlags(&b->extra[i - 4], hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
@@ -373,6 +376,10 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = ok && dalloc(b, o.pair_q, B * K) && dalloc(b, o.pair_m, B * K) && dalloc(b, o.pair_d, B * K) && dalloc(b, o.pair_cnt, B * K) && dalloc(b, o.pair_of_prev, B * K) && dalloc(b, o.pair_of_cur, B * K);
     ok = ok && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B) && dalloc(b, o.wl_nb, B) && dalloc(b, o.wl, B * N);
     if (d.use_hash) ok = ok && dalloc(b, o.chash, 2 * B * (size_t)d.Hcell);
+    if (b->lanes && d.gmode == 0) ok = ok && dalloc(b, o.pkey, B * N);   // split | grid build are two pieces
+    if (d.gmode == 1 && b->lanes)   // voxel ground variant: its grid piece runs as six, these cross their boundaries
+      ok = ok && dalloc(b, o.rawbuf, B * N) && dalloc(b, o.is_ground, B * N) && dalloc(b, o.vcent, B * N) && dalloc(b, o.vbin, B * N) && dalloc(b, o.g2_big, B * N) && dalloc(b, o.g2_nbig, B) &&
+           dalloc(b, o.zbase, B) && dalloc(b, o.pkey, B * N) && dalloc(b, o.tile_cnt, B * T * 2) && dalloc(b, o.tile_off, B * T * 2) && dalloc(b, o.zmin_i, B) && dalloc(b, o.zmax_i, B);
     b->d_args_s[c] = dargs1; o.args = dargs1;
     if (ok) ok = hipMemcpy(o.zorg, d.zorg, B * sizeof(float), hipMemcpyDeviceToDevice) == hipSuccess;
     if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
@@ -458,13 +465,13 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   HIP_TRY(hipEventRecord(b->ev[0], s0));
   hipStream_t tail = b->lanes ? lane : b->sb;
   if (b->lanes) {
-    for (int pc = 0; pc < MOR_N_PIECES; ++pc) {
+    for (int pc = 0; pc < b->n_pieces; ++pc) {
       if (pc > 0 && k > 0) HIP_TRY(hipStreamWaitEvent(lane, b->ev_piece[pc][(k - 1) % MOR_MAX_SLOTS], 0));
-      if (pc == MOR_N_PIECES - 1 && b->last_track) HIP_TRY(hipStreamWaitEvent(lane, *b->last_track, 0));   // tracking state: after the previous frame's filterCloud
-      mor_launch_piece(d, pc, lane, &b->timer);
+      if (pc == b->n_pieces - 1 && b->last_track) HIP_TRY(hipStreamWaitEvent(lane, *b->last_track, 0));   // tracking state: after the previous frame's filterCloud
+      mor_launch_piece(d, b->piece_id[pc], lane, &b->timer);
       HIP_TRY(hipEventRecord(b->ev_piece[pc][k % MOR_MAX_SLOTS], lane));
     }
-    b->last_track = &b->ev_piece[MOR_N_PIECES - 1][k % MOR_MAX_SLOTS];
+    b->last_track = &b->ev_piece[b->n_pieces - 1][k % MOR_MAX_SLOTS];
   } else {
     for (int pc = 0; pc < MOR_N_PIECES; ++pc) {
       hipStream_t st = S[b->stage_of[pc]];
@@ -685,7 +692,7 @@ long long mor_debug_read(const mor_batch *b, const char *name, int s, void *out,
       {"pkey", d.pkey, N * 4}, {"sorted", d.sorted, N * 16}, {"cloud", d.cloud, N * 16}, {"cmin", d.cmin, N * 4}, {"cmeta", d.cmeta, 2 * N * 16}, {"crep", d.crep, N * 16},
       {"slab_y", d.slab_y, S * 4}, {"slab_c", d.slab_c, S * 4}, {"slab_e", d.slab_e, S * 4}, {"lroot_a", d.lroot_a, N * 4}, {"lroot_b", d.lroot_b, N * 4},
       {"ccid", d.ccid, N * 4}, {"pcid", d.pcid, N * 4}, {"chash", d.chash, (size_t)d.Hcell * 16}, {"info", d.info, sizeof(MorFrameInfo)},
-      {"xcent", d.xcent, K * 16}, {"xamin", d.xamin, K * 16}, {"xamax", d.xamax, K * 16}, {"xfirst", d.xfirst, K * 16}, {"scell", d.scell, N * 4}, {"cgat", d.cgat, N * 16}, {"csum", d.csum, N * 48}, {"clist", d.clist, N * 4}, {"cl_pts_prev", d.cl_pts[d.prev], N * 16}, {"cl_pts", d.cl_pts[d.cur], N * 16}};
+      {"xcent", d.xcent, K * 16}, {"xamin", d.xamin, K * 16}, {"xamax", d.xamax, K * 16}, {"xfirst", d.xfirst, K * 16}, {"g2_big", d.g2_big, N * 4}, {"g2_nbig", d.g2_nbig, 4}, {"vbin", d.vbin, N * 4}, {"scell", d.scell, N * 4}, {"cgat", d.cgat, N * 16}, {"csum", d.csum, N * 48}, {"clist", d.clist, N * 4}, {"cl_pts_prev", d.cl_pts[d.prev], N * 16}, {"cl_pts", d.cl_pts[d.cur], N * 16}};
   for (const Ent &e : tab) if (!strcmp(e.n, name)) {
     if (!e.p) return set_error(MOR_ERR_INVALID, "array %s is not allocated in this configuration", name);
     const size_t n = std::min(bytes, e.stride);

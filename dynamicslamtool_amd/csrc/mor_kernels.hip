@@ -30,7 +30,7 @@ const char *const mor_kernel_names[MK_COUNT] = {
     "classify", "scan_tiles", "scatter", "split", "heads_count", "heads_scan", "heads_scatter", "hash_clear", "cellboxes", "cellgraph", 
     "label", "rhist", "rscan", "rscatter",
     "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "cluster_pairs", "score_fast", "score_near", "score_block", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
-    "out_count", "out_scan", "out_scatter", "g2_centroid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridfill", "cg_slab", "cg_final", "clusters"};
+    "out_count", "out_scan", "out_scatter", "g2_cov_mid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridfill", "cg_slab", "cg_final", "clusters"};
 
 #ifdef MOR_EXP_STAMPS
 #define RS_T(v) const unsigned long long v = wall_clock64()
@@ -577,6 +577,9 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
 // and a wide kernel (k_gridfill) moves the points.  The table doubles as the cell hash of the method-1 scoring tiers.
 // Streams with more cells than the LDS table holds run the same code on a table in global memory.
 #define GH_T 1024
+#ifndef GH_U
+#define GH_U 4        // points per thread and round trip of the sweeps (8 / 12 measured: no gain — the sweeps are bound by LDS atomics on the hot cells, not by the loads)
+#endif
 #define GH_H 16384       // slots of the LDS table (cells ≤ 3/4 of it)
 #define GH_ROWS 7167     // (y,z) rows the LDS copy of the row table holds
 template <int NT> __device__ __forceinline__ int block_excl_scan_n(int v, int *sh, int *total) {   // sh: ≥ NT/64 ints
@@ -673,16 +676,16 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
   if (tid == 0) { l_misc[0] = 0; l_misc[1] = 0; }
   __syncthreads();
   // ---- sweep 1: every point finds (or claims) the slot of its cell and counts itself; slot kept for sweep 2
-  for (int i0 = 0; i0 < M; i0 += 4 * GH_T) {
-    int key[4];
+  for (int i0 = 0; i0 < M; i0 += GH_U * GH_T) {
+    int key[GH_U];   // GH_U points per thread and round trip (a sweep is M / (GH_U·1024) dependent rounds of global latency: 52 of them with four points for the 215 000-point clouds of agg10)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int i = i0 + u * GH_T + tid; key[u] = i < M ? pkey[i] : -1; }
+    for (int u = 0; u < GH_U; ++u) { const int i = i0 + u * GH_T + tid; key[u] = i < M ? pkey[i] : -1; }
     if (gh_ld<true>(&l_misc[1])) break;
-    unsigned h0[4]; int k0[4];   // first probe of the four points as one batch of independent loads: nearly every point finds its cell's slot there
+    unsigned h0[GH_U]; int k0[GH_U];   // first probe of the points as one batch of independent loads: nearly every point finds its cell's slot there
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { h0[u] = hash_slot(max(key[u], 0), hshift); k0[u] = gh_ld<TL>(tkey + h0[u]); }
+    for (int u = 0; u < GH_U; ++u) { h0[u] = hash_slot(max(key[u], 0), hshift); k0[u] = gh_ld<TL>(tkey + h0[u]); }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GH_U; ++u) {
       if (key[u] < 0) continue;
       const int want = key[u] + 1; unsigned h = h0[u]; bool ok = k0[u] == want;
       for (int probes = 0; !ok && probes < H; ++probes) {
@@ -704,7 +707,7 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
   // the scoring tiers' cell hash: a table of its own in global memory, eight slots per cell (neighbour lookups are mostly
   // UNSUCCESSFUL searches — ≈ 4 probes each at the load of this workgroup's LDS table, ≈ 1.1 at 1/8 — and a wave waits for the
   // longest of its 64 × 26); cleared here, filled by k_gridfill
-  int xbits = 12; while ((1 << xbits) < 8 * nocc && (1 << xbits) < d.Hcell) ++xbits;
+  int xbits = 10; while ((1 << xbits) < 8 * nocc && (1 << xbits) < d.Hcell) ++xbits;   // (Hcell ≥ 1024: never beyond the allocation)
   if (chash) for (int i = tid; i < (2 << xbits); i += GH_T) chash[i] = 0ull;
   // ---- cells per row → row table
   for (int r = tid; r <= nrows; r += GH_T) gh_st<RL>(rows + r, 0);
@@ -751,12 +754,12 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
   __syncthreads();
   ST2(stw, 2);
   // ---- sweep 2: position of every point inside its cell's range
-  for (int i0 = 0; i0 < M; i0 += 4 * GH_T) {
-    int sl[4];
+  for (int i0 = 0; i0 < M; i0 += GH_U * GH_T) {
+    int sl[GH_U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int i = i0 + u * GH_T + tid; sl[u] = i < M ? pslot[i] : -1; }
+    for (int u = 0; u < GH_U; ++u) { const int i = i0 + u * GH_T + tid; sl[u] = i < M ? pslot[i] : -1; }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GH_U; ++u) {
       if (sl[u] < 0) continue;
       const int i = i0 + u * GH_T + tid;
       pcell[i] = gh_ld<TL>(tkey + sl[u]) - 1;
@@ -2610,7 +2613,88 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
     __syncthreads();
   }
 }
-// the queued voxels: one 256-thread workgroup each, up to G2_CAP neighbours in 128 KiB of LDS
+// The queued voxels, middle tier: one WAVE per voxel, up to G2_MID_CAP neighbours in its 20 KiB slice of LDS — the same
+// steps as a group of k_g2_cov (gather with ballot compaction, rank by counting, coordinates to their rank, ordered sums by
+// one lane).  A workgroup of the big-voxel kernel (bitonic sort, 128 KiB of LDS: one per CU) took ≈ 60 µs per voxel and all
+// ≈ 300 queued voxels of a stream went through it; 95 % of them have fewer than 1024 neighbours.  Done entries of the queue
+// are complemented; what is left (> G2_MID_CAP neighbours) goes to k_g2_cov_big.
+#define G2_MID_CAP 1024
+__global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
+  const int s = blockIdx.y + d.s0, nbig = d.g2_nbig[s];
+  const size_t so = (size_t)s * d.Nmax;
+  const int wv = wave_id(), lane = lane_id();
+  __shared__ unsigned long long l_key[MOR_BT / 64][G2_MID_CAP];
+  __shared__ float l_x[MOR_BT / 64][G2_MID_CAP], l_y[MOR_BT / 64][G2_MID_CAP], l_z[MOR_BT / 64][G2_MID_CAP];
+  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  const float4 *sp = d.sorted + so;
+  const int zbase = d.zbase[s];
+  for (int w0 = blockIdx.x * (MOR_BT / 64); w0 < nbig; w0 += gridDim.x * (MOR_BT / 64)) {
+    const int w = w0 + wv; const bool act = w < nbig;
+    const int v = act ? d.g2_big[so + w] : 0;
+    const float4 q = d.vcent[so + v];
+    int rb0 = 0, rlen = 0;
+    if (act && lane < 9) {
+      int cx, cy, cz; bool cl; grid_cell(d.g, q, 0.f, zbase, cx, cy, cz, cl);
+      const int y = cy + lane % 3 - 1, z = cz + lane / 3 - 1;
+      if ((unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) {
+        int lo, hi; row_cells(d.g, ckey, rs, max(cx - 1, 0), min(cx + 1, d.g.nx - 1), y, z, lo, hi);
+        if (lo < hi) { rb0 = st[lo]; rlen = st[hi] - rb0; }
+      }
+    }
+    int rb[9], rp[10]; rp[0] = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { rb[r] = __shfl(rb0, r, 64); rp[r + 1] = rp[r] + __shfl(rlen, r, 64); }
+    int n = 0;
+    for (int c0 = 0; c0 < rp[9]; c0 += 64) {
+      const int c = c0 + lane; bool hit = false; float dd = 0.f; float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < rp[9]) {
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) if (c >= rp[r] && c < rp[r + 1]) k = rb[r] + (c - rp[r]);
+        p = sp[k];
+        dd = sqdist(q.x, q.y, q.z, p.x, p.y, p.z);
+        hit = dd < d.leaf_r2;
+      }
+      const unsigned long long m = __ballot(hit);
+      if (hit) {
+        const int slot = n + __popcll(m & lanemask_lt());
+        if (slot < G2_MID_CAP) { l_key[wv][slot] = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(p.w); l_x[wv][slot] = p.x; l_y[wv][slot] = p.y; l_z[wv][slot] = p.z; }
+      }
+      n += __popcll(m);
+    }
+    __syncthreads();
+    const bool mine = act && n <= G2_MID_CAP;
+    float ex[G2_MID_CAP / 64], ey[G2_MID_CAP / 64], ez[G2_MID_CAP / 64]; int er[G2_MID_CAP / 64];
+#pragma unroll
+    for (int u = 0; u < G2_MID_CAP / 64; ++u) {
+      const int e = lane + 64 * u; er[u] = -1;
+      if (mine && e < n) {
+        const unsigned long long ke = l_key[wv][e]; int r = 0;
+        for (int j = 0; j < n; ++j) r += l_key[wv][j] < ke;
+        er[u] = r; ex[u] = l_x[wv][e]; ey[u] = l_y[wv][e]; ez[u] = l_z[wv][e];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < G2_MID_CAP / 64; ++u) if (er[u] >= 0) { l_x[wv][er[u]] = ex[u]; l_y[wv][er[u]] = ey[u]; l_z[wv][er[u]] = ez[u]; }
+    __syncthreads();
+    if (mine && lane == 0) {
+      int bin = 0x7fffffff;
+      if (n > 3) {
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        for (int i = 0; i < n; ++i) { cx += l_x[wv][i]; cy += l_y[wv][i]; cz += l_z[wv][i]; }
+        const float fn = (float)n; cx /= fn; cy /= fn; cz /= fn;
+        float c02 = 0.f, c12 = 0.f, c22 = 0.f;
+        for (int i = 0; i < n; ++i) { const float dx = l_x[wv][i] - cx, dy = l_y[wv][i] - cy, dz = l_z[wv][i] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; }
+        if ((double)fabsf(c02) < 0.001 && (double)fabsf(c12) < 0.001 && (double)fabsf(c22) < 0.001) bin = (int)(q.z * 10);
+      }
+      d.vbin[so + v] = bin;
+      d.g2_big[so + w] = ~v;   // done
+    }
+    __syncthreads();
+  }
+}
+// what the middle tier left: one 256-thread workgroup each, up to G2_CAP neighbours in 128 KiB of LDS
 __global__ __launch_bounds__(MOR_BT) void k_g2_cov_big(MorDev d) {
   int s = blockIdx.y + d.s0; const int nbig = d.g2_nbig[s];
   const size_t so = (size_t)s * d.Nmax;
@@ -2620,6 +2704,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_big(MorDev d) {
   __shared__ float acc[6];
   for (int w = blockIdx.x; w < nbig; w += gridDim.x) {
     const int v = d.g2_big[so + w];
+    if (v < 0) continue;   // settled by k_g2_cov_mid
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     const float4 q = d.vcent[so + v];
@@ -2852,8 +2937,10 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
     mor_timer_end(tm, id, st);                                            \
   } while (0)
 
-static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+// part: 0 = both, 1 = the split only, 2 = the grid build only (the lane schedule runs them as two pieces)
+static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part = 0) {
   const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B);
+  if (part == 2) goto grid;
   if (d.fuse_scans && d.gmode != 1 && !d.two_pass_split) {
     (void)hipMemsetAsync(d.split_desc + (size_t)d.s0 * d.tiles_max, 0, (size_t)d.B * d.tiles_max * sizeof(unsigned long long), st);
     MOR_LAUNCH(MK_SPLIT, k_split, gT, d);
@@ -2863,6 +2950,8 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
     if (!d.fuse_scans) MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
     MOR_LAUNCH(MK_SCATTER, k_scatter, gS, d);
   }
+  if (part == 1) return;
+grid:
   if (d.grid_mode == 1 && d.gmode != 1) {   // clustering grid by counting (k_gridhash); the VoxelGrid pass of the voxel ground variant needs the points of a voxel in index order: sort
     mor_timer_begin(tm, MK_GRIDHASH, st);
     hipLaunchKernelGGL(k_gridhash, gB, dim3(GH_T), 0, st, d);
@@ -2888,37 +2977,50 @@ static void mor_launch_boxes(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
   MOR_LAUNCH(MK_CELLBOXES, k_cellboxes, dim3(d.g_box * d.B), d);   // point boxes, smallest index, slabs (+ cell hash on the sort path)
 }
 
-static void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+// Voxel-covariance ground removal as six sub-pieces (the lane schedule runs sub-piece q of frame k beside other sub-pieces of
+// frames k ± 1; as ONE piece its 7 ms were the period of the whole pipeline): pass A (trim, VoxelGrid sort), the 16-lane voxel
+// kernel, the wave-per-voxel kernel, the big voxels, mode + marking, pass B (split by ground flag + clustering grid).
+static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gB(d.B);
-  if (d.gmode == 0) {
-    mor_launch_split_and_grid(d, st, tm);
-  } else {
-    // voxel-covariance ground removal: pass A (trim, VoxelGrid sort), voxel tests, pass B (split by ground flag)
+  MorDev da = d; da.gmode = 1; da.g = d.gv; da.cloud = d.rawbuf; da.cell_passes = d.voxel_passes; da.tiles_m = d.tiles; da.use_hash = 0;
+  da.skey = d.rkeys[da.cell_passes & 1]; da.sidx = d.rvals[da.cell_passes & 1];
+  if (sub == 0) {
     hipMemsetD32Async((hipDeviceptr_t)(d.zmin_i + d.s0), 0x7fffffff, d.B, st);
     hipMemsetD32Async((hipDeviceptr_t)(d.zmax_i + d.s0), (int)0x80000000, d.B, st);
     hipMemsetAsync(d.is_ground + (size_t)d.s0 * d.Nmax, 0, (size_t)d.B * d.Nmax * sizeof(int), st);
-    MorDev da = d; da.gmode = 1; da.g = d.gv; da.cloud = d.rawbuf; da.cell_passes = d.voxel_passes; da.tiles_m = d.tiles; da.use_hash = 0;
-    da.skey = d.rkeys[da.cell_passes & 1]; da.sidx = d.rvals[da.cell_passes & 1];
     mor_launch_split_and_grid(da, st, tm);
     (void)hipMemsetAsync(d.g2_nbig + d.s0, 0, (size_t)d.B * sizeof(int), st);
+  } else if (sub == 1) {
     mor_timer_begin(tm, MK_G2_COV, st);
     hipLaunchKernelGGL(k_g2_cov, dim3(256, d.B), dim3(MOR_BT), 0, st, da);
     mor_timer_end(tm, MK_G2_COV, st);
+  } else if (sub == 2) {
+    if (!(d.split_variant & 2048)) MOR_LAUNCH(MK_G2_CENTROID, k_g2_cov_mid, dim3(64, d.B), da);   // (timer slot of the former centroid kernel)
+  } else if (sub == 3) {
     MOR_LAUNCH(MK_G2_COV_BIG, k_g2_cov_big, dim3(64, d.B), da);
+  } else if (sub == 4) {
     MOR_LAUNCH(MK_G2_MODE, k_g2_mode, gB, da);
     mor_timer_begin(tm, MK_G2_MARK, st);
     hipLaunchKernelGGL(k_g2_mark, dim3(4096, d.B), dim3(64), 0, st, da);
     mor_timer_end(tm, MK_G2_MARK, st);
+  } else {
     MorDev db = d; db.gmode = 2;
     mor_launch_split_and_grid(db, st, tm);
   }
 }
+static void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+  if (d.gmode == 0) mor_launch_split_and_grid(d, st, tm);
+  else for (int sub = 0; sub < 6; ++sub) mor_launch_grid_sub(d, sub, st, tm);
+}
 
-static void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+static void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part = 0) {   // part: 0 both, 1 slabs, 2 merge
+  if (part == 2) goto final;
   mor_timer_begin(tm, MK_CG_SLAB, st);
   if (d.cg_big) hipLaunchKernelGGL(k_cg_slab<CGS_CAP_BIG>, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
   else hipLaunchKernelGGL(k_cg_slab<CGS_CAP>, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
   mor_timer_end(tm, MK_CG_SLAB, st);
+  if (part == 1) return;
+final:
   mor_timer_begin(tm, MK_CG_FINAL, st);
   hipLaunchKernelGGL(k_cg_final, dim3(d.B), dim3(CGF_T), 0, st, d);
   mor_timer_end(tm, MK_CG_FINAL, st);
@@ -2967,6 +3069,11 @@ void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer
     case 4: mor_launch_pairs(d, st, tm); break;
     case 5: mor_launch_scores2(d, st, tm); break;
     case 6: mor_launch_decide(d, st, tm); break;
+    case 16: mor_launch_cellgraph(d, st, tm, 1); break;   // the cell graph in two: slabs | merge
+    case 17: mor_launch_cellgraph(d, st, tm, 2); break;
+    case 7: mor_launch_split_and_grid(d, st, tm, 1); break;   // the grid piece of the crop variant in two: split | grid build
+    case 8: mor_launch_split_and_grid(d, st, tm, 2); break;
+    case 10: case 11: case 12: case 13: case 14: case 15: mor_launch_grid_sub(d, piece - 10, st, tm); break;   // the grid piece of the voxel ground variant in six
     default: break;
   }
 }
