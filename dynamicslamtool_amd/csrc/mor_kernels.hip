@@ -1195,6 +1195,9 @@ template <bool LDS> __device__ __forceinline__ void cgs_hooks(const MorDev &d, s
         }
       }
     }
+#ifdef MOR_EXP_STAMPS
+    { const int s = (int)(soc / d.Nmax); const int n_it = __popcll(__ballot(it < n_own * NR)), n_ne = __popcll(__ballot(b < hi)); if (lane == 0) { RS_ADD(0, n_it); RS_ADD(1, n_ne); } }
+#endif
     int kb[5], pb[5];   // the window holds at most five cells (x−2 … x+2): keys and parents as one batch of independent loads
 #pragma unroll
     for (int u = 0; u < 5; ++u) { const int bi = min(b + u, max(hi - 1, 0)); kb[u] = key[bi]; pb[u] = cg_ld<LDS>(par + bi); }
@@ -1207,6 +1210,9 @@ template <bool LDS> __device__ __forceinline__ void cgs_hooks(const MorDev &d, s
       if (want) queue[qn + __popcll(m & lanemask_lt())] = (lane << 26) | bb;   // (enumerating lane, neighbour): the cell is that lane's `a` (local ids < 2²⁶: mor_batch_create bounds max_points)
       qn += __popcll(m);
     }
+#ifdef MOR_EXP_STAMPS
+    { const int s = (int)(soc / d.Nmax); if (lane == 0) { RS_ADD(2, qn); RS_ADD(3, 1); } }
+#endif
     // ---- A2
     for (int q0 = 0; q0 < qn; q0 += 64) {
       const bool act = q0 + lane < qn;

@@ -32,12 +32,13 @@ rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_V
 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/tc -o t -- $PMC > /dev/null 2> $OUT/tc.err || true
 python3 - "$R" "$OUT" "$HEAD_ID" <<'PY'
 import csv, collections, glob, json, sys
+def norm(name): return name.split("(")[0].replace("void ", "").split("<")[0].strip()   # "void k_cg_slab<1024>(MorDev)" -> k_cg_slab
 R, OUT, HEAD = sys.argv[1], sys.argv[2], sys.argv[3]
 def agg(path, name):
     tot, n = collections.Counter(), collections.Counter()
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != name: continue
-        k = r["Kernel_Name"].split("(")[0]; tot[k] += float(r["Counter_Value"]); n[k] += 1
+        k = norm(r["Kernel_Name"]); tot[k] += float(r["Counter_Value"]); n[k] += 1
     return tot, n
 f, nf = agg(OUT + "/fetch/f_counter_collection.csv", "FETCH_SIZE")
 w, nw = agg(OUT + "/write/w_counter_collection.csv", "WRITE_SIZE")
@@ -51,7 +52,7 @@ ctr = collections.defaultdict(dict)
 for path in glob.glob(OUT + "/sq*/*counter_collection.csv") + glob.glob(OUT + "/tc/*counter_collection.csv"):
     tot, n = collections.defaultdict(collections.Counter), collections.Counter()
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = norm(r["Kernel_Name"])
         if not k.startswith("k_"): continue
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
     for k in tot:
@@ -61,7 +62,7 @@ def stats_table(path, o, traffic=None, top=30):
     rows = list(csv.DictReader(open(path)))
     o.write("| kernel | calls | avg µs | % | HBM KB/launch (2·FETCH+WRITE) |\n|---|---|---|---|---|\n")
     for r in rows[:top]:
-        k = r["Name"].split("(")[0]
+        k = norm(r["Name"])
         o.write("| %s | %s | %.1f | %s | %s |\n" % (k, r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"], ("%.0f" % (traffic[k]["hbm_bytes_per_launch"] / 1024)) if traffic and k in traffic else "-"))
 def bench_line(path):
     try:
@@ -72,7 +73,7 @@ def bench_line(path):
 with open("profiles/%s_summary.md" % R, "w") as o:
     o.write("# %s — rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu-baseline --no-kernel-timing --no-extras`\n\n" % R)
     o.write("repo HEAD when collected: `%s`\n\n" % HEAD)
-    o.write("Traced run: %s.  Frames are pipelined over four HIP streams, so kernels overlap and the averages are those of the pipelined regime; under the tracer the host enqueues more slowly and the run is slower than the untraced one — bench.py's own HIP-event figures (`kernels`, `kernels_alone_avg_us` in the bench line) are the untraced counterparts.\n\n" % bench_line(OUT + "/bench_trace.json"))
+    o.write("Traced run: %s.  Frames run on four HIP streams (one frame per stream, four in flight), so kernels overlap and the averages are those of the pipelined regime; under the tracer the host enqueues more slowly and the run is slower than the untraced one — bench.py's own HIP-event figures (`kernels`, `kernels_alone_avg_us` in the bench line) are the untraced counterparts.\n\n" % bench_line(OUT + "/bench_trace.json"))
     stats_table(OUT + "/trace/t_kernel_stats.csv", o, res)
     for W, title in (("os128_b64", "os128_b64 (B = 64 × 262 144 pts)"), ("agg10_b32", "agg10_b32 (B = 32 × 1 000 000 pts)"), ("hdl64_urban_b64", "hdl64_urban_b64 (street scene)"), ("g2", "hdl64_b64 with the voxel-covariance ground removal (--ground-method 1)")):
         try:
@@ -82,7 +83,7 @@ with open("profiles/%s_summary.md" % R, "w") as o:
             o.write("(not collected: %r)\n" % (e,))
     o.write("\n## SQ / TCC counters per launch (hdl64_b64, kernels serialised) — profiles/%s_counters.json\n\n" % R)
     o.write("| kernel | waves | wave-cycles (quad) | wait-any % | LDS-inst active % | VALU-inst active % | LDS bank-conflict % of LDS cycles | L2 hit % |\n|---|---|---|---|---|---|---|---|\n")
-    for k in ("k_cg_slab", "k_cg_final", "k_gridhash", "k_cellboxes", "k_score_fast", "k_score_near", "k_score_block", "k_score_pde", "k_classify", "k_scatter"):
+    for k in ("k_cg_slab", "k_cg_final", "k_gridhash", "k_gridfill", "k_cellboxes", "k_clusters", "k_xform_prev", "k_score_fast", "k_score_near", "k_score_block", "k_score_pde", "k_classify", "k_scatter", "k_out_scatter", "k_track_push"):
         c = ctr.get(k)
         if not c: continue
         wc = max(c.get("SQ_WAVE_CYCLES", 0), 1)

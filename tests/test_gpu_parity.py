@@ -870,3 +870,47 @@ def test_two_batches_in_one_process_interleaved():
             compare_tracks(ob, b, 0, "batch b frame %d" % f)
     a.close()
     b.close()
+
+
+def test_centroids_do_not_depend_on_scheduling():
+    """Cluster centroids come from exact integer coordinate sums per cell (k_cellboxes) added per cluster (k_clusters): the order in
+    which waves and atomics deliver the points must not show.  The same frames through two batches — one with 32 slabs and the
+    radix grid (another order of points inside the cells, other cells sharing wave tiles), one default — give bit-identical
+    centroids, boxes and first points; and the centroid equals the fp64 mean of the cluster's points to the last bit or one ulp."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from dynamicslamtool_amd import kitti_params, synth
+from dynamicslamtool_amd.engine import MorBatch
+p = kitti_params(1)
+b = MorBatch(p, 4, 120000)
+for f in range(2):
+    xs, ps = synth.batch([2003, 2011, 2017, 2040], [f] * 4); b.push(list(xs), ps); b.filter(to_host=False)
+out = []
+for s in range(4):
+    off, idx = b.clusters(s); pts = b.cluster_collection(s); lo, hi = b.boxes(s)
+    out.append((b.centroids(s), lo, hi, off, pts))
+np.save(sys.argv[1], np.array(out, dtype=object), allow_pickle=True)
+""" % root
+    import tempfile
+    res = []
+    with tempfile.TemporaryDirectory() as td:
+        for i, env in enumerate(({}, {"MOR_CG_P": "32", "MOR_GRID": "radix"})):
+            fn = os.path.join(td, "r%d.npy" % i)
+            r = subprocess.run([sys.executable, "-c", script, fn], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+            res.append(np.load(fn, allow_pickle=True))
+    ulp_diffs = 0
+    for s in range(4):
+        (c0, lo0, hi0, off0, pts0), (c1, lo1, hi1, off1, pts1) = res[0][s], res[1][s]
+        assert len(c0) > 5 and np.array_equal(c0.view(np.uint32), c1.view(np.uint32)) and np.array_equal(lo0, lo1) and np.array_equal(hi0, hi1)
+        assert np.array_equal(off0, off1) and np.array_equal(pts0.view(np.uint32), pts1.view(np.uint32))
+        for k in range(len(c0)):
+            q = pts0[off0[k]:off0[k + 1], :3].astype(np.float64)
+            want = (np.add.reduce(q, 0) / len(q)).astype(np.float32)   # (pairwise fp64 sum: the exact sum to ≈ 1e-16 relative)
+            d = np.abs(c0[k].view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+            assert d.max() <= 1, (s, k, c0[k], want)
+            ulp_diffs += int(d.sum())
+    assert ulp_diffs <= 2   # a cast on a rounding boundary at most
