@@ -85,6 +85,7 @@ struct mor_batch {
   // bottleneck: its kernels add up to 0.44 ms of a 0.45 ms period while the cell-graph stream idled half the time.)
   bool lanes = true; int n_lanes = 4;
   hipStream_t extra[4] = {nullptr, nullptr, nullptr, nullptr};   // lanes 5 … 8 (MOR_LANES)
+  hipStream_t strk = nullptr;   // MOR_TRACK_STREAM=1: the tracking steps of all frames (thresholds + tracking, filterCloud) on a fifth stream (measured: 106 k instead of 156 k — more than four busy streams are served worse, as with MOR_LANES > 4)
   hipStream_t lane_stream(uint64_t k) const { const int i = (int)(k % (uint64_t)n_lanes); return i == 0 ? sf : i == 1 ? sc : i == 2 ? sm : i == 3 ? sb : extra[i - 4]; }
   hipEvent_t ev_track[MOR_MAX_SLOTS] = {};      // recorded after the tracking step of a push / a filterCloud
   hipEvent_t *last_track = nullptr;             // the latest of them
@@ -211,6 +212,7 @@ static int wait_all_checked(mor_batch *b) {
   if (!b->pending) return MOR_OK;
   HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sc)); HIP_TRY(hipStreamSynchronize(b->sm)); HIP_TRY(hipStreamSynchronize(b->sb));
   for (auto &x : b->extra) if (x) HIP_TRY(hipStreamSynchronize(x));
+  if (b->strk) HIP_TRY(hipStreamSynchronize(b->strk));
   b->pending = false;
   b->timer.collect();
   int rc = MOR_OK;
@@ -248,6 +250,7 @@ void mor_batch_destroy(mor_batch *b) {
   if (b->sm) hipStreamSynchronize(b->sm);
   if (b->sb) hipStreamSynchronize(b->sb);
   for (auto &x : b->extra) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
+  if (b->strk) { hipStreamSynchronize(b->strk); hipStreamDestroy(b->strk); }
   for (auto &ev : b->args_ev) if (ev) hipEventDestroy(ev);
   for (auto &pe : b->ev_piece) for (auto &ev : pe) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->ev_back) if (ev) hipEventDestroy(ev);
@@ -301,6 +304,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   b->n_lanes = (int)std::min<uint64_t>(4, b->pipe_depth);
   if (getenv("MOR_LANES")) b->n_lanes = std::max(1, std::min<int>((int)std::min<uint64_t>(8, b->pipe_depth), atoi(getenv("MOR_LANES"))));
   for (int i = 4; i < b->n_lanes; ++i) if (hipStreamCreateWithFlags(&b->extra[i - 4], hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
+  if (b->lanes && getenv("MOR_TRACK_STREAM") && hipStreamCreateWithFlags(&b->strk, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
   MorDev &d = b->d; const size_t B = d.B, N = d.Nmax, K = d.Kcap, T = d.tiles_max;
   bool ok = true;
   MorStreamArgs *dargs = nullptr;
@@ -466,12 +470,16 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   hipStream_t tail = b->lanes ? lane : b->sb;
   if (b->lanes) {
     for (int pc = 0; pc < b->n_pieces; ++pc) {
-      if (pc > 0 && k > 0) HIP_TRY(hipStreamWaitEvent(lane, b->ev_piece[pc][(k - 1) % MOR_MAX_SLOTS], 0));
-      if (pc == b->n_pieces - 1 && b->last_track) HIP_TRY(hipStreamWaitEvent(lane, *b->last_track, 0));   // tracking state: after the previous frame's filterCloud
-      mor_launch_piece(d, b->piece_id[pc], lane, &b->timer);
-      HIP_TRY(hipEventRecord(b->ev_piece[pc][k % MOR_MAX_SLOTS], lane));
+      const bool trk = pc == b->n_pieces - 1;
+      hipStream_t ps = trk && b->strk ? b->strk : lane;
+      if (trk && b->strk) HIP_TRY(hipStreamWaitEvent(ps, b->ev_piece[pc - 1][k % MOR_MAX_SLOTS], 0));   // the frame's scores
+      else if (pc > 0 && k > 0) HIP_TRY(hipStreamWaitEvent(ps, b->ev_piece[pc][(k - 1) % MOR_MAX_SLOTS], 0));
+      if (trk && !b->strk && b->last_track) HIP_TRY(hipStreamWaitEvent(ps, *b->last_track, 0));   // tracking state: after the previous frame's filterCloud
+      mor_launch_piece(d, b->piece_id[pc], ps, &b->timer);
+      HIP_TRY(hipEventRecord(b->ev_piece[pc][k % MOR_MAX_SLOTS], ps));
     }
     b->last_track = &b->ev_piece[b->n_pieces - 1][k % MOR_MAX_SLOTS];
+    if (b->strk) tail = b->strk;
   } else {
     for (int pc = 0; pc < MOR_N_PIECES; ++pc) {
       hipStream_t st = S[b->stage_of[pc]];
@@ -502,7 +510,7 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
                        // filterCloud on the same frame walks mo_vec again and moves the confidences again
   b->filtered = true;
   d.out_ptrs = nullptr;
-  hipStream_t fs = b->lanes ? b->lane_stream(k) : b->sb;   // behind the frame's push
+  hipStream_t fs = b->lanes ? (b->strk ? b->strk : b->lane_stream(k)) : b->sb;   // behind the frame's push
   if (b->lanes && b->last_track) HIP_TRY(hipStreamWaitEvent(fs, *b->last_track, 0));   // a second filterCloud of a frame, or the frame's own tracking step (same stream: free)
   if (out && out_on_device) {
     if (b->async && b->last_filter_stream) HIP_TRY(hipStreamSynchronize(b->last_filter_stream));   // the pinned pointer table may still be in flight
