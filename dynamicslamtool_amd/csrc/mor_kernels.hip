@@ -658,15 +658,32 @@ template <bool L> __device__ __forceinline__ void slab_bounds(const MorDev &d, i
   }
   __syncthreads();
 }
+// Runs of equal values in neighbouring lanes of a wave (valid lanes only): the lane that starts the run of this lane and, for
+// a lane that starts a run, its length.  `worth`: the wave has at most half as many runs as points (else every lane is its own
+// leader with length 1: sparse stretches of a cloud only pay for the test).
+__device__ __forceinline__ void gh_runs(int v, bool valid, int &leader, int &len, bool &worth) {
+  const int lane = (int)(threadIdx.x & 63), prev = __shfl_up(v, 1, 64);
+  const unsigned long long mv = __ballot(valid), pv = mv << 1;
+  const unsigned long long ml = __ballot(valid && (lane == 0 || !((pv >> lane) & 1ull) || prev != v));
+  worth = 2 * __popcll(ml) <= __popcll(mv);
+  leader = lane; len = 1;
+  if (worth) {
+    const unsigned long long below = ml & (lanemask_lt() | (1ull << lane));
+    if (below) leader = 63 - __clzll((long long)below);
+    const unsigned long long stop = (ml | ~mv) & (lane == 63 ? 0ull : ~((2ull << lane) - 1ull));
+    len = (stop ? __ffsll((long long)stop) - 1 : 64) - lane;
+  }
+}
 // TL / RL / CL: hash table / row table / per-cell lists in LDS (else global memory).  Returns false when the table
 // overflowed (nothing published yet: the caller re-runs with a bigger table).  `cells` lists the claimed slots in
 // discovery order — every per-cell phase walks it (a few entries per thread) instead of the whole table; `rowlist`
 // first holds the x of the cells of every row, then (same memory) the point counts in compact-id order.
-template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(const MorDev &d, int s, int M, int *tkey, int *tval, int H, int cell_cap, int *rows, int *cells, int *rowlist, int *l_misc, int *l_sh) {
+template <bool TL, bool RL, bool CL, bool AGG> __device__ __forceinline__ bool gh_run(const MorDev &d, int s, int M, int *tkey, int *tval, int H, int cell_cap, int *rows, int *cells, int *rowlist, int *l_misc, int *l_sh) {
   const size_t so = (size_t)s * d.Nmax;
   const int *pkey = d.pkey + so; int *pslot = d.pslot + so, *ppos = d.ppos + so, *pcell = d.pcell + so;
   int *cstart = d.cstart + (size_t)s * (d.Nmax + 1), *ckey = d.ckey + so;
   const int nrows = d.g.nrows, nx = d.g.nx, tid = threadIdx.x;
+  constexpr bool agg = AGG;   // runs of equal keys in neighbouring lanes are counted with one atomic (dense clouds: k_gridhash picks the variant by the stream's point count)
   int hbits = 0; while ((1 << hbits) < H) ++hbits;
   const unsigned hshift = 32 - hbits, mask = (unsigned)H - 1u;
   unsigned long long *chash = d.use_hash ? d.chash + 2 * (size_t)s * d.Hcell : nullptr;
@@ -686,18 +703,29 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
     for (int u = 0; u < GH_U; ++u) { h0[u] = hash_slot(max(key[u], 0), hshift); k0[u] = gh_ld<TL>(tkey + h0[u]); }
 #pragma unroll
     for (int u = 0; u < GH_U; ++u) {
-      if (key[u] < 0) continue;
+      // Points arrive in scan order, so neighbouring lanes often hold the same cell (a wall next to the sensor: all 64): the first
+      // lane of a RUN of equal keys looks the slot up and counts the whole run with one LDS atomic; LDS atomics on one address
+      // serialise lane by lane, and they were what the sweeps of dense clouds spent their time on (agg10: 2.1 → 1.2 ms per step).
+      // Sparse clouds have runs of one or two points and would only pay for the bookkeeping: streams of < 65 536 points go lane by lane.
+      const bool valid = key[u] >= 0;
+      int run_leader = (int)(threadIdx.x & 63), runlen = 1; bool worth = false;
+      if (agg) gh_runs(key[u], valid, run_leader, runlen, worth);
+      const bool lead = valid && run_leader == (int)(threadIdx.x & 63);
       const int want = key[u] + 1; unsigned h = h0[u]; bool ok = k0[u] == want;
-      for (int probes = 0; !ok && probes < H; ++probes) {
-        int k = gh_ld<TL>(tkey + h);
-        if (k == 0) {
-          k = atomicCAS(tkey + h, 0, want);
-          if (k == 0) { k = want; const int n = atomicAdd(&l_misc[0], 1); if (n < cell_cap) gh_st<CL>(cells + n, (int)h); else gh_st<true>(&l_misc[1], 1); }
+      if (lead) {
+        for (int probes = 0; !ok && probes < H; ++probes) {
+          int k = gh_ld<TL>(tkey + h);
+          if (k == 0) {
+            k = atomicCAS(tkey + h, 0, want);
+            if (k == 0) { k = want; const int n = atomicAdd(&l_misc[0], 1); if (n < cell_cap) gh_st<CL>(cells + n, (int)h); else gh_st<true>(&l_misc[1], 1); }
+          }
+          if (k == want) { ok = true; break; }
+          h = (h + 1) & mask;
         }
-        if (k == want) { ok = true; break; }
-        h = (h + 1) & mask;
+        if (ok) atomicAdd(tval + h, runlen); else gh_st<true>(&l_misc[1], 1);
       }
-      if (ok) { atomicAdd(tval + h, 1); pslot[i0 + u * GH_T + tid] = (int)h; } else gh_st<true>(&l_misc[1], 1);
+      if (agg && worth) { h = (unsigned)__shfl((int)h, run_leader, 64); ok = __shfl((int)ok, run_leader, 64) != 0; }
+      if (valid && ok) pslot[i0 + u * GH_T + tid] = (int)h;
     }
   }
   __syncthreads();
@@ -760,10 +788,19 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
     for (int u = 0; u < GH_U; ++u) { const int i = i0 + u * GH_T + tid; sl[u] = i < M ? pslot[i] : -1; }
 #pragma unroll
     for (int u = 0; u < GH_U; ++u) {
-      if (sl[u] < 0) continue;
-      const int i = i0 + u * GH_T + tid;
-      pcell[i] = gh_ld<TL>(tkey + sl[u]) - 1;
-      ppos[i] = atomicAdd(tval + sl[u], 1);
+      const bool valid = sl[u] >= 0;
+      const int lane = (int)(threadIdx.x & 63);
+      int run_leader = lane, runlen = 1; bool worth = false;
+      if (agg) gh_runs(sl[u], valid, run_leader, runlen, worth);
+      const bool lead = valid && run_leader == lane;
+      int base = 0;
+      if (lead) base = atomicAdd(tval + sl[u], runlen);   // one cursor atomic per run of points of one cell
+      if (agg && worth) base = __shfl(base, run_leader, 64);
+      if (valid) {
+        const int i = i0 + u * GH_T + tid;
+        pcell[i] = gh_ld<TL>(tkey + sl[u]) - 1;
+        ppos[i] = base + (lane - run_leader);
+      }
     }
   }
   ST2(stw, 3); ST2V(stw, 4, M); ST2V(stw, 5, nocc);
@@ -777,8 +814,10 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
 #define GH_C0 6144
 #define GH_LDS_INTS (2 * GH_H + GH_ROWS + 1)
 static_assert(2 * GH_H0 + GH_ROWS + 1 + 2 * GH_C0 <= GH_LDS_INTS, "tier-0 layout must fit the tier-1 arena");
+#define GH_RUN(TL_, RL_, CL_, ...) (dense ? gh_run<TL_, RL_, CL_, true>(__VA_ARGS__) : gh_run<TL_, RL_, CL_, false>(__VA_ARGS__))
 __global__ __launch_bounds__(GH_T) void k_gridhash(MorDev d) {
   const int s = blockIdx.x + d.s0, M = d.info[s].M;
+  const bool dense = M >= 65536;   // long runs of points of one cell in scan order: count them per run (gh_run)
   __shared__ int l_mem[GH_LDS_INTS], l_misc[4], l_sh[48];
   const bool rows_lds = d.g.nrows <= GH_ROWS;
   int *grows = d.row_start + (size_t)s * (d.g.nrows + 1);
@@ -788,17 +827,17 @@ __global__ __launch_bounds__(GH_T) void k_gridhash(MorDev d) {
   if (d.gh_tier <= 0) {
     const int H = min(GH_H0, d.Hcell);
     int *rows = l_mem + 2 * GH_H0, *cells = rows + GH_ROWS + 1, *rl = cells + GH_C0;
-    if (rows_lds) done = gh_run<true, true, true>(d, s, M, l_mem, l_mem + H, H, min(GH_C0, H / 4 * 3), rows, cells, rl, l_misc, l_sh);
-    else done = gh_run<true, false, true>(d, s, M, l_mem, l_mem + H, H, min(GH_C0, H / 4 * 3), grows, cells, rl, l_misc, l_sh);
+    if (rows_lds) done = GH_RUN(true, true, true, d, s, M, l_mem, l_mem + H, H, min(GH_C0, H / 4 * 3), rows, cells, rl, l_misc, l_sh);
+    else done = GH_RUN(true, false, true, d, s, M, l_mem, l_mem + H, H, min(GH_C0, H / 4 * 3), grows, cells, rl, l_misc, l_sh);
   }
   if (!done && d.gh_tier <= 1) {
     const int H = min(GH_H, d.Hcell);
-    if (rows_lds) done = gh_run<true, true, false>(d, s, M, l_mem, l_mem + H, H, H / 4 * 3, l_mem + 2 * GH_H, g_cells, g_rowlist, l_misc, l_sh);
-    else done = gh_run<true, false, false>(d, s, M, l_mem, l_mem + H, H, H / 4 * 3, grows, g_cells, g_rowlist, l_misc, l_sh);
+    if (rows_lds) done = GH_RUN(true, true, false, d, s, M, l_mem, l_mem + H, H, H / 4 * 3, l_mem + 2 * GH_H, g_cells, g_rowlist, l_misc, l_sh);
+    else done = GH_RUN(true, false, false, d, s, M, l_mem, l_mem + H, H, H / 4 * 3, grows, g_cells, g_rowlist, l_misc, l_sh);
   }
   if (!done) {   // table in global memory, sized for the cloud (cells ≤ M ≤ H/2)
     int H = 1024; while (H < 2 * M && H < d.Hcell) H <<= 1;
-    gh_run<false, false, false>(d, s, M, d.gh_key + (size_t)s * d.Hcell, d.gh_val + (size_t)s * d.Hcell, H, H, grows, g_cells, g_rowlist, l_misc, l_sh);
+    GH_RUN(false, false, false, d, s, M, d.gh_key + (size_t)s * d.Hcell, d.gh_val + (size_t)s * d.Hcell, H, H, grows, g_cells, g_rowlist, l_misc, l_sh);
   }
 }
 // ---- per-cell accumulators of the streaming cell pass (k_cellboxes): point box, smallest cloud index, exact coordinate sums
