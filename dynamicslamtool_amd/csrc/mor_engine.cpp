@@ -437,7 +437,8 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
      // the launch fills the GPU (two 512-thread workgroups per CU)
     uint32_t maxocc = 0, maxloc = 0;
     for (int s = 0; s < B; ++s) { maxocc = std::max(maxocc, k > 0 ? d.h_info[s].n_occ : 0u); maxloc = std::max(maxloc, k > 0 ? d.h_info[s].max_loc : 0u); }
-    d.cg_big = b->env_cg_big >= 0 ? b->env_cg_big : (maxloc > 1024u * 15 / 16);   // slabs near or beyond the LDS of the small variant last frame: the big one
+    d.cg_big = b->env_cg_big > 0;   // big-slab variant only on request (MOR_CG_BIG=1): one workgroup per CU — the slowest slab gets faster, the kernel does not
+    (void)maxloc;
     const int p_fit = (int)((maxocc * 3ull / 2 + 818) / 819), p_par = (512 + B - 1) / B;   // a slab's LDS holds 1024 cells (own + look-ahead); two 512-thread workgroups per CU
     d.P = b->env_cg_p > 0 ? b->env_cg_p : std::max(p_fit, p_par);
     d.P = std::max(1, std::min(d.P, std::min(MOR_MAXP, std::max(1, d.g.ny / 2))));
