@@ -1202,8 +1202,8 @@ __device__ __forceinline__ int pair_points_thread(const float4 *sp, int a0, int 
 // then, for the whole workgroup:
 //  B1  one thread per listed pair: roots re-checked, then the points (pair_points_thread).
 //  B2  one wave per pair the thread test could not finish (big cells): pruned exhaustive test.
-template <bool LDS> struct CgsCells { const int *key, *pc; const float *rx, *ry, *rz, *bx; int cap; };   // bx: six planes of `cap` floats
-template <bool LDS> __device__ __forceinline__ void cgs_hooks(const MorDev &d, size_t soc, int n_own, int n_loc, const CgsCells<LDS> &L, const int *start, const int *rows, int rsub, int r0, int nlrows,
+template <bool LDS> struct CgsCells { const int *key, *pc; const float *rx, *ry, *rz, *bx; int cap; };   // bx: six planes of `cap` floats (null: samples and boxes stay in global memory)
+template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_hooks(const MorDev &d, size_t soc, int n_own, int n_loc, const CgsCells<LDS> &L, const int *start, const int *rows, int rsub, int r0, int nlrows,
                                                               int *par, const float4 *sp, int *ovf, int *l_list, int *l_queue, int *l_wcnt, int *l_n2, size_t stw) {
   const float r2 = d.r2;
   const int *key = L.key;
@@ -1260,7 +1260,7 @@ template <bool LDS> __device__ __forceinline__ void cgs_hooks(const MorDev &d, s
       bool want = act && cg_find<LDS>(par, qa) != cg_find<LDS>(par, qb);
       if (want) {
         float pax, pay, paz, alx, aly, alz, ahx, ahy, ahz, qx, qy, qz, blx, bly, blz, bhx, bhy, bhz;
-        if (LDS) {
+        if (BOXL) {
           pax = L.rx[qa]; pay = L.ry[qa]; paz = L.rz[qa]; alx = L.bx[qa]; aly = L.bx[L.cap + qa]; alz = L.bx[2 * L.cap + qa]; ahx = L.bx[3 * L.cap + qa]; ahy = L.bx[4 * L.cap + qa]; ahz = L.bx[5 * L.cap + qa];
           qx = L.rx[qb]; qy = L.ry[qb]; qz = L.rz[qb]; blx = L.bx[qb]; bly = L.bx[L.cap + qb]; blz = L.bx[2 * L.cap + qb]; bhx = L.bx[3 * L.cap + qb]; bhy = L.bx[4 * L.cap + qb]; bhz = L.bx[5 * L.cap + qb];
         } else {
@@ -1325,10 +1325,10 @@ template <bool LDS> __device__ __forceinline__ void cgs_hooks(const MorDev &d, s
   ST2V(stw, 10, n1); ST2V(stw, 11, n2);
   __syncthreads();
 }
-template <bool LDS> __device__ __forceinline__ void cgs_body(const MorDev &d, int s, size_t so, int c0, int n_own, int n_loc, const CgsCells<LDS> &L, const int *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_queue, int *l_wcnt, int *l_n2, size_t stwj) {
+template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_body(const MorDev &d, int s, size_t so, int c0, int n_own, int n_loc, const CgsCells<LDS> &L, const int *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_queue, int *l_wcnt, int *l_n2, size_t stwj) {
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1) + c0;   // start[local id]: first position of the cell in `sorted`
   const float4 *sp = d.sorted + so;
-  cgs_hooks<LDS>(d, so + c0, n_own, n_loc, L, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_queue, l_wcnt, l_n2, stwj);
+  cgs_hooks<LDS, BOXL>(d, so + c0, n_own, n_loc, L, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_queue, l_wcnt, l_n2, stwj);
   // local roots as global compact ids: own cells → lroot_a, look-ahead cells → lroot_b
   for (int c = threadIdx.x; c < n_loc; c += CGS_T) {
     const int r = c0 + cg_find<LDS>(par, c);
@@ -1347,12 +1347,18 @@ template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) 
   const size_t stwj = (size_t)s * (MOR_MAXP + 2) + j; (void)stwj;
   ST2(stwj, 0);
   const int y0 = sy[j], y2 = min(sy[j + 1] + 2, d.g.ny), r0 = y0 * d.g.nz, nlrows = (y2 - y0) * d.g.nz;
-  __shared__ float l_rx[CAP], l_ry[CAP], l_rz[CAP], l_bx[6 * CAP];
-  __shared__ int l_key[CAP], l_par[CAP], l_pc[CAP], l_rows[CGS_ROWCAP + 1], l_list[CGS_LISTW], l_queue[CGS_NW * CGS_QW], l_wcnt[CGS_NW], l_n2;
+  // 12·CAP words of cell data: CAP cells with everything in LDS (key, parent, packed coordinates, sample point, box), or —
+  // slabs of up to 4·CAP cells, e.g. a façade across a y-slice — key, parent and packed coordinates only: the enumeration
+  // (A1) and the forest stay in LDS, the decisions about queued pairs (A2) fetch samples and boxes from global memory
+  __shared__ int l_cells[12 * CAP];
+  __shared__ int l_rows[CGS_ROWCAP + 1], l_list[CGS_LISTW], l_queue[CGS_NW * CGS_QW], l_wcnt[CGS_NW], l_n2;
   int *ovf = d.cg_ovf + (size_t)(s * MOR_MAXP + j) * MOR_CGS_OVF * 2;   // [0, MOR_CGS_OVF): the waves' candidate lists, [MOR_CGS_OVF, 2·MOR_CGS_OVF): pairs for whole waves
   const int *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1) + r0;
   if (threadIdx.x == 0) l_n2 = 0;
-  if (n_loc <= CAP && nlrows <= CGS_ROWCAP && !d.cg_force_global) {
+  const bool fits_rows = nlrows <= CGS_ROWCAP && !d.cg_force_global;
+  if (fits_rows && n_loc <= CAP) {
+    int *l_key = l_cells, *l_par = l_cells + CAP, *l_pc = l_cells + 2 * CAP;
+    float *l_rx = reinterpret_cast<float *>(l_cells + 3 * CAP), *l_ry = l_rx + CAP, *l_rz = l_rx + 2 * CAP, *l_bx = l_rx + 3 * CAP;
     const int *gk = d.ckey + so + c0; const float4 *grep = d.crep + so + c0, *gm = d.cmeta + 2 * (so + c0);
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) {
       const int k = gk[i], row = k / d.g.nx;
@@ -1364,14 +1370,25 @@ template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) 
     for (int i = threadIdx.x; i <= nlrows; i += CGS_T) l_rows[i] = g_rows[i] - c0;
     __syncthreads();
     const CgsCells<true> L = {l_key, l_pc, l_rx, l_ry, l_rz, l_bx, CAP};
-    cgs_body<true>(d, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
+    cgs_body<true, true>(d, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
+  } else if (fits_rows && n_loc <= 4 * CAP && !(d.split_variant & 8192)) {
+    int *l_key = l_cells, *l_par = l_cells + 4 * CAP, *l_pc = l_cells + 8 * CAP;
+    const int *gk = d.ckey + so + c0;
+    for (int i = threadIdx.x; i < n_loc; i += CGS_T) {
+      const int k = gk[i], row = k / d.g.nx;
+      l_key[i] = k; l_par[i] = i; l_pc[i] = (int)((unsigned)(k - row * d.g.nx) | ((unsigned)(row % d.g.nz) << 11) | ((unsigned)(row / d.g.nz) << 21));
+    }
+    for (int i = threadIdx.x; i <= nlrows; i += CGS_T) l_rows[i] = g_rows[i] - c0;
+    __syncthreads();
+    const CgsCells<true> L = {l_key, l_pc, nullptr, nullptr, nullptr, nullptr, 0};
+    cgs_body<true, false>(d, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
   } else {   // slab too big for LDS: the same code on global arrays (even and odd slabs use different forests: look-aheads overlap the next slab)
     int *par = ((j & 1) ? d.parent2 : d.parent) + so + c0;
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) cg_st<false>(par + i, i);
     __threadfence();
     __syncthreads();
     const CgsCells<false> L = {d.ckey + so + c0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    cgs_body<false>(d, s, so, c0, n_own, n_loc, L, g_rows, c0, r0, nlrows, par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
+    cgs_body<false, false>(d, s, so, c0, n_own, n_loc, L, g_rows, c0, r0, nlrows, par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
   }
 }
 // One workgroup per stream: merges the slab forests, then components (size, smallest cloud index), the kept clusters
