@@ -766,7 +766,16 @@ template <bool TL, bool RL, bool CL, bool AGG> __device__ __forceinline__ bool g
     const int sl = gh_ld<CL>(cells + e), k = gh_ld<TL>(tkey + sl), key = k - 1, r = key / nx, x = key - r * nx;
     const int b = RL ? (r ? gh_ld<RL>(rows + r - 1) : 0) : gh_ld<RL>(rows + r), e2 = RL ? gh_ld<RL>(rows + r) : gh_ld<RL>(rows + r + 1);
     int c = b;
-    for (int q = b; q < e2; ++q) c += gh_ld<CL>(rowlist + q) < x;
+    if (CL) { for (int q = b; q < e2; ++q) c += gh_ld<CL>(rowlist + q) < x; }
+    else {   // lists in global memory: eight independent loads per round trip (a façade row of urban scenes has 300 cells)
+      for (int q = b; q < e2; q += 8) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = gh_ld<CL>(rowlist + min(q + u, e2 - 1));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c += (q + u < e2) && v[u] < x;
+      }
+    }
     ckey[c] = key;
     gh_st<TL>(tkey + sl, c + 1);
   }
