@@ -576,7 +576,9 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
 //   3. turns the counts into ranges of `sorted` and hands every point its position (LDS cursor per cell),
 // and a wide kernel (k_gridfill) moves the points.  The table doubles as the cell hash of the method-1 scoring tiers.
 // Streams with more cells than the LDS table holds run the same code on a table in global memory.
+#ifndef GH_T
 #define GH_T 1024
+#endif
 #ifndef GH_U
 #define GH_U 4        // points per thread and round trip of the sweeps (8 / 12 measured: no gain — the sweeps are bound by LDS atomics on the hot cells, not by the loads)
 #endif
@@ -1402,7 +1404,9 @@ template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) 
 }
 // One workgroup per stream: merges the slab forests, then components (size, smallest cloud index), the kept clusters
 // (:215-216), their order, per-cell cluster ids, offsets — the tail of the former one-workgroup kernel.
+#ifndef CGF_T
 #define CGF_T 1024
+#endif
 #ifndef CGF_CAP
 #define CGF_CAP 12288
 #endif
@@ -2489,18 +2493,6 @@ __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
 // Dead code in the reference (the call is commented out at :527 and would crash at :188); implemented with the
 // intended semantics and the deterministic definitions of DESIGN.md §G2.  Pass A has trimmed the cloud in x/y
 // and sorted it by VoxelGrid cell (stable ⇒ ascending point index inside a voxel).
-// dsc (:110-113): per voxel, fp32 sums in ascending point index, divided by the count
-__global__ __launch_bounds__(MOR_BT) void k_g2_centroid(MorDev d) {
-  int s = blockIdx.y + d.s0, V = d.info[s].n_occ;
-  const size_t so = (size_t)s * d.Nmax;
-  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
-  for (int v = blockIdx.x * MOR_BT + threadIdx.x; v < V; v += gridDim.x * MOR_BT) {
-    float sx = 0.f, sy = 0.f, sz = 0.f; const int b = st[v], e = st[v + 1];
-    for (int k = b; k < e; ++k) { float4 p = d.sorted[so + k]; sx += p.x; sy += p.y; sz += p.z; }
-    const float n = (float)(e - b);
-    d.vcent[so + v] = make_float4(sx / n, sy / n, sz / n, 0.f);
-  }
-}
 #define G2_CAP 16384    // neighbours of one voxel centroid held in LDS as (d², index) keys (128 KiB of the CU's 160): big-voxel kernel
 #define G2_SMALL 512    // … in the one-wave-per-voxel kernel (4 KiB: many workgroups per CU)
 #define G2_CHUNK 1024   // coordinates staged per step of the ordered fp32 sums

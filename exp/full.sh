@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-O=gpurun_out/r2c26; mkdir -p $O
+O=gpurun_out/full; mkdir -p $O
 export TMPDIR=/tmp
 timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; echo rc=$?; tail -3 $O/pytest.log
 echo "== bench full default"; SECONDS=0; timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo rc=$? wall=${SECONDS}s
