@@ -2566,9 +2566,24 @@ template <int CHUNK> __device__ __forceinline__ int g2_voxel_bin(const MorDev &d
       for (int i = threadIdx.x; i < m; i += blockDim.x) { float4 p = d.rawbuf[so + (int)(key[c0 + i] & 0xffffffffu)]; px[i] = p.x; py[i] = p.y; pz[i] = p.z; }
       __syncthreads();
       if (threadIdx.x == 0) {
-        if (pass == 0) { float cx = acc[0], cy = acc[1], cz = acc[2]; for (int i = 0; i < m; ++i) { cx += px[i]; cy += py[i]; cz += pz[i]; } acc[0] = cx; acc[1] = cy; acc[2] = cz; }
+        // (the sums are a serial chain by definition; what can be hidden is the LDS latency: sixteen elements are loaded ahead of the adds)
+        if (pass == 0) { float cx = acc[0], cy = acc[1], cz = acc[2];
+          int i = 0;
+          for (; i + 16 <= m; i += 16) { float vx[16], vy[16], vz[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { vx[u] = px[i + u]; vy[u] = py[i + u]; vz[u] = pz[i + u]; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { cx += vx[u]; cy += vy[u]; cz += vz[u]; } }
+          for (; i < m; ++i) { cx += px[i]; cy += py[i]; cz += pz[i]; }
+          acc[0] = cx; acc[1] = cy; acc[2] = cz; }
         else { const float cx = acc[0], cy = acc[1], cz = acc[2]; float c02 = acc[3], c12 = acc[4], c22 = acc[5];
-          for (int i = 0; i < m; ++i) { float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; }
+          int i = 0;
+          for (; i + 16 <= m; i += 16) { float vx[16], vy[16], vz[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { vx[u] = px[i + u]; vy[u] = py[i + u]; vz[u] = pz[i + u]; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { float dx = vx[u] - cx, dy = vy[u] - cy, dz = vz[u] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; } }
+          for (; i < m; ++i) { float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; }
           acc[3] = c02; acc[4] = c12; acc[5] = c22; }
       }
       __syncthreads();
@@ -2577,6 +2592,28 @@ template <int CHUNK> __device__ __forceinline__ int g2_voxel_bin(const MorDev &d
     __syncthreads();
   }
   return ((double)fabsf(acc[3]) < 0.001 && (double)fabsf(acc[4]) < 0.001 && (double)fabsf(acc[5]) < 0.001) ? (int)(q.z * 10) : 0x7fffffff;
+}
+// Ordered fp32 sums (:142, :144) over coordinates laid out in rank order in LDS, by ONE lane: Σp / n, then the scatter terms
+// around it.  The adds are a serial chain by definition; the LDS latency is hidden by loading eight elements ahead of them.
+__device__ __forceinline__ bool g2_ordered_sums_flat(const float *lx, const float *ly, const float *lz, int n) {
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  int i = 0;
+  for (; i + 8 <= n; i += 8) { float vx[8], vy[8], vz[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { vx[u] = lx[i + u]; vy[u] = ly[i + u]; vz[u] = lz[i + u]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { cx += vx[u]; cy += vy[u]; cz += vz[u]; } }
+  for (; i < n; ++i) { cx += lx[i]; cy += ly[i]; cz += lz[i]; }
+  const float fn = (float)n; cx /= fn; cy /= fn; cz /= fn;
+  float c02 = 0.f, c12 = 0.f, c22 = 0.f;
+  i = 0;
+  for (; i + 8 <= n; i += 8) { float vx[8], vy[8], vz[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { vx[u] = lx[i + u]; vy[u] = ly[i + u]; vz[u] = lz[i + u]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const float dx = vx[u] - cx, dy = vy[u] - cy, dz = vz[u] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; } }
+  for (; i < n; ++i) { const float dx = lx[i] - cx, dy = ly[i] - cy, dz = lz[i] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; }
+  return (double)fabsf(c02) < 0.001 && (double)fabsf(c12) < 0.001 && (double)fabsf(c22) < 0.001;
 }
 // Sixteen lanes per voxel, sixteen voxels per 256-thread workgroup (a voxel centroid has a dozen neighbours on average, 96 %
 // have ≤ 64): the group computes the voxel's centroid (dsc, :110-113 — fp32 sums in ascending point index, one lane), gathers
@@ -2600,7 +2637,13 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (act && sub == 0) {
       float sx = 0.f, sy = 0.f, sz = 0.f; const int b0 = st[v], e0 = st[v + 1];
-      for (int k = b0; k < e0; ++k) { const float4 p = sp[k]; sx += p.x; sy += p.y; sz += p.z; }
+      for (int k = b0; k < e0; k += 8) {   // eight loads per round trip, the adds in index order
+        float4 p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = sp[min(k + u, e0 - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k + u < e0) { sx += p[u].x; sy += p[u].y; sz += p[u].z; }
+      }
       const float n = (float)(e0 - b0);
       q = make_float4(sx / n, sy / n, sz / n, 0.f);
       d.vcent[so + v] = q;
@@ -2625,22 +2668,27 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
     int wave_max = ncand_max;
 #pragma unroll
     for (int o = 16; o < 64; o <<= 1) wave_max = max(wave_max, __shfl_xor(wave_max, o, 64));
-    for (int c0 = 0; c0 < wave_max; c0 += 16) {
-      const int c = c0 + sub; bool hit = false; float dd = 0.f; float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < rp[9]) {
-        int k = 0;
+    for (int c0 = 0; c0 < wave_max; c0 += 64) {   // four candidates per lane and round trip
+      float4 pc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + 16 * u + sub; int k = 0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) if (c >= rp[r] && c < rp[r + 1]) k = rb[r] + (c - rp[r]);
-        p = sp[k];
-        dd = sqdist(q.x, q.y, q.z, p.x, p.y, p.z);
-        hit = dd < d.leaf_r2;
+        pc[u] = sp[c < rp[9] ? k : 0];
       }
-      const unsigned m16 = (unsigned)((__ballot(hit) >> gsh) & 0xffffull);
-      if (hit) {
-        const int slot = n + __popc(m16 & ((1u << sub) - 1u));
-        if (slot < G2_GROUP_CAP) { l_key[grp][slot] = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(p.w); l_x[grp][slot] = p.x; l_y[grp][slot] = p.y; l_z[grp][slot] = p.z; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + 16 * u + sub; const float4 p = pc[u];
+        const float dd = sqdist(q.x, q.y, q.z, p.x, p.y, p.z);
+        const bool hit = c < rp[9] && dd < d.leaf_r2;
+        const unsigned m16 = (unsigned)((__ballot(hit) >> gsh) & 0xffffull);
+        if (hit) {
+          const int slot = n + __popc(m16 & ((1u << sub) - 1u));
+          if (slot < G2_GROUP_CAP) { l_key[grp][slot] = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(p.w); l_x[grp][slot] = p.x; l_y[grp][slot] = p.y; l_z[grp][slot] = p.z; }
+        }
+        n += __popc(m16);
       }
-      n += __popc(m16);
     }
     __syncthreads();
     // ---- rank by counting (keys are unique: the index is part of them), coordinates to their rank
@@ -2661,14 +2709,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
     for (int u = 0; u < G2_GROUP_CAP / 16; ++u) if (er[u] >= 0) { l_x[grp][er[u]] = ex[u]; l_y[grp][er[u]] = ey[u]; l_z[grp][er[u]] = ez[u]; }
     __syncthreads();
     // ---- ordered fp32 sums (:142, :144) by one lane of the group
-    if (small && sub == 0) {
-      float cx = 0.f, cy = 0.f, cz = 0.f;
-      for (int i = 0; i < n; ++i) { cx += l_x[grp][i]; cy += l_y[grp][i]; cz += l_z[grp][i]; }
-      const float fn = (float)n; cx /= fn; cy /= fn; cz /= fn;
-      float c02 = 0.f, c12 = 0.f, c22 = 0.f;
-      for (int i = 0; i < n; ++i) { const float dx = l_x[grp][i] - cx, dy = l_y[grp][i] - cy, dz = l_z[grp][i] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; }
-      if ((double)fabsf(c02) < 0.001 && (double)fabsf(c12) < 0.001 && (double)fabsf(c22) < 0.001) bin = (int)(q.z * 10);
-    }
+    if (small && sub == 0 && g2_ordered_sums_flat(l_x[grp], l_y[grp], l_z[grp], n)) bin = (int)(q.z * 10);
     if (act && sub == 0) {
       if (n > G2_GROUP_CAP) { const int slot = atomicAdd(&d.g2_nbig[s], 1); d.g2_big[so + slot] = v; }
       else d.vbin[so + v] = bin;
@@ -2743,14 +2784,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
     __syncthreads();
     if (mine && lane == 0) {
       int bin = 0x7fffffff;
-      if (n > 3) {
-        float cx = 0.f, cy = 0.f, cz = 0.f;
-        for (int i = 0; i < n; ++i) { cx += l_x[wv][i]; cy += l_y[wv][i]; cz += l_z[wv][i]; }
-        const float fn = (float)n; cx /= fn; cy /= fn; cz /= fn;
-        float c02 = 0.f, c12 = 0.f, c22 = 0.f;
-        for (int i = 0; i < n; ++i) { const float dx = l_x[wv][i] - cx, dy = l_y[wv][i] - cy, dz = l_z[wv][i] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; }
-        if ((double)fabsf(c02) < 0.001 && (double)fabsf(c12) < 0.001 && (double)fabsf(c22) < 0.001) bin = (int)(q.z * 10);
-      }
+      if (n > 3 && g2_ordered_sums_flat(l_x[wv], l_y[wv], l_z[wv], n)) bin = (int)(q.z * 10);
       d.vbin[so + v] = bin;
       d.g2_big[so + w] = ~v;   // done
     }
