@@ -134,6 +134,7 @@ struct MorDev {
   int *ckey;                 // [B][Nmax]  distinct cell keys, ascending (n_occ of them)
   int *cstart;               // [B][Nmax+1]  first sorted position of each occupied cell
   int *row_start;            // [B][nrows+1]  first occupied cell of each (y,z) row
+  int *gnz, *gnz_out; int cg_nz; float cg_inv_cs;   // voxel ground variant: z layers of the clustering grid per stream (stream_grid); written by pass A through gnz_out
   unsigned long long *chash; // [B][Hcell]  open-addressing hash set of the occupied cells: (key+1) << 32 | compact id, 0 = empty (method 1 only)
   int Hcell, use_hash;       // table capacity per stream (power of two ≥ 4·Nmax); whether this pass builds it
   int *cmin;                 // [B][Nmax]  smallest cloud index in the cell

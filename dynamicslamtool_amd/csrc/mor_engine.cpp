@@ -192,6 +192,7 @@ static int configure(mor_batch *b) {
   d.split_variant = getenv("MOR_SPLIT_VARIANT") ? atoi(getenv("MOR_SPLIT_VARIANT")) : 0;
   d.use_hash = d.method == 1;
   { size_t hc = 1024; while (hc < 4 * (size_t)d.Nmax) hc <<= 1; d.Hcell = (int)hc; }
+  d.gnz = nullptr; d.gnz_out = nullptr; d.cg_nz = d.g.nz; d.cg_inv_cs = d.g.inv_cs;
   d.t1_budget = getenv("MOR_T1_BUDGET") ? atoi(getenv("MOR_T1_BUDGET")) : 64;
   // development / test switches (defaults: the fast paths): MOR_GRID=radix sorts the points by cell key instead of counting
   // cells in a hash table;
@@ -349,6 +350,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (p->method_choice == 2) ok = ok && dalloc(b, d.vox, B * (size_t)d.Hcap);
   ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_nb, B) && dalloc(b, d.wl2, B * N) && dalloc(b, d.wl2_n, B) && dalloc(b, d.dbg, B * 16) && dalloc(b, d.dbg2, B * (MOR_MAXP + 2) * 16);
   ok = ok && dalloc(b, d.zmin_i, B) && dalloc(b, d.zmax_i, B) && dalloc(b, d.zorg, B) && dalloc(b, d.zbase, B) && dalloc(b, d.mode_bin, B);
+  if (d.gmode == 1 && !getenv("MOR_G2_FULL_Z")) ok = ok && dalloc(b, d.gnz, B);
   if (d.gmode == 1) ok = ok && dalloc(b, d.rawbuf, B * N) && dalloc(b, d.is_ground, B * N) && dalloc(b, d.vcent, B * N) && dalloc(b, d.vbin, B * N) && dalloc(b, d.g2_big, B * N) && dalloc(b, d.g2_nbig, B);
   if (ok) {   // crop-box variant: the clustering grid starts at gp_limit for every stream
     std::vector<float> z0(B, p->gp_limit); std::vector<int> zb(B, 0);
@@ -383,7 +385,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     if (b->lanes && d.gmode == 0) ok = ok && dalloc(b, o.pkey, B * N);   // split | grid build are two pieces
     if (d.gmode == 1 && b->lanes)   // voxel ground variant: its grid piece runs as six, these cross their boundaries
       ok = ok && dalloc(b, o.rawbuf, B * N) && dalloc(b, o.is_ground, B * N) && dalloc(b, o.vcent, B * N) && dalloc(b, o.vbin, B * N) && dalloc(b, o.g2_big, B * N) && dalloc(b, o.g2_nbig, B) &&
-           dalloc(b, o.zbase, B) && dalloc(b, o.pkey, B * N) && dalloc(b, o.tile_cnt, B * T * 2) && dalloc(b, o.tile_off, B * T * 2) && dalloc(b, o.zmin_i, B) && dalloc(b, o.zmax_i, B);
+           (d.gnz ? dalloc(b, o.gnz, B) : true) && dalloc(b, o.zbase, B) && dalloc(b, o.pkey, B * N) && dalloc(b, o.tile_cnt, B * T * 2) && dalloc(b, o.tile_off, B * T * 2) && dalloc(b, o.zmin_i, B) && dalloc(b, o.zmax_i, B);
     b->d_args_s[c] = dargs1; o.args = dargs1;
     if (ok) ok = hipMemcpy(o.zorg, d.zorg, B * sizeof(float), hipMemcpyDeviceToDevice) == hipSuccess;
     if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));

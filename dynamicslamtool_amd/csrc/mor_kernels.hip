@@ -62,6 +62,16 @@ __device__ __forceinline__ void map_block_local(int B, int tiles, int &s, int &t
 }
 // d.B streams of this launch start at stream d.s0 of the batch (stream groups run on their own HIP streams)
 #define map_block(B_, tiles_, s_, t_) do { map_block_local((B_), (tiles_), (s_), (t_), d.xcd_map); (s_) += d.s0; } while (0)
+// Voxel ground variant: the clustering grid is laid out for 64 m of z (the variant does not crop in z), but a stream's cloud spans a few
+// metres: pass A publishes the number of z layers the stream needs (gnz) and every kernel working on the clustering grid of that stream
+// uses it — keys, the (y,z) row table and the slab tables then fit LDS as in the crop variant.  Strides of per-stream tables keep the
+// configured row count (d.g.nrows).  gnz null: the grid as configured.  (A copy, not a patch of the kernel argument: patching `d`
+// makes the compiler keep the whole 2 KB argument in scratch memory.)
+__device__ __forceinline__ MorGrid stream_grid(const MorDev &d, int s) {
+  MorGrid g = d.g;
+  if (d.gnz) { g.nz = d.gnz[s]; g.nrows = g.ny * g.nz; }
+  return g;
+}
 
 __device__ __forceinline__ int wave_incl_scan(int v) {
 #pragma unroll
@@ -256,6 +266,10 @@ __device__ __forceinline__ void publish_split(const MorDev &d, int s, int n_ng, 
   if (d.gmode == 1) {   // grids of the voxel variant hang on the lowest trimmed point
     float zmin = f.T ? ordered_float(d.zmin_i[s]) : 0.f;
     d.zorg[s] = zmin; d.zbase[s] = (int)floorf(zmin * d.gv.inv_cs);
+    if (d.gnz_out) {   // z layers of the clustering grid this stream needs (stream_grid)
+      const float zmax = f.T ? ordered_float(d.zmax_i[s]) : 0.f;
+      d.gnz_out[s] = max(1, min(d.cg_nz, (int)floorf((zmax - zmin) * d.cg_inv_cs) + 2));
+    }
   }
 }
 // one workgroup per stream: exclusive scan of the tile counts; publishes N, T, M, G  (only when fuse_scans is off)
@@ -277,6 +291,7 @@ __global__ __launch_bounds__(MOR_BT) void k_scan_tiles(MorDev d) {
 // pass 2: order-preserving split into `cloud` / ground, cell histogram, forest init
 __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   int s, t0; map_block(d.B, d.split_g, s, t0);
+  const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const MorStreamArgs a = d.args[s];
   const uint32_t n_in = pass_count(d, a, s);
   __shared__ int sh[8];
@@ -311,11 +326,11 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
     int k_ng = r_ng + __popcll(m_ng[it] & lanemask_lt());
     int k_g = r_g + __popcll(m_g[it] & lanemask_lt());
     if (cls[it] == 2) {
-      int cx, cy, cz; bool clamped; grid_cell(d.g, p[it], zorg, zbase, cx, cy, cz, clamped);
+      int cx, cy, cz; bool clamped; grid_cell(G, p[it], zorg, zbase, cx, cy, cz, clamped);
       if (clamped && d.gmode != 0) mor_raise(d, s, 8u);   // z extent beyond the grid: cells would no longer be cliques / voxels
       d.cloud[so + k_ng] = p[it];
       d.cloud_tidx[so + k_ng] = k_ng + k_g;   // index in the trimmed cloud (both ranks are exclusive counts of earlier kept points)
-      d.pkey[so + k_ng] = grid_key(d.g, cx, cy, cz);
+      d.pkey[so + k_ng] = grid_key(G, cx, cy, cz);
     } else if (cls[it] == 1) {
       d.ground[2 * so + d.Nmax + k_g] = p[it];   // final place in filterCloud's output: [kept cloud, right-aligned to slot Nmax | ground from slot Nmax]
       d.gp_idx[so + k_g] = k_ng + k_g;
@@ -339,6 +354,7 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
 __device__ __forceinline__ unsigned long long split_pack(unsigned long long st, int ng, int g) { return (st << 62) | ((unsigned long long)(unsigned)ng << 31) | (unsigned long long)(unsigned)g; }
 __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
   int s, t; map_block(d.B, d.tiles, s, t);
+  const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const MorStreamArgs a = d.args[s];
   const uint32_t n_in = pass_count(d, a, s);
   const uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
@@ -402,10 +418,10 @@ __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
     int k_ng = r_ng + __popcll(m_ng[it] & lanemask_lt());
     int k_g = r_g + __popcll(m_g[it] & lanemask_lt());
     if (cls[it] == 2) {
-      int cx, cy, cz; bool clamped; grid_cell(d.g, p[it], zorg, zbase, cx, cy, cz, clamped);
+      int cx, cy, cz; bool clamped; grid_cell(G, p[it], zorg, zbase, cx, cy, cz, clamped);
       if (clamped && d.gmode != 0) mor_raise(d, s, 8u);
       d.cloud[so + k_ng] = p[it];
-      if (!(d.split_variant & 8)) { d.cloud_tidx[so + k_ng] = k_ng + k_g; d.pkey[so + k_ng] = grid_key(d.g, cx, cy, cz); }
+      if (!(d.split_variant & 8)) { d.cloud_tidx[so + k_ng] = k_ng + k_g; d.pkey[so + k_ng] = grid_key(G, cx, cy, cz); }
     } else if (cls[it] == 1) {
       if (!(d.split_variant & 16)) d.ground[2 * so + d.Nmax + k_g] = p[it];
       if (!(d.split_variant & 8)) d.gp_idx[so + k_g] = k_ng + k_g;
@@ -499,6 +515,7 @@ __global__ __launch_bounds__(MOR_BT) void k_hash_clear(MorDev d) {
 // per sorted position: compact cell id; heads publish the cell; every point lands in `sorted`
 __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
   int s, t0; map_block(d.B, d.tiles_m, s, t0);
+  const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int M = d.info[s].M;
   const size_t so = (size_t)s * d.Nmax;
   const int *skey = d.skey + so, *sidx = d.sidx + so;
@@ -507,7 +524,7 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
   int *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
   const int nt = (M + MOR_TILE - 1) / MOR_TILE;
   if (threadIdx.x == 0) l_ng = 0;
-  if (M == 0 && t0 == 0) for (int r = threadIdx.x; r <= d.g.nrows; r += MOR_BT) rs[r] = 0;   // no cells: every row starts (and ends) at 0
+  if (M == 0 && t0 == 0) for (int r = threadIdx.x; r <= G.nrows; r += MOR_BT) rs[r] = 0;   // no cells: every row starts (and ends) at 0
   if (d.fuse_scans) {   // number of occupied cells: every workgroup sums the tile counts itself (no separate scan launch)
     int pre, nocc; wg_prefix_total(d.ktile_cnt + (size_t)s * d.tiles_max, 1, 0, nt, sh, pre, nocc);
     int bits = 10; while ((1 << bits) < 4 * nocc && (1 << bits) < d.Hcell) ++bits;   // cell hash: load factor ≤ 1/4
@@ -542,13 +559,13 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
           d.parent[so + c] = c; d.csize[so + c] = 0; d.compmin[so + c] = 0x7fffffff; d.cid_of_root[so + c] = -1;
           // dense (y,z) row table: rs[r] = first cell with key ≥ r·nx.  The head of cell c owns the rows after its
           // predecessor's row up to its own (keys ascend), so the table is written without any search
-          const int rc = kc / d.g.nx, rp = p > 0 ? skey[p - 1] / d.g.nx : -1;
+          const int rc = kc / G.nx, rp = p > 0 ? skey[p - 1] / G.nx : -1;
           if (rc - rp > 16) { const int g = atomicAdd(&l_ng, 1); if (g < 64) { l_gap[3 * g] = rp; l_gap[3 * g + 1] = rc; l_gap[3 * g + 2] = c; } else for (int r = rp + 1; r <= rc; ++r) rs[r] = c; }
           else for (int r = rp + 1; r <= rc; ++r) rs[r] = c;
         }
         if (p == M - 1) {   // rows behind the last cell (and the end sentinel) start at n_occ
-          const int rl = skey[p] / d.g.nx;
-          const int g = atomicAdd(&l_ng, 1); if (g < 64) { l_gap[3 * g] = rl; l_gap[3 * g + 1] = d.g.nrows; l_gap[3 * g + 2] = c + 1; } else for (int r = rl + 1; r <= d.g.nrows; ++r) rs[r] = c + 1;
+          const int rl = skey[p] / G.nx;
+          const int g = atomicAdd(&l_ng, 1); if (g < 64) { l_gap[3 * g] = rl; l_gap[3 * g + 1] = G.nrows; l_gap[3 * g + 2] = c + 1; } else for (int r = rl + 1; r <= G.nrows; ++r) rs[r] = c + 1;
         }
         d.pcell[so + i] = c;     // compact cell id per cloud point
         float4 q = d.cloud[so + i]; q.w = __int_as_float(i);
@@ -637,8 +654,8 @@ template <bool L> __device__ __forceinline__ int gh_scan(int *a, int n, int *sh)
 // Slab boundaries of the cell graph (k_cg_slab): P slabs of whole y-slices with about equal cell counts, each at least
 // two slices thick so that the two-slice look-ahead of a slab stays inside its successor.  rows = exclusive row table
 // (rows[r] = first compact id of row r, rows[nrows] = n_occ); threads 0 … P of the calling workgroup take part; sh: ≥ 40 ints.
-template <bool L> __device__ __forceinline__ void slab_bounds(const MorDev &d, int s, const int *rows, int nocc, int *sh) {
-  const int P = d.P, ny = d.g.ny, nz = d.g.nz, j = threadIdx.x;
+template <bool L> __device__ __forceinline__ void slab_bounds(const MorDev &d, const MorGrid &G, int s, const int *rows, int nocc, int *sh) {
+  const int P = d.P, ny = G.ny, nz = G.nz, j = threadIdx.x;
   if (j <= P) {
     int y = j == 0 ? 0 : ny;
     if (j > 0 && j < P) {   // smallest y whose first cell id reaches the j-th share of the cells
@@ -680,11 +697,11 @@ __device__ __forceinline__ void gh_runs(int v, bool valid, int &leader, int &len
 // overflowed (nothing published yet: the caller re-runs with a bigger table).  `cells` lists the claimed slots in
 // discovery order — every per-cell phase walks it (a few entries per thread) instead of the whole table; `rowlist`
 // first holds the x of the cells of every row, then (same memory) the point counts in compact-id order.
-template <bool TL, bool RL, bool CL, bool AGG> __device__ __forceinline__ bool gh_run(const MorDev &d, int s, int M, int *tkey, int *tval, int H, int cell_cap, int *rows, int *cells, int *rowlist, int *l_misc, int *l_sh) {
+template <bool TL, bool RL, bool CL, bool AGG> __device__ __forceinline__ bool gh_run(const MorDev &d, const MorGrid &G, int s, int M, int *tkey, int *tval, int H, int cell_cap, int *rows, int *cells, int *rowlist, int *l_misc, int *l_sh) {
   const size_t so = (size_t)s * d.Nmax;
   const int *pkey = d.pkey + so; int *pslot = d.pslot + so, *ppos = d.ppos + so, *pcell = d.pcell + so;
   int *cstart = d.cstart + (size_t)s * (d.Nmax + 1), *ckey = d.ckey + so;
-  const int nrows = d.g.nrows, nx = d.g.nx, tid = threadIdx.x;
+  const int nrows = G.nrows, nx = G.nx, tid = threadIdx.x;
   constexpr bool agg = AGG;   // runs of equal keys in neighbouring lanes are counted with one atomic (dense clouds: k_gridhash picks the variant by the stream's point count)
   int hbits = 0; while ((1 << hbits) < H) ++hbits;
   const unsigned hshift = 32 - hbits, mask = (unsigned)H - 1u;
@@ -747,14 +764,14 @@ template <bool TL, bool RL, bool CL, bool AGG> __device__ __forceinline__ bool g
   gh_scan<RL>(rows, nrows, l_sh);
   if (tid == 0) gh_st<RL>(rows + nrows, nocc);
   __syncthreads();
-  if (RL) { int *grs = d.row_start + (size_t)s * (nrows + 1); for (int r = tid; r <= nrows; r += GH_T) grs[r] = rows[r]; }
-  slab_bounds<RL>(d, s, rows, nocc, l_sh);
+  if (RL) { int *grs = d.row_start + (size_t)s * (d.g.nrows + 1); for (int r = tid; r <= nrows; r += GH_T) grs[r] = rows[r]; }
+  slab_bounds<RL>(d, G, s, rows, nocc, l_sh);
   // ---- the x of the cells of every row, listed (unordered) behind the row's first id.  The LDS copy of the row table
   //      serves as the fill cursor itself (rows[r] becomes the END of row r; the table proper is in global memory by now);
   //      a row table that lives in global memory stays intact and a scratch copy is the cursor
   int *fill = rows;
   if (!RL) {
-    fill = d.gh_rowfill + (size_t)s * (nrows + 1);
+    fill = d.gh_rowfill + (size_t)s * (d.g.nrows + 1);
     for (int r = tid; r < nrows; r += GH_T) gh_st<false>(fill + r, gh_ld<false>(rows + r));
     __syncthreads();
   }
@@ -825,12 +842,13 @@ template <bool TL, bool RL, bool CL, bool AGG> __device__ __forceinline__ bool g
 #define GH_C0 6144
 #define GH_LDS_INTS (2 * GH_H + GH_ROWS + 1)
 static_assert(2 * GH_H0 + GH_ROWS + 1 + 2 * GH_C0 <= GH_LDS_INTS, "tier-0 layout must fit the tier-1 arena");
-#define GH_RUN(TL_, RL_, CL_, ...) (dense ? gh_run<TL_, RL_, CL_, true>(__VA_ARGS__) : gh_run<TL_, RL_, CL_, false>(__VA_ARGS__))
+#define GH_RUN(TL_, RL_, CL_, d_, ...) (dense ? gh_run<TL_, RL_, CL_, true>(d_, G, __VA_ARGS__) : gh_run<TL_, RL_, CL_, false>(d_, G, __VA_ARGS__))
 __global__ __launch_bounds__(GH_T) void k_gridhash(MorDev d) {
   const int s = blockIdx.x + d.s0, M = d.info[s].M;
+  const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const bool dense = M >= 65536;   // long runs of points of one cell in scan order: count them per run (gh_run)
   __shared__ int l_mem[GH_LDS_INTS], l_misc[4], l_sh[48];
-  const bool rows_lds = d.g.nrows <= GH_ROWS;
+  const bool rows_lds = G.nrows <= GH_ROWS;
   int *grows = d.row_start + (size_t)s * (d.g.nrows + 1);
   const size_t so = (size_t)s * d.Nmax;
   int *g_cells = d.gh_cells + so, *g_rowlist = d.gh_rowlist + so;
@@ -1062,10 +1080,11 @@ __device__ __forceinline__ int cg_lower_bound8(const int *key, int lo, int n, in
 // add: order-free), their records were initialised by k_gridfill.
 __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
   int s, bx; map_block(d.B, d.g_box, s, bx);
+  const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int nocc = d.info[s].n_occ, M = d.info[s].M, lane = lane_id();
   const size_t so = (size_t)s * d.Nmax;
   const float4 *sp = d.sorted + so; const int *sc = d.scell + so;
-  if (bx == 0 && d.grid_mode == 0) { __shared__ int l_sb[48]; slab_bounds<false>(d, s, d.row_start + (size_t)s * (d.g.nrows + 1), nocc, l_sb); }   // (the hash path computes them in k_gridhash)
+  if (bx == 0 && d.grid_mode == 0) { __shared__ int l_sb[48]; slab_bounds<false>(d, G, s, d.row_start + (size_t)s * (d.g.nrows + 1), nocc, l_sb); }   // (the hash path computes them in k_gridhash)
   if (d.use_hash && d.grid_mode == 0) {   // cell hash: (key+1, compact id); the table was cleared by k_heads_scatter
     unsigned long long *tab = d.chash + 2 * (size_t)s * d.Hcell; const int *ckey = d.ckey + so;
     const unsigned hshift = d.info[s].hshift, hmask = (1u << (32 - hshift)) - 1u;
@@ -1214,7 +1233,7 @@ __device__ __forceinline__ int pair_points_thread(const float4 *sp, int a0, int 
 //  B1  one thread per listed pair: roots re-checked, then the points (pair_points_thread).
 //  B2  one wave per pair the thread test could not finish (big cells): pruned exhaustive test.
 template <bool LDS> struct CgsCells { const int *key, *pc; const float *rx, *ry, *rz, *bx; int cap; };   // bx: six planes of `cap` floats (null: samples and boxes stay in global memory)
-template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_hooks(const MorDev &d, size_t soc, int n_own, int n_loc, const CgsCells<LDS> &L, const int *start, const int *rows, int rsub, int r0, int nlrows,
+template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_hooks(const MorDev &d, const MorGrid &G, size_t soc, int n_own, int n_loc, const CgsCells<LDS> &L, const int *start, const int *rows, int rsub, int r0, int nlrows,
                                                               int *par, const float4 *sp, int *ovf, int *l_list, int *l_queue, int *l_wcnt, int *l_n2, size_t stw) {
   const float r2 = d.r2;
   const int *key = L.key;
@@ -1234,12 +1253,12 @@ template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_hooks(const M
       same_row = dy == 0 && dz == 0;
       int x, y, z;
       if (LDS) { const unsigned q = (unsigned)L.pc[a]; x = (int)(q & 2047u); z = (int)((q >> 11) & 1023u); y = (int)(q >> 21); }
-      else { const int ka = key[a], rowa = ka / d.g.nx; x = ka - rowa * d.g.nx; z = rowa % d.g.nz; y = rowa / d.g.nz; }
-      if (y + dy < d.g.ny && (unsigned)(z + dz) < (unsigned)d.g.nz) {
-        const int rr = grid_row(d.g, y + dy, z + dz), rl = rr - r0;
+      else { const int ka = key[a], rowa = ka / G.nx; x = ka - rowa * G.nx; z = rowa % G.nz; y = rowa / G.nz; }
+      if (y + dy < G.ny && (unsigned)(z + dz) < (unsigned)G.nz) {
+        const int rr = grid_row(G, y + dy, z + dz), rl = rr - r0;
         if (rl >= 0 && rl < nlrows) {
           const int rlo = rows[rl] - rsub, rn = rows[rl + 1] - rsub - rlo;
-          rowbase = rr * d.g.nx + x; b = rlo; hi = rlo + rn;
+          rowbase = rr * G.nx + x; b = rlo; hi = rlo + rn;
           if (rn > 5) b = cg_lower_bound8(key, rlo, rn, rowbase - 2);
           if (b < hi) ra = cg_find<LDS>(par, a);
         }
@@ -1336,10 +1355,10 @@ template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_hooks(const M
   ST2V(stw, 10, n1); ST2V(stw, 11, n2);
   __syncthreads();
 }
-template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_body(const MorDev &d, int s, size_t so, int c0, int n_own, int n_loc, const CgsCells<LDS> &L, const int *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_queue, int *l_wcnt, int *l_n2, size_t stwj) {
+template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_body(const MorDev &d, const MorGrid &G, int s, size_t so, int c0, int n_own, int n_loc, const CgsCells<LDS> &L, const int *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_queue, int *l_wcnt, int *l_n2, size_t stwj) {
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1) + c0;   // start[local id]: first position of the cell in `sorted`
   const float4 *sp = d.sorted + so;
-  cgs_hooks<LDS, BOXL>(d, so + c0, n_own, n_loc, L, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_queue, l_wcnt, l_n2, stwj);
+  cgs_hooks<LDS, BOXL>(d, G, so + c0, n_own, n_loc, L, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_queue, l_wcnt, l_n2, stwj);
   // local roots as global compact ids: own cells → lroot_a, look-ahead cells → lroot_b
   for (int c = threadIdx.x; c < n_loc; c += CGS_T) {
     const int r = c0 + cg_find<LDS>(par, c);
@@ -1351,13 +1370,14 @@ template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_body(const Mo
 // CGS_CAP_BIG (146 KB) when the previous frame had slabs beyond it (a façade across a y-slice puts > 1000 cells into it).
 template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {
   int s, j; map_block(d.B, d.P, s, j);
+  const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const size_t so = (size_t)s * d.Nmax;
   const int *sy = d.slab_y + (size_t)s * (MOR_MAXP + 1), *sc = d.slab_c + (size_t)s * (MOR_MAXP + 1), *se = d.slab_e + (size_t)s * (MOR_MAXP + 1);
   const int c0 = sc[j], c1 = sc[j + 1], c2 = se[j], n_own = c1 - c0, n_loc = c2 - c0;
   if (n_own <= 0) return;
   const size_t stwj = (size_t)s * (MOR_MAXP + 2) + j; (void)stwj;
   ST2(stwj, 0);
-  const int y0 = sy[j], y2 = min(sy[j + 1] + 2, d.g.ny), r0 = y0 * d.g.nz, nlrows = (y2 - y0) * d.g.nz;
+  const int y0 = sy[j], y2 = min(sy[j + 1] + 2, G.ny), r0 = y0 * G.nz, nlrows = (y2 - y0) * G.nz;
   // 12·CAP words of cell data: CAP cells with everything in LDS (key, parent, packed coordinates, sample point, box), or —
   // slabs of up to 4·CAP cells, e.g. a façade across a y-slice — key, parent and packed coordinates only: the enumeration
   // (A1) and the forest stay in LDS, the decisions about queued pairs (A2) fetch samples and boxes from global memory
@@ -1372,8 +1392,8 @@ template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) 
     float *l_rx = reinterpret_cast<float *>(l_cells + 3 * CAP), *l_ry = l_rx + CAP, *l_rz = l_rx + 2 * CAP, *l_bx = l_rx + 3 * CAP;
     const int *gk = d.ckey + so + c0; const float4 *grep = d.crep + so + c0, *gm = d.cmeta + 2 * (so + c0);
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) {
-      const int k = gk[i], row = k / d.g.nx;
-      l_key[i] = k; l_par[i] = i; l_pc[i] = (int)((unsigned)(k - row * d.g.nx) | ((unsigned)(row % d.g.nz) << 11) | ((unsigned)(row / d.g.nz) << 21));
+      const int k = gk[i], row = k / G.nx;
+      l_key[i] = k; l_par[i] = i; l_pc[i] = (int)((unsigned)(k - row * G.nx) | ((unsigned)(row % G.nz) << 11) | ((unsigned)(row / G.nz) << 21));
       const float4 q = grep[i], lo = gm[2 * i], hi4 = gm[2 * i + 1];
       l_rx[i] = q.x; l_ry[i] = q.y; l_rz[i] = q.z;
       l_bx[i] = lo.x; l_bx[CAP + i] = lo.y; l_bx[2 * CAP + i] = lo.z; l_bx[3 * CAP + i] = hi4.x; l_bx[4 * CAP + i] = hi4.y; l_bx[5 * CAP + i] = hi4.z;
@@ -1381,25 +1401,25 @@ template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) 
     for (int i = threadIdx.x; i <= nlrows; i += CGS_T) l_rows[i] = g_rows[i] - c0;
     __syncthreads();
     const CgsCells<true> L = {l_key, l_pc, l_rx, l_ry, l_rz, l_bx, CAP};
-    cgs_body<true, true>(d, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
+    cgs_body<true, true>(d, G, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
   } else if (fits_rows && n_loc <= 4 * CAP && !(d.split_variant & 8192)) {
     int *l_key = l_cells, *l_par = l_cells + 4 * CAP, *l_pc = l_cells + 8 * CAP;
     const int *gk = d.ckey + so + c0;
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) {
-      const int k = gk[i], row = k / d.g.nx;
-      l_key[i] = k; l_par[i] = i; l_pc[i] = (int)((unsigned)(k - row * d.g.nx) | ((unsigned)(row % d.g.nz) << 11) | ((unsigned)(row / d.g.nz) << 21));
+      const int k = gk[i], row = k / G.nx;
+      l_key[i] = k; l_par[i] = i; l_pc[i] = (int)((unsigned)(k - row * G.nx) | ((unsigned)(row % G.nz) << 11) | ((unsigned)(row / G.nz) << 21));
     }
     for (int i = threadIdx.x; i <= nlrows; i += CGS_T) l_rows[i] = g_rows[i] - c0;
     __syncthreads();
     const CgsCells<true> L = {l_key, l_pc, nullptr, nullptr, nullptr, nullptr, 0};
-    cgs_body<true, false>(d, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
+    cgs_body<true, false>(d, G, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
   } else {   // slab too big for LDS: the same code on global arrays (even and odd slabs use different forests: look-aheads overlap the next slab)
     int *par = ((j & 1) ? d.parent2 : d.parent) + so + c0;
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) cg_st<false>(par + i, i);
     __threadfence();
     __syncthreads();
     const CgsCells<false> L = {d.ckey + so + c0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    cgs_body<false, false>(d, s, so, c0, n_own, n_loc, L, g_rows, c0, r0, nlrows, par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
+    cgs_body<false, false>(d, G, s, so, c0, n_own, n_loc, L, g_rows, c0, r0, nlrows, par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
   }
 }
 // One workgroup per stream: merges the slab forests, then components (size, smallest cloud index), the kept clusters
@@ -1956,13 +1976,14 @@ __device__ __forceinline__ void count_push(bool want, int *cnt, int pr) {
 // the own cell closer than √ub), `wl` back = own cell without a matched point, `wl2` = big own cell (wave tier).
 __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
   int s, t0; map_block(d.B, d.tiles_m * d.g_fast, s, t0);
+  const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, Cp = d.slot_kc[d.prev][s].y;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
   const unsigned long long *tab = d.chash + 2 * (size_t)s * d.Hcell; const unsigned hshift = d.info[s].hshift;
   const float lbn = nextafterf(d.pde_lb, INFINITY);
-  const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + d.g.cs * 1e-3f;
-  const bool e1_local = 2.f * slb < d.g.cs;
+  const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + G.cs * 1e-3f;
+  const bool e1_local = 2.f * slb < G.cs;
   for (int base = t0 * MOR_BT; base < Cp; base += d.tiles_m * d.g_fast * MOR_BT) {
     const int j = base + threadIdx.x;
     bool nearq = false, blockq = false, big = false, counted = false; float best = INFINITY; int pr = -1, target = -1;
@@ -1975,8 +1996,8 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
       // and point → cell → hash probe → cell record → points.  (One after the other they were seven levels deep.)
       const int cidj = d.cl_cid[pv][so + j];
       const float4 q = d.cl_pts[pv][so + j];
-      const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
-      const int key = cell_key(d.g, cx, cy, cz);
+      const int cx = cell_axis_unclamped(q.x, G.ox, G.inv_cs), cy = cell_axis_unclamped(q.y, G.oy, G.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], G.inv_cs);
+      const int key = cell_key(G, cx, cy, cz);
       unsigned sl = hash_slot(max(key, 0), hshift);
       ulonglong2 ent = reinterpret_cast<const ulonglong2 *>(tab)[sl];   // (key + 1, id), (n, b0): the whole slot in one load
       pr = d.pair_of_prev[ko + cidj];
@@ -1999,7 +2020,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
         if (reach && best > d.pde_lb && !big) {
           if (!e1_local) big = true;   // √lb reaches beyond the adjacent half-cells in this configuration: wave tier
           else if (best < d.pde_ub) {
-            if (near_side(q.x, d.g.ox, d.g.inv_cs, d.g.cs, cx, slb) == 0 && near_side(q.y, d.g.oy, d.g.inv_cs, d.g.cs, cy, slb) == 0 && near_side(q.z, d.zorg[s], d.g.inv_cs, d.g.cs, cz, slb) == 0)
+            if (near_side(q.x, G.ox, G.inv_cs, G.cs, cx, slb) == 0 && near_side(q.y, G.oy, G.inv_cs, G.cs, cy, slb) == 0 && near_side(q.z, d.zorg[s], G.inv_cs, G.cs, cz, slb) == 0)
               counted = true;   // deep inside its cell: no other cell can hold a point within √lb ⇒ counted
             else nearq = true;
           } else blockq = true;
@@ -2059,21 +2080,22 @@ __device__ __forceinline__ int wl_entry(const MorDev &d, int p0, int bx, int nq)
 // box records + ranges → points.  No such point ⇒ counted.
 __global__ __launch_bounds__(MOR_BT) void k_score_near(MorDev d) {
   int s, bx; map_block(d.B, d.g_score, s, bx);   // a stream's workgroups share an XCD (its cell tables stay in that L2)
+  const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, nq = (int)(unsigned)d.wl_nb[s];
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
   const unsigned long long *tab = d.chash + 2 * (size_t)s * d.Hcell; const unsigned hshift = d.info[s].hshift;
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float lbn = nextafterf(d.pde_lb, INFINITY);
-  const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + d.g.cs * 1e-3f;
+  const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + G.cs * 1e-3f;
   for (int p0 = 0; p0 < ((nq + 63) & ~63); p0 += d.g_score * MOR_BT) {
     const int w = wl_entry(d, p0, bx, nq);
     bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
     if (w < nq) {
       const int4 we = d.wl[so + w]; j = we.x; pr = we.y; target = we.z;
       const float4 q = d.cl_pts[pv][so + j];
-      const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
-      const int sx = near_side(q.x, d.g.ox, d.g.inv_cs, d.g.cs, cx, slb), sy = near_side(q.y, d.g.oy, d.g.inv_cs, d.g.cs, cy, slb), sz = near_side(q.z, d.zorg[s], d.g.inv_cs, d.g.cs, cz, slb);
+      const int cx = cell_axis_unclamped(q.x, G.ox, G.inv_cs), cy = cell_axis_unclamped(q.y, G.oy, G.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], G.inv_cs);
+      const int sx = near_side(q.x, G.ox, G.inv_cs, G.cs, cx, slb), sy = near_side(q.y, G.oy, G.inv_cs, G.cs, cy, slb), sz = near_side(q.z, d.zorg[s], G.inv_cs, G.cs, cz, slb);
       int budget = d.t1_budget; float best = 0.5f * (d.pde_lb + d.pde_ub) ;   // any value inside (lb, ub): E2 holds
       if (!(best > d.pde_lb && best < d.pde_ub)) best = d.pde_ub * 0.999f;
       int key[8]; int id[8];
@@ -2082,7 +2104,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_near(MorDev d) {
       for (int i = 1; i < 8; ++i) {
         const int ax = i & 1, ay = (i >> 1) & 1, az = i >> 2;
         const bool valid = !(ax && sx == 0) && !(ay && sy == 0) && !(az && sz == 0);
-        key[i] = valid ? cell_key(d.g, cx + ax * sx, cy + ay * sy, cz + az * sz) : -1;
+        key[i] = valid ? cell_key(G, cx + ax * sx, cy + ay * sy, cz + az * sz) : -1;
       }
       hash_resolve_all<8>(tab, hshift, key, id);
       const int ca[4] = {id[1], id[2], id[4], id[3]}, cb2[4] = {id[5], id[6], id[7], -1};   // face neighbours first
@@ -2102,6 +2124,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_near(MorDev d) {
 // box records + ranges → points.  E2 hit ⇒ E1 is decided by the same cells; no hit ⇒ the wider stencil is the wave tier's job.
 __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
   int s, bx; map_block(d.B, d.g_score, s, bx);
+  const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, nq = (int)(d.wl_nb[s] >> 32);
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
@@ -2109,7 +2132,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const int *cid_c = d.ccid + so;
   const float lbn = nextafterf(d.pde_lb, INFINITY);
-  const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + d.g.cs * 1e-3f;
+  const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + G.cs * 1e-3f;
   const bool stencil27 = d.n_rows <= 9 && d.score_R <= 1;   // the whole search stencil is the 3×3×3 block
   for (int p0 = 0; p0 < ((nq + 63) & ~63); p0 += d.g_score * MOR_BT) {
     const int w = wl_entry(d, p0, bx, nq);
@@ -2121,14 +2144,14 @@ __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
     if (w < nq) {
       const int4 we = d.wl[so + d.Nmax - 1 - w]; j = we.x; pr = we.y; target = we.z;
       const float4 q = d.cl_pts[pv][so + j];
-      const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
-      const int sx = near_side(q.x, d.g.ox, d.g.inv_cs, d.g.cs, cx, slb), sy = near_side(q.y, d.g.oy, d.g.inv_cs, d.g.cs, cy, slb), sz = near_side(q.z, d.zorg[s], d.g.inv_cs, d.g.cs, cz, slb);
+      const int cx = cell_axis_unclamped(q.x, G.ox, G.inv_cs), cy = cell_axis_unclamped(q.y, G.oy, G.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], G.inv_cs);
+      const int sx = near_side(q.x, G.ox, G.inv_cs, G.cs, cx, slb), sy = near_side(q.y, G.oy, G.inv_cs, G.cs, cy, slb), sz = near_side(q.z, d.zorg[s], G.inv_cs, G.cs, cz, slb);
       int budget = d.t1_budget; float best = INFINITY;
       int id[27];
       {
         int key[27];
 #pragma unroll
-        for (int i = 0; i < 27; ++i) key[i] = i == 13 ? -1 : cell_key(d.g, cx + i % 3 - 1, cy + (i / 3) % 3 - 1, cz + i / 9 - 1);
+        for (int i = 0; i < 27; ++i) key[i] = i == 13 ? -1 : cell_key(G, cx + i % 3 - 1, cy + (i / 3) % 3 - 1, cz + i / 9 - 1);
         hash_resolve_all<27>(tab, hshift, key, id);
       }
 #ifdef MOR_EXP_STAMPS
@@ -2209,6 +2232,7 @@ __device__ __forceinline__ float wave_scan_cell(const float4 *sp, int b0, int e0
 }
 __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
   const int s = blockIdx.y + d.s0, bx = blockIdx.x;   // a stream's waves spread over all XCDs: the deferred queries are few and uneven across streams
+  const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, nq = d.wl2_n[s];
   const int wv = bx * (MOR_BT / 64) + wave_id(), nw = d.g_pde * (MOR_BT / 64), lane = lane_id();
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
@@ -2218,17 +2242,17 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
   const int R = d.score_R;
   const int *cid_c = d.ccid + so;
   const float lbn = nextafterf(d.pde_lb, INFINITY);
-  const float cs = d.g.cs * 0.999f;   // conservative cell edge for the row lower bounds
+  const float cs = G.cs * 0.999f;   // conservative cell edge for the row lower bounds
   int acc_pr = -1, acc = 0;   // counts of consecutive queries of one pair are flushed together
   for (int w = wv; w < nq; w += nw) {
     const int4 we = d.wl2[so + w];
     const int j = we.x, pr = we.y, target = we.z;
     const float4 q = d.cl_pts[pv][so + j];
-    const int cx = cell_axis_unclamped(q.x, d.g.ox, d.g.inv_cs), cy = cell_axis_unclamped(q.y, d.g.oy, d.g.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], d.g.inv_cs);
+    const int cx = cell_axis_unclamped(q.x, G.ox, G.inv_cs), cy = cell_axis_unclamped(q.y, G.oy, G.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], G.inv_cs);
     float best = INFINITY;
     {  // the query's own cell first
-      const int key = cell_key(d.g, cx, cy, cz);
-      const int c = key >= 0 && d.use_hash ? hash_find(d.chash + 2 * (size_t)s * d.Hcell, d.info[s].hshift, key) : cell_lookup(d.g, ckey, rs, cx, cy, cz);
+      const int key = cell_key(G, cx, cy, cz);
+      const int c = key >= 0 && d.use_hash ? hash_find(d.chash + 2 * (size_t)s * d.Hcell, d.info[s].hshift, key) : cell_lookup(G, ckey, rs, cx, cy, cz);
       if (c >= 0 && d.ccid[so + c] == target) best = wave_scan_cell(sp, st[c], st[c + 1], q, d.pde_lb, lane);
     }
     for (int rb = 0; rb < d.n_rows && best > d.pde_lb; rb += 64) {
@@ -2240,10 +2264,10 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
         lbrow = ly * ly + lz * lz;
         float room = score_lim(best, lbn, d.pde_ub) - lbrow;   // a useful neighbour in this row needs dx² < room
         int y = cy + dy, z = cz + dz;
-        if (room > 0.f && (unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) {
-          int rx = min(R, (int)(sqrtf(room) * d.g.inv_cs * 1.001f) + 1);
-          int x0 = max(cx - rx, 0), x1 = min(cx + rx, d.g.nx - 1);
-          if (x0 <= x1) row_cells(d.g, ckey, rs, x0, x1, y, z, cur, hi);
+        if (room > 0.f && (unsigned)y < (unsigned)G.ny && (unsigned)z < (unsigned)G.nz) {
+          int rx = min(R, (int)(sqrtf(room) * G.inv_cs * 1.001f) + 1);
+          int x0 = max(cx - rx, 0), x1 = min(cx + rx, G.nx - 1);
+          if (x0 <= x1) row_cells(G, ckey, rs, x0, x1, y, z, cur, hi);
         }
       }
       if (__shfl(lbrow, 0, 64) >= score_lim(best, lbn, d.pde_ub)) break;   // rows are ordered by their lower bound
@@ -3080,6 +3104,7 @@ static void mor_launch_boxes(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
 static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gB(d.B);
   MorDev da = d; da.gmode = 1; da.g = d.gv; da.cloud = d.rawbuf; da.cell_passes = d.voxel_passes; da.tiles_m = d.tiles; da.use_hash = 0;
+  da.gnz_out = d.gnz; da.gnz = nullptr; da.cg_nz = d.g.nz; da.cg_inv_cs = d.g.inv_cs;
   da.skey = d.rkeys[da.cell_passes & 1]; da.sidx = d.rvals[da.cell_passes & 1];
   if (sub == 0) {
     hipMemsetD32Async((hipDeviceptr_t)(d.zmin_i + d.s0), 0x7fffffff, d.B, st);
