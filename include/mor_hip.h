@@ -120,7 +120,9 @@ int mor_get_labels(const mor_batch *b, int stream, int32_t *labels_T);
 /* gp_indices (:86): indices into the trimmed cloud, ascending */
 int mor_get_ground_indices(const mor_batch *b, int stream, int32_t *idx_G);
 /* cluster_indices (:218): offsets[K+1] and indices[C] into `cloud`, ascending inside a cluster;
- * clusters ordered by size descending, ties by first index */
+ * clusters ordered by size descending, ties by first index.  (The device keeps a cluster's points cell by cell — nothing it
+ * computes depends on their order; this read-back, the cluster collection and the markers rebuild the reference's order on
+ * the host from the labels.) */
 int mor_get_clusters(const mor_batch *b, int stream, int32_t *offsets, int32_t *indices);
 int mor_get_centroids(const mor_batch *b, int stream, float *xyz_K3);  /* centroid_collection (:243) */
 int mor_get_detection(const mor_batch *b, int stream, uint8_t *det_K); /* detection_results (:593-604) */
