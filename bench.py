@@ -164,7 +164,9 @@ class Leg:
 
     def summary0(self):
         c0 = self.batch.counts(0)
-        return {"T": int(c0.n_trim), "M": int(c0.n_cloud), "G": int(c0.n_ground), "K": int(c0.n_clusters), "C": int(c0.n_clustered), "pairs": int(c0.n_corr), "tracks": int(c0.n_tracks)}
+        tr = sorted(int(self.batch.counts(s).n_tracks) for s in range(self.B))   # tracked centroids per stream: a run that skipped scoring work shows zeros here
+        return {"T": int(c0.n_trim), "M": int(c0.n_cloud), "G": int(c0.n_ground), "K": int(c0.n_clusters), "C": int(c0.n_clustered), "pairs": int(c0.n_corr), "tracks": int(c0.n_tracks),
+                "tracks_all_streams_min_median_max": [tr[0], tr[len(tr) // 2], tr[-1]]}
 
     def close(self):
         self.batch.close()

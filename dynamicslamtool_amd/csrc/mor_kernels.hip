@@ -2876,25 +2876,22 @@ __global__ __launch_bounds__(64) void k_g2_mark(MorDev d) {
 // One workgroup (one wave) per stream.  The state is tiny (a few dozen clusters, pairs and tracked centroids) but the
 // logic is sequential, so it is staged into LDS, run there (no chain of global-memory round trips) and written back.
 // Streams whose vectors exceed the LDS slots run the same code on the global arrays.
-#define TRK 512   // clusters / pairs per window slot held in LDS
-__device__ __forceinline__ void tr_load_state(const MorTrackDev &g, MorTrackDev &l, int lane) {
+#define TRK 384   // clusters / pairs per window slot held in LDS
+// The head of a stream's tracking state (counts, window sizes) lives in LDS while a tracking kernel works on it; the tracked
+// centroids themselves (up to MOR_TR_MAXT of them: 80 KB) stay in global memory unless a kernel scans them repeatedly — k_track_push
+// caches up to TRL of them.  (The whole struct in LDS made these 64-thread workgroups wait for a CU with 117 KB of LDS free.)
+struct MorTrackHead { int n_mo, n_corr, n_res, has_cur, K_last, overflow, pad0, pad1; int corr_n[MOR_TR_NB], res_n[MOR_TR_NB + 1]; };
+static_assert(sizeof(MorTrackHead) == offsetof(MorTrackDev, mo_c), "MorTrackHead is the prefix of MorTrackDev");
+#define TRL 2048   // tracked centroids k_track_push caches in LDS (40 KB)
+__device__ __forceinline__ void tr_load_head(const MorTrackDev &g, MorTrackHead &l, int lane) {
   const int *gs = reinterpret_cast<const int *>(&g); int *ls = reinterpret_cast<int *>(&l);
-  const int head = (int)(offsetof(MorTrackDev, mo_c) / sizeof(int));
-  for (int i = lane; i < head; i += 64) ls[i] = gs[i];
-  __syncthreads();
-  const int n = l.n_mo;
-  for (int i = lane; i < n * 3; i += 64) (&l.mo_c[0][0])[i] = (&g.mo_c[0][0])[i];
-  for (int i = lane; i < n; i += 64) { l.mo_conf[i] = g.mo_conf[i]; l.mo_max[i] = g.mo_max[i]; }
+  for (int i = lane; i < (int)(sizeof(MorTrackHead) / sizeof(int)); i += 64) ls[i] = gs[i];
   __syncthreads();
 }
-__device__ __forceinline__ void tr_store_state(MorTrackDev &g, const MorTrackDev &l, int lane) {
+__device__ __forceinline__ void tr_store_head(MorTrackDev &g, const MorTrackHead &l, int lane) {
   __syncthreads();
   int *gs = reinterpret_cast<int *>(&g); const int *ls = reinterpret_cast<const int *>(&l);
-  const int head = (int)(offsetof(MorTrackDev, mo_c) / sizeof(int));
-  for (int i = lane; i < head; i += 64) gs[i] = ls[i];
-  const int n = l.n_mo;
-  for (int i = lane; i < n * 3; i += 64) (&g.mo_c[0][0])[i] = (&l.mo_c[0][0])[i];
-  for (int i = lane; i < n; i += 64) { g.mo_conf[i] = l.mo_conf[i]; g.mo_max[i] = l.mo_max[i]; }
+  for (int i = lane; i < (int)(sizeof(MorTrackHead) / sizeof(int)); i += 64) gs[i] = ls[i];
 }
 // checkMovingClusterChain (:478-514) with recurseFindClusterChain (:415-453) and pushCentroid (:455-476)
 __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
@@ -2904,10 +2901,21 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
   __syncthreads();
   const int K = d.info[s].K, np = d.has_prev ? (int)d.info[s].n_pairs : -1;
   const size_t ko = (size_t)s * d.Kcap;
-  __shared__ MorTrackDev t;
+  __shared__ MorTrackHead t;
   __shared__ int2 l_corr[MOR_TR_NB][TRK];
   __shared__ unsigned char l_res[MOR_TR_NB + 1][TRK];
-  tr_load_state(d.tr[s], t, lane);
+  __shared__ float l_mo_c[TRL][3];
+  __shared__ int l_mo_conf[TRL], l_mo_max[TRL];
+  MorTrackDev &gt = d.tr[s];
+  tr_load_head(gt, t, lane);
+  // tracked centroids: cached in LDS when they (and what this frame can add) fit, else used where they are
+  const int n_mo0 = t.n_mo; const bool mo_lds = n_mo0 + K <= TRL;
+  float (*mo_c)[3] = mo_lds ? l_mo_c : gt.mo_c; int *mo_conf = mo_lds ? l_mo_conf : gt.mo_conf, *mo_max = mo_lds ? l_mo_max : gt.mo_max;
+  if (mo_lds) {
+    for (int i = lane; i < n_mo0 * 3; i += 64) (&l_mo_c[0][0])[i] = (&gt.mo_c[0][0])[i];
+    for (int i = lane; i < n_mo0; i += 64) { l_mo_conf[i] = gt.mo_conf[i]; l_mo_max[i] = gt.mo_max[i]; }
+    __syncthreads();
+  }
   int2 *g_corr = d.tr_corr + (size_t)s * MOR_TR_NB * d.Kcap;
   unsigned char *g_res = d.tr_res + (size_t)s * (MOR_TR_NB + 1) * d.Kcap, *last = d.tr_lastdet + ko;
   bool fits = K <= TRK && t.K_last <= TRK && np <= TRK;
@@ -2955,14 +2963,15 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
         bool near = false; const int nm = t.n_mo;
         for (int m0 = 0; m0 < nm && !near; m0 += 64) {
           const int m = m0 + lane; bool hit = false;
-          if (m < nm) { double dx = (double)(pt.x - t.mo_c[m][0]), dy = (double)(pt.y - t.mo_c[m][1]), dz = (double)(pt.z - t.mo_c[m][2]); hit = sqrt(dx * dx + dy * dy + dz * dz) < (double)d.catch_up; }
+          if (m < nm) { double dx = (double)(pt.x - mo_c[m][0]), dy = (double)(pt.y - mo_c[m][1]), dz = (double)(pt.z - mo_c[m][2]); hit = sqrt(dx * dx + dy * dy + dz * dz) < (double)d.catch_up; }
           near = __ballot(hit) != 0ull;
         }
         if (near) continue;
         if (lane == 0) {
           if (nm >= MOR_TR_MAXT) { t.overflow = 1; mor_raise(d, s, 32u); }
-          else { t.mo_c[nm][0] = pt.x; t.mo_c[nm][1] = pt.y; t.mo_c[nm][2] = pt.z; t.mo_conf[nm] = t.mo_max[nm] = d.static_confidence + 1; t.n_mo = nm + 1; }   // header :91
+          else { mo_c[nm][0] = pt.x; mo_c[nm][1] = pt.y; mo_c[nm][2] = pt.z; mo_conf[nm] = mo_max[nm] = d.static_confidence + 1; t.n_mo = nm + 1; }   // header :91
         }
+        if (!mo_lds) __threadfence();   // (one wave; the appended centroid must be visible to the next cluster's scan)
         __syncthreads();
       }
     }
@@ -2986,7 +2995,13 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
   __syncthreads();
   for (int k = lane; k < K; k += 64) last[k] = d.det[ko + k];
   if (lane == 0) { t.K_last = K; t.has_cur = 1; d.h_log[(size_t)(d.frame_no % MOR_LOG_CAP) * d.Btot + s].n_mo_push = t.n_mo; }
-  tr_store_state(d.tr[s], t, lane);
+  __syncthreads();
+  if (mo_lds) {   // what this frame appended
+    const int n1 = t.n_mo;
+    for (int i = n_mo0 * 3 + lane; i < n1 * 3; i += 64) (&gt.mo_c[0][0])[i] = (&l_mo_c[0][0])[i];
+    for (int i = n_mo0 + lane; i < n1; i += 64) { gt.mo_conf[i] = l_mo_conf[i]; gt.mo_max[i] = l_mo_max[i]; }
+  }
+  tr_store_head(gt, t, lane);
   if (lane == 0) mor_publish_err(d, s);
 }
 // filterCloud's loop over mo_vec (:630-671): nearest current centroid of every tracked one (squared fp32 distance, ties →
@@ -2996,11 +3011,12 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
   const int s = blockIdx.x + d.s0, K = d.info[s].K, lane = threadIdx.x;
   const size_t ko = (size_t)s * d.Kcap;
   const int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1);
-  __shared__ MorTrackDev t;
+  __shared__ MorTrackHead t;
   __shared__ float4 l_cen[TRK];
   __shared__ int l_size[TRK];
   __shared__ unsigned char l_det[TRK], l_mov[TRK];
-  tr_load_state(d.tr[s], t, lane);
+  MorTrackDev &gt = d.tr[s];   // the tracked centroids are read once and written once (compacted in place): straight from / to global memory
+  tr_load_head(gt, t, lane);
   const bool fits = K <= TRK;
   unsigned char *moving = d.moving + ko;
   for (int k = lane; k < K; k += 64) {
@@ -3018,7 +3034,7 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
       const int i = i0 + lane; const bool v = i < n_mo;
       float c0 = 0, c1 = 0, c2 = 0; int conf = 0, mx = 0; bool keep = false; unsigned long long mine = 0;
       if (v) {
-        c0 = t.mo_c[i][0]; c1 = t.mo_c[i][1]; c2 = t.mo_c[i][2]; conf = t.mo_conf[i]; mx = t.mo_max[i];
+        c0 = gt.mo_c[i][0]; c1 = gt.mo_c[i][1]; c2 = gt.mo_c[i][2]; conf = gt.mo_conf[i]; mx = gt.mo_max[i];
         float bd = INFINITY; int bi = 0;
         for (int k = 0; k < K; ++k) { const float4 c = fits ? l_cen[k] : d.centroid[d.cur][ko + k]; float dd = sqdist(c0, c1, c2, c.x, c.y, c.z); if (dd < bd) { bd = dd; bi = k; } }   // ties → lowest index
         if (fits) l_mov[bi] = 1; else moving[bi] = 1;                      // whole cluster queued for removal before any test (:644-648)
@@ -3037,7 +3053,7 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
       total += mine;
       const unsigned long long km = __ballot(keep);
       __syncthreads();
-      if (keep) { const int o = n_keep + __popcll(km & lanemask_lt()); t.mo_c[o][0] = c0; t.mo_c[o][1] = c1; t.mo_c[o][2] = c2; t.mo_conf[o] = conf; t.mo_max[o] = mx; }
+      if (keep) { const int o = n_keep + __popcll(km & lanemask_lt()); gt.mo_c[o][0] = c0; gt.mo_c[o][1] = c1; gt.mo_c[o][2] = c2; gt.mo_conf[o] = conf; gt.mo_max[o] = mx; }
       n_keep += __popcll(km);
       __syncthreads();
     }
@@ -3047,7 +3063,7 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
   if (fits) for (int k = lane; k < K; k += 64) moving[k] = l_mov[k];
   if (lane == 0) d.moving[(size_t)d.Btot * d.Kcap + s] = total > (unsigned long long)d.info[s].M;   // ExtractIndices: more indices than points ⇒ error, empty output
   if (lane == 0) d.h_log[(size_t)(d.frame_no % MOR_LOG_CAP) * d.Btot + s].n_mo_filter = t.n_mo;
-  tr_store_state(d.tr[s], t, lane);
+  tr_store_head(gt, t, lane);
 }
 
 // ------------------------------------------------------------------------------------ launch sequences
