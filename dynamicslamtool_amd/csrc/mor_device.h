@@ -57,7 +57,7 @@ struct MorFrameInfo {        // per stream, produced on device
 #define MOR_MAX_SLOTS 10     // cluster-array slots (depth + 1 are in use)
 #define MOR_MAXP 32        // slabs per stream of the cell graph (k_cg_slab), at most
 #define MOR_CGS_OVF 8192   // overflow entries per slab of its candidate-pair lists (beyond them a pair is settled on the spot)
-#define MOR_TR_MAXT 4096  // tracked moving centroids per stream (mo_vec); the reference has no bound — beyond this one the push reports MOR_ERR_CAPACITY
+#define MOR_TR_MAXT 32768  // tracked moving centroids per stream (mo_vec); the reference has no bound — beyond this one the push reports MOR_ERR_CAPACITY
 #define MOR_TR_NB 8       // longest supported window (n_bad)
 struct MorTrackDev {
   int n_mo, n_corr, n_res, has_cur, K_last, overflow, pad0, pad1;

@@ -2878,7 +2878,7 @@ __global__ __launch_bounds__(64) void k_g2_mark(MorDev d) {
 // Streams whose vectors exceed the LDS slots run the same code on the global arrays.
 #define TRK 384   // clusters / pairs per window slot held in LDS
 // The head of a stream's tracking state (counts, window sizes) lives in LDS while a tracking kernel works on it; the tracked
-// centroids themselves (up to MOR_TR_MAXT of them: 80 KB) stay in global memory unless a kernel scans them repeatedly — k_track_push
+// centroids themselves (up to MOR_TR_MAXT of them: 640 KB) stay in global memory unless a kernel scans them repeatedly — k_track_push
 // caches up to TRL of them.  (The whole struct in LDS made these 64-thread workgroups wait for a CU with 117 KB of LDS free.)
 struct MorTrackHead { int n_mo, n_corr, n_res, has_cur, K_last, overflow, pad0, pad1; int corr_n[MOR_TR_NB], res_n[MOR_TR_NB + 1]; };
 static_assert(sizeof(MorTrackHead) == offsetof(MorTrackDev, mo_c), "MorTrackHead is the prefix of MorTrackDev");
