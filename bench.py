@@ -96,6 +96,7 @@ class Leg:
             self.B = streams
         self.npts = synth.n_points(self.sensor)
         self.seeds = shard.stream_seeds(cfg, rank, self.B)
+        self.track_capacity_hit = False
         self.n_frames = n_frames
         cb = self.npts * 16
         self.buf = engine.DeviceBuffer(n_frames * self.B * cb, device)
@@ -116,13 +117,24 @@ class Leg:
         k = step % period
         return k if k < self.n_frames else period - k
 
+    def _tolerant(self, fn, *a):
+        """The synthetic streams keep adding tracked centroids; a run of > 10 000 steps reaches the engine's bound (32 768 per stream): the
+        engine then reports MOR_ERR_CAPACITY once per wait, drops the new centroid and carries on — so does the bench (flagged in the line)."""
+        try:
+            return fn(*a)
+        except Exception as e:
+            if "tracked moving centroids" not in str(e):
+                raise
+            self.track_capacity_hit = True
+            return None
+
     def step(self, sync=True):
         f = self.frame_of(self.step_no)
         self.step_no += 1
-        self.batch.push_views(self.views[f], self.poses[f])
+        self._tolerant(self.batch.push_views, self.views[f], self.poses[f])
         if sync:
-            return self.batch.filter_device()
-        self.batch.filter_async()
+            return self._tolerant(self.batch.filter_device)
+        self._tolerant(self.batch.filter_async)
 
     def timed_async(self, steps, dist=None):
         """Enqueue `steps` push + filter pairs (asynchronous mode), wait once; returns seconds (this rank)."""
@@ -133,7 +145,7 @@ class Leg:
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step(sync=False)
-        b.wait()
+        self._tolerant(b.wait)
         b.synchronize()
         if dist:
             dist.barrier()
@@ -291,6 +303,7 @@ def main():
         sync_rate = B * n_sync / (time.perf_counter() - t1)
 
     stream0 = leg.summary0()
+    track_cap = bool(leg.track_capacity_hit)
     stage_totals = {k: sum(leg.batch.stage_counts(s)[k] for s in range(B)) for k in ("n_occ", "n_tier1b", "n_defer", "C_prev")}
     profile = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in p.as_dict().items()}
     seeds_main = leg.seeds
@@ -387,7 +400,7 @@ def main():
             "device_ms_per_step": round(dev_ms, 4), "sync_frame_pairs_per_s": None if sync_rate is None else round(sync_rate, 1),
             "e2e_host_frame_pairs_per_s": None if e2e is None else round(e2e, 2), "latency_b1_ms": None if lat is None else round(lat, 3),
             "algorithmic_bytes_per_frame_pair": int(b_alg),
-            "stage_totals": stage_totals, "stream0": stream0,
+            "stage_totals": stage_totals, "stream0": stream0, "track_capacity_hit": track_cap,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "workloads": others or None,
             "kernels": kernels, "kernels_alone_avg_us": kernels_alone,
             "setup_s": round(setup_s, 2),

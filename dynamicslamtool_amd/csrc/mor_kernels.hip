@@ -2878,11 +2878,10 @@ __global__ __launch_bounds__(64) void k_g2_mark(MorDev d) {
 // Streams whose vectors exceed the LDS slots run the same code on the global arrays.
 #define TRK 384   // clusters / pairs per window slot held in LDS
 // The head of a stream's tracking state (counts, window sizes) lives in LDS while a tracking kernel works on it; the tracked
-// centroids themselves (up to MOR_TR_MAXT of them: 640 KB) stay in global memory unless a kernel scans them repeatedly — k_track_push
-// caches up to TRL of them.  (The whole struct in LDS made these 64-thread workgroups wait for a CU with 117 KB of LDS free.)
+// centroids themselves (up to MOR_TR_MAXT of them: 640 KB) stay in global memory: both kernels stream through them once per frame.
+// (The whole struct in LDS made these 64-thread workgroups wait for a CU with 117 KB of LDS free.)
 struct MorTrackHead { int n_mo, n_corr, n_res, has_cur, K_last, overflow, pad0, pad1; int corr_n[MOR_TR_NB], res_n[MOR_TR_NB + 1]; };
 static_assert(sizeof(MorTrackHead) == offsetof(MorTrackDev, mo_c), "MorTrackHead is the prefix of MorTrackDev");
-#define TRL 2048   // tracked centroids k_track_push caches in LDS (40 KB)
 __device__ __forceinline__ void tr_load_head(const MorTrackDev &g, MorTrackHead &l, int lane) {
   const int *gs = reinterpret_cast<const int *>(&g); int *ls = reinterpret_cast<int *>(&l);
   for (int i = lane; i < (int)(sizeof(MorTrackHead) / sizeof(int)); i += 64) ls[i] = gs[i];
@@ -2904,18 +2903,10 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
   __shared__ MorTrackHead t;
   __shared__ int2 l_corr[MOR_TR_NB][TRK];
   __shared__ unsigned char l_res[MOR_TR_NB + 1][TRK];
-  __shared__ float l_mo_c[TRL][3];
-  __shared__ int l_mo_conf[TRL], l_mo_max[TRL];
+  __shared__ float4 l_cand[TRK], l_acc[TRK];   // centroids found at the end of a chain this frame; those of them already appended
+  __shared__ unsigned char l_cnear[TRK];
   MorTrackDev &gt = d.tr[s];
   tr_load_head(gt, t, lane);
-  // tracked centroids: cached in LDS when they (and what this frame can add) fit, else used where they are
-  const int n_mo0 = t.n_mo; const bool mo_lds = n_mo0 + K <= TRL;
-  float (*mo_c)[3] = mo_lds ? l_mo_c : gt.mo_c; int *mo_conf = mo_lds ? l_mo_conf : gt.mo_conf, *mo_max = mo_lds ? l_mo_max : gt.mo_max;
-  if (mo_lds) {
-    for (int i = lane; i < n_mo0 * 3; i += 64) (&l_mo_c[0][0])[i] = (&gt.mo_c[0][0])[i];
-    for (int i = lane; i < n_mo0; i += 64) { l_mo_conf[i] = gt.mo_conf[i]; l_mo_max[i] = gt.mo_max[i]; }
-    __syncthreads();
-  }
   int2 *g_corr = d.tr_corr + (size_t)s * MOR_TR_NB * d.Kcap;
   unsigned char *g_res = d.tr_res + (size_t)s * (MOR_TR_NB + 1) * d.Kcap, *last = d.tr_lastdet + ko;
   bool fits = K <= TRK && t.K_last <= TRK && np <= TRK;
@@ -2946,32 +2937,65 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
       // the outer loop (clusters flagged in the oldest frame, in index order) is sequential — the order decides which
       // centroid wins inside catch_up_distance — but every inner search runs across the 64 lanes
       const int n0 = t.res_n[0], ncol = t.n_corr;
-      for (int i = 0; i < n0; ++i) {
-        if (!res[i]) continue;
-        int track = i; bool ok = true;
-        for (int col = 0; col < ncol && ok; ++col) {                                                                       // recurseFindClusterChain
-          const int2 *c = corr + (size_t)col * stride; const int n = t.corr_n[col]; int match = -1;
-          for (int j0 = 0; j0 < n && match < 0; j0 += 64) {
-            const int j = j0 + lane; const int2 pr = j < n ? c[j] : make_int2(-1, -1);
-            unsigned long long m = __ballot(pr.x == track);
-            if (m) match = __shfl(pr.y, __ffsll((long long)m) - 1, 64);   // first pair whose query is `track`
+      // pushCentroid (:455-476) appends a centroid unless a tracked one lies within catch_up_distance — of those tracked before
+      // this frame or appended earlier in it (the order of the flagged clusters decides which of two close ones wins).  So: collect
+      // the chain ends in order; ONE pass over the tracked centroids marks the candidates that have an old neighbour (the tracks stream
+      // from global memory once, four per lane and round trip — scanning them per candidate made a stream with 15 000 tracks take
+      // milliseconds); then the candidates go through in order against the few appended before them.
+      int i = 0;
+      while (i < n0) {
+        int nc_ = 0;
+        for (; i < n0 && nc_ < TRK; ++i) {
+          if (!res[i]) continue;
+          int track = i; bool ok = true;
+          for (int col = 0; col < ncol && ok; ++col) {                                                                       // recurseFindClusterChain
+            const int2 *c = corr + (size_t)col * stride; const int n = t.corr_n[col]; int match = -1;
+            for (int j0 = 0; j0 < n && match < 0; j0 += 64) {
+              const int j = j0 + lane; const int2 pr = j < n ? c[j] : make_int2(-1, -1);
+              unsigned long long m = __ballot(pr.x == track);
+              if (m) match = __shfl(pr.y, __ffsll((long long)m) - 1, 64);   // first pair whose query is `track`
+            }
+            if (match < 0 || !res[(size_t)(col + 1) * stride + match]) ok = false; else track = match;
           }
-          if (match < 0 || !res[(size_t)(col + 1) * stride + match]) ok = false; else track = match;
+          if (!ok) continue;
+          if (lane == 0) { l_cand[nc_] = d.centroid[d.cur][ko + track]; l_cnear[nc_] = 0; }                                  // pushCentroid(cb->centroid_collection[found])
+          ++nc_;
         }
-        if (!ok) continue;
-        const float4 pt = d.centroid[d.cur][ko + track];                                                                   // pushCentroid(cb->centroid_collection[found])
-        bool near = false; const int nm = t.n_mo;
-        for (int m0 = 0; m0 < nm && !near; m0 += 64) {
-          const int m = m0 + lane; bool hit = false;
-          if (m < nm) { double dx = (double)(pt.x - mo_c[m][0]), dy = (double)(pt.y - mo_c[m][1]), dz = (double)(pt.z - mo_c[m][2]); hit = sqrt(dx * dx + dy * dy + dz * dz) < (double)d.catch_up; }
-          near = __ballot(hit) != 0ull;
+        __syncthreads();
+        const int nm = t.n_mo;
+        const float (*mc)[3] = gt.mo_c;
+        for (int m0 = 0; m0 < nm; m0 += 256) {
+          float tx[4], ty[4], tz[4]; bool tv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int m = m0 + 64 * u + lane; tv[u] = m < nm; const int mm = min(m, nm - 1); tx[u] = mc[mm][0]; ty[u] = mc[mm][1]; tz[u] = mc[mm][2]; }
+          for (int j = 0; j < nc_; ++j) {
+            if (l_cnear[j]) continue;
+            const float4 pt = l_cand[j]; bool hit = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const double dx = (double)(pt.x - tx[u]), dy = (double)(pt.y - ty[u]), dz = (double)(pt.z - tz[u]); hit |= tv[u] && sqrt(dx * dx + dy * dy + dz * dz) < (double)d.catch_up; }
+            if (__ballot(hit) && lane == 0) l_cnear[j] = 1;
+          }
+          __syncthreads();
         }
-        if (near) continue;
-        if (lane == 0) {
-          if (nm >= MOR_TR_MAXT) { t.overflow = 1; mor_raise(d, s, 32u); }
-          else { mo_c[nm][0] = pt.x; mo_c[nm][1] = pt.y; mo_c[nm][2] = pt.z; mo_conf[nm] = mo_max[nm] = d.static_confidence + 1; t.n_mo = nm + 1; }   // header :91
+        int na = 0;
+        for (int j = 0; j < nc_; ++j) {
+          if (l_cnear[j]) continue;
+          const float4 pt = l_cand[j]; bool near = false;
+          for (int a0 = 0; a0 < na && !near; a0 += 64) {
+            const int a = a0 + lane; bool hit = false;
+            if (a < na) { const float4 q = l_acc[a]; const double dx = (double)(pt.x - q.x), dy = (double)(pt.y - q.y), dz = (double)(pt.z - q.z); hit = sqrt(dx * dx + dy * dy + dz * dz) < (double)d.catch_up; }
+            near = __ballot(hit) != 0ull;
+          }
+          if (near) continue;
+          const int nmc = t.n_mo;
+          if (nmc >= MOR_TR_MAXT) { if (lane == 0) { t.overflow = 1; mor_raise(d, s, 32u); } }
+          else {
+            if (lane == 0) { gt.mo_c[nmc][0] = pt.x; gt.mo_c[nmc][1] = pt.y; gt.mo_c[nmc][2] = pt.z; gt.mo_conf[nmc] = gt.mo_max[nmc] = d.static_confidence + 1; t.n_mo = nmc + 1; l_acc[na] = pt; }   // header :91
+            ++na;
+          }
+          __syncthreads();
         }
-        if (!mo_lds) __threadfence();   // (one wave; the appended centroid must be visible to the next cluster's scan)
+        __threadfence();   // appended centroids: visible to the pass of the next batch (and to the later kernels anyway)
         __syncthreads();
       }
     }
@@ -2995,12 +3019,6 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
   __syncthreads();
   for (int k = lane; k < K; k += 64) last[k] = d.det[ko + k];
   if (lane == 0) { t.K_last = K; t.has_cur = 1; d.h_log[(size_t)(d.frame_no % MOR_LOG_CAP) * d.Btot + s].n_mo_push = t.n_mo; }
-  __syncthreads();
-  if (mo_lds) {   // what this frame appended
-    const int n1 = t.n_mo;
-    for (int i = n_mo0 * 3 + lane; i < n1 * 3; i += 64) (&gt.mo_c[0][0])[i] = (&l_mo_c[0][0])[i];
-    for (int i = n_mo0 + lane; i < n1; i += 64) { gt.mo_conf[i] = l_mo_conf[i]; gt.mo_max[i] = l_mo_max[i]; }
-  }
   tr_store_head(gt, t, lane);
   if (lane == 0) mor_publish_err(d, s);
 }
@@ -3030,31 +3048,38 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
   unsigned long long total = 0;
   const int n_mo = t.n_mo; int n_keep = 0;
   if (K > 0) {
-    for (int i0 = 0; i0 < n_mo; i0 += 64) {
-      const int i = i0 + lane; const bool v = i < n_mo;
-      float c0 = 0, c1 = 0, c2 = 0; int conf = 0, mx = 0; bool keep = false; unsigned long long mine = 0;
-      if (v) {
-        c0 = gt.mo_c[i][0]; c1 = gt.mo_c[i][1]; c2 = gt.mo_c[i][2]; conf = gt.mo_conf[i]; mx = gt.mo_max[i];
-        float bd = INFINITY; int bi = 0;
-        for (int k = 0; k < K; ++k) { const float4 c = fits ? l_cen[k] : d.centroid[d.cur][ko + k]; float dd = sqdist(c0, c1, c2, c.x, c.y, c.z); if (dd < bd) { bd = dd; bi = k; } }   // ties → lowest index
-        if (fits) l_mov[bi] = 1; else moving[bi] = 1;                      // whole cluster queued for removal before any test (:644-648)
-        mine = (unsigned long long)(fits ? l_size[bi] : off[bi + 1] - off[bi]);
-        if (!(fits ? l_det[bi] : d.det[ko + bi]) || bd > d.leave_off) {    // squared vs un-squared: reference quirk kept (:650)
-          keep = --conf != 0;                                              // erased at confidence 0 (:655-660)
-        } else {
-          const float4 c = fits ? l_cen[bi] : d.centroid[d.cur][ko + bi];
-          c0 = c.x; c1 = c.y; c2 = c.z;                                    // :664
-          if (conf < mx) ++conf;                                           // :667
-          keep = true;
+    for (int i0 = 0; i0 < n_mo; i0 += 256) {   // four tracks per lane and round trip (a stream of the bench reaches 15 000 tracked centroids on long runs)
+      float c0[4], c1[4], c2[4]; int conf[4], mx[4]; bool keep[4]; unsigned long long mine = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = min(i0 + 64 * u + lane, n_mo - 1); c0[u] = gt.mo_c[i][0]; c1[u] = gt.mo_c[i][1]; c2[u] = gt.mo_c[i][2]; conf[u] = gt.mo_conf[i]; mx[u] = gt.mo_max[i]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        keep[u] = false;
+        if (i0 + 64 * u + lane < n_mo) {
+          float bd = INFINITY; int bi = 0;
+          for (int k = 0; k < K; ++k) { const float4 c = fits ? l_cen[k] : d.centroid[d.cur][ko + k]; float dd = sqdist(c0[u], c1[u], c2[u], c.x, c.y, c.z); if (dd < bd) { bd = dd; bi = k; } }   // ties → lowest index
+          if (fits) l_mov[bi] = 1; else moving[bi] = 1;                      // whole cluster queued for removal before any test (:644-648)
+          mine += (unsigned long long)(fits ? l_size[bi] : off[bi + 1] - off[bi]);
+          if (!(fits ? l_det[bi] : d.det[ko + bi]) || bd > d.leave_off) {    // squared vs un-squared: reference quirk kept (:650)
+            keep[u] = --conf[u] != 0;                                        // erased at confidence 0 (:655-660)
+          } else {
+            const float4 c = fits ? l_cen[bi] : d.centroid[d.cur][ko + bi];
+            c0[u] = c.x; c1[u] = c.y; c2[u] = c.z;                           // :664
+            if (conf[u] < mx[u]) ++conf[u];                                  // :667
+            keep[u] = true;
+          }
         }
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
       total += mine;
-      const unsigned long long km = __ballot(keep);
-      __syncthreads();
-      if (keep) { const int o = n_keep + __popcll(km & lanemask_lt()); gt.mo_c[o][0] = c0; gt.mo_c[o][1] = c1; gt.mo_c[o][2] = c2; gt.mo_conf[o] = conf; gt.mo_max[o] = mx; }
-      n_keep += __popcll(km);
+      __syncthreads();   // (all reads of this round are done: survivors are compacted in place, order kept)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned long long km = __ballot(keep[u]);
+        if (keep[u]) { const int o = n_keep + __popcll(km & lanemask_lt()); gt.mo_c[o][0] = c0[u]; gt.mo_c[o][1] = c1[u]; gt.mo_c[o][2] = c2[u]; gt.mo_conf[o] = conf[u]; gt.mo_max[o] = mx[u]; }
+        n_keep += __popcll(km);
+      }
       __syncthreads();
     }
     if (lane == 0) t.n_mo = n_keep;
