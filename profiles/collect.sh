@@ -16,6 +16,7 @@ OUT=gpurun_out/prof_$R
 rm -rf $OUT; mkdir -p $OUT profiles
 HEAD_ID=$(cat .git_head 2>/dev/null || echo unknown)
 BASE="--no-cpu-baseline --no-kernel-timing --no-extras"
+python3 bench.py --no-cpu-baseline --no-extras > $OUT/bench_untraced.json 2> $OUT/bench_untraced.err || true   # the same leg without the tracer, bench.py's own HIP-event timing on
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py $BASE > $OUT/bench_trace.json 2> $OUT/trace.err
 cp $OUT/trace/t_kernel_stats.csv profiles/${R}_kernel_stats.csv
 for W in os128_b64 agg10_b32 hdl64_urban_b64; do
@@ -75,6 +76,15 @@ with open("profiles/%s_summary.md" % R, "w") as o:
     o.write("repo HEAD when collected: `%s`\n\n" % HEAD)
     o.write("Traced run: %s.  Frames run on four HIP streams (one frame per stream, four in flight), so kernels overlap and the averages are those of the pipelined regime; under the tracer the host enqueues more slowly and the run is slower than the untraced one — bench.py's own HIP-event figures (`kernels`, `kernels_alone_avg_us` in the bench line) are the untraced counterparts.\n\n" % bench_line(OUT + "/bench_trace.json"))
     stats_table(OUT + "/trace/t_kernel_stats.csv", o, res)
+    try:   # the untraced counterpart: bench.py's HIP-event averages of the same leg
+        d = json.loads(open(OUT + "/bench_untraced.json").read().strip().splitlines()[-1])
+        k, a = d["kernels"], d["kernels_alone_avg_us"]
+        o.write("\n### The same leg untraced (bench.py, HIP events on the launching stream): %.0f frame-pairs/s, %.4f ms per step\n\n" % (d["value"], d["ms_per_step"]))
+        o.write("Under the tracer the host enqueues ≈ 0.55 ms per step, so fewer frames overlap and every kernel runs closer to its alone time; untraced, four frames are in flight and a kernel's workgroups wait for wave slots and LDS held by the others (DESIGN.md §8).\n\n")
+        o.write("| kernel | avg µs pipelined | avg µs alone (synchronous steps) |\n|---|---|---|\n")
+        for n in sorted(k, key=lambda n: -k[n]["avg_us"]): o.write("| %s | %.1f | %.1f |\n" % (n, k[n]["avg_us"], a.get(n, 0)))
+    except Exception as e:
+        o.write("\n(untraced leg not collected: %r)\n" % (e,))
     for W, title in (("os128_b64", "os128_b64 (B = 64 × 262 144 pts)"), ("agg10_b32", "agg10_b32 (B = 32 × 1 000 000 pts)"), ("hdl64_urban_b64", "hdl64_urban_b64 (street scene)"), ("g2", "hdl64_b64 with the voxel-covariance ground removal (--ground-method 1)")):
         try:
             o.write("\n## %s\n\ntraced run: %s\n\n" % (title, bench_line(OUT + "/bench_%s.json" % W)))
