@@ -304,6 +304,12 @@ def main():
 
     stream0 = leg.summary0()
     track_cap = bool(leg.track_capacity_hit)
+    # A guard against fast-because-wrong runs (a kernel that skips work is quick): with the default arguments the synthetic streams are
+    # deterministic, so stream 0 must end the legs above in exactly this state (checked by the parity suite against the oracle, recorded here).
+    sanity = None
+    if (args.workload, args.steps, args.warmup, args.method, args.ground_method, world, bool(extras), bool(args.streams)) == ("hdl64_b64", 200, 5, 1, 0, 1, True, False):
+        want = {"T": 110036, "M": 10700, "G": 99336, "K": 19, "C": 10675, "pairs": 18, "tracks": 21}
+        sanity = {"expected_stream0": want, "ok": all(stream0.get(k) == v for k, v in want.items())}
     stage_totals = {k: sum(leg.batch.stage_counts(s)[k] for s in range(B)) for k in ("n_occ", "n_tier1b", "n_defer", "C_prev")}
     profile = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in p.as_dict().items()}
     seeds_main = leg.seeds
@@ -400,7 +406,7 @@ def main():
             "device_ms_per_step": round(dev_ms, 4), "sync_frame_pairs_per_s": None if sync_rate is None else round(sync_rate, 1),
             "e2e_host_frame_pairs_per_s": None if e2e is None else round(e2e, 2), "latency_b1_ms": None if lat is None else round(lat, 3),
             "algorithmic_bytes_per_frame_pair": int(b_alg),
-            "stage_totals": stage_totals, "stream0": stream0, "track_capacity_hit": track_cap,
+            "stage_totals": stage_totals, "stream0": stream0, "track_capacity_hit": track_cap, "sanity": sanity,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "workloads": others or None,
             "kernels": kernels, "kernels_alone_avg_us": kernels_alone,
             "setup_s": round(setup_s, 2),
