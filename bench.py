@@ -5,16 +5,24 @@ One "step" = one pushRawCloudAndPose + filterCloud pass over a batch of B indepe
 streams (B frame-pairs at steady state).  Workload at N=1: BASELINE.json configs[1] — B=64 synthetic
 KITTI-HDL-64 streams (120 000 pts per frame, SURVEY.md §8d generator), KITTI parameter profile,
 method 1 (NN-distance).  Inputs are resident in HBM before the timed region; outputs stay in HBM.
-Multi-GPU: one process per GPU, each runs its own B streams (weak scaling, no data-path
-collective); torch.distributed (gloo, CPU tensors) only provides the barrier and the max-over-ranks.
 
-Prints ONE JSON line on rank 0.  Besides the contract's keys it carries: `value_runs` (repeats of the timed leg),
-`roofline` (dominant kernel + whole-path figures), `cpu_baseline` (+ all cores), `workloads` (the other BASELINE
-configurations, short legs, never `value`), `sync_frame_pairs_per_s`, `e2e_host_frame_pairs_per_s`, `latency_b1_ms`.
+Multi-GPU (BASELINE config 4): one process per GPU, each runs its own B streams (weak scaling, NO data-path
+collective — the line says "collective": "none"); torch.distributed (gloo, CPU tensors) only provides the barrier and
+the max-over-ranks.  Launch: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N … bench.py --gpus N`, or
+simply `python bench.py --gpus N`: without WORLD_SIZE in the environment the script starts the N ranks itself (fresh
+child processes, before anything here touches HIP) and relays rank 0's line.  Rank r uses device r mod (visible devices).
+
+Prints ONE JSON line on rank 0.  Besides the contract's keys it carries `value_runs` (repeats of the timed leg), `sanity`
+(the timed frames against a synchronous re-run and against the CPU oracle's summaries of the same frames), `roofline`
+(dominant kernel + whole path + per-kernel HBM traffic), `cpu_baseline` (+ all cores, one definition), `workloads` (the
+other BASELINE configurations, method 2, the voxel-covariance ground variant: short legs, never `value`),
+`sync_frame_pairs_per_s`, `e2e_host_frame_pairs_per_s`, `latency_b1_ms`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,74 +32,144 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 WORKLOADS = {
-    # name: (sensor, streams per GPU, BASELINE.json config index — seeds are 1000·config + global stream)
-    "hdl64_b64": ("hdl64", 64, 2),
-    "os128_b64": ("os128", 64, 3),
-    "agg10_b32": ("agg10", 32, 5),
-    "hdl64_urban_b64": ("hdl64_urban", 64, 6),
+    # name: (sensor, streams per GPU, BASELINE.json config index — seeds are 1000·config + global stream, method override, ground-method override)
+    "hdl64_b64": ("hdl64", 64, 2, None, None),
+    "os128_b64": ("os128", 64, 3, None, None),
+    "agg10_b32": ("agg10", 32, 5, None, None),
+    "hdl64_urban_b64": ("hdl64_urban", 64, 6, None, None),
+    "hdl64_b64_method2": ("hdl64", 64, 2, 2, None),         # getClusterPointcloudChangeVector (:309-334), the reference's config default
+    "hdl64_b64_voxel_ground": ("hdl64", 64, 2, None, 1),    # groundPlaneRemoval(x,y) (:90-200)
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4-copy ceiling)
+LOG_KEYS = ("K", "C", "n_pairs", "cnt_sum", "det_sum", "n_mo_push", "n_mo_filter", "n_out", "flags")
+ORACLE_KEYS = ("K", "C", "n_pairs", "det_sum", "n_mo_push", "n_mo_filter", "n_out")
 
 
+# ------------------------------------------------------------------------------------------------ multi-rank self-launch
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: N fresh children (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set), started before this
+    process has imported anything that initialises HIP (it never does); rank 0 inherits stdout, so its ONE line is this command's line."""
+    port = str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, MOR_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def bind_rank_to_cores(local_rank, world):
+    """Rank r keeps the r-th slice of the cores this process may run on (host threads of one rank stay on one part of the machine; the
+    OpenMP cloud generator of each rank then uses its slice only instead of every rank using every core)."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // world
+        if world > 1 and per >= 1:
+            os.sched_setaffinity(0, cores[local_rank * per:(local_rank + 1) * per])
+            return per
+        return len(cores)
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline (the oracle, timed)
 _CPU_BARRIER = None
 
 
-def _cpu_stream(job):
-    """One independent stream through the CPU oracle (a worker of the all-cores baseline): returns (frame-pairs, seconds)."""
-    seed, sensor, method, ground_method, pairs = job
+def _cpu_worker(job):
+    """A worker of the CPU baseline: its share of the streams through the CPU oracle, one after the other.  Returns, per stream,
+    (seed, frame-pairs, busy seconds, per-frame summaries) and the (start, end) of its timed part on the system-wide monotonic clock."""
+    seeds, sensor, method, ground_method, pairs = job
     from dynamicslamtool_amd import kitti_params, synth
-    from oracle.oracle import Oracle
+    from oracle.oracle import Oracle   # the checker; timed here only as the reported CPU baseline
     p = kitti_params(method)
     p.ground_method = ground_method
-    o = Oracle(p, 4, 3)
-    x, ps = synth.frame(seed, sensor, 0)
-    o.push(x, ps)
-    o.filter()
-    frames = [synth.frame(seed, sensor, f) for f in range(1, pairs + 1)]
+    oracles, frames, sums = [], [], []
+
+    def summary(o, n_out, tracks_push):
+        c = o.counts()
+        det = o.detection()
+        return {"K": int(c.n_clusters), "C": int(c.n_clustered), "n_pairs": int(c.n_corr), "det_sum": int(sum(k + 1 for k in range(len(det)) if det[k])),
+                "n_mo_push": int(tracks_push), "n_mo_filter": int(c.n_tracks), "n_out": int(n_out)}
+    for seed in seeds:   # untimed: frame 0 (no previous frame ⇒ no frame-pair yet) and the inputs of the timed frames
+        o = Oracle(p, 4, 3)
+        x, ps = synth.frame(seed, sensor, 0)
+        o.push(x, ps)
+        tp = o.counts().n_tracks
+        out = o.filter()
+        sums.append([summary(o, len(out), tp)])
+        oracles.append(o)
+        frames.append([synth.frame(seed, sensor, f) for f in range(1, pairs + 1)])
     if _CPU_BARRIER is not None:
         _CPU_BARRIER.wait()   # every worker has its inputs: the timed parts run side by side, nothing else on the cores
-    t0 = time.perf_counter()
-    for x, ps in frames:
-        o.push(x, ps)
-        o.filter()
-    dt = time.perf_counter() - t0
-    o.close()
-    return pairs, dt
+    t_start = time.monotonic()
+    res = []
+    for i, seed in enumerate(seeds):
+        o, busy = oracles[i], 0.0
+        for x, ps in frames[i]:
+            t0 = time.perf_counter()
+            o.push(x, ps)
+            tp = o.counts().n_tracks
+            out = o.filter()
+            busy += time.perf_counter() - t0
+            sums[i].append(summary(o, len(out), tp))
+        res.append((seed, pairs, busy, sums[i]))
+        o.close()
+    return res, t_start, time.monotonic()
 
 
-def cpu_all_cores(seeds, sensor, method, ground_method, pairs=3, max_workers=64):
-    """'all cores' = one independent stream per core.  Runs before anything touches the GPU (forked workers)."""
+def cpu_baseline_run(seeds, sensor, method, ground_method, pairs=3, max_workers=64):
+    """ONE definition for both CPU figures: every stream of the GPU batch goes through the single-threaded CPU oracle for
+    `pairs` steady-state frame-pairs, one oracle process per core, all cores busy side by side.  single core = total frame-pairs ÷ total
+    core-seconds; all cores = total frame-pairs ÷ wall of the side-by-side part.  Runs before anything touches the GPU (forked workers)."""
     import multiprocessing as mp
-    n = max(1, min(os.cpu_count() or 1, max_workers, len(seeds)))
     global _CPU_BARRIER
-    jobs = [(seeds[i], sensor, method, ground_method, pairs) for i in range(n)]
-    t0 = time.perf_counter()
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = max(1, min(ncpu, max_workers, len(seeds)))
+    shares = [seeds[i::n] for i in range(n)]
     ctx = mp.get_context("fork")
     _CPU_BARRIER = ctx.Barrier(n)
     omp = os.environ.get("OMP_NUM_THREADS")
     os.environ["OMP_NUM_THREADS"] = "1"   # the synthetic-cloud generator is OpenMP-parallel: one thread per worker here
     try:
         with ctx.Pool(n) as pool:
-            res = pool.map(_cpu_stream, jobs, chunksize=1)
+            res = pool.map(_cpu_worker, [(sh, sensor, method, ground_method, pairs) for sh in shares], chunksize=1)
     finally:
         _CPU_BARRIER = None
         if omp is None:
             os.environ.pop("OMP_NUM_THREADS", None)
         else:
             os.environ["OMP_NUM_THREADS"] = omp
-    wall = time.perf_counter() - t0
-    rates = [r[0] / r[1] for r in res]
-    return {"value": round(sum(rates), 2), "unit": "frame-pairs/s", "cores": n, "kind": "port",
-            "sample": "%d independent streams x %d steady-state frame-pairs, one oracle process per core, all running side by side; value = sum of the per-core rates" % (n, pairs),
-            "per_core_min_max": [round(min(rates), 3), round(max(rates), 3)], "wall_s": round(wall, 1)}
+    streams = [r for w in res for r in w[0]]
+    wall = max(w[2] for w in res) - min(w[1] for w in res)
+    tot_pairs, core_s = sum(r[1] for r in streams), sum(r[2] for r in streams)
+    rates = [r[1] / r[2] for r in streams]
+    sample = "%d streams (the GPU batch's own) x %d steady-state frame-pairs of %s, oracle/mor_oracle.c (kd-tree + BFS restatement, not PCL), %d single-threaded processes side by side" % (len(streams), pairs, sensor, n)
+    single = {"value": round(tot_pairs / core_s, 3), "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+              "sample": sample + "; value = total frame-pairs / total core-seconds", "core_seconds": round(core_s, 2), "frame_pairs": tot_pairs,
+              "per_stream_rate_min_median_max": [round(min(rates), 3), round(float(np.median(rates)), 3), round(max(rates), 3)], "host_cpus": os.cpu_count()}
+    allc = {"value": round(tot_pairs / wall, 2), "unit": "frame-pairs/s", "cores": n, "kind": "port",
+            "sample": sample + "; value = total frame-pairs / wall of the side-by-side part", "wall_s": round(wall, 2), "frame_pairs": tot_pairs}
+    summaries = {r[0]: r[3] for r in streams}   # seed → [frame 0 … frame `pairs`]
+    return single, allc, summaries
 
 
+# ------------------------------------------------------------------------------------------------ a workload resident in HBM
 class Leg:
     """B device-resident synthetic streams of one workload + a MorBatch, ready to step."""
 
     def __init__(self, engine, synth, shard, p, workload, rank, device, n_frames, streams=0):
-        self.engine, self.name = engine, workload
-        self.sensor, self.B, cfg = WORKLOADS[workload]
+        self.engine, self.name, self.p, self.device = engine, workload, p, device
+        self.sensor, self.B, cfg = WORKLOADS[workload][:3]
         if streams:
             self.B = streams
         self.npts = synth.n_points(self.sensor)
@@ -128,13 +206,14 @@ class Leg:
             self.track_capacity_hit = True
             return None
 
-    def step(self, sync=True):
+    def step(self, sync=True, batch=None):
+        b = batch or self.batch
         f = self.frame_of(self.step_no)
         self.step_no += 1
-        self._tolerant(self.batch.push_views, self.views[f], self.poses[f])
+        self._tolerant(b.push_views, self.views[f], self.poses[f])
         if sync:
-            return self._tolerant(self.batch.filter_device)
-        self._tolerant(self.batch.filter_async)
+            return self._tolerant(b.filter_device)
+        self._tolerant(b.filter_async)
 
     def timed_async(self, steps, dist=None):
         """Enqueue `steps` push + filter pairs (asynchronous mode), wait once; returns seconds (this rank)."""
@@ -142,6 +221,7 @@ class Leg:
         b.set_async(True)
         if dist:
             dist.barrier()
+        b.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step(sync=False)
@@ -152,6 +232,23 @@ class Leg:
         dt = time.perf_counter() - t0
         b.set_async(False)
         return dt
+
+    def logs(self, first, last, batch=None):
+        """{frame: [per stream: the frame-log fields]} for the pushes first … last−1 (at most the last 64 the engine keeps)."""
+        b = batch or self.batch
+        return {f: [tuple(b.frame_log(f, s)[k] for k in LOG_KEYS) for s in range(self.B)] for f in range(max(first, last - 64, 0), last)}
+
+    def replay_sync(self, n_steps):
+        """The first n_steps of this leg again on a fresh batch, every push and filter synchronous: the reference for `sanity`."""
+        b = self.engine.MorBatch(self.p, self.B, self.npts, 4, 3, self.device)
+        keep, self.step_no = self.step_no, 0
+        try:
+            for _ in range(n_steps):
+                self.step(sync=True, batch=b)
+            return self.logs(0, n_steps, b)
+        finally:
+            self.step_no = keep
+            b.close()
 
     def b_alg(self):
         """Algorithmic bytes per frame-pair: 16·N + 16·C_prev + 16·N_out + 4·T + 32·K, batch mean."""
@@ -186,7 +283,9 @@ class Leg:
 
 
 def roofline_of(leg, value_per_gpu, steps_for_kernels, workload):
-    """Dominant kernel of the pipelined regime (live HIP-event timing on the streams the kernels are launched on)."""
+    """Dominant kernel of the pipelined regime (live HIP-event timing on the streams the kernels are launched on) + the per-kernel table:
+    live launch durations (pipelined / alone) beside the HBM bytes per launch the PMC passes of profiles/collect.sh measured for this
+    workload (2·FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md §HBM) — path traffic against the algorithmic bytes shows the re-reads."""
     b_alg = leg.b_alg()
     kernels = leg.kernel_leg(steps_for_kernels, sync=False)
     alone = leg.kernel_leg(4, sync=True)
@@ -194,23 +293,49 @@ def roofline_of(leg, value_per_gpu, steps_for_kernels, workload):
     dom = max(kernels, key=lambda k: kernels[k]["ms_total"])
     avg_s = kernels[dom]["ms_total"] / kernels[dom]["launches"] * 1e-3
     achieved = leg.B * b_alg / avg_s / 1e9
-    traffic = None
+    tr = {}
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            tr = json.load(open(tpath))
         except Exception:
-            traffic = None
+            tr = {}
+    traffic = tr.get(dom, {}).get("hbm_bytes_per_launch")
+    per_kernel, path_bytes, covered = {}, 0.0, True
+    for k, v in kernels.items():
+        hb = tr.get(k, {}).get("hbm_bytes_per_launch")
+        per_step = v["launches"] / steps_for_kernels
+        per_kernel[k] = {"avg_us": v["avg_us"], "avg_us_alone": kernels_alone.get(k), "launches_per_step": round(per_step, 2), "hbm_bytes_per_launch": hb,
+                         "GBps": None if hb is None else round(hb / (v["avg_us"] * 1e-6) / 1e9, 1), "GBps_alone": None if hb is None or not kernels_alone.get(k) else round(hb / (kernels_alone[k] * 1e-6) / 1e9, 1)}
+        if hb is None:
+            covered = False
+        else:
+            path_bytes += hb * per_step
     job = b_alg * value_per_gpu / 1e9
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBPS, 5), "frac_basis": "whole-path algorithmic bytes of one step / the dominant kernel's launch duration (pipelined)", "traffic": traffic,
             "algorithmic_bytes_per_launch": int(leg.B * b_alg), "avg_launch_us": round(avg_s * 1e6, 2),
             "avg_launch_us_alone": kernels_alone.get(dom),
             "job_GBps": round(job, 2), "job_frac": round(job / HBM_PEAK_GBPS, 5),
+            "path_traffic_bytes_per_step": int(path_bytes) if tr and covered else None,
+            "wasted_traffic_ratio": round(path_bytes / (leg.B * b_alg), 3) if tr and covered else None,
+            "launches_per_step": round(sum(v["launches"] for v in kernels.values()) / steps_for_kernels, 2),
             "sum_kernel_us_per_step_pipelined": round(sum(v["ms_total"] for v in kernels.values()) * 1e3 / steps_for_kernels, 1),
             "sum_kernel_us_per_step_alone": round(sum(kernels_alone[k] * alone[k]["launches"] / 4 for k in alone), 1),
-            "note": "frac = algorithmic bytes of one step / the dominant kernel's launch duration (frames pipelined over four HIP streams, up to four kernels share the GPU); job_frac = algorithmic bytes x frame-pairs/s / peak: the whole path"}
+            "per_kernel": per_kernel,
+            "note": "frac = algorithmic bytes of one step / the dominant kernel's launch duration (frames pipelined over four HIP streams, up to four kernels share the GPU); job_frac = algorithmic bytes x frame-pairs/s / peak: the whole path; per_kernel.hbm_bytes_per_launch from the PMC passes committed under profiles/ (null: not collected for this workload)"}
     return roof, kernels, kernels_alone, b_alg
+
+
+def compare_logs(a, b, keys_idx=None):
+    """frames present in both, (frame, stream) records that differ"""
+    frames = sorted(set(a) & set(b))
+    bad = []
+    for f in frames:
+        for s, (ra, rb) in enumerate(zip(a[f], b[f])):
+            if (ra if keys_idx is None else tuple(ra[i] for i in keys_idx)) != (rb if keys_idx is None else tuple(rb[i] for i in keys_idx)):
+                bad.append((f, s))
+    return frames, bad
 
 
 def main():
@@ -228,8 +353,12 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="exercise only the multi-rank plumbing (no GPU work, no measurement)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))   # nothing above has touched HIP; the children are fresh processes
+
     from dynamicslamtool_amd import shard
     rank, local_rank, world = shard.env_rank()
+    cores_mine = bind_rank_to_cores(local_rank, world)
     dist = shard.init_distributed()
 
     if args.dry_run:
@@ -239,23 +368,33 @@ def main():
         fake_elapsed = 1.0 + 0.5 * rank          # the slowest rank defines the job time
         rate = shard.whole_job_rate(dist, B * args.steps, fake_elapsed)
         per_rank = shard.gather_floats(dist, B * args.steps / fake_elapsed)
+        first_seeds = shard.gather_floats(dist, seeds[0])
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "value": rate, "first_seed": seeds[0], "last_seed_rank0": seeds[-1], "steps": args.steps,
-                              "per_rank_min_max": [min(per_rank), max(per_rank)]}))
+                              "per_rank_min_max": [min(per_rank), max(per_rank)], "first_seed_per_rank": [int(x) for x in first_seeds], "collective": "none",
+                              "self_launched": bool(os.environ.get("MOR_BENCH_SELF_LAUNCHED")), "cores_per_rank": cores_mine}))
         if dist:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    sensor0, B0, cfg0 = WORKLOADS[args.workload]
-    cpu_all = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_all = cpu_all_cores(shard.stream_seeds(cfg0, 0, B0), sensor0, args.method, args.ground_method)
+    sensor0, B0, cfg0, m_over, g_over = WORKLOADS[args.workload]
+    method = m_over or args.method
+    ground_method = g_over if g_over is not None else args.ground_method
+    B0 = args.streams or B0
+    cpu = cpu_all = oracle_sum = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # before HIP is initialised in this process (forked workers)
+        cpu, cpu_all, oracle_sum = cpu_baseline_run(shard.stream_seeds(cfg0, 0, B0), sensor0, method, ground_method)
 
     from dynamicslamtool_amd import engine, kitti_params, synth
 
-    p = kitti_params(args.method)
-    p.ground_method = args.ground_method
+    def params_for(name):
+        _, _, _, mo, go = WORKLOADS[name]
+        q = kitti_params(mo or args.method)
+        q.ground_method = go if go is not None else args.ground_method
+        return q
+
+    p = params_for(args.workload)
     ndev = engine.device_count()
     if ndev < 1:
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback in the product path)")
@@ -267,12 +406,36 @@ def main():
     for _ in range(args.warmup):
         leg.step()
     leg.batch.synchronize()
+    logs = leg.logs(0, args.warmup)
     # timed region: asynchronous mode — the host only enqueues push + filter of every step (clouds resident in HBM,
     # results left in HBM, tracking state on the device); one wait at the end
     mine = leg.timed_async(args.steps, dist)
     elapsed = shard.max_over_ranks(dist, mine)
     value = world * B * args.steps / elapsed
     per_rank = shard.gather_floats(dist, B * args.steps / mine)
+    first_seeds = [int(x) for x in shard.gather_floats(dist, leg.seeds[0])]
+    n_total = args.warmup + args.steps
+    logs.update(leg.logs(args.warmup, n_total))
+
+    # ---- sanity: a kernel that skips work is fast.  (1) every frame of the timed (asynchronous, pipelined) leg the engine still has in its
+    #      log — all streams: K, C, correspondences, checksum of the per-pair movement counts, detection flags, tracked centroids after push
+    #      and after filterCloud, size of the filtered cloud, error flags — against a SYNCHRONOUS re-run of the same frames on a fresh batch;
+    #      (2) the frames the CPU baseline ran (every stream of the batch) against the oracle's summaries of them.  Any step count.
+    ref_logs = leg.replay_sync(n_total)
+    frames_chk, bad = compare_logs(logs, ref_logs)
+    sanity = {"frames_checked": len(frames_chk), "frames": [frames_chk[0], frames_chk[-1]] if frames_chk else None, "streams": B, "fields": list(LOG_KEYS),
+              "async_equals_sync": not bad and bool(frames_chk), "mismatches": bad[:8]}
+    if oracle_sum is not None:
+        idx = [LOG_KEYS.index(k) for k in ORACLE_KEYS]
+        n_cmp, obad = 0, []
+        for s, seed in enumerate(leg.seeds):
+            for f, rec in enumerate(oracle_sum.get(seed, [])):
+                if f in logs:
+                    n_cmp += 1
+                    if tuple(logs[f][s][i] for i in idx) != tuple(rec[k] for k in ORACLE_KEYS):
+                        obad.append((f, s))
+        sanity.update({"oracle_records_checked": n_cmp, "oracle_fields": list(ORACLE_KEYS), "equals_oracle": not obad and n_cmp > 0, "oracle_mismatches": obad[:8]})
+    sanity["ok"] = sanity["async_equals_sync"] and sanity.get("equals_oracle", True)
 
     # device-only time of one step (HIP events around the launch sequences), two synchronous steps
     dev_ms = 0.0
@@ -295,7 +458,7 @@ def main():
         roofline, kernels, kernels_alone, b_alg = roofline_of(leg, value / world, max(8, min(args.steps, 40)), args.workload)
 
     sync_rate = None
-    if extras:   # synchronous use: every push and every filter waits for its results (what a caller without the asynchronous mode gets)
+    if extras and world == 1:   # synchronous use: every push and every filter waits for its results (what a caller without the asynchronous mode gets)
         t1 = time.perf_counter()
         n_sync = 12
         for _ in range(n_sync):
@@ -304,12 +467,6 @@ def main():
 
     stream0 = leg.summary0()
     track_cap = bool(leg.track_capacity_hit)
-    # A guard against fast-because-wrong runs (a kernel that skips work is quick): with the default arguments the synthetic streams are
-    # deterministic, so stream 0 must end the legs above in exactly this state (checked by the parity suite against the oracle, recorded here).
-    sanity = None
-    if (args.workload, args.steps, args.warmup, args.method, args.ground_method, world, bool(extras), bool(args.streams)) == ("hdl64_b64", 200, 5, 1, 0, 1, True, False):
-        want = {"T": 110036, "M": 10700, "G": 99336, "K": 19, "C": 10675, "pairs": 18, "tracks": 21}
-        sanity = {"expected_stream0": want, "ok": all(stream0.get(k) == v for k, v in want.items())}
     stage_totals = {k: sum(leg.batch.stage_counts(s)[k] for s in range(B)) for k in ("n_occ", "n_tier1b", "n_defer", "C_prev")}
     profile = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in p.as_dict().items()}
     seeds_main = leg.seeds
@@ -318,7 +475,7 @@ def main():
 
     e2e = lat = None
     others = {}
-    if extras and rank == 0:
+    if extras and world == 1:
         # PCIe-inclusive: clouds start in page-locked host memory, filtered clouds end there (synchronous push + filter)
         hin = [engine.HostBuffer((B, npts, 4)) for _ in range(2)]
         hout = engine.HostBuffer((B, npts, 4))
@@ -349,60 +506,45 @@ def main():
         b1.close()
         for x in hin + [hout]:
             x.free()
-    if extras:
-        # the other BASELINE configurations (SURVEY §8d "BASELINE configs → concrete runs"): short legs, never `value`
+        # the other BASELINE configurations (SURVEY §8d "BASELINE configs → concrete runs"), method 2 and the voxel-covariance ground
+        # variant on the headline clouds: short legs, never `value` (single rank only: a secondary leg failing on one rank must not
+        # leave the others in a barrier)
         for name in WORKLOADS:
             if name == args.workload or (name == "hdl64_urban_b64" and "hdl64_urban" not in synth.SENSORS):
                 continue
+            if args.workload != "hdl64_b64" and WORKLOADS[name][3:] != (None, None):
+                continue
             try:
-                lg = Leg(engine, synth, shard, p, name, rank, device, 6)
+                lg = Leg(engine, synth, shard, params_for(name), name, rank, device, 6)
                 for _ in range(3):
                     lg.step()
                 lg.batch.synchronize()
                 st = 10
-                dt = shard.max_over_ranks(dist, lg.timed_async(st, dist))
-                v = world * lg.B * st / dt
-                roof, ks, _, ba = roofline_of(lg, v / world, 8, name)
+                dt = lg.timed_async(st)
+                v = lg.B * st / dt
+                ref = lg.replay_sync(3 + st)
+                fr, bad2 = compare_logs(lg.logs(0, 3 + st), ref)
+                roof, ks, _, ba = roofline_of(lg, v, 8, name)
+                roof.pop("note", None)
                 top = sorted(ks.items(), key=lambda kv: -kv[1]["ms_total"])[:5]
                 others[name] = {"value": round(v, 1), "unit": "frame-pairs/s", "ms_per_step": round(1e3 * dt / st, 3), "steps": st, "streams_per_gpu": lg.B, "points_per_frame": lg.npts,
-                                "algorithmic_bytes_per_frame_pair": int(ba), "roofline": roof, "top_kernels_us": {k: v_["avg_us"] for k, v_ in top}, "stream0": lg.summary0(), "setup_s": round(lg.setup_s, 1)}
+                                "method": int(lg.p.method_choice), "ground_method": int(lg.p.ground_method),
+                                "algorithmic_bytes_per_frame_pair": int(ba), "roofline": roof, "top_kernels_us": {k: v_["avg_us"] for k, v_ in top}, "stream0": lg.summary0(),
+                                "async_equals_sync": not bad2 and bool(fr), "track_capacity_hit": bool(lg.track_capacity_hit), "setup_s": round(lg.setup_s, 1)}
                 lg.close()
             except Exception as e:   # a secondary leg must not take the headline down
                 others[name] = {"error": repr(e)[:300]}
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle.oracle import Oracle   # the checker, timed here only as the reported CPU baseline
-        S, P, budget = 4, 8, 30.0
-        t_cpu, n_cpu = 0.0, 0
-        for s in range(S):
-            o = Oracle(p, 4, 3)
-            x, ps = synth.frame(seeds_main[s], sensor, 0)
-            o.push(x, ps)
-            o.filter()
-            for f in range(1, P + 1):
-                if t_cpu > budget:   # streams differ by 100x in CPU cost (a wall next to the sensor): bounded sample
-                    break
-                x, ps = synth.frame(seeds_main[s], sensor, f)
-                t1 = time.perf_counter()
-                o.push(x, ps)
-                o.filter()
-                t_cpu += time.perf_counter() - t1
-                n_cpu += 1
-            o.close()
-        cpu = {"value": round(n_cpu / t_cpu, 3), "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-               "sample": "%d steady-state frame-pairs of the first %d streams of %s (%d pts), single thread, oracle/mor_oracle.c (kd-tree+BFS restatement, not PCL)" % (n_cpu, S, sensor, npts),
-               "host_cpus": os.cpu_count()}
 
     if rank == 0:
         line = {
             "metric": "LiDAR frame-pairs/sec (120k pts, batched)", "value": round(value, 2), "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d streams/GPU x %d pts (%s), kitti profile, method %d" % (args.workload, B, npts, sensor, args.method),
+            "config": {"workload": "%s: %d streams/GPU x %d pts (%s), kitti profile, method %d%s" % (args.workload, B, npts, sensor, method, ", voxel-covariance ground removal" if ground_method else ""),
                        "streams_per_gpu": B, "points_per_frame": npts, "parallelism": "streams sharded over %d GPU(s), no collective" % world,
                        "profile": profile},
-            "value_runs": value_runs, "per_rank_frame_pairs_per_s_min_max": [round(min(per_rank), 1), round(max(per_rank), 1)],
+            "collective": "none", "first_seed_per_rank": first_seeds, "self_launched": bool(os.environ.get("MOR_BENCH_SELF_LAUNCHED")), "devices_visible": ndev, "ranks_per_device": (world + ndev - 1) // ndev,
+            "value_runs": value_runs, "per_rank_frame_pairs_per_s": [round(x, 1) for x in per_rank], "per_rank_frame_pairs_per_s_min_max": [round(min(per_rank), 1), round(max(per_rank), 1)],
             "device_ms_per_step": round(dev_ms, 4), "sync_frame_pairs_per_s": None if sync_rate is None else round(sync_rate, 1),
             "e2e_host_frame_pairs_per_s": None if e2e is None else round(e2e, 2), "latency_b1_ms": None if lat is None else round(lat, 3),
             "algorithmic_bytes_per_frame_pair": int(b_alg),
@@ -412,6 +554,7 @@ def main():
             "setup_s": round(setup_s, 2),
         }
         print(json.dumps(line))
+        sys.stdout.flush()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

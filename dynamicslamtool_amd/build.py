@@ -8,8 +8,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-HIP_SOURCES = ["mor_kernels.hip", "mor_engine.cpp", "mor_tracker.cpp"]
-HIP_HEADERS = ["mor_device.h", "mor_tracker.h", os.path.join("..", "..", "include", "mor_hip.h")]
+HIP_SOURCES = ["mor_kernels.hip", "mor_engine.cpp"]
+HIP_HEADERS = ["mor_device.h", os.path.join("..", "..", "include", "mor_hip.h")]
 
 
 def _newer(target, deps):

@@ -156,7 +156,7 @@ bool MovingObjectRemoval::filterCloud(pcl::PCLPointCloud2 &out_cloud, std::strin
   out_cloud.header = in_header_;
   output.data = out_cloud.data;                 // pcl_conversions::fromPCL (.cpp:691)
   describe_xyzi<sensor_msgs::PointCloud2, sensor_msgs::PointField>(output, n);
-  output.header.seq = in_header_.seq; output.header.stamp = (double)in_header_.stamp * 1e-6;   // pcl stamps are microseconds
+  pcl_conversions::fromPCL(in_header_, output.header);   // seq, stamp.fromNSec(pcl stamp [µs] · 1000), frame_id — integer arithmetic, as .cpp:691 does
   output.header.frame_id = f_id;                // .cpp:692
   return true;
 }

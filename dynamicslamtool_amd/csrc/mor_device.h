@@ -91,9 +91,7 @@ struct MorDev {
   int split_g;   // workgroups per stream of the two split passes (each walks tiles split_g apart)
   int g_fast, g_score, g_pde, g_box;   // launch widths: k_score_fast workgroups per cloud tile, workgroups per stream of the worklist tiers / the wave tier / k_cellboxes (MOR_TUNE)
   int xcd_map;               // 1: the workgroups of a stream share an XCD (its tables stay in that L2); 0: streams spread over all XCDs
-  int split_variant;         // experiment bits of k_split: 1 = poll the look-back descriptors with agent-scope loads instead of read-modify-write atomics
-  int two_pass_split;        // development switch: count pass + scatter pass instead of the single-pass split
-  int fuse_scans;            // tile-count scans re-derived inside the consuming kernels instead of one-workgroup scan launches (tables of ≤ 2048 tiles)
+  int two_pass_split;        // 1 (default): count pass + scatter pass; 0: the single-pass split with decoupled look-back (MOR_SINGLE_PASS_SPLIT)
   int cur, prev, has_prev;   // cluster-array slots of cb and ca (four slots rotate: up to three frames are in flight in the stage pipeline); whether ca exists (:534)
   int run_tracker;           // filter: advance the tracking loop (first filterCloud of this frame)
   // ---- device arrays (per-stream stride noted)
@@ -106,7 +104,7 @@ struct MorDev {
   unsigned *h_err;           // [B]  pinned host mirror of `err`, refreshed by the last kernel of every push and filter
   int frame_no;              // index of this frame since the batch was created
   struct MorFrameLog *h_log; // [MOR_LOG_CAP][B]  pinned per-frame summaries (frame k in row k % MOR_LOG_CAP): lets tests compare every frame of an asynchronous run
-  int *tile_cnt, *tile_off;  // [B][tiles_max][2]   (non-ground, ground) counts / exclusive offsets
+  int *tile_cnt;             // [B][tiles_max][2]   (non-ground, ground) counts per tile
   unsigned long long *split_desc; // [B][tiles_max]  look-back descriptors of the single-pass split (status | non-ground | ground)
   float4 *cloud;             // [B][Nmax]  non-ground points, input order (`cloud`, :85)
   int *cloud_tidx;           // [B][Nmax]  index of each cloud point in the trimmed cloud
@@ -125,9 +123,9 @@ struct MorDev {
   int *gh_rowlist, *gh_cells; // [B][Nmax]  hash path, streams beyond the LDS lists: x of the cells of every row (unordered inside the row) then point counts per cell; claimed slots in discovery order
   int *gh_rowfill;           // [B][nrows+1]  hash path: per-row fill cursors when the row table does not fit the LDS copy
   int *gh_key, *gh_val;      // [B][Hcell] hash path: the cell table of streams with more cells than the LDS table holds
-  int grid_mode, gh_tier;   // grid_mode 0: points radix-sorted by cell key; 1: cells counted in a hash table (k_gridhash); gh_tier: table tier k_gridhash starts with (0 small LDS table, 1 big LDS table, 2 global memory)
+  int gh_tier;   // table tier k_gridhash starts with (0 small LDS table, 1 big LDS table, 2 global memory)
   int *slab_y, *slab_c, *slab_e;    // [B][MOR_MAXP+1]  slabs of the cell graph: first y-slice, first compact cell id, end of the look-ahead (cells of the next two y-slices)
-  int P, cg_force_global, cg_big;    // slabs per stream this frame; test knob: forests in global memory; big-slab variant of k_cg_slab
+  int P, cg_force_global;    // slabs per stream this frame; test knob: forests in global memory
   int *lroot_a, *lroot_b;    // [B][Nmax]  per cell: its local root in its own slab / in the previous slab's look-ahead (compact ids)
   int *parent2;              // [B][Nmax]  second global forest (odd slabs when they do not fit LDS)
   int *skey, *sidx;          // aliases of the radix buffers holding the cell-sorted (key, cloud index)
@@ -211,17 +209,17 @@ struct MorDev {
 struct MorCellSum { long long a[3], b[3]; };
 // kernel ids for optional per-kernel event timing
 enum MorKernelId {
-  MK_CLASSIFY, MK_SCAN_TILES, MK_SCATTER, MK_SPLIT, MK_HEADS_COUNT, MK_HEADS_SCAN, MK_HEADS_SCATTER, MK_HASH_CLEAR, MK_CELLBOXES, MK_CELLGRAPH,
-  MK_LABEL, MK_RHIST, MK_RSCAN, MK_RSCATTER,
-  MK_STATS, MK_STATS_FIN, MK_XFORM_PREV, MK_XFORM_FIN, MK_NN, MK_PAIRS, MK_SCORE_FAST, MK_SCORE_NEAR, MK_SCORE_BLOCK, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE, MK_DECIDE,
-  MK_OUT_COUNT, MK_OUT_SCAN, MK_OUT_SCATTER, MK_G2_CENTROID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_GRIDHASH, MK_GRIDFILL, MK_CG_SLAB, MK_CG_FINAL, MK_CLUSTERS, MK_COUNT
+  MK_CLASSIFY, MK_SCATTER, MK_SPLIT, MK_HEADS_COUNT, MK_HEADS_SCATTER, MK_CELLBOXES, MK_RHIST, MK_RSCAN, MK_RSCATTER,
+  MK_XFORM_PREV, MK_PAIRS, MK_SCORE_FAST, MK_SCORE_NEAR, MK_SCORE_BLOCK, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE,
+  MK_OUT_COUNT, MK_OUT_SCATTER, MK_G2_COV_MID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_GRIDHASH, MK_GRIDFILL, MK_CG_SLAB, MK_CG_FINAL, MK_CLUSTERS, MK_COUNT
 };
 extern const char *const mor_kernel_names[MK_COUNT];
 
 struct MorLaunchTimer;   // engine-owned; records event pairs when enabled
-#define MOR_N_PIECES 7
-#define MOR_MAX_PIECES 13   // with the grid piece of the voxel ground variant as six (pieces 10 … 15 instead of 0)
-void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer *tm);   // 0 split + grid, 1 cell boxes, 2 cell graph, 3 labels … centroids, 4 transform of ca … first score tiers, 5 last score tiers, 6 thresholds + tracking
+#define MOR_MAX_PIECES 13   // pieces of a push, at most (voxel ground variant: its grid stage is six of them)
+// piece ids: 7 split | 8 grid build (crop variant) or 10 … 15 (voxel ground variant) | 1 cell boxes | 16 slabs of the cell graph | 17 its merge | 3 clusters |
+//            4 transform of ca … first score tiers | 5 last score tiers | 6 thresholds + tracking
+void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer *tm);
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);
 void mor_timer_begin(MorLaunchTimer *tm, int kernel_id, hipStream_t st);
 void mor_timer_end(MorLaunchTimer *tm, int kernel_id, hipStream_t st);

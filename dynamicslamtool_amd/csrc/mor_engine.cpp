@@ -3,7 +3,7 @@
 // Mirrors MovingObjectRemoval::pushRawCloudAndPose / filterCloud
 // (/root/reference/src/MovingObjectRemoval.cpp:516-611, :613-696) for B independent streams.
 #include "mor_device.h"
-#include "mor_tracker.h"
+#include "../../include/mor_hip.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -17,8 +17,8 @@
 
 #define MOR_ARGS_RING 8
 
-// The frame pipeline wants its four stage streams on four different hardware queues.  The ROCm runtime multiplexes
-// streams onto GPU_MAX_HW_QUEUES (default 4) queues in creation order, so with the batch's main stream two stages share
+// The frame pipeline wants its four lane streams on four different hardware queues.  The ROCm runtime multiplexes
+// streams onto GPU_MAX_HW_QUEUES (default 4) queues in creation order, so with the batch's main stream two lanes share
 // one unless the PROCESS sets GPU_MAX_HW_QUEUES=8 (or more) before HIP initialises — the integrator's decision, this
 // library never touches the environment (the Python binding and the replay driver set it).  Measured on
 // MI355X: hardware queue i is served by compute pipe i % 4 and queues of one pipe do not overlap, so four is also the
@@ -72,25 +72,21 @@ struct PoseTf { double R[3][3], o[3]; };
 struct mor_batch {
   mor_params p; int n_bad, n_good, B, device; uint64_t Nmax;
   hipStream_t st = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // st: copies of read-backs; ev: push/filter timing
-  // Four in-order HIP streams form a software pipeline over frames (see mor_push_batch): grid stage on `sf`, cell graph on
-  // `sc`, cluster extraction + pair stage on `sm`, wave-tier scores + tracking + filterCloud on `sb`.
-  hipStream_t sf = nullptr, sc = nullptr, sm = nullptr, sb = nullptr;   // grid, cell graph, mid (clusters + pair stage), tail (scores wave tier, tracking, filterCloud)
+  // Four in-order HIP streams ("lanes") form a software pipeline over frames (see mor_push_batch): frame k runs ALL its
+  // pieces, then its filterCloud, on stream k % n_lanes, so every stream carries the same work whatever the pieces cost;
+  // piece p of frame k waits for piece p of frame k−1 (scratch arrays of a piece are never used by two frames at once, the
+  // pair stage of frame k sees frame k−1's clusters), and the tracking steps (last piece, filterCloud) wait for the previous
+  // tracking step.  (Rounds 1–2 also had a stage schedule — pieces on fixed streams: its tail stream carried 0.44 ms of
+  // kernels per 0.45 ms period while the cell-graph stream idled half the time; removed.)
+  hipStream_t sf = nullptr, sc = nullptr, sm = nullptr, sb = nullptr;   // lanes 1 … 4
   hipEvent_t ev_piece[MOR_MAX_PIECES][MOR_MAX_SLOTS] = {}, ev_back[MOR_MAX_SLOTS] = {};
-  int n_pieces = MOR_N_PIECES, piece_id[MOR_MAX_PIECES] = {0, 1, 2, 3, 4, 5, 6, 0, 0, 0, 0, 0, 0};   // lane schedule: the pieces of a push in order
-  // Default schedule ("lanes"): frame k runs ALL its pieces, then its filterCloud, on stream k % n_lanes, so every stream
-  // carries the same work whatever the pieces cost; piece p of frame k waits for piece p of frame k−1 (which keeps every
-  // guarantee of the stage schedule: scratch arrays of a piece are never used by two frames at once, the pair stage of
-  // frame k sees frame k−1's clusters), and the tracking steps (last piece, filterCloud) wait for the previous tracking step.
-  // (The stage schedule — pieces on fixed streams — made the stream with the scoring tiers + tracking + filterCloud the
-  // bottleneck: its kernels add up to 0.44 ms of a 0.45 ms period while the cell-graph stream idled half the time.)
-  bool lanes = true; int n_lanes = 4;
-  hipStream_t extra[4] = {nullptr, nullptr, nullptr, nullptr};   // lanes 5 … 8 (MOR_LANES)
-  hipStream_t strk = nullptr;   // MOR_TRACK_STREAM=1: the tracking steps of all frames (thresholds + tracking, filterCloud) on a fifth stream (measured: 106 k instead of 156 k — more than four busy streams are served worse, as with MOR_LANES > 4)
+  int n_pieces = 0, piece_id[MOR_MAX_PIECES] = {};   // the pieces of a push in order (ids: mor_device.h)
+  int n_lanes = 4;
+  hipStream_t extra[4] = {nullptr, nullptr, nullptr, nullptr};   // lanes 5 … 8 (MOR_LANES; measured: more than four busy streams are served worse)
   hipStream_t lane_stream(uint64_t k) const { const int i = (int)(k % (uint64_t)n_lanes); return i == 0 ? sf : i == 1 ? sc : i == 2 ? sm : i == 3 ? sb : extra[i - 4]; }
   hipEvent_t ev_track[MOR_MAX_SLOTS] = {};      // recorded after the tracking step of a push / a filterCloud
   hipEvent_t *last_track = nullptr;             // the latest of them
   hipStream_t last_filter_stream = nullptr;
-  int stage_of[MOR_N_PIECES] = {0, 0, 1, 2, 2, 3, 3};   // stage stream of every launch piece (mor_device.h); the last piece and filterCloud run on stage 3
   MorDev dtemp[MOR_MAX_DEPTH];               // descriptor templates, frame k uses dtemp[k % depth] (static part + pointers)
   MorDev d;                                  // descriptor of the latest pushed frame
   MorStreamArgs *d_args_s[MOR_MAX_DEPTH] = {};
@@ -98,7 +94,7 @@ struct mor_batch {
   MorStreamArgs *h_args_ring = nullptr, *h_args = nullptr;   // pinned ring of MOR_ARGS_RING slots (async pushes), current slot
   hipEvent_t args_ev[MOR_ARGS_RING] = {};
   uint64_t pipe_depth = 4, n_slots = 5;       // frames in flight (= copies of the per-frame arrays); cluster-array slots = depth + 1
-  int env_cg_p = 0, env_cg_big = -1, env_split_g = 0;         // tuning knobs from the environment, read once at creation
+  int env_cg_p = 0;         // tuning knob from the environment (MOR_CG_P), read once at creation
   bool async = false, pending = false;   // async: push/filter only enqueue; pending: work enqueued since the last wait
   unsigned char *d_moving = nullptr;
   float4 **h_outptrs = nullptr, **d_outptrs = nullptr;
@@ -184,20 +180,15 @@ static int configure(mor_batch *b) {
     double lf = (double)p.gp_leaf; d.leaf_r2 = (float)(lf * lf);   // radiusSearch(…, gp_leaf): (float)(radius·radius)
   }
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
-  d.fuse_scans = getenv("MOR_NO_FUSE") ? 0 : 1;   // refined per push (tile count)
   d.two_pass_split = getenv("MOR_SINGLE_PASS_SPLIT") ? 0 : 1;   // count pass + scatter pass (the second read comes from the Infinity Cache); the single-pass split with decoupled look-back measured 5 % slower in the pipeline
   d.xcd_map = getenv("MOR_NO_XCD_MAP") ? 0 : 1;
   d.g_fast = 8; d.g_score = 64; d.g_pde = 256; d.g_box = 32;
   if (const char *tn = getenv("MOR_TUNE")) { int a, b2, c, e; if (sscanf(tn, "%d,%d,%d,%d", &a, &b2, &c, &e) == 4 && a > 0 && b2 > 0 && c > 0 && e > 0) { d.g_fast = a; d.g_score = b2; d.g_pde = c; d.g_box = e; } }
-  d.split_variant = getenv("MOR_SPLIT_VARIANT") ? atoi(getenv("MOR_SPLIT_VARIANT")) : 0;
   d.use_hash = d.method == 1;
   { size_t hc = 1024; while (hc < 4 * (size_t)d.Nmax) hc <<= 1; d.Hcell = (int)hc; }
   d.gnz = nullptr; d.gnz_out = nullptr; d.cg_nz = d.g.nz; d.cg_inv_cs = d.g.inv_cs;
   d.t1_budget = getenv("MOR_T1_BUDGET") ? atoi(getenv("MOR_T1_BUDGET")) : 64;
-  // development / test switches (defaults: the fast paths): MOR_GRID=radix sorts the points by cell key instead of counting
-  // cells in a hash table;
-  // MOR_GH_TIER=1|2 starts k_gridhash with its big LDS table / its global-memory table; MOR_CG_GLOBAL forces the global-memory forests
-  d.grid_mode = (getenv("MOR_GRID") && !strcmp(getenv("MOR_GRID"), "radix")) ? 0 : 1;
+  // test switches (defaults: the fast paths): MOR_GH_TIER=1|2 starts k_gridhash with its big LDS table / its global-memory table; MOR_CG_GLOBAL forces the global-memory forests
   d.gh_tier = getenv("MOR_GH_TIER") ? atoi(getenv("MOR_GH_TIER")) : 0; d.cg_force_global = getenv("MOR_CG_GLOBAL") ? 1 : 0;
   d.P = 1;
   if (d.score_R > 60) return set_error(MOR_ERR_INVALID, "pde_ub %g needs a %d-cell search radius (> 60)", (double)p.pde_ub, d.score_R);
@@ -207,15 +198,19 @@ static int configure(mor_batch *b) {
   return MOR_OK;
 }
 
-// waits for everything enqueued on the batch and turns the sticky per-stream error words (every flag any kernel has
-// raised since the last report, whichever frame it belonged to) into an error code; reporting clears them
-static int wait_all_checked(mor_batch *b) {
+// Waits for everything enqueued on the batch (no error reporting: read-backs use this, so that a capacity or HIP error of an
+// earlier frame of an asynchronous run stays in the sticky words until mor_batch_wait / the next synchronous push or filter reports it).
+static int sync_all(mor_batch *b) {
   if (!b->pending) return MOR_OK;
   HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sc)); HIP_TRY(hipStreamSynchronize(b->sm)); HIP_TRY(hipStreamSynchronize(b->sb));
   for (auto &x : b->extra) if (x) HIP_TRY(hipStreamSynchronize(x));
-  if (b->strk) HIP_TRY(hipStreamSynchronize(b->strk));
   b->pending = false;
   b->timer.collect();
+  return MOR_OK;
+}
+// Turns the sticky per-stream error words (every flag any kernel has raised since the last report, whichever frame it belonged
+// to; mirrored to pinned memory by the last kernel of every push and filter) into an error code; reporting clears them.
+static int report_errors(mor_batch *b) {
   int rc = MOR_OK;
   const MorDev &d = b->d;
   bool any = false;
@@ -229,11 +224,14 @@ static int wait_all_checked(mor_batch *b) {
     if (f & 16u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than 16384 points within gp_leaf of a voxel centroid", s);
     if (f & 64u) rc = set_error(MOR_ERR_HIP, "stream %d: look-back of the single-pass split stalled", s);
     if (f & 32u) rc = set_error(MOR_ERR_CAPACITY, "stream %d: more than %d tracked moving centroids", s, MOR_TR_MAXT);
-    if (f & 128u) rc = set_error(MOR_ERR_HIP, "stream %d: an in-kernel hand-off timed out", s);
     d.h_err[s] = 0;
   }
   if (any) HIP_TRY(hipMemset(d.err, 0, sizeof(unsigned) * d.B));
   return rc;
+}
+static int wait_all_checked(mor_batch *b) {
+  const int rc = sync_all(b);
+  return rc != MOR_OK ? rc : report_errors(b);
 }
 
 extern "C" {
@@ -251,7 +249,6 @@ void mor_batch_destroy(mor_batch *b) {
   if (b->sm) hipStreamSynchronize(b->sm);
   if (b->sb) hipStreamSynchronize(b->sb);
   for (auto &x : b->extra) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
-  if (b->strk) { hipStreamSynchronize(b->strk); hipStreamDestroy(b->strk); }
   for (auto &ev : b->args_ev) if (ev) hipEventDestroy(ev);
   for (auto &pe : b->ev_piece) for (auto &ev : pe) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->ev_back) if (ev) hipEventDestroy(ev);
@@ -281,13 +278,6 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (getenv("MOR_PIPE_DEPTH")) b->pipe_depth = std::min(MOR_MAX_DEPTH, std::max(1, atoi(getenv("MOR_PIPE_DEPTH"))));
   b->n_slots = b->pipe_depth + 1;
   if (getenv("MOR_CG_P")) b->env_cg_p = atoi(getenv("MOR_CG_P"));
-  if (getenv("MOR_SPLIT_G")) b->env_split_g = atoi(getenv("MOR_SPLIT_G"));
-  if (getenv("MOR_CG_BIG")) b->env_cg_big = atoi(getenv("MOR_CG_BIG")) != 0;
-  if (const char *st = getenv("MOR_STAGES")) {   // tuning: stage stream (0…3) of each launch piece, e.g. 0012233; non-decreasing, last piece on stage 3
-    bool okc = strlen(st) == MOR_N_PIECES;
-    for (int i = 0; okc && i < MOR_N_PIECES; ++i) okc = st[i] >= '0' && st[i] <= '3' && (i == 0 || st[i] >= st[i - 1]);
-    if (okc && st[MOR_N_PIECES - 1] == '3') for (int i = 0; i < MOR_N_PIECES; ++i) b->stage_of[i] = st[i] - '0';
-  }
   if ((rc = configure(b)) != MOR_OK) return fail(rc);
   if (n_bad > MOR_TR_NB) return fail(set_error(MOR_ERR_INVALID, "n_bad = %d: windows longer than %d frames are not supported", n_bad, MOR_TR_NB));
   for (auto &ev : b->args_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
@@ -299,17 +289,15 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   for (auto &pe : b->ev_piece) for (auto &ev : pe) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_back) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_track) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
-  if (getenv("MOR_SCHED") && !strcmp(getenv("MOR_SCHED"), "stages")) b->lanes = false;
-  if (b->lanes && p->ground_method == 0 && !getenv("MOR_ONE_GRID_PIECE")) { const int ids[9] = {7, 8, 1, 16, 17, 3, 4, 5, 6}; b->n_pieces = 9; for (int i = 0; i < 9; ++i) b->piece_id[i] = ids[i]; }
-  if (b->lanes && p->ground_method == 1) { const int ids[MOR_MAX_PIECES] = {10, 11, 12, 13, 14, 15, 1, 16, 17, 3, 4, 5, 6}; b->n_pieces = MOR_MAX_PIECES; for (int i = 0; i < MOR_MAX_PIECES; ++i) b->piece_id[i] = ids[i]; }
+  if (p->ground_method == 0) { const int ids[9] = {7, 8, 1, 16, 17, 3, 4, 5, 6}; b->n_pieces = 9; for (int i = 0; i < 9; ++i) b->piece_id[i] = ids[i]; }
+  else { const int ids[MOR_MAX_PIECES] = {10, 11, 12, 13, 14, 15, 1, 16, 17, 3, 4, 5, 6}; b->n_pieces = MOR_MAX_PIECES; for (int i = 0; i < MOR_MAX_PIECES; ++i) b->piece_id[i] = ids[i]; }
   b->n_lanes = (int)std::min<uint64_t>(4, b->pipe_depth);
   if (getenv("MOR_LANES")) b->n_lanes = std::max(1, std::min<int>((int)std::min<uint64_t>(8, b->pipe_depth), atoi(getenv("MOR_LANES"))));
   for (int i = 4; i < b->n_lanes; ++i) if (hipStreamCreateWithFlags(&b->extra[i - 4], hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
-  if (b->lanes && getenv("MOR_TRACK_STREAM") && hipStreamCreateWithFlags(&b->strk, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
   MorDev &d = b->d; const size_t B = d.B, N = d.Nmax, K = d.Kcap, T = d.tiles_max;
   bool ok = true;
   MorStreamArgs *dargs = nullptr;
-  ok = ok && dalloc(b, dargs, B) && dalloc(b, d.info, B) && dalloc(b, d.tile_cnt, B * T * 2) && dalloc(b, d.tile_off, B * T * 2);
+  ok = ok && dalloc(b, dargs, B) && dalloc(b, d.info, B) && dalloc(b, d.tile_cnt, B * T * 2);
   b->d_args_s[0] = dargs; d.args = dargs;
   ok = ok && dalloc(b, d.cloud, B * N) && dalloc(b, d.cloud_tidx, B * N) && dalloc(b, d.ground, 2 * B * N) && dalloc(b, d.gp_idx, B * N) && dalloc(b, d.pcell, B * N);
   ok = ok && dalloc(b, d.pkey, B * N) && dalloc(b, d.ckey, B * N) && dalloc(b, d.cstart, B * (N + 1)) && dalloc(b, d.row_start, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, d.cmin, B * N) && dalloc(b, d.cmeta, 2 * B * N);
@@ -350,7 +338,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (p->method_choice == 2) ok = ok && dalloc(b, d.vox, B * (size_t)d.Hcap);
   ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_nb, B) && dalloc(b, d.wl2, B * N) && dalloc(b, d.wl2_n, B) && dalloc(b, d.dbg, B * 16) && dalloc(b, d.dbg2, B * (MOR_MAXP + 2) * 16);
   ok = ok && dalloc(b, d.zmin_i, B) && dalloc(b, d.zmax_i, B) && dalloc(b, d.zorg, B) && dalloc(b, d.zbase, B) && dalloc(b, d.mode_bin, B);
-  if (d.gmode == 1 && !getenv("MOR_G2_FULL_Z")) ok = ok && dalloc(b, d.gnz, B);
+  if (d.gmode == 1) ok = ok && dalloc(b, d.gnz, B);
   if (d.gmode == 1) ok = ok && dalloc(b, d.rawbuf, B * N) && dalloc(b, d.is_ground, B * N) && dalloc(b, d.vcent, B * N) && dalloc(b, d.vbin, B * N) && dalloc(b, d.g2_big, B * N) && dalloc(b, d.g2_nbig, B);
   if (ok) {   // crop-box variant: the clustering grid starts at gp_limit for every stream
     std::vector<float> z0(B, p->gp_limit); std::vector<int> zb(B, 0);
@@ -382,10 +370,10 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = ok && dalloc(b, o.pair_q, B * K) && dalloc(b, o.pair_m, B * K) && dalloc(b, o.pair_d, B * K) && dalloc(b, o.pair_cnt, B * K) && dalloc(b, o.pair_of_prev, B * K) && dalloc(b, o.pair_of_cur, B * K);
     ok = ok && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B) && dalloc(b, o.wl_nb, B) && dalloc(b, o.wl, B * N);
     if (d.use_hash) ok = ok && dalloc(b, o.chash, 2 * B * (size_t)d.Hcell);
-    if (b->lanes && d.gmode == 0) ok = ok && dalloc(b, o.pkey, B * N);   // split | grid build are two pieces
-    if (d.gmode == 1 && b->lanes)   // voxel ground variant: its grid piece runs as six, these cross their boundaries
+    if (d.gmode == 0) ok = ok && dalloc(b, o.pkey, B * N);   // split | grid build are two pieces
+    if (d.gmode == 1)   // voxel ground variant: its grid piece runs as six, these cross their boundaries
       ok = ok && dalloc(b, o.rawbuf, B * N) && dalloc(b, o.is_ground, B * N) && dalloc(b, o.vcent, B * N) && dalloc(b, o.vbin, B * N) && dalloc(b, o.g2_big, B * N) && dalloc(b, o.g2_nbig, B) &&
-           (d.gnz ? dalloc(b, o.gnz, B) : true) && dalloc(b, o.zbase, B) && dalloc(b, o.pkey, B * N) && dalloc(b, o.tile_cnt, B * T * 2) && dalloc(b, o.tile_off, B * T * 2) && dalloc(b, o.zmin_i, B) && dalloc(b, o.zmax_i, B);
+           (d.gnz ? dalloc(b, o.gnz, B) : true) && dalloc(b, o.zbase, B) && dalloc(b, o.pkey, B * N) && dalloc(b, o.tile_cnt, B * T * 2) && dalloc(b, o.zmin_i, B) && dalloc(b, o.zmax_i, B);
     b->d_args_s[c] = dargs1; o.args = dargs1;
     if (ok) ok = hipMemcpy(o.zorg, d.zorg, B * sizeof(float), hipMemcpyDeviceToDevice) == hipSuccess;
     if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
@@ -433,13 +421,11 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     b->prev_pose[s] = cur[s];
   }
   d.tiles = std::max<int>(1, (int)((maxn + MOR_TILE - 1) / MOR_TILE));
-  d.split_g = b->env_split_g > 0 ? std::min(b->env_split_g, d.tiles) : d.tiles;
-  d.fuse_scans = d.fuse_scans && d.tiles <= 2048;
+  d.split_g = d.tiles;
   {  // cell graph: slabs per stream (k_cg_slab) — enough that a slab's cells fit its LDS with room for imbalance, and that
      // the launch fills the GPU (two 512-thread workgroups per CU)
     uint32_t maxocc = 0, maxloc = 0;
     for (int s = 0; s < B; ++s) { maxocc = std::max(maxocc, k > 0 ? d.h_info[s].n_occ : 0u); maxloc = std::max(maxloc, k > 0 ? d.h_info[s].max_loc : 0u); }
-    d.cg_big = b->env_cg_big > 0;   // big-slab variant only on request (MOR_CG_BIG=1): one workgroup per CU — the slowest slab gets faster, the kernel does not
     (void)maxloc;
     const int p_fit = (int)((maxocc * 3ull / 2 + 818) / 819), p_par = (512 + B - 1) / B;   // a slab's LDS holds 1024 cells (own + look-ahead); two 512-thread workgroups per CU
     d.P = b->env_cg_p > 0 ? b->env_cg_p : std::max(p_fit, p_par);
@@ -455,44 +441,30 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   // ---- the launches of the push, piece by piece, on the stage streams (frames overlap as a software pipeline: piece p of
   //      frame k runs beside later pieces of frames k−1, k−2).  The first piece must not overwrite what frame k−depth still
   //      uses (same buffer copy; its cluster slot doubles as the `ca` slot of frame k−depth+1)
-  hipStream_t S[4] = {b->sf, b->sc, b->sm, b->sb};
   hipStream_t lane = b->lane_stream(k);
-  hipStream_t s0 = b->lanes ? lane : S[b->stage_of[0]];
   {
     const uint64_t depth = b->pipe_depth;   // frames in flight = copies of the per-frame arrays
-    if (k >= depth) HIP_TRY(hipStreamWaitEvent(s0, b->ev_back[(k - depth) % MOR_MAX_SLOTS], 0));
-    if (b->lanes && k > 0) HIP_TRY(hipStreamWaitEvent(s0, b->ev_piece[0][(k - 1) % MOR_MAX_SLOTS], 0));   // (also: the staging area of host blobs is free)
+    if (k >= depth) HIP_TRY(hipStreamWaitEvent(lane, b->ev_back[(k - depth) % MOR_MAX_SLOTS], 0));
+    if (k > 0) HIP_TRY(hipStreamWaitEvent(lane, b->ev_piece[0][(k - 1) % MOR_MAX_SLOTS], 0));   // (also: the staging area of host blobs is free)
   }
   for (int s = 0; s < B; ++s) {   // host-resident blobs are staged through device memory
     const mor_cloud_view &c = clouds[s];
-    if (!c.on_device && c.n_points) HIP_TRY(hipMemcpyAsync((void *)b->h_args[s].data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, s0));
+    if (!c.on_device && c.n_points) HIP_TRY(hipMemcpyAsync((void *)b->h_args[s].data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, lane));
   }
-  HIP_TRY(hipMemcpyAsync(b->d_args_s[k % b->pipe_depth], b->h_args, sizeof(MorStreamArgs) * B, hipMemcpyHostToDevice, s0));
-  HIP_TRY(hipEventRecord(b->args_ev[slot], s0));
-  HIP_TRY(hipEventRecord(b->ev[0], s0));
-  hipStream_t tail = b->lanes ? lane : b->sb;
-  if (b->lanes) {
-    for (int pc = 0; pc < b->n_pieces; ++pc) {
-      const bool trk = pc == b->n_pieces - 1;
-      hipStream_t ps = trk && b->strk ? b->strk : lane;
-      if (trk && b->strk) HIP_TRY(hipStreamWaitEvent(ps, b->ev_piece[pc - 1][k % MOR_MAX_SLOTS], 0));   // the frame's scores
-      else if (pc > 0 && k > 0) HIP_TRY(hipStreamWaitEvent(ps, b->ev_piece[pc][(k - 1) % MOR_MAX_SLOTS], 0));
-      if (trk && !b->strk && b->last_track) HIP_TRY(hipStreamWaitEvent(ps, *b->last_track, 0));   // tracking state: after the previous frame's filterCloud
-      mor_launch_piece(d, b->piece_id[pc], ps, &b->timer);
-      HIP_TRY(hipEventRecord(b->ev_piece[pc][k % MOR_MAX_SLOTS], ps));
-    }
-    b->last_track = &b->ev_piece[b->n_pieces - 1][k % MOR_MAX_SLOTS];
-    if (b->strk) tail = b->strk;
-  } else {
-    for (int pc = 0; pc < MOR_N_PIECES; ++pc) {
-      hipStream_t st = S[b->stage_of[pc]];
-      if (pc > 0 && b->stage_of[pc] != b->stage_of[pc - 1]) {
-        HIP_TRY(hipEventRecord(b->ev_piece[pc - 1][k % MOR_MAX_SLOTS], S[b->stage_of[pc - 1]]));
-        HIP_TRY(hipStreamWaitEvent(st, b->ev_piece[pc - 1][k % MOR_MAX_SLOTS], 0));
-      }
-      mor_launch_piece(d, pc, st, &b->timer);
-    }
+  HIP_TRY(hipMemcpyAsync(b->d_args_s[k % b->pipe_depth], b->h_args, sizeof(MorStreamArgs) * B, hipMemcpyHostToDevice, lane));
+  HIP_TRY(hipEventRecord(b->args_ev[slot], lane));
+  HIP_TRY(hipEventRecord(b->ev[0], lane));
+  hipStream_t tail = lane;
+  static const int exp_few = getenv("MOR_EXP_FEWER_EVENTS") ? atoi(getenv("MOR_EXP_FEWER_EVENTS")) : 0;   // timing experiment only (races on single-copy scratch arrays)
+  for (int pc = 0; pc < b->n_pieces; ++pc) {
+    const bool trk = pc == b->n_pieces - 1;
+    const bool need = !exp_few || b->piece_id[pc] == 4 || trk;
+    if (pc > 0 && k > 0 && need) HIP_TRY(hipStreamWaitEvent(lane, b->ev_piece[exp_few && b->piece_id[pc] == 4 ? pc - 1 : pc][(k - 1) % MOR_MAX_SLOTS], 0));
+    if (trk && b->last_track) HIP_TRY(hipStreamWaitEvent(lane, *b->last_track, 0));   // tracking state: after the previous frame's filterCloud
+    mor_launch_piece(d, b->piece_id[pc], lane, &b->timer);
+    if (!exp_few || b->piece_id[pc] == 3 || trk || pc == 0) HIP_TRY(hipEventRecord(b->ev_piece[pc][k % MOR_MAX_SLOTS], lane));
   }
+  b->last_track = &b->ev_piece[b->n_pieces - 1][k % MOR_MAX_SLOTS];
   HIP_TRY(hipEventRecord(b->ev[1], tail));
   HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], tail));
   HIP_TRY(hipGetLastError());
@@ -513,8 +485,8 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
                        // filterCloud on the same frame walks mo_vec again and moves the confidences again
   b->filtered = true;
   d.out_ptrs = nullptr;
-  hipStream_t fs = b->lanes ? (b->strk ? b->strk : b->lane_stream(k)) : b->sb;   // behind the frame's push
-  if (b->lanes && b->last_track) HIP_TRY(hipStreamWaitEvent(fs, *b->last_track, 0));   // a second filterCloud of a frame, or the frame's own tracking step (same stream: free)
+  hipStream_t fs = b->lane_stream(k);   // behind the frame's push
+  if (b->last_track) HIP_TRY(hipStreamWaitEvent(fs, *b->last_track, 0));   // a second filterCloud of a frame, or the frame's own tracking step (same stream: free)
   if (out && out_on_device) {
     if (b->async && b->last_filter_stream) HIP_TRY(hipStreamSynchronize(b->last_filter_stream));   // the pinned pointer table may still be in flight
     for (int s = 0; s < B; ++s) b->h_outptrs[s] = (float4 *)out[s];
@@ -526,7 +498,7 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
   mor_launch_filter(d, fs, &b->timer);
   HIP_TRY(hipEventRecord(b->ev[3], fs));
   HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], fs));
-  if (b->lanes) { HIP_TRY(hipEventRecord(b->ev_track[k % MOR_MAX_SLOTS], fs)); b->last_track = &b->ev_track[k % MOR_MAX_SLOTS]; }
+  HIP_TRY(hipEventRecord(b->ev_track[k % MOR_MAX_SLOTS], fs)); b->last_track = &b->ev_track[k % MOR_MAX_SLOTS];
   HIP_TRY(hipGetLastError());
   b->pending = true;
   const bool need_host = n_out != nullptr || (out && !out_on_device);
@@ -547,7 +519,7 @@ int mor_batch_wait(mor_batch *b) { if (!b) return MOR_ERR_INVALID; HIP_TRY(hipSe
 const void *mor_get_output_device(const mor_batch *b, int s, uint64_t *n_out) {
   if (!b || s < 0 || s >= b->B) return nullptr;
   if (n_out) *n_out = b->d.h_nout[s];
-  return b->d.ground + 2 * (size_t)s * b->d.Nmax + b->d.h_noff[s];   // assembled in place in the frame's ground buffer (valid until three more frames have been pushed)
+  return b->d.ground + 2 * (size_t)s * b->d.Nmax + b->d.h_noff[s];   // assembled in place in the frame's ground buffer (one copy per frame in flight: valid for MOR_PIPE_DEPTH − 1 = 3 further pushes by default)
 }
 
 // ---- single-stream forms
@@ -564,7 +536,7 @@ void mor_destroy(mor_ctx *c) { mor_batch_destroy(c); }
   if (!b || s < 0 || s >= b->B) return set_error(MOR_ERR_INVALID, "bad batch/stream");      \
   if (b->frame == 0) return set_error(MOR_ERR_NOT_READY, "no frame pushed yet");            \
   HIP_TRY(hipSetDevice(b->device));                                                         \
-  if (b->pending) wait_all_checked(const_cast<mor_batch *>(b));                                                         \
+  if (b->pending) { const int rc_ = sync_all(const_cast<mor_batch *>(b)); if (rc_ != MOR_OK) return rc_; }   /* (sticky error words are left for the next wait) */ \
   const MorDev &d = b->d; const MorFrameInfo &f = d.h_info[s]; const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap; (void)so; (void)ko; (void)f
 
 int mor_get_counts(const mor_batch *b, int s, mor_counts *o) {
@@ -683,7 +655,7 @@ int mor_get_boxes(const mor_batch *b, int s, float *min_K3, float *max_K3) {
 int mor_get_frame_log(const mor_batch *b, uint64_t frame, int s, int64_t *out) {
   if (!b || s < 0 || s >= b->B || !out) return set_error(MOR_ERR_INVALID, "bad batch/stream");
   HIP_TRY(hipSetDevice(b->device));
-  if (b->pending) wait_all_checked(const_cast<mor_batch *>(b));
+  if (b->pending) { const int rc_ = sync_all(const_cast<mor_batch *>(b)); if (rc_ != MOR_OK) return rc_; }
   if (frame >= b->frame || frame + MOR_LOG_CAP < b->frame) return set_error(MOR_ERR_NOT_READY, "frame %llu is not in the log (frames pushed: %llu, log depth %d)", (unsigned long long)frame, (unsigned long long)b->frame, MOR_LOG_CAP);
   const MorFrameLog &L = b->d.h_log[(size_t)(frame % MOR_LOG_CAP) * b->B + s];
   out[0] = L.frame; out[1] = L.K; out[2] = L.C; out[3] = L.n_pairs; out[4] = L.cnt_sum; out[5] = L.det_sum; out[6] = L.n_mo_push; out[7] = L.n_mo_filter; out[8] = (int64_t)L.n_out; out[9] = L.flags;
@@ -695,7 +667,7 @@ int mor_get_frame_log(const mor_batch *b, uint64_t frame, int s, int64_t *out) {
 long long mor_debug_read(const mor_batch *b, const char *name, int s, void *out, size_t bytes) {
   if (!b || s < 0 || s >= b->B || !name || !out) return set_error(MOR_ERR_INVALID, "bad arguments");
   HIP_TRY(hipSetDevice(b->device));
-  if (b->pending) wait_all_checked(const_cast<mor_batch *>(b));
+  if (b->pending) { const int rc_ = sync_all(const_cast<mor_batch *>(b)); if (rc_ != MOR_OK) return rc_; }
   const MorDev &d = b->d; const size_t N = d.Nmax, K = d.Kcap, S = MOR_MAXP + 1;
   struct Ent { const char *n; const void *p; size_t stride; };
   const Ent tab[] = {
@@ -715,7 +687,7 @@ long long mor_debug_read(const mor_batch *b, const char *name, int s, void *out,
 int mor_debug_config(const mor_batch *b, int *out, int n) {   // grid geometry and launch configuration of the latest push
   if (!b || !out) return MOR_ERR_INVALID;
   const MorDev &d = b->d;
-  const int v[12] = {d.g.nx, d.g.ny, d.g.nz, d.g.nrows, d.P, d.grid_mode, 1, d.Hcell, d.Kcap, d.tiles_m, d.cur, d.prev};
+  const int v[12] = {d.g.nx, d.g.ny, d.g.nz, d.g.nrows, d.P, 1, 1, d.Hcell, d.Kcap, d.tiles_m, d.cur, d.prev};
   for (int i = 0; i < n && i < 12; ++i) out[i] = v[i];
   return MOR_OK;
 }

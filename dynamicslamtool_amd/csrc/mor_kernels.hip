@@ -26,11 +26,10 @@
 #include <cstddef>
 #include <cstdlib>
 
-const char *const mor_kernel_names[MK_COUNT] = {
-    "classify", "scan_tiles", "scatter", "split", "heads_count", "heads_scan", "heads_scatter", "hash_clear", "cellboxes", "cellgraph", 
-    "label", "rhist", "rscan", "rscatter",
-    "stats", "stats_fin", "xform_prev", "xform_fin", "nn_centroid", "cluster_pairs", "score_fast", "score_near", "score_block", "score_pde", "vox_clear", "vox_insert", "vox_probe", "decide",
-    "out_count", "out_scan", "out_scatter", "g2_cov_mid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridfill", "cg_slab", "cg_final", "clusters"};
+const char *const mor_kernel_names[MK_COUNT] = {   // in MorKernelId order: "k_" + name = the __global__ function
+    "classify", "scatter", "split", "heads_count", "heads_scatter", "cellboxes", "rhist", "rscan", "rscatter",
+    "xform_prev", "cluster_pairs", "score_fast", "score_near", "score_block", "score_pde", "vox_clear", "vox_insert", "vox_probe",
+    "out_count", "out_scatter", "g2_cov_mid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridfill", "cg_slab", "cg_final", "clusters"};
 
 #ifdef MOR_EXP_STAMPS
 #define RS_T(v) const unsigned long long v = wall_clock64()
@@ -272,22 +271,6 @@ __device__ __forceinline__ void publish_split(const MorDev &d, int s, int n_ng, 
     }
   }
 }
-// one workgroup per stream: exclusive scan of the tile counts; publishes N, T, M, G  (only when fuse_scans is off)
-__global__ __launch_bounds__(MOR_BT) void k_scan_tiles(MorDev d) {
-  int s = blockIdx.x + d.s0;
-  __shared__ int sh[8];
-  int carry_ng = 0, carry_g = 0;
-  for (int b = 0; b < d.tiles; b += MOR_BT) {
-    int t = b + threadIdx.x;
-    const int *c = d.tile_cnt + ((size_t)s * d.tiles_max + t) * 2;
-    int v0 = t < d.tiles ? c[0] : 0, v1 = t < d.tiles ? c[1] : 0, t0, t1;
-    int e0 = block_excl_scan(v0, sh, &t0), e1 = block_excl_scan(v1, sh, &t1);
-    if (t < d.tiles) { int *o = d.tile_off + ((size_t)s * d.tiles_max + t) * 2; o[0] = carry_ng + e0; o[1] = carry_g + e1; }
-    carry_ng += t0; carry_g += t1;
-  }
-  if (threadIdx.x == 0) publish_split(d, s, carry_ng, carry_g);
-}
-
 // pass 2: order-preserving split into `cloud` / ground, cell histogram, forest init
 __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   int s, t0; map_block(d.B, d.split_g, s, t0);
@@ -298,7 +281,7 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   for (int t = t0; t < d.tiles; t += d.split_g) {
   uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
   int r_ng = 0, r_g = 0; float zorg = d.zorg[s]; int zbase = d.zbase[s];
-  if (d.fuse_scans) {   // own offsets from the per-tile counts of k_classify; tile 0 publishes the totals
+  {   // own offsets from the per-tile counts of k_classify (no scan launch in between); tile 0 publishes the totals
     const int *tc = d.tile_cnt + (size_t)s * d.tiles_max * 2; int tot_ng, tot_g;
     wg_prefix_total(tc, 2, t, d.tiles, sh, r_ng, tot_ng);
     wg_prefix_total(tc + 1, 2, t, d.tiles, sh, r_g, tot_g);
@@ -318,7 +301,6 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   }
   if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
   __syncthreads();
-  if (!d.fuse_scans) { const int *to = d.tile_off + ((size_t)s * d.tiles_max + t) * 2; r_ng = to[0]; r_g = to[1]; }
   for (int w = 0; w < wave_id(); ++w) { r_ng += sh[w]; r_g += sh[4 + w]; }
   const size_t so = (size_t)s * d.Nmax;
 #pragma unroll
@@ -379,11 +361,11 @@ __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
       atomicExch(&desc[t], split_pack(t == 0 ? SPLIT_P : SPLIT_A, tng, tg));
     }
     int ex_ng = 0, ex_g = 0;
-    if (t > 0 && !(d.split_variant & 4)) {
+    if (t > 0) {
       int back = t - 1; unsigned spins = 0;
       for (;;) {
         const int j = back - lane;
-        const unsigned long long v = j >= 0 ? ((d.split_variant & 1) ? __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : atomicAdd(&desc[j], 0ull)) : split_pack(SPLIT_P, 0, 0);   // "tile −1": prefix 0
+        const unsigned long long v = j >= 0 ? atomicAdd(&desc[j], 0ull) : split_pack(SPLIT_P, 0, 0);   // "tile −1": prefix 0
         const unsigned long long st = v >> 62;
         const unsigned long long mP = __ballot(st == SPLIT_P), mX = __ballot(st == 0ull);
         const int fp = mP ? __ffsll((long long)mP) - 1 : 64;                                 // nearest tile with a full prefix
@@ -408,7 +390,7 @@ __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
     }
   }
   __syncthreads();
-  if ((uint32_t)t * MOR_TILE >= n_in || (d.split_variant & 2)) return;
+  if ((uint32_t)t * MOR_TILE >= n_in) return;
   int r_ng = s_ex[0], r_g = s_ex[1];
   for (int w = 0; w < wave_id(); ++w) { r_ng += sh[w]; r_g += sh[4 + w]; }
   const size_t so = (size_t)s * d.Nmax;
@@ -421,10 +403,10 @@ __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
       int cx, cy, cz; bool clamped; grid_cell(G, p[it], zorg, zbase, cx, cy, cz, clamped);
       if (clamped && d.gmode != 0) mor_raise(d, s, 8u);
       d.cloud[so + k_ng] = p[it];
-      if (!(d.split_variant & 8)) { d.cloud_tidx[so + k_ng] = k_ng + k_g; d.pkey[so + k_ng] = grid_key(G, cx, cy, cz); }
+      d.cloud_tidx[so + k_ng] = k_ng + k_g; d.pkey[so + k_ng] = grid_key(G, cx, cy, cz);
     } else if (cls[it] == 1) {
-      if (!(d.split_variant & 16)) d.ground[2 * so + d.Nmax + k_g] = p[it];
-      if (!(d.split_variant & 8)) d.gp_idx[so + k_g] = k_ng + k_g;
+      d.ground[2 * so + d.Nmax + k_g] = p[it];
+      d.gp_idx[so + k_g] = k_ng + k_g;
     }
     r_ng += __popcll(m_ng[it]); r_g += __popcll(m_g[it]);
   }
@@ -443,22 +425,6 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_count(MorDev d) {
     for (int p = base + threadIdx.x; p < min(base + MOR_TILE, M); p += MOR_BT) c += is_head(skey, p);
     block_excl_scan(c, sh, &tot);
     if (threadIdx.x == 0) d.ktile_cnt[(size_t)s * d.tiles_max + t] = tot;
-  }
-}
-__global__ __launch_bounds__(MOR_BT) void k_heads_scan(MorDev d) {
-  int s = blockIdx.x + d.s0; __shared__ int sh[8]; int carry = 0;
-  int *c = d.ktile_cnt + (size_t)s * d.tiles_max;
-  const int nt = (d.info[s].M + MOR_TILE - 1) / MOR_TILE;
-  for (int b = 0; b < nt; b += MOR_BT) {
-    int t = b + threadIdx.x, v = t < nt ? c[t] : 0, tot;
-    int e = block_excl_scan(v, sh, &tot);
-    if (t < nt) c[t] = carry + e;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) {
-    d.info[s].n_occ = carry; d.cstart[(size_t)s * (d.Nmax + 1) + carry] = d.info[s].M;
-    int bits = 10; while ((1 << bits) < 4 * carry && (1 << bits) < d.Hcell) ++bits;   // load factor ≤ 1/4
-    d.info[s].hshift = 32 - bits;
   }
 }
 // ------------------------------------------------------------------------------------ cell hash (method-1 scoring)
@@ -507,11 +473,6 @@ __device__ __forceinline__ int cell_key(const MorGrid &g, int cx, int cy, int cz
   if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cy >= (unsigned)g.ny || (unsigned)cz >= (unsigned)g.nz) return -1;
   return grid_key(g, cx, cy, cz);
 }
-__global__ __launch_bounds__(MOR_BT) void k_hash_clear(MorDev d) {
-  const int s = blockIdx.y + d.s0, n = 1 << (32 - d.info[s].hshift);
-  unsigned long long *tab = d.chash + 2 * (size_t)s * d.Hcell;
-  for (int i = blockIdx.x * MOR_BT + threadIdx.x; i < 2 * n; i += gridDim.x * MOR_BT) tab[i] = 0ull;
-}
 // per sorted position: compact cell id; heads publish the cell; every point lands in `sorted`
 __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
   int s, t0; map_block(d.B, d.tiles_m, s, t0);
@@ -525,14 +486,9 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
   const int nt = (M + MOR_TILE - 1) / MOR_TILE;
   if (threadIdx.x == 0) l_ng = 0;
   if (M == 0 && t0 == 0) for (int r = threadIdx.x; r <= G.nrows; r += MOR_BT) rs[r] = 0;   // no cells: every row starts (and ends) at 0
-  if (d.fuse_scans) {   // number of occupied cells: every workgroup sums the tile counts itself (no separate scan launch)
+  {   // number of occupied cells: every workgroup sums the tile counts itself (no separate scan launch)
     int pre, nocc; wg_prefix_total(d.ktile_cnt + (size_t)s * d.tiles_max, 1, 0, nt, sh, pre, nocc);
-    int bits = 10; while ((1 << bits) < 4 * nocc && (1 << bits) < d.Hcell) ++bits;   // cell hash: load factor ≤ 1/4
-    if (t0 == 0 && threadIdx.x == 0) { d.info[s].n_occ = nocc; cstart[nocc] = M; d.info[s].hshift = 32 - bits; }
-    if (d.use_hash) {   // the stream's workgroups clear its table; k_cellboxes inserts the cells
-      unsigned long long *tab = d.chash + 2 * (size_t)s * d.Hcell;
-      for (int i = t0 * MOR_BT + threadIdx.x; i < (2 << bits); i += d.tiles_m * MOR_BT) tab[i] = 0ull;
-    }
+    if (t0 == 0 && threadIdx.x == 0) { d.info[s].n_occ = nocc; cstart[nocc] = M; }
   }
   for (int t = t0; t * MOR_TILE < M; t += d.tiles_m) {
     const int base = t * MOR_TILE + wave_id() * 512;
@@ -542,8 +498,7 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
     if (lane_id() == 0) sh[wave_id()] = cnt;
     __syncthreads();
     int r;
-    if (d.fuse_scans) { int tot; wg_prefix_total(d.ktile_cnt + (size_t)s * d.tiles_max, 1, t, nt, sh + 4, r, tot); }
-    else r = d.ktile_cnt[(size_t)s * d.tiles_max + t];
+    { int tot; wg_prefix_total(d.ktile_cnt + (size_t)s * d.tiles_max, 1, t, nt, sh + 4, r, tot); }
     for (int w = 0; w < wave_id(); ++w) r += sh[w];
     __syncthreads();
 #pragma unroll
@@ -953,13 +908,6 @@ __global__ __launch_bounds__(MOR_BT) void k_gridfill(MorDev d) {
     }
   }
 }
-// (sort path of the grid: the same initialisation as its own small launch)
-__global__ __launch_bounds__(MOR_BT) void k_cellinit(MorDev d) {
-  int s, t0; map_block(d.B, d.tiles_m, s, t0);
-  const int nocc = d.info[s].n_occ;
-  const int *cstart = d.cstart + (size_t)s * (d.Nmax + 1);
-  for (int c = t0 * MOR_BT + threadIdx.x; c < nocc; c += d.tiles_m * MOR_BT) cell_init_if_spanning(d, (size_t)s * d.Nmax, cstart, c);
-}
 // ------------------------------------------------------------------------------------ C1: Euclidean clustering = connected components over cells
 // Per-cell kernels over global memory are bound by chains of dependent loads (key → row table → key → parent →
 // parent …, ≈ 1–2 µs a hop), so the cell graph is worked on in LDS: union-find forests with LDS atomics (cg_find /
@@ -1080,22 +1028,9 @@ __device__ __forceinline__ int cg_lower_bound8(const int *key, int lo, int n, in
 // add: order-free), their records were initialised by k_gridfill.
 __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
   int s, bx; map_block(d.B, d.g_box, s, bx);
-  const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
-  const int nocc = d.info[s].n_occ, M = d.info[s].M, lane = lane_id();
+  const int M = d.info[s].M, lane = lane_id();
   const size_t so = (size_t)s * d.Nmax;
   const float4 *sp = d.sorted + so; const int *sc = d.scell + so;
-  if (bx == 0 && d.grid_mode == 0) { __shared__ int l_sb[48]; slab_bounds<false>(d, G, s, d.row_start + (size_t)s * (d.g.nrows + 1), nocc, l_sb); }   // (the hash path computes them in k_gridhash)
-  if (d.use_hash && d.grid_mode == 0) {   // cell hash: (key+1, compact id); the table was cleared by k_heads_scatter
-    unsigned long long *tab = d.chash + 2 * (size_t)s * d.Hcell; const int *ckey = d.ckey + so;
-    const unsigned hshift = d.info[s].hshift, hmask = (1u << (32 - hshift)) - 1u;
-    for (int c = bx * MOR_BT + threadIdx.x; c < nocc; c += d.g_box * MOR_BT) {
-      const int key = ckey[c]; unsigned sl = hash_slot(key, hshift);
-      const unsigned long long ent = ((unsigned long long)((unsigned)key + 1u) << 32) | (unsigned)c;
-      while (atomicCAS(&tab[2 * sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
-      const int *cst = d.cstart + (size_t)s * (d.Nmax + 1);
-      tab[2 * sl + 1] = ((unsigned long long)(unsigned)(cst[c + 1] - cst[c]) << 32) | (unsigned)cst[c];
-    }
-  }
   for (int base = (bx * (MOR_BT / 64) + wave_id()) * CB_WTILE; base < M; base += d.g_box * (MOR_BT / 64) * CB_WTILE) {
     const int j0 = base + 4 * lane;
     int c[4]; float4 p[4];
@@ -1153,7 +1088,6 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
 #ifndef CGS_CAP
 #define CGS_CAP 1024      // local cells (own + look-ahead) held in LDS
 #endif
-#define CGS_CAP_BIG 2560  // the same for the big-slab variant of the kernel
 #ifndef CGS_ROWCAP
 #define CGS_ROWCAP 2048   // local (y,z) rows held in LDS
 #endif
@@ -1366,8 +1300,7 @@ template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_body(const Mo
   }
   ST2(stwj, 9); ST2V(stwj, 14, n_own); ST2V(stwj, 15, n_loc);
 }
-// CAP: local cells (own + look-ahead) the workgroup holds in LDS — CGS_CAP (76 KB, two workgroups per CU) for open scenes,
-// CGS_CAP_BIG (146 KB) when the previous frame had slabs beyond it (a façade across a y-slice puts > 1000 cells into it).
+// CAP: local cells (own + look-ahead) the workgroup holds in LDS (76 KB: two workgroups per CU).
 template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {
   int s, j; map_block(d.B, d.P, s, j);
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
@@ -1402,7 +1335,7 @@ template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) 
     __syncthreads();
     const CgsCells<true> L = {l_key, l_pc, l_rx, l_ry, l_rz, l_bx, CAP};
     cgs_body<true, true>(d, G, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
-  } else if (fits_rows && n_loc <= 4 * CAP && !(d.split_variant & 8192)) {
+  } else if (fits_rows && n_loc <= 4 * CAP) {
     int *l_key = l_cells, *l_par = l_cells + 4 * CAP, *l_pc = l_cells + 8 * CAP;
     const int *gk = d.ckey + so + c0;
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) {
@@ -2014,9 +1947,9 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f1 = wall_clock64();
 #endif
       if (pr >= 0) {
-        int budget = (d.split_variant & 256) ? 8 : (d.split_variant & 512) ? 0 : 64;   // a big own cell that shows no close point within its first 64 goes to the wave tier (experiment bits: timing only, wrong scores)
+        int budget = 64;   // a big own cell that shows no close point among 64 evenly spread samples goes to the wave tier
         const bool reach = box_dist2(q, tlo, thi) < d.pde_ub;   // farther than √ub from the whole matched cluster: never counted
-        if (reach && c >= 0 && cid == target) { if (d.split_variant & 1024) scan4s(sp, b0, e0, q, lbn, best, budget); else scan_sampled(sp, b0, e0, q, lbn, best, budget); big = best > d.pde_lb && e0 - b0 > 64; }
+        if (reach && c >= 0 && cid == target) { scan_sampled(sp, b0, e0, q, lbn, best, budget); big = best > d.pde_lb && e0 - b0 > 64; }
         if (reach && best > d.pde_lb && !big) {
           if (!e1_local) big = true;   // √lb reaches beyond the adjacent half-cells in this configuration: wave tier
           else if (best < d.pde_ub) {
@@ -2065,16 +1998,10 @@ __device__ __forceinline__ void scan_batch4(const MorDev &d, size_t so, const in
     else if (!(best < d.pde_ub) && bd < d.pde_ub) scan8s(sp, b0[i], e0[i], q, d.pde_ub, best, budget);
   }
 }
-// Which worklist entry a thread of the worklist tiers takes in the pass starting at entry p0 (a pass = G·256 entries, nq
-// entries in all).  Default: 256 consecutive entries per workgroup.  (Measured alternatives, MOR_SPLIT_VARIANT 32 / 64 / 128:
-// entry e → workgroup e % G; chunks of 64 dealt over the workgroups; lanes of a wave nrows apart.)
-__device__ __forceinline__ int wl_entry(const MorDev &d, int p0, int bx, int nq) {
-  if (d.split_variant & 32) return p0 + threadIdx.x * d.g_score + bx;
-  if (d.split_variant & 64) return p0 + ((threadIdx.x >> 6) * d.g_score + bx) * 64 + (threadIdx.x & 63);
-  const int w = p0 + bx * MOR_BT + threadIdx.x;
-  if (d.split_variant & 128) { const int nrows = (nq + 63) >> 6; return w < nrows * 64 ? (w & 63) * nrows + (w >> 6) : nq; }
-  return w;
-}
+// Which worklist entry a thread of the worklist tiers takes in the pass starting at entry p0 (a pass = G·256 entries): 256
+// consecutive entries per workgroup.  (Measured and dropped: entry e → workgroup e % G; chunks of 64 dealt over the workgroups;
+// lanes of a wave nrows apart — all slower.)
+__device__ __forceinline__ int wl_entry(const MorDev &d, int p0, int bx, int nq) { (void)d; (void)nq; return p0 + bx * MOR_BT + threadIdx.x; }
 // Tier 1a — one THREAD per query with E2 known (worklist front).  E1: only the ≤ 7 neighbour cells across the walls q
 // is close to can hold a point within √lb (the own cell was scanned by tier 1).  Three levels of loads: hash probes →
 // box records + ranges → points.  No such point ⇒ counted.
@@ -2453,18 +2380,6 @@ __global__ __launch_bounds__(MOR_BT) void k_out_count(MorDev d) {
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(MOR_BT) void k_out_scan(MorDev d) {
-  int s = blockIdx.x + d.s0; __shared__ int sh[8]; int carry = 0;
-  int *c = d.otile_cnt + (size_t)s * d.tiles_max;
-  const int nt = (d.info[s].M + MOR_TILE - 1) / MOR_TILE;
-  for (int b = 0; b < nt; b += MOR_BT) {
-    int t = b + threadIdx.x, v = t < nt ? c[t] : 0, tot;
-    int e = block_excl_scan(v, sh, &tot);
-    if (t < nt) c[t] = carry + e;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) { d.info[s].n_keep = carry; d.h_nout[s] = (unsigned long long)carry + d.info[s].G; d.h_noff[s] = d.Nmax - carry; }
-}
 // filterCloud's output (:673-684) = [cloud minus moving clusters, original order] ++ [ground points].  The ground points
 // were written to their final place by the split kernel (from slot Nmax of the stream's 2·Nmax-slot `ground` buffer), so the
 // result is assembled in place: the kept cloud points go right-aligned in front of them and the result starts at slot
@@ -2480,10 +2395,10 @@ __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
   __shared__ int sh[12];
   const int nto = (M + MOR_TILE - 1) / MOR_TILE;
   int n_keep = 0;
-  if (d.fuse_scans) {   // kept points in total: every workgroup sums the per-tile counts of k_out_count itself
+  {   // kept points in total: every workgroup sums the per-tile counts of k_out_count itself
     int pre; wg_prefix_total(d.otile_cnt + (size_t)s * d.tiles_max, 1, 0, nto, sh, pre, n_keep);
     if (t2 == 0 && threadIdx.x == 0) { d.info[s].n_keep = n_keep; d.h_nout[s] = (unsigned long long)n_keep + d.info[s].G; d.h_noff[s] = d.Nmax - n_keep; }
-  } else n_keep = d.info[s].n_keep;
+  }
   if (t2 == 0 && threadIdx.x == 0) { d.h_log[(size_t)(d.frame_no % MOR_LOG_CAP) * d.Btot + s].n_out = (unsigned long long)n_keep + d.info[s].G; mor_publish_err(d, s); }
   if (t2 >= d.tiles_m) {
     int t = t2 - d.tiles_m, G = d.info[s].G, nk = n_keep, base = t * MOR_TILE;
@@ -2500,8 +2415,7 @@ __global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
     if (lane_id() == 0) sh[wave_id()] = c;
     __syncthreads();
     int r;
-    if (d.fuse_scans) { int tot; wg_prefix_total(d.otile_cnt + (size_t)s * d.tiles_max, 1, t, nto, sh + 4, r, tot); }
-    else r = d.otile_cnt[(size_t)s * d.tiles_max + t];
+    { int tot; wg_prefix_total(d.otile_cnt + (size_t)s * d.tiles_max, 1, t, nto, sh + 4, r, tot); }
     for (int w = 0; w < wave_id(); ++w) r += sh[w];
     __syncthreads();
 #pragma unroll
@@ -3103,36 +3017,30 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
 static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part = 0) {
   const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B);
   if (part == 2) goto grid;
-  if (d.fuse_scans && d.gmode != 1 && !d.two_pass_split) {
+  if (d.gmode != 1 && !d.two_pass_split) {
     (void)hipMemsetAsync(d.split_desc + (size_t)d.s0 * d.tiles_max, 0, (size_t)d.B * d.tiles_max * sizeof(unsigned long long), st);
     MOR_LAUNCH(MK_SPLIT, k_split, gT, d);
   } else {
     const dim3 gS(d.B * d.split_g);
     MOR_LAUNCH(MK_CLASSIFY, k_classify, gS, d);
-    if (!d.fuse_scans) MOR_LAUNCH(MK_SCAN_TILES, k_scan_tiles, gB, d);
     MOR_LAUNCH(MK_SCATTER, k_scatter, gS, d);
   }
   if (part == 1) return;
 grid:
-  if (d.grid_mode == 1 && d.gmode != 1) {   // clustering grid by counting (k_gridhash); the VoxelGrid pass of the voxel ground variant needs the points of a voxel in index order: sort
+  if (d.gmode != 1) {   // clustering grid by counting (k_gridhash); the VoxelGrid pass of the voxel ground variant needs the points of a voxel in index order: sort
     mor_timer_begin(tm, MK_GRIDHASH, st);
     hipLaunchKernelGGL(k_gridhash, gB, dim3(GH_T), 0, st, d);
     mor_timer_end(tm, MK_GRIDHASH, st);
     MOR_LAUNCH(MK_GRIDFILL, k_gridfill, gM, d);
   } else {
     for (int pass = 0; pass < d.cell_passes; ++pass) {   // points sorted by cell key; result in (skey, sidx) = buffers [cell_passes & 1]
-      MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0, d.fuse_scans && d.tiles_m <= 64};
+      MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0, d.tiles_m <= 64};
       MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
       if (!j.fuse) MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
       MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
     }
     MOR_LAUNCH(MK_HEADS_COUNT, k_heads_count, gM, d);
-    if (!d.fuse_scans) {
-      MOR_LAUNCH(MK_HEADS_SCAN, k_heads_scan, gB, d);
-      if (d.use_hash) MOR_LAUNCH(MK_HASH_CLEAR, k_hash_clear, dim3(64, d.B), d);
-    }
     MOR_LAUNCH(MK_HEADS_SCATTER, k_heads_scatter, gM, d);
-    if (d.gmode != 1) MOR_LAUNCH(MK_GRIDFILL, k_cellinit, gM, d);
   }
 }
 static void mor_launch_boxes(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
@@ -3158,7 +3066,7 @@ static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLau
     hipLaunchKernelGGL(k_g2_cov, dim3(256, d.B), dim3(MOR_BT), 0, st, da);
     mor_timer_end(tm, MK_G2_COV, st);
   } else if (sub == 2) {
-    if (!(d.split_variant & 2048)) MOR_LAUNCH(MK_G2_CENTROID, k_g2_cov_mid, dim3(64, d.B), da);   // (timer slot of the former centroid kernel)
+    MOR_LAUNCH(MK_G2_COV_MID, k_g2_cov_mid, dim3(64, d.B), da);
   } else if (sub == 3) {
     MOR_LAUNCH(MK_G2_COV_BIG, k_g2_cov_big, dim3(64, d.B), da);
   } else if (sub == 4) {
@@ -3171,16 +3079,11 @@ static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLau
     mor_launch_split_and_grid(db, st, tm);
   }
 }
-static void mor_launch_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  if (d.gmode == 0) mor_launch_split_and_grid(d, st, tm);
-  else for (int sub = 0; sub < 6; ++sub) mor_launch_grid_sub(d, sub, st, tm);
-}
 
 static void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part = 0) {   // part: 0 both, 1 slabs, 2 merge
   if (part == 2) goto final;
   mor_timer_begin(tm, MK_CG_SLAB, st);
-  if (d.cg_big) hipLaunchKernelGGL(k_cg_slab<CGS_CAP_BIG>, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
-  else hipLaunchKernelGGL(k_cg_slab<CGS_CAP>, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
+  hipLaunchKernelGGL(k_cg_slab<CGS_CAP>, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
   mor_timer_end(tm, MK_CG_SLAB, st);
   if (part == 1) return;
 final:
@@ -3225,9 +3128,7 @@ static void mor_launch_decide(const MorDev &d, hipStream_t st, MorLaunchTimer *t
 // (transform of ca … first score tiers) stay together because they mutate / read the previous frame's cluster points.
 void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer *tm) {
   switch (piece) {
-    case 0: mor_launch_grid(d, st, tm); break;
     case 1: mor_launch_boxes(d, st, tm); break;
-    case 2: mor_launch_cellgraph(d, st, tm); break;
     case 3: mor_launch_clusters(d, st, tm); break;
     case 4: mor_launch_pairs(d, st, tm); break;
     case 5: mor_launch_scores2(d, st, tm); break;
@@ -3243,12 +3144,11 @@ void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer
 
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gM(d.B * d.tiles_m), gB(d.B), gT2(d.B * (d.tiles_m + (d.out_ptrs ? d.tiles : 0)));
-  if (d.run_tracker) {   // once per frame: a repeated filterCloud on the same frame re-emits the same cloud
+  if (d.run_tracker) {   // the loop over mo_vec (:630-671): on EVERY filterCloud call, as in the reference — a second call on the same frame walks the tracks again
     mor_timer_begin(tm, MK_TRACK_FILTER, st);
     hipLaunchKernelGGL(k_track_filter, gB, dim3(64), 0, st, d);
     mor_timer_end(tm, MK_TRACK_FILTER, st);
   }
   MOR_LAUNCH(MK_OUT_COUNT, k_out_count, gM, d);
-  if (!d.fuse_scans) MOR_LAUNCH(MK_OUT_SCAN, k_out_scan, gB, d);
   MOR_LAUNCH(MK_OUT_SCATTER, k_out_scatter, gT2, d);
 }

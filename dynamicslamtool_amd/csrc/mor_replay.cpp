@@ -62,7 +62,7 @@ int main(int argc, char **argv) {
     std::ofstream mk(out_dir + name); mk.precision(9);
     const auto markers = mor.clusterMarkers();
     for (const auto &m : markers) mk << m.id << ' ' << m.position[0] << ' ' << m.position[1] << ' ' << m.position[2] << ' ' << m.scale[0] << ' ' << m.scale[1] << ' ' << m.scale[2] << ' ' << (m.moving ? 1 : 0) << '\n';
-    std::cout << "frame " << (i - 4) << ": " << cloud.width << " pts in filtered cloud, " << markers.size() << " cluster boxes, frame_id " << mor.output.header.frame_id << ", seq " << mor.output.header.seq << ", stamp " << mor.output.header.stamp << ", cloud seq " << cloud.header.seq << " stamp " << cloud.header.stamp << ", " << ms << " ms" << std::endl;
+    std::cout << "frame " << (i - 4) << ": " << cloud.width << " pts in filtered cloud, " << markers.size() << " cluster boxes, frame_id " << mor.output.header.frame_id << ", seq " << mor.output.header.seq << ", stamp " << mor.output.header.stamp << " (" << mor.output.header.stamp.toNSec() << " ns), cloud seq " << cloud.header.seq << " stamp " << cloud.header.stamp << ", " << ms << " ms" << std::endl;
   }
   return 0;
 }

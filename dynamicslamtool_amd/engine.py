@@ -18,8 +18,7 @@ EXPORTS = [
     "mor_get_labels", "mor_get_ground_indices", "mor_get_clusters", "mor_get_centroids", "mor_get_detection", "mor_get_boxes",
     "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_get_stage_counts", "mor_device_alloc", "mor_device_free", "mor_host_alloc", "mor_host_free",
     "mor_device_upload", "mor_device_download", "mor_device_synchronize", "mor_device_count", "mor_get_last_timing",
-    "mor_kernel_timing_enable", "mor_kernel_timing_read", "mor_tracker_create", "mor_tracker_destroy", "mor_tracker_push",
-    "mor_tracker_filter", "mor_tracker_get", "mor_get_frame_log", "mor_debug_read", "mor_debug_config", "mor_get_markers", "mor_kernel_timeline_read",
+    "mor_kernel_timing_enable", "mor_kernel_timing_read", "mor_get_frame_log", "mor_debug_read", "mor_debug_config", "mor_get_markers", "mor_kernel_timeline_read",
 ]
 
 
@@ -80,12 +79,6 @@ def lib():
         L.mor_get_last_timing.argtypes = [vp, vp, vp]
         L.mor_kernel_timing_enable.argtypes = [vp, i32]
         L.mor_kernel_timing_read.argtypes = [vp, i32, vp, C.c_size_t, vp, vp, i32]
-        L.mor_tracker_create.restype = vp
-        L.mor_tracker_create.argtypes = [vp, i32, i32]
-        L.mor_tracker_destroy.argtypes = [vp]
-        L.mor_tracker_push.argtypes = [vp, i32, vp, vp, i32, vp, vp]
-        L.mor_tracker_filter.argtypes = [vp, vp, vp, vp]
-        L.mor_tracker_get.argtypes = [vp, vp, vp, vp, i32]
         L.mor_get_frame_log.argtypes = [vp, u64, i32, vp]
         _LIB = L
     return _LIB
@@ -378,43 +371,3 @@ class MorBatch:
 
     def synchronize(self):
         _check(lib().mor_device_synchronize(self.device))
-
-
-class HostTracker:
-    """mor_tracker alone — the T1/F1 state machine, usable without a GPU."""
-
-    def __init__(self, params, n_bad=4, n_good=3):
-        self._h = lib().mor_tracker_create(C.addressof(params), n_bad, n_good)
-        self._K = 0
-
-    def push(self, centroids, det, pairs=None):
-        c = np.ascontiguousarray(centroids, np.float32).reshape(-1, 3)
-        d = np.ascontiguousarray(det, np.uint8)
-        self._K = len(d)
-        if pairs is None:
-            rc = lib().mor_tracker_push(self._h, len(d), c.ctypes.data, d.ctypes.data, -1, None, None)
-        else:
-            q = np.ascontiguousarray([p[0] for p in pairs], np.int32)
-            m = np.ascontiguousarray([p[1] for p in pairs], np.int32)
-            rc = lib().mor_tracker_push(self._h, len(d), c.ctypes.data, d.ctypes.data, len(q), q.ctypes.data, m.ctypes.data)
-        _check(rc)
-
-    def filter(self, sizes):
-        sz = np.ascontiguousarray(sizes, np.int32)
-        mv = np.zeros(max(self._K, 1), np.uint8)
-        n = C.c_uint64(0)
-        _check(lib().mor_tracker_filter(self._h, sz.ctypes.data, mv.ctypes.data, C.addressof(n)))
-        return mv[: self._K], int(n.value)
-
-    def tracks(self):
-        xyz, conf, mx = np.empty((4096, 3), np.float32), np.empty(4096, np.int32), np.empty(4096, np.int32)
-        k = lib().mor_tracker_get(self._h, xyz.ctypes.data, conf.ctypes.data, mx.ctypes.data, 4096)
-        return xyz[:k], conf[:k], mx[:k]
-
-    def __del__(self):
-        try:
-            if self._h:
-                lib().mor_tracker_destroy(self._h)
-                self._h = None
-        except Exception:
-            pass

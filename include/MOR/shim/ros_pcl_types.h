@@ -22,7 +22,34 @@ struct PCLPointCloud2 {
 };
 }  // namespace pcl
 
-namespace std_msgs { struct Header { uint32_t seq = 0; double stamp = 0; std::string frame_id; }; }
+// ros::Time as far as the adapter and its callers use it: integer seconds + nanoseconds, no implicit conversion from a number
+// (the real constructor from double is explicit), fromNSec / toNSec / toSec, and the stream form "sec.nnnnnnnnn"
+namespace ros {
+struct Time {
+  uint32_t sec = 0, nsec = 0;
+  Time() {}
+  Time(uint32_t s, uint32_t ns) : sec(s), nsec(ns) {}
+  explicit Time(double t) : sec((uint32_t)t), nsec((uint32_t)((t - (double)(uint32_t)t) * 1e9)) {}
+  Time &fromNSec(uint64_t t) { sec = (uint32_t)(t / 1000000000ull); nsec = (uint32_t)(t % 1000000000ull); return *this; }
+  uint64_t toNSec() const { return (uint64_t)sec * 1000000000ull + nsec; }
+  double toSec() const { return (double)sec + 1e-9 * (double)nsec; }
+  bool operator==(const Time &o) const { return sec == o.sec && nsec == o.nsec; }
+};
+template <class OS> OS &operator<<(OS &os, const Time &t) {
+  char b[32]; int n = 0; uint32_t ns = t.nsec;
+  for (int i = 8; i >= 0; --i) { b[i] = (char)('0' + ns % 10); ns /= 10; ++n; }
+  b[9] = 0; (void)n;
+  os << t.sec << "." << b;
+  return os;
+}
+}  // namespace ros
+namespace std_msgs { struct Header { uint32_t seq = 0; ros::Time stamp; std::string frame_id; }; }
+// pcl_conversions::fromPCL(const pcl::PCLHeader &, std_msgs::Header &): pcl stamps are microseconds since the epoch
+namespace pcl_conversions {
+inline void fromPCL(const pcl::PCLHeader &pcl_header, std_msgs::Header &header) {
+  header.stamp.fromNSec(pcl_header.stamp * 1000ull); header.seq = pcl_header.seq; header.frame_id = pcl_header.frame_id;
+}
+}  // namespace pcl_conversions
 namespace geometry_msgs {
 struct Point { double x = 0, y = 0, z = 0; };
 struct Quaternion { double x = 0, y = 0, z = 0, w = 1; };

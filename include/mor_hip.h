@@ -96,13 +96,15 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
  * and no host output) only enqueue their launches — the tracking state lives on the device, so a push + filter
  * pair needs no host round trip — and return at once; mor_batch_wait blocks until everything enqueued has
  * finished and reports the errors any frame has raised since the last report (a sticky error word per stream; reporting
- * clears it).  Every read-back waits by itself. */
+ * clears it).  Every read-back waits by itself but reports nothing: an error raised by an earlier frame stays pending until
+ * mor_batch_wait (or the next synchronous push / filter) returns it. */
 int mor_batch_set_async(mor_batch *b, int on);
 int mor_batch_wait(mor_batch *b);
 
 /* Device-resident result of the last filter for stream i (float4 records).  The filtered cloud is assembled in place in
- * one of the batch's three per-frame buffers (the ground points are written there once, at the split): the pointer stays
- * valid until three more frames have been pushed. */
+ * one of the batch's per-frame buffers (the ground points are written there once, at the split; there is one buffer per frame
+ * in flight, MOR_PIPE_DEPTH = 4 by default): the pointer stays valid for MOR_PIPE_DEPTH - 1 further pushes (three by default;
+ * with MOR_PIPE_DEPTH=1 the very next push overwrites it). */
 const void *mor_get_output_device(const mor_batch *b, int stream, uint64_t *n_out);
 
 /* Single-stream forms used by the class adapter (a batch with one stream). */
@@ -174,20 +176,6 @@ int mor_kernel_timing_enable(mor_batch *b, int enable);
 int mor_kernel_timing_read(mor_batch *b, int reset, char *names, size_t names_cap, float *ms_total, uint32_t *launches, int max_kernels);
 /* the launches of the last timed leg as (index into the names of mor_kernel_timing_read, start ms, end ms) on one clock */
 int mor_kernel_timeline_read(mor_batch *b, int *ids, float *t0_ms, float *t1_ms, int max_n);
-
-/* ---- the temporal logic alone as host C++ (T1/F1 state machine, the same rules as the device kernels; lets CPU-only
- * tests drive it) ---- */
-typedef struct mor_tracker mor_tracker;
-mor_tracker *mor_tracker_create(const mor_params *p, int n_bad, int n_good);
-void mor_tracker_destroy(mor_tracker *t);
-/* feed one frame's cluster summary: K centroids, detection flags, and the correspondence pairs to
- * the previous frame (n_pairs < 0: first frame, no pair stage) — runs checkMovingClusterChain */
-int mor_tracker_push(mor_tracker *t, int K, const float *centroids_K3, const uint8_t *det_K, int n_pairs,
-                     const int32_t *query, const int32_t *match);
-/* filterCloud's tracking loop (:630-671): fills moving_K (1 = cluster removed) and *n_moving_idx =
- * total indices pushed incl. duplicates (cluster sizes needed for the ExtractIndices size check) */
-int mor_tracker_filter(mor_tracker *t, const int32_t *cluster_sizes_K, uint8_t *moving_K, uint64_t *n_moving_idx);
-int mor_tracker_get(const mor_tracker *t, float *xyz_n3, int32_t *conf, int32_t *max_conf, int max_n);
 
 #ifdef __cplusplus
 }

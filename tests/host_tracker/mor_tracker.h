@@ -1,12 +1,13 @@
-// mor_tracker.h — host-side temporal logic of the hot path (SURVEY.md §8a rows T1 and the
-// tracking loop of F1).  O(clusters) per frame, strictly sequential, stays on the CPU exactly as
-// in the reference.  Follows /root/reference/src/MovingObjectRemoval.cpp:415-514 and :630-671,
+// mor_tracker.h — the temporal logic of the hot path (SURVEY.md §8a rows T1 and the tracking loop of F1) as plain host
+// C++.  TEST-ONLY: the product runs this logic on the device (k_track_push / k_track_filter in csrc/mor_kernels.hip);
+// this second, independent statement of the same rules lets CPU-only tests drive scripted cluster / score sequences
+// (tests/test_tracker_host.py) and is not part of libmor_hip.so.  Follows /root/reference/src/MovingObjectRemoval.cpp:415-514 and :630-671,
 // struct MovingObjectCentroid at include/MOR/MovingObjectRemoval.h:83-94.
 #pragma once
 #include <cstdint>
 #include <deque>
 #include <vector>
-#include "../../include/mor_hip.h"
+#include "../../include/mor_hip.h"   // mor_params, error codes
 
 struct MorCorr { int32_t query, match; };
 
@@ -37,3 +38,14 @@ struct mor_tracker {
   int recurse_find_cluster_chain(int col, int track) const;   // :415-453
   void push_centroid(const float *pt);                        // :455-476
 };
+
+extern "C" {
+mor_tracker *mor_tracker_create(const mor_params *p, int n_bad, int n_good);
+void mor_tracker_destroy(mor_tracker *t);
+/* feed one frame's cluster summary: K centroids, detection flags, and the correspondence pairs to the previous frame
+ * (n_pairs < 0: first frame, no pair stage) — runs checkMovingClusterChain */
+int mor_tracker_push(mor_tracker *t, int K, const float *centroids_K3, const uint8_t *det_K, int n_pairs, const int32_t *query, const int32_t *match);
+/* filterCloud's tracking loop (:630-671): fills moving_K (1 = cluster removed) and *n_moving_idx = total indices pushed incl. duplicates */
+int mor_tracker_filter(mor_tracker *t, const int32_t *cluster_sizes_K, uint8_t *moving_K, uint64_t *n_moving_idx);
+int mor_tracker_get(const mor_tracker *t, float *xyz_n3, int32_t *conf, int32_t *max_conf, int max_n);
+}

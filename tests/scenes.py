@@ -63,3 +63,31 @@ def small_stream(seed, n_frames=7, n_objects=6, pts_per_object=220, n_floor=600,
         pose = np.concatenate([[ego_xy[0], ego_xy[1], 0.0], _yaw_quat(ego_yaw)])
         frames.append((pts, pose))
     return frames
+
+
+def sweep_case(case):
+    """Randomised parameter profile + two small streams of tests/test_gpu_parity.py::test_parameter_sweep_on_small_streams (shared with
+    tests/golden/make_sweep_minimums.py, which records what the oracle produces for each case)."""
+    rng = np.random.default_rng(1000 + case)
+    p = scene_params(method_choice=int(rng.integers(1, 3)))
+    p.ec_distance_threshold = float(rng.choice([0.06, 0.11, 0.18, 0.3]))
+    p.min_cluster_size = int(rng.choice([5, 25, 60]))
+    p.max_cluster_size = int(rng.choice([150, 400, 20000]))
+    p.trim_x, p.trim_y = float(rng.choice([2.0, 3.0, 5.0])), float(rng.choice([2.0, 3.0, 5.0]))
+    p.trim_z = float(rng.choice([0.8, 2.0]))
+    p.gp_limit = float(rng.choice([-0.6, -0.55, -0.3]))
+    p.volume_constraint = float(rng.choice([0.1, 0.3, 0.9]))
+    lb, ub = [(0.0001, 0.003), (0.002, 0.02), (0.01, 0.5), (0.05, 0.01), (-1.0, 0.004), (0.0, 0.0002), (0.0005, 2.5)][case % 7]
+    p.pde_lb, p.pde_ub = lb, ub
+    p.pde_distance_threshold = float(rng.choice([0.05, 0.15, 0.5]))
+    p.opc_normalization_factor = int(rng.choice([5, 15, 40]))
+    p.leave_off_distance, p.catch_up_distance = float(rng.choice([0.05, 0.4])), float(rng.choice([0.1, 0.3]))
+    n_bad, n_good = int(rng.integers(2, 6)), int(rng.integers(1, 5))
+    # two draws left every component outside the size window (tolerance 0.06 with min 60; tolerance 0.3 with max 150 merges whole boxes):
+    # a sweep case that forms no cluster exercises nothing behind the clustering, so those two get the neighbouring choice
+    if case == 7:
+        p.min_cluster_size = 5
+    if case == 13:
+        p.max_cluster_size = 400
+    streams = [small_stream(100 + 3 * case + i, n_frames=8, n_objects=int(rng.integers(3, 9))) for i in range(2)]
+    return p, n_bad, n_good, streams

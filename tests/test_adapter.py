@@ -81,6 +81,17 @@ def test_replay_matches_oracle(tmp_path, method):
             assert np.array_equal(got_xyz.view(np.uint32), cc[:, :3].view(np.uint32)) and np.array_equal(got_i.view(np.uint32), cc[:, 3].view(np.uint32)), "frame %d" % i
             assert ("pushed %d: caller cloud width %d point_step 32 output.width %d output.frame_id %s" % (i, len(cc), len(cc), "/debug")) in r.stdout, r.stdout
         # filterCloud: the incoming cloud's header travels through to out_cloud and `output` (.cpp:690-691), frame_id replaced (.cpp:692)
-        assert ("frame %d:" % i) in r.stdout and ("frame_id /filtered, seq %d, stamp %d, cloud seq %d stamp %d" % (i, 100 + i, i, 1000000 * (100 + i))) in r.stdout, r.stdout
+        assert ("frame %d:" % i) in r.stdout and ("frame_id /filtered, seq %d, stamp %d.000000000 (%d ns), cloud seq %d stamp %d" % (i, 100 + i, 1000000000 * (100 + i), i, 1000000 * (100 + i))) in r.stdout, r.stdout
     if method == 2:
         assert removed > 0
+
+
+def test_adapter_compiles_against_ros_shaped_types(tmp_path):
+    """INTEGRATION.md's build (`-DMOR_WITH_ROS_PCL`): mor_adapter.cpp must compile against headers shaped like the REAL ROS / PCL types —
+    ros::Time with an explicit constructor (no assignment from double), allocator-templated messages, pcl::uint8_t vectors,
+    pcl_conversions::fromPCL — not only against the in-repo shim.  Compile-only (tests/ros_stub/ are data carriers)."""
+    src = os.path.join(ROOT, "dynamicslamtool_amd", "csrc", "mor_adapter.cpp")
+    for extra in ([], ["-DMOR_NO_VISUALIZE"]):
+        r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-c", "-DMOR_WITH_ROS_PCL", "-I", os.path.join(ROOT, "tests", "ros_stub"), "-I", os.path.join(ROOT, "include"),
+                            src, "-o", str(tmp_path / "adapter.o")] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr

@@ -1,0 +1,28 @@
+"""-m gpu: `python bench.py --gpus 2` on whatever devices exist (both ranks on device 0 of a 1-GPU box): BASELINE config 4's launch path
+with real GPU work — two rank processes, disjoint streams, one line, self-checked results."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_share_the_visible_devices():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "8", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-extras"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["self_launched"] and d["collective"] == "none" and d["scaling"] == "weak"
+    assert d["first_seed_per_rank"] == [2000, 2008]                      # rank r owns streams r·B … r·B + B − 1
+    assert len(d["per_rank_frame_pairs_per_s"]) == 2 and min(d["per_rank_frame_pairs_per_s"]) > 0
+    # whole-job rate = all ranks' frame-pairs ÷ the slowest rank's time: between N × the slowest and the sum of the per-rank rates
+    assert 2 * min(d["per_rank_frame_pairs_per_s"]) * 0.999 <= d["value"] <= sum(d["per_rank_frame_pairs_per_s"]) * 1.001
+    assert d["sanity"]["ok"] and d["sanity"]["async_equals_sync"] and d["sanity"]["frames_checked"] == 6
+    assert d["roofline"]["frac"] > 0 and d["config"]["streams_per_gpu"] == 8

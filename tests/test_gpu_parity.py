@@ -8,7 +8,7 @@ from dynamicslamtool_amd import kitti_params, synth
 from dynamicslamtool_amd.engine import DeviceBuffer, MorBatch, MorError
 from oracle.oracle import Oracle
 from parity import compare_frame, compare_output, compare_tracks
-from scenes import scene_params, small_stream
+from scenes import scene_params, small_stream, sweep_case
 
 pytestmark = pytest.mark.gpu
 
@@ -54,29 +54,24 @@ def test_small_stream_exercises_removal():
     assert st["tracks"] >= 1 and st["removed"] > 0 and st["moving"] > 0
 
 
+_SWEEP_MIN = None   # filled from tests/golden/sweep_minimums.json (oracle-only counts per case: clusters, correspondences)
+
+
 @pytest.mark.parametrize("case", range(14))
 def test_parameter_sweep_on_small_streams(case):
     """Randomised parameter profiles (cluster tolerance, size limits, trim box, both scoring methods with bounds that
     exercise every scoring tier — √lb wider than half a cell, lb ≥ ub, negative lb, a search stencil of one cell,
-    a wide one —, window lengths) on small streams, everything compared with the oracle frame by frame."""
-    rng = np.random.default_rng(1000 + case)
-    p = scene_params(method_choice=int(rng.integers(1, 3)))
-    p.ec_distance_threshold = float(rng.choice([0.06, 0.11, 0.18, 0.3]))
-    p.min_cluster_size = int(rng.choice([5, 25, 60]))
-    p.max_cluster_size = int(rng.choice([150, 400, 20000]))
-    p.trim_x, p.trim_y = float(rng.choice([2.0, 3.0, 5.0])), float(rng.choice([2.0, 3.0, 5.0]))
-    p.trim_z = float(rng.choice([0.8, 2.0]))
-    p.gp_limit = float(rng.choice([-0.6, -0.55, -0.3]))
-    p.volume_constraint = float(rng.choice([0.1, 0.3, 0.9]))
-    lb, ub = [(0.0001, 0.003), (0.002, 0.02), (0.01, 0.5), (0.05, 0.01), (-1.0, 0.004), (0.0, 0.0002), (0.0005, 2.5)][case % 7]
-    p.pde_lb, p.pde_ub = lb, ub
-    p.pde_distance_threshold = float(rng.choice([0.05, 0.15, 0.5]))
-    p.opc_normalization_factor = int(rng.choice([5, 15, 40]))
-    p.leave_off_distance, p.catch_up_distance = float(rng.choice([0.05, 0.4])), float(rng.choice([0.1, 0.3]))
-    n_bad, n_good = int(rng.integers(2, 6)), int(rng.integers(1, 5))
-    streams = [small_stream(100 + 3 * case + i, n_frames=8, n_objects=int(rng.integers(3, 9))) for i in range(2)]
+    a wide one —, window lengths) on small streams, everything compared with the oracle frame by frame.  No case is vacuous:
+    tests/golden/sweep_minimums.json holds the clusters and correspondences the ORACLE alone produces for each case
+    (make_sweep_minimums.py), all non-zero, and the run must reproduce exactly those sums."""
+    global _SWEEP_MIN
+    if _SWEEP_MIN is None:
+        import json
+        _SWEEP_MIN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sweep_minimums.json")))["cases"]
+    p, n_bad, n_good, streams = sweep_case(case)
     st = _run_lockstep(p, streams, n_bad=n_bad, n_good=n_good)
-    assert st["clusters"] >= 0
+    assert _SWEEP_MIN[case][0] > 0 and _SWEEP_MIN[case][1] > 0
+    assert [st["clusters"], st["corr"]] == _SWEEP_MIN[case], (case, st)
 
 
 @pytest.mark.parametrize("lb,ub", [(0.05, 0.5), (0.005, 0.05), (0.0004, 0.9), (0.3, 0.2), (0.005, 3.0)])
@@ -387,17 +382,13 @@ print("OK")
 """
 
 
-@pytest.mark.parametrize("env", [{"MOR_GH_TIER": "1"}, {"MOR_GH_TIER": "2", "MOR_CG_GLOBAL": "1"}, {"MOR_GRID": "radix"}, {"MOR_SINGLE_PASS_SPLIT": "1"},
-                                 {"MOR_SCHED": "stages", "MOR_STAGES": "0123333", "MOR_PIPE_DEPTH": "2"}, {"MOR_SCHED": "stages", "MOR_STAGES": "0001123", "MOR_PIPE_DEPTH": "6"},
-                                 {"MOR_LANES": "2"}, {"MOR_PIPE_DEPTH": "8", "MOR_LANES": "6"}, {"MOR_PIPE_DEPTH": "1"},
-                                 {"MOR_CG_BIG": "1", "MOR_SPLIT_G": "8"}, {"MOR_SPLIT_VARIANT": "32"}, {"MOR_SPLIT_VARIANT": "1216"}])
+@pytest.mark.parametrize("env", [{"MOR_GH_TIER": "1"}, {"MOR_GH_TIER": "2", "MOR_CG_GLOBAL": "1"}, {"MOR_LANES": "2"}, {"MOR_PIPE_DEPTH": "8", "MOR_LANES": "6"}, {"MOR_PIPE_DEPTH": "1"},
+                                 {"MOR_PIPE_DEPTH": "2", "MOR_LANES": "1"}])
 def test_kernel_variants(env):
-    """The variants behind the default paths must give the same results: k_gridhash with its big LDS table / its
-    global-memory table, slab and merge forests in global memory, the radix-sort grid build, the single-pass ground split, the
-    stage schedule with other stage assignments, other numbers of lanes / pipeline depths, the big-slab kernel of the cell graph,
-    strided tile loops in the split, other worklist mappings and the unsampled own-cell scan of tier 1.  The variant is chosen
-    when the batch is created, from the environment: child process (synchronous frames against the oracle, then an asynchronous
-    run without waits against a synchronous one)."""
+    """The tiers behind the default paths must give the same results: k_gridhash with its big LDS table / its global-memory table,
+    slab and merge forests in global memory, other numbers of lanes / pipeline depths.  The tier is chosen when the batch is created,
+    from the environment: child process (synchronous frames against the oracle, then an asynchronous run without waits against a
+    synchronous one)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT % (root, os.path.join(root, "tests"))], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
@@ -875,7 +866,7 @@ def test_two_batches_in_one_process_interleaved():
 def test_centroids_do_not_depend_on_scheduling():
     """Cluster centroids come from exact integer coordinate sums per cell (k_cellboxes) added per cluster (k_clusters): the order in
     which waves and atomics deliver the points must not show.  The same frames through two batches — one with 32 slabs and the
-    radix grid (another order of points inside the cells, other cells sharing wave tiles), one default — give bit-identical
+    big-table tier of the grid build (another order of discovery of the cells, other interleavings of the cursors), one default — give bit-identical
     centroids, boxes and first points; and the centroid equals the fp64 mean of the cluster's points to the last bit or one ulp."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -897,7 +888,7 @@ np.save(sys.argv[1], np.array(out, dtype=object), allow_pickle=True)
     import tempfile
     res = []
     with tempfile.TemporaryDirectory() as td:
-        for i, env in enumerate(({}, {"MOR_CG_P": "32", "MOR_GRID": "radix"})):
+        for i, env in enumerate(({}, {"MOR_CG_P": "32", "MOR_GH_TIER": "1"})):
             fn = os.path.join(td, "r%d.npy" % i)
             r = subprocess.run([sys.executable, "-c", script, fn], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -914,3 +905,111 @@ np.save(sys.argv[1], np.array(out, dtype=object), allow_pickle=True)
             assert d.max() <= 1, (s, k, c0[k], want)
             ulp_diffs += int(d.sum())
     assert ulp_diffs <= 2   # a cast on a rounding boundary at most
+
+
+def test_readbacks_do_not_swallow_the_error_of_an_earlier_frame():
+    """in asynchronous mode a read-back issued before the wait (counts, frame log, intermediate arrays) synchronises but
+    must not consume the sticky error word of an earlier frame — the wait that follows still raises it, exactly once."""
+    p = scene_params(method_choice=2)
+    p.ground_method = 1
+    p.gp_leaf = 0.1
+    frames = small_stream(2, n_frames=5, with_nan=False)
+    bad = frames[2][0].copy()
+    bad[5] = (0.5, 0.5, 150.0, 0.0)
+    b = MorBatch(p, 1, len(bad) + 16)
+    b.set_async(True)
+    for f, (pts, pose) in enumerate(frames):
+        b.push([bad if f == 2 else pts], pose[None, :])
+        b.filter_async()
+    assert b.counts(0).n_in == len(frames[4][0])          # read-backs wait by themselves …
+    assert b.frame_log(2, 0)["flags"] & 8                   # … the frame log shows which frame raised what …
+    b.debug_read("pcid", 0, count=16)
+    with pytest.raises(MorError, match="z extent"):       # … and the error is still there for the wait
+        b.wait()
+    b.wait()                                                # reported once
+    b.close()
+
+
+def test_all_64_streams_of_one_frame_pair_against_the_oracle():
+    """BASELINE configs[1] at full size: EVERY stream of the B = 64 batch against the CPU oracle for the first two frame pairs — counts,
+    CRC of the labels, correspondences, scores, detection flags, filtered-cloud bytes (the oracle's 64 streams run in worker processes
+    started before this process touches the GPU ... they only use the CPU)."""
+    import multiprocessing as mp, zlib
+    p = kitti_params(1)
+    B, nf = 64, 3
+    seeds = [2000 + s for s in range(B)]
+    with mp.get_context("spawn").Pool(min(os.cpu_count() or 1, 32)) as pool:
+        want = pool.map(_oracle_stream_digest, [(seed, nf) for seed in seeds], chunksize=1)
+    b = MorBatch(p, B, 120000)
+    for f in range(nf):
+        xs, ps = synth.batch(seeds, [f] * B)
+        b.push(list(xs), ps)
+        got = []
+        for s in range(B):
+            c = b.counts(s)
+            q, m, _, sc = b.correspondences(s)
+            got.append([int(c.n_trim), int(c.n_cloud), int(c.n_ground), int(c.n_clusters), int(c.n_clustered), int(c.n_corr), zlib.crc32(b.labels(s).tobytes()),
+                        zlib.crc32(q.tobytes() + m.tobytes() + sc.tobytes()), zlib.crc32(b.detection(s).tobytes())])
+        outs = b.filter()
+        for s in range(B):
+            got[s] += [len(outs[s]), zlib.crc32(outs[s].tobytes()), int(b.counts(s).n_tracks)]
+            assert got[s] == want[s][f], (f, s, got[s], want[s][f])
+    assert sum(w[nf - 1][5] for w in want) > 500   # hundreds of correspondences in the batch
+    b.close()
+
+
+def _oracle_stream_digest(job):
+    import zlib
+    seed, nf = job
+    p = kitti_params(1)
+    o, out = Oracle(p), []
+    for f in range(nf):
+        x, ps = synth.frame(seed, "hdl64", f)
+        o.push(x, ps)
+        c = o.counts()
+        q, m, _, sc = o.correspondences()
+        rec = [int(c.n_trim), int(c.n_cloud), int(c.n_ground), int(c.n_clusters), int(c.n_clustered), int(c.n_corr), zlib.crc32(o.labels().tobytes()),
+               zlib.crc32(q.tobytes() + m.tobytes() + sc.tobytes()), zlib.crc32(o.detection().tobytes())]
+        fo = o.filter()
+        out.append(rec + [len(fo), zlib.crc32(fo.tobytes()), int(o.counts().n_tracks)])
+    o.close()
+    return out
+
+
+def test_soak_500_asynchronous_steps_equal_synchronous_use():
+    """500 push + filter pairs without a wait (device-resident clouds, B = 64 × 120 000 pts) against a synchronous run of the same
+    length: each of the last 64 frame summaries, all tracks and the output sizes agree, and no error flag was raised on the way."""
+    p = kitti_params(1)
+    B, npts, nf, steps = 64, 120000, 12, 500
+    seeds = [2000 + s for s in range(B)]
+    buf = DeviceBuffer(nf * B * npts * 16)
+    poses = np.empty((nf, B, 7))
+    for f in range(nf):
+        xs, ps = synth.batch(seeds, [f] * B)
+        buf.upload(xs, f * B * npts * 16)
+        poses[f] = ps
+
+    def fr(i):
+        k = i % (2 * (nf - 1))
+        return k if k < nf else 2 * (nf - 1) - k
+    res = []
+    for mode in ("async", "sync"):
+        b = MorBatch(p, B, npts)
+        views = [b.make_views([(buf.ptr + (f * B + s) * npts * 16, npts) for s in range(B)]) for f in range(nf)]
+        if mode == "async":
+            b.set_async(True)
+        for i in range(steps):
+            b.push_views(views[fr(i)], poses[fr(i)])
+            if mode == "async":
+                b.filter_async()
+            else:
+                b.filter_device()
+        b.wait()
+        logs = [[b.frame_log(f, s) for s in range(B)] for f in range(steps - 64, steps)]
+        tr = [tuple(np.asarray(x).tobytes() for x in b.tracks(s)) for s in range(B)]
+        res.append((logs, tr, [b.output_device(s)[1] for s in range(B)]))
+        b.close()
+    buf.free()
+    assert res[0][0] == res[1][0], "frame summaries differ"
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    assert max(L["n_mo_filter"] for L in res[0][0][-1]) > 50 and all(L["flags"] == 0 for fl in res[0][0] for L in fl)

@@ -39,3 +39,19 @@ def test_stream_seeds_are_disjoint_across_ranks():
         assert not (seen & set(s))
         seen |= set(s)
     assert len(seen) == 512 and min(seen) == 2000
+
+
+def test_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the script starts two fresh rank processes before touching HIP
+    and relays rank 0's single line (BASELINE config 4 is `python bench.py --gpus 8`)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run", "--streams", "8"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["self_launched"] and d["collective"] == "none"
+    assert d["first_seed_per_rank"] == [2000, 2008]
+    assert abs(d["value"] - (2 * 8 * 4) / 1.5) < 1e-9

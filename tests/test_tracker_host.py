@@ -1,10 +1,10 @@
 """Host tracker (csrc/mor_tracker.cpp: checkMovingClusterChain / recurseFindClusterChain /
 pushCentroid and filterCloud's loop) against the oracle, driven with the oracle's own per-frame
-cluster summaries.  CPU only — the tracker is plain host C++ inside libmor_hip.so."""
+cluster summaries.  CPU only — a test-only host statement of the rules the device kernels k_track_push / k_track_filter implement (tests/host_tracker/)."""
 import numpy as np
 import pytest
 
-from dynamicslamtool_amd.engine import HostTracker
+from host_tracker import HostTracker
 from oracle.oracle import Oracle
 from scenes import scene_params, small_stream
 
