@@ -73,6 +73,7 @@ void MovingObjectRemoval::setVariables(const std::string &path) {
     else if (key == "method_choice") { params_.method_choice = std::stoi(val); std::cout << params_.method_choice; known = true; }
     else if (key == "opc_normalization_factor") { params_.opc_normalization_factor = (int)std::stof(val); std::cout << params_.opc_normalization_factor; known = true; }   // stof into an int (.cpp:843)
     else if (key == "ground_method") { params_.ground_method = std::stoi(val); std::cout << params_.ground_method; known = true; }   // extension key: 0 crop box, 1 voxel covariance
+    else if (key == "opc_anchor") { params_.opc_anchor = std::stoi(val); std::cout << params_.opc_anchor; known = true; }   // extension key: method-2 voxel lattice anchored at p0 − res (0) or p0 − res/2 (1)
     else if (key == "volume_abs_int") { params_.volume_abs_int = std::stoi(val); std::cout << params_.volume_abs_int; known = true; }   // extension key: 1 = the abs() of .cpp:277 truncates to int first (old libstdc++)
     if (!known) { std::cout << "Invalid parameter found in config file\n"; std::exit(0); }
     std::cout << std::endl;

@@ -56,6 +56,7 @@ struct MorFrameInfo {        // per stream, produced on device
 #define MOR_MAX_DEPTH 8     // frames in flight in the stage pipeline, at most (one copy of every per-frame array each)
 #define MOR_MAX_SLOTS 10     // cluster-array slots (depth + 1 are in use)
 #define MOR_MAXP 32        // slabs per stream of the cell graph (k_cg_slab), at most
+#define MOR_CGS_FCAP 6300  // cells per stream the fused merge at the tail of k_cg_slab holds in LDS (beyond: its global-memory path; the host then prefers the separate k_cg_final)
 #define MOR_CGS_OVF 8192   // overflow entries per slab of its candidate-pair lists (beyond them a pair is settled on the spot)
 #define MOR_TR_MAXT 32768  // tracked moving centroids per stream (mo_vec); the reference has no bound — beyond this one the push reports MOR_ERR_CAPACITY
 #define MOR_TR_NB 8       // longest supported window (n_bad)
@@ -78,7 +79,7 @@ struct MorDev {
   long long min_cs, max_cs;
   float pde_lb, pde_ub;
   double pde_thr, vol_thr, opc_res;
-  int method, opc_norm, score_R, n_rows, t1_budget, vol_abs_int;
+  int method, opc_norm, score_R, n_rows, t1_budget, vol_abs_int, opc_anchor_half;
   const signed char *row_order; // [n_rows][2] (dy,dz) of the method-1 search stencil, nearest rows first
   MorGrid g;                 // clustering grid (cell edge 0.57·r)
   MorGrid gv;                // VoxelGrid lattice of the voxel-covariance ground removal (cell edge gp_leaf)
@@ -100,6 +101,7 @@ struct MorDev {
   int2 *slot_kc[MOR_MAX_SLOTS];          // [B]  (K, C) of the frame that owns the cluster slot: written by the cell graph of that frame, read by the
                              //      next frame's pair stage as ca's K and C (never through another frame's `info` copy, which the grid
                              //      stage of a later frame resets while the pair stage may still be running)
+  int *tickets;              // [B][8]  arrival counters of the "last workgroup of the stream" hand-offs (one set per frame in flight)
   unsigned *err;             // [B]  sticky error word per stream: every raised flag is OR-ed in and stays until the host has reported it
   unsigned *h_err;           // [B]  pinned host mirror of `err`, refreshed by the last kernel of every push and filter
   int frame_no;              // index of this frame since the batch was created
@@ -126,6 +128,7 @@ struct MorDev {
   int gh_tier;   // table tier k_gridhash starts with (0 small LDS table, 1 big LDS table, 2 global memory)
   int *slab_y, *slab_c, *slab_e;    // [B][MOR_MAXP+1]  slabs of the cell graph: first y-slice, first compact cell id, end of the look-ahead (cells of the next two y-slices)
   int P, cg_force_global;    // slabs per stream this frame; test knob: forests in global memory
+  int cg_fused;              // the merge of the slab forests (k_cg_final's work) runs in each stream's last slab workgroup of k_cg_slab
   int *lroot_a, *lroot_b;    // [B][Nmax]  per cell: its local root in its own slab / in the previous slab's look-ahead (compact ids)
   int *parent2;              // [B][Nmax]  second global forest (odd slabs when they do not fit LDS)
   int *skey, *sidx;          // aliases of the radix buffers holding the cell-sorted (key, cloud index)
@@ -210,15 +213,15 @@ struct MorCellSum { long long a[3], b[3]; };
 // kernel ids for optional per-kernel event timing
 enum MorKernelId {
   MK_CLASSIFY, MK_SCATTER, MK_SPLIT, MK_HEADS_COUNT, MK_HEADS_SCATTER, MK_CELLBOXES, MK_RHIST, MK_RSCAN, MK_RSCATTER,
-  MK_XFORM_PREV, MK_PAIRS, MK_SCORE_FAST, MK_SCORE_NEAR, MK_SCORE_BLOCK, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE,
+  MK_XFORM_PREV, MK_PAIRS, MK_SCORE_FAST, MK_SCORE_NB, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE,
   MK_OUT_COUNT, MK_OUT_SCATTER, MK_G2_COV_MID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_GRIDHASH, MK_GRIDFILL, MK_CG_SLAB, MK_CG_FINAL, MK_CLUSTERS, MK_COUNT
 };
 extern const char *const mor_kernel_names[MK_COUNT];
 
 struct MorLaunchTimer;   // engine-owned; records event pairs when enabled
 #define MOR_MAX_PIECES 13   // pieces of a push, at most (voxel ground variant: its grid stage is six of them)
-// piece ids: 7 split | 8 grid build (crop variant) or 10 … 15 (voxel ground variant) | 1 cell boxes | 16 slabs of the cell graph | 17 its merge | 3 clusters |
-//            4 transform of ca … first score tiers | 5 last score tiers | 6 thresholds + tracking
+// piece ids: 7 split | 8 grid build (crop variant) or 10 … 15 (voxel ground variant) | 1 cell boxes | 2 cell graph | 3 clusters |
+//            4 transform of ca … first score tier | 5 last score tiers + thresholds + tracking
 void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer *tm);
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);
 void mor_timer_begin(MorLaunchTimer *tm, int kernel_id, hipStream_t st);

@@ -151,7 +151,7 @@ static int configure(mor_batch *b) {
   double tol = (double)p.ec_distance_threshold; d.r2 = (float)(tol * tol);   // KdTreeFLANN::radiusSearch: (float)(radius·radius)
   d.min_cs = p.min_cluster_size; d.max_cs = p.max_cluster_size;
   d.pde_lb = p.pde_lb; d.pde_ub = p.pde_ub; d.pde_thr = (double)p.pde_distance_threshold; d.vol_thr = (double)p.volume_constraint;
-  d.opc_res = (double)p.opc_resolution; d.method = p.method_choice; d.opc_norm = p.opc_normalization_factor; d.vol_abs_int = p.volume_abs_int ? 1 : 0;
+  d.opc_res = (double)p.opc_resolution; d.method = p.method_choice; d.opc_norm = p.opc_normalization_factor; d.vol_abs_int = p.volume_abs_int ? 1 : 0; d.opc_anchor_half = p.opc_anchor ? 1 : 0;
   // grid: cell edge 0.57·r (cell diagonal 0.987·r < r ⇒ a cell is a clique; the 1.3 % margin dwarfs the
   // fp32 rounding of the cell map, ≤ 1e-3 cell at ≤ 2048 cells per axis)
   float cs = p.ec_distance_threshold * 0.57f;
@@ -289,8 +289,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   for (auto &pe : b->ev_piece) for (auto &ev : pe) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_back) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_track) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
-  if (p->ground_method == 0) { const int ids[9] = {7, 8, 1, 16, 17, 3, 4, 5, 6}; b->n_pieces = 9; for (int i = 0; i < 9; ++i) b->piece_id[i] = ids[i]; }
-  else { const int ids[MOR_MAX_PIECES] = {10, 11, 12, 13, 14, 15, 1, 16, 17, 3, 4, 5, 6}; b->n_pieces = MOR_MAX_PIECES; for (int i = 0; i < MOR_MAX_PIECES; ++i) b->piece_id[i] = ids[i]; }
+  if (p->ground_method == 0) { const int ids[7] = {7, 8, 1, 2, 3, 4, 5}; b->n_pieces = 7; for (int i = 0; i < 7; ++i) b->piece_id[i] = ids[i]; }
+  else { const int ids[11] = {10, 11, 12, 13, 14, 15, 1, 2, 3, 4, 5}; b->n_pieces = 11; for (int i = 0; i < 11; ++i) b->piece_id[i] = ids[i]; }
   b->n_lanes = (int)std::min<uint64_t>(4, b->pipe_depth);
   if (getenv("MOR_LANES")) b->n_lanes = std::max(1, std::min<int>((int)std::min<uint64_t>(8, b->pipe_depth), atoi(getenv("MOR_LANES"))));
   for (int i = 4; i < b->n_lanes; ++i) if (hipStreamCreateWithFlags(&b->extra[i - 4], hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
@@ -346,7 +346,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   }
   ok = ok && dalloc(b, b->d_moving, B * K + B) && dalloc(b, d.otile_cnt, B * T) && dalloc(b, b->d_outptrs, B);
   for (int i = 0; i < (int)b->n_slots; ++i) ok = ok && dalloc(b, d.slot_kc[i], B);
-  ok = ok && dalloc(b, d.err, B) && halloc(b, d.h_err, B) && halloc(b, d.h_log, B * (size_t)MOR_LOG_CAP);
+  ok = ok && dalloc(b, d.err, B) && halloc(b, d.h_err, B) && halloc(b, d.h_log, B * (size_t)MOR_LOG_CAP) && dalloc(b, d.tickets, B * 8);
+  if (ok) ok = hipMemset(d.tickets, 0, B * 8 * sizeof(int)) == hipSuccess;
   if (ok) { ok = hipMemset(d.err, 0, B * sizeof(unsigned)) == hipSuccess; for (int i = 0; i < (int)b->n_slots; ++i) ok = ok && hipMemset(d.slot_kc[i], 0, B * sizeof(int2)) == hipSuccess; }
   d.moving = b->d_moving;
   ok = ok && dalloc(b, d.tr, B) && dalloc(b, d.tr_corr, B * MOR_TR_NB * K) && dalloc(b, d.tr_res, B * (MOR_TR_NB + 1) * K) && dalloc(b, d.tr_lastdet, B * K);
@@ -362,7 +363,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   for (int c = 1; c < (int)b->pipe_depth; ++c) {
     b->dtemp[c] = d;
     MorDev &o = b->dtemp[c]; MorStreamArgs *dargs1 = nullptr;
-    ok = dalloc(b, dargs1, B) && dalloc(b, o.info, B) && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, 2 * B * N) && dalloc(b, o.gp_idx, B * N);
+    ok = dalloc(b, dargs1, B) && dalloc(b, o.tickets, B * 8) && hipMemset(o.tickets, 0, B * 8 * sizeof(int)) == hipSuccess && dalloc(b, o.info, B) && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, 2 * B * N) && dalloc(b, o.gp_idx, B * N);
     ok = ok && dalloc(b, o.sorted, B * N) && dalloc(b, o.ckey, B * N) && dalloc(b, o.cstart, B * (N + 1)) && dalloc(b, o.row_start, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, o.cmeta, 2 * B * N) && dalloc(b, o.crep, B * N);
     ok = ok && dalloc(b, o.pcid, B * N) && dalloc(b, o.ccid, B * N) && dalloc(b, o.det, B * K) && dalloc(b, o.zorg, B);
     ok = ok && dalloc(b, o.scell, B * N) && dalloc(b, o.csum, B * N) && dalloc(b, o.cgat, B * N) && dalloc(b, o.clist, B * N) && dalloc(b, o.cl_coff, B * (K + 1));
@@ -430,6 +431,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     const int p_fit = (int)((maxocc * 3ull / 2 + 818) / 819), p_par = (512 + B - 1) / B;   // a slab's LDS holds 1024 cells (own + look-ahead); two 512-thread workgroups per CU
     d.P = b->env_cg_p > 0 ? b->env_cg_p : std::max(p_fit, p_par);
     d.P = std::max(1, std::min(d.P, std::min(MOR_MAXP, std::max(1, d.g.ny / 2))));
+    d.cg_fused = (maxocc * 5ull / 4 <= MOR_CGS_FCAP && !getenv("MOR_CG_UNFUSED")) ? 1 : 0;   // (a stream beyond it runs the merge on global-memory arrays: correct, slow — hence the separate kernel when that is foreseeable)
     if (!getenv("MOR_GH_TIER")) d.gh_tier = maxocc * 5ull / 4 > 6144 ? (maxocc * 5ull / 4 > 12288 ? 2 : 1) : 0;   // table tier k_gridhash starts with (a stream whose table overflows moves up by itself)
   }
   d.cur = (int)(k % b->n_slots); d.prev = (int)((k + b->n_slots - 1) % b->n_slots); d.has_prev = k > 0; d.out_ptrs = nullptr; d.run_tracker = 0; d.frame_no = (int)k;

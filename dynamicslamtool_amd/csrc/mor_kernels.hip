@@ -28,7 +28,7 @@
 
 const char *const mor_kernel_names[MK_COUNT] = {   // in MorKernelId order: "k_" + name = the __global__ function
     "classify", "scatter", "split", "heads_count", "heads_scatter", "cellboxes", "rhist", "rscan", "rscatter",
-    "xform_prev", "cluster_pairs", "score_fast", "score_near", "score_block", "score_pde", "vox_clear", "vox_insert", "vox_probe",
+    "xform_prev", "cluster_pairs", "score_fast", "score_nb", "score_pde", "vox_clear", "vox_insert", "vox_probe",
     "out_count", "out_scatter", "g2_cov_mid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridfill", "cg_slab", "cg_final", "clusters"};
 
 #ifdef MOR_EXP_STAMPS
@@ -114,6 +114,31 @@ __device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, 
 __device__ __forceinline__ void mor_raise(const MorDev &d, int s, unsigned bit) { atomicOr(&d.info[s].flags, bit); atomicOr(&d.err[s], bit); }
 // last kernel of a push / filter: refresh the pinned mirror of the sticky error word (one thread per stream)
 __device__ __forceinline__ void mor_publish_err(const MorDev &d, int s) { d.h_err[s] = __hip_atomic_load(&d.err[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// "Last workgroup of the stream": every workgroup of a stream's share of a launch calls this once, after its last store; it returns true
+// in exactly one of them — the one that arrives last — and that one may then read what all the others wrote (plain stores and
+// atomics alike).  No workgroup waits for another, so no assumption about residency or dispatch order is needed.  Producer side
+// (MI355X_MICROARCH.md, valid forms): every storing wave drains its stores, workgroup barrier, one lane: agent-scope release fence,
+// drained (the inline asm keeps the compiler from dropping that wait), then the ticket; consumer side: agent-scope acquire by every
+// wave of the last workgroup before its first load.  The ticket word is reset by the last arriver for the next frame that uses this
+// copy of the per-frame arrays (tickets exist once per frame in flight).  l_flag: one int of LDS.
+__device__ __forceinline__ bool stream_last_block(int *ticket, int n_blocks, int *l_flag) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *l_flag = t == n_blocks - 1;
+    if (t == n_blocks - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const bool last = *l_flag != 0;
+  if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  __syncthreads();
+  return last;
+}
+enum { TK_TRACK = 0, TK_CGFINAL = 1, TK_PAIRS = 2, TK_COUNT = 8 };   // ticket words per stream
 
 // fromPCLPointCloud2 (:523): named float32 fields of a blob record → (x,y,z,intensity)
 __device__ __forceinline__ float ld_f32_bytes(const char *p) {   // a float32 field at any byte address
@@ -1300,9 +1325,41 @@ template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_body(const Mo
   }
   ST2(stwj, 9); ST2V(stwj, 14, n_own); ST2V(stwj, 15, n_loc);
 }
+template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDev &d, int s, int nocc, int *par, int *size, int *mn, int *cidr, int *l_misc, const int *l_sc, const int *l_se);
 // CAP: local cells (own + look-ahead) the workgroup holds in LDS (76 KB: two workgroups per CU).
+// With d.cg_fused the stream's LAST slab workgroup to finish (stream_last_block) goes on with the merge of the slab forests and everything
+// k_cg_final does, in the same LDS (three arrays of CGS_FCAP cells; streams with more cells: global-memory arrays) — one launch and one
+// queueing delay less per frame; the host falls back to the separate k_cg_final launch (147 KB of LDS: 12 288 cells) when the previous
+// frame's cell counts say a stream would not fit.
+#define CGS_SLAB_WORDS (12 * CGS_CAP + CGS_ROWCAP + 1 + CGS_LISTW + CGS_NW * CGS_QW)
+#define CGS_ARENA (CGS_SLAB_WORDS > 3 * MOR_CGS_FCAP ? CGS_SLAB_WORDS : 3 * MOR_CGS_FCAP)   // (the slab layout of the default build is 18 945 words)
+#define CGS_FCAP (CGS_ARENA / 3)
+template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d, int s, int j, int *l_arena, int *l_wcnt, int *l_n2p);
 template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {
   int s, j; map_block(d.B, d.P, s, j);
+  static_assert(CAP == CGS_CAP, "the LDS arena is laid out for CGS_CAP");
+  __shared__ int l_arena[CGS_ARENA], l_wcnt[CGS_NW], l_n2, l_last;
+  cg_slab_body<CAP>(d, s, j, l_arena, l_wcnt, &l_n2);
+  if (!d.cg_fused) return;
+  if (!stream_last_block(d.tickets + (size_t)s * TK_COUNT + TK_CGFINAL, d.P, &l_last)) return;
+  const int nocc = d.info[s].n_occ;
+  const size_t so = (size_t)s * d.Nmax;
+  __shared__ int l_misc[1 + CGS_T / 64], l_sc[MOR_MAXP + 1], l_se[MOR_MAXP + 1];
+  if (threadIdx.x <= d.P) { l_sc[threadIdx.x] = d.slab_c[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; l_se[threadIdx.x] = d.slab_e[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; }
+  if (nocc <= CGS_FCAP && !d.cg_force_global) {
+    int *l_par = l_arena, *l_a = l_arena + CGS_FCAP, *l_b = l_arena + 2 * CGS_FCAP;
+    for (int i = threadIdx.x; i < nocc; i += CGS_T) l_par[i] = i;
+    __syncthreads();
+    cgf_body<true, CGS_T>(d, s, nocc, l_par, l_a, l_b, l_a, l_misc, l_sc, l_se);
+  } else {
+    int *par = d.parent + so;
+    for (int i = threadIdx.x; i < nocc; i += CGS_T) cg_st<false>(par + i, i);
+    __threadfence();
+    __syncthreads();
+    cgf_body<false, CGS_T>(d, s, nocc, par, d.csize + so, d.compmin + so, d.cid_of_root + so, l_misc, l_sc, l_se);
+  }
+}
+template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d, int s, int j, int *l_arena, int *l_wcnt, int *l_n2p) {
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const size_t so = (size_t)s * d.Nmax;
   const int *sy = d.slab_y + (size_t)s * (MOR_MAXP + 1), *sc = d.slab_c + (size_t)s * (MOR_MAXP + 1), *se = d.slab_e + (size_t)s * (MOR_MAXP + 1);
@@ -1314,8 +1371,8 @@ template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) 
   // 12·CAP words of cell data: CAP cells with everything in LDS (key, parent, packed coordinates, sample point, box), or —
   // slabs of up to 4·CAP cells, e.g. a façade across a y-slice — key, parent and packed coordinates only: the enumeration
   // (A1) and the forest stay in LDS, the decisions about queued pairs (A2) fetch samples and boxes from global memory
-  __shared__ int l_cells[12 * CAP];
-  __shared__ int l_rows[CGS_ROWCAP + 1], l_list[CGS_LISTW], l_queue[CGS_NW * CGS_QW], l_wcnt[CGS_NW], l_n2;
+  int *l_cells = l_arena, *l_rows = l_cells + 12 * CAP, *l_list = l_rows + CGS_ROWCAP + 1, *l_queue = l_list + CGS_LISTW;
+  int &l_n2 = *l_n2p;
   int *ovf = d.cg_ovf + (size_t)(s * MOR_MAXP + j) * MOR_CGS_OVF * 2;   // [0, MOR_CGS_OVF): the waves' candidate lists, [MOR_CGS_OVF, 2·MOR_CGS_OVF): pairs for whole waves
   const int *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1) + r0;
   if (threadIdx.x == 0) l_n2 = 0;
@@ -1363,12 +1420,12 @@ template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) 
 #ifndef CGF_CAP
 #define CGF_CAP 12288
 #endif
-template <bool LDS> __device__ __forceinline__ void cgf_body(const MorDev &d, int s, int nocc, int *par, int *size, int *mn, int *cidr, int *l_misc, const int *l_sc, const int *l_se) {
+template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDev &d, int s, int nocc, int *par, int *size, int *mn, int *cidr, int *l_misc, const int *l_sc, const int *l_se) {
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1);
   const int lane = lane_id(), P = d.P;
   // ---- merge: (c, local root in its own slab) and, for the look-ahead cells of the previous slab, (c, local root there)
-  for (int c = threadIdx.x; c < nocc; c += CGF_T) {
+  for (int c = threadIdx.x; c < nocc; c += NT) {
     cg_unite<LDS>(par, c, d.lroot_a[so + c]);
     int j = 0;
     for (int k = 1; k < P; ++k) j += l_sc[k] <= c;            // slab owning c
@@ -1376,19 +1433,19 @@ template <bool LDS> __device__ __forceinline__ void cgf_body(const MorDev &d, in
   }
   __threadfence_block();
   __syncthreads();
-  for (int c = threadIdx.x; c < nocc; c += CGF_T) { const int r = cg_find<LDS>(par, c); if (r != c) cg_st<LDS>(par + c, r); }
+  for (int c = threadIdx.x; c < nocc; c += NT) { const int r = cg_find<LDS>(par, c); if (r != c) cg_st<LDS>(par + c, r); }
   __syncthreads();
   // ---- components: size (points) and smallest cloud index at the root
-  for (int c = threadIdx.x; c < nocc; c += CGF_T) { cg_st<LDS>(size + c, 0); cg_st<LDS>(mn + c, 0x7fffffff); }
+  for (int c = threadIdx.x; c < nocc; c += NT) { cg_st<LDS>(size + c, 0); cg_st<LDS>(mn + c, 0x7fffffff); }
   __threadfence_block();
   __syncthreads();
-  for (int c = threadIdx.x; c < nocc; c += CGF_T) { const int r = cg_ld<LDS>(par + c); atomicAdd(&size[r], start[c + 1] - start[c]); atomicMin(&mn[r], d.cmin[so + c]); }
+  for (int c = threadIdx.x; c < nocc; c += NT) { const int r = cg_ld<LDS>(par + c); atomicAdd(&size[r], start[c + 1] - start[c]); atomicMin(&mn[r], d.cmin[so + c]); }
   __threadfence_block();
   __syncthreads();
   // ---- kept components (:215-216) → scratch list; K
   if (threadIdx.x == 0) l_misc[0] = 0;
   __syncthreads();
-  for (int c = threadIdx.x; c < nocc; c += CGF_T) {
+  for (int c = threadIdx.x; c < nocc; c += NT) {
     const bool root = cg_ld<LDS>(par + c) == c;
     const long long n = root ? (long long)cg_ld<LDS>(size + c) : 0;
     if (root && n >= d.min_cs && n <= d.max_cs) {
@@ -1402,10 +1459,10 @@ template <bool LDS> __device__ __forceinline__ void cgf_body(const MorDev &d, in
   if (K > d.Kcap) { if (threadIdx.x == 0) mor_raise(d, s, 1u); K = d.Kcap; }
   __syncthreads();
   // ---- cluster order: size descending, ties by smaller first cloud index; rank by counting (cidr may alias `size`: sizes were copied to ksize)
-  for (int c = threadIdx.x; c < nocc; c += CGF_T) cg_st<LDS>(cidr + c, -1);
+  for (int c = threadIdx.x; c < nocc; c += NT) cg_st<LDS>(cidr + c, -1);
   __threadfence_block();
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += CGF_T) {
+  for (int k = threadIdx.x; k < K; k += NT) {
     const int my_sz = d.ksize[ko + k], my_rt = d.kroot[ko + k]; int rank = 0;
     for (int u = 0; u < K; ++u) { const int sz = d.ksize[ko + u], rt = d.kroot[ko + u]; rank += (sz > my_sz) || (sz == my_sz && rt < my_rt); }
     cg_st<LDS>(cidr + d.kcell[ko + k], rank);
@@ -1414,19 +1471,19 @@ template <bool LDS> __device__ __forceinline__ void cgf_body(const MorDev &d, in
   __threadfence_block();
   __syncthreads();
   // ---- per-cell cluster id (a cell is a clique ⇒ one cluster); kept in place of the parent from here on
-  for (int c = threadIdx.x; c < nocc; c += CGF_T) { const int r = cg_ld<LDS>(par + c), id = cg_ld<LDS>(cidr + r); d.ccid[so + c] = id; reinterpret_cast<int *>(&d.cmeta[2 * (so + c)])[3] = id; cg_st<LDS>(par + c, id); }
+  for (int c = threadIdx.x; c < nocc; c += NT) { const int r = cg_ld<LDS>(par + c), id = cg_ld<LDS>(cidr + r); d.ccid[so + c] = id; reinterpret_cast<int *>(&d.cmeta[2 * (so + c)])[3] = id; cg_st<LDS>(par + c, id); }
   __threadfence_block();
   __syncthreads();
   // ---- cluster offsets (exclusive scan of sizes in cluster order), C, clear detection_results (:250-254)
   int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1);
   int carry = 0;
-  for (int b = 0; b < K; b += CGF_T) {
+  for (int b = 0; b < K; b += NT) {
     const int k = b + threadIdx.x, v = k < K ? d.csz[ko + k] : 0;
     const int inc = wave_incl_scan(v);
     if (lane == 63) l_misc[1 + wave_id()] = inc;
     __syncthreads();
     int basew = 0, tot = 0;
-    for (int w = 0; w < CGF_T / 64; ++w) { const int xw = l_misc[1 + w]; if (w < wave_id()) basew += xw; tot += xw; }
+    for (int w = 0; w < NT / 64; ++w) { const int xw = l_misc[1 + w]; if (w < wave_id()) basew += xw; tot += xw; }
     __syncthreads();
     if (k < K) { off[k] = carry + basew + inc - v; d.det[ko + k] = 0; }
     carry += tot;
@@ -1436,13 +1493,13 @@ template <bool LDS> __device__ __forceinline__ void cgf_body(const MorDev &d, in
   int *coff = d.chunk_off[d.cur] + (size_t)s * (d.Kcap + 1);
   carry = 0;
   __syncthreads();
-  for (int b = 0; b < K; b += CGF_T) {
+  for (int b = 0; b < K; b += NT) {
     const int k = b + threadIdx.x, v = k < K ? (d.csz[ko + k] + MOR_CHUNK - 1) / MOR_CHUNK : 0;
     const int inc = wave_incl_scan(v);
     if (lane == 63) l_misc[1 + wave_id()] = inc;
     __syncthreads();
     int basew = 0, tot = 0;
-    for (int w = 0; w < CGF_T / 64; ++w) { const int xw = l_misc[1 + w]; if (w < wave_id()) basew += xw; tot += xw; }
+    for (int w = 0; w < NT / 64; ++w) { const int xw = l_misc[1 + w]; if (w < wave_id()) basew += xw; tot += xw; }
     __syncthreads();
     if (k < K) coff[k] = carry + basew + inc - v;
     carry += tot;
@@ -1455,21 +1512,21 @@ template <bool LDS> __device__ __forceinline__ void cgf_body(const MorDev &d, in
   //      on it; read-backs that promise the reference's order rebuild it from the labels.)
   int *ncell = size, *cur = mn;   // both free by now: [K] cells per cluster → first list entry; next free slot of the cluster's range
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += CGF_T) cg_st<LDS>(ncell + k, 0);
+  for (int k = threadIdx.x; k < K; k += NT) cg_st<LDS>(ncell + k, 0);
   __threadfence_block();
   __syncthreads();
-  for (int c = threadIdx.x; c < nocc; c += CGF_T) { const int k = cg_ld<LDS>(par + c); if (k >= 0) atomicAdd(&ncell[k], 1); }
+  for (int c = threadIdx.x; c < nocc; c += NT) { const int k = cg_ld<LDS>(par + c); if (k >= 0) atomicAdd(&ncell[k], 1); }
   __threadfence_block();
   __syncthreads();
   int *lcoff = d.cl_coff + (size_t)s * (d.Kcap + 1);
   carry = 0;
-  for (int b = 0; b < K; b += CGF_T) {
+  for (int b = 0; b < K; b += NT) {
     const int k = b + threadIdx.x, v = k < K ? cg_ld<LDS>(ncell + k) : 0;
     const int inc = wave_incl_scan(v);
     if (lane == 63) l_misc[1 + wave_id()] = inc;
     __syncthreads();
     int basew = 0, tot = 0;
-    for (int w = 0; w < CGF_T / 64; ++w) { const int xw = l_misc[1 + w]; if (w < wave_id()) basew += xw; tot += xw; }
+    for (int w = 0; w < NT / 64; ++w) { const int xw = l_misc[1 + w]; if (w < wave_id()) basew += xw; tot += xw; }
     __syncthreads();
     if (k < K) { const int e = carry + basew + inc - v; lcoff[k] = e; cg_st<LDS>(ncell + k, e); }
     carry += tot;
@@ -1478,13 +1535,13 @@ template <bool LDS> __device__ __forceinline__ void cgf_body(const MorDev &d, in
   __threadfence_block();
   __syncthreads();
   // the cell with the cluster's first point opens the range
-  for (int c = threadIdx.x; c < nocc; c += CGF_T) {
+  for (int c = threadIdx.x; c < nocc; c += NT) {
     const int k = cg_ld<LDS>(par + c);
     if (k >= 0 && d.cmin[so + c] == d.kroot[ko + d.krank_inv[ko + k]]) cg_st<LDS>(cur + k, off[k] + (start[c + 1] - start[c]));
   }
   __threadfence_block();
   __syncthreads();
-  for (int c = threadIdx.x; c < nocc; c += CGF_T) {
+  for (int c = threadIdx.x; c < nocc; c += NT) {
     const int k = cg_ld<LDS>(par + c);
     int4 g = make_int4(0, -1, -1, 0);
     if (k >= 0) {
@@ -1505,13 +1562,13 @@ __global__ __launch_bounds__(CGF_T) void k_cg_final(MorDev d) {
   if (nocc <= CGF_CAP && !d.cg_force_global) {          // forest, sizes (then cluster ids), minima: three LDS arrays
     for (int i = threadIdx.x; i < nocc; i += CGF_T) l_par[i] = i;
     __syncthreads();
-    cgf_body<true>(d, s, nocc, l_par, l_a, l_b, l_a, l_misc, l_sc, l_se);
+    cgf_body<true, CGF_T>(d, s, nocc, l_par, l_a, l_b, l_a, l_misc, l_sc, l_se);
   } else {
     int *par = d.parent + so;
     for (int i = threadIdx.x; i < nocc; i += CGF_T) cg_st<false>(par + i, i);
     __threadfence();
     __syncthreads();
-    cgf_body<false>(d, s, nocc, par, d.csize + so, d.compmin + so, d.cid_of_root + so, l_misc, l_sc, l_se);
+    cgf_body<false, CGF_T>(d, s, nocc, par, d.csize + so, d.compmin + so, d.cid_of_root + so, l_misc, l_sc, l_se);
   }
 }
 
@@ -2005,8 +2062,7 @@ __device__ __forceinline__ int wl_entry(const MorDev &d, int p0, int bx, int nq)
 // Tier 1a — one THREAD per query with E2 known (worklist front).  E1: only the ≤ 7 neighbour cells across the walls q
 // is close to can hold a point within √lb (the own cell was scanned by tier 1).  Three levels of loads: hash probes →
 // box records + ranges → points.  No such point ⇒ counted.
-__global__ __launch_bounds__(MOR_BT) void k_score_near(MorDev d) {
-  int s, bx; map_block(d.B, d.g_score, s, bx);   // a stream's workgroups share an XCD (its cell tables stay in that L2)
+__device__ __forceinline__ void score_near_body(const MorDev &d, int s, int bx) {
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, nq = (int)(unsigned)d.wl_nb[s];
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
@@ -2049,8 +2105,7 @@ __global__ __launch_bounds__(MOR_BT) void k_score_near(MorDev d) {
 // Tier 1b — one THREAD per query whose own cell holds no matched point (worklist back).  The 26 other cells of the
 // 3×3×3 block: hash probes → cluster ids → up to 8 matched cells (those that can hold a point within √lb first) →
 // box records + ranges → points.  E2 hit ⇒ E1 is decided by the same cells; no hit ⇒ the wider stencil is the wave tier's job.
-__global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
-  int s, bx; map_block(d.B, d.g_score, s, bx);
+__device__ __forceinline__ void score_block_body(const MorDev &d, int s, int bx) {
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, nq = (int)(d.wl_nb[s] >> 32);
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
@@ -2136,6 +2191,13 @@ __global__ __launch_bounds__(MOR_BT) void k_score_block(MorDev d) {
 #endif
   }
 }
+// Tiers 1a and 1b in ONE launch (both only need tier 1's worklists; as two launches in two pieces of the frame pipeline they cost a
+// launch boundary and a queueing delay each): workgroups [0, g_score) of a stream take the front of the worklist, [g_score, 2·g_score)
+// its back.  A stream's workgroups share an XCD (its cell tables stay in that L2).
+__global__ __launch_bounds__(MOR_BT) void k_score_nb(MorDev d) {
+  int s, bx; map_block(d.B, 2 * d.g_score, s, bx);
+  if (bx < d.g_score) score_near_body(d, s, bx); else score_block_body(d, s, bx - d.g_score);
+}
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
@@ -2157,8 +2219,7 @@ __device__ __forceinline__ float wave_scan_cell(const float4 *sp, int b0, int e0
   }
   return wave_min(local);
 }
-__global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
-  const int s = blockIdx.y + d.s0, bx = blockIdx.x;   // a stream's waves spread over all XCDs: the deferred queries are few and uneven across streams
+__device__ __forceinline__ void score_pde_body(const MorDev &d, int s, int bx) {   // a stream's waves spread over all XCDs: the deferred queries are few and uneven across streams
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, nq = d.wl2_n[s];
   const int wv = bx * (MOR_BT / 64) + wave_id(), nw = d.g_pde * (MOR_BT / 64), lane = lane_id();
@@ -2247,6 +2308,18 @@ __global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
   }
   if (lane == 0 && acc) atomicAdd(&d.pair_cnt[ko + acc_pr], acc);
 }
+template <int TRKN> __device__ __forceinline__ void track_push_body(const MorDev &d, int s);
+// The wave tier and, in the stream's LAST workgroup to finish (stream_last_block), the thresholds and the tracking step of the push
+// (P5 + T1): the per-pair counts are final when every workgroup of the stream has gone through its queries, and the tracking step is
+// one wave of work per stream — as a launch of its own it cost a launch boundary plus 40–60 µs of a lane for 64 waves.
+__global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
+  const int s = blockIdx.y + d.s0;
+  score_pde_body(d, s, blockIdx.x);
+  __shared__ int l_last;
+  if (!stream_last_block(d.tickets + (size_t)s * TK_COUNT + TK_TRACK, gridDim.x, &l_last)) return;
+  if (wave_id() != 0) return;   // one wave carries on (barriers of a workgroup count its surviving waves only)
+  track_push_body<128>(d, s);
+}
 
 // ------------------------------------------------------------------------------------ P4: method 2 (:309-334)
 // OctreePointCloudChangeDetector as a voxel hash set.  PCL grows its octree from the first inserted
@@ -2267,7 +2340,7 @@ __device__ __forceinline__ bool vox_key(const MorDev &d, int s, int pr, float4 p
   for (int a = 0; a < 3; ++a) {
     double mn = (double)p0c[a] - res / 2, mx = (double)p0c[a] + res / 2;
     double over = (2.0 * res - (mx - mn)) / 2.0;
-    if (over > eps) mn -= over;
+    if (over > eps && !d.opc_anchor_half) mn -= over;   // getKeyBitSize on the empty tree re-centres the first box (mor_params.opc_anchor = 1: it does not)
     kk[a] = (long long)floor(((double)pc[a] - mn) / res);
     ok = ok && kk[a] >= -32768 && kk[a] < 32768;
   }
@@ -2790,7 +2863,7 @@ __global__ __launch_bounds__(64) void k_g2_mark(MorDev d) {
 // One workgroup (one wave) per stream.  The state is tiny (a few dozen clusters, pairs and tracked centroids) but the
 // logic is sequential, so it is staged into LDS, run there (no chain of global-memory round trips) and written back.
 // Streams whose vectors exceed the LDS slots run the same code on the global arrays.
-#define TRK 384   // clusters / pairs per window slot held in LDS
+#define TRK 384   // clusters / pairs per window slot held in LDS (the tracking kernels; 128 where the step runs at the tail of k_score_pde)
 // The head of a stream's tracking state (counts, window sizes) lives in LDS while a tracking kernel works on it; the tracked
 // centroids themselves (up to MOR_TR_MAXT of them: 640 KB) stay in global memory: both kernels stream through them once per frame.
 // (The whole struct in LDS made these 64-thread workgroups wait for a CU with 117 KB of LDS free.)
@@ -2807,30 +2880,30 @@ __device__ __forceinline__ void tr_store_head(MorTrackDev &g, const MorTrackHead
   for (int i = lane; i < (int)(sizeof(MorTrackHead) / sizeof(int)); i += 64) gs[i] = ls[i];
 }
 // checkMovingClusterChain (:478-514) with recurseFindClusterChain (:415-453) and pushCentroid (:455-476)
-__global__ __launch_bounds__(64) void k_track_push(MorDev d) {
-  const int s = blockIdx.x + d.s0, lane = threadIdx.x;
+template <int TRKN> __device__ __forceinline__ void track_push_body(const MorDev &d, int s) {   // one wave (threads 0 … 63 of its workgroup)
+  const int lane = threadIdx.x;
   decide_body<64>(d, s);   // P5: thresholds, detection_results, host summary
   __threadfence_block();
   __syncthreads();
   const int K = d.info[s].K, np = d.has_prev ? (int)d.info[s].n_pairs : -1;
   const size_t ko = (size_t)s * d.Kcap;
   __shared__ MorTrackHead t;
-  __shared__ int2 l_corr[MOR_TR_NB][TRK];
-  __shared__ unsigned char l_res[MOR_TR_NB + 1][TRK];
-  __shared__ float4 l_cand[TRK], l_acc[TRK];   // centroids found at the end of a chain this frame; those of them already appended
-  __shared__ unsigned char l_cnear[TRK];
+  __shared__ int2 l_corr[MOR_TR_NB][TRKN];
+  __shared__ unsigned char l_res[MOR_TR_NB + 1][TRKN];
+  __shared__ float4 l_cand[TRKN], l_acc[TRKN];   // centroids found at the end of a chain this frame; those of them already appended
+  __shared__ unsigned char l_cnear[TRKN];
   MorTrackDev &gt = d.tr[s];
   tr_load_head(gt, t, lane);
   int2 *g_corr = d.tr_corr + (size_t)s * MOR_TR_NB * d.Kcap;
   unsigned char *g_res = d.tr_res + (size_t)s * (MOR_TR_NB + 1) * d.Kcap, *last = d.tr_lastdet + ko;
-  bool fits = K <= TRK && t.K_last <= TRK && np <= TRK;
-  for (int c = 0; c < t.n_corr; ++c) fits = fits && t.corr_n[c] <= TRK;
-  for (int r = 0; r < t.n_res; ++r) fits = fits && t.res_n[r] <= TRK;
+  bool fits = K <= TRKN && t.K_last <= TRKN && np <= TRKN;
+  for (int c = 0; c < t.n_corr; ++c) fits = fits && t.corr_n[c] <= TRKN;
+  for (int r = 0; r < t.n_res; ++r) fits = fits && t.res_n[r] <= TRKN;
   int2 *corr = g_corr; unsigned char *res = g_res; int stride = d.Kcap;
   if (fits) {   // stage the window
     for (int c = 0; c < t.n_corr; ++c) for (int j = lane; j < t.corr_n[c]; j += 64) l_corr[c][j] = g_corr[(size_t)c * d.Kcap + j];
     for (int r = 0; r < t.n_res; ++r) for (int k = lane; k < t.res_n[r]; k += 64) l_res[r][k] = g_res[(size_t)r * d.Kcap + k];
-    corr = &l_corr[0][0]; res = &l_res[0][0]; stride = TRK;
+    corr = &l_corr[0][0]; res = &l_res[0][0]; stride = TRKN;
     __syncthreads();
   }
   const bool chain = np >= 0 && t.has_cur;
@@ -2859,7 +2932,7 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
       int i = 0;
       while (i < n0) {
         int nc_ = 0;
-        for (; i < n0 && nc_ < TRK; ++i) {
+        for (; i < n0 && nc_ < TRKN; ++i) {
           if (!res[i]) continue;
           int track = i; bool ok = true;
           for (int col = 0; col < ncol && ok; ++col) {                                                                       // recurseFindClusterChain
@@ -2936,6 +3009,7 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
   tr_store_head(gt, t, lane);
   if (lane == 0) mor_publish_err(d, s);
 }
+__global__ __launch_bounds__(64) void k_track_push(MorDev d) { track_push_body<TRK>(d, blockIdx.x + d.s0); }   // frames without a method-1 wave tier (first frame, method 2)
 // filterCloud's loop over mo_vec (:630-671): nearest current centroid of every tracked one (squared fp32 distance, ties →
 // lowest index), its whole cluster queued for removal before any test, confidence bookkeeping.  Writes the per-cluster
 // removal flags and the ExtractIndices size-check flag the output kernels read.
@@ -3080,13 +3154,11 @@ static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLau
   }
 }
 
-static void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part = 0) {   // part: 0 both, 1 slabs, 2 merge
-  if (part == 2) goto final;
+static void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // slabs (+ merge in each stream's last slab workgroup), or slabs | merge
   mor_timer_begin(tm, MK_CG_SLAB, st);
   hipLaunchKernelGGL(k_cg_slab<CGS_CAP>, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
   mor_timer_end(tm, MK_CG_SLAB, st);
-  if (part == 1) return;
-final:
+  if (d.cg_fused) return;
   mor_timer_begin(tm, MK_CG_FINAL, st);
   hipLaunchKernelGGL(k_cg_final, dim3(d.B), dim3(CGF_T), 0, st, d);
   mor_timer_end(tm, MK_CG_FINAL, st);
@@ -3101,7 +3173,7 @@ static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
   MOR_LAUNCH(MK_PAIRS, k_cluster_pairs, gB, d);
   if (d.has_prev) {
     if (d.method == 1) {
-      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * d.g_fast), d); MOR_LAUNCH(MK_SCORE_NEAR, k_score_near, dim3(d.g_score * d.B), d); }
+      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * d.g_fast), d);
     } else if (d.method == 2) {
       MOR_LAUNCH(MK_VOX_CLEAR, k_vox_clear, dim3(64, d.B), d);
       MOR_LAUNCH(MK_VOX_INSERT, k_vox_insert, gT, d);
@@ -3112,14 +3184,12 @@ static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
 
 static void mor_launch_scores2(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   if (d.has_prev && d.method == 1 && d.pde_ub > 0.f && d.pde_ub > d.pde_lb) {
-    MOR_LAUNCH(MK_SCORE_BLOCK, k_score_block, dim3(d.g_score * d.B), d);
-    MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(d.g_pde, d.B), d);
+    MOR_LAUNCH(MK_SCORE_NB, k_score_nb, dim3(2 * d.g_score * d.B), d);
+    MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(d.g_pde, d.B), d);   // … and the thresholds + tracking step, in each stream's last workgroup
+    return;
   }
-}
-static void mor_launch_decide(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  const dim3 gB(d.B);
   mor_timer_begin(tm, MK_TRACK_PUSH, st);
-  hipLaunchKernelGGL(k_track_push, gB, dim3(64), 0, st, d);
+  hipLaunchKernelGGL(k_track_push, dim3(d.B), dim3(64), 0, st, d);
   mor_timer_end(tm, MK_TRACK_PUSH, st);
 }
 
@@ -3132,9 +3202,7 @@ void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer
     case 3: mor_launch_clusters(d, st, tm); break;
     case 4: mor_launch_pairs(d, st, tm); break;
     case 5: mor_launch_scores2(d, st, tm); break;
-    case 6: mor_launch_decide(d, st, tm); break;
-    case 16: mor_launch_cellgraph(d, st, tm, 1); break;   // the cell graph in two: slabs | merge
-    case 17: mor_launch_cellgraph(d, st, tm, 2); break;
+    case 2: mor_launch_cellgraph(d, st, tm); break;
     case 7: mor_launch_split_and_grid(d, st, tm, 1); break;   // the grid piece of the crop variant in two: split | grid build
     case 8: mor_launch_split_and_grid(d, st, tm, 2); break;
     case 10: case 11: case 12: case 13: case 14: case 15: mor_launch_grid_sub(d, piece - 10, st, tm); break;   // the grid piece of the voxel ground variant in six

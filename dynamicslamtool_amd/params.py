@@ -19,6 +19,7 @@ class MorParams(C.Structure):
         ("ec_distance_threshold", C.c_float), ("pde_distance_threshold", C.c_float),
         ("method_choice", C.c_int32), ("opc_normalization_factor", C.c_int32),
         ("ground_method", C.c_int32), ("opc_resolution", C.c_float), ("volume_abs_int", C.c_int32),
+        ("opc_anchor", C.c_int32),
     ]
 
     def as_dict(self):
@@ -63,6 +64,8 @@ def parse_config_text(text):
             p.ground_method = int(val)
         elif key == "volume_abs_int":  # extension key: 1 = the unqualified abs() of :277 truncates to int first (old libstdc++)
             p.volume_abs_int = int(val)
+        elif key == "opc_anchor":  # extension key: method-2 voxel lattice anchored at p0 − res (0, default) or p0 − res/2 (1)
+            p.opc_anchor = int(val)
         elif key in _STRING_KEYS:
             strings[key] = val
         else:

@@ -47,6 +47,10 @@ typedef struct mor_params {
   float opc_resolution;             /* 0.1f — literal at the call site :575 */
   int32_t volume_abs_int;           /* 0 (default): the unqualified abs(volp-volc) of :277 is fabs, as with libstdc++ >= 6; 1: it is C's int abs(int) — the
                                        difference is truncated towards zero first (what an older libstdc++ can pick); DESIGN.md §2 */
+  int32_t opc_anchor;               /* voxel lattice of method 2 (OctreePointCloudChangeDetector, :319-329), anchored at the first point p0 of the previous
+                                       cluster: 0 (default) = p0 - res (adoptBoundingBoxToPoint sets p0 +- res/2, getKeyBitSize then widens the empty
+                                       tree to two voxels per axis and re-centres it); 1 = p0 - res/2 (no re-centring: SURVEY.md Appendix A's reading).
+                                       Neither can be checked against a PCL build here; DESIGN.md §2 */
 } mor_params;
 
 /* One incoming cloud: a pcl::PCLPointCloud2-style blob (what fromPCLPointCloud2 consumes at :523).

@@ -455,7 +455,7 @@ static double score_point_distance(const opoint *c1, int n1, const opoint *c2, i
 typedef struct { long long k[3]; } vkey;
 static int vkey_cmp(const void *a, const void *b) { const vkey *x = (const vkey *)a, *y = (const vkey *)b;
   for (int d = 0; d < 3; ++d) if (x->k[d] != y->k[d]) return x->k[d] < y->k[d] ? -1 : 1; return 0; }
-typedef struct { double mn[3], mx[3]; long long shift[3]; int depth; int defined; double res; } octbox;
+typedef struct { double mn[3], mx[3]; long long shift[3]; int depth; int defined; double res; int anchor_half; } octbox;
 static void oct_adopt(octbox *b, const float *pt) {
   const double eps = (double)FLT_EPSILON;
   for (;;) {
@@ -464,6 +464,8 @@ static void oct_adopt(octbox *b, const float *pt) {
     if (!any) return;
     if (!b->defined) {
       for (int d = 0; d < 3; ++d) { b->mn[d] = (double)pt[d] - b->res / 2; b->mx[d] = (double)pt[d] + b->res / 2; }
+      /* opc_anchor = 1 (SURVEY App. A's reading): the first box stays p0 ± res/2 — one voxel, depth 0, no re-centring */
+      if (b->anchor_half) { b->depth = 0; b->defined = 1; continue; }
       /* getKeyBitSize() on an empty tree */
       unsigned mk = 2;
       for (int d = 0; d < 3; ++d) { unsigned k = (unsigned)ceil((b->mx[d] - b->mn[d] - eps) / b->res); if (k > mk) mk = k; }
@@ -479,8 +481,8 @@ static void oct_adopt(octbox *b, const float *pt) {
     for (int d = 0; d < 3; ++d) b->mx[d] = b->mn[d] + side;
   }
 }
-static double score_octree_change(const opoint *c1, int n1, const opoint *c2, int n2, float resolution) {
-  octbox b; memset(&b, 0, sizeof b); b.res = (double)resolution;
+static double score_octree_change(const opoint *c1, int n1, const opoint *c2, int n2, float resolution, int anchor_half) {
+  octbox b; memset(&b, 0, sizeof b); b.res = (double)resolution; b.anchor_half = anchor_half;
   vkey *k1 = (vkey *)malloc((n1 ? n1 : 1) * sizeof(vkey));
   for (int i = 0; i < n1; ++i) { oct_adopt(&b, &c1[i].x);
     for (int d = 0; d < 3; ++d) k1[i].k[d] = (long long)(unsigned)(((double)(&c1[i].x)[d] - b.mn[d]) / b.res) - b.shift[d]; }
@@ -561,7 +563,7 @@ int oracle_push(oracle_ctx *c, const void *data, uint64_t n_points, uint32_t poi
     for (int j = 0; j < mp.n; ++j) {
       int q = mp.c[j].query, mt = mp.c[j].match; int n1 = ca->cl_off[q + 1] - ca->cl_off[q], n2 = cb->cl_off[mt + 1] - cb->cl_off[mt];
       if (c->p.method_choice == 1) score[j] = score_point_distance(ca->clusters[q], n1, cb->clusters[mt], n2, c->p.pde_lb, c->p.pde_ub); /* :571 */
-      else if (c->p.method_choice == 2) score[j] = score_octree_change(ca->clusters[q], n1, cb->clusters[mt], n2, c->p.opc_resolution); /* :575 */
+      else if (c->p.method_choice == 2) score[j] = score_octree_change(ca->clusters[q], n1, cb->clusters[mt], n2, c->p.opc_resolution, c->p.opc_anchor != 0); /* :575 */
       else score[j] = 0; /* reference: param_vec stays empty ⇒ UB; defined as 0 */
       double threshold = 0;
       if (c->p.method_choice == 1) threshold = (double)c->p.pde_distance_threshold; /* :586 */

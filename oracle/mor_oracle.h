@@ -43,6 +43,7 @@ typedef struct oracle_params {
   int32_t ground_method;            /* 0 = crop (:526, active), 1 = voxel covariance (:527, intended) */
   float opc_resolution;             /* 0.1f, hard-coded at the call site :575 */
   int32_t volume_abs_int;           /* 0: abs(volp-volc) at :277 is fabs (libstdc++ >= 6); 1: it is C's int abs(int) (truncates first) */
+  int32_t opc_anchor;               /* method-2 voxel lattice: 0 = anchored at p0 - res (getKeyBitSize re-centres the first box), 1 = at p0 - res/2 */
 } oracle_params;
 
 typedef struct oracle_ctx oracle_ctx;

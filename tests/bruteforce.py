@@ -190,7 +190,7 @@ def score_method1(c1, c2, p):
     return cnt / float((len(c1) + len(c2)) // 2)
 
 
-def score_method2(c1, c2, res):
+def score_method2(c1, c2, res, anchor_half=0):
     """:309-334 — voxel lattice anchored at c1[0] − res (OctreePointCloud: first point ± res/2, then
     getKeyBitSize re-centres the 2-voxel root), keys by floor in fp64; count c2 points in voxels
     without c1 points."""
@@ -199,7 +199,7 @@ def score_method2(c1, c2, res):
     mn = p0 - res / 2
     mx = p0 + res / 2
     over = (2 * res - (mx - mn)) / 2.0
-    anchor = np.where(over > np.float64(np.finfo(np.float32).eps), mn - over, mn)
+    anchor = mn if anchor_half else np.where(over > np.float64(np.finfo(np.float32).eps), mn - over, mn)   # opc_anchor = 1: the first box is not re-centred
     k1 = np.floor((c1.astype(np.float64) - anchor) / res).astype(np.int64)
     k2 = np.floor((c2.astype(np.float64) - anchor) / res).astype(np.int64)
     s1 = set(map(tuple, k1))
@@ -238,7 +238,7 @@ class BruteMOR:
                     s = score_method1(c1, c2, p)
                     thr = np.float64(f32(p.pde_distance_threshold))
                 else:
-                    s = score_method2(c1, c2, p.opc_resolution)
+                    s = score_method2(c1, c2, p.opc_resolution, getattr(p, "opc_anchor", 0))
                     thr = float((len(c1) + len(c2)) // p.opc_normalization_factor)
                 cb["det"][mt] = s > thr
                 self.last_score.append(s)

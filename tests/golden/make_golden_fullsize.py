@@ -17,6 +17,9 @@ CASES = [   # name, sensor, method, ground_method, seeds, frames
     ("hdl64_m2", "hdl64", 2, 0, [2003, 2033], 4),
     ("hdl64_m1_voxel_ground", "hdl64", 1, 1, [2002], 3),
     ("os128_m1", "os128", 1, 0, [3001], 3),
+    ("os128_m2", "os128", 2, 0, [3002], 3),
+    ("hdl64_urban_m1", "hdl64_urban", 1, 0, [6000], 3),
+    ("hdl64_urban_m2", "hdl64_urban", 2, 0, [6001], 3),
 ]
 
 
@@ -57,9 +60,10 @@ def main():
                 res["%s/%d/%d" % (name, seed, f)] = d
             o.close()
     path = os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")
-    provenance = ("digests of oracle/mor_oracle.c outputs (this script); the cases hdl64_m1/2000, hdl64_m1/2005, hdl64_m2/2003 and os128_m1/3001 are "
-                  "reproduced without the oracle by the independent full-size implementation tests/independent_fullsize.py "
-                  "(tests/test_oracle_independent_fullsize.py); no output of the real reference (PCL/ROS, unbuildable here) backs any of them")
+    provenance = ("digests of oracle/mor_oracle.c outputs (this script); the cases hdl64_m1/2000, hdl64_m1/2005, hdl64_m2/2003, hdl64_m1_voxel_ground/2002, "
+                  "os128_m1/3001, os128_m2/3002, hdl64_urban_m1/6000 and hdl64_urban_m2/6001 are reproduced without the oracle by the independent "
+                  "full-size implementation tests/independent_fullsize.py (tests/test_oracle_independent_fullsize.py); no output of the real "
+                  "reference (PCL/ROS, unbuildable here) backs any of them")
     json.dump({"cases": [list(c[:4]) + [c[4], c[5]] for c in CASES], "digests": res, "provenance": provenance}, open(path, "w"), indent=0, sort_keys=True)
     print("wrote", path, len(res), "frames")
 

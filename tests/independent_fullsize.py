@@ -71,21 +71,84 @@ def score_method1(c1, c2, p):
     return cnt / float((len(c1) + len(c2)) // 2)
 
 
+def _seq_sum32(v):
+    """fp32 sum of v in storage order, every add rounded (np.cumsum is a sequential recurrence in the array's dtype)."""
+    return np.cumsum(v, dtype=f32)[-1]
+
+
+def ground_voxel(xyzi, p):
+    """:90-200 with the deterministic definitions of DESIGN.md §4.6 at full size: the neighbours of a voxel centroid come from a
+    cKDTree ball query with a widened radius and are re-tested with the exact fp32 predicate; every ordered fp32 sum is a cumulative
+    sum in float32.  Nothing shared with tests/bruteforce.py::ground_voxel but the definitions."""
+    x, y, z = xyzi[:, 0], xyzi[:, 1], xyzi[:, 2]
+    X, Y = f32(p.trim_x), f32(p.trim_y)
+    fin = np.isfinite(x) & np.isfinite(y) & np.isfinite(z)
+    raw = xyzi[fin & (x >= -X) & (x <= X) & (y >= -Y) & (y <= Y)]
+    T = len(raw)
+    is_ground = np.zeros(T, bool)
+    if T:
+        leaf = f32(p.gp_leaf)
+        inv = f32(1.0) / leaf
+        pts = np.ascontiguousarray(raw[:, :3], f32)
+        ijk = np.floor(pts * inv).astype(np.int64)
+        order = np.lexsort((np.arange(T), ijk[:, 0], ijk[:, 1], ijk[:, 2]))   # voxels in (z, y, x) order, ascending point index inside a voxel
+        keys = ijk[order]
+        starts = np.flatnonzero(np.r_[True, np.any(keys[1:] != keys[:-1], axis=1)])
+        ends = np.r_[starts[1:], T]
+        cents = np.empty((len(starts), 3), f32)
+        for v, (s0, e0) in enumerate(zip(starts, ends)):
+            q = pts[order[s0:e0]]
+            n = f32(e0 - s0)
+            cents[v] = (_seq_sum32(q[:, 0]) / n, _seq_sum32(q[:, 1]) / n, _seq_sum32(q[:, 2]) / n)
+        rr = np.float64(leaf)
+        r2 = f32(rr * rr)
+        tree = cKDTree(pts.astype(np.float64))
+        cand = tree.query_ball_point(cents.astype(np.float64), rr * 1.001, return_sorted=True)
+        accepted = []
+        for v, nb in enumerate(cand):
+            nb = np.asarray(nb, np.int64)
+            if len(nb) <= 3:
+                continue
+            c = cents[v]
+            d = _sqdist_rows(np.broadcast_to(c, (len(nb), 3)), pts[nb])
+            keep = d < r2
+            nb, d = nb[keep], d[keep]
+            if len(nb) <= 3:
+                continue
+            o = np.lexsort((nb, d))   # (d², index), as radiusSearch returns them
+            q = pts[nb[o]]
+            fn = f32(len(nb))
+            cx, cy, cz = _seq_sum32(q[:, 0]) / fn, _seq_sum32(q[:, 1]) / fn, _seq_sum32(q[:, 2]) / fn
+            dx, dy, dz = q[:, 0] - cx, q[:, 1] - cy, q[:, 2] - cz
+            c12, c22, c02 = _seq_sum32(dy * dz), _seq_sum32(dz * dz), _seq_sum32(dz * dx)
+            if abs(np.float64(c02)) < 0.001 and abs(np.float64(c12)) < 0.001 and abs(np.float64(c22)) < 0.001:
+                accepted.append((int(f32(c[2] * f32(10))), nb))
+        if accepted:
+            cnt = {}
+            for b, _ in accepted:
+                cnt[b] = cnt.get(b, 0) + 1
+            best = min(cnt, key=lambda b: (-cnt[b], b))
+            for b, nb in accepted:
+                if b == best:
+                    is_ground[nb] = True
+    return raw, np.flatnonzero(~is_ground), np.flatnonzero(is_ground)
+
+
 class Counts(types.SimpleNamespace):
     pass
 
 
 class IndependentMOR(bf.BruteMOR):
-    """BruteMOR with the two O(n²) pieces replaced by the tree-pruned exact versions above, and the read-backs of
+    """BruteMOR with the O(n²) pieces (clustering, method-1 scores, the voxel-covariance ground removal) replaced by the tree-pruned exact versions above, and the read-backs of
     oracle.Oracle so that the same digest / comparison code applies."""
 
     def push(self, xyzi, pose):
-        saved = bf.clusters, bf.score_method1
-        bf.clusters, bf.score_method1 = clusters, score_method1
+        saved = bf.clusters, bf.score_method1, bf.ground_voxel
+        bf.clusters, bf.score_method1, bf.ground_voxel = clusters, score_method1, ground_voxel
         try:
             super().push(xyzi, pose)
         finally:
-            bf.clusters, bf.score_method1 = saved
+            bf.clusters, bf.score_method1, bf.ground_voxel = saved
         self._n_in = len(np.asarray(xyzi).reshape(-1, 4))
 
     def counts(self):

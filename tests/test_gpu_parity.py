@@ -383,10 +383,10 @@ print("OK")
 
 
 @pytest.mark.parametrize("env", [{"MOR_GH_TIER": "1"}, {"MOR_GH_TIER": "2", "MOR_CG_GLOBAL": "1"}, {"MOR_LANES": "2"}, {"MOR_PIPE_DEPTH": "8", "MOR_LANES": "6"}, {"MOR_PIPE_DEPTH": "1"},
-                                 {"MOR_PIPE_DEPTH": "2", "MOR_LANES": "1"}])
+                                 {"MOR_PIPE_DEPTH": "2", "MOR_LANES": "1"}, {"MOR_CG_UNFUSED": "1"}])
 def test_kernel_variants(env):
     """The tiers behind the default paths must give the same results: k_gridhash with its big LDS table / its global-memory table,
-    slab and merge forests in global memory, other numbers of lanes / pipeline depths.  The tier is chosen when the batch is created,
+    slab and merge forests in global memory, other numbers of lanes / pipeline depths, the merge of the slab forests as its own launch.  The tier is chosen when the batch is created,
     from the environment: child process (synchronous frames against the oracle, then an asynchronous run without waits against a
     synchronous one)."""
     import subprocess, sys
@@ -1013,3 +1013,26 @@ def test_soak_500_asynchronous_steps_equal_synchronous_use():
     assert res[0][0] == res[1][0], "frame summaries differ"
     assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
     assert max(L["n_mo_filter"] for L in res[0][0][-1]) > 50 and all(L["flags"] == 0 for fl in res[0][0] for L in fl)
+
+
+def test_octree_anchor_both_readings():
+    """mor_params.opc_anchor selects where method 2's voxel lattice hangs (0: p0 − res, default; 1: p0 − res/2, SURVEY App. A's reading):
+    HIP and oracle agree on both, scores included, and the readings are observably different."""
+    diffs = 0
+    for seed in (1, 2, 4):
+        frames = small_stream(seed, n_frames=6)
+        got = {}
+        for flag in (0, 1):
+            p = scene_params(method_choice=2)
+            p.opc_anchor = flag
+            st = _run_lockstep(p, [frames])
+            o = Oracle(p)
+            acc = []
+            for pts, pose in frames:
+                o.push(pts, pose)
+                acc += list(o.correspondences()[3])
+                o.filter()
+            got[flag] = acc
+            assert st["corr"] > 0
+        diffs += got[0] != got[1]
+    assert diffs > 0

@@ -160,3 +160,41 @@ def test_volume_gate_integer_abs_reading():
         assert corr[1] >= corr[0]   # the truncating reading only ever lets more pairs through
         differ += corr[1] > corr[0]
     assert differ > 0
+
+
+def test_octree_anchor_both_readings():
+    """Method 2's voxel lattice hangs on the first point p0 of the previous cluster.  Default (opc_anchor = 0): p0 − res — PCL's
+    adoptBoundingBoxToPoint sets p0 ± res/2 and getKeyBitSize() re-centres the empty two-voxel root (oracle header).
+    opc_anchor = 1: p0 − res/2, the reading of SURVEY.md Appendix A (no re-centring).  Neither can be checked against a PCL build
+    here, so both are implemented; oracle and brute force agree on each, and the two readings give different scores."""
+    differ = 0
+    for seed in (1, 2, 4):
+        scores = {}
+        for flag in (0, 1):
+            p = scene_params(method_choice=2)
+            p.opc_anchor = flag
+            o, b = Oracle(p, 4, 3), BruteMOR(p, 4, 3)
+            acc = []
+            for f, (pts, pose) in enumerate(small_stream(seed, n_frames=6)):
+                o.push(pts, pose)
+                b.push(pts, pose)
+                _compare_frame(o, b, "opc_anchor %d seed %d frame %d" % (flag, seed, f))
+                assert np.array_equal(o.filter().view(np.uint32), b.filter().view(np.uint32))
+                acc += list(o.correspondences()[3])
+            scores[flag] = acc
+        differ += scores[0] != scores[1]
+    assert differ > 0
+
+
+def test_reference_config_file_parses_to_the_default_profile():
+    """tests/golden/MOR_config_reference.txt = the reference's config/MOR_config.txt byte for byte (39 lines: comment blocks, blank
+    lines, 24 keys): the parser must skip what setVariables skips (:709-733) and give the values the stripped copy in params.py holds."""
+    import os
+    from dynamicslamtool_amd.params import parse_config, ref_default_params
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "MOR_config_reference.txt")
+    text = open(path).read()
+    assert len(text.splitlines()) == 39 and text.count("#") == 8 and "\n\n" in text
+    p, strings = parse_config(path)
+    assert p.as_dict() == ref_default_params().as_dict()
+    assert strings == {"output_topic": "/output", "debug_topic": "/check", "marker_topic": "/bbox", "input_pointcloud_topic": "/velodyne_points",
+                       "input_odometry_topic": "/camera/odom/sample", "output_fid": "/filtered", "debug_fid": "/debug"}

@@ -13,7 +13,8 @@ from independent_fullsize import IndependentMOR
 from oracle.oracle import Oracle
 from test_golden import _fullsize
 
-CASES = [("hdl64_m1", 2000, 3), ("hdl64_m1", 2005, 4), ("hdl64_m2", 2003, 4), ("os128_m1", 3001, 3)]
+CASES = [("hdl64_m1", 2000, 3), ("hdl64_m1", 2005, 4), ("hdl64_m2", 2003, 4), ("os128_m1", 3001, 3),
+         ("hdl64_m1_voxel_ground", 2002, 3), ("os128_m2", 3002, 3), ("hdl64_urban_m1", 6000, 3), ("hdl64_urban_m2", 6001, 3)]
 
 
 def _compare(o, b, tag):
@@ -53,7 +54,7 @@ def test_oracle_matches_independent_fullsize(name, seed, frames):
         assert out_o.shape == out_b.shape and np.array_equal(out_o.view(np.uint32), out_b.view(np.uint32)), tag
         # the committed digest of this frame, reproduced WITHOUT the oracle
         assert mod.digest(b, out_b) == fx["digests"]["%s/%d/%d" % (name, seed, f)], tag
-    assert o.counts().n_clusters > 10 and o.counts().n_corr > 5 and moving > 0
+    assert o.counts().n_clusters > 10 and o.counts().n_corr > 5 and (moving > 0 or gm == 1)   # (the voxel-ground case's three frames hold no mover yet)
     o.close()
 
 
