@@ -221,8 +221,8 @@ extern const char *const mor_kernel_names[MK_COUNT];
 struct MorLaunchTimer;   // engine-owned; records event pairs when enabled
 #define MOR_MAX_PIECES 13   // pieces of a push, at most (voxel ground variant: its grid stage is six of them)
 // piece ids: 7 split | 8 grid build (crop variant) or 10 … 15 (voxel ground variant) | 1 cell boxes | 2 cell graph | 3 clusters |
-//            4 transform of ca … first score tier | 5 last score tiers + thresholds + tracking
+//            4 transform of ca … thread tiers of the scores | 5 wave tier | 6 thresholds + tracking
 void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer *tm);
-void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);
+void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part);
 void mor_timer_begin(MorLaunchTimer *tm, int kernel_id, hipStream_t st);
 void mor_timer_end(MorLaunchTimer *tm, int kernel_id, hipStream_t st);

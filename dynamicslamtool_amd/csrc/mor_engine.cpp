@@ -73,19 +73,24 @@ struct mor_batch {
   mor_params p; int n_bad, n_good, B, device; uint64_t Nmax;
   hipStream_t st = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // st: copies of read-backs; ev: push/filter timing
   // Four in-order HIP streams ("lanes") form a software pipeline over frames (see mor_push_batch): frame k runs ALL its
-  // pieces, then its filterCloud, on stream k % n_lanes, so every stream carries the same work whatever the pieces cost;
-  // piece p of frame k waits for piece p of frame k−1 (scratch arrays of a piece are never used by two frames at once, the
-  // pair stage of frame k sees frame k−1's clusters), and the tracking steps (last piece, filterCloud) wait for the previous
-  // tracking step.  (Rounds 1–2 also had a stage schedule — pieces on fixed streams: its tail stream carried 0.44 ms of
-  // kernels per 0.45 ms period while the cell-graph stream idled half the time; removed.)
+  // pieces, then its filterCloud, on stream k % n_lanes, so every stream carries the same work whatever the pieces cost.
+  // Every array a frame writes exists once per frame in flight, so the only orderings between frames are the true ones:
+  // the pair stage of frame k follows the clusters of frame k − 1 (ca), the tracking steps (last piece, filterCloud's loop)
+  // follow the previous tracking step, the output kernels of filterCloud run in frame order, and frame k waits for frame
+  // k − depth to have left its copy of the arrays.  (Round 2 also ordered piece p of frame k behind piece p of frame k − 1 to
+  // protect shared scratch arrays: sixteen more event records and waits per frame — each a packet the command processor
+  // handles between two kernels of a lane.  Rounds 1–2 also had a stage schedule, pieces on fixed streams; removed.)
   hipStream_t sf = nullptr, sc = nullptr, sm = nullptr, sb = nullptr;   // lanes 1 … 4
-  hipEvent_t ev_piece[MOR_MAX_PIECES][MOR_MAX_SLOTS] = {}, ev_back[MOR_MAX_SLOTS] = {};
+  hipEvent_t ev_split[MOR_MAX_SLOTS] = {}, ev_clusters[MOR_MAX_SLOTS] = {}, ev_pairs[MOR_MAX_SLOTS] = {}, ev_tpush[MOR_MAX_SLOTS] = {}, ev_back[MOR_MAX_SLOTS] = {};
+  hipEvent_t *last_split = nullptr;             // split of the latest push that staged host-resident blobs (the staging area exists once)
   int n_pieces = 0, piece_id[MOR_MAX_PIECES] = {};   // the pieces of a push in order (ids: mor_device.h)
   int n_lanes = 4;
   hipStream_t extra[4] = {nullptr, nullptr, nullptr, nullptr};   // lanes 5 … 8 (MOR_LANES; measured: more than four busy streams are served worse)
   hipStream_t lane_stream(uint64_t k) const { const int i = (int)(k % (uint64_t)n_lanes); return i == 0 ? sf : i == 1 ? sc : i == 2 ? sm : i == 3 ? sb : extra[i - 4]; }
-  hipEvent_t ev_track[MOR_MAX_SLOTS] = {};      // recorded after the tracking step of a push / a filterCloud
+  hipEvent_t ev_track[MOR_MAX_SLOTS] = {};      // recorded after the tracking step of a push / the tracking loop of a filterCloud
   hipEvent_t *last_track = nullptr;             // the latest of them
+  hipEvent_t ev_out[MOR_MAX_SLOTS] = {};        // recorded after the output kernels of a filterCloud (they run in frame order: pinned size mirrors, tile counts)
+  hipEvent_t *last_out = nullptr;
   hipStream_t last_filter_stream = nullptr;
   MorDev dtemp[MOR_MAX_DEPTH];               // descriptor templates, frame k uses dtemp[k % depth] (static part + pointers)
   MorDev d;                                  // descriptor of the latest pushed frame
@@ -96,7 +101,6 @@ struct mor_batch {
   uint64_t pipe_depth = 4, n_slots = 5;       // frames in flight (= copies of the per-frame arrays); cluster-array slots = depth + 1
   int env_cg_p = 0;         // tuning knob from the environment (MOR_CG_P), read once at creation
   bool async = false, pending = false;   // async: push/filter only enqueue; pending: work enqueued since the last wait
-  unsigned char *d_moving = nullptr;
   float4 **h_outptrs = nullptr, **d_outptrs = nullptr;
   unsigned char *d_stage = nullptr; size_t stage_stride = 0;   // staging for host-resident input blobs
   std::vector<PoseTf> prev_pose;
@@ -180,7 +184,7 @@ static int configure(mor_batch *b) {
     double lf = (double)p.gp_leaf; d.leaf_r2 = (float)(lf * lf);   // radiusSearch(…, gp_leaf): (float)(radius·radius)
   }
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
-  d.two_pass_split = getenv("MOR_SINGLE_PASS_SPLIT") ? 0 : 1;   // count pass + scatter pass (the second read comes from the Infinity Cache); the single-pass split with decoupled look-back measured 5 % slower in the pipeline
+  d.two_pass_split = (getenv("MOR_SINGLE_PASS_SPLIT") && atoi(getenv("MOR_SINGLE_PASS_SPLIT")) != 0) ? 0 : 1;   // count pass + scatter pass (the second read comes from the Infinity Cache) | the single-read split
   d.xcd_map = getenv("MOR_NO_XCD_MAP") ? 0 : 1;
   d.g_fast = 8; d.g_score = 64; d.g_pde = 256; d.g_box = 32;
   if (const char *tn = getenv("MOR_TUNE")) { int a, b2, c, e; if (sscanf(tn, "%d,%d,%d,%d", &a, &b2, &c, &e) == 4 && a > 0 && b2 > 0 && c > 0 && e > 0) { d.g_fast = a; d.g_score = b2; d.g_pde = c; d.g_box = e; } }
@@ -250,9 +254,10 @@ void mor_batch_destroy(mor_batch *b) {
   if (b->sb) hipStreamSynchronize(b->sb);
   for (auto &x : b->extra) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
   for (auto &ev : b->args_ev) if (ev) hipEventDestroy(ev);
-  for (auto &pe : b->ev_piece) for (auto &ev : pe) if (ev) hipEventDestroy(ev);
+  for (auto *arr : {b->ev_split, b->ev_clusters, b->ev_pairs, b->ev_tpush}) for (int i = 0; i < MOR_MAX_SLOTS; ++i) if (arr[i]) hipEventDestroy(arr[i]);
   for (auto &ev : b->ev_back) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->ev_track) if (ev) hipEventDestroy(ev);
+  for (auto &ev : b->ev_out) if (ev) hipEventDestroy(ev);
   if (b->sf) hipStreamDestroy(b->sf);
   if (b->sc) hipStreamDestroy(b->sc);
   if (b->sm) hipStreamDestroy(b->sm);
@@ -286,23 +291,17 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   // (Tried and measured without effect on the pipeline: highest stream priority for the cell-graph stream, and CU masks
   //  that give it 32-96 CUs of its own.)
   if (hipStreamCreateWithFlags(&b->sf, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sc, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sm, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sb, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
-  for (auto &pe : b->ev_piece) for (auto &ev : pe) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+  for (auto *arr : {b->ev_split, b->ev_clusters, b->ev_pairs, b->ev_tpush}) for (int i = 0; i < MOR_MAX_SLOTS; ++i) if (hipEventCreateWithFlags(&arr[i], hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_back) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_track) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
-  if (p->ground_method == 0) { const int ids[7] = {7, 8, 1, 2, 3, 4, 5}; b->n_pieces = 7; for (int i = 0; i < 7; ++i) b->piece_id[i] = ids[i]; }
-  else { const int ids[11] = {10, 11, 12, 13, 14, 15, 1, 2, 3, 4, 5}; b->n_pieces = 11; for (int i = 0; i < 11; ++i) b->piece_id[i] = ids[i]; }
+  for (auto &ev : b->ev_out) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+  if (p->ground_method == 0) { const int ids[8] = {7, 8, 1, 2, 3, 4, 5, 6}; b->n_pieces = 8; for (int i = 0; i < 8; ++i) b->piece_id[i] = ids[i]; }
+  else { const int ids[12] = {10, 11, 12, 13, 14, 15, 1, 2, 3, 4, 5, 6}; b->n_pieces = 12; for (int i = 0; i < 12; ++i) b->piece_id[i] = ids[i]; }
   b->n_lanes = (int)std::min<uint64_t>(4, b->pipe_depth);
   if (getenv("MOR_LANES")) b->n_lanes = std::max(1, std::min<int>((int)std::min<uint64_t>(8, b->pipe_depth), atoi(getenv("MOR_LANES"))));
   for (int i = 4; i < b->n_lanes; ++i) if (hipStreamCreateWithFlags(&b->extra[i - 4], hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
   MorDev &d = b->d; const size_t B = d.B, N = d.Nmax, K = d.Kcap, T = d.tiles_max;
   bool ok = true;
-  MorStreamArgs *dargs = nullptr;
-  ok = ok && dalloc(b, dargs, B) && dalloc(b, d.info, B) && dalloc(b, d.tile_cnt, B * T * 2);
-  b->d_args_s[0] = dargs; d.args = dargs;
-  ok = ok && dalloc(b, d.cloud, B * N) && dalloc(b, d.cloud_tidx, B * N) && dalloc(b, d.ground, 2 * B * N) && dalloc(b, d.gp_idx, B * N) && dalloc(b, d.pcell, B * N);
-  ok = ok && dalloc(b, d.pkey, B * N) && dalloc(b, d.ckey, B * N) && dalloc(b, d.cstart, B * (N + 1)) && dalloc(b, d.row_start, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, d.cmin, B * N) && dalloc(b, d.cmeta, 2 * B * N);
-  ok = ok && dalloc(b, d.sorted, B * N) && dalloc(b, d.parent, B * N) && dalloc(b, d.croot, B * N) && dalloc(b, d.csize, B * N) && dalloc(b, d.compmin, B * N) && dalloc(b, d.cid_of_root, B * N) && dalloc(b, d.pcid, B * N) && dalloc(b, d.ccid, B * N);
-  ok = ok && dalloc(b, d.ktile_cnt, B * T) && dalloc(b, d.kcell, B * K) && dalloc(b, d.kroot, B * K) && dalloc(b, d.ksize, B * K) && dalloc(b, d.csz, B * K) && dalloc(b, d.krank_inv, B * K);
   {  // method-1 search stencil: (dy,dz) rows ordered by their distance lower bound, then by centre distance
     const int R = d.score_R, side = 2 * R + 1;
     std::vector<std::pair<std::pair<int, int>, std::pair<int, int>>> rows;
@@ -318,68 +317,53 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     if (ok) ok = hipMemcpy(dtab, tab.data(), tab.size(), hipMemcpyHostToDevice) == hipSuccess;
     d.row_order = dtab; d.n_rows = side * side;
   }
-  for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, d.rkeys[i], B * N) && dalloc(b, d.rvals[i], B * N);
-  ok = ok && dalloc(b, d.rhist, B * T * 256);
-  ok = ok && dalloc(b, d.scell, B * N) && dalloc(b, d.csum, B * N) && dalloc(b, d.cgat, B * N) && dalloc(b, d.clist, B * N) && dalloc(b, d.cl_coff, B * (K + 1));
-  d.skey = d.rkeys[d.cell_passes & 1]; d.sidx = d.rvals[d.cell_passes & 1];
-  if (d.use_hash) ok = ok && dalloc(b, d.chash, 2 * B * (size_t)d.Hcell); else d.chash = nullptr;
-  ok = ok && dalloc(b, d.split_desc, B * T);
-  ok = ok && dalloc(b, d.crep, B * N);
-  ok = ok && dalloc(b, d.cg_ovf, B * (size_t)MOR_MAXP * MOR_CGS_OVF * 2);
-  ok = ok && dalloc(b, d.ppos, B * N) && dalloc(b, d.pslot, B * N) && dalloc(b, d.gh_rowlist, B * N) && dalloc(b, d.gh_cells, B * N) && dalloc(b, d.gh_rowfill, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, d.gh_key, B * (size_t)d.Hcell) && dalloc(b, d.gh_val, B * (size_t)d.Hcell);
-  ok = ok && dalloc(b, d.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, d.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, d.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, d.lroot_a, B * N) && dalloc(b, d.lroot_b, B * N) && dalloc(b, d.parent2, B * N);
-  ok = ok && dalloc(b, d.xcent, B * K) && dalloc(b, d.xamin, B * K) && dalloc(b, d.xamax, B * K) && dalloc(b, d.xfirst, B * K);
-  for (int i = 0; i < (int)b->n_slots; ++i)
-    ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.chunk_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K) && dalloc(b, d.cl_first[i], B * K);
   d.Wcap = (int)(N / MOR_CHUNK + K + 2);
-  ok = ok && dalloc(b, d.part_back, B * (size_t)d.Wcap);
-  ok = ok && dalloc(b, d.nn_fwd, B * K) && dalloc(b, d.nn_bwd, B * K) && dalloc(b, d.nn_fwd_d, B * K) && dalloc(b, d.pair_q, B * K) && dalloc(b, d.pair_m, B * K) && dalloc(b, d.pair_d, B * K);
-  ok = ok && dalloc(b, d.pair_cnt, B * K) && dalloc(b, d.pair_of_prev, B * K) && dalloc(b, d.pair_of_cur, B * K) && dalloc(b, d.det, B * K);
-  if (p->method_choice == 2) ok = ok && dalloc(b, d.vox, B * (size_t)d.Hcap);
-  ok = ok && dalloc(b, d.wl, B * N) && dalloc(b, d.wl_nb, B) && dalloc(b, d.wl2, B * N) && dalloc(b, d.wl2_n, B) && dalloc(b, d.dbg, B * 16) && dalloc(b, d.dbg2, B * (MOR_MAXP + 2) * 16);
-  ok = ok && dalloc(b, d.zmin_i, B) && dalloc(b, d.zmax_i, B) && dalloc(b, d.zorg, B) && dalloc(b, d.zbase, B) && dalloc(b, d.mode_bin, B);
-  if (d.gmode == 1) ok = ok && dalloc(b, d.gnz, B);
-  if (d.gmode == 1) ok = ok && dalloc(b, d.rawbuf, B * N) && dalloc(b, d.is_ground, B * N) && dalloc(b, d.vcent, B * N) && dalloc(b, d.vbin, B * N) && dalloc(b, d.g2_big, B * N) && dalloc(b, d.g2_nbig, B);
-  if (ok) {   // crop-box variant: the clustering grid starts at gp_limit for every stream
-    std::vector<float> z0(B, p->gp_limit); std::vector<int> zb(B, 0);
-    ok = hipMemcpy(d.zorg, z0.data(), B * sizeof(float), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d.zbase, zb.data(), B * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
-  }
-  ok = ok && dalloc(b, b->d_moving, B * K + B) && dalloc(b, d.otile_cnt, B * T) && dalloc(b, b->d_outptrs, B);
-  for (int i = 0; i < (int)b->n_slots; ++i) ok = ok && dalloc(b, d.slot_kc[i], B);
-  ok = ok && dalloc(b, d.err, B) && halloc(b, d.h_err, B) && halloc(b, d.h_log, B * (size_t)MOR_LOG_CAP) && dalloc(b, d.tickets, B * 8);
-  if (ok) ok = hipMemset(d.tickets, 0, B * 8 * sizeof(int)) == hipSuccess;
-  if (ok) { ok = hipMemset(d.err, 0, B * sizeof(unsigned)) == hipSuccess; for (int i = 0; i < (int)b->n_slots; ++i) ok = ok && hipMemset(d.slot_kc[i], 0, B * sizeof(int2)) == hipSuccess; }
-  d.moving = b->d_moving;
-  ok = ok && dalloc(b, d.tr, B) && dalloc(b, d.tr_corr, B * MOR_TR_NB * K) && dalloc(b, d.tr_res, B * (MOR_TR_NB + 1) * K) && dalloc(b, d.tr_lastdet, B * K);
-  if (ok) ok = hipMemset(d.tr, 0, B * sizeof(MorTrackDev)) == hipSuccess && hipMemset(b->d_moving, 0, B * K + B) == hipSuccess;
   d.moving_confidence = n_bad; d.static_confidence = n_good; d.leave_off = p->leave_off_distance; d.catch_up = p->catch_up_distance;
+  // ---- shared by all frames: the cluster arrays (frame-slotted: cb, ca and the frames in flight behind them), the tracking state (strictly
+  //      serial across frames), the sticky error words, the pinned host mirrors (written by the serial tracking / output steps)
+  for (int i = 0; i < (int)b->n_slots; ++i)
+    ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.chunk_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K) && dalloc(b, d.cl_first[i], B * K) && dalloc(b, d.slot_kc[i], B) && hipMemset(d.slot_kc[i], 0, B * sizeof(int2)) == hipSuccess;
+  ok = ok && dalloc(b, d.err, B) && hipMemset(d.err, 0, B * sizeof(unsigned)) == hipSuccess && halloc(b, d.h_err, B) && halloc(b, d.h_log, B * (size_t)MOR_LOG_CAP) && dalloc(b, b->d_outptrs, B);
+  ok = ok && dalloc(b, d.dbg, B * 16) && dalloc(b, d.dbg2, B * (MOR_MAXP + 2) * 16);
+  ok = ok && dalloc(b, d.tr, B) && hipMemset(d.tr, 0, B * sizeof(MorTrackDev)) == hipSuccess && dalloc(b, d.tr_corr, B * MOR_TR_NB * K) && dalloc(b, d.tr_res, B * (MOR_TR_NB + 1) * K) && dalloc(b, d.tr_lastdet, B * K);
   ok = ok && halloc(b, b->h_args_ring, B * MOR_ARGS_RING) && halloc(b, b->h_outptrs, B);
   b->h_args = b->h_args_ring;
   ok = ok && halloc(b, d.h_info, B) && halloc(b, d.h_centroid, B * K) && halloc(b, d.h_cl_off, B * (K + 1)) && halloc(b, d.h_det, B * K);
   ok = ok && halloc(b, d.h_pair_q, B * K) && halloc(b, d.h_pair_m, B * K) && halloc(b, d.h_pair_d, B * K) && halloc(b, d.h_score, B * K) && halloc(b, d.h_nout, B) && halloc(b, d.h_noff, B);
   if (!ok) return fail(set_error(MOR_ERR_HIP, "device/host allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
-  // two more copies of every per-frame array that crosses a stage boundary (frame k uses copy k % 3)
-  b->dtemp[0] = d;
-  for (int c = 1; c < (int)b->pipe_depth; ++c) {
-    b->dtemp[c] = d;
-    MorDev &o = b->dtemp[c]; MorStreamArgs *dargs1 = nullptr;
-    ok = dalloc(b, dargs1, B) && dalloc(b, o.tickets, B * 8) && hipMemset(o.tickets, 0, B * 8 * sizeof(int)) == hipSuccess && dalloc(b, o.info, B) && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, 2 * B * N) && dalloc(b, o.gp_idx, B * N);
-    ok = ok && dalloc(b, o.sorted, B * N) && dalloc(b, o.ckey, B * N) && dalloc(b, o.cstart, B * (N + 1)) && dalloc(b, o.row_start, B * ((size_t)std::max(d.g.nrows, d.gv.nrows) + 1)) && dalloc(b, o.cmeta, 2 * B * N) && dalloc(b, o.crep, B * N);
-    ok = ok && dalloc(b, o.pcid, B * N) && dalloc(b, o.ccid, B * N) && dalloc(b, o.det, B * K) && dalloc(b, o.zorg, B);
-    ok = ok && dalloc(b, o.scell, B * N) && dalloc(b, o.csum, B * N) && dalloc(b, o.cgat, B * N) && dalloc(b, o.clist, B * N) && dalloc(b, o.cl_coff, B * (K + 1));
-    ok = ok && dalloc(b, o.pcell, B * N) && dalloc(b, o.ppos, B * N) && dalloc(b, o.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, o.lroot_a, B * N) && dalloc(b, o.lroot_b, B * N) && dalloc(b, o.cmin, B * N) && dalloc(b, o.parent, B * N) && dalloc(b, o.csize, B * N) && dalloc(b, o.compmin, B * N) && dalloc(b, o.cid_of_root, B * N);
-    ok = ok && dalloc(b, o.pair_q, B * K) && dalloc(b, o.pair_m, B * K) && dalloc(b, o.pair_d, B * K) && dalloc(b, o.pair_cnt, B * K) && dalloc(b, o.pair_of_prev, B * K) && dalloc(b, o.pair_of_cur, B * K);
-    ok = ok && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B) && dalloc(b, o.wl_nb, B) && dalloc(b, o.wl, B * N);
-    if (d.use_hash) ok = ok && dalloc(b, o.chash, 2 * B * (size_t)d.Hcell);
-    if (d.gmode == 0) ok = ok && dalloc(b, o.pkey, B * N);   // split | grid build are two pieces
-    if (d.gmode == 1)   // voxel ground variant: its grid piece runs as six, these cross their boundaries
-      ok = ok && dalloc(b, o.rawbuf, B * N) && dalloc(b, o.is_ground, B * N) && dalloc(b, o.vcent, B * N) && dalloc(b, o.vbin, B * N) && dalloc(b, o.g2_big, B * N) && dalloc(b, o.g2_nbig, B) &&
-           (d.gnz ? dalloc(b, o.gnz, B) : true) && dalloc(b, o.zbase, B) && dalloc(b, o.pkey, B * N) && dalloc(b, o.tile_cnt, B * T * 2) && dalloc(b, o.zmin_i, B) && dalloc(b, o.zmax_i, B);
-    b->d_args_s[c] = dargs1; o.args = dargs1;
-    if (ok) ok = hipMemcpy(o.zorg, d.zorg, B * sizeof(float), hipMemcpyDeviceToDevice) == hipSuccess;
-    if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d, max_points=%llu)", d.B, (unsigned long long)max_points));
+  // ---- once per frame in flight (frame k uses copy k mod depth): EVERY array a push or a filter writes outside the shared set above,
+  //      scratch included — so two frames never share a buffer and the only orderings between their launches are the true dependencies
+  //      (mor_push_batch).  288 GB of HBM3E make that cheap: ≈ 4 GB per copy at B = 64 × 120 000 points.
+  const size_t R1 = (size_t)std::max(d.g.nrows, d.gv.nrows) + 1;
+  std::vector<float> z0(B, p->gp_limit);   // crop-box variant: the clustering grid starts at gp_limit for every stream
+  for (int c = 0; c < (int)b->pipe_depth; ++c) {
+    MorDev o = d; MorStreamArgs *dargs = nullptr;
+    ok = dalloc(b, dargs, B) && dalloc(b, o.info, B) && hipMemset(o.info, 0, B * sizeof(MorFrameInfo)) == hipSuccess && dalloc(b, o.tickets, B * 8) && hipMemset(o.tickets, 0, B * 8 * sizeof(int)) == hipSuccess;
+    ok = ok && dalloc(b, o.tile_cnt, B * T * 2) && dalloc(b, o.split_desc, B * T) && hipMemset(o.split_desc, 0, B * T * sizeof(unsigned long long)) == hipSuccess;   // (frame tags of the single-read split start at 1)
+    ok = ok && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, 2 * B * N) && dalloc(b, o.gp_idx, B * N) && dalloc(b, o.pkey, B * N) && dalloc(b, o.pcell, B * N) && dalloc(b, o.ppos, B * N) && dalloc(b, o.pslot, B * N);
+    ok = ok && dalloc(b, o.gh_rowlist, B * N) && dalloc(b, o.gh_cells, B * N) && dalloc(b, o.gh_rowfill, B * R1) && dalloc(b, o.gh_key, B * (size_t)d.Hcell) && dalloc(b, o.gh_val, B * (size_t)d.Hcell);
+    ok = ok && dalloc(b, o.ckey, B * N) && dalloc(b, o.cstart, B * (N + 1)) && dalloc(b, o.row_start, B * R1) && dalloc(b, o.cmin, B * N) && dalloc(b, o.cmeta, 2 * B * N) && dalloc(b, o.crep, B * N) && dalloc(b, o.sorted, B * N) && dalloc(b, o.scell, B * N) && dalloc(b, o.csum, B * N);
+    ok = ok && dalloc(b, o.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, o.lroot_a, B * N) && dalloc(b, o.lroot_b, B * N) && dalloc(b, o.parent, B * N) && dalloc(b, o.parent2, B * N) && dalloc(b, o.cg_ovf, B * (size_t)MOR_MAXP * MOR_CGS_OVF * 2);
+    ok = ok && dalloc(b, o.croot, B * N) && dalloc(b, o.csize, B * N) && dalloc(b, o.compmin, B * N) && dalloc(b, o.cid_of_root, B * N) && dalloc(b, o.pcid, B * N) && dalloc(b, o.ccid, B * N) && dalloc(b, o.cgat, B * N) && dalloc(b, o.clist, B * N) && dalloc(b, o.cl_coff, B * (K + 1));
+    ok = ok && dalloc(b, o.ktile_cnt, B * T) && dalloc(b, o.kcell, B * K) && dalloc(b, o.kroot, B * K) && dalloc(b, o.ksize, B * K) && dalloc(b, o.csz, B * K) && dalloc(b, o.krank_inv, B * K);
+    ok = ok && dalloc(b, o.xcent, B * K) && dalloc(b, o.xamin, B * K) && dalloc(b, o.xamax, B * K) && dalloc(b, o.xfirst, B * K) && dalloc(b, o.part_back, B * (size_t)d.Wcap);
+    ok = ok && dalloc(b, o.nn_fwd, B * K) && dalloc(b, o.nn_bwd, B * K) && dalloc(b, o.nn_fwd_d, B * K) && dalloc(b, o.pair_q, B * K) && dalloc(b, o.pair_m, B * K) && dalloc(b, o.pair_d, B * K);
+    ok = ok && dalloc(b, o.pair_cnt, B * K) && dalloc(b, o.pair_of_prev, B * K) && dalloc(b, o.pair_of_cur, B * K) && dalloc(b, o.det, B * K);
+    ok = ok && dalloc(b, o.wl, B * N) && dalloc(b, o.wl_nb, B) && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B);
+    if (d.use_hash) ok = ok && dalloc(b, o.chash, 2 * B * (size_t)d.Hcell); else o.chash = nullptr;
+    if (p->method_choice == 2) ok = ok && dalloc(b, o.vox, B * (size_t)d.Hcap);
+    ok = ok && dalloc(b, o.moving, B * K + B) && hipMemset(o.moving, 0, B * K + B) == hipSuccess && dalloc(b, o.otile_cnt, B * T);
+    ok = ok && dalloc(b, o.zmin_i, B) && dalloc(b, o.zmax_i, B) && dalloc(b, o.zorg, B) && dalloc(b, o.zbase, B) && hipMemset(o.zbase, 0, B * sizeof(int)) == hipSuccess && dalloc(b, o.mode_bin, B);
+    if (ok) ok = hipMemcpy(o.zorg, z0.data(), B * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    if (d.gmode == 1) {   // voxel-covariance ground variant: the VoxelGrid sort and the per-voxel results
+      for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, o.rkeys[i], B * N) && dalloc(b, o.rvals[i], B * N);
+      ok = ok && dalloc(b, o.rhist, B * T * 256) && dalloc(b, o.gnz, B) && dalloc(b, o.rawbuf, B * N) && dalloc(b, o.is_ground, B * N) && dalloc(b, o.vcent, B * N) && dalloc(b, o.vbin, B * N) && dalloc(b, o.g2_big, B * N) && dalloc(b, o.g2_nbig, B);
+      o.skey = o.rkeys[d.voxel_passes & 1]; o.sidx = o.rvals[d.voxel_passes & 1];
+    }
+    if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d, max_points=%llu, copy %d of %d)", d.B, (unsigned long long)max_points, c + 1, (int)b->pipe_depth));
+    b->d_args_s[c] = dargs; o.args = dargs;
+    b->dtemp[c] = o;
   }
-  for (int i = 0; i < (int)b->pipe_depth; ++i) if (hipMemset(b->dtemp[i].info, 0, B * sizeof(MorFrameInfo)) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "memset failed"));
   b->d = b->dtemp[0];
   b->prev_pose.resize(B);
   if (err) *err = MOR_OK;
@@ -444,11 +428,10 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   //      frame k runs beside later pieces of frames k−1, k−2).  The first piece must not overwrite what frame k−depth still
   //      uses (same buffer copy; its cluster slot doubles as the `ca` slot of frame k−depth+1)
   hipStream_t lane = b->lane_stream(k);
-  {
-    const uint64_t depth = b->pipe_depth;   // frames in flight = copies of the per-frame arrays
-    if (k >= depth) HIP_TRY(hipStreamWaitEvent(lane, b->ev_back[(k - depth) % MOR_MAX_SLOTS], 0));
-    if (k > 0) HIP_TRY(hipStreamWaitEvent(lane, b->ev_piece[0][(k - 1) % MOR_MAX_SLOTS], 0));   // (also: the staging area of host blobs is free)
-  }
+  const uint64_t depth = b->pipe_depth, ks = k % MOR_MAX_SLOTS, kp = (k + MOR_MAX_SLOTS - 1) % MOR_MAX_SLOTS;
+  if (k >= depth) HIP_TRY(hipStreamWaitEvent(lane, b->ev_back[(k - depth) % MOR_MAX_SLOTS], 0));   // the frame that used this copy of the per-frame arrays (and this cluster slot as its ca) is done
+  const bool staged = max_host_bytes > 0;
+  if (staged && b->last_split) HIP_TRY(hipStreamWaitEvent(lane, *b->last_split, 0));   // the one staging area of host blobs is free
   for (int s = 0; s < B; ++s) {   // host-resident blobs are staged through device memory
     const mor_cloud_view &c = clouds[s];
     if (!c.on_device && c.n_points) HIP_TRY(hipMemcpyAsync((void *)b->h_args[s].data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, lane));
@@ -457,16 +440,20 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   HIP_TRY(hipEventRecord(b->args_ev[slot], lane));
   HIP_TRY(hipEventRecord(b->ev[0], lane));
   hipStream_t tail = lane;
-  static const int exp_few = getenv("MOR_EXP_FEWER_EVENTS") ? atoi(getenv("MOR_EXP_FEWER_EVENTS")) : 0;   // timing experiment only (races on single-copy scratch arrays)
   for (int pc = 0; pc < b->n_pieces; ++pc) {
+    const int id = b->piece_id[pc];
     const bool trk = pc == b->n_pieces - 1;
-    const bool need = !exp_few || b->piece_id[pc] == 4 || trk;
-    if (pc > 0 && k > 0 && need) HIP_TRY(hipStreamWaitEvent(lane, b->ev_piece[exp_few && b->piece_id[pc] == 4 ? pc - 1 : pc][(k - 1) % MOR_MAX_SLOTS], 0));
-    if (trk && b->last_track) HIP_TRY(hipStreamWaitEvent(lane, *b->last_track, 0));   // tracking state: after the previous frame's filterCloud
-    mor_launch_piece(d, b->piece_id[pc], lane, &b->timer);
-    if (!exp_few || b->piece_id[pc] == 3 || trk || pc == 0) HIP_TRY(hipEventRecord(b->ev_piece[pc][k % MOR_MAX_SLOTS], lane));
+    if (id == 4 && k > 0) {   // the pair stage reads (and transforms in place, :540-551) frame k − 1's clusters
+      HIP_TRY(hipStreamWaitEvent(lane, b->ev_clusters[kp], 0));
+      if (d.method == 2) HIP_TRY(hipStreamWaitEvent(lane, b->ev_pairs[kp], 0));   // … which frame k − 1's own voxel probe (method 2) must have finished reading
+    }
+    if (trk && b->last_track) HIP_TRY(hipStreamWaitEvent(lane, *b->last_track, 0));   // tracking state: after the previous frame's filterCloud loop
+    mor_launch_piece(d, id, lane, &b->timer);
+    if ((id == 7 || id == 10) && staged) { HIP_TRY(hipEventRecord(b->ev_split[ks], lane)); b->last_split = &b->ev_split[ks]; }
+    if (id == 3) HIP_TRY(hipEventRecord(b->ev_clusters[ks], lane));
+    if (id == 4 && d.method == 2) HIP_TRY(hipEventRecord(b->ev_pairs[ks], lane));
+    if (trk) { HIP_TRY(hipEventRecord(b->ev_tpush[ks], lane)); b->last_track = &b->ev_tpush[ks]; }
   }
-  b->last_track = &b->ev_piece[b->n_pieces - 1][k % MOR_MAX_SLOTS];
   HIP_TRY(hipEventRecord(b->ev[1], tail));
   HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], tail));
   HIP_TRY(hipGetLastError());
@@ -497,10 +484,13 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
     b->last_filter_stream = fs;
   }
   HIP_TRY(hipEventRecord(b->ev[2], fs));
-  mor_launch_filter(d, fs, &b->timer);
+  mor_launch_filter(d, fs, &b->timer, 1);
+  HIP_TRY(hipEventRecord(b->ev_track[k % MOR_MAX_SLOTS], fs)); b->last_track = &b->ev_track[k % MOR_MAX_SLOTS];   // the tracking state is settled: the next frame's tracking step may follow
+  if (b->last_out) HIP_TRY(hipStreamWaitEvent(fs, *b->last_out, 0));
+  mor_launch_filter(d, fs, &b->timer, 2);
+  HIP_TRY(hipEventRecord(b->ev_out[k % MOR_MAX_SLOTS], fs)); b->last_out = &b->ev_out[k % MOR_MAX_SLOTS];
   HIP_TRY(hipEventRecord(b->ev[3], fs));
   HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], fs));
-  HIP_TRY(hipEventRecord(b->ev_track[k % MOR_MAX_SLOTS], fs)); b->last_track = &b->ev_track[k % MOR_MAX_SLOTS];
   HIP_TRY(hipGetLastError());
   b->pending = true;
   const bool need_host = n_out != nullptr || (out && !out_on_device);

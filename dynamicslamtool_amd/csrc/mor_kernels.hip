@@ -116,27 +116,23 @@ __device__ __forceinline__ void mor_raise(const MorDev &d, int s, unsigned bit) 
 __device__ __forceinline__ void mor_publish_err(const MorDev &d, int s) { d.h_err[s] = __hip_atomic_load(&d.err[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // "Last workgroup of the stream": every workgroup of a stream's share of a launch calls this once, after its last store; it returns true
-// in exactly one of them — the one that arrives last — and that one may then read what all the others wrote (plain stores and
-// atomics alike).  No workgroup waits for another, so no assumption about residency or dispatch order is needed.  Producer side
-// (MI355X_MICROARCH.md, valid forms): every storing wave drains its stores, workgroup barrier, one lane: agent-scope release fence,
-// drained (the inline asm keeps the compiler from dropping that wait), then the ticket; consumer side: agent-scope acquire by every
-// wave of the last workgroup before its first load.  The ticket word is reset by the last arriver for the next frame that uses this
-// copy of the per-frame arrays (tickets exist once per frame in flight).  l_flag: one int of LDS.
+// in exactly one of them — the one that arrives last — and that one may then read what all the others handed over.  No workgroup waits
+// for another, so no assumption about residency or dispatch order is needed.  What is handed over must be written with agent-scope
+// atomics or agent-scope (write-through, `sc1`) stores and read by the last workgroup with agent-scope loads (ld_agent): then no
+// release fence is needed — an agent-scope release writes back the whole L2 of the XCD, and thousands of workgroups doing that per
+// launch cost 200 µs (measured: k_score_pde 65 → 275 µs).  Every storing wave drains its stores, workgroup barrier, then one lane
+// takes the ticket (MI355X_MICROARCH.md, hand-offs with `sc1` loads in place of the acquire).  The ticket word is reset by the last
+// arriver for the next frame that uses this copy of the per-frame arrays (tickets exist once per frame in flight).  l_flag: one int of LDS.
 __device__ __forceinline__ bool stream_last_block(int *ticket, int n_blocks, int *l_flag) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *l_flag = t == n_blocks - 1;
     if (t == n_blocks - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  const bool last = *l_flag != 0;
-  if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-  __syncthreads();
-  return last;
+  return *l_flag != 0;
 }
 enum { TK_TRACK = 0, TK_CGFINAL = 1, TK_PAIRS = 2, TK_COUNT = 8 };   // ticket words per stream
 
@@ -348,92 +344,117 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   }
 }
 
-// Single-pass variant of k_classify + k_scatter (crop-box variant and pass B of the voxel variant): the cloud is read
-// ONCE.  Every tile counts its (non-ground, ground) points, publishes the pair in a 64-bit descriptor and obtains its
-// exclusive prefix by decoupled look-back over the descriptors of the earlier tiles of its stream (status A = tile
-// aggregate, P = inclusive prefix; Merrill & Garland).  Workgroups of a stream are dispatched in tile order
-// (map_block), so a tile only ever waits for workgroups that are already running.  Descriptors are zeroed by a
-// memset in front of the kernel; they are polled and published with agent-scope read-modify-write atomics (coherent
-// across the XCDs' L2s).  The last tile publishes N, T, M, G.
-#define SPLIT_A 1ull
-#define SPLIT_P 2ull
+// Single-READ variant of k_classify + k_scatter (crop-box variant and pass B of the voxel variant).  SP_G workgroups per stream walk the
+// stream's tiles round-robin (workgroup g: tiles g, g + SP_G, …), so at every step the SP_G workgroups of a stream hold SP_G consecutive
+// tiles.  A tile's output offsets are the counts of all earlier tiles: a workgroup carries the prefix of its previous tile along and adds
+// the aggregates of the ≤ SP_G − 1 tiles in between, which its peers publish — right after their loads have landed — in 64-bit descriptors
+// tagged with the frame (no reset pass; polled and published with agent-scope accesses: a stream's workgroups share an XCD under map_block,
+// but correctness does not depend on it).  The loads of a workgroup's NEXT tile are issued before it waits for the descriptors of the
+// current one, so the reads of step i + 1 overlap the look-back and the stores of step i.  (Round 2's form — one workgroup per tile, all
+// resident at once, look-back over all earlier tiles — read, waited and stored in lock step: 91 µs against 44 µs without the look-back.)
+// All SP_G workgroups of a stream must get to run while their peers spin: 8 × B workgroups of 256 threads are a fraction of what the GPU
+// holds (8 per CU), and a peer that never shows up raises the "look-back stalled" flag after SPLIT_SPIN_LIMIT polls instead of hanging.
+#ifndef SP_G
+#define SP_G 8
+#endif
 #define SPLIT_SPIN_LIMIT (1u << 22)
-__device__ __forceinline__ unsigned long long split_pack(unsigned long long st, int ng, int g) { return (st << 62) | ((unsigned long long)(unsigned)ng << 31) | (unsigned long long)(unsigned)g; }
-__global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
-  int s, t; map_block(d.B, d.tiles, s, t);
-  const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
-  const MorStreamArgs a = d.args[s];
-  const uint32_t n_in = pass_count(d, a, s);
+__device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// loads only (no use of the data here: the wait for them belongs to split_tile, a step later); cls carries the ground flag of pass B
+__device__ __forceinline__ void split_load_tile(const MorDev &d, const MorStreamArgs &a, int s, uint32_t n_in, int t, float4 (&p)[8], int (&cls)[8]) {
   const uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
-  float4 p[8]; int cls[8]; unsigned long long m_ng[8], m_g[8];
-  int c_ng = 0, c_g = 0;
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
-    uint32_t i = base + it * 64 + lane_id();
-    cls[it] = 0;
-    if (i < n_in) cls[it] = pass_item(d, a, s, i, p[it]);
-    m_ng[it] = __ballot(cls[it] == 2); m_g[it] = __ballot(cls[it] == 1);
-    c_ng += __popcll(m_ng[it]); c_g += __popcll(m_g[it]);
+    const uint32_t i = min(base + it * 64 + lane_id(), n_in - 1);   // (clamped: out-of-range lanes repeat the last record and are masked in split_tile)
+    if (d.gmode == 2) { p[it] = d.rawbuf[(size_t)s * d.Nmax + i]; cls[it] = d.is_ground[(size_t)s * d.Nmax + i]; }
+    else { p[it] = load_point(a, i); cls[it] = 0; }
   }
-  __shared__ int sh[8], s_ex[2];
+}
+__device__ __forceinline__ void split_tile(const MorDev &d, const MorGrid &G, int s, int t, int nt, int t_prev, unsigned epoch, const float4 (&p)[8], const int (&cls)[8],
+                                           int &ex_ng, int &ex_g, int *sh, int *s_ex) {
+  unsigned long long m_ng[8], m_g[8];
+  int c_ng = 0, c_g = 0, cl[8];
+  const uint32_t n_in = pass_count(d, d.args[s], s), base = (uint32_t)t * MOR_TILE + wave_id() * 512;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    cl[it] = base + it * 64 + lane_id() < n_in ? (d.gmode == 2 ? (cls[it] ? 1 : 2) : classify(d, p[it])) : 0;
+    m_ng[it] = __ballot(cl[it] == 2); m_g[it] = __ballot(cl[it] == 1); c_ng += __popcll(m_ng[it]); c_g += __popcll(m_g[it]);
+  }
   if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
   __syncthreads();
+  const int tng = sh[0] + sh[1] + sh[2] + sh[3], tg = sh[4] + sh[5] + sh[6] + sh[7];
   if (wave_id() == 0) {
-    const int tng = sh[0] + sh[1] + sh[2] + sh[3], tg = sh[4] + sh[5] + sh[6] + sh[7], lane = lane_id();
     unsigned long long *desc = d.split_desc + (size_t)s * d.tiles_max;
-    if (lane == 0) {
-      if (t == 0) { reset_frame_info(d, s); __threadfence(); }   // every other tile raises flags only after its look-back has seen this tile's descriptor
-      atomicExch(&desc[t], split_pack(t == 0 ? SPLIT_P : SPLIT_A, tng, tg));
-    }
-    int ex_ng = 0, ex_g = 0;
-    if (t > 0) {
-      int back = t - 1; unsigned spins = 0;
+    const int lane = lane_id();
+    if (lane == 0) __hip_atomic_store(&desc[t], ((unsigned long long)epoch << 32) | ((unsigned long long)(unsigned)tng << 16) | (unsigned long long)(unsigned)tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // aggregates of the tiles between this workgroup's previous tile and this one (the peers' tiles of this step and the last)
+    const int u = t - 1 - lane;
+    int an = 0, ag = 0;
+    if (u > t_prev && u >= 0) {
+      unsigned spins = 0;
       for (;;) {
-        const int j = back - lane;
-        const unsigned long long v = j >= 0 ? atomicAdd(&desc[j], 0ull) : split_pack(SPLIT_P, 0, 0);   // "tile −1": prefix 0
-        const unsigned long long st = v >> 62;
-        const unsigned long long mP = __ballot(st == SPLIT_P), mX = __ballot(st == 0ull);
-        const int fp = mP ? __ffsll((long long)mP) - 1 : 64;                                 // nearest tile with a full prefix
-        const unsigned long long need = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);          // lanes 0 … fp
-        if (mX & need) {                                                                     // a needed tile has not published yet
-          if (++spins > SPLIT_SPIN_LIMIT) { if (lane == 0) mor_raise(d, s, 64u); break; }
-          __builtin_amdgcn_s_sleep(2);
-          continue;
-        }
-        int cn = lane <= fp ? (int)((v >> 31) & 0x7fffffffu) : 0, cg = lane <= fp ? (int)(v & 0x7fffffffu) : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { cn += __shfl_xor(cn, o, 64); cg += __shfl_xor(cg, o, 64); }
-        ex_ng += cn; ex_g += cg;
-        if (fp < 64) break;
-        back -= 64;
+        const unsigned long long v = ld_agent64(&desc[u]);
+        if ((unsigned)(v >> 32) == epoch) { an = (int)((v >> 16) & 0xffffu); ag = (int)(v & 0xffffu); break; }
+        if (++spins > SPLIT_SPIN_LIMIT) { mor_raise(d, s, 64u); break; }
+        __builtin_amdgcn_s_sleep(1);
       }
-      if (lane == 0) atomicExch(&desc[t], split_pack(SPLIT_P, ex_ng + tng, ex_g + tg));
     }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { an += __shfl_xor(an, o, 64); ag += __shfl_xor(ag, o, 64); }   // (lanes 0 … SP_G − 2 carry values: SP_G ≤ 16)
     if (lane == 0) {
-      s_ex[0] = ex_ng; s_ex[1] = ex_g;
-      if (t == d.tiles - 1) publish_split(d, s, ex_ng + tng, ex_g + tg);
+      s_ex[0] = ex_ng + an; s_ex[1] = ex_g + ag;
+      if (t == nt - 1) publish_split(d, s, ex_ng + an + tng, ex_g + ag + tg);   // the stream's last tile: T, M, G of the frame
     }
   }
   __syncthreads();
-  if ((uint32_t)t * MOR_TILE >= n_in) return;
   int r_ng = s_ex[0], r_g = s_ex[1];
+  ex_ng = r_ng + tng; ex_g = r_g + tg;   // prefix behind this tile: what the workgroup carries to its next one
   for (int w = 0; w < wave_id(); ++w) { r_ng += sh[w]; r_g += sh[4 + w]; }
   const size_t so = (size_t)s * d.Nmax;
   const float zorg = d.zorg[s]; const int zbase = d.zbase[s];
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
-    int k_ng = r_ng + __popcll(m_ng[it] & lanemask_lt());
-    int k_g = r_g + __popcll(m_g[it] & lanemask_lt());
-    if (cls[it] == 2) {
+    const int k_ng = r_ng + __popcll(m_ng[it] & lanemask_lt()), k_g = r_g + __popcll(m_g[it] & lanemask_lt());
+    if (cl[it] == 2) {
       int cx, cy, cz; bool clamped; grid_cell(G, p[it], zorg, zbase, cx, cy, cz, clamped);
       if (clamped && d.gmode != 0) mor_raise(d, s, 8u);
       d.cloud[so + k_ng] = p[it];
       d.cloud_tidx[so + k_ng] = k_ng + k_g; d.pkey[so + k_ng] = grid_key(G, cx, cy, cz);
-    } else if (cls[it] == 1) {
-      d.ground[2 * so + d.Nmax + k_g] = p[it];
+    } else if (cl[it] == 1) {
+      d.ground[2 * so + d.Nmax + k_g] = p[it];   // final place in filterCloud's output
       d.gp_idx[so + k_g] = k_ng + k_g;
     }
     r_ng += __popcll(m_ng[it]); r_g += __popcll(m_g[it]);
+  }
+  __syncthreads();
+}
+__global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
+  int s, g; map_block(d.B, SP_G, s, g);
+  static_assert(SP_G <= 16 && SP_G >= 2, "the look-back sums 16 lanes");
+  const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
+  const MorStreamArgs a = d.args[s];
+  const uint32_t n_in = pass_count(d, a, s);
+  const int nt = (int)((n_in + MOR_TILE - 1) / MOR_TILE);
+  const unsigned epoch = 2u * (unsigned)d.frame_no + (d.gmode == 2 ? 2u : 1u);   // never 0 (fresh descriptors), never the tag of an earlier pass over this table
+  __shared__ int sh[8], s_ex[2];
+  if (g == 0 && threadIdx.x == 0) {   // start of the frame: before any flag of this stream can be raised (every other tile waits for tile 0's descriptor)
+    reset_frame_info(d, s);
+    if (nt == 0) publish_split(d, s, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  int ex_ng = 0, ex_g = 0, t_prev = -1;
+  float4 pa[8], pb[8]; int ca[8], cb[8];
+  int t = g;
+  if (t < nt) split_load_tile(d, a, s, n_in, t, pa, ca);
+  while (t < nt) {
+    const int t1 = t + SP_G, t2 = t + 2 * SP_G;
+    if (t1 < nt) split_load_tile(d, a, s, n_in, t1, pb, cb);   // the next tile's loads are in flight while this one waits for its peers and stores
+    split_tile(d, G, s, t, nt, t_prev, epoch, pa, ca, ex_ng, ex_g, sh, s_ex);
+    t_prev = t;
+    if (t1 >= nt) break;
+    if (t2 < nt) split_load_tile(d, a, s, n_in, t2, pa, ca);
+    split_tile(d, G, s, t1, nt, t_prev, epoch, pb, cb, ex_ng, ex_g, sh, s_ex);
+    t_prev = t1;
+    t = t2;
   }
 }
 
@@ -1321,7 +1342,7 @@ template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_body(const Mo
   // local roots as global compact ids: own cells → lroot_a, look-ahead cells → lroot_b
   for (int c = threadIdx.x; c < n_loc; c += CGS_T) {
     const int r = c0 + cg_find<LDS>(par, c);
-    if (c < n_own) d.lroot_a[so + c0 + c] = r; else d.lroot_b[so + c0 + c] = r;
+    if (c < n_own) st_agent(&d.lroot_a[so + c0 + c], r); else st_agent(&d.lroot_b[so + c0 + c], r);   // (agent scope: the merge may run in another slab's workgroup of this launch, stream_last_block)
   }
   ST2(stwj, 9); ST2V(stwj, 14, n_own); ST2V(stwj, 15, n_loc);
 }
@@ -1426,10 +1447,10 @@ template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDe
   const int lane = lane_id(), P = d.P;
   // ---- merge: (c, local root in its own slab) and, for the look-ahead cells of the previous slab, (c, local root there)
   for (int c = threadIdx.x; c < nocc; c += NT) {
-    cg_unite<LDS>(par, c, d.lroot_a[so + c]);
+    cg_unite<LDS>(par, c, ld_agent(&d.lroot_a[so + c]));
     int j = 0;
     for (int k = 1; k < P; ++k) j += l_sc[k] <= c;            // slab owning c
-    if (j > 0 && c < l_se[j - 1] && l_sc[j] > l_sc[j - 1]) cg_unite<LDS>(par, c, d.lroot_b[so + c]);   // (an empty slab publishes nothing)
+    if (j > 0 && c < l_se[j - 1] && l_sc[j] > l_sc[j - 1]) cg_unite<LDS>(par, c, ld_agent(&d.lroot_b[so + c]));   // (an empty slab publishes nothing)
   }
   __threadfence_block();
   __syncthreads();
@@ -2308,18 +2329,9 @@ __device__ __forceinline__ void score_pde_body(const MorDev &d, int s, int bx) {
   }
   if (lane == 0 && acc) atomicAdd(&d.pair_cnt[ko + acc_pr], acc);
 }
-template <int TRKN> __device__ __forceinline__ void track_push_body(const MorDev &d, int s);
-// The wave tier and, in the stream's LAST workgroup to finish (stream_last_block), the thresholds and the tracking step of the push
-// (P5 + T1): the per-pair counts are final when every workgroup of the stream has gone through its queries, and the tracking step is
-// one wave of work per stream — as a launch of its own it cost a launch boundary plus 40–60 µs of a lane for 64 waves.
-__global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) {
-  const int s = blockIdx.y + d.s0;
-  score_pde_body(d, s, blockIdx.x);
-  __shared__ int l_last;
-  if (!stream_last_block(d.tickets + (size_t)s * TK_COUNT + TK_TRACK, gridDim.x, &l_last)) return;
-  if (wave_id() != 0) return;   // one wave carries on (barriers of a workgroup count its surviving waves only)
-  track_push_body<128>(d, s);
-}
+__global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) { score_pde_body(d, blockIdx.y + d.s0, blockIdx.x); }
+// (Tried: thresholds + tracking step in the stream's last workgroup of this kernel.  The tracking step of frame k must follow frame
+//  k − 1's filterCloud, so the whole wave tier then waited for it and the frames stopped overlapping: 150 k → 125 k frame-pairs/s.)
 
 // ------------------------------------------------------------------------------------ P4: method 2 (:309-334)
 // OctreePointCloudChangeDetector as a voxel hash set.  PCL grows its octree from the first inserted
@@ -2397,7 +2409,7 @@ template <int NT> __device__ __forceinline__ void decide_body(const MorDev &d, i
   for (int pr = threadIdx.x; pr < np; pr += NT) {
     int q = d.pair_q[ko + pr], m = d.pair_m[ko + pr];
     unsigned long long n1 = (unsigned long long)(offp[q + 1] - offp[q]), n2 = (unsigned long long)(offc[m + 1] - offc[m]);
-    double cnt = (double)d.pair_cnt[ko + pr], score, thr;
+    double cnt = (double)ld_agent(&d.pair_cnt[ko + pr]), score, thr;   // (agent scope: in the fused form the counts come from atomics of the other workgroups of this launch)
     if (d.method == 1) { score = cnt / (double)((n1 + n2) / 2ull); thr = d.pde_thr; }             // :361, :586
     else if (d.method == 2) { score = cnt; thr = (double)((n1 + n2) / (unsigned long long)d.opc_norm); } // :330, :590
     else { score = 0; thr = 0; }
@@ -2419,7 +2431,7 @@ template <int NT> __device__ __forceinline__ void decide_body(const MorDev &d, i
     if (threadIdx.x == 0) { l_sum[0] = 0; l_sum[1] = 0; }
     __syncthreads();
     unsigned cs = 0, ds = 0;
-    for (int pr = threadIdx.x; pr < np; pr += NT) cs += (unsigned)d.pair_cnt[ko + pr] * (unsigned)(2 * pr + 1) + (unsigned)d.pair_m[ko + pr];
+    for (int pr = threadIdx.x; pr < np; pr += NT) cs += (unsigned)ld_agent(&d.pair_cnt[ko + pr]) * (unsigned)(2 * pr + 1) + (unsigned)d.pair_m[ko + pr];
     for (int k = threadIdx.x; k < K; k += NT) ds += d.det[ko + k] ? (unsigned)(k + 1) : 0u;
     atomicAdd(&l_sum[0], cs); atomicAdd(&l_sum[1], ds);
     __syncthreads();
@@ -2863,7 +2875,7 @@ __global__ __launch_bounds__(64) void k_g2_mark(MorDev d) {
 // One workgroup (one wave) per stream.  The state is tiny (a few dozen clusters, pairs and tracked centroids) but the
 // logic is sequential, so it is staged into LDS, run there (no chain of global-memory round trips) and written back.
 // Streams whose vectors exceed the LDS slots run the same code on the global arrays.
-#define TRK 384   // clusters / pairs per window slot held in LDS (the tracking kernels; 128 where the step runs at the tail of k_score_pde)
+#define TRK 384   // clusters / pairs per window slot held in LDS
 // The head of a stream's tracking state (counts, window sizes) lives in LDS while a tracking kernel works on it; the tracked
 // centroids themselves (up to MOR_TR_MAXT of them: 640 KB) stay in global memory: both kernels stream through them once per frame.
 // (The whole struct in LDS made these 64-thread workgroups wait for a CU with 117 KB of LDS free.)
@@ -2880,8 +2892,9 @@ __device__ __forceinline__ void tr_store_head(MorTrackDev &g, const MorTrackHead
   for (int i = lane; i < (int)(sizeof(MorTrackHead) / sizeof(int)); i += 64) gs[i] = ls[i];
 }
 // checkMovingClusterChain (:478-514) with recurseFindClusterChain (:415-453) and pushCentroid (:455-476)
-template <int TRKN> __device__ __forceinline__ void track_push_body(const MorDev &d, int s) {   // one wave (threads 0 … 63 of its workgroup)
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(64) void k_track_push(MorDev d) {
+  const int s = blockIdx.x + d.s0, lane = threadIdx.x;
+  constexpr int TRKN = TRK;
   decide_body<64>(d, s);   // P5: thresholds, detection_results, host summary
   __threadfence_block();
   __syncthreads();
@@ -3009,7 +3022,6 @@ template <int TRKN> __device__ __forceinline__ void track_push_body(const MorDev
   tr_store_head(gt, t, lane);
   if (lane == 0) mor_publish_err(d, s);
 }
-__global__ __launch_bounds__(64) void k_track_push(MorDev d) { track_push_body<TRK>(d, blockIdx.x + d.s0); }   // frames without a method-1 wave tier (first frame, method 2)
 // filterCloud's loop over mo_vec (:630-671): nearest current centroid of every tracked one (squared fp32 distance, ties →
 // lowest index), its whole cluster queued for removal before any test, confidence bookkeeping.  Writes the per-cluster
 // removal flags and the ExtractIndices size-check flag the output kernels read.
@@ -3092,8 +3104,7 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
   const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B);
   if (part == 2) goto grid;
   if (d.gmode != 1 && !d.two_pass_split) {
-    (void)hipMemsetAsync(d.split_desc + (size_t)d.s0 * d.tiles_max, 0, (size_t)d.B * d.tiles_max * sizeof(unsigned long long), st);
-    MOR_LAUNCH(MK_SPLIT, k_split, gT, d);
+    MOR_LAUNCH(MK_SPLIT, k_split, dim3(d.B * SP_G), d);
   } else {
     const dim3 gS(d.B * d.split_g);
     MOR_LAUNCH(MK_CLASSIFY, k_classify, gS, d);
@@ -3173,7 +3184,7 @@ static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
   MOR_LAUNCH(MK_PAIRS, k_cluster_pairs, gB, d);
   if (d.has_prev) {
     if (d.method == 1) {
-      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * d.g_fast), d);
+      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * d.g_fast), d); MOR_LAUNCH(MK_SCORE_NB, k_score_nb, dim3(2 * d.g_score * d.B), d); }
     } else if (d.method == 2) {
       MOR_LAUNCH(MK_VOX_CLEAR, k_vox_clear, dim3(64, d.B), d);
       MOR_LAUNCH(MK_VOX_INSERT, k_vox_insert, gT, d);
@@ -3184,10 +3195,10 @@ static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
 
 static void mor_launch_scores2(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   if (d.has_prev && d.method == 1 && d.pde_ub > 0.f && d.pde_ub > d.pde_lb) {
-    MOR_LAUNCH(MK_SCORE_NB, k_score_nb, dim3(2 * d.g_score * d.B), d);
-    MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(d.g_pde, d.B), d);   // … and the thresholds + tracking step, in each stream's last workgroup
-    return;
+    MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(d.g_pde, d.B), d);
   }
+}
+static void mor_launch_decide(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   mor_timer_begin(tm, MK_TRACK_PUSH, st);
   hipLaunchKernelGGL(k_track_push, dim3(d.B), dim3(64), 0, st, d);
   mor_timer_end(tm, MK_TRACK_PUSH, st);
@@ -3202,6 +3213,7 @@ void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer
     case 3: mor_launch_clusters(d, st, tm); break;
     case 4: mor_launch_pairs(d, st, tm); break;
     case 5: mor_launch_scores2(d, st, tm); break;
+    case 6: mor_launch_decide(d, st, tm); break;
     case 2: mor_launch_cellgraph(d, st, tm); break;
     case 7: mor_launch_split_and_grid(d, st, tm, 1); break;   // the grid piece of the crop variant in two: split | grid build
     case 8: mor_launch_split_and_grid(d, st, tm, 2); break;
@@ -3210,12 +3222,13 @@ void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer
   }
 }
 
-void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
+void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part) {   // part 1: the tracking loop (the next frame's tracking step waits for this only); part 2: the output
   const dim3 gM(d.B * d.tiles_m), gB(d.B), gT2(d.B * (d.tiles_m + (d.out_ptrs ? d.tiles : 0)));
-  if (d.run_tracker) {   // the loop over mo_vec (:630-671): on EVERY filterCloud call, as in the reference — a second call on the same frame walks the tracks again
+  if (part == 1) {   // the loop over mo_vec (:630-671): on EVERY filterCloud call, as in the reference — a second call on the same frame walks the tracks again
     mor_timer_begin(tm, MK_TRACK_FILTER, st);
     hipLaunchKernelGGL(k_track_filter, gB, dim3(64), 0, st, d);
     mor_timer_end(tm, MK_TRACK_FILTER, st);
+    return;
   }
   MOR_LAUNCH(MK_OUT_COUNT, k_out_count, gM, d);
   MOR_LAUNCH(MK_OUT_SCATTER, k_out_scatter, gT2, d);
