@@ -92,6 +92,7 @@ struct MorDev {
   int split_g;   // workgroups per stream of the two split passes (each walks tiles split_g apart)
   int g_fast, g_score, g_pde, g_box;   // launch widths: k_score_fast workgroups per cloud tile, workgroups per stream of the worklist tiers / the wave tier / k_cellboxes (MOR_TUNE)
   int xcd_map;               // 1: the workgroups of a stream share an XCD (its tables stay in that L2); 0: streams spread over all XCDs
+  int nt_ground;             // non-temporal stores for the ground points at the split (MOR_NT_GROUND, experiment)
   int two_pass_split;        // 1 (default): count pass + scatter pass; 0: the single-pass split with decoupled look-back (MOR_SINGLE_PASS_SPLIT)
   int cur, prev, has_prev;   // cluster-array slots of cb and ca (four slots rotate: up to three frames are in flight in the stage pipeline); whether ca exists (:534)
   int run_tracker;           // filter: advance the tracking loop (first filterCloud of this frame)
@@ -120,8 +121,9 @@ struct MorDev {
   float *zorg; int *zbase;   // [B]  z origin of the clustering grid / z base of the voxel lattice
   int *mode_bin;             // [B]  dominant z-bin (:169-178)
   int *pkey;                 // [B][Nmax]  linear cell key per cloud point
-  int *pcell;                // [B][Nmax]  compact cell id per cloud point
-  int *ppos, *pslot;         // [B][Nmax]  hash path of the grid: position of each cloud point in `sorted`; its slot in the cell table
+  int *pslot;                // [B][Nmax]  grid build: per cloud point, its entry in its chunk's list of cells
+  int2 *gc_list, *gc_ent;    // [B][Nmax]  grid build, chunk c at c·GC_CHUNK: (cell key, points) of every cell of the chunk (k_gridcount); (slot, offset) then (compact cell id, first position) of the same entries (k_gridhash)
+  int *gc_n; int gc_chunks, gc_P;   // [B][gc_chunks] entries per chunk; chunks per stream at most; workgroups per stream of k_gridcount / k_gridplace
   int *gh_rowlist, *gh_cells; // [B][Nmax]  hash path, streams beyond the LDS lists: x of the cells of every row (unordered inside the row) then point counts per cell; claimed slots in discovery order
   int *gh_rowfill;           // [B][nrows+1]  hash path: per-row fill cursors when the row table does not fit the LDS copy
   int *gh_key, *gh_val;      // [B][Hcell] hash path: the cell table of streams with more cells than the LDS table holds
@@ -214,7 +216,7 @@ struct MorCellSum { long long a[3], b[3]; };
 enum MorKernelId {
   MK_CLASSIFY, MK_SCATTER, MK_SPLIT, MK_HEADS_COUNT, MK_HEADS_SCATTER, MK_CELLBOXES, MK_RHIST, MK_RSCAN, MK_RSCATTER,
   MK_XFORM_PREV, MK_PAIRS, MK_SCORE_FAST, MK_SCORE_NB, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE,
-  MK_OUT_COUNT, MK_OUT_SCATTER, MK_G2_COV_MID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_GRIDHASH, MK_GRIDFILL, MK_CG_SLAB, MK_CG_FINAL, MK_CLUSTERS, MK_COUNT
+  MK_OUT_COUNT, MK_OUT_SCATTER, MK_G2_COV_MID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_GRIDHASH, MK_GRIDCOUNT, MK_GRIDPLACE, MK_CG_SLAB, MK_CG_FINAL, MK_CLUSTERS, MK_COUNT
 };
 extern const char *const mor_kernel_names[MK_COUNT];
 

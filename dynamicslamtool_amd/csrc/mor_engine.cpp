@@ -16,6 +16,7 @@
 #include <vector>
 
 #define MOR_ARGS_RING 8
+#define SP_G_HOST 16   // workgroups per stream of k_split (SP_G in mor_kernels.hip)
 
 // The frame pipeline wants its four lane streams on four different hardware queues.  The ROCm runtime multiplexes
 // streams onto GPU_MAX_HW_QUEUES (default 4) queues in creation order, so with the batch's main stream two lanes share
@@ -99,7 +100,7 @@ struct mor_batch {
   MorStreamArgs *h_args_ring = nullptr, *h_args = nullptr;   // pinned ring of MOR_ARGS_RING slots (async pushes), current slot
   hipEvent_t args_ev[MOR_ARGS_RING] = {};
   uint64_t pipe_depth = 4, n_slots = 5;       // frames in flight (= copies of the per-frame arrays); cluster-array slots = depth + 1
-  int env_cg_p = 0;         // tuning knob from the environment (MOR_CG_P), read once at creation
+  int env_cg_p = 0, env_gc_p = 0;         // tuning knobs from the environment (MOR_CG_P, MOR_GC_P), read once at creation
   bool async = false, pending = false;   // async: push/filter only enqueue; pending: work enqueued since the last wait
   float4 **h_outptrs = nullptr, **d_outptrs = nullptr;
   unsigned char *d_stage = nullptr; size_t stage_stride = 0;   // staging for host-resident input blobs
@@ -184,8 +185,10 @@ static int configure(mor_batch *b) {
     double lf = (double)p.gp_leaf; d.leaf_r2 = (float)(lf * lf);   // radiusSearch(…, gp_leaf): (float)(radius·radius)
   }
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
-  d.two_pass_split = (getenv("MOR_SINGLE_PASS_SPLIT") && atoi(getenv("MOR_SINGLE_PASS_SPLIT")) != 0) ? 0 : 1;   // count pass + scatter pass (the second read comes from the Infinity Cache) | the single-read split
+  d.two_pass_split = (getenv("MOR_SINGLE_PASS_SPLIT") && atoi(getenv("MOR_SINGLE_PASS_SPLIT")) == 0) ? 1 : 0;   // default: the single-read split (k_split); MOR_SINGLE_PASS_SPLIT=0: count pass + scatter pass (what pass A of the voxel ground variant always uses)
+  if ((size_t)b->B * SP_G_HOST > 4096) d.two_pass_split = 1;   // (all workgroups of the single-read split have to be resident together)
   d.xcd_map = getenv("MOR_NO_XCD_MAP") ? 0 : 1;
+  d.nt_ground = getenv("MOR_NT_GROUND") ? atoi(getenv("MOR_NT_GROUND")) : 0;
   d.g_fast = 8; d.g_score = 64; d.g_pde = 256; d.g_box = 32;
   if (const char *tn = getenv("MOR_TUNE")) { int a, b2, c, e; if (sscanf(tn, "%d,%d,%d,%d", &a, &b2, &c, &e) == 4 && a > 0 && b2 > 0 && c > 0 && e > 0) { d.g_fast = a; d.g_score = b2; d.g_pde = c; d.g_box = e; } }
   d.use_hash = d.method == 1;
@@ -283,6 +286,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (getenv("MOR_PIPE_DEPTH")) b->pipe_depth = std::min(MOR_MAX_DEPTH, std::max(1, atoi(getenv("MOR_PIPE_DEPTH"))));
   b->n_slots = b->pipe_depth + 1;
   if (getenv("MOR_CG_P")) b->env_cg_p = atoi(getenv("MOR_CG_P"));
+  if (getenv("MOR_GC_P")) b->env_gc_p = atoi(getenv("MOR_GC_P"));
   if ((rc = configure(b)) != MOR_OK) return fail(rc);
   if (n_bad > MOR_TR_NB) return fail(set_error(MOR_ERR_INVALID, "n_bad = %d: windows longer than %d frames are not supported", n_bad, MOR_TR_NB));
   for (auto &ev : b->args_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
@@ -318,6 +322,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     d.row_order = dtab; d.n_rows = side * side;
   }
   d.Wcap = (int)(N / MOR_CHUNK + K + 2);
+  d.gc_chunks = (int)(N / 6144 + 1); d.gc_P = 1;   // (GC_CHUNK of mor_kernels.hip)
   d.moving_confidence = n_bad; d.static_confidence = n_good; d.leave_off = p->leave_off_distance; d.catch_up = p->catch_up_distance;
   // ---- shared by all frames: the cluster arrays (frame-slotted: cb, ca and the frames in flight behind them), the tracking state (strictly
   //      serial across frames), the sticky error words, the pinned host mirrors (written by the serial tracking / output steps)
@@ -340,7 +345,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     MorDev o = d; MorStreamArgs *dargs = nullptr;
     ok = dalloc(b, dargs, B) && dalloc(b, o.info, B) && hipMemset(o.info, 0, B * sizeof(MorFrameInfo)) == hipSuccess && dalloc(b, o.tickets, B * 8) && hipMemset(o.tickets, 0, B * 8 * sizeof(int)) == hipSuccess;
     ok = ok && dalloc(b, o.tile_cnt, B * T * 2) && dalloc(b, o.split_desc, B * T) && hipMemset(o.split_desc, 0, B * T * sizeof(unsigned long long)) == hipSuccess;   // (frame tags of the single-read split start at 1)
-    ok = ok && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, 2 * B * N) && dalloc(b, o.gp_idx, B * N) && dalloc(b, o.pkey, B * N) && dalloc(b, o.pcell, B * N) && dalloc(b, o.ppos, B * N) && dalloc(b, o.pslot, B * N);
+    ok = ok && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, 2 * B * N) && dalloc(b, o.gp_idx, B * N) && dalloc(b, o.pkey, B * N) && dalloc(b, o.pslot, B * N) && dalloc(b, o.gc_list, B * N) && dalloc(b, o.gc_ent, B * N) && dalloc(b, o.gc_n, B * (size_t)d.gc_chunks);
     ok = ok && dalloc(b, o.gh_rowlist, B * N) && dalloc(b, o.gh_cells, B * N) && dalloc(b, o.gh_rowfill, B * R1) && dalloc(b, o.gh_key, B * (size_t)d.Hcell) && dalloc(b, o.gh_val, B * (size_t)d.Hcell);
     ok = ok && dalloc(b, o.ckey, B * N) && dalloc(b, o.cstart, B * (N + 1)) && dalloc(b, o.row_start, B * R1) && dalloc(b, o.cmin, B * N) && dalloc(b, o.cmeta, 2 * B * N) && dalloc(b, o.crep, B * N) && dalloc(b, o.sorted, B * N) && dalloc(b, o.scell, B * N) && dalloc(b, o.csum, B * N);
     ok = ok && dalloc(b, o.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, o.lroot_a, B * N) && dalloc(b, o.lroot_b, B * N) && dalloc(b, o.parent, B * N) && dalloc(b, o.parent2, B * N) && dalloc(b, o.cg_ovf, B * (size_t)MOR_MAXP * MOR_CGS_OVF * 2);
@@ -415,6 +420,11 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     const int p_fit = (int)((maxocc * 3ull / 2 + 818) / 819), p_par = (512 + B - 1) / B;   // a slab's LDS holds 1024 cells (own + look-ahead); two 512-thread workgroups per CU
     d.P = b->env_cg_p > 0 ? b->env_cg_p : std::max(p_fit, p_par);
     d.P = std::max(1, std::min(d.P, std::min(MOR_MAXP, std::max(1, d.g.ny / 2))));
+    {  // grid build: workgroups per stream of k_gridcount / k_gridplace — one per chunk of 6144 points of the largest cloud the device last reported (+ 25 %), enough to fill the GPU
+      uint32_t mxM = 0; for (int s = 0; s < B; ++s) mxM = std::max(mxM, k > 0 ? d.h_info[s].M : (uint32_t)maxn);
+      const int want = (int)((mxM * 5ull / 4 + 6143) / 6144);
+      d.gc_P = b->env_gc_p > 0 ? b->env_gc_p : std::max(1, std::min(std::min(want, d.gc_chunks), std::max(1, 2048 / B)));
+    }
     d.cg_fused = (maxocc * 5ull / 4 <= MOR_CGS_FCAP && !getenv("MOR_CG_UNFUSED")) ? 1 : 0;   // (a stream beyond it runs the merge on global-memory arrays: correct, slow — hence the separate kernel when that is foreseeable)
     if (!getenv("MOR_GH_TIER")) d.gh_tier = maxocc * 5ull / 4 > 6144 ? (maxocc * 5ull / 4 > 12288 ? 2 : 1) : 0;   // table tier k_gridhash starts with (a stream whose table overflows moves up by itself)
   }
@@ -663,7 +673,7 @@ long long mor_debug_read(const mor_batch *b, const char *name, int s, void *out,
   const MorDev &d = b->d; const size_t N = d.Nmax, K = d.Kcap, S = MOR_MAXP + 1;
   struct Ent { const char *n; const void *p; size_t stride; };
   const Ent tab[] = {
-      {"ckey", d.ckey, N * 4}, {"cstart", d.cstart, (N + 1) * 4}, {"row_start", d.row_start, ((size_t)d.g.nrows + 1) * 4}, {"pcell", d.pcell, N * 4}, {"ppos", d.ppos, N * 4},
+      {"ckey", d.ckey, N * 4}, {"cstart", d.cstart, (N + 1) * 4}, {"row_start", d.row_start, ((size_t)d.g.nrows + 1) * 4}, 
       {"pkey", d.pkey, N * 4}, {"sorted", d.sorted, N * 16}, {"cloud", d.cloud, N * 16}, {"cmin", d.cmin, N * 4}, {"cmeta", d.cmeta, 2 * N * 16}, {"crep", d.crep, N * 16},
       {"slab_y", d.slab_y, S * 4}, {"slab_c", d.slab_c, S * 4}, {"slab_e", d.slab_e, S * 4}, {"lroot_a", d.lroot_a, N * 4}, {"lroot_b", d.lroot_b, N * 4},
       {"ccid", d.ccid, N * 4}, {"pcid", d.pcid, N * 4}, {"chash", d.chash, (size_t)d.Hcell * 16}, {"info", d.info, sizeof(MorFrameInfo)},

@@ -29,7 +29,7 @@
 const char *const mor_kernel_names[MK_COUNT] = {   // in MorKernelId order: "k_" + name = the __global__ function
     "classify", "scatter", "split", "heads_count", "heads_scatter", "cellboxes", "rhist", "rscan", "rscatter",
     "xform_prev", "cluster_pairs", "score_fast", "score_nb", "score_pde", "vox_clear", "vox_insert", "vox_probe",
-    "out_count", "out_scatter", "g2_cov_mid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridfill", "cg_slab", "cg_final", "clusters"};
+    "out_count", "out_scatter", "g2_cov_mid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridcount", "gridplace", "cg_slab", "cg_final", "clusters"};
 
 #ifdef MOR_EXP_STAMPS
 #define RS_T(v) const unsigned long long v = wall_clock64()
@@ -107,6 +107,16 @@ __device__ __forceinline__ void wg_prefix_total(const int *c, int stride, int t,
 
 __device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Stores of data nothing on the device reads again soon (the ground points: 90 % of a sweep, written once at the split, read at the
+// earliest when the caller fetches the filtered cloud): non-temporal, so they do not push the small hot arrays of the frames in
+// flight (a few MB per stream) out of the L2s and the Infinity Cache.
+__device__ __forceinline__ void st_stream(float4 *p, const float4 &v, int nt) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  if (nt) { const v4f w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<v4f *>(p)); }   // one global_store_dwordx4 … nt
+  else *p = v;
+}
+__device__ __forceinline__ void st_stream(int *p, int v, int nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
 
 // Error flags: into the frame's info record (reset at the start of every frame) and into the stream's sticky error word,
 // which the host reports and clears at its next wait — so an error of ANY frame of an asynchronous run is reported, and
@@ -335,8 +345,8 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
       d.cloud_tidx[so + k_ng] = k_ng + k_g;   // index in the trimmed cloud (both ranks are exclusive counts of earlier kept points)
       d.pkey[so + k_ng] = grid_key(G, cx, cy, cz);
     } else if (cls[it] == 1) {
-      d.ground[2 * so + d.Nmax + k_g] = p[it];   // final place in filterCloud's output: [kept cloud, right-aligned to slot Nmax | ground from slot Nmax]
-      d.gp_idx[so + k_g] = k_ng + k_g;
+      st_stream(&d.ground[2 * so + d.Nmax + k_g], p[it], d.nt_ground);   // final place in filterCloud's output: [kept cloud, right-aligned to slot Nmax | ground from slot Nmax]
+      st_stream(&d.gp_idx[so + k_g], k_ng + k_g, d.nt_ground);
     }
     r_ng += __popcll(m_ng[it]); r_g += __popcll(m_g[it]);
   }
@@ -353,9 +363,9 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
 // current one, so the reads of step i + 1 overlap the look-back and the stores of step i.  (Round 2's form — one workgroup per tile, all
 // resident at once, look-back over all earlier tiles — read, waited and stored in lock step: 91 µs against 44 µs without the look-back.)
 // All SP_G workgroups of a stream must get to run while their peers spin: 8 × B workgroups of 256 threads are a fraction of what the GPU
-// holds (8 per CU), and a peer that never shows up raises the "look-back stalled" flag after SPLIT_SPIN_LIMIT polls instead of hanging.
+// holds (16 × B workgroups against 8 per CU × 256 CUs), and a peer that never shows up raises the "look-back stalled" flag after SPLIT_SPIN_LIMIT polls instead of hanging.
 #ifndef SP_G
-#define SP_G 8
+#define SP_G 16   // measured alone, B = 64 × 120 000 points: 154 / 110 / 79 µs with 4 / 8 / 16 workgroups per stream (count + scatter passes: 36 + 58 µs and one more read of the cloud)
 #endif
 #define SPLIT_SPIN_LIMIT (1u << 22)
 __device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -420,8 +430,8 @@ __device__ __forceinline__ void split_tile(const MorDev &d, const MorGrid &G, in
       d.cloud[so + k_ng] = p[it];
       d.cloud_tidx[so + k_ng] = k_ng + k_g; d.pkey[so + k_ng] = grid_key(G, cx, cy, cz);
     } else if (cl[it] == 1) {
-      d.ground[2 * so + d.Nmax + k_g] = p[it];   // final place in filterCloud's output
-      d.gp_idx[so + k_g] = k_ng + k_g;
+      st_stream(&d.ground[2 * so + d.Nmax + k_g], p[it], d.nt_ground);   // final place in filterCloud's output
+      st_stream(&d.gp_idx[so + k_g], k_ng + k_g, d.nt_ground);
     }
     r_ng += __popcll(m_ng[it]); r_g += __popcll(m_g[it]);
   }
@@ -568,7 +578,6 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
           const int rl = skey[p] / G.nx;
           const int g = atomicAdd(&l_ng, 1); if (g < 64) { l_gap[3 * g] = rl; l_gap[3 * g + 1] = G.nrows; l_gap[3 * g + 2] = c + 1; } else for (int r = rl + 1; r <= G.nrows; ++r) rs[r] = c + 1;
         }
-        d.pcell[so + i] = c;     // compact cell id per cloud point
         float4 q = d.cloud[so + i]; q.w = __int_as_float(i);
         d.sorted[so + p] = q; if (d.scell) d.scell[so + p] = c;
       }
@@ -594,6 +603,7 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
 //   3. turns the counts into ranges of `sorted` and hands every point its position (LDS cursor per cell),
 // and a wide kernel (k_gridfill) moves the points.  The table doubles as the cell hash of the method-1 scoring tiers.
 // Streams with more cells than the LDS table holds run the same code on a table in global memory.
+#define CB_WTILE 256      // positions of `sorted` one wave of k_cellboxes handles per step (four consecutive ones per lane)
 #ifndef GH_T
 #define GH_T 1024
 #endif
@@ -694,16 +704,116 @@ __device__ __forceinline__ void gh_runs(int v, bool valid, int &leader, int &len
     len = (stop ? __ffsll((long long)stop) - 1 : 64) - lane;
   }
 }
+// The grid build over MANY workgroups per stream (round 2: one 1024-thread workgroup per stream swept all its points twice — 108 µs for
+// the 57 000-point stream of the bench batch, 664 µs for the 420 000-point streams of agg10).  The points of a stream are cut into chunks
+// of GC_CHUNK consecutive points; a chunk holds at most GC_CHUNK distinct cells, so its LDS table of GC_H slots can never overflow:
+//   k_gridcount  (gc_P workgroups per stream, chunk after chunk): counts the points of every cell of the chunk in an LDS hash table and
+//                writes the chunk's list of (cell key, count) and, per point, its entry in that list;
+//   k_gridhash   (one workgroup per stream): merges the chunk lists — a few hundred entries per chunk instead of thousands of points — into
+//                the stream's cell table, orders the cells, lays out the ranges and hands every chunk entry (cell id, first position);
+//   k_gridplace  (as k_gridcount): every point draws its position from its chunk entry's LDS cursor and moves there.
+// Points of one cell end up grouped by chunk and in arbitrary order inside a chunk's piece: every consumer tests existence, takes min / max,
+// counts or adds exact integers.
+#define GC_CHUNK 6144
+#define GC_H 8192
+#define GC_T 1024
+#define GC_U (GC_CHUNK / GC_T)
+__global__ __launch_bounds__(GC_T) void k_gridcount(MorDev d) {
+  int s, j; map_block(d.B, d.gc_P, s, j);
+  const int M = d.info[s].M, nch = (M + GC_CHUNK - 1) / GC_CHUNK, tid = threadIdx.x, lane = tid & 63;
+  const size_t so = (size_t)s * d.Nmax;
+  const int *pkey = d.pkey + so; int *pent = d.pslot + so;
+  __shared__ int l_key[GC_H], l_cnt[GC_H], l_sh[GC_T / 64 + 1];
+  constexpr unsigned hshift = 32 - 13, mask = GC_H - 1; static_assert(GC_H == 8192, "hshift");
+  for (int c = j; c < nch; c += d.gc_P) {
+    for (int i = tid; i < GC_H; i += GC_T) { l_key[i] = 0; l_cnt[i] = 0; }
+    __syncthreads();
+    const int i0 = c * GC_CHUNK, i1 = min(i0 + GC_CHUNK, M);
+    int key[GC_U], sl[GC_U];
+#pragma unroll
+    for (int u = 0; u < GC_U; ++u) { const int i = i0 + u * GC_T + tid; key[u] = i < i1 ? pkey[i] : -1; }
+#pragma unroll
+    for (int u = 0; u < GC_U; ++u) {
+      // points arrive in scan order: neighbouring lanes often hold the same cell (a wall next to the sensor: all 64) — the first lane of a
+      // run of equal keys counts the whole run with one LDS atomic (LDS atomics on one address serialise lane by lane)
+      const bool valid = key[u] >= 0;
+      int run_leader = lane, runlen = 1; bool worth = false;
+      gh_runs(key[u], valid, run_leader, runlen, worth);
+      unsigned h = hash_slot(max(key[u], 0), hshift);
+      if (valid && run_leader == lane) {
+        const int want = key[u] + 1;
+        for (;;) {   // (cannot overflow: ≤ GC_CHUNK distinct keys in GC_H slots)
+          int k = l_key[h];
+          if (k == 0) { k = atomicCAS(&l_key[h], 0, want); if (k == 0) k = want; }
+          if (k == want) break;
+          h = (h + 1) & mask;
+        }
+        atomicAdd(&l_cnt[h], runlen);
+      }
+      if (worth) h = (unsigned)__shfl((int)h, run_leader, 64);
+      sl[u] = (int)h;
+    }
+    __syncthreads();
+    // the claimed slots as a list (any order): every thread looks at GC_H / GC_T consecutive slots
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < GC_H / GC_T; ++q) mine += l_key[tid * (GC_H / GC_T) + q] != 0;
+    int total; int base = block_excl_scan_n<GC_T>(mine, l_sh, &total);
+    int2 *list = d.gc_list + so + (size_t)c * GC_CHUNK;
+#pragma unroll
+    for (int q = 0; q < GC_H / GC_T; ++q) {
+      const int h = tid * (GC_H / GC_T) + q, k = l_key[h];
+      if (k != 0) { list[base] = make_int2(k - 1, l_cnt[h]); l_cnt[h] = base; ++base; }   // the slot now names its entry
+    }
+    if (tid == 0) d.gc_n[(size_t)s * d.gc_chunks + c] = total;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < GC_U; ++u) { const int i = i0 + u * GC_T + tid; if (i < i1) pent[i] = l_cnt[sl[u]]; }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(GC_T) void k_gridplace(MorDev d) {
+  int s, j; map_block(d.B, d.gc_P, s, j);
+  const int M = d.info[s].M, nch = (M + GC_CHUNK - 1) / GC_CHUNK, tid = threadIdx.x, lane = tid & 63;
+  const size_t so = (size_t)s * d.Nmax;
+  const int *pent = d.pslot + so; const float4 *cloud = d.cloud + so; float4 *sorted = d.sorted + so; int *scell = d.scell + so;
+  __shared__ int l_cell[GC_CHUNK], l_cur[GC_CHUNK];
+  for (int c = j; c < nch; c += d.gc_P) {
+    const int ne = d.gc_n[(size_t)s * d.gc_chunks + c];
+    const int2 *ent = d.gc_ent + so + (size_t)c * GC_CHUNK;
+    for (int e = tid; e < ne; e += GC_T) { const int2 v = ent[e]; l_cell[e] = v.x; l_cur[e] = v.y; }
+    __syncthreads();
+    const int i0 = c * GC_CHUNK, i1 = min(i0 + GC_CHUNK, M);
+    int en[GC_U]; float4 q[GC_U];
+#pragma unroll
+    for (int u = 0; u < GC_U; ++u) { const int i = i0 + u * GC_T + tid; en[u] = i < i1 ? pent[i] : -1; q[u] = cloud[min(i, max(M - 1, 0))]; }
+#pragma unroll
+    for (int u = 0; u < GC_U; ++u) {
+      const bool valid = en[u] >= 0;
+      int run_leader = lane, runlen = 1; bool worth = false;
+      gh_runs(en[u], valid, run_leader, runlen, worth);
+      int base = 0;
+      if (valid && run_leader == lane) base = atomicAdd(&l_cur[en[u]], runlen);   // one cursor atomic per run of points of one cell
+      if (worth) base = __shfl(base, run_leader, 64);
+      if (valid) {
+        const int i = i0 + u * GC_T + tid, pos = base + (lane - run_leader);
+        q[u].w = __int_as_float(i);
+        sorted[pos] = q[u]; scell[pos] = l_cell[en[u]];
+      }
+    }
+    __syncthreads();
+  }
+}
 // TL / RL / CL: hash table / row table / per-cell lists in LDS (else global memory).  Returns false when the table
 // overflowed (nothing published yet: the caller re-runs with a bigger table).  `cells` lists the claimed slots in
 // discovery order — every per-cell phase walks it (a few entries per thread) instead of the whole table; `rowlist`
 // first holds the x of the cells of every row, then (same memory) the point counts in compact-id order.
-template <bool TL, bool RL, bool CL, bool AGG> __device__ __forceinline__ bool gh_run(const MorDev &d, const MorGrid &G, int s, int M, int *tkey, int *tval, int H, int cell_cap, int *rows, int *cells, int *rowlist, int *l_misc, int *l_sh) {
+template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(const MorDev &d, const MorGrid &G, int s, int M, int *tkey, int *tval, int H, int cell_cap, int *rows, int *cells, int *rowlist, int *l_misc, int *l_sh) {
   const size_t so = (size_t)s * d.Nmax;
-  const int *pkey = d.pkey + so; int *pslot = d.pslot + so, *ppos = d.ppos + so, *pcell = d.pcell + so;
   int *cstart = d.cstart + (size_t)s * (d.Nmax + 1), *ckey = d.ckey + so;
   const int nrows = G.nrows, nx = G.nx, tid = threadIdx.x;
-  constexpr bool agg = AGG;   // runs of equal keys in neighbouring lanes are counted with one atomic (dense clouds: k_gridhash picks the variant by the stream's point count)
+  const int nch = (M + GC_CHUNK - 1) / GC_CHUNK;
+  const int2 *clist = d.gc_list + so; int2 *cent = d.gc_ent + so; const int *cn = d.gc_n + (size_t)s * d.gc_chunks;
   int hbits = 0; while ((1 << hbits) < H) ++hbits;
   const unsigned hshift = 32 - hbits, mask = (unsigned)H - 1u;
   unsigned long long *chash = d.use_hash ? d.chash + 2 * (size_t)s * d.Hcell : nullptr;
@@ -712,40 +822,24 @@ template <bool TL, bool RL, bool CL, bool AGG> __device__ __forceinline__ bool g
   for (int i = tid; i < H; i += GH_T) { gh_st<TL>(tkey + i, 0); gh_st<TL>(tval + i, 0); }
   if (tid == 0) { l_misc[0] = 0; l_misc[1] = 0; }
   __syncthreads();
-  // ---- sweep 1: every point finds (or claims) the slot of its cell and counts itself; slot kept for sweep 2
-  for (int i0 = 0; i0 < M; i0 += GH_U * GH_T) {
-    int key[GH_U];   // GH_U points per thread and round trip (a sweep is M / (GH_U·1024) dependent rounds of global latency: 52 of them with four points for the 215 000-point clouds of agg10)
-#pragma unroll
-    for (int u = 0; u < GH_U; ++u) { const int i = i0 + u * GH_T + tid; key[u] = i < M ? pkey[i] : -1; }
+  // ---- sweep over the chunks' lists (k_gridcount: the distinct cells of every chunk of GC_CHUNK points with their point counts): every
+  //      entry finds (or claims) the slot of its cell and reserves its chunk's piece of the cell's range; (slot, offset in the cell) kept
+  for (int c = 0; c < nch; ++c) {
+    const int ne = cn[c];
     if (gh_ld<true>(&l_misc[1])) break;
-    unsigned h0[GH_U]; int k0[GH_U];   // first probe of the points as one batch of independent loads: nearly every point finds its cell's slot there
-#pragma unroll
-    for (int u = 0; u < GH_U; ++u) { h0[u] = hash_slot(max(key[u], 0), hshift); k0[u] = gh_ld<TL>(tkey + h0[u]); }
-#pragma unroll
-    for (int u = 0; u < GH_U; ++u) {
-      // Points arrive in scan order, so neighbouring lanes often hold the same cell (a wall next to the sensor: all 64): the first
-      // lane of a RUN of equal keys looks the slot up and counts the whole run with one LDS atomic; LDS atomics on one address
-      // serialise lane by lane, and they were what the sweeps of dense clouds spent their time on (agg10: 2.1 → 1.2 ms per step).
-      // Sparse clouds have runs of one or two points and would only pay for the bookkeeping: streams of < 65 536 points go lane by lane.
-      const bool valid = key[u] >= 0;
-      int run_leader = (int)(threadIdx.x & 63), runlen = 1; bool worth = false;
-      if (agg) gh_runs(key[u], valid, run_leader, runlen, worth);
-      const bool lead = valid && run_leader == (int)(threadIdx.x & 63);
-      const int want = key[u] + 1; unsigned h = h0[u]; bool ok = k0[u] == want;
-      if (lead) {
-        for (int probes = 0; !ok && probes < H; ++probes) {
-          int k = gh_ld<TL>(tkey + h);
-          if (k == 0) {
-            k = atomicCAS(tkey + h, 0, want);
-            if (k == 0) { k = want; const int n = atomicAdd(&l_misc[0], 1); if (n < cell_cap) gh_st<CL>(cells + n, (int)h); else gh_st<true>(&l_misc[1], 1); }
-          }
-          if (k == want) { ok = true; break; }
-          h = (h + 1) & mask;
+    for (int e = tid; e < ne; e += GH_T) {
+      const int2 kc = clist[(size_t)c * GC_CHUNK + e];
+      const int want = kc.x + 1; unsigned h = hash_slot(kc.x, hshift); bool ok = false;
+      for (int probes = 0; probes < H; ++probes) {
+        int k = gh_ld<TL>(tkey + h);
+        if (k == 0) {
+          k = atomicCAS(tkey + h, 0, want);
+          if (k == 0) { k = want; const int n = atomicAdd(&l_misc[0], 1); if (n < cell_cap) gh_st<CL>(cells + n, (int)h); else gh_st<true>(&l_misc[1], 1); }
         }
-        if (ok) atomicAdd(tval + h, runlen); else gh_st<true>(&l_misc[1], 1);
+        if (k == want) { ok = true; break; }
+        h = (h + 1) & mask;
       }
-      if (agg && worth) { h = (unsigned)__shfl((int)h, run_leader, 64); ok = __shfl((int)ok, run_leader, 64) != 0; }
-      if (valid && ok) pslot[i0 + u * GH_T + tid] = (int)h;
+      if (ok) cent[(size_t)c * GC_CHUNK + e] = make_int2((int)h, atomicAdd(tval + h, kc.y)); else gh_st<true>(&l_misc[1], 1);
     }
   }
   __syncthreads();
@@ -754,7 +848,7 @@ template <bool TL, bool RL, bool CL, bool AGG> __device__ __forceinline__ bool g
   ST2(stw, 1);
   // the scoring tiers' cell hash: a table of its own in global memory, eight slots per cell (neighbour lookups are mostly
   // UNSUCCESSFUL searches — ≈ 4 probes each at the load of this workgroup's LDS table, ≈ 1.1 at 1/8 — and a wave waits for the
-  // longest of its 64 × 26); cleared here, filled by k_gridfill
+  // longest of its 64 × 26); cleared here, filled below once the compact ids and ranges are known
   int xbits = 10; while ((1 << xbits) < 8 * nocc && (1 << xbits) < d.Hcell) ++xbits;   // (Hcell ≥ 1024: never beyond the allocation)
   if (chash) for (int i = tid; i < (2 << xbits); i += GH_T) chash[i] = 0ull;
   // ---- cells per row → row table
@@ -800,36 +894,39 @@ template <bool TL, bool RL, bool CL, bool AGG> __device__ __forceinline__ bool g
     gh_st<TL>(tkey + sl, c + 1);
   }
   __syncthreads();
+  auto ckey_of = [&](int c) { return __hip_atomic_load(ckey + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // (written by other threads of this workgroup two barriers ago)
   // ---- point counts in id order (same memory as the row lists) → first position of every cell
   int *cnt = rowlist;
   for (int e = tid; e < nocc; e += GH_T) { const int sl = gh_ld<CL>(cells + e); gh_st<CL>(cnt + gh_ld<TL>(tkey + sl) - 1, gh_ld<TL>(tval + sl)); }
   __syncthreads();
   gh_scan<CL>(cnt, nocc, l_sh);
-  for (int c = tid; c < nocc; c += GH_T) cstart[c] = gh_ld<CL>(cnt + c);
+  for (int c = tid; c < nocc; c += GH_T) {
+    const int b0 = gh_ld<CL>(cnt + c), n = (c + 1 < nocc ? gh_ld<CL>(cnt + c + 1) : M) - b0;
+    cstart[c] = b0;
+    // records of the cells that span wave tiles of k_cellboxes start from the neutral element (their pieces are merged with atomics)
+    if (b0 / CB_WTILE != (b0 + n - 1) / CB_WTILE) {
+      d.cmeta[2 * (so + c)] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f); d.cmeta[2 * (so + c) + 1] = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.f);
+      d.cmin[so + c] = 0x7fffffff;
+      MorCellSum z = {{0, 0, 0}, {0, 0, 0}}; d.csum[so + c] = z;
+    }
+    if (chash) {   // cell hash entry: (key + 1, compact id), (n, first position) — one 16-byte slot
+      const int key = ckey_of(c);
+      const unsigned hmask = (1u << xbits) - 1u; unsigned sl = hash_slot(key, 32 - xbits);
+      const unsigned long long ent = ((unsigned long long)((unsigned)key + 1u) << 32) | (unsigned)c;
+      while (atomicCAS(&chash[2 * sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
+      chash[2 * sl + 1] = ((unsigned long long)(unsigned)n << 32) | (unsigned)b0;
+    }
+  }
   if (tid == 0) { cstart[nocc] = M; d.info[s].n_occ = nocc; d.info[s].hshift = 32 - xbits; }
   for (int e = tid; e < nocc; e += GH_T) { const int sl = gh_ld<CL>(cells + e); gh_st<TL>(tval + sl, gh_ld<CL>(cnt + gh_ld<TL>(tkey + sl) - 1)); }
   __syncthreads();
   ST2(stw, 2);
-  // ---- sweep 2: position of every point inside its cell's range
-  for (int i0 = 0; i0 < M; i0 += GH_U * GH_T) {
-    int sl[GH_U];
-#pragma unroll
-    for (int u = 0; u < GH_U; ++u) { const int i = i0 + u * GH_T + tid; sl[u] = i < M ? pslot[i] : -1; }
-#pragma unroll
-    for (int u = 0; u < GH_U; ++u) {
-      const bool valid = sl[u] >= 0;
-      const int lane = (int)(threadIdx.x & 63);
-      int run_leader = lane, runlen = 1; bool worth = false;
-      if (agg) gh_runs(sl[u], valid, run_leader, runlen, worth);
-      const bool lead = valid && run_leader == lane;
-      int base = 0;
-      if (lead) base = atomicAdd(tval + sl[u], runlen);   // one cursor atomic per run of points of one cell
-      if (agg && worth) base = __shfl(base, run_leader, 64);
-      if (valid) {
-        const int i = i0 + u * GH_T + tid;
-        pcell[i] = gh_ld<TL>(tkey + sl[u]) - 1;
-        ppos[i] = base + (lane - run_leader);
-      }
+  // ---- every chunk entry: (slot, offset in the cell) → (compact cell id, first position of the chunk's piece); k_gridplace moves the points
+  for (int c = 0; c < nch; ++c) {
+    const int ne = cn[c];
+    for (int e = tid; e < ne; e += GH_T) {
+      const int2 so2 = cent[(size_t)c * GC_CHUNK + e];
+      cent[(size_t)c * GC_CHUNK + e] = make_int2(gh_ld<TL>(tkey + so2.x) - 1, gh_ld<TL>(tval + so2.x) + so2.y);
     }
   }
   ST2(stw, 3); ST2V(stw, 4, M); ST2V(stw, 5, nocc);
@@ -843,11 +940,10 @@ template <bool TL, bool RL, bool CL, bool AGG> __device__ __forceinline__ bool g
 #define GH_C0 6144
 #define GH_LDS_INTS (2 * GH_H + GH_ROWS + 1)
 static_assert(2 * GH_H0 + GH_ROWS + 1 + 2 * GH_C0 <= GH_LDS_INTS, "tier-0 layout must fit the tier-1 arena");
-#define GH_RUN(TL_, RL_, CL_, d_, ...) (dense ? gh_run<TL_, RL_, CL_, true>(d_, G, __VA_ARGS__) : gh_run<TL_, RL_, CL_, false>(d_, G, __VA_ARGS__))
+#define GH_RUN(TL_, RL_, CL_, d_, ...) gh_run<TL_, RL_, CL_>(d_, G, __VA_ARGS__)
 __global__ __launch_bounds__(GH_T) void k_gridhash(MorDev d) {
   const int s = blockIdx.x + d.s0, M = d.info[s].M;
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
-  const bool dense = M >= 65536;   // long runs of points of one cell in scan order: count them per run (gh_run)
   __shared__ int l_mem[GH_LDS_INTS], l_misc[4], l_sh[48];
   const bool rows_lds = G.nrows <= GH_ROWS;
   int *grows = d.row_start + (size_t)s * (d.g.nrows + 1);
@@ -871,7 +967,6 @@ __global__ __launch_bounds__(GH_T) void k_gridhash(MorDev d) {
   }
 }
 // ---- per-cell accumulators of the streaming cell pass (k_cellboxes): point box, smallest cloud index, exact coordinate sums
-#define CB_WTILE 256      // positions of `sorted` one wave handles per step (four consecutive ones per lane)
 struct CellAcc { float lx, ly, lz, hx, hy, hz; int mi; long long a[3], b[3]; };
 __device__ __forceinline__ void fx_split(float x, long long &a, long long &b) {   // x = a·2^-24 + b·2^-56 (MorCellSum); every step is exact for |x| ≥ 2^-32 (below: truncated at 2^-56)
   const double xd = (double)x, fa = floor(xd * 16777216.0);
@@ -907,8 +1002,8 @@ __device__ __forceinline__ CellAcc acc_shfl_up(const CellAcc &r, int o) {
 // float min / max through integer atomics (no NaNs here; −0 is folded into +0 first)
 __device__ __forceinline__ void atomic_fmin(float *p, float v) { v += 0.f; if (v >= 0.f) atomicMin((int *)p, __float_as_int(v)); else atomicMax((unsigned *)p, __float_as_uint(v)); }
 __device__ __forceinline__ void atomic_fmax(float *p, float v) { v += 0.f; if (v >= 0.f) atomicMax((int *)p, __float_as_int(v)); else atomicMin((unsigned *)p, __float_as_uint(v)); }
-// the record of cell c: alone (the cell lies inside one wave tile) or merged into what other waves deliver (k_gridfill /
-// k_cellinit initialised the records of the cells that span tiles)
+// the record of cell c: alone (the cell lies inside one wave tile) or merged into what other waves deliver (k_gridhash
+// initialised the records of the cells that span wave tiles)
 __device__ __forceinline__ void acc_emit(const MorDev &d, size_t so, int c, const CellAcc &r, bool shared) {
   float *lo = reinterpret_cast<float *>(&d.cmeta[2 * (so + c)]), *hi = lo + 4;
   MorCellSum *cs = d.csum + so + c;
@@ -922,36 +1017,6 @@ __device__ __forceinline__ void acc_emit(const MorDev &d, size_t so, int c, cons
     atomicMin(&d.cmin[so + c], r.mi);
 #pragma unroll
     for (int k = 0; k < 3; ++k) { atomicAdd((unsigned long long *)&cs->a[k], (unsigned long long)r.a[k]); atomicAdd((unsigned long long *)&cs->b[k], (unsigned long long)r.b[k]); }
-  }
-}
-__device__ __forceinline__ void cell_init_if_spanning(const MorDev &d, size_t so, const int *cstart, int c) {
-  const int b = cstart[c], e = cstart[c + 1];
-  if (b / CB_WTILE == (e - 1) / CB_WTILE) return;
-  d.cmeta[2 * (so + c)] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f); d.cmeta[2 * (so + c) + 1] = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.f);
-  d.cmin[so + c] = 0x7fffffff;
-  MorCellSum z = {{0, 0, 0}, {0, 0, 0}}; d.csum[so + c] = z;
-}
-// the points into cell order: sorted[position] = (x, y, z, bits(cloud index)), scell[position] = compact cell id
-__global__ __launch_bounds__(MOR_BT) void k_gridfill(MorDev d) {
-  int s, t0; map_block(d.B, d.tiles_m, s, t0);
-  const int M = d.info[s].M, nocc = d.info[s].n_occ;
-  const size_t so = (size_t)s * d.Nmax;
-  for (int i = t0 * MOR_BT + threadIdx.x; i < M; i += d.tiles_m * MOR_BT) {
-    float4 q = d.cloud[so + i]; q.w = __int_as_float(i);
-    const int pos = d.ppos[so + i];
-    d.sorted[so + pos] = q; d.scell[so + pos] = d.pcell[so + i];
-  }
-  const int *cstart = d.cstart + (size_t)s * (d.Nmax + 1);
-  unsigned long long *tab = d.use_hash ? d.chash + 2 * (size_t)s * d.Hcell : nullptr;
-  const unsigned hshift = d.info[s].hshift, hmask = (1u << (32 - hshift)) - 1u;
-  for (int c = t0 * MOR_BT + threadIdx.x; c < nocc; c += d.tiles_m * MOR_BT) {
-    cell_init_if_spanning(d, so, cstart, c);
-    if (tab) {   // cell hash entry: (key + 1, compact id); the table was cleared by k_gridhash
-      const int key = d.ckey[so + c]; unsigned sl = hash_slot(key, hshift);
-      const unsigned long long ent = ((unsigned long long)((unsigned)key + 1u) << 32) | (unsigned)c;
-      while (atomicCAS(&tab[2 * sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
-      tab[2 * sl + 1] = ((unsigned long long)(unsigned)(cstart[c + 1] - cstart[c]) << 32) | (unsigned)cstart[c];
-    }
   }
 }
 // ------------------------------------------------------------------------------------ C1: Euclidean clustering = connected components over cells
@@ -1071,7 +1136,7 @@ __device__ __forceinline__ int cg_lower_bound8(const int *key, int lo, int n, in
 // consecutive positions, four per lane; a lane folds its four points serially, the open runs at lane boundaries go
 // through a segmented scan over the lanes (19 words × 6 shuffles per 256 points), and whoever holds the last point of a
 // cell writes its record.  Cells that continue into another wave tile are merged with atomics (min / max / integer
-// add: order-free), their records were initialised by k_gridfill.
+// add: order-free), their records were initialised by k_gridhash.
 __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
   int s, bx; map_block(d.B, d.g_box, s, bx);
   const int M = d.info[s].M, lane = lane_id();
@@ -1735,10 +1800,10 @@ __global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
     const int M = d.info[s].M;
     float4 *dst = d.cl_pts[d.cur] + so; int *dcid = d.cl_cid[d.cur] + so;
     for (int j = t * MOR_BT + threadIdx.x; j < M; j += d.tiles_m * MOR_BT) {
-      d.pcid[so + j] = d.ccid[so + d.pcell[so + j]];
-      const int4 g = d.cgat[so + d.scell[so + j]];
-      if (g.y < 0) continue;
       const float4 p = d.sorted[so + j];
+      const int4 g = d.cgat[so + d.scell[so + j]];
+      d.pcid[so + __float_as_int(p.w)] = g.y;   // label of the cloud point (its index travels in .w)
+      if (g.y < 0) continue;
       dst[j + g.x] = p; dcid[j + g.x] = g.y;
       if (__float_as_int(p.w) == g.z) d.cl_first[d.cur][ko + g.y] = p;
     }
@@ -3092,10 +3157,12 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
 }
 
 // ------------------------------------------------------------------------------------ launch sequences
+static int mor_exp_dup() { static const int v = getenv("MOR_EXP_DUP") ? atoi(getenv("MOR_EXP_DUP")) : -1; return v; }   // experiment: launch kernel <id> twice (idempotent kernels only)
 #define MOR_LAUNCH(id, kern, grid, ...)                                   \
   do {                                                                    \
     mor_timer_begin(tm, id, st);                                          \
     hipLaunchKernelGGL(kern, grid, dim3(MOR_BT), 0, st, __VA_ARGS__);     \
+    if (mor_exp_dup() == (int)(id)) hipLaunchKernelGGL(kern, grid, dim3(MOR_BT), 0, st, __VA_ARGS__); \
     mor_timer_end(tm, id, st);                                            \
   } while (0)
 
@@ -3113,10 +3180,15 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
   if (part == 1) return;
 grid:
   if (d.gmode != 1) {   // clustering grid by counting (k_gridhash); the VoxelGrid pass of the voxel ground variant needs the points of a voxel in index order: sort
+    mor_timer_begin(tm, MK_GRIDCOUNT, st);
+    hipLaunchKernelGGL(k_gridcount, dim3(d.B * d.gc_P), dim3(GC_T), 0, st, d);
+    mor_timer_end(tm, MK_GRIDCOUNT, st);
     mor_timer_begin(tm, MK_GRIDHASH, st);
     hipLaunchKernelGGL(k_gridhash, gB, dim3(GH_T), 0, st, d);
     mor_timer_end(tm, MK_GRIDHASH, st);
-    MOR_LAUNCH(MK_GRIDFILL, k_gridfill, gM, d);
+    mor_timer_begin(tm, MK_GRIDPLACE, st);
+    hipLaunchKernelGGL(k_gridplace, dim3(d.B * d.gc_P), dim3(GC_T), 0, st, d);
+    mor_timer_end(tm, MK_GRIDPLACE, st);
   } else {
     for (int pass = 0; pass < d.cell_passes; ++pass) {   // points sorted by cell key; result in (skey, sidx) = buffers [cell_passes & 1]
       MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0, d.tiles_m <= 64};
@@ -3168,6 +3240,7 @@ static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLau
 static void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // slabs (+ merge in each stream's last slab workgroup), or slabs | merge
   mor_timer_begin(tm, MK_CG_SLAB, st);
   hipLaunchKernelGGL(k_cg_slab<CGS_CAP>, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
+  if (mor_exp_dup() == MK_CG_SLAB && !d.cg_fused) hipLaunchKernelGGL(k_cg_slab<CGS_CAP>, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
   mor_timer_end(tm, MK_CG_SLAB, st);
   if (d.cg_fused) return;
   mor_timer_begin(tm, MK_CG_FINAL, st);
