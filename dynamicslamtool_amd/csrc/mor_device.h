@@ -93,6 +93,7 @@ struct MorDev {
   int g_fast, g_score, g_pde, g_box;   // launch widths: k_score_fast workgroups per cloud tile, workgroups per stream of the worklist tiers / the wave tier / k_cellboxes (MOR_TUNE)
   int xcd_map;               // 1: the workgroups of a stream share an XCD (its tables stay in that L2); 0: streams spread over all XCDs
   int nt_ground;             // non-temporal stores for the ground points at the split (MOR_NT_GROUND, experiment)
+  int sp_g;                  // workgroups per stream of the single-read split (2 … 64)
   int two_pass_split;        // 1 (default): count pass + scatter pass; 0: the single-pass split with decoupled look-back (MOR_SINGLE_PASS_SPLIT)
   int cur, prev, has_prev;   // cluster-array slots of cb and ca (four slots rotate: up to three frames are in flight in the stage pipeline); whether ca exists (:534)
   int run_tracker;           // filter: advance the tracking loop (first filterCloud of this frame)
@@ -138,8 +139,8 @@ struct MorDev {
   int *cstart;               // [B][Nmax+1]  first sorted position of each occupied cell
   int *row_start;            // [B][nrows+1]  first occupied cell of each (y,z) row
   int *gnz, *gnz_out; int cg_nz; float cg_inv_cs;   // voxel ground variant: z layers of the clustering grid per stream (stream_grid); written by pass A through gnz_out
-  unsigned long long *chash; // [B][Hcell]  open-addressing hash set of the occupied cells: (key+1) << 32 | compact id, 0 = empty (method 1 only)
-  int Hcell, use_hash;       // table capacity per stream (power of two ≥ 4·Nmax); whether this pass builds it
+  unsigned short *rs16, *cx16; int rs16_stride;   // [B][rs16_stride], [B][Nmax]  16-bit copies of the row table and of the x of every occupied cell: the cell index the method-1 scoring tiers keep in LDS
+  int Hcell, use_hash;       // capacity per stream of the grid build's global-memory cell table (power of two ≥ 4·Nmax); whether the 16-bit index is written (method 1)
   int *cmin;                 // [B][Nmax]  smallest cloud index in the cell
   float4 *cmeta;             // [B][2·Nmax]  per occupied cell: low corner of its point box (.w = cluster id bits), high corner
   float4 *crep;              // [B][Nmax]  per occupied cell: its first point (sample for the quick edge test of the cell graph)
@@ -226,5 +227,6 @@ struct MorLaunchTimer;   // engine-owned; records event pairs when enabled
 //            4 transform of ca … thread tiers of the scores | 5 wave tier | 6 thresholds + tracking
 void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer *tm);
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part);
+int mor_split_blocks_per_cu();
 void mor_timer_begin(MorLaunchTimer *tm, int kernel_id, hipStream_t st);
 void mor_timer_end(MorLaunchTimer *tm, int kernel_id, hipStream_t st);

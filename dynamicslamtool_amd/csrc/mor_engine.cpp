@@ -16,7 +16,6 @@
 #include <vector>
 
 #define MOR_ARGS_RING 8
-#define SP_G_HOST 16   // workgroups per stream of k_split (SP_G in mor_kernels.hip)
 
 // The frame pipeline wants its four lane streams on four different hardware queues.  The ROCm runtime multiplexes
 // streams onto GPU_MAX_HW_QUEUES (default 4) queues in creation order, so with the batch's main stream two lanes share
@@ -186,10 +185,17 @@ static int configure(mor_batch *b) {
   }
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
   d.two_pass_split = (getenv("MOR_SINGLE_PASS_SPLIT") && atoi(getenv("MOR_SINGLE_PASS_SPLIT")) == 0) ? 1 : 0;   // default: the single-read split (k_split); MOR_SINGLE_PASS_SPLIT=0: count pass + scatter pass (what pass A of the voxel ground variant always uses)
-  if ((size_t)b->B * SP_G_HOST > 4096) d.two_pass_split = 1;   // (all workgroups of the single-read split have to be resident together)
+  {  // all workgroups of the single-read split should be resident together (peers spin on each other): what the device holds of them, with a margin of a half for the kernels of other frames
+    int ncu = 256; hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b->device);
+    const int hold = std::max(1, mor_split_blocks_per_cu()) * ncu / 2;
+    d.sp_g = std::max(2, std::min(32, hold / b->B));   // (64 per stream stalled on the 1 M-point clouds of agg10 — cause not found; 32 and fewer are what the suite runs)
+    if (getenv("MOR_SP_G")) d.sp_g = std::max(2, std::min(32, atoi(getenv("MOR_SP_G"))));
+    if (b->B * 2 > hold) d.two_pass_split = 1;
+    if (getenv("MOR_DEBUG")) fprintf(stderr, "mor: k_split %d workgroups per CU, sp_g %d\n", mor_split_blocks_per_cu(), d.sp_g);
+  }
   d.xcd_map = getenv("MOR_NO_XCD_MAP") ? 0 : 1;
   d.nt_ground = getenv("MOR_NT_GROUND") ? atoi(getenv("MOR_NT_GROUND")) : 0;
-  d.g_fast = 8; d.g_score = 64; d.g_pde = 256; d.g_box = 32;
+  d.g_fast = 16; d.g_score = 16; d.g_pde = 256; d.g_box = 32;   // workgroups per stream: tier 1 (1024 threads each), tiers 1a / 1b (512 threads, g_score each), wave tier, cell boxes
   if (const char *tn = getenv("MOR_TUNE")) { int a, b2, c, e; if (sscanf(tn, "%d,%d,%d,%d", &a, &b2, &c, &e) == 4 && a > 0 && b2 > 0 && c > 0 && e > 0) { d.g_fast = a; d.g_score = b2; d.g_pde = c; d.g_box = e; } }
   d.use_hash = d.method == 1;
   { size_t hc = 1024; while (hc < 4 * (size_t)d.Nmax) hc <<= 1; d.Hcell = (int)hc; }
@@ -323,6 +329,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   }
   d.Wcap = (int)(N / MOR_CHUNK + K + 2);
   d.gc_chunks = (int)(N / 6144 + 1); d.gc_P = 1;   // (GC_CHUNK of mor_kernels.hip)
+  d.rs16_stride = (int)(((size_t)std::max(d.g.nrows, d.gv.nrows) + 1 + 7) & ~(size_t)7);
   d.moving_confidence = n_bad; d.static_confidence = n_good; d.leave_off = p->leave_off_distance; d.catch_up = p->catch_up_distance;
   // ---- shared by all frames: the cluster arrays (frame-slotted: cb, ca and the frames in flight behind them), the tracking state (strictly
   //      serial across frames), the sticky error words, the pinned host mirrors (written by the serial tracking / output steps)
@@ -355,7 +362,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = ok && dalloc(b, o.nn_fwd, B * K) && dalloc(b, o.nn_bwd, B * K) && dalloc(b, o.nn_fwd_d, B * K) && dalloc(b, o.pair_q, B * K) && dalloc(b, o.pair_m, B * K) && dalloc(b, o.pair_d, B * K);
     ok = ok && dalloc(b, o.pair_cnt, B * K) && dalloc(b, o.pair_of_prev, B * K) && dalloc(b, o.pair_of_cur, B * K) && dalloc(b, o.det, B * K);
     ok = ok && dalloc(b, o.wl, B * N) && dalloc(b, o.wl_nb, B) && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B);
-    if (d.use_hash) ok = ok && dalloc(b, o.chash, 2 * B * (size_t)d.Hcell); else o.chash = nullptr;
+    ok = ok && dalloc(b, o.rs16, B * (size_t)d.rs16_stride) && dalloc(b, o.cx16, B * N);
     if (p->method_choice == 2) ok = ok && dalloc(b, o.vox, B * (size_t)d.Hcap);
     ok = ok && dalloc(b, o.moving, B * K + B) && hipMemset(o.moving, 0, B * K + B) == hipSuccess && dalloc(b, o.otile_cnt, B * T);
     ok = ok && dalloc(b, o.zmin_i, B) && dalloc(b, o.zmax_i, B) && dalloc(b, o.zorg, B) && dalloc(b, o.zbase, B) && hipMemset(o.zbase, 0, B * sizeof(int)) == hipSuccess && dalloc(b, o.mode_bin, B);
@@ -425,7 +432,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
       const int want = (int)((mxM * 5ull / 4 + 6143) / 6144);
       d.gc_P = b->env_gc_p > 0 ? b->env_gc_p : std::max(1, std::min(std::min(want, d.gc_chunks), std::max(1, 2048 / B)));
     }
-    d.cg_fused = (maxocc * 5ull / 4 <= MOR_CGS_FCAP && !getenv("MOR_CG_UNFUSED")) ? 1 : 0;   // (a stream beyond it runs the merge on global-memory arrays: correct, slow — hence the separate kernel when that is foreseeable)
+    d.cg_fused = (maxocc * 11ull / 10 <= MOR_CGS_FCAP && !getenv("MOR_CG_UNFUSED")) ? 1 : 0;   // (a stream beyond it runs the merge on global-memory arrays: correct, slow — hence the separate kernel when that is foreseeable)
     if (!getenv("MOR_GH_TIER")) d.gh_tier = maxocc * 5ull / 4 > 6144 ? (maxocc * 5ull / 4 > 12288 ? 2 : 1) : 0;   // table tier k_gridhash starts with (a stream whose table overflows moves up by itself)
   }
   d.cur = (int)(k % b->n_slots); d.prev = (int)((k + b->n_slots - 1) % b->n_slots); d.has_prev = k > 0; d.out_ptrs = nullptr; d.run_tracker = 0; d.frame_no = (int)k;
@@ -676,7 +683,7 @@ long long mor_debug_read(const mor_batch *b, const char *name, int s, void *out,
       {"ckey", d.ckey, N * 4}, {"cstart", d.cstart, (N + 1) * 4}, {"row_start", d.row_start, ((size_t)d.g.nrows + 1) * 4}, 
       {"pkey", d.pkey, N * 4}, {"sorted", d.sorted, N * 16}, {"cloud", d.cloud, N * 16}, {"cmin", d.cmin, N * 4}, {"cmeta", d.cmeta, 2 * N * 16}, {"crep", d.crep, N * 16},
       {"slab_y", d.slab_y, S * 4}, {"slab_c", d.slab_c, S * 4}, {"slab_e", d.slab_e, S * 4}, {"lroot_a", d.lroot_a, N * 4}, {"lroot_b", d.lroot_b, N * 4},
-      {"ccid", d.ccid, N * 4}, {"pcid", d.pcid, N * 4}, {"chash", d.chash, (size_t)d.Hcell * 16}, {"info", d.info, sizeof(MorFrameInfo)},
+      {"ccid", d.ccid, N * 4}, {"pcid", d.pcid, N * 4}, {"info", d.info, sizeof(MorFrameInfo)},
       {"xcent", d.xcent, K * 16}, {"xamin", d.xamin, K * 16}, {"xamax", d.xamax, K * 16}, {"xfirst", d.xfirst, K * 16}, {"g2_big", d.g2_big, N * 4}, {"g2_nbig", d.g2_nbig, 4}, {"vbin", d.vbin, N * 4}, {"scell", d.scell, N * 4}, {"cgat", d.cgat, N * 16}, {"csum", d.csum, N * 48}, {"clist", d.clist, N * 4}, {"cl_pts_prev", d.cl_pts[d.prev], N * 16}, {"cl_pts", d.cl_pts[d.cur], N * 16}};
   for (const Ent &e : tab) if (!strcmp(e.n, name)) {
     if (!e.p) return set_error(MOR_ERR_INVALID, "array %s is not allocated in this configuration", name);

@@ -354,19 +354,18 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   }
 }
 
-// Single-READ variant of k_classify + k_scatter (crop-box variant and pass B of the voxel variant).  SP_G workgroups per stream walk the
-// stream's tiles round-robin (workgroup g: tiles g, g + SP_G, …), so at every step the SP_G workgroups of a stream hold SP_G consecutive
+// Single-READ variant of k_classify + k_scatter (crop-box variant and pass B of the voxel variant).  sp_g workgroups per stream walk the
+// stream's tiles round-robin (workgroup g: tiles g, g + sp_g, …), so at every step the sp_g workgroups of a stream hold sp_g consecutive
 // tiles.  A tile's output offsets are the counts of all earlier tiles: a workgroup carries the prefix of its previous tile along and adds
-// the aggregates of the ≤ SP_G − 1 tiles in between, which its peers publish — right after their loads have landed — in 64-bit descriptors
+// the aggregates of the ≤ sp_g − 1 tiles in between, which its peers publish — right after their loads have landed — in 64-bit descriptors
 // tagged with the frame (no reset pass; polled and published with agent-scope accesses: a stream's workgroups share an XCD under map_block,
 // but correctness does not depend on it).  The loads of a workgroup's NEXT tile are issued before it waits for the descriptors of the
 // current one, so the reads of step i + 1 overlap the look-back and the stores of step i.  (Round 2's form — one workgroup per tile, all
 // resident at once, look-back over all earlier tiles — read, waited and stored in lock step: 91 µs against 44 µs without the look-back.)
-// All SP_G workgroups of a stream must get to run while their peers spin: 8 × B workgroups of 256 threads are a fraction of what the GPU
+// All sp_g workgroups of a stream must get to run while their peers spin: sp_g × B ≤ 2048 workgroups of 256 threads are what the GPU
 // holds (16 × B workgroups against 8 per CU × 256 CUs), and a peer that never shows up raises the "look-back stalled" flag after SPLIT_SPIN_LIMIT polls instead of hanging.
-#ifndef SP_G
-#define SP_G 16   // measured alone, B = 64 × 120 000 points: 154 / 110 / 79 µs with 4 / 8 / 16 workgroups per stream (count + scatter passes: 36 + 58 µs and one more read of the cloud)
-#endif
+// d.sp_g workgroups per stream (2 … 64, chosen by the host so that all of them are resident together: 2048 / B).  Measured alone, B = 64 ×
+// 120 000 points: 154 / 110 / 79 µs with 4 / 8 / 16 workgroups per stream (count + scatter passes: 36 + 58 µs and one more read of the cloud).
 #define SPLIT_SPIN_LIMIT (1u << 22)
 __device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // loads only (no use of the data here: the wait for them belongs to split_tile, a step later); cls carries the ground flag of pass B
@@ -409,7 +408,7 @@ __device__ __forceinline__ void split_tile(const MorDev &d, const MorGrid &G, in
       }
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { an += __shfl_xor(an, o, 64); ag += __shfl_xor(ag, o, 64); }   // (lanes 0 … SP_G − 2 carry values: SP_G ≤ 16)
+    for (int o = 32; o > 0; o >>= 1) { an += __shfl_xor(an, o, 64); ag += __shfl_xor(ag, o, 64); }   // (lanes 0 … sp_g − 2 carry values: sp_g ≤ 64)
     if (lane == 0) {
       s_ex[0] = ex_ng + an; s_ex[1] = ex_g + ag;
       if (t == nt - 1) publish_split(d, s, ex_ng + an + tng, ex_g + ag + tg);   // the stream's last tile: T, M, G of the frame
@@ -438,8 +437,8 @@ __device__ __forceinline__ void split_tile(const MorDev &d, const MorGrid &G, in
   __syncthreads();
 }
 __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
-  int s, g; map_block(d.B, SP_G, s, g);
-  static_assert(SP_G <= 16 && SP_G >= 2, "the look-back sums 16 lanes");
+  int s, g; map_block(d.B, d.sp_g, s, g);
+  const int SP_G = d.sp_g;
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const MorStreamArgs a = d.args[s];
   const uint32_t n_in = pass_count(d, a, s);
@@ -483,47 +482,55 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_count(MorDev d) {
     if (threadIdx.x == 0) d.ktile_cnt[(size_t)s * d.tiles_max + t] = tot;
   }
 }
-// ------------------------------------------------------------------------------------ cell hash (method-1 scoring)
-// The scoring tiers look cells up by coordinates a few million times per batch.  Through the row table that is a chain
-// of dependent loads (row bounds → keys → …); a hash probe is one.  Open addressing, linear probing, load ≤ 1/4.
-__device__ __forceinline__ unsigned hash_slot(int key, unsigned hshift) { return ((unsigned)key * 0x9E3779B1u) >> hshift; }
-// A slot of the cell hash is two 64-bit words: (key + 1) << 32 | compact id (0 = empty), and n << 32 | b0 — the cell's range
-// of `sorted`, so a probe that is loaded as one 16-byte entry brings what the first tier needs without another round trip.
-__device__ __forceinline__ int hash_resolve(const unsigned long long *tab, unsigned hshift, int key, unsigned sl, unsigned long long e) {
-  const unsigned mask = (1u << (32 - hshift)) - 1u;
-  for (;;) {   // e = tab[2·sl] was fetched by the caller (first probes of a batch are independent loads)
-    if (e == 0ull) return -1;
-    if ((unsigned)(e >> 32) == (unsigned)key + 1u) return (int)(unsigned)e;
-    sl = (sl + 1) & mask; e = tab[2 * sl];
+// ------------------------------------------------------------------------------------ cell index of the scoring tiers (method 1)
+// The scoring tiers look cells up by coordinates a few million times per batch.  Round 2 did that through a hash table in global memory
+// (16-byte slots, eight per cell: cleared — 33 MB per step — and filled by the grid build, probed with random 16-byte loads that every
+// other kernel in flight paid for).  The grid is small: a stream has a few thousand occupied cells in a few thousand (y,z) rows, so every
+// scoring workgroup now keeps the stream's ROW TABLE (first compact id of every row) and the x of every cell in its own LDS as 16-bit
+// values (k_gridhash writes them once per frame: rs16, cx16) and a lookup is two LDS reads plus a short scan of the row — no global access.
+// Streams whose tables do not fit (more than CIDX_CAP entries, or ≥ 65 536 cells) use the 32-bit tables in global memory (L2).
+#define CIDX_CAP 12288   // 16-bit entries per workgroup (24 KB: six 256-thread workgroups per CU)
+struct CellIdx { const unsigned short *rs16, *cx16; const int *rs, *ckey; int nx, ny, nz; bool lds; };
+__device__ __forceinline__ CellIdx cidx_load(const MorDev &d, const MorGrid &G, int s, unsigned short *l_idx) {   // l_idx null: the global tables (kernels with a handful of lookups per workgroup)
+  CellIdx I; I.nx = G.nx; I.ny = G.ny; I.nz = G.nz;
+  I.rs = d.row_start + (size_t)s * (d.g.nrows + 1); I.ckey = d.ckey + (size_t)s * d.Nmax;
+  const int nocc = (int)d.info[s].n_occ, nr = G.nrows + 1;
+  I.lds = l_idx != nullptr && nocc <= 65535 && nr + nocc + 2 <= CIDX_CAP;
+  const int nr2 = (nr + 1) & ~1;   // (the x table starts at an even entry: both tables are copied two entries at a time)
+  if (I.lds) {
+    const unsigned *g_rs = reinterpret_cast<const unsigned *>(d.rs16 + (size_t)s * d.rs16_stride), *g_cx = reinterpret_cast<const unsigned *>(d.cx16 + (size_t)s * d.Nmax);
+    unsigned *l32 = reinterpret_cast<unsigned *>(l_idx);
+    for (int i = threadIdx.x; i < nr2 / 2; i += blockDim.x) l32[i] = g_rs[i];
+    for (int i = threadIdx.x; i < (nocc + 1) / 2; i += blockDim.x) l32[nr2 / 2 + i] = g_cx[i];
+    I.rs16 = l_idx; I.cx16 = l_idx + nr2;
+  } else { I.rs16 = nullptr; I.cx16 = nullptr; }
+  if (l_idx) __syncthreads();
+  return I;
+}
+// occupied cells with x in [x0, x1] of row (cy,cz): the consecutive compact ids [lo, hi)  (cy, cz inside the grid)
+__device__ __forceinline__ void cidx_row(const CellIdx &I, int x0, int x1, int cy, int cz, int &lo, int &hi) {
+  const int r = cy * I.nz + cz;
+  if (!I.lds) {
+    const int e = I.rs[r + 1], base = r * I.nx; int a = I.rs[r], b = e; const int k0 = base + x0, k1 = base + x1;
+    while (a < b) { const int m = (a + b) >> 1; if (I.ckey[m] < k0) a = m + 1; else b = m; }
+    lo = a; b = e;
+    while (a < b) { const int m = (a + b) >> 1; if (I.ckey[m] <= k1) a = m + 1; else b = m; }
+    hi = a; return;
   }
+  int a = I.rs16[r]; const int e = I.rs16[r + 1];
+  if (e - a > 8) { int b = e; while (a < b) { const int m = (a + b) >> 1; if ((int)I.cx16[m] < x0) a = m + 1; else b = m; } }   // long row (a wall along x)
+  else while (a < e && (int)I.cx16[a] < x0) ++a;
+  lo = a;
+  while (a < e && (int)I.cx16[a] <= x1) ++a;   // (windows are a few cells wide)
+  hi = a;
 }
-// N lookups of one thread resolved in LOCK-STEP: round r loads probe r of every lookup still open (independent loads), so
-// a thread waits max-over-lookups round trips, not their sum.  (Resolved one after the other — N while-loops in program
-// order — the 26 neighbour lookups of k_score_block cost a wave 30 µs: most of them are unsuccessful searches, ≈ 1.7 probes
-// each at load 1/3 and a long tail; the wave pays the sum for its unluckiest lane.)  key < 0: no lookup; ent = first probes.
-template <int N> __device__ __forceinline__ void hash_resolve_all(const unsigned long long *tab, unsigned hshift, const int (&key)[N], int (&id)[N]) {
-  const unsigned mask = (1u << (32 - hshift)) - 1u;
-  const unsigned *t32 = reinterpret_cast<const unsigned *>(tab);   // slot = four 32-bit words: compact id, key + 1, b0, n
-  unsigned open = 0;
-#pragma unroll
-  for (int i = 0; i < N; ++i) { id[i] = -1; if (key[i] >= 0) open |= 1u << i; }
-  for (unsigned r = 0; open; ++r) {   // every open lookup is at its r-th probe
-    unsigned kw[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) kw[i] = t32[4 * ((hash_slot(max(key[i], 0), hshift) + r) & mask) + 1];   // (closed lookups re-read their last slot: no branch around the loads)
-#pragma unroll
-    for (int i = 0; i < N; ++i) if ((open >> i) & 1u) {
-      if (kw[i] == 0u) open &= ~(1u << i);
-      else if (kw[i] == (unsigned)key[i] + 1u) { id[i] = (int)((hash_slot(key[i], hshift) + r) & mask); open &= ~(1u << i); }   // slot for now; its id is fetched below
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) if (id[i] >= 0) id[i] = (int)t32[4 * id[i]];
+// compact id of cell (cx,cy,cz) or −1 when empty / outside
+__device__ __forceinline__ int cidx_find(const CellIdx &I, int cx, int cy, int cz) {
+  if ((unsigned)cx >= (unsigned)I.nx || (unsigned)cy >= (unsigned)I.ny || (unsigned)cz >= (unsigned)I.nz) return -1;
+  int lo, hi; cidx_row(I, cx, cx, cy, cz, lo, hi);
+  return lo < hi ? lo : -1;
 }
-__device__ __forceinline__ int hash_find(const unsigned long long *tab, unsigned hshift, int key) {
-  const unsigned sl = hash_slot(key, hshift);
-  return hash_resolve(tab, hshift, key, sl, tab[2 * sl]);
-}
+__device__ __forceinline__ unsigned hash_slot(int key, unsigned hshift) { return ((unsigned)key * 0x9E3779B1u) >> hshift; }   // (the LDS / global cell tables of the grid build)
 // linear key of cell (cx,cy,cz), −1 outside the grid
 __device__ __forceinline__ int cell_key(const MorGrid &g, int cx, int cy, int cz) {
   if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cy >= (unsigned)g.ny || (unsigned)cz >= (unsigned)g.nz) return -1;
@@ -816,7 +823,7 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
   const int2 *clist = d.gc_list + so; int2 *cent = d.gc_ent + so; const int *cn = d.gc_n + (size_t)s * d.gc_chunks;
   int hbits = 0; while ((1 << hbits) < H) ++hbits;
   const unsigned hshift = 32 - hbits, mask = (unsigned)H - 1u;
-  unsigned long long *chash = d.use_hash ? d.chash + 2 * (size_t)s * d.Hcell : nullptr;
+  unsigned short *rs16 = d.rs16 + (size_t)s * d.rs16_stride, *cx16 = d.cx16 + so;   // 16-bit copies of the row table and the cells' x for the scoring tiers (cidx_load)
   const size_t stw = (size_t)s * (MOR_MAXP + 2) + MOR_MAXP; (void)stw;
   ST2(stw, 0);
   for (int i = tid; i < H; i += GH_T) { gh_st<TL>(tkey + i, 0); gh_st<TL>(tval + i, 0); }
@@ -846,11 +853,6 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
   if (l_misc[1]) { __syncthreads(); return false; }
   const int nocc = l_misc[0];
   ST2(stw, 1);
-  // the scoring tiers' cell hash: a table of its own in global memory, eight slots per cell (neighbour lookups are mostly
-  // UNSUCCESSFUL searches — ≈ 4 probes each at the load of this workgroup's LDS table, ≈ 1.1 at 1/8 — and a wave waits for the
-  // longest of its 64 × 26); cleared here, filled below once the compact ids and ranges are known
-  int xbits = 10; while ((1 << xbits) < 8 * nocc && (1 << xbits) < d.Hcell) ++xbits;   // (Hcell ≥ 1024: never beyond the allocation)
-  if (chash) for (int i = tid; i < (2 << xbits); i += GH_T) chash[i] = 0ull;
   // ---- cells per row → row table
   for (int r = tid; r <= nrows; r += GH_T) gh_st<RL>(rows + r, 0);
   __syncthreads();
@@ -859,7 +861,8 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
   gh_scan<RL>(rows, nrows, l_sh);
   if (tid == 0) gh_st<RL>(rows + nrows, nocc);
   __syncthreads();
-  if (RL) { int *grs = d.row_start + (size_t)s * (d.g.nrows + 1); for (int r = tid; r <= nrows; r += GH_T) grs[r] = rows[r]; }
+  if (RL) { int *grs = d.row_start + (size_t)s * (d.g.nrows + 1); for (int r = tid; r <= nrows; r += GH_T) { const int v = rows[r]; grs[r] = v; rs16[r] = (unsigned short)v; } }
+  else if (d.use_hash) for (int r = tid; r <= nrows; r += GH_T) rs16[r] = (unsigned short)gh_ld<RL>(rows + r);   // (meaningful while nocc ≤ 65 535: cidx_load checks)
   slab_bounds<RL>(d, G, s, rows, nocc, l_sh);
   // ---- the x of the cells of every row, listed (unordered) behind the row's first id.  The LDS copy of the row table
   //      serves as the fill cursor itself (rows[r] becomes the END of row r; the table proper is in global memory by now);
@@ -890,11 +893,10 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
         for (int u = 0; u < 8; ++u) c += (q + u < e2) && v[u] < x;
       }
     }
-    ckey[c] = key;
+    ckey[c] = key; cx16[c] = (unsigned short)x;
     gh_st<TL>(tkey + sl, c + 1);
   }
   __syncthreads();
-  auto ckey_of = [&](int c) { return __hip_atomic_load(ckey + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // (written by other threads of this workgroup two barriers ago)
   // ---- point counts in id order (same memory as the row lists) → first position of every cell
   int *cnt = rowlist;
   for (int e = tid; e < nocc; e += GH_T) { const int sl = gh_ld<CL>(cells + e); gh_st<CL>(cnt + gh_ld<TL>(tkey + sl) - 1, gh_ld<TL>(tval + sl)); }
@@ -909,15 +911,8 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
       d.cmin[so + c] = 0x7fffffff;
       MorCellSum z = {{0, 0, 0}, {0, 0, 0}}; d.csum[so + c] = z;
     }
-    if (chash) {   // cell hash entry: (key + 1, compact id), (n, first position) — one 16-byte slot
-      const int key = ckey_of(c);
-      const unsigned hmask = (1u << xbits) - 1u; unsigned sl = hash_slot(key, 32 - xbits);
-      const unsigned long long ent = ((unsigned long long)((unsigned)key + 1u) << 32) | (unsigned)c;
-      while (atomicCAS(&chash[2 * sl], 0ull, ent) != 0ull) sl = (sl + 1) & hmask;
-      chash[2 * sl + 1] = ((unsigned long long)(unsigned)n << 32) | (unsigned)b0;
-    }
   }
-  if (tid == 0) { cstart[nocc] = M; d.info[s].n_occ = nocc; d.info[s].hshift = 32 - xbits; }
+  if (tid == 0) { cstart[nocc] = M; d.info[s].n_occ = nocc; }
   for (int e = tid; e < nocc; e += GH_T) { const int sl = gh_ld<CL>(cells + e); gh_st<TL>(tval + sl, gh_ld<CL>(cnt + gh_ld<TL>(tkey + sl) - 1)); }
   __syncthreads();
   ST2(stw, 2);
@@ -2050,17 +2045,20 @@ __device__ __forceinline__ void count_push(bool want, int *cnt, int pr) {
 // within √lb of q, almost always in q's own cell: ≈ 85 % of the queries end here (never counted).  The rest is
 // compacted into worklists so the next tiers run full waves of like queries: `wl` front = E2 known (a matched point of
 // the own cell closer than √ub), `wl` back = own cell without a matched point, `wl2` = big own cell (wave tier).
-__global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
-  int s, t0; map_block(d.B, d.tiles_m * d.g_fast, s, t0);
+#define SCF_T 1024   // threads per workgroup of tier 1: sixteen waves share one LDS copy of the stream's cell index (loading it per 256 queries cost more than the lookups saved)
+__global__ __launch_bounds__(SCF_T) void k_score_fast(MorDev d) {
+  int s, t0; map_block(d.B, d.g_fast, s, t0);
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, Cp = d.slot_kc[d.prev][s].y;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
-  const unsigned long long *tab = d.chash + 2 * (size_t)s * d.Hcell; const unsigned hshift = d.info[s].hshift;
+  __shared__ unsigned short l_idx[CIDX_CAP];
+  const CellIdx I = cidx_load(d, G, s, l_idx);
+  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + G.cs * 1e-3f;
   const bool e1_local = 2.f * slb < G.cs;
-  for (int base = t0 * MOR_BT; base < Cp; base += d.tiles_m * d.g_fast * MOR_BT) {
+  for (int base = t0 * SCF_T; base < Cp; base += d.g_fast * SCF_T) {
     const int j = base + threadIdx.x;
     bool nearq = false, blockq = false, big = false, counted = false; float best = INFINITY; int pr = -1, target = -1;
     RS_T(f0);
@@ -2069,21 +2067,13 @@ __global__ __launch_bounds__(MOR_BT) void k_score_fast(MorDev d) {
 #endif
     if (j < Cp) {
       // two chains of dependent loads, issued side by side (no branch between them): cluster → pair → matched cluster → its box,
-      // and point → cell → hash probe → cell record → points.  (One after the other they were seven levels deep.)
+      // and point → cell (LDS index) → range + cluster id of the cell → points.  (One after the other they were seven levels deep.)
       const int cidj = d.cl_cid[pv][so + j];
       const float4 q = d.cl_pts[pv][so + j];
       const int cx = cell_axis_unclamped(q.x, G.ox, G.inv_cs), cy = cell_axis_unclamped(q.y, G.oy, G.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], G.inv_cs);
-      const int key = cell_key(G, cx, cy, cz);
-      unsigned sl = hash_slot(max(key, 0), hshift);
-      ulonglong2 ent = reinterpret_cast<const ulonglong2 *>(tab)[sl];   // (key + 1, id), (n, b0): the whole slot in one load
+      const int c = cidx_find(I, cx, cy, cz);   // (LDS: no global access)
       pr = d.pair_of_prev[ko + cidj];
-      int c = -1;
-      if (key >= 0) {
-        const unsigned hmask = (1u << (32 - hshift)) - 1u;
-        while (ent.x != 0ull && (unsigned)(ent.x >> 32) != (unsigned)key + 1u) { sl = (sl + 1) & hmask; ent = reinterpret_cast<const ulonglong2 *>(tab)[sl]; }
-        if (ent.x != 0ull) c = (int)(unsigned)ent.x;
-      }
-      const int cc = max(c, 0), cid = d.ccid[so + cc], b0 = c >= 0 ? (int)(unsigned)ent.y : 0, e0 = c >= 0 ? b0 + (int)(ent.y >> 32) : 0;
+      const int cc = max(c, 0), cid = d.ccid[so + cc], b0 = c >= 0 ? st[cc] : 0, e0 = c >= 0 ? st[cc + 1] : 0;
       target = min(max(d.pair_m[ko + max(pr, 0)], 0), d.Kcap - 1);   // (pr < 0: a stale entry, clamped — its box is loaded but not used)
       const float4 tlo = d.amin[d.cur][ko + target], thi = d.amax[d.cur][ko + target];
 #ifdef MOR_EXP_STAMPS
@@ -2144,20 +2134,20 @@ __device__ __forceinline__ void scan_batch4(const MorDev &d, size_t so, const in
 // Which worklist entry a thread of the worklist tiers takes in the pass starting at entry p0 (a pass = G·256 entries): 256
 // consecutive entries per workgroup.  (Measured and dropped: entry e → workgroup e % G; chunks of 64 dealt over the workgroups;
 // lanes of a wave nrows apart — all slower.)
-__device__ __forceinline__ int wl_entry(const MorDev &d, int p0, int bx, int nq) { (void)d; (void)nq; return p0 + bx * MOR_BT + threadIdx.x; }
+#define SCN_T 512   // threads per workgroup of tiers 1a / 1b (eight waves share one LDS copy of the cell index)
+__device__ __forceinline__ int wl_entry(const MorDev &d, int p0, int bx, int nq) { (void)d; (void)nq; return p0 + bx * SCN_T + threadIdx.x; }
 // Tier 1a — one THREAD per query with E2 known (worklist front).  E1: only the ≤ 7 neighbour cells across the walls q
 // is close to can hold a point within √lb (the own cell was scanned by tier 1).  Three levels of loads: hash probes →
 // box records + ranges → points.  No such point ⇒ counted.
-__device__ __forceinline__ void score_near_body(const MorDev &d, int s, int bx) {
+__device__ __forceinline__ void score_near_body(const MorDev &d, const CellIdx &I, int s, int bx) {
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, nq = (int)(unsigned)d.wl_nb[s];
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
-  const unsigned long long *tab = d.chash + 2 * (size_t)s * d.Hcell; const unsigned hshift = d.info[s].hshift;
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + G.cs * 1e-3f;
-  for (int p0 = 0; p0 < ((nq + 63) & ~63); p0 += d.g_score * MOR_BT) {
+  for (int p0 = 0; p0 < ((nq + 63) & ~63); p0 += d.g_score * SCN_T) {
     const int w = wl_entry(d, p0, bx, nq);
     bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
     if (w < nq) {
@@ -2167,15 +2157,14 @@ __device__ __forceinline__ void score_near_body(const MorDev &d, int s, int bx) 
       const int sx = near_side(q.x, G.ox, G.inv_cs, G.cs, cx, slb), sy = near_side(q.y, G.oy, G.inv_cs, G.cs, cy, slb), sz = near_side(q.z, d.zorg[s], G.inv_cs, G.cs, cz, slb);
       int budget = d.t1_budget; float best = 0.5f * (d.pde_lb + d.pde_ub) ;   // any value inside (lb, ub): E2 holds
       if (!(best > d.pde_lb && best < d.pde_ub)) best = d.pde_ub * 0.999f;
-      int key[8]; int id[8];
-      key[0] = -1;
+      int id[8];
+      id[0] = -1;
 #pragma unroll
       for (int i = 1; i < 8; ++i) {
         const int ax = i & 1, ay = (i >> 1) & 1, az = i >> 2;
         const bool valid = !(ax && sx == 0) && !(ay && sy == 0) && !(az && sz == 0);
-        key[i] = valid ? cell_key(G, cx + ax * sx, cy + ay * sy, cz + az * sz) : -1;
+        id[i] = valid ? cidx_find(I, cx + ax * sx, cy + ay * sy, cz + az * sz) : -1;
       }
-      hash_resolve_all<8>(tab, hshift, key, id);
       const int ca[4] = {id[1], id[2], id[4], id[3]}, cb2[4] = {id[5], id[6], id[7], -1};   // face neighbours first
       scan_batch4(d, so, st, sp, ca, target, true, q, lbn, best, budget);
       if ((cb2[0] >= 0 || cb2[1] >= 0 || cb2[2] >= 0) && best > d.pde_lb) scan_batch4(d, so, st, sp, cb2, target, true, q, lbn, best, budget);
@@ -2191,18 +2180,17 @@ __device__ __forceinline__ void score_near_body(const MorDev &d, int s, int bx) 
 // Tier 1b — one THREAD per query whose own cell holds no matched point (worklist back).  The 26 other cells of the
 // 3×3×3 block: hash probes → cluster ids → up to 8 matched cells (those that can hold a point within √lb first) →
 // box records + ranges → points.  E2 hit ⇒ E1 is decided by the same cells; no hit ⇒ the wider stencil is the wave tier's job.
-__device__ __forceinline__ void score_block_body(const MorDev &d, int s, int bx) {
+__device__ __forceinline__ void score_block_body(const MorDev &d, const CellIdx &I, int s, int bx) {
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, nq = (int)(d.wl_nb[s] >> 32);
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
-  const unsigned long long *tab = d.chash + 2 * (size_t)s * d.Hcell; const unsigned hshift = d.info[s].hshift;
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const int *cid_c = d.ccid + so;
   const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + G.cs * 1e-3f;
   const bool stencil27 = d.n_rows <= 9 && d.score_R <= 1;   // the whole search stencil is the 3×3×3 block
-  for (int p0 = 0; p0 < ((nq + 63) & ~63); p0 += d.g_score * MOR_BT) {
+  for (int p0 = 0; p0 < ((nq + 63) & ~63); p0 += d.g_score * SCN_T) {
     const int w = wl_entry(d, p0, bx, nq);
     bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
 #ifdef MOR_EXP_STAMPS
@@ -2215,13 +2203,23 @@ __device__ __forceinline__ void score_block_body(const MorDev &d, int s, int bx)
       const int cx = cell_axis_unclamped(q.x, G.ox, G.inv_cs), cy = cell_axis_unclamped(q.y, G.oy, G.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], G.inv_cs);
       const int sx = near_side(q.x, G.ox, G.inv_cs, G.cs, cx, slb), sy = near_side(q.y, G.oy, G.inv_cs, G.cs, cy, slb), sz = near_side(q.z, d.zorg[s], G.inv_cs, G.cs, cz, slb);
       int budget = d.t1_budget; float best = INFINITY;
-      int id[27];
-      {
-        int key[27];
+      int id[27];   // the 3×3×3 block row by row: one row of the LDS index holds the (≤ 3) cells x − 1 … x + 1 as consecutive ids
 #pragma unroll
-        for (int i = 0; i < 27; ++i) key[i] = i == 13 ? -1 : cell_key(G, cx + i % 3 - 1, cy + (i / 3) % 3 - 1, cz + i / 9 - 1);
-        hash_resolve_all<27>(tab, hshift, key, id);
+      for (int rw = 0; rw < 9; ++rw) {
+        const int y = cy + rw % 3 - 1, z = cz + rw / 3 - 1;
+        int lo = 0, hi = 0;
+        if ((unsigned)y < (unsigned)I.ny && (unsigned)z < (unsigned)I.nz) cidx_row(I, max(cx - 1, 0), min(cx + 1, I.nx - 1), y, z, lo, hi);
+        int x0 = -9, x1 = -9, x2 = -9;   // x of the (≤ 3) cells found
+        if (lo < hi) x0 = I.lds ? (int)I.cx16[lo] : I.ckey[lo] - (y * I.nz + z) * I.nx;
+        if (lo + 1 < hi) x1 = I.lds ? (int)I.cx16[lo + 1] : I.ckey[lo + 1] - (y * I.nz + z) * I.nx;
+        if (lo + 2 < hi) x2 = I.lds ? (int)I.cx16[lo + 2] : I.ckey[lo + 2] - (y * I.nz + z) * I.nx;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int xw = cx + dx - 1;
+          id[rw * 3 + dx] = x0 == xw ? lo : x1 == xw ? lo + 1 : x2 == xw ? lo + 2 : -1;
+        }
       }
+      id[13] = -1;   // (the own cell was tier 1's)
 #ifdef MOR_EXP_STAMPS
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g1 = wall_clock64();
 #endif
@@ -2280,9 +2278,11 @@ __device__ __forceinline__ void score_block_body(const MorDev &d, int s, int bx)
 // Tiers 1a and 1b in ONE launch (both only need tier 1's worklists; as two launches in two pieces of the frame pipeline they cost a
 // launch boundary and a queueing delay each): workgroups [0, g_score) of a stream take the front of the worklist, [g_score, 2·g_score)
 // its back.  A stream's workgroups share an XCD (its cell tables stay in that L2).
-__global__ __launch_bounds__(MOR_BT) void k_score_nb(MorDev d) {
+__global__ __launch_bounds__(SCN_T) void k_score_nb(MorDev d) {
   int s, bx; map_block(d.B, 2 * d.g_score, s, bx);
-  if (bx < d.g_score) score_near_body(d, s, bx); else score_block_body(d, s, bx - d.g_score);
+  __shared__ unsigned short l_idx[CIDX_CAP];
+  const CellIdx I = cidx_load(d, stream_grid(d, s), s, l_idx);
+  if (bx < d.g_score) score_near_body(d, I, s, bx); else score_block_body(d, I, s, bx - d.g_score);
 }
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
@@ -2311,8 +2311,8 @@ __device__ __forceinline__ void score_pde_body(const MorDev &d, int s, int bx) {
   const int wv = bx * (MOR_BT / 64) + wave_id(), nw = d.g_pde * (MOR_BT / 64), lane = lane_id();
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
-  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  const CellIdx I = cidx_load(d, G, s, nullptr);   // the 32-bit tables in global memory: a workgroup of the wave tier has a query or two
   const int R = d.score_R;
   const int *cid_c = d.ccid + so;
   const float lbn = nextafterf(d.pde_lb, INFINITY);
@@ -2325,8 +2325,7 @@ __device__ __forceinline__ void score_pde_body(const MorDev &d, int s, int bx) {
     const int cx = cell_axis_unclamped(q.x, G.ox, G.inv_cs), cy = cell_axis_unclamped(q.y, G.oy, G.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], G.inv_cs);
     float best = INFINITY;
     {  // the query's own cell first
-      const int key = cell_key(G, cx, cy, cz);
-      const int c = key >= 0 && d.use_hash ? hash_find(d.chash + 2 * (size_t)s * d.Hcell, d.info[s].hshift, key) : cell_lookup(G, ckey, rs, cx, cy, cz);
+      const int c = cidx_find(I, cx, cy, cz);
       if (c >= 0 && d.ccid[so + c] == target) best = wave_scan_cell(sp, st[c], st[c + 1], q, d.pde_lb, lane);
     }
     for (int rb = 0; rb < d.n_rows && best > d.pde_lb; rb += 64) {
@@ -2341,7 +2340,7 @@ __device__ __forceinline__ void score_pde_body(const MorDev &d, int s, int bx) {
         if (room > 0.f && (unsigned)y < (unsigned)G.ny && (unsigned)z < (unsigned)G.nz) {
           int rx = min(R, (int)(sqrtf(room) * G.inv_cs * 1.001f) + 1);
           int x0 = max(cx - rx, 0), x1 = min(cx + rx, G.nx - 1);
-          if (x0 <= x1) row_cells(G, ckey, rs, x0, x1, y, z, cur, hi);
+          if (x0 <= x1) cidx_row(I, x0, x1, y, z, cur, hi);
         }
       }
       if (__shfl(lbrow, 0, 64) >= score_lim(best, lbn, d.pde_ub)) break;   // rows are ordered by their lower bound
@@ -3171,7 +3170,7 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
   const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B);
   if (part == 2) goto grid;
   if (d.gmode != 1 && !d.two_pass_split) {
-    MOR_LAUNCH(MK_SPLIT, k_split, dim3(d.B * SP_G), d);
+    MOR_LAUNCH(MK_SPLIT, k_split, dim3(d.B * d.sp_g), d);
   } else {
     const dim3 gS(d.B * d.split_g);
     MOR_LAUNCH(MK_CLASSIFY, k_classify, gS, d);
@@ -3257,7 +3256,10 @@ static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
   MOR_LAUNCH(MK_PAIRS, k_cluster_pairs, gB, d);
   if (d.has_prev) {
     if (d.method == 1) {
-      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) { MOR_LAUNCH(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.tiles_m * d.g_fast), d); MOR_LAUNCH(MK_SCORE_NB, k_score_nb, dim3(2 * d.g_score * d.B), d); }
+      if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) {
+        mor_timer_begin(tm, MK_SCORE_FAST, st); hipLaunchKernelGGL(k_score_fast, dim3(d.B * d.g_fast), dim3(SCF_T), 0, st, d); mor_timer_end(tm, MK_SCORE_FAST, st);
+        mor_timer_begin(tm, MK_SCORE_NB, st); hipLaunchKernelGGL(k_score_nb, dim3(2 * d.g_score * d.B), dim3(SCN_T), 0, st, d); mor_timer_end(tm, MK_SCORE_NB, st);
+      }
     } else if (d.method == 2) {
       MOR_LAUNCH(MK_VOX_CLEAR, k_vox_clear, dim3(64, d.B), d);
       MOR_LAUNCH(MK_VOX_INSERT, k_vox_insert, gT, d);
@@ -3305,4 +3307,11 @@ void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int 
   }
   MOR_LAUNCH(MK_OUT_COUNT, k_out_count, gM, d);
   MOR_LAUNCH(MK_OUT_SCATTER, k_out_scatter, gT2, d);
+}
+
+// workgroups of k_split one CU holds (registers decide): the host keeps sp_g × B within what the whole GPU holds at once
+int mor_split_blocks_per_cu() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_split, MOR_BT, 0) != hipSuccess) n = 2;
+  return n < 1 ? 1 : n;
 }
