@@ -25,6 +25,7 @@ import socket
 import subprocess
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -473,7 +474,7 @@ def main():
     setup_s = leg.setup_s
     leg.close()
 
-    e2e = lat = None
+    e2e = lat = e2e_async = e2e_async_ok = None
     others = {}
     if extras and world == 1:
         # PCIe-inclusive: clouds start in page-locked host memory, filtered clouds end there (synchronous push + filter)
@@ -485,15 +486,42 @@ def main():
             hin[f].array[...] = np.asarray(xs).reshape(B, npts, 4)
             pp.append(np.ascontiguousarray(ps_))
         hb = engine.MorBatch(p, B, npts, 4, 3, device)
-        hb.push([hin[0].array[s] for s in range(B)], pp[0])
-        hb.filter_into([hout.array[s] for s in range(B)])
+        sviews = [hb.make_host_views([hin[f].array[s] for s in range(B)]) for f in range(2)]
+        houts = [hout.array[s] for s in range(B)]
+        hb.push_views(sviews[0], pp[0])
+        hb.filter_into(houts)
         t1 = time.perf_counter()
-        reps = 6
+        reps = 8
         for r in range(reps):
-            hb.push([hin[(r + 1) % 2].array[s] for s in range(B)], pp[(r + 1) % 2])
-            hb.filter_into([hout.array[s] for s in range(B)])
+            hb.push_views(sviews[(r + 1) % 2], pp[(r + 1) % 2])
+            hb.filter_into(houts)
         e2e = B * reps / (time.perf_counter() - t1)
+        nout_sync = [hb.output_device(s)[1] for s in range(B)]
+        crc_sync = [zlib.crc32(hout.array[s][:nout_sync[s]].tobytes()) for s in range(B)]
         hb.close()
+        # the same with the host only enqueueing (asynchronous mode): the staged copy of frame k + 1 runs beside the kernels of frame k, the
+        # filtered clouds are assembled on the device and leave by DMA into page-locked host memory behind the kernels; one wait at the end.  Checked against the
+        # synchronous run above (same frames: sizes and CRC of every stream's last filtered cloud)
+        hout2 = [engine.HostBuffer((B, npts, 4)) for _ in range(2)]
+        ha = engine.MorBatch(p, B, npts, 4, 3, device)
+        hviews = [ha.make_host_views([hin[f].array[s] for s in range(B)]) for f in range(2)]
+        optrs = [ha.make_out_pointers([hout2[f].array[s] for s in range(B)]) for f in range(2)]
+        ha.push_views(hviews[0], pp[0])
+        ha.filter_device()
+        ha.set_async(True)
+        t1 = time.perf_counter()
+        for r in range(reps):
+            ha.push_views(hviews[(r + 1) % 2], pp[(r + 1) % 2])
+            ha.filter_async_to(optrs[r % 2], on_device=False)
+        ha.wait()
+        e2e_async = B * reps / (time.perf_counter() - t1)
+        last = (reps - 1) % 2
+        nout_async = [ha.output_device(s)[1] for s in range(B)]
+        e2e_async_ok = nout_async == nout_sync and [zlib.crc32(hout2[last].array[s][:nout_async[s]].tobytes()) for s in range(B)] == crc_sync
+        ha.set_async(False)
+        ha.close()
+        for x in hout2:
+            x.free()
         # one stream (what the drop-in class does for one ROS node): push + filter of one cloud from / to page-locked host memory
         b1 = engine.MorBatch(p, 1, npts, 4, 3, device)
         ts = []
@@ -546,7 +574,7 @@ def main():
             "collective": "none", "first_seed_per_rank": first_seeds, "self_launched": bool(os.environ.get("MOR_BENCH_SELF_LAUNCHED")), "devices_visible": ndev, "ranks_per_device": (world + ndev - 1) // ndev,
             "value_runs": value_runs, "per_rank_frame_pairs_per_s": [round(x, 1) for x in per_rank], "per_rank_frame_pairs_per_s_min_max": [round(min(per_rank), 1), round(max(per_rank), 1)],
             "device_ms_per_step": round(dev_ms, 4), "sync_frame_pairs_per_s": None if sync_rate is None else round(sync_rate, 1),
-            "e2e_host_frame_pairs_per_s": None if e2e is None else round(e2e, 2), "latency_b1_ms": None if lat is None else round(lat, 3),
+            "e2e_host_frame_pairs_per_s": None if e2e is None else round(e2e, 2), "e2e_host_async_frame_pairs_per_s": None if e2e_async is None else round(e2e_async, 2), "e2e_host_async_equals_sync": e2e_async_ok, "latency_b1_ms": None if lat is None else round(lat, 3),
             "algorithmic_bytes_per_frame_pair": int(b_alg),
             "stage_totals": stage_totals, "stream0": stream0, "track_capacity_hit": track_cap, "sanity": sanity,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "workloads": others or None,

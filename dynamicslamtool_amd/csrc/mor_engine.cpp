@@ -81,17 +81,21 @@ struct mor_batch {
   // protect shared scratch arrays: sixteen more event records and waits per frame — each a packet the command processor
   // handles between two kernels of a lane.  Rounds 1–2 also had a stage schedule, pieces on fixed streams; removed.)
   hipStream_t sf = nullptr, sc = nullptr, sm = nullptr, sb = nullptr;   // lanes 1 … 4
-  hipEvent_t ev_split[MOR_MAX_SLOTS] = {}, ev_clusters[MOR_MAX_SLOTS] = {}, ev_pairs[MOR_MAX_SLOTS] = {}, ev_tpush[MOR_MAX_SLOTS] = {}, ev_back[MOR_MAX_SLOTS] = {};
-  hipEvent_t *last_split = nullptr;             // split of the latest push that staged host-resident blobs (the staging area exists once)
+  hipEvent_t ev_clusters[MOR_MAX_SLOTS] = {}, ev_pairs[MOR_MAX_SLOTS] = {}, ev_tpush[MOR_MAX_SLOTS] = {}, ev_back[MOR_MAX_SLOTS] = {};
   int n_pieces = 0, piece_id[MOR_MAX_PIECES] = {};   // the pieces of a push in order (ids: mor_device.h)
   int n_lanes = 4;
   hipStream_t extra[4] = {nullptr, nullptr, nullptr, nullptr};   // lanes 5 … 8 (MOR_LANES; measured: more than four busy streams are served worse)
   hipStream_t lane_stream(uint64_t k) const { const int i = (int)(k % (uint64_t)n_lanes); return i == 0 ? sf : i == 1 ? sc : i == 2 ? sm : i == 3 ? sb : extra[i - 4]; }
   hipEvent_t ev_track[MOR_MAX_SLOTS] = {};      // recorded after the tracking step of a push / the tracking loop of a filterCloud
   hipEvent_t *last_track = nullptr;             // the latest of them
+  // Copies between host and device memory run on two streams of their own, one per direction: the runtime serves a stream's copies by
+  // one DMA engine, and with the copies on the lanes the two directions shared engines — host → device and device → host took turns
+  // (4.85 ms per step of 64 × 120 000 points each way instead of 2.8 ms with both directions at once, exp/tools/duplex.cpp).
+  hipStream_t s_h2d_[1] = {nullptr}, s_d2h_[1] = {nullptr};   // (one per direction: with two per direction the four streams shared engines again — 7 k instead of 16 k frame-pairs/s end to end; blobs that lie back to back in host memory travel as ONE copy, which is what makes a stream reach the link rate)
+  hipEvent_t ev_h2d[MOR_MAX_SLOTS] = {}, ev_d2h[MOR_MAX_SLOTS] = {};   // staged input of frame k is on the device; its filtered clouds have left the output staging area
+  bool d2h_used[MOR_MAX_SLOTS] = {};
   hipEvent_t ev_out[MOR_MAX_SLOTS] = {};        // recorded after the output kernels of a filterCloud (they run in frame order: pinned size mirrors, tile counts)
   hipEvent_t *last_out = nullptr;
-  hipStream_t last_filter_stream = nullptr;
   MorDev dtemp[MOR_MAX_DEPTH];               // descriptor templates, frame k uses dtemp[k % depth] (static part + pointers)
   MorDev d;                                  // descriptor of the latest pushed frame
   MorStreamArgs *d_args_s[MOR_MAX_DEPTH] = {};
@@ -101,8 +105,11 @@ struct mor_batch {
   uint64_t pipe_depth = 4, n_slots = 5;       // frames in flight (= copies of the per-frame arrays); cluster-array slots = depth + 1
   int env_cg_p = 0, env_gc_p = 0;         // tuning knobs from the environment (MOR_CG_P, MOR_GC_P), read once at creation
   bool async = false, pending = false;   // async: push/filter only enqueue; pending: work enqueued since the last wait
-  float4 **h_outptrs = nullptr, **d_outptrs = nullptr;
-  unsigned char *d_stage = nullptr; size_t stage_stride = 0;   // staging for host-resident input blobs
+  float4 **h_outptrs = nullptr, **d_outptrs = nullptr;   // caller-provided output pointers: pinned ring of MOR_ARGS_RING tables (one per filterCloud in flight), device copy per frame in flight
+  hipEvent_t outptr_ev[MOR_ARGS_RING] = {}; uint64_t n_filters = 0;
+  float4 *d_outstage = nullptr;   // [depth][B][Nmax]  asynchronous filterCloud into host memory: the filtered clouds are assembled here and leave by DMA (allocated at the first such call)
+  std::vector<uint64_t> last_n;   // points per stream of the latest push
+  unsigned char *d_stage = nullptr; size_t stage_stride = 0;   // staging for host-resident input blobs: one area per frame in flight (frame k: area k mod depth), so the copy of frame k + 1 runs beside the kernels of frame k
   std::vector<PoseTf> prev_pose;
   uint64_t frame = 0;
   bool filtered = false;
@@ -217,6 +224,7 @@ static int sync_all(mor_batch *b) {
   if (!b->pending) return MOR_OK;
   HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sc)); HIP_TRY(hipStreamSynchronize(b->sm)); HIP_TRY(hipStreamSynchronize(b->sb));
   for (auto &x : b->extra) if (x) HIP_TRY(hipStreamSynchronize(x));
+  HIP_TRY(hipStreamSynchronize(b->s_h2d_[0])); HIP_TRY(hipStreamSynchronize(b->s_d2h_[0]));
   b->pending = false;
   b->timer.collect();
   return MOR_OK;
@@ -263,10 +271,15 @@ void mor_batch_destroy(mor_batch *b) {
   if (b->sb) hipStreamSynchronize(b->sb);
   for (auto &x : b->extra) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
   for (auto &ev : b->args_ev) if (ev) hipEventDestroy(ev);
-  for (auto *arr : {b->ev_split, b->ev_clusters, b->ev_pairs, b->ev_tpush}) for (int i = 0; i < MOR_MAX_SLOTS; ++i) if (arr[i]) hipEventDestroy(arr[i]);
+  for (auto &ev : b->outptr_ev) if (ev) hipEventDestroy(ev);
+  for (auto *arr : {b->ev_clusters, b->ev_pairs, b->ev_tpush}) for (int i = 0; i < MOR_MAX_SLOTS; ++i) if (arr[i]) hipEventDestroy(arr[i]);
   for (auto &ev : b->ev_back) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->ev_track) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->ev_out) if (ev) hipEventDestroy(ev);
+  for (auto &ev : b->ev_h2d) if (ev) hipEventDestroy(ev);
+  for (auto &ev : b->ev_d2h) if (ev) hipEventDestroy(ev);
+  for (auto &x : b->s_h2d_) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
+  for (auto &x : b->s_d2h_) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
   if (b->sf) hipStreamDestroy(b->sf);
   if (b->sc) hipStreamDestroy(b->sc);
   if (b->sm) hipStreamDestroy(b->sm);
@@ -274,6 +287,7 @@ void mor_batch_destroy(mor_batch *b) {
   for (void *p : b->dev_allocs) hipFree(p);
   for (void *p : b->host_allocs) hipHostFree(p);
   if (b->d_stage) hipFree(b->d_stage);
+  if (b->d_outstage) hipFree(b->d_outstage);
   for (auto &e : b->ev) if (e) hipEventDestroy(e);
   if (b->st) hipStreamDestroy(b->st);
   delete b;
@@ -296,15 +310,19 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if ((rc = configure(b)) != MOR_OK) return fail(rc);
   if (n_bad > MOR_TR_NB) return fail(set_error(MOR_ERR_INVALID, "n_bad = %d: windows longer than %d frames are not supported", n_bad, MOR_TR_NB));
   for (auto &ev : b->args_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+  for (auto &ev : b->outptr_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   if (hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
   for (auto &e : b->ev) if (hipEventCreate(&e) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   // (Tried and measured without effect on the pipeline: highest stream priority for the cell-graph stream, and CU masks
   //  that give it 32-96 CUs of its own.)
   if (hipStreamCreateWithFlags(&b->sf, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sc, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sm, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->sb, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
-  for (auto *arr : {b->ev_split, b->ev_clusters, b->ev_pairs, b->ev_tpush}) for (int i = 0; i < MOR_MAX_SLOTS; ++i) if (hipEventCreateWithFlags(&arr[i], hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+  for (auto *arr : {b->ev_clusters, b->ev_pairs, b->ev_tpush}) for (int i = 0; i < MOR_MAX_SLOTS; ++i) if (hipEventCreateWithFlags(&arr[i], hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_back) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_track) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_out) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+  for (auto &ev : b->ev_h2d) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+  for (auto &ev : b->ev_d2h) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
+  for (int i = 0; i < 1; ++i) if (hipStreamCreateWithFlags(&b->s_h2d_[i], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->s_d2h_[i], hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
   if (p->ground_method == 0) { const int ids[8] = {7, 8, 1, 2, 3, 4, 5, 6}; b->n_pieces = 8; for (int i = 0; i < 8; ++i) b->piece_id[i] = ids[i]; }
   else { const int ids[12] = {10, 11, 12, 13, 14, 15, 1, 2, 3, 4, 5, 6}; b->n_pieces = 12; for (int i = 0; i < 12; ++i) b->piece_id[i] = ids[i]; }
   b->n_lanes = (int)std::min<uint64_t>(4, b->pipe_depth);
@@ -335,10 +353,10 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   //      serial across frames), the sticky error words, the pinned host mirrors (written by the serial tracking / output steps)
   for (int i = 0; i < (int)b->n_slots; ++i)
     ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.chunk_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K) && dalloc(b, d.cl_first[i], B * K) && dalloc(b, d.slot_kc[i], B) && hipMemset(d.slot_kc[i], 0, B * sizeof(int2)) == hipSuccess;
-  ok = ok && dalloc(b, d.err, B) && hipMemset(d.err, 0, B * sizeof(unsigned)) == hipSuccess && halloc(b, d.h_err, B) && halloc(b, d.h_log, B * (size_t)MOR_LOG_CAP) && dalloc(b, b->d_outptrs, B);
+  ok = ok && dalloc(b, d.err, B) && hipMemset(d.err, 0, B * sizeof(unsigned)) == hipSuccess && halloc(b, d.h_err, B) && halloc(b, d.h_log, B * (size_t)MOR_LOG_CAP) && dalloc(b, b->d_outptrs, B * MOR_MAX_DEPTH);
   ok = ok && dalloc(b, d.dbg, B * 16) && dalloc(b, d.dbg2, B * (MOR_MAXP + 2) * 16);
   ok = ok && dalloc(b, d.tr, B) && hipMemset(d.tr, 0, B * sizeof(MorTrackDev)) == hipSuccess && dalloc(b, d.tr_corr, B * MOR_TR_NB * K) && dalloc(b, d.tr_res, B * (MOR_TR_NB + 1) * K) && dalloc(b, d.tr_lastdet, B * K);
-  ok = ok && halloc(b, b->h_args_ring, B * MOR_ARGS_RING) && halloc(b, b->h_outptrs, B);
+  ok = ok && halloc(b, b->h_args_ring, B * MOR_ARGS_RING) && halloc(b, b->h_outptrs, B * MOR_ARGS_RING);
   b->h_args = b->h_args_ring;
   ok = ok && halloc(b, d.h_info, B) && halloc(b, d.h_centroid, B * K) && halloc(b, d.h_cl_off, B * (K + 1)) && halloc(b, d.h_det, B * K);
   ok = ok && halloc(b, d.h_pair_q, B * K) && halloc(b, d.h_pair_m, B * K) && halloc(b, d.h_pair_d, B * K) && halloc(b, d.h_score, B * K) && halloc(b, d.h_nout, B) && halloc(b, d.h_noff, B);
@@ -377,7 +395,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     b->dtemp[c] = o;
   }
   b->d = b->dtemp[0];
-  b->prev_pose.resize(B);
+  b->prev_pose.resize(B); b->last_n.assign(B, 0);
   if (err) *err = MOR_OK;
   return b;
 }
@@ -402,7 +420,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   if (max_host_bytes > b->stage_stride) {   // (re)allocate the staging area for host-resident blobs
     if (b->d_stage) { b->pending = true; int rcw = wait_all_checked(b); if (rcw != MOR_OK) return rcw; HIP_TRY(hipFree(b->d_stage)); b->d_stage = nullptr; }
     b->stage_stride = (max_host_bytes + 255) & ~(size_t)255;
-    HIP_TRY(hipMalloc((void **)&b->d_stage, b->stage_stride * B));
+    HIP_TRY(hipMalloc((void **)&b->d_stage, b->stage_stride * B * b->pipe_depth));
   }
   // pinned argument slot of this push (a ring, so asynchronous pushes never overwrite a slot the GPU still has to copy)
   const int slot = (int)(k % MOR_ARGS_RING);
@@ -412,7 +430,8 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   for (int s = 0; s < B; ++s) {
     const mor_cloud_view &c = clouds[s]; MorStreamArgs &a = b->h_args[s];
     a.n = (uint32_t)c.n_points; a.step = c.point_step; a.off_x = c.off_x; a.off_y = c.off_y; a.off_z = c.off_z; a.off_i = c.off_intensity;
-    a.data = (c.on_device || c.n_points == 0) ? c.data : (const void *)(b->d_stage + b->stage_stride * s);
+    a.data = (c.on_device || c.n_points == 0) ? c.data : (const void *)(b->d_stage + b->stage_stride * ((k % b->pipe_depth) * B + s));
+    b->last_n[s] = c.n_points;
     pose_to_tf(poses + 7 * s, cur[s]);
     if (k > 0) relative_transform(cur[s], b->prev_pose[s], a.xf); else memset(a.xf, 0, sizeof a.xf);
     b->prev_pose[s] = cur[s];
@@ -447,11 +466,20 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   hipStream_t lane = b->lane_stream(k);
   const uint64_t depth = b->pipe_depth, ks = k % MOR_MAX_SLOTS, kp = (k + MOR_MAX_SLOTS - 1) % MOR_MAX_SLOTS;
   if (k >= depth) HIP_TRY(hipStreamWaitEvent(lane, b->ev_back[(k - depth) % MOR_MAX_SLOTS], 0));   // the frame that used this copy of the per-frame arrays (and this cluster slot as its ca) is done
-  const bool staged = max_host_bytes > 0;
-  if (staged && b->last_split) HIP_TRY(hipStreamWaitEvent(lane, *b->last_split, 0));   // the one staging area of host blobs is free
-  for (int s = 0; s < B; ++s) {   // host-resident blobs are staged through device memory
-    const mor_cloud_view &c = clouds[s];
-    if (!c.on_device && c.n_points) HIP_TRY(hipMemcpyAsync((void *)b->h_args[s].data, c.data, (size_t)c.n_points * c.point_step, hipMemcpyHostToDevice, lane));
+  // (the staging area of this frame's copy was last read by the split of frame k − depth: covered by the wait above)
+  if (max_host_bytes > 0) {   // host-resident blobs are staged through device memory, on the host → device copy stream
+    hipStream_t cs = b->s_h2d_[0];
+    if (k >= depth) HIP_TRY(hipStreamWaitEvent(cs, b->ev_back[(k - depth) % MOR_MAX_SLOTS], 0));   // (this frame's staging area was read by the split of frame k − depth)
+    for (int s = 0; s < B;) {   // runs of blobs that lie back to back in host memory and in the staging area travel as one copy
+      const mor_cloud_view &c = clouds[s];
+      if (c.on_device || !c.n_points) { ++s; continue; }
+      const char *src = (const char *)c.data; char *dst = (char *)b->h_args[s].data; size_t bytes = (size_t)c.n_points * c.point_step; int e = s + 1;
+      while (e < B && !clouds[e].on_device && clouds[e].n_points && (const char *)clouds[e].data == src + bytes && (char *)b->h_args[e].data == dst + bytes) { bytes += (size_t)clouds[e].n_points * clouds[e].point_step; ++e; }
+      HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs));
+      s = e;
+    }
+    HIP_TRY(hipEventRecord(b->ev_h2d[ks], cs));
+    HIP_TRY(hipStreamWaitEvent(lane, b->ev_h2d[ks], 0));
   }
   HIP_TRY(hipMemcpyAsync(b->d_args_s[k % b->pipe_depth], b->h_args, sizeof(MorStreamArgs) * B, hipMemcpyHostToDevice, lane));
   HIP_TRY(hipEventRecord(b->args_ev[slot], lane));
@@ -466,7 +494,6 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     }
     if (trk && b->last_track) HIP_TRY(hipStreamWaitEvent(lane, *b->last_track, 0));   // tracking state: after the previous frame's filterCloud loop
     mor_launch_piece(d, id, lane, &b->timer);
-    if ((id == 7 || id == 10) && staged) { HIP_TRY(hipEventRecord(b->ev_split[ks], lane)); b->last_split = &b->ev_split[ks]; }
     if (id == 3) HIP_TRY(hipEventRecord(b->ev_clusters[ks], lane));
     if (id == 4 && d.method == 2) HIP_TRY(hipEventRecord(b->ev_pairs[ks], lane));
     if (trk) { HIP_TRY(hipEventRecord(b->ev_tpush[ks], lane)); b->last_track = &b->ev_tpush[ks]; }
@@ -493,24 +520,47 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
   d.out_ptrs = nullptr;
   hipStream_t fs = b->lane_stream(k);   // behind the frame's push
   if (b->last_track) HIP_TRY(hipStreamWaitEvent(fs, *b->last_track, 0));   // a second filterCloud of a frame, or the frame's own tracking step (same stream: free)
-  if (out && out_on_device) {
-    if (b->async && b->last_filter_stream) HIP_TRY(hipStreamSynchronize(b->last_filter_stream));   // the pinned pointer table may still be in flight
-    for (int s = 0; s < B; ++s) b->h_outptrs[s] = (float4 *)out[s];
-    HIP_TRY(hipMemcpyAsync(b->d_outptrs, b->h_outptrs, sizeof(float4 *) * B, hipMemcpyHostToDevice, fs));
-    d.out_ptrs = b->d_outptrs;
-    b->last_filter_stream = fs;
+  // Asynchronous mode with HOST output pointers: the output kernels assemble every stream's filtered cloud in a device staging area of
+  // this frame and DMA copies of the stream's input size (an upper bound of the output: the caller's buffers hold n_in points, as the
+  // synchronous form requires) carry them out behind the kernels — nothing waits; the sizes are read after the wait (mor_get_output_device).
+  const bool host_async = out && !out_on_device && b->async && !n_out;
+  if (host_async && !b->d_outstage) HIP_TRY(hipMalloc((void **)&b->d_outstage, sizeof(float4) * (size_t)d.Nmax * B * b->pipe_depth));
+  if ((out && out_on_device) || host_async) {
+    const int oslot = (int)(b->n_filters++ % MOR_ARGS_RING);   // pinned pointer table of this call (a ring: an earlier table may still be in flight)
+    HIP_TRY(hipEventSynchronize(b->outptr_ev[oslot]));
+    float4 **hp = b->h_outptrs + (size_t)oslot * B, **dp = b->d_outptrs + (size_t)(k % b->pipe_depth) * B;
+    for (int s = 0; s < B; ++s) hp[s] = host_async ? b->d_outstage + ((size_t)(k % b->pipe_depth) * B + s) * d.Nmax : (float4 *)out[s];
+    HIP_TRY(hipMemcpyAsync(dp, hp, sizeof(float4 *) * B, hipMemcpyHostToDevice, fs));
+    HIP_TRY(hipEventRecord(b->outptr_ev[oslot], fs));
+    d.out_ptrs = dp;
   }
   HIP_TRY(hipEventRecord(b->ev[2], fs));
   mor_launch_filter(d, fs, &b->timer, 1);
   HIP_TRY(hipEventRecord(b->ev_track[k % MOR_MAX_SLOTS], fs)); b->last_track = &b->ev_track[k % MOR_MAX_SLOTS];   // the tracking state is settled: the next frame's tracking step may follow
   if (b->last_out) HIP_TRY(hipStreamWaitEvent(fs, *b->last_out, 0));
+  if (host_async && k >= b->pipe_depth && b->d2h_used[(k - b->pipe_depth) % MOR_MAX_SLOTS]) {   // the output staging area of this frame's copy has been carried out
+    HIP_TRY(hipStreamWaitEvent(fs, b->ev_d2h[(k - b->pipe_depth) % MOR_MAX_SLOTS], 0));
+  }
   mor_launch_filter(d, fs, &b->timer, 2);
   HIP_TRY(hipEventRecord(b->ev_out[k % MOR_MAX_SLOTS], fs)); b->last_out = &b->ev_out[k % MOR_MAX_SLOTS];
+  if (host_async) {   // on the device → host copy stream, behind the output kernels
+    hipStream_t cs = b->s_d2h_[0];
+    HIP_TRY(hipStreamWaitEvent(cs, b->ev_out[k % MOR_MAX_SLOTS], 0));
+    for (int s = 0; s < B;) {   // (back-to-back buffers: one copy)
+      if (!out[s] || !b->last_n[s]) { ++s; continue; }
+      char *dst = (char *)out[s]; const char *src = (const char *)(b->d_outstage + ((size_t)(k % b->pipe_depth) * B + s) * d.Nmax); size_t bytes = b->last_n[s] * sizeof(float4); int e = s + 1;
+      while (e < B && out[e] && b->last_n[e] && (char *)out[e] == dst + bytes && (const char *)(b->d_outstage + ((size_t)(k % b->pipe_depth) * B + e) * d.Nmax) == src + bytes) { bytes += b->last_n[e] * sizeof(float4); ++e; }
+      HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cs));
+      s = e;
+    }
+    HIP_TRY(hipEventRecord(b->ev_d2h[k % MOR_MAX_SLOTS], cs));
+    b->d2h_used[k % MOR_MAX_SLOTS] = true;
+  }
   HIP_TRY(hipEventRecord(b->ev[3], fs));
   HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], fs));
   HIP_TRY(hipGetLastError());
   b->pending = true;
-  const bool need_host = n_out != nullptr || (out && !out_on_device);
+  const bool need_host = n_out != nullptr || (out && !out_on_device && !host_async);
   if (b->async && !need_host) return MOR_OK;
   int rc = wait_all_checked(b);
   hipEventElapsedTime(&b->filter_ms, b->ev[2], b->ev[3]);

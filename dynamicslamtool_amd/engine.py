@@ -206,6 +206,25 @@ class MorBatch:
             v[s].point_step, v[s].off_x, v[s].off_y, v[s].off_z, v[s].off_intensity = point_step, offsets[0], offsets[1], offsets[2], offsets[3]
         return v
 
+    def make_host_views(self, arrays, point_step=16, offsets=(0, 4, 8, 12)):
+        """The same for host-resident clouds (page-locked arrays, e.g. HostBuffer.array rows): staged by the library, beside the kernels of
+        the frames in flight in asynchronous mode.  The arrays must stay alive and unchanged until their push has been waited for."""
+        v = (CloudView * self.B)()
+        for s, a in enumerate(arrays):
+            v[s].data, v[s].n_points, v[s].on_device = a.ctypes.data, a.nbytes // point_step, 0
+            v[s].point_step, v[s].off_x, v[s].off_y, v[s].off_z, v[s].off_intensity = point_step, offsets[0], offsets[1], offsets[2], offsets[3]
+        return v
+
+    def make_out_pointers(self, arrays):
+        """Pointer table for filter_async_to: one output array per stream (device memory, or page-locked host memory the GPU writes directly)."""
+        return (C.c_void_p * self.B)(*[a if isinstance(a, int) else a.ctypes.data for a in arrays])
+
+    def filter_async_to(self, out_pointers, on_device=True):
+        """filterCloud for all streams, enqueue only: every stream's filtered cloud goes to its pointer — device memory (written by the
+        output kernel), or with on_device=False page-locked host memory (assembled on the device, carried out by DMA behind the kernels;
+        each buffer holds the stream's input point count)."""
+        _check(lib().mor_filter_batch(self._h, C.addressof(out_pointers), 1 if on_device else 0, None))
+
     def push_views(self, views, poses):
         poses = np.ascontiguousarray(poses, np.float64)
         _check(lib().mor_push_batch(self._h, C.addressof(views), poses.ctypes.data))

@@ -96,9 +96,12 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
  * batch's own device buffers (mor_get_output_device). */
 int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t *n_out);
 
-/* Asynchronous mode (off by default).  With it on, mor_push_batch and mor_filter_batch (called with n_out == NULL
- * and no host output) only enqueue their launches — the tracking state lives on the device, so a push + filter
- * pair needs no host round trip — and return at once; mor_batch_wait blocks until everything enqueued has
+/* Asynchronous mode (off by default).  With it on, mor_push_batch and mor_filter_batch (called with n_out == NULL) only
+ * enqueue their work — host-resident input blobs are staged by copies that run beside the kernels of the frames in
+ * flight, and with host output pointers (out_on_device = 0) every stream's filtered cloud leaves by a DMA copy of the
+ * stream's input size behind the kernels (page-locked caller memory: mor_host_alloc; the buffers must not be touched
+ * before the wait; the sizes are read after it, mor_get_output_device) — the tracking state lives on the device, so a push + filter
+ * pair needs no host round trip, and return at once; mor_batch_wait blocks until everything enqueued has
  * finished and reports the errors any frame has raised since the last report (a sticky error word per stream; reporting
  * clears it).  Every read-back waits by itself but reports nothing: an error raised by an earlier frame stays pending until
  * mor_batch_wait (or the next synchronous push / filter) returns it. */

@@ -1036,3 +1036,52 @@ def test_octree_anchor_both_readings():
             assert st["corr"] > 0
         diffs += got[0] != got[1]
     assert diffs > 0
+
+
+@pytest.mark.parametrize("contiguous", [True, False])
+def test_asynchronous_mode_with_host_resident_clouds_and_outputs(contiguous):
+    """The drop-in caller owns HOST blobs (src/external_sync_test.cpp:14-17).  In asynchronous mode pushes stage them by copies beside the
+    kernels of the frames in flight and filterCloud hands the filtered clouds to DMA copies into the caller's page-locked buffers; nothing
+    waits until mor_batch_wait.  Every frame's output must equal the synchronous call sequence's — with the streams' buffers back to back
+    in one arena (the copies of a frame then travel as one) and in separate allocations."""
+    from dynamicslamtool_amd.engine import HostBuffer
+    p = kitti_params(1)
+    B, nf, npts = 4, 6, 120000
+    seeds = [2003, 2011, 2017, 2040]
+    frames = [synth.batch(seeds, [f] * B) for f in range(nf)]
+    ref = MorBatch(p, B, npts)
+    want = []
+    for xs, ps in frames:
+        ref.push(list(xs), ps)
+        want.append([o.copy() for o in ref.filter()])
+    ref.close()
+    if contiguous:
+        arena_in = [HostBuffer((B, npts, 4)) for _ in range(nf)]
+        arena_out = [HostBuffer((B, npts, 4)) for _ in range(nf)]
+        hin = [[arena_in[f].array[s] for s in range(B)] for f in range(nf)]
+        hout = [[arena_out[f].array[s] for s in range(B)] for f in range(nf)]
+        keep = arena_in + arena_out
+    else:
+        keep = [HostBuffer((npts + 7 * (i % 3), 4)) for i in range(2 * nf * B)]   # separate allocations (different sizes: never adjacent by accident)
+        hin = [[keep[f * B + s].array[:npts] for s in range(B)] for f in range(nf)]
+        hout = [[keep[nf * B + f * B + s].array[:npts] for s in range(B)] for f in range(nf)]
+    for f, (xs, _) in enumerate(frames):
+        for s in range(B):
+            hin[f][s][...] = xs[s]
+            hout[f][s][...] = -1.0
+    b = MorBatch(p, B, npts)
+    b.set_async(True)
+    views = [b.make_host_views(hin[f]) for f in range(nf)]
+    optrs = [b.make_out_pointers(hout[f]) for f in range(nf)]
+    for f in range(nf):
+        b.push_views(views[f], frames[f][1])
+        b.filter_async_to(optrs[f], on_device=False)
+    b.wait()
+    for f in range(nf):
+        for s in range(B):
+            n = len(want[f][s])
+            assert np.array_equal(hout[f][s][:n].view(np.uint32), want[f][s].view(np.uint32)), (f, s)
+    assert b.output_device(0)[1] == len(want[-1][0])
+    b.close()
+    for x in keep:
+        x.free()
