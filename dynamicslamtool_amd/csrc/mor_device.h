@@ -124,6 +124,7 @@ struct MorDev {
   int *pkey;                 // [B][Nmax]  linear cell key per cloud point
   int *pslot;                // [B][Nmax]  grid build: per cloud point, its entry in its chunk's list of cells
   int2 *gc_list, *gc_ent;    // [B][Nmax]  grid build, chunk c at c·GC_CHUNK: (cell key, points) of every cell of the chunk (k_gridcount); (slot, offset) then (compact cell id, first position) of the same entries (k_gridhash)
+  int2 *gc_tab; int *gc_tabsel;   // [B][16384 = GH_H], [B]  grid build: the stream's cell table as k_gridhash leaves it (slot → compact id + 1, first position) for k_gridplace; 0 = it is in gh_key / gh_val
   int *gc_n; int gc_chunks, gc_P;   // [B][gc_chunks] entries per chunk; chunks per stream at most; workgroups per stream of k_gridcount / k_gridplace
   int *gh_rowlist, *gh_cells; // [B][Nmax]  hash path, streams beyond the LDS lists: x of the cells of every row (unordered inside the row) then point counts per cell; claimed slots in discovery order
   int *gh_rowfill;           // [B][nrows+1]  hash path: per-row fill cursors when the row table does not fit the LDS copy

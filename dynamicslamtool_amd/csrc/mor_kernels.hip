@@ -618,7 +618,10 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
 #define GH_U 4        // points per thread and round trip of the sweeps (8 / 12 measured: no gain — the sweeps are bound by LDS atomics on the hot cells, not by the loads)
 #endif
 #define GH_H 16384       // slots of the LDS table (cells ≤ 3/4 of it)
-#define GH_ROWS 7167     // (y,z) rows the LDS copy of the row table holds
+#define GH_ROWS 7039     // (y,z) rows the LDS copy of the row table holds
+#ifndef GH_SHORT
+#define GH_SHORT 32      // rows of at most this many cells rank their cells by counting; longer rows (a wall along x) through a bitmap of their x (≈ 1.5 µs of a wave per row: with 8 here the open scenes lost what the urban ones won)
+#endif
 template <int NT> __device__ __forceinline__ int block_excl_scan_n(int v, int *sh, int *total) {   // sh: ≥ NT/64 ints
   const int inc = wave_incl_scan(v);
   __syncthreads();
@@ -784,11 +787,17 @@ __global__ __launch_bounds__(GC_T) void k_gridplace(MorDev d) {
   const int M = d.info[s].M, nch = (M + GC_CHUNK - 1) / GC_CHUNK, tid = threadIdx.x, lane = tid & 63;
   const size_t so = (size_t)s * d.Nmax;
   const int *pent = d.pslot + so; const float4 *cloud = d.cloud + so; float4 *sorted = d.sorted + so; int *scell = d.scell + so;
+  const int tabsel = d.gc_tabsel[s]; const int2 *gtab = d.gc_tab + (size_t)s * 16384; const int *gkey = d.gh_key + (size_t)s * d.Hcell, *gval = d.gh_val + (size_t)s * d.Hcell;
   __shared__ int l_cell[GC_CHUNK], l_cur[GC_CHUNK];
   for (int c = j; c < nch; c += d.gc_P) {
     const int ne = d.gc_n[(size_t)s * d.gc_chunks + c];
     const int2 *ent = d.gc_ent + so + (size_t)c * GC_CHUNK;
-    for (int e = tid; e < ne; e += GC_T) { const int2 v = ent[e]; l_cell[e] = v.x; l_cur[e] = v.y; }
+    for (int e = tid; e < ne; e += GC_T) {   // (slot, offset in the cell) → (compact cell id, first position of this chunk's piece of the cell)
+      const int2 v = ent[e];
+      int id1, first;
+      if (tabsel) { const int2 tv = gtab[v.x]; id1 = tv.x; first = tv.y; } else { id1 = gkey[v.x]; first = gval[v.x]; }
+      l_cell[e] = id1 - 1; l_cur[e] = first + v.y;
+    }
     __syncthreads();
     const int i0 = c * GC_CHUNK, i1 = min(i0 + GC_CHUNK, M);
     int en[GC_U]; float4 q[GC_U];
@@ -815,7 +824,7 @@ __global__ __launch_bounds__(GC_T) void k_gridplace(MorDev d) {
 // overflowed (nothing published yet: the caller re-runs with a bigger table).  `cells` lists the claimed slots in
 // discovery order — every per-cell phase walks it (a few entries per thread) instead of the whole table; `rowlist`
 // first holds the x of the cells of every row, then (same memory) the point counts in compact-id order.
-template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(const MorDev &d, const MorGrid &G, int s, int M, int *tkey, int *tval, int H, int cell_cap, int *rows, int *cells, int *rowlist, int *l_misc, int *l_sh) {
+template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(const MorDev &d, const MorGrid &G, int s, int M, int *tkey, int *tval, int H, int cell_cap, int *rows, int *cells, int *rowlist, int *l_misc, int *l_sh, int *l_bits) {
   const size_t so = (size_t)s * d.Nmax;
   int *cstart = d.cstart + (size_t)s * (d.Nmax + 1), *ckey = d.ckey + so;
   const int nrows = G.nrows, nx = G.nx, tid = threadIdx.x;
@@ -831,6 +840,34 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
   __syncthreads();
   // ---- sweep over the chunks' lists (k_gridcount: the distinct cells of every chunk of GC_CHUNK points with their point counts): every
   //      entry finds (or claims) the slot of its cell and reserves its chunk's piece of the cell's range; (slot, offset in the cell) kept
+  // (All entries of all chunks as ONE index space dealt over the 1024 threads — chunk after chunk with the whole workgroup idles most threads
+  //  on the short lists of big clouds, a wave per chunk serialises the long lists of small ones: 57 → 9.5 µs and back to 35 in between.)
+  int *cpre = l_bits;   // exclusive prefix of the chunks' entry counts (≤ 1024 chunks: 6 M points; beyond: chunk after chunk)
+  if (nch <= (GH_T / 64) * 64) {
+    const int mine = tid < nch ? cn[tid] : 0;
+    int total; const int ex = block_excl_scan_n<GH_T>(mine, l_sh, &total);
+    __syncthreads();
+    cpre[tid] = ex;
+    __syncthreads();
+    for (int g = tid; g < total; g += GH_T) {
+      if (gh_ld<true>(&l_misc[1])) break;
+      int lo = 0, hi = nch - 1;   // last chunk whose prefix ≤ g
+      while (lo < hi) { const int m = (lo + hi + 1) >> 1; if (cpre[m] <= g) lo = m; else hi = m - 1; }
+      const size_t at = (size_t)lo * GC_CHUNK + (g - cpre[lo]);
+      const int2 kc = clist[at];
+      const int want = kc.x + 1; unsigned h = hash_slot(kc.x, hshift); bool ok = false;
+      for (int probes = 0; probes < H; ++probes) {
+        int k = gh_ld<TL>(tkey + h);
+        if (k == 0) {
+          k = atomicCAS(tkey + h, 0, want);
+          if (k == 0) { k = want; const int n = atomicAdd(&l_misc[0], 1); if (n < cell_cap) gh_st<CL>(cells + n, (int)h); else gh_st<true>(&l_misc[1], 1); }
+        }
+        if (k == want) { ok = true; break; }
+        h = (h + 1) & mask;
+      }
+      if (ok) cent[at] = make_int2((int)h, atomicAdd(tval + h, kc.y)); else gh_st<true>(&l_misc[1], 1);
+    }
+  } else
   for (int c = 0; c < nch; ++c) {
     const int ne = cn[c];
     if (gh_ld<true>(&l_misc[1])) break;
@@ -858,12 +895,14 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
   __syncthreads();
   for (int e = tid; e < nocc; e += GH_T) { const int key = gh_ld<TL>(tkey + gh_ld<CL>(cells + e)) - 1; atomicAdd(rows + key / nx, 1); }
   __syncthreads();
+  ST2(stw, 6);
   gh_scan<RL>(rows, nrows, l_sh);
   if (tid == 0) gh_st<RL>(rows + nrows, nocc);
   __syncthreads();
   if (RL) { int *grs = d.row_start + (size_t)s * (d.g.nrows + 1); for (int r = tid; r <= nrows; r += GH_T) { const int v = rows[r]; grs[r] = v; rs16[r] = (unsigned short)v; } }
   else if (d.use_hash) for (int r = tid; r <= nrows; r += GH_T) rs16[r] = (unsigned short)gh_ld<RL>(rows + r);   // (meaningful while nocc ≤ 65 535: cidx_load checks)
   slab_bounds<RL>(d, G, s, rows, nocc, l_sh);
+  ST2(stw, 7);
   // ---- the x of the cells of every row, listed (unordered) behind the row's first id.  The LDS copy of the row table
   //      serves as the fill cursor itself (rows[r] becomes the END of row r; the table proper is in global memory by now);
   //      a row table that lives in global memory stays intact and a scratch copy is the cursor
@@ -874,34 +913,68 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
     __syncthreads();
   }
   for (int e = tid; e < nocc; e += GH_T) {
-    const int key = gh_ld<TL>(tkey + gh_ld<CL>(cells + e)) - 1, r = key / nx;
-    gh_st<CL>(rowlist + atomicAdd(fill + r, 1), key - r * nx);
+    const int sl = gh_ld<CL>(cells + e), key = gh_ld<TL>(tkey + sl) - 1, r = key / nx;
+    gh_st<CL>(rowlist + atomicAdd(fill + r, 1), TL ? ((key - r * nx) << 16) | sl : key - r * nx);   // (LDS-table tiers: the slot travels with the x — slots < 65 536)
   }
   __syncthreads();
-  // ---- compact id = first id of the row + cells of the row with a smaller x; slot → id
+  ST2(stw, 8);
+  // ---- compact id = first id of the row + cells of the row with a smaller x; slot → id.  Short rows: every cell counts the smaller x of
+  //      its row.  Long rows (a façade along x: 300 cells — counting is quadratic, 95 of 165 µs of this kernel on the urban scenes): one wave
+  //      per row sets a bit per occupied x (x < 2048: 64 words), a wave scan of the popcounts gives every cell its rank in two LDS reads.
   for (int e = tid; e < nocc; e += GH_T) {
     const int sl = gh_ld<CL>(cells + e), k = gh_ld<TL>(tkey + sl), key = k - 1, r = key / nx, x = key - r * nx;
     const int b = RL ? (r ? gh_ld<RL>(rows + r - 1) : 0) : gh_ld<RL>(rows + r), e2 = RL ? gh_ld<RL>(rows + r) : gh_ld<RL>(rows + r + 1);
+    if (TL && e2 - b > GH_SHORT) continue;
     int c = b;
-    if (CL) { for (int q = b; q < e2; ++q) c += gh_ld<CL>(rowlist + q) < x; }
-    else {   // lists in global memory: eight independent loads per round trip (a façade row of urban scenes has 300 cells)
+    if (CL) { for (int q = b; q < e2; ++q) c += (TL ? gh_ld<CL>(rowlist + q) >> 16 : gh_ld<CL>(rowlist + q)) < x; }
+    else {   // lists in global memory: eight independent loads per round trip
       for (int q = b; q < e2; q += 8) {
         int v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = gh_ld<CL>(rowlist + min(q + u, e2 - 1));
 #pragma unroll
-        for (int u = 0; u < 8; ++u) c += (q + u < e2) && v[u] < x;
+        for (int u = 0; u < 8; ++u) c += (q + u < e2) && (TL ? v[u] >> 16 : v[u]) < x;
       }
     }
     ckey[c] = key; cx16[c] = (unsigned short)x;
     gh_st<TL>(tkey + sl, c + 1);
   }
+  if (TL) {
+    __syncthreads();   // (the loop above has read every cell's key from its slot; the one below overwrites the slots of the long rows' cells)
+    const int w = tid >> 6, lane = tid & 63;
+    unsigned *bits = reinterpret_cast<unsigned *>(l_bits) + w * 64;
+    for (int r0 = w * 64; r0 < nrows; r0 += (GH_T / 64) * 64) {
+      const int r = r0 + lane;
+      int b = 0, e2 = 0;
+      if (r < nrows) { b = RL ? (r ? gh_ld<RL>(rows + r - 1) : 0) : gh_ld<RL>(rows + r); e2 = RL ? gh_ld<RL>(rows + r) : gh_ld<RL>(rows + r + 1); }
+      unsigned long long m = __ballot(e2 - b > GH_SHORT);
+      while (m) {
+        const int l = __ffsll((long long)m) - 1; m &= m - 1;
+        const int rb = __shfl(b, l, 64), re = __shfl(e2, l, 64), rr = r0 + l;
+        // (the lanes of this wave hand bits to each other through LDS: a workgroup-scope fence between the steps makes the wave wait for its own LDS operations)
+        bits[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        for (int q = rb + lane; q < re; q += 64) { const int x = gh_ld<CL>(rowlist + q) >> 16; atomicOr(&bits[x >> 5], 1u << (x & 31)); }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const int pc = __popc(bits[lane]), ex = wave_incl_scan(pc) - pc;   // occupied x below word `lane`
+        for (int q0 = rb; q0 < re; q0 += 64) {   // (all lanes go through the shuffle: the word's prefix lives in lane x / 32)
+          const int q = q0 + lane; const bool valid = q < re;
+          const int v = valid ? gh_ld<CL>(rowlist + q) : 0, x = v >> 16, sl = v & 0xffff;
+          const int c = rb + __shfl(ex, x >> 5, 64) + __popc(bits[x >> 5] & ((1u << (x & 31)) - 1u));
+          if (valid) { ckey[c] = rr * nx + x; cx16[c] = (unsigned short)x; gh_st<TL>(tkey + sl, c + 1); }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      }
+    }
+  }
   __syncthreads();
+  ST2(stw, 10);
   // ---- point counts in id order (same memory as the row lists) → first position of every cell
   int *cnt = rowlist;
   for (int e = tid; e < nocc; e += GH_T) { const int sl = gh_ld<CL>(cells + e); gh_st<CL>(cnt + gh_ld<TL>(tkey + sl) - 1, gh_ld<TL>(tval + sl)); }
   __syncthreads();
   gh_scan<CL>(cnt, nocc, l_sh);
+  ST2(stw, 11);
   for (int c = tid; c < nocc; c += GH_T) {
     const int b0 = gh_ld<CL>(cnt + c), n = (c + 1 < nocc ? gh_ld<CL>(cnt + c + 1) : M) - b0;
     cstart[c] = b0;
@@ -916,14 +989,13 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
   for (int e = tid; e < nocc; e += GH_T) { const int sl = gh_ld<CL>(cells + e); gh_st<TL>(tval + sl, gh_ld<CL>(cnt + gh_ld<TL>(tkey + sl) - 1)); }
   __syncthreads();
   ST2(stw, 2);
-  // ---- every chunk entry: (slot, offset in the cell) → (compact cell id, first position of the chunk's piece); k_gridplace moves the points
-  for (int c = 0; c < nch; ++c) {
-    const int ne = cn[c];
-    for (int e = tid; e < ne; e += GH_T) {
-      const int2 so2 = cent[(size_t)c * GC_CHUNK + e];
-      cent[(size_t)c * GC_CHUNK + e] = make_int2(gh_ld<TL>(tkey + so2.x) - 1, gh_ld<TL>(tval + so2.x) + so2.y);
-    }
+  // ---- the table itself (slot → compact cell id + 1, slot → first position of the cell) goes to global memory: k_gridplace turns its chunks'
+  //      (slot, offset) entries into (cell, position) — no second sweep over the entries here, in the one workgroup the stream waits for
+  if (TL) {
+    int2 *gt = d.gc_tab + (size_t)s * 16384;
+    for (int i = tid; i < H; i += GH_T) gt[i] = make_int2(gh_ld<TL>(tkey + i), gh_ld<TL>(tval + i));
   }
+  if (tid == 0) d.gc_tabsel[s] = TL ? 1 : 0;   // 0: the table already lives in global memory (gh_key / gh_val)
   ST2(stw, 3); ST2V(stw, 4, M); ST2V(stw, 5, nocc);
   return true;
 }
@@ -939,7 +1011,7 @@ static_assert(2 * GH_H0 + GH_ROWS + 1 + 2 * GH_C0 <= GH_LDS_INTS, "tier-0 layout
 __global__ __launch_bounds__(GH_T) void k_gridhash(MorDev d) {
   const int s = blockIdx.x + d.s0, M = d.info[s].M;
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
-  __shared__ int l_mem[GH_LDS_INTS], l_misc[4], l_sh[48];
+  __shared__ int l_mem[GH_LDS_INTS], l_misc[4], l_sh[48], l_bits[(GH_T / 64) * 64];
   const bool rows_lds = G.nrows <= GH_ROWS;
   int *grows = d.row_start + (size_t)s * (d.g.nrows + 1);
   const size_t so = (size_t)s * d.Nmax;
@@ -948,17 +1020,17 @@ __global__ __launch_bounds__(GH_T) void k_gridhash(MorDev d) {
   if (d.gh_tier <= 0) {
     const int H = min(GH_H0, d.Hcell);
     int *rows = l_mem + 2 * GH_H0, *cells = rows + GH_ROWS + 1, *rl = cells + GH_C0;
-    if (rows_lds) done = GH_RUN(true, true, true, d, s, M, l_mem, l_mem + H, H, min(GH_C0, H / 4 * 3), rows, cells, rl, l_misc, l_sh);
-    else done = GH_RUN(true, false, true, d, s, M, l_mem, l_mem + H, H, min(GH_C0, H / 4 * 3), grows, cells, rl, l_misc, l_sh);
+    if (rows_lds) done = GH_RUN(true, true, true, d, s, M, l_mem, l_mem + H, H, min(GH_C0, H / 4 * 3), rows, cells, rl, l_misc, l_sh, l_bits);
+    else done = GH_RUN(true, false, true, d, s, M, l_mem, l_mem + H, H, min(GH_C0, H / 4 * 3), grows, cells, rl, l_misc, l_sh, l_bits);
   }
   if (!done && d.gh_tier <= 1) {
     const int H = min(GH_H, d.Hcell);
-    if (rows_lds) done = GH_RUN(true, true, false, d, s, M, l_mem, l_mem + H, H, H / 4 * 3, l_mem + 2 * GH_H, g_cells, g_rowlist, l_misc, l_sh);
-    else done = GH_RUN(true, false, false, d, s, M, l_mem, l_mem + H, H, H / 4 * 3, grows, g_cells, g_rowlist, l_misc, l_sh);
+    if (rows_lds) done = GH_RUN(true, true, false, d, s, M, l_mem, l_mem + H, H, H / 4 * 3, l_mem + 2 * GH_H, g_cells, g_rowlist, l_misc, l_sh, l_bits);
+    else done = GH_RUN(true, false, false, d, s, M, l_mem, l_mem + H, H, H / 4 * 3, grows, g_cells, g_rowlist, l_misc, l_sh, l_bits);
   }
   if (!done) {   // table in global memory, sized for the cloud (cells ≤ M ≤ H/2)
     int H = 1024; while (H < 2 * M && H < d.Hcell) H <<= 1;
-    GH_RUN(false, false, false, d, s, M, d.gh_key + (size_t)s * d.Hcell, d.gh_val + (size_t)s * d.Hcell, H, H, grows, g_cells, g_rowlist, l_misc, l_sh);
+    GH_RUN(false, false, false, d, s, M, d.gh_key + (size_t)s * d.Hcell, d.gh_val + (size_t)s * d.Hcell, H, H, grows, g_cells, g_rowlist, l_misc, l_sh, l_bits);
   }
 }
 // ---- per-cell accumulators of the streaming cell pass (k_cellboxes): point box, smallest cloud index, exact coordinate sums

@@ -19,6 +19,15 @@ L.mor_exp_read_stamps2(b._h, out.ctypes.data)
 P = b.debug_config()["P"]
 print("P =", P)
 g = out[:, MAXP, :].astype(np.int64)
+names = ["entries sweep", "row counts", "row scan + copy + slabs", "row lists", "compact ids", "counts + scan", "cstart + init", "entries pass 2"]
+cols = [0, 1, 6, 7, 8, 10, 11, 2, 3]
+ph = np.diff(g[:, cols], axis=1) / 100.0
+tot2 = ph.sum(1)
+i2 = int(np.argmax(tot2))
+print("k_gridhash (merge) phases, us: mean over streams | slowest stream %d (M %d n_occ %d)" % (i2, g[i2, 4], g[i2, 5]))
+for n, col in zip(names, range(ph.shape[1])):
+    print("   %-26s %7.1f | %7.1f" % (n, ph[:, col].mean(), ph[i2, col]))
+print("   %-26s %7.1f | %7.1f" % ("total", tot2.mean(), tot2[i2]))
 t = np.diff(g[:, 0:4], axis=1) / 100.0
 print("k_gridhash per stream (us): sweep1 mean %.1f max %.1f | cells/rank/scan mean %.1f max %.1f | sweep2 mean %.1f max %.1f | total mean %.1f max %.1f" % (
     t[:, 0].mean(), t[:, 0].max(), t[:, 1].mean(), t[:, 1].max(), t[:, 2].mean(), t[:, 2].max(), t.sum(1).mean(), t.sum(1).max()))
