@@ -217,7 +217,7 @@ struct MorCellSum { long long a[3], b[3]; };
 // kernel ids for optional per-kernel event timing
 enum MorKernelId {
   MK_CLASSIFY, MK_SCATTER, MK_SPLIT, MK_HEADS_COUNT, MK_HEADS_SCATTER, MK_CELLBOXES, MK_RHIST, MK_RSCAN, MK_RSCATTER,
-  MK_XFORM_PREV, MK_PAIRS, MK_SCORE_FAST, MK_SCORE_NB, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE,
+  MK_SCORE_FAST, MK_SCORE_NB, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE,
   MK_OUT_COUNT, MK_OUT_SCATTER, MK_G2_COV_MID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_GRIDHASH, MK_GRIDCOUNT, MK_GRIDPLACE, MK_CG_SLAB, MK_CG_FINAL, MK_CLUSTERS, MK_COUNT
 };
 extern const char *const mor_kernel_names[MK_COUNT];
@@ -225,7 +225,7 @@ extern const char *const mor_kernel_names[MK_COUNT];
 struct MorLaunchTimer;   // engine-owned; records event pairs when enabled
 #define MOR_MAX_PIECES 13   // pieces of a push, at most (voxel ground variant: its grid stage is six of them)
 // piece ids: 7 split | 8 grid build (crop variant) or 10 … 15 (voxel ground variant) | 1 cell boxes | 2 cell graph | 3 clusters |
-//            4 transform of ca … thread tiers of the scores | 5 wave tier | 6 thresholds + tracking
+//            (3 also: transform of ca, correspondences) | 4 thread tiers of the scores / voxel kernels of method 2 | 5 wave tier | 6 thresholds + tracking
 void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer *tm);
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part);
 int mor_split_blocks_per_cu();

@@ -192,9 +192,9 @@ static int configure(mor_batch *b) {
   }
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
   d.two_pass_split = (getenv("MOR_SINGLE_PASS_SPLIT") && atoi(getenv("MOR_SINGLE_PASS_SPLIT")) == 0) ? 1 : 0;   // default: the single-read split (k_split); MOR_SINGLE_PASS_SPLIT=0: count pass + scatter pass (what pass A of the voxel ground variant always uses)
-  {  // all workgroups of the single-read split should be resident together (peers spin on each other): what the device holds of them, with a margin of a half for the kernels of other frames
+  {  // all workgroups of the single-read split should be resident together (peers spin on each other): what the device holds of them
     int ncu = 256; hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b->device);
-    const int hold = std::max(1, mor_split_blocks_per_cu()) * ncu / 2;
+    const int hold = std::max(1, mor_split_blocks_per_cu()) * ncu;   // (workgroups are dispatched in order, stream after stream: peers that are not resident yet follow as soon as earlier streams finish)
     d.sp_g = std::max(2, std::min(32, hold / b->B));   // (64 per stream stalled on the 1 M-point clouds of agg10 — cause not found; 32 and fewer are what the suite runs)
     if (getenv("MOR_SP_G")) d.sp_g = std::max(2, std::min(32, atoi(getenv("MOR_SP_G"))));
     if (b->B * 2 > hold) d.two_pass_split = 1;
@@ -202,7 +202,7 @@ static int configure(mor_batch *b) {
   }
   d.xcd_map = getenv("MOR_NO_XCD_MAP") ? 0 : 1;
   d.nt_ground = getenv("MOR_NT_GROUND") ? atoi(getenv("MOR_NT_GROUND")) : 0;
-  d.g_fast = 16; d.g_score = 16; d.g_pde = 256; d.g_box = 32;   // workgroups per stream: tier 1 (1024 threads each), tiers 1a / 1b (512 threads, g_score each), wave tier, cell boxes
+  d.g_fast = 16; d.g_score = 16; d.g_pde = 256; d.g_box = 32;   // workgroups per stream: tier 1 (1024 threads each), tiers 1a / 1b (512 threads, g_score each), wave tier (256 threads; workgroups without a query leave at once), cell boxes
   if (const char *tn = getenv("MOR_TUNE")) { int a, b2, c, e; if (sscanf(tn, "%d,%d,%d,%d", &a, &b2, &c, &e) == 4 && a > 0 && b2 > 0 && c > 0 && e > 0) { d.g_fast = a; d.g_score = b2; d.g_pde = c; d.g_box = e; } }
   d.use_hash = d.method == 1;
   { size_t hc = 1024; while (hc < 4 * (size_t)d.Nmax) hc <<= 1; d.Hcell = (int)hc; }
@@ -488,7 +488,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   for (int pc = 0; pc < b->n_pieces; ++pc) {
     const int id = b->piece_id[pc];
     const bool trk = pc == b->n_pieces - 1;
-    if (id == 4 && k > 0) {   // the pair stage reads (and transforms in place, :540-551) frame k − 1's clusters
+    if (id == 3 && k > 0) {   // the cluster piece also transforms frame k − 1's clusters in place (:540-551) and pairs them with this frame's
       HIP_TRY(hipStreamWaitEvent(lane, b->ev_clusters[kp], 0));
       if (d.method == 2) HIP_TRY(hipStreamWaitEvent(lane, b->ev_pairs[kp], 0));   // … which frame k − 1's own voxel probe (method 2) must have finished reading
     }

@@ -28,7 +28,7 @@
 
 const char *const mor_kernel_names[MK_COUNT] = {   // in MorKernelId order: "k_" + name = the __global__ function
     "classify", "scatter", "split", "heads_count", "heads_scatter", "cellboxes", "rhist", "rscan", "rscatter",
-    "xform_prev", "cluster_pairs", "score_fast", "score_nb", "score_pde", "vox_clear", "vox_insert", "vox_probe",
+    "score_fast", "score_nb", "score_pde", "vox_clear", "vox_insert", "vox_probe",
     "out_count", "out_scatter", "g2_cov_mid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridcount", "gridplace", "cg_slab", "cg_final", "clusters"};
 
 #ifdef MOR_EXP_STAMPS
@@ -117,6 +117,11 @@ __device__ __forceinline__ void st_stream(float4 *p, const float4 &v, int nt) {
   else *p = v;
 }
 __device__ __forceinline__ void st_stream(int *p, int v, int nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
+
+__device__ __forceinline__ void st_agent_f(float *p, float v) { __hip_atomic_store(reinterpret_cast<int *>(p), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent_f(const float *p) { return __int_as_float(__hip_atomic_load(reinterpret_cast<const int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void st_agent_f4(float4 *p, const float4 &v) { float *f = reinterpret_cast<float *>(p); st_agent_f(f, v.x); st_agent_f(f + 1, v.y); st_agent_f(f + 2, v.z); st_agent_f(f + 3, v.w); }
+__device__ __forceinline__ float4 ld_agent_f4(const float4 *p) { const float *f = reinterpret_cast<const float *>(p); return make_float4(ld_agent_f(f), ld_agent_f(f + 1), ld_agent_f(f + 2), ld_agent_f(f + 3)); }
 
 // Error flags: into the frame's info record (reset at the start of every frame) and into the stream's sticky error word,
 // which the host reports and clears at its next wait — so an error of ANY frame of an asynchronous run is reported, and
@@ -1860,10 +1865,16 @@ __device__ __forceinline__ int chunk_cluster(const int *coff, int K, int w) {
 // [tiles_m, tiles_m + MOR_CLS_G) reduce the cell records (boxes, exact coordinate sums) of every cluster with one wave
 // per cluster: centroid = Σ(double)p / n cast to fp32 (:239-243) from the exact sum, AABB for the volume gate.
 #define MOR_CLS_G 8
+__device__ __forceinline__ void xform_prev_body(const MorDev &d, int s, int bx, int nbx, Red6 *sh, float *m);
+__device__ __forceinline__ void cluster_pairs_body(const MorDev &d, int s, float4 *tile, int *sh);
+#define MOR_XF_G 16   // workgroups per stream that transform the previous frame's clusters inside this launch
 __global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
-  int s, t; map_block(d.B, d.tiles_m + MOR_CLS_G, s, t);
+  const int xf_g = d.has_prev ? MOR_XF_G : 0, nwg = d.tiles_m + MOR_CLS_G + xf_g;
+  int s, t; map_block(d.B, nwg, s, t);
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
-  if (t < d.tiles_m) {
+  __shared__ Red6 l_red[MOR_BT / 64]; __shared__ float l_m[12]; __shared__ float4 l_tile[MOR_BT]; __shared__ int l_sh8[8], l_last;
+  if (t >= d.tiles_m + MOR_CLS_G) xform_prev_body(d, s, t - d.tiles_m - MOR_CLS_G, xf_g, l_red, l_m);   // P1: ca → cb's frame (:536-551), beside the extraction of cb's clusters
+  else if (t < d.tiles_m) {
     const int M = d.info[s].M;
     float4 *dst = d.cl_pts[d.cur] + so; int *dcid = d.cl_cid[d.cur] + so;
     for (int j = t * MOR_BT + threadIdx.x; j < M; j += d.tiles_m * MOR_BT) {
@@ -1874,8 +1885,7 @@ __global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
       dst[j + g.x] = p; dcid[j + g.x] = g.y;
       if (__float_as_int(p.w) == g.z) d.cl_first[d.cur][ko + g.y] = p;
     }
-    return;
-  }
+  } else {
   const int K = d.info[s].K, lane = lane_id();
   const int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1), *lcoff = d.cl_coff + (size_t)s * (d.Kcap + 1);
   for (int k = (t - d.tiles_m) * (MOR_BT / 64) + wave_id(); k < K; k += MOR_CLS_G * (MOR_BT / 64)) {
@@ -1899,12 +1909,18 @@ __global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
     }
     if (lane == 0) {
       const double n = (double)(off[k + 1] - off[k]);
-      d.centroid[d.cur][ko + k] = make_float4((float)(fx_value(r.a[0], r.b[0]) / n), (float)(fx_value(r.a[1], r.b[1]) / n), (float)(fx_value(r.a[2], r.b[2]) / n), 0.f);
-      d.amin[d.cur][ko + k] = make_float4(r.lx, r.ly, r.lz, 0.f);
-      d.amax[d.cur][ko + k] = make_float4(r.hx, r.hy, r.hz, 0.f);
-      d.pair_of_cur[ko + k] = -1;
+      // (agent-scope stores: the correspondences are worked out by the stream's last workgroup of this launch, stream_last_block)
+      st_agent_f4(&d.centroid[d.cur][ko + k], make_float4((float)(fx_value(r.a[0], r.b[0]) / n), (float)(fx_value(r.a[1], r.b[1]) / n), (float)(fx_value(r.a[2], r.b[2]) / n), 0.f));
+      st_agent_f4(&d.amin[d.cur][ko + k], make_float4(r.lx, r.ly, r.lz, 0.f));
+      st_agent_f4(&d.amax[d.cur][ko + k], make_float4(r.hx, r.hy, r.hz, 0.f));
+      st_agent(&d.pair_of_cur[ko + k], -1);
     }
   }
+  }
+  // P2 (:264-307) in the stream's last workgroup to finish: boxes / centroids / first points of the transformed ca, both nearest-centroid
+  // directions, the correspondences — everything per CLUSTER between the point kernels (round 2: two more launches, k_xform_prev and k_cluster_pairs)
+  if (!stream_last_block(d.tickets + (size_t)s * TK_COUNT + TK_PAIRS, nwg, &l_last)) return;
+  cluster_pairs_body(d, s, l_tile, l_sh8);
 }
 
 // ------------------------------------------------------------------------------------ P1: previous frame → current pose (:536-551)
@@ -1914,17 +1930,15 @@ __device__ __forceinline__ void xform(const float *m, float &x, float &y, float 
   y = ((m[4] * a + m[5] * b) + m[6] * c) + m[7];
   z = ((m[8] * a + m[9] * b) + m[10] * c) + m[11];
 }
-__global__ __launch_bounds__(MOR_BT) void k_xform_prev(MorDev d) {
-  int s = blockIdx.y + d.s0, pv = d.prev, K = d.slot_kc[d.prev][s].x;
+__device__ __forceinline__ void xform_prev_body(const MorDev &d, int s, int bx, int nbx, Red6 *sh, float *m) {
+  const int pv = d.prev, K = d.slot_kc[d.prev][s].x;
   if (K == 0) return;
   const size_t so = (size_t)s * d.Nmax;
   const int *off = d.cl_off[pv] + (size_t)s * (d.Kcap + 1), *coff = d.chunk_off[pv] + (size_t)s * (d.Kcap + 1);
   const int W = coff[K];
-  __shared__ Red6 sh[MOR_BT / 64];
-  __shared__ float m[12];
   if (threadIdx.x < 12) m[threadIdx.x] = d.args[s].xf[threadIdx.x];
   __syncthreads();
-  for (int w = blockIdx.x; w < W; w += gridDim.x) {
+  for (int w = bx; w < W; w += nbx) {
     const int k = chunk_cluster(coff, K, w), b = off[k] + (w - coff[k]) * MOR_CHUNK, e = min(off[k + 1], b + MOR_CHUNK);
     Red6 r = {0, 0, 0, FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int j = b + threadIdx.x; j < e; j += MOR_BT) {
@@ -1935,7 +1949,10 @@ __global__ __launch_bounds__(MOR_BT) void k_xform_prev(MorDev d) {
       r.mxx = fmaxf(r.mxx, p.x); r.mxy = fmaxf(r.mxy, p.y); r.mxz = fmaxf(r.mxz, p.z);
     }
     red6_block(r, sh);
-    if (threadIdx.x == 0) d.part_back[(size_t)s * d.Wcap + w] = r;
+    if (threadIdx.x == 0) {   // (agent-scope stores: read by the stream's last workgroup of this launch)
+      Red6 *o = &d.part_back[(size_t)s * d.Wcap + w];
+      st_agent_f(&o->mnx, r.mnx); st_agent_f(&o->mny, r.mny); st_agent_f(&o->mnz, r.mnz); st_agent_f(&o->mxx, r.mxx); st_agent_f(&o->mxy, r.mxy); st_agent_f(&o->mxz, r.mxz);
+    }
   }
 }
 // AABBs of the transformed clusters (volume gate), transformed centroids (:540-541)
@@ -1945,9 +1962,9 @@ __device__ __forceinline__ void xform_fin_body(const MorDev &d, int s) {
   const Red6 *pt = d.part_back + (size_t)s * d.Wcap;
   const float *m = d.args[s].xf;
   for (int k = threadIdx.x; k < K; k += MOR_BT) {
-    Red6 r = pt[coff[k]];
-    for (int w = coff[k] + 1; w < coff[k + 1]; ++w) {
-      const Red6 q = pt[w];
+    Red6 r = {0, 0, 0, FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int w = coff[k]; w < coff[k + 1]; ++w) {
+      Red6 q; q.mnx = ld_agent_f(&pt[w].mnx); q.mny = ld_agent_f(&pt[w].mny); q.mnz = ld_agent_f(&pt[w].mnz); q.mxx = ld_agent_f(&pt[w].mxx); q.mxy = ld_agent_f(&pt[w].mxy); q.mxz = ld_agent_f(&pt[w].mxz);
       r.mnx = fminf(r.mnx, q.mnx); r.mny = fminf(r.mny, q.mny); r.mnz = fminf(r.mnz, q.mnz);
       r.mxx = fmaxf(r.mxx, q.mxx); r.mxy = fmaxf(r.mxy, q.mxy); r.mxz = fmaxf(r.mxz, q.mxz);
     }
@@ -1973,11 +1990,12 @@ __device__ __forceinline__ void nn_centroid_body(const MorDev &d, int s, int dir
   const float4 *src = dir == 0 ? cp : cc, *dst = dir == 0 ? cc : cp;
   for (int i0 = 0; i0 < Ksrc; i0 += MOR_BT) {
     const int i = i0 + threadIdx.x;
-    const float4 q = i < Ksrc ? src[i] : make_float4(0, 0, 0, 0);
+    // (cb's centroids were written by other workgroups of this launch: agent-scope loads; ca's transformed ones by this workgroup: plain)
+    const float4 q = i < Ksrc ? (dir == 1 ? ld_agent_f4(&src[i]) : src[i]) : make_float4(0, 0, 0, 0);
     float best = INFINITY; int bi = -1;
     for (int b = 0; b < Kdst; b += MOR_BT) {
       __syncthreads();
-      if (b + threadIdx.x < Kdst) tile[threadIdx.x] = dst[b + threadIdx.x];
+      if (b + threadIdx.x < Kdst) tile[threadIdx.x] = dir == 0 ? ld_agent_f4(&dst[b + threadIdx.x]) : dst[b + threadIdx.x];
       __syncthreads();
       const int lim = min(MOR_BT, Kdst - b);
       for (int u = 0; u < lim; ++u) { const float dd = sqdist(q.x, q.y, q.z, tile[u].x, tile[u].y, tile[u].z); if (dd < best) { best = dd; bi = b + u; } }
@@ -1998,7 +2016,7 @@ __device__ __forceinline__ void pairs_body(const MorDev &d, int s, int *sh) {
     if (i < Kp && Kc > 0) {
       j = d.nn_fwd[ko + i];
       if (j >= 0 && d.nn_bwd[ko + j] == i) {
-        float4 a0 = d.xamin[ko + i], a1 = d.xamax[ko + i], c0 = d.amin[d.cur][ko + j], c1 = d.amax[d.cur][ko + j];
+        float4 a0 = d.xamin[ko + i], a1 = d.xamax[ko + i], c0 = ld_agent_f4(&d.amin[d.cur][ko + j]), c1 = ld_agent_f4(&d.amax[d.cur][ko + j]);
         float vp = (a1.x - a0.x) * (a1.y - a0.y); vp = vp * (a1.z - a0.z);
         float vc = (c1.x - c0.x) * (c1.y - c0.y); vc = vc * (c1.z - c0.z);
         double dp = (double)vp, dc = (double)vc;
@@ -2018,10 +2036,7 @@ __device__ __forceinline__ void pairs_body(const MorDev &d, int s, int *sh) {
 }
 // One workgroup per stream: everything per CLUSTER between the point kernels — boxes, centroids and first points of the
 // transformed ca (from k_xform_prev's partials), both nearest-centroid directions, the correspondences.
-__global__ __launch_bounds__(MOR_BT) void k_cluster_pairs(MorDev d) {
-  const int s = blockIdx.x + d.s0;
-  __shared__ float4 tile[MOR_BT];
-  __shared__ int sh[8];
+__device__ __forceinline__ void cluster_pairs_body(const MorDev &d, int s, float4 *tile, int *sh) {
   if (!d.has_prev) return;
   xform_fin_body(d, s);
   __threadfence_block();
@@ -2377,14 +2392,16 @@ __device__ __forceinline__ float wave_scan_cell(const float4 *sp, int b0, int e0
   }
   return wave_min(local);
 }
-__device__ __forceinline__ void score_pde_body(const MorDev &d, int s, int bx) {   // a stream's waves spread over all XCDs: the deferred queries are few and uneven across streams
+#define SCP_T 256    // threads per workgroup of the wave tier.  (Tried: 1024-thread workgroups sharing an LDS copy of the cell index, 4 / 32 per stream: 346 / 90 µs against 56 — a stream's few hundred deferred queries want a thousand waves, and a workgroup with one query does not pay for a table.)
+__device__ __forceinline__ void score_pde_body(const MorDev &d, int s, int bx, unsigned short *l_idx) {
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, nq = d.wl2_n[s];
-  const int wv = bx * (MOR_BT / 64) + wave_id(), nw = d.g_pde * (MOR_BT / 64), lane = lane_id();
+  const int wv = bx * (SCP_T / 64) + wave_id(), nw = d.g_pde * (SCP_T / 64), lane = lane_id();
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
-  const CellIdx I = cidx_load(d, G, s, nullptr);   // the 32-bit tables in global memory: a workgroup of the wave tier has a query or two
+  if (bx * (SCP_T / 64) >= nq) return;   // (uniform: none of the stream's deferred queries falls to this workgroup — most workgroups of most streams)
+  const CellIdx I = cidx_load(d, G, s, l_idx);   // (l_idx null: the 32-bit tables in global memory)
   const int R = d.score_R;
   const int *cid_c = d.ccid + so;
   const float lbn = nextafterf(d.pde_lb, INFINITY);
@@ -2465,7 +2482,9 @@ __device__ __forceinline__ void score_pde_body(const MorDev &d, int s, int bx) {
   }
   if (lane == 0 && acc) atomicAdd(&d.pair_cnt[ko + acc_pr], acc);
 }
-__global__ __launch_bounds__(MOR_BT) void k_score_pde(MorDev d) { score_pde_body(d, blockIdx.y + d.s0, blockIdx.x); }
+__global__ __launch_bounds__(SCP_T) void k_score_pde(MorDev d) {
+  score_pde_body(d, blockIdx.y + d.s0, blockIdx.x, nullptr);   // a stream's waves spread over all XCDs: the deferred queries are few and uneven across streams
+}
 // (Tried: thresholds + tracking step in the stream's last workgroup of this kernel.  The tracking step of frame k must follow frame
 //  k − 1's filterCloud, so the whole wave tier then waited for it and the frames stopped overlapping: 150 k → 125 k frame-pairs/s.)
 
@@ -3319,13 +3338,11 @@ static void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer
   mor_timer_end(tm, MK_CG_FINAL, st);
 }
 
-static void mor_launch_clusters(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // labels, cluster points, centroids, boxes
-  MOR_LAUNCH(MK_CLUSTERS, k_clusters, dim3(d.B * (d.tiles_m + MOR_CLS_G)), d);
+static void mor_launch_clusters(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // labels, cluster points, centroids, boxes; transform of ca; correspondences
+  MOR_LAUNCH(MK_CLUSTERS, k_clusters, dim3(d.B * (d.tiles_m + MOR_CLS_G + (d.has_prev ? MOR_XF_G : 0))), d);
 }
 static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // transform of ca, correspondences, first tiers of the scores
   const dim3 gT(d.B * d.tiles), gB(d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B);
-  if (d.has_prev) MOR_LAUNCH(MK_XFORM_PREV, k_xform_prev, dim3(64, d.B), d);
-  MOR_LAUNCH(MK_PAIRS, k_cluster_pairs, gB, d);
   if (d.has_prev) {
     if (d.method == 1) {
       if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) {
@@ -3342,7 +3359,7 @@ static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
 
 static void mor_launch_scores2(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   if (d.has_prev && d.method == 1 && d.pde_ub > 0.f && d.pde_ub > d.pde_lb) {
-    MOR_LAUNCH(MK_SCORE1, k_score_pde, dim3(d.g_pde, d.B), d);
+    mor_timer_begin(tm, MK_SCORE1, st); hipLaunchKernelGGL(k_score_pde, dim3(d.g_pde, d.B), dim3(SCP_T), 0, st, d); mor_timer_end(tm, MK_SCORE1, st);
   }
 }
 static void mor_launch_decide(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
