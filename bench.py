@@ -401,11 +401,82 @@ def main():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback in the product path)")
     device = local_rank % ndev
 
+    # ---- end-to-end legs FIRST: on this stack device → host copies of a batch created after gigabytes of device memory have come and gone
+    #      (the headline leg's) run at 10 GB/s instead of 55 (exp/e2e_probe.py --prelude); an application has one batch per process, as here
+    e2e = lat = e2e_async = e2e_async_ok = e2e_ms = None
+    if not args.no_extras and world == 1:
+        B, npts, sensor = B0, synth.n_points(sensor0), sensor0
+        seeds_main = shard.stream_seeds(cfg0, rank, B)
+        hin, hout = [engine.HostBuffer((B, npts, 4)) for _ in range(2)], engine.HostBuffer((B, npts, 4))
+        hout2 = [engine.HostBuffer((B, npts, 4)) for _ in range(2)]
+        # PCIe-inclusive: clouds start in page-locked host memory, filtered clouds end there (synchronous push + filter)
+        pp = []
+        for f in range(2):
+            xs, ps_ = synth.batch(seeds_main, [f] * B, sensor)
+            hin[f].array[...] = np.asarray(xs).reshape(B, npts, 4)
+            pp.append(np.ascontiguousarray(ps_))
+        # ONE batch for both timed legs (the second batch of a process already copies device → host more slowly on this stack, see above):
+        # synchronous push + filter pairs first, then the same calls enqueue-only (asynchronous mode: the staged copy of frame k + 1 runs
+        # beside the kernels of frame k, the filtered clouds are assembled on the device and leave by DMA behind the kernels; one wait)
+        hb = engine.MorBatch(p, B, npts, 4, 3, device)
+        sviews = [hb.make_host_views([hin[f].array[s] for s in range(B)]) for f in range(2)]
+        houts = [hout.array[s] for s in range(B)]
+        optrs = [hb.make_out_pointers([hout2[f].array[s] for s in range(B)]) for f in range(2)]
+        hb.push_views(sviews[0], pp[0])
+        hb.filter_into(houts)
+        t1 = time.perf_counter()
+        reps, t_push = 8, 0.0
+        for r in range(reps):
+            t2 = time.perf_counter()
+            hb.push_views(sviews[(r + 1) % 2], pp[(r + 1) % 2])
+            t_push += time.perf_counter() - t2
+            hb.filter_into(houts)
+        e2e_dt = time.perf_counter() - t1
+        e2e = B * reps / e2e_dt
+        e2e_ms = {"push": round(1e3 * t_push / reps, 3), "filter": round(1e3 * (e2e_dt - t_push) / reps, 3)}
+        hb.set_async(True)
+        areps = 16
+        t1 = time.perf_counter()
+        for r in range(reps, reps + areps):
+            hb.push_views(sviews[(r + 1) % 2], pp[(r + 1) % 2])
+            hb.filter_async_to(optrs[r % 2], on_device=False)
+        hb.wait()
+        e2e_async = B * areps / (time.perf_counter() - t1)
+        last = (reps + areps - 1) % 2
+        nout_async = [hb.output_device(s)[1] for s in range(B)]
+        crc_async = [zlib.crc32(hout2[last].array[s][:nout_async[s]].tobytes()) for s in range(B)]
+        hb.set_async(False)
+        hb.close()
+        # untimed check of the asynchronous leg: the same 1 + reps + areps frames through synchronous calls on a fresh batch must end in the same filtered clouds
+        hv = engine.MorBatch(p, B, npts, 4, 3, device)
+        vviews = [hv.make_host_views([hin[f].array[s] for s in range(B)]) for f in range(2)]
+        hv.push_views(vviews[0], pp[0])
+        hv.filter_into(houts)
+        for r in range(reps + areps):
+            hv.push_views(vviews[(r + 1) % 2], pp[(r + 1) % 2])
+            nv = hv.filter_into(houts)
+        e2e_async_ok = nv == nout_async and [zlib.crc32(hout.array[s][:nv[s]].tobytes()) for s in range(B)] == crc_async
+        hv.close()
+        for x in hout2:
+            x.free()
+        # one stream (what the drop-in class does for one ROS node): push + filter of one cloud from / to page-locked host memory
+        b1 = engine.MorBatch(p, 1, npts, 4, 3, device)
+        ts = []
+        for r in range(12):
+            t1 = time.perf_counter()
+            b1.push([hin[r % 2].array[0]], pp[r % 2][:1])
+            b1.filter_into([hout.array[0]])
+            ts.append(time.perf_counter() - t1)
+        lat = 1e3 * float(np.median(ts[2:]))
+        b1.close()
+        for x in hin + [hout]:
+            x.free()
+
     # ---- headline leg: synthetic streams resident in HBM, frame f of stream s at offset ((f*B)+s)*npts*16
     leg = Leg(engine, synth, shard, p, args.workload, rank, device, min(args.warmup + args.steps + 1, 24), args.streams)
     B, npts, sensor = leg.B, leg.npts, leg.sensor
-    for _ in range(args.warmup):
-        leg.step()
+    if args.warmup:   # the W untimed warm-up steps run in the regime of the timed ones (asynchronous, frames pipelined): launch widths, table tiers and
+        leg.timed_async(args.warmup)   # slab counts adapt to what the device reports, and the lanes' streams and events are in use before the clock starts
     leg.batch.synchronize()
     logs = leg.logs(0, args.warmup)
     # timed region: asynchronous mode — the host only enqueues push + filter of every step (clouds resident in HBM,
@@ -474,66 +545,8 @@ def main():
     setup_s = leg.setup_s
     leg.close()
 
-    e2e = lat = e2e_async = e2e_async_ok = None
     others = {}
     if extras and world == 1:
-        # PCIe-inclusive: clouds start in page-locked host memory, filtered clouds end there (synchronous push + filter)
-        hin = [engine.HostBuffer((B, npts, 4)) for _ in range(2)]
-        hout = engine.HostBuffer((B, npts, 4))
-        pp = []
-        for f in range(2):
-            xs, ps_ = synth.batch(seeds_main, [f] * B, sensor)
-            hin[f].array[...] = np.asarray(xs).reshape(B, npts, 4)
-            pp.append(np.ascontiguousarray(ps_))
-        hb = engine.MorBatch(p, B, npts, 4, 3, device)
-        sviews = [hb.make_host_views([hin[f].array[s] for s in range(B)]) for f in range(2)]
-        houts = [hout.array[s] for s in range(B)]
-        hb.push_views(sviews[0], pp[0])
-        hb.filter_into(houts)
-        t1 = time.perf_counter()
-        reps = 8
-        for r in range(reps):
-            hb.push_views(sviews[(r + 1) % 2], pp[(r + 1) % 2])
-            hb.filter_into(houts)
-        e2e = B * reps / (time.perf_counter() - t1)
-        nout_sync = [hb.output_device(s)[1] for s in range(B)]
-        crc_sync = [zlib.crc32(hout.array[s][:nout_sync[s]].tobytes()) for s in range(B)]
-        hb.close()
-        # the same with the host only enqueueing (asynchronous mode): the staged copy of frame k + 1 runs beside the kernels of frame k, the
-        # filtered clouds are assembled on the device and leave by DMA into page-locked host memory behind the kernels; one wait at the end.  Checked against the
-        # synchronous run above (same frames: sizes and CRC of every stream's last filtered cloud)
-        hout2 = [engine.HostBuffer((B, npts, 4)) for _ in range(2)]
-        ha = engine.MorBatch(p, B, npts, 4, 3, device)
-        hviews = [ha.make_host_views([hin[f].array[s] for s in range(B)]) for f in range(2)]
-        optrs = [ha.make_out_pointers([hout2[f].array[s] for s in range(B)]) for f in range(2)]
-        ha.push_views(hviews[0], pp[0])
-        ha.filter_device()
-        ha.set_async(True)
-        t1 = time.perf_counter()
-        for r in range(reps):
-            ha.push_views(hviews[(r + 1) % 2], pp[(r + 1) % 2])
-            ha.filter_async_to(optrs[r % 2], on_device=False)
-        ha.wait()
-        e2e_async = B * reps / (time.perf_counter() - t1)
-        last = (reps - 1) % 2
-        nout_async = [ha.output_device(s)[1] for s in range(B)]
-        e2e_async_ok = nout_async == nout_sync and [zlib.crc32(hout2[last].array[s][:nout_async[s]].tobytes()) for s in range(B)] == crc_sync
-        ha.set_async(False)
-        ha.close()
-        for x in hout2:
-            x.free()
-        # one stream (what the drop-in class does for one ROS node): push + filter of one cloud from / to page-locked host memory
-        b1 = engine.MorBatch(p, 1, npts, 4, 3, device)
-        ts = []
-        for r in range(12):
-            t1 = time.perf_counter()
-            b1.push([hin[r % 2].array[0]], pp[r % 2][:1])
-            b1.filter_into([hout.array[0]])
-            ts.append(time.perf_counter() - t1)
-        lat = 1e3 * float(np.median(ts[2:]))
-        b1.close()
-        for x in hin + [hout]:
-            x.free()
         # the other BASELINE configurations (SURVEY §8d "BASELINE configs → concrete runs"), method 2 and the voxel-covariance ground
         # variant on the headline clouds: short legs, never `value` (single rank only: a secondary leg failing on one rank must not
         # leave the others in a barrier)
@@ -574,7 +587,7 @@ def main():
             "collective": "none", "first_seed_per_rank": first_seeds, "self_launched": bool(os.environ.get("MOR_BENCH_SELF_LAUNCHED")), "devices_visible": ndev, "ranks_per_device": (world + ndev - 1) // ndev,
             "value_runs": value_runs, "per_rank_frame_pairs_per_s": [round(x, 1) for x in per_rank], "per_rank_frame_pairs_per_s_min_max": [round(min(per_rank), 1), round(max(per_rank), 1)],
             "device_ms_per_step": round(dev_ms, 4), "sync_frame_pairs_per_s": None if sync_rate is None else round(sync_rate, 1),
-            "e2e_host_frame_pairs_per_s": None if e2e is None else round(e2e, 2), "e2e_host_async_frame_pairs_per_s": None if e2e_async is None else round(e2e_async, 2), "e2e_host_async_equals_sync": e2e_async_ok, "latency_b1_ms": None if lat is None else round(lat, 3),
+            "e2e_host_frame_pairs_per_s": None if e2e is None else round(e2e, 2), "e2e_host_sync_ms_per_step": e2e_ms, "e2e_host_async_frame_pairs_per_s": None if e2e_async is None else round(e2e_async, 2), "e2e_host_async_equals_sync": e2e_async_ok, "latency_b1_ms": None if lat is None else round(lat, 3),
             "algorithmic_bytes_per_frame_pair": int(b_alg),
             "stage_totals": stage_totals, "stream0": stream0, "track_capacity_hit": track_cap, "sanity": sanity,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "workloads": others or None,

@@ -25,6 +25,20 @@
 // useful maximum of concurrently busy streams.  Stream creation order below is st, sf, sc, sm, sb ⇒ queues 0…4 ⇒
 // pipes 0,1,2,3,0 with `st` idle during pushes.
 
+// The three copy streams of a device (read-backs, host → device, device → host) are created ONCE per process and device and shared by all
+// batches on it (copies of different batches queue behind each other; they share the link anyway).  The runtime binds a stream to its DMA
+// engine when the stream is created, and streams created after others have come and gone get worse ones: the second batch of a process
+// moved device → host at 10 GB/s instead of 55 (exp/e2e_probe.py --prelude).
+struct MorCopyStreams { hipStream_t st = nullptr, h2d = nullptr, d2h = nullptr; };
+static MorCopyStreams *copy_streams(int device) {
+  static std::map<int, MorCopyStreams> all;   // (batches are created from one thread at a time: the C ABI is not thread-safe per batch, creation included)
+  MorCopyStreams &c = all[device];
+  if (!c.st) {
+    if (hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c.h2d, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c.d2h, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  }
+  return &c;
+}
+
 static thread_local std::string g_last_error;
 static int set_error(int code, const char *fmt, ...) {
   char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -265,6 +279,8 @@ void mor_batch_destroy(mor_batch *b) {
   if (!b) return;
   hipSetDevice(b->device);
   if (b->st) hipStreamSynchronize(b->st);
+  for (auto &x : b->s_h2d_) if (x) hipStreamSynchronize(x);
+  for (auto &x : b->s_d2h_) if (x) hipStreamSynchronize(x);
   if (b->sf) hipStreamSynchronize(b->sf);
   if (b->sc) hipStreamSynchronize(b->sc);
   if (b->sm) hipStreamSynchronize(b->sm);
@@ -278,8 +294,6 @@ void mor_batch_destroy(mor_batch *b) {
   for (auto &ev : b->ev_out) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->ev_h2d) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->ev_d2h) if (ev) hipEventDestroy(ev);
-  for (auto &x : b->s_h2d_) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
-  for (auto &x : b->s_d2h_) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
   if (b->sf) hipStreamDestroy(b->sf);
   if (b->sc) hipStreamDestroy(b->sc);
   if (b->sm) hipStreamDestroy(b->sm);
@@ -289,7 +303,6 @@ void mor_batch_destroy(mor_batch *b) {
   if (b->d_stage) hipFree(b->d_stage);
   if (b->d_outstage) hipFree(b->d_outstage);
   for (auto &e : b->ev) if (e) hipEventDestroy(e);
-  if (b->st) hipStreamDestroy(b->st);
   delete b;
 }
 
@@ -311,7 +324,11 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (n_bad > MOR_TR_NB) return fail(set_error(MOR_ERR_INVALID, "n_bad = %d: windows longer than %d frames are not supported", n_bad, MOR_TR_NB));
   for (auto &ev : b->args_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->outptr_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
-  if (hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
+  {
+    MorCopyStreams *cs = copy_streams(device);
+    if (!cs) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
+    b->st = cs->st; b->s_h2d_[0] = cs->h2d; b->s_d2h_[0] = cs->d2h;
+  }
   for (auto &e : b->ev) if (hipEventCreate(&e) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   // (Tried and measured without effect on the pipeline: highest stream priority for the cell-graph stream, and CU masks
   //  that give it 32-96 CUs of its own.)
@@ -322,7 +339,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   for (auto &ev : b->ev_out) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_h2d) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->ev_d2h) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
-  for (int i = 0; i < 1; ++i) if (hipStreamCreateWithFlags(&b->s_h2d_[i], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->s_d2h_[i], hipStreamNonBlocking) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipStreamCreate failed"));
+
   if (p->ground_method == 0) { const int ids[8] = {7, 8, 1, 2, 3, 4, 5, 6}; b->n_pieces = 8; for (int i = 0; i < 8; ++i) b->piece_id[i] = ids[i]; }
   else { const int ids[12] = {10, 11, 12, 13, 14, 15, 1, 2, 3, 4, 5, 6}; b->n_pieces = 12; for (int i = 0; i < 12; ++i) b->piece_id[i] = ids[i]; }
   b->n_lanes = (int)std::min<uint64_t>(4, b->pipe_depth);
@@ -346,7 +363,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     d.row_order = dtab; d.n_rows = side * side;
   }
   d.Wcap = (int)(N / MOR_CHUNK + K + 2);
-  d.gc_chunks = (int)(N / 6144 + 1); d.gc_P = 1;   // (GC_CHUNK of mor_kernels.hip)
+  d.gc_chunks = (int)(N / MOR_GC_CHUNK + 1); d.gc_P = 1;
   d.rs16_stride = (int)(((size_t)std::max(d.g.nrows, d.gv.nrows) + 1 + 7) & ~(size_t)7);
   d.moving_confidence = n_bad; d.static_confidence = n_good; d.leave_off = p->leave_off_distance; d.catch_up = p->catch_up_distance;
   // ---- shared by all frames: the cluster arrays (frame-slotted: cb, ca and the frames in flight behind them), the tracking state (strictly
@@ -446,9 +463,9 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     const int p_fit = (int)((maxocc * 3ull / 2 + 818) / 819), p_par = (512 + B - 1) / B;   // a slab's LDS holds 1024 cells (own + look-ahead); two 512-thread workgroups per CU
     d.P = b->env_cg_p > 0 ? b->env_cg_p : std::max(p_fit, p_par);
     d.P = std::max(1, std::min(d.P, std::min(MOR_MAXP, std::max(1, d.g.ny / 2))));
-    {  // grid build: workgroups per stream of k_gridcount / k_gridplace — one per chunk of 6144 points of the largest cloud the device last reported (+ 25 %), enough to fill the GPU
+    {  // grid build: workgroups per stream of k_gridcount / k_gridplace — one per chunk of MOR_GC_CHUNK points of the largest cloud the device last reported (+ 25 %), enough to fill the GPU
       uint32_t mxM = 0; for (int s = 0; s < B; ++s) mxM = std::max(mxM, k > 0 ? d.h_info[s].M : (uint32_t)maxn);
-      const int want = (int)((mxM * 5ull / 4 + 6143) / 6144);
+      const int want = (int)((mxM * 5ull / 4 + MOR_GC_CHUNK - 1) / MOR_GC_CHUNK);
       d.gc_P = b->env_gc_p > 0 ? b->env_gc_p : std::max(1, std::min(std::min(want, d.gc_chunks), std::max(1, 2048 / B)));
     }
     d.cg_fused = (maxocc * 11ull / 10 <= MOR_CGS_FCAP && !getenv("MOR_CG_UNFUSED")) ? 1 : 0;   // (a stream beyond it runs the merge on global-memory arrays: correct, slow — hence the separate kernel when that is foreseeable)

@@ -729,9 +729,12 @@ __device__ __forceinline__ void gh_runs(int v, bool valid, int &leader, int &len
 //   k_gridplace  (as k_gridcount): every point draws its position from its chunk entry's LDS cursor and moves there.
 // Points of one cell end up grouped by chunk and in arbitrary order inside a chunk's piece: every consumer tests existence, takes min / max,
 // counts or adds exact integers.
-#define GC_CHUNK 6144
-#define GC_H 8192
-#define GC_T 1024
+#ifndef GC_HBITS
+#define GC_CHUNK MOR_GC_CHUNK    // (6144-point chunks in 1024-thread workgroups with 64 KB of LDS took 20 µs alone and 110 µs in the pipeline: they waited for a CU with that much room)
+#define GC_HBITS 12
+#define GC_T 256
+#endif
+#define GC_H (1 << GC_HBITS)
 #define GC_U (GC_CHUNK / GC_T)
 __global__ __launch_bounds__(GC_T) void k_gridcount(MorDev d) {
   int s, j; map_block(d.B, d.gc_P, s, j);
@@ -739,7 +742,7 @@ __global__ __launch_bounds__(GC_T) void k_gridcount(MorDev d) {
   const size_t so = (size_t)s * d.Nmax;
   const int *pkey = d.pkey + so; int *pent = d.pslot + so;
   __shared__ int l_key[GC_H], l_cnt[GC_H], l_sh[GC_T / 64 + 1];
-  constexpr unsigned hshift = 32 - 13, mask = GC_H - 1; static_assert(GC_H == 8192, "hshift");
+  constexpr unsigned hshift = 32 - GC_HBITS, mask = GC_H - 1; static_assert(GC_H >= GC_CHUNK + GC_CHUNK / 2, "a chunk's table cannot overflow");
   for (int c = j; c < nch; c += d.gc_P) {
     for (int i = tid; i < GC_H; i += GC_T) { l_key[i] = 0; l_cnt[i] = 0; }
     __syncthreads();
@@ -1890,12 +1893,20 @@ __global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
   const int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1), *lcoff = d.cl_coff + (size_t)s * (d.Kcap + 1);
   for (int k = (t - d.tiles_m) * (MOR_BT / 64) + wave_id(); k < K; k += MOR_CLS_G * (MOR_BT / 64)) {
     CellAcc r; acc_clear(r);
-    for (int e = lcoff[k] + lane; e < lcoff[k + 1]; e += 64) {
-      const int c = d.clist[so + e];
-      const float4 lo = d.cmeta[2 * (so + c)], hi = d.cmeta[2 * (so + c) + 1]; const MorCellSum cs = d.csum[so + c];
-      r.lx = fminf(r.lx, lo.x); r.ly = fminf(r.ly, lo.y); r.lz = fminf(r.lz, lo.z); r.hx = fmaxf(r.hx, hi.x); r.hy = fmaxf(r.hy, hi.y); r.hz = fmaxf(r.hz, hi.z);
+    const int e1 = lcoff[k + 1];
+    for (int e0 = lcoff[k] + lane; e0 < e1; e0 += 256) {   // four cells per lane and round trip (a wall of 3000 cells is 12 dependent rounds, not 47)
+      int c[4];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { r.a[a] += cs.a[a]; r.b[a] += cs.b[a]; }
+      for (int u = 0; u < 4; ++u) c[u] = d.clist[so + min(e0 + 64 * u, e1 - 1)];
+      float4 lo[4], hi[4]; MorCellSum cs[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { lo[u] = d.cmeta[2 * (so + c[u])]; hi[u] = d.cmeta[2 * (so + c[u]) + 1]; cs[u] = d.csum[so + c[u]]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (e0 + 64 * u < e1) {
+        r.lx = fminf(r.lx, lo[u].x); r.ly = fminf(r.ly, lo[u].y); r.lz = fminf(r.lz, lo[u].z); r.hx = fmaxf(r.hx, hi[u].x); r.hy = fmaxf(r.hy, hi[u].y); r.hz = fmaxf(r.hz, hi[u].z);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { r.a[a] += cs[u].a[a]; r.b[a] += cs[u].b[a]; }
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -7,6 +7,13 @@ seeds = [2000 + s for s in range(B)]
 hin = [engine.HostBuffer((B, npts, 4)) for _ in range(2)]; hout = [engine.HostBuffer((B, npts, 4)) for _ in range(2)]; pp = []
 for f in range(2):
     xs, ps = synth.batch(seeds, [f] * B); hin[f].array[...] = np.asarray(xs).reshape(B, npts, 4); pp.append(np.ascontiguousarray(ps))
+if "--prelude" in sys.argv:   # what bench.py does before its end-to-end legs: a device-resident leg on another batch, closed again
+    import bench
+    from dynamicslamtool_amd import shard
+    leg = bench.Leg(engine, synth, shard, p, "hdl64_b64", 0, 0, 24)
+    leg.timed_async(25)
+    if "--timing" in sys.argv: leg.kernel_leg(8, sync=False)
+    leg.close()
 b = engine.MorBatch(p, B, npts)
 views = [b.make_host_views([hin[f].array[s] for s in range(B)]) for f in range(2)]
 optr = [b.make_out_pointers([hout[f].array[s] for s in range(B)]) for f in range(2)]
