@@ -206,11 +206,12 @@ static int configure(mor_batch *b) {
   }
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
   d.two_pass_split = (getenv("MOR_SINGLE_PASS_SPLIT") && atoi(getenv("MOR_SINGLE_PASS_SPLIT")) == 0) ? 1 : 0;   // default: the single-read split (k_split); MOR_SINGLE_PASS_SPLIT=0: count pass + scatter pass (what pass A of the voxel ground variant always uses)
-  {  // all workgroups of the single-read split should be resident together (peers spin on each other): what the device holds of them
+  {  // workgroups per stream of the single-read split: what the device holds at once, shared out over the streams (a matter of speed only:
+     // tiles are handed out by ticket, so the look-back does not depend on which workgroups are resident)
     int ncu = 256; hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b->device);
-    const int hold = std::max(1, mor_split_blocks_per_cu()) * ncu;   // (workgroups are dispatched in order, stream after stream: peers that are not resident yet follow as soon as earlier streams finish)
-    d.sp_g = std::max(2, std::min(32, hold / b->B));   // (64 per stream stalled on the 1 M-point clouds of agg10 — cause not found; 32 and fewer are what the suite runs)
-    if (getenv("MOR_SP_G")) d.sp_g = std::max(2, std::min(32, atoi(getenv("MOR_SP_G"))));
+    const int hold = std::max(1, mor_split_blocks_per_cu()) * ncu;
+    d.sp_g = std::max(2, std::min(32, hold / b->B));
+    if (getenv("MOR_SP_G")) d.sp_g = std::max(2, std::min(64, atoi(getenv("MOR_SP_G"))));
     if (b->B * 2 > hold) d.two_pass_split = 1;
     if (getenv("MOR_DEBUG")) fprintf(stderr, "mor: k_split %d workgroups per CU, sp_g %d\n", mor_split_blocks_per_cu(), d.sp_g);
   }

@@ -149,7 +149,7 @@ __device__ __forceinline__ bool stream_last_block(int *ticket, int n_blocks, int
   __syncthreads();
   return *l_flag != 0;
 }
-enum { TK_TRACK = 0, TK_CGFINAL = 1, TK_PAIRS = 2, TK_COUNT = 8 };   // ticket words per stream
+enum { TK_TRACK = 0, TK_CGFINAL = 1, TK_PAIRS = 2, TK_SPLIT = 3, TK_COUNT = 8 };   // ticket words per stream
 
 // fromPCLPointCloud2 (:523): named float32 fields of a blob record → (x,y,z,intensity)
 __device__ __forceinline__ float ld_f32_bytes(const char *p) {   // a float32 field at any byte address
@@ -359,18 +359,27 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   }
 }
 
-// Single-READ variant of k_classify + k_scatter (crop-box variant and pass B of the voxel variant).  sp_g workgroups per stream walk the
-// stream's tiles round-robin (workgroup g: tiles g, g + sp_g, …), so at every step the sp_g workgroups of a stream hold sp_g consecutive
-// tiles.  A tile's output offsets are the counts of all earlier tiles: a workgroup carries the prefix of its previous tile along and adds
-// the aggregates of the ≤ sp_g − 1 tiles in between, which its peers publish — right after their loads have landed — in 64-bit descriptors
-// tagged with the frame (no reset pass; polled and published with agent-scope accesses: a stream's workgroups share an XCD under map_block,
-// but correctness does not depend on it).  The loads of a workgroup's NEXT tile are issued before it waits for the descriptors of the
-// current one, so the reads of step i + 1 overlap the look-back and the stores of step i.  (Round 2's form — one workgroup per tile, all
-// resident at once, look-back over all earlier tiles — read, waited and stored in lock step: 91 µs against 44 µs without the look-back.)
-// All sp_g workgroups of a stream must get to run while their peers spin: sp_g × B ≤ 2048 workgroups of 256 threads are what the GPU
-// holds (16 × B workgroups against 8 per CU × 256 CUs), and a peer that never shows up raises the "look-back stalled" flag after SPLIT_SPIN_LIMIT polls instead of hanging.
-// d.sp_g workgroups per stream (2 … 64, chosen by the host so that all of them are resident together: 2048 / B).  Measured alone, B = 64 ×
-// 120 000 points: 154 / 110 / 79 µs with 4 / 8 / 16 workgroups per stream (count + scatter passes: 36 + 58 µs and one more read of the cloud).
+// Single-READ variant of k_classify + k_scatter (crop-box variant and pass B of the voxel variant).  sp_g workgroups per stream take the
+// stream's tiles from a ticket counter (TK_SPLIT), in order of arrival.  A tile's output offsets are the counts of all earlier tiles: a
+// workgroup carries the prefix of its previous tile along and adds the aggregates of the tiles in between, which the other workgroups
+// publish — right after their loads have landed — in 64-bit descriptors tagged with the frame (no reset pass; polled and published with
+// agent-scope accesses).  Tiles handed out by ticket make the look-back safe whatever the dispatcher does: every tile below a
+// workgroup's own was taken by a workgroup that is already running, and the owner of the lowest unpublished tile never waits for
+// anything unpublished, so somebody always makes progress.  (The first form of this kernel gave workgroup g the tiles g, g + sp_g, …:
+// a tile then waits for tiles of workgroups with HIGHER numbers, which may not be resident yet, and with four frames' splits in flight
+// the wave slots of an XCD can fill up with such waiters — 4 × (sp_g − 1) ≥ 128: it stalled at sp_g = 48 on the 1 M-point clouds.)
+// Every tile goes through three steps — loads issued, counted (its aggregate published), look-back + stores — and a workgroup holds
+// two tiles: the NEXT tile is counted and published BEFORE the workgroup waits for the descriptors of the current one, so nobody ever
+// waits for a tile whose owner is itself waiting, and the current tile's look-back and stores overlap the ticket for the tile after
+// (taken by one lane, handed round through LDS).  Publishing a tile only when its turn to be stored comes — the natural order — made
+// this 3× slower (234 against 79 µs alone): a workgroup's second tile lies right behind its first, the next workgroup's first tile
+// waits for it, and the stream's workgroups end up running one after the other.  (Round 2's form — one workgroup per tile, look-back
+// over all earlier tiles — read, waited and stored in lock step: 91 µs against 44 µs without the look-back.)  Per workgroup two
+// tickets at the start and one per tile it stores: 2·sp_g + nt in all, and whoever takes the last one clears the counter for the next
+// frame that uses this copy of the per-frame arrays.  A peer that never shows up raises the "look-back stalled" flag after
+// SPLIT_SPIN_LIMIT polls instead of hanging.  Measured alone: B = 64 × 120 000 points 86 µs (16 workgroups per stream; static tiles
+// 79 µs, count + scatter passes 36 + 58 µs and one more read of the cloud), B = 32 × 1 M points 306 µs (static tiles 360 µs); the
+// pipelined throughput of both workloads is that of the static form or better.
 #define SPLIT_SPIN_LIMIT (1u << 22)
 __device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // loads only (no use of the data here: the wait for them belongs to split_tile, a step later); cls carries the ground flag of pass B
@@ -383,92 +392,124 @@ __device__ __forceinline__ void split_load_tile(const MorDev &d, const MorStream
     else { p[it] = load_point(a, i); cls[it] = 0; }
   }
 }
-__device__ __forceinline__ void split_tile(const MorDev &d, const MorGrid &G, int s, int t, int nt, int t_prev, unsigned epoch, const float4 (&p)[8], const int (&cls)[8],
-                                           int &ex_ng, int &ex_g, int *sh, int *s_ex) {
-  unsigned long long m_ng[8], m_g[8];
-  int c_ng = 0, c_g = 0, cl[8];
-  const uint32_t n_in = pass_count(d, d.args[s], s), base = (uint32_t)t * MOR_TILE + wave_id() * 512;
+struct SplitMeta { int tng, tg, wng, wg; };   // a counted tile: its totals and this wave's offsets inside it
+__device__ __forceinline__ int split_class(const MorDev &d, uint32_t n_in, uint32_t i, const float4 &p, int cls) {
+  return i < n_in ? (d.gmode == 2 ? (cls ? 1 : 2) : classify(d, p)) : 0;
+}
+// stage 1 of a tile (its loads were issued a step earlier): counts, and the tile's aggregate goes out to the other workgroups
+__device__ __forceinline__ void split_count(const MorDev &d, int s, int t, uint32_t n_in, unsigned epoch, const float4 (&p)[8], const int (&cls)[8], int *sh, SplitMeta &m) {
+  int c_ng = 0, c_g = 0;
+  const uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512 + lane_id();
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
-    cl[it] = base + it * 64 + lane_id() < n_in ? (d.gmode == 2 ? (cls[it] ? 1 : 2) : classify(d, p[it])) : 0;
-    m_ng[it] = __ballot(cl[it] == 2); m_g[it] = __ballot(cl[it] == 1); c_ng += __popcll(m_ng[it]); c_g += __popcll(m_g[it]);
+    const int c = split_class(d, n_in, base + it * 64, p[it], cls[it]);
+    c_ng += __popcll(__ballot(c == 2)); c_g += __popcll(__ballot(c == 1));
   }
   if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
   __syncthreads();
-  const int tng = sh[0] + sh[1] + sh[2] + sh[3], tg = sh[4] + sh[5] + sh[6] + sh[7];
+  m.tng = sh[0] + sh[1] + sh[2] + sh[3]; m.tg = sh[4] + sh[5] + sh[6] + sh[7];
+  m.wng = 0; m.wg = 0;
+  for (int w = 0; w < wave_id(); ++w) { m.wng += sh[w]; m.wg += sh[4 + w]; }
+  if (threadIdx.x == 0)
+    __hip_atomic_store(d.split_desc + (size_t)s * d.tiles_max + t, ((unsigned long long)epoch << 32) | ((unsigned long long)(unsigned)m.tng << 16) | (unsigned long long)(unsigned)m.tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// stage 2: look-back over the tiles between this workgroup's previous tile and this one, then the stores.
+// tk_next (thread 0 only): the ticket this workgroup has just taken for a later tile — passed on to all threads through s_ex[2]
+__device__ __forceinline__ void split_store(const MorDev &d, const MorGrid &G, int s, int t, int nt, int t_prev, uint32_t n_in, unsigned epoch, const float4 (&p)[8], const int (&cls)[8],
+                                            const SplitMeta &m, int &ex_ng, int &ex_g, int *s_ex, int tk_next) {
   if (wave_id() == 0) {
-    unsigned long long *desc = d.split_desc + (size_t)s * d.tiles_max;
+    const unsigned long long *desc = d.split_desc + (size_t)s * d.tiles_max;
     const int lane = lane_id();
-    if (lane == 0) __hip_atomic_store(&desc[t], ((unsigned long long)epoch << 32) | ((unsigned long long)(unsigned)tng << 16) | (unsigned long long)(unsigned)tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // aggregates of the tiles between this workgroup's previous tile and this one (the peers' tiles of this step and the last)
-    const int u = t - 1 - lane;
     int an = 0, ag = 0;
-    if (u > t_prev && u >= 0) {
-      unsigned spins = 0;
-      for (;;) {
-        const unsigned long long v = ld_agent64(&desc[u]);
-        if ((unsigned)(v >> 32) == epoch) { an = (int)((v >> 16) & 0xffffu); ag = (int)(v & 0xffffu); break; }
-        if (++spins > SPLIT_SPIN_LIMIT) { mor_raise(d, s, 64u); break; }
-        __builtin_amdgcn_s_sleep(1);
+    for (int hi = t - 1; hi > t_prev; hi -= 64) {   // 64 at a time (normally about sp_g of them in all)
+      const int u = hi - lane;
+      if (u > t_prev) {
+        unsigned spins = 0;
+        for (;;) {
+          const unsigned long long v = ld_agent64(&desc[u]);
+          if ((unsigned)(v >> 32) == epoch) { an += (int)((v >> 16) & 0xffffu); ag += (int)(v & 0xffffu); break; }
+          if (++spins > SPLIT_SPIN_LIMIT) { mor_raise(d, s, 64u); break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
       }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { an += __shfl_xor(an, o, 64); ag += __shfl_xor(ag, o, 64); }   // (lanes 0 … sp_g − 2 carry values: sp_g ≤ 64)
+    for (int o = 32; o > 0; o >>= 1) { an += __shfl_xor(an, o, 64); ag += __shfl_xor(ag, o, 64); }
     if (lane == 0) {
-      s_ex[0] = ex_ng + an; s_ex[1] = ex_g + ag;
-      if (t == nt - 1) publish_split(d, s, ex_ng + an + tng, ex_g + ag + tg);   // the stream's last tile: T, M, G of the frame
+      s_ex[0] = ex_ng + an; s_ex[1] = ex_g + ag; s_ex[2] = tk_next;
+      if (t == nt - 1) publish_split(d, s, ex_ng + an + m.tng, ex_g + ag + m.tg);   // the stream's last tile: T, M, G of the frame
     }
   }
   __syncthreads();
   int r_ng = s_ex[0], r_g = s_ex[1];
-  ex_ng = r_ng + tng; ex_g = r_g + tg;   // prefix behind this tile: what the workgroup carries to its next one
-  for (int w = 0; w < wave_id(); ++w) { r_ng += sh[w]; r_g += sh[4 + w]; }
+  ex_ng = r_ng + m.tng; ex_g = r_g + m.tg;   // prefix behind this tile: what the workgroup carries to its next one
+  r_ng += m.wng; r_g += m.wg;
   const size_t so = (size_t)s * d.Nmax;
   const float zorg = d.zorg[s]; const int zbase = d.zbase[s];
+  const uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512 + lane_id();
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
-    const int k_ng = r_ng + __popcll(m_ng[it] & lanemask_lt()), k_g = r_g + __popcll(m_g[it] & lanemask_lt());
-    if (cl[it] == 2) {
+    const int c = split_class(d, n_in, base + it * 64, p[it], cls[it]);
+    const unsigned long long m_ng = __ballot(c == 2), m_g = __ballot(c == 1);
+    const int k_ng = r_ng + __popcll(m_ng & lanemask_lt()), k_g = r_g + __popcll(m_g & lanemask_lt());
+    if (c == 2) {
       int cx, cy, cz; bool clamped; grid_cell(G, p[it], zorg, zbase, cx, cy, cz, clamped);
       if (clamped && d.gmode != 0) mor_raise(d, s, 8u);
       d.cloud[so + k_ng] = p[it];
       d.cloud_tidx[so + k_ng] = k_ng + k_g; d.pkey[so + k_ng] = grid_key(G, cx, cy, cz);
-    } else if (cl[it] == 1) {
+    } else if (c == 1) {
       st_stream(&d.ground[2 * so + d.Nmax + k_g], p[it], d.nt_ground);   // final place in filterCloud's output
       st_stream(&d.gp_idx[so + k_g], k_ng + k_g, d.nt_ground);
     }
-    r_ng += __popcll(m_ng[it]); r_g += __popcll(m_g[it]);
+    r_ng += __popcll(m_ng); r_g += __popcll(m_g);
   }
-  __syncthreads();
 }
 __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
   int s, g; map_block(d.B, d.sp_g, s, g);
-  const int SP_G = d.sp_g;
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const MorStreamArgs a = d.args[s];
   const uint32_t n_in = pass_count(d, a, s);
   const int nt = (int)((n_in + MOR_TILE - 1) / MOR_TILE);
   const unsigned epoch = 2u * (unsigned)d.frame_no + (d.gmode == 2 ? 2u : 1u);   // never 0 (fresh descriptors), never the tag of an earlier pass over this table
-  __shared__ int sh[8], s_ex[2];
-  if (g == 0 && threadIdx.x == 0) {   // start of the frame: before any flag of this stream can be raised (every other tile waits for tile 0's descriptor)
-    reset_frame_info(d, s);
-    if (nt == 0) publish_split(d, s, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __shared__ int sh[16], s_ex[6];   // two copies of each, used in turn by the two halves of the loop: between two uses of a copy lies a workgroup barrier of the other half
+  int *tk = d.tickets + (size_t)s * TK_COUNT + TK_SPLIT;
+  const int tk_total = 2 * d.sp_g + nt;
+  if (threadIdx.x == 0) {
+    const int v = __hip_atomic_fetch_add(tk, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ex[5] = v;
+    if (v + 2 == tk_total) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v == 0) {   // the owner of tile 0 starts the frame: before any flag of this stream can be raised (every other tile waits for tile 0's descriptor)
+      reset_frame_info(d, s);
+      if (nt == 0) publish_split(d, s, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
-  int ex_ng = 0, ex_g = 0, t_prev = -1;
+  __syncthreads();
+  int t = __builtin_amdgcn_readfirstlane(s_ex[5]), t1 = t + 1, t_prev = -1;
+  int ex_ng = 0, ex_g = 0;
   float4 pa[8], pb[8]; int ca[8], cb[8];
-  int t = g;
+  SplitMeta ma, mb;
   if (t < nt) split_load_tile(d, a, s, n_in, t, pa, ca);
-  while (t < nt) {
-    const int t1 = t + SP_G, t2 = t + 2 * SP_G;
-    if (t1 < nt) split_load_tile(d, a, s, n_in, t1, pb, cb);   // the next tile's loads are in flight while this one waits for its peers and stores
-    split_tile(d, G, s, t, nt, t_prev, epoch, pa, ca, ex_ng, ex_g, sh, s_ex);
+  if (t1 < nt) split_load_tile(d, a, s, n_in, t1, pb, cb);
+  if (t < nt) split_count(d, s, t, n_in, epoch, pa, ca, sh, ma);
+  while (t < nt) {   // pa: tile t, counted and published; pb: tile t1, loaded
+    int nx = 0;
+    if (t1 < nt) split_count(d, s, t1, n_in, epoch, pb, cb, sh + 8, mb);   // the next tile's aggregate is out before this workgroup waits for anybody
+    if (threadIdx.x == 0) nx = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    split_store(d, G, s, t, nt, t_prev, n_in, epoch, pa, ca, ma, ex_ng, ex_g, s_ex, nx);
+    if (threadIdx.x == 0 && nx + 1 == tk_total) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t_prev = t;
-    if (t1 >= nt) break;
+    const int t2 = __builtin_amdgcn_readfirstlane(s_ex[2]);
     if (t2 < nt) split_load_tile(d, a, s, n_in, t2, pa, ca);
-    split_tile(d, G, s, t1, nt, t_prev, epoch, pb, cb, ex_ng, ex_g, sh, s_ex);
+    if (t1 >= nt) break;
+    if (t2 < nt) split_count(d, s, t2, n_in, epoch, pa, ca, sh, ma);
+    if (threadIdx.x == 0) nx = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    split_store(d, G, s, t1, nt, t_prev, n_in, epoch, pb, cb, mb, ex_ng, ex_g, s_ex + 3, nx);
+    if (threadIdx.x == 0 && nx + 1 == tk_total) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t_prev = t1;
-    t = t2;
+    const int t3 = __builtin_amdgcn_readfirstlane(s_ex[5]);
+    if (t3 < nt) split_load_tile(d, a, s, n_in, t3, pb, cb);
+    t = t2; t1 = t3;
   }
 }
 

@@ -383,7 +383,7 @@ print("OK")
 
 
 @pytest.mark.parametrize("env", [{"MOR_GH_TIER": "1"}, {"MOR_GH_TIER": "2", "MOR_CG_GLOBAL": "1"}, {"MOR_LANES": "2"}, {"MOR_PIPE_DEPTH": "8", "MOR_LANES": "6"}, {"MOR_PIPE_DEPTH": "1"},
-                                 {"MOR_PIPE_DEPTH": "2", "MOR_LANES": "1"}, {"MOR_CG_UNFUSED": "1"}, {"MOR_SINGLE_PASS_SPLIT": "1"}, {"MOR_SINGLE_PASS_SPLIT": "0"}])
+                                 {"MOR_PIPE_DEPTH": "2", "MOR_LANES": "1"}, {"MOR_CG_UNFUSED": "1"}, {"MOR_SINGLE_PASS_SPLIT": "1"}, {"MOR_SINGLE_PASS_SPLIT": "0"}, {"MOR_SP_G": "64"}, {"MOR_SP_G": "2"}])
 def test_kernel_variants(env):
     """The tiers behind the default paths must give the same results: k_gridhash with its big LDS table / its global-memory table,
     slab and merge forests in global memory, other numbers of lanes / pipeline depths, the merge of the slab forests as its own launch.  The tier is chosen when the batch is created,
@@ -393,6 +393,45 @@ def test_kernel_variants(env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT % (root, os.path.join(root, "tests"))], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_single_read_split_with_more_workgroups_than_the_gpu_holds():
+    """k_split's workgroups wait for each other's tile counts.  64 streams × 64 workgroups of the single-read split are four times what
+    the GPU holds at once, with four frames' splits in flight: tiles handed out by ticket must get through whatever is resident (tiles
+    assigned by workgroup number stalled in this regime), and the frames must equal those of the count pass + scatter pass."""
+    import subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys, pickle
+sys.path.insert(0, %r)
+from dynamicslamtool_amd import kitti_params, synth
+from dynamicslamtool_amd.engine import MorBatch, DeviceBuffer
+p = kitti_params(1)
+B, nf, npts = 64, 6, synth.n_points("os128")
+seeds = [2000 + s for s in range(B)]
+buf = DeviceBuffer(nf * B * npts * 16); poses = []
+for f in range(nf):
+    xs, ps = synth.batch(seeds, [f] * B, "os128"); buf.upload(xs, f * B * npts * 16); poses.append(ps)
+b = MorBatch(p, B, npts)
+views = [b.make_views([(buf.ptr + (f * B + s) * npts * 16, npts) for s in range(B)]) for f in range(nf)]
+b.set_async(True)
+for rep in range(3):
+    for f in range(nf):
+        b.push_views(views[f], poses[f]); b.filter_async()
+b.wait()
+pickle.dump([[b.frame_log(f, s) for s in range(B)] for f in range(2 * nf, 3 * nf)], open(sys.argv[1], "wb"))
+b.close(); buf.free()
+""" % root
+    res = []
+    with tempfile.TemporaryDirectory() as td:
+        for i, env in enumerate(({"MOR_SP_G": "64"}, {"MOR_SINGLE_PASS_SPLIT": "0"})):
+            fn = os.path.join(td, "r%d.pkl" % i)
+            r = subprocess.run([sys.executable, "-c", script, fn], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+            import pickle
+            res.append(pickle.load(open(fn, "rb")))
+    assert res[0] == res[1]
+    assert sum(L["n_pairs"] for L in res[0][-1]) > 100
 
 
 def test_async_pipeline_equals_synchronous_use_at_full_batch_size():
