@@ -217,7 +217,10 @@ static int configure(mor_batch *b) {
   }
   d.xcd_map = getenv("MOR_NO_XCD_MAP") ? 0 : 1;
   d.nt_ground = getenv("MOR_NT_GROUND") ? atoi(getenv("MOR_NT_GROUND")) : 0;
-  d.g_fast = 16; d.g_score = 16; d.g_pde = 256; d.g_box = 32;   // workgroups per stream: tier 1 (1024 threads each), tiers 1a / 1b (512 threads, g_score each), wave tier (256 threads; workgroups without a query leave at once), cell boxes
+  d.g_fast = 8; d.g_score = 4; d.g_pde = 256; d.g_box = 32;   // workgroups per stream: tier 1 (1024 threads each, two per CU), tiers 1a + 1b together (512 threads; they share out the chunks of the two worklists), wave tier (256 threads; workgroups without a query leave at once), cell boxes
+  if (getenv("MOR_G_FAST")) d.g_fast = std::max(1, atoi(getenv("MOR_G_FAST")));
+  if (getenv("MOR_G_SCORE")) d.g_score = std::max(1, atoi(getenv("MOR_G_SCORE")));
+   // workgroups per stream: tier 1 (1024 threads each), tiers 1a / 1b (512 threads, g_score each), wave tier (256 threads; workgroups without a query leave at once), cell boxes
   if (const char *tn = getenv("MOR_TUNE")) { int a, b2, c, e; if (sscanf(tn, "%d,%d,%d,%d", &a, &b2, &c, &e) == 4 && a > 0 && b2 > 0 && c > 0 && e > 0) { d.g_fast = a; d.g_score = b2; d.g_pde = c; d.g_box = e; } }
   d.use_hash = d.method == 1;
   { size_t hc = 1024; while (hc < 4 * (size_t)d.Nmax) hc <<= 1; d.Hcell = (int)hc; }

@@ -2185,13 +2185,17 @@ __device__ __forceinline__ void count_push(bool want, int *cnt, int pr) {
 // compacted into worklists so the next tiers run full waves of like queries: `wl` front = E2 known (a matched point of
 // the own cell closer than √ub), `wl` back = own cell without a matched point, `wl2` = big own cell (wave tier).
 #define SCF_T 1024   // threads per workgroup of tier 1: sixteen waves share one LDS copy of the stream's cell index (loading it per 256 queries cost more than the lookups saved)
-__global__ __launch_bounds__(SCF_T) void k_score_fast(MorDev d) {
+#ifndef SCF_MINW
+#define SCF_MINW 8   // ≤ 64 VGPRs: two 1024-thread workgroups per CU (69 VGPRs were one)
+#endif
+__global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
   int s, t0; map_block(d.B, d.g_fast, s, t0);
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, Cp = d.slot_kc[d.prev][s].y;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
   __shared__ unsigned short l_idx[CIDX_CAP];
+  if (t0 * SCF_T >= Cp) return;   // nothing for this workgroup: not worth a copy of the cell index
   const CellIdx I = cidx_load(d, G, s, l_idx);
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float lbn = nextafterf(d.pde_lb, INFINITY);
@@ -2270,15 +2274,14 @@ __device__ __forceinline__ void scan_batch4(const MorDev &d, size_t so, const in
     else if (!(best < d.pde_ub) && bd < d.pde_ub) scan8s(sp, b0[i], e0[i], q, d.pde_ub, best, budget);
   }
 }
-// Which worklist entry a thread of the worklist tiers takes in the pass starting at entry p0 (a pass = G·256 entries): 256
-// consecutive entries per workgroup.  (Measured and dropped: entry e → workgroup e % G; chunks of 64 dealt over the workgroups;
-// lanes of a wave nrows apart — all slower.)
+// Worklist tiers: SCN_T consecutive entries per workgroup and chunk.  (Measured and dropped: entry e → workgroup e % G; chunks of 64 dealt
+// over the workgroups; lanes of a wave nrows apart — all slower.)
 #define SCN_T 512   // threads per workgroup of tiers 1a / 1b (eight waves share one LDS copy of the cell index)
-__device__ __forceinline__ int wl_entry(const MorDev &d, int p0, int bx, int nq) { (void)d; (void)nq; return p0 + bx * SCN_T + threadIdx.x; }
+
 // Tier 1a — one THREAD per query with E2 known (worklist front).  E1: only the ≤ 7 neighbour cells across the walls q
 // is close to can hold a point within √lb (the own cell was scanned by tier 1).  Three levels of loads: hash probes →
 // box records + ranges → points.  No such point ⇒ counted.
-__device__ __forceinline__ void score_near_body(const MorDev &d, const CellIdx &I, int s, int bx) {
+__device__ __forceinline__ void score_near_body(const MorDev &d, const CellIdx &I, int s, int chunk) {
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, nq = (int)(unsigned)d.wl_nb[s];
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
@@ -2286,8 +2289,8 @@ __device__ __forceinline__ void score_near_body(const MorDev &d, const CellIdx &
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + G.cs * 1e-3f;
-  for (int p0 = 0; p0 < ((nq + 63) & ~63); p0 += d.g_score * SCN_T) {
-    const int w = wl_entry(d, p0, bx, nq);
+  {
+    const int w = chunk * SCN_T + threadIdx.x;
     bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
     if (w < nq) {
       const int4 we = d.wl[so + w]; j = we.x; pr = we.y; target = we.z;
@@ -2319,7 +2322,7 @@ __device__ __forceinline__ void score_near_body(const MorDev &d, const CellIdx &
 // Tier 1b — one THREAD per query whose own cell holds no matched point (worklist back).  The 26 other cells of the
 // 3×3×3 block: hash probes → cluster ids → up to 8 matched cells (those that can hold a point within √lb first) →
 // box records + ranges → points.  E2 hit ⇒ E1 is decided by the same cells; no hit ⇒ the wider stencil is the wave tier's job.
-__device__ __forceinline__ void score_block_body(const MorDev &d, const CellIdx &I, int s, int bx) {
+__device__ __forceinline__ void score_block_body(const MorDev &d, const CellIdx &I, int s, int chunk) {
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, nq = (int)(d.wl_nb[s] >> 32);
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
@@ -2329,8 +2332,8 @@ __device__ __forceinline__ void score_block_body(const MorDev &d, const CellIdx 
   const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + G.cs * 1e-3f;
   const bool stencil27 = d.n_rows <= 9 && d.score_R <= 1;   // the whole search stencil is the 3×3×3 block
-  for (int p0 = 0; p0 < ((nq + 63) & ~63); p0 += d.g_score * SCN_T) {
-    const int w = wl_entry(d, p0, bx, nq);
+  {
+    const int w = chunk * SCN_T + threadIdx.x;
     bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
 #ifdef MOR_EXP_STAMPS
     bool dbg_budget = false, dbg_nocand = false;
@@ -2414,14 +2417,24 @@ __device__ __forceinline__ void score_block_body(const MorDev &d, const CellIdx 
 #endif
   }
 }
+#ifndef SCN_MINW
+#define SCN_MINW 1
+#endif
 // Tiers 1a and 1b in ONE launch (both only need tier 1's worklists; as two launches in two pieces of the frame pipeline they cost a
-// launch boundary and a queueing delay each): workgroups [0, g_score) of a stream take the front of the worklist, [g_score, 2·g_score)
-// its back.  A stream's workgroups share an XCD (its cell tables stay in that L2).
-__global__ __launch_bounds__(SCN_T) void k_score_nb(MorDev d) {
-  int s, bx; map_block(d.B, 2 * d.g_score, s, bx);
+// launch boundary and a queueing delay each).  The two ends of the worklist are cut into chunks of SCN_T entries — the front's chunks
+// first, then the back's — and the stream's g_score workgroups take the chunks round-robin, so the split between the two tiers follows
+// the lists (≈ 1700 and ≈ 900 entries per stream on the headline workload: five chunks) and a workgroup without a chunk leaves before
+// it copies the cell index.  A stream's workgroups share an XCD (its cell tables stay in that L2).
+__global__ __launch_bounds__(SCN_T, SCN_MINW) void k_score_nb(MorDev d) {
+  int s, bx; map_block(d.B, d.g_score, s, bx);
   __shared__ unsigned short l_idx[CIDX_CAP];
+  const unsigned long long nb = d.wl_nb[s];
+  const int cn = ((int)(unsigned)nb + SCN_T - 1) / SCN_T, cb = ((int)(nb >> 32) + SCN_T - 1) / SCN_T;
+  if (bx >= cn + cb) return;
   const CellIdx I = cidx_load(d, stream_grid(d, s), s, l_idx);
-  if (bx < d.g_score) score_near_body(d, I, s, bx); else score_block_body(d, I, s, bx - d.g_score);
+  for (int c = bx; c < cn + cb; c += d.g_score) {
+    if (c < cn) score_near_body(d, I, s, c); else score_block_body(d, I, s, c - cn);
+  }
 }
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
@@ -3300,13 +3313,14 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
 
 // ------------------------------------------------------------------------------------ launch sequences
 static int mor_exp_dup() { static const int v = getenv("MOR_EXP_DUP") ? atoi(getenv("MOR_EXP_DUP")) : -1; return v; }   // experiment: launch kernel <id> twice (idempotent kernels only)
-#define MOR_LAUNCH(id, kern, grid, ...)                                   \
+#define MOR_LAUNCH_T(id, kern, grid, threads, ...)                        \
   do {                                                                    \
     mor_timer_begin(tm, id, st);                                          \
-    hipLaunchKernelGGL(kern, grid, dim3(MOR_BT), 0, st, __VA_ARGS__);     \
-    if (mor_exp_dup() == (int)(id)) hipLaunchKernelGGL(kern, grid, dim3(MOR_BT), 0, st, __VA_ARGS__); \
+    hipLaunchKernelGGL(kern, grid, dim3(threads), 0, st, __VA_ARGS__);    \
+    if (mor_exp_dup() == (int)(id)) hipLaunchKernelGGL(kern, grid, dim3(threads), 0, st, __VA_ARGS__); \
     mor_timer_end(tm, id, st);                                            \
   } while (0)
+#define MOR_LAUNCH(id, kern, grid, ...) MOR_LAUNCH_T(id, kern, grid, MOR_BT, __VA_ARGS__)
 
 // part: 0 = both, 1 = the split only, 2 = the grid build only (the lane schedule runs them as two pieces)
 static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part = 0) {
@@ -3322,15 +3336,9 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
   if (part == 1) return;
 grid:
   if (d.gmode != 1) {   // clustering grid by counting (k_gridhash); the VoxelGrid pass of the voxel ground variant needs the points of a voxel in index order: sort
-    mor_timer_begin(tm, MK_GRIDCOUNT, st);
-    hipLaunchKernelGGL(k_gridcount, dim3(d.B * d.gc_P), dim3(GC_T), 0, st, d);
-    mor_timer_end(tm, MK_GRIDCOUNT, st);
-    mor_timer_begin(tm, MK_GRIDHASH, st);
-    hipLaunchKernelGGL(k_gridhash, gB, dim3(GH_T), 0, st, d);
-    mor_timer_end(tm, MK_GRIDHASH, st);
-    mor_timer_begin(tm, MK_GRIDPLACE, st);
-    hipLaunchKernelGGL(k_gridplace, dim3(d.B * d.gc_P), dim3(GC_T), 0, st, d);
-    mor_timer_end(tm, MK_GRIDPLACE, st);
+    MOR_LAUNCH_T(MK_GRIDCOUNT, k_gridcount, dim3(d.B * d.gc_P), GC_T, d);
+    MOR_LAUNCH_T(MK_GRIDHASH, k_gridhash, gB, GH_T, d);
+    MOR_LAUNCH_T(MK_GRIDPLACE, k_gridplace, dim3(d.B * d.gc_P), GC_T, d);
   } else {
     for (int pass = 0; pass < d.cell_passes; ++pass) {   // points sorted by cell key; result in (skey, sidx) = buffers [cell_passes & 1]
       MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0, d.tiles_m <= 64};
@@ -3361,18 +3369,14 @@ static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLau
     mor_launch_split_and_grid(da, st, tm);
     (void)hipMemsetAsync(d.g2_nbig + d.s0, 0, (size_t)d.B * sizeof(int), st);
   } else if (sub == 1) {
-    mor_timer_begin(tm, MK_G2_COV, st);
-    hipLaunchKernelGGL(k_g2_cov, dim3(256, d.B), dim3(MOR_BT), 0, st, da);
-    mor_timer_end(tm, MK_G2_COV, st);
+    MOR_LAUNCH_T(MK_G2_COV, k_g2_cov, dim3(256, d.B), MOR_BT, da);
   } else if (sub == 2) {
     MOR_LAUNCH(MK_G2_COV_MID, k_g2_cov_mid, dim3(64, d.B), da);
   } else if (sub == 3) {
     MOR_LAUNCH(MK_G2_COV_BIG, k_g2_cov_big, dim3(64, d.B), da);
   } else if (sub == 4) {
     MOR_LAUNCH(MK_G2_MODE, k_g2_mode, gB, da);
-    mor_timer_begin(tm, MK_G2_MARK, st);
-    hipLaunchKernelGGL(k_g2_mark, dim3(4096, d.B), dim3(64), 0, st, da);
-    mor_timer_end(tm, MK_G2_MARK, st);
+    MOR_LAUNCH_T(MK_G2_MARK, k_g2_mark, dim3(4096, d.B), 64, da);
   } else {
     MorDev db = d; db.gmode = 2;
     mor_launch_split_and_grid(db, st, tm);
@@ -3380,14 +3384,9 @@ static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLau
 }
 
 static void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // slabs (+ merge in each stream's last slab workgroup), or slabs | merge
-  mor_timer_begin(tm, MK_CG_SLAB, st);
-  hipLaunchKernelGGL(k_cg_slab<CGS_CAP>, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
-  if (mor_exp_dup() == MK_CG_SLAB && !d.cg_fused) hipLaunchKernelGGL(k_cg_slab<CGS_CAP>, dim3(d.B * d.P), dim3(CGS_T), 0, st, d);
-  mor_timer_end(tm, MK_CG_SLAB, st);
+  MOR_LAUNCH_T(MK_CG_SLAB, (k_cg_slab<CGS_CAP>), dim3(d.B * d.P), CGS_T, d);
   if (d.cg_fused) return;
-  mor_timer_begin(tm, MK_CG_FINAL, st);
-  hipLaunchKernelGGL(k_cg_final, dim3(d.B), dim3(CGF_T), 0, st, d);
-  mor_timer_end(tm, MK_CG_FINAL, st);
+  MOR_LAUNCH_T(MK_CG_FINAL, k_cg_final, dim3(d.B), CGF_T, d);
 }
 
 static void mor_launch_clusters(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // labels, cluster points, centroids, boxes; transform of ca; correspondences
@@ -3398,8 +3397,8 @@ static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
   if (d.has_prev) {
     if (d.method == 1) {
       if (d.pde_ub > 0.f && d.pde_ub > d.pde_lb) {
-        mor_timer_begin(tm, MK_SCORE_FAST, st); hipLaunchKernelGGL(k_score_fast, dim3(d.B * d.g_fast), dim3(SCF_T), 0, st, d); mor_timer_end(tm, MK_SCORE_FAST, st);
-        mor_timer_begin(tm, MK_SCORE_NB, st); hipLaunchKernelGGL(k_score_nb, dim3(2 * d.g_score * d.B), dim3(SCN_T), 0, st, d); mor_timer_end(tm, MK_SCORE_NB, st);
+        MOR_LAUNCH_T(MK_SCORE_FAST, k_score_fast, dim3(d.B * d.g_fast), SCF_T, d);
+        MOR_LAUNCH_T(MK_SCORE_NB, k_score_nb, dim3(d.g_score * d.B), SCN_T, d);
       }
     } else if (d.method == 2) {
       MOR_LAUNCH(MK_VOX_CLEAR, k_vox_clear, dim3(64, d.B), d);
@@ -3411,13 +3410,11 @@ static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
 
 static void mor_launch_scores2(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   if (d.has_prev && d.method == 1 && d.pde_ub > 0.f && d.pde_ub > d.pde_lb) {
-    mor_timer_begin(tm, MK_SCORE1, st); hipLaunchKernelGGL(k_score_pde, dim3(d.g_pde, d.B), dim3(SCP_T), 0, st, d); mor_timer_end(tm, MK_SCORE1, st);
+    MOR_LAUNCH_T(MK_SCORE1, k_score_pde, dim3(d.g_pde, d.B), SCP_T, d);
   }
 }
 static void mor_launch_decide(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  mor_timer_begin(tm, MK_TRACK_PUSH, st);
-  hipLaunchKernelGGL(k_track_push, dim3(d.B), dim3(64), 0, st, d);
-  mor_timer_end(tm, MK_TRACK_PUSH, st);
+  MOR_LAUNCH_T(MK_TRACK_PUSH, k_track_push, dim3(d.B), 64, d);
 }
 
 // The launches of one push, in dependency order, as MOR_N_PIECES pieces; the engine assigns consecutive pieces to its
@@ -3441,9 +3438,7 @@ void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part) {   // part 1: the tracking loop (the next frame's tracking step waits for this only); part 2: the output
   const dim3 gM(d.B * d.tiles_m), gB(d.B), gT2(d.B * (d.tiles_m + (d.out_ptrs ? d.tiles : 0)));
   if (part == 1) {   // the loop over mo_vec (:630-671): on EVERY filterCloud call, as in the reference — a second call on the same frame walks the tracks again
-    mor_timer_begin(tm, MK_TRACK_FILTER, st);
-    hipLaunchKernelGGL(k_track_filter, gB, dim3(64), 0, st, d);
-    mor_timer_end(tm, MK_TRACK_FILTER, st);
+    MOR_LAUNCH_T(MK_TRACK_FILTER, k_track_filter, gB, 64, d);
     return;
   }
   MOR_LAUNCH(MK_OUT_COUNT, k_out_count, gM, d);
