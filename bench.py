@@ -339,6 +339,32 @@ def compare_logs(a, b, keys_idx=None):
     return frames, bad
 
 
+def latency_b1(workload, device):
+    """One stream, synchronous push + filter of one cloud from / to page-locked host memory (what the drop-in class does per frame): median ms."""
+    from dynamicslamtool_amd import engine, kitti_params, synth
+    sensor, _, cfg, mo, go = WORKLOADS[workload]
+    p = kitti_params(mo or 1)
+    p.ground_method = go if go is not None else 0
+    npts = synth.n_points(sensor)
+    b1 = engine.MorBatch(p, 1, npts, 4, 3, device)
+    hin, hout = [engine.HostBuffer((npts, 4)) for _ in range(2)], engine.HostBuffer((npts, 4))
+    poses = []
+    for f in range(2):
+        x, pose = synth.frame(1000 * cfg, sensor, f)
+        hin[f].array[...] = x
+        poses.append(np.ascontiguousarray(pose[None, :]))
+    ts = []
+    for r in range(14):
+        t1 = time.perf_counter()
+        b1.push([hin[r % 2].array], poses[r % 2])
+        b1.filter_into([hout.array])
+        ts.append(time.perf_counter() - t1)
+    b1.close()
+    for x in hin + [hout]:
+        x.free()
+    return round(1e3 * float(np.median(ts[2:])), 3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -352,7 +378,13 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip value_runs, the other workloads, e2e / sync / latency legs")
     ap.add_argument("--dry-run", action="store_true", help="exercise only the multi-rank plumbing (no GPU work, no measurement)")
+    ap.add_argument("--latency-only", action="store_true", help="child process of the default run: push + filter latency of ONE stream, prints {\"latency_b1_ms\": …}")
+    ap.add_argument("--device", type=int, default=0, help="HIP ordinal for --latency-only")
     args = ap.parse_args()
+
+    if args.latency_only:
+        print(json.dumps({"latency_b1_ms": latency_b1(args.workload, args.device)}))
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))   # nothing above has touched HIP; the children are fresh processes
@@ -415,6 +447,16 @@ def main():
             xs, ps_ = synth.batch(seeds_main, [f] * B, sensor)
             hin[f].array[...] = np.asarray(xs).reshape(B, npts, 4)
             pp.append(np.ascontiguousarray(ps_))
+        # one stream (what the drop-in class does for one ROS node): push + filter of one cloud from / to page-locked host memory, in a
+        # process of its own as in a node (a batch behind other batches of the same process copies more slowly, see above: 0.64 against
+        # 0.46 ms — and a one-stream batch in THIS process in front of the end-to-end legs slows THEIR copies down the same way)
+        try:
+            import subprocess
+            r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--latency-only", "--device", str(device)], capture_output=True, text=True, timeout=300)
+            lat = json.loads(r_.stdout.strip().splitlines()[-1])["latency_b1_ms"]
+        except Exception as e_:   # reported as null, never silently
+            print("latency leg failed: %r" % (e_,), file=sys.stderr)
+            lat = None
         # ONE batch for both timed legs (the second batch of a process already copies device → host more slowly on this stack, see above):
         # synchronous push + filter pairs first, then the same calls enqueue-only (asynchronous mode: the staged copy of frame k + 1 runs
         # beside the kernels of frame k, the filtered clouds are assembled on the device and leave by DMA behind the kernels; one wait)
@@ -459,16 +501,6 @@ def main():
         hv.close()
         for x in hout2:
             x.free()
-        # one stream (what the drop-in class does for one ROS node): push + filter of one cloud from / to page-locked host memory
-        b1 = engine.MorBatch(p, 1, npts, 4, 3, device)
-        ts = []
-        for r in range(12):
-            t1 = time.perf_counter()
-            b1.push([hin[r % 2].array[0]], pp[r % 2][:1])
-            b1.filter_into([hout.array[0]])
-            ts.append(time.perf_counter() - t1)
-        lat = 1e3 * float(np.median(ts[2:]))
-        b1.close()
         for x in hin + [hout]:
             x.free()
 
