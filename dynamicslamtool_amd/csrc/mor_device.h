@@ -184,6 +184,7 @@ struct MorDev {
   float *pair_d;             // [B][Kcap]
   int *pair_cnt;             // [B][Kcap]
   int *pair_of_prev, *pair_of_cur; // [B][Kcap]
+  float4 *qrec;              // [B][Kcap][2]  per cluster of the previous frame, for the scoring tiers: (matched cluster's box low corner, pair index as int bits), (high corner, matched cluster) — one record instead of the chain pair_of_prev → pair_m → amin / amax
   int4 *wl; unsigned long long *wl_nb; // [B][Nmax], [B]  method-1 worklists after tier 1 (query, pair, matched cluster, –): E2-known queries from the front, block queries from the back; their counts share a word (low / high half)
   int4 *wl2; int *wl2_n;          // [B][Nmax], [B]  method-1 worklist of the wave tier
   unsigned long long *vox;   // [B][Hcap]

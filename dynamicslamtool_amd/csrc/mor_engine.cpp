@@ -399,7 +399,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = ok && dalloc(b, o.ktile_cnt, B * T) && dalloc(b, o.kcell, B * K) && dalloc(b, o.kroot, B * K) && dalloc(b, o.ksize, B * K) && dalloc(b, o.csz, B * K) && dalloc(b, o.krank_inv, B * K);
     ok = ok && dalloc(b, o.xcent, B * K) && dalloc(b, o.xamin, B * K) && dalloc(b, o.xamax, B * K) && dalloc(b, o.xfirst, B * K) && dalloc(b, o.part_back, B * (size_t)d.Wcap);
     ok = ok && dalloc(b, o.nn_fwd, B * K) && dalloc(b, o.nn_bwd, B * K) && dalloc(b, o.nn_fwd_d, B * K) && dalloc(b, o.pair_q, B * K) && dalloc(b, o.pair_m, B * K) && dalloc(b, o.pair_d, B * K);
-    ok = ok && dalloc(b, o.pair_cnt, B * K) && dalloc(b, o.pair_of_prev, B * K) && dalloc(b, o.pair_of_cur, B * K) && dalloc(b, o.det, B * K);
+    ok = ok && dalloc(b, o.pair_cnt, B * K) && dalloc(b, o.pair_of_prev, B * K) && dalloc(b, o.qrec, B * K * 2) && dalloc(b, o.pair_of_cur, B * K) && dalloc(b, o.det, B * K);
     ok = ok && dalloc(b, o.wl, B * N) && dalloc(b, o.wl_nb, B) && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B);
     ok = ok && dalloc(b, o.rs16, B * (size_t)d.rs16_stride) && dalloc(b, o.cx16, B * N);
     if (p->method_choice == 2) ok = ok && dalloc(b, o.vox, B * (size_t)d.Hcap);

@@ -2029,6 +2029,7 @@ __device__ __forceinline__ void xform_fin_body(const MorDev &d, int s) {
     d.xamin[(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
     d.xamax[(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
     d.pair_of_prev[(size_t)s * d.Kcap + k] = -1;
+    d.qrec[2 * ((size_t)s * d.Kcap + k)] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));   // no pair (pairs_body fills in the matched ones)
   }
 }
 
@@ -2081,6 +2082,8 @@ __device__ __forceinline__ void pairs_body(const MorDev &d, int s, int *sh) {
       int pr = carry + e;
       d.pair_q[ko + pr] = i; d.pair_m[ko + pr] = j; d.pair_d[ko + pr] = d.nn_fwd_d[ko + i]; d.pair_cnt[ko + pr] = 0;
       d.pair_of_prev[ko + i] = pr; d.pair_of_cur[ko + j] = pr;
+      const float4 c0 = ld_agent_f4(&d.amin[d.cur][ko + j]), c1 = ld_agent_f4(&d.amax[d.cur][ko + j]);
+      d.qrec[2 * (ko + i)] = make_float4(c0.x, c0.y, c0.z, __int_as_float(pr)); d.qrec[2 * (ko + i) + 1] = make_float4(c1.x, c1.y, c1.z, __int_as_float(j));
     }
     carry += tot;
   }
@@ -2209,16 +2212,15 @@ __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
     unsigned long long f1 = f0, f2 = f0;
 #endif
     if (j < Cp) {
-      // two chains of dependent loads, issued side by side (no branch between them): cluster → pair → matched cluster → its box,
-      // and point → cell (LDS index) → range + cluster id of the cell → points.  (One after the other they were seven levels deep.)
+      // two short chains of dependent loads, issued side by side (no branch between them): cluster → its record (pair, matched cluster,
+      // that cluster's box), and point → cell (LDS index) → range + cluster id of the cell → points.  (Round 1: seven levels, one after the other.)
       const int cidj = d.cl_cid[pv][so + j];
       const float4 q = d.cl_pts[pv][so + j];
       const int cx = cell_axis_unclamped(q.x, G.ox, G.inv_cs), cy = cell_axis_unclamped(q.y, G.oy, G.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], G.inv_cs);
       const int c = cidx_find(I, cx, cy, cz);   // (LDS: no global access)
-      pr = d.pair_of_prev[ko + cidj];
+      const float4 tlo = d.qrec[2 * (ko + cidj)], thi = d.qrec[2 * (ko + cidj) + 1];   // the matched cluster's box, the pair, the matched cluster: one record per previous cluster (pairs_body)
       const int cc = max(c, 0), cid = d.ccid[so + cc], b0 = c >= 0 ? st[cc] : 0, e0 = c >= 0 ? st[cc + 1] : 0;
-      target = min(max(d.pair_m[ko + max(pr, 0)], 0), d.Kcap - 1);   // (pr < 0: a stale entry, clamped — its box is loaded but not used)
-      const float4 tlo = d.amin[d.cur][ko + target], thi = d.amax[d.cur][ko + target];
+      pr = __float_as_int(tlo.w); target = __float_as_int(thi.w);
 #ifdef MOR_EXP_STAMPS
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f1 = wall_clock64();
 #endif
@@ -2239,19 +2241,22 @@ __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f2 = wall_clock64();
 #endif
     }
-    count_push(counted, d.pair_cnt + ko, pr);
-    {  // both ends of `wl` with ONE returning atomic per wave (the two counters share a 64-bit word)
-      const unsigned long long mn = __ballot(nearq), mb = __ballot(blockq);
-      if (mn | mb) {
-        const int leader = __ffsll((long long)(mn | mb)) - 1;
-        unsigned long long base = 0ull;
-        if (lane_id() == leader) base = atomicAdd(&d.wl_nb[s], (unsigned long long)__popcll(mn) | ((unsigned long long)__popcll(mb) << 32));
-        const int bn = __shfl((int)(unsigned)base, leader, 64), bb = __shfl((int)(base >> 32), leader, 64);
+    {  // the worklists: both ends of `wl` with ONE returning atomic per wave (the two counters share a 64-bit word), `wl2` with another,
+       // both issued by lane 0 before either answer is used (one round trip instead of two)
+      const unsigned long long mn = __ballot(nearq), mb = __ballot(blockq), mg = __ballot(big);
+      if (mn | mb | mg) {
+        unsigned long long base = 0ull; int base2 = 0;
+        if (lane_id() == 0) {
+          if (mn | mb) base = atomicAdd(&d.wl_nb[s], (unsigned long long)__popcll(mn) | ((unsigned long long)__popcll(mb) << 32));
+          if (mg) base2 = atomicAdd(&d.wl2_n[s], __popcll(mg));
+        }
+        const int bn = __shfl((int)(unsigned)base, 0, 64), bb = __shfl((int)(base >> 32), 0, 64), b2 = __shfl(base2, 0, 64);
         if (nearq) d.wl[so + bn + __popcll(mn & lanemask_lt())] = make_int4(j, pr, target, 0);
         if (blockq) d.wl[so + d.Nmax - 1 - (bb + __popcll(mb & lanemask_lt()))] = make_int4(j, pr, target, 0);
+        if (big) d.wl2[so + b2 + __popcll(mg & lanemask_lt())] = make_int4(j, pr, target, 0);
       }
     }
-    wl_push(big, &d.wl2_n[s], d.wl2 + so, j, pr, target);
+    count_push(counted, d.pair_cnt + ko, pr);
 #ifdef MOR_EXP_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     { const int n_near = __popcll(__ballot(nearq)), n_block = __popcll(__ballot(blockq)), n_big = __popcll(__ballot(big));
