@@ -47,7 +47,7 @@ struct MorStreamArgs {       // per stream, per push (host → device, one small
 struct MorFrameInfo {        // per stream, produced on device
   uint32_t N, T, M, G, K, C, n_pairs, flags;   // flags bit0: cluster capacity exceeded, bit1: voxel key overflow
   uint32_t Kprev, Cprev, n_keep, n_occ;   // n_occ: occupied grid cells
-  uint32_t n_defer, pad0, hshift, max_loc;   // n_defer: method-1 queries handed to the wave tier; hshift: 32 − log2(size of the stream's cell hash table); max_loc: cells (own + look-ahead) of the largest slab of the cell graph
+  uint32_t n_defer, pad0, hshift, max_loc;   // n_defer: method-1 queries handed to the wave tier; hshift: unused; max_loc: cells (own + look-ahead) of the largest slab of the cell graph
 };
 
 // Temporal logic (T1 + the tracking loop of F1) as device state, one instance per stream.  O(clusters) sequential work
@@ -171,7 +171,7 @@ struct MorDev {
   int *cl_cid[MOR_MAX_SLOTS];            // [B][Nmax]  cluster id per cl_pts entry
   int *cl_off[MOR_MAX_SLOTS];            // [B][Kcap+1]
   int *chunk_off[MOR_MAX_SLOTS];         // [B][Kcap+1]  first reduction chunk of each cluster
-  Red6 *part_back; int Wcap; // [B][Wcap]  per-chunk partials of k_xform_prev (pair stage)
+  Red6 *part_back; int Wcap; // [B][Wcap]  per-chunk partials of the transform of ca (k_clusters' transform workgroups)
   float4 *centroid[MOR_MAX_SLOTS];       // [B][Kcap]  centroid_collection (:243)
   float4 *amin[MOR_MAX_SLOTS], *amax[MOR_MAX_SLOTS]; // [B][Kcap]  cluster AABBs (getMinMax3D, :272-274)
   float4 *xcent, *xamin, *xamax; // [B][Kcap]  ca's centroids and AABBs after the transform into cb's frame (:540-550)

@@ -649,13 +649,14 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
 // (a wall two metres from the sensor puts thousands of returns into one 28-cm cell; M ranges 5 k … 60 k over the
 // streams of one batch).  Sorting all points by key moves every point three times; what the later stages need is only:
 // the distinct keys in ascending order (compact cell ids), the points grouped by cell (any order inside a cell — every
-// consumer tests existence, takes a min / max or counts), and the (y,z) row table.  So one workgroup per stream
-//   1. counts the points of every cell in an LDS hash table (open addressing; LDS atomics digest the hot cells),
-//   2. orders the distinct cells through the row table: a cell's compact id is its row's first id plus the number of
-//      cells of the row with a smaller x (rows are short) — no sort,
-//   3. turns the counts into ranges of `sorted` and hands every point its position (LDS cursor per cell),
-// and a wide kernel (k_gridfill) moves the points.  The table doubles as the cell hash of the method-1 scoring tiers.
-// Streams with more cells than the LDS table holds run the same code on a table in global memory.
+// consumer tests existence, takes a min / max or counts), and the (y,z) row table.  So the build
+//   1. counts the points of every cell in LDS hash tables (open addressing; LDS atomics digest the hot cells) — chunk by chunk, many
+//      workgroups per stream (k_gridcount),
+//   2. merges the chunks' short lists of distinct cells in ONE workgroup per stream (k_gridhash) and orders the cells through the row
+//      table: a cell's compact id is its row's first id plus the number of cells of the row with a smaller x — no sort,
+//   3. turns the counts into ranges of `sorted`, and every point draws its position from an LDS cursor of its chunk's entry (k_gridplace).
+// k_gridhash also writes the 16-bit row table + x of every cell that the scoring tiers copy into their LDS (CellIdx above).
+// Streams with more cells than the LDS tables hold run the same code on tables in global memory (tiers 1 / 2).
 #define CB_WTILE 256      // positions of `sorted` one wave of k_cellboxes handles per step (four consecutive ones per lane)
 #ifndef GH_T
 #define GH_T 1024
@@ -2090,7 +2091,7 @@ __device__ __forceinline__ void pairs_body(const MorDev &d, int s, int *sh) {
   if (threadIdx.x == 0) { d.info[s].n_pairs = carry; d.wl_nb[s] = 0ull; d.wl2_n[s] = 0; }
 }
 // One workgroup per stream: everything per CLUSTER between the point kernels — boxes, centroids and first points of the
-// transformed ca (from k_xform_prev's partials), both nearest-centroid directions, the correspondences.
+// transformed ca (from the partials of k_clusters' transform workgroups), both nearest-centroid directions, the correspondences.
 __device__ __forceinline__ void cluster_pairs_body(const MorDev &d, int s, float4 *tile, int *sh) {
   if (!d.has_prev) return;
   xform_fin_body(d, s);
@@ -2112,9 +2113,9 @@ __device__ __forceinline__ void cluster_pairs_body(const MorDev &d, int s, float
 // iff E2 ∧ ¬E1.  All points of a grid cell belong to one component (the cell is a clique), so the cluster id is a
 // per-CELL attribute (ccid, also in .w of the cell's box record): candidates are filtered cell by cell without
 // touching their points, and a cell's point box gives a lower bound that prunes it.
-//   tier 1  k_score_fast   thread per query, its own cell (hash probe → cell → points): static surfaces end here
-//   tier 1a k_score_near   thread per query with E2 known: the ≤ 7 neighbour cells across the walls q is close to
-//   tier 1b k_score_block  thread per query whose own cell has no matched point: E2 (then E1) in the 3×3×3 block
+//   tier 1  k_score_fast   thread per query, its own cell (LDS cell index → cell → points): static surfaces end here
+//   tier 1a k_score_nb (front of the worklist)   thread per query with E2 known: the ≤ 7 neighbour cells across the walls q is close to
+//   tier 1b k_score_nb (back of the worklist)    thread per query whose own cell has no matched point: E2 (then E1) in the 3×3×3 block
 //   tier 2  k_score_pde    wave per query for what is left: big cells, matches farther than one cell
 // Lesson of the profile: a thread's time is the NUMBER of dependent load levels (≈ 2 µs each under load), not bytes;
 // every tier is written as a few levels of batched independent loads.
@@ -2284,7 +2285,7 @@ __device__ __forceinline__ void scan_batch4(const MorDev &d, size_t so, const in
 #define SCN_T 512   // threads per workgroup of tiers 1a / 1b (eight waves share one LDS copy of the cell index)
 
 // Tier 1a — one THREAD per query with E2 known (worklist front).  E1: only the ≤ 7 neighbour cells across the walls q
-// is close to can hold a point within √lb (the own cell was scanned by tier 1).  Three levels of loads: hash probes →
+// is close to can hold a point within √lb (the own cell was scanned by tier 1).  Three levels of loads: cell lookups (LDS index) →
 // box records + ranges → points.  No such point ⇒ counted.
 __device__ __forceinline__ void score_near_body(const MorDev &d, const CellIdx &I, int s, int chunk) {
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
@@ -2325,7 +2326,7 @@ __device__ __forceinline__ void score_near_body(const MorDev &d, const CellIdx &
   }
 }
 // Tier 1b — one THREAD per query whose own cell holds no matched point (worklist back).  The 26 other cells of the
-// 3×3×3 block: hash probes → cluster ids → up to 8 matched cells (those that can hold a point within √lb first) →
+// 3×3×3 block: cell lookups (LDS index, row by row) → cluster ids → up to 8 matched cells (those that can hold a point within √lb first) →
 // box records + ranges → points.  E2 hit ⇒ E1 is decided by the same cells; no hit ⇒ the wider stencil is the wave tier's job.
 __device__ __forceinline__ void score_block_body(const MorDev &d, const CellIdx &I, int s, int chunk) {
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
@@ -3356,7 +3357,7 @@ grid:
   }
 }
 static void mor_launch_boxes(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
-  MOR_LAUNCH(MK_CELLBOXES, k_cellboxes, dim3(d.g_box * d.B), d);   // point boxes, smallest index, slabs (+ cell hash on the sort path)
+  MOR_LAUNCH(MK_CELLBOXES, k_cellboxes, dim3(d.g_box * d.B), d);   // point boxes, smallest index, exact coordinate sums of every cell
 }
 
 // Voxel-covariance ground removal as six sub-pieces (the lane schedule runs sub-piece q of frame k beside other sub-pieces of
