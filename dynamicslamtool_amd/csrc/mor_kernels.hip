@@ -1922,13 +1922,22 @@ __global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
   else if (t < d.tiles_m) {
     const int M = d.info[s].M;
     float4 *dst = d.cl_pts[d.cur] + so; int *dcid = d.cl_cid[d.cur] + so;
-    for (int j = t * MOR_BT + threadIdx.x; j < M; j += d.tiles_m * MOR_BT) {
-      const float4 p = d.sorted[so + j];
-      const int4 g = d.cgat[so + d.scell[so + j]];
-      d.pcid[so + __float_as_int(p.w)] = g.y;   // label of the cloud point (its index travels in .w)
-      if (g.y < 0) continue;
-      dst[j + g.x] = p; dcid[j + g.x] = g.y;
-      if (__float_as_int(p.w) == g.z) d.cl_first[d.cur][ko + g.y] = p;
+    const int stride = d.tiles_m * MOR_BT;
+    for (int j0 = t * MOR_BT + threadIdx.x; j0 < M; j0 += 4 * stride) {   // four positions per thread and round trip: point + cell id, then the cell's record, then the stores
+      float4 p[4]; int sc[4]; int4 g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int j = min(j0 + u * stride, M - 1); p[u] = d.sorted[so + j]; sc[u] = d.scell[so + j]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g[u] = d.cgat[so + sc[u]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u * stride;
+        if (j >= M) continue;
+        d.pcid[so + __float_as_int(p[u].w)] = g[u].y;   // label of the cloud point (its index travels in .w)
+        if (g[u].y < 0) continue;
+        dst[j + g[u].x] = p[u]; dcid[j + g[u].x] = g[u].y;
+        if (__float_as_int(p[u].w) == g[u].z) d.cl_first[d.cur][ko + g[u].y] = p[u];
+      }
     }
   } else {
   const int K = d.info[s].K, lane = lane_id();
