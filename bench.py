@@ -68,11 +68,16 @@ def self_launch(n, argv):
     return rc
 
 
+_ALL_CORES = None
+
+
 def bind_rank_to_cores(local_rank, world):
     """Rank r keeps the r-th slice of the cores this process may run on (host threads of one rank stay on one part of the machine; the
     OpenMP cloud generator of each rank then uses its slice only instead of every rank using every core)."""
+    global _ALL_CORES
     try:
         cores = sorted(os.sched_getaffinity(0))
+        _ALL_CORES = cores
         per = len(cores) // world
         if world > 1 and per >= 1:
             os.sched_setaffinity(0, cores[local_rank * per:(local_rank + 1) * per])
@@ -346,6 +351,7 @@ def latency_b1(workload, device):
     p = kitti_params(mo or 1)
     p.ground_method = go if go is not None else 0
     npts = synth.n_points(sensor)
+    engine.bind_thread_to_device_node(device)
     b1 = engine.MorBatch(p, 1, npts, 4, 3, device)
     hin, hout = [engine.HostBuffer((npts, 4)) for _ in range(2)], engine.HostBuffer((npts, 4))
     poses = []
@@ -432,6 +438,19 @@ def main():
     if ndev < 1:
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback in the product path)")
     device = local_rank % ndev
+    # the enqueueing thread (and everything it allocates from here on) next to its GPU: from the other socket the same run is 5–6 % slower.
+    # Ranks whose GPUs hang on the same NUMA node share that node's cores in equal slices.
+    numa_node = engine.device_numa_node(device)
+    if numa_node >= 0:
+        peers = [r for r in range(world) if engine.device_numa_node(r % ndev) == numa_node]   # (one node: local rank = rank)
+        mine_before = sorted(os.sched_getaffinity(0))
+        if _ALL_CORES:
+            os.sched_setaffinity(0, _ALL_CORES)   # the slice taken for the CPU legs may lie on the other socket: choose among all cores again
+        kept = engine.bind_thread_to_device_node(device, peers.index(local_rank) if local_rank in peers else 0, max(len(peers), 1))
+        if kept:
+            cores_mine = kept
+        else:
+            os.sched_setaffinity(0, mine_before)
 
     # ---- end-to-end legs FIRST: on this stack device → host copies of a batch created after gigabytes of device memory have come and gone
     #      (the headline leg's) run at 10 GB/s instead of 55 (exp/e2e_probe.py --prelude); an application has one batch per process, as here
@@ -617,6 +636,7 @@ def main():
                        "streams_per_gpu": B, "points_per_frame": npts, "parallelism": "streams sharded over %d GPU(s), no collective" % world,
                        "profile": profile},
             "collective": "none", "first_seed_per_rank": first_seeds, "self_launched": bool(os.environ.get("MOR_BENCH_SELF_LAUNCHED")), "devices_visible": ndev, "ranks_per_device": (world + ndev - 1) // ndev,
+            "host_numa_node_of_gpu": numa_node, "host_cores_bound_rank0": cores_mine,
             "value_runs": value_runs, "per_rank_frame_pairs_per_s": [round(x, 1) for x in per_rank], "per_rank_frame_pairs_per_s_min_max": [round(min(per_rank), 1), round(max(per_rank), 1)],
             "device_ms_per_step": round(dev_ms, 4), "sync_frame_pairs_per_s": None if sync_rate is None else round(sync_rate, 1),
             "e2e_host_frame_pairs_per_s": None if e2e is None else round(e2e, 2), "e2e_host_sync_ms_per_step": e2e_ms, "e2e_host_async_frame_pairs_per_s": None if e2e_async is None else round(e2e_async, 2), "e2e_host_async_equals_sync": e2e_async_ok, "latency_b1_ms": None if lat is None else round(lat, 3),

@@ -4,6 +4,7 @@
 // (/root/reference/src/MovingObjectRemoval.cpp:516-611, :613-696) for B independent streams.
 #include "mor_device.h"
 #include "../../include/mor_hip.h"
+#include <sched.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -278,6 +279,41 @@ extern "C" {
 size_t mor_sizeof_params(void) { return sizeof(mor_params); }
 const char *mor_last_error(void) { return g_last_error.c_str(); }
 int mor_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+
+// NUMA node of a HIP device: its PCI address → /sys/bus/pci/devices/<address>/numa_node
+int mor_device_numa_node(int device) {
+  char id[64] = {0};
+  if (hipDeviceGetPCIBusId(id, (int)sizeof id - 1, device) != hipSuccess) return -1;
+  for (char *c = id; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+  char path[160]; snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", id);
+  FILE *f = fopen(path, "r"); if (!f) return -1;
+  int node = -1; if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  return node;
+}
+int mor_bind_thread_to_device_node(int device, int share_index, int share_count) {
+  const int node = mor_device_numa_node(device);
+  if (node < 0) return 0;
+  char path[96]; snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+  FILE *f = fopen(path, "r"); if (!f) return 0;
+  char buf[4096] = {0}; const size_t got = fread(buf, 1, sizeof buf - 1, f); fclose(f);
+  if (!got) return 0;
+  cpu_set_t allowed, want; CPU_ZERO(&want);
+  if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return 0;
+  std::vector<int> cpus;
+  for (char *p = buf; *p;) {   // "0-63,128-191"
+    char *e; long a = strtol(p, &e, 10); if (e == p) break; long b2 = a;
+    if (*e == '-') { p = e + 1; b2 = strtol(p, &e, 10); }
+    for (long c = a; c <= b2 && c < CPU_SETSIZE; ++c) if (CPU_ISSET((int)c, &allowed)) cpus.push_back((int)c);
+    p = (*e == ',') ? e + 1 : e; if (*p == '\n') break;
+  }
+  if (cpus.empty()) return 0;
+  size_t lo = 0, hi = cpus.size();
+  if (share_count > 1 && share_index >= 0 && share_index < share_count && cpus.size() >= (size_t)share_count) { const size_t per = cpus.size() / share_count; lo = per * share_index; hi = lo + per; }
+  for (size_t i = lo; i < hi; ++i) CPU_SET(cpus[i], &want);
+  if (sched_setaffinity(0, sizeof want, &want) != 0) return 0;
+  return (int)(hi - lo);
+}
 
 void mor_batch_destroy(mor_batch *b) {
   if (!b) return;

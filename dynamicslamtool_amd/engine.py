@@ -19,6 +19,7 @@ EXPORTS = [
     "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_get_stage_counts", "mor_device_alloc", "mor_device_free", "mor_host_alloc", "mor_host_free",
     "mor_device_upload", "mor_device_download", "mor_device_synchronize", "mor_device_count", "mor_get_last_timing",
     "mor_kernel_timing_enable", "mor_kernel_timing_read", "mor_get_frame_log", "mor_debug_read", "mor_debug_config", "mor_get_markers", "mor_kernel_timeline_read",
+    "mor_device_numa_node", "mor_bind_thread_to_device_node",
 ]
 
 
@@ -95,6 +96,17 @@ def _check(rc):
 
 def device_count():
     return int(lib().mor_device_count())
+
+
+def device_numa_node(device=0):
+    """NUMA node the HIP device is attached to (−1: unknown)."""
+    return int(lib().mor_device_numa_node(int(device)))
+
+
+def bind_thread_to_device_node(device=0, share_index=0, share_count=1):
+    """Restricts the calling thread to the CPUs of the device's NUMA node (a slice of them when several processes share the node);
+    returns the number of CPUs kept, 0 when nothing was changed.  Create the batch and enqueue its frames from that thread."""
+    return int(lib().mor_bind_thread_to_device_node(int(device), int(share_index), int(share_count)))
 
 
 class DeviceBuffer:

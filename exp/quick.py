@@ -3,6 +3,14 @@ usage: quick.py [tag] [--kernels] [--workload W] [--steps S] [--reps N]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("PIN_NODE"):   # experiment: run (and allocate page-locked memory) on the cores of one NUMA node
+    def _cpus(txt):
+        out = []
+        for part in txt.strip().split(","):
+            a, _, b = part.partition("-")
+            out += list(range(int(a), int(b or a) + 1))
+        return out
+    os.sched_setaffinity(0, _cpus(open("/sys/devices/system/node/node%s/cpulist" % os.environ["PIN_NODE"]).read()))
 import numpy as np
 import bench
 from dynamicslamtool_amd import engine, kitti_params, synth, shard

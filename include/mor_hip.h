@@ -174,6 +174,14 @@ int mor_device_upload(int device, void *dst, const void *src, size_t bytes);
 int mor_device_download(int device, void *dst, const void *src, size_t bytes);
 int mor_device_synchronize(int device);
 int mor_device_count(void);
+/* Host placement.  The thread that creates a batch and enqueues its frames should run on the NUMA node the GPU is attached to: the
+ * command queues and the page-locked rings it fills live where it runs, and from the other socket the same run is 5–6 % slower
+ * (measured on a two-socket MI355X host: 166 k against 176 k frame-pairs/s).  mor_device_numa_node returns that node (from the device's
+ * PCI address and sysfs; −1 when it cannot be told); mor_bind_thread_to_device_node restricts the CALLING thread to the CPUs of that
+ * node it is already allowed on — `share_index` of `share_count` equal slices of them when several processes serve GPUs of one node
+ * (0, 1: all of them) — and returns the number of CPUs it kept (0: nothing changed).  The library never changes affinities by itself. */
+int mor_device_numa_node(int device);
+int mor_bind_thread_to_device_node(int device, int share_index, int share_count);
 
 /* ---- timing hooks (HIP events on the batch's own stream) ---- */
 /* milliseconds spent in device work of the last push / filter (event-timed), and the accumulated
