@@ -228,6 +228,8 @@ struct MorLaunchTimer;   // engine-owned; records event pairs when enabled
 #define MOR_MAX_PIECES 13   // pieces of a push, at most (voxel ground variant: its grid stage is six of them)
 // piece ids: 7 split | 8 grid build (crop variant) or 10 … 15 (voxel ground variant) | 1 cell boxes | 2 cell graph | 3 clusters |
 //            (3 also: transform of ca, correspondences) | 4 thread tiers of the scores / voxel kernels of method 2 | 5 wave tier | 6 thresholds + tracking
+// small host → device copies on a stream as a one-workgroup kernel (the source is page-locked host memory the device reads directly)
+void mor_launch_copy(void *dst, const void *src_pinned, size_t bytes, hipStream_t st);
 void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer *tm);
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part);
 int mor_split_blocks_per_cu();

@@ -111,12 +111,14 @@ struct mor_batch {
   bool d2h_used[MOR_MAX_SLOTS] = {};
   hipEvent_t ev_out[MOR_MAX_SLOTS] = {};        // recorded after the output kernels of a filterCloud (they run in frame order: pinned size mirrors, tile counts)
   hipEvent_t *last_out = nullptr;
+  // The stream every such event was last recorded on: a wait for an event of the SAME stream is implied by stream order, and every
+  // packet the command processor does not have to fetch, resolve and signal is a few microseconds of a lane (exp/gaps.py)
+  hipStream_t ev_back_st[MOR_MAX_SLOTS] = {}; hipStream_t last_track_st = nullptr, last_out_st = nullptr;
   MorDev dtemp[MOR_MAX_DEPTH];               // descriptor templates, frame k uses dtemp[k % depth] (static part + pointers)
   MorDev d;                                  // descriptor of the latest pushed frame
   MorStreamArgs *d_args_s[MOR_MAX_DEPTH] = {};
   std::vector<void *> dev_allocs, host_allocs;
   MorStreamArgs *h_args_ring = nullptr, *h_args = nullptr;   // pinned ring of MOR_ARGS_RING slots (async pushes), current slot
-  hipEvent_t args_ev[MOR_ARGS_RING] = {};
   uint64_t pipe_depth = 4, n_slots = 5;       // frames in flight (= copies of the per-frame arrays); cluster-array slots = depth + 1
   int env_cg_p = 0, env_gc_p = 0;         // tuning knobs from the environment (MOR_CG_P, MOR_GC_P), read once at creation
   bool async = false, pending = false;   // async: push/filter only enqueue; pending: work enqueued since the last wait
@@ -326,7 +328,6 @@ void mor_batch_destroy(mor_batch *b) {
   if (b->sm) hipStreamSynchronize(b->sm);
   if (b->sb) hipStreamSynchronize(b->sb);
   for (auto &x : b->extra) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
-  for (auto &ev : b->args_ev) if (ev) hipEventDestroy(ev);
   for (auto &ev : b->outptr_ev) if (ev) hipEventDestroy(ev);
   for (auto *arr : {b->ev_clusters, b->ev_pairs, b->ev_tpush}) for (int i = 0; i < MOR_MAX_SLOTS; ++i) if (arr[i]) hipEventDestroy(arr[i]);
   for (auto &ev : b->ev_back) if (ev) hipEventDestroy(ev);
@@ -362,7 +363,6 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (getenv("MOR_GC_P")) b->env_gc_p = atoi(getenv("MOR_GC_P"));
   if ((rc = configure(b)) != MOR_OK) return fail(rc);
   if (n_bad > MOR_TR_NB) return fail(set_error(MOR_ERR_INVALID, "n_bad = %d: windows longer than %d frames are not supported", n_bad, MOR_TR_NB));
-  for (auto &ev : b->args_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   for (auto &ev : b->outptr_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
   {
     MorCopyStreams *cs = copy_streams(device);
@@ -479,9 +479,16 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     b->stage_stride = (max_host_bytes + 255) & ~(size_t)255;
     HIP_TRY(hipMalloc((void **)&b->d_stage, b->stage_stride * B * b->pipe_depth));
   }
-  // pinned argument slot of this push (a ring, so asynchronous pushes never overwrite a slot the GPU still has to copy)
+  // The frame before this one was pushed but not filtered (push, push): its tracking step and its end get their events now, on its lane
+  // — a filterCloud records them itself, and a push that is followed by its filterCloud (the usual case) needs neither
+  if (k > 0 && !b->filtered) {
+    const uint64_t kq = (k - 1) % MOR_MAX_SLOTS; hipStream_t pl = b->lane_stream(k - 1);
+    HIP_TRY(hipEventRecord(b->ev_tpush[kq], pl)); b->last_track = &b->ev_tpush[kq]; b->last_track_st = pl;
+    HIP_TRY(hipEventRecord(b->ev_back[kq], pl)); b->ev_back_st[kq] = pl;
+  }
+  // pinned argument slot of this push: a ring of MOR_ARGS_RING slots; the slot's last user, frame k − MOR_ARGS_RING, must have completed
   const int slot = (int)(k % MOR_ARGS_RING);
-  HIP_TRY(hipEventSynchronize(b->args_ev[slot]));
+  if (k >= MOR_ARGS_RING) HIP_TRY(hipEventSynchronize(b->ev_back[(k - MOR_ARGS_RING) % MOR_MAX_SLOTS]));
   b->h_args = b->h_args_ring + (size_t)slot * B;
   std::vector<PoseTf> cur(B);
   for (int s = 0; s < B; ++s) {
@@ -522,7 +529,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   //      uses (same buffer copy; its cluster slot doubles as the `ca` slot of frame k−depth+1)
   hipStream_t lane = b->lane_stream(k);
   const uint64_t depth = b->pipe_depth, ks = k % MOR_MAX_SLOTS, kp = (k + MOR_MAX_SLOTS - 1) % MOR_MAX_SLOTS;
-  if (k >= depth) HIP_TRY(hipStreamWaitEvent(lane, b->ev_back[(k - depth) % MOR_MAX_SLOTS], 0));   // the frame that used this copy of the per-frame arrays (and this cluster slot as its ca) is done
+  if (k >= depth && b->ev_back_st[(k - depth) % MOR_MAX_SLOTS] != lane) HIP_TRY(hipStreamWaitEvent(lane, b->ev_back[(k - depth) % MOR_MAX_SLOTS], 0));   // the frame that used this copy of the per-frame arrays (and this cluster slot as its ca) is done (with as many lanes as copies it ran on this very lane)
   // (the staging area of this frame's copy was last read by the split of frame k − depth: covered by the wait above)
   if (max_host_bytes > 0) {   // host-resident blobs are staged through device memory, on the host → device copy stream
     hipStream_t cs = b->s_h2d_[0];
@@ -538,10 +545,10 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     HIP_TRY(hipEventRecord(b->ev_h2d[ks], cs));
     HIP_TRY(hipStreamWaitEvent(lane, b->ev_h2d[ks], 0));
   }
-  HIP_TRY(hipMemcpyAsync(b->d_args_s[k % b->pipe_depth], b->h_args, sizeof(MorStreamArgs) * B, hipMemcpyHostToDevice, lane));
-  HIP_TRY(hipEventRecord(b->args_ev[slot], lane));
-  HIP_TRY(hipEventRecord(b->ev[0], lane));
-  hipStream_t tail = lane;
+  // the per-stream arguments: a one-workgroup kernel reads the page-locked slot (5 KB) — a hipMemcpyAsync here kept the lane idle for ≈ 35 µs
+  // in front of every frame's first kernel (copy packet, its signal, the barrier behind it)
+  mor_launch_copy(b->d_args_s[k % b->pipe_depth], b->h_args, sizeof(MorStreamArgs) * B, lane);
+  if (!b->async) HIP_TRY(hipEventRecord(b->ev[0], lane));
   for (int pc = 0; pc < b->n_pieces; ++pc) {
     const int id = b->piece_id[pc];
     const bool trk = pc == b->n_pieces - 1;
@@ -549,14 +556,14 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
       HIP_TRY(hipStreamWaitEvent(lane, b->ev_clusters[kp], 0));
       if (d.method == 2) HIP_TRY(hipStreamWaitEvent(lane, b->ev_pairs[kp], 0));   // … which frame k − 1's own voxel probe (method 2) must have finished reading
     }
-    if (trk && b->last_track) HIP_TRY(hipStreamWaitEvent(lane, *b->last_track, 0));   // tracking state: after the previous frame's filterCloud loop
+    if (trk && b->last_track && b->last_track_st != lane) HIP_TRY(hipStreamWaitEvent(lane, *b->last_track, 0));   // tracking state: after the previous frame's filterCloud loop
     mor_launch_piece(d, id, lane, &b->timer);
     if (id == 3) HIP_TRY(hipEventRecord(b->ev_clusters[ks], lane));
     if (id == 4 && d.method == 2) HIP_TRY(hipEventRecord(b->ev_pairs[ks], lane));
-    if (trk) { HIP_TRY(hipEventRecord(b->ev_tpush[ks], lane)); b->last_track = &b->ev_tpush[ks]; }
   }
-  HIP_TRY(hipEventRecord(b->ev[1], tail));
-  HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], tail));
+  if (!b->async) HIP_TRY(hipEventRecord(b->ev[1], lane));
+  // (no event for the tracking step or the end of the frame here: the frame's filterCloud follows on this lane and records both;
+  //  a push without one gets them at the start of the next push)
   HIP_TRY(hipGetLastError());
   b->d = d; b->frame++; b->filtered = false; b->pending = true;
   if (b->async) return MOR_OK;
@@ -576,7 +583,7 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
   b->filtered = true;
   d.out_ptrs = nullptr;
   hipStream_t fs = b->lane_stream(k);   // behind the frame's push
-  if (b->last_track) HIP_TRY(hipStreamWaitEvent(fs, *b->last_track, 0));   // a second filterCloud of a frame, or the frame's own tracking step (same stream: free)
+  // (the tracking step in front of this one — the frame's push, or an earlier filterCloud of the same frame — ran on this very stream)
   // Asynchronous mode with HOST output pointers: the output kernels assemble every stream's filtered cloud in a device staging area of
   // this frame and DMA copies of the stream's input size (an upper bound of the output: the caller's buffers hold n_in points, as the
   // synchronous form requires) carry them out behind the kernels — nothing waits; the sizes are read after the wait (mor_get_output_device).
@@ -587,19 +594,19 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
     HIP_TRY(hipEventSynchronize(b->outptr_ev[oslot]));
     float4 **hp = b->h_outptrs + (size_t)oslot * B, **dp = b->d_outptrs + (size_t)(k % b->pipe_depth) * B;
     for (int s = 0; s < B; ++s) hp[s] = host_async ? b->d_outstage + ((size_t)(k % b->pipe_depth) * B + s) * d.Nmax : (float4 *)out[s];
-    HIP_TRY(hipMemcpyAsync(dp, hp, sizeof(float4 *) * B, hipMemcpyHostToDevice, fs));
+    mor_launch_copy(dp, hp, sizeof(float4 *) * B, fs);
     HIP_TRY(hipEventRecord(b->outptr_ev[oslot], fs));
     d.out_ptrs = dp;
   }
-  HIP_TRY(hipEventRecord(b->ev[2], fs));
+  if (!b->async) HIP_TRY(hipEventRecord(b->ev[2], fs));
   mor_launch_filter(d, fs, &b->timer, 1);
-  HIP_TRY(hipEventRecord(b->ev_track[k % MOR_MAX_SLOTS], fs)); b->last_track = &b->ev_track[k % MOR_MAX_SLOTS];   // the tracking state is settled: the next frame's tracking step may follow
-  if (b->last_out) HIP_TRY(hipStreamWaitEvent(fs, *b->last_out, 0));
+  HIP_TRY(hipEventRecord(b->ev_track[k % MOR_MAX_SLOTS], fs)); b->last_track = &b->ev_track[k % MOR_MAX_SLOTS]; b->last_track_st = fs;   // the tracking state is settled: the next frame's tracking step may follow
+  if (b->last_out && b->last_out_st != fs) HIP_TRY(hipStreamWaitEvent(fs, *b->last_out, 0));
   if (host_async && k >= b->pipe_depth && b->d2h_used[(k - b->pipe_depth) % MOR_MAX_SLOTS]) {   // the output staging area of this frame's copy has been carried out
     HIP_TRY(hipStreamWaitEvent(fs, b->ev_d2h[(k - b->pipe_depth) % MOR_MAX_SLOTS], 0));
   }
   mor_launch_filter(d, fs, &b->timer, 2);
-  HIP_TRY(hipEventRecord(b->ev_out[k % MOR_MAX_SLOTS], fs)); b->last_out = &b->ev_out[k % MOR_MAX_SLOTS];
+  HIP_TRY(hipEventRecord(b->ev_out[k % MOR_MAX_SLOTS], fs)); b->last_out = &b->ev_out[k % MOR_MAX_SLOTS]; b->last_out_st = fs;
   if (host_async) {   // on the device → host copy stream, behind the output kernels
     hipStream_t cs = b->s_d2h_[0];
     HIP_TRY(hipStreamWaitEvent(cs, b->ev_out[k % MOR_MAX_SLOTS], 0));
@@ -613,8 +620,8 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
     HIP_TRY(hipEventRecord(b->ev_d2h[k % MOR_MAX_SLOTS], cs));
     b->d2h_used[k % MOR_MAX_SLOTS] = true;
   }
-  HIP_TRY(hipEventRecord(b->ev[3], fs));
-  HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], fs));
+  if (!b->async) HIP_TRY(hipEventRecord(b->ev[3], fs));
+  HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], fs)); b->ev_back_st[k % MOR_MAX_SLOTS] = fs;
   HIP_TRY(hipGetLastError());
   b->pending = true;
   const bool need_host = n_out != nullptr || (out && !out_on_device && !host_async);

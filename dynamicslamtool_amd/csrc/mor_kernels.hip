@@ -3460,6 +3460,16 @@ void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int 
   MOR_LAUNCH(MK_OUT_SCATTER, k_out_scatter, gT2, d);
 }
 
+// A few KB from page-locked host memory into device memory, on the stream, by one workgroup (bytes: a multiple of 4)
+__global__ __launch_bounds__(MOR_BT) void k_copy_small(uint4 *dst, const uint4 *src, int n16, unsigned *dst4, const unsigned *src4, int n4) {
+  for (int i = threadIdx.x; i < n16; i += MOR_BT) dst[i] = src[i];
+  for (int i = threadIdx.x; i < n4; i += MOR_BT) dst4[i] = src4[i];
+}
+void mor_launch_copy(void *dst, const void *src_pinned, size_t bytes, hipStream_t st) {
+  const bool al = (((uintptr_t)dst | (uintptr_t)src_pinned) & 15u) == 0;
+  const int n16 = al ? (int)(bytes / 16) : 0; const size_t done = (size_t)n16 * 16;
+  hipLaunchKernelGGL(k_copy_small, dim3(1), dim3(MOR_BT), 0, st, (uint4 *)dst, (const uint4 *)src_pinned, n16, (unsigned *)((char *)dst + done), (const unsigned *)((const char *)src_pinned + done), (int)((bytes - done) / 4));
+}
 // workgroups of k_split one CU holds (registers decide): the host keeps sp_g × B within what the whole GPU holds at once
 int mor_split_blocks_per_cu() {
   int n = 0;

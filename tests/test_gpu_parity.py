@@ -705,6 +705,45 @@ def test_async_without_waits_matches_synchronous_use_frame_by_frame():
     assert tracks > 0 and any(logs[0][nf - 1][s]["n_pairs"] > 0 for s in range(B))
 
 
+def test_pushes_without_filter_cloud_in_asynchronous_mode():
+    """push → push (no filterCloud in between), filterCloud called twice, and the usual pairs, mixed, with no wait anywhere: the engine
+    records the events a frame's successor needs only where they are needed (a push followed by its filterCloud needs none of its own),
+    so every calling pattern must still see the tracking state and the per-frame arrays in order.  Frame by frame against the same
+    sequence of calls in synchronous mode."""
+    p = kitti_params(1)
+    B, npts = 16, 120000
+    pattern = "PFPPFPFFPPPFPFPPFPF"   # P = push of the next frame, F = filterCloud of the latest one
+    nf = pattern.count("P")
+    seeds = [2000 + s for s in range(B)]
+    buf = DeviceBuffer(nf * B * npts * 16)
+    poses = []
+    for f in range(nf):
+        xs, ps = synth.batch(seeds, [f] * B)
+        buf.upload(xs, f * B * npts * 16)
+        poses.append(ps)
+    logs = []
+    for mode in ("async", "sync"):
+        b = MorBatch(p, B, npts)
+        views = [b.make_views([(buf.ptr + (f * B + s) * npts * 16, npts) for s in range(B)]) for f in range(nf)]
+        if mode == "async":
+            b.set_async(True)
+        f = 0
+        for op in pattern:
+            if op == "P":
+                b.push_views(views[f], poses[f])
+                f += 1
+            elif mode == "async":
+                b.filter_async()
+            else:
+                b.filter_device()
+        b.wait()
+        logs.append([[b.frame_log(i, s) for s in range(B)] for i in range(nf)])
+        b.close()
+    buf.free()
+    assert logs[0] == logs[1]
+    assert max(L["n_mo_filter"] for L in logs[0][-1]) > 0 and any(L["n_pairs"] > 0 for L in logs[0][-1])
+
+
 def test_unaligned_blob_records():
     """Packed sensor records whose float32 fields sit at odd addresses (the Velodyne driver's PointXYZIRT: x y z
     intensity float32, ring uint16, time float32 → point_step 22): fromPCLPointCloud2 memcpy's the named fields, so the
