@@ -100,6 +100,7 @@ struct MorDev {
   int run_tracker;           // filter: advance the tracking loop (first filterCloud of this frame)
   // ---- device arrays (per-stream stride noted)
   const MorStreamArgs *args; // [B]
+  const MorStreamArgs *args_src; MorStreamArgs *args_out;   // crop variant with the single-read split: the page-locked host slot k_split reads the arguments from (null: `args` is already filled), and `args` again, writable
   MorFrameInfo *info;        // [B]  this frame (one copy per frame in flight, like every array that crosses a stage boundary)
   int2 *slot_kc[MOR_MAX_SLOTS];          // [B]  (K, C) of the frame that owns the cluster slot: written by the cell graph of that frame, read by the
                              //      next frame's pair stage as ca's K and C (never through another frame's `info` copy, which the grid

@@ -109,11 +109,11 @@ struct mor_batch {
   hipStream_t s_h2d_[1] = {nullptr}, s_d2h_[1] = {nullptr};   // (one per direction: with two per direction the four streams shared engines again — 7 k instead of 16 k frame-pairs/s end to end; blobs that lie back to back in host memory travel as ONE copy, which is what makes a stream reach the link rate)
   hipEvent_t ev_h2d[MOR_MAX_SLOTS] = {}, ev_d2h[MOR_MAX_SLOTS] = {};   // staged input of frame k is on the device; its filtered clouds have left the output staging area
   bool d2h_used[MOR_MAX_SLOTS] = {};
-  hipEvent_t ev_out[MOR_MAX_SLOTS] = {};        // recorded after the output kernels of a filterCloud (they run in frame order: pinned size mirrors, tile counts)
-  hipEvent_t *last_out = nullptr;
+  hipEvent_t ev_out[MOR_MAX_SLOTS] = {};        // recorded after the output kernels of a filterCloud whose clouds leave by DMA (the copies follow it)
   // The stream every such event was last recorded on: a wait for an event of the SAME stream is implied by stream order, and every
   // packet the command processor does not have to fetch, resolve and signal is a few microseconds of a lane (exp/gaps.py)
-  hipStream_t ev_back_st[MOR_MAX_SLOTS] = {}; hipStream_t last_track_st = nullptr, last_out_st = nullptr;
+  bool pargs_copy = false;   // MOR_ARGS_COPY=1: always copy the arguments with the copy kernel (test switch)
+  hipStream_t ev_back_st[MOR_MAX_SLOTS] = {}; hipStream_t last_track_st = nullptr;
   MorDev dtemp[MOR_MAX_DEPTH];               // descriptor templates, frame k uses dtemp[k % depth] (static part + pointers)
   MorDev d;                                  // descriptor of the latest pushed frame
   MorStreamArgs *d_args_s[MOR_MAX_DEPTH] = {};
@@ -219,6 +219,7 @@ static int configure(mor_batch *b) {
     if (getenv("MOR_DEBUG")) fprintf(stderr, "mor: k_split %d workgroups per CU, sp_g %d\n", mor_split_blocks_per_cu(), d.sp_g);
   }
   d.xcd_map = getenv("MOR_NO_XCD_MAP") ? 0 : 1;
+  b->pargs_copy = getenv("MOR_ARGS_COPY") && atoi(getenv("MOR_ARGS_COPY")) != 0;
   d.nt_ground = getenv("MOR_NT_GROUND") ? atoi(getenv("MOR_NT_GROUND")) : 0;
   d.g_fast = 8; d.g_score = 4; d.g_pde = 256; d.g_box = 32;   // workgroups per stream: tier 1 (1024 threads each, two per CU), tiers 1a + 1b together (512 threads; they share out the chunks of the two worklists), wave tier (256 threads; workgroups without a query leave at once), cell boxes
   if (getenv("MOR_G_FAST")) d.g_fast = std::max(1, atoi(getenv("MOR_G_FAST")));
@@ -439,7 +440,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = ok && dalloc(b, o.wl, B * N) && dalloc(b, o.wl_nb, B) && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B);
     ok = ok && dalloc(b, o.rs16, B * (size_t)d.rs16_stride) && dalloc(b, o.cx16, B * N);
     if (p->method_choice == 2) ok = ok && dalloc(b, o.vox, B * (size_t)d.Hcap);
-    ok = ok && dalloc(b, o.moving, B * K + B) && hipMemset(o.moving, 0, B * K + B) == hipSuccess && dalloc(b, o.otile_cnt, B * T);
+    ok = ok && dalloc(b, o.moving, B * K + B) && hipMemset(o.moving, 0, B * K + B) == hipSuccess && dalloc(b, o.otile_cnt, B * T) && halloc(b, o.h_nout, B) && halloc(b, o.h_noff, B);   // (the size mirrors of the filtered clouds too: the output kernels of consecutive frames need no order among themselves)
     ok = ok && dalloc(b, o.zmin_i, B) && dalloc(b, o.zmax_i, B) && dalloc(b, o.zorg, B) && dalloc(b, o.zbase, B) && hipMemset(o.zbase, 0, B * sizeof(int)) == hipSuccess && dalloc(b, o.mode_bin, B);
     if (ok) ok = hipMemcpy(o.zorg, z0.data(), B * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     if (d.gmode == 1) {   // voxel-covariance ground variant: the VoxelGrid sort and the per-voxel results
@@ -547,7 +548,10 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   }
   // the per-stream arguments: a one-workgroup kernel reads the page-locked slot (5 KB) — a hipMemcpyAsync here kept the lane idle for ≈ 35 µs
   // in front of every frame's first kernel (copy packet, its signal, the barrier behind it)
-  mor_launch_copy(b->d_args_s[k % b->pipe_depth], b->h_args, sizeof(MorStreamArgs) * B, lane);
+  // (crop variant: the frame's first kernel, k_split, reads the slot itself and leaves the device copy behind — nothing at all in front of it)
+  d.args_src = nullptr; d.args_out = b->d_args_s[k % b->pipe_depth];
+  if (d.gmode == 0 && !d.two_pass_split && !b->pargs_copy) d.args_src = b->h_args;
+  else mor_launch_copy(b->d_args_s[k % b->pipe_depth], b->h_args, sizeof(MorStreamArgs) * B, lane);
   if (!b->async) HIP_TRY(hipEventRecord(b->ev[0], lane));
   for (int pc = 0; pc < b->n_pieces; ++pc) {
     const int id = b->piece_id[pc];
@@ -601,12 +605,12 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
   if (!b->async) HIP_TRY(hipEventRecord(b->ev[2], fs));
   mor_launch_filter(d, fs, &b->timer, 1);
   HIP_TRY(hipEventRecord(b->ev_track[k % MOR_MAX_SLOTS], fs)); b->last_track = &b->ev_track[k % MOR_MAX_SLOTS]; b->last_track_st = fs;   // the tracking state is settled: the next frame's tracking step may follow
-  if (b->last_out && b->last_out_st != fs) HIP_TRY(hipStreamWaitEvent(fs, *b->last_out, 0));
+
   if (host_async && k >= b->pipe_depth && b->d2h_used[(k - b->pipe_depth) % MOR_MAX_SLOTS]) {   // the output staging area of this frame's copy has been carried out
     HIP_TRY(hipStreamWaitEvent(fs, b->ev_d2h[(k - b->pipe_depth) % MOR_MAX_SLOTS], 0));
   }
   mor_launch_filter(d, fs, &b->timer, 2);
-  HIP_TRY(hipEventRecord(b->ev_out[k % MOR_MAX_SLOTS], fs)); b->last_out = &b->ev_out[k % MOR_MAX_SLOTS]; b->last_out_st = fs;
+  if (host_async) HIP_TRY(hipEventRecord(b->ev_out[k % MOR_MAX_SLOTS], fs));   // (the device → host copies below follow it)
   if (host_async) {   // on the device → host copy stream, behind the output kernels
     hipStream_t cs = b->s_d2h_[0];
     HIP_TRY(hipStreamWaitEvent(cs, b->ev_out[k % MOR_MAX_SLOTS], 0));

@@ -253,10 +253,10 @@ __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, 
 
 // start of a frame: input size, error flags and cluster counts of the stream's info record (not in pass B of the voxel
 // variant, which continues the frame).  Runs in the first kernel of the frame, before any kernel that raises a flag.
-__device__ __forceinline__ void reset_frame_info(const MorDev &d, int s) {
+__device__ __forceinline__ void reset_frame_info(const MorDev &d, int s, uint32_t n_points) {
   if (d.gmode == 2) return;
   MorFrameInfo &f = d.info[s];
-  f.N = d.args[s].n; f.flags = 0; f.n_pairs = 0; f.K = 0; f.C = 0; f.max_loc = 0;
+  f.N = n_points; f.flags = 0; f.n_pairs = 0; f.K = 0; f.C = 0; f.max_loc = 0;
 }
 // ------------------------------------------------------------------------------------ G1: trim + ground split
 // pass 1: per-tile counts of (non-ground, ground)
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(MOR_BT) void k_classify(MorDev d) {
   if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (t == 0) reset_frame_info(d, s);
+    if (t == 0) reset_frame_info(d, s, a.n);
     int *o = d.tile_cnt + ((size_t)s * d.tiles_max + t) * 2;
     o[0] = sh[0] + sh[1] + sh[2] + sh[3];
     o[1] = sh[4] + sh[5] + sh[6] + sh[7];
@@ -467,7 +467,9 @@ __device__ __forceinline__ void split_store(const MorDev &d, const MorGrid &G, i
 __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
   int s, g; map_block(d.B, d.sp_g, s, g);
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
-  const MorStreamArgs a = d.args[s];
+  // As the first kernel of a frame (crop variant) this one reads the stream's arguments straight from the page-locked slot the host filled,
+  // and the owner of tile 0 leaves the device copy for the kernels behind it: no copy, no launch and no wait in front of the frame
+  const MorStreamArgs a = d.args_src ? d.args_src[s] : d.args[s];
   const uint32_t n_in = pass_count(d, a, s);
   const int nt = (int)((n_in + MOR_TILE - 1) / MOR_TILE);
   const unsigned epoch = 2u * (unsigned)d.frame_no + (d.gmode == 2 ? 2u : 1u);   // never 0 (fresh descriptors), never the tag of an earlier pass over this table
@@ -479,7 +481,8 @@ __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
     s_ex[5] = v;
     if (v + 2 == tk_total) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v == 0) {   // the owner of tile 0 starts the frame: before any flag of this stream can be raised (every other tile waits for tile 0's descriptor)
-      reset_frame_info(d, s);
+      reset_frame_info(d, s, a.n);
+      if (d.args_src) d.args_out[s] = a;
       if (nt == 0) publish_split(d, s, 0, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }

@@ -383,7 +383,7 @@ print("OK")
 
 
 @pytest.mark.parametrize("env", [{"MOR_GH_TIER": "1"}, {"MOR_GH_TIER": "2", "MOR_CG_GLOBAL": "1"}, {"MOR_LANES": "2"}, {"MOR_PIPE_DEPTH": "8", "MOR_LANES": "6"}, {"MOR_PIPE_DEPTH": "1"},
-                                 {"MOR_PIPE_DEPTH": "2", "MOR_LANES": "1"}, {"MOR_CG_UNFUSED": "1"}, {"MOR_SINGLE_PASS_SPLIT": "1"}, {"MOR_SINGLE_PASS_SPLIT": "0"}, {"MOR_SP_G": "64"}, {"MOR_SP_G": "2"}])
+                                 {"MOR_PIPE_DEPTH": "2", "MOR_LANES": "1"}, {"MOR_CG_UNFUSED": "1"}, {"MOR_SINGLE_PASS_SPLIT": "1"}, {"MOR_SINGLE_PASS_SPLIT": "0"}, {"MOR_SP_G": "64"}, {"MOR_SP_G": "2"}, {"MOR_ARGS_COPY": "1"}])
 def test_kernel_variants(env):
     """The tiers behind the default paths must give the same results: k_gridhash with its big LDS table / its global-memory table,
     slab and merge forests in global memory, other numbers of lanes / pipeline depths, the merge of the slab forests as its own launch.  The tier is chosen when the batch is created,
