@@ -489,7 +489,8 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   }
   // pinned argument slot of this push: a ring of MOR_ARGS_RING slots; the slot's last user, frame k − MOR_ARGS_RING, must have completed
   const int slot = (int)(k % MOR_ARGS_RING);
-  if (k >= MOR_ARGS_RING) HIP_TRY(hipEventSynchronize(b->ev_back[(k - MOR_ARGS_RING) % MOR_MAX_SLOTS]));
+  if (k >= MOR_ARGS_RING) HIP_TRY(hipEventSynchronize(b->ev_back[(k - MOR_ARGS_RING) % MOR_MAX_SLOTS]));   // (never recorded for a frame whose lane orders it anyway, below: then the tracking event of that frame, which lies behind its k_split — the slot's reader — on its lane)
+  if (k >= MOR_ARGS_RING) HIP_TRY(hipEventSynchronize(b->ev_track[(k - MOR_ARGS_RING) % MOR_MAX_SLOTS]));
   b->h_args = b->h_args_ring + (size_t)slot * B;
   std::vector<PoseTf> cur(B);
   for (int s = 0; s < B; ++s) {
@@ -625,7 +626,10 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
     b->d2h_used[k % MOR_MAX_SLOTS] = true;
   }
   if (!b->async) HIP_TRY(hipEventRecord(b->ev[3], fs));
-  HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], fs)); b->ev_back_st[k % MOR_MAX_SLOTS] = fs;
+  // end of the frame: frame k + depth reuses this frame's copy of the arrays.  With as many lanes as copies that frame runs on this very
+  // stream and needs no event; the copy stream of host-resident clouds (its staging area) does
+  if (b->lane_stream(k + b->pipe_depth) != fs || b->stage_stride > 0) { HIP_TRY(hipEventRecord(b->ev_back[k % MOR_MAX_SLOTS], fs)); b->ev_back_st[k % MOR_MAX_SLOTS] = fs; }
+  else b->ev_back_st[k % MOR_MAX_SLOTS] = fs;
   HIP_TRY(hipGetLastError());
   b->pending = true;
   const bool need_host = n_out != nullptr || (out && !out_on_device && !host_async);
