@@ -344,6 +344,77 @@ def compare_logs(a, b, keys_idx=None):
     return frames, bad
 
 
+def e2e_legs(workload, device, streams=0):
+    """PCIe-inclusive legs on ONE batch of a fresh process: clouds start in page-locked host memory, filtered clouds end there — synchronous push +
+    filter pairs, then the same calls enqueue-only (asynchronous mode), then an untimed synchronous replay on a second batch as the check."""
+    from dynamicslamtool_amd import engine, kitti_params, synth, shard
+    sensor0, B0, cfg0, mo, go = WORKLOADS[workload]
+    B0 = streams or B0
+    p = kitti_params(mo or 1)
+    p.ground_method = go if go is not None else 0
+    if not os.environ.get("MOR_BENCH_NO_BIND"):
+        engine.bind_thread_to_device_node(device)
+    rank = 0
+    B, npts, sensor = B0, synth.n_points(sensor0), sensor0
+    seeds_main = shard.stream_seeds(cfg0, rank, B)
+    hin, hout = [engine.HostBuffer((B, npts, 4)) for _ in range(2)], engine.HostBuffer((B, npts, 4))
+    hout2 = [engine.HostBuffer((B, npts, 4)) for _ in range(2)]
+    # PCIe-inclusive: clouds start in page-locked host memory, filtered clouds end there (synchronous push + filter)
+    pp = []
+    for f in range(2):
+        xs, ps_ = synth.batch(seeds_main, [f] * B, sensor)
+        hin[f].array[...] = np.asarray(xs).reshape(B, npts, 4)
+        pp.append(np.ascontiguousarray(ps_))
+    # ONE batch for both timed legs (the second batch of a process already copies device → host more slowly on this stack, see above):
+    # synchronous push + filter pairs first, then the same calls enqueue-only (asynchronous mode: the staged copy of frame k + 1 runs
+    # beside the kernels of frame k, the filtered clouds are assembled on the device and leave by DMA behind the kernels; one wait)
+    hb = engine.MorBatch(p, B, npts, 4, 3, device)
+    sviews = [hb.make_host_views([hin[f].array[s] for s in range(B)]) for f in range(2)]
+    houts = [hout.array[s] for s in range(B)]
+    optrs = [hb.make_out_pointers([hout2[f].array[s] for s in range(B)]) for f in range(2)]
+    hb.push_views(sviews[0], pp[0])
+    hb.filter_into(houts)
+    t1 = time.perf_counter()
+    reps, t_push = 8, 0.0
+    for r in range(reps):
+        t2 = time.perf_counter()
+        hb.push_views(sviews[(r + 1) % 2], pp[(r + 1) % 2])
+        t_push += time.perf_counter() - t2
+        hb.filter_into(houts)
+    e2e_dt = time.perf_counter() - t1
+    e2e = B * reps / e2e_dt
+    e2e_ms = {"push": round(1e3 * t_push / reps, 3), "filter": round(1e3 * (e2e_dt - t_push) / reps, 3)}
+    hb.set_async(True)
+    areps = 16
+    t1 = time.perf_counter()
+    for r in range(reps, reps + areps):
+        hb.push_views(sviews[(r + 1) % 2], pp[(r + 1) % 2])
+        hb.filter_async_to(optrs[r % 2], on_device=False)
+    hb.wait()
+    e2e_async = B * areps / (time.perf_counter() - t1)
+    last = (reps + areps - 1) % 2
+    nout_async = [hb.output_device(s)[1] for s in range(B)]
+    crc_async = [zlib.crc32(hout2[last].array[s][:nout_async[s]].tobytes()) for s in range(B)]
+    hb.set_async(False)
+    hb.close()
+    # untimed check of the asynchronous leg: the same 1 + reps + areps frames through synchronous calls on a fresh batch must end in the same filtered clouds
+    hv = engine.MorBatch(p, B, npts, 4, 3, device)
+    vviews = [hv.make_host_views([hin[f].array[s] for s in range(B)]) for f in range(2)]
+    hv.push_views(vviews[0], pp[0])
+    hv.filter_into(houts)
+    for r in range(reps + areps):
+        hv.push_views(vviews[(r + 1) % 2], pp[(r + 1) % 2])
+        nv = hv.filter_into(houts)
+    e2e_async_ok = nv == nout_async and [zlib.crc32(hout.array[s][:nv[s]].tobytes()) for s in range(B)] == crc_async
+    hv.close()
+    for x in hout2:
+        x.free()
+    for x in hin + [hout]:
+        x.free()
+
+    return {"e2e": round(e2e, 2), "e2e_ms": e2e_ms, "e2e_async": round(e2e_async, 2), "e2e_async_ok": bool(e2e_async_ok)}
+
+
 def latency_b1(workload, device):
     """One stream, synchronous push + filter of one cloud from / to page-locked host memory (what the drop-in class does per frame): median ms."""
     from dynamicslamtool_amd import engine, kitti_params, synth
@@ -385,11 +456,15 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip value_runs, the other workloads, e2e / sync / latency legs")
     ap.add_argument("--dry-run", action="store_true", help="exercise only the multi-rank plumbing (no GPU work, no measurement)")
     ap.add_argument("--latency-only", action="store_true", help="child process of the default run: push + filter latency of ONE stream, prints {\"latency_b1_ms\": …}")
-    ap.add_argument("--device", type=int, default=0, help="HIP ordinal for --latency-only")
+    ap.add_argument("--e2e-only", action="store_true", help="child process of the default run: the host-resident end-to-end legs, prints their figures as JSON")
+    ap.add_argument("--device", type=int, default=0, help="HIP ordinal for --latency-only / --e2e-only")
     args = ap.parse_args()
 
     if args.latency_only:
         print(json.dumps({"latency_b1_ms": latency_b1(args.workload, args.device)}))
+        return
+    if args.e2e_only:
+        print(json.dumps(e2e_legs(args.workload, args.device, args.streams)))
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -425,6 +500,24 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # before HIP is initialised in this process (forked workers)
         cpu, cpu_all, oracle_sum = cpu_baseline_run(shard.stream_seeds(cfg0, 0, B0), sensor0, method, ground_method)
 
+    # ---- end-to-end legs and the one-stream latency: each in a process of its own, like an application with ONE batch per process.  (On this stack
+    #      a batch created after other batches of the same process have come and gone copies device → host at 10 GB/s instead of 55 —
+    #      exp/e2e_probe.py --prelude — and, the other way round, the headline leg's first timed steps ran 5 % slower behind those batches.)
+    #      They run BEFORE this process touches the GPU: with two processes' hardware queues alive the child's asynchronous leg lost 12 %.
+    e2e = lat = e2e_async = e2e_async_ok = e2e_ms = None
+    if not args.no_extras and world == 1:
+        def child(flag):
+            try:
+                r_ = subprocess.run([sys.executable, os.path.abspath(__file__), flag, "--device", str(local_rank), "--workload", args.workload] + (["--streams", str(args.streams)] if args.streams else []),
+                                    capture_output=True, text=True, timeout=600)
+                return json.loads(r_.stdout.strip().splitlines()[-1])
+            except Exception as e_:   # reported as nulls, never silently
+                print("%s leg failed: %r" % (flag, e_), file=sys.stderr)
+                return {}
+        lat = child("--latency-only").get("latency_b1_ms")
+        ee = child("--e2e-only")
+        e2e, e2e_ms, e2e_async, e2e_async_ok = ee.get("e2e"), ee.get("e2e_ms"), ee.get("e2e_async"), ee.get("e2e_async_ok")
+
     from dynamicslamtool_amd import engine, kitti_params, synth
 
     def params_for(name):
@@ -451,77 +544,6 @@ def main():
             cores_mine = kept
         else:
             os.sched_setaffinity(0, mine_before)
-
-    # ---- end-to-end legs FIRST: on this stack device → host copies of a batch created after gigabytes of device memory have come and gone
-    #      (the headline leg's) run at 10 GB/s instead of 55 (exp/e2e_probe.py --prelude); an application has one batch per process, as here
-    e2e = lat = e2e_async = e2e_async_ok = e2e_ms = None
-    if not args.no_extras and world == 1:
-        B, npts, sensor = B0, synth.n_points(sensor0), sensor0
-        seeds_main = shard.stream_seeds(cfg0, rank, B)
-        hin, hout = [engine.HostBuffer((B, npts, 4)) for _ in range(2)], engine.HostBuffer((B, npts, 4))
-        hout2 = [engine.HostBuffer((B, npts, 4)) for _ in range(2)]
-        # PCIe-inclusive: clouds start in page-locked host memory, filtered clouds end there (synchronous push + filter)
-        pp = []
-        for f in range(2):
-            xs, ps_ = synth.batch(seeds_main, [f] * B, sensor)
-            hin[f].array[...] = np.asarray(xs).reshape(B, npts, 4)
-            pp.append(np.ascontiguousarray(ps_))
-        # one stream (what the drop-in class does for one ROS node): push + filter of one cloud from / to page-locked host memory, in a
-        # process of its own as in a node (a batch behind other batches of the same process copies more slowly, see above: 0.64 against
-        # 0.46 ms — and a one-stream batch in THIS process in front of the end-to-end legs slows THEIR copies down the same way)
-        try:
-            import subprocess
-            r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--latency-only", "--device", str(device)], capture_output=True, text=True, timeout=300)
-            lat = json.loads(r_.stdout.strip().splitlines()[-1])["latency_b1_ms"]
-        except Exception as e_:   # reported as null, never silently
-            print("latency leg failed: %r" % (e_,), file=sys.stderr)
-            lat = None
-        # ONE batch for both timed legs (the second batch of a process already copies device → host more slowly on this stack, see above):
-        # synchronous push + filter pairs first, then the same calls enqueue-only (asynchronous mode: the staged copy of frame k + 1 runs
-        # beside the kernels of frame k, the filtered clouds are assembled on the device and leave by DMA behind the kernels; one wait)
-        hb = engine.MorBatch(p, B, npts, 4, 3, device)
-        sviews = [hb.make_host_views([hin[f].array[s] for s in range(B)]) for f in range(2)]
-        houts = [hout.array[s] for s in range(B)]
-        optrs = [hb.make_out_pointers([hout2[f].array[s] for s in range(B)]) for f in range(2)]
-        hb.push_views(sviews[0], pp[0])
-        hb.filter_into(houts)
-        t1 = time.perf_counter()
-        reps, t_push = 8, 0.0
-        for r in range(reps):
-            t2 = time.perf_counter()
-            hb.push_views(sviews[(r + 1) % 2], pp[(r + 1) % 2])
-            t_push += time.perf_counter() - t2
-            hb.filter_into(houts)
-        e2e_dt = time.perf_counter() - t1
-        e2e = B * reps / e2e_dt
-        e2e_ms = {"push": round(1e3 * t_push / reps, 3), "filter": round(1e3 * (e2e_dt - t_push) / reps, 3)}
-        hb.set_async(True)
-        areps = 16
-        t1 = time.perf_counter()
-        for r in range(reps, reps + areps):
-            hb.push_views(sviews[(r + 1) % 2], pp[(r + 1) % 2])
-            hb.filter_async_to(optrs[r % 2], on_device=False)
-        hb.wait()
-        e2e_async = B * areps / (time.perf_counter() - t1)
-        last = (reps + areps - 1) % 2
-        nout_async = [hb.output_device(s)[1] for s in range(B)]
-        crc_async = [zlib.crc32(hout2[last].array[s][:nout_async[s]].tobytes()) for s in range(B)]
-        hb.set_async(False)
-        hb.close()
-        # untimed check of the asynchronous leg: the same 1 + reps + areps frames through synchronous calls on a fresh batch must end in the same filtered clouds
-        hv = engine.MorBatch(p, B, npts, 4, 3, device)
-        vviews = [hv.make_host_views([hin[f].array[s] for s in range(B)]) for f in range(2)]
-        hv.push_views(vviews[0], pp[0])
-        hv.filter_into(houts)
-        for r in range(reps + areps):
-            hv.push_views(vviews[(r + 1) % 2], pp[(r + 1) % 2])
-            nv = hv.filter_into(houts)
-        e2e_async_ok = nv == nout_async and [zlib.crc32(hout.array[s][:nv[s]].tobytes()) for s in range(B)] == crc_async
-        hv.close()
-        for x in hout2:
-            x.free()
-        for x in hin + [hout]:
-            x.free()
 
     # ---- headline leg: synthetic streams resident in HBM, frame f of stream s at offset ((f*B)+s)*npts*16
     leg = Leg(engine, synth, shard, p, args.workload, rank, device, min(args.warmup + args.steps + 1, 24), args.streams)
