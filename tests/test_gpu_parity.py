@@ -744,6 +744,26 @@ def test_pushes_without_filter_cloud_in_asynchronous_mode():
     assert max(L["n_mo_filter"] for L in logs[0][-1]) > 0 and any(L["n_pairs"] > 0 for L in logs[0][-1])
 
 
+def test_thread_can_be_bound_to_the_gpus_numa_node():
+    """mor_device_numa_node / mor_bind_thread_to_device_node (host placement): the node comes from the device's PCI address, the
+    binding keeps a non-empty subset of the CPUs the thread was allowed on, a slice of them for one of several sharers; the affinity is restored."""
+    from dynamicslamtool_amd import engine
+    before = os.sched_getaffinity(0)
+    try:
+        node = engine.device_numa_node(0)
+        assert node >= -1
+        kept = engine.bind_thread_to_device_node(0)
+        now = os.sched_getaffinity(0)
+        assert now <= before and len(now) >= 1
+        if node >= 0 and kept:
+            assert kept == len(now)
+            os.sched_setaffinity(0, before)
+            part = engine.bind_thread_to_device_node(0, 1, 2)
+            assert part in (0, kept // 2) and os.sched_getaffinity(0) <= now
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 def test_unaligned_blob_records():
     """Packed sensor records whose float32 fields sit at odd addresses (the Velodyne driver's PointXYZIRT: x y z
     intensity float32, ring uint16, time float32 → point_step 22): fromPCLPointCloud2 memcpy's the named fields, so the
