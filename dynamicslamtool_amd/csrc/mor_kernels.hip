@@ -186,7 +186,7 @@ __device__ __forceinline__ int classify(const MorDev &d, float4 p) {
 // trimmed cloud and splits it by the ground flag, :194-198)
 __device__ __forceinline__ uint32_t pass_count(const MorDev &d, const MorStreamArgs &a, int s) { return d.gmode == 2 ? d.info[s].T : a.n; }
 __device__ __forceinline__ int pass_item(const MorDev &d, const MorStreamArgs &a, int s, uint32_t i, float4 &p) {
-  if (d.gmode == 2) { p = d.rawbuf[(size_t)s * d.Nmax + i]; return d.is_ground[(size_t)s * d.Nmax + i] ? 1 : 2; }
+  if (d.gmode == 2) { p = d.rawbuf[(size_t)s * d.Nmax + i]; return d.is_ground[(size_t)s * d.Nmax + i] == d.frame_no + 1 ? 1 : 2; }   // (ground flags carry the frame's tag: no clearing pass)
   p = load_point(a, i);
   return classify(d, p);
 }
@@ -298,6 +298,7 @@ __global__ __launch_bounds__(MOR_BT) void k_classify(MorDev d) {
 __device__ __forceinline__ void publish_split(const MorDev &d, int s, int n_ng, int n_g) {
   MorFrameInfo &f = d.info[s];
   f.M = n_ng; f.G = n_g; f.T = n_ng + n_g;
+  if (d.gmode == 2) { d.zmin_i[s] = 0x7fffffff; d.zmax_i[s] = (int)0x80000000; }   // pass B ends the frame's use of the z range: ready for the next frame on this copy (no memset launches)
   if (d.gmode == 1) {   // grids of the voxel variant hang on the lowest trimmed point
     float zmin = f.T ? ordered_float(d.zmin_i[s]) : 0.f;
     d.zorg[s] = zmin; d.zbase[s] = (int)floorf(zmin * d.gv.inv_cs);
@@ -388,7 +389,7 @@ __device__ __forceinline__ void split_load_tile(const MorDev &d, const MorStream
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const uint32_t i = min(base + it * 64 + lane_id(), n_in - 1);   // (clamped: out-of-range lanes repeat the last record and are masked in split_tile)
-    if (d.gmode == 2) { p[it] = d.rawbuf[(size_t)s * d.Nmax + i]; cls[it] = d.is_ground[(size_t)s * d.Nmax + i]; }
+    if (d.gmode == 2) { p[it] = d.rawbuf[(size_t)s * d.Nmax + i]; cls[it] = d.is_ground[(size_t)s * d.Nmax + i] == d.frame_no + 1; }
     else { p[it] = load_point(a, i); cls[it] = 0; }
   }
 }
@@ -2826,26 +2827,33 @@ template <int CHUNK> __device__ __forceinline__ int g2_voxel_bin(const MorDev &d
       const int m = min(CHUNK, n - c0);
       for (int i = threadIdx.x; i < m; i += blockDim.x) { float4 p = d.rawbuf[so + (int)(key[c0 + i] & 0xffffffffu)]; px[i] = p.x; py[i] = p.y; pz[i] = p.z; }
       __syncthreads();
-      if (threadIdx.x == 0) {
-        // (the sums are a serial chain by definition; what can be hidden is the LDS latency: sixteen elements are loaded ahead of the adds)
-        if (pass == 0) { float cx = acc[0], cy = acc[1], cz = acc[2];
+      if (threadIdx.x < 3) {
+        // Each sum is a serial chain by definition (fp32 adds in the neighbours' order), but the three sums of a pass are independent: lanes 0, 1, 2
+        // of one wave run one chain each in lock step — x, y, z of the centroid, then the terms dz·dx, dy·dz, dz·dz.  Sixteen elements are loaded
+        // ahead of the adds (the LDS latency is hidden, the add latency is what is left).
+        const int t = threadIdx.x;
+        const float *pa = t == 0 ? px : t == 1 ? py : pz;
+        if (pass == 0) {
+          float a = acc[t];
           int i = 0;
-          for (; i + 16 <= m; i += 16) { float vx[16], vy[16], vz[16];
+          for (; i + 16 <= m; i += 16) { float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { vx[u] = px[i + u]; vy[u] = py[i + u]; vz[u] = pz[i + u]; }
+            for (int u = 0; u < 16; ++u) v[u] = pa[i + u];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { cx += vx[u]; cy += vy[u]; cz += vz[u]; } }
-          for (; i < m; ++i) { cx += px[i]; cy += py[i]; cz += pz[i]; }
-          acc[0] = cx; acc[1] = cy; acc[2] = cz; }
-        else { const float cx = acc[0], cy = acc[1], cz = acc[2]; float c02 = acc[3], c12 = acc[4], c22 = acc[5];
+            for (int u = 0; u < 16; ++u) a += v[u]; }
+          for (; i < m; ++i) a += pa[i];
+          acc[t] = a;
+        } else {
+          const float ca = acc[t], cz = acc[2]; float a = acc[3 + t];   // lane 0: c02 = Σ dz·dx, lane 1: c12 = Σ dy·dz, lane 2: c22 = Σ dz·dz
           int i = 0;
-          for (; i + 16 <= m; i += 16) { float vx[16], vy[16], vz[16];
+          for (; i + 16 <= m; i += 16) { float va[16], vz[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { vx[u] = px[i + u]; vy[u] = py[i + u]; vz[u] = pz[i + u]; }
+            for (int u = 0; u < 16; ++u) { va[u] = pa[i + u]; vz[u] = pz[i + u]; }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { float dx = vx[u] - cx, dy = vy[u] - cy, dz = vz[u] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; } }
-          for (; i < m; ++i) { float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; }
-          acc[3] = c02; acc[4] = c12; acc[5] = c22; }
+            for (int u = 0; u < 16; ++u) { const float da_ = va[u] - ca, dz = vz[u] - cz; a += (t == 1 ? da_ * dz : dz * da_); } }
+          for (; i < m; ++i) { const float da_ = pa[i] - ca, dz = pz[i] - cz; a += (t == 1 ? da_ * dz : dz * da_); }
+          acc[3 + t] = a;
+        }
       }
       __syncthreads();
     }
@@ -3052,8 +3060,10 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
     __syncthreads();
   }
 }
-// what the middle tier left: one 256-thread workgroup each, up to G2_CAP neighbours in 128 KiB of LDS
-__global__ __launch_bounds__(MOR_BT) void k_g2_cov_big(MorDev d) {
+// what the middle tier left: one 1024-thread workgroup each (the LDS lets only one live on a CU anyway: sixteen waves sort four times faster than
+// four), up to G2_CAP neighbours in 128 KiB of LDS
+#define G2_BIG_T 1024
+__global__ __launch_bounds__(G2_BIG_T) void k_g2_cov_big(MorDev d) {
   int s = blockIdx.y + d.s0; const int nbig = d.g2_nbig[s];
   const size_t so = (size_t)s * d.Nmax;
   __shared__ unsigned long long key[G2_CAP];
@@ -3094,7 +3104,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mode(MorDev d) {
   __syncthreads();
   for (int i = threadIdx.x; i < 4096; i += MOR_BT) if (best_cnt > 0 && hist[i] == best_cnt) atomicMin(&best_bin, i - 2048);
   __syncthreads();
-  if (threadIdx.x == 0) d.mode_bin[s] = best_bin;
+  if (threadIdx.x == 0) { d.mode_bin[s] = best_bin; d.g2_nbig[s] = 0; }   // (the queue of big voxels is empty again for the next frame on this copy)
 }
 // ground = union of the neighbour lists of the dominant bin's voxels (:184-191, de-duplicated): one wave per such
 // voxel marks every trimmed point within the radius (no list, no sort needed here)
@@ -3105,7 +3115,7 @@ __global__ __launch_bounds__(64) void k_g2_mark(MorDev d) {
   for (int v = blockIdx.x; v < V; v += gridDim.x) {
     if (d.vbin[so + v] != mode) continue;
     const float4 q = d.vcent[so + v];
-    g2_for_neighbours(d, s, q, [&](float, const float4 &p) { d.is_ground[so + __float_as_int(p.w)] = 1; });
+    g2_for_neighbours(d, s, q, [&](float, const float4 &p) { d.is_ground[so + __float_as_int(p.w)] = d.frame_no + 1; });   // the frame's tag (never 0, never an earlier frame's on this copy of the array): nothing has to be cleared
   }
 }
 
@@ -3381,17 +3391,15 @@ static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLau
   da.gnz_out = d.gnz; da.gnz = nullptr; da.cg_nz = d.g.nz; da.cg_inv_cs = d.g.inv_cs;
   da.skey = d.rkeys[da.cell_passes & 1]; da.sidx = d.rvals[da.cell_passes & 1];
   if (sub == 0) {
-    hipMemsetD32Async((hipDeviceptr_t)(d.zmin_i + d.s0), 0x7fffffff, d.B, st);
-    hipMemsetD32Async((hipDeviceptr_t)(d.zmax_i + d.s0), (int)0x80000000, d.B, st);
-    hipMemsetAsync(d.is_ground + (size_t)d.s0 * d.Nmax, 0, (size_t)d.B * d.Nmax * sizeof(int), st);
+    // (z range, ground flags and the queue of big voxels need no clearing launches: their last readers of the previous frame on this copy
+    //  leave them ready — publish_split of pass B, the frame tag in is_ground, k_g2_mode)
     mor_launch_split_and_grid(da, st, tm);
-    (void)hipMemsetAsync(d.g2_nbig + d.s0, 0, (size_t)d.B * sizeof(int), st);
   } else if (sub == 1) {
     MOR_LAUNCH_T(MK_G2_COV, k_g2_cov, dim3(256, d.B), MOR_BT, da);
   } else if (sub == 2) {
     MOR_LAUNCH(MK_G2_COV_MID, k_g2_cov_mid, dim3(64, d.B), da);
   } else if (sub == 3) {
-    MOR_LAUNCH(MK_G2_COV_BIG, k_g2_cov_big, dim3(64, d.B), da);
+    MOR_LAUNCH_T(MK_G2_COV_BIG, k_g2_cov_big, dim3(64, d.B), G2_BIG_T, da);
   } else if (sub == 4) {
     MOR_LAUNCH(MK_G2_MODE, k_g2_mode, gB, da);
     MOR_LAUNCH_T(MK_G2_MARK, k_g2_mark, dim3(4096, d.B), 64, da);
