@@ -2862,27 +2862,38 @@ template <int CHUNK> __device__ __forceinline__ int g2_voxel_bin(const MorDev &d
   }
   return ((double)fabsf(acc[3]) < 0.001 && (double)fabsf(acc[4]) < 0.001 && (double)fabsf(acc[5]) < 0.001) ? (int)(q.z * 10) : 0x7fffffff;
 }
-// Ordered fp32 sums (:142, :144) over coordinates laid out in rank order in LDS, by ONE lane: Σp / n, then the scatter terms
-// around it.  The adds are a serial chain by definition; the LDS latency is hidden by loading eight elements ahead of them.
-__device__ __forceinline__ bool g2_ordered_sums_flat(const float *lx, const float *ly, const float *lz, int n) {
-  float cx = 0.f, cy = 0.f, cz = 0.f;
-  int i = 0;
-  for (; i + 8 <= n; i += 8) { float vx[8], vy[8], vz[8];
+// Ordered fp32 sums (:142, :144) over coordinates laid out in rank order in LDS: Σp / n, then the scatter terms around it.  Each sum is a
+// serial chain by definition, but the three sums of a pass are independent: lanes base, base + 1, base + 2 of the wave run one chain each
+// in lock step (x, y, z of the centroid; then dz·dx, dy·dz, dz·dz), eight elements loaded ahead of the adds.  Called by ALL lanes of the
+// wave (shuffles inside); `doit` and n are those of the lane's group; the verdict is valid in every lane of a group that did it.
+__device__ __forceinline__ bool g2_ordered_sums3(const float *lx, const float *ly, const float *lz, int n, bool doit, int base) {
+  const int t = lane_id() - base;
+  const bool mine = doit && t >= 0 && t < 3;
+  const float *pa = t == 0 ? lx : t == 1 ? ly : lz;
+  float a = 0.f;
+  if (mine) {
+    int i = 0;
+    for (; i + 8 <= n; i += 8) { float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { vx[u] = lx[i + u]; vy[u] = ly[i + u]; vz[u] = lz[i + u]; }
+      for (int u = 0; u < 8; ++u) v[u] = pa[i + u];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { cx += vx[u]; cy += vy[u]; cz += vz[u]; } }
-  for (; i < n; ++i) { cx += lx[i]; cy += ly[i]; cz += lz[i]; }
-  const float fn = (float)n; cx /= fn; cy /= fn; cz /= fn;
-  float c02 = 0.f, c12 = 0.f, c22 = 0.f;
-  i = 0;
-  for (; i + 8 <= n; i += 8) { float vx[8], vy[8], vz[8];
+      for (int u = 0; u < 8; ++u) a += v[u]; }
+    for (; i < n; ++i) a += pa[i];
+  }
+  const float ca = a / (float)n;
+  const float cz = __shfl(ca, (base + 2) & 63, 64);
+  float c = 0.f;
+  if (mine) {
+    int i = 0;
+    for (; i + 8 <= n; i += 8) { float va[8], vz[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { vx[u] = lx[i + u]; vy[u] = ly[i + u]; vz[u] = lz[i + u]; }
+      for (int u = 0; u < 8; ++u) { va[u] = pa[i + u]; vz[u] = lz[i + u]; }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { const float dx = vx[u] - cx, dy = vy[u] - cy, dz = vz[u] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; } }
-  for (; i < n; ++i) { const float dx = lx[i] - cx, dy = ly[i] - cy, dz = lz[i] - cz; c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; }
-  return (double)fabsf(c02) < 0.001 && (double)fabsf(c12) < 0.001 && (double)fabsf(c22) < 0.001;
+      for (int u = 0; u < 8; ++u) { const float da = va[u] - ca, dz = vz[u] - cz; c += (t == 1 ? da * dz : dz * da); } }   // lane 0: dz·dx, lane 1: dy·dz, lane 2: dz·dz
+    for (; i < n; ++i) { const float da = pa[i] - ca, dz = lz[i] - cz; c += (t == 1 ? da * dz : dz * da); }
+  }
+  const int ok = mine && (double)fabsf(c) < 0.001;
+  return __shfl(ok, base & 63, 64) && __shfl(ok, (base + 1) & 63, 64) && __shfl(ok, (base + 2) & 63, 64);
 }
 // Sixteen lanes per voxel, sixteen voxels per 256-thread workgroup (a voxel centroid has a dozen neighbours on average, 96 %
 // have ≤ 64): the group computes the voxel's centroid (dsc, :110-113 — fp32 sums in ascending point index, one lane), gathers
@@ -2977,8 +2988,8 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
 #pragma unroll
     for (int u = 0; u < G2_GROUP_CAP / 16; ++u) if (er[u] >= 0) { l_x[grp][er[u]] = ex[u]; l_y[grp][er[u]] = ey[u]; l_z[grp][er[u]] = ez[u]; }
     __syncthreads();
-    // ---- ordered fp32 sums (:142, :144) by one lane of the group
-    if (small && sub == 0 && g2_ordered_sums_flat(l_x[grp], l_y[grp], l_z[grp], n)) bin = (int)(q.z * 10);
+    // ---- ordered fp32 sums (:142, :144): three lanes of the group, one chain each
+    if (g2_ordered_sums3(l_x[grp], l_y[grp], l_z[grp], n, small, (int)lane_id() & ~15) && small && sub == 0) bin = (int)(q.z * 10);
     if (act && sub == 0) {
       if (n > G2_GROUP_CAP) { const int slot = atomicAdd(&d.g2_nbig[s], 1); d.g2_big[so + slot] = v; }
       else d.vbin[so + v] = bin;
@@ -3051,9 +3062,9 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
 #pragma unroll
     for (int u = 0; u < G2_MID_CAP / 64; ++u) if (er[u] >= 0) { l_x[wv][er[u]] = ex[u]; l_y[wv][er[u]] = ey[u]; l_z[wv][er[u]] = ez[u]; }
     __syncthreads();
+    const bool acc3 = g2_ordered_sums3(l_x[wv], l_y[wv], l_z[wv], n, mine && n > 3, 0);
     if (mine && lane == 0) {
-      int bin = 0x7fffffff;
-      if (n > 3 && g2_ordered_sums_flat(l_x[wv], l_y[wv], l_z[wv], n)) bin = (int)(q.z * 10);
+      const int bin = (n > 3 && acc3) ? (int)(q.z * 10) : 0x7fffffff;
       d.vbin[so + v] = bin;
       d.g2_big[so + w] = ~v;   // done
     }
