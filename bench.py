@@ -41,9 +41,93 @@ WORKLOADS = {
     "hdl64_b64_method2": ("hdl64", 64, 2, 2, None),         # getClusterPointcloudChangeVector (:309-334), the reference's config default
     "hdl64_b64_voxel_ground": ("hdl64", 64, 2, None, 1),    # groundPlaneRemoval(x,y) (:90-200)
 }
+LINE_LIMIT = 4096        # the driver keeps ~8 000 characters of stdout: the ONE line stays well below that, hard-asserted before printing
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4-copy ceiling)
 LOG_KEYS = ("K", "C", "n_pairs", "cnt_sum", "det_sum", "n_mo_push", "n_mo_filter", "n_out", "flags")
 ORACLE_KEYS = ("K", "C", "n_pairs", "det_sum", "n_mo_push", "n_mo_filter", "n_out")
+
+
+# ------------------------------------------------------------------------------------------------ the ONE stdout line (bounded) + the detail file
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us", "avg_launch_us_alone",
+             "job_GBps", "job_frac", "path_traffic_bytes_per_step", "wasted_traffic_ratio", "launches_per_step")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "core_seconds", "frame_pairs", "host_cpus")
+DROP_ORDER = ("e2e_host_sync_ms_per_step", "stream0", "stage_totals", "first_seed_per_rank", "per_rank_frame_pairs_per_s", "cpu_baseline_all_cores", "workloads", "latency_b1_ms",
+              "sync_frame_pairs_per_s", "device_ms_per_step", "value_runs")   # least important first; the contract keys, roofline, cpu_baseline and sanity never go
+
+
+def compact_line(full, detail_path=None, limit=LINE_LIMIT):
+    """The bounded stdout line from the full record: the contract's keys, `config`, a roofline without tables, `cpu_baseline`, the sanity verdict and per
+    secondary workload only {value, ms_per_step, frac, wasted}.  Everything else (per-kernel tables, the workloads' rooflines, profiles, mismatch
+    lists) lives in the detail file.  Optional keys are shed in DROP_ORDER if a pathological run would still overflow; then the limit is asserted."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: full.get(k) for k in keep}
+    cfg = dict(full.get("config") or {})
+    cfg.pop("profile", None)   # the parameter profile is in the detail file (and in dynamicslamtool_amd/params.py: kitti_params)
+    line["config"] = cfg
+    for k in ("collective", "self_launched", "legs_failed", "first_seed_per_rank", "value_runs", "per_rank_frame_pairs_per_s", "device_ms_per_step", "sync_frame_pairs_per_s", "e2e_host_frame_pairs_per_s",
+              "e2e_host_sync_ms_per_step", "e2e_host_async_frame_pairs_per_s", "e2e_host_async_equals_sync", "latency_b1_ms", "algorithmic_bytes_per_frame_pair", "stage_totals", "stream0"):
+        if full.get(k) is not None:
+            line[k] = full[k]
+    if isinstance(line.get("per_rank_frame_pairs_per_s"), list) and len(line["per_rank_frame_pairs_per_s"]) > 8:
+        pr = line["per_rank_frame_pairs_per_s"]
+        line["per_rank_frame_pairs_per_s"] = {"n": len(pr), "min": min(pr), "max": max(pr)}
+    if isinstance(line.get("first_seed_per_rank"), list) and len(line["first_seed_per_rank"]) > 8:
+        line.pop("first_seed_per_rank")
+    if isinstance(line.get("stream0"), dict):
+        line["stream0"] = {k: v for k, v in line["stream0"].items() if k != "tracks_all_streams_min_median_max"}
+    sn = full.get("sanity") or {}
+    line["sanity"] = {k: sn.get(k) for k in ("ok", "frames_checked", "streams", "async_equals_sync", "oracle_records_checked", "equals_oracle") if k in sn}
+    if sn.get("mismatches") or sn.get("oracle_mismatches"):
+        line["sanity"]["n_mismatches"] = len(sn.get("mismatches") or []) + len(sn.get("oracle_mismatches") or [])
+    rf = full.get("roofline")
+    line["roofline"] = None if not rf else {k: rf.get(k) for k in ROOF_KEYS}
+    cb = full.get("cpu_baseline")
+    line["cpu_baseline"] = None if not cb else {k: cb.get(k) for k in CPU_KEYS if k in cb}
+    ca = full.get("cpu_baseline_all_cores")
+    if ca:
+        line["cpu_baseline_all_cores"] = {k: ca.get(k) for k in ("value", "unit", "cores", "kind", "wall_s") if k in ca}
+    wl = full.get("workloads")
+    if isinstance(wl, dict):
+        out = {}
+        for name, w in wl.items():
+            if "error" in w:
+                out[name] = {"error": str(w["error"])[:80]}
+            else:
+                r = w.get("roofline") or {}
+                out[name] = {"value": w.get("value"), "ms_per_step": w.get("ms_per_step"), "frac": r.get("frac"), "job_frac": r.get("job_frac"), "wasted": r.get("wasted_traffic_ratio"),
+                             "ok": w.get("async_equals_sync")}
+        line["workloads"] = out
+    elif wl is not None:
+        line["workloads"] = wl   # "skipped: world>1" and the like
+    if detail_path:
+        line["detail"] = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT) else detail_path
+    for k in DROP_ORDER:
+        if len(json.dumps(line)) <= limit:
+            break
+        line.pop(k, None)
+    text = json.dumps(line)
+    assert len(text) <= limit, "bench line of %d characters exceeds the %d the contract allows" % (len(text), limit)
+    return text
+
+
+def emit(full, detail_path):
+    """Full record → the detail file (and a copy under gpurun_out/ when that directory exists, so it comes back from a gpurun call); the bounded
+    line → stdout, as the LAST thing this process prints there."""
+    blob = json.dumps(full, indent=1)
+    paths = [detail_path]
+    if os.path.dirname(os.path.abspath(detail_path)) == ROOT and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    written = None
+    for q in paths:
+        try:
+            with open(q, "w") as f:
+                f.write(blob)
+            written = written or q
+        except OSError as e:
+            print("bench: could not write %s: %r" % (q, e), file=sys.stderr)
+    sys.stderr.flush()
+    print(compact_line(full, written))
+    sys.stdout.flush()
 
 
 # ------------------------------------------------------------------------------------------------ multi-rank self-launch
@@ -61,10 +145,25 @@ def self_launch(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, MOR_BENCH_SELF_LAUNCHED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=None if r == 0 else sys.stderr))
-    rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    # poll: the first rank that fails takes the others with it (they would otherwise sit in a gloo barrier until its timeout)
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in live:
+                    q.terminate()
+                t_end = time.time() + 10
+                for q in live:
+                    try:
+                        q.wait(max(0.1, t_end - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
     return rc
 
 
@@ -180,7 +279,6 @@ class Leg:
             self.B = streams
         self.npts = synth.n_points(self.sensor)
         self.seeds = shard.stream_seeds(cfg, rank, self.B)
-        self.track_capacity_hit = False
         self.n_frames = n_frames
         cb = self.npts * 16
         self.buf = engine.DeviceBuffer(n_frames * self.B * cb, device)
@@ -201,25 +299,14 @@ class Leg:
         k = step % period
         return k if k < self.n_frames else period - k
 
-    def _tolerant(self, fn, *a):
-        """The synthetic streams keep adding tracked centroids; a run of > 10 000 steps reaches the engine's bound (32 768 per stream): the
-        engine then reports MOR_ERR_CAPACITY once per wait, drops the new centroid and carries on — so does the bench (flagged in the line)."""
-        try:
-            return fn(*a)
-        except Exception as e:
-            if "tracked moving centroids" not in str(e):
-                raise
-            self.track_capacity_hit = True
-            return None
-
     def step(self, sync=True, batch=None):
         b = batch or self.batch
         f = self.frame_of(self.step_no)
         self.step_no += 1
-        self._tolerant(b.push_views, self.views[f], self.poses[f])
+        b.push_views(self.views[f], self.poses[f])
         if sync:
-            return self._tolerant(b.filter_device)
-        self._tolerant(b.filter_async)
+            return b.filter_device()
+        b.filter_async()
 
     def timed_async(self, steps, dist=None):
         """Enqueue `steps` push + filter pairs (asynchronous mode), wait once; returns seconds (this rank)."""
@@ -231,7 +318,7 @@ class Leg:
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step(sync=False)
-        self._tolerant(b.wait)
+        b.wait()   # any sticky error of any frame of the leg (track capacity included) fails the leg
         b.synchronize()
         if dist:
             dist.barrier()
@@ -457,7 +544,9 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="exercise only the multi-rank plumbing (no GPU work, no measurement)")
     ap.add_argument("--latency-only", action="store_true", help="child process of the default run: push + filter latency of ONE stream, prints {\"latency_b1_ms\": …}")
     ap.add_argument("--e2e-only", action="store_true", help="child process of the default run: the host-resident end-to-end legs, prints their figures as JSON")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="child process of the default run: the CPU oracle on the batch's own streams (never touches HIP), prints its figures as JSON")
     ap.add_argument("--device", type=int, default=0, help="HIP ordinal for --latency-only / --e2e-only")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), help="where the full record goes (per-kernel tables, every workload's roofline …); the stdout line stays under %d bytes" % LINE_LIMIT)
     args = ap.parse_args()
 
     if args.latency_only:
@@ -465,6 +554,13 @@ def main():
         return
     if args.e2e_only:
         print(json.dumps(e2e_legs(args.workload, args.device, args.streams)))
+        return
+
+    if args.cpu_baseline_only:
+        sensor_, B_, cfg_, mo_, go_ = WORKLOADS[args.workload]
+        from dynamicslamtool_amd import shard as shard_
+        single, allc, sums = cpu_baseline_run(shard_.stream_seeds(cfg_, 0, args.streams or B_), sensor_, mo_ or args.method, go_ if go_ is not None else args.ground_method)
+        print(json.dumps({"single": single, "all": allc, "summaries": {str(k): v for k, v in sums.items()}}))
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -477,16 +573,28 @@ def main():
 
     if args.dry_run:
         B = args.streams or WORKLOADS[args.workload][1]
-        seeds = shard.stream_seeds(2, rank, B)
+        seeds = shard.stream_seeds(WORKLOADS[args.workload][2], rank, B)
+        if os.environ.get("MOR_BENCH_FAIL_RANK") == str(rank):   # test hook: a rank that dies in front of a barrier (tests/test_shard_gloo.py)
+            os._exit(3)
         shard.barrier(dist)
         fake_elapsed = 1.0 + 0.5 * rank          # the slowest rank defines the job time
         rate = shard.whole_job_rate(dist, B * args.steps, fake_elapsed)
         per_rank = shard.gather_floats(dist, B * args.steps / fake_elapsed)
         first_seeds = shard.gather_floats(dist, seeds[0])
+        last_seeds = shard.gather_floats(dist, seeds[-1])
+        slices = None
+        topo = os.environ.get("MOR_FAKE_TOPOLOGY")   # {"gpu_node": [0,0,0,0,1,1,1,1], "node_cpus": {"0": [0..63], "1": [64..127]}}: the host placement of a node this box is not
+        if topo:
+            t_ = json.loads(topo)
+            sl = shard.numa_core_slices(t_["gpu_node"], {int(k): v for k, v in t_["node_cpus"].items()}, world)
+            slices = [[x[0], x[-1], len(x)] for x in sl]
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "value": rate, "first_seed": seeds[0], "last_seed_rank0": seeds[-1], "steps": args.steps,
-                              "per_rank_min_max": [min(per_rank), max(per_rank)], "first_seed_per_rank": [int(x) for x in first_seeds], "collective": "none",
-                              "self_launched": bool(os.environ.get("MOR_BENCH_SELF_LAUNCHED")), "cores_per_rank": cores_mine}))
+            text = json.dumps({"dry_run": True, "n_gpus": world, "value": rate, "first_seed": seeds[0], "last_seed_rank0": seeds[-1], "steps": args.steps,
+                               "per_rank_min_max": [min(per_rank), max(per_rank)], "first_seed_per_rank": [int(x) for x in first_seeds], "last_seed_per_rank": [int(x) for x in last_seeds],
+                               "collective": "none", "workloads": "skipped: world>1" if world > 1 else "skipped: dry run", "numa_core_slices_first_last_n": slices,
+                               "self_launched": bool(os.environ.get("MOR_BENCH_SELF_LAUNCHED")), "cores_per_rank": cores_mine})
+            assert len(text) <= LINE_LIMIT
+            print(text)
         if dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -497,8 +605,17 @@ def main():
     ground_method = g_over if g_over is not None else args.ground_method
     B0 = args.streams or B0
     cpu = cpu_all = oracle_sum = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # before HIP is initialised in this process (forked workers)
-        cpu, cpu_all, oracle_sum = cpu_baseline_run(shard.stream_seeds(cfg0, 0, B0), sensor0, method, ground_method)
+    if rank == 0 and not args.no_cpu_baseline:
+        # rank 0 at ANY world size (an N = 8 line carries its cpu_baseline too), in a child process that never touches HIP and before this
+        # one does: the oracle on rank 0's own streams, one single-threaded worker per core of rank 0's slice of the host.  The other ranks
+        # meanwhile build their batches on their own cores and meet rank 0 at the barrier in front of the timed region.
+        try:
+            r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload, "--method", str(args.method), "--ground-method", str(args.ground_method)]
+                                + (["--streams", str(args.streams)] if args.streams else []), capture_output=True, text=True, timeout=900)
+            j_ = json.loads(r_.stdout.strip().splitlines()[-1])
+            cpu, cpu_all, oracle_sum = j_["single"], j_["all"], {int(k): v for k, v in j_["summaries"].items()}
+        except Exception as e_:
+            print("cpu baseline leg failed: %r" % (e_,), file=sys.stderr)
 
     # ---- end-to-end legs and the one-stream latency: each in a process of its own, like an application with ONE batch per process.  (On this stack
     #      a batch created after other batches of the same process have come and gone copies device → host at 10 GB/s instead of 55 —
@@ -580,7 +697,9 @@ def main():
                     if tuple(logs[f][s][i] for i in idx) != tuple(rec[k] for k in ORACLE_KEYS):
                         obad.append((f, s))
         sanity.update({"oracle_records_checked": n_cmp, "oracle_fields": list(ORACLE_KEYS), "equals_oracle": not obad and n_cmp > 0, "oracle_mismatches": obad[:8]})
-    sanity["ok"] = sanity["async_equals_sync"] and sanity.get("equals_oracle", True)
+    if e2e_async_ok is not None:
+        sanity["e2e_host_async_equals_sync"] = bool(e2e_async_ok)
+    sanity["ok"] = bool(sanity["async_equals_sync"] and sanity.get("equals_oracle", True) and sanity.get("e2e_host_async_equals_sync", True))
 
     # device-only time of one step (HIP events around the launch sequences), two synchronous steps
     dev_ms = 0.0
@@ -611,7 +730,6 @@ def main():
         sync_rate = B * n_sync / (time.perf_counter() - t1)
 
     stream0 = leg.summary0()
-    track_cap = bool(leg.track_capacity_hit)
     stage_totals = {k: sum(leg.batch.stage_counts(s)[k] for s in range(B)) for k in ("n_occ", "n_tier1b", "n_defer", "C_prev")}
     profile = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in p.as_dict().items()}
     seeds_main = leg.seeds
@@ -644,7 +762,7 @@ def main():
                 others[name] = {"value": round(v, 1), "unit": "frame-pairs/s", "ms_per_step": round(1e3 * dt / st, 3), "steps": st, "streams_per_gpu": lg.B, "points_per_frame": lg.npts,
                                 "method": int(lg.p.method_choice), "ground_method": int(lg.p.ground_method),
                                 "algorithmic_bytes_per_frame_pair": int(ba), "roofline": roof, "top_kernels_us": {k: v_["avg_us"] for k, v_ in top}, "stream0": lg.summary0(),
-                                "async_equals_sync": not bad2 and bool(fr), "track_capacity_hit": bool(lg.track_capacity_hit), "setup_s": round(lg.setup_s, 1)}
+                                "async_equals_sync": not bad2 and bool(fr), "setup_s": round(lg.setup_s, 1)}
                 lg.close()
             except Exception as e:   # a secondary leg must not take the headline down
                 others[name] = {"error": repr(e)[:300]}
@@ -654,7 +772,7 @@ def main():
             "metric": "LiDAR frame-pairs/sec (120k pts, batched)", "value": round(value, 2), "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d streams/GPU x %d pts (%s), kitti profile, method %d%s" % (args.workload, B, npts, sensor, method, ", voxel-covariance ground removal" if ground_method else ""),
+            "config": {"workload": "%s: %d streams/GPU x %d pts (%s), device-resident clouds (inputs and filtered clouds stay in HBM; PCIe-inclusive rate = e2e_host_async_frame_pairs_per_s), kitti profile, method %d%s" % (args.workload, B, npts, sensor, method, ", voxel-covariance ground removal" if ground_method else ""),
                        "streams_per_gpu": B, "points_per_frame": npts, "parallelism": "streams sharded over %d GPU(s), no collective" % world,
                        "profile": profile},
             "collective": "none", "first_seed_per_rank": first_seeds, "self_launched": bool(os.environ.get("MOR_BENCH_SELF_LAUNCHED")), "devices_visible": ndev, "ranks_per_device": (world + ndev - 1) // ndev,
@@ -663,13 +781,14 @@ def main():
             "device_ms_per_step": round(dev_ms, 4), "sync_frame_pairs_per_s": None if sync_rate is None else round(sync_rate, 1),
             "e2e_host_frame_pairs_per_s": None if e2e is None else round(e2e, 2), "e2e_host_sync_ms_per_step": e2e_ms, "e2e_host_async_frame_pairs_per_s": None if e2e_async is None else round(e2e_async, 2), "e2e_host_async_equals_sync": e2e_async_ok, "latency_b1_ms": None if lat is None else round(lat, 3),
             "algorithmic_bytes_per_frame_pair": int(b_alg),
-            "stage_totals": stage_totals, "stream0": stream0, "track_capacity_hit": track_cap, "sanity": sanity,
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "workloads": others or None,
+            "stage_totals": stage_totals, "stream0": stream0, "sanity": sanity,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
+            "workloads": "skipped: world>1" if world > 1 else ("skipped: --no-extras" if not extras else others),
             "kernels": kernels, "kernels_alone_avg_us": kernels_alone,
             "setup_s": round(setup_s, 2),
+            "legs_failed": [n_ for n_, v_ in (("cpu_baseline", cpu if not args.no_cpu_baseline else 0), ("latency_b1", lat if extras and world == 1 else 0), ("e2e_host", e2e if extras and world == 1 else 0)) if v_ is None] or None,
         }
-        print(json.dumps(line))
-        sys.stdout.flush()
+        emit(line, args.detail)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

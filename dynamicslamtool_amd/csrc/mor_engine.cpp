@@ -279,6 +279,11 @@ static int wait_all_checked(mor_batch *b) {
 
 extern "C" {
 
+#ifndef MOR_SRC_HASH_STR
+#define MOR_SRC_HASH_STR "MOR_SRC_HASH=unknown"
+#endif
+// hash of the sources + compiler flags this library was built from (dynamicslamtool_amd/build.py embeds it; the loader compares it with the tree)
+const char *mor_build_hash(void) { return MOR_SRC_HASH_STR; }
 size_t mor_sizeof_params(void) { return sizeof(mor_params); }
 const char *mor_last_error(void) { return g_last_error.c_str(); }
 int mor_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }

@@ -21,8 +21,12 @@ static bool read_file(const std::string &path, std::vector<uint8_t> &out) {
   return (bool)f.read((char *)out.data(), n);
 }
 
+#ifndef MOR_SRC_HASH_STR
+#define MOR_SRC_HASH_STR "MOR_SRC_HASH=unknown"
+#endif
+
 int main(int argc, char **argv) {
-  if (argc < 5) { std::fprintf(stderr, "usage: %s <config> <poses.txt> <out_dir> <cloud.bin>...\n", argv[0]); return 2; }
+  if (argc < 5) { std::fprintf(stderr, "usage: %s <config> <poses.txt> <out_dir> <cloud.bin>...\n(%s)\n", argv[0], MOR_SRC_HASH_STR); return 2; }
   setenv("GPU_MAX_HW_QUEUES", "8", 0);   // the application's choice: one hardware queue per stage stream of the library's frame pipeline
   ros::NodeHandle nh;
   MovingObjectRemoval mor(nh, argv[1], 4, 3);   // n_bad = 4, n_good = 3 as in external_sync_test.cpp:37

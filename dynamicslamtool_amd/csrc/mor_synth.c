@@ -191,3 +191,8 @@ int mor_synth_batch(int sensor, int n_frames, const uint64_t *seeds, const int *
   for (int i = 0; i < n_frames; ++i) { if (mor_synth_frame(seeds[i], sensor, frame_idx[i], out_xyzi + (size_t)i * np * 4, pose7 + 7 * (size_t)i)) rc = -1; }
   return rc;
 }
+
+#ifndef MOR_SRC_HASH_STR
+#define MOR_SRC_HASH_STR "MOR_SRC_HASH=unknown"
+#endif
+const char *mor_synth_build_hash(void) { return MOR_SRC_HASH_STR; }

@@ -19,7 +19,7 @@ EXPORTS = [
     "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_get_stage_counts", "mor_device_alloc", "mor_device_free", "mor_host_alloc", "mor_host_free",
     "mor_device_upload", "mor_device_download", "mor_device_synchronize", "mor_device_count", "mor_get_last_timing",
     "mor_kernel_timing_enable", "mor_kernel_timing_read", "mor_get_frame_log", "mor_debug_read", "mor_debug_config", "mor_get_markers", "mor_kernel_timeline_read",
-    "mor_device_numa_node", "mor_bind_thread_to_device_node",
+    "mor_device_numa_node", "mor_bind_thread_to_device_node", "mor_build_hash",
 ]
 
 
@@ -38,6 +38,11 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libmor_hip.so is not built (python -m dynamicslamtool_amd.build); there is no CPU fallback")
+        if not os.environ.get("MOR_HIP_LIB") and not os.environ.get("MOR_ALLOW_STALE_LIB"):
+            from . import build as _build
+            if _build.stale("hip"):   # a library that travelled with the tree but was built from other sources must not be what gets tested or measured
+                raise RuntimeError("libmor_hip.so was built from other sources or flags than the ones in this tree (carries %r, tree is %r): run `python -m dynamicslamtool_amd.build`"
+                                   % (_build.built_hash(LIB_PATH), _build.source_hash(*_build._targets()["hip"][1:])))
         # one hardware queue per stage stream of the frame pipeline (csrc/mor_engine.cpp): the application's choice, made
         # here for the test / bench processes before HIP initialises; a value the caller has set is left alone
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

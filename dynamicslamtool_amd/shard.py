@@ -18,7 +18,10 @@ def init_distributed():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if not dist.is_initialized():
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        import datetime
+        # a rank that died before the rendezvous or inside a barrier must not hold the others for gloo's default 30 minutes; long enough
+        # for rank 0's CPU-baseline leg (tens of seconds) to run while the other ranks wait at the barrier in front of the timed region
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("MOR_DIST_TIMEOUT_S", "600"))))
     return dist
 
 
@@ -65,3 +68,27 @@ def gather_floats(dist, value):
     t[dist.get_rank()] = float(value)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [float(x) for x in t]
+
+
+def numa_core_slices(gpu_node, node_cpus, world, allowed=None):
+    """Host cores of every rank for a node topology: rank r drives GPU r mod len(gpu_node); the ranks whose GPUs hang on one NUMA node share that
+    node's cores (those in `allowed`, if given) in equal contiguous slices, in rank order — what `mor_bind_thread_to_device_node(device, index among
+    the node's ranks, ranks on the node)` does for one rank from sysfs.  gpu_node: NUMA node per HIP ordinal (−1: unknown ⇒ that rank keeps every
+    allowed core); node_cpus: {node: [cpu, …]}.  Pure function: the 2-socket / 8-GPU map of an MI355X node is tested without one."""
+    ndev = len(gpu_node)
+    nodes = [gpu_node[r % ndev] for r in range(world)]
+    out = []
+    for r in range(world):
+        n = nodes[r]
+        cpus = sorted(c for c in node_cpus.get(n, []) if allowed is None or c in allowed) if n >= 0 else []
+        if not cpus:
+            out.append(sorted(allowed) if allowed is not None else sorted(c for v in node_cpus.values() for c in v))
+            continue
+        peers = [q for q in range(world) if nodes[q] == n]
+        if len(cpus) >= len(peers):
+            per = len(cpus) // len(peers)
+            i = peers.index(r)
+            out.append(cpus[i * per:(i + 1) * per])
+        else:
+            out.append(cpus)
+    return out

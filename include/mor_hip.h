@@ -174,6 +174,8 @@ int mor_device_upload(int device, void *dst, const void *src, size_t bytes);
 int mor_device_download(int device, void *dst, const void *src, size_t bytes);
 int mor_device_synchronize(int device);
 int mor_device_count(void);
+/* "MOR_SRC_HASH=<24 hex digits>": hash of the sources + compiler flags the library was built from (build.py); "…=unknown" for a build made by hand. */
+const char *mor_build_hash(void);
 /* Host placement.  The thread that creates a batch and enqueues its frames should run on the NUMA node the GPU is attached to: the
  * command queues and the page-locked rings it fills live where it runs, and from the other socket the same run is 5–6 % slower
  * (measured on a two-socket MI355X host: 166 k against 176 k frame-pairs/s).  mor_device_numa_node returns that node (from the device's

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_two_ranks_share_the_visible_devices():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "8", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-extras"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "8", "--steps", "4", "--warmup", "2", "--no-extras"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -26,3 +26,7 @@ def test_two_ranks_share_the_visible_devices():
     assert 2 * min(d["per_rank_frame_pairs_per_s"]) * 0.999 <= d["value"] <= sum(d["per_rank_frame_pairs_per_s"]) * 1.001
     assert d["sanity"]["ok"] and d["sanity"]["async_equals_sync"] and d["sanity"]["frames_checked"] == 6
     assert d["roofline"]["frac"] > 0 and d["config"]["streams_per_gpu"] == 8
+    # an N > 1 line carries rank 0's CPU baseline too, says that the secondary legs were skipped, and stays inside the driver's window
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["sanity"]["equals_oracle"]
+    assert d["workloads"] == "skipped: world>1" and len(lines[0]) <= 4096
+    assert os.path.exists(os.path.join(ROOT, d["detail"]))

@@ -55,3 +55,47 @@ def test_gpus_flag_starts_the_ranks_itself():
     assert d["n_gpus"] == 2 and d["self_launched"] and d["collective"] == "none"
     assert d["first_seed_per_rank"] == [2000, 2008]
     assert abs(d["value"] - (2 * 8 * 4) / 1.5) < 1e-9
+
+
+def test_eight_rank_dry_run_with_a_two_socket_node_map():
+    """BASELINE config 4 without the hardware: `python bench.py --gpus 8 --dry-run` starts 8 gloo ranks itself — 64 streams each, seeds 2000 … 2511,
+    one line — and places every rank on its GPU's socket for the map of an 8-GPU / 2-socket node (4 GPUs per socket, 64 cores each)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    env["MOR_FAKE_TOPOLOGY"] = json.dumps({"gpu_node": [0, 0, 0, 0, 1, 1, 1, 1], "node_cpus": {"0": list(range(0, 64)), "1": list(range(64, 128))}})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) <= 4096
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["self_launched"] and d["collective"] == "none"
+    assert d["first_seed_per_rank"] == [2000 + 64 * r for r in range(8)] and d["last_seed_per_rank"][-1] == 2511
+    assert d["workloads"] == "skipped: world>1"
+    # rank r: 16 cores of its GPU's socket, disjoint from every other rank's
+    assert d["numa_core_slices_first_last_n"] == [[16 * r, 16 * r + 15, 16] for r in range(8)]
+    # 8 ranks x 64 streams x 4 steps over the slowest rank's 1 + 0.5·7 s
+    assert abs(d["value"] - 8 * 64 * 4 / 4.5) < 1e-9
+
+
+def test_numa_core_slices():
+    from dynamicslamtool_amd import shard
+    cpus = {0: list(range(0, 8)), 1: list(range(8, 16))}
+    assert shard.numa_core_slices([0, 1], cpus, 2) == [list(range(0, 8)), list(range(8, 16))]
+    assert shard.numa_core_slices([0, 0, 1, 1], cpus, 4) == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]]
+    # two ranks on the one visible GPU share its node; an unknown node keeps every allowed core; `allowed` filters
+    assert shard.numa_core_slices([1], cpus, 2) == [[8, 9, 10, 11], [12, 13, 14, 15]]
+    assert shard.numa_core_slices([-1], cpus, 1, allowed={1, 2, 9}) == [[1, 2, 9]]
+    assert shard.numa_core_slices([0, 1], cpus, 2, allowed=set(range(4, 12))) == [[4, 5, 6, 7], [8, 9, 10, 11]]
+
+
+def test_a_failing_rank_ends_the_self_launched_job():
+    """A rank that dies takes the others with it instead of leaving them in a barrier until the gloo timeout."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="1", MOR_BENCH_FAIL_RANK="1")
+    import time
+    t = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run", "--streams", "8"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and time.time() - t < 120
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
