@@ -3,6 +3,7 @@
 #include "MOR/MovingObjectRemoval.h"
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <fstream>
 #include <iostream>
 
@@ -27,11 +28,29 @@ void expand(const float *xyzi, size_t n, std::vector<uint8_t> &blob) {
 }
 }  // namespace
 
+#ifdef MOR_WITH_ROS_PCL
+MovingObjectRemoval::MovingObjectRemoval(ros::NodeHandle nh, std::string config_path, int n_bad, int n_good) : nh_(nh) {
+#else
 MovingObjectRemoval::MovingObjectRemoval(ros::NodeHandle, std::string config_path, int n_bad, int n_good) {
+#endif
   std::memset(&params_, 0, sizeof params_);
   params_.opc_resolution = 0.1f;   // literal at the reference call site (.cpp:575)
   params_.ground_method = 0;       // .cpp:526 is the active call
   setVariables(config_path);
+#ifdef MOR_WITH_ROS_PCL
+  /*ROS setup* (.cpp:372-385): topics from the config file, same queue sizes */
+#ifdef MOR_VISUALIZE
+  pub_ = nh_.advertise<sensor_msgs::PointCloud2>(output_topic_, 10);
+  debug_pub_ = nh_.advertise<sensor_msgs::PointCloud2>(debug_topic_, 10);
+  marker_pub_ = nh_.advertise<visualization_msgs::Marker>(marker_topic_, 10);
+#endif
+#ifdef INTERNAL_SYNC
+  pc_sub_.subscribe(nh_, input_pointcloud_topic_, 1);
+  odom_sub_.subscribe(nh_, input_odometry_topic_, 1);
+  sync_.reset(new message_filters::Synchronizer<MySyncPolicy>(MySyncPolicy(10), pc_sub_, odom_sub_));   // ROS Approximate Time policy (.cpp:381)
+  sync_->registerCallback(&MovingObjectRemoval::movingCloudObjectSubscriber, this);
+#endif
+#endif
   const char *dev = std::getenv("MOR_DEVICE"), *cap = std::getenv("MOR_MAX_POINTS");
   int err = 0;
   // MOR_BIND_NUMA=1: keep the constructing thread (the one that will call push / filter) on the CPUs of the GPU's NUMA node — opt-in,
@@ -123,8 +142,59 @@ void MovingObjectRemoval::pushRawCloudAndPose(pcl::PCLPointCloud2 &cloud, geomet
     describe_xyzi<sensor_msgs::PointCloud2, sensor_msgs::PointField>(output, c.n_clustered);
     output.header = std_msgs::Header();   // fromPCL copies the (default) header (.cpp:555) …
     output.header.frame_id = debug_fid_;  // … then .cpp:556
+#ifdef MOR_WITH_ROS_PCL
+    debug_pub_.publish(output);           // .cpp:557
+#endif
   }
 #endif
+}
+
+#if defined(MOR_WITH_ROS_PCL) && defined(INTERNAL_SYNC)
+// subscriber for internal sync (.cpp:393-413): toPCL → push → filter → publish, CPU time of the iteration printed in ms between two rules
+void MovingObjectRemoval::movingCloudObjectSubscriber(const sensor_msgs::PointCloud2ConstPtr &input, const nav_msgs::OdometryConstPtr &odm) {
+  clock_t begin_time = clock();
+  std::cout << "-----------------------------------------------------\n";
+  pcl::PCLPointCloud2 cloud;
+  pcl_conversions::toPCL(*input, cloud);
+  pushRawCloudAndPose(cloud, odm->pose.pose);
+  if (filterCloud(cloud, output_fid_)) {
+#ifdef MOR_VISUALIZE
+    pub_.publish(output);
+#endif
+  }
+  std::cout << 1000.0 * (clock() - begin_time) / CLOCKS_PER_SEC << std::endl;
+  std::cout << "-----------------------------------------------------\n";
+}
+#endif
+
+#if defined(MOR_WITH_ROS_PCL) && defined(MOR_VISUALIZE)
+// mark_cluster (.cpp:7-58): CUBE at the float-accumulated centroid, scale = box extent (0 → 0.1), colour and lifetime of the caller at .cpp:623/:641
+visualization_msgs::Marker MovingObjectRemoval::toMarker(const BoxMarker &m, int id) const {
+  visualization_msgs::Marker marker;
+  marker.header.frame_id = debug_fid_;
+  marker.header.stamp = ros::Time::now();
+  marker.ns = "bounding_box";
+  marker.id = id;
+  marker.type = visualization_msgs::Marker::CUBE;
+  marker.action = visualization_msgs::Marker::ADD;
+  marker.pose.position.x = m.position[0]; marker.pose.position.y = m.position[1]; marker.pose.position.z = m.position[2];
+  marker.pose.orientation.x = 0.0; marker.pose.orientation.y = 0.0; marker.pose.orientation.z = 0.0; marker.pose.orientation.w = 1.0;
+  marker.scale.x = m.scale[0]; marker.scale.y = m.scale[1]; marker.scale.z = m.scale[2];
+  marker.color.r = 0.8f; marker.color.g = 0.1f; marker.color.b = 0.4f; marker.color.a = 0.5f;   // rd, gd, bd of .cpp:623; opacity .cpp:53
+  marker.lifetime = ros::Duration(2);
+  return marker;
+}
+#endif
+
+std::vector<MovingObjectRemoval::BoxMarker> MovingObjectRemoval::movingMarkers() const {
+  std::vector<BoxMarker> out;
+  uint32_t n = 0;
+  if (!ctx_ || mor_get_moving_clusters(ctx_, 0, nullptr, &n) != MOR_OK || n == 0) return out;
+  std::vector<int32_t> cl(n);
+  if (mor_get_moving_clusters(ctx_, 0, cl.data(), &n) != MOR_OK) return out;
+  const std::vector<BoxMarker> all = clusterMarkers();
+  for (uint32_t i = 0; i < n; ++i) if (cl[i] >= 0 && (size_t)cl[i] < all.size()) { BoxMarker m = all[(size_t)cl[i]]; m.id = (int)i + 1; out.push_back(m); }   // id starts at 1, one per visited tracked centroid (.cpp:623, :669)
+  return out;
 }
 
 std::vector<MovingObjectRemoval::BoxMarker> MovingObjectRemoval::clusterMarkers() const {
@@ -162,5 +232,8 @@ bool MovingObjectRemoval::filterCloud(pcl::PCLPointCloud2 &out_cloud, std::strin
   describe_xyzi<sensor_msgs::PointCloud2, sensor_msgs::PointField>(output, n);
   pcl_conversions::fromPCL(in_header_, output.header);   // seq, stamp.fromNSec(pcl stamp [µs] · 1000), frame_id — integer arithmetic, as .cpp:691 does
   output.header.frame_id = f_id;                // .cpp:692
+#if defined(MOR_WITH_ROS_PCL) && defined(MOR_VISUALIZE)
+  for (const BoxMarker &m : movingMarkers()) marker_pub_.publish(toMarker(m, m.id));   // the reference publishes them inside its loop over mo_vec (.cpp:641)
+#endif
   return true;
 }

@@ -196,6 +196,7 @@ struct MorDev {
   int2 *tr_corr;             // [B][MOR_TR_NB][Kcap]   corrs_vec (query, match), oldest first
   unsigned char *tr_res;     // [B][MOR_TR_NB+1][Kcap] res_vec, oldest first
   unsigned char *tr_lastdet; // [B][Kcap]  detection_results of the previous frame (ca)
+  int *tr_match;             // [B][MOR_TR_MAXT+1]  latest filterCloud: number of tracked centroids its loop visited, then the cluster each was matched to, in mo_vec order (the reference's bounding-box markers, :641)
   int moving_confidence, static_confidence; float leave_off, catch_up;
   int *otile_cnt;            // [B][tiles_max]
   float4 *const *out_ptrs;   // [B] or null

@@ -418,7 +418,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.chunk_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K) && dalloc(b, d.cl_first[i], B * K) && dalloc(b, d.slot_kc[i], B) && hipMemset(d.slot_kc[i], 0, B * sizeof(int2)) == hipSuccess;
   ok = ok && dalloc(b, d.err, B) && hipMemset(d.err, 0, B * sizeof(unsigned)) == hipSuccess && halloc(b, d.h_err, B) && halloc(b, d.h_log, B * (size_t)MOR_LOG_CAP) && dalloc(b, b->d_outptrs, B * MOR_MAX_DEPTH);
   ok = ok && dalloc(b, d.dbg, B * 16) && dalloc(b, d.dbg2, B * (MOR_MAXP + 2) * 16);
-  ok = ok && dalloc(b, d.tr, B) && hipMemset(d.tr, 0, B * sizeof(MorTrackDev)) == hipSuccess && dalloc(b, d.tr_corr, B * MOR_TR_NB * K) && dalloc(b, d.tr_res, B * (MOR_TR_NB + 1) * K) && dalloc(b, d.tr_lastdet, B * K);
+  ok = ok && dalloc(b, d.tr, B) && hipMemset(d.tr, 0, B * sizeof(MorTrackDev)) == hipSuccess && dalloc(b, d.tr_corr, B * MOR_TR_NB * K) && dalloc(b, d.tr_res, B * (MOR_TR_NB + 1) * K) && dalloc(b, d.tr_lastdet, B * K) && dalloc(b, d.tr_match, B * (size_t)(MOR_TR_MAXT + 1)) && hipMemset(d.tr_match, 0, B * (size_t)(MOR_TR_MAXT + 1) * sizeof(int)) == hipSuccess;
   ok = ok && halloc(b, b->h_args_ring, B * MOR_ARGS_RING) && halloc(b, b->h_outptrs, B * MOR_ARGS_RING);
   b->h_args = b->h_args_ring;
   ok = ok && halloc(b, d.h_info, B) && halloc(b, d.h_centroid, B * K) && halloc(b, d.h_cl_off, B * (K + 1)) && halloc(b, d.h_det, B * K);
@@ -730,6 +730,17 @@ int mor_get_tracks(const mor_batch *b, int s, float *xyz, int32_t *conf, int32_t
   std::vector<MorTrackDev> t(1);
   HIP_TRY(hipMemcpy(t.data(), &d.tr[s], sizeof(MorTrackDev), hipMemcpyDeviceToHost));
   for (int i = 0; i < t[0].n_mo; ++i) { if (xyz) memcpy(xyz + 3 * i, t[0].mo_c[i], 3 * sizeof(float)); if (conf) conf[i] = t[0].mo_conf[i]; if (maxc) maxc[i] = t[0].mo_max[i]; }
+  return MOR_OK;
+}
+// the clusters the latest filterCloud's loop over mo_vec matched its tracked centroids to, in loop order (:630-642)
+int mor_get_moving_clusters(const mor_batch *b, int s, int32_t *cluster_of_track, uint32_t *n) {
+  CHECK_STREAM();
+  if (!n) return set_error(MOR_ERR_INVALID, "null argument");
+  int cnt = 0;
+  HIP_TRY(hipMemcpy(&cnt, d.tr_match + (size_t)s * (MOR_TR_MAXT + 1), sizeof(int), hipMemcpyDeviceToHost));
+  if (!b->filtered) cnt = 0;   // no filterCloud on the latest frame yet
+  *n = (uint32_t)cnt;
+  if (cluster_of_track && cnt > 0) HIP_TRY(hipMemcpy(cluster_of_track, d.tr_match + (size_t)s * (MOR_TR_MAXT + 1) + 1, sizeof(int) * (size_t)cnt, hipMemcpyDeviceToHost));
   return MOR_OK;
 }
 // cluster_collection (:229): the clustered points (x, y, z, intensity) in the reference's order

@@ -3318,6 +3318,7 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
           float bd = INFINITY; int bi = 0;
           for (int k = 0; k < K; ++k) { const float4 c = fits ? l_cen[k] : d.centroid[d.cur][ko + k]; float dd = sqdist(c0[u], c1[u], c2[u], c.x, c.y, c.z); if (dd < bd) { bd = dd; bi = k; } }   // ties → lowest index
           if (fits) l_mov[bi] = 1; else moving[bi] = 1;                      // whole cluster queued for removal before any test (:644-648)
+          d.tr_match[(size_t)s * (MOR_TR_MAXT + 1) + 1 + i0 + 64 * u + lane] = bi;   // (the marker the reference publishes for this tracked centroid, :641)
           mine += (unsigned long long)(fits ? l_size[bi] : off[bi + 1] - off[bi]);
           if (!(fits ? l_det[bi] : d.det[ko + bi]) || bd > d.leave_off) {    // squared vs un-squared: reference quirk kept (:650)
             keep[u] = --conf[u] != 0;                                        // erased at confidence 0 (:655-660)
@@ -3347,6 +3348,7 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
   if (fits) for (int k = lane; k < K; k += 64) moving[k] = l_mov[k];
   if (lane == 0) d.moving[(size_t)d.Btot * d.Kcap + s] = total > (unsigned long long)d.info[s].M;   // ExtractIndices: more indices than points ⇒ error, empty output
   if (lane == 0) d.h_log[(size_t)(d.frame_no % MOR_LOG_CAP) * d.Btot + s].n_mo_filter = t.n_mo;
+  if (lane == 0) d.tr_match[(size_t)s * (MOR_TR_MAXT + 1)] = K > 0 ? n_mo : 0;
   tr_store_head(gt, t, lane);
 }
 

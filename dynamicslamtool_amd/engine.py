@@ -19,7 +19,7 @@ EXPORTS = [
     "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_get_stage_counts", "mor_device_alloc", "mor_device_free", "mor_host_alloc", "mor_host_free",
     "mor_device_upload", "mor_device_download", "mor_device_synchronize", "mor_device_count", "mor_get_last_timing",
     "mor_kernel_timing_enable", "mor_kernel_timing_read", "mor_get_frame_log", "mor_debug_read", "mor_debug_config", "mor_get_markers", "mor_kernel_timeline_read",
-    "mor_device_numa_node", "mor_bind_thread_to_device_node", "mor_build_hash",
+    "mor_device_numa_node", "mor_bind_thread_to_device_node", "mor_build_hash", "mor_get_moving_clusters",
 ]
 
 
@@ -73,6 +73,7 @@ def lib():
         L.mor_get_stage_counts.argtypes = [vp, i32, vp, i32]
         L.mor_get_boxes.argtypes = [vp, i32, vp, vp]
         L.mor_get_markers.argtypes = [vp, i32, vp, vp]
+        L.mor_get_moving_clusters.argtypes = [vp, i32, vp, vp]
         L.mor_device_alloc.restype = vp
         L.mor_device_alloc.argtypes = [i32, C.c_size_t]
         L.mor_device_free.argtypes = [i32, vp]
@@ -323,6 +324,14 @@ class MorBatch:
         pos, scale = np.empty((max(K, 1), 3), np.float32), np.empty((max(K, 1), 3), np.float32)
         _check(lib().mor_get_markers(self._h, s, pos.ctypes.data, scale.ctypes.data))
         return pos[:K], scale[:K]
+
+    def moving_clusters(self, s=0):
+        """Cluster index per tracked centroid the latest filterCloud visited, in mo_vec order (the reference's bounding-box markers, :641)."""
+        n = C.c_uint32(0)
+        _check(lib().mor_get_moving_clusters(self._h, s, None, C.byref(n)))
+        out = np.empty(max(int(n.value), 1), np.int32)
+        _check(lib().mor_get_moving_clusters(self._h, s, out.ctypes.data, C.byref(n)))
+        return out[:int(n.value)]
 
     def detection(self, s=0):
         return self._get(lib().mor_get_detection, s, self.counts(s).n_clusters, np.uint8)

@@ -9,6 +9,10 @@
 #include "MOR/IncludeAll.h"
 #include "mor_hip.h"
 
+#ifdef MOR_WITH_ROS_PCL
+typedef message_filters::sync_policies::ApproximateTime<sensor_msgs::PointCloud2, nav_msgs::Odometry> MySyncPolicy;   // reference header :2
+#endif
+
 class MovingObjectRemoval {
  public:
   sensor_msgs::PointCloud2 output;   // filtered cloud of the last filterCloud() (reference header :159)
@@ -42,6 +46,8 @@ class MovingObjectRemoval {
   const mor_params &params() const { return params_; }
   const std::string &debug_fid() const { return debug_fid_; }
   const std::string &output_fid() const { return output_fid_; }
+  // the tracked moving clusters of the latest filterCloud, in mo_vec order: one marker per tracked centroid visited by the loop (.cpp:630-642), id 1, 2, …
+  std::vector<BoxMarker> movingMarkers() const;
 
  private:
   void setVariables(const std::string &config_file_path);
@@ -53,4 +59,18 @@ class MovingObjectRemoval {
   pcl::PCLHeader in_header_;        // header of the latest incoming cloud
   std::vector<float> scratch_;
   std::vector<uint8_t> rows_;       // de-padded rows of an organised cloud
+#ifdef MOR_WITH_ROS_PCL
+  // ---- ROS plumbing of the reference's constructor (.cpp:372-385) and of its internal-sync callback (.cpp:393-413)
+  ros::NodeHandle nh_;              // (the reference keeps a reference to its by-value constructor argument, header :131; a copy here)
+#ifdef MOR_VISUALIZE
+  ros::Publisher pub_, debug_pub_, marker_pub_;   // output_topic, debug_topic, marker_topic of the config file (.cpp:374-376)
+  visualization_msgs::Marker toMarker(const BoxMarker &m, int id) const;   // mark_cluster (.cpp:7-58)
+#endif
+#ifdef INTERNAL_SYNC
+  message_filters::Subscriber<sensor_msgs::PointCloud2> pc_sub_;
+  message_filters::Subscriber<nav_msgs::Odometry> odom_sub_;
+  std::unique_ptr<message_filters::Synchronizer<MySyncPolicy>> sync_;
+  void movingCloudObjectSubscriber(const sensor_msgs::PointCloud2ConstPtr &input, const nav_msgs::OdometryConstPtr &odm);
+#endif
+#endif
 };

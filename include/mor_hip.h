@@ -141,6 +141,10 @@ int mor_get_boxes(const mor_batch *b, int stream, float *min_K3, float *max_K3);
 /* the marker data itself, as mark_cluster computes it: position = FLOAT-accumulated centroid of the cluster's points (:15 — not
  * the fp64 centroid of :239-243), scale = box extent with zero extents replaced by 0.1 */
 int mor_get_markers(const mor_batch *b, int stream, float *pos_K3, float *scale_K3);
+/* the latest filterCloud's loop over mo_vec (:630-671): for every tracked centroid it visited, in order, the cluster of the latest frame it was matched to
+ * (the cluster whose bounding box the reference publishes as a marker with id 1, 2, … at :641).  *n = entries (0 before the frame's first filterCloud);
+ * cluster_of_track may be null to query the count (at most mor_get_tracks' count before that filterCloud). */
+int mor_get_moving_clusters(const mor_batch *b, int stream, int32_t *cluster_of_track, uint32_t *n);
 /* correspondence map mp (:564) + movement scores param_vec (:571/:575) of the last push */
 int mor_get_correspondences(const mor_batch *b, int stream, int32_t *query, int32_t *match, float *dist, double *score);
 /* mo_vec (header :109): centroid xyz, confidence, max_confidence */

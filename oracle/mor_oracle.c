@@ -179,6 +179,7 @@ struct oracle_ctx {
   mo_centroid *mo; int n_mo, cap_mo;
   /* last push's correspondences + scores (for read-back) */
   corr_t *last_corr; double *last_score; int n_last_corr;
+  ivec marked; /* clusters the latest filterCloud published a bounding-box marker for, in loop order (:641) */
   double busy;
 };
 
@@ -198,7 +199,7 @@ void oracle_destroy(oracle_ctx *c) {
   frame_free(c->ca); frame_free(c->cb);
   for (int i = 0; i < c->n_corrs_vec; ++i) free(c->corrs_vec[i].c);
   for (int i = 0; i < c->n_res_vec; ++i) free(c->res_vec[i].v);
-  free(c->corrs_vec); free(c->res_vec); free(c->mo); free(c->last_corr); free(c->last_score); free(c);
+  free(c->corrs_vec); free(c->res_vec); free(c->mo); free(c->last_corr); free(c->last_score); iv_free(&c->marked); free(c);
 }
 
 /* ------------------------------------------------------------------ G1
@@ -583,9 +584,11 @@ int oracle_filter(oracle_ctx *c, float *out, uint64_t *n_out) {
   frame *cb = c->cb; if (!cb->init) { *n_out = 0; return -1; }
   kdtree tree; kd_build(&tree, cb->centroid, 3, cb->K); /* :618 */
   ivec moving = { 0 };
+  c->marked.n = 0;
   for (int i = 0; i < c->n_mo; ++i) { /* :630 */
     float d; int nn = kd_nn(&tree, c->mo[i].c, &d); /* :636 */
     if (nn < 0) continue; /* empty centroid set: nearestKSearch returns 0 (defined) */
+    iv_push(&c->marked, nn); /* :641 marker_pub.publish(mark_cluster(cb->clusters[nn], id, …)); id++ at :669 */
     for (int j = cb->cl_off[nn]; j < cb->cl_off[nn + 1]; ++j) iv_push(&moving, cb->cl_idx[j]); /* :644-648, before the distance test */
     if (!cb->det[nn] || d > c->p.leave_off_distance) { /* :650 squared vs un-squared: quirk kept */
       if (--c->mo[i].confidence == 0) { memmove(&c->mo[i], &c->mo[i + 1], (c->n_mo - i - 1) * sizeof(mo_centroid)); c->n_mo--; i--; } /* :655-660 */
@@ -615,6 +618,10 @@ void oracle_get_counts(const oracle_ctx *c, oracle_counts *o) {
   o->n_in = f->n_in; o->n_trim = f->n_raw; o->n_cloud = f->n_cloud; o->n_ground = f->n_gp;
   o->n_clusters = (uint32_t)f->K; o->n_clustered = f->cl_off ? (uint32_t)f->cl_off[f->K] : 0;
   o->n_corr = (uint32_t)c->n_last_corr; o->n_tracks = (uint32_t)c->n_mo;
+}
+uint32_t oracle_get_moving_clusters(const oracle_ctx *c, int32_t *cluster_of_track) {
+  if (cluster_of_track) for (size_t i = 0; i < c->marked.n; ++i) cluster_of_track[i] = c->marked.d[i];
+  return (uint32_t)c->marked.n;
 }
 void oracle_get_labels(const oracle_ctx *c, int32_t *lab) {
   const frame *f = c->cb;

@@ -94,6 +94,8 @@ uint32_t oracle_get_prev_clustered(const oracle_ctx *c);
 void oracle_get_prev_transformed(const oracle_ctx *c, float *cent_K3, float *pts_C4);
 /* mark_cluster (:7-58) of every cluster of `cb`: fp32-centroid position and box extent (zero extent -> 0.1) */
 void oracle_get_markers(const oracle_ctx *c, float *pos_K3, float *scale_K3);
+/* clusters the latest oracle_filter's loop over mo_vec matched its tracked centroids to, in loop order (the markers of :641, ids 1, 2, …); returns the count */
+uint32_t oracle_get_moving_clusters(const oracle_ctx *c, int32_t *cluster_of_track);
 
 /* wall-clock seconds spent inside oracle_push + oracle_filter since creation */
 double oracle_get_busy_seconds(const oracle_ctx *c);

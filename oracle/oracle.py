@@ -39,6 +39,8 @@ def lib():
         L.oracle_get_prev_clustered.argtypes = [C.c_void_p]
         L.oracle_get_prev_transformed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_get_markers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_get_moving_clusters.restype = C.c_uint32
+        L.oracle_get_moving_clusters.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_get_prev_cluster_count.argtypes = [C.c_void_p]
         L.oracle_get_busy_seconds.restype = C.c_double
         L.oracle_get_busy_seconds.argtypes = [C.c_void_p]
@@ -153,6 +155,13 @@ class Oracle:
         pos, scale = np.empty((max(K, 1), 3), np.float32), np.empty((max(K, 1), 3), np.float32)
         lib().oracle_get_markers(self._h, pos.ctypes.data, scale.ctypes.data)
         return pos[:K], scale[:K]
+
+    def moving_clusters(self):
+        """Cluster index per tracked centroid the latest filterCloud visited, in mo_vec order (the markers of :641)."""
+        n = int(lib().oracle_get_moving_clusters(self._h, None))
+        out = np.empty(max(n, 1), np.int32)
+        lib().oracle_get_moving_clusters(self._h, out.ctypes.data)
+        return out[:n]
 
     def prev_transformed(self):
         """ca after the in-place transform of :540-551: (centroids K_prev×3, cluster points C_prev×4 in cluster order)."""

@@ -42,3 +42,11 @@ def compare_tracks(o, b, s=0, tag=""):
 def compare_output(out_o, out_b, tag=""):
     assert out_o.shape == out_b.shape, "%s filtered cloud size: oracle %s hip %s" % (tag, out_o.shape, out_b.shape)
     assert np.array_equal(out_o.view(np.uint32), out_b.view(np.uint32)), tag + " filtered cloud bytes"
+
+
+def compare_after_filter(o, b, s=0, tag=""):
+    """After filterCloud on both: the tracked centroids (confidences moved by the loop) and the clusters the loop matched them to, in mo_vec order
+    (the bounding-box markers the reference publishes at :641)."""
+    compare_tracks(o, b, s, tag)
+    assert np.array_equal(o.moving_clusters(), b.moving_clusters(s)), tag + " clusters matched by the filterCloud loop"
+    return len(o.moving_clusters())

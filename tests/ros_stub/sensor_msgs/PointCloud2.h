@@ -1,5 +1,6 @@
 #pragma once
 #include <vector>
+#include <boost/shared_ptr.hpp>
 #include <sensor_msgs/PointField.h>
 #include <std_msgs/Header.h>
 namespace sensor_msgs {
@@ -14,4 +15,6 @@ template <class A> struct PointCloud2_ {
   uint8_t is_dense;
 };
 typedef PointCloud2_<std::allocator<void>> PointCloud2;
+typedef boost::shared_ptr<PointCloud2> PointCloud2Ptr;
+typedef boost::shared_ptr<PointCloud2 const> PointCloud2ConstPtr;
 }  // namespace sensor_msgs

@@ -113,7 +113,83 @@ def test_adapter_compiles_against_ros_shaped_types(tmp_path):
     ros::Time with an explicit constructor (no assignment from double), allocator-templated messages, pcl::uint8_t vectors,
     pcl_conversions::fromPCL — not only against the in-repo shim.  Compile-only (tests/ros_stub/ are data carriers)."""
     src = os.path.join(ROOT, "dynamicslamtool_amd", "csrc", "mor_adapter.cpp")
-    for extra in ([], ["-DMOR_NO_VISUALIZE"]):
+    for extra in ([], ["-DMOR_NO_VISUALIZE"], ["-DINTERNAL_SYNC"], ["-DINTERNAL_SYNC", "-DMOR_NO_VISUALIZE"]):   # the reference's two compile-time flags (IncludeAll.h:32, :36)
         r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-c", "-DMOR_WITH_ROS_PCL", "-I", os.path.join(ROOT, "tests", "ros_stub"), "-I", os.path.join(ROOT, "include"),
                             src, "-o", str(tmp_path / "adapter.o")] + extra, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def _build_internal_sync_node(tmp_path):
+    """The class with -DMOR_WITH_ROS_PCL -DINTERNAL_SYNC against tests/ros_stub + the test node that stands in for internal_sync_test.cpp."""
+    exe = str(tmp_path / "internal_sync_node")
+    csrc = os.path.join(ROOT, "dynamicslamtool_amd", "csrc")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-DMOR_WITH_ROS_PCL", "-DINTERNAL_SYNC", "-I", os.path.join(ROOT, "tests", "ros_stub"), "-I", os.path.join(ROOT, "include"),
+                        "-o", exe, os.path.join(ROOT, "tests", "ros_stub", "internal_sync_node.cpp"), os.path.join(csrc, "mor_adapter.cpp"), "-L", csrc, "-lmor_hip",
+                        "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_internal_sync_build_links_and_parses_the_reference_config(tmp_path):
+    """SURVEY §8f-4, compile + link level (CPU): the constructor's advertise / subscribe / synchroniser block (.cpp:372-385) and
+    movingCloudObjectSubscriber (.cpp:393-413) build against ROS-shaped headers, and the node gets as far as the reference's does without a
+    device: the config echo, then mor_create's refusal (no CPU fallback)."""
+    exe = _build_internal_sync_node(tmp_path)
+    r = subprocess.run([exe, REF_CONFIG_FILE, "/dev/null", str(tmp_path), "/dev/null"], capture_output=True, text=True)
+    assert "input_pointcloud_topic:/velodyne_points" in r.stdout and "input_odometry_topic:/camera/odom/sample" in r.stdout and "Invalid parameter" not in r.stdout
+
+
+@pytest.mark.gpu
+def test_internal_sync_callback_publishes_what_the_external_sync_calls_return(tmp_path):
+    """SURVEY §8f-4 end to end without ROS: clouds and odometry published into the class's own subscriptions (in-process bus of tests/ros_stub) come
+    out on output_topic exactly as pushRawCloudAndPose + filterCloud return them to an external-sync caller (mor_replay) and as the oracle says;
+    the debug topic carries the clustered points from the second frame on (.cpp:553-558); the marker topic one CUBE per tracked centroid the
+    filterCloud loop visited — ids 1, 2, …, the matched cluster's float centroid and extent, the reference's colour and lifetime (.cpp:7-58, :623, :641)."""
+    from oracle.oracle import Oracle
+    exe = _build_internal_sync_node(tmp_path)
+    cfg = tmp_path / "MOR_config.txt"
+    cfg.write_text(_config_text(method=2))
+    frames = small_stream(1, n_frames=8, with_nan=True)
+    files = []
+    with open(tmp_path / "poses.txt", "w") as pf:
+        for i, (pts, pose) in enumerate(frames):
+            fn = tmp_path / ("cloud_%04d.bin" % i)
+            pts.astype(np.float32).tofile(fn)
+            files.append(str(fn))
+            pf.write(" ".join(repr(float(v)) for v in pose) + "\n")
+    ext, internal = tmp_path / "ext", tmp_path / "int"
+    ext.mkdir()
+    internal.mkdir()
+    r1 = subprocess.run([REPLAY, str(cfg), str(tmp_path / "poses.txt"), str(ext)] + files, capture_output=True, text=True)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    r2 = subprocess.run([exe, str(cfg), str(tmp_path / "poses.txt"), str(internal)] + files, capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    assert r2.stdout.count("-----------------------------------------------------") == 2 * len(frames)   # the callback's two rules per iteration (.cpp:398, :412)
+    p_ = scene_params(method_choice=2)
+    o = Oracle(p_, 4, 3)
+    n_markers = 0
+    for i, (pts, pose) in enumerate(frames):
+        o.push(pts, pose)
+        off, idx = o.clusters()
+        raw = pts[np.isfinite(pts[:, :3]).all(1) & (np.abs(pts[:, 0]) <= p_.trim_x) & (np.abs(pts[:, 1]) <= p_.trim_y)]
+        o_cloud = raw[(raw[:, 2] >= p_.gp_limit) & (raw[:, 2] <= p_.trim_z)]
+        want = o.filter()
+        got = np.fromfile(internal / ("filtered_%04d.bin" % i), np.float32).reshape(-1, 4)
+        same = np.fromfile(ext / ("filtered_%04d.bin" % i), np.float32).reshape(-1, 4)
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)) and np.array_equal(got.view(np.uint32), same.view(np.uint32)), "frame %d" % i
+        assert ("frame %d: published %d pts, frame_id /filtered, seq %d, stamp %d ns, debug clouds %d" % (i, len(want), i, 1000000000 * (100 + i), 1 if i else 0)) in r2.stdout, r2.stdout
+        if i:
+            dbg = np.fromfile(internal / ("debug_%04d.bin" % i), np.float32).reshape(-1, 4)
+            assert np.array_equal(dbg.view(np.uint32), o_cloud[idx].astype(np.float32).view(np.uint32)), "frame %d" % i
+        # markers: one per tracked centroid visited by the loop, on the cluster it was matched to
+        mc = o.moving_clusters()
+        rows = [l.split() for l in open(internal / ("moving_markers_%04d.txt" % i)).read().splitlines()]
+        assert len(rows) == len(mc), "frame %d" % i
+        if len(mc):
+            pos, scale = o.markers()
+            for j, row in enumerate(rows):
+                assert int(row[0]) == j + 1 and row[12] == "bounding_box" and row[13] == "/debug" and int(row[14]) == 1 and int(row[15]) == 0
+                assert np.allclose([float(v) for v in row[1:4]], pos[mc[j]], rtol=0, atol=2e-6) and np.allclose([float(v) for v in row[4:7]], scale[mc[j]], rtol=0, atol=2e-6)
+                assert np.allclose([float(v) for v in row[7:12]], [0.8, 0.1, 0.4, 0.5, 2.0], rtol=0, atol=1e-6)
+        n_markers += len(mc)
+    assert n_markers > 0

@@ -11,9 +11,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_share_the_visible_devices():
+def test_two_ranks_share_the_visible_devices(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "8", "--steps", "4", "--warmup", "2", "--no-extras"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "8", "--steps", "4", "--warmup", "2", "--no-extras", "--detail", str(tmp_path / "detail.json")],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -29,4 +29,4 @@ def test_two_ranks_share_the_visible_devices():
     # an N > 1 line carries rank 0's CPU baseline too, says that the secondary legs were skipped, and stays inside the driver's window
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["sanity"]["equals_oracle"]
     assert d["workloads"] == "skipped: world>1" and len(lines[0]) <= 4096
-    assert os.path.exists(os.path.join(ROOT, d["detail"]))
+    assert d["detail"] == str(tmp_path / "detail.json") and "per_kernel" in json.load(open(d["detail"]))["roofline"]

@@ -834,6 +834,29 @@ def test_filter_cloud_called_twice_walks_the_tracks_twice():
     b.close()
 
 
+def test_clusters_matched_by_the_filtercloud_loop_full_size():
+    """The loop over mo_vec (:630-671) visits every tracked centroid once, in order, and matches it to its nearest current cluster — the cluster
+    whose bounding box the reference publishes (:641).  mor_get_moving_clusters against the oracle over ten frames of four 120 000-point streams
+    (tracks appear after the confidence window has filled), plus the count before the frame's first filterCloud (0)."""
+    from parity import compare_after_filter
+    p = kitti_params(1)
+    seeds = [2000, 2007, 2021, 2040]
+    b, oracles = MorBatch(p, len(seeds), 120000), [Oracle(p) for _ in seeds]
+    seen = 0
+    for f in range(10):
+        xs, ps = synth.batch(seeds, [f] * len(seeds))
+        b.push(list(xs), ps)
+        for s in range(len(seeds)):
+            oracles[s].push(xs[s], ps[s])
+            assert len(b.moving_clusters(s)) == 0
+        outs = b.filter()
+        for s in range(len(seeds)):
+            compare_output(oracles[s].filter(), outs[s], "stream %d frame %d" % (s, f))
+            seen += compare_after_filter(oracles[s], b, s, "stream %d frame %d" % (s, f))
+    assert seen > 20
+    b.close()
+
+
 def test_markers_match_oracle_including_zero_extent():
     """mark_cluster (:7-58): position = FLOAT-accumulated centroid of the cluster's points (not the fp64 centroid of :239-243),
     scale = box extent, zero extents → 0.1.  Compared with the oracle's restatement; one cluster is a flat patch (all z
