@@ -92,6 +92,7 @@ struct MorDev {
                              // previous frame; those kernels grid-stride over the tiles a stream really has, so any value ≥ 1 is correct
   int split_g;   // workgroups per stream of the two split passes (each walks tiles split_g apart)
   int g_fast, g_score, g_pde, g_box;   // launch widths: k_score_fast workgroups per cloud tile, workgroups per stream of the worklist tiers / the wave tier / k_cellboxes (MOR_TUNE)
+  int prop_map;              // 1 (default): launches share their workgroups out over the streams in proportion to the streams' work (map_block_work); 0: the same number for every stream (MOR_PROP_MAP=0)
   int xcd_map;               // 1: the workgroups of a stream share an XCD (its tables stay in that L2); 0: streams spread over all XCDs
   int nt_ground;             // non-temporal stores for the ground points at the split (MOR_NT_GROUND, experiment)
   int sp_g;                  // workgroups per stream of the single-read split (2 … 64)
@@ -133,7 +134,8 @@ struct MorDev {
   int *gh_key, *gh_val;      // [B][Hcell] hash path: the cell table of streams with more cells than the LDS table holds
   int gh_tier;   // table tier k_gridhash starts with (0 small LDS table, 1 big LDS table, 2 global memory)
   int *slab_y, *slab_c, *slab_e;    // [B][MOR_MAXP+1]  slabs of the cell graph: first y-slice, first compact cell id, end of the look-ahead (cells of the next two y-slices)
-  int P, cg_force_global;    // slabs per stream this frame; test knob: forests in global memory
+  int P, cg_force_global;    // workgroups per stream of k_cg_slab this frame (= slabs per stream when every stream gets the same); test knob: forests in global memory
+  int *slab_p; int slab_T;   // [B] slabs of each stream (slab_bounds); own cells per slab the host aims at when the slabs follow the streams' cell counts (0: d.P slabs for every stream)
   int cg_fused;              // the merge of the slab forests (k_cg_final's work) runs in each stream's last slab workgroup of k_cg_slab
   int *lroot_a, *lroot_b;    // [B][Nmax]  per cell: its local root in its own slab / in the previous slab's look-ahead (compact ids)
   int *parent2;              // [B][Nmax]  second global forest (odd slabs when they do not fit LDS)

@@ -219,6 +219,7 @@ static int configure(mor_batch *b) {
     if (getenv("MOR_DEBUG")) fprintf(stderr, "mor: k_split %d workgroups per CU, sp_g %d\n", mor_split_blocks_per_cu(), d.sp_g);
   }
   d.xcd_map = getenv("MOR_NO_XCD_MAP") ? 0 : 1;
+  d.prop_map = getenv("MOR_PROP_MAP") ? atoi(getenv("MOR_PROP_MAP")) != 0 : 1;
   b->pargs_copy = getenv("MOR_ARGS_COPY") && atoi(getenv("MOR_ARGS_COPY")) != 0;
   d.nt_ground = getenv("MOR_NT_GROUND") ? atoi(getenv("MOR_NT_GROUND")) : 0;
   d.g_fast = 8; d.g_score = 4; d.g_pde = 256; d.g_box = 32;   // workgroups per stream: tier 1 (1024 threads each, two per CU), tiers 1a + 1b together (512 threads; they share out the chunks of the two worklists), wave tier (256 threads; workgroups without a query leave at once), cell boxes
@@ -436,7 +437,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = ok && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, 2 * B * N) && dalloc(b, o.gp_idx, B * N) && dalloc(b, o.pkey, B * N) && dalloc(b, o.pslot, B * N) && dalloc(b, o.gc_list, B * N) && dalloc(b, o.gc_ent, B * N) && dalloc(b, o.gc_n, B * (size_t)d.gc_chunks) && dalloc(b, o.gc_tab, B * (size_t)16384) && dalloc(b, o.gc_tabsel, B);
     ok = ok && dalloc(b, o.gh_rowlist, B * N) && dalloc(b, o.gh_cells, B * N) && dalloc(b, o.gh_rowfill, B * R1) && dalloc(b, o.gh_key, B * (size_t)d.Hcell) && dalloc(b, o.gh_val, B * (size_t)d.Hcell);
     ok = ok && dalloc(b, o.ckey, B * N) && dalloc(b, o.cstart, B * (N + 1)) && dalloc(b, o.row_start, B * R1) && dalloc(b, o.cmin, B * N) && dalloc(b, o.cmeta, 2 * B * N) && dalloc(b, o.crep, B * N) && dalloc(b, o.sorted, B * N) && dalloc(b, o.scell, B * N) && dalloc(b, o.csum, B * N);
-    ok = ok && dalloc(b, o.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, o.lroot_a, B * N) && dalloc(b, o.lroot_b, B * N) && dalloc(b, o.parent, B * N) && dalloc(b, o.parent2, B * N) && dalloc(b, o.cg_ovf, B * (size_t)MOR_MAXP * MOR_CGS_OVF * 2);
+    ok = ok && dalloc(b, o.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_p, B) && dalloc(b, o.lroot_a, B * N) && dalloc(b, o.lroot_b, B * N) && dalloc(b, o.parent, B * N) && dalloc(b, o.parent2, B * N) && dalloc(b, o.cg_ovf, B * (size_t)MOR_MAXP * MOR_CGS_OVF * 2);
     ok = ok && dalloc(b, o.croot, B * N) && dalloc(b, o.csize, B * N) && dalloc(b, o.compmin, B * N) && dalloc(b, o.cid_of_root, B * N) && dalloc(b, o.pcid, B * N) && dalloc(b, o.ccid, B * N) && dalloc(b, o.cgat, B * N) && dalloc(b, o.clist, B * N) && dalloc(b, o.cl_coff, B * (K + 1));
     ok = ok && dalloc(b, o.ktile_cnt, B * T) && dalloc(b, o.kcell, B * K) && dalloc(b, o.kroot, B * K) && dalloc(b, o.ksize, B * K) && dalloc(b, o.csz, B * K) && dalloc(b, o.krank_inv, B * K);
     ok = ok && dalloc(b, o.xcent, B * K) && dalloc(b, o.xamin, B * K) && dalloc(b, o.xamax, B * K) && dalloc(b, o.xfirst, B * K) && dalloc(b, o.part_back, B * (size_t)d.Wcap);
@@ -517,6 +518,11 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     const int p_fit = (int)((maxocc * 3ull / 2 + 818) / 819), p_par = (512 + B - 1) / B;   // a slab's LDS holds 1024 cells (own + look-ahead); two 512-thread workgroups per CU
     d.P = b->env_cg_p > 0 ? b->env_cg_p : std::max(p_fit, p_par);
     d.P = std::max(1, std::min(d.P, std::min(MOR_MAXP, std::max(1, d.g.ny / 2))));
+    {  // slabs in proportion to the streams' cell counts: own cells per slab such that the slabs of all streams together are the launch's B·P workgroups
+       // (Σ ceil(n_occ / T) ≤ Σ n_occ / T + B); never more than a slab's LDS holds with its look-ahead.  Counts of the latest frame the device reported.
+      unsigned long long tot = 0; for (int s = 0; s < B; ++s) tot += k > 0 ? d.h_info[s].n_occ : 0u;
+      d.slab_T = (k > 0 && tot > 0 && d.P > 1 && b->env_cg_p <= 0) ? (int)std::min<unsigned long long>(600, std::max<unsigned long long>(32, (tot + (unsigned long long)B * (d.P - 1) - 1) / ((unsigned long long)B * (d.P - 1)))) : 0;
+    }
     {  // grid build: workgroups per stream of k_gridcount / k_gridplace — one per chunk of MOR_GC_CHUNK points of the largest cloud the device last reported (+ 25 %), enough to fill the GPU
       uint32_t mxM = 0; for (int s = 0; s < B; ++s) mxM = std::max(mxM, k > 0 ? d.h_info[s].M : (uint32_t)maxn);
       const int want = (int)((mxM * 5ull / 4 + MOR_GC_CHUNK - 1) / MOR_GC_CHUNK);

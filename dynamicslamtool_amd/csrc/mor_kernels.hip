@@ -77,6 +77,49 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
   for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(v, o, 64); if (lane_id() >= o) v += n; }
   return v;
 }
+// Work-proportional share-out of a launch's workgroups over the streams.  The streams of one batch differ a lot (the non-ground cloud of a stream of
+// the bench batch has 5 000 … 57 000 points, 1 300 … 5 400 occupied cells): with the same number of workgroups for every stream a launch ends with the
+// workgroups of its biggest stream walking chunk after chunk while the others have long left — the lane waits for that tail.  Here every workgroup
+// works out, from the streams' work counts (wf(s): chunks of work of stream s, read from what earlier kernels of the frame left on the device — exact,
+// no host estimate), how many workgroups each stream gets — one, plus its share of the spare ones in proportion to its work — and which stream and
+// which of that stream's workgroups it is itself.  Any share is correct (kernels stride over their stream's chunks by `g`); a workgroup beyond the
+// sum of the shares returns false and leaves.  With B a multiple of 8 the streams of XCD group x (s % 8 == x) share out the workgroups with
+// blockIdx % 8 == x among themselves, so a stream's workgroups still meet in one L2 (map_block_local).  Called by all lanes of every wave before
+// any divergence (every wave works it out for itself: a handful of loads and two wave scans, no LDS, no barrier); the results are wave-uniform.
+template <class WF> __device__ __forceinline__ bool map_block_work(const MorDev &d, WF wf, int &s, int &t, int &g) {
+  const int nblk = (int)gridDim.x, lane = lane_id();
+  const bool x8 = (d.B & 7) == 0 && d.xcd_map && (nblk & 7) == 0;
+  const int ng = x8 ? d.B >> 3 : d.B, G = x8 ? nblk >> 3 : nblk, x = x8 ? (int)(blockIdx.x & 7) : 0, r = x8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, stp = x8 ? 8 : 1;
+  if (!d.prop_map || G < ng) {   // same share for every stream (MOR_PROP_MAP=0; or fewer workgroups than streams: then the plain map with what there is)
+    const int per = max(G / max(ng, 1), 1);
+    const int i = r / per; if (i >= ng) return false;
+    s = x + stp * i + d.s0; t = r - i * per; g = per; return true;
+  }
+  long long W = 0;
+  for (int i0 = 0; i0 < ng; i0 += 64) {
+    long long w = i0 + lane < ng ? (long long)wf(x + stp * (i0 + lane) + d.s0) : 0ll;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) w += ((long long)__shfl_xor((int)(w >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)w, o, 64);
+    W += w;
+  }
+  const long long spare = G - ng;
+  int carry = 0;
+  for (int i0 = 0; i0 < ng; i0 += 64) {
+    const int i = i0 + lane;
+    const int gi = i < ng ? 1 + (int)((long long)wf(x + stp * i + d.s0) * spare / (W > 0 ? W : 1ll)) : 0;
+    const int incl = wave_incl_scan(gi);
+    const unsigned long long m = __ballot(i < ng && r < carry + incl);
+    if (m) {
+      const int l = __ffsll((long long)m) - 1;
+      g = __builtin_amdgcn_readfirstlane(__shfl(gi, l, 64));
+      t = __builtin_amdgcn_readfirstlane(r - (carry + __shfl(incl, l, 64) - g));
+      s = __builtin_amdgcn_readfirstlane(x + stp * (i0 + l) + d.s0);
+      return true;
+    }
+    carry += __shfl(incl, 63, 64);
+  }
+  return false;
+}
 // exclusive scan over the 256 threads of a workgroup; *total = sum.  sh: ≥ 5 ints of LDS.
 __device__ __forceinline__ int block_excl_scan(int v, int *sh, int *total) {
   int inc = wave_incl_scan(v);
@@ -727,7 +770,11 @@ template <bool L> __device__ __forceinline__ int gh_scan(int *a, int n, int *sh)
 // two slices thick so that the two-slice look-ahead of a slab stays inside its successor.  rows = exclusive row table
 // (rows[r] = first compact id of row r, rows[nrows] = n_occ); threads 0 … P of the calling workgroup take part; sh: ≥ 40 ints.
 template <bool L> __device__ __forceinline__ void slab_bounds(const MorDev &d, const MorGrid &G, int s, const int *rows, int nocc, int *sh) {
-  const int P = d.P, ny = G.ny, nz = G.nz, j = threadIdx.x;
+  const int ny = G.ny, nz = G.nz, j = threadIdx.x;
+  // slabs of this stream: the launch's width for every stream, or (map_block_work) as many as the stream's cells ask for at slab_T own cells a slab —
+  // a stream of 5 400 cells then gets four times the workgroups of one with 1 300 instead of slabs four times as big
+  const int P = (d.prop_map && d.slab_T > 0) ? max(1, min((nocc + d.slab_T - 1) / d.slab_T, min(MOR_MAXP, max(1, ny / 2)))) : d.P;
+  if (j == 0) d.slab_p[s] = P;
   if (j <= P) {
     int y = j == 0 ? 0 : ny;
     if (j > 0 && j < P) {   // smallest y whose first cell id reaches the j-th share of the cells
@@ -1259,11 +1306,12 @@ __device__ __forceinline__ int cg_lower_bound8(const int *key, int lo, int n, in
 // cell writes its record.  Cells that continue into another wave tile are merged with atomics (min / max / integer
 // add: order-free), their records were initialised by k_gridhash.
 __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
-  int s, bx; map_block(d.B, d.g_box, s, bx);
+  int s, bx, gbx;
+  if (!map_block_work(d, [&](int s_) { return ((int)d.info[s_].M + (MOR_BT / 64) * CB_WTILE - 1) / ((MOR_BT / 64) * CB_WTILE); }, s, bx, gbx)) return;   // work: steps of one workgroup over the stream's cell-ordered points
   const int M = d.info[s].M, lane = lane_id();
   const size_t so = (size_t)s * d.Nmax;
   const float4 *sp = d.sorted + so; const int *sc = d.scell + so;
-  for (int base = (bx * (MOR_BT / 64) + wave_id()) * CB_WTILE; base < M; base += d.g_box * (MOR_BT / 64) * CB_WTILE) {
+  for (int base = (bx * (MOR_BT / 64) + wave_id()) * CB_WTILE; base < M; base += gbx * (MOR_BT / 64) * CB_WTILE) {
     const int j0 = base + 4 * lane;
     int c[4]; float4 p[4];
 #pragma unroll
@@ -1543,16 +1591,18 @@ template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDe
 #define CGS_FCAP (CGS_ARENA / 3)
 template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d, int s, int j, int *l_arena, int *l_wcnt, int *l_n2p);
 template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {
-  int s, j; map_block(d.B, d.P, s, j);
+  int s, j0, gs;
+  if (!map_block_work(d, [&](int s_) { return d.slab_p[s_]; }, s, j0, gs)) return;   // work: the stream's slabs (normally one workgroup each)
   static_assert(CAP == CGS_CAP, "the LDS arena is laid out for CGS_CAP");
   __shared__ int l_arena[CGS_ARENA], l_wcnt[CGS_NW], l_n2, l_last;
-  cg_slab_body<CAP>(d, s, j, l_arena, l_wcnt, &l_n2);
+  const int Ps = d.slab_p[s];
+  for (int j = j0; j < Ps; j += gs) { cg_slab_body<CAP>(d, s, j, l_arena, l_wcnt, &l_n2); __syncthreads(); }
   if (!d.cg_fused) return;
-  if (!stream_last_block(d.tickets + (size_t)s * TK_COUNT + TK_CGFINAL, d.P, &l_last)) return;
+  if (!stream_last_block(d.tickets + (size_t)s * TK_COUNT + TK_CGFINAL, gs, &l_last)) return;
   const int nocc = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
   __shared__ int l_misc[1 + CGS_T / 64], l_sc[MOR_MAXP + 1], l_se[MOR_MAXP + 1];
-  if (threadIdx.x <= d.P) { l_sc[threadIdx.x] = d.slab_c[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; l_se[threadIdx.x] = d.slab_e[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; }
+  if (threadIdx.x <= Ps) { l_sc[threadIdx.x] = d.slab_c[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; l_se[threadIdx.x] = d.slab_e[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; }
   if (nocc <= CGS_FCAP && !d.cg_force_global) {
     int *l_par = l_arena, *l_a = l_arena + CGS_FCAP, *l_b = l_arena + 2 * CGS_FCAP;
     for (int i = threadIdx.x; i < nocc; i += CGS_T) l_par[i] = i;
@@ -1630,7 +1680,7 @@ template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d,
 template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDev &d, int s, int nocc, int *par, int *size, int *mn, int *cidr, int *l_misc, const int *l_sc, const int *l_se) {
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1);
-  const int lane = lane_id(), P = d.P;
+  const int lane = lane_id(), P = d.slab_p[s];
   // ---- merge: (c, local root in its own slab) and, for the look-ahead cells of the previous slab, (c, local root there)
   for (int c = threadIdx.x; c < nocc; c += NT) {
     cg_unite<LDS>(par, c, ld_agent(&d.lroot_a[so + c]));
@@ -1765,7 +1815,7 @@ __global__ __launch_bounds__(CGF_T) void k_cg_final(MorDev d) {
   const int s = blockIdx.x + d.s0, nocc = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
   __shared__ int l_par[CGF_CAP], l_a[CGF_CAP], l_b[CGF_CAP], l_misc[1 + CGF_T / 64], l_sc[MOR_MAXP + 1], l_se[MOR_MAXP + 1];
-  if (threadIdx.x <= d.P) { l_sc[threadIdx.x] = d.slab_c[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; l_se[threadIdx.x] = d.slab_e[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; }
+  if (threadIdx.x <= d.slab_p[s]) { l_sc[threadIdx.x] = d.slab_c[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; l_se[threadIdx.x] = d.slab_e[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; }
   if (nocc <= CGF_CAP && !d.cg_force_global) {          // forest, sizes (then cluster ids), minima: three LDS arrays
     for (int i = threadIdx.x; i < nocc; i += CGF_T) l_par[i] = i;
     __syncthreads();
@@ -2206,7 +2256,8 @@ __device__ __forceinline__ void count_push(bool want, int *cnt, int pr) {
 #define SCF_MINW 8   // ≤ 64 VGPRs: two 1024-thread workgroups per CU (69 VGPRs were one)
 #endif
 __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
-  int s, t0; map_block(d.B, d.g_fast, s, t0);
+  int s, t0, g_fast;
+  if (!map_block_work(d, [&](int s_) { return (d.slot_kc[d.prev][s_].y + SCF_T - 1) / SCF_T; }, s, t0, g_fast)) return;   // work: rounds of one workgroup over ca's cluster points
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, Cp = d.slot_kc[d.prev][s].y;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
@@ -2218,7 +2269,7 @@ __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
   const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + G.cs * 1e-3f;
   const bool e1_local = 2.f * slb < G.cs;
-  for (int base = t0 * SCF_T; base < Cp; base += d.g_fast * SCF_T) {
+  for (int base = t0 * SCF_T; base < Cp; base += g_fast * SCF_T) {
     const int j = base + threadIdx.x;
     bool nearq = false, blockq = false, big = false, counted = false; float best = INFINITY; int pr = -1, target = -1;
     RS_T(f0);
@@ -2445,13 +2496,14 @@ __device__ __forceinline__ void score_block_body(const MorDev &d, const CellIdx 
 // the lists (≈ 1700 and ≈ 900 entries per stream on the headline workload: five chunks) and a workgroup without a chunk leaves before
 // it copies the cell index.  A stream's workgroups share an XCD (its cell tables stay in that L2).
 __global__ __launch_bounds__(SCN_T, SCN_MINW) void k_score_nb(MorDev d) {
-  int s, bx; map_block(d.B, d.g_score, s, bx);
+  int s, bx, g_score;
+  if (!map_block_work(d, [&](int s_) { const unsigned long long v = d.wl_nb[s_]; return ((int)(unsigned)v + SCN_T - 1) / SCN_T + ((int)(v >> 32) + SCN_T - 1) / SCN_T; }, s, bx, g_score)) return;   // work: chunks of the two worklists
   __shared__ unsigned short l_idx[CIDX_CAP];
   const unsigned long long nb = d.wl_nb[s];
   const int cn = ((int)(unsigned)nb + SCN_T - 1) / SCN_T, cb = ((int)(nb >> 32) + SCN_T - 1) / SCN_T;
   if (bx >= cn + cb) return;
   const CellIdx I = cidx_load(d, stream_grid(d, s), s, l_idx);
-  for (int c = bx; c < cn + cb; c += d.g_score) {
+  for (int c = bx; c < cn + cb; c += g_score) {
     if (c < cn) score_near_body(d, I, s, c); else score_block_body(d, I, s, c - cn);
   }
 }
