@@ -61,6 +61,7 @@ struct MorFrameInfo {        // per stream, produced on device
 #define MOR_CGS_OVF 8192   // overflow entries per slab of its candidate-pair lists (beyond them a pair is settled on the spot)
 #define MOR_TR_MAXT 32768  // tracked moving centroids per stream (mo_vec); the reference has no bound — beyond this one the push reports MOR_ERR_CAPACITY
 #define MOR_TR_NB 8       // longest supported window (n_bad)
+#define MOR_KCAP_MAX 16384 // clusters per stream, at most (Kcap = min(max_points / min_cluster_size + 1, this))
 struct MorTrackDev {
   int n_mo, n_corr, n_res, has_cur, K_last, overflow, pad0, pad1;
   int corr_n[MOR_TR_NB], res_n[MOR_TR_NB + 1];
@@ -98,7 +99,6 @@ struct MorDev {
   int sp_g;                  // workgroups per stream of the single-read split (2 … 64)
   int two_pass_split;        // 1 (default): count pass + scatter pass; 0: the single-pass split with decoupled look-back (MOR_SINGLE_PASS_SPLIT)
   int cur, prev, has_prev;   // cluster-array slots of cb and ca (four slots rotate: up to three frames are in flight in the stage pipeline); whether ca exists (:534)
-  int run_tracker;           // filter: advance the tracking loop (first filterCloud of this frame)
   // ---- device arrays (per-stream stride noted)
   const MorStreamArgs *args; // [B]
   const MorStreamArgs *args_src; MorStreamArgs *args_out;   // crop variant with the single-read split: the page-locked host slot k_split reads the arguments from (null: `args` is already filled), and `args` again, writable
@@ -193,14 +193,15 @@ struct MorDev {
   unsigned long long *vox;   // [B][Hcap]
   unsigned char *det;        // [B][Kcap]  detection_results of cb
   // filter stage
-  unsigned char *moving;     // [B][Kcap] + [B] extract-error flags at the end (written by k_track_filter)
+  unsigned *moving;          // [B][Kcap/32 + 2]  k_filter's hand-over inside the launch: a bit per cluster queued for removal, then the ExtractIndices size-check flag and the number of kept cloud points
+  unsigned long long *out_desc;   // [B][tiles_max]  look-back descriptors of the output compaction (call epoch | kept points of the tile)
+  unsigned filter_epoch;     // tag of this filterCloud call (never 0, never repeated): descriptors and the "ready" word of k_filter
   MorTrackDev *tr;           // [B]
   int2 *tr_corr;             // [B][MOR_TR_NB][Kcap]   corrs_vec (query, match), oldest first
   unsigned char *tr_res;     // [B][MOR_TR_NB+1][Kcap] res_vec, oldest first
   unsigned char *tr_lastdet; // [B][Kcap]  detection_results of the previous frame (ca)
   int *tr_match;             // [B][MOR_TR_MAXT+1]  latest filterCloud: number of tracked centroids its loop visited, then the cluster each was matched to, in mo_vec order (the reference's bounding-box markers, :641)
   int moving_confidence, static_confidence; float leave_off, catch_up;
-  int *otile_cnt;            // [B][tiles_max]
   float4 *const *out_ptrs;   // [B] or null
   unsigned long long *dbg;   // [B][16] experiment stamps (MOR_EXP_STAMPS builds only)
   unsigned long long *dbg2;  // [B][MOR_MAXP+2][16] experiment stamps of the slab workgroups, k_gridhash, k_cg_final
@@ -224,7 +225,7 @@ struct MorCellSum { long long a[3], b[3]; };
 enum MorKernelId {
   MK_CLASSIFY, MK_SCATTER, MK_SPLIT, MK_HEADS_COUNT, MK_HEADS_SCATTER, MK_CELLBOXES, MK_RHIST, MK_RSCAN, MK_RSCATTER,
   MK_SCORE_FAST, MK_SCORE_NB, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE,
-  MK_OUT_COUNT, MK_OUT_SCATTER, MK_G2_COV_MID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_GRIDHASH, MK_GRIDCOUNT, MK_GRIDPLACE, MK_CG_SLAB, MK_CG_FINAL, MK_CLUSTERS, MK_COUNT
+  MK_FILTER, MK_G2_COV_MID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_GRIDHASH, MK_GRIDCOUNT, MK_GRIDPLACE, MK_CG_SLAB, MK_CG_FINAL, MK_CLUSTERS, MK_COUNT
 };
 extern const char *const mor_kernel_names[MK_COUNT];
 
@@ -235,7 +236,7 @@ struct MorLaunchTimer;   // engine-owned; records event pairs when enabled
 // small host → device copies on a stream as a one-workgroup kernel (the source is page-locked host memory the device reads directly)
 void mor_launch_copy(void *dst, const void *src_pinned, size_t bytes, hipStream_t st);
 void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer *tm);
-void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part);
+void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);
 int mor_split_blocks_per_cu();
 void mor_timer_begin(MorLaunchTimer *tm, int kernel_id, hipStream_t st);
 void mor_timer_end(MorLaunchTimer *tm, int kernel_id, hipStream_t st);

@@ -123,7 +123,7 @@ struct mor_batch {
   int env_cg_p = 0, env_gc_p = 0;         // tuning knobs from the environment (MOR_CG_P, MOR_GC_P), read once at creation
   bool async = false, pending = false;   // async: push/filter only enqueue; pending: work enqueued since the last wait
   float4 **h_outptrs = nullptr, **d_outptrs = nullptr;   // caller-provided output pointers: pinned ring of MOR_ARGS_RING tables (one per filterCloud in flight), device copy per frame in flight
-  hipEvent_t outptr_ev[MOR_ARGS_RING] = {}; uint64_t n_filters = 0;
+  hipEvent_t outptr_ev[MOR_ARGS_RING] = {}; uint64_t n_filters = 0, n_filter_calls = 0;
   float4 *d_outstage = nullptr;   // [depth][B][Nmax]  asynchronous filterCloud into host memory: the filtered clouds are assembled here and leave by DMA (allocated at the first such call)
   std::vector<uint64_t> last_n;   // points per stream of the latest push
   unsigned char *d_stage = nullptr; size_t stage_stride = 0;   // staging for host-resident input blobs: one area per frame in flight (frame k: area k mod depth), so the copy of frame k + 1 runs beside the kernels of frame k
@@ -173,7 +173,8 @@ static int configure(mor_batch *b) {
   if (p.ground_method == 1 && !(p.gp_leaf > 0.f)) return set_error(MOR_ERR_INVALID, "gp_leaf must be > 0 for the voxel-covariance ground removal");
   d.B = b->B; d.Btot = b->B; d.s0 = 0; d.Nmax = (int)b->Nmax;
   long long mn = std::max<long long>(p.min_cluster_size, 1);
-  d.Kcap = (int)std::min<long long>((long long)b->Nmax / mn + 1, 16384);
+  d.Kcap = (int)std::min<long long>((long long)b->Nmax / mn + 1, MOR_KCAP_MAX);
+  d.Kcap = (d.Kcap + 31) & ~31;   // (a whole number of words of the removal bit mask)
   d.tiles_max = (int)((b->Nmax + MOR_TILE - 1) / MOR_TILE);
   d.trim_x = p.trim_x; d.trim_y = p.trim_y; d.trim_z = p.trim_z; d.gp_limit = p.gp_limit;
   double tol = (double)p.ec_distance_threshold; d.r2 = (float)(tol * tol);   // KdTreeFLANN::radiusSearch: (float)(radius·radius)
@@ -446,7 +447,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = ok && dalloc(b, o.wl, B * N) && dalloc(b, o.wl_nb, B) && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B);
     ok = ok && dalloc(b, o.rs16, B * (size_t)d.rs16_stride) && dalloc(b, o.cx16, B * N);
     if (p->method_choice == 2) ok = ok && dalloc(b, o.vox, B * (size_t)d.Hcap);
-    ok = ok && dalloc(b, o.moving, B * K + B) && hipMemset(o.moving, 0, B * K + B) == hipSuccess && dalloc(b, o.otile_cnt, B * T) && halloc(b, o.h_nout, B) && halloc(b, o.h_noff, B);   // (the size mirrors of the filtered clouds too: the output kernels of consecutive frames need no order among themselves)
+    ok = ok && dalloc(b, o.moving, B * (K / 32 + 2)) && hipMemset(o.moving, 0, B * (K / 32 + 2) * sizeof(unsigned)) == hipSuccess && dalloc(b, o.out_desc, B * T) && hipMemset(o.out_desc, 0, B * T * sizeof(unsigned long long)) == hipSuccess && halloc(b, o.h_nout, B) && halloc(b, o.h_noff, B);   // (the size mirrors of the filtered clouds too: the output kernels of consecutive frames need no order among themselves)
     ok = ok && dalloc(b, o.zmin_i, B) && dalloc(b, o.zmax_i, B) && hipMemsetD32((hipDeviceptr_t)o.zmin_i, 0x7fffffff, B) == hipSuccess && hipMemsetD32((hipDeviceptr_t)o.zmax_i, (int)0x80000000, B) == hipSuccess && dalloc(b, o.zorg, B) && dalloc(b, o.zbase, B) && hipMemset(o.zbase, 0, B * sizeof(int)) == hipSuccess && dalloc(b, o.mode_bin, B);
     if (ok) ok = hipMemcpy(o.zorg, z0.data(), B * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     if (d.gmode == 1) {   // voxel-covariance ground variant: the VoxelGrid sort and the per-voxel results
@@ -531,7 +532,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     d.cg_fused = (maxocc * 11ull / 10 <= MOR_CGS_FCAP && !getenv("MOR_CG_UNFUSED")) ? 1 : 0;   // (a stream beyond it runs the merge on global-memory arrays: correct, slow — hence the separate kernel when that is foreseeable)
     if (!getenv("MOR_GH_TIER")) d.gh_tier = maxocc * 5ull / 4 > 6144 ? (maxocc * 5ull / 4 > 12288 ? 2 : 1) : 0;   // table tier k_gridhash starts with (a stream whose table overflows moves up by itself)
   }
-  d.cur = (int)(k % b->n_slots); d.prev = (int)((k + b->n_slots - 1) % b->n_slots); d.has_prev = k > 0; d.out_ptrs = nullptr; d.run_tracker = 0; d.frame_no = (int)k;
+  d.cur = (int)(k % b->n_slots); d.prev = (int)((k + b->n_slots - 1) % b->n_slots); d.has_prev = k > 0; d.out_ptrs = nullptr; d.frame_no = (int)k;
   {  // workgroups for the cloud-sized kernels: 1.25 × the largest cloud / cluster set the device last reported
     uint32_t mx = 0;
     for (int s = 0; s < B; ++s) mx = std::max(mx, std::max(d.h_info[s].M, d.h_info[s].C));
@@ -594,8 +595,9 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
   HIP_TRY(hipSetDevice(b->device));
   MorDev d = b->d; const int B = d.B;
   const uint64_t k = b->frame - 1;
-  d.run_tracker = 1;   // the tracking loop of filterCloud (:630-671) runs on the device — on EVERY call, as in the reference: a second
-                       // filterCloud on the same frame walks mo_vec again and moves the confidences again
+  // (the tracking loop of filterCloud (:630-671) runs on the device — on EVERY call, as in the reference: a second filterCloud on the same
+  //  frame walks mo_vec again and moves the confidences again)
+  d.filter_epoch = (unsigned)(++b->n_filter_calls); if (d.filter_epoch == 0) d.filter_epoch = (unsigned)(++b->n_filter_calls);
   b->filtered = true;
   d.out_ptrs = nullptr;
   hipStream_t fs = b->lane_stream(k);   // behind the frame's push
@@ -615,13 +617,12 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
     d.out_ptrs = dp;
   }
   if (!b->async) HIP_TRY(hipEventRecord(b->ev[2], fs));
-  mor_launch_filter(d, fs, &b->timer, 1);
-  HIP_TRY(hipEventRecord(b->ev_track[k % MOR_MAX_SLOTS], fs)); b->last_track = &b->ev_track[k % MOR_MAX_SLOTS]; b->last_track_st = fs;   // the tracking state is settled: the next frame's tracking step may follow
-
   if (host_async && k >= b->pipe_depth && b->d2h_used[(k - b->pipe_depth) % MOR_MAX_SLOTS]) {   // the output staging area of this frame's copy has been carried out
     HIP_TRY(hipStreamWaitEvent(fs, b->ev_d2h[(k - b->pipe_depth) % MOR_MAX_SLOTS], 0));
   }
-  mor_launch_filter(d, fs, &b->timer, 2);
+  if (host_async && b->d2h_used[k % MOR_MAX_SLOTS]) HIP_TRY(hipStreamWaitEvent(fs, b->ev_d2h[k % MOR_MAX_SLOTS], 0));   // a second filterCloud on this very frame rewrites its staging area: after the first call's copies
+  mor_launch_filter(d, fs, &b->timer);
+  HIP_TRY(hipEventRecord(b->ev_track[k % MOR_MAX_SLOTS], fs)); b->last_track = &b->ev_track[k % MOR_MAX_SLOTS]; b->last_track_st = fs;   // the tracking state is settled: the next frame's tracking step may follow
   if (host_async) HIP_TRY(hipEventRecord(b->ev_out[k % MOR_MAX_SLOTS], fs));   // (the device → host copies below follow it)
   if (host_async) {   // on the device → host copy stream, behind the output kernels
     hipStream_t cs = b->s_d2h_[0];

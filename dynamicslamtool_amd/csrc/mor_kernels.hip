@@ -29,7 +29,7 @@
 const char *const mor_kernel_names[MK_COUNT] = {   // in MorKernelId order: "k_" + name = the __global__ function
     "classify", "scatter", "split", "heads_count", "heads_scatter", "cellboxes", "rhist", "rscan", "rscatter",
     "score_fast", "score_nb", "score_pde", "vox_clear", "vox_insert", "vox_probe",
-    "out_count", "out_scatter", "g2_cov_mid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridcount", "gridplace", "cg_slab", "cg_final", "clusters"};
+    "filter", "g2_cov_mid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "gridhash", "gridcount", "gridplace", "cg_slab", "cg_final", "clusters"};
 
 #ifdef MOR_EXP_STAMPS
 #define RS_T(v) const unsigned long long v = wall_clock64()
@@ -192,7 +192,7 @@ __device__ __forceinline__ bool stream_last_block(int *ticket, int n_blocks, int
   __syncthreads();
   return *l_flag != 0;
 }
-enum { TK_TRACK = 0, TK_CGFINAL = 1, TK_PAIRS = 2, TK_SPLIT = 3, TK_COUNT = 8 };   // ticket words per stream
+enum { TK_TRACK = 0, TK_CGFINAL = 1, TK_PAIRS = 2, TK_SPLIT = 3, TK_OUT = 4, TK_FREADY = 5, TK_COUNT = 8 };   // ticket words per stream
 
 // fromPCLPointCloud2 (:523): named float32 fields of a blob record → (x,y,z,intensity)
 __device__ __forceinline__ float ld_f32_bytes(const char *p) {   // a float32 field at any byte address
@@ -2272,6 +2272,9 @@ __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
   for (int base = t0 * SCF_T; base < Cp; base += g_fast * SCF_T) {
     const int j = base + threadIdx.x;
     bool nearq = false, blockq = false, big = false, counted = false; float best = INFINITY; int pr = -1, target = -1;
+#ifdef MOR_EXP_ROUNDS
+    int exp_rounds = 0, exp_cell = 0; bool exp_found = false;
+#endif
     RS_T(f0);
 #ifdef MOR_EXP_STAMPS
     unsigned long long f1 = f0, f2 = f0;
@@ -2293,6 +2296,9 @@ __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
         int budget = 64;   // a big own cell that shows no close point among 64 evenly spread samples goes to the wave tier
         const bool reach = box_dist2(q, tlo, thi) < d.pde_ub;   // farther than √ub from the whole matched cluster: never counted
         if (reach && c >= 0 && cid == target) { scan_sampled(sp, b0, e0, q, lbn, best, budget); big = best > d.pde_lb && e0 - b0 > 64; }
+#ifdef MOR_EXP_ROUNDS
+        exp_rounds = (64 - budget) / 8; exp_found = best <= d.pde_lb; exp_cell = e0 - b0;
+#endif
         if (reach && best > d.pde_lb && !big) {
           if (!e1_local) big = true;   // √lb reaches beyond the adjacent half-cells in this configuration: wave tier
           else if (best < d.pde_ub) {
@@ -2322,6 +2328,14 @@ __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
       }
     }
     count_push(counted, d.pair_cnt + ko, pr);
+#ifdef MOR_EXP_ROUNDS
+    {  // experiment: rounds of the sampled scan per lane and per wave (the wave lives as long as its slowest lane)
+      int mx = exp_rounds, sum = exp_rounds, nq_ = j < Cp ? 1 : 0, nf1 = (exp_found && exp_rounds <= 1) ? 1 : 0, nbig = exp_cell > 64 ? 1 : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { mx = max(mx, __shfl_xor(mx, o, 64)); sum += __shfl_xor(sum, o, 64); nq_ += __shfl_xor(nq_, o, 64); nf1 += __shfl_xor(nf1, o, 64); nbig += __shfl_xor(nbig, o, 64); }
+      if (lane_id() == 0 && nq_) { unsigned long long *g = d.dbg + (size_t)s * 16; atomicAdd(&g[0], (unsigned long long)nq_); atomicAdd(&g[1], (unsigned long long)sum); atomicAdd(&g[2], 1ull); atomicAdd(&g[3], (unsigned long long)mx); atomicAdd(&g[4 + min(mx, 8)], 1ull); atomicAdd(&g[13], (unsigned long long)nf1); atomicAdd(&g[14], (unsigned long long)nbig); }
+    }
+#endif
 #ifdef MOR_EXP_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     { const int n_near = __popcll(__ballot(nearq)), n_block = __popcll(__ballot(blockq)), n_big = __popcll(__ballot(big));
@@ -2729,76 +2743,6 @@ template <int NT> __device__ __forceinline__ void decide_body(const MorDev &d, i
     if (threadIdx.x == 0) {
       MorFrameLog &L = d.h_log[(size_t)(d.frame_no % MOR_LOG_CAP) * d.Btot + s];
       L.frame = d.frame_no; L.K = K; L.C = (int)f.C; L.n_pairs = np; L.cnt_sum = l_sum[0]; L.det_sum = l_sum[1]; L.flags = (int)d.info[s].flags;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------ F1: filtered cloud (:673-687)
-// keep = cloud points whose cluster is not flagged moving (ExtractIndices negative, set semantics;
-// the per-stream error flag reproduces "more indices than points ⇒ empty output"), then ground.
-__device__ __forceinline__ bool out_keep(const MorDev &d, int s, size_t so, int i) {
-  if (d.moving[(size_t)d.Btot * d.Kcap + s]) return false;
-  int cid = d.pcid[so + i];   // cluster id per cloud point (written by k_clusters)
-  return !(cid >= 0 && d.moving[(size_t)s * d.Kcap + cid]);
-}
-__global__ __launch_bounds__(MOR_BT) void k_out_count(MorDev d) {
-  int s, t0; map_block(d.B, d.tiles_m, s, t0);
-  const int M = d.info[s].M;
-  const size_t so = (size_t)s * d.Nmax;
-  __shared__ int sh[4];
-  for (int t = t0; t * MOR_TILE < M; t += d.tiles_m) {
-    int base = t * MOR_TILE + wave_id() * 512, c = 0;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) { int i = base + it * 64 + lane_id(); c += __popcll(__ballot(i < M && out_keep(d, s, so, i))); }
-    if (lane_id() == 0) sh[wave_id()] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) d.otile_cnt[(size_t)s * d.tiles_max + t] = sh[0] + sh[1] + sh[2] + sh[3];
-    __syncthreads();
-  }
-}
-// filterCloud's output (:673-684) = [cloud minus moving clusters, original order] ++ [ground points].  The ground points
-// were written to their final place by the split kernel (from slot Nmax of the stream's 2·Nmax-slot `ground` buffer), so the
-// result is assembled in place: the kept cloud points go right-aligned in front of them and the result starts at slot
-// Nmax − n_keep —
-// the bulk of the frame (the ground, ≈ 90 % of a LiDAR sweep) is not copied again.  With caller-provided device
-// pointers both parts are copied out: workgroups [0, tiles_m) per stream the kept cloud points (grid-stride over the
-// cloud's tiles), workgroups [tiles_m, tiles_m + tiles) the ground points.
-__global__ __launch_bounds__(MOR_BT) void k_out_scatter(MorDev d) {
-  int s, t2; map_block(d.B, d.tiles_m + (d.out_ptrs ? d.tiles : 0), s, t2);
-  const size_t so = (size_t)s * d.Nmax;
-  float4 *og = d.ground + 2 * so;
-  const int M = d.info[s].M;
-  __shared__ int sh[12];
-  const int nto = (M + MOR_TILE - 1) / MOR_TILE;
-  int n_keep = 0;
-  {   // kept points in total: every workgroup sums the per-tile counts of k_out_count itself
-    int pre; wg_prefix_total(d.otile_cnt + (size_t)s * d.tiles_max, 1, 0, nto, sh, pre, n_keep);
-    if (t2 == 0 && threadIdx.x == 0) { d.info[s].n_keep = n_keep; d.h_nout[s] = (unsigned long long)n_keep + d.info[s].G; d.h_noff[s] = d.Nmax - n_keep; }
-  }
-  if (t2 == 0 && threadIdx.x == 0) { d.h_log[(size_t)(d.frame_no % MOR_LOG_CAP) * d.Btot + s].n_out = (unsigned long long)n_keep + d.info[s].G; mor_publish_err(d, s); }
-  if (t2 >= d.tiles_m) {
-    int t = t2 - d.tiles_m, G = d.info[s].G, nk = n_keep, base = t * MOR_TILE;
-    float4 *out = d.out_ptrs[s];
-    for (int i = base + threadIdx.x; i < min(base + MOR_TILE, G); i += MOR_BT) out[nk + i] = og[d.Nmax + i];
-    return;
-  }
-  float4 *dst = d.out_ptrs ? d.out_ptrs[s] : og + (d.Nmax - n_keep);
-  for (int t = t2; t * MOR_TILE < M; t += d.tiles_m) {
-    int base = t * MOR_TILE + wave_id() * 512, c = 0;
-    unsigned long long mk[8];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) { int i = base + it * 64 + lane_id(); mk[it] = __ballot(i < M && out_keep(d, s, so, i)); c += __popcll(mk[it]); }
-    if (lane_id() == 0) sh[wave_id()] = c;
-    __syncthreads();
-    int r;
-    { int tot; wg_prefix_total(d.otile_cnt + (size_t)s * d.tiles_max, 1, t, nto, sh + 4, r, tot); }
-    for (int w = 0; w < wave_id(); ++w) r += sh[w];
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      int i = base + it * 64 + lane_id();
-      if ((mk[it] >> lane_id()) & 1ull) dst[r + __popcll(mk[it] & lanemask_lt())] = d.cloud[so + i];
-      r += __popcll(mk[it]);
     }
   }
 }
@@ -3333,33 +3277,47 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
   tr_store_head(gt, t, lane);
   if (lane == 0) mor_publish_err(d, s);
 }
-// filterCloud's loop over mo_vec (:630-671): nearest current centroid of every tracked one (squared fp32 distance, ties →
-// lowest index), its whole cluster queued for removal before any test, confidence bookkeeping.  Writes the per-cluster
-// removal flags and the ExtractIndices size-check flag the output kernels read.
-__global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
-  const int s = blockIdx.x + d.s0, K = d.info[s].K, lane = threadIdx.x;
+// filterCloud (:613-696) in ONE launch (round 3: k_track_filter | k_out_count | k_out_scatter).
+// (1) The loop over mo_vec (:630-671): nearest current centroid of every tracked one (squared fp32 distance, ties → lowest index), its whole
+//     cluster queued for removal before any test, confidence bookkeeping.  One workgroup of the stream does it — the one that draws ticket 0,
+//     so it is running and waits for nobody — and hands over, with agent-scope stores: the removal flags as a bit per cluster, the
+//     ExtractIndices size-check flag and the number of kept cloud points, n_keep = M − Σ sizes of the flagged clusters (known without a
+//     counting pass over the points: a cluster's size is the number of cloud points that carry its label).  Then it raises the stream's
+//     "ready" word to this call's epoch; the stream's other workgroups poll it.
+// (2) The output (:673-687) = [cloud minus moving clusters, original order] ++ [ground points].  The ground points were written to their final
+//     place by the split kernel (from slot Nmax of the stream's 2·Nmax-slot `ground` buffer), so the result is assembled in place: the kept
+//     cloud points go right-aligned in front of them, the result starts at slot Nmax − n_keep, and the bulk of the frame (the ground, ≈ 90 %
+//     of a LiDAR sweep) is not copied again.  ONE pass over the labels: tiles of 2048 cloud points are handed out by ticket (a tile's
+//     predecessors are then owned by workgroups that are already running), a tile publishes its kept count in a descriptor tagged with the
+//     epoch and adds up the descriptors of the tiles below it (decoupled look-back; no count pass, no scan).  With caller-provided device
+//     pointers both parts are copied out: the workgroups [tiles_m, tiles_m + tiles) of a stream copy the ground points behind the kept ones.
+// The keep test is ExtractIndices' negative set semantics; the size-check flag reproduces "more indices than points ⇒ empty output" (:676-678).
+#define FLT_T MOR_BT
+__device__ __forceinline__ void track_filter_body(const MorDev &d, int s, unsigned *l_mov /* Kcap / 32 words */) {
+  const int K = d.info[s].K, tid = threadIdx.x, lane = tid & 63;
+  const bool w0 = tid < 64;   // the loop itself is the work of one wave (as a kernel of its own it was a 64-thread workgroup); the other waves help with the tables and keep the barriers
   const size_t ko = (size_t)s * d.Kcap;
   const int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1);
   __shared__ MorTrackHead t;
   __shared__ float4 l_cen[TRK];
   __shared__ int l_size[TRK];
-  __shared__ unsigned char l_det[TRK], l_mov[TRK];
+  __shared__ unsigned char l_det[TRK];
+  __shared__ unsigned long long l_tot;
   MorTrackDev &gt = d.tr[s];   // the tracked centroids are read once and written once (compacted in place): straight from / to global memory
-  tr_load_head(gt, t, lane);
+  if (w0) { const int *gs = reinterpret_cast<const int *>(&gt); int *ls = reinterpret_cast<int *>(&t); for (int i = lane; i < (int)(sizeof(MorTrackHead) / sizeof(int)); i += 64) ls[i] = gs[i]; }
   const bool fits = K <= TRK;
-  unsigned char *moving = d.moving + ko;
-  for (int k = lane; k < K; k += 64) {
-    if (fits) { l_cen[k] = d.centroid[d.cur][ko + k]; l_size[k] = off[k + 1] - off[k]; l_det[k] = d.det[ko + k]; l_mov[k] = 0; }
-    else moving[k] = 0;
-  }
+  for (int k = tid; k < (d.Kcap + 31) / 32; k += FLT_T) l_mov[k] = 0u;
+  if (fits) for (int k = tid; k < K; k += FLT_T) { l_cen[k] = d.centroid[d.cur][ko + k]; l_size[k] = off[k + 1] - off[k]; l_det[k] = d.det[ko + k]; }
+  if (tid == 0) l_tot = 0ull;
   __syncthreads();
   // Every tracked centroid is handled independently of the others (its nearest cluster, its confidence, its own new
-  // position); erasing only compacts the vector, order kept.  So: one lane per track, 64 tracks per round, survivors
-  // compacted in place with a ballot prefix (reads of a round happen before its writes, and writes never pass reads).
-  unsigned long long total = 0;
-  const int n_mo = t.n_mo; int n_keep = 0;
-  if (K > 0) {
-    for (int i0 = 0; i0 < n_mo; i0 += 256) {   // four tracks per lane and round trip (a stream of the bench reaches 15 000 tracked centroids on long runs)
+  // position); erasing only compacts the vector, order kept.  So: one lane per track, four tracks per lane and round trip (a stream
+  // of the bench reaches 15 000 tracked centroids on long runs), survivors compacted in place with a ballot prefix (reads of a round
+  // happen before its writes, and writes never pass reads).
+  const int n_mo = t.n_mo;
+  if (w0 && K > 0) {
+    unsigned long long total = 0; int n_keep = 0;
+    for (int i0 = 0; i0 < n_mo; i0 += 256) {
       float c0[4], c1[4], c2[4]; int conf[4], mx[4]; bool keep[4]; unsigned long long mine = 0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) { const int i = min(i0 + 64 * u + lane, n_mo - 1); c0[u] = gt.mo_c[i][0]; c1[u] = gt.mo_c[i][1]; c2[u] = gt.mo_c[i][2]; conf[u] = gt.mo_conf[i]; mx[u] = gt.mo_max[i]; }
@@ -3369,7 +3327,7 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
         if (i0 + 64 * u + lane < n_mo) {
           float bd = INFINITY; int bi = 0;
           for (int k = 0; k < K; ++k) { const float4 c = fits ? l_cen[k] : d.centroid[d.cur][ko + k]; float dd = sqdist(c0[u], c1[u], c2[u], c.x, c.y, c.z); if (dd < bd) { bd = dd; bi = k; } }   // ties → lowest index
-          if (fits) l_mov[bi] = 1; else moving[bi] = 1;                      // whole cluster queued for removal before any test (:644-648)
+          atomicOr(&l_mov[bi >> 5], 1u << (bi & 31));                        // whole cluster queued for removal before any test (:644-648)
           d.tr_match[(size_t)s * (MOR_TR_MAXT + 1) + 1 + i0 + 64 * u + lane] = bi;   // (the marker the reference publishes for this tracked centroid, :641)
           mine += (unsigned long long)(fits ? l_size[bi] : off[bi + 1] - off[bi]);
           if (!(fits ? l_det[bi] : d.det[ko + bi]) || bd > d.leave_off) {    // squared vs un-squared: reference quirk kept (:650)
@@ -3383,25 +3341,137 @@ __global__ __launch_bounds__(64) void k_track_filter(MorDev d) {
         }
       }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+      for (int o = 32; o > 0; o >>= 1) mine += ((unsigned long long)(unsigned)__shfl_xor((int)(mine >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)mine, o, 64);
       total += mine;
-      __syncthreads();   // (all reads of this round are done: survivors are compacted in place, order kept)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (all reads of this round are done — one wave: no barrier needed; survivors are compacted in place, order kept)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const unsigned long long km = __ballot(keep[u]);
         if (keep[u]) { const int o = n_keep + __popcll(km & lanemask_lt()); gt.mo_c[o][0] = c0[u]; gt.mo_c[o][1] = c1[u]; gt.mo_c[o][2] = c2[u]; gt.mo_conf[o] = conf[u]; gt.mo_max[o] = mx[u]; }
         n_keep += __popcll(km);
       }
-      __syncthreads();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (lane == 0) t.n_mo = n_keep;
+    if (lane == 0) { t.n_mo = n_keep; l_tot = total; }
   }
   __syncthreads();
-  if (fits) for (int k = lane; k < K; k += 64) moving[k] = l_mov[k];
-  if (lane == 0) d.moving[(size_t)d.Btot * d.Kcap + s] = total > (unsigned long long)d.info[s].M;   // ExtractIndices: more indices than points ⇒ error, empty output
-  if (lane == 0) d.h_log[(size_t)(d.frame_no % MOR_LOG_CAP) * d.Btot + s].n_mo_filter = t.n_mo;
-  if (lane == 0) d.tr_match[(size_t)s * (MOR_TR_MAXT + 1)] = K > 0 ? n_mo : 0;
-  tr_store_head(gt, t, lane);
+  // ---- hand-over: removal bits, size-check flag (ExtractIndices: more indices than points ⇒ error, empty output), kept cloud points
+  const unsigned M = d.info[s].M;
+  const bool xerr = l_tot > (unsigned long long)M;
+  unsigned removed = 0;
+  for (int k = tid; k < K; k += FLT_T) if ((l_mov[k >> 5] >> (k & 31)) & 1u) removed += (unsigned)(fits ? l_size[k] : off[k + 1] - off[k]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) removed += (unsigned)__shfl_xor((int)removed, o, 64);
+  __shared__ unsigned l_rem[FLT_T / 64];
+  if (lane == 0) l_rem[tid >> 6] = removed;
+  __syncthreads();
+  unsigned *gm = d.moving + (size_t)s * (d.Kcap / 32 + 2);
+  for (int k = tid; k < (K + 31) / 32; k += FLT_T) st_agent(reinterpret_cast<int *>(gm + k), (int)l_mov[k]);
+  if (tid == 0) {
+    unsigned rem = 0; for (int w = 0; w < FLT_T / 64; ++w) rem += l_rem[w];
+    const unsigned n_keep = xerr ? 0u : M - rem;
+    st_agent(reinterpret_cast<int *>(gm + d.Kcap / 32), xerr ? 1 : 0);
+    st_agent(reinterpret_cast<int *>(gm + d.Kcap / 32 + 1), (int)n_keep);
+    d.info[s].n_keep = n_keep; d.h_nout[s] = (unsigned long long)n_keep + d.info[s].G; d.h_noff[s] = d.Nmax - (int)n_keep;
+    MorFrameLog &L = d.h_log[(size_t)(d.frame_no % MOR_LOG_CAP) * d.Btot + s];
+    L.n_mo_filter = t.n_mo; L.n_out = (unsigned long long)n_keep + d.info[s].G;
+    d.tr_match[(size_t)s * (MOR_TR_MAXT + 1)] = K > 0 ? n_mo : 0;
+    mor_publish_err(d, s);
+  }
+  if (w0) { int *gs = reinterpret_cast<int *>(&gt); const int *ls = reinterpret_cast<const int *>(&t); for (int i = lane; i < (int)(sizeof(MorTrackHead) / sizeof(int)); i += 64) gs[i] = ls[i]; }
+}
+__global__ __launch_bounds__(FLT_T) void k_filter(MorDev d) {
+  int s, t2; map_block(d.B, d.tiles_m + (d.out_ptrs ? d.tiles : 0), s, t2);
+  const size_t so = (size_t)s * d.Nmax;
+  float4 *og = d.ground + 2 * so;
+  __shared__ unsigned l_mov[MOR_KCAP_MAX / 32];
+  __shared__ int l_ex[4], sh[4];
+  const unsigned epoch = d.filter_epoch;
+  int *tk = d.tickets + (size_t)s * TK_COUNT + TK_OUT, *ready = d.tickets + (size_t)s * TK_COUNT + TK_FREADY;
+  const bool ground_wg = t2 >= d.tiles_m;
+  const int M = d.info[s].M, nto = (M + MOR_TILE - 1) / MOR_TILE, tk_total = nto + d.tiles_m;   // every cloud workgroup draws one ticket beyond its last tile
+  int t = 0;
+  if (!ground_wg) {
+    if (threadIdx.x == 0) { const int v = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); l_ex[0] = v; if (v + 1 == tk_total) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __syncthreads();
+    t = __builtin_amdgcn_readfirstlane(l_ex[0]);
+  }
+  if (!ground_wg && t == 0) {   // the first to arrive runs the loop over mo_vec and hands its results to the others
+    track_filter_body(d, s, l_mov);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(ready, (int)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (threadIdx.x == 0) {
+      unsigned spins = 0;
+      while ((unsigned)ld_agent(ready) != epoch) { if (++spins > SPLIT_SPIN_LIMIT) { mor_raise(d, s, 64u); break; } __builtin_amdgcn_s_sleep(2); }
+    }
+    __syncthreads();
+  }
+  const unsigned *gm = d.moving + (size_t)s * (d.Kcap / 32 + 2);
+  const int xerr = ld_agent(reinterpret_cast<const int *>(gm + d.Kcap / 32)), n_keep = ld_agent(reinterpret_cast<const int *>(gm + d.Kcap / 32 + 1));
+  if (ground_wg) {
+    const int tg = t2 - d.tiles_m, G = d.info[s].G, base = tg * MOR_TILE;
+    float4 *out = d.out_ptrs[s];
+    for (int i = base + threadIdx.x; i < min(base + MOR_TILE, G); i += FLT_T) out[n_keep + i] = og[d.Nmax + i];
+    return;
+  }
+  if (t >= nto) return;
+  const int K = d.info[s].K;
+  if (t != 0) { for (int k = threadIdx.x; k < (K + 31) / 32; k += FLT_T) l_mov[k] = (unsigned)ld_agent(reinterpret_cast<const int *>(gm + k)); }   // (the tracking workgroup still holds the bits in its LDS)
+  __syncthreads();
+  float4 *dst = d.out_ptrs ? d.out_ptrs[s] : og + (d.Nmax - n_keep);
+  unsigned long long *desc = d.out_desc + (size_t)s * d.tiles_max;
+  int t_prev = -1, ex = 0;   // this workgroup's previous tile and the kept points up to and including it
+  while (t < nto) {
+    const int base = t * MOR_TILE + wave_id() * 512; int c = 0;
+    unsigned long long mk[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int i = base + it * 64 + lane_id();
+      bool keep = false;
+      if (i < M && !xerr) { const int cid = d.pcid[so + i]; keep = !(cid >= 0 && ((l_mov[cid >> 5] >> (cid & 31)) & 1u)); }   // cluster id per cloud point (written by k_clusters)
+      mk[it] = __ballot(keep); c += __popcll(mk[it]);
+    }
+    if (lane_id() == 0) sh[wave_id()] = c;
+    __syncthreads();
+    const int tot = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(desc + t, ((unsigned long long)epoch << 32) | (unsigned long long)(unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int v = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next tile of this workgroup (its loads come after the look-back: tiles are short)
+      l_ex[1] = v; if (v + 1 == tk_total) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wave_id() == 0) {   // look-back over the tiles between this workgroup's previous tile and this one
+      int an = 0;
+      for (int hi = t - 1; hi > t_prev; hi -= 64) {
+        const int u = hi - lane_id();
+        if (u > t_prev) {
+          unsigned spins = 0;
+          for (;;) {
+            const unsigned long long v = ld_agent64(&desc[u]);
+            if ((unsigned)(v >> 32) == epoch) { an += (int)(unsigned)v; break; }
+            if (++spins > SPLIT_SPIN_LIMIT) { mor_raise(d, s, 64u); break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) an += __shfl_xor(an, o, 64);
+      if (lane_id() == 0) l_ex[2] = ex + an;
+    }
+    __syncthreads();
+    int r = l_ex[2];
+    ex = r + tot; t_prev = t;
+    for (int w = 0; w < wave_id(); ++w) r += sh[w];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int i = base + it * 64 + lane_id();
+      if ((mk[it] >> lane_id()) & 1ull) dst[r + __popcll(mk[it] & lanemask_lt())] = d.cloud[so + i];
+      r += __popcll(mk[it]);
+    }
+    t = __builtin_amdgcn_readfirstlane(l_ex[1]);
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------ launch sequences
@@ -3526,14 +3596,8 @@ void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer
   }
 }
 
-void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part) {   // part 1: the tracking loop (the next frame's tracking step waits for this only); part 2: the output
-  const dim3 gM(d.B * d.tiles_m), gB(d.B), gT2(d.B * (d.tiles_m + (d.out_ptrs ? d.tiles : 0)));
-  if (part == 1) {   // the loop over mo_vec (:630-671): on EVERY filterCloud call, as in the reference — a second call on the same frame walks the tracks again
-    MOR_LAUNCH_T(MK_TRACK_FILTER, k_track_filter, gB, 64, d);
-    return;
-  }
-  MOR_LAUNCH(MK_OUT_COUNT, k_out_count, gM, d);
-  MOR_LAUNCH(MK_OUT_SCATTER, k_out_scatter, gT2, d);
+void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // the loop over mo_vec (:630-671, on EVERY filterCloud call, as in the reference — a second call on the same frame walks the tracks again) and the output, one launch
+  MOR_LAUNCH_T(MK_FILTER, k_filter, dim3(d.B * (d.tiles_m + (d.out_ptrs ? d.tiles : 0))), FLT_T, d);
 }
 
 // A few KB from page-locked host memory into device memory, on the stream, by one workgroup (bytes: a multiple of 4)

@@ -14,6 +14,8 @@ if os.environ.get("PIN_NODE"):   # experiment: run (and allocate page-locked mem
 import numpy as np
 import bench
 from dynamicslamtool_amd import engine, kitti_params, synth, shard
+if not os.environ.get("PIN_NODE"):
+    engine.bind_thread_to_device_node(0)   # the enqueueing thread next to its GPU, as bench.py does
 a = sys.argv[1:]
 tag = a[0] if a and not a[0].startswith("--") else "run"
 def opt(name, default):
