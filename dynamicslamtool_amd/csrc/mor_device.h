@@ -193,9 +193,9 @@ struct MorDev {
   unsigned long long *vox;   // [B][Hcap]
   unsigned char *det;        // [B][Kcap]  detection_results of cb
   // filter stage
-  unsigned *moving;          // [B][Kcap/32 + 2]  k_filter's hand-over inside the launch: a bit per cluster queued for removal, then the ExtractIndices size-check flag and the number of kept cloud points
+  unsigned *moving;          // [B][Kcap/32 + 2]  k_track_filter → k_out: a bit per cluster queued for removal, then the ExtractIndices size-check flag and the number of kept cloud points
   unsigned long long *out_desc;   // [B][tiles_max]  look-back descriptors of the output compaction (call epoch | kept points of the tile)
-  unsigned filter_epoch;     // tag of this filterCloud call (never 0, never repeated): descriptors and the "ready" word of k_filter
+  unsigned filter_epoch;     // tag of this filterCloud call (never 0, never repeated): tag of k_out's look-back descriptors
   MorTrackDev *tr;           // [B]
   int2 *tr_corr;             // [B][MOR_TR_NB][Kcap]   corrs_vec (query, match), oldest first
   unsigned char *tr_res;     // [B][MOR_TR_NB+1][Kcap] res_vec, oldest first
@@ -225,7 +225,7 @@ struct MorCellSum { long long a[3], b[3]; };
 enum MorKernelId {
   MK_CLASSIFY, MK_SCATTER, MK_SPLIT, MK_HEADS_COUNT, MK_HEADS_SCATTER, MK_CELLBOXES, MK_RHIST, MK_RSCAN, MK_RSCATTER,
   MK_SCORE_FAST, MK_SCORE_NB, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE,
-  MK_FILTER, MK_G2_COV_MID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_GRIDHASH, MK_GRIDCOUNT, MK_GRIDPLACE, MK_CG_SLAB, MK_CG_FINAL, MK_CLUSTERS, MK_COUNT
+  MK_OUT, MK_G2_COV_MID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_GRIDHASH, MK_GRIDCOUNT, MK_GRIDPLACE, MK_CG_SLAB, MK_CG_FINAL, MK_CLUSTERS, MK_COUNT
 };
 extern const char *const mor_kernel_names[MK_COUNT];
 
@@ -236,7 +236,7 @@ struct MorLaunchTimer;   // engine-owned; records event pairs when enabled
 // small host → device copies on a stream as a one-workgroup kernel (the source is page-locked host memory the device reads directly)
 void mor_launch_copy(void *dst, const void *src_pinned, size_t bytes, hipStream_t st);
 void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer *tm);
-void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm);
+void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part);
 int mor_split_blocks_per_cu();
 void mor_timer_begin(MorLaunchTimer *tm, int kernel_id, hipStream_t st);
 void mor_timer_end(MorLaunchTimer *tm, int kernel_id, hipStream_t st);

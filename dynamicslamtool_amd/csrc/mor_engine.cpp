@@ -621,8 +621,9 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
     HIP_TRY(hipStreamWaitEvent(fs, b->ev_d2h[(k - b->pipe_depth) % MOR_MAX_SLOTS], 0));
   }
   if (host_async && b->d2h_used[k % MOR_MAX_SLOTS]) HIP_TRY(hipStreamWaitEvent(fs, b->ev_d2h[k % MOR_MAX_SLOTS], 0));   // a second filterCloud on this very frame rewrites its staging area: after the first call's copies
-  mor_launch_filter(d, fs, &b->timer);
+  mor_launch_filter(d, fs, &b->timer, 1);
   HIP_TRY(hipEventRecord(b->ev_track[k % MOR_MAX_SLOTS], fs)); b->last_track = &b->ev_track[k % MOR_MAX_SLOTS]; b->last_track_st = fs;   // the tracking state is settled: the next frame's tracking step may follow
+  mor_launch_filter(d, fs, &b->timer, 2);
   if (host_async) HIP_TRY(hipEventRecord(b->ev_out[k % MOR_MAX_SLOTS], fs));   // (the device → host copies below follow it)
   if (host_async) {   // on the device → host copy stream, behind the output kernels
     hipStream_t cs = b->s_d2h_[0];

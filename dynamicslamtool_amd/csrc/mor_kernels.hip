@@ -29,7 +29,7 @@
 const char *const mor_kernel_names[MK_COUNT] = {   // in MorKernelId order: "k_" + name = the __global__ function
     "classify", "scatter", "split", "heads_count", "heads_scatter", "cellboxes", "rhist", "rscan", "rscatter",
     "score_fast", "score_nb", "score_pde", "vox_clear", "vox_insert", "vox_probe",
-    "filter", "g2_cov_mid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "gridhash", "gridcount", "gridplace", "cg_slab", "cg_final", "clusters"};
+    "out", "g2_cov_mid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridcount", "gridplace", "cg_slab", "cg_final", "clusters"};
 
 #ifdef MOR_EXP_STAMPS
 #define RS_T(v) const unsigned long long v = wall_clock64()
@@ -86,17 +86,19 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 // sum of the shares returns false and leaves.  With B a multiple of 8 the streams of XCD group x (s % 8 == x) share out the workgroups with
 // blockIdx % 8 == x among themselves, so a stream's workgroups still meet in one L2 (map_block_local).  Called by all lanes of every wave before
 // any divergence (every wave works it out for itself: a handful of loads and two wave scans, no LDS, no barrier); the results are wave-uniform.
-template <class WF> __device__ __forceinline__ bool map_block_work(const MorDev &d, WF wf, int &s, int &t, int &g) {
+// EXACT: wf(s) IS the number of workgroups of stream s (the launch holds at least their sum: the slabs of the cell graph, whose number per stream an
+// earlier kernel fixed within the launch's budget).
+template <bool EXACT = false, class WF> __device__ __forceinline__ bool map_block_work(const MorDev &d, WF wf, int &s, int &t, int &g) {
   const int nblk = (int)gridDim.x, lane = lane_id();
   const bool x8 = (d.B & 7) == 0 && d.xcd_map && (nblk & 7) == 0;
   const int ng = x8 ? d.B >> 3 : d.B, G = x8 ? nblk >> 3 : nblk, x = x8 ? (int)(blockIdx.x & 7) : 0, r = x8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, stp = x8 ? 8 : 1;
-  if (!d.prop_map || G < ng) {   // same share for every stream (MOR_PROP_MAP=0; or fewer workgroups than streams: then the plain map with what there is)
+  if (!EXACT && (!d.prop_map || G < ng)) {   // same share for every stream (MOR_PROP_MAP=0; or fewer workgroups than streams: then the plain map with what there is)
     const int per = max(G / max(ng, 1), 1);
     const int i = r / per; if (i >= ng) return false;
     s = x + stp * i + d.s0; t = r - i * per; g = per; return true;
   }
   long long W = 0;
-  for (int i0 = 0; i0 < ng; i0 += 64) {
+  if (!EXACT) for (int i0 = 0; i0 < ng; i0 += 64) {
     long long w = i0 + lane < ng ? (long long)wf(x + stp * (i0 + lane) + d.s0) : 0ll;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) w += ((long long)__shfl_xor((int)(w >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)w, o, 64);
@@ -106,7 +108,7 @@ template <class WF> __device__ __forceinline__ bool map_block_work(const MorDev 
   int carry = 0;
   for (int i0 = 0; i0 < ng; i0 += 64) {
     const int i = i0 + lane;
-    const int gi = i < ng ? 1 + (int)((long long)wf(x + stp * i + d.s0) * spare / (W > 0 ? W : 1ll)) : 0;
+    const int gi = i < ng ? (EXACT ? (int)wf(x + stp * i + d.s0) : 1 + (int)((long long)wf(x + stp * i + d.s0) * spare / (W > 0 ? W : 1ll))) : 0;
     const int incl = wave_incl_scan(gi);
     const unsigned long long m = __ballot(i < ng && r < carry + incl);
     if (m) {
@@ -192,7 +194,7 @@ __device__ __forceinline__ bool stream_last_block(int *ticket, int n_blocks, int
   __syncthreads();
   return *l_flag != 0;
 }
-enum { TK_TRACK = 0, TK_CGFINAL = 1, TK_PAIRS = 2, TK_SPLIT = 3, TK_OUT = 4, TK_FREADY = 5, TK_COUNT = 8 };   // ticket words per stream
+enum { TK_TRACK = 0, TK_CGFINAL = 1, TK_PAIRS = 2, TK_SPLIT = 3, TK_OUT = 4, TK_SLABCNT = 5, TK_COUNT = 8 };   // ticket words per stream
 
 // fromPCLPointCloud2 (:523): named float32 fields of a blob record → (x,y,z,intensity)
 __device__ __forceinline__ float ld_f32_bytes(const char *p) {   // a float32 field at any byte address
@@ -300,6 +302,7 @@ __device__ __forceinline__ void reset_frame_info(const MorDev &d, int s, uint32_
   if (d.gmode == 2) return;
   MorFrameInfo &f = d.info[s];
   f.N = n_points; f.flags = 0; f.n_pairs = 0; f.K = 0; f.C = 0; f.max_loc = 0;
+  d.tickets[(size_t)s * TK_COUNT + TK_SLABCNT] = 0;   // slabs handed out so far to the streams of this stream's XCD group (slab_bounds; the word of the group's first stream counts)
 }
 // ------------------------------------------------------------------------------------ G1: trim + ground split
 // pass 1: per-tile counts of (non-ground, ground)
@@ -771,10 +774,26 @@ template <bool L> __device__ __forceinline__ int gh_scan(int *a, int n, int *sh)
 // (rows[r] = first compact id of row r, rows[nrows] = n_occ); threads 0 … P of the calling workgroup take part; sh: ≥ 40 ints.
 template <bool L> __device__ __forceinline__ void slab_bounds(const MorDev &d, const MorGrid &G, int s, const int *rows, int nocc, int *sh) {
   const int ny = G.ny, nz = G.nz, j = threadIdx.x;
-  // slabs of this stream: the launch's width for every stream, or (map_block_work) as many as the stream's cells ask for at slab_T own cells a slab —
-  // a stream of 5 400 cells then gets four times the workgroups of one with 1 300 instead of slabs four times as big
-  const int P = (d.prop_map && d.slab_T > 0) ? max(1, min((nocc + d.slab_T - 1) / d.slab_T, min(MOR_MAXP, max(1, ny / 2)))) : d.P;
-  if (j == 0) d.slab_p[s] = P;
+  // Slabs of this stream: the launch's width for every stream, or (map_block_work) as many as the stream's cells ask for at slab_T own cells a slab —
+  // a stream of 5 400 cells then gets four times the workgroups of one with 1 300 instead of slabs four times as big.  k_cg_slab runs ONE slab per
+  // workgroup and its launch holds P + 1 workgroups per stream, shared within an XCD group: every stream has one slab for sure and draws the others
+  // from the group's budget (a counter in the group's first stream's ticket words, reset by the frame's first kernel); a stream that finds the
+  // budget short gets fewer, larger slabs (never seen with slab_T from the previous frame's counts; any partition gives the same components).
+  if (j == 0) {
+    int P = d.P;
+    if (d.prop_map && d.slab_T > 0) {
+      const bool x8 = (d.B & 7) == 0 && d.xcd_map;
+      const int ng = x8 ? d.B >> 3 : d.B, budget = ng * d.P, first = x8 ? d.s0 + ((s - d.s0) & 7) : d.s0;   // (P + 1 workgroups per stream in the launch, one of them the stream's own)
+      const int want = max(1, min((nocc + d.slab_T - 1) / d.slab_T, min(MOR_MAXP, max(1, ny / 2)))) - 1;
+      int extra = 0;
+      if (want > 0) { const int base = __hip_atomic_fetch_add(d.tickets + (size_t)first * TK_COUNT + TK_SLABCNT, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); extra = max(0, min(want, budget - base)); }
+      P = 1 + extra;
+    }
+    d.slab_p[s] = P; sh[40] = P;
+  }
+  __syncthreads();
+  const int P = sh[40];
+  __syncthreads();
   if (j <= P) {
     int y = j == 0 ? 0 : ny;
     if (j > 0 && j < P) {   // smallest y whose first cell id reaches the j-th share of the cells
@@ -1590,15 +1609,14 @@ template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDe
 #define CGS_ARENA (CGS_SLAB_WORDS > 3 * MOR_CGS_FCAP ? CGS_SLAB_WORDS : 3 * MOR_CGS_FCAP)   // (the slab layout of the default build is 18 945 words)
 #define CGS_FCAP (CGS_ARENA / 3)
 template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d, int s, int j, int *l_arena, int *l_wcnt, int *l_n2p);
-template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {
-  int s, j0, gs;
-  if (!map_block_work(d, [&](int s_) { return d.slab_p[s_]; }, s, j0, gs)) return;   // work: the stream's slabs (normally one workgroup each)
+template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {   // (keep it at ≤ 128 VGPRs — two workgroups per CU; a loop over several slabs per workgroup took 157: 228 → 350 µs in the pipeline)
+  int s, j, Ps;
+  if (!map_block_work<true>(d, [&](int s_) { return d.slab_p[s_]; }, s, j, Ps)) return;   // one workgroup per slab; the stream's number of slabs was fixed by slab_bounds within the launch's budget
   static_assert(CAP == CGS_CAP, "the LDS arena is laid out for CGS_CAP");
   __shared__ int l_arena[CGS_ARENA], l_wcnt[CGS_NW], l_n2, l_last;
-  const int Ps = d.slab_p[s];
-  for (int j = j0; j < Ps; j += gs) { cg_slab_body<CAP>(d, s, j, l_arena, l_wcnt, &l_n2); __syncthreads(); }
+  cg_slab_body<CAP>(d, s, j, l_arena, l_wcnt, &l_n2);
   if (!d.cg_fused) return;
-  if (!stream_last_block(d.tickets + (size_t)s * TK_COUNT + TK_CGFINAL, gs, &l_last)) return;
+  if (!stream_last_block(d.tickets + (size_t)s * TK_COUNT + TK_CGFINAL, Ps, &l_last)) return;
   const int nocc = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
   __shared__ int l_misc[1 + CGS_T / 64], l_sc[MOR_MAXP + 1], l_se[MOR_MAXP + 1];
@@ -3277,20 +3295,20 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
   tr_store_head(gt, t, lane);
   if (lane == 0) mor_publish_err(d, s);
 }
-// filterCloud (:613-696) in ONE launch (round 3: k_track_filter | k_out_count | k_out_scatter).
-// (1) The loop over mo_vec (:630-671): nearest current centroid of every tracked one (squared fp32 distance, ties → lowest index), its whole
-//     cluster queued for removal before any test, confidence bookkeeping.  One workgroup of the stream does it — the one that draws ticket 0,
-//     so it is running and waits for nobody — and hands over, with agent-scope stores: the removal flags as a bit per cluster, the
-//     ExtractIndices size-check flag and the number of kept cloud points, n_keep = M − Σ sizes of the flagged clusters (known without a
-//     counting pass over the points: a cluster's size is the number of cloud points that carry its label).  Then it raises the stream's
-//     "ready" word to this call's epoch; the stream's other workgroups poll it.
-// (2) The output (:673-687) = [cloud minus moving clusters, original order] ++ [ground points].  The ground points were written to their final
+// filterCloud (:613-696) in two launches (round 3: k_track_filter | k_out_count | k_out_scatter).
+// k_track_filter — the loop over mo_vec (:630-671): nearest current centroid of every tracked one (squared fp32 distance, ties → lowest index), its
+//     whole cluster queued for removal before any test, confidence bookkeeping.  One workgroup per stream; it leaves the removal flags as a bit per
+//     cluster, the ExtractIndices size-check flag and the number of kept cloud points, n_keep = M − Σ sizes of the flagged clusters (known without a
+//     counting pass over the points: a cluster's size is the number of cloud points that carry its label).
+// k_out — the output (:673-687) = [cloud minus moving clusters, original order] ++ [ground points].  The ground points were written to their final
 //     place by the split kernel (from slot Nmax of the stream's 2·Nmax-slot `ground` buffer), so the result is assembled in place: the kept
 //     cloud points go right-aligned in front of them, the result starts at slot Nmax − n_keep, and the bulk of the frame (the ground, ≈ 90 %
 //     of a LiDAR sweep) is not copied again.  ONE pass over the labels: tiles of 2048 cloud points are handed out by ticket (a tile's
 //     predecessors are then owned by workgroups that are already running), a tile publishes its kept count in a descriptor tagged with the
-//     epoch and adds up the descriptors of the tiles below it (decoupled look-back; no count pass, no scan).  With caller-provided device
+//     call's epoch and adds up the descriptors of the tiles below it (decoupled look-back; no count pass, no scan).  With caller-provided device
 //     pointers both parts are copied out: the workgroups [tiles_m, tiles_m + tiles) of a stream copy the ground points behind the kept ones.
+// (Both in ONE launch — the first workgroup of a stream to arrive runs the loop, the others poll a ready word — was correct and 5 % slower: a
+//  stream's two thousand output workgroups sat in the GPU's wave slots spinning while one wave walked the tracks, and kept the other lanes' kernels out.)
 // The keep test is ExtractIndices' negative set semantics; the size-check flag reproduces "more indices than points ⇒ empty output" (:676-678).
 #define FLT_T MOR_BT
 __device__ __forceinline__ void track_filter_body(const MorDev &d, int s, unsigned *l_mov /* Kcap / 32 words */) {
@@ -3366,12 +3384,11 @@ __device__ __forceinline__ void track_filter_body(const MorDev &d, int s, unsign
   if (lane == 0) l_rem[tid >> 6] = removed;
   __syncthreads();
   unsigned *gm = d.moving + (size_t)s * (d.Kcap / 32 + 2);
-  for (int k = tid; k < (K + 31) / 32; k += FLT_T) st_agent(reinterpret_cast<int *>(gm + k), (int)l_mov[k]);
+  for (int k = tid; k < (K + 31) / 32; k += FLT_T) gm[k] = l_mov[k];
   if (tid == 0) {
     unsigned rem = 0; for (int w = 0; w < FLT_T / 64; ++w) rem += l_rem[w];
     const unsigned n_keep = xerr ? 0u : M - rem;
-    st_agent(reinterpret_cast<int *>(gm + d.Kcap / 32), xerr ? 1 : 0);
-    st_agent(reinterpret_cast<int *>(gm + d.Kcap / 32 + 1), (int)n_keep);
+    gm[d.Kcap / 32] = xerr ? 1u : 0u; gm[d.Kcap / 32 + 1] = n_keep;
     d.info[s].n_keep = n_keep; d.h_nout[s] = (unsigned long long)n_keep + d.info[s].G; d.h_noff[s] = d.Nmax - (int)n_keep;
     MorFrameLog &L = d.h_log[(size_t)(d.frame_no % MOR_LOG_CAP) * d.Btot + s];
     L.n_mo_filter = t.n_mo; L.n_out = (unsigned long long)n_keep + d.info[s].G;
@@ -3380,14 +3397,18 @@ __device__ __forceinline__ void track_filter_body(const MorDev &d, int s, unsign
   }
   if (w0) { int *gs = reinterpret_cast<int *>(&gt); const int *ls = reinterpret_cast<const int *>(&t); for (int i = lane; i < (int)(sizeof(MorTrackHead) / sizeof(int)); i += 64) gs[i] = ls[i]; }
 }
-__global__ __launch_bounds__(FLT_T) void k_filter(MorDev d) {
+__global__ __launch_bounds__(FLT_T) void k_track_filter(MorDev d) {
+  __shared__ unsigned l_mov[MOR_KCAP_MAX / 32];
+  track_filter_body(d, blockIdx.x + d.s0, l_mov);
+}
+__global__ __launch_bounds__(FLT_T) void k_out(MorDev d) {
   int s, t2; map_block(d.B, d.tiles_m + (d.out_ptrs ? d.tiles : 0), s, t2);
   const size_t so = (size_t)s * d.Nmax;
   float4 *og = d.ground + 2 * so;
   __shared__ unsigned l_mov[MOR_KCAP_MAX / 32];
   __shared__ int l_ex[4], sh[4];
   const unsigned epoch = d.filter_epoch;
-  int *tk = d.tickets + (size_t)s * TK_COUNT + TK_OUT, *ready = d.tickets + (size_t)s * TK_COUNT + TK_FREADY;
+  int *tk = d.tickets + (size_t)s * TK_COUNT + TK_OUT;
   const bool ground_wg = t2 >= d.tiles_m;
   const int M = d.info[s].M, nto = (M + MOR_TILE - 1) / MOR_TILE, tk_total = nto + d.tiles_m;   // every cloud workgroup draws one ticket beyond its last tile
   int t = 0;
@@ -3396,20 +3417,8 @@ __global__ __launch_bounds__(FLT_T) void k_filter(MorDev d) {
     __syncthreads();
     t = __builtin_amdgcn_readfirstlane(l_ex[0]);
   }
-  if (!ground_wg && t == 0) {   // the first to arrive runs the loop over mo_vec and hands its results to the others
-    track_filter_body(d, s, l_mov);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(ready, (int)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    if (threadIdx.x == 0) {
-      unsigned spins = 0;
-      while ((unsigned)ld_agent(ready) != epoch) { if (++spins > SPLIT_SPIN_LIMIT) { mor_raise(d, s, 64u); break; } __builtin_amdgcn_s_sleep(2); }
-    }
-    __syncthreads();
-  }
   const unsigned *gm = d.moving + (size_t)s * (d.Kcap / 32 + 2);
-  const int xerr = ld_agent(reinterpret_cast<const int *>(gm + d.Kcap / 32)), n_keep = ld_agent(reinterpret_cast<const int *>(gm + d.Kcap / 32 + 1));
+  const int xerr = (int)gm[d.Kcap / 32], n_keep = (int)gm[d.Kcap / 32 + 1];   // (k_track_filter's results: a kernel boundary lies in between)
   if (ground_wg) {
     const int tg = t2 - d.tiles_m, G = d.info[s].G, base = tg * MOR_TILE;
     float4 *out = d.out_ptrs[s];
@@ -3418,7 +3427,7 @@ __global__ __launch_bounds__(FLT_T) void k_filter(MorDev d) {
   }
   if (t >= nto) return;
   const int K = d.info[s].K;
-  if (t != 0) { for (int k = threadIdx.x; k < (K + 31) / 32; k += FLT_T) l_mov[k] = (unsigned)ld_agent(reinterpret_cast<const int *>(gm + k)); }   // (the tracking workgroup still holds the bits in its LDS)
+  for (int k = threadIdx.x; k < (K + 31) / 32; k += FLT_T) l_mov[k] = gm[k];
   __syncthreads();
   float4 *dst = d.out_ptrs ? d.out_ptrs[s] : og + (d.Nmax - n_keep);
   unsigned long long *desc = d.out_desc + (size_t)s * d.tiles_max;
@@ -3545,7 +3554,7 @@ static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLau
 }
 
 static void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // slabs (+ merge in each stream's last slab workgroup), or slabs | merge
-  MOR_LAUNCH_T(MK_CG_SLAB, (k_cg_slab<CGS_CAP>), dim3(d.B * d.P), CGS_T, d);
+  MOR_LAUNCH_T(MK_CG_SLAB, (k_cg_slab<CGS_CAP>), dim3(d.B * ((d.prop_map && d.slab_T > 0) ? d.P + 1 : d.P)), CGS_T, d);
   if (d.cg_fused) return;
   MOR_LAUNCH_T(MK_CG_FINAL, k_cg_final, dim3(d.B), CGF_T, d);
 }
@@ -3596,8 +3605,9 @@ void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer
   }
 }
 
-void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // the loop over mo_vec (:630-671, on EVERY filterCloud call, as in the reference — a second call on the same frame walks the tracks again) and the output, one launch
-  MOR_LAUNCH_T(MK_FILTER, k_filter, dim3(d.B * (d.tiles_m + (d.out_ptrs ? d.tiles : 0))), FLT_T, d);
+void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part) {   // part 1: the loop over mo_vec (:630-671; on EVERY filterCloud call, as in the reference — a second call on the same frame walks the tracks again; the next frame's tracking step waits for this only); part 2: the output
+  if (part == 1) { MOR_LAUNCH_T(MK_TRACK_FILTER, k_track_filter, dim3(d.B), FLT_T, d); return; }
+  MOR_LAUNCH_T(MK_OUT, k_out, dim3(d.B * (d.tiles_m + (d.out_ptrs ? d.tiles : 0))), FLT_T, d);
 }
 
 // A few KB from page-locked host memory into device memory, on the stream, by one workgroup (bytes: a multiple of 4)

@@ -26,7 +26,7 @@ tl = b.kernel_timeline()
 per = collections.defaultdict(list)
 for n, a, c in tl: per[n].append((a, c))
 for n in per: per[n].sort()
-order = ["split", "gridcount", "gridhash", "gridplace", "cellboxes", "cg_slab", "clusters", "score_fast", "score_nb", "score_pde", "track_push", "filter"]
+order = ["split", "gridcount", "gridhash", "gridplace", "cellboxes", "cg_slab", "clusters", "score_fast", "score_nb", "score_pde", "track_push", "track_filter", "out"]
 nfr = min(len(per[n]) for n in order)
 lo, hi = nfr // 4, nfr - 4
 gaps = collections.defaultdict(list); durs = collections.defaultdict(list); frame_len = []
@@ -36,8 +36,8 @@ for i in range(lo, hi):
         a, c = per[n][i]
         if prev_end is not None: gaps[n].append(1e3 * (a - prev_end))
         durs[n].append(1e3 * (c - a)); prev_end = c
-    frame_len.append(1e3 * (per["filter"][i][1] - per["split"][i][0]))
-    if i >= 4: gaps["split"].append(1e3 * (per["split"][i][0] - per["filter"][i - 4][1]))   # the lane's previous frame
+    frame_len.append(1e3 * (per["out"][i][1] - per["split"][i][0]))
+    if i >= 4: gaps["split"].append(1e3 * (per["split"][i][0] - per["out"][i - 4][1]))   # the lane's previous frame
 period = 1e3 * (per["split"][hi - 1][0] - per["split"][lo][0]) / (hi - 1 - lo)
 print("period %.1f us (event timing on); a frame takes %.0f us from its split to its output; kernels %.0f us, gaps %.0f us per frame" % (
     period, np.mean(frame_len), sum(np.mean(durs[n]) for n in order), sum(np.mean(gaps[n]) for n in order if n != "split")))

@@ -105,7 +105,7 @@ with open("profiles/%s_summary.md" % R, "w") as o:
             o.write("(not collected: %r)\n" % (e,))
     o.write("\n## SQ / TCC counters per launch (hdl64_b64, kernels serialised) — profiles/%s_counters.json\n\n" % R)
     o.write("| kernel | waves | wave-cycles (quad) | wait-any % | LDS-inst active % | VALU-inst active % | LDS bank-conflict % of LDS cycles | L2 hit % |\n|---|---|---|---|---|---|---|---|\n")
-    for k in ("k_split", "k_gridcount", "k_gridhash", "k_gridplace", "k_cellboxes", "k_cg_slab", "k_cg_final", "k_clusters", "k_score_fast", "k_score_nb", "k_score_pde", "k_track_push", "k_filter"):
+    for k in ("k_split", "k_gridcount", "k_gridhash", "k_gridplace", "k_cellboxes", "k_cg_slab", "k_cg_final", "k_clusters", "k_score_fast", "k_score_nb", "k_score_pde", "k_track_push", "k_track_filter", "k_out"):
         c = ctr.get(k)
         if not c:
             continue

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 KERNELS = ["k_split", "k_gridcount", "k_gridhash", "k_gridplace", "k_cellboxes", "k_cg_slab", "k_cg_final", "k_clusters", "k_score_fast", "k_score_nb", "k_score_pde",
-           "k_track_push", "k_filter", "k_g2_cov", "k_g2_cov_mid", "k_g2_cov_big", "k_g2_mode", "k_g2_mark", "k_radix_hist", "k_radix_scatter",
+           "k_track_push", "k_track_filter", "k_out", "k_g2_cov", "k_g2_cov_mid", "k_g2_cov_big", "k_g2_mode", "k_g2_mark", "k_radix_hist", "k_radix_scatter",
            "k_heads_scatter", "k_vox_clear", "k_vox_insert", "k_vox_probe"]
 
 
