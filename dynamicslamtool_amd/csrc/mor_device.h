@@ -92,10 +92,9 @@ struct MorDev {
   int tiles_m;               // workgroups per stream for kernels over the non-ground cloud / clusters: an estimate from the
                              // previous frame; those kernels grid-stride over the tiles a stream really has, so any value ≥ 1 is correct
   int split_g;   // workgroups per stream of the two split passes (each walks tiles split_g apart)
-  int g_fast, g_score, g_pde, g_box;   // launch widths: k_score_fast workgroups per cloud tile, workgroups per stream of the worklist tiers / the wave tier / k_cellboxes (MOR_TUNE)
+  int g_fast, g_score, g_pde, g_box;   // launch widths, workgroups per stream (shared out by work inside the launch): tier 1 of the scores, the worklist tiers, the wave tier, k_cellboxes
   int prop_map;              // 1 (default): launches share their workgroups out over the streams in proportion to the streams' work (map_block_work); 0: the same number for every stream (MOR_PROP_MAP=0)
   int xcd_map;               // 1: the workgroups of a stream share an XCD (its tables stay in that L2); 0: streams spread over all XCDs
-  int nt_ground;             // non-temporal stores for the ground points at the split (MOR_NT_GROUND, experiment)
   int sp_g;                  // workgroups per stream of the single-read split (2 … 64)
   int two_pass_split;        // 1 (default): count pass + scatter pass; 0: the single-pass split with decoupled look-back (MOR_SINGLE_PASS_SPLIT)
   int cur, prev, has_prev;   // cluster-array slots of cb and ca (four slots rotate: up to three frames are in flight in the stage pipeline); whether ca exists (:534)
@@ -144,7 +143,7 @@ struct MorDev {
   int *cstart;               // [B][Nmax+1]  first sorted position of each occupied cell
   int *row_start;            // [B][nrows+1]  first occupied cell of each (y,z) row
   int *gnz, *gnz_out; int cg_nz; float cg_inv_cs;   // voxel ground variant: z layers of the clustering grid per stream (stream_grid); written by pass A through gnz_out
-  unsigned short *rs16, *cx16; int rs16_stride;   // [B][rs16_stride], [B][Nmax]  16-bit copies of the row table and of the x of every occupied cell: the cell index the method-1 scoring tiers keep in LDS
+  unsigned short *rs16, *cx16; int rs16_stride, cx16_stride;   // [B][rs16_stride], [B][cx16_stride] (even strides ≥ rows + 1 / Nmax + 1)  16-bit copies of the row table and of the x of every occupied cell: the cell index the method-1 scoring tiers keep in LDS
   int Hcell, use_hash;       // capacity per stream of the grid build's global-memory cell table (power of two ≥ 4·Nmax); whether the 16-bit index is written (method 1)
   int *cmin;                 // [B][Nmax]  smallest cloud index in the cell
   float4 *cmeta;             // [B][2·Nmax]  per occupied cell: low corner of its point box (.w = cluster id bits), high corner

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -19,12 +20,12 @@
 #define MOR_ARGS_RING 8
 
 // The frame pipeline wants its four lane streams on four different hardware queues.  The ROCm runtime multiplexes
-// streams onto GPU_MAX_HW_QUEUES (default 4) queues in creation order, so with the batch's main stream two lanes share
-// one unless the PROCESS sets GPU_MAX_HW_QUEUES=8 (or more) before HIP initialises — the integrator's decision, this
-// library never touches the environment (the Python binding and the replay driver set it).  Measured on
-// MI355X: hardware queue i is served by compute pipe i % 4 and queues of one pipe do not overlap, so four is also the
-// useful maximum of concurrently busy streams.  Stream creation order below is st, sf, sc, sm, sb ⇒ queues 0…4 ⇒
-// pipes 0,1,2,3,0 with `st` idle during pushes.
+// streams onto GPU_MAX_HW_QUEUES (default 4) queues in creation order; the three copy streams of the device (below) are created first,
+// then the lanes sf, sc, sm, sb — seven streams: with the default of four queues the lanes share queues with each other and with the copy
+// streams (107 k instead of 180 k frame-pairs/s), so the PROCESS sets GPU_MAX_HW_QUEUES=8 (or more) before HIP initialises — the integrator's
+// decision, this library never touches the environment (the Python binding and the replay driver set it).  Measured on
+// MI355X (round 4, GPU_MAX_HW_QUEUES=16): 5 / 6 / 8 lanes give 169 / 176 / 184 k against 186 k with four — more frames in flight do not help,
+// the GPU's memory pipeline is busy with four.
 
 // The three copy streams of a device (read-backs, host → device, device → host) are created ONCE per process and device and shared by all
 // batches on it (copies of different batches queue behind each other; they share the link anyway).  The runtime binds a stream to its DMA
@@ -32,7 +33,8 @@
 // moved device → host at 10 GB/s instead of 55 (exp/e2e_probe.py --prelude).
 struct MorCopyStreams { hipStream_t st = nullptr, h2d = nullptr, d2h = nullptr; };
 static MorCopyStreams *copy_streams(int device) {
-  static std::map<int, MorCopyStreams> all;   // (batches are created from one thread at a time: the C ABI is not thread-safe per batch, creation included)
+  static std::map<int, MorCopyStreams> all; static std::mutex mu;   // (two adapters may be constructed from two threads: the map and the creation are guarded; the streams are never released)
+  std::lock_guard<std::mutex> lk(mu);
   MorCopyStreams &c = all[device];
   if (!c.st) {
     if (hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c.h2d, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c.d2h, hipStreamNonBlocking) != hipSuccess) return nullptr;
@@ -112,7 +114,6 @@ struct mor_batch {
   hipEvent_t ev_out[MOR_MAX_SLOTS] = {};        // recorded after the output kernels of a filterCloud whose clouds leave by DMA (the copies follow it)
   // The stream every such event was last recorded on: a wait for an event of the SAME stream is implied by stream order, and every
   // packet the command processor does not have to fetch, resolve and signal is a few microseconds of a lane (exp/gaps.py)
-  bool pargs_copy = false;   // MOR_ARGS_COPY=1: always copy the arguments with the copy kernel (test switch)
   hipStream_t ev_back_st[MOR_MAX_SLOTS] = {}; hipStream_t last_track_st = nullptr;
   MorDev dtemp[MOR_MAX_DEPTH];               // descriptor templates, frame k uses dtemp[k % depth] (static part + pointers)
   MorDev d;                                  // descriptor of the latest pushed frame
@@ -215,19 +216,20 @@ static int configure(mor_batch *b) {
     int ncu = 256; hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b->device);
     const int hold = std::max(1, mor_split_blocks_per_cu()) * ncu;
     d.sp_g = std::max(2, std::min(32, hold / b->B));
-    if (getenv("MOR_SP_G")) d.sp_g = std::max(2, std::min(64, atoi(getenv("MOR_SP_G"))));
+    if (getenv("MOR_SP_G")) d.sp_g = std::max(2, std::min(64, atoi(getenv("MOR_SP_G"))));   // (test knob: tests/test_gpu_parity.py runs 64 per stream, four times what the GPU holds)
     if (b->B * 2 > hold) d.two_pass_split = 1;
     if (getenv("MOR_DEBUG")) fprintf(stderr, "mor: k_split %d workgroups per CU, sp_g %d\n", mor_split_blocks_per_cu(), d.sp_g);
   }
   d.xcd_map = getenv("MOR_NO_XCD_MAP") ? 0 : 1;
   d.prop_map = getenv("MOR_PROP_MAP") ? atoi(getenv("MOR_PROP_MAP")) != 0 : 1;
-  b->pargs_copy = getenv("MOR_ARGS_COPY") && atoi(getenv("MOR_ARGS_COPY")) != 0;
-  d.nt_ground = getenv("MOR_NT_GROUND") ? atoi(getenv("MOR_NT_GROUND")) : 0;
-  d.g_fast = 8; d.g_score = 4; d.g_pde = 256; d.g_box = 32;   // workgroups per stream: tier 1 (1024 threads each, two per CU), tiers 1a + 1b together (512 threads; they share out the chunks of the two worklists), wave tier (256 threads; workgroups without a query leave at once), cell boxes
+  // workgroups per stream (launch widths; the kernels share them out over the streams in proportion to the streams' work, map_block_work): tier 1 of the scores
+  // (1024 threads each, two per CU), tiers 1a + 1b together (512 threads; they share out the chunks of the two worklists), wave tier (256 threads: a wave per
+  // deferred query; 24 × B workgroups hold about one query per wave slot of the GPU — with 256 × B, one workgroup per four queries of the fullest stream, the
+  // launch was mostly workgroups that found nothing to do: 175 k against 182 k frame-pairs/s), cell boxes
+  d.g_fast = 6; d.g_score = 4; d.g_pde = 24; d.g_box = 32;
   if (getenv("MOR_G_FAST")) d.g_fast = std::max(1, atoi(getenv("MOR_G_FAST")));
   if (getenv("MOR_G_SCORE")) d.g_score = std::max(1, atoi(getenv("MOR_G_SCORE")));
-   // workgroups per stream: tier 1 (1024 threads each), tiers 1a / 1b (512 threads, g_score each), wave tier (256 threads; workgroups without a query leave at once), cell boxes
-  if (const char *tn = getenv("MOR_TUNE")) { int a, b2, c, e; if (sscanf(tn, "%d,%d,%d,%d", &a, &b2, &c, &e) == 4 && a > 0 && b2 > 0 && c > 0 && e > 0) { d.g_fast = a; d.g_score = b2; d.g_pde = c; d.g_box = e; } }
+  if (getenv("MOR_G_PDE")) d.g_pde = std::max(1, atoi(getenv("MOR_G_PDE")));
   d.use_hash = d.method == 1;
   { size_t hc = 1024; while (hc < 4 * (size_t)d.Nmax) hc <<= 1; d.Hcell = (int)hc; }
   d.gnz = nullptr; d.gnz_out = nullptr; d.cg_nz = d.g.nz; d.cg_inv_cs = d.g.inv_cs;
@@ -413,6 +415,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   d.Wcap = (int)(N / MOR_CHUNK + K + 2);
   d.gc_chunks = (int)(N / MOR_GC_CHUNK + 1); d.gc_P = 1;
   d.rs16_stride = (int)(((size_t)std::max(d.g.nrows, d.gv.nrows) + 1 + 7) & ~(size_t)7);
+  d.cx16_stride = (int)((N + 2) & ~(size_t)1);   // even, and one entry beyond the last cell (the scoring tiers copy the table two entries at a time)
   d.moving_confidence = n_bad; d.static_confidence = n_good; d.leave_off = p->leave_off_distance; d.catch_up = p->catch_up_distance;
   // ---- shared by all frames: the cluster arrays (frame-slotted: cb, ca and the frames in flight behind them), the tracking state (strictly
   //      serial across frames), the sticky error words, the pinned host mirrors (written by the serial tracking / output steps)
@@ -445,7 +448,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = ok && dalloc(b, o.nn_fwd, B * K) && dalloc(b, o.nn_bwd, B * K) && dalloc(b, o.nn_fwd_d, B * K) && dalloc(b, o.pair_q, B * K) && dalloc(b, o.pair_m, B * K) && dalloc(b, o.pair_d, B * K);
     ok = ok && dalloc(b, o.pair_cnt, B * K) && dalloc(b, o.pair_of_prev, B * K) && dalloc(b, o.qrec, B * K * 2) && dalloc(b, o.pair_of_cur, B * K) && dalloc(b, o.det, B * K);
     ok = ok && dalloc(b, o.wl, B * N) && dalloc(b, o.wl_nb, B) && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B);
-    ok = ok && dalloc(b, o.rs16, B * (size_t)d.rs16_stride) && dalloc(b, o.cx16, B * N);
+    ok = ok && dalloc(b, o.rs16, B * (size_t)d.rs16_stride) && dalloc(b, o.cx16, B * (size_t)d.cx16_stride);
     if (p->method_choice == 2) ok = ok && dalloc(b, o.vox, B * (size_t)d.Hcap);
     ok = ok && dalloc(b, o.moving, B * (K / 32 + 2)) && hipMemset(o.moving, 0, B * (K / 32 + 2) * sizeof(unsigned)) == hipSuccess && dalloc(b, o.out_desc, B * T) && hipMemset(o.out_desc, 0, B * T * sizeof(unsigned long long)) == hipSuccess && halloc(b, o.h_nout, B) && halloc(b, o.h_noff, B);   // (the size mirrors of the filtered clouds too: the output kernels of consecutive frames need no order among themselves)
     ok = ok && dalloc(b, o.zmin_i, B) && dalloc(b, o.zmax_i, B) && hipMemsetD32((hipDeviceptr_t)o.zmin_i, 0x7fffffff, B) == hipSuccess && hipMemsetD32((hipDeviceptr_t)o.zmax_i, (int)0x80000000, B) == hipSuccess && dalloc(b, o.zorg, B) && dalloc(b, o.zbase, B) && hipMemset(o.zbase, 0, B * sizeof(int)) == hipSuccess && dalloc(b, o.mode_bin, B);
@@ -563,7 +566,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   // in front of every frame's first kernel (copy packet, its signal, the barrier behind it)
   // (crop variant: the frame's first kernel, k_split, reads the slot itself and leaves the device copy behind — nothing at all in front of it)
   d.args_src = nullptr; d.args_out = b->d_args_s[k % b->pipe_depth];
-  if (d.gmode == 0 && !d.two_pass_split && !b->pargs_copy) d.args_src = b->h_args;
+  if (d.gmode == 0 && !d.two_pass_split) d.args_src = b->h_args;
   else mor_launch_copy(b->d_args_s[k % b->pipe_depth], b->h_args, sizeof(MorStreamArgs) * B, lane);
   if (!b->async) HIP_TRY(hipEventRecord(b->ev[0], lane));
   for (int pc = 0; pc < b->n_pieces; ++pc) {

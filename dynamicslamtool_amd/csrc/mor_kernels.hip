@@ -88,9 +88,10 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 // any divergence (every wave works it out for itself: a handful of loads and two wave scans, no LDS, no barrier); the results are wave-uniform.
 // EXACT: wf(s) IS the number of workgroups of stream s (the launch holds at least their sum: the slabs of the cell graph, whose number per stream an
 // earlier kernel fixed within the launch's budget).
-template <bool EXACT = false, class WF> __device__ __forceinline__ bool map_block_work(const MorDev &d, WF wf, int &s, int &t, int &g) {
+// SPREAD: the streams share ALL workgroups of the launch (no XCD groups): for work that is small and uneven across streams.
+template <bool EXACT = false, bool SPREAD = false, class WF> __device__ __forceinline__ bool map_block_work(const MorDev &d, WF wf, int &s, int &t, int &g) {
   const int nblk = (int)gridDim.x, lane = lane_id();
-  const bool x8 = (d.B & 7) == 0 && d.xcd_map && (nblk & 7) == 0;
+  const bool x8 = !SPREAD && (d.B & 7) == 0 && d.xcd_map && (nblk & 7) == 0;
   const int ng = x8 ? d.B >> 3 : d.B, G = x8 ? nblk >> 3 : nblk, x = x8 ? (int)(blockIdx.x & 7) : 0, r = x8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, stp = x8 ? 8 : 1;
   if (!EXACT && (!d.prop_map || G < ng)) {   // same share for every stream (MOR_PROP_MAP=0; or fewer workgroups than streams: then the plain map with what there is)
     const int per = max(G / max(ng, 1), 1);
@@ -153,15 +154,8 @@ __device__ __forceinline__ void wg_prefix_total(const int *c, int stride, int t,
 __device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Stores of data nothing on the device reads again soon (the ground points: 90 % of a sweep, written once at the split, read at the
-// earliest when the caller fetches the filtered cloud): non-temporal, so they do not push the small hot arrays of the frames in
-// flight (a few MB per stream) out of the L2s and the Infinity Cache.
-__device__ __forceinline__ void st_stream(float4 *p, const float4 &v, int nt) {
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  if (nt) { const v4f w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<v4f *>(p)); }   // one global_store_dwordx4 … nt
-  else *p = v;
-}
-__device__ __forceinline__ void st_stream(int *p, int v, int nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
+__device__ __forceinline__ void st_stream(float4 *p, const float4 &v) { *p = v; }   // (non-temporal stores for the ground points — 90 % of a sweep, read again only when the caller fetches the cloud — were measured: no gain)
+__device__ __forceinline__ void st_stream(int *p, int v) { *p = v; }
 
 __device__ __forceinline__ void st_agent_f(float *p, float v) { __hip_atomic_store(reinterpret_cast<int *>(p), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent_f(const float *p) { return __int_as_float(__hip_atomic_load(reinterpret_cast<const int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
@@ -397,8 +391,8 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
       d.cloud_tidx[so + k_ng] = k_ng + k_g;   // index in the trimmed cloud (both ranks are exclusive counts of earlier kept points)
       d.pkey[so + k_ng] = grid_key(G, cx, cy, cz);
     } else if (cls[it] == 1) {
-      st_stream(&d.ground[2 * so + d.Nmax + k_g], p[it], d.nt_ground);   // final place in filterCloud's output: [kept cloud, right-aligned to slot Nmax | ground from slot Nmax]
-      st_stream(&d.gp_idx[so + k_g], k_ng + k_g, d.nt_ground);
+      st_stream(&d.ground[2 * so + d.Nmax + k_g], p[it]);   // final place in filterCloud's output: [kept cloud, right-aligned to slot Nmax | ground from slot Nmax]
+      st_stream(&d.gp_idx[so + k_g], k_ng + k_g);
     }
     r_ng += __popcll(m_ng[it]); r_g += __popcll(m_g[it]);
   }
@@ -505,8 +499,8 @@ __device__ __forceinline__ void split_store(const MorDev &d, const MorGrid &G, i
       d.cloud[so + k_ng] = p[it];
       d.cloud_tidx[so + k_ng] = k_ng + k_g; d.pkey[so + k_ng] = grid_key(G, cx, cy, cz);
     } else if (c == 1) {
-      st_stream(&d.ground[2 * so + d.Nmax + k_g], p[it], d.nt_ground);   // final place in filterCloud's output
-      st_stream(&d.gp_idx[so + k_g], k_ng + k_g, d.nt_ground);
+      st_stream(&d.ground[2 * so + d.Nmax + k_g], p[it]);   // final place in filterCloud's output
+      st_stream(&d.gp_idx[so + k_g], k_ng + k_g);
     }
     r_ng += __popcll(m_ng); r_g += __popcll(m_g);
   }
@@ -594,7 +588,7 @@ __device__ __forceinline__ CellIdx cidx_load(const MorDev &d, const MorGrid &G, 
   I.lds = l_idx != nullptr && nocc <= 65535 && nr + nocc + 2 <= CIDX_CAP;
   const int nr2 = (nr + 1) & ~1;   // (the x table starts at an even entry: both tables are copied two entries at a time)
   if (I.lds) {
-    const unsigned *g_rs = reinterpret_cast<const unsigned *>(d.rs16 + (size_t)s * d.rs16_stride), *g_cx = reinterpret_cast<const unsigned *>(d.cx16 + (size_t)s * d.Nmax);
+    const unsigned *g_rs = reinterpret_cast<const unsigned *>(d.rs16 + (size_t)s * d.rs16_stride), *g_cx = reinterpret_cast<const unsigned *>(d.cx16 + (size_t)s * d.cx16_stride);   // (both strides are even: the copies below move two entries at a time from 4-byte aligned addresses)
     unsigned *l32 = reinterpret_cast<unsigned *>(l_idx);
     for (int i = threadIdx.x; i < nr2 / 2; i += blockDim.x) l32[i] = g_rs[i];
     for (int i = threadIdx.x; i < (nocc + 1) / 2; i += blockDim.x) l32[nr2 / 2 + i] = g_cx[i];
@@ -952,7 +946,7 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
   const int2 *clist = d.gc_list + so; int2 *cent = d.gc_ent + so; const int *cn = d.gc_n + (size_t)s * d.gc_chunks;
   int hbits = 0; while ((1 << hbits) < H) ++hbits;
   const unsigned hshift = 32 - hbits, mask = (unsigned)H - 1u;
-  unsigned short *rs16 = d.rs16 + (size_t)s * d.rs16_stride, *cx16 = d.cx16 + so;   // 16-bit copies of the row table and the cells' x for the scoring tiers (cidx_load)
+  unsigned short *rs16 = d.rs16 + (size_t)s * d.rs16_stride, *cx16 = d.cx16 + (size_t)s * d.cx16_stride;   // 16-bit copies of the row table and the cells' x for the scoring tiers (cidx_load)
   const size_t stw = (size_t)s * (MOR_MAXP + 2) + MOR_MAXP; (void)stw;
   ST2(stw, 0);
   for (int i = tid; i < H; i += GH_T) { gh_st<TL>(tkey + i, 0); gh_st<TL>(tval + i, 0); }
@@ -2561,10 +2555,10 @@ __device__ __forceinline__ float wave_scan_cell(const float4 *sp, int b0, int e0
   return wave_min(local);
 }
 #define SCP_T 256    // threads per workgroup of the wave tier.  (Tried: 1024-thread workgroups sharing an LDS copy of the cell index, 4 / 32 per stream: 346 / 90 µs against 56 — a stream's few hundred deferred queries want a thousand waves, and a workgroup with one query does not pay for a table.)
-__device__ __forceinline__ void score_pde_body(const MorDev &d, int s, int bx, unsigned short *l_idx) {
+__device__ __forceinline__ void score_pde_body(const MorDev &d, int s, int bx, int g_pde, unsigned short *l_idx) {
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int pv = d.prev, nq = d.wl2_n[s];
-  const int wv = bx * (SCP_T / 64) + wave_id(), nw = d.g_pde * (SCP_T / 64), lane = lane_id();
+  const int wv = bx * (SCP_T / 64) + wave_id(), nw = g_pde * (SCP_T / 64), lane = lane_id();
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const float4 *sp = d.sorted + so;
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
@@ -2651,7 +2645,11 @@ __device__ __forceinline__ void score_pde_body(const MorDev &d, int s, int bx, u
   if (lane == 0 && acc) atomicAdd(&d.pair_cnt[ko + acc_pr], acc);
 }
 __global__ __launch_bounds__(SCP_T) void k_score_pde(MorDev d) {
-  score_pde_body(d, blockIdx.y + d.s0, blockIdx.x, nullptr);   // a stream's waves spread over all XCDs: the deferred queries are few and uneven across streams
+  // a wave per deferred query: the launch's workgroups go to the streams in proportion to their queues (a few hundred queries in one stream, none in the
+  // next), spread over all XCDs
+  int s, bx, g;
+  if (!map_block_work<false, true>(d, [&](int s_) { return (d.wl2_n[s_] + SCP_T / 64 - 1) / (SCP_T / 64); }, s, bx, g)) return;
+  score_pde_body(d, s, bx, g, nullptr);
 }
 // (Tried: thresholds + tracking step in the stream's last workgroup of this kernel.  The tracking step of frame k must follow frame
 //  k − 1's filterCloud, so the whole wave tier then waited for it and the frames stopped overlapping: 150 k → 125 k frame-pairs/s.)
@@ -3580,7 +3578,7 @@ static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
 
 static void mor_launch_scores2(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {
   if (d.has_prev && d.method == 1 && d.pde_ub > 0.f && d.pde_ub > d.pde_lb) {
-    MOR_LAUNCH_T(MK_SCORE1, k_score_pde, dim3(d.g_pde, d.B), SCP_T, d);
+    MOR_LAUNCH_T(MK_SCORE1, k_score_pde, dim3(d.g_pde * d.B), SCP_T, d);
   }
 }
 static void mor_launch_decide(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {

@@ -383,10 +383,11 @@ print("OK")
 
 
 @pytest.mark.parametrize("env", [{"MOR_GH_TIER": "1"}, {"MOR_GH_TIER": "2", "MOR_CG_GLOBAL": "1"}, {"MOR_LANES": "2"}, {"MOR_PIPE_DEPTH": "8", "MOR_LANES": "6"}, {"MOR_PIPE_DEPTH": "1"},
-                                 {"MOR_PIPE_DEPTH": "2", "MOR_LANES": "1"}, {"MOR_CG_UNFUSED": "1"}, {"MOR_SINGLE_PASS_SPLIT": "1"}, {"MOR_SINGLE_PASS_SPLIT": "0"}, {"MOR_SP_G": "64"}, {"MOR_SP_G": "2"}, {"MOR_ARGS_COPY": "1"}])
+                                 {"MOR_PIPE_DEPTH": "2", "MOR_LANES": "1"}, {"MOR_CG_UNFUSED": "1"}, {"MOR_SINGLE_PASS_SPLIT": "0"}, {"MOR_PROP_MAP": "0"}])
 def test_kernel_variants(env):
     """The tiers behind the default paths must give the same results: k_gridhash with its big LDS table / its global-memory table,
-    slab and merge forests in global memory, other numbers of lanes / pipeline depths, the merge of the slab forests as its own launch.  The tier is chosen when the batch is created,
+    slab and merge forests in global memory, other numbers of lanes / pipeline depths, the merge of the slab forests as its own launch, the count + scatter
+    form of the split, the same number of workgroups for every stream instead of shares by work.  The tier is chosen when the batch is created,
     from the environment: child process (synchronous frames against the oracle, then an asynchronous run without waits against a
     synchronous one)."""
     import subprocess, sys
@@ -790,6 +791,28 @@ def test_unaligned_blob_records():
     compare_output(o2.filter(), b2.filter()[0], "17-byte records")
     b.close()
     b2.close()
+
+
+def test_odd_capacity_with_three_streams_method_1():
+    """An odd max_points puts the odd streams' per-stream tables at odd element offsets: the 16-bit cell index the method-1 scoring tiers copy into
+    LDS two entries at a time must still start 4-byte aligned for every stream and end inside its own slice.  Three streams of
+    different sizes, capacity = the largest cloud rounded up to an odd number, five frames against the oracle."""
+    p = scene_params(method_choice=1)
+    streams = [small_stream(11 + s, n_frames=5, n_objects=4 + 2 * s) for s in range(3)]
+    cap = max(len(fr[0]) for st in streams for fr in st) | 1
+    b, oracles = MorBatch(p, 3, cap), [Oracle(p) for _ in range(3)]
+    pairs = 0
+    for f in range(5):
+        b.push([streams[s][f][0] for s in range(3)], np.stack([streams[s][f][1] for s in range(3)]))
+        for s in range(3):
+            oracles[s].push(*streams[s][f])
+            compare_frame(oracles[s], b, s, "odd capacity, stream %d frame %d" % (s, f))
+            pairs += int(oracles[s].counts().n_corr)
+        outs = b.filter()
+        for s in range(3):
+            compare_output(oracles[s].filter(), outs[s], "odd capacity, stream %d frame %d" % (s, f))
+    assert pairs > 20
+    b.close()
 
 
 def test_error_of_an_intermediate_frame_is_reported_once():
