@@ -527,10 +527,15 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
       unsigned long long tot = 0; for (int s = 0; s < B; ++s) tot += k > 0 ? d.h_info[s].n_occ : 0u;
       d.slab_T = (k > 0 && tot > 0 && d.P > 1 && b->env_cg_p <= 0) ? (int)std::min<unsigned long long>(600, std::max<unsigned long long>(32, (tot + (unsigned long long)B * (d.P - 1) - 1) / ((unsigned long long)B * (d.P - 1)))) : 0;
     }
-    {  // grid build: workgroups per stream of k_gridcount / k_gridplace — one per chunk of MOR_GC_CHUNK points of the largest cloud the device last reported (+ 25 %), enough to fill the GPU
-      uint32_t mxM = 0; for (int s = 0; s < B; ++s) mxM = std::max(mxM, k > 0 ? d.h_info[s].M : (uint32_t)maxn);
-      const int want = (int)((mxM * 5ull / 4 + MOR_GC_CHUNK - 1) / MOR_GC_CHUNK);
+    {  // grid build, cell pass, output: workgroups per stream of k_gridcount / k_gridplace / k_cellboxes / k_out.  The kernels share the launch out over the
+       // streams by their point counts (map_block_work), so the width follows the MEAN cloud the device last reported (+ 15 %, + 1), not the largest:
+       // a launch sized for the largest stream was mostly workgroups that found nothing to do (32 per stream for a mean of 5 chunks).
+      uint64_t sumM = 0; uint32_t mxM = 0; for (int s = 0; s < B; ++s) { const uint32_t m = k > 0 ? d.h_info[s].M : (uint32_t)maxn; sumM += m; mxM = std::max(mxM, m); }
+      const uint64_t meanM = (sumM + B - 1) / B, ref = d.prop_map ? meanM * 23 / 20 : (uint64_t)mxM * 5 / 4;
+      const int want = (int)((ref + MOR_GC_CHUNK - 1) / MOR_GC_CHUNK) + (d.prop_map ? 1 : 0);
       d.gc_P = b->env_gc_p > 0 ? b->env_gc_p : std::max(1, std::min(std::min(want, d.gc_chunks), std::max(1, 2048 / B)));
+      d.g_out = std::max(1, std::min(want, d.tiles));
+      d.g_box = getenv("MOR_G_BOX") ? std::max(1, atoi(getenv("MOR_G_BOX"))) : std::max(2, std::min(32, (int)((ref + 1023) / 1024) + 1));   // (a workgroup of the cell pass takes 1024 positions per round)
     }
     d.cg_fused = (maxocc * 11ull / 10 <= MOR_CGS_FCAP && !getenv("MOR_CG_UNFUSED")) ? 1 : 0;   // (a stream beyond it runs the merge on global-memory arrays: correct, slow — hence the separate kernel when that is foreseeable)
     if (!getenv("MOR_GH_TIER")) d.gh_tier = maxocc * 5ull / 4 > 6144 ? (maxocc * 5ull / 4 > 12288 ? 2 : 1) : 0;   // table tier k_gridhash starts with (a stream whose table overflows moves up by itself)

@@ -89,10 +89,12 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 // EXACT: wf(s) IS the number of workgroups of stream s (the launch holds at least their sum: the slabs of the cell graph, whose number per stream an
 // earlier kernel fixed within the launch's budget).
 // SPREAD: the streams share ALL workgroups of the launch (no XCD groups): for work that is small and uneven across streams.
-template <bool EXACT = false, bool SPREAD = false, class WF> __device__ __forceinline__ bool map_block_work(const MorDev &d, WF wf, int &s, int &t, int &g) {
-  const int nblk = (int)gridDim.x, lane = lane_id();
+// nblk / bid: the workgroups that take part and this one's number among them (default: the whole launch) — a launch may hold several kinds of workgroups.
+template <bool EXACT = false, bool SPREAD = false, class WF> __device__ __forceinline__ bool map_block_work(const MorDev &d, WF wf, int &s, int &t, int &g, int nblk = -1, int bid = -1) {
+  if (nblk < 0) { nblk = (int)gridDim.x; bid = (int)blockIdx.x; }
+  const int lane = lane_id();
   const bool x8 = !SPREAD && (d.B & 7) == 0 && d.xcd_map && (nblk & 7) == 0;
-  const int ng = x8 ? d.B >> 3 : d.B, G = x8 ? nblk >> 3 : nblk, x = x8 ? (int)(blockIdx.x & 7) : 0, r = x8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, stp = x8 ? 8 : 1;
+  const int ng = x8 ? d.B >> 3 : d.B, G = x8 ? nblk >> 3 : nblk, x = x8 ? (bid & 7) : 0, r = x8 ? (bid >> 3) : bid, stp = x8 ? 8 : 1;
   if (!EXACT && (!d.prop_map || G < ng)) {   // same share for every stream (MOR_PROP_MAP=0; or fewer workgroups than streams: then the plain map with what there is)
     const int per = max(G / max(ng, 1), 1);
     const int i = r / per; if (i >= ng) return false;
@@ -424,26 +426,26 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
 #define SPLIT_SPIN_LIMIT (1u << 22)
 __device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // loads only (no use of the data here: the wait for them belongs to split_tile, a step later); cls carries the ground flag of pass B
-__device__ __forceinline__ void split_load_tile(const MorDev &d, const MorStreamArgs &a, int s, uint32_t n_in, int t, float4 (&p)[8], int (&cls)[8]) {
+template <bool PASSB> __device__ __forceinline__ void split_load_tile(const MorDev &d, const MorStreamArgs &a, int s, uint32_t n_in, int t, float4 (&p)[8], int (&cls)[8]) {
   const uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const uint32_t i = min(base + it * 64 + lane_id(), n_in - 1);   // (clamped: out-of-range lanes repeat the last record and are masked in split_tile)
-    if (d.gmode == 2) { p[it] = d.rawbuf[(size_t)s * d.Nmax + i]; cls[it] = d.is_ground[(size_t)s * d.Nmax + i] == d.frame_no + 1; }
+    if (PASSB) { p[it] = d.rawbuf[(size_t)s * d.Nmax + i]; cls[it] = d.is_ground[(size_t)s * d.Nmax + i] == d.frame_no + 1; }
     else { p[it] = load_point(a, i); cls[it] = 0; }
   }
 }
 struct SplitMeta { int tng, tg, wng, wg; };   // a counted tile: its totals and this wave's offsets inside it
-__device__ __forceinline__ int split_class(const MorDev &d, uint32_t n_in, uint32_t i, const float4 &p, int cls) {
-  return i < n_in ? (d.gmode == 2 ? (cls ? 1 : 2) : classify(d, p)) : 0;
+template <bool PASSB> __device__ __forceinline__ int split_class(const MorDev &d, uint32_t n_in, uint32_t i, const float4 &p, int cls) {
+  return i < n_in ? (PASSB ? (cls ? 1 : 2) : classify(d, p)) : 0;
 }
 // stage 1 of a tile (its loads were issued a step earlier): counts, and the tile's aggregate goes out to the other workgroups
-__device__ __forceinline__ void split_count(const MorDev &d, int s, int t, uint32_t n_in, unsigned epoch, const float4 (&p)[8], const int (&cls)[8], int *sh, SplitMeta &m) {
+template <bool PASSB> __device__ __forceinline__ void split_count(const MorDev &d, int s, int t, uint32_t n_in, unsigned epoch, const float4 (&p)[8], const int (&cls)[8], int *sh, SplitMeta &m) {
   int c_ng = 0, c_g = 0;
   const uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512 + lane_id();
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
-    const int c = split_class(d, n_in, base + it * 64, p[it], cls[it]);
+    const int c = split_class<PASSB>(d, n_in, base + it * 64, p[it], cls[it]);
     c_ng += __popcll(__ballot(c == 2)); c_g += __popcll(__ballot(c == 1));
   }
   if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
@@ -456,7 +458,7 @@ __device__ __forceinline__ void split_count(const MorDev &d, int s, int t, uint3
 }
 // stage 2: look-back over the tiles between this workgroup's previous tile and this one, then the stores.
 // tk_next (thread 0 only): the ticket this workgroup has just taken for a later tile — passed on to all threads through s_ex[2]
-__device__ __forceinline__ void split_store(const MorDev &d, const MorGrid &G, int s, int t, int nt, int t_prev, uint32_t n_in, unsigned epoch, const float4 (&p)[8], const int (&cls)[8],
+template <bool PASSB> __device__ __forceinline__ void split_store(const MorDev &d, const MorGrid &G, int s, int t, int nt, int t_prev, uint32_t n_in, unsigned epoch, const float4 (&p)[8], const int (&cls)[8],
                                             const SplitMeta &m, int &ex_ng, int &ex_g, int *s_ex, int tk_next) {
   if (wave_id() == 0) {
     const unsigned long long *desc = d.split_desc + (size_t)s * d.tiles_max;
@@ -490,7 +492,7 @@ __device__ __forceinline__ void split_store(const MorDev &d, const MorGrid &G, i
   const uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512 + lane_id();
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
-    const int c = split_class(d, n_in, base + it * 64, p[it], cls[it]);
+    const int c = split_class<PASSB>(d, n_in, base + it * 64, p[it], cls[it]);
     const unsigned long long m_ng = __ballot(c == 2), m_g = __ballot(c == 1);
     const int k_ng = r_ng + __popcll(m_ng & lanemask_lt()), k_g = r_g + __popcll(m_g & lanemask_lt());
     if (c == 2) {
@@ -505,7 +507,7 @@ __device__ __forceinline__ void split_store(const MorDev &d, const MorGrid &G, i
     r_ng += __popcll(m_ng); r_g += __popcll(m_g);
   }
 }
-__global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
+template <bool PASSB> __global__ __launch_bounds__(MOR_BT, 4) void k_split(MorDev d) {   // (≤ 128 VGPRs: four workgroups per CU; the compiler left to itself wanders between 126 and 150 registers with unrelated edits — at 150 the split took 115 instead of 89 µs)   // (≤ 128 VGPRs: four workgroups per CU — the compiler's own choice wanders between 126 and 150 registers with unrelated edits, and at 150 the split is 115 instead of 89 µs)
   int s, g; map_block(d.B, d.sp_g, s, g);
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   // As the first kernel of a frame (crop variant) this one reads the stream's arguments straight from the page-locked slot the host filled,
@@ -533,26 +535,26 @@ __global__ __launch_bounds__(MOR_BT) void k_split(MorDev d) {
   int ex_ng = 0, ex_g = 0;
   float4 pa[8], pb[8]; int ca[8], cb[8];
   SplitMeta ma, mb;
-  if (t < nt) split_load_tile(d, a, s, n_in, t, pa, ca);
-  if (t1 < nt) split_load_tile(d, a, s, n_in, t1, pb, cb);
-  if (t < nt) split_count(d, s, t, n_in, epoch, pa, ca, sh, ma);
+  if (t < nt) split_load_tile<PASSB>(d, a, s, n_in, t, pa, ca);
+  if (t1 < nt) split_load_tile<PASSB>(d, a, s, n_in, t1, pb, cb);
+  if (t < nt) split_count<PASSB>(d, s, t, n_in, epoch, pa, ca, sh, ma);
   while (t < nt) {   // pa: tile t, counted and published; pb: tile t1, loaded
     int nx = 0;
-    if (t1 < nt) split_count(d, s, t1, n_in, epoch, pb, cb, sh + 8, mb);   // the next tile's aggregate is out before this workgroup waits for anybody
+    if (t1 < nt) split_count<PASSB>(d, s, t1, n_in, epoch, pb, cb, sh + 8, mb);   // the next tile's aggregate is out before this workgroup waits for anybody
     if (threadIdx.x == 0) nx = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    split_store(d, G, s, t, nt, t_prev, n_in, epoch, pa, ca, ma, ex_ng, ex_g, s_ex, nx);
+    split_store<PASSB>(d, G, s, t, nt, t_prev, n_in, epoch, pa, ca, ma, ex_ng, ex_g, s_ex, nx);
     if (threadIdx.x == 0 && nx + 1 == tk_total) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t_prev = t;
     const int t2 = __builtin_amdgcn_readfirstlane(s_ex[2]);
-    if (t2 < nt) split_load_tile(d, a, s, n_in, t2, pa, ca);
+    if (t2 < nt) split_load_tile<PASSB>(d, a, s, n_in, t2, pa, ca);
     if (t1 >= nt) break;
-    if (t2 < nt) split_count(d, s, t2, n_in, epoch, pa, ca, sh, ma);
+    if (t2 < nt) split_count<PASSB>(d, s, t2, n_in, epoch, pa, ca, sh, ma);
     if (threadIdx.x == 0) nx = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    split_store(d, G, s, t1, nt, t_prev, n_in, epoch, pb, cb, mb, ex_ng, ex_g, s_ex + 3, nx);
+    split_store<PASSB>(d, G, s, t1, nt, t_prev, n_in, epoch, pb, cb, mb, ex_ng, ex_g, s_ex + 3, nx);
     if (threadIdx.x == 0 && nx + 1 == tk_total) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t_prev = t1;
     const int t3 = __builtin_amdgcn_readfirstlane(s_ex[5]);
-    if (t3 < nt) split_load_tile(d, a, s, n_in, t3, pb, cb);
+    if (t3 < nt) split_load_tile<PASSB>(d, a, s, n_in, t3, pb, cb);
     t = t2; t1 = t3;
   }
 }
@@ -843,13 +845,14 @@ __device__ __forceinline__ void gh_runs(int v, bool valid, int &leader, int &len
 #define GC_H (1 << GC_HBITS)
 #define GC_U (GC_CHUNK / GC_T)
 __global__ __launch_bounds__(GC_T) void k_gridcount(MorDev d) {
-  int s, j; map_block(d.B, d.gc_P, s, j);
+  int s, j, gcp;
+  if (!map_block_work(d, [&](int s_) { return ((int)d.info[s_].M + GC_CHUNK - 1) / GC_CHUNK; }, s, j, gcp)) return;   // work: the stream's chunks
   const int M = d.info[s].M, nch = (M + GC_CHUNK - 1) / GC_CHUNK, tid = threadIdx.x, lane = tid & 63;
   const size_t so = (size_t)s * d.Nmax;
   const int *pkey = d.pkey + so; int *pent = d.pslot + so;
   __shared__ int l_key[GC_H], l_cnt[GC_H], l_sh[GC_T / 64 + 1];
   constexpr unsigned hshift = 32 - GC_HBITS, mask = GC_H - 1; static_assert(GC_H >= GC_CHUNK + GC_CHUNK / 2, "a chunk's table cannot overflow");
-  for (int c = j; c < nch; c += d.gc_P) {
+  for (int c = j; c < nch; c += gcp) {
     for (int i = tid; i < GC_H; i += GC_T) { l_key[i] = 0; l_cnt[i] = 0; }
     __syncthreads();
     const int i0 = c * GC_CHUNK, i1 = min(i0 + GC_CHUNK, M);
@@ -897,13 +900,14 @@ __global__ __launch_bounds__(GC_T) void k_gridcount(MorDev d) {
   }
 }
 __global__ __launch_bounds__(GC_T) void k_gridplace(MorDev d) {
-  int s, j; map_block(d.B, d.gc_P, s, j);
+  int s, j, gcp;
+  if (!map_block_work(d, [&](int s_) { return ((int)d.info[s_].M + GC_CHUNK - 1) / GC_CHUNK; }, s, j, gcp)) return;   // work: the stream's chunks
   const int M = d.info[s].M, nch = (M + GC_CHUNK - 1) / GC_CHUNK, tid = threadIdx.x, lane = tid & 63;
   const size_t so = (size_t)s * d.Nmax;
   const int *pent = d.pslot + so; const float4 *cloud = d.cloud + so; float4 *sorted = d.sorted + so; int *scell = d.scell + so;
   const int tabsel = d.gc_tabsel[s]; const int2 *gtab = d.gc_tab + (size_t)s * 16384; const int *gkey = d.gh_key + (size_t)s * d.Hcell, *gval = d.gh_val + (size_t)s * d.Hcell;
   __shared__ int l_cell[GC_CHUNK], l_cur[GC_CHUNK];
-  for (int c = j; c < nch; c += d.gc_P) {
+  for (int c = j; c < nch; c += gcp) {
     const int ne = d.gc_n[(size_t)s * d.gc_chunks + c];
     const int2 *ent = d.gc_ent + so + (size_t)c * GC_CHUNK;
     for (int e = tid; e < ne; e += GC_T) {   // (slot, offset in the cell) → (compact cell id, first position of this chunk's piece of the cell)
@@ -3400,15 +3404,20 @@ __global__ __launch_bounds__(FLT_T) void k_track_filter(MorDev d) {
   track_filter_body(d, blockIdx.x + d.s0, l_mov);
 }
 __global__ __launch_bounds__(FLT_T) void k_out(MorDev d) {
-  int s, t2; map_block(d.B, d.tiles_m + (d.out_ptrs ? d.tiles : 0), s, t2);
+  // the launch: B·g_out workgroups for the kept cloud points (shared out by the streams' tile counts; tiles go by ticket, so any share is correct), then,
+  // with caller-provided pointers, B·tiles workgroups that copy the ground points
+  const int n_cloud = d.B * d.g_out;
+  const bool ground_wg = (int)blockIdx.x >= n_cloud;
+  int s, t2, gs = 0;
+  if (ground_wg) { int L = (int)blockIdx.x - n_cloud; s = L / d.tiles + d.s0; t2 = L % d.tiles; }
+  else if (!map_block_work(d, [&](int s_) { return ((int)d.info[s_].M + MOR_TILE - 1) / MOR_TILE; }, s, t2, gs, n_cloud, (int)blockIdx.x)) return;
   const size_t so = (size_t)s * d.Nmax;
   float4 *og = d.ground + 2 * so;
   __shared__ unsigned l_mov[MOR_KCAP_MAX / 32];
   __shared__ int l_ex[4], sh[4];
   const unsigned epoch = d.filter_epoch;
   int *tk = d.tickets + (size_t)s * TK_COUNT + TK_OUT;
-  const bool ground_wg = t2 >= d.tiles_m;
-  const int M = d.info[s].M, nto = (M + MOR_TILE - 1) / MOR_TILE, tk_total = nto + d.tiles_m;   // every cloud workgroup draws one ticket beyond its last tile
+  const int M = d.info[s].M, nto = (M + MOR_TILE - 1) / MOR_TILE, tk_total = nto + gs;   // every cloud workgroup draws one ticket beyond its last tile
   int t = 0;
   if (!ground_wg) {
     if (threadIdx.x == 0) { const int v = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); l_ex[0] = v; if (v + 1 == tk_total) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -3418,7 +3427,7 @@ __global__ __launch_bounds__(FLT_T) void k_out(MorDev d) {
   const unsigned *gm = d.moving + (size_t)s * (d.Kcap / 32 + 2);
   const int xerr = (int)gm[d.Kcap / 32], n_keep = (int)gm[d.Kcap / 32 + 1];   // (k_track_filter's results: a kernel boundary lies in between)
   if (ground_wg) {
-    const int tg = t2 - d.tiles_m, G = d.info[s].G, base = tg * MOR_TILE;
+    const int tg = t2, G = d.info[s].G, base = tg * MOR_TILE;
     float4 *out = d.out_ptrs[s];
     for (int i = base + threadIdx.x; i < min(base + MOR_TILE, G); i += FLT_T) out[n_keep + i] = og[d.Nmax + i];
     return;
@@ -3497,7 +3506,8 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
   const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B);
   if (part == 2) goto grid;
   if (d.gmode != 1 && !d.two_pass_split) {
-    MOR_LAUNCH(MK_SPLIT, k_split, dim3(d.B * d.sp_g), d);
+    if (d.gmode == 2) MOR_LAUNCH(MK_SPLIT, k_split<true>, dim3(d.B * d.sp_g), d);   // (pass B of the voxel ground variant: the records carry a ground flag; two instances so that the crop variant does not keep registers for it)
+    else MOR_LAUNCH(MK_SPLIT, k_split<false>, dim3(d.B * d.sp_g), d);
   } else {
     const dim3 gS(d.B * d.split_g);
     MOR_LAUNCH(MK_CLASSIFY, k_classify, gS, d);
@@ -3605,7 +3615,7 @@ void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer
 
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part) {   // part 1: the loop over mo_vec (:630-671; on EVERY filterCloud call, as in the reference — a second call on the same frame walks the tracks again; the next frame's tracking step waits for this only); part 2: the output
   if (part == 1) { MOR_LAUNCH_T(MK_TRACK_FILTER, k_track_filter, dim3(d.B), FLT_T, d); return; }
-  MOR_LAUNCH_T(MK_OUT, k_out, dim3(d.B * (d.tiles_m + (d.out_ptrs ? d.tiles : 0))), FLT_T, d);
+  MOR_LAUNCH_T(MK_OUT, k_out, dim3(d.B * (d.g_out + (d.out_ptrs ? d.tiles : 0))), FLT_T, d);
 }
 
 // A few KB from page-locked host memory into device memory, on the stream, by one workgroup (bytes: a multiple of 4)
@@ -3621,6 +3631,6 @@ void mor_launch_copy(void *dst, const void *src_pinned, size_t bytes, hipStream_
 // workgroups of k_split one CU holds (registers decide): the host keeps sp_g × B within what the whole GPU holds at once
 int mor_split_blocks_per_cu() {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_split, MOR_BT, 0) != hipSuccess) n = 2;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_split<false>, MOR_BT, 0) != hipSuccess) n = 2;
   return n < 1 ? 1 : n;
 }
