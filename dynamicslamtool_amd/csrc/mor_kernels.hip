@@ -190,7 +190,7 @@ __device__ __forceinline__ bool stream_last_block(int *ticket, int n_blocks, int
   __syncthreads();
   return *l_flag != 0;
 }
-enum { TK_TRACK = 0, TK_CGFINAL = 1, TK_PAIRS = 2, TK_SPLIT = 3, TK_OUT = 4, TK_SLABCNT = 5, TK_COUNT = 8 };   // ticket words per stream
+enum { TK_TRACK = 0, TK_CGFINAL = 1, TK_PAIRS = 2, TK_SPLIT = 3, TK_OUT = 4, TK_SLABCNT = 5, TK_MOVERS = 6, TK_COUNT = 8 };   // ticket words per stream
 
 // fromPCLPointCloud2 (:523): named float32 fields of a blob record → (x,y,z,intensity)
 __device__ __forceinline__ float ld_f32_bytes(const char *p) {   // a float32 field at any byte address
@@ -1984,15 +1984,19 @@ __device__ __forceinline__ void xform_prev_body(const MorDev &d, int s, int bx, 
 __device__ __forceinline__ void cluster_pairs_body(const MorDev &d, int s, float4 *tile, int *sh);
 #define MOR_XF_G 16   // workgroups per stream that transform the previous frame's clusters inside this launch
 __global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
-  const int xf_g = d.has_prev ? MOR_XF_G : 0, nwg = d.tiles_m + MOR_CLS_G + xf_g;
-  int s, t; map_block(d.B, nwg, s, t);
+  // the launch: B·g_out movers (shared out by the streams' point counts, map_block_work), then per stream MOR_CLS_G reducers and (with a previous frame) MOR_XF_G transformers
+  const int xf_g = d.has_prev ? MOR_XF_G : 0, n_mv = d.B * d.g_out, n_rest = MOR_CLS_G + xf_g;
+  int s, t, gmv = 0;
+  const bool mover = (int)blockIdx.x < n_mv;
+  if (mover) { if (!map_block_work(d, [&](int s_) { return ((int)d.info[s_].M + 4 * MOR_BT - 1) / (4 * MOR_BT); }, s, t, gmv, n_mv, (int)blockIdx.x)) return; }
+  else { const int L = (int)blockIdx.x - n_mv; if ((d.B & 7) == 0 && d.xcd_map) { const int x = L & 7, r = L >> 3; s = (r / n_rest) * 8 + x; t = r % n_rest; } else { s = L / n_rest; t = L % n_rest; } s += d.s0; }
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   __shared__ Red6 l_red[MOR_BT / 64]; __shared__ float l_m[12]; __shared__ float4 l_tile[MOR_BT]; __shared__ int l_sh8[8], l_last;
-  if (t >= d.tiles_m + MOR_CLS_G) xform_prev_body(d, s, t - d.tiles_m - MOR_CLS_G, xf_g, l_red, l_m);   // P1: ca → cb's frame (:536-551), beside the extraction of cb's clusters
-  else if (t < d.tiles_m) {
+  if (!mover && t >= MOR_CLS_G) xform_prev_body(d, s, t - MOR_CLS_G, xf_g, l_red, l_m);   // P1: ca → cb's frame (:536-551), beside the extraction of cb's clusters
+  else if (mover) {
     const int M = d.info[s].M;
     float4 *dst = d.cl_pts[d.cur] + so; int *dcid = d.cl_cid[d.cur] + so;
-    const int stride = d.tiles_m * MOR_BT;
+    const int stride = gmv * MOR_BT;
     for (int j0 = t * MOR_BT + threadIdx.x; j0 < M; j0 += 4 * stride) {   // four positions per thread and round trip: point + cell id, then the cell's record, then the stores
       float4 p[4]; int sc[4]; int4 g[4];
 #pragma unroll
@@ -2012,7 +2016,7 @@ __global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
   } else {
   const int K = d.info[s].K, lane = lane_id();
   const int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1), *lcoff = d.cl_coff + (size_t)s * (d.Kcap + 1);
-  for (int k = (t - d.tiles_m) * (MOR_BT / 64) + wave_id(); k < K; k += MOR_CLS_G * (MOR_BT / 64)) {
+  for (int k = t * (MOR_BT / 64) + wave_id(); k < K; k += MOR_CLS_G * (MOR_BT / 64)) {
     CellAcc r; acc_clear(r);
     const int e1 = lcoff[k + 1];
     for (int e0 = lcoff[k] + lane; e0 < e1; e0 += 256) {   // four cells per lane and round trip (a wall of 3000 cells is 12 dependent rounds, not 47)
@@ -2051,7 +2055,9 @@ __global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
   }
   // P2 (:264-307) in the stream's last workgroup to finish: boxes / centroids / first points of the transformed ca, both nearest-centroid
   // directions, the correspondences — everything per CLUSTER between the point kernels (round 2: two more launches, k_xform_prev and k_cluster_pairs)
-  if (!stream_last_block(d.tickets + (size_t)s * TK_COUNT + TK_PAIRS, nwg, &l_last)) return;
+  // (two tickets: the stream's movers — as many as its share of the launch — among themselves, then their last one with the reducers and transformers)
+  if (mover && !stream_last_block(d.tickets + (size_t)s * TK_COUNT + TK_MOVERS, gmv, &l_last)) return;
+  if (!stream_last_block(d.tickets + (size_t)s * TK_COUNT + TK_PAIRS, n_rest + 1, &l_last)) return;
   cluster_pairs_body(d, s, l_tile, l_sh8);
 }
 
@@ -3568,7 +3574,7 @@ static void mor_launch_cellgraph(const MorDev &d, hipStream_t st, MorLaunchTimer
 }
 
 static void mor_launch_clusters(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // labels, cluster points, centroids, boxes; transform of ca; correspondences
-  MOR_LAUNCH(MK_CLUSTERS, k_clusters, dim3(d.B * (d.tiles_m + MOR_CLS_G + (d.has_prev ? MOR_XF_G : 0))), d);
+  MOR_LAUNCH(MK_CLUSTERS, k_clusters, dim3(d.B * (d.g_out + MOR_CLS_G + (d.has_prev ? MOR_XF_G : 0))), d);
 }
 static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm) {   // transform of ca, correspondences, first tiers of the scores
   const dim3 gT(d.B * d.tiles), gB(d.B), gKt((d.Kcap + MOR_BT - 1) / MOR_BT, d.B);
