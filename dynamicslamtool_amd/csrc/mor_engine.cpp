@@ -525,7 +525,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     {  // slabs in proportion to the streams' cell counts: own cells per slab such that the slabs of all streams together are the launch's B·P workgroups
        // (Σ ceil(n_occ / T) ≤ Σ n_occ / T + B); never more than a slab's LDS holds with its look-ahead.  Counts of the latest frame the device reported.
       unsigned long long tot = 0; for (int s = 0; s < B; ++s) tot += k > 0 ? d.h_info[s].n_occ : 0u;
-      d.slab_T = (k > 0 && tot > 0 && d.P > 1 && b->env_cg_p <= 0) ? (int)std::min<unsigned long long>(600, std::max<unsigned long long>(32, (tot + (unsigned long long)B * (d.P - 1) - 1) / ((unsigned long long)B * (d.P - 1)))) : 0;
+      d.slab_T = (k > 0 && tot > 0 && d.P > 1 && !getenv("MOR_CG_EQUAL")) ? (int)std::min<unsigned long long>(600, std::max<unsigned long long>(32, (tot + (unsigned long long)B * (d.P - 1) - 1) / ((unsigned long long)B * (d.P - 1)))) : 0;
     }
     {  // grid build, cell pass, output: workgroups per stream of k_gridcount / k_gridplace / k_cellboxes / k_out.  The kernels share the launch out over the
        // streams by their point counts (map_block_work), so the width follows the MEAN cloud the device last reported (+ 15 %, + 1), not the largest:

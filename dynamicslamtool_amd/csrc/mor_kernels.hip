@@ -3026,7 +3026,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
 // are complemented; what is left (> G2_MID_CAP neighbours) goes to k_g2_cov_big.
 #define G2_MID_CAP 1024
 __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
-  const int s = blockIdx.y + d.s0, nbig = d.g2_nbig[s];
+  const int s = blockIdx.y + d.s0, nbig = d.g2_nbig[s], bxq = blockIdx.x, gq = gridDim.x;
   const size_t so = (size_t)s * d.Nmax;
   const int wv = wave_id(), lane = lane_id();
   __shared__ unsigned long long l_key[MOR_BT / 64][G2_MID_CAP];
@@ -3034,7 +3034,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
   const int zbase = d.zbase[s];
-  for (int w0 = blockIdx.x * (MOR_BT / 64); w0 < nbig; w0 += gridDim.x * (MOR_BT / 64)) {
+  for (int w0 = bxq * (MOR_BT / 64); w0 < nbig; w0 += gq * (MOR_BT / 64)) {
     const int w = w0 + wv; const bool act = w < nbig;
     const int v = act ? d.g2_big[so + w] : 0;
     const float4 q = d.vcent[so + v];
@@ -3097,13 +3097,13 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
 // four), up to G2_CAP neighbours in 128 KiB of LDS
 #define G2_BIG_T 1024
 __global__ __launch_bounds__(G2_BIG_T) void k_g2_cov_big(MorDev d) {
-  int s = blockIdx.y + d.s0; const int nbig = d.g2_nbig[s];
+  const int s = blockIdx.y + d.s0, nbig = d.g2_nbig[s], bxq = blockIdx.x, gq = gridDim.x;   // (tried: two workgroups per stream shared out by the queues — the queue holds mostly entries the middle tier has settled, so a stream's few big voxels ended up behind each other in one workgroup: 4.3 ms)
   const size_t so = (size_t)s * d.Nmax;
   __shared__ unsigned long long key[G2_CAP];
   __shared__ float px[G2_CHUNK], py[G2_CHUNK], pz[G2_CHUNK];
   __shared__ int cnt;
   __shared__ float acc[6];
-  for (int w = blockIdx.x; w < nbig; w += gridDim.x) {
+  for (int w = bxq; w < nbig; w += gq) {
     const int v = d.g2_big[so + w];
     if (v < 0) continue;   // settled by k_g2_cov_mid
     if (threadIdx.x == 0) cnt = 0;
@@ -3141,14 +3141,20 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mode(MorDev d) {
 }
 // ground = union of the neighbour lists of the dominant bin's voxels (:184-191, de-duplicated): one wave per such
 // voxel marks every trimmed point within the radius (no list, no sort needed here)
-__global__ __launch_bounds__(64) void k_g2_mark(MorDev d) {
+__global__ __launch_bounds__(MOR_BT) void k_g2_mark(MorDev d) {
+  // (waves look at 64 voxels at a time and take the mode bin's voxels among them one by one; 4096 one-wave workgroups per stream that looked at
+  //  fifteen voxels each made this launch 260 000 workgroups)
   int s = blockIdx.y + d.s0, V = d.info[s].n_occ, mode = d.mode_bin[s];
   if (mode == 0x7fffffff) return;
   const size_t so = (size_t)s * d.Nmax;
-  for (int v = blockIdx.x; v < V; v += gridDim.x) {
-    if (d.vbin[so + v] != mode) continue;
-    const float4 q = d.vcent[so + v];
-    g2_for_neighbours(d, s, q, [&](float, const float4 &p) { d.is_ground[so + __float_as_int(p.w)] = d.frame_no + 1; });   // the frame's tag (never 0, never an earlier frame's on this copy of the array): nothing has to be cleared
+  const int lane = lane_id(), nw = gridDim.x * (MOR_BT / 64);
+  for (int v0 = (blockIdx.x * (MOR_BT / 64) + wave_id()) * 64; v0 < V; v0 += nw * 64) {
+    unsigned long long m = __ballot(v0 + lane < V && d.vbin[so + min(v0 + lane, V - 1)] == mode);
+    while (m) {
+      const int l = __ffsll((long long)m) - 1; m &= m - 1;
+      const float4 q = d.vcent[so + v0 + l];
+      g2_for_neighbours(d, s, q, [&](float, const float4 &p) { d.is_ground[so + __float_as_int(p.w)] = d.frame_no + 1; });   // the frame's tag (never 0, never an earlier frame's on this copy of the array): nothing has to be cleared
+    }
   }
 }
 
@@ -3560,7 +3566,7 @@ static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLau
     MOR_LAUNCH_T(MK_G2_COV_BIG, k_g2_cov_big, dim3(64, d.B), G2_BIG_T, da);
   } else if (sub == 4) {
     MOR_LAUNCH(MK_G2_MODE, k_g2_mode, gB, da);
-    MOR_LAUNCH_T(MK_G2_MARK, k_g2_mark, dim3(4096, d.B), 64, da);
+    MOR_LAUNCH(MK_G2_MARK, k_g2_mark, dim3(128, d.B), da);
   } else {
     MorDev db = d; db.gmode = 2;
     mor_launch_split_and_grid(db, st, tm);
