@@ -10,28 +10,31 @@
 # scattered 16-byte accesses of the grid build / scoring kernels.
 # Counter passes never combine --pmc with sys/hip/hsa tracing (only --kernel-trace), and the profiled program follows `--` directly.
 set -e
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$R
 rm -rf $OUT; mkdir -p $OUT profiles
 HEAD_ID=$(cat .git_head 2>/dev/null || echo unknown)
 BASE="--no-cpu-baseline --no-kernel-timing --no-extras"
 WL="os128_b64 agg10_b32 hdl64_urban_b64 hdl64_b64_method2 hdl64_b64_voxel_ground"
-python3 bench.py --no-cpu-baseline --no-extras > $OUT/bench_untraced.json 2> $OUT/bench_untraced.err || true   # the same leg without the tracer, bench.py's own HIP-event timing on
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py $BASE > $OUT/bench_trace.json 2> $OUT/trace.err
+python3 bench.py --no-cpu-baseline --no-extras --detail $OUT/bench_untraced_detail.json > $OUT/bench_untraced.json 2> $OUT/bench_untraced.err || true   # the same leg without the tracer, bench.py's own HIP-event timing on
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py $BASE --detail $OUT/bench_trace_detail.json > $OUT/bench_trace.json 2> $OUT/trace.err
 cp $OUT/trace/t_kernel_stats.csv profiles/${R}_kernel_stats.csv
 for W in $WL; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -o t -- python3 bench.py --workload $W --steps 20 --warmup 3 $BASE > $OUT/bench_$W.json 2> $OUT/trace_$W.err || true
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -o t -- python3 bench.py --workload $W --steps 20 --warmup 3 $BASE --detail $OUT/bench_${W}_detail.json > $OUT/bench_$W.json 2> $OUT/trace_$W.err || true
   cp $OUT/trace_$W/t_kernel_stats.csv profiles/${R}_kernel_stats_$W.csv 2>/dev/null || true
 done
-for W in hdl64_b64 $WL; do   # counter passes serialise the kernels anyway
-  PMC="python3 bench.py --workload $W --steps 10 --warmup 3 $BASE"
+# counter passes serialise the kernels and cost about a second per dispatch: they profile exp/pmc_run.py (three synchronous steps of the workload, nothing else);
+# the first step (no previous frame: no pair stage) is part of the per-launch averages of the frame-independent kernels only
+for W in hdl64_b64 $WL; do
+  PMC="python3 exp/pmc_run.py $W 3"
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$W -o f -- $PMC > /dev/null 2> $OUT/fetch_$W.err || true
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write_$W -o w -- $PMC > /dev/null 2> $OUT/write_$W.err || true
 done
-PMC="python3 bench.py --steps 10 --warmup 3 $BASE"
+PMC="python3 exp/pmc_run.py hdl64_b64 3"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/sq -o s -- $PMC > /dev/null 2> $OUT/sq.err || true
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/sq2 -o s -- $PMC > /dev/null 2> $OUT/sq2.err || true
 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/tc -o t -- $PMC > /dev/null 2> $OUT/tc.err || true
+rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum --output-format csv -d $OUT/sq3 -o s -- $PMC > /dev/null 2> $OUT/sq3.err || true
 python3 profiles/summarise.py "$R" "$OUT" "$HEAD_ID"
 cp profiles/traffic_*.json profiles/${R}_summary.md profiles/${R}_kernel_stats*.csv profiles/${R}_counters.json gpurun_out/ 2>/dev/null || true

@@ -87,7 +87,7 @@ with open("profiles/%s_summary.md" % R, "w") as o:
         tot = sum(v["hbm_bytes_per_launch"] for v in traffic["hdl64_b64"].values())
         o.write("\nSum over the kernels of one step (one launch each): %.0f MB of HBM / Infinity-Cache traffic.\n" % (tot / 1e6))
     try:   # the untraced counterpart: bench.py's HIP-event averages of the same leg
-        d = json.loads(open(OUT + "/bench_untraced.json").read().strip().splitlines()[-1])
+        d = json.load(open(OUT + "/bench_untraced_detail.json"))   # (the per-kernel tables live in bench.py's detail file, not in its bounded stdout line)
         k, a = d["kernels"], d["kernels_alone_avg_us"]
         o.write("\n### The same leg untraced (bench.py, HIP events on the launching stream): %.0f frame-pairs/s, %.4f ms per step\n\n" % (d["value"], d["ms_per_step"]))
         o.write("| kernel | avg µs pipelined | avg µs alone (synchronous steps) |\n|---|---|---|\n")
