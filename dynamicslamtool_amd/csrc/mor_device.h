@@ -73,6 +73,10 @@ struct MorTrackDev {
 #define MOR_LOG_CAP 64
 struct MorFrameLog { int frame, K, C, n_pairs; unsigned cnt_sum, det_sum; int n_mo_push, n_mo_filter; unsigned long long n_out; int flags, pad; };
 
+// per cluster of ca / cb (method 2): its pair and the origin of the pair's voxel lattice as ONE record — the voxel kernels go point → cluster id → record →
+// table instead of point → cluster id → pair → previous cluster → its first point → table
+struct MorVoxRec { double mn[3]; int pr, pad; };
+
 struct MorDev {
   // ---- static configuration
   int B, s0, Btot;           // streams in this launch, first stream, streams in the batch
@@ -191,6 +195,7 @@ struct MorDev {
   int4 *wl; unsigned long long *wl_nb; // [B][Nmax], [B]  method-1 worklists after tier 1 (query, pair, matched cluster, –): E2-known queries from the front, block queries from the back; their counts share a word (low / high half)
   int4 *wl2; int *wl2_n;          // [B][Nmax], [B]  method-1 worklist of the wave tier
   unsigned long long *vox;   // [B][Hcap]
+  struct MorVoxRec *vrec;    // [B][2][Kcap]  method 2: per cluster of ca (first half) / cb (second half) its pair and the origin of the pair's voxel lattice
   unsigned char *det;        // [B][Kcap]  detection_results of cb
   // filter stage
   unsigned *moving;          // [B][Kcap/32 + 2]  k_track_filter → k_out: a bit per cluster queued for removal, then the ExtractIndices size-check flag and the number of kept cloud points

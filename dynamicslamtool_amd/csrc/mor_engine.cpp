@@ -449,7 +449,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = ok && dalloc(b, o.pair_cnt, B * K) && dalloc(b, o.pair_of_prev, B * K) && dalloc(b, o.qrec, B * K * 2) && dalloc(b, o.pair_of_cur, B * K) && dalloc(b, o.det, B * K);
     ok = ok && dalloc(b, o.wl, B * N) && dalloc(b, o.wl_nb, B) && dalloc(b, o.wl2, B * N) && dalloc(b, o.wl2_n, B);
     ok = ok && dalloc(b, o.rs16, B * (size_t)d.rs16_stride) && dalloc(b, o.cx16, B * (size_t)d.cx16_stride);
-    if (p->method_choice == 2) ok = ok && dalloc(b, o.vox, B * (size_t)d.Hcap);
+    if (p->method_choice == 2) ok = ok && dalloc(b, o.vox, B * (size_t)d.Hcap) && dalloc(b, *reinterpret_cast<unsigned char **>(&o.vrec), B * 2 * K * 32);
     ok = ok && dalloc(b, o.moving, B * (K / 32 + 2)) && hipMemset(o.moving, 0, B * (K / 32 + 2) * sizeof(unsigned)) == hipSuccess && dalloc(b, o.out_desc, B * T) && hipMemset(o.out_desc, 0, B * T * sizeof(unsigned long long)) == hipSuccess && halloc(b, o.h_nout, B) && halloc(b, o.h_noff, B);   // (the size mirrors of the filtered clouds too: the output kernels of consecutive frames need no order among themselves)
     ok = ok && dalloc(b, o.zmin_i, B) && dalloc(b, o.zmax_i, B) && hipMemsetD32((hipDeviceptr_t)o.zmin_i, 0x7fffffff, B) == hipSuccess && hipMemsetD32((hipDeviceptr_t)o.zmax_i, (int)0x80000000, B) == hipSuccess && dalloc(b, o.zorg, B) && dalloc(b, o.zbase, B) && hipMemset(o.zbase, 0, B * sizeof(int)) == hipSuccess && dalloc(b, o.mode_bin, B);
     if (ok) ok = hipMemcpy(o.zorg, z0.data(), B * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;

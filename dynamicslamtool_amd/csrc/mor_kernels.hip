@@ -2050,6 +2050,7 @@ __global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
       st_agent_f4(&d.amin[d.cur][ko + k], make_float4(r.lx, r.ly, r.lz, 0.f));
       st_agent_f4(&d.amax[d.cur][ko + k], make_float4(r.hx, r.hy, r.hz, 0.f));
       st_agent(&d.pair_of_cur[ko + k], -1);
+      if (d.method == 2) st_agent(&d.vrec[2 * ko + d.Kcap + k].pr, -1);
     }
   }
   }
@@ -2115,6 +2116,7 @@ __device__ __forceinline__ void xform_fin_body(const MorDev &d, int s) {
     d.xamin[(size_t)s * d.Kcap + k] = make_float4(r.mnx, r.mny, r.mnz, 0.f);
     d.xamax[(size_t)s * d.Kcap + k] = make_float4(r.mxx, r.mxy, r.mxz, 0.f);
     d.pair_of_prev[(size_t)s * d.Kcap + k] = -1;
+    if (d.method == 2) d.vrec[2 * (size_t)s * d.Kcap + k].pr = -1;
     d.qrec[2 * ((size_t)s * d.Kcap + k)] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));   // no pair (pairs_body fills in the matched ones)
   }
 }
@@ -2145,6 +2147,18 @@ __device__ __forceinline__ void nn_centroid_body(const MorDev &d, int s, int dir
     }
   }
 }
+// lattice origin of a pair's voxel set: the first point p0 of the previous cluster (after the transform) − res/2, moved down by what getKeyBitSize adds (fp64, per axis)
+__device__ __forceinline__ void vox_anchor(const MorDev &d, const float4 &p0, double (&mn)[3]) {
+  const double res = d.opc_res, eps = (double)FLT_EPSILON;
+  const float p0c[3] = {p0.x, p0.y, p0.z};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    double lo = (double)p0c[a] - res / 2, hi = (double)p0c[a] + res / 2;
+    const double over = (2.0 * res - (hi - lo)) / 2.0;
+    if (over > eps && !d.opc_anchor_half) lo -= over;   // getKeyBitSize on the empty tree re-centres the first box (mor_params.opc_anchor = 1: it does not)
+    mn[a] = lo;
+  }
+}
 // reciprocal test + volumeConstraint (:264-283), correspondences emitted in source-index order
 __device__ __forceinline__ void pairs_body(const MorDev &d, int s, int *sh) {
   const int Kp = d.slot_kc[d.prev][s].x, Kc = d.info[s].K;
@@ -2168,6 +2182,10 @@ __device__ __forceinline__ void pairs_body(const MorDev &d, int s, int *sh) {
       int pr = carry + e;
       d.pair_q[ko + pr] = i; d.pair_m[ko + pr] = j; d.pair_d[ko + pr] = d.nn_fwd_d[ko + i]; d.pair_cnt[ko + pr] = 0;
       d.pair_of_prev[ko + i] = pr; d.pair_of_cur[ko + j] = pr;
+      if (d.method == 2) {   // (ca's record and cb's: the lattice hangs on ca's first point after the transform, xfirst — written by this workgroup, above)
+        MorVoxRec vr; vox_anchor(d, d.xfirst[ko + i], vr.mn); vr.pr = pr; vr.pad = 0;
+        d.vrec[2 * ko + i] = vr; d.vrec[2 * ko + d.Kcap + j] = vr;
+      }
       const float4 c0 = ld_agent_f4(&d.amin[d.cur][ko + j]), c1 = ld_agent_f4(&d.amax[d.cur][ko + j]);
       d.qrec[2 * (ko + i)] = make_float4(c0.x, c0.y, c0.z, __int_as_float(pr)); d.qrec[2 * (ko + i) + 1] = make_float4(c1.x, c1.y, c1.z, __int_as_float(j));
     }
@@ -2672,19 +2690,13 @@ __global__ __launch_bounds__(SCP_T) void k_score_pde(MorDev d) {
 #define VOX_EMPTY 0xFFFFFFFFFFFFFFFFull
 __device__ __forceinline__ int vox_table_size(const MorDev &d, int Cprev) { int h = 64; while (h < 2 * Cprev && h < d.Hcap) h <<= 1; return h; }
 __device__ __forceinline__ unsigned long long vox_hash(unsigned long long k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; }
-__device__ __forceinline__ bool vox_key(const MorDev &d, int s, int pr, float4 p, unsigned long long &key) {
-  const size_t ko = (size_t)s * d.Kcap;
-  int q = d.pair_q[ko + pr];
-  const float4 p0 = d.xfirst[ko + q];   // clusters[q][0] of ca after the transform: the first point the octree sees
-  const double res = d.opc_res, eps = (double)FLT_EPSILON;
-  long long kk[3]; const float pc[3] = {p.x, p.y, p.z}, p0c[3] = {p0.x, p0.y, p0.z};
+__device__ __forceinline__ bool vox_key(const MorDev &d, int pr, const double (&mn)[3], float4 p, unsigned long long &key) {
+  const double res = d.opc_res;
+  long long kk[3]; const float pc[3] = {p.x, p.y, p.z};
   bool ok = pr < 65535;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    double mn = (double)p0c[a] - res / 2, mx = (double)p0c[a] + res / 2;
-    double over = (2.0 * res - (mx - mn)) / 2.0;
-    if (over > eps && !d.opc_anchor_half) mn -= over;   // getKeyBitSize on the empty tree re-centres the first box (mor_params.opc_anchor = 1: it does not)
-    kk[a] = (long long)floor(((double)pc[a] - mn) / res);
+    kk[a] = (long long)floor(((double)pc[a] - mn[a]) / res);
     ok = ok && kk[a] >= -32768 && kk[a] < 32768;
   }
   key = ((unsigned long long)pr << 48) | ((unsigned long long)(kk[0] + 32768) << 32) | ((unsigned long long)(kk[1] + 32768) << 16) | (unsigned long long)(kk[2] + 32768);
@@ -2696,34 +2708,51 @@ __global__ __launch_bounds__(MOR_BT) void k_vox_clear(MorDev d) {
   for (int i = blockIdx.x * MOR_BT + threadIdx.x; i < H; i += gridDim.x * MOR_BT) tab[i] = VOX_EMPTY;
 }
 __global__ __launch_bounds__(MOR_BT) void k_vox_insert(MorDev d) {
-  int s, t; map_block(d.B, d.tiles, s, t);
-  int pv = d.prev, Cp = d.slot_kc[d.prev][s].y, base = t * MOR_TILE;
-  if (base >= Cp) return;
+  int s, t, g;   // the launch's workgroups go to the streams in proportion to their cluster points (tiles of MOR_TILE)
+  if (!map_block_work(d, [&](int s_) { return (d.slot_kc[d.prev][s_].y + MOR_TILE - 1) / MOR_TILE; }, s, t, g)) return;
+  const int pv = d.prev, Cp = d.slot_kc[d.prev][s].y;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   unsigned long long *tab = d.vox + (size_t)s * d.Hcap; int H = vox_table_size(d, Cp);
+  for (int base = t * MOR_TILE; base < Cp; base += g * MOR_TILE)
   for (int j = base + threadIdx.x; j < min(base + MOR_TILE, Cp); j += MOR_BT) {
-    int pr = d.pair_of_prev[ko + d.cl_cid[pv][so + j]];
+    const MorVoxRec vr = d.vrec[2 * ko + d.cl_cid[pv][so + j]];
+    const int pr = vr.pr;
     if (pr < 0) continue;
     unsigned long long key;
-    if (!vox_key(d, s, pr, d.cl_pts[pv][so + j], key)) { mor_raise(d, s, 2u); continue; }
+    if (!vox_key(d, pr, vr.mn, d.cl_pts[pv][so + j], key)) { mor_raise(d, s, 2u); continue; }
     unsigned h = (unsigned)vox_hash(key) & (H - 1);
-    for (;;) { unsigned long long old = atomicCAS(&tab[h], VOX_EMPTY, key); if (old == VOX_EMPTY || old == key) break; h = (h + 1) & (H - 1); }
+    for (;;) {   // (a look first: most points find their voxel in the table already, and compare-and-swaps of many lanes on one slot queue up in L2)
+      unsigned long long old = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == VOX_EMPTY) old = atomicCAS(&tab[h], VOX_EMPTY, key);
+      if (old == VOX_EMPTY || old == key) break;
+      h = (h + 1) & (H - 1);
+    }
   }
 }
 __global__ __launch_bounds__(MOR_BT) void k_vox_probe(MorDev d) {
-  int s, t; map_block(d.B, d.tiles, s, t);
-  int C = d.info[s].C, base = t * MOR_TILE;
-  if (base >= C) return;
+  int s, t, g;
+  if (!map_block_work(d, [&](int s_) { return ((int)d.info[s_].C + MOR_TILE - 1) / MOR_TILE; }, s, t, g)) return;
+  const int C = d.info[s].C;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const unsigned long long *tab = d.vox + (size_t)s * d.Hcap; int H = vox_table_size(d, d.slot_kc[d.prev][s].y);
-  for (int j = base + threadIdx.x; j < min(base + MOR_TILE, C); j += MOR_BT) {
-    int pr = d.pair_of_cur[ko + d.cl_cid[d.cur][so + j]];
-    if (pr < 0) continue;
-    unsigned long long key;
-    if (!vox_key(d, s, pr, d.cl_pts[d.cur][so + j], key)) { mor_raise(d, s, 2u); continue; }
-    unsigned h = (unsigned)vox_hash(key) & (H - 1); bool found = false;
-    for (;;) { unsigned long long v = tab[h]; if (v == key) { found = true; break; } if (v == VOX_EMPTY) break; h = (h + 1) & (H - 1); }
-    if (!found) atomicAdd(&d.pair_cnt[ko + pr], 1);
+  for (int base = t * MOR_TILE; base < C; base += g * MOR_TILE)
+  for (int j0 = base; j0 < min(base + MOR_TILE, C); j0 += MOR_BT) {   // (all lanes stay in the loop: the counts of a wave are combined per pair before they go to memory)
+    const int j = j0 + threadIdx.x;
+    bool fresh = false; int pr = -1;
+    if (j < min(base + MOR_TILE, C)) {
+      const MorVoxRec vr = d.vrec[2 * ko + d.Kcap + d.cl_cid[d.cur][so + j]];
+      pr = vr.pr;
+      if (pr >= 0) {
+        unsigned long long key;
+        if (!vox_key(d, pr, vr.mn, d.cl_pts[d.cur][so + j], key)) mor_raise(d, s, 2u);
+        else {
+          unsigned h = (unsigned)vox_hash(key) & (H - 1); bool found = false;
+          for (;;) { unsigned long long v = tab[h]; if (v == key) { found = true; break; } if (v == VOX_EMPTY) break; h = (h + 1) & (H - 1); }
+          fresh = !found;   // a point of cb in a voxel that holds no point of ca (:319-330)
+        }
+      }
+    }
+    count_push(fresh, d.pair_cnt + ko, pr);   // (one atomic per wave and pair: thousands of single adds to a pair's counter serialise in L2 — 180 µs of this kernel)
   }
 }
 
@@ -3592,8 +3621,8 @@ static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
       }
     } else if (d.method == 2) {
       MOR_LAUNCH(MK_VOX_CLEAR, k_vox_clear, dim3(64, d.B), d);
-      MOR_LAUNCH(MK_VOX_INSERT, k_vox_insert, gT, d);
-      MOR_LAUNCH(MK_VOX_PROBE, k_vox_probe, gT, d);
+      MOR_LAUNCH(MK_VOX_INSERT, k_vox_insert, dim3(d.B * 2 * d.g_out), d);   // (cluster points of ca / cb: at most the cloud; 1024-point half tiles would do, so twice the cloud's width)
+      MOR_LAUNCH(MK_VOX_PROBE, k_vox_probe, dim3(d.B * 2 * d.g_out), d);
     }
   }
 }
