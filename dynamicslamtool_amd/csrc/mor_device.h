@@ -118,9 +118,8 @@ struct MorDev {
   int *tile_cnt;             // [B][tiles_max][2]   (non-ground, ground) counts per tile
   unsigned long long *split_desc; // [B][tiles_max]  look-back descriptors of the single-pass split (status | non-ground | ground)
   float4 *cloud;             // [B][Nmax]  non-ground points, input order (`cloud`, :85)
-  int *cloud_tidx;           // [B][Nmax]  index of each cloud point in the trimmed cloud
   float4 *ground;            // [B][2·Nmax]  slots [Nmax, Nmax+G): removed points in order (raw_cloud[gp_indices], :683); slots [Nmax − n_keep, Nmax): the kept cloud points after filterCloud — together the filtered cloud, assembled in place
-  int *gp_idx;               // [B][Nmax]  gp_indices (:86)
+  unsigned long long *cls_mask; int cls_rows;   // [B][cls_rows][2]  per 64 input records of the split: which went to `cloud`, which to the ground — gp_indices (:86) and the cloud points' indices in the trimmed cloud are rebuilt from them on the host
   float4 *rawbuf;            // [B][Nmax]  trimmed cloud (voxel ground variant only)
   int *is_ground;            // [B][Nmax]  per trimmed point
   float4 *vcent; int *vbin;  // [B][Nmax]  voxel centroids (dsc, :113) and bin id of accepted voxels

@@ -415,6 +415,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   d.Wcap = (int)(N / MOR_CHUNK + K + 2);
   d.gc_chunks = (int)(N / MOR_GC_CHUNK + 1); d.gc_P = 1;
   d.rs16_stride = (int)(((size_t)std::max(d.g.nrows, d.gv.nrows) + 1 + 7) & ~(size_t)7);
+  d.cls_rows = (int)((N + 63) / 64);
   d.cx16_stride = (int)((N + 2) & ~(size_t)1);   // even, and one entry beyond the last cell (the scoring tiers copy the table two entries at a time)
   d.moving_confidence = n_bad; d.static_confidence = n_good; d.leave_off = p->leave_off_distance; d.catch_up = p->catch_up_distance;
   // ---- shared by all frames: the cluster arrays (frame-slotted: cb, ca and the frames in flight behind them), the tracking state (strictly
@@ -438,7 +439,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     MorDev o = d; MorStreamArgs *dargs = nullptr;
     ok = dalloc(b, dargs, B) && dalloc(b, o.info, B) && hipMemset(o.info, 0, B * sizeof(MorFrameInfo)) == hipSuccess && dalloc(b, o.tickets, B * 8) && hipMemset(o.tickets, 0, B * 8 * sizeof(int)) == hipSuccess;
     ok = ok && dalloc(b, o.tile_cnt, B * T * 2) && dalloc(b, o.split_desc, B * T) && hipMemset(o.split_desc, 0, B * T * sizeof(unsigned long long)) == hipSuccess;   // (frame tags of the single-read split start at 1)
-    ok = ok && dalloc(b, o.cloud, B * N) && dalloc(b, o.cloud_tidx, B * N) && dalloc(b, o.ground, 2 * B * N) && dalloc(b, o.gp_idx, B * N) && dalloc(b, o.pkey, B * N) && dalloc(b, o.pslot, B * N) && dalloc(b, o.gc_list, B * N) && dalloc(b, o.gc_ent, B * N) && dalloc(b, o.gc_n, B * (size_t)d.gc_chunks) && dalloc(b, o.gc_tab, B * (size_t)16384) && dalloc(b, o.gc_tabsel, B);
+    ok = ok && dalloc(b, o.cloud, B * N) && dalloc(b, o.ground, 2 * B * N) && dalloc(b, o.cls_mask, B * (size_t)d.cls_rows * 2) && dalloc(b, o.pkey, B * N) && dalloc(b, o.pslot, B * N) && dalloc(b, o.gc_list, B * N) && dalloc(b, o.gc_ent, B * N) && dalloc(b, o.gc_n, B * (size_t)d.gc_chunks) && dalloc(b, o.gc_tab, B * (size_t)16384) && dalloc(b, o.gc_tabsel, B);
     ok = ok && dalloc(b, o.gh_rowlist, B * N) && dalloc(b, o.gh_cells, B * N) && dalloc(b, o.gh_rowfill, B * R1) && dalloc(b, o.gh_key, B * (size_t)d.Hcell) && dalloc(b, o.gh_val, B * (size_t)d.Hcell);
     ok = ok && dalloc(b, o.ckey, B * N) && dalloc(b, o.cstart, B * (N + 1)) && dalloc(b, o.row_start, B * R1) && dalloc(b, o.cmin, B * N) && dalloc(b, o.cmeta, 2 * B * N) && dalloc(b, o.crep, B * N) && dalloc(b, o.sorted, B * N) && dalloc(b, o.scell, B * N) && dalloc(b, o.csum, B * N);
     ok = ok && dalloc(b, o.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_p, B) && dalloc(b, o.lroot_a, B * N) && dalloc(b, o.lroot_b, B * N) && dalloc(b, o.parent, B * N) && dalloc(b, o.parent2, B * N) && dalloc(b, o.cg_ovf, B * (size_t)MOR_MAXP * MOR_CGS_OVF * 2);
@@ -698,17 +699,44 @@ int mor_get_counts(const mor_batch *b, int s, mor_counts *o) {
   { int n_mo = 0; HIP_TRY(hipMemcpy(&n_mo, &d.tr[s].n_mo, sizeof(int), hipMemcpyDeviceToHost)); o->n_tracks = (uint32_t)n_mo; }
   return MOR_OK;
 }
+// the split's class masks (two 64-bit words per 64 input records: cloud, ground) → for every cloud point / ground point, in order, its index in the trimmed cloud
+static int trimmed_indices(const mor_batch *b, int s, std::vector<int> *cloud_ti, std::vector<int> *ground_ti) {
+  const MorDev &d = b->d; const MorFrameInfo &f = d.h_info[s];
+  const uint32_t n_in = d.gmode ? f.T : f.N;   // (voxel ground variant: pass B splits the trimmed cloud)
+  const size_t rows = ((size_t)n_in + 63) / 64;
+  std::vector<unsigned long long> m(rows * 2);
+  if (rows) HIP_TRY(hipMemcpy(m.data(), d.cls_mask + (size_t)s * d.cls_rows * 2, rows * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (cloud_ti) cloud_ti->clear();
+  if (ground_ti) ground_ti->clear();
+  int t = 0;
+  for (size_t r = 0; r < rows; ++r) {
+    const unsigned long long ng = m[2 * r], g = m[2 * r + 1];
+    for (unsigned long long any = ng | g; any; any &= any - 1) {
+      const int l = __builtin_ctzll(any);
+      if ((ng >> l) & 1ull) { if (cloud_ti) cloud_ti->push_back(t); } else if (ground_ti) ground_ti->push_back(t);
+      ++t;
+    }
+  }
+  return MOR_OK;
+}
 int mor_get_labels(const mor_batch *b, int s, int32_t *lab) {
   CHECK_STREAM();
-  std::vector<int> pc(f.M), ti(f.M);
-  if (f.M) { HIP_TRY(hipMemcpy(pc.data(), d.pcid + so, f.M * sizeof(int), hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(ti.data(), d.cloud_tidx + so, f.M * sizeof(int), hipMemcpyDeviceToHost)); }
+  std::vector<int> pc(f.M), ti;
+  if (f.M) HIP_TRY(hipMemcpy(pc.data(), d.pcid + so, f.M * sizeof(int), hipMemcpyDeviceToHost));
+  const int rc = trimmed_indices(b, s, &ti, nullptr);
+  if (rc != MOR_OK) return rc;
+  if (ti.size() != f.M) return set_error(MOR_ERR_HIP, "stream %d: class masks name %zu cloud points, the frame has %u", s, ti.size(), f.M);
   for (uint32_t i = 0; i < f.T; ++i) lab[i] = -2;
   for (uint32_t i = 0; i < f.M; ++i) lab[ti[i]] = pc[i];
   return MOR_OK;
 }
 int mor_get_ground_indices(const mor_batch *b, int s, int32_t *idx) {
   CHECK_STREAM();
-  if (f.G) HIP_TRY(hipMemcpy(idx, d.gp_idx + so, f.G * sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<int> gi;
+  const int rc = trimmed_indices(b, s, nullptr, &gi);
+  if (rc != MOR_OK) return rc;
+  if (gi.size() != f.G) return set_error(MOR_ERR_HIP, "stream %d: class masks name %zu ground points, the frame has %u", s, gi.size(), f.G);
+  if (f.G) memcpy(idx, gi.data(), f.G * sizeof(int));
   return MOR_OK;
 }
 // cluster_indices (:218) in the reference's order — cluster after cluster, ascending cloud index inside a cluster —

@@ -390,12 +390,11 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
       int cx, cy, cz; bool clamped; grid_cell(G, p[it], zorg, zbase, cx, cy, cz, clamped);
       if (clamped && d.gmode != 0) mor_raise(d, s, 8u);   // z extent beyond the grid: cells would no longer be cliques / voxels
       d.cloud[so + k_ng] = p[it];
-      d.cloud_tidx[so + k_ng] = k_ng + k_g;   // index in the trimmed cloud (both ranks are exclusive counts of earlier kept points)
       d.pkey[so + k_ng] = grid_key(G, cx, cy, cz);
     } else if (cls[it] == 1) {
       st_stream(&d.ground[2 * so + d.Nmax + k_g], p[it]);   // final place in filterCloud's output: [kept cloud, right-aligned to slot Nmax | ground from slot Nmax]
-      st_stream(&d.gp_idx[so + k_g], k_ng + k_g);
     }
+    if (lane_id() == 0 && base + it * 64 < n_in) { unsigned long long *cm = d.cls_mask + ((size_t)s * d.cls_rows + (base + it * 64) / 64) * 2; cm[0] = m_ng[it]; cm[1] = m_g[it]; }   // the classes of these 64 records (split_store)
     r_ng += __popcll(m_ng[it]); r_g += __popcll(m_g[it]);
   }
   __syncthreads();
@@ -446,7 +445,12 @@ template <bool PASSB> __device__ __forceinline__ void split_count(const MorDev &
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int c = split_class<PASSB>(d, n_in, base + it * 64, p[it], cls[it]);
-    c_ng += __popcll(__ballot(c == 2)); c_g += __popcll(__ballot(c == 1));
+    const unsigned long long m_ng = __ballot(c == 2), m_g = __ballot(c == 1);
+    c_ng += __popcll(m_ng); c_g += __popcll(m_g);
+    // gp_indices (:86) and the trimmed-cloud index of every cloud point are read-backs only: instead of 4 bytes per trimmed point the split leaves the
+    // classes of every 64 records as two bit masks (16 bytes: cloud, ground; rows that hold records only — a tile reaches beyond the stream's slice of the
+    // array); the host rebuilds the index lists from them when asked (mor_get_ground_indices, mor_get_labels)
+    if (lane_id() == 0 && base + it * 64 < n_in) { unsigned long long *cm = d.cls_mask + ((size_t)s * d.cls_rows + (base + it * 64) / 64) * 2; cm[0] = m_ng; cm[1] = m_g; }
   }
   if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
   __syncthreads();
@@ -499,15 +503,14 @@ template <bool PASSB> __device__ __forceinline__ void split_store(const MorDev &
       int cx, cy, cz; bool clamped; grid_cell(G, p[it], zorg, zbase, cx, cy, cz, clamped);
       if (clamped && d.gmode != 0) mor_raise(d, s, 8u);
       d.cloud[so + k_ng] = p[it];
-      d.cloud_tidx[so + k_ng] = k_ng + k_g; d.pkey[so + k_ng] = grid_key(G, cx, cy, cz);
+      d.pkey[so + k_ng] = grid_key(G, cx, cy, cz);
     } else if (c == 1) {
       st_stream(&d.ground[2 * so + d.Nmax + k_g], p[it]);   // final place in filterCloud's output
-      st_stream(&d.gp_idx[so + k_g], k_ng + k_g);
     }
     r_ng += __popcll(m_ng); r_g += __popcll(m_g);
   }
 }
-template <bool PASSB> __global__ __launch_bounds__(MOR_BT, 4) void k_split(MorDev d) {   // (≤ 128 VGPRs: four workgroups per CU; the compiler left to itself wanders between 126 and 150 registers with unrelated edits — at 150 the split took 115 instead of 89 µs)   // (≤ 128 VGPRs: four workgroups per CU — the compiler's own choice wanders between 126 and 150 registers with unrelated edits, and at 150 the split is 115 instead of 89 µs)
+template <bool PASSB> __global__ __launch_bounds__(MOR_BT, 4) void k_split(MorDev d) {   // (≤ 128 VGPRs: four workgroups per CU; the compiler left to itself wanders between 126 and 150 registers with unrelated edits — at 150 the split took 115 instead of 89 µs)
   int s, g; map_block(d.B, d.sp_g, s, g);
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   // As the first kernel of a frame (crop variant) this one reads the stream's arguments straight from the page-locked slot the host filled,
