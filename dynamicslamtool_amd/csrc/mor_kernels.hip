@@ -3314,7 +3314,7 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
           }
           __syncthreads();
         }
-        __threadfence();   // appended centroids: visible to the pass of the next batch (and to the later kernels anyway)
+        __threadfence_block();   // appended centroids: visible to the pass of the next batch — the same wave (one-wave workgroup), so workgroup scope will do: an agent-scope fence writes back the XCD's whole L2, 64 times per step here (the later kernels see them by the kernel boundary)
         __syncthreads();
       }
     }
