@@ -474,6 +474,9 @@ template <bool PASSB> __device__ __forceinline__ void split_store(const MorDev &
         unsigned spins = 0;
         for (;;) {
           const unsigned long long v = ld_agent64(&desc[u]);
+#ifdef MOR_EXP_SPLITVAR
+          if ((d.t1_budget >> 16) & 1) break;   // experiment (exp/split_var.py): no look-back wait — prefixes are wrong, only the duration is read
+#endif
           if ((unsigned)(v >> 32) == epoch) { an += (int)((v >> 16) & 0xffffu); ag += (int)(v & 0xffffu); break; }
           if (++spins > SPLIT_SPIN_LIMIT) { mor_raise(d, s, 64u); break; }
           __builtin_amdgcn_s_sleep(1);
@@ -505,6 +508,9 @@ template <bool PASSB> __device__ __forceinline__ void split_store(const MorDev &
       d.cloud[so + k_ng] = p[it];
       d.pkey[so + k_ng] = grid_key(G, cx, cy, cz);
     } else if (c == 1) {
+#ifdef MOR_EXP_SPLITVAR
+      if (!((d.t1_budget >> 17) & 1))   // experiment: no ground stores
+#endif
       st_stream(&d.ground[2 * so + d.Nmax + k_g], p[it]);   // final place in filterCloud's output
     }
     r_ng += __popcll(m_ng); r_g += __popcll(m_g);
@@ -537,6 +543,23 @@ template <bool PASSB> __global__ __launch_bounds__(MOR_BT, 4) void k_split(MorDe
   int t = __builtin_amdgcn_readfirstlane(s_ex[5]), t1 = t + 1, t_prev = -1;
   int ex_ng = 0, ex_g = 0;
   float4 pa[8], pb[8]; int ca[8], cb[8];
+#ifdef MOR_EXP_SPLITVAR
+  if ((d.t1_budget >> 19) & 1) {   // experiment: pure read of the stream's tiles (static tiles, two in flight), one dummy store
+    float acc = 0.f;
+    for (int tt = g; tt < nt; tt += 2 * d.sp_g) {
+      split_load_tile<PASSB>(d, a, s, n_in, tt, pa, ca);
+      if (tt + d.sp_g < nt) split_load_tile<PASSB>(d, a, s, n_in, tt + d.sp_g, pb, cb);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) acc += pa[it].x + pa[it].w;
+      if (tt + d.sp_g < nt) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) acc += pb[it].y;
+      }
+    }
+    if (acc == 12345.678f) d.cloud[(size_t)s * d.Nmax] = make_float4(acc, 0, 0, 0);
+    return;
+  }
+#endif
   SplitMeta ma, mb;
   if (t < nt) split_load_tile<PASSB>(d, a, s, n_in, t, pa, ca);
   if (t1 < nt) split_load_tile<PASSB>(d, a, s, n_in, t1, pb, cb);

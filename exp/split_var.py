@@ -1,5 +1,7 @@
-"""Timing attribution of k_split: library built with the experiment hooks (exp/libmor_splitvar.so, see exp/README.md), MOR_SPLIT_VARIANT bit 0 = no look-back
-wait (prefixes wrong), bit 1 = no ground stores.  Results are wrong for variants > 0; only the kernel's duration (synchronous steps, alone) is read."""
+"""Timing attribution of k_split: library built with -DMOR_EXP_SPLITVAR as exp/libmor_splitvar.so (same hipcc line as dynamicslamtool_amd/build.py);
+MOR_SPLIT_VARIANT bit 0 = no look-back wait (prefixes wrong), bit 1 = no ground stores, bit 3 (8) = pure read of the tiles.  Results are wrong for
+variants > 0; only the kernel's duration (synchronous steps, alone) is read.  Round 4, B = 64 × 120 000 points: full 81–98 µs, no wait + no ground
+stores 62–74 µs, pure read 44 µs (123 MB: 2.8 TB/s)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = r'''
