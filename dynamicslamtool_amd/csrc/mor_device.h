@@ -56,7 +56,7 @@ struct MorFrameInfo {        // per stream, produced on device
 #define MOR_MAX_DEPTH 8     // frames in flight in the stage pipeline, at most (one copy of every per-frame array each)
 #define MOR_MAX_SLOTS 10     // cluster-array slots (depth + 1 are in use)
 #define MOR_MAXP 32        // slabs per stream of the cell graph (k_cg_slab), at most
-#define MOR_CGS_FCAP 6300  // cells per stream the fused merge at the tail of k_cg_slab holds in LDS (beyond: its global-memory path; the host then prefers the separate k_cg_final)
+#define MOR_CGS_FCAP 9400  // cells per stream the fused merge at the tail of k_cg_slab holds in LDS (beyond: its global-memory path; the host then prefers the separate k_cg_final)
 #define MOR_GC_CHUNK 2048   // points per chunk of the grid build (k_gridcount / k_gridplace)
 #define MOR_CGS_OVF 8192   // overflow entries per slab of its candidate-pair lists (beyond them a pair is settled on the spot)
 #define MOR_TR_MAXT 32768  // tracked moving centroids per stream (mo_vec); the reference has no bound — beyond this one the push reports MOR_ERR_CAPACITY

@@ -1623,15 +1623,15 @@ template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_body(const Mo
   }
   ST2(stwj, 9); ST2V(stwj, 14, n_own); ST2V(stwj, 15, n_loc);
 }
-template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDev &d, int s, int nocc, int *par, int *size, int *mn, int *cidr, int *l_misc, const int *l_sc, const int *l_se);
+template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDev &d, int s, int nocc, int *par, int *scr, int *l_misc, const int *l_sc, const int *l_se);
 // CAP: local cells (own + look-ahead) the workgroup holds in LDS (76 KB: two workgroups per CU).
 // With d.cg_fused the stream's LAST slab workgroup to finish (stream_last_block) goes on with the merge of the slab forests and everything
 // k_cg_final does, in the same LDS (three arrays of CGS_FCAP cells; streams with more cells: global-memory arrays) — one launch and one
 // queueing delay less per frame; the host falls back to the separate k_cg_final launch (147 KB of LDS: 12 288 cells) when the previous
 // frame's cell counts say a stream would not fit.
 #define CGS_SLAB_WORDS (12 * CGS_CAP + CGS_ROWCAP + 1 + CGS_LISTW + CGS_NW * CGS_QW)
-#define CGS_ARENA (CGS_SLAB_WORDS > 3 * MOR_CGS_FCAP ? CGS_SLAB_WORDS : 3 * MOR_CGS_FCAP)   // (the slab layout of the default build is 18 945 words)
-#define CGS_FCAP (CGS_ARENA / 3)
+#define CGS_ARENA (CGS_SLAB_WORDS > 2 * MOR_CGS_FCAP ? CGS_SLAB_WORDS : 2 * MOR_CGS_FCAP)   // (the slab layout of the default build is 18 945 words)
+#define CGS_FCAP (CGS_ARENA / 2)
 template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d, int s, int j, int *l_arena, int *l_wcnt, int *l_n2p);
 template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {   // (keep it at ≤ 128 VGPRs — two workgroups per CU; a loop over several slabs per workgroup took 157: 228 → 350 µs in the pipeline)
   int s, j, Ps;
@@ -1646,16 +1646,16 @@ template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) 
   __shared__ int l_misc[1 + CGS_T / 64], l_sc[MOR_MAXP + 1], l_se[MOR_MAXP + 1];
   if (threadIdx.x <= Ps) { l_sc[threadIdx.x] = d.slab_c[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; l_se[threadIdx.x] = d.slab_e[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; }
   if (nocc <= CGS_FCAP && !d.cg_force_global) {
-    int *l_par = l_arena, *l_a = l_arena + CGS_FCAP, *l_b = l_arena + 2 * CGS_FCAP;
+    int *l_par = l_arena, *l_a = l_arena + CGS_FCAP;
     for (int i = threadIdx.x; i < nocc; i += CGS_T) l_par[i] = i;
     __syncthreads();
-    cgf_body<true, CGS_T>(d, s, nocc, l_par, l_a, l_b, l_a, l_misc, l_sc, l_se);
+    cgf_body<true, CGS_T>(d, s, nocc, l_par, l_a, l_misc, l_sc, l_se);
   } else {
     int *par = d.parent + so;
     for (int i = threadIdx.x; i < nocc; i += CGS_T) cg_st<false>(par + i, i);
     __threadfence();
     __syncthreads();
-    cgf_body<false, CGS_T>(d, s, nocc, par, d.csize + so, d.compmin + so, d.cid_of_root + so, l_misc, l_sc, l_se);
+    cgf_body<false, CGS_T>(d, s, nocc, par, d.csize + so, l_misc, l_sc, l_se);
   }
 }
 template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d, int s, int j, int *l_arena, int *l_wcnt, int *l_n2p) {
@@ -1717,9 +1717,13 @@ template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d,
 #define CGF_T 1024
 #endif
 #ifndef CGF_CAP
-#define CGF_CAP 12288
+#define CGF_CAP 18432
 #endif
-template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDev &d, int s, int nocc, int *par, int *size, int *mn, int *cidr, int *l_misc, const int *l_sc, const int *l_se) {
+// Two arrays of nocc ints besides the forest: `par` and ONE scratch array that is, in turn, the components' sizes, their smallest cloud indices, the
+// roots' cluster ids and two per-cluster cursors (round 3 kept sizes and minima side by side: three arrays, 6 300 cells in the slab workgroup's LDS; two
+// arrays hold 9 400, so the street scenes and the 262 144-point clouds merge inside k_cg_slab too).  kscr: 2·K ints of scratch when 2·K > nocc (never in practice).
+template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDev &d, int s, int nocc, int *par, int *scr, int *l_misc, const int *l_sc, const int *l_se) {
+  int *size = scr, *mn = scr, *cidr = scr;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1);
   const int lane = lane_id(), P = d.slab_p[s];
@@ -1734,11 +1738,11 @@ template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDe
   __syncthreads();
   for (int c = threadIdx.x; c < nocc; c += NT) { const int r = cg_find<LDS>(par, c); if (r != c) cg_st<LDS>(par + c, r); }
   __syncthreads();
-  // ---- components: size (points) and smallest cloud index at the root
-  for (int c = threadIdx.x; c < nocc; c += NT) { cg_st<LDS>(size + c, 0); cg_st<LDS>(mn + c, 0x7fffffff); }
+  // ---- components: size (points) at the root
+  for (int c = threadIdx.x; c < nocc; c += NT) cg_st<LDS>(size + c, 0);
   __threadfence_block();
   __syncthreads();
-  for (int c = threadIdx.x; c < nocc; c += NT) { const int r = cg_ld<LDS>(par + c); atomicAdd(&size[r], start[c + 1] - start[c]); atomicMin(&mn[r], d.cmin[so + c]); }
+  for (int c = threadIdx.x; c < nocc; c += NT) { const int r = cg_ld<LDS>(par + c); atomicAdd(&size[r], start[c + 1] - start[c]); }
   __threadfence_block();
   __syncthreads();
   // ---- kept components (:215-216) → scratch list; K
@@ -1749,7 +1753,7 @@ template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDe
     const long long n = root ? (long long)cg_ld<LDS>(size + c) : 0;
     if (root && n >= d.min_cs && n <= d.max_cs) {
       const int k = atomicAdd(&l_misc[0], 1);
-      if (k < d.Kcap) { d.kcell[ko + k] = c; d.kroot[ko + k] = cg_ld<LDS>(mn + c); d.ksize[ko + k] = (int)n; }
+      if (k < d.Kcap) { d.kcell[ko + k] = c; d.ksize[ko + k] = (int)n; }
     }
   }
   __threadfence_block();
@@ -1757,7 +1761,17 @@ template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDe
   int K = l_misc[0];
   if (K > d.Kcap) { if (threadIdx.x == 0) mor_raise(d, s, 1u); K = d.Kcap; }
   __syncthreads();
-  // ---- cluster order: size descending, ties by smaller first cloud index; rank by counting (cidr may alias `size`: sizes were copied to ksize)
+  // ---- smallest cloud index of every component at its root (the scratch array again: the sizes of the kept ones are in ksize)
+  for (int c = threadIdx.x; c < nocc; c += NT) cg_st<LDS>(mn + c, 0x7fffffff);
+  __threadfence_block();
+  __syncthreads();
+  for (int c = threadIdx.x; c < nocc; c += NT) atomicMin(&mn[cg_ld<LDS>(par + c)], d.cmin[so + c]);
+  __threadfence_block();
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += NT) d.kroot[ko + k] = cg_ld<LDS>(mn + d.kcell[ko + k]);
+  __threadfence_block();
+  __syncthreads();
+  // ---- cluster order: size descending, ties by smaller first cloud index; rank by counting (the scratch array becomes the roots' cluster ids)
   for (int c = threadIdx.x; c < nocc; c += NT) cg_st<LDS>(cidr + c, -1);
   __threadfence_block();
   __syncthreads();
@@ -1809,7 +1823,8 @@ template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDe
   //      cell holding the cluster's first point (smallest cloud index), which takes the first piece.  (Any order will do:
   //      what is computed from cluster points — counts, existence tests, min / max, exact integer sums — does not depend
   //      on it; read-backs that promise the reference's order rebuild it from the labels.)
-  int *ncell = size, *cur = mn;   // both free by now: [K] cells per cluster → first list entry; next free slot of the cluster's range
+  int *ncell = scr, *cur = scr + K;   // the scratch array is free by now: [K] cells per cluster → first list entry; [K] next free slot of the cluster's range
+  if (2 * K > nocc) { ncell = d.ktile_cnt + (size_t)s * d.tiles_max; cur = d.nn_fwd + ko; }   // (more kept clusters than half the cells: K-sized scratch of other stages — min_cluster_size 1 on a sparse cloud; LDS-scope accesses on global memory are fine inside one workgroup after the barriers)
   __syncthreads();
   for (int k = threadIdx.x; k < K; k += NT) cg_st<LDS>(ncell + k, 0);
   __threadfence_block();
@@ -1856,18 +1871,18 @@ template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDe
 __global__ __launch_bounds__(CGF_T) void k_cg_final(MorDev d) {
   const int s = blockIdx.x + d.s0, nocc = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
-  __shared__ int l_par[CGF_CAP], l_a[CGF_CAP], l_b[CGF_CAP], l_misc[1 + CGF_T / 64], l_sc[MOR_MAXP + 1], l_se[MOR_MAXP + 1];
+  __shared__ int l_par[CGF_CAP], l_a[CGF_CAP], l_misc[1 + CGF_T / 64], l_sc[MOR_MAXP + 1], l_se[MOR_MAXP + 1];
   if (threadIdx.x <= d.slab_p[s]) { l_sc[threadIdx.x] = d.slab_c[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; l_se[threadIdx.x] = d.slab_e[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; }
   if (nocc <= CGF_CAP && !d.cg_force_global) {          // forest, sizes (then cluster ids), minima: three LDS arrays
     for (int i = threadIdx.x; i < nocc; i += CGF_T) l_par[i] = i;
     __syncthreads();
-    cgf_body<true, CGF_T>(d, s, nocc, l_par, l_a, l_b, l_a, l_misc, l_sc, l_se);
+    cgf_body<true, CGF_T>(d, s, nocc, l_par, l_a, l_misc, l_sc, l_se);
   } else {
     int *par = d.parent + so;
     for (int i = threadIdx.x; i < nocc; i += CGF_T) cg_st<false>(par + i, i);
     __threadfence();
     __syncthreads();
-    cgf_body<false, CGF_T>(d, s, nocc, par, d.csize + so, d.compmin + so, d.cid_of_root + so, l_misc, l_sc, l_se);
+    cgf_body<false, CGF_T>(d, s, nocc, par, d.csize + so, l_misc, l_sc, l_se);
   }
 }
 
