@@ -237,6 +237,9 @@ static int configure(mor_batch *b) {
 #ifdef MOR_EXP_SPLITVAR
   d.t1_budget |= (getenv("MOR_SPLIT_VARIANT") ? atoi(getenv("MOR_SPLIT_VARIANT")) : 0) << 16;   // experiment bits of exp/split_var.py (results are wrong with any of them set)
 #endif
+#ifdef MOR_EXP_T1CUT
+  d.t1_budget |= (getenv("MOR_EXP_T1") ? atoi(getenv("MOR_EXP_T1")) : 0) << 16;   // cut point of exp/t1exp.py
+#endif
   // test switches (defaults: the fast paths): MOR_GH_TIER=1|2 starts k_gridhash with its big LDS table / its global-memory table; MOR_CG_GLOBAL forces the global-memory forests
   d.gh_tier = getenv("MOR_GH_TIER") ? atoi(getenv("MOR_GH_TIER")) : 0; d.cg_force_global = getenv("MOR_CG_GLOBAL") ? 1 : 0;
   d.P = 1;

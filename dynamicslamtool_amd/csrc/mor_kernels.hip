@@ -2345,13 +2345,23 @@ __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
   const float4 *sp = d.sorted + so;
   __shared__ unsigned short l_idx[CIDX_CAP];
   if (t0 * SCF_T >= Cp) return;   // nothing for this workgroup: not worth a copy of the cell index
+#ifdef MOR_EXP_T1CUT
+  const int expv = d.t1_budget >> 16;   // experiment (exp/t1exp.py): cut tier 1 short — 1 before the cell index, 2 behind it, 3 behind the loads of the query, 4 before the scan, 5 before the pushes; results are wrong
+  if (expv == 1) return;
+#endif
   const CellIdx I = cidx_load(d, G, s, l_idx);
+#ifdef MOR_EXP_T1CUT
+  if (expv == 2) return;
+#endif
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float lbn = nextafterf(d.pde_lb, INFINITY);
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + G.cs * 1e-3f;
   const bool e1_local = 2.f * slb < G.cs;
   for (int base = t0 * SCF_T; base < Cp; base += g_fast * SCF_T) {
     const int j = base + threadIdx.x;
+#ifdef MOR_EXP_T1CUT
+    if (expv == 3) { if (j < Cp) { const int cidj = d.cl_cid[pv][so + j]; const float4 q = d.cl_pts[pv][so + j]; if (cidj == -12345 && q.x == 1.2345f) d.pair_cnt[ko] = 1; } continue; }
+#endif
     bool nearq = false, blockq = false, big = false, counted = false; float best = INFINITY; int pr = -1, target = -1;
 #ifdef MOR_EXP_ROUNDS
     int exp_rounds = 0, exp_cell = 0; bool exp_found = false;
@@ -2370,6 +2380,9 @@ __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
       const float4 tlo = d.qrec[2 * (ko + cidj)], thi = d.qrec[2 * (ko + cidj) + 1];   // the matched cluster's box, the pair, the matched cluster: one record per previous cluster (pairs_body)
       const int cc = max(c, 0), cid = d.ccid[so + cc], b0 = c >= 0 ? st[cc] : 0, e0 = c >= 0 ? st[cc + 1] : 0;
       pr = __float_as_int(tlo.w); target = __float_as_int(thi.w);
+#ifdef MOR_EXP_T1CUT
+      if (expv == 4) { if (cid == -12345 && b0 == -7 && e0 == -9 && pr == -12345) d.pair_cnt[ko] = 1; pr = -1; }
+#endif
 #ifdef MOR_EXP_STAMPS
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f1 = wall_clock64();
 #endif
@@ -2393,6 +2406,9 @@ __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); f2 = wall_clock64();
 #endif
     }
+#ifdef MOR_EXP_T1CUT
+    if (expv == 5) { if (nearq && blockq && big && counted) d.pair_cnt[ko] = 2; nearq = blockq = big = counted = false; }
+#endif
     {  // the worklists: both ends of `wl` with ONE returning atomic per wave (the two counters share a 64-bit word), `wl2` with another,
        // both issued by lane 0 before either answer is used (one round trip instead of two)
       const unsigned long long mn = __ballot(nearq), mb = __ballot(blockq), mg = __ballot(big);
