@@ -198,8 +198,12 @@ __device__ __forceinline__ float ld_f32_bytes(const char *p) {   // a float32 fi
   return __uint_as_float((unsigned)u[0] | ((unsigned)u[1] << 8) | ((unsigned)u[2] << 16) | ((unsigned)u[3] << 24));
 }
 __device__ __forceinline__ float4 load_point(const MorStreamArgs &a, uint32_t i) {
-  if (a.step == 16 && a.off_x == 0 && a.off_y == 4 && a.off_z == 8 && a.off_i == 12 && (reinterpret_cast<uintptr_t>(a.data) & 15) == 0)
-    return reinterpret_cast<const float4 *>(a.data)[i];
+  if (a.step == 16 && a.off_x == 0 && a.off_y == 4 && a.off_z == 8 && a.off_i == 12 && (reinterpret_cast<uintptr_t>(a.data) & 15) == 0) {
+    // the incoming cloud is read exactly once: a streaming (non-temporal) load, so that 123 MB per step do not push the frames' small hot tables out of the 4-MB L2s
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f w = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(a.data) + i);
+    return make_float4(w.x, w.y, w.z, w.w);
+  }
   const char *r = reinterpret_cast<const char *>(a.data) + (size_t)i * a.step;
   float4 p;
   const uint32_t oi = a.off_i == 0xFFFFFFFFu ? 0u : a.off_i;
