@@ -156,8 +156,13 @@ __device__ __forceinline__ void wg_prefix_total(const int *c, int stride, int t,
 __device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ void st_stream(float4 *p, const float4 &v) { *p = v; }   // (non-temporal stores for the ground points — 90 % of a sweep, read again only when the caller fetches the cloud — were measured: no gain)
-__device__ __forceinline__ void st_stream(int *p, int v) { *p = v; }
+// Streaming accesses: data that is written once and not read again soon (the ground points — 90 % of a sweep, read again only when the caller fetches the cloud;
+// the filtered cloud) or read exactly once (the incoming cloud, ca's cluster points in tier 1) goes past the caches with the non-temporal hint, so that it does not
+// push the frames' small hot tables out of the 4-MB L2s: the gather kernels live on their L2 hit rate.
+typedef float mor_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_stream(float4 *p, const float4 &v) { const mor_v4f w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<mor_v4f *>(p)); }
+__device__ __forceinline__ float4 ld_stream(const float4 *p) { const mor_v4f w = __builtin_nontemporal_load(reinterpret_cast<const mor_v4f *>(p)); return make_float4(w.x, w.y, w.z, w.w); }
+__device__ __forceinline__ int ld_stream(const int *p) { return __builtin_nontemporal_load(p); }
 
 __device__ __forceinline__ void st_agent_f(float *p, float v) { __hip_atomic_store(reinterpret_cast<int *>(p), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent_f(const float *p) { return __int_as_float(__hip_atomic_load(reinterpret_cast<const int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
@@ -2377,8 +2382,8 @@ __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
     if (j < Cp) {
       // two short chains of dependent loads, issued side by side (no branch between them): cluster → its record (pair, matched cluster,
       // that cluster's box), and point → cell (LDS index) → range + cluster id of the cell → points.  (Round 1: seven levels, one after the other.)
-      const int cidj = d.cl_cid[pv][so + j];
-      const float4 q = d.cl_pts[pv][so + j];
+      const int cidj = ld_stream(&d.cl_cid[pv][so + j]);
+      const float4 q = ld_stream(&d.cl_pts[pv][so + j]);   // (read once here; the few queries the later tiers take up again fetch theirs from HBM)
       const int cx = cell_axis_unclamped(q.x, G.ox, G.inv_cs), cy = cell_axis_unclamped(q.y, G.oy, G.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], G.inv_cs);
       const int c = cidx_find(I, cx, cy, cz);   // (LDS: no global access)
       const float4 tlo = d.qrec[2 * (ko + cidj)], thi = d.qrec[2 * (ko + cidj) + 1];   // the matched cluster's box, the pair, the matched cluster: one record per previous cluster (pairs_body)
@@ -3584,7 +3589,7 @@ __global__ __launch_bounds__(FLT_T) void k_out(MorDev d) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int i = base + it * 64 + lane_id();
-      if ((mk[it] >> lane_id()) & 1ull) dst[r + __popcll(mk[it] & lanemask_lt())] = d.cloud[so + i];
+      if ((mk[it] >> lane_id()) & 1ull) st_stream(&dst[r + __popcll(mk[it] & lanemask_lt())], ld_stream(&d.cloud[so + i]));   // (the filtered cloud is the caller's; the cloud is not read again on the device)
       r += __popcll(mk[it]);
     }
     t = __builtin_amdgcn_readfirstlane(l_ex[1]);
