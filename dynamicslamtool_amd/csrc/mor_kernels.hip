@@ -163,6 +163,7 @@ typedef float mor_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_stream(float4 *p, const float4 &v) { const mor_v4f w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<mor_v4f *>(p)); }
 __device__ __forceinline__ float4 ld_stream(const float4 *p) { const mor_v4f w = __builtin_nontemporal_load(reinterpret_cast<const mor_v4f *>(p)); return make_float4(w.x, w.y, w.z, w.w); }
 __device__ __forceinline__ int ld_stream(const int *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_stream(int *p, int v) { __builtin_nontemporal_store(v, p); }
 
 __device__ __forceinline__ void st_agent_f(float *p, float v) { __hip_atomic_store(reinterpret_cast<int *>(p), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent_f(const float *p) { return __int_as_float(__hip_atomic_load(reinterpret_cast<const int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
@@ -893,7 +894,7 @@ __global__ __launch_bounds__(GC_T) void k_gridcount(MorDev d) {
     const int i0 = c * GC_CHUNK, i1 = min(i0 + GC_CHUNK, M);
     int key[GC_U], sl[GC_U];
 #pragma unroll
-    for (int u = 0; u < GC_U; ++u) { const int i = i0 + u * GC_T + tid; key[u] = i < i1 ? pkey[i] : -1; }
+    for (int u = 0; u < GC_U; ++u) { const int i = i0 + u * GC_T + tid; key[u] = i < i1 ? ld_stream(&pkey[i]) : -1; }
 #pragma unroll
     for (int u = 0; u < GC_U; ++u) {
       // points arrive in scan order: neighbouring lanes often hold the same cell (a wall next to the sensor: all 64) — the first lane of a
@@ -955,7 +956,7 @@ __global__ __launch_bounds__(GC_T) void k_gridplace(MorDev d) {
     const int i0 = c * GC_CHUNK, i1 = min(i0 + GC_CHUNK, M);
     int en[GC_U]; float4 q[GC_U];
 #pragma unroll
-    for (int u = 0; u < GC_U; ++u) { const int i = i0 + u * GC_T + tid; en[u] = i < i1 ? pent[i] : -1; q[u] = cloud[min(i, max(M - 1, 0))]; }
+    for (int u = 0; u < GC_U; ++u) { const int i = i0 + u * GC_T + tid; en[u] = i < i1 ? ld_stream(&pent[i]) : -1; q[u] = ld_stream(&cloud[min(i, max(M - 1, 0))]); }
 #pragma unroll
     for (int u = 0; u < GC_U; ++u) {
       const bool valid = en[u] >= 0;
@@ -2057,9 +2058,9 @@ __global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
       for (int u = 0; u < 4; ++u) {
         const int j = j0 + u * stride;
         if (j >= M) continue;
-        d.pcid[so + __float_as_int(p[u].w)] = g[u].y;   // label of the cloud point (its index travels in .w)
+        st_stream(&d.pcid[so + __float_as_int(p[u].w)], g[u].y);   // label of the cloud point (its index travels in .w); read once more, by the output
         if (g[u].y < 0) continue;
-        dst[j + g[u].x] = p[u]; dcid[j + g[u].x] = g[u].y;
+        st_stream(&dst[j + g[u].x], p[u]); st_stream(&dcid[j + g[u].x], g[u].y);   // (cb's cluster points are read by the NEXT frame: streaming stores, they would only push this frame's cell-ordered points out of the L2 before its scoring tiers run)
         if (__float_as_int(p[u].w) == g[u].z) d.cl_first[d.cur][ko + g[u].y] = p[u];
       }
     }
@@ -2781,11 +2782,11 @@ __global__ __launch_bounds__(MOR_BT) void k_vox_insert(MorDev d) {
   unsigned long long *tab = d.vox + (size_t)s * d.Hcap; int H = vox_table_size(d, Cp);
   for (int base = t * MOR_TILE; base < Cp; base += g * MOR_TILE)
   for (int j = base + threadIdx.x; j < min(base + MOR_TILE, Cp); j += MOR_BT) {
-    const MorVoxRec vr = d.vrec[2 * ko + d.cl_cid[pv][so + j]];
+    const MorVoxRec vr = d.vrec[2 * ko + ld_stream(&d.cl_cid[pv][so + j])];
     const int pr = vr.pr;
     if (pr < 0) continue;
     unsigned long long key;
-    if (!vox_key(d, pr, vr.mn, d.cl_pts[pv][so + j], key)) { mor_raise(d, s, 2u); continue; }
+    if (!vox_key(d, pr, vr.mn, ld_stream(&d.cl_pts[pv][so + j]), key)) { mor_raise(d, s, 2u); continue; }
     unsigned h = (unsigned)vox_hash(key) & (H - 1);
     for (;;) {   // (a look first: most points find their voxel in the table already, and compare-and-swaps of many lanes on one slot queue up in L2)
       unsigned long long old = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2806,11 +2807,11 @@ __global__ __launch_bounds__(MOR_BT) void k_vox_probe(MorDev d) {
     const int j = j0 + threadIdx.x;
     bool fresh = false; int pr = -1;
     if (j < min(base + MOR_TILE, C)) {
-      const MorVoxRec vr = d.vrec[2 * ko + d.Kcap + d.cl_cid[d.cur][so + j]];
+      const MorVoxRec vr = d.vrec[2 * ko + d.Kcap + ld_stream(&d.cl_cid[d.cur][so + j])];
       pr = vr.pr;
       if (pr >= 0) {
         unsigned long long key;
-        if (!vox_key(d, pr, vr.mn, d.cl_pts[d.cur][so + j], key)) mor_raise(d, s, 2u);
+        if (!vox_key(d, pr, vr.mn, ld_stream(&d.cl_pts[d.cur][so + j]), key)) mor_raise(d, s, 2u);
         else {
           unsigned h = (unsigned)vox_hash(key) & (H - 1); bool found = false;
           for (;;) { unsigned long long v = tab[h]; if (v == key) { found = true; break; } if (v == VOX_EMPTY) break; h = (h + 1) & (H - 1); }
@@ -3536,7 +3537,7 @@ __global__ __launch_bounds__(FLT_T) void k_out(MorDev d) {
   if (ground_wg) {
     const int tg = t2, G = d.info[s].G, base = tg * MOR_TILE;
     float4 *out = d.out_ptrs[s];
-    for (int i = base + threadIdx.x; i < min(base + MOR_TILE, G); i += FLT_T) out[n_keep + i] = og[d.Nmax + i];
+    for (int i = base + threadIdx.x; i < min(base + MOR_TILE, G); i += FLT_T) st_stream(&out[n_keep + i], ld_stream(&og[d.Nmax + i]));
     return;
   }
   if (t >= nto) return;
@@ -3553,7 +3554,7 @@ __global__ __launch_bounds__(FLT_T) void k_out(MorDev d) {
     for (int it = 0; it < 8; ++it) {
       const int i = base + it * 64 + lane_id();
       bool keep = false;
-      if (i < M && !xerr) { const int cid = d.pcid[so + i]; keep = !(cid >= 0 && ((l_mov[cid >> 5] >> (cid & 31)) & 1u)); }   // cluster id per cloud point (written by k_clusters)
+      if (i < M && !xerr) { const int cid = ld_stream(&d.pcid[so + i]); keep = !(cid >= 0 && ((l_mov[cid >> 5] >> (cid & 31)) & 1u)); }   // cluster id per cloud point (written by k_clusters)
       mk[it] = __ballot(keep); c += __popcll(mk[it]);
     }
     if (lane_id() == 0) sh[wave_id()] = c;

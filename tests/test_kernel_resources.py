@@ -13,7 +13,7 @@ SRC = os.path.join(ROOT, "dynamicslamtool_amd", "csrc", "mor_kernels.hip")
 LIMITS = {
     "k_split<false>": (128, 16, 16 * 1024),         # four 256-thread workgroups per CU (a few spilled dwords per tile are tolerated: eight scratch accesses in the whole kernel)
     "k_gridcount": (64, 0, 36 * 1024),
-    "k_gridplace": (64, 96, 24 * 1024),
+    "k_gridplace": (80, 0, 24 * 1024),
     "k_cellboxes": (128, 0, 1024),
     "k_cg_slab": (128, 0, 78 * 1024),               # two 512-thread workgroups per CU (registers and LDS)
     "k_clusters": (128, 0, 20 * 1024),
