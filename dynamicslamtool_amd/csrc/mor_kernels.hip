@@ -2770,9 +2770,10 @@ __device__ __forceinline__ bool vox_key(const MorDev &d, int pr, const double (&
   return ok;
 }
 __global__ __launch_bounds__(MOR_BT) void k_vox_clear(MorDev d) {
-  int s = blockIdx.y + d.s0, H = vox_table_size(d, d.slot_kc[d.prev][s].y);
+  int s, bxc; map_block(d.B, 64, s, bxc);
+  const int H = vox_table_size(d, d.slot_kc[d.prev][s].y);
   unsigned long long *tab = d.vox + (size_t)s * d.Hcap;
-  for (int i = blockIdx.x * MOR_BT + threadIdx.x; i < H; i += gridDim.x * MOR_BT) tab[i] = VOX_EMPTY;
+  for (int i = bxc * MOR_BT + threadIdx.x; i < H; i += 64 * MOR_BT) tab[i] = VOX_EMPTY;
 }
 __global__ __launch_bounds__(MOR_BT) void k_vox_insert(MorDev d) {
   int s, t, g;   // the launch's workgroups go to the streams in proportion to their cluster points (tiles of MOR_TILE)
@@ -3020,8 +3021,10 @@ __device__ __forceinline__ bool g2_ordered_sums3(const float *lx, const float *l
 // coordinates out in rank order and lets one lane add up the ordered sums — four groups of a wave do that side by side.
 // Voxels with more than G2_GROUP_CAP neighbours (a dense surface next to the sensor) are queued for k_g2_cov_big.
 #define G2_GROUP_CAP 128
+#define G2_COV_G 256   // workgroups per stream of k_g2_cov; 64 of the middle / big tiers, 128 of k_g2_mark
 __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
-  const int s = blockIdx.y + d.s0, V = d.info[s].n_occ;
+  int s, bxv; map_block(d.B, G2_COV_G, s, bxv);   // (a stream's workgroups on one XCD, as everywhere else: as a two-dimensional launch a stream's voxels went round all eight L2s)
+  const int V = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
   const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15, lane = lane_id(), gsh = lane & 48;   // group in the workgroup, lane in the group, shift of the group's bits in a wave ballot
   __shared__ unsigned long long l_key[MOR_BT / 16][G2_GROUP_CAP];
@@ -3029,7 +3032,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
   const int zbase = d.zbase[s];
-  for (int v0 = blockIdx.x * (MOR_BT / 16); v0 < V; v0 += gridDim.x * (MOR_BT / 16)) {
+  for (int v0 = bxv * (MOR_BT / 16); v0 < V; v0 += G2_COV_G * (MOR_BT / 16)) {
     const int v = v0 + grp; const bool act = v < V;
     // ---- voxel centroid: sequential fp32 sums over the voxel's points in ascending index (stable sort ⇒ storage order)
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -3122,7 +3125,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
 // are complemented; what is left (> G2_MID_CAP neighbours) goes to k_g2_cov_big.
 #define G2_MID_CAP 1024
 __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
-  const int s = blockIdx.y + d.s0, nbig = d.g2_nbig[s], bxq = blockIdx.x, gq = gridDim.x;
+  const int s = blockIdx.y + d.s0, nbig = d.g2_nbig[s], bxq = blockIdx.x, gq = gridDim.x;   // (spread over all XCDs: the queues are uneven across streams, and a workgroup holds 80 KB of LDS)
   const size_t so = (size_t)s * d.Nmax;
   const int wv = wave_id(), lane = lane_id();
   __shared__ unsigned long long l_key[MOR_BT / 64][G2_MID_CAP];
@@ -3240,11 +3243,12 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mode(MorDev d) {
 __global__ __launch_bounds__(MOR_BT) void k_g2_mark(MorDev d) {
   // (waves look at 64 voxels at a time and take the mode bin's voxels among them one by one; 4096 one-wave workgroups per stream that looked at
   //  fifteen voxels each made this launch 260 000 workgroups)
-  int s = blockIdx.y + d.s0, V = d.info[s].n_occ, mode = d.mode_bin[s];
+  int s, bxm; map_block(d.B, 128, s, bxm);
+  const int V = d.info[s].n_occ, mode = d.mode_bin[s];
   if (mode == 0x7fffffff) return;
   const size_t so = (size_t)s * d.Nmax;
-  const int lane = lane_id(), nw = gridDim.x * (MOR_BT / 64);
-  for (int v0 = (blockIdx.x * (MOR_BT / 64) + wave_id()) * 64; v0 < V; v0 += nw * 64) {
+  const int lane = lane_id(), nw = 128 * (MOR_BT / 64);
+  for (int v0 = (bxm * (MOR_BT / 64) + wave_id()) * 64; v0 < V; v0 += nw * 64) {
     unsigned long long m = __ballot(v0 + lane < V && d.vbin[so + min(v0 + lane, V - 1)] == mode);
     while (m) {
       const int l = __ffsll((long long)m) - 1; m &= m - 1;
@@ -3655,14 +3659,14 @@ static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLau
     //  leave them ready — publish_split of pass B, the frame tag in is_ground, k_g2_mode)
     mor_launch_split_and_grid(da, st, tm);
   } else if (sub == 1) {
-    MOR_LAUNCH_T(MK_G2_COV, k_g2_cov, dim3(256, d.B), MOR_BT, da);
+    MOR_LAUNCH_T(MK_G2_COV, k_g2_cov, dim3(G2_COV_G * d.B), MOR_BT, da);
   } else if (sub == 2) {
     MOR_LAUNCH(MK_G2_COV_MID, k_g2_cov_mid, dim3(64, d.B), da);
   } else if (sub == 3) {
     MOR_LAUNCH_T(MK_G2_COV_BIG, k_g2_cov_big, dim3(64, d.B), G2_BIG_T, da);
   } else if (sub == 4) {
     MOR_LAUNCH(MK_G2_MODE, k_g2_mode, gB, da);
-    MOR_LAUNCH(MK_G2_MARK, k_g2_mark, dim3(128, d.B), da);
+    MOR_LAUNCH(MK_G2_MARK, k_g2_mark, dim3(128 * d.B), da);
   } else {
     MorDev db = d; db.gmode = 2;
     mor_launch_split_and_grid(db, st, tm);
@@ -3687,7 +3691,7 @@ static void mor_launch_pairs(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
         MOR_LAUNCH_T(MK_SCORE_NB, k_score_nb, dim3(d.g_score * d.B), SCN_T, d);
       }
     } else if (d.method == 2) {
-      MOR_LAUNCH(MK_VOX_CLEAR, k_vox_clear, dim3(64, d.B), d);
+      MOR_LAUNCH(MK_VOX_CLEAR, k_vox_clear, dim3(64 * d.B), d);
       MOR_LAUNCH(MK_VOX_INSERT, k_vox_insert, dim3(d.B * 2 * d.g_out), d);   // (cluster points of ca / cb: at most the cloud; 1024-point half tiles would do, so twice the cloud's width)
       MOR_LAUNCH(MK_VOX_PROBE, k_vox_probe, dim3(d.B * 2 * d.g_out), d);
     }
