@@ -1500,7 +1500,7 @@ __device__ __forceinline__ int pair_points_thread(const float4 *sp, int a0, int 
 //  B1  one thread per listed pair: roots re-checked, then the points (pair_points_thread).
 //  B2  one wave per pair the thread test could not finish (big cells): pruned exhaustive test.
 template <bool LDS> struct CgsCells { const int *key, *pc; const float *rx, *ry, *rz, *bx; int cap; };   // bx: six planes of `cap` floats (null: samples and boxes stay in global memory)
-template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_hooks(const MorDev &d, const MorGrid &G, size_t soc, int n_own, int n_loc, const CgsCells<LDS> &L, const int *start, const int *rows, int rsub, int r0, int nlrows,
+template <bool LDS, bool BOXL, typename RT> __device__ __forceinline__ void cgs_hooks(const MorDev &d, const MorGrid &G, size_t soc, int n_own, int n_loc, const CgsCells<LDS> &L, const int *start, const RT *rows, int rsub, int r0, int nlrows,
                                                               int *par, const float4 *sp, int *ovf, int *l_list, int *l_queue, int *l_wcnt, int *l_n2, size_t stw) {
   const float r2 = d.r2;
   const int *key = L.key;
@@ -1524,7 +1524,7 @@ template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_hooks(const M
       if (y + dy < G.ny && (unsigned)(z + dz) < (unsigned)G.nz) {
         const int rr = grid_row(G, y + dy, z + dz), rl = rr - r0;
         if (rl >= 0 && rl < nlrows) {
-          const int rlo = rows[rl] - rsub, rn = rows[rl + 1] - rsub - rlo;
+          const int rlo = (int)rows[rl] - rsub, rn = (int)rows[rl + 1] - rsub - rlo;
           rowbase = rr * G.nx + x; b = rlo; hi = rlo + rn;
           if (rn > 5) b = cg_lower_bound8(key, rlo, rn, rowbase - 2);
           if (b < hi) ra = cg_find<LDS>(par, a);
@@ -1622,16 +1622,16 @@ template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_hooks(const M
   ST2V(stw, 10, n1); ST2V(stw, 11, n2);
   __syncthreads();
 }
-template <bool LDS, bool BOXL> __device__ __forceinline__ void cgs_body(const MorDev &d, const MorGrid &G, int s, size_t so, int c0, int n_own, int n_loc, const CgsCells<LDS> &L, const int *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_queue, int *l_wcnt, int *l_n2, size_t stwj) {
+template <bool LDS, bool BOXL, typename RT> __device__ __forceinline__ void cgs_body(const MorDev &d, const MorGrid &G, int s, size_t so, int c0, int n_own, int n_loc, const CgsCells<LDS> &L, const RT *rows, int rsub, int r0, int nlrows, int *par, int *ovf, int *l_list, int *l_queue, int *l_wcnt, int *l_n2, size_t stwj) {
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1) + c0;   // start[local id]: first position of the cell in `sorted`
   const float4 *sp = d.sorted + so;
-  cgs_hooks<LDS, BOXL>(d, G, so + c0, n_own, n_loc, L, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_queue, l_wcnt, l_n2, stwj);
+  cgs_hooks<LDS, BOXL, RT>(d, G, so + c0, n_own, n_loc, L, start, rows, rsub, r0, nlrows, par, sp, ovf, l_list, l_queue, l_wcnt, l_n2, stwj);
   // local roots as global compact ids: own cells → lroot_a, look-ahead cells → lroot_b
   for (int c = threadIdx.x; c < n_loc; c += CGS_T) {
     const int r = c0 + cg_find<LDS>(par, c);
     if (c < n_own) st_agent(&d.lroot_a[so + c0 + c], r); else st_agent(&d.lroot_b[so + c0 + c], r);   // (agent scope: the merge may run in another slab's workgroup of this launch, stream_last_block)
   }
-  ST2(stwj, 9); ST2V(stwj, 14, n_own); ST2V(stwj, 15, n_loc);
+  ST2(stwj, 9); ST2V(stwj, 14, n_own); ST2V(stwj, 15, n_loc); ST2V(stwj, 12, nlrows); ST2V(stwj, 13, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));   // (HW_ID: wave, SIMD, CU, SE … of the recording wave)
 }
 template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDev &d, int s, int nocc, int *par, int *scr, int *l_misc, const int *l_sc, const int *l_se);
 // CAP: local cells (own + look-ahead) the workgroup holds in LDS (76 KB: two workgroups per CU).
@@ -1680,12 +1680,13 @@ template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d,
   // 12·CAP words of cell data: CAP cells with everything in LDS (key, parent, packed coordinates, sample point, box), or —
   // slabs of up to 4·CAP cells, e.g. a façade across a y-slice — key, parent and packed coordinates only: the enumeration
   // (A1) and the forest stay in LDS, the decisions about queued pairs (A2) fetch samples and boxes from global memory
-  int *l_cells = l_arena, *l_rows = l_cells + 12 * CAP, *l_list = l_rows + CGS_ROWCAP + 1, *l_queue = l_list + CGS_LISTW;
+  int *l_cells = l_arena, *l_list = l_cells + 12 * CAP + CGS_ROWCAP + 1, *l_queue = l_list + CGS_LISTW;
+  unsigned short *l_rows = reinterpret_cast<unsigned short *>(l_cells + 12 * CAP);   // local row table as 16-bit offsets (≤ 4·CAP local cells): 2·CGS_ROWCAP rows in CGS_ROWCAP + 1 words
   int &l_n2 = *l_n2p;
   int *ovf = d.cg_ovf + (size_t)(s * MOR_MAXP + j) * MOR_CGS_OVF * 2;   // [0, MOR_CGS_OVF): the waves' candidate lists, [MOR_CGS_OVF, 2·MOR_CGS_OVF): pairs for whole waves
   const int *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1) + r0;
   if (threadIdx.x == 0) l_n2 = 0;
-  const bool fits_rows = nlrows <= CGS_ROWCAP && !d.cg_force_global;
+  const bool fits_rows = nlrows <= 2 * CGS_ROWCAP && !d.cg_force_global;   // (thick slabs of the sparse far ends of a cloud: 150 slices × 14 layers seen at 120 000 points; beyond the table they ran the global-memory path, 3× slower, and set the kernel's span)
   if (fits_rows && n_loc <= CAP) {
     int *l_key = l_cells, *l_par = l_cells + CAP, *l_pc = l_cells + 2 * CAP;
     float *l_rx = reinterpret_cast<float *>(l_cells + 3 * CAP), *l_ry = l_rx + CAP, *l_rz = l_rx + 2 * CAP, *l_bx = l_rx + 3 * CAP;
@@ -1697,10 +1698,10 @@ template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d,
       l_rx[i] = q.x; l_ry[i] = q.y; l_rz[i] = q.z;
       l_bx[i] = lo.x; l_bx[CAP + i] = lo.y; l_bx[2 * CAP + i] = lo.z; l_bx[3 * CAP + i] = hi4.x; l_bx[4 * CAP + i] = hi4.y; l_bx[5 * CAP + i] = hi4.z;
     }
-    for (int i = threadIdx.x; i <= nlrows; i += CGS_T) l_rows[i] = g_rows[i] - c0;
+    for (int i = threadIdx.x; i <= nlrows; i += CGS_T) l_rows[i] = (unsigned short)(g_rows[i] - c0);
     __syncthreads();
     const CgsCells<true> L = {l_key, l_pc, l_rx, l_ry, l_rz, l_bx, CAP};
-    cgs_body<true, true>(d, G, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
+    cgs_body<true, true, unsigned short>(d, G, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
   } else if (fits_rows && n_loc <= 4 * CAP) {
     int *l_key = l_cells, *l_par = l_cells + 4 * CAP, *l_pc = l_cells + 8 * CAP;
     const int *gk = d.ckey + so + c0;
@@ -1708,17 +1709,17 @@ template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d,
       const int k = gk[i], row = k / G.nx;
       l_key[i] = k; l_par[i] = i; l_pc[i] = (int)((unsigned)(k - row * G.nx) | ((unsigned)(row % G.nz) << 11) | ((unsigned)(row / G.nz) << 21));
     }
-    for (int i = threadIdx.x; i <= nlrows; i += CGS_T) l_rows[i] = g_rows[i] - c0;
+    for (int i = threadIdx.x; i <= nlrows; i += CGS_T) l_rows[i] = (unsigned short)(g_rows[i] - c0);
     __syncthreads();
     const CgsCells<true> L = {l_key, l_pc, nullptr, nullptr, nullptr, nullptr, 0};
-    cgs_body<true, false>(d, G, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
+    cgs_body<true, false, unsigned short>(d, G, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
   } else {   // slab too big for LDS: the same code on global arrays (even and odd slabs use different forests: look-aheads overlap the next slab)
     int *par = ((j & 1) ? d.parent2 : d.parent) + so + c0;
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) cg_st<false>(par + i, i);
     __threadfence();
     __syncthreads();
     const CgsCells<false> L = {d.ckey + so + c0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    cgs_body<false, false>(d, G, s, so, c0, n_own, n_loc, L, g_rows, c0, r0, nlrows, par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
+    cgs_body<false, false, int>(d, G, s, so, c0, n_own, n_loc, L, g_rows, c0, r0, nlrows, par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
   }
 }
 // One workgroup per stream: merges the slab forests, then components (size, smallest cloud index), the kept clusters

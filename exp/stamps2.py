@@ -35,7 +35,7 @@ i = int(np.argmax(t.sum(1)))
 print("   slowest stream %d: M %d n_occ %d phases %s; kernel span %.1f us" % (i, g[i, 4], g[i, 5], np.round(t[i], 1).tolist(), (g[:, 3].max() - g[:, 0].min()) / 100.0))
 order = np.argsort(-t.sum(1))[:6]
 print("   six slowest: " + ", ".join("s%d M=%d %.0fus" % (k, g[k, 4], t[k].sum()) for k in order))
-w = out[:, :P, :].astype(np.int64).reshape(-1, 16)
+w = out[:, :MAXP, :].astype(np.int64).reshape(-1, 16)   # (slabs per stream follow the cell counts: up to MAXP)
 w = w[w[:, 0] > 0]
 tot = (w[:, 9] - w[:, 0]) / 100.0
 ph = {"load": w[:, 1] - w[:, 0], "A": w[:, 2] - w[:, 1], "B1": w[:, 3] - w[:, 2], "B2": w[:, 4] - w[:, 3], "out": w[:, 9] - w[:, 4]}
@@ -46,3 +46,9 @@ for k, v in ph.items():
 print("   pairs listed mean %.0f max %d | for waves mean %.1f max %d | n_own mean %.0f max %d n_loc max %d" % (w[:, 10].mean(), w[:, 10].max(), w[:, 11].mean(), w[:, 11].max(), w[:, 14].mean(), w[:, 14].max(), w[:, 15].max()))
 for k in np.argsort(-tot)[:8]:
     print("   slow wg: total %.0f us  " % tot[k] + " ".join("%s=%.0f" % (n, v[k] / 100.0) for n, v in ph.items()) + "  n1=%d n2=%d own=%d loc=%d" % (w[k, 10], w[k, 11], w[k, 14], w[k, 15]))
+# round 4: where the slow slab workgroups sit (HW_ID of the recording wave: bits 8-11 CU, 13-15 SE (XCC id is not in it), and their row counts
+hw = w[:, 13]; cu = (hw >> 8) & 15; se = (hw >> 13) & 7
+print("   total us histogram (10-us bins from 20):", np.histogram(tot, bins=[0, 20, 30, 40, 50, 60, 70, 80, 100, 120, 200])[0].tolist())
+for k in np.argsort(-tot)[:12]:
+    print("   slow wg: %.0f us A=%.0f rows=%d own=%d loc=%d n1=%d  se=%d cu=%d start=%.0f us" % (tot[k], ph["A"][k] / 100.0, w[k, 12], w[k, 14], w[k, 15], w[k, 10], se[k], cu[k], (w[k, 0] - w[:, 0].min()) / 100.0))
+print("   start times (us after the first): p50 %.0f p90 %.0f max %.0f" % tuple(np.percentile((w[:, 0] - w[:, 0].min()) / 100.0, [50, 90, 100])))
