@@ -692,13 +692,20 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
     { int tot; wg_prefix_total(d.ktile_cnt + (size_t)s * d.tiles_max, 1, t, nt, sh + 4, r, tot); }
     for (int w = 0; w < wave_id(); ++w) r += sh[w];
     __syncthreads();
+    // the eight gathers of a thread as one batch of independent loads, ahead of the stores (which may alias them as far as the compiler knows and kept
+    // them one round trip after the other: 7 M random 16-byte reads per launch of the voxel ground variant, 544 µs alone)
+    int pi[8]; float4 pq[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) { const int p = base + it * 64 + lane_id(); pi[it] = p < M ? ld_stream(sidx + p) : 0; }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) pq[it] = d.cloud[so + pi[it]];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       int p = base + it * 64 + lane_id();
       if (p < M) {
         bool head = (mh[it] >> lane_id()) & 1ull;
         int c = r + __popcll(mh[it] & lanemask_lt()) + (head ? 1 : 0) - 1;
-        int i = sidx[p];
+        int i = pi[it];
         if (head) {
           const int kc = skey[p];
           d.ckey[so + c] = kc; cstart[c] = p;
@@ -713,7 +720,7 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
           const int rl = skey[p] / G.nx;
           const int g = atomicAdd(&l_ng, 1); if (g < 64) { l_gap[3 * g] = rl; l_gap[3 * g + 1] = G.nrows; l_gap[3 * g + 2] = c + 1; } else for (int r = rl + 1; r <= G.nrows; ++r) rs[r] = c + 1;
         }
-        float4 q = d.cloud[so + i]; q.w = __int_as_float(i);
+        float4 q = pq[it]; q.w = __int_as_float(i);
         d.sorted[so + p] = q; if (d.scell) d.scell[so + p] = c;
       }
       r += __popcll(mh[it]);
@@ -2982,6 +2989,7 @@ template <int CHUNK> __device__ __forceinline__ int g2_voxel_bin(const MorDev &d
   }
   return ((double)fabsf(acc[3]) < 0.001 && (double)fabsf(acc[4]) < 0.001 && (double)fabsf(acc[5]) < 0.001) ? (int)(q.z * 10) : 0x7fffffff;
 }
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }   // keeps the compiler from moving LDS accesses across it; lanes of one wave then see each other's LDS writes
 // Ordered fp32 sums (:142, :144) over coordinates laid out in rank order in LDS: Σp / n, then the scatter terms around it.  Each sum is a
 // serial chain by definition, but the three sums of a pass are independent: lanes base, base + 1, base + 2 of the wave run one chain each
 // in lock step (x, y, z of the centroid; then dz·dx, dy·dz, dz·dz), eight elements loaded ahead of the adds.  Called by ALL lanes of the
@@ -3020,6 +3028,8 @@ __device__ __forceinline__ bool g2_ordered_sums3(const float *lx, const float *l
 // the points within the radius from the 3×3×3 voxel block into its slice of LDS (lanes 0–8 resolve the nine rows, ballot
 // compaction inside the group: no atomics), ranks the (d², index) keys by counting (they are unique), lays the
 // coordinates out in rank order and lets one lane add up the ordered sums — four groups of a wave do that side by side.
+// (Every group / wave of the two kernels below works in its own slice of LDS: what its lanes exchange needs the order of ONE wave's LDS accesses — which the hardware keeps —
+// not a workgroup barrier.  With barriers the sixteen groups of a workgroup went through every voxel round in lock step, at the pace of the slowest.)
 // Voxels with more than G2_GROUP_CAP neighbours (a dense surface next to the sensor) are queued for k_g2_cov_big.
 #define G2_GROUP_CAP 128
 #define G2_COV_G 256   // workgroups per stream of k_g2_cov; 64 of the middle / big tiers, 128 of k_g2_mark
@@ -3092,7 +3102,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
         n += __popc(m16);
       }
     }
-    __syncthreads();
+    wave_lds_fence();
     // ---- rank by counting (keys are unique: the index is part of them), coordinates to their rank
     int bin = 0x7fffffff;
     const bool small = act && n > 3 && n <= G2_GROUP_CAP;
@@ -3106,17 +3116,17 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
         er[u] = r; ex[u] = l_x[grp][e]; ey[u] = l_y[grp][e]; ez[u] = l_z[grp][e];
       }
     }
-    __syncthreads();
+    wave_lds_fence();
 #pragma unroll
     for (int u = 0; u < G2_GROUP_CAP / 16; ++u) if (er[u] >= 0) { l_x[grp][er[u]] = ex[u]; l_y[grp][er[u]] = ey[u]; l_z[grp][er[u]] = ez[u]; }
-    __syncthreads();
+    wave_lds_fence();
     // ---- ordered fp32 sums (:142, :144): three lanes of the group, one chain each
     if (g2_ordered_sums3(l_x[grp], l_y[grp], l_z[grp], n, small, (int)lane_id() & ~15) && small && sub == 0) bin = (int)(q.z * 10);
     if (act && sub == 0) {
       if (n > G2_GROUP_CAP) { const int slot = atomicAdd(&d.g2_nbig[s], 1); d.g2_big[so + slot] = v; }
       else d.vbin[so + v] = bin;
     }
-    __syncthreads();
+    wave_lds_fence();
   }
 }
 // The queued voxels, middle tier: one WAVE per voxel, up to G2_MID_CAP neighbours in its 20 KiB slice of LDS — the same
@@ -3168,7 +3178,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
       }
       n += __popcll(m);
     }
-    __syncthreads();
+    wave_lds_fence();
     const bool mine = act && n <= G2_MID_CAP;
     float ex[G2_MID_CAP / 64], ey[G2_MID_CAP / 64], ez[G2_MID_CAP / 64]; int er[G2_MID_CAP / 64];
 #pragma unroll
@@ -3180,17 +3190,17 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
         er[u] = r; ex[u] = l_x[wv][e]; ey[u] = l_y[wv][e]; ez[u] = l_z[wv][e];
       }
     }
-    __syncthreads();
+    wave_lds_fence();
 #pragma unroll
     for (int u = 0; u < G2_MID_CAP / 64; ++u) if (er[u] >= 0) { l_x[wv][er[u]] = ex[u]; l_y[wv][er[u]] = ey[u]; l_z[wv][er[u]] = ez[u]; }
-    __syncthreads();
+    wave_lds_fence();
     const bool acc3 = g2_ordered_sums3(l_x[wv], l_y[wv], l_z[wv], n, mine && n > 3, 0);
     if (mine && lane == 0) {
       const int bin = (n > 3 && acc3) ? (int)(q.z * 10) : 0x7fffffff;
       d.vbin[so + v] = bin;
       d.g2_big[so + w] = ~v;   // done
     }
-    __syncthreads();
+    wave_lds_fence();
   }
 }
 // what the middle tier left: one 1024-thread workgroup each (the LDS lets only one live on a CU anyway: sixteen waves sort four times faster than

@@ -7,6 +7,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 sensor = sys.argv[2] if len(sys.argv) > 2 else "hdl64"
 MAXP = 32
 p = kitti_params(1)
+if len(sys.argv) > 3: p.ground_method = int(sys.argv[3])   # 1: the voxel-covariance ground removal
 b = engine.MorBatch(p, B, synth.n_points(sensor))
 L = engine.lib(); L.mor_exp_read_stamps2.argtypes = [C.c_void_p, C.c_void_p]
 out = np.zeros((B, MAXP + 2, 16), np.uint64)
