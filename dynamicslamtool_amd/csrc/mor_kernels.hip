@@ -1346,16 +1346,22 @@ __device__ __forceinline__ void wave_box(const float4 *sp, int b, int e, int lan
 // loads, so a row of 500 cells costs three load latencies instead of the nine dependent ones of a binary search (the
 // wave pays the latency of its longest row in every iteration of the hook passes)
 __device__ __forceinline__ int cg_lower_bound8(const int *key, int lo, int n, int k0) {
+  // (loads first, unconditionally, then the comparisons with `&`: written as `in range && key[…] < k0` every load sat in its own branch with its own wait — seven
+  //  round trips one after the other per step, by the ISA)
   while (n > 8) {
     const int step = (n + 7) >> 3;
-    int c = 0;
+    int kv[7], c = 0;
 #pragma unroll
-    for (int j = 1; j < 8; ++j) c += (j * step < n) && key[min(lo + j * step, lo + n - 1)] < k0;
+    for (int j = 1; j < 8; ++j) kv[j - 1] = key[min(lo + j * step, lo + n - 1)];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) c += (int)(j * step < n) & (int)(kv[j - 1] < k0);
     lo += c * step; n = min(step, n - c * step);
   }
-  int below = 0;
+  int kv[8], below = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) below += (i < n) && key[lo + min(i, n - 1)] < k0;
+  for (int i = 0; i < 8; ++i) kv[i] = key[lo + min(i, n - 1)];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) below += (int)(i < n) & (int)(kv[i] < k0);
   return lo + below;
 }
 // Per occupied cell: the box of its points, its first point (sample for the quick edge test of the cell graph), its
@@ -1516,8 +1522,15 @@ template <bool LDS, bool BOXL, typename RT> __device__ __forceinline__ void cgs_
   int *queue = l_queue + w * CGS_QW;
   int wcount = 0;
   ST2(stw, 1);
+#ifdef MOR_EXP_STAMPS
+  unsigned long long ta = 0, tb = 0, tc = 0, td = 0;
+#define CGS_TICK(v) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long v = wall_clock64()
+#else
+#define CGS_TICK(v)
+#endif
   for (int it0 = w * 64; it0 < n_own * NR; it0 += CGS_T) {
     // ---- A1
+    CGS_TICK(k0);
     const int it = it0 + lane;
     int a = 0, rowbase = 0, b = 0, hi = 0, ra = -1; bool same_row = false;
     if (it < n_own * NR) {
@@ -1538,6 +1551,7 @@ template <bool LDS, bool BOXL, typename RT> __device__ __forceinline__ void cgs_
         }
       }
     }
+    CGS_TICK(k1);
 #ifdef MOR_EXP_STAMPS
     { const int s = (int)(soc / d.Nmax); const int n_it = __popcll(__ballot(it < n_own * NR)), n_ne = __popcll(__ballot(b < hi)); if (lane == 0) { RS_ADD(0, n_it); RS_ADD(1, n_ne); } }
 #endif
@@ -1553,6 +1567,7 @@ template <bool LDS, bool BOXL, typename RT> __device__ __forceinline__ void cgs_
       if (want) queue[qn + __popcll(m & lanemask_lt())] = (lane << 26) | bb;   // (enumerating lane, neighbour): the cell is that lane's `a` (local ids < 2²⁶: mor_batch_create bounds max_points)
       qn += __popcll(m);
     }
+    CGS_TICK(k2);
 #ifdef MOR_EXP_STAMPS
     { const int s = (int)(soc / d.Nmax); if (lane == 0) { RS_ADD(2, qn); RS_ADD(3, 1); } }
 #endif
@@ -1589,7 +1604,13 @@ template <bool LDS, bool BOXL, typename RT> __device__ __forceinline__ void cgs_
         wcount += __popcll(m);
       }
     }
+#ifdef MOR_EXP_STAMPS
+    { CGS_TICK(k3); ta += k1 - k0; tb += k2 - k1; tc += k3 - k2; }
+#endif
   }
+#ifdef MOR_EXP_STAMPS
+  { const int s = (int)(soc / d.Nmax); if (lane == 0) { RS_ADD(4, ta); RS_ADD(5, tb); RS_ADD(6, tc); RS_ADD(7, 1); } (void)td; }
+#endif
   if (lane == 0) l_wcnt[w] = min(wcount, cgs_wlist_cap<LDS>());
   __threadfence_block();
   __syncthreads();

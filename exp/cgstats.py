@@ -16,3 +16,4 @@ b.push(list(xs), ps); b.filter(to_host=False)
 L.mor_exp_read_stamps(b._h, out.ctypes.data)
 c = out.astype(np.float64).sum(0)
 print("items (cell, row) %d, with a non-empty window start %d (%.1f %%), queued pairs %d (%.2f per item, %.1f per batch of 64), batches %d" % (c[0], c[1], 100 * c[1] / c[0], c[2], c[2] / c[0], c[2] / c[3], c[3]))
+print("per wave, us: A1 lookup (decode, row, lower bound, find) %.1f | window loads + queue %.1f | A2 %.1f   (waves %d)" % (c[4] / c[7] / 100, c[5] / c[7] / 100, c[6] / c[7] / 100, c[7]))
