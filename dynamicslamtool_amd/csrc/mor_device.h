@@ -47,7 +47,7 @@ struct MorStreamArgs {       // per stream, per push (host → device, one small
 struct MorFrameInfo {        // per stream, produced on device
   uint32_t N, T, M, G, K, C, n_pairs, flags;   // flags bit0: cluster capacity exceeded, bit1: voxel key overflow
   uint32_t Kprev, Cprev, n_keep, n_occ;   // n_occ: occupied grid cells
-  uint32_t n_defer, pad0, hshift, max_loc;   // n_defer: method-1 queries handed to the wave tier; hshift: unused; max_loc: cells (own + look-ahead) of the largest slab of the cell graph
+  uint32_t n_defer, pad0, g2_exact, max_loc;   // n_defer: method-1 queries handed to the wave tier; g2_exact: voxels of the voxel ground variant whose ordered sums had to be evaluated (the screen left them open); max_loc: cells (own + look-ahead) of the largest slab of the cell graph
 };
 
 // Temporal logic (T1 + the tracking loop of F1) as device state, one instance per stream.  O(clusters) sequential work
@@ -137,6 +137,7 @@ struct MorDev {
   int *gh_key, *gh_val;      // [B][Hcell] hash path: the cell table of streams with more cells than the LDS table holds
   int gh_tier;   // table tier k_gridhash starts with (0 small LDS table, 1 big LDS table, 2 global memory)
   int *slab_y, *slab_c, *slab_e;    // [B][MOR_MAXP+1]  slabs of the cell graph: first y-slice, first compact cell id, end of the look-ahead (cells of the next two y-slices)
+  int g2_exact_only;         // test knob (MOR_G2_EXACT): the voxel ground variant takes no verdict from the screen — every voxel goes through the ordered sums
   int P, cg_force_global;    // workgroups per stream of k_cg_slab this frame (= slabs per stream when every stream gets the same); test knob: forests in global memory
   int *slab_p; int slab_T;   // [B] slabs of each stream (slab_bounds); own cells per slab the host aims at when the slabs follow the streams' cell counts (0: d.P slabs for every stream)
   int cg_fused;              // the merge of the slab forests (k_cg_final's work) runs in each stream's last slab workgroup of k_cg_slab

@@ -241,7 +241,7 @@ static int configure(mor_batch *b) {
   d.t1_budget |= (getenv("MOR_EXP_T1") ? atoi(getenv("MOR_EXP_T1")) : 0) << 16;   // cut point of exp/t1exp.py
 #endif
   // test switches (defaults: the fast paths): MOR_GH_TIER=1|2 starts k_gridhash with its big LDS table / its global-memory table; MOR_CG_GLOBAL forces the global-memory forests
-  d.gh_tier = getenv("MOR_GH_TIER") ? atoi(getenv("MOR_GH_TIER")) : 0; d.cg_force_global = getenv("MOR_CG_GLOBAL") ? 1 : 0;
+  d.gh_tier = getenv("MOR_GH_TIER") ? atoi(getenv("MOR_GH_TIER")) : 0; d.cg_force_global = getenv("MOR_CG_GLOBAL") ? 1 : 0; d.g2_exact_only = getenv("MOR_G2_EXACT") ? 1 : 0;
   d.P = 1;
   if (d.score_R > 60) return set_error(MOR_ERR_INVALID, "pde_ub %g needs a %d-cell search radius (> 60)", (double)p.pde_ub, d.score_R);
   int bits = 1; while ((1 << bits) < d.Kcap) ++bits;
@@ -904,8 +904,8 @@ int mor_exp_read_stamps2(const mor_batch *b, unsigned long long *out) {
 }
 int mor_get_stage_counts(const mor_batch *b, int s, uint32_t *out, int n) {
   CHECK_STREAM();
-  const uint32_t v[4] = {f.n_occ, f.n_defer, f.pad0, f.Cprev};   // v[2] = queries left after tier 1
-  for (int i = 0; i < n && i < 4; ++i) out[i] = v[i];
+  const uint32_t v[5] = {f.n_occ, f.n_defer, f.pad0, f.Cprev, f.g2_exact};   // v[2] = queries left after tier 1; v[4] = voxels whose ordered sums were evaluated (voxel ground variant)
+  for (int i = 0; i < n && i < 5; ++i) out[i] = v[i];
   return MOR_OK;
 }
 

@@ -307,7 +307,7 @@ __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, 
 __device__ __forceinline__ void reset_frame_info(const MorDev &d, int s, uint32_t n_points) {
   if (d.gmode == 2) return;
   MorFrameInfo &f = d.info[s];
-  f.N = n_points; f.flags = 0; f.n_pairs = 0; f.K = 0; f.C = 0; f.max_loc = 0;
+  f.N = n_points; f.flags = 0; f.n_pairs = 0; f.K = 0; f.C = 0; f.max_loc = 0; f.g2_exact = 0;
   d.tickets[(size_t)s * TK_COUNT + TK_SLABCNT] = 0;   // slabs handed out so far to the streams of this stream's XCD group (slab_bounds; the word of the group's first stream counts)
 }
 // ------------------------------------------------------------------------------------ G1: trim + ground split
@@ -3044,23 +3044,67 @@ __device__ __forceinline__ bool g2_ordered_sums3(const float *lx, const float *l
   const int ok = mine && (double)fabsf(c) < 0.001;
   return __shfl(ok, base & 63, 64) && __shfl(ok, (base + 1) & 63, 64) && __shfl(ok, (base + 2) & 63, 64);
 }
+// ---- The verdict of a voxel without its ordered sums.  What a voxel contributes is ONE BIT — all three scatter terms below 0.001 (:145) — and
+// its z-bin; the fp32 sums in (d², index) order only matter when a term lies so close to 0.001 that the rounding of that very order decides.  So
+// every tier first adds the terms up in fp64 in whatever order the lanes meet the neighbours (shifted by the voxel centroid q, one pass:
+// Σa, Σc, Σa·c … with a = x − q.x; t = Σa·c − Σa·Σc / n), bounds how far the reference's fp32 evaluation can lie from that, and settles the voxel when
+// the bound leaves no doubt; only the rest — none in the bench scenes — is sorted and summed in order.  The bound (u = 2⁻²⁴, γ_k = k·u / (1 − k·u)):
+//   centroid, sequential fp32 sum and one division:  |c_ref − c| ≤ γ_n · X,  X ≥ max |x_i|                                   =: Δx
+//   a term, two subtractions and a product:          |fl((z_i − cz_ref)·(x_i − cx_ref)) − (z_i − cz)(x_i − cx)| ≤ Δz·|a_i| + Δx·|c_i| + Δx·Δz + γ_3·(|a_i| + Δx)(|c_i| + Δz)
+//   their sequential fp32 sum:                       ≤ γ_{n−1} · Σ (|a_i| + Δx)(|c_i| + Δz)
+//   ⇒ |t_ref − t| ≤ (1 + γ)(Δz·Σ|a_i| + Δx·Σ|c_i| + n·Δx·Δz) + γ·Σ|a_i·c_i|,  γ = γ_{n+3}
+// (the sums of absolute values around c are bounded through those around q).  The verdict is taken with TWICE that bound plus 1e-9 for the fp64 arithmetic here.
+struct G2Acc { double Sa, Sb, Sc, Sac, Sbc, Scc, Aa, Ab, Ac, Aac, Abc; int n; };
+__device__ __forceinline__ void g2_acc_zero(G2Acc &A) { A.Sa = A.Sb = A.Sc = A.Sac = A.Sbc = A.Scc = A.Aa = A.Ab = A.Ac = A.Aac = A.Abc = 0.0; A.n = 0; }
+__device__ __forceinline__ void g2_acc_add(G2Acc &A, const float4 &q, const float4 &p) {
+  const double a = (double)p.x - (double)q.x, b = (double)p.y - (double)q.y, c = (double)p.z - (double)q.z;   // exact: differences of two floats
+  A.Sa += a; A.Sb += b; A.Sc += c; A.Sac += a * c; A.Sbc += b * c; A.Scc += c * c;
+  A.Aa += fabs(a); A.Ab += fabs(b); A.Ac += fabs(c); A.Aac += fabs(a * c); A.Abc += fabs(b * c);
+  ++A.n;
+}
+template <int W> __device__ __forceinline__ void g2_acc_reduce(G2Acc &A) {   // over the W lanes of the caller's group (W = 16 or 64, aligned)
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) {
+    A.Sa += __shfl_xor(A.Sa, o, 64); A.Sb += __shfl_xor(A.Sb, o, 64); A.Sc += __shfl_xor(A.Sc, o, 64);
+    A.Sac += __shfl_xor(A.Sac, o, 64); A.Sbc += __shfl_xor(A.Sbc, o, 64); A.Scc += __shfl_xor(A.Scc, o, 64);
+    A.Aa += __shfl_xor(A.Aa, o, 64); A.Ab += __shfl_xor(A.Ab, o, 64); A.Ac += __shfl_xor(A.Ac, o, 64);
+    A.Aac += __shfl_xor(A.Aac, o, 64); A.Abc += __shfl_xor(A.Abc, o, 64); A.n += __shfl_xor(A.n, o, 64);
+  }
+}
+// 1: accepted (:145 holds whatever the order), 0: rejected, −1: too close to call — the ordered sums decide.  n > 3.
+__device__ __forceinline__ int g2_screen(const G2Acc &A, const float4 &q, float leaf_r2) {
+  const double n = (double)A.n, u = 5.9604644775390625e-8, r = sqrt((double)leaf_r2) * 1.0001 + 1e-6;
+  const double ma = A.Sa / n, mb = A.Sb / n, mc = A.Sc / n;   // centroid − q
+  const double txz = A.Sac - A.Sa * mc, tyz = A.Sbc - A.Sb * mc, tzz = A.Scc - A.Sc * mc;
+  const double fa = fabs(ma), fb = fabs(mb), fc = fabs(mc);
+  const double sa = A.Aa + n * fa, sb = A.Ab + n * fb, sc = A.Ac + n * fc;   // ≥ Σ|x_i − c| …
+  const double axz = A.Aac + fc * A.Aa + fa * A.Ac + n * fa * fc, ayz = A.Abc + fc * A.Ab + fb * A.Ac + n * fb * fc, azz = A.Scc + 2.0 * fc * A.Ac + n * fc * fc;   // ≥ Σ|(x_i − c)(z_i − c)| …
+  const double g = 1.01 * (n + 4.0) * u / (1.0 - (n + 4.0) * u);
+  const double Dx = g * (fabs((double)q.x) + r), Dy = g * (fabs((double)q.y) + r), Dz = g * (fabs((double)q.z) + r);
+  const double Exz = (1.0 + g) * (Dz * sa + Dx * sc + n * Dx * Dz) + g * axz;
+  const double Eyz = (1.0 + g) * (Dz * sb + Dy * sc + n * Dy * Dz) + g * ayz;
+  const double Ezz = (1.0 + g) * (2.0 * Dz * sc + n * Dz * Dz) + g * azz;
+  const double T = 0.001, tiny = 1e-9;
+  const double lxz = fabs(txz) - 2.0 * Exz - tiny, lyz = fabs(tyz) - 2.0 * Eyz - tiny, lzz = fabs(tzz) - 2.0 * Ezz - tiny;   // lower bounds of |t_ref|
+  if (lxz > T || lyz > T || lzz > T) return 0;
+  const double hxz = fabs(txz) + 2.0 * Exz + tiny, hyz = fabs(tyz) + 2.0 * Eyz + tiny, hzz = fabs(tzz) + 2.0 * Ezz + tiny;   // upper bounds
+  if (hxz < T && hyz < T && hzz < T) return 1;
+  return -1;
+}
 // Sixteen lanes per voxel, sixteen voxels per 256-thread workgroup (a voxel centroid has a dozen neighbours on average, 96 %
-// have ≤ 64): the group computes the voxel's centroid (dsc, :110-113 — fp32 sums in ascending point index, one lane), gathers
-// the points within the radius from the 3×3×3 voxel block into its slice of LDS (lanes 0–8 resolve the nine rows, ballot
-// compaction inside the group: no atomics), ranks the (d², index) keys by counting (they are unique), lays the
-// coordinates out in rank order and lets one lane add up the ordered sums — four groups of a wave do that side by side.
-// (Every group / wave of the two kernels below works in its own slice of LDS: what its lanes exchange needs the order of ONE wave's LDS accesses — which the hardware keeps —
-// not a workgroup barrier.  With barriers the sixteen groups of a workgroup went through every voxel round in lock step, at the pace of the slowest.)
-// Voxels with more than G2_GROUP_CAP neighbours (a dense surface next to the sensor) are queued for k_g2_cov_big.
-#define G2_GROUP_CAP 128
+// have ≤ 64): the group computes the voxel's centroid (dsc, :110-113 — fp32 sums in ascending point index, one lane), walks the points
+// of the 3×3×3 voxel block (lanes 0–8 resolve the nine rows) and adds the neighbours within the radius into the screen's sums; the
+// verdict is taken from those (above).  No LDS, no sort.  Queued for k_g2_cov_mid (a whole wave each): voxels with more than
+// G2_NARROW_CAND candidates — dense surfaces next to the sensor, walked sixteen at a time they held their wave's other three groups up —
+// and the voxels the screen could not settle (tagged: their ordered sums are due).
+#define G2_NARROW_CAND 512
+#define G2_Q_EXACT (1 << 30)   // queue entry: the screen has been through this voxel and left it to the ordered sums
 #define G2_COV_G 256   // workgroups per stream of k_g2_cov; 64 of the middle / big tiers, 128 of k_g2_mark
 __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
   int s, bxv; map_block(d.B, G2_COV_G, s, bxv);   // (a stream's workgroups on one XCD, as everywhere else: as a two-dimensional launch a stream's voxels went round all eight L2s)
   const int V = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
-  const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15, lane = lane_id(), gsh = lane & 48;   // group in the workgroup, lane in the group, shift of the group's bits in a wave ballot
-  __shared__ unsigned long long l_key[MOR_BT / 16][G2_GROUP_CAP];
-  __shared__ float l_x[MOR_BT / 16][G2_GROUP_CAP], l_y[MOR_BT / 16][G2_GROUP_CAP], l_z[MOR_BT / 16][G2_GROUP_CAP];
+  const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15, lane = lane_id();   // group in the workgroup, lane in the group
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
   const int zbase = d.zbase[s];
@@ -3095,66 +3139,41 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
     int rb[9], rp[10]; rp[0] = 0;
 #pragma unroll
     for (int r = 0; r < 9; ++r) { rb[r] = __shfl(rb0, (lane & 48) + r, 64); rp[r + 1] = rp[r] + __shfl(rlen, (lane & 48) + r, 64); }
-    // ---- gather: candidates sixteen at a time, hits compacted into the group's list
-    int n = 0;
-    const int ncand_max = __shfl(rp[9], lane & 48, 64);   // (uniform in the group anyway)
-    int wave_max = ncand_max;
+    // ---- walk: candidates sixteen at a time, four per lane and round trip; the hits go into the screen's sums
+    const bool wide = rp[9] > G2_NARROW_CAND;   // (uniform in the group)
+    const int ncand = wide ? 0 : rp[9];
+    int wave_max = ncand;
 #pragma unroll
     for (int o = 16; o < 64; o <<= 1) wave_max = max(wave_max, __shfl_xor(wave_max, o, 64));
-    for (int c0 = 0; c0 < wave_max; c0 += 64) {   // four candidates per lane and round trip
+    G2Acc A; g2_acc_zero(A);
+    for (int c0 = 0; c0 < wave_max; c0 += 64) {
       float4 pc[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = c0 + 16 * u + sub; int k = 0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) if (c >= rp[r] && c < rp[r + 1]) k = rb[r] + (c - rp[r]);
-        pc[u] = sp[c < rp[9] ? k : 0];
+        pc[u] = sp[c < ncand ? k : 0];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = c0 + 16 * u + sub; const float4 p = pc[u];
-        const float dd = sqdist(q.x, q.y, q.z, p.x, p.y, p.z);
-        const bool hit = c < rp[9] && dd < d.leaf_r2;
-        const unsigned m16 = (unsigned)((__ballot(hit) >> gsh) & 0xffffull);
-        if (hit) {
-          const int slot = n + __popc(m16 & ((1u << sub) - 1u));
-          if (slot < G2_GROUP_CAP) { l_key[grp][slot] = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(p.w); l_x[grp][slot] = p.x; l_y[grp][slot] = p.y; l_z[grp][slot] = p.z; }
-        }
-        n += __popc(m16);
+        if (c < ncand && sqdist(q.x, q.y, q.z, p.x, p.y, p.z) < d.leaf_r2) g2_acc_add(A, q, p);
       }
     }
-    wave_lds_fence();
-    // ---- rank by counting (keys are unique: the index is part of them), coordinates to their rank
-    int bin = 0x7fffffff;
-    const bool small = act && n > 3 && n <= G2_GROUP_CAP;
-    float ex[G2_GROUP_CAP / 16], ey[G2_GROUP_CAP / 16], ez[G2_GROUP_CAP / 16]; int er[G2_GROUP_CAP / 16];
-#pragma unroll
-    for (int u = 0; u < G2_GROUP_CAP / 16; ++u) {
-      const int e = sub + 16 * u; er[u] = -1;
-      if (small && e < n) {
-        const unsigned long long ke = l_key[grp][e]; int r = 0;
-        for (int j = 0; j < n; ++j) r += l_key[grp][j] < ke;
-        er[u] = r; ex[u] = l_x[grp][e]; ey[u] = l_y[grp][e]; ez[u] = l_z[grp][e];
-      }
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int u = 0; u < G2_GROUP_CAP / 16; ++u) if (er[u] >= 0) { l_x[grp][er[u]] = ex[u]; l_y[grp][er[u]] = ey[u]; l_z[grp][er[u]] = ez[u]; }
-    wave_lds_fence();
-    // ---- ordered fp32 sums (:142, :144): three lanes of the group, one chain each
-    if (g2_ordered_sums3(l_x[grp], l_y[grp], l_z[grp], n, small, (int)lane_id() & ~15) && small && sub == 0) bin = (int)(q.z * 10);
+    g2_acc_reduce<16>(A);
     if (act && sub == 0) {
-      if (n > G2_GROUP_CAP) { const int slot = atomicAdd(&d.g2_nbig[s], 1); d.g2_big[so + slot] = v; }
-      else d.vbin[so + v] = bin;
+      const int verdict = wide ? -2 : A.n > 3 ? (d.g2_exact_only ? -1 : g2_screen(A, q, d.leaf_r2)) : 0;
+      if (verdict < 0) { const int slot = atomicAdd(&d.g2_nbig[s], 1); d.g2_big[so + slot] = verdict == -1 ? (v | G2_Q_EXACT) : v; }
+      else d.vbin[so + v] = verdict ? (int)(q.z * 10) : 0x7fffffff;
     }
-    wave_lds_fence();
   }
 }
-// The queued voxels, middle tier: one WAVE per voxel, up to G2_MID_CAP neighbours in its 20 KiB slice of LDS — the same
-// steps as a group of k_g2_cov (gather with ballot compaction, rank by counting, coordinates to their rank, ordered sums by
-// one lane).  A workgroup of the big-voxel kernel (bitonic sort, 128 KiB of LDS: one per CU) took ≈ 60 µs per voxel and all
-// ≈ 300 queued voxels of a stream went through it; 95 % of them have fewer than 1024 neighbours.  Done entries of the queue
-// are complemented; what is left (> G2_MID_CAP neighbours) goes to k_g2_cov_big.
+// The queued voxels, one WAVE per voxel: the same screen with sixty-four lanes for the voxels k_g2_cov did not walk; the ordered sums for those
+// the screen leaves open, up to G2_MID_CAP neighbours in the wave's 20 KiB slice of LDS (gather with ballot compaction, rank by counting — the
+// (d², index) keys are unique —, coordinates to their rank, ordered sums as three chains in three lanes).  Settled entries of the queue are
+// complemented; what is left (open AND more than G2_MID_CAP neighbours) goes to k_g2_cov_big.  A wave works in its own slice of LDS: the
+// order of ONE wave's LDS accesses — which the hardware keeps — is all its lanes need, not a workgroup barrier.
 #define G2_MID_CAP 1024
 __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
   const int s = blockIdx.y + d.s0, nbig = d.g2_nbig[s], bxq = blockIdx.x, gq = gridDim.x;   // (spread over all XCDs: the queues are uneven across streams, and a workgroup holds 80 KB of LDS)
@@ -3166,11 +3185,12 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
   const float4 *sp = d.sorted + so;
   const int zbase = d.zbase[s];
   for (int w0 = bxq * (MOR_BT / 64); w0 < nbig; w0 += gq * (MOR_BT / 64)) {
-    const int w = w0 + wv; const bool act = w < nbig;
-    const int v = act ? d.g2_big[so + w] : 0;
+    const int w = w0 + wv;
+    if (w >= nbig) continue;   // (wave-uniform; nothing below synchronises the workgroup)
+    const int qe = d.g2_big[so + w], v = qe & ~G2_Q_EXACT;
     const float4 q = d.vcent[so + v];
     int rb0 = 0, rlen = 0;
-    if (act && lane < 9) {
+    if (lane < 9) {
       int cx, cy, cz; bool cl; grid_cell(d.g, q, 0.f, zbase, cx, cy, cz, cl);
       const int y = cy + lane % 3 - 1, z = cz + lane / 3 - 1;
       if ((unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) {
@@ -3181,14 +3201,33 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
     int rb[9], rp[10]; rp[0] = 0;
 #pragma unroll
     for (int r = 0; r < 9; ++r) { rb[r] = __shfl(rb0, r, 64); rp[r + 1] = rp[r] + __shfl(rlen, r, 64); }
+    auto cand = [&](int c) { int k = 0;
+#pragma unroll
+      for (int r = 0; r < 9; ++r) if (c >= rp[r] && c < rp[r + 1]) k = rb[r] + (c - rp[r]);
+      return k; };
+    if (!(qe & G2_Q_EXACT) && !d.g2_exact_only) {   // not screened yet (too many candidates for sixteen lanes): 256 candidates per round trip
+      G2Acc A; g2_acc_zero(A);
+      for (int c0 = 0; c0 < rp[9]; c0 += 256) {
+        float4 pc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int c = c0 + 64 * u + lane; pc[u] = sp[c < rp[9] ? cand(c) : 0]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int c = c0 + 64 * u + lane; const float4 p = pc[u]; if (c < rp[9] && sqdist(q.x, q.y, q.z, p.x, p.y, p.z) < d.leaf_r2) g2_acc_add(A, q, p); }
+      }
+      g2_acc_reduce<64>(A);
+      const int verdict = A.n > 3 ? g2_screen(A, q, d.leaf_r2) : 0;
+      if (verdict >= 0) {
+        if (lane == 0) { d.vbin[so + v] = verdict ? (int)(q.z * 10) : 0x7fffffff; d.g2_big[so + w] = ~v; }
+        continue;
+      }
+    }
+    // ---- the ordered sums
+    if (lane == 0) atomicAdd(&d.info[s].g2_exact, 1u);
     int n = 0;
     for (int c0 = 0; c0 < rp[9]; c0 += 64) {
       const int c = c0 + lane; bool hit = false; float dd = 0.f; float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c < rp[9]) {
-        int k = 0;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) if (c >= rp[r] && c < rp[r + 1]) k = rb[r] + (c - rp[r]);
-        p = sp[k];
+        p = sp[cand(c)];
         dd = sqdist(q.x, q.y, q.z, p.x, p.y, p.z);
         hit = dd < d.leaf_r2;
       }
@@ -3200,12 +3239,13 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
       n += __popcll(m);
     }
     wave_lds_fence();
-    const bool mine = act && n <= G2_MID_CAP;
+    const bool mine = n <= G2_MID_CAP;
+    if (!mine) { if (lane == 0) d.g2_big[so + w] = v; continue; }   // (the tag comes off: k_g2_cov_big takes every entry ≥ 0)
     float ex[G2_MID_CAP / 64], ey[G2_MID_CAP / 64], ez[G2_MID_CAP / 64]; int er[G2_MID_CAP / 64];
 #pragma unroll
     for (int u = 0; u < G2_MID_CAP / 64; ++u) {
       const int e = lane + 64 * u; er[u] = -1;
-      if (mine && e < n) {
+      if (e < n) {
         const unsigned long long ke = l_key[wv][e]; int r = 0;
         for (int j = 0; j < n; ++j) r += l_key[wv][j] < ke;
         er[u] = r; ex[u] = l_x[wv][e]; ey[u] = l_y[wv][e]; ez[u] = l_z[wv][e];
@@ -3215,10 +3255,9 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
 #pragma unroll
     for (int u = 0; u < G2_MID_CAP / 64; ++u) if (er[u] >= 0) { l_x[wv][er[u]] = ex[u]; l_y[wv][er[u]] = ey[u]; l_z[wv][er[u]] = ez[u]; }
     wave_lds_fence();
-    const bool acc3 = g2_ordered_sums3(l_x[wv], l_y[wv], l_z[wv], n, mine && n > 3, 0);
-    if (mine && lane == 0) {
-      const int bin = (n > 3 && acc3) ? (int)(q.z * 10) : 0x7fffffff;
-      d.vbin[so + v] = bin;
+    const bool acc3 = g2_ordered_sums3(l_x[wv], l_y[wv], l_z[wv], n, n > 3, 0);
+    if (lane == 0) {
+      d.vbin[so + v] = (n > 3 && acc3) ? (int)(q.z * 10) : 0x7fffffff;
       d.g2_big[so + w] = ~v;   // done
     }
     wave_lds_fence();

@@ -30,6 +30,7 @@ def _run_lockstep(p, streams, n_bad=4, n_good=3, max_points=None, check_tracks=T
             stats["clusters"] += c.n_clusters
             stats["corr"] += c.n_corr
             stats["moving"] += int(os_[s].detection().sum())
+            stats["g2_exact"] = stats.get("g2_exact", 0) + b.stage_counts(s)["g2_exact"]
         outs = b.filter()
         for s in range(B):
             c = os_[s].counts()
@@ -621,6 +622,22 @@ def test_voxel_covariance_ground_hdl64():
     o = Oracle(p)
     o.push(*frames[0])
     assert o.counts().n_ground > 20000   # the ground plane is the dominant bin
+
+
+def test_voxel_covariance_ground_ordered_sums_only(monkeypatch):
+    """The voxel ground variant settles a voxel from order-free fp64 sums when their distance to the 0.001 threshold exceeds what the
+    rounding of the reference's ordered fp32 sums can move (k_g2_cov: g2_screen); the ordered sums themselves — rank by (d², index),
+    three serial chains — run only for the voxels left open, which the bench scenes have few of.  MOR_G2_EXACT=1 takes no verdict
+    from the screen: every voxel with more than three neighbours goes through the ordered sums of the middle / big tier, and the frames must be the oracle's
+    all the same (and the same as the default's, which the tests above compare with the oracle)."""
+    p = kitti_params(1)
+    p.ground_method = 1
+    streams = [[synth.frame(1000 + s, "hdl64", f) for f in range(2)] for s in range(2)]
+    st = _run_lockstep(p, streams)
+    monkeypatch.setenv("MOR_G2_EXACT", "1")
+    st2 = _run_lockstep(p, streams)
+    assert st2["g2_exact"] > 10000 and st["g2_exact"] * 50 < st2["g2_exact"], (st, st2)   # the screen settles nearly all of them (130 of 65 414 voxels with more than three neighbours are left open in these four frames)
+    print("ordered sums evaluated: by default %d voxels, with MOR_G2_EXACT %d" % (st["g2_exact"], st2["g2_exact"]))
 
 
 @pytest.mark.parametrize("method", [1, 2])
