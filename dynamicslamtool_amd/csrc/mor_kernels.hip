@@ -267,16 +267,44 @@ __device__ __forceinline__ int cell_axis_unclamped(float v, float o, float inv) 
 #ifndef ROW_BATCH
 #define ROW_BATCH 8
 #endif
+// first index in [lo, lo+n) whose key is ≥ k0, by 8-ary search: every step fetches its seven pivots with independent
+// loads, so a row of 500 cells costs three load latencies instead of the nine dependent ones of a binary search (the
+// wave pays the latency of its longest row in every iteration of the hook passes)
+__device__ __forceinline__ int cg_lower_bound8(const int *key, int lo, int n, int k0) {
+  // (loads first, unconditionally, then the comparisons with `&`: written as `in range && key[…] < k0` every load sat in its own branch with its own wait — seven
+  //  round trips one after the other per step, by the ISA)
+  while (n > 8) {
+    const int step = (n + 7) >> 3;
+    int kv[7], c = 0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) kv[j - 1] = key[min(lo + j * step, lo + n - 1)];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) c += (int)(j * step < n) & (int)(kv[j - 1] < k0);
+    lo += c * step; n = min(step, n - c * step);
+  }
+  int kv[8], below = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) kv[i] = key[lo + min(i, n - 1)];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) below += (int)(i < n) & (int)(kv[i] < k0);
+  return lo + below;
+}
 // occupied cells with x in [x0,x1] of row (cy,cz) have the consecutive compact ids [lo, hi)
 __device__ __forceinline__ void row_cells(const MorGrid &g, const int *ckey, const int *rs, int x0, int x1, int cy, int cz, int &lo, int &hi) {
   const int r = grid_row(g, cy, cz), e = rs[r + 1], base = r * g.nx;
   lo = rs[r];
-  if (e - lo > ROW_BATCH) {   // long row (a wall along x): binary search
-    int a = lo, b = e, k0 = base + x0;
-    while (a < b) { int m = (a + b) >> 1; if (ckey[m] < k0) a = m + 1; else b = m; }
-    lo = a; b = e; int k1 = base + x1;
-    while (a < b) { int m = (a + b) >> 1; if (ckey[m] <= k1) a = m + 1; else b = m; }
-    hi = a;
+  if (e - lo > ROW_BATCH) {   // long row (a wall along x; every row of the voxel ground variant's lattice): 8-ary search — three round trips for 512 cells where two binary searches took eighteen
+    const int k0 = base + x0, k1 = base + x1;
+    lo = cg_lower_bound8(ckey, lo, e - lo, k0);
+    const int w = min(e - lo, x1 - x0 + 1);   // cells that can lie in [k0, k1]
+    if (w <= 8) {
+      int kv[8], within = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) kv[i] = ckey[min(lo + i, e - 1)];   // (the row is not empty)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) within += (int)(i < w) & (int)(kv[i] <= k1);
+      hi = lo + within;
+    } else hi = cg_lower_bound8(ckey, lo, e - lo, k1 + 1);
     return;
   }
   // short row: fetch up to 8 keys with independent loads (one memory latency, not a chain of them)
@@ -1342,28 +1370,6 @@ __device__ __forceinline__ void wave_box(const float4 *sp, int b, int e, int lan
   lo = make_float4(lx, ly, lz, 0.f); hi = make_float4(hx, hy, hz, 0.f);
 }
 
-// first index in [lo, lo+n) whose key is ≥ k0, by 8-ary search: every step fetches its seven pivots with independent
-// loads, so a row of 500 cells costs three load latencies instead of the nine dependent ones of a binary search (the
-// wave pays the latency of its longest row in every iteration of the hook passes)
-__device__ __forceinline__ int cg_lower_bound8(const int *key, int lo, int n, int k0) {
-  // (loads first, unconditionally, then the comparisons with `&`: written as `in range && key[…] < k0` every load sat in its own branch with its own wait — seven
-  //  round trips one after the other per step, by the ISA)
-  while (n > 8) {
-    const int step = (n + 7) >> 3;
-    int kv[7], c = 0;
-#pragma unroll
-    for (int j = 1; j < 8; ++j) kv[j - 1] = key[min(lo + j * step, lo + n - 1)];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) c += (int)(j * step < n) & (int)(kv[j - 1] < k0);
-    lo += c * step; n = min(step, n - c * step);
-  }
-  int kv[8], below = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) kv[i] = key[lo + min(i, n - 1)];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) below += (int)(i < n) & (int)(kv[i] < k0);
-  return lo + below;
-}
 // Per occupied cell: the box of its points, its first point (sample for the quick edge test of the cell graph), its
 // smallest cloud index and the exact sums of its coordinates — ONE streaming pass over `sorted`, balanced whatever the
 // cell sizes are (a thread group per cell — round 1/2 — ended with the cells of thousands of points): a wave takes 256
@@ -3100,6 +3106,11 @@ __device__ __forceinline__ int g2_screen(const G2Acc &A, const float4 &q, float 
 #define G2_NARROW_CAND 512
 #define G2_Q_EXACT (1 << 30)   // queue entry: the screen has been through this voxel and left it to the ordered sums
 #define G2_COV_G 256   // workgroups per stream of k_g2_cov; 64 of the middle / big tiers, 128 of k_g2_mark
+#ifdef MOR_EXP_STAMPS
+#define G2_TICK(v) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long v = wall_clock64()
+#else
+#define G2_TICK(v)
+#endif
 __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
   int s, bxv; map_block(d.B, G2_COV_G, s, bxv);   // (a stream's workgroups on one XCD, as everywhere else: as a two-dimensional launch a stream's voxels went round all eight L2s)
   const int V = d.info[s].n_occ;
@@ -3110,6 +3121,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
   const int zbase = d.zbase[s];
   for (int v0 = bxv * (MOR_BT / 16); v0 < V; v0 += G2_COV_G * (MOR_BT / 16)) {
     const int v = v0 + grp; const bool act = v < V;
+    G2_TICK(k0);
     // ---- voxel centroid: sequential fp32 sums over the voxel's points in ascending index (stable sort ⇒ storage order)
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (act && sub == 0) {
@@ -3126,6 +3138,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
       d.vcent[so + v] = q;
     }
     q.x = __shfl(q.x, lane & 48, 64); q.y = __shfl(q.y, lane & 48, 64); q.z = __shfl(q.z, lane & 48, 64);
+    G2_TICK(k1);
     // ---- the nine (y,z) rows of the 3×3×3 block: lanes 0 … 8 of the group, each row's three x-cells are one range of `sorted`
     int rb0 = 0, rlen = 0;
     if (act && sub < 9) {
@@ -3139,6 +3152,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
     int rb[9], rp[10]; rp[0] = 0;
 #pragma unroll
     for (int r = 0; r < 9; ++r) { rb[r] = __shfl(rb0, (lane & 48) + r, 64); rp[r + 1] = rp[r] + __shfl(rlen, (lane & 48) + r, 64); }
+    G2_TICK(k2);
     // ---- walk: candidates sixteen at a time, four per lane and round trip; the hits go into the screen's sums
     const bool wide = rp[9] > G2_NARROW_CAND;   // (uniform in the group)
     const int ncand = wide ? 0 : rp[9];
@@ -3161,12 +3175,16 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
         if (c < ncand && sqdist(q.x, q.y, q.z, p.x, p.y, p.z) < d.leaf_r2) g2_acc_add(A, q, p);
       }
     }
+    G2_TICK(k3);
     g2_acc_reduce<16>(A);
     if (act && sub == 0) {
       const int verdict = wide ? -2 : A.n > 3 ? (d.g2_exact_only ? -1 : g2_screen(A, q, d.leaf_r2)) : 0;
       if (verdict < 0) { const int slot = atomicAdd(&d.g2_nbig[s], 1); d.g2_big[so + slot] = verdict == -1 ? (v | G2_Q_EXACT) : v; }
       else d.vbin[so + v] = verdict ? (int)(q.z * 10) : 0x7fffffff;
     }
+#ifdef MOR_EXP_STAMPS
+    { G2_TICK(k4); if (lane == 0) { RS_ADD(0, k1 - k0); RS_ADD(1, k2 - k1); RS_ADD(2, k3 - k2); RS_ADD(3, k4 - k3); RS_ADD(4, 1); RS_ADD(5, wave_max); } if (act && sub == 0) { RS_ADD(6, 1); RS_ADD(7, A.n); RS_ADD(8, ncand); RS_ADD(9, wide); } }
+#endif
   }
 }
 // The queued voxels, one WAVE per voxel: the same screen with sixty-four lanes for the voxels k_g2_cov did not walk; the ordered sums for those
