@@ -290,11 +290,11 @@ __device__ __forceinline__ int cg_lower_bound8(const int *key, int lo, int n, in
   return lo + below;
 }
 // occupied cells with x in [x0,x1] of row (cy,cz) have the consecutive compact ids [lo, hi)
-__device__ __forceinline__ void row_cells(const MorGrid &g, const int *ckey, const int *rs, int x0, int x1, int cy, int cz, int &lo, int &hi) {
-  const int r = grid_row(g, cy, cz), e = rs[r + 1], base = r * g.nx;
-  lo = rs[r];
+// (the cells [lo0, e) of one row, keys ascending from base = row · nx)
+__device__ __forceinline__ void row_range(const int *ckey, int lo0, int e, int base, int x0, int x1, int &lo, int &hi) {
+  lo = lo0;
+  const int k0 = base + x0, k1 = base + x1;
   if (e - lo > ROW_BATCH) {   // long row (a wall along x; every row of the voxel ground variant's lattice): 8-ary search — three round trips for 512 cells where two binary searches took eighteen
-    const int k0 = base + x0, k1 = base + x1;
     lo = cg_lower_bound8(ckey, lo, e - lo, k0);
     const int w = min(e - lo, x1 - x0 + 1);   // cells that can lie in [k0, k1]
     if (w <= 8) {
@@ -308,13 +308,17 @@ __device__ __forceinline__ void row_cells(const MorGrid &g, const int *ckey, con
     return;
   }
   // short row: fetch up to 8 keys with independent loads (one memory latency, not a chain of them)
-  const int n = e - lo, k0 = base + x0, k1 = base + x1;
+  const int n = e - lo;
   int below = 0, within = 0;
   if (n > 0) {
 #pragma unroll
     for (int i = 0; i < ROW_BATCH; ++i) { int k = ckey[lo + min(i, n - 1)]; bool v = i < n; below += v && k < k0; within += v && k >= k0 && k <= k1; }
   }
   lo += below; hi = lo + within;
+}
+__device__ __forceinline__ void row_cells(const MorGrid &g, const int *ckey, const int *rs, int x0, int x1, int cy, int cz, int &lo, int &hi) {
+  const int r = grid_row(g, cy, cz);
+  row_range(ckey, rs[r], rs[r + 1], r * g.nx, x0, x1, lo, hi);
 }
 // compact id of cell (cx,cy,cz) or −1 when empty / outside
 __device__ __forceinline__ int cell_lookup(const MorGrid &g, const int *ckey, const int *rs, int cx, int cy, int cz) {
@@ -667,7 +671,7 @@ __device__ __forceinline__ CellIdx cidx_load(const MorDev &d, const MorGrid &G, 
 __device__ __forceinline__ void cidx_row(const CellIdx &I, int x0, int x1, int cy, int cz, int &lo, int &hi) {
   const int r = cy * I.nz + cz;
   if (!I.lds) {
-    const int e = I.rs[r + 1], base = r * I.nx; int a = I.rs[r], b = e; const int k0 = base + x0, k1 = base + x1;
+    const int e = I.rs[r + 1], base = r * I.nx; int a = I.rs[r], b = e; const int k0 = base + x0, k1 = base + x1;   // (binary searches on purpose: the batched loads of row_range cost k_score_pde 25 registers — 8 → 5 waves per SIMD — and the run 2 %)
     while (a < b) { const int m = (a + b) >> 1; if (I.ckey[m] < k0) a = m + 1; else b = m; }
     lo = a; b = e;
     while (a < b) { const int m = (a + b) >> 1; if (I.ckey[m] <= k1) a = m + 1; else b = m; }
