@@ -6,6 +6,9 @@
 #include <hip/hip_runtime.h>
 
 #define MOR_TILE 2048   // points per workgroup tile: 4 waves × 8 coalesced 1-KiB rows of float4
+#ifndef MOR_SP_ROWS
+#define MOR_SP_ROWS 4    // rows of 64 records per wave and tile of the single-read split (k_split): its tiles are 4 waves × MOR_SP_ROWS × 64 records (8, 4 or 2 rows)
+#endif
 #define MOR_BT 256      // threads per workgroup
 #define MOR_CHUNK 2048  // points per work item of the per-cluster reductions
 #define MOR_KGRID 128   // workgroups per stream for per-cluster kernels (grid-stride over clusters)

@@ -464,13 +464,21 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
 // SPLIT_SPIN_LIMIT polls instead of hanging.  Measured alone: B = 64 × 120 000 points 86 µs (16 workgroups per stream; static tiles
 // 79 µs, count + scatter passes 36 + 58 µs and one more read of the cloud), B = 32 × 1 M points 306 µs (static tiles 360 µs); the
 // pipelined throughput of both workloads is that of the static form or better.
+// Tiles of the split are 1024 records (MOR_SP_ROWS = 4 rows of 64 per wave), half the 2048 of the other streaming kernels: a workgroup then goes through seven
+// tiles instead of four per 120 000-point cloud and holds 32 instead of 64 data registers (105 → 73 VGPRs: six workgroups per CU); the stream's workgroups fall
+// out of step sooner, so loads, look-back waits and stores of different workgroups overlap better (204.8–207.3 → 210.7–211.2 k frame-pairs/s; 512-record tiles 207.7 k).
+// Tried on top: THREE tiles per workgroup — two counted and published, the third landing, so that no tile is counted right behind its own loads — 208 k: the
+// exposed load latency is not what the split waits for.
 #define SPLIT_SPIN_LIMIT (1u << 22)
+#define SP_ROWS MOR_SP_ROWS
+#define SP_TILE (4 * SP_ROWS * 64)   // records per tile of the single-read split
+#define SP_DESC_STRIDE(d) ((size_t)(d).tiles_max * (8 / SP_ROWS))
 __device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // loads only (no use of the data here: the wait for them belongs to split_tile, a step later); cls carries the ground flag of pass B
-template <bool PASSB> __device__ __forceinline__ void split_load_tile(const MorDev &d, const MorStreamArgs &a, int s, uint32_t n_in, int t, float4 (&p)[8], int (&cls)[8]) {
-  const uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512;
+template <bool PASSB> __device__ __forceinline__ void split_load_tile(const MorDev &d, const MorStreamArgs &a, int s, uint32_t n_in, int t, float4 (&p)[SP_ROWS], int (&cls)[SP_ROWS]) {
+  const uint32_t base = (uint32_t)t * SP_TILE + wave_id() * (SP_ROWS * 64);
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < SP_ROWS; ++it) {
     const uint32_t i = min(base + it * 64 + lane_id(), n_in - 1);   // (clamped: out-of-range lanes repeat the last record and are masked in split_tile)
     if (PASSB) { p[it] = d.rawbuf[(size_t)s * d.Nmax + i]; cls[it] = d.is_ground[(size_t)s * d.Nmax + i] == d.frame_no + 1; }
     else { p[it] = load_point(a, i); cls[it] = 0; }
@@ -481,11 +489,11 @@ template <bool PASSB> __device__ __forceinline__ int split_class(const MorDev &d
   return i < n_in ? (PASSB ? (cls ? 1 : 2) : classify(d, p)) : 0;
 }
 // stage 1 of a tile (its loads were issued a step earlier): counts, and the tile's aggregate goes out to the other workgroups
-template <bool PASSB> __device__ __forceinline__ void split_count(const MorDev &d, int s, int t, uint32_t n_in, unsigned epoch, const float4 (&p)[8], const int (&cls)[8], int *sh, SplitMeta &m) {
+template <bool PASSB> __device__ __forceinline__ void split_count(const MorDev &d, int s, int t, uint32_t n_in, unsigned epoch, const float4 (&p)[SP_ROWS], const int (&cls)[SP_ROWS], int *sh, SplitMeta &m) {
   int c_ng = 0, c_g = 0;
-  const uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512 + lane_id();
+  const uint32_t base = (uint32_t)t * SP_TILE + wave_id() * (SP_ROWS * 64) + lane_id();
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < SP_ROWS; ++it) {
     const int c = split_class<PASSB>(d, n_in, base + it * 64, p[it], cls[it]);
     const unsigned long long m_ng = __ballot(c == 2), m_g = __ballot(c == 1);
     c_ng += __popcll(m_ng); c_g += __popcll(m_g);
@@ -500,14 +508,14 @@ template <bool PASSB> __device__ __forceinline__ void split_count(const MorDev &
   m.wng = 0; m.wg = 0;
   for (int w = 0; w < wave_id(); ++w) { m.wng += sh[w]; m.wg += sh[4 + w]; }
   if (threadIdx.x == 0)
-    __hip_atomic_store(d.split_desc + (size_t)s * d.tiles_max + t, ((unsigned long long)epoch << 32) | ((unsigned long long)(unsigned)m.tng << 16) | (unsigned long long)(unsigned)m.tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d.split_desc + (size_t)s * SP_DESC_STRIDE(d) + t, ((unsigned long long)epoch << 32) | ((unsigned long long)(unsigned)m.tng << 16) | (unsigned long long)(unsigned)m.tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // stage 2: look-back over the tiles between this workgroup's previous tile and this one, then the stores.
 // tk_next (thread 0 only): the ticket this workgroup has just taken for a later tile — passed on to all threads through s_ex[2]
-template <bool PASSB> __device__ __forceinline__ void split_store(const MorDev &d, const MorGrid &G, int s, int t, int nt, int t_prev, uint32_t n_in, unsigned epoch, const float4 (&p)[8], const int (&cls)[8],
+template <bool PASSB> __device__ __forceinline__ void split_store(const MorDev &d, const MorGrid &G, int s, int t, int nt, int t_prev, uint32_t n_in, unsigned epoch, const float4 (&p)[SP_ROWS], const int (&cls)[SP_ROWS],
                                             const SplitMeta &m, int &ex_ng, int &ex_g, int *s_ex, int tk_next) {
   if (wave_id() == 0) {
-    const unsigned long long *desc = d.split_desc + (size_t)s * d.tiles_max;
+    const unsigned long long *desc = d.split_desc + (size_t)s * SP_DESC_STRIDE(d);
     const int lane = lane_id();
     int an = 0, ag = 0;
     for (int hi = t - 1; hi > t_prev; hi -= 64) {   // 64 at a time (normally about sp_g of them in all)
@@ -538,9 +546,9 @@ template <bool PASSB> __device__ __forceinline__ void split_store(const MorDev &
   r_ng += m.wng; r_g += m.wg;
   const size_t so = (size_t)s * d.Nmax;
   const float zorg = d.zorg[s]; const int zbase = d.zbase[s];
-  const uint32_t base = (uint32_t)t * MOR_TILE + wave_id() * 512 + lane_id();
+  const uint32_t base = (uint32_t)t * SP_TILE + wave_id() * (SP_ROWS * 64) + lane_id();
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < SP_ROWS; ++it) {
     const int c = split_class<PASSB>(d, n_in, base + it * 64, p[it], cls[it]);
     const unsigned long long m_ng = __ballot(c == 2), m_g = __ballot(c == 1);
     const int k_ng = r_ng + __popcll(m_ng & lanemask_lt()), k_g = r_g + __popcll(m_g & lanemask_lt());
@@ -558,14 +566,14 @@ template <bool PASSB> __device__ __forceinline__ void split_store(const MorDev &
     r_ng += __popcll(m_ng); r_g += __popcll(m_g);
   }
 }
-template <bool PASSB> __global__ __launch_bounds__(MOR_BT, 4) void k_split(MorDev d) {   // (≤ 128 VGPRs: four workgroups per CU; the compiler left to itself wanders between 126 and 150 registers with unrelated edits — at 150 the split took 115 instead of 89 µs)
+template <bool PASSB> __global__ __launch_bounds__(MOR_BT, 4) void k_split(MorDev d) {   // (≤ 128 VGPRs at least — 73 with 1024-record tiles; with 2048-record tiles the compiler left to itself wandered between 126 and 150 registers with unrelated edits, and at 150 the split took 115 instead of 89 µs)
   int s, g; map_block(d.B, d.sp_g, s, g);
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   // As the first kernel of a frame (crop variant) this one reads the stream's arguments straight from the page-locked slot the host filled,
   // and the owner of tile 0 leaves the device copy for the kernels behind it: no copy, no launch and no wait in front of the frame
   const MorStreamArgs a = d.args_src ? d.args_src[s] : d.args[s];
   const uint32_t n_in = pass_count(d, a, s);
-  const int nt = (int)((n_in + MOR_TILE - 1) / MOR_TILE);
+  const int nt = (int)((n_in + SP_TILE - 1) / SP_TILE);
   const unsigned epoch = 2u * (unsigned)d.frame_no + (d.gmode == 2 ? 2u : 1u);   // never 0 (fresh descriptors), never the tag of an earlier pass over this table
   __shared__ int sh[16], s_ex[6];   // two copies of each, used in turn by the two halves of the loop: between two uses of a copy lies a workgroup barrier of the other half
   int *tk = d.tickets + (size_t)s * TK_COUNT + TK_SPLIT;
@@ -584,7 +592,7 @@ template <bool PASSB> __global__ __launch_bounds__(MOR_BT, 4) void k_split(MorDe
   __syncthreads();
   int t = __builtin_amdgcn_readfirstlane(s_ex[5]), t1 = t + 1, t_prev = -1;
   int ex_ng = 0, ex_g = 0;
-  float4 pa[8], pb[8]; int ca[8], cb[8];
+  float4 pa[SP_ROWS], pb[SP_ROWS]; int ca[SP_ROWS], cb[SP_ROWS];
 #ifdef MOR_EXP_SPLITVAR
   if ((d.t1_budget >> 19) & 1) {   // experiment: pure read of the stream's tiles (static tiles, two in flight), one dummy store
     float acc = 0.f;
@@ -592,10 +600,10 @@ template <bool PASSB> __global__ __launch_bounds__(MOR_BT, 4) void k_split(MorDe
       split_load_tile<PASSB>(d, a, s, n_in, tt, pa, ca);
       if (tt + d.sp_g < nt) split_load_tile<PASSB>(d, a, s, n_in, tt + d.sp_g, pb, cb);
 #pragma unroll
-      for (int it = 0; it < 8; ++it) acc += pa[it].x + pa[it].w;
+      for (int it = 0; it < SP_ROWS; ++it) acc += pa[it].x + pa[it].w;
       if (tt + d.sp_g < nt) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) acc += pb[it].y;
+        for (int it = 0; it < SP_ROWS; ++it) acc += pb[it].y;
       }
     }
     if (acc == 12345.678f) d.cloud[(size_t)s * d.Nmax] = make_float4(acc, 0, 0, 0);
