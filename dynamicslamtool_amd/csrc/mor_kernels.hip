@@ -3339,22 +3339,69 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mode(MorDev d) {
   __syncthreads();
   if (threadIdx.x == 0) { d.mode_bin[s] = best_bin; d.g2_nbig[s] = 0; }   // (the queue of big voxels is empty again for the next frame on this copy)
 }
-// ground = union of the neighbour lists of the dominant bin's voxels (:184-191, de-duplicated): one wave per such
-// voxel marks every trimmed point within the radius (no list, no sort needed here)
+// ground = union of the neighbour lists of the dominant bin's voxels (:184-191, de-duplicated): every trimmed point within the radius of such a
+// voxel's centroid is marked (no list, no sort needed here).  Waves look at 64 voxels at a time and take the mode bin's voxels among them FOUR at a
+// time, sixteen lanes each as in k_g2_cov (a centroid has 3.5 candidates: a whole wave per voxel — the first form — kept 55 lanes idle); voxels with
+// more than G2_NARROW_CAND candidates are left to the whole wave afterwards.
 __global__ __launch_bounds__(MOR_BT) void k_g2_mark(MorDev d) {
-  // (waves look at 64 voxels at a time and take the mode bin's voxels among them one by one; 4096 one-wave workgroups per stream that looked at
-  //  fifteen voxels each made this launch 260 000 workgroups)
   int s, bxm; map_block(d.B, 128, s, bxm);
   const int V = d.info[s].n_occ, mode = d.mode_bin[s];
   if (mode == 0x7fffffff) return;
   const size_t so = (size_t)s * d.Nmax;
-  const int lane = lane_id(), nw = 128 * (MOR_BT / 64);
+  const int lane = lane_id(), nw = 128 * (MOR_BT / 64), grp = lane >> 4, sub = lane & 15;
+  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  const float4 *sp = d.sorted + so;
+  const int zbase = d.zbase[s], tag = d.frame_no + 1;   // the frame's tag (never 0, never an earlier frame's on this copy of the array): nothing has to be cleared
   for (int v0 = (bxm * (MOR_BT / 64) + wave_id()) * 64; v0 < V; v0 += nw * 64) {
     unsigned long long m = __ballot(v0 + lane < V && d.vbin[so + min(v0 + lane, V - 1)] == mode);
+    unsigned long long wide_m = 0;
     while (m) {
-      const int l = __ffsll((long long)m) - 1; m &= m - 1;
+      // the group's voxel: the grp-th set bit of m; the four lowest bits leave m
+      unsigned long long mm = m; int l = -1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { if (mm) { if (k == grp) l = __ffsll((long long)mm) - 1; mm &= mm - 1; } }
+      m = mm;
+      const bool act = l >= 0;
+      const float4 q = d.vcent[so + v0 + max(l, 0)];
+      int rb0 = 0, rlen = 0;
+      if (act && sub < 9) {
+        int cx, cy, cz; bool cl; grid_cell(d.g, q, 0.f, zbase, cx, cy, cz, cl);
+        const int y = cy + sub % 3 - 1, z = cz + sub / 3 - 1;
+        if ((unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) {
+          int lo, hi; row_cells(d.g, ckey, rs, max(cx - 1, 0), min(cx + 1, d.g.nx - 1), y, z, lo, hi);
+          if (lo < hi) { rb0 = st[lo]; rlen = st[hi] - rb0; }
+        }
+      }
+      int rb[9], rp[10]; rp[0] = 0;
+#pragma unroll
+      for (int r = 0; r < 9; ++r) { rb[r] = __shfl(rb0, (lane & 48) + r, 64); rp[r + 1] = rp[r] + __shfl(rlen, (lane & 48) + r, 64); }
+      const bool wide = rp[9] > G2_NARROW_CAND;   // (uniform in the group)
+      { const unsigned long long wb = __ballot(act && wide && sub == 0);   // one bit per group with a wide voxel: its voxel goes to the wave's list
+        unsigned long long t = wb; while (t) { const int gl = __ffsll((long long)t) - 1; t &= t - 1; wide_m |= 1ull << __shfl(l, gl, 64); } }
+      const int ncand = (act && !wide) ? rp[9] : 0;
+      int wave_max = ncand;
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) wave_max = max(wave_max, __shfl_xor(wave_max, o, 64));
+      for (int c0 = 0; c0 < wave_max; c0 += 64) {   // four candidates per lane and round trip
+        float4 pc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + 16 * u + sub; int k = 0;
+#pragma unroll
+          for (int r = 0; r < 9; ++r) if (c >= rp[r] && c < rp[r + 1]) k = rb[r] + (c - rp[r]);
+          pc[u] = sp[c < ncand ? k : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + 16 * u + sub; const float4 p = pc[u];
+          if (c < ncand && sqdist(q.x, q.y, q.z, p.x, p.y, p.z) < d.leaf_r2) d.is_ground[so + __float_as_int(p.w)] = tag;
+        }
+      }
+    }
+    while (wide_m) {   // dense voxels next to the sensor: the whole wave walks their candidates
+      const int l = __ffsll((long long)wide_m) - 1; wide_m &= wide_m - 1;
       const float4 q = d.vcent[so + v0 + l];
-      g2_for_neighbours(d, s, q, [&](float, const float4 &p) { d.is_ground[so + __float_as_int(p.w)] = d.frame_no + 1; });   // the frame's tag (never 0, never an earlier frame's on this copy of the array): nothing has to be cleared
+      g2_for_neighbours(d, s, q, [&](float, const float4 &p) { d.is_ground[so + __float_as_int(p.w)] = tag; });
     }
   }
 }
