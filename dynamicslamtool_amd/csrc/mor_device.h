@@ -138,7 +138,8 @@ struct MorDev {
   int *gh_rowlist, *gh_cells; // [B][Nmax]  hash path, streams beyond the LDS lists: x of the cells of every row (unordered inside the row) then point counts per cell; claimed slots in discovery order
   int *gh_rowfill;           // [B][nrows+1]  hash path: per-row fill cursors when the row table does not fit the LDS copy
   int *gh_key, *gh_val;      // [B][Hcell] hash path: the cell table of streams with more cells than the LDS table holds
-  int gh_tier;   // table tier k_gridhash starts with (0 small LDS table, 1 big LDS table, 2 global memory)
+  int gh_tier;   // table tier k_gridhash starts with (0 small LDS table, 1 big LDS table, 2 global memory; −1: per stream, from gh_hint)
+  int *gh_hint;  // [B] occupied cells of the stream's latest grid build (one array for all copies of the per-frame state): a stream starts at the smallest tier that holds 17/16 of it and moves up when its table overflows
   int *slab_y, *slab_c, *slab_e;    // [B][MOR_MAXP+1]  slabs of the cell graph: first y-slice, first compact cell id, end of the look-ahead (cells of the next two y-slices)
   int g2_exact_only;         // test knob (MOR_G2_EXACT): the voxel ground variant takes no verdict from the screen — every voxel goes through the ordered sums
   int P, cg_force_global;    // workgroups per stream of k_cg_slab this frame (= slabs per stream when every stream gets the same); test knob: forests in global memory

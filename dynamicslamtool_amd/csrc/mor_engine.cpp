@@ -241,7 +241,7 @@ static int configure(mor_batch *b) {
   d.t1_budget |= (getenv("MOR_EXP_T1") ? atoi(getenv("MOR_EXP_T1")) : 0) << 16;   // cut point of exp/t1exp.py
 #endif
   // test switches (defaults: the fast paths): MOR_GH_TIER=1|2 starts k_gridhash with its big LDS table / its global-memory table; MOR_CG_GLOBAL forces the global-memory forests
-  d.gh_tier = getenv("MOR_GH_TIER") ? atoi(getenv("MOR_GH_TIER")) : 0; d.cg_force_global = getenv("MOR_CG_GLOBAL") ? 1 : 0; d.g2_exact_only = getenv("MOR_G2_EXACT") ? 1 : 0;
+  d.gh_tier = getenv("MOR_GH_TIER") ? atoi(getenv("MOR_GH_TIER")) : -1; d.cg_force_global = getenv("MOR_CG_GLOBAL") ? 1 : 0; d.g2_exact_only = getenv("MOR_G2_EXACT") ? 1 : 0;
   d.P = 1;
   if (d.score_R > 60) return set_error(MOR_ERR_INVALID, "pde_ub %g needs a %d-cell search radius (> 60)", (double)p.pde_ub, d.score_R);
   int bits = 1; while ((1 << bits) < d.Kcap) ++bits;
@@ -441,6 +441,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   //      (mor_push_batch).  288 GB of HBM3E make that cheap: ≈ 4 GB per copy at B = 64 × 120 000 points.
   const size_t R1 = (size_t)std::max(d.g.nrows, d.gv.nrows) + 1;
   std::vector<float> z0(B, p->gp_limit);   // crop-box variant: the clustering grid starts at gp_limit for every stream
+  ok = dalloc(b, d.gh_hint, B) && hipMemset(d.gh_hint, 0, B * sizeof(int)) == hipSuccess;   // (one for all copies: a stream's cell count of the latest grid build, the next build's tier hint)
+  if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d)", d.B));
   for (int c = 0; c < (int)b->pipe_depth; ++c) {
     MorDev o = d; MorStreamArgs *dargs = nullptr;
     ok = dalloc(b, dargs, B) && dalloc(b, o.info, B) && hipMemset(o.info, 0, B * sizeof(MorFrameInfo)) == hipSuccess && dalloc(b, o.tickets, B * 8) && hipMemset(o.tickets, 0, B * 8 * sizeof(int)) == hipSuccess;
@@ -545,7 +547,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
       d.g_box = getenv("MOR_G_BOX") ? std::max(1, atoi(getenv("MOR_G_BOX"))) : std::max(2, std::min(32, (int)((ref + 1023) / 1024) + 1));   // (a workgroup of the cell pass takes 1024 positions per round)
     }
     d.cg_fused = (maxocc * 11ull / 10 <= MOR_CGS_FCAP && !getenv("MOR_CG_UNFUSED")) ? 1 : 0;   // (a stream beyond it runs the merge on global-memory arrays: correct, slow — hence the separate kernel when that is foreseeable)
-    if (!getenv("MOR_GH_TIER")) d.gh_tier = maxocc * 5ull / 4 > 6144 ? (maxocc * 5ull / 4 > 12288 ? 2 : 1) : 0;   // table tier k_gridhash starts with (a stream whose table overflows moves up by itself)
+    // (table tier of k_gridhash: −1 = every stream by its own cell count of the latest build; MOR_GH_TIER forces the tier all streams start with)
   }
   d.cur = (int)(k % b->n_slots); d.prev = (int)((k + b->n_slots - 1) % b->n_slots); d.has_prev = k > 0; d.out_ptrs = nullptr; d.frame_no = (int)k;
   {  // workgroups for the cloud-sized kernels: 1.25 × the largest cloud / cluster set the device last reported
