@@ -3101,6 +3101,7 @@ __device__ __forceinline__ int g2_screen(const G2Acc &A, const float4 &q, float 
   const double fa = fabs(ma), fb = fabs(mb), fc = fabs(mc);
   const double sa = A.Aa + n * fa, sb = A.Ab + n * fb, sc = A.Ac + n * fc;   // ≥ Σ|x_i − c| …
   const double axz = A.Aac + fc * A.Aa + fa * A.Ac + n * fa * fc, ayz = A.Abc + fc * A.Ab + fb * A.Ac + n * fb * fc, azz = A.Scc + 2.0 * fc * A.Ac + n * fc * fc;   // ≥ Σ|(x_i − c)(z_i − c)| …
+  if ((n + 4.0) * u > 0.25) return -1;   // (millions of neighbours: the bound says nothing any more)
   const double g = 1.01 * (n + 4.0) * u / (1.0 - (n + 4.0) * u);
   const double Dx = g * (fabs((double)q.x) + r), Dy = g * (fabs((double)q.y) + r), Dz = g * (fabs((double)q.z) + r);
   const double Exz = (1.0 + g) * (Dz * sa + Dx * sc + n * Dx * Dz) + g * axz;

@@ -640,6 +640,39 @@ def test_voxel_covariance_ground_ordered_sums_only(monkeypatch):
     print("ordered sums evaluated: by default %d voxels, with MOR_G2_EXACT %d" % (st["g2_exact"], st2["g2_exact"]))
 
 
+def test_voxel_covariance_ground_near_the_threshold():
+    """A dense floor (2 cm lattice, ≈ 78 neighbours within gp_leaf of a voxel centroid) whose z noise puts Σ dz² of most voxels close to the 0.001 of :145, and
+    two tilted patches that do the same for the mixed terms: voxels land on both sides of the threshold and a good share of them inside the screen's
+    rounding bound — those must go through the ordered sums and every frame must still be the oracle's."""
+    rng = np.random.default_rng(77)
+    p = scene_params(method_choice=1)
+    p.ground_method = 1
+    p.gp_leaf = 0.1
+    frames = []
+    for f in range(2):
+        gx, gy = np.meshgrid(np.arange(-2.4, 2.4, 0.02), np.arange(-2.4, 2.4, 0.02))
+        n = gx.size
+        sig = np.where(gx.ravel() < 0, 0.0036, 0.0030)   # Σ dz² ≈ 78 σ²: 0.0010 on one half, 0.0007 on the other
+        floor = np.column_stack([gx.ravel() + rng.normal(0, 0.002, n), gy.ravel() + rng.normal(0, 0.002, n), -0.62 + rng.normal(0, 1, n) * sig])
+        tx, ty = np.meshgrid(np.arange(0.5, 1.5, 0.02), np.arange(-1.0, 0.0, 0.02))
+        tilt = np.column_stack([tx.ravel(), ty.ravel(), 0.2 + 0.004 * (tx.ravel() - 1.0) + rng.normal(0, 0.0005, tx.size)])   # Σ dz·dx around the threshold
+        box = _box(rng, np.array([-1.0, 1.0, 0.0]) + 0.01 * f, 400)
+        w = np.concatenate([floor, tilt, box])
+        pts = np.column_stack([w, rng.random(len(w))]).astype(np.float32)
+        frames.append((pts[rng.permutation(len(pts))], np.array([0, 0, 0, 0, 0, 0, 1.0])))
+    st = _run_lockstep(p, [frames])
+    o = Oracle(p); o.push(*frames[0])
+    assert 1000 < o.counts().n_ground < len(frames[0][0]) - 1000   # voxels on both sides of the threshold
+    assert st["g2_exact"] > 50, st   # the screen left voxels open (and the frames above equal the oracle's all the same)
+    print("ordered sums evaluated for %d voxels; ground %d of %d points" % (st["g2_exact"], o.counts().n_ground, len(frames[0][0])))
+
+
+def _box(rng, center, n):
+    q = (rng.random((n, 3)) - 0.5) * 0.4
+    q[np.arange(n), rng.integers(0, 3, n)] = 0.2 * (rng.integers(0, 2, n) * 2 - 1)
+    return q + center
+
+
 @pytest.mark.parametrize("method", [1, 2])
 def test_async_pipeline_matches_oracle(method):
     """Asynchronous mode: pushes and filters are only enqueued (three-stage frame pipeline on three HIP streams, state
