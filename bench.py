@@ -730,7 +730,7 @@ def main():
         sync_rate = B * n_sync / (time.perf_counter() - t1)
 
     stream0 = leg.summary0()
-    stage_totals = {k: sum(leg.batch.stage_counts(s)[k] for s in range(B)) for k in ("n_occ", "n_tier1b", "n_defer", "C_prev")}
+    stage_totals = {k: sum(leg.batch.stage_counts(s)[k] for s in range(B)) for k in ("n_occ", "n_tier1b", "n_defer", "C_prev") + (("g2_exact",) if ground_method == 1 else ())}
     profile = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in p.as_dict().items()}
     seeds_main = leg.seeds
     setup_s = leg.setup_s
