@@ -30,7 +30,9 @@ def _run_lockstep(p, streams, n_bad=4, n_good=3, max_points=None, check_tracks=T
             stats["clusters"] += c.n_clusters
             stats["corr"] += c.n_corr
             stats["moving"] += int(os_[s].detection().sum())
-            stats["g2_exact"] = stats.get("g2_exact", 0) + b.stage_counts(s)["g2_exact"]
+            sc = b.stage_counts(s)
+            stats["g2_exact"] = stats.get("g2_exact", 0) + sc["g2_exact"]
+            stats["max_cells"] = max(stats.get("max_cells", 0), sc["n_occ"]); stats["min_cells"] = min(stats.get("min_cells", 1 << 30), sc["n_occ"])
         outs = b.filter()
         for s in range(B):
             c = os_[s].counts()
@@ -638,6 +640,20 @@ def test_voxel_covariance_ground_ordered_sums_only(monkeypatch):
     st2 = _run_lockstep(p, streams)
     assert st2["g2_exact"] > 10000 and st["g2_exact"] * 50 < st2["g2_exact"], (st, st2)   # the screen settles nearly all of them (130 of 65 414 voxels with more than three neighbours are left open in these four frames)
     print("ordered sums evaluated: by default %d voxels, with MOR_G2_EXACT %d" % (st["g2_exact"], st2["g2_exact"]))
+
+
+def test_grid_merge_moves_between_its_tiers_from_frame_to_frame():
+    """k_gridhash starts every stream at the table tier its cell count of the latest build asks for and moves up when the table overflows: a stream that
+    alternates between a small indoor cloud (a few hundred cells) and a street scene (more cells than the all-LDS tier holds) overflows on every other frame,
+    next to a stream that stays small; every frame must be the oracle's."""
+    p = kitti_params(1)
+    big = [synth.frame(6100, "hdl64_urban", f) for f in range(4)]
+    small = [(f[0][:6000].copy(), f[1]) for f in (synth.frame(6200, "hdl64", k) for k in range(4))]
+    a = [big[0], small[1], big[2], small[3]]
+    b_ = [small[0], small[1], small[2], small[3]]
+    st = _run_lockstep(p, [a, b_], max_points=120000, check_tracks=True)
+    assert st["max_cells"] > 6144 and st["min_cells"] < 1000, st   # (the all-LDS tier holds 6 144 cells)
+    assert st["clusters"] > 10
 
 
 def test_voxel_covariance_ground_near_the_threshold():
