@@ -261,6 +261,38 @@ def test_fine_grid_takes_the_global_memory_cell_graph():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("slabs", [4, 16, 32])
+def test_tall_sparse_scene_with_thick_slabs(slabs, monkeypatch):
+    """A slab of the cell graph keeps its (y,z) row table in LDS as 16-bit offsets, up to 4 096 rows; thicker slabs run on the global-memory tables.  A scene
+    140 z-layers tall (trim_z = 40 m) cut into 4 / 16 / 32 slabs per stream has slabs of ≈ 12 000 / 3 000 / 1 500 rows: all three paths against the oracle."""
+    from dynamicslamtool_amd.engine import MorBatch
+    from oracle.oracle import Oracle
+    monkeypatch.setenv("MOR_CG_P", str(slabs))
+    p = kitti_params(1)
+    p.trim_z = 40.0
+    p.min_cluster_size = 8
+    rng = np.random.default_rng(5)
+    frames = []
+    centers = np.column_stack([rng.uniform(-40, 40, 40), rng.uniform(-40, 40, 40), rng.uniform(0, 36, 40)])
+    for f in range(3):
+        blobs = np.concatenate([c + np.array([0.05 * f * (k % 3 == 0), 0, 0]) + rng.normal(0, 0.25, (120, 3)) for k, c in enumerate(centers)])
+        haze = np.column_stack([rng.uniform(-45, 45, 3000), rng.uniform(-45, 45, 3000), rng.uniform(-1.0, 38.0, 3000)])
+        chains = np.concatenate([np.column_stack([np.linspace(-30, 30, 300), np.full(300, y), np.linspace(0, 35, 300)]) for y in (-20.0, 0.0, 20.0)])   # three long thin diagonals: one cluster each, across every slab
+        w = np.concatenate([blobs, haze, chains + rng.normal(0, 0.02, chains.shape)])
+        pts = np.column_stack([w, rng.random(len(w))]).astype(np.float32)
+        frames.append((pts[rng.permutation(len(pts))], np.array([0, 0, 0, 0, 0, 0, 1.0])))
+    b, o = MorBatch(p, 1, len(frames[0][0])), Oracle(p)
+    assert b.debug_config()["nz"] > 100
+    for f, (x, pose) in enumerate(frames):
+        b.push([x], pose[None, :])
+        o.push(x, pose)
+        compare_frame(o, b, 0, "tall scene, %d slabs, frame %d" % (slabs, f))
+        compare_output(o.filter(), b.filter()[0], "tall scene, %d slabs, frame %d" % (slabs, f))
+    assert o.counts().n_clusters >= 40
+    b.close()
+
+
+@pytest.mark.gpu
 def test_dense_sheets_overflow_the_deferred_pair_list():
     """Two dense wavy sheets 0.6 m apart (r = 0.5): every cell holds dozens of points, cells of the two sheets are
     two apart with overlapping-looking boxes, and no pair of points is within r — thousands of big × big cell
