@@ -449,7 +449,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = ok && dalloc(b, o.tile_cnt, B * T * 2) && dalloc(b, o.split_desc, B * T * (8 / MOR_SP_ROWS)) && hipMemset(o.split_desc, 0, B * T * (8 / MOR_SP_ROWS) * sizeof(unsigned long long)) == hipSuccess;   // (frame tags of the single-read split start at 1)
     ok = ok && dalloc(b, o.cloud, B * N) && dalloc(b, o.ground, 2 * B * N) && dalloc(b, o.cls_mask, B * (size_t)d.cls_rows * 2) && dalloc(b, o.pkey, B * N) && dalloc(b, o.pslot, B * N) && dalloc(b, o.gc_list, B * N) && dalloc(b, o.gc_ent, B * N) && dalloc(b, o.gc_n, B * (size_t)d.gc_chunks) && dalloc(b, o.gc_tab, B * (size_t)16384) && dalloc(b, o.gc_tabsel, B);
     ok = ok && dalloc(b, o.gh_rowlist, B * N) && dalloc(b, o.gh_cells, B * N) && dalloc(b, o.gh_rowfill, B * R1) && dalloc(b, o.gh_key, B * (size_t)d.Hcell) && dalloc(b, o.gh_val, B * (size_t)d.Hcell);
-    ok = ok && dalloc(b, o.ckey, B * N) && dalloc(b, o.cstart, B * (N + 1)) && dalloc(b, o.row_start, B * R1) && dalloc(b, o.cmin, B * N) && dalloc(b, o.cmeta, 2 * B * N) && dalloc(b, o.crep, B * N) && dalloc(b, o.sorted, B * N) && dalloc(b, o.scell, B * N) && dalloc(b, o.csum, B * N);
+    ok = ok && dalloc(b, o.ckey, B * N + 8) && dalloc(b, o.cstart, B * (N + 1)) && dalloc(b, o.row_start, B * R1) && dalloc(b, o.cmin, B * N) && dalloc(b, o.cmeta, 2 * B * N) && dalloc(b, o.crep, B * N) && dalloc(b, o.sorted, B * N) && dalloc(b, o.scell, B * N) && dalloc(b, o.csum, B * N);
     ok = ok && dalloc(b, o.slab_y, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_c, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_e, B * (MOR_MAXP + 1)) && dalloc(b, o.slab_p, B) && dalloc(b, o.lroot_a, B * N) && dalloc(b, o.lroot_b, B * N) && dalloc(b, o.parent, B * N) && dalloc(b, o.parent2, B * N) && dalloc(b, o.cg_ovf, B * (size_t)MOR_MAXP * MOR_CGS_OVF * 2);
     ok = ok && dalloc(b, o.croot, B * N) && dalloc(b, o.csize, B * N) && dalloc(b, o.compmin, B * N) && dalloc(b, o.cid_of_root, B * N) && dalloc(b, o.pcid, B * N) && dalloc(b, o.ccid, B * N) && dalloc(b, o.cgat, B * N) && dalloc(b, o.clist, B * N) && dalloc(b, o.cl_coff, B * (K + 1));
     ok = ok && dalloc(b, o.ktile_cnt, B * T) && dalloc(b, o.kcell, B * K) && dalloc(b, o.kroot, B * K) && dalloc(b, o.ksize, B * K) && dalloc(b, o.csz, B * K) && dalloc(b, o.krank_inv, B * K);

@@ -311,8 +311,15 @@ __device__ __forceinline__ void row_range(const int *ckey, int lo0, int e, int b
   const int n = e - lo;
   int below = 0, within = 0;
   if (n > 0) {
+    int kv[ROW_BATCH];
+#if ROW_BATCH == 8
+    __builtin_memcpy(kv, ckey + lo, 32);   // two 16-byte loads (dword-aligned addresses are fine for global loads); entries beyond the row are keys of later rows — masked below — and the arrays end ROW_BATCH entries behind the last cell (mor_batch_create)
+#else
 #pragma unroll
-    for (int i = 0; i < ROW_BATCH; ++i) { int k = ckey[lo + min(i, n - 1)]; bool v = i < n; below += v && k < k0; within += v && k >= k0 && k <= k1; }
+    for (int i = 0; i < ROW_BATCH; ++i) kv[i] = ckey[lo + min(i, n - 1)];
+#endif
+#pragma unroll
+    for (int i = 0; i < ROW_BATCH; ++i) { const bool v = i < n; below += (int)v & (int)(kv[i] < k0); within += (int)v & (int)(kv[i] >= k0) & (int)(kv[i] <= k1); }
   }
   lo += below; hi = lo + within;
 }
