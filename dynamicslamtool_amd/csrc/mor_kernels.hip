@@ -1720,7 +1720,7 @@ template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) 
   } else {
     int *par = d.parent + so;
     for (int i = threadIdx.x; i < nocc; i += CGS_T) cg_st<false>(par + i, i);
-    __threadfence();
+    __threadfence_block();   // (the forest is this workgroup's alone and accessed with agent-scope operations; a device-wide fence writes the XCD's whole L2 back: 32 µs)
     __syncthreads();
     cgf_body<false, CGS_T>(d, s, nocc, par, d.csize + so, l_misc, l_sc, l_se);
   }
@@ -1773,7 +1773,7 @@ template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d,
   } else {   // slab too big for LDS: the same code on global arrays (even and odd slabs use different forests: look-aheads overlap the next slab)
     int *par = ((j & 1) ? d.parent2 : d.parent) + so + c0;
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) cg_st<false>(par + i, i);
-    __threadfence();
+    __threadfence_block();   // (the forest is this workgroup's alone and accessed with agent-scope operations; a device-wide fence writes the XCD's whole L2 back: 32 µs)
     __syncthreads();
     const CgsCells<false> L = {d.ckey + so + c0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     cgs_body<false, false, int>(d, G, s, so, c0, n_own, n_loc, L, g_rows, c0, r0, nlrows, par, ovf, l_list, l_queue, l_wcnt, &l_n2, stwj);
@@ -1948,7 +1948,7 @@ __global__ __launch_bounds__(CGF_T) void k_cg_final(MorDev d) {
   } else {
     int *par = d.parent + so;
     for (int i = threadIdx.x; i < nocc; i += CGF_T) cg_st<false>(par + i, i);
-    __threadfence();
+    __threadfence_block();   // (the forest is this workgroup's alone and accessed with agent-scope operations; a device-wide fence writes the XCD's whole L2 back: 32 µs)
     __syncthreads();
     cgf_body<false, CGF_T>(d, s, nocc, par, d.csize + so, l_misc, l_sc, l_se);
   }
