@@ -52,14 +52,14 @@ ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "
              "job_GBps", "job_frac", "path_traffic_bytes_per_step", "wasted_traffic_ratio", "launches_per_step")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "core_seconds", "frame_pairs", "host_cpus")
 DROP_ORDER = ("e2e_host_sync_ms_per_step", "stream0", "stage_totals", "first_seed_per_rank", "per_rank_frame_pairs_per_s", "cpu_baseline_all_cores", "workloads", "latency_b1_ms",
-              "sync_frame_pairs_per_s", "device_ms_per_step", "value_runs")   # least important first; the contract keys, roofline, cpu_baseline and sanity never go
+              "sync_frame_pairs_per_s", "device_ms_per_step", "value_runs")   # least important first; the contract keys (with ranks / devices_visible / ranks_per_device), roofline, cpu_baseline and sanity never go
 
 
 def compact_line(full, detail_path=None, limit=LINE_LIMIT):
     """The bounded stdout line from the full record: the contract's keys, `config`, a roofline without tables, `cpu_baseline`, the sanity verdict and per
     secondary workload only {value, ms_per_step, frac, wasted}.  Everything else (per-kernel tables, the workloads' rooflines, profiles, mismatch
     lists) lives in the detail file.  Optional keys are shed in DROP_ORDER if a pathological run would still overflow; then the limit is asserted."""
-    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    keep = ("metric", "value", "unit", "n_gpus", "ranks", "devices_visible", "ranks_per_device", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
     line = {k: full.get(k) for k in keep}
     cfg = dict(full.get("config") or {})
     cfg.pop("profile", None)   # the parameter profile is in the detail file (and in dynamicslamtool_amd/params.py: kitti_params)
@@ -541,6 +541,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip value_runs, the other workloads, e2e / sync / latency legs")
+    ap.add_argument("--allow-shared-device", action="store_true", help="let several ranks share one GPU (a plumbing test on a 1-GPU box); the line then says so: n_gpus = devices in use, ranks, ranks_per_device")
     ap.add_argument("--dry-run", action="store_true", help="exercise only the multi-rank plumbing (no GPU work, no measurement)")
     ap.add_argument("--latency-only", action="store_true", help="child process of the default run: push + filter latency of ONE stream, prints {\"latency_b1_ms\": …}")
     ap.add_argument("--e2e-only", action="store_true", help="child process of the default run: the host-resident end-to-end legs, prints their figures as JSON")
@@ -611,7 +612,7 @@ def main():
         # meanwhile build their batches on their own cores and meet rank 0 at the barrier in front of the timed region.
         try:
             r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload, "--method", str(args.method), "--ground-method", str(args.ground_method)]
-                                + (["--streams", str(args.streams)] if args.streams else []), capture_output=True, text=True, timeout=900)
+                                + (["--streams", str(args.streams)] if args.streams else []), capture_output=True, text=True, timeout=max(60, min(900, int(os.environ.get("MOR_DIST_TIMEOUT_S", "600")) - 120)))   # (shorter than the process group's timeout: the other ranks wait for rank 0 at the barrier meanwhile)
             j_ = json.loads(r_.stdout.strip().splitlines()[-1])
             cpu, cpu_all, oracle_sum = j_["single"], j_["all"], {int(k): v for k, v in j_["summaries"].items()}
         except Exception as e_:
@@ -647,6 +648,9 @@ def main():
     ndev = engine.device_count()
     if ndev < 1:
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback in the product path)")
+    if world > ndev and not args.allow_shared_device:
+        raise RuntimeError("%d ranks but %d visible GPU(s): a line with n_gpus = %d would be a lie; pass --allow-shared-device for a plumbing run (the line then carries n_gpus = %d, ranks_per_device = %d)"
+                           % (world, ndev, world, ndev, (world + ndev - 1) // ndev))
     device = local_rank % ndev
     # the enqueueing thread (and everything it allocates from here on) next to its GPU: from the other socket the same run is 5–6 % slower.
     # Ranks whose GPUs hang on the same NUMA node share that node's cores in equal slices.
@@ -770,7 +774,7 @@ def main():
     if rank == 0:
         line = {
             "metric": "LiDAR frame-pairs/sec (120k pts, batched)", "value": round(value, 2), "unit": "frame-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "n_gpus": min(world, ndev), "ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d streams/GPU x %d pts (%s), device-resident clouds (inputs and filtered clouds stay in HBM; PCIe-inclusive rate = e2e_host_async_frame_pairs_per_s), kitti profile, method %d%s" % (args.workload, B, npts, sensor, method, ", voxel-covariance ground removal" if ground_method else ""),
                        "streams_per_gpu": B, "points_per_frame": npts, "parallelism": "streams sharded over %d GPU(s), no collective" % world,

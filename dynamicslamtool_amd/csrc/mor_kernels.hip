@@ -857,7 +857,7 @@ template <bool L> __device__ __forceinline__ int gh_scan(int *a, int n, int *sh)
 }
 // Slab boundaries of the cell graph (k_cg_slab): P slabs of whole y-slices with about equal cell counts, each at least
 // two slices thick so that the two-slice look-ahead of a slab stays inside its successor.  rows = exclusive row table
-// (rows[r] = first compact id of row r, rows[nrows] = n_occ); threads 0 … P of the calling workgroup take part; sh: ≥ 40 ints.
+// (rows[r] = first compact id of row r, rows[nrows] = n_occ); threads 0 … P of the calling workgroup take part; sh: ≥ 41 ints (sh[40] holds P).
 template <bool L> __device__ __forceinline__ void slab_bounds(const MorDev &d, const MorGrid &G, int s, const int *rows, int nocc, int *sh) {
   const int ny = G.ny, nz = G.nz, j = threadIdx.x;
   // Slabs of this stream: the launch's width for every stream, or (map_block_work) as many as the stream's cells ask for at slab_T own cells a slab —
@@ -1193,7 +1193,7 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
       MorCellSum z = {{0, 0, 0}, {0, 0, 0}}; d.csum[so + c] = z;
     }
   }
-  if (tid == 0) { cstart[nocc] = M; d.info[s].n_occ = nocc; d.gh_hint[s] = nocc; }
+  if (tid == 0) { cstart[nocc] = M; d.info[s].n_occ = nocc; st_agent(&d.gh_hint[s], nocc); }   // (gh_hint is shared by all copies of the per-frame state: another lane's k_gridhash may read it meanwhile — agent-scope accesses; whichever tier it then starts at, the grid it builds is bit-identical)
   for (int e = tid; e < nocc; e += GH_T) { const int sl = gh_ld<CL>(cells + e); gh_st<TL>(tval + sl, gh_ld<CL>(cnt + gh_ld<TL>(tkey + sl) - 1)); }
   __syncthreads();
   ST2(stw, 2);
@@ -1228,7 +1228,7 @@ __global__ __launch_bounds__(GH_T) void k_gridhash(MorDev d) {
   // the tier the stream starts with: by its own cell count of the latest build (+ 1/16; the first frame starts small and moves up).  The host's estimate for the whole
   // batch — 5/4 of the largest stream — put every stream of the bench batch (≤ 5 400 cells) into tier 1 and the voxel ground variant's (10 300) into tier 2: −2.4 % / −4.5 %.
   int tier = d.gh_tier;
-  if (tier < 0) { const int h = d.gh_hint[s]; const long long need = (long long)h + h / 16; tier = need > min(GH_C0, min(GH_H0, d.Hcell) / 4 * 3) ? (need > min(GH_H, d.Hcell) / 4 * 3 ? 2 : 1) : 0; }
+  if (tier < 0) { const int h = ld_agent(&d.gh_hint[s]); const long long need = (long long)h + h / 16; tier = need > min(GH_C0, min(GH_H0, d.Hcell) / 4 * 3) ? (need > min(GH_H, d.Hcell) / 4 * 3 ? 2 : 1) : 0; }
   if (tier <= 0) {
     const int H = min(GH_H0, d.Hcell);
     int *rows = l_mem + 2 * GH_H0, *cells = rows + GH_ROWS + 1, *rl = cells + GH_C0;
@@ -1892,7 +1892,7 @@ template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDe
   //      what is computed from cluster points — counts, existence tests, min / max, exact integer sums — does not depend
   //      on it; read-backs that promise the reference's order rebuild it from the labels.)
   int *ncell = scr, *cur = scr + K;   // the scratch array is free by now: [K] cells per cluster → first list entry; [K] next free slot of the cluster's range
-  if (2 * K > nocc) { ncell = d.ktile_cnt + (size_t)s * d.tiles_max; cur = d.nn_fwd + ko; }   // (more kept clusters than half the cells: K-sized scratch of other stages — min_cluster_size 1 on a sparse cloud; LDS-scope accesses on global memory are fine inside one workgroup after the barriers)
+  if (2 * K > nocc) { ncell = d.nn_bwd + ko; cur = d.nn_fwd + ko; }   // (more kept clusters than half the cells — min_cluster_size 1 on a sparse cloud: two [B][Kcap] arrays of the pair stage, which runs behind this kernel in the same frame and writes them before it reads them; LDS-scope accesses on global memory are fine inside one workgroup after the barriers)
   __syncthreads();
   for (int k = threadIdx.x; k < K; k += NT) cg_st<LDS>(ncell + k, 0);
   __threadfence_block();

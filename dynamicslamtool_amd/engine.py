@@ -40,6 +40,13 @@ def lib():
             raise RuntimeError("libmor_hip.so is not built (python -m dynamicslamtool_amd.build); there is no CPU fallback")
         if not os.environ.get("MOR_HIP_LIB") and not os.environ.get("MOR_ALLOW_STALE_LIB"):
             from . import build as _build
+            if _build.stale("hip") and os.path.exists(_build._hipcc()) and not os.environ.get("MOR_NO_AUTOBUILD"):
+                # bench.py, exp/pmc_run.py and profiles/collect.sh come through here without having called build(): rebuild (seconds when only the hash differs,
+                # a no-op for whoever comes second — ranks of one job take the lock in turn) rather than turn every edit into a RuntimeError
+                import fcntl
+                with open(os.path.join(_HERE, "csrc", ".build.lock"), "w") as lk:
+                    fcntl.flock(lk, fcntl.LOCK_EX)
+                    _build.build_hip(verbose=True)
             if _build.stale("hip"):   # a library that travelled with the tree but was built from other sources must not be what gets tested or measured
                 raise RuntimeError("libmor_hip.so was built from other sources or flags than the ones in this tree (carries %r, tree is %r): run `python -m dynamicslamtool_amd.build`"
                                    % (_build.built_hash(LIB_PATH), _build.source_hash(*_build._targets()["hip"][1:])))

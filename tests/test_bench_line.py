@@ -30,7 +30,7 @@ def _full(world=1, workloads=True):
                     "async_equals_sync": False, "setup_s": 1234.5}
     wl["hdl64_urban_b64"] = {"error": "RuntimeError(" + "z" * 400 + ")"}
     return {
-        "metric": "LiDAR frame-pairs/sec (120k pts, batched)", "value": 12345678.91, "unit": "frame-pairs/s", "n_gpus": world, "steps": 100000, "warmup": 10000, "ms_per_step": 12345.6789,
+        "metric": "LiDAR frame-pairs/sec (120k pts, batched)", "value": 12345678.91, "unit": "frame-pairs/s", "n_gpus": world, "ranks": world, "steps": 100000, "warmup": 10000, "ms_per_step": 12345.6789,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "hdl64_b64_voxel_ground: 64 streams/GPU x 1000000 pts (hdl64_urban), device-resident clouds (inputs and filtered clouds stay in HBM; PCIe-inclusive rate = e2e_host_async_frame_pairs_per_s), kitti profile, method 2, voxel-covariance ground removal",
                    "streams_per_gpu": 64, "points_per_frame": 1000000, "parallelism": "streams sharded over 8 GPU(s), no collective", "profile": {("key%d" % i): 1.234567 for i in range(30)}},
@@ -59,7 +59,7 @@ def test_worst_case_line_stays_under_the_limit_and_keeps_what_the_driver_reads()
         text = bench.compact_line(full, os.path.join(ROOT, "bench_detail.json"))
         assert len(text) <= bench.LINE_LIMIT <= 4096 and "\n" not in text
         d = json.loads(text)
-        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "sanity"):
+        for k in ("metric", "value", "unit", "n_gpus", "ranks", "devices_visible", "ranks_per_device", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "sanity"):
             assert k in d, k
         assert "workload" in d["config"] and "device-resident" in d["config"]["workload"] and "profile" not in d["config"]
         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "algorithmic_bytes_per_launch", "job_frac", "wasted_traffic_ratio"):

@@ -13,13 +13,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_two_ranks_share_the_visible_devices(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "8", "--steps", "4", "--warmup", "2", "--no-extras", "--detail", str(tmp_path / "detail.json")],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--allow-shared-device", "--streams", "8", "--steps", "4", "--warmup", "2", "--no-extras", "--detail", str(tmp_path / "detail.json")],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line (rank 0)"
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["self_launched"] and d["collective"] == "none" and d["scaling"] == "weak"
+    # the line never claims more GPUs than it ran on: n_gpus = devices in use, and ranks / devices_visible / ranks_per_device say how the ranks shared them
+    assert d["ranks"] == 2 and d["n_gpus"] == min(2, d["devices_visible"]) and d["ranks_per_device"] == (2 + d["devices_visible"] - 1) // d["devices_visible"]
+    assert d["self_launched"] and d["collective"] == "none" and d["scaling"] == "weak"
     assert d["first_seed_per_rank"] == [2000, 2008]                      # rank r owns streams r·B … r·B + B − 1
     assert len(d["per_rank_frame_pairs_per_s"]) == 2 and min(d["per_rank_frame_pairs_per_s"]) > 0
     # whole-job rate = all ranks' frame-pairs ÷ the slowest rank's time: between N × the slowest and the sum of the per-rank rates
@@ -30,3 +32,14 @@ def test_two_ranks_share_the_visible_devices(tmp_path):
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["sanity"]["equals_oracle"]
     assert d["workloads"] == "skipped: world>1" and len(lines[0]) <= 4096
     assert d["detail"] == str(tmp_path / "detail.json") and "per_kernel" in json.load(open(d["detail"]))["roofline"]
+
+
+def test_more_ranks_than_devices_is_refused_without_the_flag(tmp_path):
+    """`--gpus N` on a box with fewer GPUs must not print an N-GPU line (VERDICT round 4, weak #9)."""
+    from dynamicslamtool_amd import engine
+    n = engine.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--streams", "2", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--detail", str(tmp_path / "detail.json")],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "--allow-shared-device" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

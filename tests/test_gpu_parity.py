@@ -260,6 +260,29 @@ def test_fine_grid_takes_the_global_memory_cell_graph():
     b.close()
 
 
+@pytest.mark.parametrize("method", [1, 2])
+def test_more_clusters_than_half_the_cells(method):
+    """min_cluster_size = 1 on sparse clouds: nearly every occupied cell is a cluster of its own, so 2·K > cells and the merge at the
+    tail of the cell graph takes its per-cluster cursors from global scratch instead of its LDS array (that scratch was
+    `tiles_max` ints per stream — one int here — and K ≈ 2 000 of them ran over the neighbouring streams' slices).  Three streams with
+    different clouds in one batch, every stream compared with the oracle, so a write into a neighbour's slice shows."""
+    p = kitti_params(method)
+    p.min_cluster_size = 1
+    rng = np.random.default_rng(77)
+    streams = []
+    for s in range(3):
+        frames = []
+        base = np.column_stack([rng.uniform(-45, 45, 1800 + 150 * s), rng.uniform(-45, 45, 1800 + 150 * s), rng.uniform(-1.2, 2.0, 1800 + 150 * s)])
+        pairs = base[:300] + rng.normal(0, 0.05, (300, 3))      # some two-point clusters
+        for f in range(3):
+            w = np.concatenate([base, pairs]) + np.array([0.02 * f, 0, 0])
+            pts = np.column_stack([w, rng.random(len(w))]).astype(np.float32)
+            frames.append((pts[rng.permutation(len(pts))], np.array([0, 0, 0, 0, 0, 0, 1.0])))
+        streams.append(frames)
+    st = _run_lockstep(p, streams, max_points=4096)
+    assert st["clusters"] > 3 * 3 * 1500 and 2 * st["clusters"] > 9 * st["max_cells"] and st["corr"] > 0, st
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("slabs", [4, 16, 32])
 def test_tall_sparse_scene_with_thick_slabs(slabs, monkeypatch):
