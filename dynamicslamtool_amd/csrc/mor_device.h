@@ -39,6 +39,9 @@ struct MorRadix {
   int *hist;              // [B][tiles_max][256] histogram / offset scratch of this sort
   int skip_k_le;          // > 0: streams with K ≤ this need no further pass — the kernel returns at once for them
   int fuse;               // k_rscatter derives the offsets from the raw histograms itself (no k_rscan launch; ≤ 64 tiles)
+  int vox;                // keys are voxel keys of the voxel ground variant: a stream takes part in the passes its own key width needs (voxel_passes_of)
+  int inverse;            // last pass: vout[value] = position (the inverse permutation) instead of vout[position] = value — the points are then MOVED to their places
+                          // by coalesced reads and fire-and-forget writes (k_heads_scatter) instead of gathered by 7 M dependent random 16-byte reads per step
 };
 
 struct MorStreamArgs {       // per stream, per push (host → device, one small copy)
@@ -151,6 +154,7 @@ struct MorDev {
   int *ckey;                 // [B][Nmax]  distinct cell keys, ascending (n_occ of them)
   int *cstart;               // [B][Nmax+1]  first sorted position of each occupied cell
   int *row_start;            // [B][nrows+1]  first occupied cell of each (y,z) row
+  int *vnz, *vnz_out;        // [B]  voxel ground variant: z layers of the VoxelGrid lattice per stream (pass A writes it through vnz_out; its later kernels read it as gnz)
   int *gnz, *gnz_out; int cg_nz; float cg_inv_cs;   // voxel ground variant: z layers of the clustering grid per stream (stream_grid); written by pass A through gnz_out
   unsigned short *rs16, *cx16; int rs16_stride, cx16_stride;   // [B][rs16_stride], [B][cx16_stride] (even strides ≥ rows + 1 / Nmax + 1)  16-bit copies of the row table and of the x of every occupied cell: the cell index the method-1 scoring tiers keep in LDS
   int Hcell, use_hash;       // capacity per stream of the grid build's global-memory cell table (power of two ≥ 4·Nmax); whether the 16-bit index is written (method 1)

@@ -232,7 +232,7 @@ static int configure(mor_batch *b) {
   if (getenv("MOR_G_PDE")) d.g_pde = std::max(1, atoi(getenv("MOR_G_PDE")));
   d.use_hash = d.method == 1;
   { size_t hc = 1024; while (hc < 4 * (size_t)d.Nmax) hc <<= 1; d.Hcell = (int)hc; }
-  d.gnz = nullptr; d.gnz_out = nullptr; d.cg_nz = d.g.nz; d.cg_inv_cs = d.g.inv_cs;
+  d.gnz = nullptr; d.gnz_out = nullptr; d.vnz = nullptr; d.vnz_out = nullptr; d.cg_nz = d.g.nz; d.cg_inv_cs = d.g.inv_cs;
   d.t1_budget = getenv("MOR_T1_BUDGET") ? atoi(getenv("MOR_T1_BUDGET")) : 64;
 #ifdef MOR_EXP_SPLITVAR
   d.t1_budget |= (getenv("MOR_SPLIT_VARIANT") ? atoi(getenv("MOR_SPLIT_VARIANT")) : 0) << 16;   // experiment bits of exp/split_var.py (results are wrong with any of them set)
@@ -464,7 +464,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     if (ok) ok = hipMemcpy(o.zorg, z0.data(), B * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     if (d.gmode == 1) {   // voxel-covariance ground variant: the VoxelGrid sort and the per-voxel results
       for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, o.rkeys[i], B * N) && dalloc(b, o.rvals[i], B * N);
-      ok = ok && dalloc(b, o.rhist, B * T * 256) && dalloc(b, o.gnz, B) && dalloc(b, o.rawbuf, B * N) && dalloc(b, o.is_ground, B * N) && dalloc(b, o.vcent, B * N) && dalloc(b, o.vbin, B * N) && dalloc(b, o.g2_big, B * N) && dalloc(b, o.g2_nbig, B) && hipMemset(o.g2_nbig, 0, B * sizeof(int)) == hipSuccess && hipMemset(o.is_ground, 0, B * N * sizeof(int)) == hipSuccess;
+      ok = ok && dalloc(b, o.rhist, B * T * 256) && dalloc(b, o.gnz, B) && dalloc(b, o.vnz, B) && dalloc(b, o.rawbuf, B * N) && dalloc(b, o.is_ground, B * N) && dalloc(b, o.vcent, B * N) && dalloc(b, o.vbin, B * N) && dalloc(b, o.g2_big, B * N) && dalloc(b, o.g2_nbig, B) && hipMemset(o.g2_nbig, 0, B * sizeof(int)) == hipSuccess && hipMemset(o.is_ground, 0, B * N * sizeof(int)) == hipSuccess;
       o.skey = o.rkeys[d.voxel_passes & 1]; o.sidx = o.rvals[d.voxel_passes & 1];
     }
     if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d, max_points=%llu, copy %d of %d)", d.B, (unsigned long long)max_points, c + 1, (int)b->pipe_depth));

@@ -385,6 +385,21 @@ __global__ __launch_bounds__(MOR_BT) void k_classify(MorDev d) {
   }
 }
 
+// Voxel ground variant, pass A: z layers of the VoxelGrid lattice this stream's trimmed cloud needs (cz = floor(z·inv) − floor(zmin·inv)), at most the configured
+// number.  The lattice is laid out for 64 m of z, a sweep spans a few metres: with the stream's own layer count the voxel keys are 23 instead of 27 bits (three
+// radix passes instead of four) and the (y,z) row table 12 000 instead of 161 000 rows.  From the ordered-int z range k_classify leaves (final at the kernel boundary).
+__device__ __forceinline__ int voxel_layers(const MorDev &d, int s) {
+  const int zl = d.zmin_i[s], zh = d.zmax_i[s];
+  if (zl > zh) return 1;   // no trimmed point
+  const int l = (int)floorf(ordered_float(zh) * d.g.inv_cs) - (int)floorf(ordered_float(zl) * d.g.inv_cs) + 1;
+  return max(1, min(d.g.nz, l));
+}
+// radix passes (8-bit digits) the stream's voxel keys need: keys < nx·ny·(its layers)
+__device__ __forceinline__ int voxel_passes_of(const MorDev &d, int s) {
+  const long long cells = (long long)d.g.nx * d.g.ny * (d.gnz ? d.gnz[s] : d.g.nz);
+  const int bits = cells > 1 ? 64 - __clzll(cells - 1) : 1;
+  return (bits + 7) >> 3;
+}
 // T, M, G of the frame (and, for pass A of the voxel variant, the z origin of its grids)
 __device__ __forceinline__ void publish_split(const MorDev &d, int s, int n_ng, int n_g) {
   MorFrameInfo &f = d.info[s];
@@ -397,12 +412,14 @@ __device__ __forceinline__ void publish_split(const MorDev &d, int s, int n_ng, 
       const float zmax = f.T ? ordered_float(d.zmax_i[s]) : 0.f;
       d.gnz_out[s] = max(1, min(d.cg_nz, (int)floorf((zmax - zmin) * d.cg_inv_cs) + 2));
     }
+    if (d.vnz_out) d.vnz_out[s] = voxel_layers(d, s);   // layers of the VoxelGrid lattice (the later kernels of pass A read it through stream_grid)
   }
 }
 // pass 2: order-preserving split into `cloud` / ground, cell histogram, forest init
 __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
   int s, t0; map_block(d.B, d.split_g, s, t0);
-  const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
+  MorGrid G = d.gmode == 1 ? d.g : stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers); pass A: the VoxelGrid lattice, whose layers for this stream follow from the z range k_classify left (below)
+  if (d.gmode == 1) { G.nz = voxel_layers(d, s); G.nrows = G.ny * G.nz; }
   const MorStreamArgs a = d.args[s];
   const uint32_t n_in = pass_count(d, a, s);
   __shared__ int sh[8];
@@ -648,7 +665,7 @@ __device__ __forceinline__ bool is_head(const int *skey, int p) { return p == 0 
 __global__ __launch_bounds__(MOR_BT) void k_heads_count(MorDev d) {
   int s, t0; map_block(d.B, d.tiles_m, s, t0);
   const int M = d.info[s].M;
-  const int *skey = d.skey + (size_t)s * d.Nmax;
+  const int *skey = d.rkeys[voxel_passes_of(d, s) & 1] + (size_t)s * d.Nmax;   // (the ping-pong buffer the stream's last radix pass wrote)
   __shared__ int sh[8];
   for (int t = t0; t * MOR_TILE < M; t += d.tiles_m) {   // grid-stride over the tiles this stream really has
     int base = t * MOR_TILE, c = 0, tot;
@@ -717,7 +734,8 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   const int M = d.info[s].M;
   const size_t so = (size_t)s * d.Nmax;
-  const int *skey = d.skey + so, *sidx = d.sidx + so;
+  const int np_s = voxel_passes_of(d, s);
+  const int *skey = d.rkeys[np_s & 1] + so, *sidx = d.rvals[np_s & 1] + so;   // (the ping-pong buffers the stream's last radix pass wrote: keys in order, inverse permutation)
   int *cstart = d.cstart + (size_t)s * (d.Nmax + 1);
   __shared__ int sh[12], l_gap[3 * 64], l_ng;
   int *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
@@ -739,24 +757,26 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
     { int tot; wg_prefix_total(d.ktile_cnt + (size_t)s * d.tiles_max, 1, t, nt, sh + 4, r, tot); }
     for (int w = 0; w < wave_id(); ++w) r += sh[w];
     __syncthreads();
-    // the eight gathers of a thread as one batch of independent loads, ahead of the stores (which may alias them as far as the compiler knows and kept
-    // them one round trip after the other: 7 M random 16-byte reads per launch of the voxel ground variant, 544 µs alone)
-    int pi[8]; float4 pq[8];
+    // The points MOVE to their places: `sidx` holds the inverse permutation (input index → sorted position, written by the last radix pass), so the
+    // trimmed cloud is read in input order (coalesced) and every point is stored to its slot — writes nobody waits for, which the L2 combines (points that
+    // follow each other in a sweep fall into the same or neighbouring voxels).  (Rounds 2–4 gathered: sorted position → input index → point, 7 M dependent
+    // random 16-byte reads per step that each pulled a whole sector: 650 MB and 417 µs alone.)
+    {
+      int pi[8]; float4 pq[8];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) { const int p = base + it * 64 + lane_id(); pi[it] = p < M ? ld_stream(sidx + p) : 0; }
+      for (int it = 0; it < 8; ++it) { const int i = base + it * 64 + lane_id(); pi[it] = i < M ? ld_stream(sidx + i) : 0; pq[it] = ld_stream(&d.cloud[so + min(i, M - 1)]); }
 #pragma unroll
-    for (int it = 0; it < 8; ++it) pq[it] = d.cloud[so + pi[it]];
+      for (int it = 0; it < 8; ++it) { const int i = base + it * 64 + lane_id(); if (i < M) { float4 q = pq[it]; q.w = __int_as_float(i); d.sorted[so + pi[it]] = q; } }
+    }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       int p = base + it * 64 + lane_id();
       if (p < M) {
         bool head = (mh[it] >> lane_id()) & 1ull;
         int c = r + __popcll(mh[it] & lanemask_lt()) + (head ? 1 : 0) - 1;
-        int i = pi[it];
         if (head) {
           const int kc = skey[p];
           d.ckey[so + c] = kc; cstart[c] = p;
-          d.parent[so + c] = c; d.csize[so + c] = 0; d.compmin[so + c] = 0x7fffffff; d.cid_of_root[so + c] = -1;
           // dense (y,z) row table: rs[r] = first cell with key ≥ r·nx.  The head of cell c owns the rows after its
           // predecessor's row up to its own (keys ascend), so the table is written without any search
           const int rc = kc / G.nx, rp = p > 0 ? skey[p - 1] / G.nx : -1;
@@ -767,8 +787,7 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
           const int rl = skey[p] / G.nx;
           const int g = atomicAdd(&l_ng, 1); if (g < 64) { l_gap[3 * g] = rl; l_gap[3 * g + 1] = G.nrows; l_gap[3 * g + 2] = c + 1; } else for (int r = rl + 1; r <= G.nrows; ++r) rs[r] = c + 1;
         }
-        float4 q = pq[it]; q.w = __int_as_float(i);
-        d.sorted[so + p] = q; if (d.scell) d.scell[so + p] = c;
+        if (d.scell) d.scell[so + p] = c;
       }
       r += __popcll(mh[it]);
     }
@@ -1964,6 +1983,7 @@ __device__ __forceinline__ void radix_item(const MorRadix &j, size_t so, int cou
 }
 __device__ __forceinline__ int radix_count(const MorDev &d, const MorRadix &j, int s) {
   if (j.skip_k_le > 0 && (int)d.info[s].K <= j.skip_k_le) return 0;   // all higher digits are zero: the previous pass already produced the final order
+  if (j.vox && (j.shift >> 3) >= voxel_passes_of(d, s)) return 0;   // voxel keys of this stream end below this digit: its order is final (the consumers pick the buffer by the stream's pass count)
   return j.count_sel == 0 ? d.info[s].M : d.info[s].C;
 }
 
@@ -2002,6 +2022,7 @@ __global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, MorRadix j) {
   int s, t0; map_block(d.B, d.tiles_m, s, t0);
   const int count = radix_count(d, j, s);
   const size_t so = (size_t)s * d.Nmax;
+  const bool inverse = j.inverse && (!j.vox || (j.shift >> 3) == voxel_passes_of(d, s) - 1);   // the stream's LAST pass leaves the inverse permutation
   __shared__ int wcnt[4][256]; __shared__ int shs[8];
   for (int t = t0; t * MOR_TILE < count; t += d.tiles_m) {
     const int tb = t * MOR_TILE;
@@ -2048,7 +2069,7 @@ __global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, MorRadix j) {
       int dg = (key[it] >> j.shift) & 255;
       int pos = wcnt[wave_id()][dg] + pre[it];
       if (j.kout) j.kout[so + pos] = key[it];
-      j.vout[so + pos] = val[it];
+      if (inverse) j.vout[so + val[it]] = pos; else j.vout[so + pos] = val[it];
       if (j.vout2) j.vout2[so + pos] = val[it];
     }
     __syncthreads();
@@ -2940,11 +2961,12 @@ template <int NT> __device__ __forceinline__ void decide_body(const MorDev &d, i
 __device__ __forceinline__ void g2_gather(const MorDev &d, int s, float4 q, unsigned long long *key, int *cnt, int cap) {
   const size_t so = (size_t)s * d.Nmax;
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
-  int cx, cy, cz; bool cl; grid_cell(d.g, q, 0.f, d.zbase[s], cx, cy, cz, cl);
+  const MorGrid G = stream_grid(d, s);   // the lattice with the stream's own z layers
+  int cx, cy, cz; bool cl; grid_cell(G, q, 0.f, d.zbase[s], cx, cy, cz, cl);
   for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
     const int y = cy + dy, z = cz + dz;
-    if ((unsigned)y >= (unsigned)d.g.ny || (unsigned)z >= (unsigned)d.g.nz) continue;
-    int lo, hi; row_cells(d.g, ckey, rs, max(cx - 1, 0), min(cx + 1, d.g.nx - 1), y, z, lo, hi);
+    if ((unsigned)y >= (unsigned)G.ny || (unsigned)z >= (unsigned)G.nz) continue;
+    int lo, hi; row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
     if (lo >= hi) continue;
     for (int k = st[lo] + threadIdx.x, e = st[hi]; k < e; k += blockDim.x) {
       const float4 p = d.sorted[so + k];
@@ -2963,12 +2985,13 @@ template <class F> __device__ __forceinline__ void g2_for_neighbours(const MorDe
   const size_t so = (size_t)s * d.Nmax;
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const int lane = threadIdx.x & 63;
-  int cx, cy, cz; bool cl; grid_cell(d.g, q, 0.f, d.zbase[s], cx, cy, cz, cl);
+  const MorGrid G = stream_grid(d, s);
+  int cx, cy, cz; bool cl; grid_cell(G, q, 0.f, d.zbase[s], cx, cy, cz, cl);
   int b0 = 0, len = 0;
   if (lane < 9) {
     const int y = cy + lane % 3 - 1, z = cz + lane / 3 - 1;
-    if ((unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) {
-      int lo, hi; row_cells(d.g, ckey, rs, max(cx - 1, 0), min(cx + 1, d.g.nx - 1), y, z, lo, hi);
+    if ((unsigned)y < (unsigned)G.ny && (unsigned)z < (unsigned)G.nz) {
+      int lo, hi; row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
       if (lo < hi) { b0 = st[lo]; len = st[hi] - b0; }
     }
   }
@@ -3142,7 +3165,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
   const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15, lane = lane_id();   // group in the workgroup, lane in the group
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
-  const int zbase = d.zbase[s];
+  const int zbase = d.zbase[s]; const MorGrid G = stream_grid(d, s);   // (the lattice with the stream's own z layers)
   for (int v0 = bxv * (MOR_BT / 16); v0 < V; v0 += G2_COV_G * (MOR_BT / 16)) {
     const int v = v0 + grp; const bool act = v < V;
     G2_TICK(k0);
@@ -3166,10 +3189,10 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
     // ---- the nine (y,z) rows of the 3×3×3 block: lanes 0 … 8 of the group, each row's three x-cells are one range of `sorted`
     int rb0 = 0, rlen = 0;
     if (act && sub < 9) {
-      int cx, cy, cz; bool cl; grid_cell(d.g, q, 0.f, zbase, cx, cy, cz, cl);
+      int cx, cy, cz; bool cl; grid_cell(G, q, 0.f, zbase, cx, cy, cz, cl);
       const int y = cy + sub % 3 - 1, z = cz + sub / 3 - 1;
-      if ((unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) {
-        int lo, hi; row_cells(d.g, ckey, rs, max(cx - 1, 0), min(cx + 1, d.g.nx - 1), y, z, lo, hi);
+      if ((unsigned)y < (unsigned)G.ny && (unsigned)z < (unsigned)G.nz) {
+        int lo, hi; row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
         if (lo < hi) { rb0 = st[lo]; rlen = st[hi] - rb0; }
       }
     }
@@ -3225,7 +3248,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
   __shared__ float l_x[MOR_BT / 64][G2_MID_CAP], l_y[MOR_BT / 64][G2_MID_CAP], l_z[MOR_BT / 64][G2_MID_CAP];
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
-  const int zbase = d.zbase[s];
+  const int zbase = d.zbase[s]; const MorGrid G = stream_grid(d, s);   // (the lattice with the stream's own z layers)
   for (int w0 = bxq * (MOR_BT / 64); w0 < nbig; w0 += gq * (MOR_BT / 64)) {
     const int w = w0 + wv;
     if (w >= nbig) continue;   // (wave-uniform; nothing below synchronises the workgroup)
@@ -3233,10 +3256,10 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
     const float4 q = d.vcent[so + v];
     int rb0 = 0, rlen = 0;
     if (lane < 9) {
-      int cx, cy, cz; bool cl; grid_cell(d.g, q, 0.f, zbase, cx, cy, cz, cl);
+      int cx, cy, cz; bool cl; grid_cell(G, q, 0.f, zbase, cx, cy, cz, cl);
       const int y = cy + lane % 3 - 1, z = cz + lane / 3 - 1;
-      if ((unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) {
-        int lo, hi; row_cells(d.g, ckey, rs, max(cx - 1, 0), min(cx + 1, d.g.nx - 1), y, z, lo, hi);
+      if ((unsigned)y < (unsigned)G.ny && (unsigned)z < (unsigned)G.nz) {
+        int lo, hi; row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
         if (lo < hi) { rb0 = st[lo]; rlen = st[hi] - rb0; }
       }
     }
@@ -3363,6 +3386,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mark(MorDev d) {
   const int lane = lane_id(), nw = 128 * (MOR_BT / 64), grp = lane >> 4, sub = lane & 15;
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
+  const MorGrid G = stream_grid(d, s);   // (the lattice with the stream's own z layers)
   const int zbase = d.zbase[s], tag = d.frame_no + 1;   // the frame's tag (never 0, never an earlier frame's on this copy of the array): nothing has to be cleared
   for (int v0 = (bxm * (MOR_BT / 64) + wave_id()) * 64; v0 < V; v0 += nw * 64) {
     unsigned long long m = __ballot(v0 + lane < V && d.vbin[so + min(v0 + lane, V - 1)] == mode);
@@ -3377,10 +3401,10 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mark(MorDev d) {
       const float4 q = d.vcent[so + v0 + max(l, 0)];
       int rb0 = 0, rlen = 0;
       if (act && sub < 9) {
-        int cx, cy, cz; bool cl; grid_cell(d.g, q, 0.f, zbase, cx, cy, cz, cl);
+        int cx, cy, cz; bool cl; grid_cell(G, q, 0.f, zbase, cx, cy, cz, cl);
         const int y = cy + sub % 3 - 1, z = cz + sub / 3 - 1;
-        if ((unsigned)y < (unsigned)d.g.ny && (unsigned)z < (unsigned)d.g.nz) {
-          int lo, hi; row_cells(d.g, ckey, rs, max(cx - 1, 0), min(cx + 1, d.g.nx - 1), y, z, lo, hi);
+        if ((unsigned)y < (unsigned)G.ny && (unsigned)z < (unsigned)G.nz) {
+          int lo, hi; row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
           if (lo < hi) { rb0 = st[lo]; rlen = st[hi] - rb0; }
         }
       }
@@ -3793,7 +3817,7 @@ grid:
     MOR_LAUNCH_T(MK_GRIDPLACE, k_gridplace, dim3(d.B * d.gc_P), GC_T, d);
   } else {
     for (int pass = 0; pass < d.cell_passes; ++pass) {   // points sorted by cell key; result in (skey, sidx) = buffers [cell_passes & 1]
-      MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0, d.tiles_m <= 64};
+      MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0, d.tiles_m <= 64, 1, 1};   // (a stream's last pass — by its own key width — leaves the inverse permutation: k_heads_scatter moves the points)
       MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
       if (!j.fuse) MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
       MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
@@ -3812,7 +3836,7 @@ static void mor_launch_boxes(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
 static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gB(d.B);
   MorDev da = d; da.gmode = 1; da.g = d.gv; da.cloud = d.rawbuf; da.cell_passes = d.voxel_passes; da.tiles_m = d.tiles; da.use_hash = 0;
-  da.gnz_out = d.gnz; da.gnz = nullptr; da.cg_nz = d.g.nz; da.cg_inv_cs = d.g.inv_cs;
+  da.gnz_out = d.gnz; da.gnz = d.vnz; da.vnz_out = d.vnz; da.cg_nz = d.g.nz; da.cg_inv_cs = d.g.inv_cs;   // (pass A's kernels behind the split see the lattice with the stream's own layers through stream_grid) da.scell = nullptr;   // (nobody reads the cell of a position of the voxel-ordered cloud)
   da.skey = d.rkeys[da.cell_passes & 1]; da.sidx = d.rvals[da.cell_passes & 1];
   if (sub == 0) {
     // (z range, ground flags and the queue of big voxels need no clearing launches: their last readers of the previous frame on this copy
