@@ -96,7 +96,7 @@ struct MorDev {
   MorGrid g;                 // clustering grid (cell edge 0.57·r)
   MorGrid gv;                // VoxelGrid lattice of the voxel-covariance ground removal (cell edge gp_leaf)
   int gmode;                 // 0: crop-box ground removal; 1 / 2: passes A (trim) / B (split by ground flag) of the voxel variant
-  int voxel_passes; float leaf_r2;
+  int voxel_passes; float leaf_r2; double g2_r, g2_inv_r;   // g2_r = √leaf_r2 · 1.0001 + 1e-6: the radius as the screen of the voxel verdicts bounds coordinates with it; g2_inv_r = 1 / √leaf_r2 · 1.0001
   // ---- per call
   int tiles;                 // ceil(max n_points of this batch / MOR_TILE)
   int tiles_m;               // workgroups per stream for kernels over the non-ground cloud / clusters: an estimate from the

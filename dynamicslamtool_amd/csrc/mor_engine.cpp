@@ -196,7 +196,7 @@ static int configure(mor_batch *b) {
   d.g.keybits = 1; while ((1ll << d.g.keybits) < (long long)(nx * ny * nz)) ++d.g.keybits;
   d.cell_passes = (d.g.keybits + 7) / 8;
   d.g.ox = -p.trim_x; d.g.oy = -p.trim_y; d.g.oz = zlo; d.g.cs = cs; d.g.inv_cs = 1.0f / cs; d.g.mode = 0; d.g.ibx = d.g.iby = 0;
-  d.gv = d.g; d.voxel_passes = 0; d.leaf_r2 = 0.f;
+  d.gv = d.g; d.voxel_passes = 0; d.leaf_r2 = 0.f; d.g2_r = 0.0; d.g2_inv_r = 0.0;
   if (d.gmode == 1) {   // VoxelGrid lattice: cells at absolute multiples of the leaf (pcl::VoxelGrid: floor(x·inv_leaf)), :110-113
     MorGrid &v = d.gv; v.mode = 1; v.cs = p.gp_leaf; v.inv_cs = 1.0f / p.gp_leaf;
     v.ibx = (int)std::floor(-p.trim_x * v.inv_cs); v.iby = (int)std::floor(-p.trim_y * v.inv_cs);
@@ -207,7 +207,7 @@ static int configure(mor_batch *b) {
     v.nx = (int)vx; v.ny = (int)vy; v.nz = (int)vz; v.nrows = v.ny * v.nz;
     v.keybits = 1; while ((1ll << v.keybits) < (long long)(vx * vy * vz)) ++v.keybits;
     d.voxel_passes = (v.keybits + 7) / 8;
-    double lf = (double)p.gp_leaf; d.leaf_r2 = (float)(lf * lf);   // radiusSearch(…, gp_leaf): (float)(radius·radius)
+    double lf = (double)p.gp_leaf; d.leaf_r2 = (float)(lf * lf); d.g2_r = std::sqrt((double)d.leaf_r2) * 1.0001 + 1e-6; d.g2_inv_r = 1.0001 / std::sqrt((double)d.leaf_r2);   // radiusSearch(…, gp_leaf): (float)(radius·radius)
   }
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
   d.two_pass_split = (getenv("MOR_SINGLE_PASS_SPLIT") && atoi(getenv("MOR_SINGLE_PASS_SPLIT")) == 0) ? 1 : 0;   // default: the single-read split (k_split); MOR_SINGLE_PASS_SPLIT=0: count pass + scatter pass (what pass A of the voxel ground variant always uses)

@@ -3106,12 +3106,14 @@ __device__ __forceinline__ bool g2_ordered_sums3(const float *lx, const float *l
 //   their sequential fp32 sum:                       ≤ γ_{n−1} · Σ (|a_i| + Δx)(|c_i| + Δz)
 //   ⇒ |t_ref − t| ≤ (1 + γ)(Δz·Σ|a_i| + Δx·Σ|c_i| + n·Δx·Δz) + γ·Σ|a_i·c_i|,  γ = γ_{n+3}
 // (the sums of absolute values around c are bounded through those around q).  The verdict is taken with TWICE that bound plus 1e-9 for the fp64 arithmetic here.
-struct G2Acc { double Sa, Sb, Sc, Sac, Sbc, Scc, Aa, Ab, Ac, Aac, Abc; int n; };
-__device__ __forceinline__ void g2_acc_zero(G2Acc &A) { A.Sa = A.Sb = A.Sc = A.Sac = A.Sbc = A.Scc = A.Aa = A.Ab = A.Ac = A.Aac = A.Abc = 0.0; A.n = 0; }
-__device__ __forceinline__ void g2_acc_add(G2Acc &A, const float4 &q, const float4 &p) {
+// (Sums of absolute values are not accumulated one by one: Σd² — the squared distances the radius test has just worked out — bounds them all: |a| ≤ (r + a²/r) / 2 gives
+//  Σ|a_i| ≤ (n·r + Σd²/r) / 2 and |a·c| ≤ (a² + c²) / 2 gives Σ|a_i·c_i| ≤ Σd² / 2.  The sixteen-lane kernel's time IS this fp64 arithmetic — every candidate step pays for it as
+//  soon as one lane has a hit, then the sums are reduced over the group —: seven additions per hit and eight reduced values instead of eleven and twelve.)
+struct G2Acc { double Sa, Sb, Sc, Sac, Sbc, Scc, Sdd; int n; };
+__device__ __forceinline__ void g2_acc_zero(G2Acc &A) { A.Sa = A.Sb = A.Sc = A.Sac = A.Sbc = A.Scc = A.Sdd = 0.0; A.n = 0; }
+__device__ __forceinline__ void g2_acc_add(G2Acc &A, const float4 &q, const float4 &p, float dd /* sqdist(q, p) */) {
   const double a = (double)p.x - (double)q.x, b = (double)p.y - (double)q.y, c = (double)p.z - (double)q.z;   // exact: differences of two floats
-  A.Sa += a; A.Sb += b; A.Sc += c; A.Sac += a * c; A.Sbc += b * c; A.Scc += c * c;
-  A.Aa += fabs(a); A.Ab += fabs(b); A.Ac += fabs(c); A.Aac += fabs(a * c); A.Abc += fabs(b * c);
+  A.Sa += a; A.Sb += b; A.Sc += c; A.Sac += a * c; A.Sbc += b * c; A.Scc += c * c; A.Sdd += (double)dd;
   ++A.n;
 }
 template <int W> __device__ __forceinline__ void g2_acc_reduce(G2Acc &A) {   // over the W lanes of the caller's group (W = 16 or 64, aligned)
@@ -3119,20 +3121,22 @@ template <int W> __device__ __forceinline__ void g2_acc_reduce(G2Acc &A) {   // 
   for (int o = W / 2; o > 0; o >>= 1) {
     A.Sa += __shfl_xor(A.Sa, o, 64); A.Sb += __shfl_xor(A.Sb, o, 64); A.Sc += __shfl_xor(A.Sc, o, 64);
     A.Sac += __shfl_xor(A.Sac, o, 64); A.Sbc += __shfl_xor(A.Sbc, o, 64); A.Scc += __shfl_xor(A.Scc, o, 64);
-    A.Aa += __shfl_xor(A.Aa, o, 64); A.Ab += __shfl_xor(A.Ab, o, 64); A.Ac += __shfl_xor(A.Ac, o, 64);
-    A.Aac += __shfl_xor(A.Aac, o, 64); A.Abc += __shfl_xor(A.Abc, o, 64); A.n += __shfl_xor(A.n, o, 64);
+    A.Sdd += __shfl_xor(A.Sdd, o, 64); A.n += __shfl_xor(A.n, o, 64);
   }
 }
 // 1: accepted (:145 holds whatever the order), 0: rejected, −1: too close to call — the ordered sums decide.  n > 3.
-__device__ __forceinline__ int g2_screen(const G2Acc &A, const float4 &q, float leaf_r2) {
-  const double n = (double)A.n, u = 5.9604644775390625e-8, r = sqrt((double)leaf_r2) * 1.0001 + 1e-6;
-  const double ma = A.Sa / n, mb = A.Sb / n, mc = A.Sc / n;   // centroid − q
+__device__ __forceinline__ int g2_screen(const G2Acc &A, const float4 &q, double leaf_r /* √leaf² · 1.0001 + 1e-6, from the host */, double inv_r /* 1 / √leaf² */) {
+  // (one division and no square root: sixteen lanes wait while one works this out for its group — r comes from the host, 1 / (1 − x) ≤ 1 + 2x for x ≤ ½)
+  const double n = (double)A.n, u = 5.9604644775390625e-8, r = leaf_r;
+  const double inv_n = 1.0 / n, ma = A.Sa * inv_n, mb = A.Sb * inv_n, mc = A.Sc * inv_n;   // centroid − q
   const double txz = A.Sac - A.Sa * mc, tyz = A.Sbc - A.Sb * mc, tzz = A.Scc - A.Sc * mc;
   const double fa = fabs(ma), fb = fabs(mb), fc = fabs(mc);
-  const double sa = A.Aa + n * fa, sb = A.Ab + n * fb, sc = A.Ac + n * fc;   // ≥ Σ|x_i − c| …
-  const double axz = A.Aac + fc * A.Aa + fa * A.Ac + n * fa * fc, ayz = A.Abc + fc * A.Ab + fb * A.Ac + n * fb * fc, azz = A.Scc + 2.0 * fc * A.Ac + n * fc * fc;   // ≥ Σ|(x_i − c)(z_i − c)| …
+  const double sdd = A.Sdd * 1.000001 + 1e-12;   // ≥ Σ d_i² (the fp32 distances carry three roundings each)
+  const double ab1 = 0.5 * (n * r + sdd * inv_r), ab2 = 0.5 * sdd;   // ≥ Σ|a_i|, Σ|b_i|, Σ|c_i|;  ≥ Σ|a_i·c_i|, Σ|b_i·c_i|
+  const double sa = ab1 + n * fa, sb = ab1 + n * fb, sc = ab1 + n * fc;   // ≥ Σ|x_i − c| …
+  const double axz = ab2 + fc * ab1 + fa * ab1 + n * fa * fc, ayz = ab2 + fc * ab1 + fb * ab1 + n * fb * fc, azz = A.Scc + 2.0 * fc * ab1 + n * fc * fc;   // ≥ Σ|(x_i − c)(z_i − c)| …
   if ((n + 4.0) * u > 0.25) return -1;   // (millions of neighbours: the bound says nothing any more)
-  const double g = 1.01 * (n + 4.0) * u / (1.0 - (n + 4.0) * u);
+  const double xg = (n + 4.0) * u, g = 1.01 * xg * (1.0 + 2.0 * xg);   // ≥ 1.01·γ_{n+4}
   const double Dx = g * (fabs((double)q.x) + r), Dy = g * (fabs((double)q.y) + r), Dz = g * (fabs((double)q.z) + r);
   const double Exz = (1.0 + g) * (Dz * sa + Dx * sc + n * Dx * Dz) + g * axz;
   const double Eyz = (1.0 + g) * (Dz * sb + Dy * sc + n * Dy * Dz) + g * ayz;
@@ -3152,6 +3156,7 @@ __device__ __forceinline__ int g2_screen(const G2Acc &A, const float4 &q, float 
 // and the voxels the screen could not settle (tagged: their ordered sums are due).
 #define G2_NARROW_CAND 512
 #define G2_Q_EXACT (1 << 30)   // queue entry: the screen has been through this voxel and left it to the ordered sums
+#define G2_V_NONE 0x7fffffff   // bin word of a voxel without a bin (rejected, or ≤ 3 neighbours)
 #define G2_COV_G 256   // workgroups per stream of k_g2_cov; 64 of the middle / big tiers, 128 of k_g2_mark
 #ifdef MOR_EXP_STAMPS
 #define G2_TICK(v) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long v = wall_clock64()
@@ -3219,14 +3224,15 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = c0 + 16 * u + sub; const float4 p = pc[u];
-        if (c < ncand && sqdist(q.x, q.y, q.z, p.x, p.y, p.z) < d.leaf_r2) g2_acc_add(A, q, p);
+        const float dd = sqdist(q.x, q.y, q.z, p.x, p.y, p.z);
+        if (c < ncand && dd < d.leaf_r2) g2_acc_add(A, q, p, dd);
       }
     }
     G2_TICK(k3);
     g2_acc_reduce<16>(A);
     if (act && sub == 0) {
-      const int verdict = wide ? -2 : A.n > 3 ? (d.g2_exact_only ? -1 : g2_screen(A, q, d.leaf_r2)) : 0;
-      if (verdict < 0) { const int slot = atomicAdd(&d.g2_nbig[s], 1); d.g2_big[so + slot] = verdict == -1 ? (v | G2_Q_EXACT) : v; }
+      const int verdict = wide ? -2 : A.n > 3 ? (d.g2_exact_only ? -1 : g2_screen(A, q, d.g2_r, d.g2_inv_r)) : 0;
+      if (verdict < 0) d.g2_big[so + atomicAdd(&d.g2_nbig[s], 1)] = verdict == -1 ? (v | G2_Q_EXACT) : v;
       else d.vbin[so + v] = verdict ? (int)(q.z * 10) : 0x7fffffff;
     }
 #ifdef MOR_EXP_STAMPS
@@ -3250,6 +3256,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
   const float4 *sp = d.sorted + so;
   const int zbase = d.zbase[s]; const MorGrid G = stream_grid(d, s);   // (the lattice with the stream's own z layers)
   for (int w0 = bxq * (MOR_BT / 64); w0 < nbig; w0 += gq * (MOR_BT / 64)) {
+   {
     const int w = w0 + wv;
     if (w >= nbig) continue;   // (wave-uniform; nothing below synchronises the workgroup)
     const int qe = d.g2_big[so + w], v = qe & ~G2_Q_EXACT;
@@ -3277,12 +3284,12 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const int c = c0 + 64 * u + lane; pc[u] = sp[c < rp[9] ? cand(c) : 0]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int c = c0 + 64 * u + lane; const float4 p = pc[u]; if (c < rp[9] && sqdist(q.x, q.y, q.z, p.x, p.y, p.z) < d.leaf_r2) g2_acc_add(A, q, p); }
+        for (int u = 0; u < 4; ++u) { const int c = c0 + 64 * u + lane; const float4 p = pc[u]; const float dd = sqdist(q.x, q.y, q.z, p.x, p.y, p.z); if (c < rp[9] && dd < d.leaf_r2) g2_acc_add(A, q, p, dd); }
       }
       g2_acc_reduce<64>(A);
-      const int verdict = A.n > 3 ? g2_screen(A, q, d.leaf_r2) : 0;
+      const int verdict = A.n > 3 ? g2_screen(A, q, d.g2_r, d.g2_inv_r) : 0;
       if (verdict >= 0) {
-        if (lane == 0) { d.vbin[so + v] = verdict ? (int)(q.z * 10) : 0x7fffffff; d.g2_big[so + w] = ~v; }
+        if (lane == 0) { d.vbin[so + v] = verdict ? (int)(q.z * 10) : G2_V_NONE; d.g2_big[so + w] = ~v; }
         continue;
       }
     }
@@ -3305,7 +3312,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
     }
     wave_lds_fence();
     const bool mine = n <= G2_MID_CAP;
-    if (!mine) { if (lane == 0) d.g2_big[so + w] = v; continue; }   // (the tag comes off: k_g2_cov_big takes every entry ≥ 0)
+    if (!mine) { if (lane == 0) d.g2_big[so + w] = v; continue; }   // (the tags come off: k_g2_cov_big takes every entry ≥ 0)
     float ex[G2_MID_CAP / 64], ey[G2_MID_CAP / 64], ez[G2_MID_CAP / 64]; int er[G2_MID_CAP / 64];
 #pragma unroll
     for (int u = 0; u < G2_MID_CAP / 64; ++u) {
@@ -3321,11 +3328,9 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
     for (int u = 0; u < G2_MID_CAP / 64; ++u) if (er[u] >= 0) { l_x[wv][er[u]] = ex[u]; l_y[wv][er[u]] = ey[u]; l_z[wv][er[u]] = ez[u]; }
     wave_lds_fence();
     const bool acc3 = g2_ordered_sums3(l_x[wv], l_y[wv], l_z[wv], n, n > 3, 0);
-    if (lane == 0) {
-      d.vbin[so + v] = (n > 3 && acc3) ? (int)(q.z * 10) : 0x7fffffff;
-      d.g2_big[so + w] = ~v;   // done
-    }
+    if (lane == 0) { d.vbin[so + v] = (n > 3 && acc3) ? (int)(q.z * 10) : G2_V_NONE; d.g2_big[so + w] = ~v; }
     wave_lds_fence();
+   }
   }
 }
 // what the middle tier left: one 1024-thread workgroup each (the LDS lets only one live on a CU anyway: sixteen waves sort four times faster than
