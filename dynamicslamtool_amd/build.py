@@ -18,7 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.normpath(os.path.join(HERE, "..", "include"))
 HIP_SOURCES = ["mor_kernels.hip", "mor_engine.cpp"]
-HIP_HEADERS = ["mor_device.h", os.path.join(INC, "mor_hip.h")]
+HIP_HEADERS = ["mor_device.h", os.path.join(INC, "mor_hip.h"), "kernels_common.h", "kernels_split.h", "kernels_grid.h", "kernels_cellgraph.h", "kernels_radix.h", "kernels_clusters.h",
+               "kernels_scores.h", "kernels_ground_voxel.h", "kernels_track_out.h"]   # the kernels by stage: #included by mor_kernels.hip (one translation unit)
 HIP_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
              "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 SYNTH_FLAGS = ["-O2", "-fPIC", "-shared", "-fopenmp"]

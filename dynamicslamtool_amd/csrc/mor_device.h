@@ -216,8 +216,6 @@ struct MorDev {
   int *tr_match;             // [B][MOR_TR_MAXT+1]  latest filterCloud: number of tracked centroids its loop visited, then the cluster each was matched to, in mo_vec order (the reference's bounding-box markers, :641)
   int moving_confidence, static_confidence; float leave_off, catch_up;
   float4 *const *out_ptrs;   // [B] or null
-  unsigned long long *dbg;   // [B][16] experiment stamps (MOR_EXP_STAMPS builds only)
-  unsigned long long *dbg2;  // [B][MOR_MAXP+2][16] experiment stamps of the slab workgroups, k_gridhash, k_cg_final
   // ---- pinned host mirrors written by the device (zero-copy summaries)
   MorFrameInfo *h_info;      // [B]
   float4 *h_centroid;        // [B][Kcap]

@@ -121,7 +121,7 @@ struct mor_batch {
   std::vector<void *> dev_allocs, host_allocs;
   MorStreamArgs *h_args_ring = nullptr, *h_args = nullptr;   // pinned ring of MOR_ARGS_RING slots (async pushes), current slot
   uint64_t pipe_depth = 4, n_slots = 5;       // frames in flight (= copies of the per-frame arrays); cluster-array slots = depth + 1
-  int env_cg_p = 0, env_gc_p = 0;         // tuning knobs from the environment (MOR_CG_P, MOR_GC_P), read once at creation
+  int env_cg_p = 0;         // test knob from the environment (MOR_CG_P: slabs per stream of the cell graph), read once at creation
   bool async = false, pending = false;   // async: push/filter only enqueue; pending: work enqueued since the last wait
   float4 **h_outptrs = nullptr, **d_outptrs = nullptr;   // caller-provided output pointers: pinned ring of MOR_ARGS_RING tables (one per filterCloud in flight), device copy per frame in flight
   hipEvent_t outptr_ev[MOR_ARGS_RING] = {}; uint64_t n_filters = 0, n_filter_calls = 0;
@@ -218,28 +218,18 @@ static int configure(mor_batch *b) {
     d.sp_g = std::max(2, std::min(32, hold / b->B));
     if (getenv("MOR_SP_G")) d.sp_g = std::max(2, std::min(64, atoi(getenv("MOR_SP_G"))));   // (test knob: tests/test_gpu_parity.py runs 64 per stream, four times what the GPU holds)
     if (b->B * 2 > hold) d.two_pass_split = 1;
-    if (getenv("MOR_DEBUG")) fprintf(stderr, "mor: k_split %d workgroups per CU, sp_g %d\n", mor_split_blocks_per_cu(), d.sp_g);
   }
-  d.xcd_map = getenv("MOR_NO_XCD_MAP") ? 0 : 1;
+  d.xcd_map = 1;   // the workgroups of a stream share an XCD (streams spread over all XCDs: −24 %)
   d.prop_map = getenv("MOR_PROP_MAP") ? atoi(getenv("MOR_PROP_MAP")) != 0 : 1;
   // workgroups per stream (launch widths; the kernels share them out over the streams in proportion to the streams' work, map_block_work): tier 1 of the scores
   // (1024 threads each, two per CU), tiers 1a + 1b together (512 threads; they share out the chunks of the two worklists), wave tier (256 threads: a wave per
   // deferred query; 24 × B workgroups hold about one query per wave slot of the GPU — with 256 × B, one workgroup per four queries of the fullest stream, the
   // launch was mostly workgroups that found nothing to do: 175 k against 182 k frame-pairs/s), cell boxes
   d.g_fast = 6; d.g_score = 4; d.g_pde = 24; d.g_box = 32;
-  if (getenv("MOR_G_FAST")) d.g_fast = std::max(1, atoi(getenv("MOR_G_FAST")));
-  if (getenv("MOR_G_SCORE")) d.g_score = std::max(1, atoi(getenv("MOR_G_SCORE")));
-  if (getenv("MOR_G_PDE")) d.g_pde = std::max(1, atoi(getenv("MOR_G_PDE")));
   d.use_hash = d.method == 1;
   { size_t hc = 1024; while (hc < 4 * (size_t)d.Nmax) hc <<= 1; d.Hcell = (int)hc; }
   d.gnz = nullptr; d.gnz_out = nullptr; d.vnz = nullptr; d.vnz_out = nullptr; d.cg_nz = d.g.nz; d.cg_inv_cs = d.g.inv_cs;
-  d.t1_budget = getenv("MOR_T1_BUDGET") ? atoi(getenv("MOR_T1_BUDGET")) : 64;
-#ifdef MOR_EXP_SPLITVAR
-  d.t1_budget |= (getenv("MOR_SPLIT_VARIANT") ? atoi(getenv("MOR_SPLIT_VARIANT")) : 0) << 16;   // experiment bits of exp/split_var.py (results are wrong with any of them set)
-#endif
-#ifdef MOR_EXP_T1CUT
-  d.t1_budget |= (getenv("MOR_EXP_T1") ? atoi(getenv("MOR_EXP_T1")) : 0) << 16;   // cut point of exp/t1exp.py
-#endif
+  d.t1_budget = 64;   // points a thread of the worklist tiers looks at before it hands its query to the wave tier
   // test switches (defaults: the fast paths): MOR_GH_TIER=1|2 starts k_gridhash with its big LDS table / its global-memory table; MOR_CG_GLOBAL forces the global-memory forests
   d.gh_tier = getenv("MOR_GH_TIER") ? atoi(getenv("MOR_GH_TIER")) : -1; d.cg_force_global = getenv("MOR_CG_GLOBAL") ? 1 : 0; d.g2_exact_only = getenv("MOR_G2_EXACT") ? 1 : 0;
   d.P = 1;
@@ -376,7 +366,6 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (getenv("MOR_PIPE_DEPTH")) b->pipe_depth = std::min(MOR_MAX_DEPTH, std::max(1, atoi(getenv("MOR_PIPE_DEPTH"))));
   b->n_slots = b->pipe_depth + 1;
   if (getenv("MOR_CG_P")) b->env_cg_p = atoi(getenv("MOR_CG_P"));
-  if (getenv("MOR_GC_P")) b->env_gc_p = atoi(getenv("MOR_GC_P"));
   if ((rc = configure(b)) != MOR_OK) return fail(rc);
   if (n_bad > MOR_TR_NB) return fail(set_error(MOR_ERR_INVALID, "n_bad = %d: windows longer than %d frames are not supported", n_bad, MOR_TR_NB));
   for (auto &ev : b->outptr_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
@@ -429,7 +418,6 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   for (int i = 0; i < (int)b->n_slots; ++i)
     ok = ok && dalloc(b, d.cl_pts[i], B * N) && dalloc(b, d.cl_cid[i], B * N) && dalloc(b, d.cl_off[i], B * (K + 1)) && dalloc(b, d.chunk_off[i], B * (K + 1)) && dalloc(b, d.centroid[i], B * K) && dalloc(b, d.amin[i], B * K) && dalloc(b, d.amax[i], B * K) && dalloc(b, d.cl_first[i], B * K) && dalloc(b, d.slot_kc[i], B) && hipMemset(d.slot_kc[i], 0, B * sizeof(int2)) == hipSuccess;
   ok = ok && dalloc(b, d.err, B) && hipMemset(d.err, 0, B * sizeof(unsigned)) == hipSuccess && halloc(b, d.h_err, B) && halloc(b, d.h_log, B * (size_t)MOR_LOG_CAP) && dalloc(b, b->d_outptrs, B * MOR_MAX_DEPTH);
-  ok = ok && dalloc(b, d.dbg, B * 16) && dalloc(b, d.dbg2, B * (MOR_MAXP + 2) * 16);
   ok = ok && dalloc(b, d.tr, B) && hipMemset(d.tr, 0, B * sizeof(MorTrackDev)) == hipSuccess && dalloc(b, d.tr_corr, B * MOR_TR_NB * K) && dalloc(b, d.tr_res, B * (MOR_TR_NB + 1) * K) && dalloc(b, d.tr_lastdet, B * K) && dalloc(b, d.tr_match, B * (size_t)(MOR_TR_MAXT + 1)) && hipMemset(d.tr_match, 0, B * (size_t)(MOR_TR_MAXT + 1) * sizeof(int)) == hipSuccess;
   ok = ok && halloc(b, b->h_args_ring, B * MOR_ARGS_RING) && halloc(b, b->h_outptrs, B * MOR_ARGS_RING);
   b->h_args = b->h_args_ring;
@@ -534,7 +522,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     {  // slabs in proportion to the streams' cell counts: own cells per slab such that the slabs of all streams together are the launch's B·P workgroups
        // (Σ ceil(n_occ / T) ≤ Σ n_occ / T + B); never more than a slab's LDS holds with its look-ahead.  Counts of the latest frame the device reported.
       unsigned long long tot = 0; for (int s = 0; s < B; ++s) tot += k > 0 ? d.h_info[s].n_occ : 0u;
-      d.slab_T = (k > 0 && tot > 0 && d.P > 1 && !getenv("MOR_CG_EQUAL")) ? (int)std::min<unsigned long long>(600, std::max<unsigned long long>(32, (tot + (unsigned long long)B * (d.P - 1) - 1) / ((unsigned long long)B * (d.P - 1)))) : 0;
+      d.slab_T = (k > 0 && tot > 0 && d.P > 1) ? (int)std::min<unsigned long long>(600, std::max<unsigned long long>(32, (tot + (unsigned long long)B * (d.P - 1) - 1) / ((unsigned long long)B * (d.P - 1)))) : 0;
     }
     {  // grid build, cell pass, output: workgroups per stream of k_gridcount / k_gridplace / k_cellboxes / k_out.  The kernels share the launch out over the
        // streams by their point counts (map_block_work), so the width follows the MEAN cloud the device last reported (+ 15 %, + 1), not the largest:
@@ -542,9 +530,9 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
       uint64_t sumM = 0; uint32_t mxM = 0; for (int s = 0; s < B; ++s) { const uint32_t m = k > 0 ? d.h_info[s].M : (uint32_t)maxn; sumM += m; mxM = std::max(mxM, m); }
       const uint64_t meanM = (sumM + B - 1) / B, ref = d.prop_map ? meanM * 23 / 20 : (uint64_t)mxM * 5 / 4;
       const int want = (int)((ref + MOR_GC_CHUNK - 1) / MOR_GC_CHUNK) + (d.prop_map ? 1 : 0);
-      d.gc_P = b->env_gc_p > 0 ? b->env_gc_p : std::max(1, std::min(std::min(want, d.gc_chunks), std::max(1, 2048 / B)));
+      d.gc_P = std::max(1, std::min(std::min(want, d.gc_chunks), std::max(1, 2048 / B)));
       d.g_out = std::max(1, std::min(want, d.tiles));
-      d.g_box = getenv("MOR_G_BOX") ? std::max(1, atoi(getenv("MOR_G_BOX"))) : std::max(2, std::min(32, (int)((ref + 1023) / 1024) + 1));   // (a workgroup of the cell pass takes 1024 positions per round)
+      d.g_box = std::max(2, std::min(32, (int)((ref + 1023) / 1024) + 1));   // (a workgroup of the cell pass takes 1024 positions per round)
     }
     d.cg_fused = (maxocc * 11ull / 10 <= MOR_CGS_FCAP && !getenv("MOR_CG_UNFUSED")) ? 1 : 0;   // (a stream beyond it runs the merge on global-memory arrays: correct, slow — hence the separate kernel when that is foreseeable)
     // (table tier of k_gridhash: −1 = every stream by its own cell count of the latest build; MOR_GH_TIER forces the tier all streams start with)
@@ -891,19 +879,6 @@ int mor_debug_config(const mor_batch *b, int *out, int n) {   // grid geometry a
   return MOR_OK;
 }
 
-int mor_exp_read_stamps(const mor_batch *b, unsigned long long *out) {
-  if (!b) return MOR_ERR_INVALID;
-  HIP_TRY(hipMemcpy(out, b->d.dbg, sizeof(unsigned long long) * 16 * b->B, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemset(b->d.dbg, 0, sizeof(unsigned long long) * 16 * b->B));   // counters restart
-  return MOR_OK;
-}
-int mor_exp_read_stamps2(const mor_batch *b, unsigned long long *out) {
-  if (!b) return MOR_ERR_INVALID;
-  const size_t n = sizeof(unsigned long long) * 16 * (MOR_MAXP + 2) * b->B;
-  HIP_TRY(hipMemcpy(out, b->d.dbg2, n, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemset(b->d.dbg2, 0, n));
-  return MOR_OK;
-}
 int mor_get_stage_counts(const mor_batch *b, int s, uint32_t *out, int n) {
   CHECK_STREAM();
   const uint32_t v[5] = {f.n_occ, f.n_defer, f.pad0, f.Cprev, f.g2_exact};   // v[2] = queries left after tier 1; v[4] = voxels whose ordered sums were evaluated (voxel ground variant)

@@ -22,6 +22,7 @@ LIMITS = {
     "k_score_pde": (64, 0, 1024),
     "k_track_filter": (128, 0, 12 * 1024),
     "k_out": (64, 0, 4 * 1024),
+    "k_g2_cov": (104, 0, 1024),                     # voxel ground variant: four waves per SIMD, no LDS (its time is fp64 arithmetic per candidate step)
 }
 
 
