@@ -94,19 +94,43 @@ static void kd_build(kdtree *t, const float *src, int stride, int n) {
 }
 static void kd_free(kdtree *t) { free(t->perm); free(t->xyz); free(t->nodes); memset(t, 0, sizeof *t); }
 
-typedef struct { const kdtree *t; const float *q; float r2; ivec *out; float *out_d; size_t dcap; } kd_rq;
+/* ------------------------------------------------------------------ margin census + literal pruning (test infrastructure of the test infrastructure)
+ * The reference's numbers come out of PCL / FLANN binaries this image cannot build, so the restatement is pinned by definition-level second implementations only.  How much
+ * could a real FLANN change?  Two things are counted while the oracle runs (process-wide, oracle_census_*):
+ *  - how many decisions sit within a few ulp of their threshold (an edge at d² ≈ r², a 1-NN tie, equal-size clusters, a volume gate at the constraint, a method-1 distance at a
+ *    bound, a method-2 point at a voxel face, a covariance term at 0.001): only those can differ between two correct evaluations;
+ *  - how many results the kd-tree owes to the SLACK of its pruning test.  FLANN's KDTreeSingleIndex descends into the far child iff `mindistsq * epsError <= worstDist` with
+ *    epsError = 1 — the fp32 lower bound itself may round above a true distance, and FLANN then misses the point; this restatement prunes with a 1.0001 slack and misses
+ *    nothing.  oracle_set_literal_pruning(1) switches to FLANN's literal test (on THIS tree: FLANN's own split planes differ), and tests/test_margin_census.py holds every
+ *    golden stream to identical results in both modes. */
+enum { CEN_EDGE_C1 = 0, CEN_EDGE_G2, CEN_RAD_SLACK_VISITS, CEN_RAD_SLACK_HITS, CEN_NN_SLACK_VISITS, CEN_NN_SLACK_WINS, CEN_NN_TIES, CEN_EQUAL_SIZE, CEN_VOLUME_GATE, CEN_PDE_BOUND,
+       CEN_VOXEL_FACE, CEN_G2_TERM, CEN_RADIUS_QUERIES, CEN_NN_QUERIES, CEN_COUNT };
+static unsigned long long g_cen[CEN_COUNT];
+static int g_literal = 0, g_edge_kind = CEN_EDGE_C1;
+void oracle_census_reset(void) { memset(g_cen, 0, sizeof g_cen); }
+int oracle_census_read(unsigned long long *out, int n) { for (int i = 0; i < n && i < CEN_COUNT; ++i) out[i] = g_cen[i]; return CEN_COUNT; }
+void oracle_set_literal_pruning(int on) { g_literal = on ? 1 : 0; }
+static inline int within_ulps(float a, float b, int k) {   /* |a − b| ≤ k ulp (same sign, finite) */
+  int ia, ib; memcpy(&ia, &a, 4); memcpy(&ib, &b, 4);
+  if ((ia < 0) != (ib < 0)) return a == b;
+  long long d = (long long)ia - (long long)ib; if (d < 0) d = -d; return d <= k;
+}
+typedef struct { const kdtree *t; const float *q; float r2; ivec *out; float *out_d; size_t dcap; int slack_depth; } kd_rq;
 static void kd_radius_rec(kd_rq *s, int id, float mind, float *dists) {
   const kdnode *nd = &s->t->nodes[id];
   if (nd->dim < 0) {
     for (int i = nd->a; i < nd->b; ++i) { float d = sqdist3(s->q, s->t->xyz + 3 * (size_t)i);
-      if (d < s->r2) iv_push(s->out, s->t->perm[i]); } /* strict <, RadiusResultSet [PCL-1.8] */
+      if (within_ulps(d, s->r2, 4)) g_cen[g_edge_kind]++;
+      if (d < s->r2) { iv_push(s->out, s->t->perm[i]); if (s->slack_depth) g_cen[CEN_RAD_SLACK_HITS]++; } } /* strict <, RadiusResultSet [PCL-1.8] */
     return;
   }
   float v = s->q[nd->dim], d1 = v - nd->lo, d2 = v - nd->hi; int near, far; float cut;
   if (d1 + d2 < 0) { near = nd->a; far = nd->b; cut = d2 * d2; } else { near = nd->b; far = nd->a; cut = d1 * d1; }
   kd_radius_rec(s, near, mind, dists);
   float old = dists[nd->dim]; float m2 = mind + cut - old; dists[nd->dim] = cut;
-  if (m2 <= s->r2 * 1.0001f) kd_radius_rec(s, far, m2, dists); /* slack: the fp32 bound may round above the true distance */
+  if (m2 <= s->r2) kd_radius_rec(s, far, m2, dists);   /* FLANN's test (epsError = 1) */
+  else if (!g_literal && m2 <= s->r2 * 1.0001f) {   /* slack: the fp32 bound may round above the true distance */
+    g_cen[CEN_RAD_SLACK_VISITS]++; s->slack_depth++; kd_radius_rec(s, far, m2, dists); s->slack_depth--; }
   dists[nd->dim] = old;
 }
 /* appends indices (original numbering, unsorted) of all points with d² < r2 */
@@ -114,23 +138,26 @@ static void kd_radius(const kdtree *t, const float *q, float r2, ivec *out) {
   if (t->n == 0) return;
   float dists[3], mind = 0;
   for (int d = 0; d < 3; ++d) { dists[d] = 0; if (q[d] < t->bb[d][0]) { float e = q[d] - t->bb[d][0]; dists[d] = e * e; } else if (q[d] > t->bb[d][1]) { float e = q[d] - t->bb[d][1]; dists[d] = e * e; } mind += dists[d]; }
-  if (mind > r2 * 1.0001f) return;
-  kd_rq s = { t, q, r2, out, NULL, 0 };
+  g_cen[CEN_RADIUS_QUERIES]++;
+  if (!g_literal && mind > r2 * 1.0001f) return;   /* (FLANN has no test at the root) */
+  kd_rq s = { t, q, r2, out, NULL, 0, 0 };
   kd_radius_rec(&s, 0, mind, dists);
 }
-typedef struct { const kdtree *t; const float *q; float best; int besti; } kd_nq;
+typedef struct { const kdtree *t; const float *q; float best; int besti; int slack_depth; } kd_nq;
 static void kd_nn_rec(kd_nq *s, int id, float mind, float *dists) {
   const kdnode *nd = &s->t->nodes[id];
   if (nd->dim < 0) {
     for (int i = nd->a; i < nd->b; ++i) { float d = sqdist3(s->q, s->t->xyz + 3 * (size_t)i); int oi = s->t->perm[i];
-      if (d < s->best || (d == s->best && oi < s->besti)) { s->best = d; s->besti = oi; } }
+      if (d == s->best && oi != s->besti && s->besti >= 0) g_cen[CEN_NN_TIES]++;
+      if (d < s->best || (d == s->best && oi < s->besti)) { s->best = d; s->besti = oi; if (s->slack_depth) g_cen[CEN_NN_SLACK_WINS]++; } }
     return;
   }
   float v = s->q[nd->dim], d1 = v - nd->lo, d2 = v - nd->hi; int near, far; float cut;
   if (d1 + d2 < 0) { near = nd->a; far = nd->b; cut = d2 * d2; } else { near = nd->b; far = nd->a; cut = d1 * d1; }
   kd_nn_rec(s, near, mind, dists);
   float old = dists[nd->dim]; float m2 = mind + cut - old; dists[nd->dim] = cut;
-  if (m2 <= s->best * 1.0001f) kd_nn_rec(s, far, m2, dists);
+  if (m2 <= s->best) kd_nn_rec(s, far, m2, dists);   /* FLANN's test */
+  else if (!g_literal && m2 <= s->best * 1.0001f) { g_cen[CEN_NN_SLACK_VISITS]++; s->slack_depth++; kd_nn_rec(s, far, m2, dists); s->slack_depth--; }
   dists[nd->dim] = old;
 }
 /* 1-NN; returns index or -1 for an empty tree; *d2 = squared fp32 distance */
@@ -138,7 +165,8 @@ static int kd_nn(const kdtree *t, const float *q, float *d2) {
   if (t->n == 0) return -1;
   float dists[3], mind = 0;
   for (int d = 0; d < 3; ++d) { dists[d] = 0; if (q[d] < t->bb[d][0]) { float e = q[d] - t->bb[d][0]; dists[d] = e * e; } else if (q[d] > t->bb[d][1]) { float e = q[d] - t->bb[d][1]; dists[d] = e * e; } mind += dists[d]; }
-  kd_nq s = { t, q, INFINITY, -1 };
+  g_cen[CEN_NN_QUERIES]++;
+  kd_nq s = { t, q, INFINITY, -1, 0 };
   kd_nn_rec(&s, 0, mind, dists);
   *d2 = s.best; return s.besti;
 }
@@ -277,7 +305,7 @@ static void ground_removal_voxel(frame *f, const oracle_params *p) {
       while (e < t && items[e].idx == items[s].idx) { const opoint *q = &f->raw[items[e].pt]; sx += q->x; sy += q->y; sz += q->z; ++e; }
       float n = (float)(e - s); float c[3] = { sx / n, sy / n, sz / n }; s = e;
       /* :125 radiusSearch(dsc[i], gp_leaf), sorted by (d², index) [PCL-1.8] */
-      nb.n = 0; kd_radius(&tree, c, r2, &nb);
+      nb.n = 0; g_edge_kind = CEN_EDGE_G2; kd_radius(&tree, c, r2, &nb); g_edge_kind = CEN_EDGE_C1;
       if (nb.n <= 3) continue; /* :131 */
       if (nb.n > srt_cap) { srt_cap = nb.n * 2; srt = (di_item *)realloc(srt, srt_cap * sizeof(di_item)); }
       for (size_t j = 0; j < nb.n; ++j) { srt[j].i = nb.d[j]; srt[j].d = sqdist3(c, &f->raw[nb.d[j]].x); }
@@ -290,6 +318,7 @@ static void ground_removal_voxel(frame *f, const oracle_params *p) {
       float c02 = 0, c12 = 0, c22 = 0;
       for (size_t j = 0; j < nb.n; ++j) { const opoint *q = &f->raw[srt[j].i]; float dx = q->x - cx, dy = q->y - cy, dz = q->z - cz;
         c12 += dy * dz; c22 += dz * dz; c02 += dz * dx; }
+      if (fabs((double)fabsf(c02) - 0.001) <= 1e-6 || fabs((double)fabsf(c12) - 0.001) <= 1e-6 || fabs((double)fabsf(c22) - 0.001) <= 1e-6) g_cen[CEN_G2_TERM]++;
       if (!((double)fabsf(c02) < 0.001 && (double)fabsf(c12) < 0.001 && (double)fabsf(c22) < 0.001)) continue; /* :145 */
       if (n_acc == cap_acc) { cap_acc *= 2; acc_bin = (int *)realloc(acc_bin, cap_acc * sizeof(int)); acc_nb = (ivec *)realloc(acc_nb, cap_acc * sizeof(ivec)); }
       acc_bin[n_acc] = (int)(c[2] * 10); /* :166 key = (float)((int)(z*10))/bin_gap — grouping is by the int */
@@ -344,6 +373,7 @@ static void compute_clusters(frame *f, const oracle_params *p) {
     }
   }
   qsort(recs, n_recs, sizeof(cl_rec), cl_cmp);
+  for (int k = 1; k < n_recs; ++k) if (recs[k].n == recs[k - 1].n) g_cen[CEN_EQUAL_SIZE]++;   /* std::sort leaves their order unspecified (:217) */
   f->K = n_recs; f->cl_off = (int *)malloc((n_recs + 1) * sizeof(int)); f->cl_idx = (int *)malloc((all.n ? all.n : 1) * sizeof(int));
   f->clusters = (opoint **)calloc(n_recs ? n_recs : 1, sizeof(opoint *)); f->centroid = (float *)malloc((n_recs ? n_recs : 1) * 3 * sizeof(float));
   f->det = (unsigned char *)calloc(n_recs ? n_recs : 1, 1); /* :250-254 all false */
@@ -407,6 +437,7 @@ static int volume_constraint(const opoint *fp, int np, const opoint *fc, int nc,
    * apart always pass the gate.  volume_abs_int = 1 restates that reading (tested both ways). */
   double diff = vol[0] - vol[1];
   double ad = abs_int ? (double)abs((int)diff) : fabs(diff);
+  if (fabs(ad / (vol[0] + vol[1]) - threshold) <= 1e-6) g_cen[CEN_VOLUME_GATE]++;
   return (ad / (vol[0] + vol[1])) < threshold;
 }
 /* calculateCorrespondenceCentroid — :285-307.  determineReciprocalCorrespondences [PCL-1.8]:
@@ -434,7 +465,7 @@ static corr_list correspondence_centroid(const frame *ca, const frame *cb, doubl
 static double score_point_distance(const opoint *c1, int n1, const opoint *c2, int n2, float lb, float ub) {
   kdtree t; kd_build(&t, &c2[0].x, 8, n2);
   double count = 0;
-  for (int i = 0; i < n1; ++i) { float d; kd_nn(&t, &c1[i].x, &d); if (d > lb && d < ub) count++; }
+  for (int i = 0; i < n1; ++i) { float d; kd_nn(&t, &c1[i].x, &d); if (within_ulps(d, lb, 4) || within_ulps(d, ub, 4)) g_cen[CEN_PDE_BOUND]++; if (d > lb && d < ub) count++; }
   kd_free(&t);
   return count / (double)(((size_t)n1 + (size_t)n2) / 2);
 }
@@ -491,6 +522,8 @@ static double score_octree_change(const opoint *c1, int n1, const opoint *c2, in
   int changed = 0;
   for (int i = 0; i < n2; ++i) { oct_adopt(&b, &c2[i].x); vkey k;
     for (int d = 0; d < 3; ++d) k.k[d] = (long long)(unsigned)(((double)(&c2[i].x)[d] - b.mn[d]) / b.res) - b.shift[d];
+    for (int d = 0; d < 3; ++d) { const float v = (&c2[i].x)[d], lo = nextafterf(v, -INFINITY), hi = nextafterf(v, INFINITY);
+      if ((long long)(unsigned)(((double)lo - b.mn[d]) / b.res) - b.shift[d] != k.k[d] || (long long)(unsigned)(((double)hi - b.mn[d]) / b.res) - b.shift[d] != k.k[d]) { g_cen[CEN_VOXEL_FACE]++; break; } }
     if (!bsearch(&k, k1, n1, sizeof(vkey), vkey_cmp)) ++changed; }
   free(k1);
   return (double)changed;

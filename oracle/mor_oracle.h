@@ -97,6 +97,16 @@ void oracle_get_markers(const oracle_ctx *c, float *pos_K3, float *scale_K3);
 /* clusters the latest oracle_filter's loop over mo_vec matched its tracked centroids to, in loop order (the markers of :641, ids 1, 2, …); returns the count */
 uint32_t oracle_get_moving_clusters(const oracle_ctx *c, int32_t *cluster_of_track);
 
+/* Margin census (process-wide counters, see mor_oracle.c): [0] C1 pairs with d² within 4 ulp of r², [1] the same for the voxel ground variant's radius searches,
+ * [2] far-subtree visits of radius searches taken only thanks to the pruning slack, [3] neighbours found in them (what FLANN's literal test would lose on this tree),
+ * [4] / [5] the same for 1-NN searches (visits, new best found), [6] exact 1-NN distance ties, [7] equal-size clusters next to each other in the order,
+ * [8] volume gates within 1e-6 of the constraint, [9] method-1 distances within 4 ulp of a bound, [10] method-2 points within one ulp of a voxel face,
+ * [11] voxels with a covariance term within 1e-6 of 0.001, [12] radius queries, [13] 1-NN queries.  oracle_census_read returns the number of counters. */
+void oracle_census_reset(void);
+int oracle_census_read(unsigned long long *out, int n);
+/* 1: the kd-tree prunes with FLANN's literal test (mindist <= worst, no slack); 0 (default): with the 1.0001 slack that misses nothing */
+void oracle_set_literal_pruning(int on);
+
 /* wall-clock seconds spent inside oracle_push + oracle_filter since creation */
 double oracle_get_busy_seconds(const oracle_ctx *c);
 

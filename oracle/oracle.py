@@ -44,8 +44,32 @@ def lib():
         L.oracle_get_prev_cluster_count.argtypes = [C.c_void_p]
         L.oracle_get_busy_seconds.restype = C.c_double
         L.oracle_get_busy_seconds.argtypes = [C.c_void_p]
+        L.oracle_census_read.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_set_literal_pruning.argtypes = [C.c_int]
         _LIB = L
     return _LIB
+
+
+CENSUS_KEYS = ("c1_pairs_within_4ulp_of_r2", "g2_pairs_within_4ulp_of_leaf2", "radius_visits_owed_to_slack", "radius_neighbours_owed_to_slack", "nn_visits_owed_to_slack",
+               "nn_results_owed_to_slack", "nn_exact_ties", "equal_size_clusters", "volume_gates_within_1e-6", "method1_distances_within_4ulp_of_a_bound",
+               "method2_points_within_1ulp_of_a_voxel_face", "g2_terms_within_1e-6_of_threshold", "radius_queries", "nn_queries")
+
+
+def census_reset():
+    lib().oracle_census_reset()
+
+
+def census_read():
+    """Process-wide margin counters of the oracle since the last reset (mor_oracle.h), as a dict."""
+    a = (C.c_ulonglong * len(CENSUS_KEYS))()
+    n = lib().oracle_census_read(a, len(CENSUS_KEYS))
+    assert n == len(CENSUS_KEYS)
+    return {k: int(a[i]) for i, k in enumerate(CENSUS_KEYS)}
+
+
+def set_literal_pruning(on):
+    """True: the kd-tree prunes with FLANN's literal test (no slack); False (default): with the slack that misses nothing."""
+    lib().oracle_set_literal_pruning(1 if on else 0)
 
 
 class Counts(C.Structure):
