@@ -47,6 +47,7 @@ def _full(world=1, workloads=True):
                          "per_stream_rate_min_median_max": [1234.567] * 3, "host_cpus": 384},
         "cpu_baseline_all_cores": {"value": 12345.67, "unit": "frame-pairs/s", "cores": 384, "kind": "port", "sample": "s" * 330, "wall_s": 12345.67, "frame_pairs": 192},
         "workloads": wl if workloads else "skipped: world>1",
+        "kitti_density": {"workload": "hdl64_urban_b64", "value": 1234567.8, "unit": "frame-pairs/s", "steps": 40, "ratio_to_value": 0.123, "non_ground_share_stream0": 0.123, "job_frac": 0.12345, "wasted": 12.345},
         "kernels": {k: {"ms_total": 12345.6789, "launches": 123456, "avg_us": 12345.67} for k in KERNELS}, "kernels_alone_avg_us": {k: 12345.67 for k in KERNELS},
         "setup_s": 1234.56, "legs_failed": ["cpu_baseline", "latency_b1", "e2e_host"],
     }
