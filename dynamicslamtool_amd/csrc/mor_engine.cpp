@@ -881,8 +881,8 @@ int mor_debug_config(const mor_batch *b, int *out, int n) {   // grid geometry a
 
 int mor_get_stage_counts(const mor_batch *b, int s, uint32_t *out, int n) {
   CHECK_STREAM();
-  const uint32_t v[5] = {f.n_occ, f.n_defer, f.pad0, f.Cprev, f.g2_exact};   // v[2] = queries left after tier 1; v[4] = voxels whose ordered sums were evaluated (voxel ground variant)
-  for (int i = 0; i < n && i < 5; ++i) out[i] = v[i];
+  const uint32_t v[6] = {f.n_occ, f.n_defer, f.pad0, f.Cprev, f.g2_exact, f.max_loc};   // v[2] = queries left after tier 1; v[4] = voxels whose ordered sums were evaluated (voxel ground variant)
+  for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];   // v[5] = cells (own + look-ahead) of the stream's largest slab of the cell graph
   return MOR_OK;
 }
 

@@ -385,9 +385,9 @@ class MorBatch:
         return dict(zip(("nx", "ny", "nz", "nrows", "P", "grid_mode", "cg_mode", "Hcell", "Kcap", "tiles_m", "cur", "prev"), [int(x) for x in a]))
 
     def stage_counts(self, s=0):
-        a = (C.c_uint32 * 5)()
-        _check(lib().mor_get_stage_counts(self._h, s, a, 5))
-        return {"n_occ": int(a[0]), "n_defer": int(a[1]), "n_tier1b": int(a[2]), "C_prev": int(a[3]), "g2_exact": int(a[4])}
+        a = (C.c_uint32 * 6)()
+        _check(lib().mor_get_stage_counts(self._h, s, a, 6))
+        return {"n_occ": int(a[0]), "n_defer": int(a[1]), "n_tier1b": int(a[2]), "C_prev": int(a[3]), "g2_exact": int(a[4]), "max_loc": int(a[5])}
 
     def output_device(self, s=0):
         n = C.c_uint64(0)

@@ -155,7 +155,7 @@ int mor_get_cluster_collection(const mor_batch *b, int stream, float *out_xyzi);
 
 /* diagnostics of the last push of stream i: out[0] = occupied grid cells, out[1] = method-1 queries that
  * needed the wave tier, out[2] = method-1 queries left after the own-cell tier, out[3] = clustered points of the previous frame,
- * out[4] = voxels of the voxel ground variant whose ordered sums had to be evaluated */
+ * out[4] = voxels of the voxel ground variant whose ordered sums had to be evaluated, out[5] = cells (own + look-ahead) of the stream's largest slab of the cell graph */
 int mor_get_stage_counts(const mor_batch *b, int stream, uint32_t *out, int n);
 
 /* Per-frame summary log (the last 64 frames): lets a caller of the asynchronous mode inspect EVERY frame after one wait.
