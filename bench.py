@@ -51,7 +51,7 @@ ORACLE_KEYS = ("K", "C", "n_pairs", "det_sum", "n_mo_push", "n_mo_filter", "n_ou
 ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us", "avg_launch_us_alone",
              "job_GBps", "job_frac", "path_traffic_bytes_per_step", "wasted_traffic_ratio", "launches_per_step")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "core_seconds", "frame_pairs", "host_cpus")
-DROP_ORDER = ("e2e_host_sync_ms_per_step", "stream0", "stage_totals", "first_seed_per_rank", "per_rank_frame_pairs_per_s", "cpu_baseline_all_cores", "workloads", "latency_b1_ms",
+DROP_ORDER = ("e2e_host_sync_ms_per_step", "gathered", "stream0", "stage_totals", "first_seed_per_rank", "per_rank_frame_pairs_per_s", "cpu_baseline_all_cores", "workloads", "latency_b1_ms",
               "sync_frame_pairs_per_s", "device_ms_per_step", "value_runs")   # least important first; the contract keys (with ranks / devices_visible / ranks_per_device), roofline, cpu_baseline and sanity never go
 
 
@@ -64,7 +64,7 @@ def compact_line(full, detail_path=None, limit=LINE_LIMIT):
     cfg = dict(full.get("config") or {})
     cfg.pop("profile", None)   # the parameter profile is in the detail file (and in dynamicslamtool_amd/params.py: kitti_params)
     line["config"] = cfg
-    for k in ("kitti_density", "collective", "self_launched", "legs_failed", "first_seed_per_rank", "value_runs", "per_rank_frame_pairs_per_s", "device_ms_per_step", "sync_frame_pairs_per_s", "e2e_host_frame_pairs_per_s",
+    for k in ("kitti_density", "gathered", "collective", "self_launched", "legs_failed", "first_seed_per_rank", "value_runs", "per_rank_frame_pairs_per_s", "device_ms_per_step", "sync_frame_pairs_per_s", "e2e_host_frame_pairs_per_s",
               "e2e_host_sync_ms_per_step", "e2e_host_async_frame_pairs_per_s", "e2e_host_async_equals_sync", "latency_b1_ms", "algorithmic_bytes_per_frame_pair", "stage_totals", "stream0"):
         if full.get(k) is not None:
             line[k] = full[k]
@@ -541,6 +541,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip value_runs, the other workloads, e2e / sync / latency legs")
+    ap.add_argument("--gather-summaries", choices=["off", "gloo", "rccl"], default="off", help="optional result gather (north_star): per-stream summaries of the last frame-pair of every rank to rank 0, "
+                    "behind the timed region — over the host (gloo) or as one RCCL gather between the devices (needs one rank per device)")
     ap.add_argument("--allow-shared-device", action="store_true", help="let several ranks share one GPU (a plumbing test on a 1-GPU box); the line then says so: n_gpus = devices in use, ranks, ranks_per_device")
     ap.add_argument("--dry-run", action="store_true", help="exercise only the multi-rank plumbing (no GPU work, no measurement)")
     ap.add_argument("--latency-only", action="store_true", help="child process of the default run: push + filter latency of ONE stream, prints {\"latency_b1_ms\": …}")
@@ -569,6 +571,11 @@ def main():
 
     from dynamicslamtool_amd import shard
     rank, local_rank, world = shard.env_rank()
+    if args.gather_summaries == "rccl" and not args.dry_run:
+        # torch brings its own copy of the HIP runtime; a process that has initialised the system's one first (libmor_hip.so) shows torch no GPU.  For the RCCL gather torch's
+        # runtime is therefore loaded — and initialised — FIRST, and libmor_hip.so's libamdhip64 dependency resolves to the copy that is already in the process
+        import torch
+        torch.cuda.init()
     cores_mine = bind_rank_to_cores(local_rank, world)
     dist = shard.init_distributed()
 
@@ -583,6 +590,11 @@ def main():
         per_rank = shard.gather_floats(dist, B * args.steps / fake_elapsed)
         first_seeds = shard.gather_floats(dist, seeds[0])
         last_seeds = shard.gather_floats(dist, seeds[-1])
+        gathered = None
+        if args.gather_summaries == "gloo":   # (the dry run gathers what it has: every stream's seed and rank — the plumbing of the optional result gather on CPU)
+            mat, ginfo = shard.gather_summaries(dist, np.array([[sd, rank] for sd in seeds], np.float32))
+            if rank == 0:
+                gathered = dict(ginfo, rows=int(mat.shape[0]), first_row=[float(x) for x in mat[0]], last_row=[float(x) for x in mat[-1]])
         slices = None
         topo = os.environ.get("MOR_FAKE_TOPOLOGY")   # {"gpu_node": [0,0,0,0,1,1,1,1], "node_cpus": {"0": [0..63], "1": [64..127]}}: the host placement of a node this box is not
         if topo:
@@ -593,7 +605,7 @@ def main():
             text = json.dumps({"dry_run": True, "n_gpus": world, "value": rate, "first_seed": seeds[0], "last_seed_rank0": seeds[-1], "steps": args.steps,
                                "per_rank_min_max": [min(per_rank), max(per_rank)], "first_seed_per_rank": [int(x) for x in first_seeds], "last_seed_per_rank": [int(x) for x in last_seeds],
                                "collective": "none", "workloads": "skipped: world>1" if world > 1 else "skipped: dry run", "numa_core_slices_first_last_n": slices,
-                               "self_launched": bool(os.environ.get("MOR_BENCH_SELF_LAUNCHED")), "cores_per_rank": cores_mine})
+                               "self_launched": bool(os.environ.get("MOR_BENCH_SELF_LAUNCHED")), "cores_per_rank": cores_mine, "gathered": gathered})
             assert len(text) <= LINE_LIMIT
             print(text)
         if dist:
@@ -733,6 +745,17 @@ def main():
             leg.step(sync=True)
         sync_rate = B * n_sync / (time.perf_counter() - t1)
 
+    gathered = None
+    if args.gather_summaries != "off":
+        # north_star's optional result gather, behind the timed region: per stream of this rank the summary of its latest frame-pair → rank 0
+        if args.gather_summaries == "rccl" and world > ndev:
+            raise RuntimeError("--gather-summaries rccl needs one rank per device (%d ranks, %d devices)" % (world, ndev))
+        lastf = leg.step_no - 1
+        mat_l = np.array([[leg.batch.frame_log(lastf, s)[k] for k in ("K", "C", "n_pairs", "det_sum", "n_mo_filter", "n_out")] for s in range(B)], np.float32)
+        mat, ginfo = shard.gather_summaries(dist, mat_l, device, rccl=args.gather_summaries == "rccl")
+        if rank == 0:
+            gathered = dict(ginfo, rows=int(mat.shape[0]), columns=["K", "C", "n_pairs", "det_sum", "n_mo_filter", "n_out"], equals_rank0_rows=bool(np.array_equal(mat[:B], mat_l)),
+                            clusters_all_streams=int(mat[:, 0].sum()), filtered_points_all_streams=int(mat[:, 5].sum()))
     stream0 = leg.summary0()
     stage_totals = {k: sum(leg.batch.stage_counts(s)[k] for s in range(B)) for k in ("n_occ", "n_tier1b", "n_defer", "C_prev") + (("g2_exact",) if ground_method == 1 else ())}
     profile = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in p.as_dict().items()}
@@ -795,6 +818,7 @@ def main():
                 "ratio_to_value": round(others["hdl64_urban_b64"]["value"] / value, 3) if value else None,
                 "non_ground_share_stream0": round(others["hdl64_urban_b64"]["stream0"]["M"] / max(others["hdl64_urban_b64"]["stream0"]["T"], 1), 3),
                 "job_frac": others["hdl64_urban_b64"]["roofline"].get("job_frac"), "wasted": others["hdl64_urban_b64"]["roofline"].get("wasted_traffic_ratio")},
+            "gathered": gathered,
             "kernels": kernels, "kernels_alone_avg_us": kernels_alone,
             "setup_s": round(setup_s, 2),
             "legs_failed": [n_ for n_, v_ in (("cpu_baseline", cpu if not args.no_cpu_baseline else 0), ("latency_b1", lat if extras and world == 1 else 0), ("e2e_host", e2e if extras and world == 1 else 0)) if v_ is None] or None,

@@ -1,7 +1,8 @@
 """Multi-GPU plumbing for the batched hot path: independent sensor streams are sharded across
 ranks (one process per GPU), no data-path collective.  torch.distributed is used only for the
 barrier around the timed region and the max-over-ranks of the elapsed time (gloo on CPU tensors:
-nothing on the hot path crosses xGMI, so RCCL would add nothing)."""
+nothing on the hot path crosses xGMI, so RCCL would add nothing) — and for the OPTIONAL gather of per-frame-pair result
+summaries to rank 0 (`gather_summaries`: RCCL between devices when asked for, never inside a timed region)."""
 import os
 
 
@@ -68,6 +69,44 @@ def gather_floats(dist, value):
     t[dist.get_rank()] = float(value)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [float(x) for x in t]
+
+
+def gather_summaries(dist, local, device=None, rccl=False):
+    """north_star's optional result gather: every rank's summaries (a float32 matrix, one row per stream: clusters, clustered points, correspondences, detection
+    digest, tracked centroids, points of the filtered cloud — a few hundred bytes per rank, never the clouds) to rank 0.  rccl=True: the rows are device tensors and
+    travel as ONE RCCL gather (backend "nccl" IS RCCL on ROCm: between the GPUs of a node that is xGMI) in a process group of its own — one rank per device is required,
+    and the caller keeps it out of every timed region; rccl=False: over the host (gloo), which is what a summary this small deserves unless its consumer lives on GPU 0.
+    Returns (matrix [world·rows, cols] on rank 0 / None elsewhere, {"backend", "ranks", "bytes_per_rank", "ms"})."""
+    import time
+    import numpy as np
+    import torch
+    local = np.ascontiguousarray(local, np.float32)
+    world = 1 if dist is None else dist.get_world_size()
+    rank = 0 if dist is None else dist.get_rank()
+    t0 = time.perf_counter()
+    if rccl:
+        import torch.distributed as td
+        if not td.is_initialized():   # a single rank: a group of one, so that the same RCCL call runs (and is tested) on a one-GPU box
+            td.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % (29600 + os.getpid() % 300), rank=0, world_size=1)
+            grp = None
+        else:
+            grp = td.new_group(backend="nccl")   # (collective: every rank calls it)
+        torch.cuda.set_device(device or 0)
+        t = torch.from_numpy(local).cuda(device or 0)
+        out = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        td.gather(t, out, dst=0, group=grp)
+        torch.cuda.synchronize()
+        res = torch.cat(out).cpu().numpy() if rank == 0 else None
+        backend = "nccl"
+    elif dist is None:
+        res, backend = local.copy(), "none"
+    else:
+        t = torch.from_numpy(local)
+        out = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        dist.gather(t, out, dst=0)
+        res = torch.cat(out).numpy() if rank == 0 else None
+        backend = "gloo"
+    return res, {"backend": backend, "ranks": world, "bytes_per_rank": int(local.nbytes), "ms": round(1e3 * (time.perf_counter() - t0), 3)}
 
 
 def numa_core_slices(gpu_node, node_cpus, world, allowed=None):

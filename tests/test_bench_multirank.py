@@ -43,3 +43,16 @@ def test_more_ranks_than_devices_is_refused_without_the_flag(tmp_path):
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode != 0 and "--allow-shared-device" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_optional_result_gather_over_rccl(tmp_path):
+    """north_star's optional result gather as ONE RCCL gather of device tensors (shard.gather_summaries, backend "nccl" = RCCL): a single rank on the visible GPU — a group of
+    one, the same call an 8-GPU node makes over xGMI — behind the timed region; the gathered rows are rank 0's own summaries."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--streams", "4", "--steps", "3", "--warmup", "2", "--no-extras", "--no-cpu-baseline", "--gather-summaries", "rccl",
+                        "--detail", str(tmp_path / "detail.json")], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    g = d["gathered"]
+    assert g["backend"] == "nccl" and g["ranks"] == 1 and g["rows"] == 4 and g["equals_rank0_rows"] and g["clusters_all_streams"] > 0 and g["filtered_points_all_streams"] > 100000
+    assert d["sanity"]["ok"]

@@ -57,6 +57,20 @@ def test_gpus_flag_starts_the_ranks_itself():
     assert abs(d["value"] - (2 * 8 * 4) / 1.5) < 1e-9
 
 
+def test_optional_result_gather_brings_every_ranks_rows_to_rank_0():
+    """north_star's optional result gather (shard.gather_summaries), host path: three gloo ranks, eight streams each; rank 0 ends up with every rank's rows in rank order.
+    (The RCCL form of the same call runs on the GPU: tests/test_bench_multirank.py.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "4", "--warmup", "1", "--dry-run", "--streams", "8", "--gather-summaries", "gloo"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    g = d["gathered"]
+    assert g["backend"] == "gloo" and g["ranks"] == 3 and g["rows"] == 24 and g["bytes_per_rank"] == 8 * 2 * 4
+    assert g["first_row"] == [2000.0, 0.0] and g["last_row"] == [2023.0, 2.0]
+
+
 def test_eight_rank_dry_run_with_a_two_socket_node_map():
     """BASELINE config 4 without the hardware: `python bench.py --gpus 8 --dry-run` starts 8 gloo ranks itself — 64 streams each, seeds 2000 … 2511,
     one line — and places every rank on its GPU's socket for the map of an 8-GPU / 2-socket node (4 GPUs per socket, 64 cores each)."""
