@@ -821,6 +821,7 @@ def main():
             "gathered": gathered,
             "kernels": kernels, "kernels_alone_avg_us": kernels_alone,
             "setup_s": round(setup_s, 2),
+            "library": {"path": engine.LIB_PATH, "hash": engine.build_hash(), "staleness_check_bypassed": bool(os.environ.get("MOR_HIP_LIB") or os.environ.get("MOR_ALLOW_STALE_LIB"))},
             "legs_failed": [n_ for n_, v_ in (("cpu_baseline", cpu if not args.no_cpu_baseline else 0), ("latency_b1", lat if extras and world == 1 else 0), ("e2e_host", e2e if extras and world == 1 else 0)) if v_ is None] or None,
         }
         emit(line, args.detail)

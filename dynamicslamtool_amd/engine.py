@@ -107,6 +107,14 @@ def _check(rc):
         raise MorError("rc=%d: %s" % (rc, lib().mor_last_error().decode()))
 
 
+def build_hash():
+    """The sources + flags hash the loaded library carries (mor_build_hash): bench.py puts it into its record, so a library loaded through MOR_HIP_LIB /
+    MOR_ALLOW_STALE_LIB — which bypass the staleness check — is named in what it measured."""
+    L = lib()
+    L.mor_build_hash.restype = C.c_char_p
+    return (L.mor_build_hash() or b"").decode()
+
+
 def device_count():
     return int(lib().mor_device_count())
 
