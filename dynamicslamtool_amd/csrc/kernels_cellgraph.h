@@ -58,22 +58,72 @@ __device__ __forceinline__ float point_box_gap2(const float4 &p, const float4 &l
 // (mostly true non-edges: two dense surfaces a cell apart).  A and B are read in coalesced chunks of 64 points; a point
 // takes part only if it lies within r of the OTHER cell's point box, which removes nearly everything when the cells
 // are two apart; the surviving B points of a chunk are broadcast by shuffles — no memory access in the inner loop.
+// min / max of a value over the wave (all lanes get the result)
+__device__ __forceinline__ float wave_fmin(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_fmax(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
 __device__ __forceinline__ bool pair_hit_wave(const float4 *sp, int a0, int na, int b0, int nb, float r2, int lane,
                                               const float4 &alo, const float4 &ahi, const float4 &blo, const float4 &bhi) {
-  for (int ia0 = 0; ia0 < na; ia0 += 64) {
-    const int ia = ia0 + lane; const float4 pa = sp[a0 + min(ia, na - 1)];
-    const bool a_act = ia < na && point_box_gap2(pa, blo, bhi) < r2;
-    if (!__ballot(a_act)) continue;
-    for (int ib0 = 0; ib0 < nb; ib0 += 64) {
-      const int ib = ib0 + lane; const float4 pb = sp[b0 + min(ib, nb - 1)];
-      unsigned long long mb = __ballot(ib < nb && point_box_gap2(pb, alo, ahi) < r2);
-      bool hit = false;
-      while (mb) {
-        const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
-        const float bx = __shfl(pb.x, l, 64), by = __shfl(pb.y, l, 64), bz = __shfl(pb.z, l, 64);
-        hit |= a_act && sqdist(pa.x, pa.y, pa.z, bx, by, bz) < r2;
+  if (nb <= 256) {   // (a few chunks of B: the plain form)
+    for (int ia0 = 0; ia0 < na; ia0 += 64) {
+      const int ia = ia0 + lane; const float4 pa = sp[a0 + min(ia, na - 1)];
+      const bool a_act = ia < na && point_box_gap2(pa, blo, bhi) < r2;
+      if (!__ballot(a_act)) continue;
+      for (int ib0 = 0; ib0 < nb; ib0 += 64) {
+        const int ib = ib0 + lane; const float4 pb = sp[b0 + min(ib, nb - 1)];
+        unsigned long long mb = __ballot(ib < nb && point_box_gap2(pb, alo, ahi) < r2);
+        bool hit = false;
+        while (mb) {
+          const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
+          const float bx = __shfl(pb.x, l, 64), by = __shfl(pb.y, l, 64), bz = __shfl(pb.z, l, 64);
+          hit |= a_act && sqdist(pa.x, pa.y, pa.z, bx, by, bz) < r2;
+        }
+        if (__ballot(hit)) return true;
       }
-      if (__ballot(hit)) return true;
+    }
+    return false;
+  }
+  // Two BIG cells (the 128-beam clouds put thousands of returns into a 28-cm cell next to the sensor: 15 M point pairs per step in 110 such non-edges, each proven by ONE wave —
+  // 320 of k_cg_slab's 440 µs on `os128_b64`, found by cutting the kernel's phases out one at a time).  Points arrive in a cell in scan order, so 64 consecutive ones are a short
+  // arc with a tight box: the boxes of B's chunks go to the lanes (lane l ← chunk l, 64 chunks at a time), and a chunk of A is compared with the chunk BOXES first — only chunk
+  // pairs whose boxes are closer than r are looked at point by point.  Two parallel surfaces more than r apart are proven apart by a few hundred box tests.
+  for (int cb0 = 0; cb0 < nb; cb0 += 64 * 64) {
+    const int nch = min(64, (nb - cb0 + 63) >> 6);
+    float clx = FLT_MAX, cly = FLT_MAX, clz = FLT_MAX, chx = -FLT_MAX, chy = -FLT_MAX, chz = -FLT_MAX;   // lane l: box of chunk l of this block
+    for (int k = 0; k < nch; ++k) {
+      const float4 p = sp[b0 + min(cb0 + k * 64 + lane, nb - 1)];   // (clamped lanes repeat a real point of the cell: the box stays a box of B's points)
+      const float lx = wave_fmin(p.x), ly = wave_fmin(p.y), lz = wave_fmin(p.z), hx = wave_fmax(p.x), hy = wave_fmax(p.y), hz = wave_fmax(p.z);
+      if (lane == k) { clx = lx; cly = ly; clz = lz; chx = hx; chy = hy; chz = hz; }
+    }
+    for (int ia0 = 0; ia0 < na; ia0 += 64) {
+      const int ia = ia0 + lane; const float4 pa = sp[a0 + min(ia, na - 1)];
+      const bool a_act = ia < na && point_box_gap2(pa, blo, bhi) < r2;
+      if (!__ballot(a_act)) continue;
+      // box of this chunk's candidates
+      const float qlx = wave_fmin(a_act ? pa.x : FLT_MAX), qly = wave_fmin(a_act ? pa.y : FLT_MAX), qlz = wave_fmin(a_act ? pa.z : FLT_MAX);
+      const float qhx = wave_fmax(a_act ? pa.x : -FLT_MAX), qhy = wave_fmax(a_act ? pa.y : -FLT_MAX), qhz = wave_fmax(a_act ? pa.z : -FLT_MAX);
+      const float4 qlo = make_float4(qlx, qly, qlz, 0.f), qhi = make_float4(qhx, qhy, qhz, 0.f);
+      const float gx = fmaxf(fmaxf(clx - qhx, qlx - chx), 0.f), gy = fmaxf(fmaxf(cly - qhy, qly - chy), 0.f), gz = fmaxf(fmaxf(clz - qhz, qlz - chz), 0.f);
+      unsigned long long mc = __ballot(lane < nch && (gx * gx + gy * gy + gz * gz) * 0.999f < r2);   // chunks of B whose box comes within r of this chunk's
+      while (mc) {
+        const int k = __ffsll((long long)mc) - 1; mc &= mc - 1;
+        const int ib = cb0 + k * 64 + lane; const float4 pb = sp[b0 + min(ib, nb - 1)];
+        unsigned long long mb = __ballot(ib < nb && point_box_gap2(pb, qlo, qhi) < r2);
+        bool hit = false;
+        while (mb) {
+          const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
+          const float bx = __shfl(pb.x, l, 64), by = __shfl(pb.y, l, 64), bz = __shfl(pb.z, l, 64);
+          hit |= a_act && sqdist(pa.x, pa.y, pa.z, bx, by, bz) < r2;
+        }
+        if (__ballot(hit)) return true;
+      }
     }
   }
   return false;
