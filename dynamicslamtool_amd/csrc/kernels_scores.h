@@ -59,13 +59,13 @@ __device__ __forceinline__ int near_side(float v, float o, float inv, float cs, 
 }
 // wave-aggregated append of a query to a per-stream worklist; `back`: the list grows downwards from list[cap−1]
 // An entry is (query, pair, matched cluster) so the next tier starts without the chain query → cluster → pair → match.
-__device__ __forceinline__ void wl_push(bool want, int *n, int4 *list, int j, int pr, int target, bool back = false, int cap = 0) {
+__device__ __forceinline__ void wl_push(bool want, int *n, int4 *list, int j, int pr, int target, int own_cell, bool back = false, int cap = 0) {
   unsigned long long m = __ballot(want);
   if (!m) return;
   int basew = 0, leader = __ffsll((long long)m) - 1;
   if (lane_id() == leader) basew = atomicAdd(n, __popcll(m));
   basew = __shfl(basew, leader, 64);
-  if (want) { int pos = basew + __popcll(m & lanemask_lt()); list[back ? cap - 1 - pos : pos] = make_int4(j, pr, target, 0); }
+  if (want) { int pos = basew + __popcll(m & lanemask_lt()); list[back ? cap - 1 - pos : pos] = make_int4(j, pr, target, own_cell); }
 }
 // wave-aggregated count: all counted queries of a pair add to ONE address (a few dozen addresses per stream), and
 // same-address atomics serialise in L2 — thousands of them per stream were the real cost of these kernels.  Lanes
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
   const bool e1_local = 2.f * slb < G.cs;
   for (int base = t0 * SCF_T; base < Cp; base += g_fast * SCF_T) {
     const int j = base + threadIdx.x;
-    bool nearq = false, blockq = false, big = false, counted = false; float best = INFINITY; int pr = -1, target = -1;
+    bool nearq = false, blockq = false, big = false, counted = false; float best = INFINITY; int pr = -1, target = -1, own_c = -1;
     if (j < Cp) {
       // two short chains of dependent loads, issued side by side (no branch between them): cluster → its record (pair, matched cluster,
       // that cluster's box), and point → cell (LDS index) → range + cluster id of the cell → points.  (Round 1: seven levels, one after the other.)
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
       const float4 q = ld_stream(&d.cl_pts[pv][so + j]);   // (read once here; the few queries the later tiers take up again fetch theirs from HBM)
       const int cx = cell_axis_unclamped(q.x, G.ox, G.inv_cs), cy = cell_axis_unclamped(q.y, G.oy, G.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], G.inv_cs);
       const int c = cidx_find(I, cx, cy, cz);   // (LDS: no global access)
+      own_c = c;
       const float4 tlo = d.qrec[2 * (ko + cidj)], thi = d.qrec[2 * (ko + cidj) + 1];   // the matched cluster's box, the pair, the matched cluster: one record per previous cluster (pairs_body)
       const int cc = max(c, 0), cid = d.ccid[so + cc], b0 = c >= 0 ? st[cc] : 0, e0 = c >= 0 ? st[cc + 1] : 0;
       pr = __float_as_int(tlo.w); target = __float_as_int(thi.w);
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
         const int bn = __shfl((int)(unsigned)base, 0, 64), bb = __shfl((int)(base >> 32), 0, 64), b2 = __shfl(base2, 0, 64);
         if (nearq) d.wl[so + bn + __popcll(mn & lanemask_lt())] = make_int4(j, pr, target, 0);
         if (blockq) d.wl[so + d.Nmax - 1 - (bb + __popcll(mb & lanemask_lt()))] = make_int4(j, pr, target, 0);
-        if (big) d.wl2[so + b2 + __popcll(mg & lanemask_lt())] = make_int4(j, pr, target, 0);
+        if (big) d.wl2[so + b2 + __popcll(mg & lanemask_lt())] = make_int4(j, pr, target, own_c);   // (.w: the query's own cell — the wave tier starts there without looking it up again)
       }
     }
     count_push(counted, d.pair_cnt + ko, pr);
@@ -178,7 +179,7 @@ __device__ __forceinline__ void score_near_body(const MorDev &d, const CellIdx &
   const float slb = sqrtf(fmaxf(d.pde_lb, 0.f)) * 1.01f + G.cs * 1e-3f;
   {
     const int w = chunk * SCN_T + threadIdx.x;
-    bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
+    bool defer = false, counted = false; int j = 0, pr = -1, target = -1, own_c = -1;
     if (w < nq) {
       const int4 we = d.wl[so + w]; j = we.x; pr = we.y; target = we.z;
       const float4 q = d.cl_pts[pv][so + j];
@@ -197,10 +198,10 @@ __device__ __forceinline__ void score_near_body(const MorDev &d, const CellIdx &
       const int ca[4] = {id[1], id[2], id[4], id[3]}, cb2[4] = {id[5], id[6], id[7], -1};   // face neighbours first
       scan_batch4(d, so, st, sp, ca, target, true, q, lbn, best, budget);
       if ((cb2[0] >= 0 || cb2[1] >= 0 || cb2[2] >= 0) && best > d.pde_lb) scan_batch4(d, so, st, sp, cb2, target, true, q, lbn, best, budget);
-      if (best > d.pde_lb) { if (budget <= 0) defer = true; else counted = true; }
+      if (best > d.pde_lb) { if (budget <= 0) { defer = true; own_c = cidx_find(I, cx, cy, cz); } else counted = true; }
     }
     count_push(counted, d.pair_cnt + ko, pr);
-    wl_push(defer, &d.wl2_n[s], d.wl2 + so, j, pr, target);
+    wl_push(defer, &d.wl2_n[s], d.wl2 + so, j, pr, target, own_c);
   }
 }
 // Tier 1b — one THREAD per query whose own cell holds no matched point (worklist back).  The 26 other cells of the
@@ -218,7 +219,7 @@ __device__ __forceinline__ void score_block_body(const MorDev &d, const CellIdx 
   const bool stencil27 = d.n_rows <= 9 && d.score_R <= 1;   // the whole search stencil is the 3×3×3 block
   {
     const int w = chunk * SCN_T + threadIdx.x;
-    bool defer = false, counted = false; int j = 0, pr = -1, target = -1;
+    bool defer = false, counted = false; int j = 0, pr = -1, target = -1, own_c = -1;
     if (w < nq) {
       const int4 we = d.wl[so + d.Nmax - 1 - w]; j = we.x; pr = we.y; target = we.z;
       const float4 q = d.cl_pts[pv][so + j];
@@ -272,9 +273,10 @@ __device__ __forceinline__ void score_block_body(const MorDev &d, const CellIdx 
         else if (best < d.pde_ub) counted = true;   // all cells that can hold a point within √lb were among the slots
         else if (!(stencil27 && ncand <= 8)) defer = true;              // E2 still open: wider search
       }
+      if (defer) own_c = cidx_find(I, cx, cy, cz);   // (the wave tier starts at the query's own cell: its id travels with the entry)
     }
     count_push(counted, d.pair_cnt + ko, pr);
-    wl_push(defer, &d.wl2_n[s], d.wl2 + so, j, pr, target);
+    wl_push(defer, &d.wl2_n[s], d.wl2 + so, j, pr, target, own_c);
   }
 }
 #ifndef SCN_MINW
@@ -339,8 +341,8 @@ __device__ __forceinline__ void score_pde_body(const MorDev &d, int s, int bx, i
     const float4 q = d.cl_pts[pv][so + j];
     const int cx = cell_axis_unclamped(q.x, G.ox, G.inv_cs), cy = cell_axis_unclamped(q.y, G.oy, G.inv_cs), cz = cell_axis_unclamped(q.z, d.zorg[s], G.inv_cs);
     float best = INFINITY;
-    {  // the query's own cell first
-      const int c = cidx_find(I, cx, cy, cz);
+    {  // the query's own cell first (its id came with the entry: the tier that deferred the query had looked it up in its LDS index — here that was a chain of ten dependent loads)
+      const int c = we.w;
       if (c >= 0 && d.ccid[so + c] == target) best = wave_scan_cell(sp, st[c], st[c + 1], q, d.pde_lb, lane);
     }
     for (int rb = 0; rb < d.n_rows && best > d.pde_lb; rb += 64) {
