@@ -214,7 +214,7 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
 #define CGS_T 512
 #endif
 #ifndef CGS_CAP
-#define CGS_CAP 1024      // local cells (own + look-ahead) held in LDS
+#define CGS_CAP 1360      // local cells (own + look-ahead) held in LDS with everything the pair decisions need: nine words each (CGS_CW)
 #endif
 #ifndef CGS_ROWCAP
 #define CGS_ROWCAP 2048   // local (y,z) rows held in LDS
@@ -294,7 +294,11 @@ __device__ __forceinline__ int pair_points_thread(const float4 *sp, int a0, int 
 // then, for the whole workgroup:
 //  B1  one thread per listed pair: roots re-checked, then the points (pair_points_thread).
 //  B2  one wave per pair the thread test could not finish (big cells): pruned exhaustive test.
-template <bool LDS> struct CgsCells { const int *key, *pc; const float *rx, *ry, *rz, *bx; int cap; };   // bx: six planes of `cap` floats (null: samples and boxes stay in global memory)
+template <bool LDS> struct CgsCells { const int *key, *pc; const float *rx, *ry, *rz; const unsigned *bx; int cap; };   // bx: three planes of `cap` words, (low, high) of one axis as two halves each (null: samples and boxes stay in global memory)
+// a box edge [lo, hi] as two halves that contain it: lo rounded down, hi rounded up
+__device__ __forceinline__ unsigned box_halves(float lo, float hi) { return (unsigned)__half_as_ushort(__float2half_rd(lo)) | ((unsigned)__half_as_ushort(__float2half_ru(hi)) << 16); }
+__device__ __forceinline__ float box_lo(unsigned w) { return __half2float(__ushort_as_half((unsigned short)(w & 0xffffu))); }
+__device__ __forceinline__ float box_hi(unsigned w) { return __half2float(__ushort_as_half((unsigned short)(w >> 16))); }
 template <bool LDS, bool BOXL, typename RT> __device__ __forceinline__ void cgs_hooks(const MorDev &d, const MorGrid &G, size_t soc, int n_own, int n_loc, const CgsCells<LDS> &L, const int *start, const RT *rows, int rsub, int r0, int nlrows,
                                                               int *par, const float4 *sp, int *ovf, int *l_list, int *l_queue, int *l_wcnt, int *l_n2) {
   const float r2 = d.r2;
@@ -350,8 +354,9 @@ template <bool LDS, bool BOXL, typename RT> __device__ __forceinline__ void cgs_
       if (want) {
         float pax, pay, paz, alx, aly, alz, ahx, ahy, ahz, qx, qy, qz, blx, bly, blz, bhx, bhy, bhz;
         if (BOXL) {
-          pax = L.rx[qa]; pay = L.ry[qa]; paz = L.rz[qa]; alx = L.bx[qa]; aly = L.bx[L.cap + qa]; alz = L.bx[2 * L.cap + qa]; ahx = L.bx[3 * L.cap + qa]; ahy = L.bx[4 * L.cap + qa]; ahz = L.bx[5 * L.cap + qa];
-          qx = L.rx[qb]; qy = L.ry[qb]; qz = L.rz[qb]; blx = L.bx[qb]; bly = L.bx[L.cap + qb]; blz = L.bx[2 * L.cap + qb]; bhx = L.bx[3 * L.cap + qb]; bhy = L.bx[4 * L.cap + qb]; bhz = L.bx[5 * L.cap + qb];
+          const unsigned ax_ = L.bx[qa], ay_ = L.bx[L.cap + qa], az_ = L.bx[2 * L.cap + qa], bx_ = L.bx[qb], by_ = L.bx[L.cap + qb], bz_ = L.bx[2 * L.cap + qb];
+          pax = L.rx[qa]; pay = L.ry[qa]; paz = L.rz[qa]; alx = box_lo(ax_); aly = box_lo(ay_); alz = box_lo(az_); ahx = box_hi(ax_); ahy = box_hi(ay_); ahz = box_hi(az_);
+          qx = L.rx[qb]; qy = L.ry[qb]; qz = L.rz[qb]; blx = box_lo(bx_); bly = box_lo(by_); blz = box_lo(bz_); bhx = box_hi(bx_); bhy = box_hi(by_); bhz = box_hi(bz_);
         } else {
           const float4 q = d.crep[soc + qa], lo = d.cmeta[2 * (soc + qa)], h4 = d.cmeta[2 * (soc + qa) + 1]; pax = q.x; pay = q.y; paz = q.z; alx = lo.x; aly = lo.y; alz = lo.z; ahx = h4.x; ahy = h4.y; ahz = h4.z;
           const float4 q2 = d.crep[soc + qb], lo2 = d.cmeta[2 * (soc + qb)], h42 = d.cmeta[2 * (soc + qb) + 1]; qx = q2.x; qy = q2.y; qz = q2.z; blx = lo2.x; bly = lo2.y; blz = lo2.z; bhx = h42.x; bhy = h42.y; bhz = h42.z;
@@ -427,7 +432,8 @@ template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDe
 // k_cg_final does, in the same LDS (three arrays of CGS_FCAP cells; streams with more cells: global-memory arrays) — one launch and one
 // queueing delay less per frame; the host falls back to the separate k_cg_final launch (147 KB of LDS: 12 288 cells) when the previous
 // frame's cell counts say a stream would not fit.
-#define CGS_SLAB_WORDS (12 * CGS_CAP + CGS_ROWCAP + 1 + CGS_LISTW + CGS_NW * CGS_QW)
+#define CGS_CW 9   // LDS words per local cell: key, parent, packed coordinates, sample point (3), point box as six halves (3)
+#define CGS_SLAB_WORDS (CGS_CW * CGS_CAP + CGS_ROWCAP + 1 + CGS_LISTW + CGS_NW * CGS_QW)
 #define CGS_ARENA (CGS_SLAB_WORDS > 2 * MOR_CGS_FCAP ? CGS_SLAB_WORDS : 2 * MOR_CGS_FCAP)   // (the slab layout of the default build is 18 945 words)
 #define CGS_FCAP (CGS_ARENA / 2)
 template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d, int s, int j, int *l_arena, int *l_wcnt, int *l_n2p);
@@ -463,11 +469,15 @@ template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d,
   const int c0 = sc[j], c1 = sc[j + 1], c2 = se[j], n_own = c1 - c0, n_loc = c2 - c0;
   if (n_own <= 0) return;
   const int y0 = sy[j], y2 = min(sy[j + 1] + 2, G.ny), r0 = y0 * G.nz, nlrows = (y2 - y0) * G.nz;
-  // 12·CAP words of cell data: CAP cells with everything in LDS (key, parent, packed coordinates, sample point, box), or —
-  // slabs of up to 4·CAP cells, e.g. a façade across a y-slice — key, parent and packed coordinates only: the enumeration
+  // CGS_CW·CAP words of cell data: CAP cells with everything in LDS (key, parent, packed coordinates, sample point, box), or —
+  // slabs of up to 3·CAP cells, e.g. a façade across a y-slice — key, parent and packed coordinates only: the enumeration
   // (A1) and the forest stay in LDS, the decisions about queued pairs (A2) fetch samples and boxes from global memory
-  int *l_cells = l_arena, *l_list = l_cells + 12 * CAP + CGS_ROWCAP + 1, *l_queue = l_list + CGS_LISTW;
-  unsigned short *l_rows = reinterpret_cast<unsigned short *>(l_cells + 12 * CAP);   // local row table as 16-bit offsets (≤ 4·CAP local cells): 2·CGS_ROWCAP rows in CGS_ROWCAP + 1 words
+  // The point box of a cell is held as six HALVES, low corner rounded down and high corner rounded up (round 5: 9 instead of 12 words per cell — 1 360 instead of 1 024 cells with
+  // everything in LDS, 4 080 with key / parent / coordinates only): the box only FILTERS pairs — "boxes ≥ r apart: no edge", "farthest corners within r: edge" — and a box that is
+  // a few centimetres too big leaves both tests valid and a few more pairs to the point tests.  With the host's slab policy scaled to it (8 instead of 10 slabs per stream on the open
+  // scenes — 512 workgroups, ONE round on the GPU's 512 slots —, 9 instead of 12 on the street scenes): hdl64_b64 +0.8 %, hdl64_urban_b64 +1.0 % (interleaved).
+  int *l_cells = l_arena, *l_list = l_cells + CGS_CW * CAP + CGS_ROWCAP + 1, *l_queue = l_list + CGS_LISTW;
+  unsigned short *l_rows = reinterpret_cast<unsigned short *>(l_cells + CGS_CW * CAP);   // local row table as 16-bit offsets (≤ 3·CAP local cells): 2·CGS_ROWCAP rows in CGS_ROWCAP + 1 words
   int &l_n2 = *l_n2p;
   int *ovf = d.cg_ovf + (size_t)(s * MOR_MAXP + j) * MOR_CGS_OVF * 2;   // [0, MOR_CGS_OVF): the waves' candidate lists, [MOR_CGS_OVF, 2·MOR_CGS_OVF): pairs for whole waves
   const int *g_rows = d.row_start + (size_t)s * (d.g.nrows + 1) + r0;
@@ -475,21 +485,21 @@ template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d,
   const bool fits_rows = nlrows <= 2 * CGS_ROWCAP && !d.cg_force_global;   // (thick slabs of the sparse far ends of a cloud: 150 slices × 14 layers seen at 120 000 points; beyond the table they ran the global-memory path, 3× slower, and set the kernel's span)
   if (fits_rows && n_loc <= CAP) {
     int *l_key = l_cells, *l_par = l_cells + CAP, *l_pc = l_cells + 2 * CAP;
-    float *l_rx = reinterpret_cast<float *>(l_cells + 3 * CAP), *l_ry = l_rx + CAP, *l_rz = l_rx + 2 * CAP, *l_bx = l_rx + 3 * CAP;
+    float *l_rx = reinterpret_cast<float *>(l_cells + 3 * CAP), *l_ry = l_rx + CAP, *l_rz = l_rx + 2 * CAP; unsigned *l_bx = reinterpret_cast<unsigned *>(l_cells + 6 * CAP);
     const int *gk = d.ckey + so + c0; const float4 *grep = d.crep + so + c0, *gm = d.cmeta + 2 * (so + c0);
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) {
       const int k = gk[i], row = k / G.nx;
       l_key[i] = k; l_par[i] = i; l_pc[i] = (int)((unsigned)(k - row * G.nx) | ((unsigned)(row % G.nz) << 11) | ((unsigned)(row / G.nz) << 21));
       const float4 q = grep[i], lo = gm[2 * i], hi4 = gm[2 * i + 1];
       l_rx[i] = q.x; l_ry[i] = q.y; l_rz[i] = q.z;
-      l_bx[i] = lo.x; l_bx[CAP + i] = lo.y; l_bx[2 * CAP + i] = lo.z; l_bx[3 * CAP + i] = hi4.x; l_bx[4 * CAP + i] = hi4.y; l_bx[5 * CAP + i] = hi4.z;
+      l_bx[i] = box_halves(lo.x, hi4.x); l_bx[CAP + i] = box_halves(lo.y, hi4.y); l_bx[2 * CAP + i] = box_halves(lo.z, hi4.z);
     }
     for (int i = threadIdx.x; i <= nlrows; i += CGS_T) l_rows[i] = (unsigned short)(g_rows[i] - c0);
     __syncthreads();
     const CgsCells<true> L = {l_key, l_pc, l_rx, l_ry, l_rz, l_bx, CAP};
     cgs_body<true, true, unsigned short>(d, G, s, so, c0, n_own, n_loc, L, l_rows, 0, r0, nlrows, l_par, ovf, l_list, l_queue, l_wcnt, &l_n2);
-  } else if (fits_rows && n_loc <= 4 * CAP) {
-    int *l_key = l_cells, *l_par = l_cells + 4 * CAP, *l_pc = l_cells + 8 * CAP;
+  } else if (fits_rows && n_loc <= 3 * CAP) {
+    int *l_key = l_cells, *l_par = l_cells + 3 * CAP, *l_pc = l_cells + 6 * CAP;
     const int *gk = d.ckey + so + c0;
     for (int i = threadIdx.x; i < n_loc; i += CGS_T) {
       const int k = gk[i], row = k / G.nx;

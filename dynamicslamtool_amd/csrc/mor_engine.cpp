@@ -516,13 +516,13 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     uint32_t maxocc = 0, maxloc = 0;
     for (int s = 0; s < B; ++s) { maxocc = std::max(maxocc, k > 0 ? d.h_info[s].n_occ : 0u); maxloc = std::max(maxloc, k > 0 ? d.h_info[s].max_loc : 0u); }
     (void)maxloc;
-    const int p_fit = (int)((maxocc * 3ull / 2 + 818) / 819), p_par = (512 + B - 1) / B;   // a slab's LDS holds 1024 cells (own + look-ahead); two 512-thread workgroups per CU
+    const int p_fit = (int)((maxocc * 3ull / 2 + 1087) / 1088), p_par = (512 + B - 1) / B;   // a slab's LDS holds 1360 cells (own + look-ahead; CGS_CAP); two 512-thread workgroups per CU
     d.P = b->env_cg_p > 0 ? b->env_cg_p : std::max(p_fit, p_par);
     d.P = std::max(1, std::min(d.P, std::min(MOR_MAXP, std::max(1, d.g.ny / 2))));
     {  // slabs in proportion to the streams' cell counts: own cells per slab such that the slabs of all streams together are the launch's B·P workgroups
        // (Σ ceil(n_occ / T) ≤ Σ n_occ / T + B); never more than a slab's LDS holds with its look-ahead.  Counts of the latest frame the device reported.
       unsigned long long tot = 0; for (int s = 0; s < B; ++s) tot += k > 0 ? d.h_info[s].n_occ : 0u;
-      d.slab_T = (k > 0 && tot > 0 && d.P > 1) ? (int)std::min<unsigned long long>(600, std::max<unsigned long long>(32, (tot + (unsigned long long)B * (d.P - 1) - 1) / ((unsigned long long)B * (d.P - 1)))) : 0;
+      d.slab_T = (k > 0 && tot > 0 && d.P > 1) ? (int)std::min<unsigned long long>(800, std::max<unsigned long long>(32, (tot + (unsigned long long)B * (d.P - 1) - 1) / ((unsigned long long)B * (d.P - 1)))) : 0;
     }
     {  // grid build, cell pass, output: workgroups per stream of k_gridcount / k_gridplace / k_cellboxes / k_out.  The kernels share the launch out over the
        // streams by their point counts (map_block_work), so the width follows the MEAN cloud the device last reported (+ 15 %, + 1), not the largest:

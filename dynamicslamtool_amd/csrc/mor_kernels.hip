@@ -25,6 +25,7 @@
 #include <cfloat>
 #include <cstddef>
 #include <cstdlib>
+#include <hip/hip_fp16.h>
 
 const char *const mor_kernel_names[MK_COUNT] = {   // in MorKernelId order: "k_" + name = the __global__ function
     "classify", "scatter", "split", "heads_count", "heads_scatter", "cellboxes", "rhist", "rscan", "rscatter",
