@@ -34,10 +34,14 @@ __device__ __forceinline__ int chunk_cluster(const int *coff, int K, int w) {
 // pieces of consecutive positions, coalesced on both sides — and write the label of cloud point j; workgroups
 // [tiles_m, tiles_m + MOR_CLS_G) reduce the cell records (boxes, exact coordinate sums) of every cluster with one wave
 // per cluster: centroid = Σ(double)p / n cast to fp32 (:239-243) from the exact sum, AABB for the volume gate.
+#ifndef MOR_CLS_G
 #define MOR_CLS_G 8
+#endif
 __device__ __forceinline__ void xform_prev_body(const MorDev &d, int s, int bx, int nbx, Red6 *sh, float *m);
 __device__ __forceinline__ void cluster_pairs_body(const MorDev &d, int s, float4 *tile, int *sh);
+#ifndef MOR_XF_G
 #define MOR_XF_G 16   // workgroups per stream that transform the previous frame's clusters inside this launch
+#endif
 __global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
   // the launch: B·g_out movers (shared out by the streams' point counts, map_block_work), then per stream MOR_CLS_G reducers and (with a previous frame) MOR_XF_G transformers
   const int xf_g = d.has_prev ? MOR_XF_G : 0, n_mv = d.B * d.g_out, n_rest = MOR_CLS_G + xf_g;
