@@ -344,6 +344,46 @@ def test_dense_sheets_overflow_the_deferred_pair_list():
     b.close()
 
 
+@pytest.mark.parametrize("order", ["scan", "shuffled"])
+@pytest.mark.parametrize("gap", ["apart", "touching"])
+def test_big_cells_two_apart_are_proven_by_their_chunk_boxes(order, gap):
+    """Pairs of BIG cells (thousands of points each) two cells apart whose point BOXES come within r while no point pair does: only an exhaustive test can
+    reject them, and pair_hit_wave does it by the boxes of 64-point chunks first (round 5).  Two clumps in opposite corners of a cell make its box the whole
+    cell; the partner cell, diagonally two cells away, has its clumps in the corners that keep every pair ≥ 0.57 m apart (r = 0.5).  In scan order a chunk is one
+    clump (tight boxes, proven by box tests); shuffled, every chunk's box is the whole cell (every chunk pair goes point by point).  "touching": one extra point
+    bridges the gap — the two cells are then ONE cluster.  Both against the oracle, with the cells' neighbours empty so that no chain connects them."""
+    p = kitti_params(1)
+    p.min_cluster_size = 100
+    cs = np.float32(0.57 * 0.5)
+    rng = np.random.default_rng(11)
+    ox, oy = np.float32(-50.0), np.float32(-50.0)       # the clustering grid hangs on (−trim_x, −trim_y, gp_limit)
+    def clump(cx, cy, fx, fy, n):                          # n points in a 2-cm blob at fraction (fx, fy) of cell (cx, cy), 0.5 m above the ground limit
+        q = np.empty((n, 4), np.float32)
+        q[:, 0] = ox + (cx + fx) * cs + rng.uniform(-0.01, 0.01, n)
+        q[:, 1] = oy + (cy + fy) * cs + rng.uniform(-0.01, 0.01, n)
+        q[:, 2] = -0.9 + rng.uniform(-0.01, 0.01, n)
+        q[:, 3] = 0.5
+        return q
+    cx0, cy0 = 200, 200
+    A = np.concatenate([clump(cx0, cy0, 0.04, 0.96, 2500), clump(cx0, cy0, 0.96, 0.04, 2500)])
+    B = np.concatenate([clump(cx0 + 2, cy0 + 2, 0.96, 0.04, 2500), clump(cx0 + 2, cy0 + 2, 0.04, 0.96, 2500)])
+    parts = [A, B]
+    if gap == "touching":
+        parts.append(np.array([[ox + (cx0 + 1.9) * cs, oy + (cy0 + 1.1) * cs, -0.9, 0.5]], np.float32))   # 0.40 m from A's lower-right clump and from B's: a one-point bridge through the cell between them
+    x = np.concatenate(parts).astype(np.float32)
+    if order == "shuffled":
+        x = x[rng.permutation(len(x))]
+    pose = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    b, o = MorBatch(p, 1, len(x)), Oracle(p)
+    for f in range(2):
+        b.push([x], pose[None, :])
+        o.push(x, pose)
+        compare_frame(o, b, 0, "big cells (%s, %s) frame %d" % (order, gap, f))
+        compare_output(o.filter(), b.filter()[0], "big cells (%s, %s) frame %d" % (order, gap, f))
+    assert o.counts().n_clusters == (1 if gap == "touching" else 2)
+    b.close()
+
+
 def test_cluster_boxes_are_the_min_max_of_their_points():
     """mor_get_boxes = getMinMax3D of every cluster (the data of the reference's bounding-box markers, :7-58): exact
     fp32 min / max over the cluster's points as listed by cluster_indices."""
