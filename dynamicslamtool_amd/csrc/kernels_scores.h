@@ -434,7 +434,12 @@ __device__ __forceinline__ bool vox_key(const MorDev &d, int pr, const double (&
   bool ok = pr < 65535;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    kk[a] = (long long)floor(((double)pc[a] - mn[a]) / res);
+    // floor((p − min) / res) as the octree computes its keys (fp64 DIVISION) — by a multiplication with 1 / res where that cannot differ: the product lies within 3·2⁻⁵² · 65 536 < 1e-10 of the
+    // quotient, so when it is farther than 1e-7 from an integer both have the same floor; the few points closer to a voxel face than that take the division.  (Three fp64 divisions per
+    // point — thirty instructions each — were the bulk of the arithmetic of both voxel kernels.)
+    const double t = (double)pc[a] - mn[a], q = t * d.opc_inv_res; double f = floor(q); const double r = q - f;
+    if (r < 1e-7 || r > 1.0 - 1e-7) f = floor(t / res);
+    kk[a] = (long long)f;
     ok = ok && kk[a] >= -32768 && kk[a] < 32768;
   }
   key = ((unsigned long long)pr << 48) | ((unsigned long long)(kk[0] + 32768) << 32) | ((unsigned long long)(kk[1] + 32768) << 16) | (unsigned long long)(kk[2] + 32768);

@@ -90,7 +90,7 @@ struct MorDev {
   float trim_x, trim_y, trim_z, gp_limit, r2;
   long long min_cs, max_cs;
   float pde_lb, pde_ub;
-  double pde_thr, vol_thr, opc_res;
+  double pde_thr, vol_thr, opc_res, opc_inv_res;   // opc_inv_res = 1 / opc_res (fp64): the voxel keys of method 2 by a multiplication where that cannot differ from the division
   int method, opc_norm, score_R, n_rows, t1_budget, vol_abs_int, opc_anchor_half;
   const signed char *row_order; // [n_rows][2] (dy,dz) of the method-1 search stencil, nearest rows first
   MorGrid g;                 // clustering grid (cell edge 0.57·r)

@@ -181,7 +181,7 @@ static int configure(mor_batch *b) {
   double tol = (double)p.ec_distance_threshold; d.r2 = (float)(tol * tol);   // KdTreeFLANN::radiusSearch: (float)(radius·radius)
   d.min_cs = p.min_cluster_size; d.max_cs = p.max_cluster_size;
   d.pde_lb = p.pde_lb; d.pde_ub = p.pde_ub; d.pde_thr = (double)p.pde_distance_threshold; d.vol_thr = (double)p.volume_constraint;
-  d.opc_res = (double)p.opc_resolution; d.method = p.method_choice; d.opc_norm = p.opc_normalization_factor; d.vol_abs_int = p.volume_abs_int ? 1 : 0; d.opc_anchor_half = p.opc_anchor ? 1 : 0;
+  d.opc_res = (double)p.opc_resolution; d.opc_inv_res = p.opc_resolution > 0.f ? 1.0 / (double)p.opc_resolution : 0.0; d.method = p.method_choice; d.opc_norm = p.opc_normalization_factor; d.vol_abs_int = p.volume_abs_int ? 1 : 0; d.opc_anchor_half = p.opc_anchor ? 1 : 0;
   // grid: cell edge 0.57·r (cell diagonal 0.987·r < r ⇒ a cell is a clique; the 1.3 % margin dwarfs the
   // fp32 rounding of the cell map, ≤ 1e-3 cell at ≤ 2048 cells per axis)
   float cs = p.ec_distance_threshold * 0.57f;
