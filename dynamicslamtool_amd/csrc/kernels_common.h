@@ -191,7 +191,7 @@ __device__ __forceinline__ int classify(const MorDev &d, float4 p) {
 // trimmed cloud and splits it by the ground flag, :194-198)
 __device__ __forceinline__ uint32_t pass_count(const MorDev &d, const MorStreamArgs &a, int s) { return d.gmode == 2 ? d.info[s].T : a.n; }
 __device__ __forceinline__ int pass_item(const MorDev &d, const MorStreamArgs &a, int s, uint32_t i, float4 &p) {
-  if (d.gmode == 2) { p = d.rawbuf[(size_t)s * d.Nmax + i]; return d.is_ground[(size_t)s * d.Nmax + i] == d.frame_no + 1 ? 1 : 2; }   // (ground flags carry the frame's tag: no clearing pass)
+  if (d.gmode == 2) { p = d.rawbuf[(size_t)s * d.Nmax + i]; return d.is_ground[(size_t)s * d.Nmax + i] == d.g2_tag[s] ? 1 : 2; }   // (ground flags carry the frame's tag — the speculative one if the bet on the mode bin held, k_g2_mode —: no clearing pass)
   p = load_point(a, i);
   return classify(d, p);
 }

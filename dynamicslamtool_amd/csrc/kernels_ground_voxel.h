@@ -218,6 +218,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
   const int zbase = d.zbase[s]; const MorGrid G = stream_grid(d, s);   // (the lattice with the stream's own z layers)
+  const int pred = d.g2_used[s], tag_spec = 2 * d.frame_no + 1;   // the mode bin this frame's kernels bet on (pass A's snapshot of the latest known one), and the tag of the marks made on that bet
   for (int v0 = bxv * (MOR_BT / 16); v0 < V; v0 += G2_COV_G * (MOR_BT / 16)) {
     const int v = v0 + grp; const bool act = v < V;
     // ---- voxel centroid: sequential fp32 sums over the voxel's points in ascending index (stable sort ⇒ storage order)
@@ -273,10 +274,33 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
       }
     }
     g2_acc_reduce<16>(A);
+    int spec = 0;
     if (act && sub == 0) {
       const int verdict = wide ? -2 : A.n > 3 ? (d.g2_exact_only ? -1 : g2_screen(A, q, d.g2_r, d.g2_inv_r)) : 0;
       if (verdict < 0) d.g2_big[so + atomicAdd(&d.g2_nbig[s], 1)] = verdict == -1 ? (v | G2_Q_EXACT) : v;
       else d.vbin[so + v] = verdict ? (int)(q.z * 10) : 0x7fffffff;
+      spec = verdict == 1 && (int)(q.z * 10) == pred;
+    }
+    // ---- speculative marks (see k_g2_mode): an accepted voxel of the PREDICTED mode bin marks its neighbours at once, while its candidate ranges are at hand
+    spec = __shfl(spec, lane & 48, 64);
+    const int nmark = spec ? ncand : 0;
+    int mark_max = nmark;
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) mark_max = max(mark_max, __shfl_xor(mark_max, o, 64));
+    for (int c0 = 0; c0 < mark_max; c0 += 64) {
+      float4 pc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + 16 * u + sub; int k = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) if (c >= rp[r] && c < rp[r + 1]) k = rb[r] + (c - rp[r]);
+        pc[u] = sp[c < nmark ? k : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + 16 * u + sub; const float4 p = pc[u];
+        if (c < nmark && sqdist(q.x, q.y, q.z, p.x, p.y, p.z) < d.leaf_r2) d.is_ground[so + __float_as_int(p.w)] = tag_spec;
+      }
     }
   }
 }
@@ -329,6 +353,8 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
       g2_acc_reduce<64>(A);
       const int verdict = A.n > 3 ? g2_screen(A, q, d.g2_r, d.g2_inv_r) : 0;
       if (verdict >= 0) {
+        if (verdict == 1 && (int)(q.z * 10) == d.g2_used[s])   // speculative marks (k_g2_mode)
+          for (int c0 = 0; c0 < rp[9]; c0 += 64) { const int c = c0 + lane; if (c < rp[9]) { const float4 p = sp[cand(c)]; if (sqdist(q.x, q.y, q.z, p.x, p.y, p.z) < d.leaf_r2) d.is_ground[so + __float_as_int(p.w)] = 2 * d.frame_no + 1; } }
         if (lane == 0) { d.vbin[so + v] = verdict ? (int)(q.z * 10) : G2_V_NONE; d.g2_big[so + w] = ~v; }
         continue;
       }
@@ -368,6 +394,9 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
     for (int u = 0; u < G2_MID_CAP / 64; ++u) if (er[u] >= 0) { l_x[wv][er[u]] = ex[u]; l_y[wv][er[u]] = ey[u]; l_z[wv][er[u]] = ez[u]; }
     wave_lds_fence();
     const bool acc3 = g2_ordered_sums3(l_x[wv], l_y[wv], l_z[wv], n, n > 3, 0);
+    if (n > 3 && acc3 && (int)(q.z * 10) == d.g2_used[s]) {   // speculative marks (k_g2_mode): the keys stay where the gather put them, a neighbour's index in the low half
+      for (int e = lane; e < n; e += 64) d.is_ground[so + (int)(unsigned)l_key[wv][e]] = 2 * d.frame_no + 1;
+    }
     if (lane == 0) { d.vbin[so + v] = (n > 3 && acc3) ? (int)(q.z * 10) : G2_V_NONE; d.g2_big[so + w] = ~v; }
     wave_lds_fence();
    }
@@ -395,6 +424,7 @@ __global__ __launch_bounds__(G2_BIG_T) void k_g2_cov_big(MorDev d) {
     int bin = 0x7fffffff;
     if (n > G2_CAP) { if (threadIdx.x == 0) mor_raise(d, s, 16u); }
     else if (n > 3) bin = g2_voxel_bin<G2_CHUNK>(d, so, q, key, n, px, py, pz, acc);
+    if (bin != 0x7fffffff && bin == d.g2_used[s]) for (int i = threadIdx.x; i < n; i += G2_BIG_T) d.is_ground[so + (int)(unsigned)key[i]] = 2 * d.frame_no + 1;   // speculative marks (k_g2_mode)
     if (threadIdx.x == 0) d.vbin[so + v] = bin;
     __syncthreads();
   }
@@ -417,7 +447,16 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mode(MorDev d) {
   __syncthreads();
   for (int i = threadIdx.x; i < 4096; i += MOR_BT) if (best_cnt > 0 && hist[i] == best_cnt) atomicMin(&best_bin, i - 2048);
   __syncthreads();
-  if (threadIdx.x == 0) { d.mode_bin[s] = best_bin; d.g2_nbig[s] = 0; }   // (the queue of big voxels is empty again for the next frame on this copy)
+  if (threadIdx.x == 0) {
+    // The mode bin is known only now, but it hardly ever moves from frame to frame (it is the height of the ground): the kernels that take the verdicts have marked the neighbours of
+    // the accepted voxels of the bin they BET on (g2_used: pass A's snapshot of the latest mode any frame of the stream has reported) with the tag 2·frame + 1 — while their candidate
+    // ranges were at hand, without k_g2_mark's chains of lookups.  If the bet holds, those marks are the frame's ground and k_g2_mark has nothing to do for this stream; if not
+    // (the first frame, a ramp), the frame's tag is 2·frame + 2 and k_g2_mark writes it for the true mode bin — the marks of the lost bet are simply never looked at.
+    const int pred = d.g2_used[s];
+    d.g2_tag[s] = (best_bin != 0x7fffffff && best_bin == pred) ? 2 * d.frame_no + 1 : 2 * d.frame_no + 2;
+    st_agent(&d.g2_pred[s], best_bin);
+    d.mode_bin[s] = best_bin; d.g2_nbig[s] = 0;
+  }   // (the queue of big voxels is empty again for the next frame on this copy)
 }
 // ground = union of the neighbour lists of the dominant bin's voxels (:184-191, de-duplicated): every trimmed point within the radius of such a
 // voxel's centroid is marked (no list, no sort needed here).  Waves look at 64 voxels at a time and take the mode bin's voxels among them FOUR at a
@@ -426,13 +465,13 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mode(MorDev d) {
 __global__ __launch_bounds__(MOR_BT) void k_g2_mark(MorDev d) {
   int s, bxm; map_block(d.B, 128, s, bxm);
   const int V = d.info[s].n_occ, mode = d.mode_bin[s];
-  if (mode == 0x7fffffff) return;
+  if (mode == 0x7fffffff || d.g2_tag[s] == 2 * d.frame_no + 1) return;   // (no accepted voxel at all; or the bet on the mode bin held: the marks are there already)
   const size_t so = (size_t)s * d.Nmax;
   const int lane = lane_id(), nw = 128 * (MOR_BT / 64), grp = lane >> 4, sub = lane & 15;
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
   const MorGrid G = stream_grid(d, s);   // (the lattice with the stream's own z layers)
-  const int zbase = d.zbase[s], tag = d.frame_no + 1;   // the frame's tag (never 0, never an earlier frame's on this copy of the array): nothing has to be cleared
+  const int zbase = d.zbase[s], tag = 2 * d.frame_no + 2;   // the frame's tag when the bet was lost (never 0, never an earlier frame's on this copy of the array): nothing has to be cleared
   for (int v0 = (bxm * (MOR_BT / 64) + wave_id()) * 64; v0 < V; v0 += nw * 64) {
     unsigned long long m = __ballot(v0 + lane < V && d.vbin[so + min(v0 + lane, V - 1)] == mode);
     unsigned long long wide_m = 0;

@@ -64,7 +64,7 @@ __device__ __forceinline__ void publish_split(const MorDev &d, int s, int n_ng, 
       const float zmax = f.T ? ordered_float(d.zmax_i[s]) : 0.f;
       d.gnz_out[s] = max(1, min(d.cg_nz, (int)floorf((zmax - zmin) * d.cg_inv_cs) + 2));
     }
-    if (d.vnz_out) d.vnz_out[s] = voxel_layers(d, s);   // layers of the VoxelGrid lattice (the later kernels of pass A read it through stream_grid)
+    if (d.vnz_out) { d.vnz_out[s] = voxel_layers(d, s); d.g2_used[s] = ld_agent(&d.g2_pred[s]); }   // … and the bet on the mode bin this frame's kernels mark by: ONE snapshot per frame (later frames' k_g2_mode update g2_pred while this frame's kernels run)   // layers of the VoxelGrid lattice (the later kernels of pass A read it through stream_grid)
   }
 }
 // pass 2: order-preserving split into `cloud` / ground, cell histogram, forest init
@@ -152,11 +152,12 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
 __device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // loads only (no use of the data here: the wait for them belongs to split_tile, a step later); cls carries the ground flag of pass B
 template <bool PASSB> __device__ __forceinline__ void split_load_tile(const MorDev &d, const MorStreamArgs &a, int s, uint32_t n_in, int t, float4 (&p)[SP_ROWS], int (&cls)[SP_ROWS]) {
+  const int gtag = PASSB ? d.g2_tag[s] : 0;   // pass B: the frame's ground tag (k_g2_mode)
   const uint32_t base = (uint32_t)t * SP_TILE + wave_id() * (SP_ROWS * 64);
 #pragma unroll
   for (int it = 0; it < SP_ROWS; ++it) {
     const uint32_t i = min(base + it * 64 + lane_id(), n_in - 1);   // (clamped: out-of-range lanes repeat the last record and are masked in split_tile)
-    if (PASSB) { p[it] = d.rawbuf[(size_t)s * d.Nmax + i]; cls[it] = d.is_ground[(size_t)s * d.Nmax + i] == d.frame_no + 1; }
+    if (PASSB) { p[it] = d.rawbuf[(size_t)s * d.Nmax + i]; cls[it] = d.is_ground[(size_t)s * d.Nmax + i] == gtag; }
     else { p[it] = load_point(a, i); cls[it] = 0; }
   }
 }

@@ -133,6 +133,7 @@ struct MorDev {
   int *zmin_i, *zmax_i;      // [B]  ordered-int min / max z of the trimmed cloud
   float *zorg; int *zbase;   // [B]  z origin of the clustering grid / z base of the voxel lattice
   int *mode_bin;             // [B]  dominant z-bin (:169-178)
+  int *g2_pred, *g2_used, *g2_tag;   // [B] the latest mode bin any frame of the stream has reported (ONE array for all copies of the per-frame state); [B] this frame's snapshot of it — the bin its kernels mark speculatively; [B] the tag of this frame's ground marks (k_g2_mode)
   int *pkey;                 // [B][Nmax]  linear cell key per cloud point
   int *pslot;                // [B][Nmax]  grid build: per cloud point, its entry in its chunk's list of cells
   int2 *gc_list, *gc_ent;    // [B][Nmax]  grid build, chunk c at c·GC_CHUNK: (cell key, points) of every cell of the chunk (k_gridcount); (slot, offset) then (compact cell id, first position) of the same entries (k_gridhash)

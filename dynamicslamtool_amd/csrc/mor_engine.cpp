@@ -429,7 +429,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   //      (mor_push_batch).  288 GB of HBM3E make that cheap: ≈ 4 GB per copy at B = 64 × 120 000 points.
   const size_t R1 = (size_t)std::max(d.g.nrows, d.gv.nrows) + 1;
   std::vector<float> z0(B, p->gp_limit);   // crop-box variant: the clustering grid starts at gp_limit for every stream
-  ok = dalloc(b, d.gh_hint, B) && hipMemset(d.gh_hint, 0, B * sizeof(int)) == hipSuccess;   // (one for all copies: a stream's cell count of the latest grid build, the next build's tier hint)
+  ok = dalloc(b, d.gh_hint, B) && hipMemset(d.gh_hint, 0, B * sizeof(int)) == hipSuccess;
+  ok = ok && dalloc(b, d.g2_pred, B) && hipMemsetD32((hipDeviceptr_t)d.g2_pred, 0x7fffffff, B) == hipSuccess;   // (one for all copies: the latest mode bin of the voxel ground variant — the next frames' bet)   // (one for all copies: a stream's cell count of the latest grid build, the next build's tier hint)
   if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d)", d.B));
   for (int c = 0; c < (int)b->pipe_depth; ++c) {
     MorDev o = d; MorStreamArgs *dargs = nullptr;
@@ -448,7 +449,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = ok && dalloc(b, o.rs16, B * (size_t)d.rs16_stride) && dalloc(b, o.cx16, B * (size_t)d.cx16_stride);
     if (p->method_choice == 2) ok = ok && dalloc(b, o.vox, B * (size_t)d.Hcap) && dalloc(b, *reinterpret_cast<unsigned char **>(&o.vrec), B * 2 * K * 32);
     ok = ok && dalloc(b, o.moving, B * (K / 32 + 2)) && hipMemset(o.moving, 0, B * (K / 32 + 2) * sizeof(unsigned)) == hipSuccess && dalloc(b, o.out_desc, B * T) && hipMemset(o.out_desc, 0, B * T * sizeof(unsigned long long)) == hipSuccess && halloc(b, o.h_nout, B) && halloc(b, o.h_noff, B);   // (the size mirrors of the filtered clouds too: the output kernels of consecutive frames need no order among themselves)
-    ok = ok && dalloc(b, o.zmin_i, B) && dalloc(b, o.zmax_i, B) && hipMemsetD32((hipDeviceptr_t)o.zmin_i, 0x7fffffff, B) == hipSuccess && hipMemsetD32((hipDeviceptr_t)o.zmax_i, (int)0x80000000, B) == hipSuccess && dalloc(b, o.zorg, B) && dalloc(b, o.zbase, B) && hipMemset(o.zbase, 0, B * sizeof(int)) == hipSuccess && dalloc(b, o.mode_bin, B);
+    ok = ok && dalloc(b, o.zmin_i, B) && dalloc(b, o.zmax_i, B) && hipMemsetD32((hipDeviceptr_t)o.zmin_i, 0x7fffffff, B) == hipSuccess && hipMemsetD32((hipDeviceptr_t)o.zmax_i, (int)0x80000000, B) == hipSuccess && dalloc(b, o.zorg, B) && dalloc(b, o.zbase, B) && hipMemset(o.zbase, 0, B * sizeof(int)) == hipSuccess && dalloc(b, o.mode_bin, B) && dalloc(b, o.g2_used, B) && dalloc(b, o.g2_tag, B) && hipMemset(o.g2_tag, 0, B * sizeof(int)) == hipSuccess && hipMemsetD32((hipDeviceptr_t)o.g2_used, 0x7fffffff, B) == hipSuccess;
     if (ok) ok = hipMemcpy(o.zorg, z0.data(), B * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     if (d.gmode == 1) {   // voxel-covariance ground variant: the VoxelGrid sort and the per-voxel results
       for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, o.rkeys[i], B * N) && dalloc(b, o.rvals[i], B * N);

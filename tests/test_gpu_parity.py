@@ -696,6 +696,55 @@ def test_hdl64_urban_matches_oracle():
         assert st["clusters"] > 40 and st["corr"] > 20
 
 
+def test_voxel_covariance_ground_when_the_mode_bin_moves():
+    """The voxel ground variant marks the ground speculatively: the kernels that take the voxel verdicts bet on the mode bin the stream reported last (k_g2_mode) and mark the neighbours
+    of the accepted voxels of THAT bin at once; a lost bet falls back to k_g2_mark.  Two streams whose ground jumps by 0.37 m (four bins) and back — frame 0 has no bet, frames 1, 4 win
+    theirs, frames 2, 3 and 5 lose them (stream 1 jumps one frame later) — synchronously and in the asynchronous pipeline (where a frame may bet on an older report), every frame
+    against the oracle."""
+    p = scene_params(method_choice=1)
+    p.ground_method = 1
+    p.gp_leaf = 0.1
+    streams = []
+    for s in range(2):
+        fr = small_stream(7 + s, n_frames=7, n_floor=900)
+        up = [0, 0, 1, 0, 0, 1, 1] if s == 0 else [0, 0, 0, 1, 0, 0, 1]
+        streams.append([((x + np.array([0, 0, 0.37 * u, 0], np.float32)).astype(np.float32), ps) for (x, ps), u in zip(fr, up)])
+    st = _run_lockstep(p, streams)
+    assert st["clusters"] > 0
+    grounds = []
+    o = Oracle(p)
+    for x, ps in streams[0]:
+        o.push(x, ps)
+        grounds.append(int(o.counts().n_ground))
+        o.filter()
+    assert min(grounds) > 30, grounds
+    # the same frames without a wait between them
+    B, npt = 2, max(len(f[0]) for stq in streams for f in stq)
+    b = MorBatch(p, B, npt)
+    b.set_async(True)
+    bufs = []
+    for f in range(7):
+        db = DeviceBuffer(B * npt * 16)
+        for s in range(B):
+            db.upload(streams[s][f][0], s * npt * 16)
+        bufs.append(db)
+    for f in range(7):
+        b.push_views(b.make_views([(bufs[f].ptr + s * npt * 16, len(streams[s][f][0])) for s in range(B)]), np.stack([streams[s][f][1] for s in range(B)]))
+        b.filter_async()
+    b.wait()
+    os_ = [Oracle(p) for _ in range(B)]
+    for s in range(B):
+        for f in range(7):
+            os_[s].push(*streams[s][f])
+            os_[s].filter()
+        co, cb = os_[s].counts(), b.counts(s)
+        assert (co.n_trim, co.n_cloud, co.n_ground, co.n_clusters, co.n_clustered, co.n_corr, co.n_tracks) == (cb.n_trim, cb.n_cloud, cb.n_ground, cb.n_clusters, cb.n_clustered, cb.n_corr, cb.n_tracks), s
+        assert np.array_equal(os_[s].labels(), b.labels(s)) and np.array_equal(os_[s].detection(), b.detection(s)), s
+    b.close()
+    for db in bufs:
+        db.free()
+
+
 @pytest.mark.parametrize("seed", [1, 4])
 def test_voxel_covariance_ground_small_streams(seed):
     """G2 (reference :90-200): voxel-covariance ground removal, full pipeline on top of it."""
