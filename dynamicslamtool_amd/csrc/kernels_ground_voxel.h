@@ -305,11 +305,13 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
   }
 }
 // The queued voxels, one WAVE per voxel: the same screen with sixty-four lanes for the voxels k_g2_cov did not walk; the ordered sums for those
-// the screen leaves open, up to G2_MID_CAP neighbours in the wave's 20 KiB slice of LDS (gather with ballot compaction, rank by counting — the
+// the screen leaves open, up to G2_MID_CAP neighbours in the wave's 5 KiB slice of LDS (gather with ballot compaction, rank by counting — the
 // (d², index) keys are unique —, coordinates to their rank, ordered sums as three chains in three lanes).  Settled entries of the queue are
 // complemented; what is left (open AND more than G2_MID_CAP neighbours) goes to k_g2_cov_big.  A wave works in its own slice of LDS: the
 // order of ONE wave's LDS accesses — which the hardware keeps — is all its lanes need, not a workgroup barrier.
-#define G2_MID_CAP 1024
+#ifndef G2_MID_CAP
+#define G2_MID_CAP 256   // (round 5: 1024 — 80 KB of LDS per workgroup, two per CU — made this kernel wait for CUs the other lanes' kernels had not filled: 149 µs alone, 1 030 in the pipeline; the voxels the screen leaves open have a few dozen neighbours)
+#endif
 __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
   const int s = blockIdx.y + d.s0, nbig = d.g2_nbig[s], bxq = blockIdx.x, gq = gridDim.x;   // (spread over all XCDs: the queues are uneven across streams, and a workgroup holds 80 KB of LDS)
   const size_t so = (size_t)s * d.Nmax;
@@ -405,6 +407,9 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
 // what the middle tier left: one 1024-thread workgroup each (the LDS lets only one live on a CU anyway: sixteen waves sort four times faster than
 // four), up to G2_CAP neighbours in 128 KiB of LDS
 #define G2_BIG_T 1024
+#ifndef G2_BIG_G
+#define G2_BIG_G 8    // workgroups per stream of k_g2_cov_big
+#endif
 __global__ __launch_bounds__(G2_BIG_T) void k_g2_cov_big(MorDev d) {
   const int s = blockIdx.y + d.s0, nbig = d.g2_nbig[s], bxq = blockIdx.x, gq = gridDim.x;   // (tried: two workgroups per stream shared out by the queues — the queue holds mostly entries the middle tier has settled, so a stream's few big voxels ended up behind each other in one workgroup: 4.3 ms)
   const size_t so = (size_t)s * d.Nmax;
