@@ -83,6 +83,9 @@ __device__ __forceinline__ void count_push(bool want, int *cnt, int pr) {
 // within √lb of q, almost always in q's own cell: ≈ 85 % of the queries end here (never counted).  The rest is
 // compacted into worklists so the next tiers run full waves of like queries: `wl` front = E2 known (a matched point of
 // the own cell closer than √ub), `wl` back = own cell without a matched point, `wl2` = big own cell (wave tier).
+#ifndef SCF_BUDGET
+#define SCF_BUDGET 64   // samples of its own cell a thread of tier 1 looks at
+#endif
 #define SCF_T 1024   // threads per workgroup of tier 1: sixteen waves share one LDS copy of the stream's cell index (loading it per 256 queries cost more than the lookups saved)
 #ifndef SCF_MINW
 #define SCF_MINW 8   // ≤ 64 VGPRs: two 1024-thread workgroups per CU (69 VGPRs were one)
@@ -116,9 +119,9 @@ __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
       const int cc = max(c, 0), cid = d.ccid[so + cc], b0 = c >= 0 ? st[cc] : 0, e0 = c >= 0 ? st[cc + 1] : 0;
       pr = __float_as_int(tlo.w); target = __float_as_int(thi.w);
       if (pr >= 0) {
-        int budget = 64;   // a big own cell that shows no close point among 64 evenly spread samples goes to the wave tier
+        int budget = SCF_BUDGET;   // a big own cell that shows no close point among SCF_BUDGET evenly spread samples goes to the wave tier
         const bool reach = box_dist2(q, tlo, thi) < d.pde_ub;   // farther than √ub from the whole matched cluster: never counted
-        if (reach && c >= 0 && cid == target) { scan_sampled(sp, b0, e0, q, lbn, best, budget); big = best > d.pde_lb && e0 - b0 > 64; }
+        if (reach && c >= 0 && cid == target) { scan_sampled(sp, b0, e0, q, lbn, best, budget); big = best > d.pde_lb && e0 - b0 > SCF_BUDGET; }
         if (reach && best > d.pde_lb && !big) {
           if (!e1_local) big = true;   // √lb reaches beyond the adjacent half-cells in this configuration: wave tier
           else if (best < d.pde_ub) {
