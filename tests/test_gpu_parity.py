@@ -683,7 +683,7 @@ def test_full_size_batch_properties_os128_b64():
 
 def test_full_size_batch_properties_agg10_b32():
     """BASELINE configs[4]: B = 32 aggregated 10-sweep clouds of 1 000 000 points."""
-    _full_batch_properties("agg10", 32, 5000)
+    _full_batch_properties("agg10", 32, 5000, n_frames=2)   # (two frames: generating 32 × 1 M points per frame is this test's time; tests/test_fullbatch.py holds every stream of the batch to the oracle's records over three)
 
 
 def test_hdl64_urban_matches_oracle():
@@ -838,7 +838,7 @@ def test_async_pipeline_matches_oracle(method):
     """Asynchronous mode: pushes and filters are only enqueued (three-stage frame pipeline on three HIP streams, state
     double/triple-buffered); the host waits every few frames and the state it then reads must equal the oracle's."""
     p = kitti_params(method)
-    B, nf = 8, 10
+    B, nf = 4, 8   # (the CPU oracle is this test's time: 4 streams × 8 frames of 120 000 points)
     streams = [[synth.frame(2100 + s, "hdl64", f) for f in range(nf)] for s in range(B)]
     b = MorBatch(p, B, 120000)
     b.set_async(True)
