@@ -441,17 +441,29 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mode(MorDev d) {
   for (int i = threadIdx.x; i < 4096; i += MOR_BT) hist[i] = 0;
   if (threadIdx.x == 0) { best_cnt = 0; best_bin = 0x7fffffff; }
   __syncthreads();
-  for (int v = threadIdx.x; v < V; v += MOR_BT) {
-    int b = d.vbin[so + v];
-    if (b == 0x7fffffff) continue;
-    if (b < -2048 || b >= 2048) { mor_raise(d, s, 8u); continue; }
-    atomicAdd(&hist[b + 2048], 1);
+  for (int v0 = threadIdx.x; v0 < V; v0 += 8 * MOR_BT) {   // eight bin words per thread and round trip (one at a time this one-workgroup kernel was 90 dependent round trips: 72 µs)
+    int bb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) bb[u] = d.vbin[so + min(v0 + u * MOR_BT, V - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = bb[u];
+      if (v0 + u * MOR_BT >= V || b == 0x7fffffff) continue;
+      if (b < -2048 || b >= 2048) { mor_raise(d, s, 8u); continue; }
+      atomicAdd(&hist[b + 2048], 1);
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 4096; i += MOR_BT) atomicMax(&best_cnt, hist[i]);
-  __syncthreads();
-  for (int i = threadIdx.x; i < 4096; i += MOR_BT) if (best_cnt > 0 && hist[i] == best_cnt) atomicMin(&best_bin, i - 2048);
-  __syncthreads();
+  {  // the fullest bin, ties → the smallest bin: every thread over its sixteen bins, then the wave by shuffles, then one atomic pair per wave (4 096 atomics on one LDS word each way before)
+    int cnt = 0, bin = 0x7fffffff;
+    for (int i = threadIdx.x; i < 4096; i += MOR_BT) { const int h = hist[i]; if (h > cnt) { cnt = h; bin = i - 2048; } }   // (ascending i: a later bin with the same count does not replace an earlier one)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int c2 = __shfl_xor(cnt, o, 64), b2 = __shfl_xor(bin, o, 64); if (c2 > cnt || (c2 == cnt && b2 < bin)) { cnt = c2; bin = b2; } }
+    if (lane_id() == 0) atomicMax(&best_cnt, cnt);
+    __syncthreads();
+    if (lane_id() == 0 && cnt > 0 && cnt == best_cnt) atomicMin(&best_bin, bin);
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     // The mode bin is known only now, but it hardly ever moves from frame to frame (it is the height of the ground): the kernels that take the verdicts have marked the neighbours of
     // the accepted voxels of the bin they BET on (g2_used: pass A's snapshot of the latest mode any frame of the stream has reported) with the tag 2·frame + 1 — while their candidate
