@@ -696,6 +696,26 @@ def test_hdl64_urban_matches_oracle():
         assert st["clusters"] > 40 and st["corr"] > 20
 
 
+def test_voxel_covariance_ground_streams_with_different_key_widths():
+    """The VoxelGrid lattice has the stream's own z layers, and a stream takes part in the radix passes ITS key width needs: a sweep that spans 4 m of z has 22-bit voxel keys (three
+    passes, the result in one ping-pong buffer), one with a 15-m mast 25-bit keys (four passes, the other buffer).  Both in one batch, three frames, every frame against the oracle."""
+    p = kitti_params(1)
+    p.ground_method = 1
+    rng = np.random.default_rng(3)
+    streams = []
+    for s in range(2):
+        frames = []
+        for f in range(3):
+            x, ps = synth.frame(2040 + s, "hdl64", f)
+            if s == 1:   # a mast: 3 000 returns between 2 and 15 m above the sensor replace the sweep's last records
+                mast = np.column_stack([6.0 + rng.normal(0, 0.05, 3000), -4.0 + rng.normal(0, 0.05, 3000), rng.uniform(2.0, 15.0, 3000), rng.random(3000)]).astype(np.float32)
+                x = np.concatenate([x[:-3000], mast]).astype(np.float32)
+            frames.append((x, ps))
+        streams.append(frames)
+    st = _run_lockstep(p, streams, max_points=120000)
+    assert st["clusters"] > 0
+
+
 def test_voxel_covariance_ground_when_the_mode_bin_moves():
     """The voxel ground variant marks the ground speculatively: the kernels that take the voxel verdicts bet on the mode bin the stream reported last (k_g2_mode) and mark the neighbours
     of the accepted voxels of THAT bin at once; a lost bet falls back to k_g2_mark.  Two streams whose ground jumps by 0.37 m (four bins) and back — frame 0 has no bet, frames 1, 4 win
