@@ -281,6 +281,20 @@ __device__ __forceinline__ void row_cells(const MorGrid &g, const int *ckey, con
   const int r = grid_row(g, cy, cz);
   row_range(ckey, rs[r], rs[r + 1], r * g.nx, x0, x1, lo, hi);
 }
+// The same from the occupancy bits of the VoxelGrid lattice (voxel ground variant, round 5): bits[row][x], a row padded to chunks of 512 cells = eight words = one 64-byte line,
+// and beside every word the compact id of the first cell at or behind its bit 0 (dir, written by k_g2_cent from the row table and the bits): the directory entry, the word of x0
+// and its successor — THREE independent loads and two popcounts where the key search is a chain of four round trips and three dozen loads per row.  k_heads_scatter sets the
+// bits, k_g2_mark clears them.  (First form: row table + the row's whole line, the cells in front of x0 counted from its eight words — a hundred ALU instructions per row.)
+__device__ __forceinline__ void row_cells_bits(const unsigned long long *bits, const int *dir, int nw /* words per row */, int r, int x0, int x1, int &lo, int &hi) {
+  const int w0 = x0 >> 6, sh = x0 & 63;
+  const size_t o = (size_t)r * nw + w0;
+  const unsigned long long a = bits[o], b1 = bits[o + (w0 + 1 < nw ? 1 : 0)];
+  const int base = dir[o];
+  const unsigned long long b = w0 + 1 < nw ? b1 : 0ull;
+  const unsigned long long win = sh ? (a >> sh) | (b << (64 - sh)) : a;   // cells x0, x0 + 1, … in bits 0, 1, …
+  lo = base + __popcll(a & ((1ull << sh) - 1ull));
+  hi = lo + __popcll(win & ((2ull << (x1 - x0)) - 1ull));   // (x1 − x0 ≤ 62)
+}
 // compact id of cell (cx,cy,cz) or −1 when empty / outside
 __device__ __forceinline__ int cell_lookup(const MorGrid &g, const int *ckey, const int *rs, int cx, int cy, int cz) {
   if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cy >= (unsigned)g.ny || (unsigned)cz >= (unsigned)g.nz) return -1;

@@ -210,6 +210,52 @@ __device__ __forceinline__ int g2_screen(const G2Acc &A, const float4 &q, double
 #define G2_Q_EXACT (1 << 30)   // queue entry: the screen has been through this voxel and left it to the ordered sums
 #define G2_V_NONE 0x7fffffff   // bin word of a voxel without a bin (rejected, or ≤ 3 neighbours)
 #define G2_COV_G 256   // workgroups per stream of k_g2_cov; 64 of the middle / big tiers, 128 of k_g2_mark
+#define G2_CENT_G 32   // workgroups per stream of k_g2_cent (a thread per voxel)
+// Voxel centroids (dsc, :110-113): sequential fp32 sums over a voxel's points in ascending index (stable sort ⇒ storage order), one THREAD per voxel, sixteen loads per round
+// trip.  Its own launch since round 5: k_g2_cov — whose time, cut into pieces, was 58 % the chains of dependent loads in front of its walks (voxel range → points → centroid →
+// its cell → row table → key search → ranges → candidates, at five waves per SIMD) — now starts its row lookups from the voxel's own key at once, beside ONE load of the centroid.
+// (196 µs alone, 38 with every voxel cut to 64 points: a few streams hold a voxel of 1 400 – 3 000 points — something right at the sensor —, one stream 215 voxels of 47 000
+//  points.  Tried: the wave of the voxel's thread taking its big voxels one after the other, 64 points per coalesced load — they share a wave, 560 µs; a queue of the voxels over
+//  64 points and a second launch with a wave each, sums by broadcast reads from LDS — 37 + 61 µs alone and NOTHING in the pipeline (35.10 against 35.06 k frame-pairs/s,
+//  interleaved): a tail on a few CUs is not what the other lanes' kernels wait for.)
+__global__ __launch_bounds__(MOR_BT) void k_g2_cent(MorDev d) {
+  int s, bx; map_block(d.B, G2_CENT_G, s, bx);
+  const int V = d.info[s].n_occ;
+  const size_t so = (size_t)s * d.Nmax;
+  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  const float4 *sp = d.sorted + so;
+  if (d.g2_bits) {   // the directory of the lattice's occupancy bits (row_cells_bits): a thread per (y,z) row of the stream's own layers — row table + the row's bits → first cell of every word
+    const int nrows = V > 0 ? stream_grid(d, s).nrows : 0, nch = d.g2_nch;
+    const int *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
+    const size_t bo = (size_t)s * d.g.nrows * (size_t)(nch * 8);
+    for (int r = bx * MOR_BT + threadIdx.x; r < nrows; r += G2_CENT_G * MOR_BT) {
+      int c = rs[r];
+      for (int k = 0; k < nch; ++k) {
+        const ulonglong2 *w = reinterpret_cast<const ulonglong2 *>(d.g2_bits + bo + ((size_t)r * nch + k) * 8);
+        ulonglong2 q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = w[i];
+        int o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { o[i] = c; c += __popcll((i & 1) ? q[i >> 1].y : q[i >> 1].x); }
+        int4 *dd = reinterpret_cast<int4 *>(d.g2_dir + bo + ((size_t)r * nch + k) * 8);
+        dd[0] = make_int4(o[0], o[1], o[2], o[3]); dd[1] = make_int4(o[4], o[5], o[6], o[7]);
+      }
+    }
+  }
+  for (int v = bx * MOR_BT + threadIdx.x; v < V; v += G2_CENT_G * MOR_BT) {
+    float sx = 0.f, sy = 0.f, sz = 0.f; const int b0 = st[v], n = st[v + 1] - b0;
+    for (int k = 0; k < n; k += 16) {
+      float4 p[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) p[u] = sp[b0 + min(k + u, n - 1)];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) if (k + u < n) { sx += p[u].x; sy += p[u].y; sz += p[u].z; }
+    }
+    const float fn = (float)n;
+    d.vcent[so + v] = make_float4(sx / fn, sy / fn, sz / fn, 0.f);
+  }
+}
 __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
   int s, bxv; map_block(d.B, G2_COV_G, s, bxv);   // (a stream's workgroups on one XCD, as everywhere else: as a two-dimensional launch a stream's voxels went round all eight L2s)
   const int V = d.info[s].n_occ;
@@ -218,32 +264,27 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
   const int zbase = d.zbase[s]; const MorGrid G = stream_grid(d, s);   // (the lattice with the stream's own z layers)
+  const unsigned long long *bits = d.g2_bits ? d.g2_bits + (size_t)s * d.g.nrows * (size_t)(d.g2_nch * 8) : nullptr;   // occupancy bits of the lattice (none: the key search)
+  const int *dir = d.g2_dir + (size_t)s * d.g.nrows * (size_t)(d.g2_nch * 8);
   const int pred = d.g2_used[s], tag_spec = 2 * d.frame_no + 1;   // the mode bin this frame's kernels bet on (pass A's snapshot of the latest known one), and the tag of the marks made on that bet
   for (int v0 = bxv * (MOR_BT / 16); v0 < V; v0 += G2_COV_G * (MOR_BT / 16)) {
     const int v = v0 + grp; const bool act = v < V;
-    // ---- voxel centroid: sequential fp32 sums over the voxel's points in ascending index (stable sort ⇒ storage order)
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (act && sub == 0) {
-      float sx = 0.f, sy = 0.f, sz = 0.f; const int b0 = st[v], e0 = st[v + 1];
-      for (int k = b0; k < e0; k += 8) {   // eight loads per round trip, the adds in index order
-        float4 p[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = sp[min(k + u, e0 - 1)];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (k + u < e0) { sx += p[u].x; sy += p[u].y; sz += p[u].z; }
-      }
-      const float n = (float)(e0 - b0);
-      q = make_float4(sx / n, sy / n, sz / n, 0.f);
-      d.vcent[so + v] = q;
+    // ---- the voxel's centroid (k_g2_cent) and its key, one load each; the nine (y,z) rows of the 3×3×3 block start from the KEY's cell at once — lanes 0 … 8 of the group,
+    //      each row's three x-cells are one range of `sorted` — and are looked up again from the centroid's cell in the rare case that the fp32 centroid rounds into a neighbour
+    const float4 q = d.vcent[so + min(v, V - 1)];
+    const int key = ckey[min(v, V - 1)], krow = key / G.nx;
+    int cx = key - krow * G.nx, cy = krow / G.nz, cz = krow - cy * G.nz;
+    {
+      int qx, qy, qz; bool cl; grid_cell(G, q, 0.f, zbase, qx, qy, qz, cl);
+      if (qx != cx || qy != cy || qz != cz) { cx = qx; cy = qy; cz = qz; }   // (the block is the one around the CENTROID's cell, :125)
     }
-    q.x = __shfl(q.x, lane & 48, 64); q.y = __shfl(q.y, lane & 48, 64); q.z = __shfl(q.z, lane & 48, 64);
-    // ---- the nine (y,z) rows of the 3×3×3 block: lanes 0 … 8 of the group, each row's three x-cells are one range of `sorted`
     int rb0 = 0, rlen = 0;
     if (act && sub < 9) {
-      int cx, cy, cz; bool cl; grid_cell(G, q, 0.f, zbase, cx, cy, cz, cl);
       const int y = cy + sub % 3 - 1, z = cz + sub / 3 - 1;
       if ((unsigned)y < (unsigned)G.ny && (unsigned)z < (unsigned)G.nz) {
-        int lo, hi; row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
+        int lo, hi;
+        if (bits) row_cells_bits(bits, dir, d.g2_nch * 8, grid_row(G, y, z), max(cx - 1, 0), min(cx + 1, G.nx - 1), lo, hi);
+        else row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
         if (lo < hi) { rb0 = st[lo]; rlen = st[hi] - rb0; }
       }
     }
@@ -321,6 +362,8 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
   const int zbase = d.zbase[s]; const MorGrid G = stream_grid(d, s);   // (the lattice with the stream's own z layers)
+  const unsigned long long *bits = d.g2_bits ? d.g2_bits + (size_t)s * d.g.nrows * (size_t)(d.g2_nch * 8) : nullptr;   // occupancy bits of the lattice (none: the key search)
+  const int *dir = d.g2_dir + (size_t)s * d.g.nrows * (size_t)(d.g2_nch * 8);
   for (int w0 = bxq * (MOR_BT / 64); w0 < nbig; w0 += gq * (MOR_BT / 64)) {
    {
     const int w = w0 + wv;
@@ -332,7 +375,9 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
       int cx, cy, cz; bool cl; grid_cell(G, q, 0.f, zbase, cx, cy, cz, cl);
       const int y = cy + lane % 3 - 1, z = cz + lane / 3 - 1;
       if ((unsigned)y < (unsigned)G.ny && (unsigned)z < (unsigned)G.nz) {
-        int lo, hi; row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
+        int lo, hi;
+        if (bits) row_cells_bits(bits, dir, d.g2_nch * 8, grid_row(G, y, z), max(cx - 1, 0), min(cx + 1, G.nx - 1), lo, hi);
+        else row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
         if (lo < hi) { rb0 = st[lo]; rlen = st[hi] - rb0; }
       }
     }
@@ -482,8 +527,12 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mode(MorDev d) {
 __global__ __launch_bounds__(MOR_BT) void k_g2_mark(MorDev d) {
   int s, bxm; map_block(d.B, 128, s, bxm);
   const int V = d.info[s].n_occ, mode = d.mode_bin[s];
-  if (mode == 0x7fffffff || d.g2_tag[s] == 2 * d.frame_no + 1) return;   // (no accepted voxel at all; or the bet on the mode bin held: the marks are there already)
   const size_t so = (size_t)s * d.Nmax;
+  if (d.g2_bits) {   // the lattice's occupancy bits go back to zero for the copy's next frame, word by word through the voxels that set them (this kernel's own lookups search the keys)
+    unsigned long long *bits = d.g2_bits + (size_t)s * d.g.nrows * (size_t)(d.g2_nch * 8);
+    for (int v = bxm * MOR_BT + threadIdx.x; v < V; v += 128 * MOR_BT) { const int kc = d.ckey[so + v], r0 = kc / d.g.nx, x = kc - r0 * d.g.nx; bits[(size_t)r0 * (d.g2_nch * 8) + (x >> 6)] = 0ull; }
+  }
+  if (mode == 0x7fffffff || d.g2_tag[s] == 2 * d.frame_no + 1) return;   // (no accepted voxel at all; or the bet on the mode bin held: the marks are there already)
   const int lane = lane_id(), nw = 128 * (MOR_BT / 64), grp = lane >> 4, sub = lane & 15;
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;

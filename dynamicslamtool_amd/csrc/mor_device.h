@@ -130,6 +130,7 @@ struct MorDev {
   int *is_ground;            // [B][Nmax]  per trimmed point
   float4 *vcent; int *vbin;  // [B][Nmax]  voxel centroids (dsc, :113) and bin id of accepted voxels
   int *g2_big, *g2_nbig;     // [B][Nmax], [B]  voxels with more neighbours than the one-wave kernel holds
+  unsigned long long *g2_bits; int *g2_dir; int g2_nch;   // [B][gv.nrows][g2_nch·8]  occupancy bits of the VoxelGrid lattice, a row padded to g2_nch chunks of 512 cells, and the first cell of every word of them (row_cells_bits); null: the kernels search the keys (MOR_G2_NOBITS, or a lattice whose bits would not fit 2 GB per frame in flight)
   int *zmin_i, *zmax_i;      // [B]  ordered-int min / max z of the trimmed cloud
   float *zorg; int *zbase;   // [B]  z origin of the clustering grid / z base of the voxel lattice
   int *mode_bin;             // [B]  dominant z-bin (:169-178)
@@ -237,7 +238,7 @@ struct MorCellSum { long long a[3], b[3]; };
 enum MorKernelId {
   MK_CLASSIFY, MK_SCATTER, MK_SPLIT, MK_HEADS_COUNT, MK_HEADS_SCATTER, MK_CELLBOXES, MK_RHIST, MK_RSCAN, MK_RSCATTER,
   MK_SCORE_FAST, MK_SCORE_NB, MK_SCORE1, MK_VOX_CLEAR, MK_VOX_INSERT, MK_VOX_PROBE,
-  MK_OUT, MK_G2_COV_MID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_GRIDHASH, MK_GRIDCOUNT, MK_GRIDPLACE, MK_CG_SLAB, MK_CG_FINAL, MK_CLUSTERS, MK_COUNT
+  MK_OUT, MK_G2_COV_MID, MK_G2_COV, MK_G2_COV_BIG, MK_G2_MODE, MK_G2_MARK, MK_TRACK_PUSH, MK_TRACK_FILTER, MK_GRIDHASH, MK_GRIDCOUNT, MK_GRIDPLACE, MK_CG_SLAB, MK_CG_FINAL, MK_CLUSTERS, MK_G2_CENT, MK_COUNT
 };
 extern const char *const mor_kernel_names[MK_COUNT];
 

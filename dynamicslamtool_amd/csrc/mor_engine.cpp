@@ -196,7 +196,7 @@ static int configure(mor_batch *b) {
   d.g.keybits = 1; while ((1ll << d.g.keybits) < (long long)(nx * ny * nz)) ++d.g.keybits;
   d.cell_passes = (d.g.keybits + 7) / 8;
   d.g.ox = -p.trim_x; d.g.oy = -p.trim_y; d.g.oz = zlo; d.g.cs = cs; d.g.inv_cs = 1.0f / cs; d.g.mode = 0; d.g.ibx = d.g.iby = 0;
-  d.gv = d.g; d.voxel_passes = 0; d.leaf_r2 = 0.f; d.g2_r = 0.0; d.g2_inv_r = 0.0;
+  d.gv = d.g; d.voxel_passes = 0; d.leaf_r2 = 0.f; d.g2_r = 0.0; d.g2_inv_r = 0.0; d.g2_bits = nullptr; d.g2_dir = nullptr; d.g2_nch = 0;
   if (d.gmode == 1) {   // VoxelGrid lattice: cells at absolute multiples of the leaf (pcl::VoxelGrid: floor(x·inv_leaf)), :110-113
     MorGrid &v = d.gv; v.mode = 1; v.cs = p.gp_leaf; v.inv_cs = 1.0f / p.gp_leaf;
     v.ibx = (int)std::floor(-p.trim_x * v.inv_cs); v.iby = (int)std::floor(-p.trim_y * v.inv_cs);
@@ -207,6 +207,7 @@ static int configure(mor_batch *b) {
     v.nx = (int)vx; v.ny = (int)vy; v.nz = (int)vz; v.nrows = v.ny * v.nz;
     v.keybits = 1; while ((1ll << v.keybits) < (long long)(vx * vy * vz)) ++v.keybits;
     d.voxel_passes = (v.keybits + 7) / 8;
+    d.g2_nch = (v.nx + 511) / 512;
     double lf = (double)p.gp_leaf; d.leaf_r2 = (float)(lf * lf); d.g2_r = std::sqrt((double)d.leaf_r2) * 1.0001 + 1e-6; d.g2_inv_r = 1.0001 / std::sqrt((double)d.leaf_r2);   // radiusSearch(…, gp_leaf): (float)(radius·radius)
   }
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
@@ -455,6 +456,10 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
       for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, o.rkeys[i], B * N) && dalloc(b, o.rvals[i], B * N);
       ok = ok && dalloc(b, o.rhist, B * T * 256) && dalloc(b, o.gnz, B) && dalloc(b, o.vnz, B) && dalloc(b, o.rawbuf, B * N) && dalloc(b, o.is_ground, B * N) && dalloc(b, o.vcent, B * N) && dalloc(b, o.vbin, B * N) && dalloc(b, o.g2_big, B * N) && dalloc(b, o.g2_nbig, B) && hipMemset(o.g2_nbig, 0, B * sizeof(int)) == hipSuccess && hipMemset(o.is_ground, 0, B * N * sizeof(int)) == hipSuccess;
       o.skey = o.rkeys[d.voxel_passes & 1]; o.sidx = o.rvals[d.voxel_passes & 1];
+      {   // occupancy bits of the lattice: 64 + 32 bytes per (y,z) row and 512 cells in x — 990 MB per frame in flight at B = 64, ±50 m, 0.2-m leaves, of which a frame touches the rows of its own z layers (25 MB)
+        const size_t words = (size_t)B * (size_t)d.gv.nrows * (size_t)d.g2_nch * 8;
+        if (!getenv("MOR_G2_NOBITS") && words * 12 <= ((size_t)2 << 30)) ok = ok && dalloc(b, o.g2_bits, words) && hipMemset(o.g2_bits, 0, words * 8) == hipSuccess && dalloc(b, o.g2_dir, words);
+      }
     }
     if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d, max_points=%llu, copy %d of %d)", d.B, (unsigned long long)max_points, c + 1, (int)b->pipe_depth));
     b->d_args_s[c] = dargs; o.args = dargs;

@@ -30,7 +30,7 @@
 const char *const mor_kernel_names[MK_COUNT] = {   // in MorKernelId order: "k_" + name = the __global__ function
     "classify", "scatter", "split", "heads_count", "heads_scatter", "cellboxes", "rhist", "rscan", "rscatter",
     "score_fast", "score_nb", "score_pde", "vox_clear", "vox_insert", "vox_probe",
-    "out", "g2_cov_mid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridcount", "gridplace", "cg_slab", "cg_final", "clusters"};
+    "out", "g2_cov_mid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridcount", "gridplace", "cg_slab", "cg_final", "clusters", "g2_cent"};
 
 // The kernels by stage (one translation unit; every file is #included exactly here):
 #include "kernels_common.h"
@@ -107,6 +107,7 @@ static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLau
     //  leave them ready — publish_split of pass B, the frame tag in is_ground, k_g2_mode)
     mor_launch_split_and_grid(da, st, tm);
   } else if (sub == 1) {
+    MOR_LAUNCH_T(MK_G2_CENT, k_g2_cent, dim3(G2_CENT_G * d.B), MOR_BT, da);
     MOR_LAUNCH_T(MK_G2_COV, k_g2_cov, dim3(G2_COV_G * d.B), MOR_BT, da);
   } else if (sub == 2) {
     MOR_LAUNCH(MK_G2_COV_MID, k_g2_cov_mid, dim3(64, d.B), da);

@@ -806,6 +806,23 @@ def test_voxel_covariance_ground_ordered_sums_only(monkeypatch):
     print("ordered sums evaluated: by default %d voxels, with MOR_G2_EXACT %d" % (st["g2_exact"], st2["g2_exact"]))
 
 
+def test_voxel_covariance_ground_lattice_lookups_by_key_search_and_two_chunks_wide(monkeypatch):
+    """The 3×3×3 block of a voxel centroid is resolved from the lattice's occupancy bits and their word directory (row_cells_bits: a (y,z) row is chunks of 512 cells);
+    lattices whose bits would not fit — and MOR_G2_NOBITS=1 — search the sorted voxel keys instead (row_cells), as k_g2_mark always does.  Both must give the oracle's
+    frames; and so must a lattice more than 512 cells wide (trim_x 60 m at 0.2-m leaves: two chunks per row, ranges that straddle the chunk boundary at x = 512)."""
+    p = kitti_params(1)
+    p.ground_method = 1
+    streams = [[synth.frame(1000 + s, "hdl64", f) for f in range(2)] for s in range(2)]
+    st = _run_lockstep(p, streams)
+    monkeypatch.setenv("MOR_G2_NOBITS", "1")
+    st2 = _run_lockstep(p, streams)
+    assert st2["clusters"] == st["clusters"] and st2["g2_exact"] == st["g2_exact"], (st, st2)
+    monkeypatch.delenv("MOR_G2_NOBITS")
+    p.trim_x = 60.0   # 601 cells in x: the cloud's centre (x ≈ 0) lies at cell 300, x = +42 m … +43 m across the chunk boundary
+    st3 = _run_lockstep(p, streams)
+    assert st3["clusters"] > 0
+
+
 def test_grid_merge_moves_between_its_tiers_from_frame_to_frame():
     """k_gridhash starts every stream at the table tier its cell count of the latest build asks for and moves up when the table overflows: a stream that
     alternates between a small indoor cloud (a few hundred cells) and a street scene (more cells than the all-LDS tier holds) overflows on every other frame,
