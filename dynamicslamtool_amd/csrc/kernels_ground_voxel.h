@@ -161,11 +161,15 @@ __device__ __forceinline__ bool g2_ordered_sums3(const float *lx, const float *l
 // (Sums of absolute values are not accumulated one by one: Σd² — the squared distances the radius test has just worked out — bounds them all: |a| ≤ (r + a²/r) / 2 gives
 //  Σ|a_i| ≤ (n·r + Σd²/r) / 2 and |a·c| ≤ (a² + c²) / 2 gives Σ|a_i·c_i| ≤ Σd² / 2.  The sixteen-lane kernel's time IS this fp64 arithmetic — every candidate step pays for it as
 //  soon as one lane has a hit, then the sums are reduced over the group —: seven additions per hit and eight reduced values instead of eleven and twelve.)
-struct G2Acc { double Sa, Sb, Sc, Sac, Sbc, Scc, Sdd; int n; };
-__device__ __forceinline__ void g2_acc_zero(G2Acc &A) { A.Sa = A.Sb = A.Sc = A.Sac = A.Sbc = A.Scc = A.Sdd = 0.0; A.n = 0; }
+// (Round 5, second step: the sums themselves are fp32 — differences to q, their products, a lane's hits one after the other, then the tree over the lanes: at most n + 8 roundings
+//  on any path, each relative to |a|, |a·c| … — and the screen charges them to its bound: every sum is off by at most g'·Σ|terms|, g' = 1.01·γ_{n+10}, which moves a term t by at
+//  most g'·(Σ|a·c| + |mc|·Σ|a| + |ma|·Σ|c|) ≤ g'·axz — the last summand of the bound once more.  The coordinates here are decimetres around q where the reference's are tens of
+//  metres around the origin: its roundings, not these, are what the bound consists of.  Measured: nothing by itself — see G2_GW.)
+struct G2Acc { float Sa, Sb, Sc, Sac, Sbc, Scc, Sdd; int n; };
+__device__ __forceinline__ void g2_acc_zero(G2Acc &A) { A.Sa = A.Sb = A.Sc = A.Sac = A.Sbc = A.Scc = A.Sdd = 0.f; A.n = 0; }
 __device__ __forceinline__ void g2_acc_add(G2Acc &A, const float4 &q, const float4 &p, float dd /* sqdist(q, p) */) {
-  const double a = (double)p.x - (double)q.x, b = (double)p.y - (double)q.y, c = (double)p.z - (double)q.z;   // exact: differences of two floats
-  A.Sa += a; A.Sb += b; A.Sc += c; A.Sac += a * c; A.Sbc += b * c; A.Scc += c * c; A.Sdd += (double)dd;
+  const float a = p.x - q.x, b = p.y - q.y, c = p.z - q.z;
+  A.Sa += a; A.Sb += b; A.Sc += c; A.Sac += a * c; A.Sbc += b * c; A.Scc += c * c; A.Sdd += dd;
   ++A.n;
 }
 template <int W> __device__ __forceinline__ void g2_acc_reduce(G2Acc &A) {   // over the W lanes of the caller's group (W = 16 or 64, aligned)
@@ -180,19 +184,21 @@ template <int W> __device__ __forceinline__ void g2_acc_reduce(G2Acc &A) {   // 
 __device__ __forceinline__ int g2_screen(const G2Acc &A, const float4 &q, double leaf_r /* √leaf² · 1.0001 + 1e-6, from the host */, double inv_r /* 1 / √leaf² */) {
   // (one division and no square root: sixteen lanes wait while one works this out for its group — r comes from the host, 1 / (1 − x) ≤ 1 + 2x for x ≤ ½)
   const double n = (double)A.n, u = 5.9604644775390625e-8, r = leaf_r;
-  const double inv_n = 1.0 / n, ma = A.Sa * inv_n, mb = A.Sb * inv_n, mc = A.Sc * inv_n;   // centroid − q
-  const double txz = A.Sac - A.Sa * mc, tyz = A.Sbc - A.Sb * mc, tzz = A.Scc - A.Sc * mc;
+  if ((n + 10.0) * u > 0.25) return -1;   // (millions of neighbours: the bounds say nothing any more)
+  const double xo = (n + 10.0) * u, go = 1.01 * xo * (1.0 + 2.0 * xo);   // ≥ 1.01·γ_{n+10}: what the fp32 sums of THIS kernel can be off by, relative to the sums of the absolute values of their terms
+  const double Sa = A.Sa, Sb = A.Sb, Sc = A.Sc, Sac = A.Sac, Sbc = A.Sbc, Scc = A.Scc;
+  const double inv_n = 1.0 / n, ma = Sa * inv_n, mb = Sb * inv_n, mc = Sc * inv_n;   // centroid − q
+  const double txz = Sac - Sa * mc, tyz = Sbc - Sb * mc, tzz = Scc - Sc * mc;
   const double fa = fabs(ma), fb = fabs(mb), fc = fabs(mc);
-  const double sdd = A.Sdd * 1.000001 + 1e-12;   // ≥ Σ d_i² (the fp32 distances carry three roundings each)
+  const double sdd = (double)A.Sdd * (1.000001 + 2.0 * go) + 1e-12;   // ≥ Σ d_i² (the fp32 distances carry three roundings each, their fp32 sum its own)
   const double ab1 = 0.5 * (n * r + sdd * inv_r), ab2 = 0.5 * sdd;   // ≥ Σ|a_i|, Σ|b_i|, Σ|c_i|;  ≥ Σ|a_i·c_i|, Σ|b_i·c_i|
   const double sa = ab1 + n * fa, sb = ab1 + n * fb, sc = ab1 + n * fc;   // ≥ Σ|x_i − c| …
-  const double axz = ab2 + fc * ab1 + fa * ab1 + n * fa * fc, ayz = ab2 + fc * ab1 + fb * ab1 + n * fb * fc, azz = A.Scc + 2.0 * fc * ab1 + n * fc * fc;   // ≥ Σ|(x_i − c)(z_i − c)| …
-  if ((n + 4.0) * u > 0.25) return -1;   // (millions of neighbours: the bound says nothing any more)
+  const double axz = ab2 + fc * ab1 + fa * ab1 + n * fa * fc, ayz = ab2 + fc * ab1 + fb * ab1 + n * fb * fc, azz = Scc * (1.0 + 2.0 * go) + 2.0 * fc * ab1 + n * fc * fc;   // ≥ Σ|(x_i − c)(z_i − c)| …
   const double xg = (n + 4.0) * u, g = 1.01 * xg * (1.0 + 2.0 * xg);   // ≥ 1.01·γ_{n+4}
   const double Dx = g * (fabs((double)q.x) + r), Dy = g * (fabs((double)q.y) + r), Dz = g * (fabs((double)q.z) + r);
-  const double Exz = (1.0 + g) * (Dz * sa + Dx * sc + n * Dx * Dz) + g * axz;
-  const double Eyz = (1.0 + g) * (Dz * sb + Dy * sc + n * Dy * Dz) + g * ayz;
-  const double Ezz = (1.0 + g) * (2.0 * Dz * sc + n * Dz * Dz) + g * azz;
+  const double Exz = (1.0 + g) * (Dz * sa + Dx * sc + n * Dx * Dz) + (g + go) * axz;   // (the reference's roundings + this kernel's)
+  const double Eyz = (1.0 + g) * (Dz * sb + Dy * sc + n * Dy * Dz) + (g + go) * ayz;
+  const double Ezz = (1.0 + g) * (2.0 * Dz * sc + n * Dz * Dz) + (g + go) * azz;
   const double T = 0.001, tiny = 1e-9;
   const double lxz = fabs(txz) - 2.0 * Exz - tiny, lyz = fabs(tyz) - 2.0 * Eyz - tiny, lzz = fabs(tzz) - 2.0 * Ezz - tiny;   // lower bounds of |t_ref|
   if (lxz > T || lyz > T || lzz > T) return 0;
@@ -200,16 +206,14 @@ __device__ __forceinline__ int g2_screen(const G2Acc &A, const float4 &q, double
   if (hxz < T && hyz < T && hzz < T) return 1;
   return -1;
 }
-// Sixteen lanes per voxel, sixteen voxels per 256-thread workgroup (a voxel centroid has a dozen neighbours on average, 96 %
-// have ≤ 64): the group computes the voxel's centroid (dsc, :110-113 — fp32 sums in ascending point index, one lane), walks the points
-// of the 3×3×3 voxel block (lanes 0–8 resolve the nine rows) and adds the neighbours within the radius into the screen's sums; the
-// verdict is taken from those (above).  No LDS, no sort.  Queued for k_g2_cov_mid (a whole wave each): voxels with more than
-// G2_NARROW_CAND candidates — dense surfaces next to the sensor, walked sixteen at a time they held their wave's other three groups up —
-// and the voxels the screen could not settle (tagged: their ordered sums are due).
+// k_g2_cov: a few lanes per voxel (G2_GW, below), 64 voxels per 256-thread workgroup (a voxel centroid has a dozen neighbours on average, 96 % have ≤ 64): the group reads
+// the voxel's centroid (k_g2_cent), resolves the nine rows of the 3×3×3 voxel block, walks their points and adds the neighbours within the radius into the screen's sums; the
+// verdict is taken from those (above).  No LDS, no sort.  Queued for k_g2_cov_mid (a whole wave each): voxels with more than G2_NARROW_CAND candidates — dense surfaces next
+// to the sensor, walked a few at a time they held their wave's other groups up — and the voxels the screen could not settle (tagged: their ordered sums are due).
 #define G2_NARROW_CAND 512
 #define G2_Q_EXACT (1 << 30)   // queue entry: the screen has been through this voxel and left it to the ordered sums
 #define G2_V_NONE 0x7fffffff   // bin word of a voxel without a bin (rejected, or ≤ 3 neighbours)
-#define G2_COV_G 256   // workgroups per stream of k_g2_cov; 64 of the middle / big tiers, 128 of k_g2_mark
+#define G2_COV_G 128   // workgroups per stream of k_g2_cov; 64 of the middle / big tiers, 128 of k_g2_mark
 #define G2_CENT_G 32   // workgroups per stream of k_g2_cent (a thread per voxel)
 // Voxel centroids (dsc, :110-113): sequential fp32 sums over a voxel's points in ascending index (stable sort ⇒ storage order), one THREAD per voxel, sixteen loads per round
 // trip.  Its own launch since round 5: k_g2_cov — whose time, cut into pieces, was 58 % the chains of dependent loads in front of its walks (voxel range → points → centroid →
@@ -256,18 +260,23 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cent(MorDev d) {
     d.vcent[so + v] = make_float4(sx / fn, sy / fn, sz / fn, 0.f);
   }
 }
-__global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
+// G2_GW lanes per voxel.  Sixteen until round 5; the kernel's time is rounds of waves × the chain of dependent loads of an iteration (centroid + key → directory + bits → point
+// ranges → candidates → marks), not arithmetic — the same sums in fp32 instead of fp64 changed nothing before the compiler's register count moved — so what counts is how many
+// voxels a resident wave carries: 16 / 8 / 4 / 2 / 1 lanes per voxel → 38.2 / 40.9 / 42.1 / 42.5 / 41.6 k frame-pairs/s (interleaved; alone 491 / 340 / 303 / 329 µs).  A lane
+// takes rows sub, sub + G2_GW, … of the nine and four candidates per round trip.  (Five waves per SIMD asked of the compiler: at 105 registers — four waves — the pipeline lost 2 %.)
+#define G2_GW 4
+__global__ __launch_bounds__(MOR_BT, 5) void k_g2_cov(MorDev d) {
   int s, bxv; map_block(d.B, G2_COV_G, s, bxv);   // (a stream's workgroups on one XCD, as everywhere else: as a two-dimensional launch a stream's voxels went round all eight L2s)
   const int V = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
-  const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15, lane = lane_id();   // group in the workgroup, lane in the group
+  const int grp = threadIdx.x / G2_GW, sub = threadIdx.x % G2_GW, lane = lane_id(), lane0 = lane & ~(G2_GW - 1);   // group in the workgroup, lane in the group
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
   const int zbase = d.zbase[s]; const MorGrid G = stream_grid(d, s);   // (the lattice with the stream's own z layers)
   const unsigned long long *bits = d.g2_bits ? d.g2_bits + (size_t)s * d.g.nrows * (size_t)(d.g2_nch * 8) : nullptr;   // occupancy bits of the lattice (none: the key search)
   const int *dir = d.g2_dir + (size_t)s * d.g.nrows * (size_t)(d.g2_nch * 8);
   const int pred = d.g2_used[s], tag_spec = 2 * d.frame_no + 1;   // the mode bin this frame's kernels bet on (pass A's snapshot of the latest known one), and the tag of the marks made on that bet
-  for (int v0 = bxv * (MOR_BT / 16); v0 < V; v0 += G2_COV_G * (MOR_BT / 16)) {
+  for (int v0 = bxv * (MOR_BT / G2_GW); v0 < V; v0 += G2_COV_G * (MOR_BT / G2_GW)) {
     const int v = v0 + grp; const bool act = v < V;
     // ---- the voxel's centroid (k_g2_cent) and its key, one load each; the nine (y,z) rows of the 3×3×3 block start from the KEY's cell at once — lanes 0 … 8 of the group,
     //      each row's three x-cells are one range of `sorted` — and are looked up again from the centroid's cell in the rare case that the fp32 centroid rounds into a neighbour
@@ -278,43 +287,49 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
       int qx, qy, qz; bool cl; grid_cell(G, q, 0.f, zbase, qx, qy, qz, cl);
       if (qx != cx || qy != cy || qz != cz) { cx = qx; cy = qy; cz = qz; }   // (the block is the one around the CENTROID's cell, :125)
     }
-    int rb0 = 0, rlen = 0;
-    if (act && sub < 9) {
-      const int y = cy + sub % 3 - 1, z = cz + sub / 3 - 1;
-      if ((unsigned)y < (unsigned)G.ny && (unsigned)z < (unsigned)G.nz) {
-        int lo, hi;
-        if (bits) row_cells_bits(bits, dir, d.g2_nch * 8, grid_row(G, y, z), max(cx - 1, 0), min(cx + 1, G.nx - 1), lo, hi);
-        else row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
-        if (lo < hi) { rb0 = st[lo]; rlen = st[hi] - rb0; }
+    constexpr int RPL = (9 + G2_GW - 1) / G2_GW;   // rows per lane (lane `sub` takes rows sub, sub + G2_GW)
+    int rb0[RPL], rlen[RPL];
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) {
+      rb0[j] = 0; rlen[j] = 0;
+      const int row = sub + j * G2_GW;
+      if (act && row < 9) {
+        const int y = cy + row % 3 - 1, z = cz + row / 3 - 1;
+        if ((unsigned)y < (unsigned)G.ny && (unsigned)z < (unsigned)G.nz) {
+          int lo, hi;
+          if (bits) row_cells_bits(bits, dir, d.g2_nch * 8, grid_row(G, y, z), max(cx - 1, 0), min(cx + 1, G.nx - 1), lo, hi);
+          else row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
+          if (lo < hi) { rb0[j] = st[lo]; rlen[j] = st[hi] - rb0[j]; }
+        }
       }
     }
     int rb[9], rp[10]; rp[0] = 0;
 #pragma unroll
-    for (int r = 0; r < 9; ++r) { rb[r] = __shfl(rb0, (lane & 48) + r, 64); rp[r + 1] = rp[r] + __shfl(rlen, (lane & 48) + r, 64); }
+    for (int r = 0; r < 9; ++r) { rb[r] = __shfl(rb0[r / G2_GW], lane0 + r % G2_GW, 64); rp[r + 1] = rp[r] + __shfl(rlen[r / G2_GW], lane0 + r % G2_GW, 64); }
     // ---- walk: candidates sixteen at a time, four per lane and round trip; the hits go into the screen's sums
     const bool wide = rp[9] > G2_NARROW_CAND;   // (uniform in the group)
     const int ncand = wide ? 0 : rp[9];
     int wave_max = ncand;
 #pragma unroll
-    for (int o = 16; o < 64; o <<= 1) wave_max = max(wave_max, __shfl_xor(wave_max, o, 64));
+    for (int o = G2_GW; o < 64; o <<= 1) wave_max = max(wave_max, __shfl_xor(wave_max, o, 64));
     G2Acc A; g2_acc_zero(A);
-    for (int c0 = 0; c0 < wave_max; c0 += 64) {
+    for (int c0 = 0; c0 < wave_max; c0 += 4 * G2_GW) {
       float4 pc[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int c = c0 + 16 * u + sub; int k = 0;
+        const int c = c0 + G2_GW * u + sub; int k = 0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) if (c >= rp[r] && c < rp[r + 1]) k = rb[r] + (c - rp[r]);
         pc[u] = sp[c < ncand ? k : 0];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int c = c0 + 16 * u + sub; const float4 p = pc[u];
+        const int c = c0 + G2_GW * u + sub; const float4 p = pc[u];
         const float dd = sqdist(q.x, q.y, q.z, p.x, p.y, p.z);
         if (c < ncand && dd < d.leaf_r2) g2_acc_add(A, q, p, dd);
       }
     }
-    g2_acc_reduce<16>(A);
+    g2_acc_reduce<G2_GW>(A);
     int spec = 0;
     if (act && sub == 0) {
       const int verdict = wide ? -2 : A.n > 3 ? (d.g2_exact_only ? -1 : g2_screen(A, q, d.g2_r, d.g2_inv_r)) : 0;
@@ -323,23 +338,23 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov(MorDev d) {
       spec = verdict == 1 && (int)(q.z * 10) == pred;
     }
     // ---- speculative marks (see k_g2_mode): an accepted voxel of the PREDICTED mode bin marks its neighbours at once, while its candidate ranges are at hand
-    spec = __shfl(spec, lane & 48, 64);
+    spec = __shfl(spec, lane0, 64);
     const int nmark = spec ? ncand : 0;
     int mark_max = nmark;
 #pragma unroll
-    for (int o = 16; o < 64; o <<= 1) mark_max = max(mark_max, __shfl_xor(mark_max, o, 64));
-    for (int c0 = 0; c0 < mark_max; c0 += 64) {
+    for (int o = G2_GW; o < 64; o <<= 1) mark_max = max(mark_max, __shfl_xor(mark_max, o, 64));
+    for (int c0 = 0; c0 < mark_max; c0 += 4 * G2_GW) {
       float4 pc[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int c = c0 + 16 * u + sub; int k = 0;
+        const int c = c0 + G2_GW * u + sub; int k = 0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) if (c >= rp[r] && c < rp[r + 1]) k = rb[r] + (c - rp[r]);
         pc[u] = sp[c < nmark ? k : 0];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int c = c0 + 16 * u + sub; const float4 p = pc[u];
+        const int c = c0 + G2_GW * u + sub; const float4 p = pc[u];
         if (c < nmark && sqdist(q.x, q.y, q.z, p.x, p.y, p.z) < d.leaf_r2) d.is_ground[so + __float_as_int(p.w)] = tag_spec;
       }
     }
