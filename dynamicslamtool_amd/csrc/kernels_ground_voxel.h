@@ -221,7 +221,8 @@ __device__ __forceinline__ int g2_screen(const G2Acc &A, const float4 &q, double
 // (196 µs alone, 38 with every voxel cut to 64 points: a few streams hold a voxel of 1 400 – 3 000 points — something right at the sensor —, one stream 215 voxels of 47 000
 //  points.  Tried: the wave of the voxel's thread taking its big voxels one after the other, 64 points per coalesced load — they share a wave, 560 µs; a queue of the voxels over
 //  64 points and a second launch with a wave each, sums by broadcast reads from LDS — 37 + 61 µs alone and NOTHING in the pipeline (35.10 against 35.06 k frame-pairs/s,
-//  interleaved): a tail on a few CUs is not what the other lanes' kernels wait for.)
+//  interleaved): a tail on a few CUs is not what the other lanes' kernels wait for; a wave per 64 voxels, their points — one range of `sorted` — staged 512 at a time through
+//  LDS, every lane adding up its own voxel's part of the chunk: 214 µs alone and nothing either, 43.55 against 43.55 k.)
 __global__ __launch_bounds__(MOR_BT) void k_g2_cent(MorDev d) {
   int s, bx; map_block(d.B, G2_CENT_G, s, bx);
   const int V = d.info[s].n_occ;
