@@ -283,8 +283,8 @@ __device__ __forceinline__ void row_cells(const MorGrid &g, const int *ckey, con
 }
 // The same from the occupancy bits of the VoxelGrid lattice (voxel ground variant, round 5): bits[row][x], a row padded to chunks of 512 cells = eight words = one 64-byte line,
 // and beside every word the compact id of the first cell at or behind its bit 0 (dir, written by k_g2_cent from the row table and the bits): the directory entry, the word of x0
-// and its successor — THREE independent loads and two popcounts where the key search is a chain of four round trips and three dozen loads per row.  k_heads_scatter sets the
-// bits, k_g2_mark clears them.  (First form: row table + the row's whole line, the cells in front of x0 counted from its eight words — a hundred ALU instructions per row.)
+// and its successor — THREE independent loads and two popcounts where the key search is a chain of four round trips and three dozen loads per row.  k_g2_cent writes both, whole rows
+// at a time (first form: an atomic OR per voxel in k_heads_scatter — 35 µs of that kernel — and a clearing pass in k_g2_mark).  (First form: row table + the row's whole line, the cells in front of x0 counted from its eight words — a hundred ALU instructions per row.)
 __device__ __forceinline__ void row_cells_bits(const unsigned long long *bits, const int *dir, int nw /* words per row */, int r, int x0, int x1, int &lo, int &hi) {
   const int w0 = x0 >> 6, sh = x0 & 63;
   const size_t o = (size_t)r * nw + w0;

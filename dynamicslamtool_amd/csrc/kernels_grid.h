@@ -119,7 +119,6 @@ __global__ __launch_bounds__(MOR_BT) void k_heads_scatter(MorDev d) {
         if (head) {
           const int kc = skey[p];
           d.ckey[so + c] = kc; cstart[c] = p;
-          if (d.g2_bits) { const int r0 = kc / G.nx, x = kc - r0 * G.nx; atomicOr(&d.g2_bits[((size_t)s * d.g.nrows + r0) * (size_t)(d.g2_nch * 8) + (x >> 6)], 1ull << (x & 63)); }   // the lattice's occupancy bits (row_cells_bits)
           // dense (y,z) row table: rs[r] = first cell with key ≥ r·nx.  The head of cell c owns the rows after its
           // predecessor's row up to its own (keys ascend), so the table is written without any search
           const int rc = kc / G.nx, rp = p > 0 ? skey[p - 1] / G.nx : -1;

@@ -229,20 +229,37 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cent(MorDev d) {
   const size_t so = (size_t)s * d.Nmax;
   const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
-  if (d.g2_bits) {   // the directory of the lattice's occupancy bits (row_cells_bits): a thread per (y,z) row of the stream's own layers — row table + the row's bits → first cell of every word
-    const int nrows = V > 0 ? stream_grid(d, s).nrows : 0, nch = d.g2_nch;
-    const int *rs = d.row_start + (size_t)s * (d.g.nrows + 1);
+  if (d.g2_bits) {   // the lattice's occupancy bits and their directory (row_cells_bits): a thread per (y,z) row of the stream's own layers — the row's cells from the row table, their
+    // x from the sorted keys, eight at a time → the row's words, written whole (empty rows and words too: nothing to clear, no atomics) → first cell of every word
+    const MorGrid G = stream_grid(d, s);
+    const int nrows = V > 0 ? G.nrows : 0, nch = d.g2_nch;
+    const int *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *ckey = d.ckey + so;
     const size_t bo = (size_t)s * d.g.nrows * (size_t)(nch * 8);
     for (int r = bx * MOR_BT + threadIdx.x; r < nrows; r += G2_CENT_G * MOR_BT) {
-      int c = rs[r];
-      for (int k = 0; k < nch; ++k) {
-        const ulonglong2 *w = reinterpret_cast<const ulonglong2 *>(d.g2_bits + bo + ((size_t)r * nch + k) * 8);
-        ulonglong2 q[4];
+      const int c0 = rs[r], c1 = rs[r + 1], kb = r * G.nx;
+      int c = c0;
+      for (int k = 0; k < nch; ++k) {   // (one chunk up to 512 cells in x)
+        unsigned long long w[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) q[i] = w[i];
+        for (int i = 0; i < 8; ++i) w[i] = 0ull;
+        for (int cc = c0; cc < c1; cc += 8) {   // (every chunk looks at all the row's cells: a second chunk is rare)
+          int kv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) kv[i] = ckey[min(cc + i, c1 - 1)];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int x = kv[i] - kb - 512 * k;
+            const unsigned long long bit = (cc + i < c1 && (unsigned)x < 512u) ? 1ull << (x & 63) : 0ull;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] |= (x >> 6) == j ? bit : 0ull;
+          }
+        }
+        ulonglong2 *wo = reinterpret_cast<ulonglong2 *>(d.g2_bits + bo + ((size_t)r * nch + k) * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wo[i] = make_ulonglong2(w[2 * i], w[2 * i + 1]);
         int o[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { o[i] = c; c += __popcll((i & 1) ? q[i >> 1].y : q[i >> 1].x); }
+        for (int i = 0; i < 8; ++i) { o[i] = c; c += __popcll(w[i]); }
         int4 *dd = reinterpret_cast<int4 *>(d.g2_dir + bo + ((size_t)r * nch + k) * 8);
         dd[0] = make_int4(o[0], o[1], o[2], o[3]); dd[1] = make_int4(o[4], o[5], o[6], o[7]);
       }
@@ -544,10 +561,6 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mark(MorDev d) {
   int s, bxm; map_block(d.B, 128, s, bxm);
   const int V = d.info[s].n_occ, mode = d.mode_bin[s];
   const size_t so = (size_t)s * d.Nmax;
-  if (d.g2_bits) {   // the lattice's occupancy bits go back to zero for the copy's next frame, word by word through the voxels that set them (this kernel's own lookups search the keys)
-    unsigned long long *bits = d.g2_bits + (size_t)s * d.g.nrows * (size_t)(d.g2_nch * 8);
-    for (int v = bxm * MOR_BT + threadIdx.x; v < V; v += 128 * MOR_BT) { const int kc = d.ckey[so + v], r0 = kc / d.g.nx, x = kc - r0 * d.g.nx; bits[(size_t)r0 * (d.g2_nch * 8) + (x >> 6)] = 0ull; }
-  }
   if (mode == 0x7fffffff || d.g2_tag[s] == 2 * d.frame_no + 1) return;   // (no accepted voxel at all; or the bet on the mode bin held: the marks are there already)
   const int lane = lane_id(), nw = 128 * (MOR_BT / 64), grp = lane >> 4, sub = lane & 15;
   const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);

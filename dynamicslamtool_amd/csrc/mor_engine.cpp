@@ -458,7 +458,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
       o.skey = o.rkeys[d.voxel_passes & 1]; o.sidx = o.rvals[d.voxel_passes & 1];
       {   // occupancy bits of the lattice: 64 + 32 bytes per (y,z) row and 512 cells in x — 990 MB per frame in flight at B = 64, ±50 m, 0.2-m leaves, of which a frame touches the rows of its own z layers (25 MB)
         const size_t words = (size_t)B * (size_t)d.gv.nrows * (size_t)d.g2_nch * 8;
-        if (!getenv("MOR_G2_NOBITS") && words * 12 <= ((size_t)2 << 30)) ok = ok && dalloc(b, o.g2_bits, words) && hipMemset(o.g2_bits, 0, words * 8) == hipSuccess && dalloc(b, o.g2_dir, words);
+        if (!getenv("MOR_G2_NOBITS") && words * 12 <= ((size_t)2 << 30)) ok = ok && dalloc(b, o.g2_bits, words) && dalloc(b, o.g2_dir, words);   // (k_g2_cent writes every row of the stream's layers, every frame: no clearing)
       }
     }
     if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d, max_points=%llu, copy %d of %d)", d.B, (unsigned long long)max_points, c + 1, (int)b->pipe_depth));
