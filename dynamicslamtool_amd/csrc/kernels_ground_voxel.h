@@ -8,19 +8,31 @@
 #define G2_CAP 16384    // neighbours of one voxel centroid held in LDS as (d², index) keys (128 KiB of the CU's 160): big-voxel kernel
 #define G2_SMALL 512    // … in the one-wave-per-voxel kernel (4 KiB: many workgroups per CU)
 #define G2_CHUNK 1024   // coordinates staged per step of the ordered fp32 sums
-// all trimmed points with d² < leaf² around q (radiusSearch, :125), appended to the LDS list in arbitrary order;
-// the count keeps running beyond `cap` so the caller sees the overflow
-__device__ __forceinline__ void g2_gather(const MorDev &d, int s, float4 q, unsigned long long *key, int *cnt, int cap) {
+// the nine (y,z) rows of the 3×3×3 voxel block around q, row `row` of them: the points of its three x-cells are positions [b0, b0 + len) of `sorted` (occupancy bits + directory
+// of the lattice, or — lattices too large for them, MOR_G2_NOBITS — a search of the sorted keys)
+__device__ __forceinline__ void g2_row_range(const MorDev &d, int s, const MorGrid &G, int cx, int cy, int cz, int row, int &b0, int &len) {
+  b0 = 0; len = 0;
+  const int y = cy + row % 3 - 1, z = cz + row / 3 - 1;
+  if ((unsigned)y >= (unsigned)G.ny || (unsigned)z >= (unsigned)G.nz) return;
   const size_t so = (size_t)s * d.Nmax;
-  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  const int *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  int lo, hi;
+  if (d.g2_bits) { const size_t bo = (size_t)s * d.g.nrows * (size_t)(d.g2_nch * 8); row_cells_bits(d.g2_bits + bo, d.g2_dir + bo, d.g2_nch * 8, grid_row(G, y, z), max(cx - 1, 0), min(cx + 1, G.nx - 1), lo, hi); }
+  else row_cells(G, d.ckey + so, d.row_start + (size_t)s * (d.g.nrows + 1), max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
+  if (lo < hi) { b0 = st[lo]; len = st[hi] - b0; }
+}
+// all trimmed points with d² < leaf² around q (radiusSearch, :125), appended to the LDS list in arbitrary order; the count keeps running beyond `cap` so the caller sees the
+// overflow.  Threads 0 … 8 resolve the nine rows side by side (one after the other they were a chain of forty round trips in front of every voxel of the big tier), then the
+// whole workgroup walks them.  l_rng: 18 ints of LDS.
+__device__ __forceinline__ void g2_gather(const MorDev &d, int s, float4 q, unsigned long long *key, int *cnt, int cap, int *l_rng) {
+  const size_t so = (size_t)s * d.Nmax;
   const MorGrid G = stream_grid(d, s);   // the lattice with the stream's own z layers
   int cx, cy, cz; bool cl; grid_cell(G, q, 0.f, d.zbase[s], cx, cy, cz, cl);
-  for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
-    const int y = cy + dy, z = cz + dz;
-    if ((unsigned)y >= (unsigned)G.ny || (unsigned)z >= (unsigned)G.nz) continue;
-    int lo, hi; row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
-    if (lo >= hi) continue;
-    for (int k = st[lo] + threadIdx.x, e = st[hi]; k < e; k += blockDim.x) {
+  if (threadIdx.x < 9) { int b0, len; g2_row_range(d, s, G, cx, cy, cz, threadIdx.x, b0, len); l_rng[2 * threadIdx.x] = b0; l_rng[2 * threadIdx.x + 1] = len; }
+  __syncthreads();
+  for (int r = 0; r < 9; ++r) {
+    const int b0 = l_rng[2 * r], len = l_rng[2 * r + 1];
+    for (int k = b0 + threadIdx.x, e = b0 + len; k < e; k += blockDim.x) {
       const float4 p = d.sorted[so + k];
       const float dd = sqdist(q.x, q.y, q.z, p.x, p.y, p.z);
       if (dd < d.leaf_r2) {
@@ -35,18 +47,11 @@ __device__ __forceinline__ void g2_gather(const MorDev &d, int s, float4 q, unsi
 // a time.  f(k, point) is called for every candidate within the radius.
 template <class F> __device__ __forceinline__ void g2_for_neighbours(const MorDev &d, int s, const float4 &q, F f) {
   const size_t so = (size_t)s * d.Nmax;
-  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const int lane = threadIdx.x & 63;
   const MorGrid G = stream_grid(d, s);
   int cx, cy, cz; bool cl; grid_cell(G, q, 0.f, d.zbase[s], cx, cy, cz, cl);
   int b0 = 0, len = 0;
-  if (lane < 9) {
-    const int y = cy + lane % 3 - 1, z = cz + lane / 3 - 1;
-    if ((unsigned)y < (unsigned)G.ny && (unsigned)z < (unsigned)G.nz) {
-      int lo, hi; row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
-      if (lo < hi) { b0 = st[lo]; len = st[hi] - b0; }
-    }
-  }
+  if (lane < 9) g2_row_range(d, s, G, cx, cy, cz, lane, b0, len);
   int rb[9], rp[10]; rp[0] = 0;
 #pragma unroll
   for (int r = 0; r < 9; ++r) { rb[r] = __shfl(b0, r, 64); rp[r + 1] = rp[r] + __shfl(len, r, 64); }
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(G2_BIG_T) void k_g2_cov_big(MorDev d) {
   const size_t so = (size_t)s * d.Nmax;
   __shared__ unsigned long long key[G2_CAP];
   __shared__ float px[G2_CHUNK], py[G2_CHUNK], pz[G2_CHUNK];
-  __shared__ int cnt;
+  __shared__ int cnt, l_rng[18];
   __shared__ float acc[6];
   for (int w = bxq; w < nbig; w += gq) {
     const int v = d.g2_big[so + w];
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(G2_BIG_T) void k_g2_cov_big(MorDev d) {
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     const float4 q = d.vcent[so + v];
-    g2_gather(d, s, q, key, &cnt, G2_CAP);
+    g2_gather(d, s, q, key, &cnt, G2_CAP, l_rng);
     __syncthreads();
     const int n = cnt;
     int bin = 0x7fffffff;
