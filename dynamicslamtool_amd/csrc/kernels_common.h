@@ -150,7 +150,7 @@ __device__ __forceinline__ bool stream_last_block(int *ticket, int n_blocks, int
   __syncthreads();
   return *l_flag != 0;
 }
-enum { TK_TRACK = 0, TK_CGFINAL = 1, TK_PAIRS = 2, TK_SPLIT = 3, TK_OUT = 4, TK_SLABCNT = 5, TK_MOVERS = 6, TK_COUNT = 8 };   // ticket words per stream
+enum { TK_TRACK = 0, TK_CGFINAL = 1, TK_PAIRS = 2, TK_SPLIT = 3, TK_OUT = 4, TK_SLABCNT = 5, TK_MOVERS = 6, TK_RADIX = 7, TK_COUNT = 8 };   // ticket words per stream
 
 // fromPCLPointCloud2 (:523): named float32 fields of a blob record → (x,y,z,intensity)
 __device__ __forceinline__ float ld_f32_bytes(const char *p) {   // a float32 field at any byte address

@@ -15,10 +15,13 @@ __device__ __forceinline__ int radix_count(const MorDev &d, const MorRadix &j, i
   return j.count_sel == 0 ? d.info[s].M : d.info[s].C;
 }
 
+// With j.fuse the stream's LAST workgroup to arrive (stream_last_block) turns the stream's raw per-tile histograms into offsets in place — offsets[tile][digit] = Σ smaller digits +
+// Σ earlier tiles, one thread per digit — so that k_rscatter reads ONE word per thread and tile.  (Rounds 2 – 5 had every workgroup of k_rscatter re-derive its offsets from the raw
+// histograms of all the stream's tiles: 59 loads per thread and tile, 226 MB of L2 reads per pass for 112 MB of keys and values — the scatter's price in the pipeline, 50 µs per pass.)
 __global__ __launch_bounds__(MOR_BT) void k_rhist(MorDev d, MorRadix j) {
   int s, t0; map_block(d.B, d.tiles_m, s, t0);
   const int count = radix_count(d, j, s);
-  __shared__ int h[256];
+  __shared__ int h[256], sh[8], l_last;
   const size_t so = (size_t)s * d.Nmax;
   for (int t = t0; t * MOR_TILE < count; t += d.tiles_m) {
     const int base = t * MOR_TILE;
@@ -29,8 +32,24 @@ __global__ __launch_bounds__(MOR_BT) void k_rhist(MorDev d, MorRadix j) {
       if (valid) atomicAdd(&h[(key >> j.shift) & 255], 1);
     }
     __syncthreads();
-    j.hist[((size_t)s * d.tiles_max + t) * 256 + threadIdx.x] = h[threadIdx.x];
+    st_agent(&j.hist[((size_t)s * d.tiles_max + t) * 256 + threadIdx.x], h[threadIdx.x]);   // (agent scope: the scan below may run in a workgroup on another XCD)
+    __syncthreads();
   }
+  if (!j.fuse || count == 0) return;
+  if (!stream_last_block(d.tickets + (size_t)s * TK_COUNT + TK_RADIX, d.tiles_m, &l_last)) return;
+  int *hh = j.hist + (size_t)s * d.tiles_max * 256 + threadIdx.x;
+  const int nt = (count + MOR_TILE - 1) / MOR_TILE;
+  int run = 0, t = 0;
+  for (; t + 8 <= nt; t += 8) {   // eight independent loads per step
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ld_agent(&hh[(t + u) * 256]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { hh[(t + u) * 256] = run; run += v[u]; }
+  }
+  for (; t < nt; ++t) { const int v = ld_agent(&hh[t * 256]); hh[t * 256] = run; run += v; }
+  int tot; const int base = block_excl_scan(run, sh, &tot);
+  for (t = 0; t < nt; ++t) hh[t * 256] += base;
 }
 // one workgroup per stream, one thread per digit: offsets[tile][digit] = Σ smaller digits + Σ earlier tiles
 __global__ __launch_bounds__(MOR_BT) void k_rscan(MorDev d, MorRadix j) {
@@ -51,7 +70,7 @@ __global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, MorRadix j) {
   const int count = radix_count(d, j, s);
   const size_t so = (size_t)s * d.Nmax;
   const bool inverse = j.inverse && (!j.vox || (j.shift >> 3) == voxel_passes_of(d, s) - 1);   // the stream's LAST pass leaves the inverse permutation
-  __shared__ int wcnt[4][256]; __shared__ int shs[8];
+  __shared__ int wcnt[4][256];
   for (int t = t0; t * MOR_TILE < count; t += d.tiles_m) {
     const int tb = t * MOR_TILE;
     for (int k = threadIdx.x; k < 4 * 256; k += MOR_BT) (&wcnt[0][0])[k] = 0;
@@ -77,16 +96,7 @@ __global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, MorRadix j) {
     __syncthreads();
     {  // exclusive prefix over the 4 waves per digit + global offset of (tile, digit)
       int dg = threadIdx.x, run;
-      if (j.fuse) {   // raw per-tile histograms: Σ smaller digits (all tiles) + Σ earlier tiles (this digit), re-derived per workgroup
-        const int *hh = j.hist + (size_t)s * d.tiles_max * 256 + dg; const int nt = (count + MOR_TILE - 1) / MOR_TILE;
-        int before = 0, all = 0, u = 0;
-        for (; u + 4 <= nt; u += 4) {
-          const int v0 = hh[u * 256], v1 = hh[(u + 1) * 256], v2 = hh[(u + 2) * 256], v3 = hh[(u + 3) * 256];
-          all += v0 + v1 + v2 + v3; before += (u < t ? v0 : 0) + (u + 1 < t ? v1 : 0) + (u + 2 < t ? v2 : 0) + (u + 3 < t ? v3 : 0);
-        }
-        for (; u < nt; ++u) { const int v = hh[u * 256]; all += v; before += u < t ? v : 0; }
-        int tot; run = block_excl_scan(all, shs, &tot) + before;
-      } else run = j.hist[((size_t)s * d.tiles_max + t) * 256 + dg];
+      run = j.hist[((size_t)s * d.tiles_max + t) * 256 + dg];   // (k_rscan, or the tail of k_rhist)
 #pragma unroll
       for (int w = 0; w < 4; ++w) { int v = wcnt[w][dg]; wcnt[w][dg] = run; run += v; }
     }

@@ -38,7 +38,7 @@ struct MorRadix {
   int *vout2;             // optional second copy of the values (pass 0 of the cluster partition also writes cl_idx)
   int *hist;              // [B][tiles_max][256] histogram / offset scratch of this sort
   int skip_k_le;          // > 0: streams with K ≤ this need no further pass — the kernel returns at once for them
-  int fuse;               // k_rscatter derives the offsets from the raw histograms itself (no k_rscan launch; ≤ 64 tiles)
+  int fuse;               // the stream's last workgroup of k_rhist scans the histograms (no k_rscan launch)
   int vox;                // keys are voxel keys of the voxel ground variant: a stream takes part in the passes its own key width needs (voxel_passes_of)
   int inverse;            // last pass: vout[value] = position (the inverse permutation) instead of vout[position] = value — the points are then MOVED to their places
                           // by coalesced reads and fire-and-forget writes (k_heads_scatter) instead of gathered by 7 M dependent random 16-byte reads per step

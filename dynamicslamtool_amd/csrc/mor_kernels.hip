@@ -81,7 +81,7 @@ grid:
     MOR_LAUNCH_T(MK_GRIDPLACE, k_gridplace, dim3(d.B * d.gc_P), GC_T, d);
   } else {
     for (int pass = 0; pass < d.cell_passes; ++pass) {   // points sorted by cell key; result in (skey, sidx) = buffers [cell_passes & 1]
-      MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0, d.tiles_m <= 64, 1, 1};   // (a stream's last pass — by its own key width — leaves the inverse permutation: k_heads_scatter moves the points)
+      MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0, 1, 1, 1};   // (a stream's last pass — by its own key width — leaves the inverse permutation: k_heads_scatter moves the points)
       MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
       if (!j.fuse) MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
       MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
