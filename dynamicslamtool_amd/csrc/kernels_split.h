@@ -23,7 +23,7 @@ __global__ __launch_bounds__(MOR_BT) void k_classify(MorDev d) {
   if (d.gmode == 1) {   // z extent of the trimmed cloud: the voxel variant does not crop in z
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { zlo = fminf(zlo, __shfl_xor(zlo, o, 64)); zhi = fmaxf(zhi, __shfl_xor(zhi, o, 64)); }
-    if (lane_id() == 0 && zlo <= zhi) { atomicMin(&d.zmin_i[s], float_ordered(zlo)); atomicMax(&d.zmax_i[s], float_ordered(zhi)); }
+    if (lane_id() == 0 && zlo <= zhi) { atomicMin(&d.zmin_i[MOR_ZR * s], float_ordered(zlo)); atomicMax(&d.zmax_i[MOR_ZR * s], float_ordered(zhi)); }   // (a stream's word on a cache line of its own: 30 000 atomics per step on the FOUR lines of the dense arrays went through the L2 one after the other — 96 of the kernel's 129 µs)
   }
   if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
   __syncthreads();
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(MOR_BT) void k_classify(MorDev d) {
 // number.  The lattice is laid out for 64 m of z, a sweep spans a few metres: with the stream's own layer count the voxel keys are 23 instead of 27 bits (three
 // radix passes instead of four) and the (y,z) row table 12 000 instead of 161 000 rows.  From the ordered-int z range k_classify leaves (final at the kernel boundary).
 __device__ __forceinline__ int voxel_layers(const MorDev &d, int s) {
-  const int zl = d.zmin_i[s], zh = d.zmax_i[s];
+  const int zl = d.zmin_i[MOR_ZR * s], zh = d.zmax_i[MOR_ZR * s];
   if (zl > zh) return 1;   // no trimmed point
   const int l = (int)floorf(ordered_float(zh) * d.g.inv_cs) - (int)floorf(ordered_float(zl) * d.g.inv_cs) + 1;
   return max(1, min(d.g.nz, l));
@@ -56,12 +56,12 @@ __device__ __forceinline__ int voxel_passes_of(const MorDev &d, int s) {
 __device__ __forceinline__ void publish_split(const MorDev &d, int s, int n_ng, int n_g) {
   MorFrameInfo &f = d.info[s];
   f.M = n_ng; f.G = n_g; f.T = n_ng + n_g;
-  if (d.gmode == 2) { d.zmin_i[s] = 0x7fffffff; d.zmax_i[s] = (int)0x80000000; }   // pass B ends the frame's use of the z range: ready for the next frame on this copy (no memset launches)
+  if (d.gmode == 2) { d.zmin_i[MOR_ZR * s] = 0x7fffffff; d.zmax_i[MOR_ZR * s] = (int)0x80000000; }   // pass B ends the frame's use of the z range: ready for the next frame on this copy (no memset launches)
   if (d.gmode == 1) {   // grids of the voxel variant hang on the lowest trimmed point
-    float zmin = f.T ? ordered_float(d.zmin_i[s]) : 0.f;
+    float zmin = f.T ? ordered_float(d.zmin_i[MOR_ZR * s]) : 0.f;
     d.zorg[s] = zmin; d.zbase[s] = (int)floorf(zmin * d.gv.inv_cs);
     if (d.gnz_out) {   // z layers of the clustering grid this stream needs (stream_grid)
-      const float zmax = f.T ? ordered_float(d.zmax_i[s]) : 0.f;
+      const float zmax = f.T ? ordered_float(d.zmax_i[MOR_ZR * s]) : 0.f;
       d.gnz_out[s] = max(1, min(d.cg_nz, (int)floorf((zmax - zmin) * d.cg_inv_cs) + 2));
     }
     if (d.vnz_out) { d.vnz_out[s] = voxel_layers(d, s); d.g2_used[s] = ld_agent(&d.g2_pred[s]); }   // … and the bet on the mode bin this frame's kernels mark by: ONE snapshot per frame (later frames' k_g2_mode update g2_pred while this frame's kernels run)   // layers of the VoxelGrid lattice (the later kernels of pass A read it through stream_grid)
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
     const int *tc = d.tile_cnt + (size_t)s * d.tiles_max * 2; int tot_ng, tot_g;
     wg_prefix_total(tc, 2, t, d.tiles, sh, r_ng, tot_ng);
     wg_prefix_total(tc + 1, 2, t, d.tiles, sh, r_g, tot_g);
-    if (d.gmode == 1) { zorg = (tot_ng + tot_g) ? ordered_float(d.zmin_i[s]) : 0.f; zbase = (int)floorf(zorg * d.gv.inv_cs); }
+    if (d.gmode == 1) { zorg = (tot_ng + tot_g) ? ordered_float(d.zmin_i[MOR_ZR * s]) : 0.f; zbase = (int)floorf(zorg * d.gv.inv_cs); }
     if (t == 0 && threadIdx.x == 0) publish_split(d, s, tot_ng, tot_g);
   }
   if ((uint32_t)t * MOR_TILE >= n_in) break;

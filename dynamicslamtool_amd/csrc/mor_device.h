@@ -61,6 +61,7 @@ struct MorFrameInfo {        // per stream, produced on device
 // host round trip in between.  Mirrors csrc/mor_tracker.cpp (the host version behind the mor_tracker_* C ABI).
 #define MOR_MAX_DEPTH 8     // frames in flight in the stage pipeline, at most (one copy of every per-frame array each)
 #define MOR_MAX_SLOTS 10     // cluster-array slots (depth + 1 are in use)
+#define MOR_ZR 32            // ints between the z-range words of two streams: a 128-byte line each — every wave of k_classify hits them with atomics, and on dense [B] arrays 64 streams are two lines whose atomics go through the L2 one after the other.  (The same spacing for the worklist counters of the scoring tiers, the queue counter of the voxel tiers and the tile tickets — returning atomics of every wave / tile — measured nothing: 219.2 against 218.3 k, 44.1 against 44.5 k.)
 #define MOR_MAXP 32        // slabs per stream of the cell graph (k_cg_slab), at most
 #define MOR_CGS_FCAP 9400  // cells per stream the fused merge at the tail of k_cg_slab holds in LDS (beyond: its global-memory path; the host then prefers the separate k_cg_final)
 #define MOR_GC_CHUNK 2048   // points per chunk of the grid build (k_gridcount / k_gridplace)
@@ -131,7 +132,7 @@ struct MorDev {
   float4 *vcent; int *vbin;  // [B][Nmax]  voxel centroids (dsc, :113) and bin id of accepted voxels
   int *g2_big, *g2_nbig;     // [B][Nmax], [B]  voxels with more neighbours than the one-wave kernel holds
   unsigned long long *g2_bits; int *g2_dir; int g2_nch;   // [B][gv.nrows][g2_nch·8]  occupancy bits of the VoxelGrid lattice, a row padded to g2_nch chunks of 512 cells, and the first cell of every word of them (row_cells_bits); null: the kernels search the keys (MOR_G2_NOBITS, or a lattice whose bits would not fit 2 GB per frame in flight)
-  int *zmin_i, *zmax_i;      // [B]  ordered-int min / max z of the trimmed cloud
+  int *zmin_i, *zmax_i;      // [B·MOR_ZR]  ordered-int min / max z of the trimmed cloud, stream s at s·MOR_ZR
   float *zorg; int *zbase;   // [B]  z origin of the clustering grid / z base of the voxel lattice
   int *mode_bin;             // [B]  dominant z-bin (:169-178)
   int *g2_pred, *g2_used, *g2_tag;   // [B] the latest mode bin any frame of the stream has reported (ONE array for all copies of the per-frame state); [B] this frame's snapshot of it — the bin its kernels mark speculatively; [B] the tag of this frame's ground marks (k_g2_mode)

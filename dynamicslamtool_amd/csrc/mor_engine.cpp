@@ -450,7 +450,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     ok = ok && dalloc(b, o.rs16, B * (size_t)d.rs16_stride) && dalloc(b, o.cx16, B * (size_t)d.cx16_stride);
     if (p->method_choice == 2) ok = ok && dalloc(b, o.vox, B * (size_t)d.Hcap) && dalloc(b, *reinterpret_cast<unsigned char **>(&o.vrec), B * 2 * K * 32);
     ok = ok && dalloc(b, o.moving, B * (K / 32 + 2)) && hipMemset(o.moving, 0, B * (K / 32 + 2) * sizeof(unsigned)) == hipSuccess && dalloc(b, o.out_desc, B * T) && hipMemset(o.out_desc, 0, B * T * sizeof(unsigned long long)) == hipSuccess && halloc(b, o.h_nout, B) && halloc(b, o.h_noff, B);   // (the size mirrors of the filtered clouds too: the output kernels of consecutive frames need no order among themselves)
-    ok = ok && dalloc(b, o.zmin_i, B) && dalloc(b, o.zmax_i, B) && hipMemsetD32((hipDeviceptr_t)o.zmin_i, 0x7fffffff, B) == hipSuccess && hipMemsetD32((hipDeviceptr_t)o.zmax_i, (int)0x80000000, B) == hipSuccess && dalloc(b, o.zorg, B) && dalloc(b, o.zbase, B) && hipMemset(o.zbase, 0, B * sizeof(int)) == hipSuccess && dalloc(b, o.mode_bin, B) && dalloc(b, o.g2_used, B) && dalloc(b, o.g2_tag, B) && hipMemset(o.g2_tag, 0, B * sizeof(int)) == hipSuccess && hipMemsetD32((hipDeviceptr_t)o.g2_used, 0x7fffffff, B) == hipSuccess;
+    ok = ok && dalloc(b, o.zmin_i, B * MOR_ZR) && dalloc(b, o.zmax_i, B * MOR_ZR) && hipMemsetD32((hipDeviceptr_t)o.zmin_i, 0x7fffffff, B * MOR_ZR) == hipSuccess && hipMemsetD32((hipDeviceptr_t)o.zmax_i, (int)0x80000000, B * MOR_ZR) == hipSuccess && dalloc(b, o.zorg, B) && dalloc(b, o.zbase, B) && hipMemset(o.zbase, 0, B * sizeof(int)) == hipSuccess && dalloc(b, o.mode_bin, B) && dalloc(b, o.g2_used, B) && dalloc(b, o.g2_tag, B) && hipMemset(o.g2_tag, 0, B * sizeof(int)) == hipSuccess && hipMemsetD32((hipDeviceptr_t)o.g2_used, 0x7fffffff, B) == hipSuccess;
     if (ok) ok = hipMemcpy(o.zorg, z0.data(), B * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     if (d.gmode == 1) {   // voxel-covariance ground variant: the VoxelGrid sort and the per-voxel results
       for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, o.rkeys[i], B * N) && dalloc(b, o.rvals[i], B * N);
