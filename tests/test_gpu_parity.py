@@ -178,6 +178,50 @@ def test_edge_cases():
     b.close()
 
 
+def test_edge_cases_voxel_ground():
+    """The degenerate inputs of test_edge_cases through the voxel-covariance ground variant (occupancy bits written row-wise by k_g2_cent, lookups by bits and directory): a single
+    point, nothing inside the trim box, NaNs, 300 identical points (one voxel), a ragged count, an empty cloud between two full ones — and a lattice three chunks wide
+    (trim_x = 150 m at 0.2-m leaves: 1 501 cells in x)."""
+    p = scene_params()
+    p.ground_method = 1
+    p.gp_leaf = 0.1
+    pose = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    rng = np.random.default_rng(5)
+    floor = np.column_stack([rng.uniform(-2, 2, (1500, 2)), rng.normal(-0.7, 0.003, 1500), np.zeros(1500)]).astype(np.float32)
+    cases = {
+        "single point": np.array([[0.1, 0.2, 0.3, 0.5]], np.float32),
+        "all outside trim": np.full((100, 4), 10.0, np.float32),
+        "a floor": floor,
+        "all nan": np.full((64, 4), np.nan, np.float32),
+        "identical points": np.tile(np.array([[0.5, 0.5, 0.5, 1.0]], np.float32), (300, 1)),
+        "ragged 2049": rng.uniform(-1, 1, (2049, 4)).astype(np.float32),
+    }
+    for name, pts in cases.items():
+        b, o = MorBatch(p, 1, 4096), Oracle(p)
+        for rep in range(2):
+            b.push([pts], pose[None, :])
+            o.push(pts, pose)
+            compare_frame(o, b, 0, name)
+            compare_output(o.filter(), b.filter()[0], name)
+        b.close()
+    # an empty cloud between two full ones (the bits and the directory of the frame before must not leak into the next)
+    b, o = MorBatch(p, 1, 4096), Oracle(p)
+    e = np.zeros((0, 4), np.float32)
+    for k, pts in enumerate([floor, e, cases["ragged 2049"], floor]):
+        b.push([pts], pose[None, :])
+        o.push(pts, pose)
+        compare_frame(o, b, 0, "sequence %d" % k)
+        compare_output(o.filter(), b.filter()[0], "sequence %d" % k)
+    b.close()
+    # three chunks of 512 cells per (y,z) row
+    q = kitti_params(1)
+    q.ground_method = 1
+    q.trim_x = 150.0
+    streams = [[synth.frame(1000 + s, "hdl64", f) for f in range(2)] for s in range(2)]
+    st = _run_lockstep(q, streams)
+    assert st["clusters"] > 0
+
+
 def test_errors_are_loud():
     p = scene_params()
     b = MorBatch(p, 1, 100)
