@@ -1,11 +1,12 @@
 """Long asynchronous run (device-resident clouds, no waits) against a synchronous run of the same length: every one of the last 64 frame
-summaries, the tracks and the output sizes must agree; the sticky error word must stay clear.  Usage: soak.py [steps]"""
+summaries, the tracks and the output sizes must agree; the sticky error word must stay clear.  Usage: soak.py [steps] [voxel]   (voxel: the voxel-covariance ground variant)"""
 import os, sys, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dynamicslamtool_amd import engine, kitti_params, synth
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 B, npts, nf = 64, 120000, 12
 p = kitti_params(1)
+if len(sys.argv) > 2 and sys.argv[2] == "voxel": p.ground_method = 1
 seeds = [2000 + s for s in range(B)]
 buf = engine.DeviceBuffer(nf * B * npts * 16); poses = np.empty((nf, B, 7))
 for f in range(nf):
