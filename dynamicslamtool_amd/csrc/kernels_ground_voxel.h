@@ -292,11 +292,9 @@ __global__ __launch_bounds__(MOR_BT, 5) void k_g2_cov(MorDev d) {
   const int V = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
   const int grp = threadIdx.x / G2_GW, sub = threadIdx.x % G2_GW, lane = lane_id(), lane0 = lane & ~(G2_GW - 1);   // group in the workgroup, lane in the group
-  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
+  const int *ckey = d.ckey + so;
   const float4 *sp = d.sorted + so;
   const int zbase = d.zbase[s]; const MorGrid G = stream_grid(d, s);   // (the lattice with the stream's own z layers)
-  const unsigned long long *bits = d.g2_bits ? d.g2_bits + (size_t)s * d.g.nrows * (size_t)(d.g2_nch * 8) : nullptr;   // occupancy bits of the lattice (none: the key search)
-  const int *dir = d.g2_dir + (size_t)s * d.g.nrows * (size_t)(d.g2_nch * 8);
   const int pred = d.g2_used[s], tag_spec = 2 * d.frame_no + 1;   // the mode bin this frame's kernels bet on (pass A's snapshot of the latest known one), and the tag of the marks made on that bet
   for (int v0 = bxv * (MOR_BT / G2_GW); v0 < V; v0 += G2_COV_G * (MOR_BT / G2_GW)) {
     const int v = v0 + grp; const bool act = v < V;
@@ -316,13 +314,7 @@ __global__ __launch_bounds__(MOR_BT, 5) void k_g2_cov(MorDev d) {
       rb0[j] = 0; rlen[j] = 0;
       const int row = sub + j * G2_GW;
       if (act && row < 9) {
-        const int y = cy + row % 3 - 1, z = cz + row / 3 - 1;
-        if ((unsigned)y < (unsigned)G.ny && (unsigned)z < (unsigned)G.nz) {
-          int lo, hi;
-          if (bits) row_cells_bits(bits, dir, d.g2_nch * 8, grid_row(G, y, z), max(cx - 1, 0), min(cx + 1, G.nx - 1), lo, hi);
-          else row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
-          if (lo < hi) { rb0[j] = st[lo]; rlen[j] = st[hi] - rb0[j]; }
-        }
+        g2_row_range(d, s, G, cx, cy, cz, row, rb0[j], rlen[j]);
       }
     }
     int rb[9], rp[10]; rp[0] = 0;
@@ -396,11 +388,8 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
   const int wv = wave_id(), lane = lane_id();
   __shared__ unsigned long long l_key[MOR_BT / 64][G2_MID_CAP];
   __shared__ float l_x[MOR_BT / 64][G2_MID_CAP], l_y[MOR_BT / 64][G2_MID_CAP], l_z[MOR_BT / 64][G2_MID_CAP];
-  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
   const int zbase = d.zbase[s]; const MorGrid G = stream_grid(d, s);   // (the lattice with the stream's own z layers)
-  const unsigned long long *bits = d.g2_bits ? d.g2_bits + (size_t)s * d.g.nrows * (size_t)(d.g2_nch * 8) : nullptr;   // occupancy bits of the lattice (none: the key search)
-  const int *dir = d.g2_dir + (size_t)s * d.g.nrows * (size_t)(d.g2_nch * 8);
   for (int w0 = bxq * (MOR_BT / 64); w0 < nbig; w0 += gq * (MOR_BT / 64)) {
    {
     const int w = w0 + wv;
@@ -408,16 +397,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
     const int qe = d.g2_big[so + w], v = qe & ~G2_Q_EXACT;
     const float4 q = d.vcent[so + v];
     int rb0 = 0, rlen = 0;
-    if (lane < 9) {
-      int cx, cy, cz; bool cl; grid_cell(G, q, 0.f, zbase, cx, cy, cz, cl);
-      const int y = cy + lane % 3 - 1, z = cz + lane / 3 - 1;
-      if ((unsigned)y < (unsigned)G.ny && (unsigned)z < (unsigned)G.nz) {
-        int lo, hi;
-        if (bits) row_cells_bits(bits, dir, d.g2_nch * 8, grid_row(G, y, z), max(cx - 1, 0), min(cx + 1, G.nx - 1), lo, hi);
-        else row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
-        if (lo < hi) { rb0 = st[lo]; rlen = st[hi] - rb0; }
-      }
-    }
+    if (lane < 9) { int cx, cy, cz; bool cl; grid_cell(G, q, 0.f, zbase, cx, cy, cz, cl); g2_row_range(d, s, G, cx, cy, cz, lane, rb0, rlen); }
     int rb[9], rp[10]; rp[0] = 0;
 #pragma unroll
     for (int r = 0; r < 9; ++r) { rb[r] = __shfl(rb0, r, 64); rp[r + 1] = rp[r] + __shfl(rlen, r, 64); }
@@ -567,7 +547,6 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mark(MorDev d) {
   const size_t so = (size_t)s * d.Nmax;
   if (mode == 0x7fffffff || d.g2_tag[s] == 2 * d.frame_no + 1) return;   // (no accepted voxel at all; or the bet on the mode bin held: the marks are there already)
   const int lane = lane_id(), nw = 128 * (MOR_BT / 64), grp = lane >> 4, sub = lane & 15;
-  const int *ckey = d.ckey + so, *rs = d.row_start + (size_t)s * (d.g.nrows + 1), *st = d.cstart + (size_t)s * (d.Nmax + 1);
   const float4 *sp = d.sorted + so;
   const MorGrid G = stream_grid(d, s);   // (the lattice with the stream's own z layers)
   const int zbase = d.zbase[s], tag = 2 * d.frame_no + 2;   // the frame's tag when the bet was lost (never 0, never an earlier frame's on this copy of the array): nothing has to be cleared
@@ -583,14 +562,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mark(MorDev d) {
       const bool act = l >= 0;
       const float4 q = d.vcent[so + v0 + max(l, 0)];
       int rb0 = 0, rlen = 0;
-      if (act && sub < 9) {
-        int cx, cy, cz; bool cl; grid_cell(G, q, 0.f, zbase, cx, cy, cz, cl);
-        const int y = cy + sub % 3 - 1, z = cz + sub / 3 - 1;
-        if ((unsigned)y < (unsigned)G.ny && (unsigned)z < (unsigned)G.nz) {
-          int lo, hi; row_cells(G, ckey, rs, max(cx - 1, 0), min(cx + 1, G.nx - 1), y, z, lo, hi);
-          if (lo < hi) { rb0 = st[lo]; rlen = st[hi] - rb0; }
-        }
-      }
+      if (act && sub < 9) { int cx, cy, cz; bool cl; grid_cell(G, q, 0.f, zbase, cx, cy, cz, cl); g2_row_range(d, s, G, cx, cy, cz, sub, rb0, rlen); }
       int rb[9], rp[10]; rp[0] = 0;
 #pragma unroll
       for (int r = 0; r < 9; ++r) { rb[r] = __shfl(rb0, (lane & 48) + r, 64); rp[r + 1] = rp[r] + __shfl(rlen, (lane & 48) + r, 64); }
