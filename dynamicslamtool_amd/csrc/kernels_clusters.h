@@ -66,7 +66,7 @@ __global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
       for (int u = 0; u < 4; ++u) {
         const int j = j0 + u * stride;
         if (j >= M) continue;
-        st_stream(&d.pcid[so + __float_as_int(p[u].w)], g[u].y);   // label of the cloud point (its index travels in .w); read once more, by the output
+        if (g[u].y >= 0 || !d.label_prefill) st_stream(&d.pcid[so + __float_as_int(p[u].w)], g[u].y);   // label of the cloud point (its index travels in .w); read once more, by the output.  (label_prefill: k_gridplace has left −1 in every label — coalesced — and only the clustered points' labels are scattered from here)
         if (g[u].y < 0) continue;
         st_stream(&dst[j + g[u].x], p[u]); st_stream(&dcid[j + g[u].x], g[u].y);   // (cb's cluster points are read by the NEXT frame: streaming stores, they would only push this frame's cell-ordered points out of the L2 before its scoring tiers run)
         if (__float_as_int(p[u].w) == g[u].z) d.cl_first[d.cur][ko + g[u].y] = p[u];

@@ -384,6 +384,7 @@ __global__ __launch_bounds__(GC_T) void k_gridplace(MorDev d) {
         const int i = i0 + u * GC_T + tid, pos = base + (lane - run_leader);
         q[u].w = __int_as_float(i);
         sorted[pos] = q[u]; scell[pos] = l_cell[en[u]];
+        if (d.label_prefill) d.pcid[so + i] = -1;   // label of the cloud point until k_clusters says otherwise: written here in input order (coalesced) — k_clusters then stores the labels of CLUSTERED points only (its stores are scattered: the index travels with the point), a seventh of the points in the voxel ground variant's pass B
       }
     }
     __syncthreads();

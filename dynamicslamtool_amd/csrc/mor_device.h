@@ -105,6 +105,7 @@ struct MorDev {
   int split_g;   // workgroups per stream of the two split passes (each walks tiles split_g apart)
   int g_out;                 // workgroups per stream of k_out's compaction (from the streams' mean tile count)
   int g_fast, g_score, g_pde, g_box;   // launch widths, workgroups per stream (shared out by work inside the launch): tier 1 of the scores, the worklist tiers, the wave tier, k_cellboxes
+  int label_prefill;         // 1: k_gridplace leaves −1 in every cloud point's label (input order, coalesced) and k_clusters stores the labels of clustered points only (its label stores are scattered); the host sets it when fewer than half of the cloud points of the latest reported frame lay in clusters (the voxel ground variant's pass B: a seventh)
   int prop_map;              // 1 (default): launches share their workgroups out over the streams in proportion to the streams' work (map_block_work); 0: the same number for every stream (MOR_PROP_MAP=0)
   int xcd_map;               // 1: the workgroups of a stream share an XCD (its tables stay in that L2); 0: streams spread over all XCDs
   int sp_g;                  // workgroups per stream of the single-read split (2 … 64)

@@ -221,7 +221,7 @@ static int configure(mor_batch *b) {
     if (b->B * 2 > hold) d.two_pass_split = 1;
   }
   d.xcd_map = 1;   // the workgroups of a stream share an XCD (streams spread over all XCDs: −24 %)
-  d.prop_map = getenv("MOR_PROP_MAP") ? atoi(getenv("MOR_PROP_MAP")) != 0 : 1;
+  d.prop_map = getenv("MOR_PROP_MAP") ? atoi(getenv("MOR_PROP_MAP")) != 0 : 1; d.label_prefill = 0;
   // workgroups per stream (launch widths; the kernels share them out over the streams in proportion to the streams' work, map_block_work): tier 1 of the scores
   // (1024 threads each, two per CU), tiers 1a + 1b together (512 threads; they share out the chunks of the two worklists), wave tier (256 threads: a wave per
   // deferred query; 24 × B workgroups hold about one query per wave slot of the GPU — with 256 × B, one workgroup per four queries of the fullest stream, the
@@ -535,6 +535,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
        // a launch sized for the largest stream was mostly workgroups that found nothing to do (32 per stream for a mean of 5 chunks).
       uint64_t sumM = 0; uint32_t mxM = 0; for (int s = 0; s < B; ++s) { const uint32_t m = k > 0 ? d.h_info[s].M : (uint32_t)maxn; sumM += m; mxM = std::max(mxM, m); }
       const uint64_t meanM = (sumM + B - 1) / B, ref = d.prop_map ? meanM * 23 / 20 : (uint64_t)mxM * 5 / 4;
+      { uint64_t sumC = 0; for (int s = 0; s < B; ++s) sumC += k > 0 ? d.h_info[s].C : 0u; d.label_prefill = k > 0 && 2 * sumC < sumM; }   // (either way the labels are the same: a matter of where the −1 of an unclustered point is written)
       const int want = (int)((ref + MOR_GC_CHUNK - 1) / MOR_GC_CHUNK) + (d.prop_map ? 1 : 0);
       d.gc_P = std::max(1, std::min(std::min(want, d.gc_chunks), std::max(1, 2048 / B)));
       d.g_out = std::max(1, std::min(want, d.tiles));
