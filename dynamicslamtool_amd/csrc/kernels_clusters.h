@@ -58,10 +58,19 @@ __global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
     const int stride = gmv * MOR_BT;
     for (int j0 = t * MOR_BT + threadIdx.x; j0 < M; j0 += 4 * stride) {   // four positions per thread and round trip: point + cell id, then the cell's record, then the stores
       float4 p[4]; int sc[4]; int4 g[4];
+      if (d.label_prefill) {   // little of the cloud is clustered (the voxel ground variant's pass B: a seventh): the cell's record first, the point only when it belongs to a cluster
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int j = min(j0 + u * stride, M - 1); p[u] = d.sorted[so + j]; sc[u] = d.scell[so + j]; }
+        for (int u = 0; u < 4; ++u) sc[u] = d.scell[so + min(j0 + u * stride, M - 1)];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) g[u] = d.cgat[so + sc[u]];
+        for (int u = 0; u < 4; ++u) g[u] = d.cgat[so + sc[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = g[u].y >= 0 ? d.sorted[so + min(j0 + u * stride, M - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int j = min(j0 + u * stride, M - 1); p[u] = d.sorted[so + j]; sc[u] = d.scell[so + j]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = d.cgat[so + sc[u]];
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int j = j0 + u * stride;
