@@ -778,7 +778,7 @@ def main():
                 for _ in range(3):
                     lg.step()
                 lg.batch.synchronize()
-                st = 40 if name == "hdl64_urban_b64" else 10   # (the street scene is the line's named companion — KITTI-like density, half of the sweep non-ground —: a leg long enough that the pipeline's fill and drain do not set its figure)
+                st = 40   # (legs long enough that the pipeline's fill and drain do not set their figures: a 10-step leg of the million-point clouds read 41 k where 40 steps read 45 k)
                 dt = lg.timed_async(st)
                 ref = lg.replay_sync(3 + st)
                 fr, bad2 = compare_logs(lg.logs(0, 3 + st), ref)   # (the first leg's frames: the log keeps the latest 64)
