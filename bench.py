@@ -16,7 +16,8 @@ Prints ONE JSON line on rank 0.  Besides the contract's keys it carries `value_r
 (the timed frames against a synchronous re-run and against the CPU oracle's summaries of the same frames), `roofline`
 (dominant kernel + whole path + per-kernel HBM traffic), `cpu_baseline` (+ all cores, one definition), `workloads` (the
 other BASELINE configurations, method 2, the voxel-covariance ground variant: short legs, never `value`),
-`sync_frame_pairs_per_s`, `e2e_host_frame_pairs_per_s`, `latency_b1_ms`.
+`sync_frame_pairs_per_s`, `e2e_host_frame_pairs_per_s` (+ the asynchronous form; at N > 1 the SUM over the ranks' side-by-side legs with the per-rank min / max),
+`latency_b1_ms`, `class_latency_ms` (one stream through the drop-in C++ class), `value_long` (median of three 40-step legs: what the secondary legs are compared with).
 """
 import argparse
 import json
@@ -51,8 +52,8 @@ ORACLE_KEYS = ("K", "C", "n_pairs", "det_sum", "n_mo_push", "n_mo_filter", "n_ou
 ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us", "avg_launch_us_alone",
              "job_GBps", "job_frac", "path_traffic_bytes_per_step", "wasted_traffic_ratio", "launches_per_step")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "core_seconds", "frame_pairs", "host_cpus")
-DROP_ORDER = ("e2e_host_sync_ms_per_step", "gathered", "stream0", "stage_totals", "first_seed_per_rank", "per_rank_frame_pairs_per_s", "cpu_baseline_all_cores", "workloads", "latency_b1_ms",
-              "sync_frame_pairs_per_s", "device_ms_per_step", "value_runs")   # least important first; the contract keys (with ranks / devices_visible / ranks_per_device), roofline, cpu_baseline and sanity never go
+DROP_ORDER = ("e2e_host_sync_ms_per_step", "gathered", "stream0", "stage_totals", "first_seed_per_rank", "per_rank_frame_pairs_per_s", "cpu_baseline_all_cores", "class_latency_visualize_ms", "workloads", "latency_b1_ms",
+              "class_latency_ms", "e2e_host_async_per_rank_min_max", "sync_frame_pairs_per_s", "device_ms_per_step", "value_runs", "value_long")   # least important first; the contract keys (with ranks / devices_visible / ranks_per_device), roofline, cpu_baseline and sanity never go
 
 
 def compact_line(full, detail_path=None, limit=LINE_LIMIT):
@@ -64,8 +65,8 @@ def compact_line(full, detail_path=None, limit=LINE_LIMIT):
     cfg = dict(full.get("config") or {})
     cfg.pop("profile", None)   # the parameter profile is in the detail file (and in dynamicslamtool_amd/params.py: kitti_params)
     line["config"] = cfg
-    for k in ("kitti_density", "gathered", "collective", "self_launched", "legs_failed", "first_seed_per_rank", "value_runs", "per_rank_frame_pairs_per_s", "device_ms_per_step", "sync_frame_pairs_per_s", "e2e_host_frame_pairs_per_s",
-              "e2e_host_sync_ms_per_step", "e2e_host_async_frame_pairs_per_s", "e2e_host_async_equals_sync", "latency_b1_ms", "algorithmic_bytes_per_frame_pair", "stage_totals", "stream0"):
+    for k in ("kitti_density", "value_long", "gathered", "collective", "self_launched", "legs_failed", "first_seed_per_rank", "value_runs", "per_rank_frame_pairs_per_s", "device_ms_per_step", "sync_frame_pairs_per_s", "e2e_host_frame_pairs_per_s",
+              "e2e_host_sync_ms_per_step", "e2e_host_async_frame_pairs_per_s", "e2e_host_async_per_rank_min_max", "e2e_host_async_equals_sync", "latency_b1_ms", "class_latency_ms", "class_latency_visualize_ms", "algorithmic_bytes_per_frame_pair", "stage_totals", "stream0"):
         if full.get(k) is not None:
             line[k] = full[k]
     if isinstance(line.get("per_rank_frame_pairs_per_s"), list) and len(line["per_rank_frame_pairs_per_s"]) > 8:
@@ -431,19 +432,50 @@ def compare_logs(a, b, keys_idx=None):
     return frames, bad
 
 
-def e2e_legs(workload, device, streams=0):
+def e2e_over_ranks(shard, dist, mine):
+    """The job's PCIe-inclusive figures from every rank's side-by-side legs: frame-pairs/s summed over the ranks (their timed legs start behind one barrier and
+    overlap), the per-rank min / max of the asynchronous leg (a rank behind a shared root port shows here), the checks AND-ed.  A rank whose leg failed makes the sums null."""
+    a = shard.gather_floats(dist, (mine or {}).get("e2e_async") or 0.0)
+    sy = shard.gather_floats(dist, (mine or {}).get("e2e") or 0.0)
+    ok = shard.gather_floats(dist, 1.0 if (mine or {}).get("e2e_async_ok") else 0.0)
+    bad = any(x <= 0 for x in a) or any(x <= 0 for x in sy)
+    return {"e2e": None if bad else round(sum(sy), 2), "e2e_async": None if bad else round(sum(a), 2), "per_rank_min_max": [round(min(a), 1), round(max(a), 1)],
+            "ok": None if bad else all(x > 0.5 for x in ok), "ranks": len(a)}
+
+
+def bind_to_gpu_node(engine, local_rank, world, ndev):
+    """The calling thread next to the GPU of rank `local_rank` (device local_rank mod ndev); ranks whose GPUs hang on one NUMA node share that node's cores in equal
+    slices, in rank order.  Returns the cores kept (0: nothing changed)."""
+    device = local_rank % ndev
+    node = engine.device_numa_node(device)
+    if node < 0:
+        return 0
+    peers = [r for r in range(world) if engine.device_numa_node(r % ndev) == node]   # (one node: local rank = rank)
+    return engine.bind_thread_to_device_node(device, peers.index(local_rank) if local_rank in peers else 0, max(len(peers), 1))
+
+
+def e2e_legs(workload, device, streams=0, rank=0, world=1, allow_shared=False):
     """PCIe-inclusive legs on ONE batch of a fresh process: clouds start in page-locked host memory, filtered clouds end there — synchronous push +
-    filter pairs, then the same calls enqueue-only (asynchronous mode), then an untimed synchronous replay on a second batch as the check."""
+    filter pairs, then the same calls enqueue-only (asynchronous mode), then an untimed synchronous replay on a second batch as the check.
+    world > 1 ("host-side staging / PCIe root complex" is what will bend the scaling curve): the children of all ranks run their legs SIDE BY SIDE — a gloo
+    group of their own, a barrier in front of and behind every timed leg — each on its own GPU with its own streams and its own slice of its GPU's socket."""
     from dynamicslamtool_amd import engine, kitti_params, synth, shard
     sensor0, B0, cfg0, mo, go = WORKLOADS[workload]
     B0 = streams or B0
     p = kitti_params(mo or 1)
     p.ground_method = go if go is not None else 0
-    if not os.environ.get("MOR_BENCH_NO_BIND"):
+    dist = shard.init_distributed() if world > 1 else None
+    if world > 1:
+        ndev = engine.device_count()
+        if ndev < 1 or (world > ndev and not allow_shared):
+            raise RuntimeError("%d ranks, %d visible GPU(s)" % (world, ndev))
+        device = rank % ndev
+        if not os.environ.get("MOR_BENCH_NO_BIND"):
+            bind_to_gpu_node(engine, rank, world, ndev)
+    elif not os.environ.get("MOR_BENCH_NO_BIND"):
         engine.bind_thread_to_device_node(device)
-    rank = 0
     B, npts, sensor = B0, synth.n_points(sensor0), sensor0
-    seeds_main = shard.stream_seeds(cfg0, rank, B)
+    seeds_main = shard.stream_seeds(cfg0, rank, B)   # rank r's own streams, as in the headline leg
     hin, hout = [engine.HostBuffer((B, npts, 4)) for _ in range(2)], engine.HostBuffer((B, npts, 4))
     hout2 = [engine.HostBuffer((B, npts, 4)) for _ in range(2)]
     # PCIe-inclusive: clouds start in page-locked host memory, filtered clouds end there (synchronous push + filter)
@@ -461,6 +493,7 @@ def e2e_legs(workload, device, streams=0):
     optrs = [hb.make_out_pointers([hout2[f].array[s] for s in range(B)]) for f in range(2)]
     hb.push_views(sviews[0], pp[0])
     hb.filter_into(houts)
+    shard.barrier(dist)
     t1 = time.perf_counter()
     reps, t_push = 8, 0.0
     for r in range(reps):
@@ -473,12 +506,14 @@ def e2e_legs(workload, device, streams=0):
     e2e_ms = {"push": round(1e3 * t_push / reps, 3), "filter": round(1e3 * (e2e_dt - t_push) / reps, 3)}
     hb.set_async(True)
     areps = 16
+    shard.barrier(dist)   # (world > 1: every rank's asynchronous leg starts here and is timed by its own clock; the job's rate is the sum of the ranks' rates, all legs overlapping)
     t1 = time.perf_counter()
     for r in range(reps, reps + areps):
         hb.push_views(sviews[(r + 1) % 2], pp[(r + 1) % 2])
         hb.filter_async_to(optrs[r % 2], on_device=False)
     hb.wait()
     e2e_async = B * areps / (time.perf_counter() - t1)
+    shard.barrier(dist)
     last = (reps + areps - 1) % 2
     nout_async = [hb.output_device(s)[1] for s in range(B)]
     crc_async = [zlib.crc32(hout2[last].array[s][:nout_async[s]].tobytes()) for s in range(B)]
@@ -499,7 +534,10 @@ def e2e_legs(workload, device, streams=0):
     for x in hin + [hout]:
         x.free()
 
-    return {"e2e": round(e2e, 2), "e2e_ms": e2e_ms, "e2e_async": round(e2e_async, 2), "e2e_async_ok": bool(e2e_async_ok)}
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return {"e2e": round(e2e, 2), "e2e_ms": e2e_ms, "e2e_async": round(e2e_async, 2), "e2e_async_ok": bool(e2e_async_ok), "rank": rank, "device": device, "first_seed": seeds_main[0]}
 
 
 def latency_b1(workload, device):
@@ -529,6 +567,42 @@ def latency_b1(workload, device):
     return round(1e3 * float(np.median(ts[2:])), 3)
 
 
+def class_latency(workloads=("hdl64_b64", "hdl64_urban_b64"), frames=26, device=0, binary="mor_replay_novis", env_extra=None):
+    """The latency a drop-in user gets THROUGH THE CLASS (missing #4): `mor_replay` — the counterpart of the reference's demo node,
+    src/external_sync_test.cpp:7-22 — drives include/MOR/MovingObjectRemoval.h over `.bin` frames of one stream (pageable std::vector in, PCLPointCloud2 + `output`
+    out, 32-byte PointXYZI records) and prints the wall time of every pushRawCloudAndPose + filterCloud pair; median over the frames behind the first four.
+    `mor_replay_novis` is the class without the reference's VISUALIZE side effect; `mor_replay` has it (the reference's default build flag)."""
+    import tempfile
+    from dynamicslamtool_amd import synth
+    from dynamicslamtool_amd.params import KITTI_CONFIG
+    exe = os.path.join(ROOT, "dynamicslamtool_amd", "csrc", binary)
+    out = {}
+    for wl in workloads:
+        sensor, _, cfg = WORKLOADS[wl][:3]
+        if sensor not in synth.SENSORS:
+            continue
+        with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+            with open(os.path.join(td, "cfg.txt"), "w") as f:
+                f.write(KITTI_CONFIG)
+            files = []
+            with open(os.path.join(td, "poses.txt"), "w") as pf:
+                for i in range(frames):
+                    x, pose = synth.frame(1000 * cfg, sensor, i)   # stream 0 of the workload, consecutive frames
+                    fn = os.path.join(td, "c%03d.bin" % i)
+                    np.asarray(x, np.float32).tofile(fn)
+                    files.append(fn)
+                    pf.write(" ".join(repr(float(v)) for v in pose) + "\n")
+            env = dict(os.environ, MOR_REPLAY_NO_OUTPUT="1", MOR_DEVICE=str(device), MOR_MAX_POINTS=str(synth.n_points(sensor)), MOR_BIND_NUMA="1")
+            env.update(env_extra or {})
+            r = subprocess.run([exe, os.path.join(td, "cfg.txt"), os.path.join(td, "poses.txt"), td] + files, capture_output=True, text=True, timeout=600, env=env)
+        if r.returncode != 0:
+            raise RuntimeError("%s failed (%d): %s" % (binary, r.returncode, (r.stdout + r.stderr)[-400:]))
+        ms = [float(l.rsplit(",", 1)[1].split()[0]) for l in r.stdout.splitlines() if l.startswith("frame ") and l.rstrip().endswith(" ms")]
+        assert len(ms) == frames, (len(ms), frames)
+        out[wl] = {"median_ms": round(float(np.median(ms[4:])), 3), "min_ms": round(min(ms[4:]), 3), "max_ms": round(max(ms[4:]), 3), "frames": len(ms) - 4}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -548,6 +622,8 @@ def main():
     ap.add_argument("--latency-only", action="store_true", help="child process of the default run: push + filter latency of ONE stream, prints {\"latency_b1_ms\": …}")
     ap.add_argument("--e2e-only", action="store_true", help="child process of the default run: the host-resident end-to-end legs, prints their figures as JSON")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="child process of the default run: the CPU oracle on the batch's own streams (never touches HIP), prints its figures as JSON")
+    ap.add_argument("--class-latency-only", action="store_true", help="child process of the default run: one stream through the drop-in C++ class (mor_replay over .bin frames), prints {\"class_latency\": …}")
+    ap.add_argument("--with-e2e", action="store_true", help="run the host-resident end-to-end legs even with --no-extras (tests/test_bench_multirank.py: two ranks side by side)")
     ap.add_argument("--device", type=int, default=0, help="HIP ordinal for --latency-only / --e2e-only")
     ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), help="where the full record goes (per-kernel tables, every workload's roofline …); the stdout line stays under %d bytes" % LINE_LIMIT)
     args = ap.parse_args()
@@ -556,7 +632,16 @@ def main():
         print(json.dumps({"latency_b1_ms": latency_b1(args.workload, args.device)}))
         return
     if args.e2e_only:
-        print(json.dumps(e2e_legs(args.workload, args.device, args.streams)))
+        r_, _, w_ = (int(os.environ.get("RANK", "0")), 0, int(os.environ.get("WORLD_SIZE", "1")))
+        print(json.dumps(e2e_legs(args.workload, args.device, args.streams, r_, w_, args.allow_shared_device)))
+        return
+    if args.class_latency_only:
+        out_ = {"novis": class_latency(device=args.device)}
+        try:
+            out_["visualize"] = class_latency(workloads=("hdl64_b64",), device=args.device, binary="mor_replay")
+        except Exception as e_:
+            out_["visualize"] = {"error": repr(e_)[:200]}
+        print(json.dumps({"class_latency": out_}))
         return
 
     if args.cpu_baseline_only:
@@ -595,6 +680,7 @@ def main():
             mat, ginfo = shard.gather_summaries(dist, np.array([[sd, rank] for sd in seeds], np.float32))
             if rank == 0:
                 gathered = dict(ginfo, rows=int(mat.shape[0]), first_row=[float(x) for x in mat[0]], last_row=[float(x) for x in mat[-1]])
+        e2e_job = e2e_over_ranks(shard, dist, {"e2e": 100.0 * (rank + 1), "e2e_async": 200.0 * (rank + 1), "e2e_async_ok": True})   # (the N-rank line's PCIe-inclusive keys, with made-up per-rank figures)
         slices = None
         topo = os.environ.get("MOR_FAKE_TOPOLOGY")   # {"gpu_node": [0,0,0,0,1,1,1,1], "node_cpus": {"0": [0..63], "1": [64..127]}}: the host placement of a node this box is not
         if topo:
@@ -605,7 +691,9 @@ def main():
             text = json.dumps({"dry_run": True, "n_gpus": world, "value": rate, "first_seed": seeds[0], "last_seed_rank0": seeds[-1], "steps": args.steps,
                                "per_rank_min_max": [min(per_rank), max(per_rank)], "first_seed_per_rank": [int(x) for x in first_seeds], "last_seed_per_rank": [int(x) for x in last_seeds],
                                "collective": "none", "workloads": "skipped: world>1" if world > 1 else "skipped: dry run", "numa_core_slices_first_last_n": slices,
-                               "self_launched": bool(os.environ.get("MOR_BENCH_SELF_LAUNCHED")), "cores_per_rank": cores_mine, "gathered": gathered})
+                               "self_launched": bool(os.environ.get("MOR_BENCH_SELF_LAUNCHED")), "cores_per_rank": cores_mine, "gathered": gathered,
+                               "e2e_host_frame_pairs_per_s": e2e_job["e2e"], "e2e_host_async_frame_pairs_per_s": e2e_job["e2e_async"], "e2e_host_async_per_rank_min_max": e2e_job["per_rank_min_max"],
+                               "e2e_host_async_equals_sync": e2e_job["ok"]})
             assert len(text) <= LINE_LIMIT
             print(text)
         if dist:
@@ -634,19 +722,47 @@ def main():
     #      a batch created after other batches of the same process have come and gone copies device → host at 10 GB/s instead of 55 —
     #      exp/e2e_probe.py --prelude — and, the other way round, the headline leg's first timed steps ran 5 % slower behind those batches.)
     #      They run BEFORE this process touches the GPU: with two processes' hardware queues alive the child's asynchronous leg lost 12 %.
-    e2e = lat = e2e_async = e2e_async_ok = e2e_ms = None
-    if not args.no_extras and world == 1:
-        def child(flag):
+    #      At N > 1 (missing #3) every rank starts its end-to-end child here too: the children form a gloo group of their own and time their legs side
+    #      by side behind one barrier — the PCIe-inclusive rate of the JOB is what host-side staging and shared root ports will bend first.
+    e2e = lat = e2e_async = e2e_async_ok = e2e_ms = e2e_minmax = class_lat = None
+    run_e2e = (not args.no_extras) or args.with_e2e
+    if run_e2e or (not args.no_extras and world == 1):
+        if world > 1 and not args.allow_shared_device:
+            import torch   # (counting devices does not initialise the GPU on this image)
+            nd_ = torch.cuda.device_count()
+            if 0 < nd_ < world:
+                raise RuntimeError("%d ranks but %d visible GPU(s): a line with n_gpus = %d would be a lie; pass --allow-shared-device for a plumbing run" % (world, nd_, world))
+
+        def child(flag, env=None):
+            before_ = None
             try:
-                r_ = subprocess.run([sys.executable, os.path.abspath(__file__), flag, "--device", str(local_rank), "--workload", args.workload] + (["--streams", str(args.streams)] if args.streams else []),
-                                    capture_output=True, text=True, timeout=600)
+                if world > 1 and _ALL_CORES:   # (the child chooses its slice of its GPU's socket among ALL cores, as this process does below — not among the slice taken for the CPU legs)
+                    before_ = os.sched_getaffinity(0)
+                    os.sched_setaffinity(0, _ALL_CORES)
+                r_ = subprocess.run([sys.executable, os.path.abspath(__file__), flag, "--device", str(local_rank), "--workload", args.workload] + (["--streams", str(args.streams)] if args.streams else [])
+                                    + (["--allow-shared-device"] if args.allow_shared_device else []), capture_output=True, text=True, timeout=600, env=env)
                 return json.loads(r_.stdout.strip().splitlines()[-1])
             except Exception as e_:   # reported as nulls, never silently
                 print("%s leg failed: %r" % (flag, e_), file=sys.stderr)
                 return {}
-        lat = child("--latency-only").get("latency_b1_ms")
-        ee = child("--e2e-only")
-        e2e, e2e_ms, e2e_async, e2e_async_ok = ee.get("e2e"), ee.get("e2e_ms"), ee.get("e2e_async"), ee.get("e2e_async_ok")
+            finally:
+                if before_ is not None:
+                    os.sched_setaffinity(0, before_)
+        if not args.no_extras and world == 1:
+            lat = child("--latency-only").get("latency_b1_ms")
+            class_lat = child("--class-latency-only").get("class_latency")
+        if run_e2e:
+            env_ = None
+            if world > 1:   # the children's own rendezvous: a port rank 0 picks, told to the others through the parents' group
+                port2 = int(sum(shard.gather_floats(dist, _free_port() if rank == 0 else 0)))
+                env_ = dict(os.environ, MASTER_PORT=str(port2), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"))
+            ee = child("--e2e-only", env_)
+            e2e_ms = ee.get("e2e_ms")
+            if world > 1:
+                job = e2e_over_ranks(shard, dist, ee)
+                e2e, e2e_async, e2e_async_ok, e2e_minmax = job["e2e"], job["e2e_async"], job["ok"], job["per_rank_min_max"]
+            else:
+                e2e, e2e_async, e2e_async_ok = ee.get("e2e"), ee.get("e2e_async"), ee.get("e2e_async_ok")
 
     from dynamicslamtool_amd import engine, kitti_params, synth
 
@@ -668,11 +784,10 @@ def main():
     # Ranks whose GPUs hang on the same NUMA node share that node's cores in equal slices.
     numa_node = engine.device_numa_node(device)
     if numa_node >= 0:
-        peers = [r for r in range(world) if engine.device_numa_node(r % ndev) == numa_node]   # (one node: local rank = rank)
         mine_before = sorted(os.sched_getaffinity(0))
         if _ALL_CORES:
             os.sched_setaffinity(0, _ALL_CORES)   # the slice taken for the CPU legs may lie on the other socket: choose among all cores again
-        kept = engine.bind_thread_to_device_node(device, peers.index(local_rank) if local_rank in peers else 0, max(len(peers), 1))
+        kept = bind_to_gpu_node(engine, local_rank, world, ndev)
         if kept:
             cores_mine = kept
         else:
@@ -731,6 +846,14 @@ def main():
         for _ in range(4):
             runs.append(world * B * args.steps / shard.max_over_ranks(dist, leg.timed_async(args.steps, dist)))
         value_runs = {"n": len(runs), "min": round(min(runs), 1), "median": round(float(np.median(runs)), 1), "max": round(max(runs), 1)}
+    value_long = None
+    if extras:   # the headline workload timed the way the secondary legs are — median of three 40-step legs — so that ratios between them compare like with like (`value` stays the first leg of --steps)
+        st_l = 40
+        if leg.n_frames < 2:
+            st_l = 0
+        lr = [world * B * st_l / shard.max_over_ranks(dist, leg.timed_async(st_l, dist)) for _ in range(3)] if st_l else []
+        if lr:
+            value_long = {"value": round(sorted(lr)[1], 1), "steps": st_l, "runs": [round(x, 1) for x in lr]}
 
     roofline = kernels = kernels_alone = None
     b_alg = leg.b_alg()
@@ -779,10 +902,10 @@ def main():
                     lg.step()
                 lg.batch.synchronize()
                 st = 40   # (legs long enough that the pipeline's fill and drain do not set their figures: a 10-step leg of the million-point clouds read 41 k where 40 steps read 45 k)
-                dt = lg.timed_async(st)
-                ref = lg.replay_sync(3 + st)
-                fr, bad2 = compare_logs(lg.logs(0, 3 + st), ref)   # (the first leg's frames: the log keeps the latest 64)
-                dts = [dt] + [lg.timed_async(st) for _ in range(2)]   # three legs, the median: one fresh-box run in seven of round 5 timed the street scene's only leg at half its rate (all other runs and legs of the same command: ± 1 %)
+                dts = [lg.timed_async(st) for _ in range(3)]   # three legs, the median: one fresh-box run in seven of round 5 timed the street scene's only leg at half its rate (all other runs and legs of the same command: ± 1 %)
+                n_run = 3 + 3 * st
+                ref = lg.replay_sync(n_run)   # every step of all three legs again, synchronously: whichever leg sets the published value, the latest 64 frames of the log — the end of the LAST leg, reached through all frames before it (the tracking state carries every earlier frame) — must equal the synchronous run's
+                fr, bad2 = compare_logs(lg.logs(0, n_run), ref)
                 dt = sorted(dts)[1]
                 v = lg.B * st / dt
                 roof, ks, _, ba = roofline_of(lg, v, 8, name)
@@ -791,7 +914,7 @@ def main():
                 others[name] = {"value": round(v, 1), "unit": "frame-pairs/s", "ms_per_step": round(1e3 * dt / st, 3), "steps": st, "streams_per_gpu": lg.B, "points_per_frame": lg.npts,
                                 "method": int(lg.p.method_choice), "ground_method": int(lg.p.ground_method),
                                 "algorithmic_bytes_per_frame_pair": int(ba), "roofline": roof, "top_kernels_us": {k: v_["avg_us"] for k, v_ in top}, "stream0": lg.summary0(),
-                                "async_equals_sync": not bad2 and bool(fr), "setup_s": round(lg.setup_s, 1), "value_runs": [round(lg.B * st / x, 1) for x in dts]}
+                                "async_equals_sync": not bad2 and bool(fr), "frames_checked": [fr[0], fr[-1]] if fr else None, "setup_s": round(lg.setup_s, 1), "value_runs": [round(lg.B * st / x, 1) for x in dts]}
                 lg.close()
             except Exception as e:   # a secondary leg must not take the headline down
                 others[name] = {"error": repr(e)[:300]}
@@ -808,7 +931,10 @@ def main():
             "host_numa_node_of_gpu": numa_node, "host_cores_bound_rank0": cores_mine,
             "value_runs": value_runs, "per_rank_frame_pairs_per_s": [round(x, 1) for x in per_rank], "per_rank_frame_pairs_per_s_min_max": [round(min(per_rank), 1), round(max(per_rank), 1)],
             "device_ms_per_step": round(dev_ms, 4), "sync_frame_pairs_per_s": None if sync_rate is None else round(sync_rate, 1),
-            "e2e_host_frame_pairs_per_s": None if e2e is None else round(e2e, 2), "e2e_host_sync_ms_per_step": e2e_ms, "e2e_host_async_frame_pairs_per_s": None if e2e_async is None else round(e2e_async, 2), "e2e_host_async_equals_sync": e2e_async_ok, "latency_b1_ms": None if lat is None else round(lat, 3),
+            "e2e_host_frame_pairs_per_s": None if e2e is None else round(e2e, 2), "e2e_host_sync_ms_per_step": e2e_ms, "e2e_host_async_frame_pairs_per_s": None if e2e_async is None else round(e2e_async, 2), "e2e_host_async_equals_sync": e2e_async_ok, "e2e_host_async_per_rank_min_max": e2e_minmax, "latency_b1_ms": None if lat is None else round(lat, 3),
+            # one stream through the drop-in C++ class (mor_replay: pageable std::vector in, PCLPointCloud2 + `output` out as 32-byte PointXYZI records), median ms per pushRawCloudAndPose + filterCloud
+            "class_latency_ms": ((class_lat or {}).get("novis") or {}).get(args.workload, {}).get("median_ms"), "class_latency_visualize_ms": ((class_lat or {}).get("visualize") or {}).get(args.workload, {}).get("median_ms"),
+            "class_latency": class_lat, "value_long": value_long,
             "algorithmic_bytes_per_frame_pair": int(b_alg),
             "stage_totals": stage_totals, "stream0": stream0, "sanity": sanity,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
@@ -817,14 +943,15 @@ def main():
             # keeps about half of its points after the ground removal: that leg by name, next to `value`
             "kitti_density": None if not isinstance(others.get("hdl64_urban_b64"), dict) or "error" in others["hdl64_urban_b64"] else {
                 "workload": "hdl64_urban_b64", "value": others["hdl64_urban_b64"]["value"], "unit": "frame-pairs/s", "steps": others["hdl64_urban_b64"]["steps"],
-                "ratio_to_value": round(others["hdl64_urban_b64"]["value"] / value, 3) if value else None,
+                "ratio_to_value": round(others["hdl64_urban_b64"]["value"] / value_long["value"], 3) if value_long and value_long.get("value") else None,
+                "ratio_basis": "median of three 40-step legs of either workload (value_long), like with like",
                 "non_ground_share_stream0": round(others["hdl64_urban_b64"]["stream0"]["M"] / max(others["hdl64_urban_b64"]["stream0"]["T"], 1), 3),
                 "job_frac": others["hdl64_urban_b64"]["roofline"].get("job_frac"), "wasted": others["hdl64_urban_b64"]["roofline"].get("wasted_traffic_ratio"), "value_runs": others["hdl64_urban_b64"].get("value_runs")},
             "gathered": gathered,
             "kernels": kernels, "kernels_alone_avg_us": kernels_alone,
             "setup_s": round(setup_s, 2),
             "library": {"path": engine.LIB_PATH, "hash": engine.build_hash(), "staleness_check_bypassed": bool(os.environ.get("MOR_HIP_LIB") or os.environ.get("MOR_ALLOW_STALE_LIB"))},
-            "legs_failed": [n_ for n_, v_ in (("cpu_baseline", cpu if not args.no_cpu_baseline else 0), ("latency_b1", lat if extras and world == 1 else 0), ("e2e_host", e2e if extras and world == 1 else 0)) if v_ is None] or None,
+            "legs_failed": [n_ for n_, v_ in (("cpu_baseline", cpu if not args.no_cpu_baseline else 0), ("latency_b1", lat if extras and world == 1 else 0), ("class_latency", class_lat if extras and world == 1 else 0), ("e2e_host", e2e if run_e2e else 0)) if v_ is None] or None,
         }
         emit(line, args.detail)
     if dist:

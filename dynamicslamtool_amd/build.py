@@ -1,7 +1,7 @@
 """Builds the in-tree native libraries:
   csrc/libmor_hip.so    — HIP kernels + C ABI (hipcc, gfx950 only)
   csrc/libmor_synth.so  — synthetic LiDAR generator (gcc)
-  csrc/mor_replay       — the drop-in class + the ROS-free replay driver (g++)
+  csrc/mor_replay       — the drop-in class + the ROS-free replay driver (g++); csrc/mor_replay_novis: the same without the VISUALIZE side effect
 The .so files stay in-tree (git-ignored) so they travel with the gpurun snapshot.
 
 An artefact is rebuilt when the hash of (its sources, its headers, its compiler flags) differs from the hash the artefact itself carries —
@@ -64,8 +64,13 @@ def _targets():
     return {
         "hip": (os.path.join(CSRC, "libmor_hip.so"), hip_files, HIP_FLAGS),
         "hip_smalllist": (os.path.join(CSRC, "libmor_hip_smalllist.so"), hip_files, HIP_FLAGS + ["-DCGS_LISTW=16"]),
+        # lab build (exp/shadow.sh, exp/shadow_g2.sh; never loaded by the product, never built by build_all): the product's flags + the duplicated-launch hook,
+        # so that shadow prices are measured on a library whose flags cannot drift from the product build's
+        "hip_experiments": (os.path.join(HERE, "..", "exp", "libmor_exp.so"), hip_files, HIP_FLAGS + ["-DMOR_EXPERIMENTS"]),
         "synth": (os.path.join(CSRC, "libmor_synth.so"), ["mor_synth.c"], SYNTH_FLAGS),
         "replay": (os.path.join(CSRC, "mor_replay"), adapter, REPLAY_FLAGS),
+        # the class without the reference's VISUALIZE side effect (IncludeAll.h:32 — a debug aid that is on by default there): what bench.py times as `class_latency_ms`
+        "replay_novis": (os.path.join(CSRC, "mor_replay_novis"), adapter, REPLAY_FLAGS + ["-DMOR_NO_VISUALIZE"]),
     }
 
 
@@ -106,6 +111,11 @@ def build_hip_smalllist(force=False, verbose=False):
     return _build("hip_smalllist", force, verbose, lambda out, fl: [_hipcc()] + fl + ["-x", "hip"] + [os.path.join(CSRC, f) for f in HIP_SOURCES] + ["-o", out])
 
 
+def build_hip_experiments(force=False, verbose=False):
+    """exp/libmor_exp.so = HIP_FLAGS + -DMOR_EXPERIMENTS (MOR_EXP_DUP=<kernel id> launches a kernel twice: exp/shadow.sh)."""
+    return _build("hip_experiments", force, verbose, lambda out, fl: [_hipcc()] + fl + ["-x", "hip"] + [os.path.join(CSRC, f) for f in HIP_SOURCES] + ["-o", out])
+
+
 def build_synth(force=False, verbose=False):
     return _build("synth", force, verbose, lambda out, fl: ["gcc"] + fl + ["-o", out, os.path.join(CSRC, "mor_synth.c"), "-lm"])
 
@@ -116,9 +126,17 @@ def build_replay(force=False, verbose=False):
     return _build("replay", force, verbose, lambda out, fl: ["g++"] + fl + ["-I", INC, "-o", out] + srcs + ["-L", CSRC, "-lmor_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
 
 
+def build_replay_novis(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, "mor_adapter.cpp"), os.path.join(CSRC, "mor_replay.cpp")]
+    return _build("replay_novis", force, verbose, lambda out, fl: ["g++"] + fl + ["-I", INC, "-o", out] + srcs + ["-L", CSRC, "-lmor_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
+
+
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_synth(force, verbose), build_replay(force, verbose), build_hip_smalllist(force, verbose)
+    return build_hip(force, verbose), build_synth(force, verbose), build_replay(force, verbose), build_replay_novis(force, verbose), build_hip_smalllist(force, verbose)
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv, verbose=True)
+    if "--experiments" in sys.argv:
+        build_hip_experiments(force="--force" in sys.argv, verbose=True)
+    else:
+        build_all(force="--force" in sys.argv, verbose=True)

@@ -258,6 +258,12 @@ __global__ __launch_bounds__(FLT_T) void k_track_filter(MorDev d) {
   __shared__ unsigned l_mov[MOR_KCAP_MAX / 32];
   track_filter_body(d, blockIdx.x + d.s0, l_mov);
 }
+// one point of the filtered cloud into slot idx of a caller-provided buffer: packed (x,y,z,intensity), or — out_step32 — the 32-byte PointXYZI record of toPCLPointCloud2 (:690):
+// x@0 y@4 z@8 (1.0f @12) intensity@16, zeros behind it; a lane writes 32 consecutive bytes, a wave 2 KB
+__device__ __forceinline__ void out_store(float4 *dst, int idx, const float4 &p, int step32) {
+  if (step32) { st_stream(&dst[2 * (size_t)idx], make_float4(p.x, p.y, p.z, 1.0f)); st_stream(&dst[2 * (size_t)idx + 1], make_float4(p.w, 0.f, 0.f, 0.f)); }
+  else st_stream(&dst[idx], p);
+}
 __global__ __launch_bounds__(FLT_T) void k_out(MorDev d) {
   // the launch: B·g_out workgroups for the kept cloud points (shared out by the streams' tile counts; tiles go by ticket, so any share is correct), then,
   // with caller-provided pointers, B·tiles workgroups that copy the ground points
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(FLT_T) void k_out(MorDev d) {
   if (ground_wg) {
     const int tg = t2, G = d.info[s].G, base = tg * MOR_TILE;
     float4 *out = d.out_ptrs[s];
-    for (int i = base + threadIdx.x; i < min(base + MOR_TILE, G); i += FLT_T) st_stream(&out[n_keep + i], ld_stream(&og[d.Nmax + i]));
+    for (int i = base + threadIdx.x; i < min(base + MOR_TILE, G); i += FLT_T) out_store(out, n_keep + i, ld_stream(&og[d.Nmax + i]), d.out_step32);
     return;
   }
   if (t >= nto) return;
@@ -292,6 +298,7 @@ __global__ __launch_bounds__(FLT_T) void k_out(MorDev d) {
   for (int k = threadIdx.x; k < (K + 31) / 32; k += FLT_T) l_mov[k] = gm[k];
   __syncthreads();
   float4 *dst = d.out_ptrs ? d.out_ptrs[s] : og + (d.Nmax - n_keep);
+  const int step32 = d.out_ptrs ? d.out_step32 : 0;
   unsigned long long *desc = d.out_desc + (size_t)s * d.tiles_max;
   int t_prev = -1, ex = 0;   // this workgroup's previous tile and the kept points up to and including it
   while (t < nto) {
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(FLT_T) void k_out(MorDev d) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int i = base + it * 64 + lane_id();
-      if ((mk[it] >> lane_id()) & 1ull) st_stream(&dst[r + __popcll(mk[it] & lanemask_lt())], ld_stream(&d.cloud[so + i]));   // (the filtered cloud is the caller's; the cloud is not read again on the device)
+      if ((mk[it] >> lane_id()) & 1ull) out_store(dst, r + __popcll(mk[it] & lanemask_lt()), ld_stream(&d.cloud[so + i]), step32);   // (the filtered cloud is the caller's; the cloud is not read again on the device)
       r += __popcll(mk[it]);
     }
     t = __builtin_amdgcn_readfirstlane(l_ex[1]);

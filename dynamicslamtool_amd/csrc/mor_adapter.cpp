@@ -56,11 +56,26 @@ MovingObjectRemoval::MovingObjectRemoval(ros::NodeHandle, std::string config_pat
   // MOR_BIND_NUMA=1: keep the constructing thread (the one that will call push / filter) on the CPUs of the GPU's NUMA node — opt-in,
   // because a library should not move an application's threads unasked (5–6 % from the wrong socket)
   if (const char *bn = std::getenv("MOR_BIND_NUMA")) if (std::atoi(bn)) mor_bind_thread_to_device_node(dev ? std::atoi(dev) : 0, 0, 1);
+  // How the incoming blob reaches the device and the filtered cloud leaves it.  Round 6 built the page-locked forms and measured them through mor_replay (bench.py's
+  // class_latency_ms; one 120 000-point stream, median of 22 frames, MI355X host): pageable in + staged out 0.597 ms, bounce + direct 0.619, pageable + direct 0.610,
+  // zerocopy + direct 0.606, bounce + staged 0.626 — against 0.438 ms for the C ABI from page-locked memory: the adapter's copies are 0.16 ms on this host whichever way
+  // they are made (the device-side chain of thirteen launches is the latency), so the default stays the simplest form and the others are opt-in:
+  //   MOR_CLASS_INPUT=pageable (default)  the caller's memory as it is, staged by the driver
+  //   MOR_CLASS_INPUT=bounce              one memcpy into a page-locked buffer of the class, DMA from there
+  //   MOR_CLASS_INPUT=zerocopy            the same buffer, read by the split kernel itself over PCIe (no staging copy on the device)
+  //   MOR_CLASS_OUTPUT=staged (default)   16-byte points to a scratch vector, expanded to PointXYZI records on the host, copied to `output`
+  //   MOR_CLASS_OUTPUT=direct             the device writes the 32-byte records straight into `output.data` (page-locked in place), ONE host copy to the caller's cloud
+  if (const char *im = std::getenv("MOR_CLASS_INPUT")) input_mode_ = !std::strcmp(im, "bounce") ? 1 : !std::strcmp(im, "zerocopy") ? 2 : 0;
+  if (const char *om = std::getenv("MOR_CLASS_OUTPUT")) output_direct_ = !std::strcmp(om, "direct");
   ctx_ = mor_create(&params_, n_bad, n_good, cap ? std::strtoull(cap, nullptr, 10) : (1ull << 20), dev ? std::atoi(dev) : 0, &err);
   if (!ctx_) { std::cerr << "MovingObjectRemoval: mor_create failed (" << err << "): " << mor_last_error() << std::endl; std::exit(1); }
 }
 
-MovingObjectRemoval::~MovingObjectRemoval() { mor_destroy(ctx_); }
+MovingObjectRemoval::~MovingObjectRemoval() {
+  if (out_reg_) mor_host_unregister(out_reg_);
+  if (in_pinned_) mor_host_free(in_pinned_);
+  mor_destroy(ctx_);
+}
 
 // same file format and the same echo as the reference's setVariables (.cpp:698-864): `key:value`,
 // '#' comment lines and lines shorter than 3 characters skipped, every ':' dropped, no trimming;
@@ -125,7 +140,17 @@ void MovingObjectRemoval::pushRawCloudAndPose(pcl::PCLPointCloud2 &cloud, geomet
     records = rows_.data();
   }
   const double p[7] = {pose.position.x, pose.position.y, pose.position.z, pose.orientation.x, pose.orientation.y, pose.orientation.z, pose.orientation.w};
-  int rc = mor_push(ctx_, records, n, cloud.point_step, off[0], off[1], off[2], off[3], p);
+  mor_cloud_view view; view.data = records; view.n_points = n; view.point_step = cloud.point_step; view.off_x = off[0]; view.off_y = off[1]; view.off_z = off[2]; view.off_intensity = off[3]; view.on_device = 0;
+  const size_t blob_bytes = (size_t)(n * cloud.point_step);
+  if (input_mode_ != 0 && blob_bytes) {   // page-locked bounce buffer: grows to the largest blob seen
+    if (in_cap_ < blob_bytes) {
+      if (in_pinned_) mor_host_free(in_pinned_);
+      in_cap_ = blob_bytes + blob_bytes / 4; in_pinned_ = static_cast<uint8_t *>(mor_host_alloc(in_cap_));
+      if (!in_pinned_) { in_cap_ = 0; std::cerr << "MovingObjectRemoval: no page-locked memory for the input (" << mor_last_error() << "), using the caller's" << std::endl; }
+    }
+    if (in_pinned_) { std::memcpy(in_pinned_, records, blob_bytes); view.data = in_pinned_; view.on_device = input_mode_ == 2 ? 1 : 0; }
+  }
+  int rc = mor_push_batch(ctx_, &view, p);
   if (rc != MOR_OK) { std::cerr << "MovingObjectRemoval: mor_push failed (" << rc << "): " << mor_last_error() << std::endl; return; }
   push_ok_ = true;
   in_header_ = cloud.header;   // raw_cloud->header (fromPCLPointCloud2 copies it, .cpp:523); filterCloud's outputs carry it (.cpp:690-691)
@@ -138,6 +163,7 @@ void MovingObjectRemoval::pushRawCloudAndPose(pcl::PCLPointCloud2 &cloud, geomet
     expand(scratch_.data(), c.n_clustered, cloud.data);
     describe_xyzi<pcl::PCLPointCloud2, pcl::PCLPointField>(cloud, c.n_clustered);
     cloud.header = pcl::PCLHeader();   // cluster_collection is a fresh PointCloud: default header (.cpp:554)
+    if (out_reg_ && output.data.capacity() < cloud.data.size()) { mor_host_unregister(out_reg_); out_reg_ = nullptr; out_dev_ = nullptr; out_reg_bytes_ = 0; }   // (the assignment below would move the registered buffer)
     output.data = cloud.data;
     describe_xyzi<sensor_msgs::PointCloud2, sensor_msgs::PointField>(output, c.n_clustered);
     output.header = std_msgs::Header();   // fromPCL copies the (default) header (.cpp:555) …
@@ -218,17 +244,41 @@ bool MovingObjectRemoval::filterCloud(pcl::PCLPointCloud2 &out_cloud, std::strin
   // malformed blob, GPU error): the frame never reached the device, so there is nothing to filter — report it
   // instead of re-emitting the previous frame's cloud
   if (!push_ok_) { std::cerr << "MovingObjectRemoval: filterCloud without a successful pushRawCloudAndPose" << std::endl; return false; }
-  scratch_.resize(4 * (size_t)last_n_ + 4);
   uint64_t n = 0;
-  int rc = mor_filter(ctx_, scratch_.data(), &n);
-  if (rc != MOR_OK) { std::cerr << "MovingObjectRemoval: mor_filter failed (" << rc << "): " << mor_last_error() << std::endl; return false; }
-  expand(scratch_.data(), n, out_cloud.data);   // toPCLPointCloud2 (.cpp:690)
+  bool direct = false;
+  if (output_direct_ && last_n_) {
+    // toPCLPointCloud2 (.cpp:690) on the device: k_out writes the 32-byte PointXYZI records straight into `output.data` — the class's own vector, page-locked
+    // and mapped for the device while its buffer stays where it is (re-registered when it has grown or the caller has moved it away) — so there is no 16-byte
+    // intermediate, no expansion loop and ONE host copy (output → out_cloud) instead of two
+    const size_t need = (size_t)last_n_ * kStep;
+    if (out_reg_ != output.data.data() || out_reg_bytes_ < need || output.data.capacity() < need) {
+      if (out_reg_) { mor_host_unregister(out_reg_); out_reg_ = nullptr; out_dev_ = nullptr; out_reg_bytes_ = 0; }
+      if (output.data.capacity() < need) { output.data.clear(); output.data.reserve(need + need / 4); }
+      void *dp = nullptr;
+      if (mor_host_register(output.data.data(), output.data.capacity(), &dp) == MOR_OK) { out_reg_ = output.data.data(); out_dev_ = dp; out_reg_bytes_ = output.data.capacity(); }
+    }
+    if (out_reg_) {
+      output.data.resize(need);   // (within the capacity: the buffer does not move; what grows is zero-filled, a few per cent of the cloud from one frame to the next)
+      void *o = out_dev_;
+      int rc = mor_filter_batch_ex(ctx_, &o, 1, &n, kStep);
+      if (rc != MOR_OK) { std::cerr << "MovingObjectRemoval: mor_filter failed (" << rc << "): " << mor_last_error() << std::endl; return false; }
+      output.data.resize((size_t)n * kStep);
+      out_cloud.data.assign(output.data.begin(), output.data.end());   // pcl_conversions::fromPCL (.cpp:691) copies in the other direction; both hold the records afterwards either way
+      direct = true;
+    }
+  }
+  if (!direct) {
+    scratch_.resize(4 * (size_t)last_n_ + 4);
+    int rc = mor_filter(ctx_, scratch_.data(), &n);
+    if (rc != MOR_OK) { std::cerr << "MovingObjectRemoval: mor_filter failed (" << rc << "): " << mor_last_error() << std::endl; return false; }
+    expand(scratch_.data(), n, out_cloud.data);   // toPCLPointCloud2 (.cpp:690)
+    output.data = out_cloud.data;                 // pcl_conversions::fromPCL (.cpp:691)
+  }
   describe_xyzi<pcl::PCLPointCloud2, pcl::PCLPointField>(out_cloud, n);
   // f_cloud is created empty and filled by ExtractIndices::filter(f_cloud), which copies the header of its input cloud
   // cb->cloud (= the incoming cloud's header, carried through fromPCLPointCloud2 and the filters); toPCLPointCloud2
   // (.cpp:690) and fromPCL (.cpp:691) pass it on, .cpp:692 then overwrites frame_id
   out_cloud.header = in_header_;
-  output.data = out_cloud.data;                 // pcl_conversions::fromPCL (.cpp:691)
   describe_xyzi<sensor_msgs::PointCloud2, sensor_msgs::PointField>(output, n);
   pcl_conversions::fromPCL(in_header_, output.header);   // seq, stamp.fromNSec(pcl stamp [µs] · 1000), frame_id — integer arithmetic, as .cpp:691 does
   output.header.frame_id = f_id;                // .cpp:692

@@ -220,6 +220,7 @@ struct MorDev {
   int *tr_match;             // [B][MOR_TR_MAXT+1]  latest filterCloud: number of tracked centroids its loop visited, then the cluster each was matched to, in mo_vec order (the reference's bounding-box markers, :641)
   int moving_confidence, static_confidence; float leave_off, catch_up;
   float4 *const *out_ptrs;   // [B] or null
+  int out_step32;            // caller-provided output pointers receive PCL's 32-byte PointXYZI records (x, y, z, 1.0f | intensity, 0, 0, 0: what toPCLPointCloud2<PointXYZI> serialises, :690) instead of packed 16-byte points — the class adapter's output, written by k_out straight into page-locked caller memory
   // ---- pinned host mirrors written by the device (zero-copy summaries)
   MorFrameInfo *h_info;      // [B]
   float4 *h_centroid;        // [B][Kcap]

@@ -430,8 +430,8 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   //      (mor_push_batch).  288 GB of HBM3E make that cheap: ≈ 4 GB per copy at B = 64 × 120 000 points.
   const size_t R1 = (size_t)std::max(d.g.nrows, d.gv.nrows) + 1;
   std::vector<float> z0(B, p->gp_limit);   // crop-box variant: the clustering grid starts at gp_limit for every stream
-  ok = dalloc(b, d.gh_hint, B) && hipMemset(d.gh_hint, 0, B * sizeof(int)) == hipSuccess;
-  ok = ok && dalloc(b, d.g2_pred, B) && hipMemsetD32((hipDeviceptr_t)d.g2_pred, 0x7fffffff, B) == hipSuccess;   // (one for all copies: the latest mode bin of the voxel ground variant — the next frames' bet)   // (one for all copies: a stream's cell count of the latest grid build, the next build's tier hint)
+  ok = dalloc(b, d.gh_hint, B) && hipMemset(d.gh_hint, 0, B * sizeof(int)) == hipSuccess;   // (one for all copies: a stream's cell count of the latest grid build, the next build's tier hint)
+  ok = ok && dalloc(b, d.g2_pred, B) && hipMemsetD32((hipDeviceptr_t)d.g2_pred, 0x7fffffff, B) == hipSuccess;   // (one for all copies: the latest mode bin of the voxel ground variant — the next frames' bet)
   if (!ok) return fail(set_error(MOR_ERR_HIP, "device allocation failed (B=%d)", d.B));
   for (int c = 0; c < (int)b->pipe_depth; ++c) {
     MorDev o = d; MorStreamArgs *dargs = nullptr;
@@ -544,7 +544,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
     d.cg_fused = (maxocc * 11ull / 10 <= MOR_CGS_FCAP && !getenv("MOR_CG_UNFUSED")) ? 1 : 0;   // (a stream beyond it runs the merge on global-memory arrays: correct, slow — hence the separate kernel when that is foreseeable)
     // (table tier of k_gridhash: −1 = every stream by its own cell count of the latest build; MOR_GH_TIER forces the tier all streams start with)
   }
-  d.cur = (int)(k % b->n_slots); d.prev = (int)((k + b->n_slots - 1) % b->n_slots); d.has_prev = k > 0; d.out_ptrs = nullptr; d.frame_no = (int)k;
+  d.cur = (int)(k % b->n_slots); d.prev = (int)((k + b->n_slots - 1) % b->n_slots); d.has_prev = k > 0; d.out_ptrs = nullptr; d.out_step32 = 0; d.frame_no = (int)k;
   {  // workgroups for the cloud-sized kernels: 1.25 × the largest cloud / cluster set the device last reported
     uint32_t mx = 0;
     for (int s = 0; s < B; ++s) mx = std::max(mx, std::max(d.h_info[s].M, d.h_info[s].C));
@@ -601,9 +601,12 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   return rc;
 }
 
-int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t *n_out) {
+int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t *n_out) { return mor_filter_batch_ex(b, out, out_on_device, n_out, 16); }
+int mor_filter_batch_ex(mor_batch *b, void *const *out, int out_on_device, uint64_t *n_out, uint32_t out_point_step) {
   if (!b) return set_error(MOR_ERR_INVALID, "null batch");
   if (b->frame == 0) return set_error(MOR_ERR_NOT_READY, "filterCloud before the first pushRawCloudAndPose");
+  if (out_point_step != 16 && out_point_step != 32) return set_error(MOR_ERR_INVALID, "out_point_step must be 16 (packed xyzi) or 32 (PointXYZI records)");
+  if (out_point_step == 32 && !(out && out_on_device)) return set_error(MOR_ERR_INVALID, "32-byte records are written by the device itself: pass device-accessible pointers (device memory, or page-locked / registered host memory) with out_on_device = 1");
   HIP_TRY(hipSetDevice(b->device));
   MorDev d = b->d; const int B = d.B;
   const uint64_t k = b->frame - 1;
@@ -611,7 +614,7 @@ int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t
   //  frame walks mo_vec again and moves the confidences again)
   d.filter_epoch = (unsigned)(++b->n_filter_calls); if (d.filter_epoch == 0) d.filter_epoch = (unsigned)(++b->n_filter_calls);
   b->filtered = true;
-  d.out_ptrs = nullptr;
+  d.out_ptrs = nullptr; d.out_step32 = out_point_step == 32 ? 1 : 0;
   hipStream_t fs = b->lane_stream(k);   // behind the frame's push
   // (the tracking step in front of this one — the frame's push, or an earlier filterCloud of the same frame — ran on this very stream)
   // Asynchronous mode with HOST output pointers: the output kernels assemble every stream's filtered cloud in a device staging area of
@@ -898,6 +901,16 @@ void *mor_device_alloc(int device, size_t bytes) { void *p = nullptr; if (hipSet
 void mor_device_free(int device, void *p) { if (hipSetDevice(device) == hipSuccess) hipFree(p); }
 void *mor_host_alloc(size_t bytes) { void *p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { set_error(MOR_ERR_HIP, "hipHostMalloc(%zu) failed", bytes); return nullptr; } return p; }
 void mor_host_free(void *p) { if (p) hipHostFree(p); }
+// page-locks caller-owned host memory (a std::vector's buffer, say) and maps it for the device: *device_ptr is what kernels and out_on_device = 1 pointers use
+int mor_host_register(void *p, size_t bytes, void **device_ptr) {
+  if (!p || !bytes || !device_ptr) return set_error(MOR_ERR_INVALID, "null argument");
+  HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterMapped));
+  void *dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || !dp) { hipHostUnregister(p); return set_error(MOR_ERR_HIP, "hipHostGetDevicePointer failed for registered memory"); }
+  *device_ptr = dp;
+  return MOR_OK;
+}
+int mor_host_unregister(void *p) { if (!p) return MOR_OK; HIP_TRY(hipHostUnregister(p)); return MOR_OK; }
 int mor_device_upload(int device, void *dst, const void *src, size_t bytes) { HIP_TRY(hipSetDevice(device)); HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return MOR_OK; }
 int mor_device_download(int device, void *dst, const void *src, size_t bytes) { HIP_TRY(hipSetDevice(device)); HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return MOR_OK; }
 int mor_device_synchronize(int device) { HIP_TRY(hipSetDevice(device)); HIP_TRY(hipDeviceSynchronize()); return MOR_OK; }

@@ -100,7 +100,8 @@ static void mor_launch_boxes(const MorDev &d, hipStream_t st, MorLaunchTimer *tm
 static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLaunchTimer *tm) {
   const dim3 gB(d.B);
   MorDev da = d; da.gmode = 1; da.g = d.gv; da.cloud = d.rawbuf; da.cell_passes = d.voxel_passes; da.tiles_m = d.tiles; da.use_hash = 0;
-  da.gnz_out = d.gnz; da.gnz = d.vnz; da.vnz_out = d.vnz; da.cg_nz = d.g.nz; da.cg_inv_cs = d.g.inv_cs;   // (pass A's kernels behind the split see the lattice with the stream's own layers through stream_grid) da.scell = nullptr;   // (nobody reads the cell of a position of the voxel-ordered cloud)
+  da.gnz_out = d.gnz; da.gnz = d.vnz; da.vnz_out = d.vnz; da.cg_nz = d.g.nz; da.cg_inv_cs = d.g.inv_cs;   // (pass A's kernels behind the split see the lattice with the stream's own layers through stream_grid)
+  da.scell = nullptr;   // (nobody reads the cell of a position of the voxel-ordered cloud: k_heads_scatter skips that store)
   da.skey = d.rkeys[da.cell_passes & 1]; da.sidx = d.rvals[da.cell_passes & 1];
   if (sub == 0) {
     // (z range, ground flags and the queue of big voxels need no clearing launches: their last readers of the previous frame on this copy

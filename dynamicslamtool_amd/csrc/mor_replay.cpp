@@ -55,6 +55,10 @@ int main(int argc, char **argv) {
     bool ok = mor.filterCloud(cloud, "/filtered");
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (!ok) return 1;
+    if (std::getenv("MOR_REPLAY_NO_OUTPUT")) {   // timing runs (bench.py's class_latency_ms): the per-frame line only
+      std::cout << "frame " << (i - 4) << ": " << cloud.width << " pts in filtered cloud, " << ms << " ms" << std::endl;
+      continue;
+    }
     // "publish": unpack the 32-byte PointXYZI records of `output` back to packed xyzi
     const size_t n = mor.output.width;
     std::vector<float> packed(4 * n);

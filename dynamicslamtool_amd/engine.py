@@ -14,9 +14,9 @@ MOR_NO_FIELD = 0xFFFFFFFF
 # every symbol include/mor_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "mor_sizeof_params", "mor_last_error", "mor_batch_create", "mor_batch_destroy", "mor_batch_streams", "mor_push_batch",
-    "mor_filter_batch", "mor_batch_set_async", "mor_batch_wait", "mor_get_output_device", "mor_create", "mor_push", "mor_filter", "mor_destroy", "mor_get_counts",
+    "mor_filter_batch", "mor_filter_batch_ex", "mor_batch_set_async", "mor_batch_wait", "mor_get_output_device", "mor_create", "mor_push", "mor_filter", "mor_destroy", "mor_get_counts",
     "mor_get_labels", "mor_get_ground_indices", "mor_get_clusters", "mor_get_centroids", "mor_get_detection", "mor_get_boxes",
-    "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_get_stage_counts", "mor_device_alloc", "mor_device_free", "mor_host_alloc", "mor_host_free",
+    "mor_get_correspondences", "mor_get_tracks", "mor_get_cluster_collection", "mor_get_stage_counts", "mor_device_alloc", "mor_device_free", "mor_host_alloc", "mor_host_free", "mor_host_register", "mor_host_unregister",
     "mor_device_upload", "mor_device_download", "mor_device_synchronize", "mor_device_count", "mor_get_last_timing",
     "mor_kernel_timing_enable", "mor_kernel_timing_read", "mor_get_frame_log", "mor_debug_read", "mor_debug_config", "mor_get_markers", "mor_kernel_timeline_read",
     "mor_device_numa_node", "mor_bind_thread_to_device_node", "mor_build_hash", "mor_get_moving_clusters",
@@ -33,6 +33,16 @@ class Counts(C.Structure):
                 ("n_clusters", C.c_uint32), ("n_clustered", C.c_uint32), ("n_corr", C.c_uint32), ("n_tracks", C.c_uint32)]
 
 
+_PROFILER_ENV = ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCP_TOOL_LIB", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD")
+
+
+def _profiler_preload(env=None):
+    """True when this process runs under a profiler / tool preload (rocprofv3 exports ROCP_TOOL_LIBRARIES, LD_PRELOAD and ROCPROF* / ROCPROFILER_* variables):
+    the GPU may then be initialised already, and no child compiler may be started from here."""
+    env = os.environ if env is None else env
+    return any(env.get(k) for k in _PROFILER_ENV) or any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCPROFV3_")) for k in env)
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -40,9 +50,12 @@ def lib():
             raise RuntimeError("libmor_hip.so is not built (python -m dynamicslamtool_amd.build); there is no CPU fallback")
         if not os.environ.get("MOR_HIP_LIB") and not os.environ.get("MOR_ALLOW_STALE_LIB"):
             from . import build as _build
-            if _build.stale("hip") and os.path.exists(_build._hipcc()) and not os.environ.get("MOR_NO_AUTOBUILD"):
-                # bench.py, exp/pmc_run.py and profiles/collect.sh come through here without having called build(): rebuild (seconds when only the hash differs,
-                # a no-op for whoever comes second — ranks of one job take the lock in turn) rather than turn every edit into a RuntimeError
+            if _build.stale("hip") and os.path.exists(_build._hipcc()) and not os.environ.get("MOR_NO_AUTOBUILD") and not _profiler_preload():
+                # bench.py and the exp/ scripts come through here without having called build(): rebuild (seconds when only the hash differs,
+                # a no-op for whoever comes second — ranks of one job take the lock in turn) rather than turn every edit into a RuntimeError.
+                # NEVER under a profiler: rocprofv3's preloaded tool library initialises the GPU in every process that inherits its environment, and hipcc is a
+                # chain of exec hops (sh -c, clang, lld) — a GPU-initialised process replacing its program takes the whole box down on this pool.  There the
+                # loud RuntimeError below stays; profiles/collect.sh and the exp/pmc_*.sh scripts build before their first rocprofv3 line.
                 import fcntl
                 with open(os.path.join(_HERE, "csrc", ".build.lock"), "w") as lk:
                     fcntl.flock(lk, fcntl.LOCK_EX)
@@ -63,6 +76,7 @@ def lib():
         L.mor_batch_streams.argtypes = [vp]
         L.mor_push_batch.argtypes = [vp, vp, vp]
         L.mor_filter_batch.argtypes = [vp, vp, i32, vp]
+        L.mor_filter_batch_ex.argtypes = [vp, vp, i32, vp, C.c_uint32]
         L.mor_batch_set_async.argtypes = [vp, i32]
         L.mor_batch_wait.argtypes = [vp]
         L.mor_get_output_device.restype = vp
@@ -87,6 +101,8 @@ def lib():
         L.mor_host_alloc.restype = vp
         L.mor_host_alloc.argtypes = [C.c_size_t]
         L.mor_host_free.argtypes = [vp]
+        L.mor_host_register.argtypes = [vp, C.c_size_t, vp]
+        L.mor_host_unregister.argtypes = [vp]
         L.mor_device_upload.argtypes = [i32, vp, vp, C.c_size_t]
         L.mor_device_download.argtypes = [i32, vp, vp, C.c_size_t]
         L.mor_device_synchronize.argtypes = [i32]
@@ -296,6 +312,14 @@ class MorBatch:
         n_out = (C.c_uint64 * self.B)()
         ptrs = (C.c_void_p * self.B)(*[o.ctypes.data for o in outs])
         _check(lib().mor_filter_batch(self._h, C.addressof(ptrs), 0, C.addressof(n_out)))
+        return [int(x) for x in n_out]
+
+    def filter_records32(self, outs):
+        """filterCloud with the DEVICE writing PCL's 32-byte PointXYZI records (mor_filter_batch_ex, out_point_step = 32) straight into device-accessible
+        memory: one page-locked array per stream (HostBuffer.array, room for the stream's input point count x 32 bytes); returns the point counts."""
+        n_out = (C.c_uint64 * self.B)()
+        ptrs = (C.c_void_p * self.B)(*[o if isinstance(o, int) else o.ctypes.data for o in outs])
+        _check(lib().mor_filter_batch_ex(self._h, C.addressof(ptrs), 1, C.addressof(n_out), 32))
         return [int(x) for x in n_out]
 
     # ---- read-backs

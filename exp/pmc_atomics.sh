@@ -1,6 +1,8 @@
 #!/bin/bash
 # L2 atomics per kernel launch (TCC_ATOMIC_sum) of a workload: pmc_atomics.sh <workload>.  Found k_classify's 30 000 atomics per step on four cache lines (round 5).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python -m dynamicslamtool_amd.build || exit 1   # BEFORE the first rocprofv3 line: no compiler may start under the profiler's preload (engine.lib() refuses to autobuild there)
+export MOR_NO_AUTOBUILD=1
 W=${1:-hdl64_b64}
 rm -rf gpurun_out/atom_$W
 rocprofv3 --kernel-trace --pmc TCC_ATOMIC_sum TCC_REQ_sum --output-format csv -d gpurun_out/atom_$W -o a -- python3 exp/pmc_run.py $W 3 > /dev/null 2> gpurun_out/atom_$W.err

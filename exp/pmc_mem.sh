@@ -1,6 +1,8 @@
 #!/bin/bash
 # Memory-pipeline counters per kernel of the headline leg (TA / TCP busy, L1 accesses and latency, address translation): bash exp/pmc_mem.sh  (through gpurun)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python -m dynamicslamtool_amd.build || exit 1   # BEFORE the first rocprofv3 line: no compiler may start under the profiler's preload (engine.lib() refuses to autobuild there)
+export MOR_NO_AUTOBUILD=1
 OUT=gpurun_out/pmc_mem; rm -rf $OUT; mkdir -p $OUT
 PMC="python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-extras"
 i=0

@@ -59,6 +59,10 @@ class MovingObjectRemoval {
   pcl::PCLHeader in_header_;        // header of the latest incoming cloud
   std::vector<float> scratch_;
   std::vector<uint8_t> rows_;       // de-padded rows of an organised cloud
+  uint8_t *in_pinned_ = nullptr; size_t in_cap_ = 0;   // page-locked bounce buffer of the incoming blob (MOR_CLASS_INPUT)
+  int input_mode_ = 0;              // 0 pageable (the caller's memory as it is), 1 bounce + DMA, 2 bounce + the split kernel reads it over PCIe
+  bool output_direct_ = false;      // MOR_CLASS_OUTPUT=direct: the device writes the PointXYZI records straight into `output.data` (page-locked while its buffer stays in place)
+  uint8_t *out_reg_ = nullptr; void *out_dev_ = nullptr; size_t out_reg_bytes_ = 0;   // the registered range of output.data and its device address
 #ifdef MOR_WITH_ROS_PCL
   // ---- ROS plumbing of the reference's constructor (.cpp:372-385) and of its internal-sync callback (.cpp:393-413)
   ros::NodeHandle nh_;              // (the reference keeps a reference to its by-value constructor argument, header :131; a copy here)

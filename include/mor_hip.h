@@ -95,6 +95,11 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
  * out_on_device: 0 = host pointers, 1 = device pointers.  out may be NULL: results then stay in the
  * batch's own device buffers (mor_get_output_device). */
 int mor_filter_batch(mor_batch *b, void *const *out, int out_on_device, uint64_t *n_out);
+/* The same with a choice of the output record: out_point_step = 16 is mor_filter_batch; 32 makes the DEVICE write PCL's PointXYZI records — x@0 y@4 z@8 (1.0f @12)
+ * intensity@16, zeros behind it: what toPCLPointCloud2<PointXYZI> serialises at :690 — straight into out[i], which must then be device-accessible memory
+ * (out_on_device = 1: device memory, or page-locked host memory of mor_host_alloc / mor_host_register through its device pointer) of n_in x 32 bytes.  This is the class
+ * adapter's output path: no 16-byte intermediate, no expansion loop on the host. */
+int mor_filter_batch_ex(mor_batch *b, void *const *out, int out_on_device, uint64_t *n_out, uint32_t out_point_step);
 
 /* Asynchronous mode (off by default).  With it on, mor_push_batch and mor_filter_batch (called with n_out == NULL) only
  * enqueue their work — host-resident input blobs are staged by copies that run beside the kernels of the frames in
@@ -175,6 +180,10 @@ void mor_device_free(int device, void *p);
  * memory works too but is staged by the driver at a fraction of it */
 void *mor_host_alloc(size_t bytes);
 void mor_host_free(void *p);
+/* page-lock caller-owned host memory (the buffer of a std::vector, say) and map it for the device; *device_ptr is the address kernels and out_on_device = 1 pointers
+ * use for it.  Unregister before the memory is freed. */
+int mor_host_register(void *p, size_t bytes, void **device_ptr);
+int mor_host_unregister(void *p);
 int mor_device_upload(int device, void *dst, const void *src, size_t bytes);
 int mor_device_download(int device, void *dst, const void *src, size_t bytes);
 int mor_device_synchronize(int device);

@@ -12,6 +12,8 @@
 set -e
 R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python -m dynamicslamtool_amd.build   # BEFORE the first rocprofv3 line: no compiler may start under the profiler's preload (engine.lib() refuses to autobuild there and fails loudly on a stale library)
+export MOR_NO_AUTOBUILD=1
 OUT=gpurun_out/prof_$R
 rm -rf $OUT; mkdir -p $OUT profiles
 HEAD_ID=$(cat .git_head 2>/dev/null || echo unknown)

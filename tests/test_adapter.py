@@ -53,9 +53,15 @@ def test_config_errors_follow_the_reference(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("io", ["default", "page-locked"])
 @pytest.mark.parametrize("method", [1, 2])
-def test_replay_matches_oracle(tmp_path, method):
+def test_replay_matches_oracle(tmp_path, method, io):
+    """io = page-locked: the adapter's opt-in forms — the blob through a page-locked bounce buffer (method 1: read by the split kernel over PCIe; method 2: by DMA), the
+    PointXYZI records written by the device straight into `output.data` — must leave the caller with the same bytes as the default (pageable in, host-side expansion)."""
     from oracle.oracle import Oracle
+    env = dict(os.environ)
+    if io == "page-locked":
+        env.update(MOR_CLASS_INPUT="zerocopy" if method == 1 else "bounce", MOR_CLASS_OUTPUT="direct")
     cfg = tmp_path / "MOR_config.txt"
     cfg.write_text(_config_text(method=method))
     frames = small_stream(1, n_frames=8, with_nan=True)
@@ -66,7 +72,7 @@ def test_replay_matches_oracle(tmp_path, method):
             pts.astype(np.float32).tofile(fn)
             files.append(str(fn))
             pf.write(" ".join(repr(float(v)) for v in pose) + "\n")
-    r = subprocess.run([REPLAY, str(cfg), str(tmp_path / "poses.txt"), str(tmp_path)] + files, capture_output=True, text=True)
+    r = subprocess.run([REPLAY, str(cfg), str(tmp_path / "poses.txt"), str(tmp_path)] + files, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "method_choice:%d" % method in r.stdout   # the echo of setVariables
     p_ = scene_params(method_choice=method)

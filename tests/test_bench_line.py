@@ -37,7 +37,9 @@ def _full(world=1, workloads=True):
         "collective": "none", "first_seed_per_rank": [2000 + 64 * r for r in range(world)], "self_launched": True, "devices_visible": 8, "ranks_per_device": 1, "host_numa_node_of_gpu": 1,
         "host_cores_bound_rank0": 128, "value_runs": {"n": 5, "min": 12345678.9, "median": 12345678.9, "max": 12345678.9}, "per_rank_frame_pairs_per_s": [1234567.8] * world,
         "per_rank_frame_pairs_per_s_min_max": [1234567.8, 1234567.8], "device_ms_per_step": 12345.6789, "sync_frame_pairs_per_s": 1234567.8, "e2e_host_frame_pairs_per_s": 1234567.89,
-        "e2e_host_sync_ms_per_step": {"push": 12345.678, "filter": 12345.678}, "e2e_host_async_frame_pairs_per_s": 1234567.89, "e2e_host_async_equals_sync": False, "latency_b1_ms": 12345.678,
+        "e2e_host_sync_ms_per_step": {"push": 12345.678, "filter": 12345.678}, "e2e_host_async_frame_pairs_per_s": 1234567.89, "e2e_host_async_equals_sync": False, "e2e_host_async_per_rank_min_max": [1234567.8, 1234567.8] if world > 1 else None, "latency_b1_ms": 12345.678, "class_latency_ms": 12345.678, "class_latency_visualize_ms": 12345.678,
+        "class_latency": {"novis": {w: {"median_ms": 12345.678, "min_ms": 12345.678, "max_ms": 12345.678, "frames": 22} for w in ("hdl64_b64", "hdl64_urban_b64")}, "visualize": {"hdl64_b64": {"median_ms": 12345.678}}},
+        "value_long": {"value": 12345678.9, "steps": 40, "runs": [12345678.9] * 3},
         "algorithmic_bytes_per_frame_pair": 123456789, "stage_totals": {"n_occ": 123456789, "n_tier1b": 123456789, "n_defer": 123456789, "C_prev": 123456789},
         "stream0": {"T": 1000000, "M": 1000000, "G": 1000000, "K": 16384, "C": 1000000, "pairs": 16384, "tracks": 32768, "tracks_all_streams_min_median_max": [32768] * 3},
         "sanity": {"frames_checked": 64, "frames": [99936, 99999], "streams": 64, "fields": list(bench.LOG_KEYS), "async_equals_sync": False, "mismatches": [(99999, 63)] * 8,
@@ -47,7 +49,7 @@ def _full(world=1, workloads=True):
                          "per_stream_rate_min_median_max": [1234.567] * 3, "host_cpus": 384},
         "cpu_baseline_all_cores": {"value": 12345.67, "unit": "frame-pairs/s", "cores": 384, "kind": "port", "sample": "s" * 330, "wall_s": 12345.67, "frame_pairs": 192},
         "workloads": wl if workloads else "skipped: world>1",
-        "kitti_density": {"workload": "hdl64_urban_b64", "value": 1234567.8, "unit": "frame-pairs/s", "steps": 40, "ratio_to_value": 0.123, "non_ground_share_stream0": 0.123, "job_frac": 0.12345, "wasted": 12.345},
+        "kitti_density": {"workload": "hdl64_urban_b64", "value": 1234567.8, "unit": "frame-pairs/s", "steps": 40, "ratio_to_value": 0.123, "ratio_basis": "median of three 40-step legs of either workload (value_long), like with like", "non_ground_share_stream0": 0.123, "job_frac": 0.12345, "wasted": 12.345},
         "kernels": {k: {"ms_total": 12345.6789, "launches": 123456, "avg_us": 12345.67} for k in KERNELS}, "kernels_alone_avg_us": {k: 12345.67 for k in KERNELS},
         "setup_s": 1234.56, "legs_failed": ["cpu_baseline", "latency_b1", "e2e_host"],
     }
@@ -70,6 +72,11 @@ def test_worst_case_line_stays_under_the_limit_and_keeps_what_the_driver_reads()
             assert k in d["cpu_baseline"], k
         assert d["sanity"]["ok"] is False and "mismatches" not in d["sanity"]
         assert d["detail"] == "bench_detail.json"
+        # round 6: the headline timed like the secondary legs (the basis of kitti_density.ratio_to_value), the latency through the drop-in class, and — at N > 1 — the
+        # PCIe-inclusive rate of the job with its per-rank spread all travel in the line; the per-workload class-latency table stays in the detail file
+        assert d["value_long"]["steps"] == 40 and len(d["value_long"]["runs"]) == 3 and d["class_latency_ms"] == 12345.678 and "class_latency" not in d
+        assert d["kitti_density"]["ratio_basis"].startswith("median of three 40-step legs")
+        assert ("e2e_host_async_per_rank_min_max" in d) == (world > 1) and d["e2e_host_async_frame_pairs_per_s"] == 1234567.89
         if wl:
             assert set(d["workloads"]) == set(bench.WORKLOADS) and set(d["workloads"]["os128_b64"]) == {"value", "ms_per_step", "frac", "job_frac", "wasted", "ok"}
         else:

@@ -34,6 +34,24 @@ def test_two_ranks_share_the_visible_devices(tmp_path):
     assert d["detail"] == str(tmp_path / "detail.json") and "per_kernel" in json.load(open(d["detail"]))["roofline"]
 
 
+def test_two_ranks_run_their_host_resident_legs_side_by_side(tmp_path):
+    """SURVEY §8e: "report device-resident and end-to-end separately" — at N > 1 too.  Two ranks, each with a child process of its own for the PCIe-inclusive legs
+    (started before the rank touches the GPU), the children timing their legs side by side behind a barrier of their own gloo group: the line carries the job's
+    end-to-end rate (sum over the ranks) and the per-rank min / max beside the device-resident `value`, and every rank's asynchronous leg is checked against its synchronous replay."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--allow-shared-device", "--streams", "4", "--steps", "4", "--warmup", "2", "--no-extras", "--with-e2e", "--no-cpu-baseline",
+                        "--detail", str(tmp_path / "detail.json")], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) <= 4096
+    d = json.loads(lines[0])
+    lo, hi = d["e2e_host_async_per_rank_min_max"]
+    assert d["ranks"] == 2 and 0 < lo <= hi
+    assert 2 * lo * 0.999 <= d["e2e_host_async_frame_pairs_per_s"] <= 2 * hi * 1.001 and d["e2e_host_frame_pairs_per_s"] > 0
+    assert d["e2e_host_async_equals_sync"] is True and d["sanity"]["ok"] and json.load(open(d["detail"]))["sanity"]["e2e_host_async_equals_sync"] is True
+    assert not d.get("legs_failed")
+
+
 def test_more_ranks_than_devices_is_refused_without_the_flag(tmp_path):
     """`--gpus N` on a box with fewer GPUs must not print an N-GPU line (VERDICT round 4, weak #9)."""
     from dynamicslamtool_amd import engine

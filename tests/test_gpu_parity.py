@@ -1520,3 +1520,41 @@ def test_asynchronous_mode_with_host_resident_clouds_and_outputs(contiguous):
     b.close()
     for x in keep:
         x.free()
+
+
+def test_filter_cloud_as_pointxyzi_records_written_by_the_device():
+    """mor_filter_batch_ex with out_point_step = 32: the DEVICE writes what toPCLPointCloud2<PointXYZI> serialises (.cpp:690) — x@0 y@4 z@8, 1.0f @12, intensity@16, zeros
+    behind it — straight into page-locked host memory; record for record the oracle's filtered cloud (kept cloud points, then the ground points), two streams of different
+    sizes over five frames with moving clusters removed; and the 16-byte form of a second filterCloud on the same frame agrees with it."""
+    from dynamicslamtool_amd.engine import HostBuffer
+    p = scene_params(method_choice=2)
+    streams = [small_stream(1, n_frames=6), small_stream(2, n_frames=6)]
+    cap = max(len(f[0]) for st in streams for f in st)
+    b = MorBatch(p, 2, cap)
+    os_ = [Oracle(p, 4, 3) for _ in range(2)]
+    bufs = [HostBuffer((cap, 8)) for _ in range(2)]
+    removed = 0
+    for f in range(6):
+        b.push([streams[s][f][0] for s in range(2)], np.stack([streams[s][f][1] for s in range(2)]))
+        for s in range(2):
+            os_[s].push(*streams[s][f])
+            bufs[s].array[...] = np.float32(-7.0)   # (stale bytes must not pass for records)
+        n = b.filter_records32([bufs[s].array for s in range(2)])
+        for s in range(2):
+            want = os_[s].filter()
+            removed = max(removed, int(os_[s].counts().n_trim) - len(want))
+            rec = bufs[s].array[: n[s]]
+            assert n[s] == len(want), (f, s)
+            assert np.array_equal(rec[:, 0:3].view(np.uint32), want[:, 0:3].view(np.uint32)) and np.array_equal(rec[:, 4].view(np.uint32), want[:, 3].view(np.uint32)), (f, s)
+            assert np.all(rec[:, 3] == np.float32(1.0)) and not rec[:, 5:8].view(np.uint32).any(), (f, s)
+            assert np.all(bufs[s].array[n[s]:] == np.float32(-7.0)), "nothing is written behind the filtered cloud"
+    assert removed > 0
+    with pytest.raises(MorError, match="device-accessible"):
+        import ctypes as C
+        from dynamicslamtool_amd import engine
+        ptrs = (C.c_void_p * 2)(*[x.array.ctypes.data for x in bufs])
+        engine._check(engine.lib().mor_filter_batch_ex(b._h, C.addressof(ptrs), 0, None, 32))
+    b.close()
+    for x in bufs:
+        x.free()
+

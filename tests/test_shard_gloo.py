@@ -55,6 +55,9 @@ def test_gpus_flag_starts_the_ranks_itself():
     assert d["n_gpus"] == 2 and d["self_launched"] and d["collective"] == "none"
     assert d["first_seed_per_rank"] == [2000, 2008]
     assert abs(d["value"] - (2 * 8 * 4) / 1.5) < 1e-9
+    # the N-rank line's PCIe-inclusive keys (round 6): every rank's side-by-side end-to-end legs summed, the asynchronous leg's per-rank min / max beside the sum
+    # (dry run: rank r reports 100·(r+1) synchronous and 200·(r+1) asynchronous frame-pairs/s), the device-resident `value` separate from them
+    assert d["e2e_host_frame_pairs_per_s"] == 300.0 and d["e2e_host_async_frame_pairs_per_s"] == 600.0 and d["e2e_host_async_per_rank_min_max"] == [200.0, 400.0] and d["e2e_host_async_equals_sync"] is True
 
 
 def test_optional_result_gather_brings_every_ranks_rows_to_rank_0():
@@ -90,6 +93,7 @@ def test_eight_rank_dry_run_with_a_two_socket_node_map():
     assert d["numa_core_slices_first_last_n"] == [[16 * r, 16 * r + 15, 16] for r in range(8)]
     # 8 ranks x 64 streams x 4 steps over the slowest rank's 1 + 0.5·7 s
     assert abs(d["value"] - 8 * 64 * 4 / 4.5) < 1e-9
+    assert d["e2e_host_async_frame_pairs_per_s"] == 200.0 * 36 and d["e2e_host_async_per_rank_min_max"] == [200.0, 1600.0]
 
 
 def test_numa_core_slices():
