@@ -59,16 +59,7 @@ __device__ __forceinline__ float point_box_gap2(const float4 &p, const float4 &l
 // takes part only if it lies within r of the OTHER cell's point box, which removes nearly everything when the cells
 // are two apart; the surviving B points of a chunk are broadcast by shuffles — no memory access in the inner loop.
 // min / max of a value over the wave (all lanes get the result)
-__device__ __forceinline__ float wave_fmin(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_fmax(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
+// (wave_fmin / wave_fmax: DPP + permlane swaps, kernels_common.h)
 __device__ __forceinline__ bool pair_hit_wave(const float4 *sp, int a0, int na, int b0, int nb, float r2, int lane,
                                               const float4 &alo, const float4 &ahi, const float4 &blo, const float4 &bhi) {
   if (nb <= 256) {   // (a few chunks of B: the plain form)
@@ -82,7 +73,7 @@ __device__ __forceinline__ bool pair_hit_wave(const float4 *sp, int a0, int na, 
         bool hit = false;
         while (mb) {
           const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
-          const float bx = __shfl(pb.x, l, 64), by = __shfl(pb.y, l, 64), bz = __shfl(pb.z, l, 64);
+          const float bx = wave_bcast(pb.x, l), by = wave_bcast(pb.y, l), bz = wave_bcast(pb.z, l);   // (l comes from a ballot: uniform — v_readlane, no LDS)
           hit |= a_act && sqdist(pa.x, pa.y, pa.z, bx, by, bz) < r2;
         }
         if (__ballot(hit)) return true;
@@ -119,7 +110,7 @@ __device__ __forceinline__ bool pair_hit_wave(const float4 *sp, int a0, int na, 
         bool hit = false;
         while (mb) {
           const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
-          const float bx = __shfl(pb.x, l, 64), by = __shfl(pb.y, l, 64), bz = __shfl(pb.z, l, 64);
+          const float bx = wave_bcast(pb.x, l), by = wave_bcast(pb.y, l), bz = wave_bcast(pb.z, l);
           hit |= a_act && sqdist(pa.x, pa.y, pa.z, bx, by, bz) < r2;
         }
         if (__ballot(hit)) return true;
@@ -137,12 +128,8 @@ __device__ __forceinline__ void wave_box(const float4 *sp, int b, int e, int lan
     hx = fmaxf(fmaxf(hx, p0.x), fmaxf(p1.x, fmaxf(p2.x, p3.x))); hy = fmaxf(fmaxf(hy, p0.y), fmaxf(p1.y, fmaxf(p2.y, p3.y))); hz = fmaxf(fmaxf(hz, p0.z), fmaxf(p1.z, fmaxf(p2.z, p3.z)));
     mi = min(min(mi, __float_as_int(p0.w)), min(__float_as_int(p1.w), min(__float_as_int(p2.w), __float_as_int(p3.w))));
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    mi = min(mi, __shfl_xor(mi, o, 64));
-    lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
-    hx = fmaxf(hx, __shfl_xor(hx, o, 64)); hy = fmaxf(hy, __shfl_xor(hy, o, 64)); hz = fmaxf(hz, __shfl_xor(hz, o, 64));
-  }
+  mi = wave_imin(mi);
+  lx = wave_fmin(lx); ly = wave_fmin(ly); lz = wave_fmin(lz); hx = wave_fmax(hx); hy = wave_fmax(hy); hz = wave_fmax(hz);
   lo = make_float4(lx, ly, lz, 0.f); hi = make_float4(hx, hy, hz, 0.f);
 }
 
@@ -150,7 +137,7 @@ __device__ __forceinline__ void wave_box(const float4 *sp, int b, int e, int lan
 // smallest cloud index and the exact sums of its coordinates — ONE streaming pass over `sorted`, balanced whatever the
 // cell sizes are (a thread group per cell — round 1/2 — ended with the cells of thousands of points): a wave takes 256
 // consecutive positions, four per lane; a lane folds its four points serially, the open runs at lane boundaries go
-// through a segmented scan over the lanes (19 words × 6 shuffles per 256 points), and whoever holds the last point of a
+// through a segmented scan over the lanes (19 words × 6 DPP moves per 256 points: acc_segmented_scan), and whoever holds the last point of a
 // cell writes its record.  Cells that continue into another wave tile are merged with atomics (min / max / integer
 // add: order-free), their records were initialised by k_gridhash.
 __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
@@ -177,11 +164,9 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
     int left = -2, right = -3;   // cells of the positions just outside the tile
     if (lane == 0 && base > 0) left = sc[base - 1];
     if (lane == 63 && base + CB_WTILE < M) right = sc[base + CB_WTILE];
-    const int cw0 = __shfl(c[0], 0, 64), cwl = __shfl(c[3], 63, 64);
-    const bool open_l = __shfl(left, 0, 64) == cw0, open_r = __shfl(right, 63, 64) == cwl;
-    int prevc = __shfl_up(c[3], 1, 64), nextc = __shfl_down(c[0], 1, 64);
-    if (lane == 0) prevc = left;
-    if (lane == 63) nextc = right;
+    const int cw0 = wave_bcast(c[0], 0), cwl = wave_bcast(c[3], 63);
+    const bool open_l = wave_bcast(left, 0) == cw0, open_r = wave_bcast(right, 63) == cwl;
+    const int prevc = wave_shift_up1(c[3], left), nextc = wave_shift_down1(c[0], right);   // (lane 0 / 63: the cells just outside the tile)
     // the lane's tail run (the run holding its last position) and whether it began in an earlier lane
     int ts = 3;
     if (c[2] == c[3]) { ts = 2; if (c[1] == c[3]) { ts = 1; if (c[0] == c[3]) ts = 0; } }
@@ -201,9 +186,8 @@ __global__ __launch_bounds__(MOR_BT) void k_cellboxes(MorDev d) {
     const bool head = !(ts == 0 && c[0] == prevc) || lane == 0;
     const unsigned long long heads = __ballot(head);
     const int hl = 63 - __clzll((long long)(heads & (lanemask_lt() | (1ull << lane))));
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const CellAcc t2 = acc_shfl_up(S, o); if (lane - o >= hl) acc_merge(S, t2); }
-    CellAcc acc = acc_shfl_up(S, 1);   // the run reaching this lane from the left, up to the previous lane
+    acc_segmented_scan(S, hl, lane);
+    CellAcc acc = acc_dpp<0x138>(S);   // wave_shr:1 — the run reaching this lane from the left, up to the previous lane
     if (lane == 0 || c[0] != prevc) acc_clear(acc);
     if (cont && lane == 0) acc = carried();   // (read again rather than kept: nineteen registers across the scan were a wave per SIMD)
     const bool keep = open_r && !last;   // the run at the right edge goes on in this wave's next tile

@@ -3,12 +3,10 @@
 // Reference citations are file:line of /root/reference/src/MovingObjectRemoval.cpp.
 // ------------------------------------------------------------------------------------ C2: per-cluster extraction + centroid + AABB
 __device__ __forceinline__ void red6_block(Red6 &r, Red6 *sh) {
+  // (min / max by the DPP all-reduce; the fp64 sums keep the shuffle tree: their ORDER of additions is part of the result — lane 0 of this tree is what the partials hold)
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    r.sx += __shfl_down(r.sx, o, 64); r.sy += __shfl_down(r.sy, o, 64); r.sz += __shfl_down(r.sz, o, 64);
-    r.mnx = fminf(r.mnx, __shfl_down(r.mnx, o, 64)); r.mny = fminf(r.mny, __shfl_down(r.mny, o, 64)); r.mnz = fminf(r.mnz, __shfl_down(r.mnz, o, 64));
-    r.mxx = fmaxf(r.mxx, __shfl_down(r.mxx, o, 64)); r.mxy = fmaxf(r.mxy, __shfl_down(r.mxy, o, 64)); r.mxz = fmaxf(r.mxz, __shfl_down(r.mxz, o, 64));
-  }
+  for (int o = 32; o > 0; o >>= 1) { r.sx += __shfl_down(r.sx, o, 64); r.sy += __shfl_down(r.sy, o, 64); r.sz += __shfl_down(r.sz, o, 64); }
+  r.mnx = wave_fmin(r.mnx); r.mny = wave_fmin(r.mny); r.mnz = wave_fmin(r.mnz); r.mxx = wave_fmax(r.mxx); r.mxy = wave_fmax(r.mxy); r.mxz = wave_fmax(r.mxz);
   if (lane_id() == 0) sh[wave_id()] = r;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -101,16 +99,9 @@ __global__ __launch_bounds__(MOR_BT) void k_clusters(MorDev d) {
         for (int a = 0; a < 3; ++a) { r.a[a] += cs[u].a[a]; r.b[a] += cs[u].b[a]; }
       }
     }
+    r.lx = wave_fmin(r.lx); r.ly = wave_fmin(r.ly); r.lz = wave_fmin(r.lz); r.hx = wave_fmax(r.hx); r.hy = wave_fmax(r.hy); r.hz = wave_fmax(r.hz);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      r.lx = fminf(r.lx, __shfl_xor(r.lx, o, 64)); r.ly = fminf(r.ly, __shfl_xor(r.ly, o, 64)); r.lz = fminf(r.lz, __shfl_xor(r.lz, o, 64));
-      r.hx = fmaxf(r.hx, __shfl_xor(r.hx, o, 64)); r.hy = fmaxf(r.hy, __shfl_xor(r.hy, o, 64)); r.hz = fmaxf(r.hz, __shfl_xor(r.hz, o, 64));
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        r.a[a] += ((long long)__shfl_xor((int)(r.a[a] >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)r.a[a], o, 64);
-        r.b[a] += ((long long)__shfl_xor((int)(r.b[a] >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)r.b[a], o, 64);
-      }
-    }
+    for (int a = 0; a < 3; ++a) { r.a[a] = wave_sum(r.a[a]); r.b[a] = wave_sum(r.b[a]); }   // (exact integer sums: any order)
     if (lane == 0) {
       const double n = (double)(off[k + 1] - off[k]);
       // (agent-scope stores: the correspondences are worked out by the stream's last workgroup of this launch, stream_last_block)

@@ -26,9 +26,68 @@ __device__ __forceinline__ MorGrid stream_grid(const MorDev &d, int s) {
   return g;
 }
 
-__device__ __forceinline__ int wave_incl_scan(int v) {
+// ---- cross-lane primitives without the LDS crossbar (round 6).  `__shfl_xor` / `__shfl_up` compile to ds_bpermute_b32: an LDS instruction with its queue and an lgkmcnt
+// wait per step — in kernels whose own counters call them LDS-bound.  gfx950 moves data between lanes in the VALU: DPP (quad_perm, row_shr, row_mirror, row_bcast, wave_shr)
+// and v_permlane16_swap / v_permlane32_swap for the steps across 16-lane rows.
+//   DPP controls: quad_perm 0x00–0xFF, row_shr:n 0x110+n, wave_shl:1 0x130, wave_shr:1 0x138, row_mirror 0x140, row_half_mirror 0x141, row_bcast15 0x142, row_bcast31 0x143
+template <int CTRL, int ROWS = 0xF, bool ZERO_OOB = false> __device__ __forceinline__ int dpp_mov(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWS, 0xF, ZERO_OOB); }
+template <class T> struct WaveWords { static_assert(sizeof(T) % 4 == 0 && sizeof(T) <= 64, "whole dwords"); int w[sizeof(T) / 4]; };
+template <class T> __device__ __forceinline__ WaveWords<T> to_words(const T &v) { WaveWords<T> r; __builtin_memcpy(&r, &v, sizeof(T)); return r; }
+template <class T> __device__ __forceinline__ T from_words(const WaveWords<T> &w) { T r; __builtin_memcpy(&r, &w, sizeof(T)); return r; }
+// op over all 64 lanes, result in every lane; op commutative and associative (min, max, integer / IEEE add of two operands, lexicographic best …).  Six steps: partners inside
+// the quad (two quad_perms), the other quad of the 8 (row_half_mirror), the other 8 of the row (row_mirror), the neighbouring row (v_permlane16_swap), the other half
+// (v_permlane32_swap) — after step k every lane of a 2^k group holds the group's result, so any partner of the other half-group will do.
+// GROUP: the aligned group of lanes reduced over (2, 4, 8, 16, 32 or 64): the first log2(GROUP) steps.  For two-operand IEEE adds the partners of the mirror steps hold the same
+// values as the xor partners of a butterfly would (groups are uniform by then), so the sums are those of the xor butterfly that starts with the nearest partner (offsets 1, 2, 4, …) bit for bit.
+template <int GROUP, class T, class OP> __device__ __forceinline__ T wave_group_allreduce(T v, OP op) {
+  static_assert(GROUP == 2 || GROUP == 4 || GROUP == 8 || GROUP == 16 || GROUP == 32 || GROUP == 64, "aligned power-of-two groups");
+  constexpr int W = (int)(sizeof(T) / 4);
+#define MOR_DPP_STEP(CTRL) { const WaveWords<T> a = to_words(v); WaveWords<T> b; _Pragma("unroll") for (int i = 0; i < W; ++i) b.w[i] = dpp_mov<CTRL>(a.w[i], a.w[i]); v = op(v, from_words<T>(b)); }
+  MOR_DPP_STEP(0xB1)
+  if (GROUP >= 4) MOR_DPP_STEP(0x4E)
+  if (GROUP >= 8) MOR_DPP_STEP(0x141)
+  if (GROUP >= 16) MOR_DPP_STEP(0x140)
+#undef MOR_DPP_STEP
+  if (GROUP >= 32) { const WaveWords<T> a = to_words(v); WaveWords<T> x, y;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(v, o, 64); if (lane_id() >= o) v += n; }
+    for (int i = 0; i < W; ++i) { const auto r = __builtin_amdgcn_permlane16_swap((unsigned)a.w[i], (unsigned)a.w[i], false, false); x.w[i] = (int)r[0]; y.w[i] = (int)r[1]; }
+    v = op(from_words<T>(x), from_words<T>(y)); }
+  if (GROUP >= 64) { const WaveWords<T> a = to_words(v); WaveWords<T> x, y;
+#pragma unroll
+    for (int i = 0; i < W; ++i) { const auto r = __builtin_amdgcn_permlane32_swap((unsigned)a.w[i], (unsigned)a.w[i], false, false); x.w[i] = (int)r[0]; y.w[i] = (int)r[1]; }
+    v = op(from_words<T>(x), from_words<T>(y)); }
+  return v;
+}
+template <class T, class OP> __device__ __forceinline__ T wave_allreduce(T v, OP op) { return wave_group_allreduce<64>(v, op); }
+template <class T> __device__ __forceinline__ T wave_sum(T v) { return wave_allreduce(v, [](T a, T b) { return a + b; }); }
+__device__ __forceinline__ float wave_fmin(float v) { return wave_allreduce(v, [](float a, float b) { return fminf(a, b); }); }   // min / max of a value over the wave (all lanes get the result)
+__device__ __forceinline__ float wave_fmax(float v) { return wave_allreduce(v, [](float a, float b) { return fmaxf(a, b); }); }
+__device__ __forceinline__ int wave_imin(int v) { return wave_allreduce(v, [](int a, int b) { return min(a, b); }); }
+__device__ __forceinline__ int wave_imax(int v) { return wave_allreduce(v, [](int a, int b) { return max(a, b); }); }
+// value of a lane every lane agrees on (a constant, or a lane picked from a ballot): v_readlane_b32 into an SGPR instead of a ds_bpermute
+template <class T> __device__ __forceinline__ T wave_bcast(const T &v, int lane_uniform) {
+  const WaveWords<T> a = to_words(v); WaveWords<T> b;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 4); ++i) b.w[i] = __builtin_amdgcn_readlane(a.w[i], lane_uniform);
+  return from_words<T>(b);
+}
+// lane l ← lane l − 1 (lane 0: `first`), lane l ← lane l + 1 (lane 63: `last`): one DPP move per dword
+template <class T> __device__ __forceinline__ T wave_shift_up1(const T &v, const T &first) {
+  const WaveWords<T> a = to_words(v), f = to_words(first); WaveWords<T> b;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 4); ++i) b.w[i] = dpp_mov<0x138>(f.w[i], a.w[i]);   // wave_shr:1 (lane 0 keeps `old` = first)
+  return from_words<T>(b);
+}
+template <class T> __device__ __forceinline__ T wave_shift_down1(const T &v, const T &last) {
+  const WaveWords<T> a = to_words(v), f = to_words(last); WaveWords<T> b;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 4); ++i) b.w[i] = dpp_mov<0x130>(f.w[i], a.w[i]);   // wave_shl:1 (lane 63 keeps `old` = last)
+  return from_words<T>(b);
+}
+// inclusive prefix sum over the wave: four row_shr steps inside the 16-lane rows, then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast15) and lane 31 into rows 2 and 3 (row_bcast31)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += dpp_mov<0x111, 0xF, true>(0, v); v += dpp_mov<0x112, 0xF, true>(0, v); v += dpp_mov<0x114, 0xF, true>(0, v); v += dpp_mov<0x118, 0xF, true>(0, v);
+  v += dpp_mov<0x142, 0xA>(0, v); v += dpp_mov<0x143, 0xC>(0, v);
   return v;
 }
 // Work-proportional share-out of a launch's workgroups over the streams.  The streams of one batch differ a lot (the non-ground cloud of a stream of
@@ -56,10 +115,8 @@ template <bool EXACT = false, bool SPREAD = false, class WF> __device__ __forcei
   }
   long long W = 0;
   if (!EXACT) for (int i0 = 0; i0 < ng; i0 += 64) {
-    long long w = i0 + lane < ng ? (long long)wf(x + stp * (i0 + lane) + d.s0) : 0ll;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) w += ((long long)__shfl_xor((int)(w >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)w, o, 64);
-    W += w;
+    const long long w = i0 + lane < ng ? (long long)wf(x + stp * (i0 + lane) + d.s0) : 0ll;
+    W += wave_sum(w);
   }
   const long long spare = G - ng;
   int carry = 0;
@@ -70,12 +127,12 @@ template <bool EXACT = false, bool SPREAD = false, class WF> __device__ __forcei
     const unsigned long long m = __ballot(i < ng && r < carry + incl);
     if (m) {
       const int l = __ffsll((long long)m) - 1;
-      g = __builtin_amdgcn_readfirstlane(__shfl(gi, l, 64));
-      t = __builtin_amdgcn_readfirstlane(r - (carry + __shfl(incl, l, 64) - g));
+      g = wave_bcast(gi, l);
+      t = __builtin_amdgcn_readfirstlane(r - (carry + wave_bcast(incl, l) - g));
       s = __builtin_amdgcn_readfirstlane(x + stp * (i0 + l) + d.s0);
       return true;
     }
-    carry += __shfl(incl, 63, 64);
+    carry += wave_bcast(incl, 63);
   }
   return false;
 }
@@ -98,8 +155,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int *sh, int *total) {
 __device__ __forceinline__ void wg_prefix_total(const int *c, int stride, int t, int nt, int *sh, int &prefix, int &total) {
   int p = 0, a = 0;
   for (int i = threadIdx.x; i < nt; i += MOR_BT) { const int v = c[(size_t)i * stride]; a += v; p += i < t ? v : 0; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { p += __shfl_xor(p, o, 64); a += __shfl_xor(a, o, 64); }
+  p = wave_sum(p); a = wave_sum(a);
   __syncthreads();
   if (lane_id() == 0) { sh[wave_id()] = p; sh[4 + wave_id()] = a; }
   __syncthreads();

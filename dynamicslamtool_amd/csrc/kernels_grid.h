@@ -200,8 +200,7 @@ template <bool L> __device__ __forceinline__ int gh_scan(int *a, int n, int *sh)
   const int seg = ((n + NW - 1) / NW + 63) / 64 * 64, b = min(wave_id() * seg, n), e = min(b + seg, n), lane = lane_id();
   int sum = 0;
   for (int i = b + lane; i < e; i += 64) sum += gh_ld<L>(a + i);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  sum = wave_sum(sum);
   __syncthreads();
   if (lane == 0) sh[wave_id()] = sum;
   __syncthreads();
@@ -211,7 +210,7 @@ template <bool L> __device__ __forceinline__ int gh_scan(int *a, int n, int *sh)
   for (int i0 = b; i0 < e; i0 += 64) {
     const int i = i0 + lane, v = i < e ? gh_ld<L>(a + i) : 0, inc = wave_incl_scan(v);
     if (i < e) gh_st<L>(a + i, run + inc - v);
-    run += __shfl(inc, 63, 64);
+    run += wave_bcast(inc, 63);
   }
   __syncthreads();
   return total;
@@ -266,7 +265,7 @@ template <bool L> __device__ __forceinline__ void slab_bounds(const MorDev &d, c
 // a lane that starts a run, its length.  `worth`: the wave has at most half as many runs as points (else every lane is its own
 // leader with length 1: sparse stretches of a cloud only pay for the test).
 __device__ __forceinline__ void gh_runs(int v, bool valid, int &leader, int &len, bool &worth) {
-  const int lane = (int)(threadIdx.x & 63), prev = __shfl_up(v, 1, 64);
+  const int lane = (int)(threadIdx.x & 63), prev = wave_shift_up1(v, v);   // (lane 0's own value: its test below never looks at it)
   const unsigned long long mv = __ballot(valid), pv = mv << 1;
   const unsigned long long ml = __ballot(valid && (lane == 0 || !((pv >> lane) & 1ull) || prev != v));
   worth = 2 * __popcll(ml) <= __popcll(mv);
@@ -618,17 +617,34 @@ __device__ __forceinline__ void acc_merge(CellAcc &r, const CellAcc &o) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) { r.a[k] += o.a[k]; r.b[k] += o.b[k]; }
 }
-__device__ __forceinline__ long long shfl_up_ll(long long v, int o) {
-  int lo = __shfl_up((int)(unsigned)v, o, 64), hi = __shfl_up((int)(v >> 32), o, 64);
-  return ((long long)hi << 32) | (unsigned)lo;
-}
-__device__ __forceinline__ CellAcc acc_shfl_up(const CellAcc &r, int o) {
-  CellAcc t;
-  t.lx = __shfl_up(r.lx, o, 64); t.ly = __shfl_up(r.ly, o, 64); t.lz = __shfl_up(r.lz, o, 64); t.hx = __shfl_up(r.hx, o, 64); t.hy = __shfl_up(r.hy, o, 64); t.hz = __shfl_up(r.hz, o, 64);
-  t.mi = __shfl_up(r.mi, o, 64);
+// an accumulator moved between lanes by DPP (nineteen v_mov_b32_dpp; lanes the control does not reach keep their own value — the caller's condition never merges those)
+template <int CTRL, int ROWS, class T> __device__ __forceinline__ T dpp_val(const T &v) {
+  const WaveWords<T> a = to_words(v); WaveWords<T> b;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { t.a[k] = shfl_up_ll(r.a[k], o); t.b[k] = shfl_up_ll(r.b[k], o); }
+  for (int i = 0; i < (int)(sizeof(T) / 4); ++i) b.w[i] = dpp_mov<CTRL, ROWS>(a.w[i], a.w[i]);
+  return from_words<T>(b);
+}
+template <int CTRL, int ROWS = 0xF> __device__ __forceinline__ CellAcc acc_dpp(const CellAcc &r) {
+  CellAcc t;
+  t.lx = dpp_val<CTRL, ROWS>(r.lx); t.ly = dpp_val<CTRL, ROWS>(r.ly); t.lz = dpp_val<CTRL, ROWS>(r.lz); t.hx = dpp_val<CTRL, ROWS>(r.hx); t.hy = dpp_val<CTRL, ROWS>(r.hy); t.hz = dpp_val<CTRL, ROWS>(r.hz);
+  t.mi = dpp_val<CTRL, ROWS>(r.mi);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { t.a[k] = dpp_val<CTRL, ROWS>(r.a[k]); t.b[k] = dpp_val<CTRL, ROWS>(r.b[k]); }
   return t;
+}
+// Segmented inclusive scan of the lanes' accumulators: lane l ends with the merge over lanes [hl, l], hl = the head of its segment (a lane ≤ l).  Four row_shr steps inside the
+// 16-lane rows — lane l then covers [max(hl, start of its row), l] — then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast15) and lane 31 into rows 2 and 3 (row_bcast31) for the
+// segments that began in an earlier row.  Six steps as the Kogge–Stone form over ds_bpermute had, but VALU moves: no LDS instruction, no lgkmcnt wait.
+__device__ __forceinline__ void acc_segmented_scan(CellAcc &S, int hl, int lane) {
+#define MOR_SEG_STEP(CTRL, ROWS, COND) { const CellAcc t2 = acc_dpp<CTRL, ROWS>(S); if (COND) acc_merge(S, t2); }
+  const int li = lane & 15;
+  MOR_SEG_STEP(0x111, 0xF, li >= 1 && lane - 1 >= hl)
+  MOR_SEG_STEP(0x112, 0xF, li >= 2 && lane - 2 >= hl)
+  MOR_SEG_STEP(0x114, 0xF, li >= 4 && lane - 4 >= hl)
+  MOR_SEG_STEP(0x118, 0xF, li >= 8 && lane - 8 >= hl)
+  MOR_SEG_STEP(0x142, 0xA, (lane & 16) && hl < (lane & ~15))
+  MOR_SEG_STEP(0x143, 0xC, lane >= 32 && hl < 32)
+#undef MOR_SEG_STEP
 }
 // float min / max through integer atomics (no NaNs here; −0 is folded into +0 first)
 __device__ __forceinline__ void atomic_fmin(float *p, float v) { v += 0.f; if (v >= 0.f) atomicMin((int *)p, __float_as_int(v)); else atomicMax((unsigned *)p, __float_as_uint(v)); }

@@ -54,7 +54,7 @@ template <class F> __device__ __forceinline__ void g2_for_neighbours(const MorDe
   if (lane < 9) g2_row_range(d, s, G, cx, cy, cz, lane, b0, len);
   int rb[9], rp[10]; rp[0] = 0;
 #pragma unroll
-  for (int r = 0; r < 9; ++r) { rb[r] = __shfl(b0, r, 64); rp[r + 1] = rp[r] + __shfl(len, r, 64); }
+  for (int r = 0; r < 9; ++r) { rb[r] = wave_bcast(b0, r); rp[r + 1] = rp[r] + wave_bcast(len, r); }
   for (int c = lane; c < rp[9]; c += 64) {
     int k = 0;
 #pragma unroll
@@ -177,12 +177,12 @@ __device__ __forceinline__ void g2_acc_add(G2Acc &A, const float4 &q, const floa
   ++A.n;
 }
 template <int W> __device__ __forceinline__ void g2_acc_reduce(G2Acc &A) {   // over the W lanes of the caller's group (W = 16 or 64, aligned)
-#pragma unroll
-  for (int o = W / 2; o > 0; o >>= 1) {
-    A.Sa += __shfl_xor(A.Sa, o, 64); A.Sb += __shfl_xor(A.Sb, o, 64); A.Sc += __shfl_xor(A.Sc, o, 64);
-    A.Sac += __shfl_xor(A.Sac, o, 64); A.Sbc += __shfl_xor(A.Sbc, o, 64); A.Scc += __shfl_xor(A.Scc, o, 64);
-    A.Sdd += __shfl_xor(A.Sdd, o, 64); A.n += __shfl_xor(A.n, o, 64);
-  }
+  // (DPP / permlane partners — kernels_common.h.  The additions pair up nearest lanes first, where the shuffle form of round 5 started with the farthest: other roundings of the same
+  //  fp32 sums, which the screen's bound covers for ANY order — g2_screen charges n + 10 roundings)
+  auto add = [](auto a, auto b) { return a + b; };
+  A.Sa = wave_group_allreduce<W>(A.Sa, add); A.Sb = wave_group_allreduce<W>(A.Sb, add); A.Sc = wave_group_allreduce<W>(A.Sc, add);
+  A.Sac = wave_group_allreduce<W>(A.Sac, add); A.Sbc = wave_group_allreduce<W>(A.Sbc, add); A.Scc = wave_group_allreduce<W>(A.Scc, add);
+  A.Sdd = wave_group_allreduce<W>(A.Sdd, add); A.n = wave_group_allreduce<W>(A.n, add);
 }
 // 1: accepted (:145 holds whatever the order), 0: rejected, −1: too close to call — the ordered sums decide.  n > 3.
 __device__ __forceinline__ int g2_screen(const G2Acc &A, const float4 &q, double leaf_r /* √leaf² · 1.0001 + 1e-6, from the host */, double inv_r /* 1 / √leaf² */) {
@@ -324,8 +324,7 @@ __global__ __launch_bounds__(MOR_BT, 5) void k_g2_cov(MorDev d) {
     const bool wide = rp[9] > G2_NARROW_CAND;   // (uniform in the group)
     const int ncand = wide ? 0 : rp[9];
     int wave_max = ncand;
-#pragma unroll
-    for (int o = G2_GW; o < 64; o <<= 1) wave_max = max(wave_max, __shfl_xor(wave_max, o, 64));
+    wave_max = wave_imax(wave_max);
     G2Acc A; g2_acc_zero(A);
     for (int c0 = 0; c0 < wave_max; c0 += 4 * G2_GW) {
       float4 pc[4];
@@ -355,8 +354,7 @@ __global__ __launch_bounds__(MOR_BT, 5) void k_g2_cov(MorDev d) {
     spec = __shfl(spec, lane0, 64);
     const int nmark = spec ? ncand : 0;
     int mark_max = nmark;
-#pragma unroll
-    for (int o = G2_GW; o < 64; o <<= 1) mark_max = max(mark_max, __shfl_xor(mark_max, o, 64));
+    mark_max = wave_imax(mark_max);
     for (int c0 = 0; c0 < mark_max; c0 += 4 * G2_GW) {
       float4 pc[4];
 #pragma unroll
@@ -400,7 +398,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
     if (lane < 9) { int cx, cy, cz; bool cl; grid_cell(G, q, 0.f, zbase, cx, cy, cz, cl); g2_row_range(d, s, G, cx, cy, cz, lane, rb0, rlen); }
     int rb[9], rp[10]; rp[0] = 0;
 #pragma unroll
-    for (int r = 0; r < 9; ++r) { rb[r] = __shfl(rb0, r, 64); rp[r + 1] = rp[r] + __shfl(rlen, r, 64); }
+    for (int r = 0; r < 9; ++r) { rb[r] = wave_bcast(rb0, r); rp[r + 1] = rp[r] + wave_bcast(rlen, r); }
     auto cand = [&](int c) { int k = 0;
 #pragma unroll
       for (int r = 0; r < 9; ++r) if (c >= rp[r] && c < rp[r + 1]) k = rb[r] + (c - rp[r]);
@@ -519,8 +517,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mode(MorDev d) {
   {  // the fullest bin, ties → the smallest bin: every thread over its sixteen bins, then the wave by shuffles, then one atomic pair per wave (4 096 atomics on one LDS word each way before)
     int cnt = 0, bin = 0x7fffffff;
     for (int i = threadIdx.x; i < 4096; i += MOR_BT) { const int h = hist[i]; if (h > cnt) { cnt = h; bin = i - 2048; } }   // (ascending i: a later bin with the same count does not replace an earlier one)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int c2 = __shfl_xor(cnt, o, 64), b2 = __shfl_xor(bin, o, 64); if (c2 > cnt || (c2 == cnt && b2 < bin)) { cnt = c2; bin = b2; } }
+    { const int2 best = wave_allreduce(make_int2(cnt, bin), [](int2 a, int2 b) { return (b.x > a.x || (b.x == a.x && b.y < a.y)) ? b : a; }); cnt = best.x; bin = best.y; }
     if (lane_id() == 0) atomicMax(&best_cnt, cnt);
     __syncthreads();
     if (lane_id() == 0 && cnt > 0 && cnt == best_cnt) atomicMin(&best_bin, bin);
@@ -571,8 +568,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mark(MorDev d) {
         unsigned long long t = wb; while (t) { const int gl = __ffsll((long long)t) - 1; t &= t - 1; wide_m |= 1ull << __shfl(l, gl, 64); } }
       const int ncand = (act && !wide) ? rp[9] : 0;
       int wave_max = ncand;
-#pragma unroll
-      for (int o = 16; o < 64; o <<= 1) wave_max = max(wave_max, __shfl_xor(wave_max, o, 64));
+      wave_max = wave_imax(wave_max);
       for (int c0 = 0; c0 < wave_max; c0 += 64) {   // four candidates per lane and round trip
         float4 pc[4];
 #pragma unroll

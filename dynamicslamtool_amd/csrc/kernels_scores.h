@@ -64,7 +64,7 @@ __device__ __forceinline__ void wl_push(bool want, int *n, int4 *list, int j, in
   if (!m) return;
   int basew = 0, leader = __ffsll((long long)m) - 1;
   if (lane_id() == leader) basew = atomicAdd(n, __popcll(m));
-  basew = __shfl(basew, leader, 64);
+  basew = wave_bcast(basew, leader);   // (the leader comes from a ballot: uniform — v_readlane instead of a trip through the LDS crossbar)
   if (want) { int pos = basew + __popcll(m & lanemask_lt()); list[back ? cap - 1 - pos : pos] = make_int4(j, pr, target, own_cell); }
 }
 // wave-aggregated count: all counted queries of a pair add to ONE address (a few dozen addresses per stream), and
@@ -73,7 +73,7 @@ __device__ __forceinline__ void wl_push(bool want, int *n, int4 *list, int j, in
 __device__ __forceinline__ void count_push(bool want, int *cnt, int pr) {
   unsigned long long m = __ballot(want);
   while (m) {
-    const int l = __ffsll((long long)m) - 1, p = __shfl(pr, l, 64);
+    const int l = __ffsll((long long)m) - 1, p = wave_bcast(pr, l);
     const unsigned long long same = __ballot(want && pr == p);
     if (lane_id() == l) atomicAdd(&cnt[p], __popcll(same));
     m &= ~same;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(SCF_T, SCF_MINW) void k_score_fast(MorDev d) {
           if (mn | mb) base = atomicAdd(&d.wl_nb[s], (unsigned long long)__popcll(mn) | ((unsigned long long)__popcll(mb) << 32));
           if (mg) base2 = atomicAdd(&d.wl2_n[s], __popcll(mg));
         }
-        const int bn = __shfl((int)(unsigned)base, 0, 64), bb = __shfl((int)(base >> 32), 0, 64), b2 = __shfl(base2, 0, 64);
+        const int bn = wave_bcast((int)(unsigned)base, 0), bb = wave_bcast((int)(base >> 32), 0), b2 = wave_bcast(base2, 0);
         if (nearq) d.wl[so + bn + __popcll(mn & lanemask_lt())] = make_int4(j, pr, target, 0);
         if (blockq) d.wl[so + d.Nmax - 1 - (bb + __popcll(mb & lanemask_lt()))] = make_int4(j, pr, target, 0);
         if (big) d.wl2[so + b2 + __popcll(mg & lanemask_lt())] = make_int4(j, pr, target, own_c);   // (.w: the query's own cell — the wave tier starts there without looking it up again)
@@ -302,11 +302,7 @@ __global__ __launch_bounds__(SCN_T, SCN_MINW) void k_score_nb(MorDev d) {
     if (c < cn) score_near_body(d, I, s, c); else score_block_body(d, I, s, c - cn);
   }
 }
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
-}
+__device__ __forceinline__ float wave_min(float v) { return wave_fmin(v); }
 // Tier 2 — one WAVE per deferred query.  Every lane owns one ROW of the search stencil (nearest rows
 // first, 64 rows per round) and walks that row's cells with a cursor: cell-level work (cluster id,
 // box distance) is lane-parallel; every surviving cell is then scanned by the whole wave, 128 points
@@ -363,7 +359,7 @@ __device__ __forceinline__ void score_pde_body(const MorDev &d, int s, int bx, i
           if (x0 <= x1) cidx_row(I, x0, x1, y, z, cur, hi);
         }
       }
-      if (__shfl(lbrow, 0, 64) >= score_lim(best, lbn, d.pde_ub)) break;   // rows are ordered by their lower bound
+      if (wave_bcast(lbrow, 0) >= score_lim(best, lbn, d.pde_ub)) break;   // rows are ordered by their lower bound
       // cluster ids of the first 8 cells of the lane's row as one batch of independent loads → bit mask of matched cells
       unsigned rowmask = 0; const int base = cur;
       {
@@ -399,7 +395,7 @@ __device__ __forceinline__ void score_pde_body(const MorDev &d, int s, int bx, i
         unsigned long long m = __ballot(cand >= 0 && !small);
         while (m && best > d.pde_lb) {
           int l = __ffsll((long long)m) - 1; m &= m - 1;
-          int c = __shfl(cand, l, 64);
+          int c = wave_bcast(cand, l);
           if (box_dist2(q, d.cmeta[2 * (so + c)], d.cmeta[2 * (so + c) + 1]) >= score_lim(best, lbn, d.pde_ub)) continue;   // best may have tightened since
           best = fminf(best, wave_scan_cell(sp, st[c], st[c + 1], q, d.pde_lb, lane));
         }

@@ -21,8 +21,7 @@ __global__ __launch_bounds__(MOR_BT) void k_classify(MorDev d) {
     c_g += __popcll(__ballot(cls == 1));
   }
   if (d.gmode == 1) {   // z extent of the trimmed cloud: the voxel variant does not crop in z
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { zlo = fminf(zlo, __shfl_xor(zlo, o, 64)); zhi = fmaxf(zhi, __shfl_xor(zhi, o, 64)); }
+    zlo = wave_fmin(zlo); zhi = wave_fmax(zhi);
     if (lane_id() == 0 && zlo <= zhi) { atomicMin(&d.zmin_i[MOR_ZR * s], float_ordered(zlo)); atomicMax(&d.zmax_i[MOR_ZR * s], float_ordered(zhi)); }   // (a stream's word on a cache line of its own: 30 000 atomics per step on the FOUR lines of the dense arrays went through the L2 one after the other — 96 of the kernel's 129 µs)
   }
   if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
@@ -207,8 +206,7 @@ template <bool PASSB> __device__ __forceinline__ void split_store(const MorDev &
         }
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { an += __shfl_xor(an, o, 64); ag += __shfl_xor(ag, o, 64); }
+    an = wave_sum(an); ag = wave_sum(ag);
     if (lane == 0) {
       s_ex[0] = ex_ng + an; s_ex[1] = ex_g + ag; s_ex[2] = tk_next;
       if (t == nt - 1) publish_split(d, s, ex_ng + an + m.tng, ex_g + ag + m.tg);   // the stream's last tile: T, M, G of the frame

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
             for (int j0 = 0; j0 < n && match < 0; j0 += 64) {
               const int j = j0 + lane; const int2 pr = j < n ? c[j] : make_int2(-1, -1);
               unsigned long long m = __ballot(pr.x == track);
-              if (m) match = __shfl(pr.y, __ffsll((long long)m) - 1, 64);   // first pair whose query is `track`
+              if (m) match = wave_bcast(pr.y, __ffsll((long long)m) - 1);   // first pair whose query is `track`
             }
             if (match < 0 || !res[(size_t)(col + 1) * stride + match]) ok = false; else track = match;
           }
@@ -215,9 +215,7 @@ __device__ __forceinline__ void track_filter_body(const MorDev &d, int s, unsign
           }
         }
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) mine += ((unsigned long long)(unsigned)__shfl_xor((int)(mine >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)mine, o, 64);
-      total += mine;
+      total += wave_sum(mine);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (all reads of this round are done — one wave: no barrier needed; survivors are compacted in place, order kept)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -235,8 +233,7 @@ __device__ __forceinline__ void track_filter_body(const MorDev &d, int s, unsign
   const bool xerr = l_tot > (unsigned long long)M;
   unsigned removed = 0;
   for (int k = tid; k < K; k += FLT_T) if ((l_mov[k >> 5] >> (k & 31)) & 1u) removed += (unsigned)(fits ? l_size[k] : off[k + 1] - off[k]);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) removed += (unsigned)__shfl_xor((int)removed, o, 64);
+  removed = wave_sum(removed);
   __shared__ unsigned l_rem[FLT_T / 64];
   if (lane == 0) l_rem[tid >> 6] = removed;
   __syncthreads();
@@ -333,8 +330,7 @@ __global__ __launch_bounds__(FLT_T) void k_out(MorDev d) {
           }
         }
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) an += __shfl_xor(an, o, 64);
+      an = wave_sum(an);
       if (lane_id() == 0) l_ex[2] = ex + an;
     }
     __syncthreads();
