@@ -448,6 +448,11 @@ template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDe
 #define CGS_SLAB_WORDS (CGS_CW * CGS_CAP + CGS_ROWCAP + 1 + CGS_LISTW + CGS_NW * CGS_QW)
 #define CGS_ARENA (CGS_SLAB_WORDS > 2 * MOR_CGS_FCAP ? CGS_SLAB_WORDS : 2 * MOR_CGS_FCAP)   // (the slab layout of the default build is 18 945 words)
 #define CGS_FCAP (CGS_ARENA / 2)
+#define CGF_KL 512   // kept clusters per stream whose records the fast tail holds in LDS
+#ifndef CGF_RC
+#define CGF_RC 14   // cells per thread the fast tail keeps in registers (cgf_fast): streams of up to 14 · 512 = 7 168 cells in k_cg_slab, 14 336 in k_cg_final
+#endif
+template <int NT, int RC> __device__ __forceinline__ bool cgf_fast(const MorDev &d, int s, int nocc, int *par, int *scr, int *kl, int *l_misc, const int *l_sc, const int *l_se);
 template <int CAP> __device__ __forceinline__ void cg_slab_body(const MorDev &d, int s, int j, int *l_arena, int *l_wcnt, int *l_n2p);
 template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) {   // (keep it at ≤ 128 VGPRs — two workgroups per CU; a loop over several slabs per workgroup took 157: 228 → 350 µs in the pipeline)
   int s, j, Ps;
@@ -459,9 +464,12 @@ template <int CAP> __global__ __launch_bounds__(CGS_T) void k_cg_slab(MorDev d) 
   if (!stream_last_block(d.tickets + (size_t)s * TK_COUNT + TK_CGFINAL, Ps, &l_last)) return;
   const int nocc = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
-  __shared__ int l_misc[1 + CGS_T / 64], l_sc[MOR_MAXP + 1], l_se[MOR_MAXP + 1];
+  __shared__ int l_misc[1 + 3 * (CGS_T / 64)], l_sc[MOR_MAXP + 1], l_se[MOR_MAXP + 1];
   if (threadIdx.x <= Ps) { l_sc[threadIdx.x] = d.slab_c[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; l_se[threadIdx.x] = d.slab_e[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; }
   if (nocc <= CGS_FCAP && !d.cg_force_global) {
+    __syncthreads();
+    if (!d.cg_slow_tail && 2 * nocc + 7 * CGF_KL <= CGS_ARENA && cgf_fast<CGS_T, CGF_RC>(d, s, nocc, l_arena, l_arena + nocc, l_arena + 2 * nocc, l_misc, l_sc, l_se)) return;
+    __syncthreads();
     int *l_par = l_arena, *l_a = l_arena + CGS_FCAP;
     for (int i = threadIdx.x; i < nocc; i += CGS_T) l_par[i] = i;
     __syncthreads();
@@ -687,12 +695,150 @@ template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDe
     d.cgat[so + c] = g;
   }
 }
+// ---- the same tail for the common case, restructured around what it waits for (round 6).  Cutting the tail's phases out one at a time (exp/cut_time.py) put it at 46 of
+// k_cg_slab's 108 µs alone on the open scenes and 61 of 184 on the street scenes, spread over every phase: each is a sweep over the stream's cells that begins with global loads
+// (local roots, cell sizes, smallest indices, per-cluster records through two dependent hops) behind a workgroup barrier — a dozen exposed round trips per thread and phase.  Here a
+// thread keeps the operands of ITS cells (cells tid, tid + NT, …: at most RC of them) in registers — one batch of coalesced loads for the whole tail —, the forest starts as the
+// stars the slabs published (a plain store per cell: a slab's local root is the smallest id of its local component, so parent ≤ child holds) and only the look-ahead cells of every
+// slab are united across slabs, and the per-cluster records (root cell, size, first cloud index, offset, cursors: CGF_KL of them at most) live in LDS.  Same results: every quantity is
+// the one cgf_body computes.  Returns false — nothing published yet, the caller runs cgf_body from scratch — for streams with more than RC·NT cells or more than CGF_KL kept clusters.
+template <int NT, int RC> __device__ __forceinline__ bool cgf_fast(const MorDev &d, int s, int nocc, int *par, int *scr, int *kl, int *l_misc, const int *l_sc, const int *l_se) {
+  static_assert(CGF_KL <= NT, "one round of the per-cluster scans");
+  if (nocc > RC * NT) return false;
+  const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
+  const int *start = d.cstart + (size_t)s * (d.Nmax + 1);
+  const int tid = threadIdx.x, lane = lane_id(), wv = wave_id(), P = d.slab_p[s];
+  int *k_cell = kl, *k_size = kl + CGF_KL, *k_root = kl + 2 * CGF_KL, *k_first = kl + 3 * CGF_KL, *k_off = kl + 4 * CGF_KL, *k_n = kl + 5 * CGF_KL, *k_cur = kl + 6 * CGF_KL;
+  int n[RC], mnc[RC], r[RC];   // per own cell: points, smallest cloud index, root (later: cluster id)
+  // ---- operands + the stars of the slab forests
+#pragma unroll
+  for (int i = 0; i < RC; ++i) {
+    const int c = tid + i * NT;
+    n[i] = 0; mnc[i] = 0x7fffffff; r[i] = -1;
+    if (c < nocc) { const int la = ld_agent(&d.lroot_a[so + c]); n[i] = start[c + 1] - start[c]; mnc[i] = d.cmin[so + c]; par[c] = la; scr[c] = 0; }
+  }
+  if (tid == 0) l_misc[0] = 0;
+  __syncthreads();
+  // ---- cross-slab unions: the look-ahead cells of slab j − 1 are the first cells of slab j, [sc[j], se[j − 1]) — (c, its local root in slab j − 1's forest)
+  {
+    int tot = 0;
+    for (int j = 1; j < P; ++j) tot += (l_sc[j] > l_sc[j - 1]) ? max(l_se[j - 1] - l_sc[j], 0) : 0;   // (an empty slab publishes nothing)
+    for (int it = tid; it < tot; it += NT) {
+      int j = 1, rem = it;
+      for (; j < P; ++j) { const int len = (l_sc[j] > l_sc[j - 1]) ? max(l_se[j - 1] - l_sc[j], 0) : 0; if (rem < len) break; rem -= len; }
+      const int c = l_sc[j] + rem;
+      cg_unite<true>(par, c, ld_agent(&d.lroot_b[so + c]));
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RC; ++i) { const int c = tid + i * NT; if (c < nocc) r[i] = cg_find<true>(par, c); }
+  // ---- components: size (points) at the root
+#pragma unroll
+  for (int i = 0; i < RC; ++i) if (r[i] >= 0) atomicAdd(&scr[r[i]], n[i]);
+  __threadfence_block();
+  __syncthreads();
+  // ---- kept components (:215-216)
+#pragma unroll
+  for (int i = 0; i < RC; ++i) {
+    const int c = tid + i * NT;
+    if (r[i] == c) {
+      const long long sz = (long long)cg_ld<true>(scr + c);
+      if (sz >= d.min_cs && sz <= d.max_cs) { const int k = atomicAdd(&l_misc[0], 1); if (k < CGF_KL) { k_cell[k] = c; k_size[k] = (int)sz; } }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int K = l_misc[0];
+  if (K > CGF_KL || K > d.Kcap) return false;
+  // ---- smallest cloud index of every component at its root (the scratch array again)
+#pragma unroll
+  for (int i = 0; i < RC; ++i) { const int c = tid + i * NT; if (c < nocc) scr[c] = 0x7fffffff; }
+  __threadfence_block();
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RC; ++i) if (r[i] >= 0) atomicMin(&scr[r[i]], mnc[i]);
+  __threadfence_block();
+  __syncthreads();
+  if (tid < K) k_root[tid] = cg_ld<true>(scr + k_cell[tid]);
+  __threadfence_block();
+  __syncthreads();
+  // ---- cluster order: size descending, ties by smaller first cloud index; rank by counting.  A kept root's scratch word becomes −(cluster id) − 2 (the words of the other
+  //      roots keep their cloud indices, ≥ 0: "not kept")
+  if (tid < K) {
+    const int my_sz = k_size[tid], my_rt = k_root[tid]; int rank = 0;
+    for (int u = 0; u < K; ++u) { const int sz = k_size[u], rt = k_root[u]; rank += (sz > my_sz) || (sz == my_sz && rt < my_rt); }
+    cg_st<true>(scr + k_cell[tid], -rank - 2);
+    k_first[rank] = my_rt; k_off[rank] = my_sz; k_n[rank] = 0;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- per-cell cluster id (a cell is a clique ⇒ one cluster), cells per cluster
+#pragma unroll
+  for (int i = 0; i < RC; ++i) {
+    const int c = tid + i * NT;
+    if (c < nocc) {
+      const int v = cg_ld<true>(scr + r[i]), id = v < 0 ? -v - 2 : -1;
+      r[i] = id;
+      d.ccid[so + c] = id; reinterpret_cast<int *>(&d.cmeta[2 * (so + c)])[3] = id;
+      if (id >= 0) atomicAdd(&k_n[id], 1);
+    } else r[i] = -1;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- three exclusive scans in cluster order, one round: points → cl_off, reduction chunks → chunk_off, cells → cl_coff; C, K, detection_results cleared (:250-254)
+  {
+    const bool v_ = tid < K;
+    const int sz = v_ ? k_off[tid] : 0, ch = v_ ? (sz + MOR_CHUNK - 1) / MOR_CHUNK : 0, nc = v_ ? k_n[tid] : 0;
+    const int i0 = wave_incl_scan(sz), i1 = wave_incl_scan(ch), i2 = wave_incl_scan(nc);
+    int *part = l_misc + 1;   // (≥ 3 · NT / 64 words behind the counter: the callers' l_misc)
+    if (lane == 63) { part[wv] = i0; part[NT / 64 + wv] = i1; part[2 * (NT / 64) + wv] = i2; }
+    __syncthreads();
+    int b0 = 0, b1 = 0, b2 = 0, t0 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { const int x0 = part[w], x1 = part[NT / 64 + w], x2 = part[2 * (NT / 64) + w]; if (w < wv) { b0 += x0; b1 += x1; b2 += x2; } t0 += x0; t1 += x1; t2 += x2; }
+    int *off = d.cl_off[d.cur] + (size_t)s * (d.Kcap + 1), *coff = d.chunk_off[d.cur] + (size_t)s * (d.Kcap + 1), *lcoff = d.cl_coff + (size_t)s * (d.Kcap + 1);
+    if (v_) {
+      const int o0 = b0 + i0 - sz, o2 = b2 + i2 - nc;
+      off[tid] = o0; coff[tid] = b1 + i1 - ch; lcoff[tid] = o2; d.det[ko + tid] = 0;
+      k_off[tid] = o0; k_n[tid] = o2;
+    }
+    if (tid == 0) { off[K] = t0; coff[K] = t1; lcoff[K] = t2; d.info[s].C = t0; d.info[s].K = K; d.slot_kc[d.cur][s] = make_int2(K, t0); }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- every cell's place in its cluster's range of cl_pts (cgf_body: the cell holding the cluster's first point opens the range, the others take consecutive pieces in the
+  //      order their atomics arrive) and the cells of every cluster as a list
+#pragma unroll
+  for (int i = 0; i < RC; ++i) if (r[i] >= 0 && mnc[i] == k_first[r[i]]) k_cur[r[i]] = k_off[r[i]] + n[i];
+  __threadfence_block();
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RC; ++i) {
+    const int c = tid + i * NT;
+    if (c >= nocc) continue;
+    const int k = r[i];
+    int4 g = make_int4(0, -1, -1, 0);
+    if (k >= 0) {
+      const int first = k_first[k]; const bool opens = mnc[i] == first;
+      const int dst = opens ? k_off[k] : atomicAdd(&k_cur[k], n[i]);
+      g = make_int4(dst - start[c], k, opens ? first : -1, 0);
+      d.clist[so + atomicAdd(&k_n[k], 1)] = c;
+    }
+    d.cgat[so + c] = g;
+  }
+  return true;
+}
 __global__ __launch_bounds__(CGF_T) void k_cg_final(MorDev d) {
   const int s = blockIdx.x + d.s0, nocc = d.info[s].n_occ;
   const size_t so = (size_t)s * d.Nmax;
-  __shared__ int l_par[CGF_CAP], l_a[CGF_CAP], l_misc[1 + CGF_T / 64], l_sc[MOR_MAXP + 1], l_se[MOR_MAXP + 1];
+  __shared__ int l_par[CGF_CAP], l_a[CGF_CAP], l_misc[1 + 3 * (CGF_T / 64)], l_sc[MOR_MAXP + 1], l_se[MOR_MAXP + 1];
   if (threadIdx.x <= d.slab_p[s]) { l_sc[threadIdx.x] = d.slab_c[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; l_se[threadIdx.x] = d.slab_e[(size_t)s * (MOR_MAXP + 1) + threadIdx.x]; }
   if (nocc <= CGF_CAP && !d.cg_force_global) {          // forest, sizes (then cluster ids), minima: three LDS arrays
+    __syncthreads();
+    if (!d.cg_slow_tail && nocc + 7 * CGF_KL <= CGF_CAP && cgf_fast<CGF_T, CGF_RC>(d, s, nocc, l_par, l_a, l_a + nocc, l_misc, l_sc, l_se)) return;
+    __syncthreads();
     for (int i = threadIdx.x; i < nocc; i += CGF_T) l_par[i] = i;
     __syncthreads();
     cgf_body<true, CGF_T>(d, s, nocc, l_par, l_a, l_misc, l_sc, l_se);

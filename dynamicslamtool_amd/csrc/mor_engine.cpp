@@ -232,7 +232,7 @@ static int configure(mor_batch *b) {
   d.gnz = nullptr; d.gnz_out = nullptr; d.vnz = nullptr; d.vnz_out = nullptr; d.cg_nz = d.g.nz; d.cg_inv_cs = d.g.inv_cs;
   d.t1_budget = 64;   // points a thread of the worklist tiers looks at before it hands its query to the wave tier
   // test switches (defaults: the fast paths): MOR_GH_TIER=1|2 starts k_gridhash with its big LDS table / its global-memory table; MOR_CG_GLOBAL forces the global-memory forests
-  d.gh_tier = getenv("MOR_GH_TIER") ? atoi(getenv("MOR_GH_TIER")) : -1; d.cg_force_global = getenv("MOR_CG_GLOBAL") ? 1 : 0; d.g2_exact_only = getenv("MOR_G2_EXACT") ? 1 : 0;
+  d.gh_tier = getenv("MOR_GH_TIER") ? atoi(getenv("MOR_GH_TIER")) : -1; d.cg_force_global = getenv("MOR_CG_GLOBAL") ? 1 : 0; d.cg_slow_tail = getenv("MOR_CG_SLOW_TAIL") ? 1 : 0; d.g2_exact_only = getenv("MOR_G2_EXACT") ? 1 : 0;
   d.P = 1;
   if (d.score_R > 60) return set_error(MOR_ERR_INVALID, "pde_ub %g needs a %d-cell search radius (> 60)", (double)p.pde_ub, d.score_R);
   int bits = 1; while ((1 << bits) < d.Kcap) ++bits;
