@@ -703,7 +703,7 @@ template <bool LDS, int NT> __device__ __forceinline__ void cgf_body(const MorDe
 // slab are united across slabs, and the per-cluster records (root cell, size, first cloud index, offset, cursors: CGF_KL of them at most) live in LDS.  Same results: every quantity is
 // the one cgf_body computes.  Returns false — nothing published yet, the caller runs cgf_body from scratch — for streams with more than RC·NT cells or more than CGF_KL kept clusters.
 template <int NT, int RC> __device__ __forceinline__ bool cgf_fast(const MorDev &d, int s, int nocc, int *par, int *scr, int *kl, int *l_misc, const int *l_sc, const int *l_se) {
-  static_assert(CGF_KL <= NT, "one round of the per-cluster scans");
+  static_assert(CGF_KL <= NT && CGF_KL <= 1024, "one round of the per-cluster scans; ten bits of cluster id beside a cell's list entry");
   if (nocc > RC * NT) return false;
   const size_t so = (size_t)s * d.Nmax, ko = (size_t)s * d.Kcap;
   const int *start = d.cstart + (size_t)s * (d.Nmax + 1);
@@ -739,50 +739,52 @@ template <int NT, int RC> __device__ __forceinline__ bool cgf_fast(const MorDev 
   for (int i = 0; i < RC; ++i) if (r[i] >= 0) atomicAdd(&scr[r[i]], n[i]);
   __threadfence_block();
   __syncthreads();
-  // ---- kept components (:215-216)
+  // ---- kept components (:215-216): the root's scratch word (its size, > 0) becomes −(entry) − 2; the entry starts the minimum of its cloud indices
 #pragma unroll
   for (int i = 0; i < RC; ++i) {
     const int c = tid + i * NT;
     if (r[i] == c) {
       const long long sz = (long long)cg_ld<true>(scr + c);
-      if (sz >= d.min_cs && sz <= d.max_cs) { const int k = atomicAdd(&l_misc[0], 1); if (k < CGF_KL) { k_cell[k] = c; k_size[k] = (int)sz; } }
+      if (sz >= d.min_cs && sz <= d.max_cs) { const int k = atomicAdd(&l_misc[0], 1); if (k < CGF_KL) { k_size[k] = (int)sz; k_root[k] = 0x7fffffff; cg_st<true>(scr + c, -k - 2); } }
     }
   }
   __threadfence_block();
   __syncthreads();
   const int K = l_misc[0];
   if (K > CGF_KL || K > d.Kcap) return false;
-  // ---- smallest cloud index of every component at its root (the scratch array again)
+  // ---- smallest cloud index of every kept component (the others' are never asked for); r[i] becomes the cell's entry (−1: not in a kept component)
 #pragma unroll
-  for (int i = 0; i < RC; ++i) { const int c = tid + i * NT; if (c < nocc) scr[c] = 0x7fffffff; }
-  __threadfence_block();
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < RC; ++i) if (r[i] >= 0) atomicMin(&scr[r[i]], mnc[i]);
-  __threadfence_block();
-  __syncthreads();
-  if (tid < K) k_root[tid] = cg_ld<true>(scr + k_cell[tid]);
-  __threadfence_block();
-  __syncthreads();
-  // ---- cluster order: size descending, ties by smaller first cloud index; rank by counting.  A kept root's scratch word becomes −(cluster id) − 2 (the words of the other
-  //      roots keep their cloud indices, ≥ 0: "not kept")
-  if (tid < K) {
-    const int my_sz = k_size[tid], my_rt = k_root[tid]; int rank = 0;
-    for (int u = 0; u < K; ++u) { const int sz = k_size[u], rt = k_root[u]; rank += (sz > my_sz) || (sz == my_sz && rt < my_rt); }
-    cg_st<true>(scr + k_cell[tid], -rank - 2);
-    k_first[rank] = my_rt; k_off[rank] = my_sz; k_n[rank] = 0;
+  for (int i = 0; i < RC; ++i) {
+    int e = -1;
+    if (r[i] >= 0) { const int v = cg_ld<true>(scr + r[i]); if (v < 0) { e = -v - 2; atomicMin(&k_root[e], mnc[i]); } }
+    r[i] = e;
   }
   __threadfence_block();
   __syncthreads();
-  // ---- per-cell cluster id (a cell is a clique ⇒ one cluster), cells per cluster
+  // ---- cluster order: size descending, ties by smaller first cloud index; rank by counting
+  if (tid < K) {
+    const int my_sz = k_size[tid], my_rt = k_root[tid]; int rank = 0;
+    for (int u = 0; u < K; ++u) { const int sz = k_size[u], rt = k_root[u]; rank += (sz > my_sz) || (sz == my_sz && rt < my_rt); }
+    k_cell[tid] = rank;   // entry → cluster id
+    k_first[rank] = my_rt; k_off[rank] = my_sz; k_n[rank] = 0; k_cur[rank] = 0;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- per-cell cluster id (a cell is a clique ⇒ one cluster); the cell's piece of its cluster's range of cl_pts and its entry in the cluster's list of cells, both RELATIVE for
+  //      now (cgf_body: the cell holding the cluster's first point opens the range, the others take consecutive pieces behind it in the order their atomics arrive)
+  int rel[RC];
 #pragma unroll
   for (int i = 0; i < RC; ++i) {
     const int c = tid + i * NT;
+    rel[i] = 0;
     if (c < nocc) {
-      const int v = cg_ld<true>(scr + r[i]), id = v < 0 ? -v - 2 : -1;
-      r[i] = id;
+      const int id = r[i] >= 0 ? k_cell[r[i]] : -1;
       d.ccid[so + c] = id; reinterpret_cast<int *>(&d.cmeta[2 * (so + c)])[3] = id;
-      if (id >= 0) atomicAdd(&k_n[id], 1);
+      if (id >= 0) {
+        const bool opens = mnc[i] == k_first[id];
+        if (opens) k_root[id] = n[i]; else rel[i] = atomicAdd(&k_cur[id], n[i]);   // (k_root is free by now: per cluster, the points of the cell that opens its range)
+        r[i] = id | (atomicAdd(&k_n[id], 1) << 10);                               // cluster id (< CGF_KL ≤ 1024) | entry in the cluster's list of cells
+      } else r[i] = -1;
     } else r[i] = -1;
   }
   __threadfence_block();
@@ -808,23 +810,17 @@ template <int NT, int RC> __device__ __forceinline__ bool cgf_fast(const MorDev 
   }
   __threadfence_block();
   __syncthreads();
-  // ---- every cell's place in its cluster's range of cl_pts (cgf_body: the cell holding the cluster's first point opens the range, the others take consecutive pieces in the
-  //      order their atomics arrive) and the cells of every cluster as a list
-#pragma unroll
-  for (int i = 0; i < RC; ++i) if (r[i] >= 0 && mnc[i] == k_first[r[i]]) k_cur[r[i]] = k_off[r[i]] + n[i];
-  __threadfence_block();
-  __syncthreads();
+  // ---- every cell's place and the cells of every cluster as a list: absolute now
 #pragma unroll
   for (int i = 0; i < RC; ++i) {
     const int c = tid + i * NT;
     if (c >= nocc) continue;
-    const int k = r[i];
     int4 g = make_int4(0, -1, -1, 0);
-    if (k >= 0) {
-      const int first = k_first[k]; const bool opens = mnc[i] == first;
-      const int dst = opens ? k_off[k] : atomicAdd(&k_cur[k], n[i]);
+    if (r[i] >= 0) {
+      const int k = r[i] & 1023, first = k_first[k]; const bool opens = mnc[i] == first;
+      const int dst = k_off[k] + (opens ? 0 : k_root[k] + rel[i]);
       g = make_int4(dst - start[c], k, opens ? first : -1, 0);
-      d.clist[so + atomicAdd(&k_n[k], 1)] = c;
+      d.clist[so + k_n[k] + (r[i] >> 10)] = c;
     }
     d.cgat[so + c] = g;
   }
