@@ -440,7 +440,10 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
     }
     wave_lds_fence();
     const bool mine = n <= G2_MID_CAP;
-    if (!mine) { if (lane == 0) d.g2_big[so + w] = v; continue; }   // (the tags come off: k_g2_cov_big takes every entry ≥ 0)
+    if (!mine) {   // (the tags come off: k_g2_cov_big takes every entry ≥ 0 — from the batch-wide list of open voxels; a list that is full sends its workgroups through the streams' queues)
+      if (lane == 0) { d.g2_big[so + w] = v; const int e = atomicAdd(&d.g2_nopen[0], 1); if (e < d.g2_opencap) d.g2_open[e] = make_int2(s, v); }
+      continue;
+    }
     float ex[G2_MID_CAP / 64], ey[G2_MID_CAP / 64], ez[G2_MID_CAP / 64]; int er[G2_MID_CAP / 64];
 #pragma unroll
     for (int u = 0; u < G2_MID_CAP / 64; ++u) {
@@ -467,31 +470,54 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_cov_mid(MorDev d) {
 // what the middle tier left: one 1024-thread workgroup each (the LDS lets only one live on a CU anyway: sixteen waves sort four times faster than
 // four), up to G2_CAP neighbours in 128 KiB of LDS
 #define G2_BIG_T 1024
-#ifndef G2_BIG_G
-#define G2_BIG_G 8    // workgroups per stream of k_g2_cov_big
-#endif
-__global__ __launch_bounds__(G2_BIG_T) void k_g2_cov_big(MorDev d) {
-  const int s = blockIdx.y + d.s0, nbig = d.g2_nbig[s], bxq = blockIdx.x, gq = gridDim.x;   // (tried: two workgroups per stream shared out by the queues — the queue holds mostly entries the middle tier has settled, so a stream's few big voxels ended up behind each other in one workgroup: 4.3 ms)
+#define G2_BIG_WG 256   // workgroups of k_g2_cov_big (one per CU: its LDS lets only one live there)
+__device__ __forceinline__ void g2_big_voxel(const MorDev &d, int s, int v, unsigned long long *key, float *px, float *py, float *pz, int *cnt, int *l_rng, float *acc) {   // all threads of the workgroup
   const size_t so = (size_t)s * d.Nmax;
+  if (threadIdx.x == 0) *cnt = 0;
+  __syncthreads();
+  const float4 q = d.vcent[so + v];
+  g2_gather(d, s, q, key, cnt, G2_CAP, l_rng);
+  __syncthreads();
+  const int n = *cnt;
+  int bin = 0x7fffffff;
+  if (n > G2_CAP) { if (threadIdx.x == 0) mor_raise(d, s, 16u); }
+  else if (n > 3) bin = g2_voxel_bin<G2_CHUNK>(d, so, q, key, n, px, py, pz, acc);
+  if (bin != 0x7fffffff && bin == d.g2_used[s]) for (int i = threadIdx.x; i < n; i += G2_BIG_T) d.is_ground[so + (int)(unsigned)key[i]] = 2 * d.frame_no + 1;   // speculative marks (k_g2_mode)
+  if (threadIdx.x == 0) d.vbin[so + v] = bin;
+  __syncthreads();
+}
+// Round 5 gave every stream eight workgroups that walked the stream's queue (thousands of entries, nearly all settled) one dependent global load at a time and worked through whatever
+// open voxels fell to them — 427 µs alone, set by the stream with the most.  Now k_g2_cov_mid lists what it leaves open for the whole batch and the workgroups take entries by ticket.
+__global__ __launch_bounds__(G2_BIG_T) void k_g2_cov_big(MorDev d) {
   __shared__ unsigned long long key[G2_CAP];
   __shared__ float px[G2_CHUNK], py[G2_CHUNK], pz[G2_CHUNK];
-  __shared__ int cnt, l_rng[18];
+  __shared__ int cnt, l_rng[18], l_take;
   __shared__ float acc[6];
-  for (int w = bxq; w < nbig; w += gq) {
-    const int v = d.g2_big[so + w];
-    if (v < 0) continue;   // settled by k_g2_cov_mid
-    if (threadIdx.x == 0) cnt = 0;
-    __syncthreads();
-    const float4 q = d.vcent[so + v];
-    g2_gather(d, s, q, key, &cnt, G2_CAP, l_rng);
-    __syncthreads();
-    const int n = cnt;
-    int bin = 0x7fffffff;
-    if (n > G2_CAP) { if (threadIdx.x == 0) mor_raise(d, s, 16u); }
-    else if (n > 3) bin = g2_voxel_bin<G2_CHUNK>(d, so, q, key, n, px, py, pz, acc);
-    if (bin != 0x7fffffff && bin == d.g2_used[s]) for (int i = threadIdx.x; i < n; i += G2_BIG_T) d.is_ground[so + (int)(unsigned)key[i]] = 2 * d.frame_no + 1;   // speculative marks (k_g2_mode)
-    if (threadIdx.x == 0) d.vbin[so + v] = bin;
-    __syncthreads();
+  const int nopen = d.g2_nopen[0];
+  if (nopen <= d.g2_opencap) {
+    for (;;) {
+      if (threadIdx.x == 0) l_take = atomicAdd(&d.g2_nopen[1], 1);
+      __syncthreads();
+      const int e = l_take;
+      __syncthreads();
+      if (e >= nopen) return;
+      const int2 sv = d.g2_open[e];
+      g2_big_voxel(d, sv.x, sv.y, key, px, py, pz, &cnt, l_rng, acc);
+    }
+  }
+  // the list overflowed (never seen: 256 open voxels per stream on average): stream by stream through the queues, 1024 entries at a time
+  __shared__ int l_open[G2_BIG_T], l_nopen;
+  for (int s = (int)blockIdx.x + d.s0; s < d.s0 + d.B; s += (int)gridDim.x) {
+    const int nbig = d.g2_nbig[s]; const size_t so = (size_t)s * d.Nmax;
+    for (int base = 0; base < nbig; base += G2_BIG_T) {
+      if (threadIdx.x == 0) l_nopen = 0;
+      __syncthreads();
+      { const int w = base + (int)threadIdx.x; const int v_ = w < nbig ? d.g2_big[so + w] : -1; if (v_ >= 0) l_open[atomicAdd(&l_nopen, 1)] = v_; }
+      __syncthreads();
+      const int no = l_nopen;
+      for (int oi = 0; oi < no; ++oi) g2_big_voxel(d, s, l_open[oi], key, px, py, pz, &cnt, l_rng, acc);
+      __syncthreads();
+    }
   }
 }
 __global__ __launch_bounds__(MOR_BT) void k_g2_mode(MorDev d) {
@@ -532,6 +558,7 @@ __global__ __launch_bounds__(MOR_BT) void k_g2_mode(MorDev d) {
     d.g2_tag[s] = (best_bin != 0x7fffffff && best_bin == pred) ? 2 * d.frame_no + 1 : 2 * d.frame_no + 2;
     st_agent(&d.g2_pred[s], best_bin);
     d.mode_bin[s] = best_bin; d.g2_nbig[s] = 0;
+    if (s == d.s0) { d.g2_nopen[0] = 0; d.g2_nopen[1] = 0; }   // (the batch-wide list of open voxels: its readers are done — a kernel boundary lies in between)
   }   // (the queue of big voxels is empty again for the next frame on this copy)
 }
 // ground = union of the neighbour lists of the dominant bin's voxels (:184-191, de-duplicated): every trimmed point within the radius of such a

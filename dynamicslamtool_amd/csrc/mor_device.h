@@ -132,6 +132,7 @@ struct MorDev {
   int *is_ground;            // [B][Nmax]  per trimmed point
   float4 *vcent; int *vbin;  // [B][Nmax]  voxel centroids (dsc, :113) and bin id of accepted voxels
   int *g2_big, *g2_nbig;     // [B][Nmax], [B]  voxels with more neighbours than the one-wave kernel holds
+  int2 *g2_open; int *g2_nopen; int g2_opencap;   // [g2_opencap] (stream, voxel), [2] (entries, entries taken)  what k_g2_cov_mid leaves for k_g2_cov_big, ALL streams in one list: its workgroups — a whole CU's LDS each — take entries by ticket instead of walking their own stream's queue (a handful of open voxels per stream, dozens in a few streams)
   unsigned long long *g2_bits; int *g2_dir; int g2_nch;   // [B][gv.nrows][g2_nch·8]  occupancy bits of the VoxelGrid lattice, a row padded to g2_nch chunks of 512 cells, and the first cell of every word of them (row_cells_bits); null: the kernels search the keys (MOR_G2_NOBITS, or a lattice whose bits would not fit 2 GB per frame in flight)
   int *zmin_i, *zmax_i;      // [B·MOR_ZR]  ordered-int min / max z of the trimmed cloud, stream s at s·MOR_ZR
   float *zorg; int *zbase;   // [B]  z origin of the clustering grid / z base of the voxel lattice

@@ -454,8 +454,9 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
     if (ok) ok = hipMemcpy(o.zorg, z0.data(), B * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     if (d.gmode == 1) {   // voxel-covariance ground variant: the VoxelGrid sort and the per-voxel results
       for (int i = 0; i < 2; ++i) ok = ok && dalloc(b, o.rkeys[i], B * N) && dalloc(b, o.rvals[i], B * N);
-      ok = ok && dalloc(b, o.rhist, B * T * 256) && dalloc(b, o.gnz, B) && dalloc(b, o.vnz, B) && dalloc(b, o.rawbuf, B * N) && dalloc(b, o.is_ground, B * N) && dalloc(b, o.vcent, B * N) && dalloc(b, o.vbin, B * N) && dalloc(b, o.g2_big, B * N) && dalloc(b, o.g2_nbig, B) && hipMemset(o.g2_nbig, 0, B * sizeof(int)) == hipSuccess && hipMemset(o.is_ground, 0, B * N * sizeof(int)) == hipSuccess;
+      ok = ok && dalloc(b, o.rhist, B * T * 256) && dalloc(b, o.gnz, B) && dalloc(b, o.vnz, B) && dalloc(b, o.rawbuf, B * N) && dalloc(b, o.is_ground, B * N) && dalloc(b, o.vcent, B * N) && dalloc(b, o.vbin, B * N) && dalloc(b, o.g2_big, B * N) && dalloc(b, o.g2_nbig, B) && hipMemset(o.g2_nbig, 0, B * sizeof(int)) == hipSuccess && dalloc(b, o.g2_open, B * (size_t)256) && dalloc(b, o.g2_nopen, 2) && hipMemset(o.g2_nopen, 0, 2 * sizeof(int)) == hipSuccess && hipMemset(o.is_ground, 0, B * N * sizeof(int)) == hipSuccess;
       o.skey = o.rkeys[d.voxel_passes & 1]; o.sidx = o.rvals[d.voxel_passes & 1];
+      o.g2_opencap = (int)(B * 256);
       {   // occupancy bits of the lattice: 64 + 32 bytes per (y,z) row and 512 cells in x — 990 MB per frame in flight at B = 64, ±50 m, 0.2-m leaves, of which a frame touches the rows of its own z layers (25 MB)
         const size_t words = (size_t)B * (size_t)d.gv.nrows * (size_t)d.g2_nch * 8;
         if (!getenv("MOR_G2_NOBITS") && words * 12 <= ((size_t)2 << 30)) ok = ok && dalloc(b, o.g2_bits, words) && dalloc(b, o.g2_dir, words);   // (k_g2_cent writes every row of the stream's layers, every frame: no clearing)

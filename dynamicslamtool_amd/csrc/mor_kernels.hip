@@ -113,7 +113,7 @@ static void mor_launch_grid_sub(const MorDev &d, int sub, hipStream_t st, MorLau
   } else if (sub == 2) {
     MOR_LAUNCH(MK_G2_COV_MID, k_g2_cov_mid, dim3(64, d.B), da);
   } else if (sub == 3) {
-    MOR_LAUNCH_T(MK_G2_COV_BIG, k_g2_cov_big, dim3(G2_BIG_G, d.B), G2_BIG_T, da);   // (a few voxels per stream at most: every workgroup is a whole CU's LDS — 64 per stream were sixteen rounds of dispatches that mostly found nothing, 158 µs)
+    MOR_LAUNCH_T(MK_G2_COV_BIG, k_g2_cov_big, dim3(G2_BIG_WG), G2_BIG_T, da);   // (every workgroup is a whole CU's LDS: one per CU, entries of the batch-wide list by ticket)
   } else if (sub == 4) {
     MOR_LAUNCH(MK_G2_MODE, k_g2_mode, gB, da);
     MOR_LAUNCH(MK_G2_MARK, k_g2_mark, dim3(128 * d.B), da);
