@@ -22,8 +22,8 @@ __device__ __forceinline__ void tr_store_head(MorTrackDev &g, const MorTrackHead
   for (int i = lane; i < (int)(sizeof(MorTrackHead) / sizeof(int)); i += 64) gs[i] = ls[i];
 }
 // checkMovingClusterChain (:478-514) with recurseFindClusterChain (:415-453) and pushCentroid (:455-476)
-__global__ __launch_bounds__(64) void k_track_push(MorDev d) {
-  const int s = blockIdx.x + d.s0, lane = threadIdx.x;
+__device__ __forceinline__ void track_push_body(const MorDev &d, int s) {   // a 64-thread workgroup
+  const int lane = threadIdx.x;
   constexpr int TRKN = TRK;
   decide_body<64>(d, s);   // P5: thresholds, detection_results, host summary
   __threadfence_block();
@@ -152,6 +152,7 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
   tr_store_head(gt, t, lane);
   if (lane == 0) mor_publish_err(d, s);
 }
+__global__ __launch_bounds__(64) void k_track_push(MorDev d) { track_push_body(d, blockIdx.x + d.s0); }
 // filterCloud (:613-696) in two launches (round 3: k_track_filter | k_out_count | k_out_scatter).
 // k_track_filter — the loop over mo_vec (:630-671): nearest current centroid of every tracked one (squared fp32 distance, ties → lowest index), its
 //     whole cluster queued for removal before any test, confidence bookkeeping.  One workgroup per stream; it leaves the removal flags as a bit per
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(64) void k_track_push(MorDev d) {
 //  stream's two thousand output workgroups sat in the GPU's wave slots spinning while one wave walked the tracks, and kept the other lanes' kernels out.)
 // The keep test is ExtractIndices' negative set semantics; the size-check flag reproduces "more indices than points ⇒ empty output" (:676-678).
 #define FLT_T MOR_BT
-__device__ __forceinline__ void track_filter_body(const MorDev &d, int s, unsigned *l_mov /* Kcap / 32 words */) {
+template <int NT> __device__ __forceinline__ void track_filter_body(const MorDev &d, int s, unsigned *l_mov /* Kcap / 32 words */) {   // NT threads (FLT_T as a kernel of its own, 64 behind the tracking step)
   const int K = d.info[s].K, tid = threadIdx.x, lane = tid & 63;
   const bool w0 = tid < 64;   // the loop itself is the work of one wave (as a kernel of its own it was a 64-thread workgroup); the other waves help with the tables and keep the barriers
   const size_t ko = (size_t)s * d.Kcap;
@@ -181,8 +182,8 @@ __device__ __forceinline__ void track_filter_body(const MorDev &d, int s, unsign
   MorTrackDev &gt = d.tr[s];   // the tracked centroids are read once and written once (compacted in place): straight from / to global memory
   if (w0) { const int *gs = reinterpret_cast<const int *>(&gt); int *ls = reinterpret_cast<int *>(&t); for (int i = lane; i < (int)(sizeof(MorTrackHead) / sizeof(int)); i += 64) ls[i] = gs[i]; }
   const bool fits = K <= TRK;
-  for (int k = tid; k < (d.Kcap + 31) / 32; k += FLT_T) l_mov[k] = 0u;
-  if (fits) for (int k = tid; k < K; k += FLT_T) { l_cen[k] = d.centroid[d.cur][ko + k]; l_size[k] = off[k + 1] - off[k]; l_det[k] = d.det[ko + k]; }
+  for (int k = tid; k < (d.Kcap + 31) / 32; k += NT) l_mov[k] = 0u;
+  if (fits) for (int k = tid; k < K; k += NT) { l_cen[k] = d.centroid[d.cur][ko + k]; l_size[k] = off[k + 1] - off[k]; l_det[k] = d.det[ko + k]; }
   if (tid == 0) l_tot = 0ull;
   __syncthreads();
   // Every tracked centroid is handled independently of the others (its nearest cluster, its confidence, its own new
@@ -232,15 +233,15 @@ __device__ __forceinline__ void track_filter_body(const MorDev &d, int s, unsign
   const unsigned M = d.info[s].M;
   const bool xerr = l_tot > (unsigned long long)M;
   unsigned removed = 0;
-  for (int k = tid; k < K; k += FLT_T) if ((l_mov[k >> 5] >> (k & 31)) & 1u) removed += (unsigned)(fits ? l_size[k] : off[k + 1] - off[k]);
+  for (int k = tid; k < K; k += NT) if ((l_mov[k >> 5] >> (k & 31)) & 1u) removed += (unsigned)(fits ? l_size[k] : off[k + 1] - off[k]);
   removed = wave_sum(removed);
-  __shared__ unsigned l_rem[FLT_T / 64];
+  __shared__ unsigned l_rem[NT / 64];
   if (lane == 0) l_rem[tid >> 6] = removed;
   __syncthreads();
   unsigned *gm = d.moving + (size_t)s * (d.Kcap / 32 + 2);
-  for (int k = tid; k < (K + 31) / 32; k += FLT_T) gm[k] = l_mov[k];
+  for (int k = tid; k < (K + 31) / 32; k += NT) gm[k] = l_mov[k];
   if (tid == 0) {
-    unsigned rem = 0; for (int w = 0; w < FLT_T / 64; ++w) rem += l_rem[w];
+    unsigned rem = 0; for (int w = 0; w < NT / 64; ++w) rem += l_rem[w];
     const unsigned n_keep = xerr ? 0u : M - rem;
     gm[d.Kcap / 32] = xerr ? 1u : 0u; gm[d.Kcap / 32 + 1] = n_keep;
     d.info[s].n_keep = n_keep; d.h_nout[s] = (unsigned long long)n_keep + d.info[s].G; d.h_noff[s] = d.Nmax - (int)n_keep;
@@ -253,7 +254,18 @@ __device__ __forceinline__ void track_filter_body(const MorDev &d, int s, unsign
 }
 __global__ __launch_bounds__(FLT_T) void k_track_filter(MorDev d) {
   __shared__ unsigned l_mov[MOR_KCAP_MAX / 32];
-  track_filter_body(d, blockIdx.x + d.s0, l_mov);
+  track_filter_body<FLT_T>(d, blockIdx.x + d.s0, l_mov);
+}
+// The tracking step of a push and the loop of the filterCloud that follows it as ONE launch (round 6): in asynchronous mode the engine holds the tracking step of a push back until
+// it knows what comes next — a filterCloud (the usual case: this kernel; one launch and one queueing delay less per frame, the tracks' head read once) or something else (then
+// k_track_push alone).  Both are the work of one wave per stream; the second part reads what the first left in global memory from the same CU, behind a workgroup barrier.
+__global__ __launch_bounds__(64) void k_track_push_filter(MorDev d) {
+  const int s = blockIdx.x + d.s0;
+  track_push_body(d, s);
+  __threadfence_block();
+  __syncthreads();
+  __shared__ unsigned l_mov[MOR_KCAP_MAX / 32];
+  track_filter_body<64>(d, s, l_mov);
 }
 // one point of the filtered cloud into slot idx of a caller-provided buffer: packed (x,y,z,intensity), or — out_step32 — the 32-byte PointXYZI record of toPCLPointCloud2 (:690):
 // x@0 y@4 z@8 (1.0f @12) intensity@16, zeros behind it; a lane writes 32 consecutive bytes, a wave 2 KB

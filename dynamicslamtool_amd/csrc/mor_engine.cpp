@@ -123,6 +123,7 @@ struct mor_batch {
   uint64_t pipe_depth = 4, n_slots = 5;       // frames in flight (= copies of the per-frame arrays); cluster-array slots = depth + 1
   int env_cg_p = 0;         // test knob from the environment (MOR_CG_P: slabs per stream of the cell graph), read once at creation
   bool async = false, pending = false;   // async: push/filter only enqueue; pending: work enqueued since the last wait
+  bool track_held = false, fuse_track = true;   // asynchronous mode: the tracking step of the latest push has not been launched yet — the filterCloud that follows launches it together with its own loop (k_track_push_filter); anything else launches it alone first (flush_track).  MOR_FUSE_TRACK=0: never held back
   float4 **h_outptrs = nullptr, **d_outptrs = nullptr;   // caller-provided output pointers: pinned ring of MOR_ARGS_RING tables (one per filterCloud in flight), device copy per frame in flight
   hipEvent_t outptr_ev[MOR_ARGS_RING] = {}; uint64_t n_filters = 0, n_filter_calls = 0;
   float4 *d_outstage = nullptr;   // [depth][B][Nmax]  asynchronous filterCloud into host memory: the filtered clouds are assembled here and leave by DMA (allocated at the first such call)
@@ -243,8 +244,17 @@ static int configure(mor_batch *b) {
 
 // Waits for everything enqueued on the batch (no error reporting: read-backs use this, so that a capacity or HIP error of an
 // earlier frame of an asynchronous run stays in the sticky words until mor_batch_wait / the next synchronous push or filter reports it).
+static int flush_track(mor_batch *b) {   // the held-back tracking step of the latest push, as a launch of its own on that frame's lane
+  if (!b->track_held) return MOR_OK;
+  hipStream_t lane = b->lane_stream(b->frame - 1);
+  if (b->last_track && b->last_track_st != lane) HIP_TRY(hipStreamWaitEvent(lane, *b->last_track, 0));   // tracking state: after the previous frame's filterCloud loop
+  mor_launch_piece(b->d, 6, lane, &b->timer);
+  b->track_held = false;
+  return MOR_OK;
+}
 static int sync_all(mor_batch *b) {
   if (!b->pending) return MOR_OK;
+  { const int rcf = flush_track(b); if (rcf != MOR_OK) return rcf; }
   HIP_TRY(hipStreamSynchronize(b->sf)); HIP_TRY(hipStreamSynchronize(b->sc)); HIP_TRY(hipStreamSynchronize(b->sm)); HIP_TRY(hipStreamSynchronize(b->sb));
   for (auto &x : b->extra) if (x) HIP_TRY(hipStreamSynchronize(x));
   HIP_TRY(hipStreamSynchronize(b->s_h2d_[0])); HIP_TRY(hipStreamSynchronize(b->s_d2h_[0]));
@@ -367,6 +377,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   if (getenv("MOR_PIPE_DEPTH")) b->pipe_depth = std::min(MOR_MAX_DEPTH, std::max(1, atoi(getenv("MOR_PIPE_DEPTH"))));
   b->n_slots = b->pipe_depth + 1;
   if (getenv("MOR_CG_P")) b->env_cg_p = atoi(getenv("MOR_CG_P"));
+  if (getenv("MOR_FUSE_TRACK")) b->fuse_track = atoi(getenv("MOR_FUSE_TRACK")) != 0;
   if ((rc = configure(b)) != MOR_OK) return fail(rc);
   if (n_bad > MOR_TR_NB) return fail(set_error(MOR_ERR_INVALID, "n_bad = %d: windows longer than %d frames are not supported", n_bad, MOR_TR_NB));
   for (auto &ev : b->outptr_ev) if (hipEventCreate(&ev) != hipSuccess) return fail(set_error(MOR_ERR_HIP, "hipEventCreate failed"));
@@ -477,6 +488,7 @@ int mor_batch_streams(const mor_batch *b) { return b ? b->B : 0; }
 int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *poses) {
   if (!b || !clouds || !poses) return set_error(MOR_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(b->device));
+  { const int rcf = flush_track(b); if (rcf != MOR_OK) return rcf; }   // (a push behind a push: the earlier frame's tracking step goes out alone)
   const uint64_t k = b->frame;
   MorDev d = b->dtemp[k % b->pipe_depth]; const int B = d.B;
   uint64_t maxn = 0; size_t max_host_bytes = 0;
@@ -586,6 +598,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
       HIP_TRY(hipStreamWaitEvent(lane, b->ev_clusters[kp], 0));
       if (d.method == 2) HIP_TRY(hipStreamWaitEvent(lane, b->ev_pairs[kp], 0));   // … which frame k − 1's own voxel probe (method 2) must have finished reading
     }
+    if (trk && b->async && b->fuse_track) { b->track_held = true; continue; }   // held back: launched with the loop of the filterCloud that follows (mor_filter_batch), or alone by flush_track
     if (trk && b->last_track && b->last_track_st != lane) HIP_TRY(hipStreamWaitEvent(lane, *b->last_track, 0));   // tracking state: after the previous frame's filterCloud loop
     mor_launch_piece(d, id, lane, &b->timer);
     if (id == 3) HIP_TRY(hipEventRecord(b->ev_clusters[ks], lane));
@@ -637,7 +650,11 @@ int mor_filter_batch_ex(mor_batch *b, void *const *out, int out_on_device, uint6
     HIP_TRY(hipStreamWaitEvent(fs, b->ev_d2h[(k - b->pipe_depth) % MOR_MAX_SLOTS], 0));
   }
   if (host_async && b->d2h_used[k % MOR_MAX_SLOTS]) HIP_TRY(hipStreamWaitEvent(fs, b->ev_d2h[k % MOR_MAX_SLOTS], 0));   // a second filterCloud on this very frame rewrites its staging area: after the first call's copies
-  mor_launch_filter(d, fs, &b->timer, 1);
+  if (b->track_held) {   // the frame's own tracking step is still to come: one launch for it and this call's loop
+    if (b->last_track && b->last_track_st != fs) HIP_TRY(hipStreamWaitEvent(fs, *b->last_track, 0));   // tracking state: after the previous frame's filterCloud loop
+    mor_launch_filter(d, fs, &b->timer, 3);
+    b->track_held = false;
+  } else mor_launch_filter(d, fs, &b->timer, 1);
   HIP_TRY(hipEventRecord(b->ev_track[k % MOR_MAX_SLOTS], fs)); b->last_track = &b->ev_track[k % MOR_MAX_SLOTS]; b->last_track_st = fs;   // the tracking state is settled: the next frame's tracking step may follow
   mor_launch_filter(d, fs, &b->timer, 2);
   if (host_async) HIP_TRY(hipEventRecord(b->ev_out[k % MOR_MAX_SLOTS], fs));   // (the device → host copies below follow it)

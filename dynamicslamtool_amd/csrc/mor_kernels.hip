@@ -30,7 +30,7 @@
 const char *const mor_kernel_names[MK_COUNT] = {   // in MorKernelId order: "k_" + name = the __global__ function
     "classify", "scatter", "split", "heads_count", "heads_scatter", "cellboxes", "rhist", "rscan", "rscatter",
     "score_fast", "score_nb", "score_pde", "vox_clear", "vox_insert", "vox_probe",
-    "out", "g2_cov_mid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridcount", "gridplace", "cg_slab", "cg_final", "clusters", "g2_cent"};
+    "out", "g2_cov_mid", "g2_cov", "g2_cov_big", "g2_mode", "g2_mark", "track_push", "track_filter", "gridhash", "gridcount", "gridplace", "cg_slab", "cg_final", "clusters", "g2_cent", "track_push_filter"};
 
 // The kernels by stage (one translation unit; every file is #included exactly here):
 #include "kernels_common.h"
@@ -177,6 +177,7 @@ void mor_launch_piece(const MorDev &d, int piece, hipStream_t st, MorLaunchTimer
 
 void mor_launch_filter(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part) {   // part 1: the loop over mo_vec (:630-671; on EVERY filterCloud call, as in the reference — a second call on the same frame walks the tracks again; the next frame's tracking step waits for this only); part 2: the output
   if (part == 1) { MOR_LAUNCH_T(MK_TRACK_FILTER, k_track_filter, dim3(d.B), FLT_T, d); return; }
+  if (part == 3) { MOR_LAUNCH_T(MK_TRACK_PUSH_FILTER, k_track_push_filter, dim3(d.B), 64, d); return; }   // the tracking step the push held back + the loop of this filterCloud
   MOR_LAUNCH_T(MK_OUT, k_out, dim3(d.B * (d.g_out + (d.out_ptrs ? d.tiles : 0))), FLT_T, d);
 }
 

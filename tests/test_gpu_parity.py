@@ -525,11 +525,12 @@ print("OK")
 
 
 @pytest.mark.parametrize("env", [{"MOR_GH_TIER": "1"}, {"MOR_GH_TIER": "2", "MOR_CG_GLOBAL": "1"}, {"MOR_LANES": "2"}, {"MOR_PIPE_DEPTH": "8", "MOR_LANES": "6"}, {"MOR_PIPE_DEPTH": "1"},
-                                 {"MOR_PIPE_DEPTH": "2", "MOR_LANES": "1"}, {"MOR_CG_UNFUSED": "1"}, {"MOR_SINGLE_PASS_SPLIT": "0"}, {"MOR_PROP_MAP": "0"}, {"MOR_CG_SLOW_TAIL": "1"}, {"MOR_CG_SLOW_TAIL": "1", "MOR_CG_UNFUSED": "1"}])
+                                 {"MOR_PIPE_DEPTH": "2", "MOR_LANES": "1"}, {"MOR_CG_UNFUSED": "1"}, {"MOR_SINGLE_PASS_SPLIT": "0"}, {"MOR_PROP_MAP": "0"}, {"MOR_CG_SLOW_TAIL": "1"}, {"MOR_CG_SLOW_TAIL": "1", "MOR_CG_UNFUSED": "1"}, {"MOR_FUSE_TRACK": "0"}])
 def test_kernel_variants(env):
     """The tiers behind the default paths must give the same results: k_gridhash with its big LDS table / its global-memory table,
     slab and merge forests in global memory, other numbers of lanes / pipeline depths, the merge of the slab forests as its own launch (with the register / LDS form of the
-    merge, cgf_fast — the default — and with the general code, MOR_CG_SLOW_TAIL), the count + scatter
+    merge, cgf_fast — the default — and with the general code, MOR_CG_SLOW_TAIL), the tracking step of an asynchronous push as a launch of its own instead of held back for the
+    filterCloud behind it (MOR_FUSE_TRACK=0; the script's asynchronous leg runs the fused launch by default and pushes without a filterCloud in test_pushes_without_…), the count + scatter
     form of the split, the same number of workgroups for every stream instead of shares by work.  The tier is chosen when the batch is created,
     from the environment: child process (synchronous frames against the oracle, then an asynchronous run without waits against a
     synchronous one)."""
