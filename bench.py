@@ -398,6 +398,10 @@ def roofline_of(leg, value_per_gpu, steps_for_kernels, workload):
     per_kernel, path_bytes, covered = {}, 0.0, True
     for k, v in kernels.items():
         hb = tr.get(k, {}).get("hbm_bytes_per_launch")
+        if hb is None and k == "k_track_push_filter" and "k_track_push" in tr and "k_track_filter" in tr:
+            # the counter passes profile SYNCHRONOUS steps (exp/pmc_run.py), where the tracking step of a push and the loop of its filterCloud are two launches; the asynchronous
+            # legs run them as one (k_track_push_filter): the same work, the two launches' bytes together (0.7 MB of a step's 640)
+            hb = tr["k_track_push"]["hbm_bytes_per_launch"] + tr["k_track_filter"]["hbm_bytes_per_launch"]
         per_step = v["launches"] / steps_for_kernels
         per_kernel[k] = {"avg_us": v["avg_us"], "avg_us_alone": kernels_alone.get(k), "launches_per_step": round(per_step, 2), "hbm_bytes_per_launch": hb,
                          "GBps": None if hb is None else round(hb / (v["avg_us"] * 1e-6) / 1e9, 1), "GBps_alone": None if hb is None or not kernels_alone.get(k) else round(hb / (kernels_alone[k] * 1e-6) / 1e9, 1)}
