@@ -63,7 +63,7 @@ __device__ __forceinline__ void publish_split(const MorDev &d, int s, int n_ng, 
       const float zmax = f.T ? ordered_float(d.zmax_i[MOR_ZR * s]) : 0.f;
       d.gnz_out[s] = max(1, min(d.cg_nz, (int)floorf((zmax - zmin) * d.cg_inv_cs) + 2));
     }
-    if (d.vnz_out) { d.vnz_out[s] = voxel_layers(d, s); d.g2_used[s] = ld_agent(&d.g2_pred[s]); }   // … and the bet on the mode bin this frame's kernels mark by: ONE snapshot per frame (later frames' k_g2_mode update g2_pred while this frame's kernels run)   // layers of the VoxelGrid lattice (the later kernels of pass A read it through stream_grid)
+    if (d.vnz_out) { d.vnz_out[s] = voxel_layers(d, s); d.g2_used[s] = d.g2_nobet ? 0x7ffffffe : ld_agent(&d.g2_pred[s]); }   // … and the bet on the mode bin this frame's kernels mark by: ONE snapshot per frame (later frames' k_g2_mode update g2_pred while this frame's kernels run)   // layers of the VoxelGrid lattice (the later kernels of pass A read it through stream_grid)
   }
 }
 // pass 2: order-preserving split into `cloud` / ground, cell histogram, forest init

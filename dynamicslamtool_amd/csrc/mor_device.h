@@ -150,6 +150,7 @@ struct MorDev {
   int *gh_hint;  // [B] occupied cells of the stream's latest grid build (one array for all copies of the per-frame state): a stream starts at the smallest tier that holds 17/16 of it and moves up when its table overflows
   int *slab_y, *slab_c, *slab_e;    // [B][MOR_MAXP+1]  slabs of the cell graph: first y-slice, first compact cell id, end of the look-ahead (cells of the next two y-slices)
   int g2_exact_only;         // test knob (MOR_G2_EXACT): the voxel ground variant takes no verdict from the screen — every voxel goes through the ordered sums
+  int g2_nobet;              // test knob (MOR_G2_NOBET): the voxel ground variant bets on a mode bin no frame has — every frame loses its bet and marks the ground in k_g2_mark
   int cg_slow_tail;          // test knob (MOR_CG_SLOW_TAIL): the merge of the slab forests by the general code (cgf_body) even where the register / LDS form (cgf_fast) applies
   int P, cg_force_global;    // workgroups per stream of k_cg_slab this frame (= slabs per stream when every stream gets the same); test knob: forests in global memory
   int *slab_p; int slab_T;   // [B] slabs of each stream (slab_bounds); own cells per slab the host aims at when the slabs follow the streams' cell counts (0: d.P slabs for every stream)

@@ -233,7 +233,7 @@ static int configure(mor_batch *b) {
   d.gnz = nullptr; d.gnz_out = nullptr; d.vnz = nullptr; d.vnz_out = nullptr; d.cg_nz = d.g.nz; d.cg_inv_cs = d.g.inv_cs;
   d.t1_budget = 64;   // points a thread of the worklist tiers looks at before it hands its query to the wave tier
   // test switches (defaults: the fast paths): MOR_GH_TIER=1|2 starts k_gridhash with its big LDS table / its global-memory table; MOR_CG_GLOBAL forces the global-memory forests
-  d.gh_tier = getenv("MOR_GH_TIER") ? atoi(getenv("MOR_GH_TIER")) : -1; d.cg_force_global = getenv("MOR_CG_GLOBAL") ? 1 : 0; d.cg_slow_tail = getenv("MOR_CG_SLOW_TAIL") ? 1 : 0; d.g2_exact_only = getenv("MOR_G2_EXACT") ? 1 : 0;
+  d.gh_tier = getenv("MOR_GH_TIER") ? atoi(getenv("MOR_GH_TIER")) : -1; d.cg_force_global = getenv("MOR_CG_GLOBAL") ? 1 : 0; d.cg_slow_tail = getenv("MOR_CG_SLOW_TAIL") ? 1 : 0; d.g2_nobet = getenv("MOR_G2_NOBET") ? 1 : 0; d.g2_exact_only = getenv("MOR_G2_EXACT") ? 1 : 0;
   d.P = 1;
   if (d.score_R > 60) return set_error(MOR_ERR_INVALID, "pde_ub %g needs a %d-cell search radius (> 60)", (double)p.pde_ub, d.score_R);
   int bits = 1; while ((1 << bits) < d.Kcap) ++bits;
@@ -548,7 +548,8 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
        // a launch sized for the largest stream was mostly workgroups that found nothing to do (32 per stream for a mean of 5 chunks).
       uint64_t sumM = 0; uint32_t mxM = 0; for (int s = 0; s < B; ++s) { const uint32_t m = k > 0 ? d.h_info[s].M : (uint32_t)maxn; sumM += m; mxM = std::max(mxM, m); }
       const uint64_t meanM = (sumM + B - 1) / B, ref = d.prop_map ? meanM * 23 / 20 : (uint64_t)mxM * 5 / 4;
-      { uint64_t sumC = 0; for (int s = 0; s < B; ++s) sumC += k > 0 ? d.h_info[s].C : 0u; d.label_prefill = k > 0 && 2 * sumC < sumM; }   // (either way the labels are the same: a matter of where the −1 of an unclustered point is written)
+      { uint64_t sumC = 0; for (int s = 0; s < B; ++s) sumC += k > 0 ? d.h_info[s].C : 0u; d.label_prefill = k > 0 && 2 * sumC < sumM; }
+      if (const char *lp = getenv("MOR_LABEL_PREFILL")) d.label_prefill = atoi(lp) != 0;   // test knob: the path is otherwise chosen per push from host mirrors the device updates asynchronously — which one a frame takes depends on timing; 0 / 1 hold each to the oracle   // (either way the labels are the same: a matter of where the −1 of an unclustered point is written)
       const int want = (int)((ref + MOR_GC_CHUNK - 1) / MOR_GC_CHUNK) + (d.prop_map ? 1 : 0);
       d.gc_P = std::max(1, std::min(std::min(want, d.gc_chunks), std::max(1, 2048 / B)));
       d.g_out = std::max(1, std::min(want, d.tiles));

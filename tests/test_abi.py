@@ -50,3 +50,17 @@ def test_product_never_references_oracle():
     import subprocess
     out = subprocess.run(["ldd", engine.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_no_autobuild_under_a_profiler():
+    """engine.lib() rebuilds a stale library by itself — but never when a profiler's preload is in the environment (rocprofv3's tool library initialises the GPU in
+    every process that inherits it, and hipcc is a chain of exec hops; a GPU-initialised process replacing its program takes the box down on this pool)."""
+    assert not engine._profiler_preload({"PATH": "/usr/bin", "HOME": "/root"})
+    for env in ({"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so"}, {"ROCP_TOOL_LIBRARIES": "x.so"}, {"ROCPROFILER_LIBRARY_CTOR": "1"}, {"ROCPROF_OUTPUT_PATH": "/tmp"}, {"HSA_TOOLS_LIB": "libx.so"}):
+        assert engine._profiler_preload(env), env
+    for script in ("profiles/collect.sh", "exp/pmc_atomics.sh", "exp/pmc_mem.sh", "exp/pmc_cg_phases.sh"):
+        lines = [l.split("   #")[0].strip() for l in open(os.path.join(ROOT, script)).read().split("\n") if l.strip() and not l.strip().startswith("#")]   # (commands without their trailing comments)
+        guard = [i for i, l in enumerate(lines) if "MOR_NO_AUTOBUILD=1" in l]
+        prof = [i for i, l in enumerate(lines) if l.startswith("rocprofv3 ") or " rocprofv3 " in l]
+        assert guard and prof and guard[0] < prof[0], script
+

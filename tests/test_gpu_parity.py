@@ -525,7 +525,7 @@ print("OK")
 
 
 @pytest.mark.parametrize("env", [{"MOR_GH_TIER": "1"}, {"MOR_GH_TIER": "2", "MOR_CG_GLOBAL": "1"}, {"MOR_LANES": "2"}, {"MOR_PIPE_DEPTH": "8", "MOR_LANES": "6"}, {"MOR_PIPE_DEPTH": "1"},
-                                 {"MOR_PIPE_DEPTH": "2", "MOR_LANES": "1"}, {"MOR_CG_UNFUSED": "1"}, {"MOR_SINGLE_PASS_SPLIT": "0"}, {"MOR_PROP_MAP": "0"}, {"MOR_CG_SLOW_TAIL": "1"}, {"MOR_CG_SLOW_TAIL": "1", "MOR_CG_UNFUSED": "1"}, {"MOR_FUSE_TRACK": "0"}])
+                                 {"MOR_PIPE_DEPTH": "2", "MOR_LANES": "1"}, {"MOR_CG_UNFUSED": "1"}, {"MOR_SINGLE_PASS_SPLIT": "0"}, {"MOR_PROP_MAP": "0"}, {"MOR_CG_SLOW_TAIL": "1"}, {"MOR_CG_SLOW_TAIL": "1", "MOR_CG_UNFUSED": "1"}, {"MOR_FUSE_TRACK": "0"}, {"MOR_LABEL_PREFILL": "1"}])
 def test_kernel_variants(env):
     """The tiers behind the default paths must give the same results: k_gridhash with its big LDS table / its global-memory table,
     slab and merge forests in global memory, other numbers of lanes / pipeline depths, the merge of the slab forests as its own launch (with the register / LDS form of the
@@ -834,6 +834,19 @@ def test_voxel_covariance_ground_hdl64():
     o = Oracle(p)
     o.push(*frames[0])
     assert o.counts().n_ground > 20000   # the ground plane is the dominant bin
+
+
+@pytest.mark.parametrize("env", [{"MOR_G2_NOBET": "1"}, {"MOR_LABEL_PREFILL": "0"}, {"MOR_LABEL_PREFILL": "1"}])
+def test_voxel_covariance_ground_paths_chosen_by_timing(env):
+    """Two choices of the voxel ground variant depend on what the device has reported by the time the host enqueues a frame: the mode bin a frame bets its
+    speculative ground marks on (lost on the first frame, won afterwards — MOR_G2_NOBET makes EVERY frame lose it, so k_g2_mark marks the ground of every frame) and where the −1
+    of unclustered cloud points is written (`label_prefill`: forced off and on).  Each forced path against the oracle, frame by frame, then without waits against synchronous use."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _VARIANT_SCRIPT.replace("p = kitti_params(1)", "p = kitti_params(1); p.ground_method = 1")
+    assert script != _VARIANT_SCRIPT
+    r = subprocess.run([sys.executable, "-c", script % (root, os.path.join(root, "tests"))], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_voxel_covariance_ground_ordered_sums_only(monkeypatch):
