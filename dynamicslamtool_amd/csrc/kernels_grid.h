@@ -416,23 +416,34 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
     __syncthreads();
     cpre[tid] = ex;
     __syncthreads();
-    for (int g = tid; g < total; g += GH_T) {
+    // (four entries per thread and round trip: the workgroup has a CU to itself — sixteen waves are all that hides the latency of its loads —, and an entry per round trip left the
+    //  sweep of the million-point clouds' 60 000 entries at 60 exposed trips)
+    for (int g0 = tid; g0 < total; g0 += 4 * GH_T) {
       if (gh_ld<true>(&l_misc[1])) break;
-      int lo = 0, hi = nch - 1;   // last chunk whose prefix ≤ g
-      while (lo < hi) { const int m = (lo + hi + 1) >> 1; if (cpre[m] <= g) lo = m; else hi = m - 1; }
-      const size_t at = (size_t)lo * GC_CHUNK + (g - cpre[lo]);
-      const int2 kc = clist[at];
-      const int want = kc.x + 1; unsigned h = hash_slot(kc.x, hshift); bool ok = false;
-      for (int probes = 0; probes < H; ++probes) {
-        int k = gh_ld<TL>(tkey + h);
-        if (k == 0) {
-          k = atomicCAS(tkey + h, 0, want);
-          if (k == 0) { k = want; const int n = atomicAdd(&l_misc[0], 1); if (n < cell_cap) gh_st<CL>(cells + n, (int)h); else gh_st<true>(&l_misc[1], 1); }
-        }
-        if (k == want) { ok = true; break; }
-        h = (h + 1) & mask;
+      size_t at[4]; int2 kc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int g = min(g0 + u * GH_T, total - 1);
+        int lo = 0, hi = nch - 1;   // last chunk whose prefix ≤ g
+        while (lo < hi) { const int m = (lo + hi + 1) >> 1; if (cpre[m] <= g) lo = m; else hi = m - 1; }
+        at[u] = (size_t)lo * GC_CHUNK + (g - cpre[lo]);
+        kc[u] = clist[at[u]];
       }
-      if (ok) cent[at] = make_int2((int)h, atomicAdd(tval + h, kc.y)); else gh_st<true>(&l_misc[1], 1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (g0 + u * GH_T >= total) break;
+        const int want = kc[u].x + 1; unsigned h = hash_slot(kc[u].x, hshift); bool ok = false;
+        for (int probes = 0; probes < H; ++probes) {
+          int k = gh_ld<TL>(tkey + h);
+          if (k == 0) {
+            k = atomicCAS(tkey + h, 0, want);
+            if (k == 0) { k = want; const int n = atomicAdd(&l_misc[0], 1); if (n < cell_cap) gh_st<CL>(cells + n, (int)h); else gh_st<true>(&l_misc[1], 1); }
+          }
+          if (k == want) { ok = true; break; }
+          h = (h + 1) & mask;
+        }
+        if (ok) cent[at[u]] = make_int2((int)h, atomicAdd(tval + h, kc[u].y)); else gh_st<true>(&l_misc[1], 1);
+      }
     }
   } else
   for (int c = 0; c < nch; ++c) {
