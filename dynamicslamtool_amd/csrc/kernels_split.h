@@ -146,8 +146,10 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
 // exposed load latency is not what the split waits for.
 #define SPLIT_SPIN_LIMIT (1u << 22)
 #define SP_ROWS MOR_SP_ROWS
-#define SP_TILE (4 * SP_ROWS * 64)   // records per tile of the single-read split
-#define SP_DESC_STRIDE(d) ((size_t)(d).tiles_max * (8 / SP_ROWS))
+#define SP_NW MOR_SP_NW
+#define SP_TILE (SP_NW * SP_ROWS * 64)   // records per tile of the single-read split
+#define SP_NWS (SP_NW < 4 ? 4 : SP_NW)   // slots per count array in LDS
+#define SP_DESC_STRIDE(d) ((size_t)(d).tiles_max * (8 / SP_ROWS) * 4 / SP_NW + 1)
 __device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // loads only (no use of the data here: the wait for them belongs to split_tile, a step later); cls carries the ground flag of pass B
 template <bool PASSB> __device__ __forceinline__ void split_load_tile(const MorDev &d, const MorStreamArgs &a, int s, uint32_t n_in, int t, float4 (&p)[SP_ROWS], int (&cls)[SP_ROWS]) {
@@ -178,11 +180,11 @@ template <bool PASSB> __device__ __forceinline__ void split_count(const MorDev &
     // array); the host rebuilds the index lists from them when asked (mor_get_ground_indices, mor_get_labels)
     if (lane_id() == 0 && base + it * 64 < n_in) { unsigned long long *cm = d.cls_mask + ((size_t)s * d.cls_rows + (base + it * 64) / 64) * 2; cm[0] = m_ng; cm[1] = m_g; }
   }
-  if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[4 + wave_id()] = c_g; }
+  if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[SP_NWS + wave_id()] = c_g; }
   __syncthreads();
-  m.tng = sh[0] + sh[1] + sh[2] + sh[3]; m.tg = sh[4] + sh[5] + sh[6] + sh[7];
-  m.wng = 0; m.wg = 0;
-  for (int w = 0; w < wave_id(); ++w) { m.wng += sh[w]; m.wg += sh[4 + w]; }
+  m.tng = 0; m.tg = 0; m.wng = 0; m.wg = 0;
+#pragma unroll
+  for (int w = 0; w < SP_NW; ++w) { m.tng += sh[w]; m.tg += sh[SP_NWS + w]; if (w < wave_id()) { m.wng += sh[w]; m.wg += sh[SP_NWS + w]; } }
   if (threadIdx.x == 0)
     __hip_atomic_store(d.split_desc + (size_t)s * SP_DESC_STRIDE(d) + t, ((unsigned long long)epoch << 32) | ((unsigned long long)(unsigned)m.tng << 16) | (unsigned long long)(unsigned)m.tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -235,7 +237,7 @@ template <bool PASSB> __device__ __forceinline__ void split_store(const MorDev &
     r_ng += __popcll(m_ng); r_g += __popcll(m_g);
   }
 }
-template <bool PASSB> __global__ __launch_bounds__(MOR_BT, 4) void k_split(MorDev d) {   // (≤ 128 VGPRs at least — 73 with 1024-record tiles; with 2048-record tiles the compiler left to itself wandered between 126 and 150 registers with unrelated edits, and at 150 the split took 115 instead of 89 µs)
+template <bool PASSB> __global__ __launch_bounds__(64 * SP_NW, 4) void k_split(MorDev d) {   // (≤ 128 VGPRs at least — 73 with 1024-record tiles; with 2048-record tiles the compiler left to itself wandered between 126 and 150 registers with unrelated edits, and at 150 the split took 115 instead of 89 µs)
   int s, g; map_block(d.B, d.sp_g, s, g);
   const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
   // As the first kernel of a frame (crop variant) this one reads the stream's arguments straight from the page-locked slot the host filled,
@@ -244,7 +246,7 @@ template <bool PASSB> __global__ __launch_bounds__(MOR_BT, 4) void k_split(MorDe
   const uint32_t n_in = pass_count(d, a, s);
   const int nt = (int)((n_in + SP_TILE - 1) / SP_TILE);
   const unsigned epoch = 2u * (unsigned)d.frame_no + (d.gmode == 2 ? 2u : 1u);   // never 0 (fresh descriptors), never the tag of an earlier pass over this table
-  __shared__ int sh[16], s_ex[6];   // two copies of each, used in turn by the two halves of the loop: between two uses of a copy lies a workgroup barrier of the other half
+  __shared__ int sh[4 * SP_NWS], s_ex[6];   // two copies of each, used in turn by the two halves of the loop: between two uses of a copy lies a workgroup barrier of the other half
   int *tk = d.tickets + (size_t)s * TK_COUNT + TK_SPLIT;
   const int tk_total = 2 * d.sp_g + nt;
   if (threadIdx.x == 0) {
@@ -268,7 +270,7 @@ template <bool PASSB> __global__ __launch_bounds__(MOR_BT, 4) void k_split(MorDe
   if (t < nt) split_count<PASSB>(d, s, t, n_in, epoch, pa, ca, sh, ma);
   while (t < nt) {   // pa: tile t, counted and published; pb: tile t1, loaded
     int nx = 0;
-    if (t1 < nt) split_count<PASSB>(d, s, t1, n_in, epoch, pb, cb, sh + 8, mb);   // the next tile's aggregate is out before this workgroup waits for anybody
+    if (t1 < nt) split_count<PASSB>(d, s, t1, n_in, epoch, pb, cb, sh + 2 * SP_NWS, mb);   // the next tile's aggregate is out before this workgroup waits for anybody
     if (threadIdx.x == 0) nx = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     split_store<PASSB>(d, G, s, t, nt, t_prev, n_in, epoch, pa, ca, ma, ex_ng, ex_g, s_ex, nx);
     if (threadIdx.x == 0 && nx + 1 == tk_total) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -7,9 +7,13 @@
 
 #define MOR_TILE 2048   // points per workgroup tile: 4 waves × 8 coalesced 1-KiB rows of float4
 #ifndef MOR_SP_ROWS
-#define MOR_SP_ROWS 4    // rows of 64 records per wave and tile of the single-read split (k_split): its tiles are 4 waves × MOR_SP_ROWS × 64 records (8, 4 or 2 rows)
+#define MOR_SP_ROWS 4    // rows of 64 records per wave and tile of the single-read split (k_split): its tiles are MOR_SP_NW waves × MOR_SP_ROWS × 64 records (8, 4 or 2 rows)
 #endif
 #define MOR_BT 256      // threads per workgroup
+#ifndef MOR_SP_NW
+#define MOR_SP_NW 8      // waves per workgroup of the single-read split (k_split): a tile is MOR_SP_NW × MOR_SP_ROWS × 64 records.  Round 6: 8 waves × 4 rows — 2048-record tiles at the 32 data registers of the
+                        // 1024-record form (half the descriptors, barriers and tickets per byte): k_split alone 97 → 82 µs, hdl64_b64 +1.9 %, agg10_b32 +2.4 % interleaved; 1 / 2 waves (tiles of 256 / 512: the wave-granular form) −6 / −3 %, 16 waves −0.5 % against 8
+#endif
 #define MOR_CHUNK 2048  // points per work item of the per-cluster reductions
 #define MOR_KGRID 128   // workgroups per stream for per-cluster kernels (grid-stride over clusters)
 

@@ -217,7 +217,7 @@ static int configure(mor_batch *b) {
      // tiles are handed out by ticket, so the look-back does not depend on which workgroups are resident)
     int ncu = 256; hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b->device);
     const int hold = std::max(1, mor_split_blocks_per_cu()) * ncu;
-    d.sp_g = std::max(2, std::min(32, hold / b->B));
+    d.sp_g = std::max(2, std::min(std::max(2, 32 * 4 / MOR_SP_NW), hold / b->B));
     if (getenv("MOR_SP_G")) d.sp_g = std::max(2, std::min(64, atoi(getenv("MOR_SP_G"))));   // (test knob: tests/test_gpu_parity.py runs 64 per stream, four times what the GPU holds)
     if (b->B * 2 > hold) d.two_pass_split = 1;
   }
@@ -447,7 +447,7 @@ mor_batch *mor_batch_create(const mor_params *p, int n_bad, int n_good, int n_st
   for (int c = 0; c < (int)b->pipe_depth; ++c) {
     MorDev o = d; MorStreamArgs *dargs = nullptr;
     ok = dalloc(b, dargs, B) && dalloc(b, o.info, B) && hipMemset(o.info, 0, B * sizeof(MorFrameInfo)) == hipSuccess && dalloc(b, o.tickets, B * 8) && hipMemset(o.tickets, 0, B * 8 * sizeof(int)) == hipSuccess;
-    ok = ok && dalloc(b, o.tile_cnt, B * T * 2) && dalloc(b, o.split_desc, B * T * (8 / MOR_SP_ROWS)) && hipMemset(o.split_desc, 0, B * T * (8 / MOR_SP_ROWS) * sizeof(unsigned long long)) == hipSuccess;   // (frame tags of the single-read split start at 1)
+    ok = ok && dalloc(b, o.tile_cnt, B * T * 2) && dalloc(b, o.split_desc, B * (T * (8 / MOR_SP_ROWS) * 4 / MOR_SP_NW + 1)) && hipMemset(o.split_desc, 0, B * (T * (8 / MOR_SP_ROWS) * 4 / MOR_SP_NW + 1) * sizeof(unsigned long long)) == hipSuccess;   // (frame tags of the single-read split start at 1)
     ok = ok && dalloc(b, o.cloud, B * N) && dalloc(b, o.ground, 2 * B * N) && dalloc(b, o.cls_mask, B * (size_t)d.cls_rows * 2) && dalloc(b, o.pkey, B * N) && dalloc(b, o.pslot, B * N) && dalloc(b, o.gc_list, B * N) && dalloc(b, o.gc_ent, B * N) && dalloc(b, o.gc_n, B * (size_t)d.gc_chunks) && dalloc(b, o.gc_tab, B * (size_t)16384) && dalloc(b, o.gc_tabsel, B);
     ok = ok && dalloc(b, o.gh_rowlist, B * N) && dalloc(b, o.gh_cells, B * N) && dalloc(b, o.gh_rowfill, B * R1) && dalloc(b, o.gh_key, B * (size_t)d.Hcell) && dalloc(b, o.gh_val, B * (size_t)d.Hcell);
     ok = ok && dalloc(b, o.ckey, B * N + 8) && dalloc(b, o.cstart, B * (N + 1)) && dalloc(b, o.row_start, B * R1) && dalloc(b, o.cmin, B * N) && dalloc(b, o.cmeta, 2 * B * N) && dalloc(b, o.crep, B * N) && dalloc(b, o.sorted, B * N) && dalloc(b, o.scell, B * N) && dalloc(b, o.csum, B * N);

@@ -66,8 +66,8 @@ static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunch
   const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B);
   if (part == 2) goto grid;
   if (d.gmode != 1 && !d.two_pass_split) {
-    if (d.gmode == 2) MOR_LAUNCH(MK_SPLIT, k_split<true>, dim3(d.B * d.sp_g), d);   // (pass B of the voxel ground variant: the records carry a ground flag; two instances so that the crop variant does not keep registers for it)
-    else MOR_LAUNCH(MK_SPLIT, k_split<false>, dim3(d.B * d.sp_g), d);
+    if (d.gmode == 2) MOR_LAUNCH_T(MK_SPLIT, k_split<true>, dim3(d.B * d.sp_g), 64 * MOR_SP_NW, d);   // (pass B of the voxel ground variant: the records carry a ground flag; two instances so that the crop variant does not keep registers for it)
+    else MOR_LAUNCH_T(MK_SPLIT, k_split<false>, dim3(d.B * d.sp_g), 64 * MOR_SP_NW, d);
   } else {
     const dim3 gS(d.B * d.split_g);
     MOR_LAUNCH(MK_CLASSIFY, k_classify, gS, d);
@@ -194,6 +194,6 @@ void mor_launch_copy(void *dst, const void *src_pinned, size_t bytes, hipStream_
 // workgroups of k_split one CU holds (registers decide): the host keeps sp_g × B within what the whole GPU holds at once
 int mor_split_blocks_per_cu() {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_split<false>, MOR_BT, 0) != hipSuccess) n = 2;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_split<false>, 64 * MOR_SP_NW, 0) != hipSuccess) n = 2;
   return n < 1 ? 1 : n;
 }

@@ -11,7 +11,7 @@ SRC = os.path.join(ROOT, "dynamicslamtool_amd", "csrc", "mor_kernels.hip")
 
 # kernel: (max VGPRs, max scratch bytes per lane, max LDS bytes per workgroup)
 LIMITS = {
-    "k_split<false>": (80, 0, 16 * 1024),           # six 256-thread workgroups per CU with 1024-record tiles (73 VGPRs)
+    "k_split<false>": (80, 0, 28 * 1024),           # three 512-thread workgroups per CU (round 6: eight waves × four rows — 2048-record tiles at 73 VGPRs; 48 bytes of LDS per thread are the compiler's: the tiles' class arrays promoted from private memory)
     "k_gridcount": (64, 0, 36 * 1024),
     "k_gridplace": (80, 0, 24 * 1024),
     "k_cellboxes": (128, 0, 1024),
