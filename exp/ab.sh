@@ -8,7 +8,7 @@ timeout 200 python exp/quick.py --workload $W --steps $S --reps 3 > /dev/null 2>
 declare -A R
 for ((i = 0; i < N; i++)); do
   for cfg in "$@"; do
-    v=$(if [ "$cfg" = "-" ]; then timeout 300 python exp/quick.py --workload $W --steps $S --reps 5; else env $cfg timeout 300 python exp/quick.py --workload $W --steps $S --reps 5; fi 2>&1 | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(int(d['median']), '' if d['sane'] else 'NOT-SANE')")
+    v=$(if [ "$cfg" = "-" ]; then timeout 300 python exp/quick.py --workload $W --steps $S --reps 5; else env $cfg timeout 300 python exp/quick.py --workload $W --steps $S --reps 5; fi 2>> gpurun_out/ab_stderr.log | tail -1 | tee -a gpurun_out/ab_stdout.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(int(d['median']), '' if d['sane'] else 'NOT-SANE')" 2>> gpurun_out/ab_stderr.log)
     R[$cfg]="${R[$cfg]} $v"
   done
 done
