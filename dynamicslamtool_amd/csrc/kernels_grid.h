@@ -589,8 +589,18 @@ __global__ __launch_bounds__(GH_T) void k_gridhash(MorDev d) {
   bool done = false;
   // the tier the stream starts with: by its own cell count of the latest build (+ 1/16; the first frame starts small and moves up).  The host's estimate for the whole
   // batch — 5/4 of the largest stream — put every stream of the bench batch (≤ 5 400 cells) into tier 1 and the voxel ground variant's (10 300) into tier 2: −2.4 % / −4.5 %.
-  int tier = d.gh_tier;
-  if (tier < 0) { const int h = ld_agent(&d.gh_hint[s]); const long long need = (long long)h + h / 16; tier = need > min(GH_C0, min(GH_H0, d.Hcell) / 4 * 3) ? (need > min(GH_H, d.Hcell) / 4 * 3 ? 2 : 1) : 0; }
+  // ONE read of the hint for the whole workgroup, handed round through LDS: the word is shared by all frames in flight, and another lane's k_gridhash of this very stream may
+  // store a new count between the loads of two waves — with a load per thread the waves of a workgroup could start at DIFFERENT tiers (a street scene's 5 800 cells sit on the
+  // boundary of the first two), run different instantiations against each other's barriers and leave cursors of a half-built row table to the stores of the fill loop: the
+  // "Memory access fault by GPU" that one run in ten of 300 asynchronous steps of the street scenes died of since round 4 (found in round 6 with rocgdb: four waves in the tier-1
+  // fill loop, twelve at a barrier of the tier-0 code; exp/fault_gdb.sh).
+  if (threadIdx.x == 0) {
+    int t_ = d.gh_tier;
+    if (t_ < 0) { const int h = ld_agent(&d.gh_hint[s]); const long long need = (long long)h + h / 16; t_ = need > min(GH_C0, min(GH_H0, d.Hcell) / 4 * 3) ? (need > min(GH_H, d.Hcell) / 4 * 3 ? 2 : 1) : 0; }
+    l_misc[3] = t_;
+  }
+  __syncthreads();
+  const int tier = l_misc[3];
   if (tier <= 0) {
     const int H = min(GH_H0, d.Hcell);
     int *rows = l_mem + 2 * GH_H0, *cells = rows + GH_ROWS + 1, *rl = cells + GH_C0;

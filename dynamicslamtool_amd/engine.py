@@ -76,7 +76,8 @@ def lib():
         L.mor_batch_streams.argtypes = [vp]
         L.mor_push_batch.argtypes = [vp, vp, vp]
         L.mor_filter_batch.argtypes = [vp, vp, i32, vp]
-        L.mor_filter_batch_ex.argtypes = [vp, vp, i32, vp, C.c_uint32]
+        if hasattr(L, "mor_filter_batch_ex"):   # (absent from libraries of earlier rounds loaded through MOR_HIP_LIB for an A/B)
+            L.mor_filter_batch_ex.argtypes = [vp, vp, i32, vp, C.c_uint32]
         L.mor_batch_set_async.argtypes = [vp, i32]
         L.mor_batch_wait.argtypes = [vp]
         L.mor_get_output_device.restype = vp
@@ -101,8 +102,9 @@ def lib():
         L.mor_host_alloc.restype = vp
         L.mor_host_alloc.argtypes = [C.c_size_t]
         L.mor_host_free.argtypes = [vp]
-        L.mor_host_register.argtypes = [vp, C.c_size_t, vp]
-        L.mor_host_unregister.argtypes = [vp]
+        if hasattr(L, "mor_host_register"):
+            L.mor_host_register.argtypes = [vp, C.c_size_t, vp]
+            L.mor_host_unregister.argtypes = [vp]
         L.mor_device_upload.argtypes = [i32, vp, vp, C.c_size_t]
         L.mor_device_download.argtypes = [i32, vp, vp, C.c_size_t]
         L.mor_device_synchronize.argtypes = [i32]

@@ -896,6 +896,57 @@ def test_grid_merge_moves_between_its_tiers_from_frame_to_frame():
     assert st["clusters"] > 10
 
 
+def test_grid_merge_tier_hint_is_read_once_per_workgroup():
+    """The cell count a stream's grid merge starts its table tier by (`gh_hint`) is ONE word for all frames in flight.  Until round 6 every thread of k_gridhash loaded it by
+    itself: with four frames in flight another lane's k_gridhash of the same stream could store a new count between the loads of two waves, the waves of one workgroup then ran
+    different tiers against each other's barriers, and the fill loop stored through cursors of a half-built row table — one run in ten of 300 asynchronous steps of the street
+    scenes died of a GPU memory fault (found with rocgdb, exp/fault_gdb.sh).  Streams that alternate between a street scene (more cells than the all-LDS tier holds) and a small
+    cloud cross the tier boundary on every frame: 240 asynchronous steps without a wait must equal the synchronous run frame by frame (and not fault).  (The window of the race
+    was microseconds wide — one failure per ≈ 190 000 stream-frames: this test walks the path, it cannot promise to hit the window; the reproducer is `exp/fault_hunt.sh`:
+    3 – 4 of 30 runs of 305 steps of `hdl64_urban_b64` died before the fix, 0 of 70 after.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from dynamicslamtool_amd import kitti_params, synth
+from dynamicslamtool_amd.engine import DeviceBuffer, MorBatch
+p = kitti_params(1)
+B, nf, npts = 16, 4, 120000
+xs = [[None] * B for _ in range(nf)]; poses = np.zeros((nf, B, 7))
+for s in range(B):
+    for f in range(nf):
+        big = (f + s) %% 2 == 0
+        x, pose = synth.frame(6100 + s, "hdl64_urban" if big else "hdl64", f)
+        if not big:
+            x = x.copy(); x[6000:, :3] = 1e6   # a few hundred cells: everything else falls outside the trim box
+        xs[f][s] = x; poses[f, s] = pose
+buf = DeviceBuffer(nf * B * npts * 16)
+for f in range(nf):
+    buf.upload(np.stack(xs[f]), f * B * npts * 16)
+logs = []
+for mode in (True, False):
+    b = MorBatch(p, B, npts)
+    views = [b.make_views([(buf.ptr + (f * B + s) * npts * 16, npts) for s in range(B)]) for f in range(nf)]
+    b.set_async(mode)
+    n = 240
+    for k in range(n):
+        f = k %% nf
+        b.push_views(views[f], poses[f])
+        if mode: b.filter_async()
+        else: b.filter_device()
+    b.wait() if mode else None
+    logs.append([[b.frame_log(k, s) for s in range(B)] for k in range(n - 60, n)])
+    cells = [b.stage_counts(s)["n_occ"] for s in range(B)]
+    b.close()
+assert logs[0] == logs[1], "asynchronous run differs from the synchronous one"
+assert max(cells) > 6144 or min(cells) < 1500, cells
+print("OK", min(cells), max(cells))
+""" % root
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
 def test_voxel_covariance_ground_near_the_threshold():
     """A dense floor (2 cm lattice, ≈ 78 neighbours within gp_leaf of a voxel centroid) whose z noise puts Σ dz² of most voxels close to the 0.001 of :145, and
     two tilted patches that do the same for the mixed terms: voxels land on both sides of the threshold and a good share of them inside the screen's
