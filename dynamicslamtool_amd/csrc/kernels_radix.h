@@ -3,10 +3,11 @@
 // Reference citations are file:line of /root/reference/src/MovingObjectRemoval.cpp.
 // ------------------------------------------------------------------------------------ stable LSD radix sort, 8-bit digits, batched over streams
 // used by the sort path of the grid (MOR_GRID=radix) and by the VoxelGrid pass of the voxel ground variant.
-__device__ __forceinline__ void radix_item(const MorRadix &j, size_t so, int count, int i, int &key, int &val, bool &valid) {
+__device__ __forceinline__ void radix_item(const MorDev &d, const MorRadix &j, const VoxZ &vz, size_t so, int count, int i, int &key, int &val, bool &valid) {
   valid = i < count; key = 0; val = 0;
   if (!valid) return;
   key = j.kin[so + i]; val = j.vin ? j.vin[so + i] : i;
+  if (j.unpack) key = voxel_unpack(d, vz, key);   // (pass 0 behind the single-read pass A: packed lattice coordinates → the stream's linear voxel key)
   if (j.drop_negative) valid = key >= 0;
 }
 __device__ __forceinline__ int radix_count(const MorDev &d, const MorRadix &j, int s) {
@@ -20,7 +21,9 @@ __device__ __forceinline__ int radix_count(const MorDev &d, const MorRadix &j, i
 // histograms of all the stream's tiles: 59 loads per thread and tile, 226 MB of L2 reads per pass for 112 MB of keys and values — the scatter's price in the pipeline, 50 µs per pass.)
 __global__ __launch_bounds__(MOR_BT) void k_rhist(MorDev d, MorRadix j) {
   int s, t0; map_block(d.B, d.tiles_m, s, t0);
-  const int count = radix_count(d, j, s);
+  if (j.unpack && t0 == 0 && threadIdx.x == 0) publish_zgrid(d, s);   // (the single-read pass A left the z range to its kernel boundary: origin and layers of the stream's grids for the kernels BEHIND this one; this launch works them out itself, voxel_z)
+  const int count = j.unpack ? (int)d.info[s].M : radix_count(d, j, s);   // (pass 0: every stream takes part; radix_count's test reads the layer count this very kernel publishes)
+  const VoxZ vz = j.unpack ? voxel_z(d, s) : VoxZ{0, 1, 0, 0};
   __shared__ int h[256], sh[8], l_last;
   const size_t so = (size_t)s * d.Nmax;
   for (int t = t0; t * MOR_TILE < count; t += d.tiles_m) {
@@ -28,7 +31,7 @@ __global__ __launch_bounds__(MOR_BT) void k_rhist(MorDev d, MorRadix j) {
     h[threadIdx.x] = 0;
     __syncthreads();
     for (int i = base + threadIdx.x; i < min(base + MOR_TILE, count); i += MOR_BT) {
-      int key, val; bool valid; radix_item(j, so, count, i, key, val, valid);
+      int key, val; bool valid; radix_item(d, j, vz, so, count, i, key, val, valid);
       if (valid) atomicAdd(&h[(key >> j.shift) & 255], 1);
     }
     __syncthreads();
@@ -68,6 +71,7 @@ __global__ __launch_bounds__(MOR_BT) void k_rscan(MorDev d, MorRadix j) {
 __global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, MorRadix j) {
   int s, t0; map_block(d.B, d.tiles_m, s, t0);
   const int count = radix_count(d, j, s);
+  const VoxZ vz = j.unpack ? voxel_z(d, s) : VoxZ{0, 1, 0, 0};
   const size_t so = (size_t)s * d.Nmax;
   const bool inverse = j.inverse && (!j.vox || (j.shift >> 3) == voxel_passes_of(d, s) - 1);   // the stream's LAST pass leaves the inverse permutation
   __shared__ int wcnt[4][256];
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(MOR_BT) void k_rscatter(MorDev d, MorRadix j) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       int i = base + it * 64 + lane_id();
-      radix_item(j, so, count, i, key[it], val[it], valid[it]);
+      radix_item(d, j, vz, so, count, i, key[it], val[it], valid[it]);
       int dg = (key[it] >> j.shift) & 255;
       unsigned long long peers = __ballot(valid[it]);
 #pragma unroll

@@ -51,20 +51,46 @@ __device__ __forceinline__ int voxel_passes_of(const MorDev &d, int s) {
   const int bits = cells > 1 ? 64 - __clzll(cells - 1) : 1;
   return (bits + 7) >> 3;
 }
-// T, M, G of the frame (and, for pass A of the voxel variant, the z origin of its grids)
-__device__ __forceinline__ void publish_split(const MorDev &d, int s, int n_ng, int n_g) {
+// Voxel ground variant, pass A: what hangs on the z range of the trimmed cloud — the origin of both grids and their layer counts for this stream, the bet on the mode bin.
+// The z range must be FINAL: k_scatter calls this behind k_classify's kernel boundary; the single-read pass A (k_split<1>), whose workgroups add to the range while
+// others already store, leaves it to the first kernel behind it (k_rhist of radix pass 0).
+__device__ __forceinline__ void publish_zgrid(const MorDev &d, int s) {
+  const MorFrameInfo &f = d.info[s];
+  const float zmin = f.T ? ordered_float(d.zmin_i[MOR_ZR * s]) : 0.f, zmax = f.T ? ordered_float(d.zmax_i[MOR_ZR * s]) : 0.f;
+  d.zorg[s] = zmin; d.zbase[s] = (int)floorf(zmin * d.gv.inv_cs);   // grids of the voxel variant hang on the lowest trimmed point
+  if (d.gnz_out) d.gnz_out[s] = max(1, min(d.cg_nz, (int)floorf((zmax - zmin) * d.cg_inv_cs) + 2));   // z layers of the clustering grid this stream needs (stream_grid)
+  if (d.vnz_out) { d.vnz_out[s] = voxel_layers(d, s); d.g2_used[s] = d.g2_nobet ? 0x7ffffffe : ld_agent(&d.g2_pred[s]); }   // layers of the VoxelGrid lattice (the later kernels of pass A read it through stream_grid) … and the bet on the mode bin this frame's kernels mark by: ONE snapshot per frame (later frames' k_g2_mode update g2_pred while this frame's kernels run)
+  if (f.T && (int)floorf(zmax * d.gv.inv_cs) - (int)floorf(zmin * d.gv.inv_cs) + 1 > d.gv.nz) mor_raise(d, s, 8u);   // z extent beyond the lattice: voxels of the top layer would be merged
+}
+// T, M, G of the frame (and, for pass A of the voxel variant, the z origin of its grids — unless the caller's z range is not final yet)
+__device__ __forceinline__ void publish_split(const MorDev &d, int s, int n_ng, int n_g, bool z_final = true) {
   MorFrameInfo &f = d.info[s];
   f.M = n_ng; f.G = n_g; f.T = n_ng + n_g;
   if (d.gmode == 2) { d.zmin_i[MOR_ZR * s] = 0x7fffffff; d.zmax_i[MOR_ZR * s] = (int)0x80000000; }   // pass B ends the frame's use of the z range: ready for the next frame on this copy (no memset launches)
-  if (d.gmode == 1) {   // grids of the voxel variant hang on the lowest trimmed point
-    float zmin = f.T ? ordered_float(d.zmin_i[MOR_ZR * s]) : 0.f;
-    d.zorg[s] = zmin; d.zbase[s] = (int)floorf(zmin * d.gv.inv_cs);
-    if (d.gnz_out) {   // z layers of the clustering grid this stream needs (stream_grid)
-      const float zmax = f.T ? ordered_float(d.zmax_i[MOR_ZR * s]) : 0.f;
-      d.gnz_out[s] = max(1, min(d.cg_nz, (int)floorf((zmax - zmin) * d.cg_inv_cs) + 2));
-    }
-    if (d.vnz_out) { d.vnz_out[s] = voxel_layers(d, s); d.g2_used[s] = d.g2_nobet ? 0x7ffffffe : ld_agent(&d.g2_pred[s]); }   // … and the bet on the mode bin this frame's kernels mark by: ONE snapshot per frame (later frames' k_g2_mode update g2_pred while this frame's kernels run)   // layers of the VoxelGrid lattice (the later kernels of pass A read it through stream_grid)
-  }
+  if (d.gmode == 1 && z_final) publish_zgrid(d, s);
+}
+// The single-read pass A does not know the stream's lowest z cell when it stores a point's voxel: it leaves the three cell coordinates PACKED — x in the low bits, y above it,
+// floor(z·inv) modulo what is left of the 32 bits (≥ 10 bits ≥ the lattice's layers: a stream whose cells span more raises the capacity flag, publish_zgrid) — and radix pass 0,
+// which runs behind the kernel boundary, turns them into the stream's linear key on the fly (k_rhist, k_rscatter; the order of the packed and the linear keys is NOT the same,
+// so every pass sorts linear keys).
+struct VoxZ { int zb, nz, bx, by; };   // the stream's lowest z cell (absolute), its layers, the bit widths of x and y
+__device__ __forceinline__ VoxZ voxel_z(const MorDev &d, int s) {
+  VoxZ v; v.bx = 32 - __clz(d.g.nx - 1); v.by = 32 - __clz(d.g.ny - 1); v.zb = 0; v.nz = 1;
+  const int zl = d.zmin_i[MOR_ZR * s], zh = d.zmax_i[MOR_ZR * s];
+  if (zl <= zh) { v.zb = (int)floorf(ordered_float(zl) * d.g.inv_cs); v.nz = max(1, min(d.g.nz, (int)floorf(ordered_float(zh) * d.g.inv_cs) - v.zb + 1)); }
+  return v;
+}
+__device__ __forceinline__ int voxel_pack(const MorGrid &g, float4 p, int bx, int by, bool &clamped) {
+  int cx = (int)floorf(p.x * g.inv_cs) - g.ibx, cy = (int)floorf(p.y * g.inv_cs) - g.iby; const int cz = (int)floorf(p.z * g.inv_cs);
+  clamped = cx < 0 || cy < 0 || cx >= g.nx || cy >= g.ny;
+  cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1);
+  return (int)((unsigned)cx | ((unsigned)cy << bx) | ((unsigned)cz << (bx + by)));   // (bx + by ≤ 22)
+}
+__device__ __forceinline__ int voxel_unpack(const MorDev &d, const VoxZ &v, int packed) {
+  const unsigned k = (unsigned)packed;
+  const int cx = (int)(k & ((1u << v.bx) - 1u)), cy = (int)((k >> v.bx) & ((1u << v.by) - 1u));
+  const int cz = min((int)(((k >> (v.bx + v.by)) - (unsigned)v.zb) & ((1u << (32 - v.bx - v.by)) - 1u)), v.nz - 1);   // (clamped as grid_cell does; the flag is publish_zgrid's)
+  return (cy * v.nz + cz) * d.g.nx + cx;
 }
 // pass 2: order-preserving split into `cloud` / ground, cell histogram, forest init
 __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
@@ -152,7 +178,8 @@ __global__ __launch_bounds__(MOR_BT) void k_scatter(MorDev d) {
 #define SP_DESC_STRIDE(d) ((size_t)(d).tiles_max * (8 / SP_ROWS) * 4 / SP_NW + 1)
 __device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // loads only (no use of the data here: the wait for them belongs to split_tile, a step later); cls carries the ground flag of pass B
-template <bool PASSB> __device__ __forceinline__ void split_load_tile(const MorDev &d, const MorStreamArgs &a, int s, uint32_t n_in, int t, float4 (&p)[SP_ROWS], int (&cls)[SP_ROWS]) {
+template <int PASS> __device__ __forceinline__ void split_load_tile(const MorDev &d, const MorStreamArgs &a, int s, uint32_t n_in, int t, float4 (&p)[SP_ROWS], int (&cls)[SP_ROWS]) {
+  constexpr bool PASSB = PASS == 2;
   const int gtag = PASSB ? d.g2_tag[s] : 0;   // pass B: the frame's ground tag (k_g2_mode)
   const uint32_t base = (uint32_t)t * SP_TILE + wave_id() * (SP_ROWS * 64);
 #pragma unroll
@@ -163,22 +190,28 @@ template <bool PASSB> __device__ __forceinline__ void split_load_tile(const MorD
   }
 }
 struct SplitMeta { int tng, tg, wng, wg; };   // a counted tile: its totals and this wave's offsets inside it
-template <bool PASSB> __device__ __forceinline__ int split_class(const MorDev &d, uint32_t n_in, uint32_t i, const float4 &p, int cls) {
-  return i < n_in ? (PASSB ? (cls ? 1 : 2) : classify(d, p)) : 0;
+template <int PASS> __device__ __forceinline__ int split_class(const MorDev &d, uint32_t n_in, uint32_t i, const float4 &p, int cls) {
+  return i < n_in ? (PASS == 2 ? (cls ? 1 : 2) : classify(d, p)) : 0;
 }
 // stage 1 of a tile (its loads were issued a step earlier): counts, and the tile's aggregate goes out to the other workgroups
-template <bool PASSB> __device__ __forceinline__ void split_count(const MorDev &d, int s, int t, uint32_t n_in, unsigned epoch, const float4 (&p)[SP_ROWS], const int (&cls)[SP_ROWS], int *sh, SplitMeta &m) {
+template <int PASS> __device__ __forceinline__ void split_count(const MorDev &d, int s, int t, uint32_t n_in, unsigned epoch, const float4 (&p)[SP_ROWS], const int (&cls)[SP_ROWS], int *sh, SplitMeta &m) {
   int c_ng = 0, c_g = 0;
+  float zlo = INFINITY, zhi = -INFINITY;   // (pass A)
   const uint32_t base = (uint32_t)t * SP_TILE + wave_id() * (SP_ROWS * 64) + lane_id();
 #pragma unroll
   for (int it = 0; it < SP_ROWS; ++it) {
-    const int c = split_class<PASSB>(d, n_in, base + it * 64, p[it], cls[it]);
+    const int c = split_class<PASS>(d, n_in, base + it * 64, p[it], cls[it]);
     const unsigned long long m_ng = __ballot(c == 2), m_g = __ballot(c == 1);
     c_ng += __popcll(m_ng); c_g += __popcll(m_g);
+    if (PASS == 1 && c == 2) { zlo = fminf(zlo, p[it].z); zhi = fmaxf(zhi, p[it].z); }
     // gp_indices (:86) and the trimmed-cloud index of every cloud point are read-backs only: instead of 4 bytes per trimmed point the split leaves the
     // classes of every 64 records as two bit masks (16 bytes: cloud, ground; rows that hold records only — a tile reaches beyond the stream's slice of the
     // array); the host rebuilds the index lists from them when asked (mor_get_ground_indices, mor_get_labels)
     if (lane_id() == 0 && base + it * 64 < n_in) { unsigned long long *cm = d.cls_mask + ((size_t)s * d.cls_rows + (base + it * 64) / 64) * 2; cm[0] = m_ng; cm[1] = m_g; }
+  }
+  if (PASS == 1) {   // z extent of the trimmed cloud (the voxel variant does not crop in z): final at the kernel boundary, for radix pass 0 and everything behind it
+    zlo = wave_fmin(zlo); zhi = wave_fmax(zhi);
+    if (lane_id() == 0 && zlo <= zhi) { atomicMin(&d.zmin_i[MOR_ZR * s], float_ordered(zlo)); atomicMax(&d.zmax_i[MOR_ZR * s], float_ordered(zhi)); }
   }
   if (lane_id() == 0) { sh[wave_id()] = c_ng; sh[SP_NWS + wave_id()] = c_g; }
   __syncthreads();
@@ -190,7 +223,7 @@ template <bool PASSB> __device__ __forceinline__ void split_count(const MorDev &
 }
 // stage 2: look-back over the tiles between this workgroup's previous tile and this one, then the stores.
 // tk_next (thread 0 only): the ticket this workgroup has just taken for a later tile — passed on to all threads through s_ex[2]
-template <bool PASSB> __device__ __forceinline__ void split_store(const MorDev &d, const MorGrid &G, int s, int t, int nt, int t_prev, uint32_t n_in, unsigned epoch, const float4 (&p)[SP_ROWS], const int (&cls)[SP_ROWS],
+template <int PASS> __device__ __forceinline__ void split_store(const MorDev &d, const MorGrid &G, int s, int t, int nt, int t_prev, uint32_t n_in, unsigned epoch, const float4 (&p)[SP_ROWS], const int (&cls)[SP_ROWS],
                                             const SplitMeta &m, int &ex_ng, int &ex_g, int *s_ex, int tk_next) {
   if (wave_id() == 0) {
     const unsigned long long *desc = d.split_desc + (size_t)s * SP_DESC_STRIDE(d);
@@ -211,7 +244,7 @@ template <bool PASSB> __device__ __forceinline__ void split_store(const MorDev &
     an = wave_sum(an); ag = wave_sum(ag);
     if (lane == 0) {
       s_ex[0] = ex_ng + an; s_ex[1] = ex_g + ag; s_ex[2] = tk_next;
-      if (t == nt - 1) publish_split(d, s, ex_ng + an + m.tng, ex_g + ag + m.tg);   // the stream's last tile: T, M, G of the frame
+      if (t == nt - 1) publish_split(d, s, ex_ng + an + m.tng, ex_g + ag + m.tg, PASS != 1);   // the stream's last tile: T, M, G of the frame (pass A: the z range is not final yet — other workgroups may still be counting; k_rhist of radix pass 0 publishes what hangs on it)
     }
   }
   __syncthreads();
@@ -219,33 +252,36 @@ template <bool PASSB> __device__ __forceinline__ void split_store(const MorDev &
   ex_ng = r_ng + m.tng; ex_g = r_g + m.tg;   // prefix behind this tile: what the workgroup carries to its next one
   r_ng += m.wng; r_g += m.wg;
   const size_t so = (size_t)s * d.Nmax;
-  const float zorg = d.zorg[s]; const int zbase = d.zbase[s];
+  const float zorg = PASS == 1 ? 0.f : d.zorg[s]; const int zbase = PASS == 1 ? 0 : d.zbase[s];
+  const int vbx = 32 - __clz(d.g.nx - 1), vby = 32 - __clz(d.g.ny - 1);   // (pass A: bit widths of the packed voxel coordinates)
   const uint32_t base = (uint32_t)t * SP_TILE + wave_id() * (SP_ROWS * 64) + lane_id();
 #pragma unroll
   for (int it = 0; it < SP_ROWS; ++it) {
-    const int c = split_class<PASSB>(d, n_in, base + it * 64, p[it], cls[it]);
+    const int c = split_class<PASS>(d, n_in, base + it * 64, p[it], cls[it]);
     const unsigned long long m_ng = __ballot(c == 2), m_g = __ballot(c == 1);
     const int k_ng = r_ng + __popcll(m_ng & lanemask_lt()), k_g = r_g + __popcll(m_g & lanemask_lt());
     if (c == 2) {
-      int cx, cy, cz; bool clamped; grid_cell(G, p[it], zorg, zbase, cx, cy, cz, clamped);
+      bool clamped; int key;
+      if (PASS == 1) key = voxel_pack(d.g, p[it], vbx, vby, clamped);   // (the stream's lowest z cell is not known yet: radix pass 0 makes the linear key, voxel_unpack)
+      else { int cx, cy, cz; grid_cell(G, p[it], zorg, zbase, cx, cy, cz, clamped); key = grid_key(G, cx, cy, cz); }
       if (clamped && d.gmode != 0) mor_raise(d, s, 8u);
       d.cloud[so + k_ng] = p[it];
-      d.pkey[so + k_ng] = grid_key(G, cx, cy, cz);
+      d.pkey[so + k_ng] = key;
     } else if (c == 1) {
       st_stream(&d.ground[2 * so + d.Nmax + k_g], p[it]);   // final place in filterCloud's output
     }
     r_ng += __popcll(m_ng); r_g += __popcll(m_g);
   }
 }
-template <bool PASSB> __global__ __launch_bounds__(64 * SP_NW, 4) void k_split(MorDev d) {   // (≤ 128 VGPRs at least — 73 with 1024-record tiles; with 2048-record tiles the compiler left to itself wandered between 126 and 150 registers with unrelated edits, and at 150 the split took 115 instead of 89 µs)
+template <int PASS> __global__ __launch_bounds__(64 * SP_NW, 4) void k_split(MorDev d) {   // (≤ 128 VGPRs at least — 73 with 1024-record tiles; with 2048-record tiles the compiler left to itself wandered between 126 and 150 registers with unrelated edits, and at 150 the split took 115 instead of 89 µs)
   int s, g; map_block(d.B, d.sp_g, s, g);
-  const MorGrid G = stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers)
-  // As the first kernel of a frame (crop variant) this one reads the stream's arguments straight from the page-locked slot the host filled,
+  const MorGrid G = PASS == 1 ? d.g : stream_grid(d, s);   // the stream's clustering grid (voxel ground variant: its own number of z layers; its pass A packs lattice coordinates instead)
+  // As the first kernel of a frame (crop variant, pass A of the voxel ground variant) this one reads the stream's arguments straight from the page-locked slot the host filled,
   // and the owner of tile 0 leaves the device copy for the kernels behind it: no copy, no launch and no wait in front of the frame
   const MorStreamArgs a = d.args_src ? d.args_src[s] : d.args[s];
   const uint32_t n_in = pass_count(d, a, s);
   const int nt = (int)((n_in + SP_TILE - 1) / SP_TILE);
-  const unsigned epoch = 2u * (unsigned)d.frame_no + (d.gmode == 2 ? 2u : 1u);   // never 0 (fresh descriptors), never the tag of an earlier pass over this table
+  const unsigned epoch = 2u * (unsigned)d.frame_no + (PASS == 2 ? 2u : 1u);   // never 0 (fresh descriptors), never the tag of an earlier pass over this table
   __shared__ int sh[4 * SP_NWS], s_ex[6];   // two copies of each, used in turn by the two halves of the loop: between two uses of a copy lies a workgroup barrier of the other half
   int *tk = d.tickets + (size_t)s * TK_COUNT + TK_SPLIT;
   const int tk_total = 2 * d.sp_g + nt;
@@ -256,7 +292,7 @@ template <bool PASSB> __global__ __launch_bounds__(64 * SP_NW, 4) void k_split(M
     if (v == 0) {   // the owner of tile 0 starts the frame: before any flag of this stream can be raised (every other tile waits for tile 0's descriptor)
       reset_frame_info(d, s, a.n);
       if (d.args_src) d.args_out[s] = a;
-      if (nt == 0) publish_split(d, s, 0, 0);
+      if (nt == 0) publish_split(d, s, 0, 0, PASS != 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
@@ -265,26 +301,26 @@ template <bool PASSB> __global__ __launch_bounds__(64 * SP_NW, 4) void k_split(M
   int ex_ng = 0, ex_g = 0;
   float4 pa[SP_ROWS], pb[SP_ROWS]; int ca[SP_ROWS], cb[SP_ROWS];
   SplitMeta ma, mb;
-  if (t < nt) split_load_tile<PASSB>(d, a, s, n_in, t, pa, ca);
-  if (t1 < nt) split_load_tile<PASSB>(d, a, s, n_in, t1, pb, cb);
-  if (t < nt) split_count<PASSB>(d, s, t, n_in, epoch, pa, ca, sh, ma);
+  if (t < nt) split_load_tile<PASS>(d, a, s, n_in, t, pa, ca);
+  if (t1 < nt) split_load_tile<PASS>(d, a, s, n_in, t1, pb, cb);
+  if (t < nt) split_count<PASS>(d, s, t, n_in, epoch, pa, ca, sh, ma);
   while (t < nt) {   // pa: tile t, counted and published; pb: tile t1, loaded
     int nx = 0;
-    if (t1 < nt) split_count<PASSB>(d, s, t1, n_in, epoch, pb, cb, sh + 2 * SP_NWS, mb);   // the next tile's aggregate is out before this workgroup waits for anybody
+    if (t1 < nt) split_count<PASS>(d, s, t1, n_in, epoch, pb, cb, sh + 2 * SP_NWS, mb);   // the next tile's aggregate is out before this workgroup waits for anybody
     if (threadIdx.x == 0) nx = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    split_store<PASSB>(d, G, s, t, nt, t_prev, n_in, epoch, pa, ca, ma, ex_ng, ex_g, s_ex, nx);
+    split_store<PASS>(d, G, s, t, nt, t_prev, n_in, epoch, pa, ca, ma, ex_ng, ex_g, s_ex, nx);
     if (threadIdx.x == 0 && nx + 1 == tk_total) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t_prev = t;
     const int t2 = __builtin_amdgcn_readfirstlane(s_ex[2]);
-    if (t2 < nt) split_load_tile<PASSB>(d, a, s, n_in, t2, pa, ca);
+    if (t2 < nt) split_load_tile<PASS>(d, a, s, n_in, t2, pa, ca);
     if (t1 >= nt) break;
-    if (t2 < nt) split_count<PASSB>(d, s, t2, n_in, epoch, pa, ca, sh, ma);
+    if (t2 < nt) split_count<PASS>(d, s, t2, n_in, epoch, pa, ca, sh, ma);
     if (threadIdx.x == 0) nx = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    split_store<PASSB>(d, G, s, t1, nt, t_prev, n_in, epoch, pb, cb, mb, ex_ng, ex_g, s_ex + 3, nx);
+    split_store<PASS>(d, G, s, t1, nt, t_prev, n_in, epoch, pb, cb, mb, ex_ng, ex_g, s_ex + 3, nx);
     if (threadIdx.x == 0 && nx + 1 == tk_total) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t_prev = t1;
     const int t3 = __builtin_amdgcn_readfirstlane(s_ex[5]);
-    if (t3 < nt) split_load_tile<PASSB>(d, a, s, n_in, t3, pb, cb);
+    if (t3 < nt) split_load_tile<PASS>(d, a, s, n_in, t3, pb, cb);
     t = t2; t1 = t3;
   }
 }

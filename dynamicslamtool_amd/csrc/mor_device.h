@@ -46,6 +46,7 @@ struct MorRadix {
   int vox;                // keys are voxel keys of the voxel ground variant: a stream takes part in the passes its own key width needs (voxel_passes_of)
   int inverse;            // last pass: vout[value] = position (the inverse permutation) instead of vout[position] = value — the points are then MOVED to their places
                           // by coalesced reads and fire-and-forget writes (k_heads_scatter) instead of gathered by 7 M dependent random 16-byte reads per step
+  int unpack;             // pass 0 behind the single-read pass A of the voxel ground variant: kin holds packed lattice coordinates (voxel_pack); the pass sorts — and writes — the stream's linear keys
 };
 
 struct MorStreamArgs {       // per stream, per push (host → device, one small copy)
@@ -113,6 +114,7 @@ struct MorDev {
   int prop_map;              // 1 (default): launches share their workgroups out over the streams in proportion to the streams' work (map_block_work); 0: the same number for every stream (MOR_PROP_MAP=0)
   int xcd_map;               // 1: the workgroups of a stream share an XCD (its tables stay in that L2); 0: streams spread over all XCDs
   int sp_g;                  // workgroups per stream of the single-read split (2 … 64)
+  int g2_passa2;             // voxel ground variant: pass A as count pass + scatter pass (MOR_G2_PASSA2=1; default: the single-read split, k_split<1>)
   int two_pass_split;        // 1 (default): count pass + scatter pass; 0: the single-pass split with decoupled look-back (MOR_SINGLE_PASS_SPLIT)
   int cur, prev, has_prev;   // cluster-array slots of cb and ca (four slots rotate: up to three frames are in flight in the stage pipeline); whether ca exists (:534)
   // ---- device arrays (per-stream stride noted)

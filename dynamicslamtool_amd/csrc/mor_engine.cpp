@@ -212,6 +212,7 @@ static int configure(mor_batch *b) {
     double lf = (double)p.gp_leaf; d.leaf_r2 = (float)(lf * lf); d.g2_r = std::sqrt((double)d.leaf_r2) * 1.0001 + 1e-6; d.g2_inv_r = 1.0001 / std::sqrt((double)d.leaf_r2);   // radiusSearch(…, gp_leaf): (float)(radius·radius)
   }
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
+  d.g2_passa2 = getenv("MOR_G2_PASSA2") ? atoi(getenv("MOR_G2_PASSA2")) != 0 : 0;
   d.two_pass_split = (getenv("MOR_SINGLE_PASS_SPLIT") && atoi(getenv("MOR_SINGLE_PASS_SPLIT")) == 0) ? 1 : 0;   // default: the single-read split (k_split); MOR_SINGLE_PASS_SPLIT=0: count pass + scatter pass (what pass A of the voxel ground variant always uses)
   {  // workgroups per stream of the single-read split: what the device holds at once, shared out over the streams (a matter of speed only:
      // tiles are handed out by ticket, so the look-back does not depend on which workgroups are resident)
@@ -589,7 +590,7 @@ int mor_push_batch(mor_batch *b, const mor_cloud_view *clouds, const double *pos
   // in front of every frame's first kernel (copy packet, its signal, the barrier behind it)
   // (crop variant: the frame's first kernel, k_split, reads the slot itself and leaves the device copy behind — nothing at all in front of it)
   d.args_src = nullptr; d.args_out = b->d_args_s[k % b->pipe_depth];
-  if (d.gmode == 0 && !d.two_pass_split) d.args_src = b->h_args;
+  if (!d.two_pass_split && (d.gmode == 0 || !d.g2_passa2)) d.args_src = b->h_args;   // (… and pass A of the voxel ground variant as the single-read split)
   else mor_launch_copy(b->d_args_s[k % b->pipe_depth], b->h_args, sizeof(MorStreamArgs) * B, lane);
   if (!b->async) HIP_TRY(hipEventRecord(b->ev[0], lane));
   for (int pc = 0; pc < b->n_pieces; ++pc) {

@@ -64,10 +64,12 @@ static int mor_exp_dup() { static const int v = getenv("MOR_EXP_DUP") ? atoi(get
 // part: 0 = both, 1 = the split only, 2 = the grid build only (the lane schedule runs them as two pieces)
 static void mor_launch_split_and_grid(const MorDev &d, hipStream_t st, MorLaunchTimer *tm, int part = 0) {
   const dim3 gT(d.B * d.tiles), gM(d.B * d.tiles_m), gB(d.B);
+  const bool single_read = !d.two_pass_split && !(d.gmode == 1 && d.g2_passa2);   // (pass A of the voxel ground variant: MOR_G2_PASSA2=1 keeps its count pass + scatter pass)
   if (part == 2) goto grid;
-  if (d.gmode != 1 && !d.two_pass_split) {
-    if (d.gmode == 2) MOR_LAUNCH_T(MK_SPLIT, k_split<true>, dim3(d.B * d.sp_g), 64 * MOR_SP_NW, d);   // (pass B of the voxel ground variant: the records carry a ground flag; two instances so that the crop variant does not keep registers for it)
-    else MOR_LAUNCH_T(MK_SPLIT, k_split<false>, dim3(d.B * d.sp_g), 64 * MOR_SP_NW, d);
+  if (single_read) {
+    if (d.gmode == 2) MOR_LAUNCH_T(MK_SPLIT, k_split<2>, dim3(d.B * d.sp_g), 64 * MOR_SP_NW, d);   // (pass B of the voxel ground variant: the records carry a ground flag; three instances so that the crop variant does not keep registers for it)
+    else if (d.gmode == 1) MOR_LAUNCH_T(MK_SPLIT, k_split<1>, dim3(d.B * d.sp_g), 64 * MOR_SP_NW, d);   // (pass A: x/y trim, z range, packed lattice coordinates — radix pass 0 makes the keys)
+    else MOR_LAUNCH_T(MK_SPLIT, k_split<0>, dim3(d.B * d.sp_g), 64 * MOR_SP_NW, d);
   } else {
     const dim3 gS(d.B * d.split_g);
     MOR_LAUNCH(MK_CLASSIFY, k_classify, gS, d);
@@ -81,7 +83,7 @@ grid:
     MOR_LAUNCH_T(MK_GRIDPLACE, k_gridplace, dim3(d.B * d.gc_P), GC_T, d);
   } else {
     for (int pass = 0; pass < d.cell_passes; ++pass) {   // points sorted by cell key; result in (skey, sidx) = buffers [cell_passes & 1]
-      MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0, 1, 1, 1};   // (a stream's last pass — by its own key width — leaves the inverse permutation: k_heads_scatter moves the points)
+      MorRadix j = {pass == 0 ? d.pkey : d.rkeys[pass & 1], pass == 0 ? nullptr : d.rvals[pass & 1], d.rkeys[(pass + 1) & 1], d.rvals[(pass + 1) & 1], 8 * pass, 0, 0, nullptr, d.rhist, 0, 1, 1, 1, (pass == 0 && single_read) ? 1 : 0};   // (a stream's last pass — by its own key width — leaves the inverse permutation: k_heads_scatter moves the points)
       MOR_LAUNCH(MK_RHIST, k_rhist, gM, d, j);
       if (!j.fuse) MOR_LAUNCH(MK_RSCAN, k_rscan, gB, d, j);
       MOR_LAUNCH(MK_RSCATTER, k_rscatter, gM, d, j);
@@ -194,6 +196,6 @@ void mor_launch_copy(void *dst, const void *src_pinned, size_t bytes, hipStream_
 // workgroups of k_split one CU holds (registers decide): the host keeps sp_g × B within what the whole GPU holds at once
 int mor_split_blocks_per_cu() {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_split<false>, 64 * MOR_SP_NW, 0) != hipSuccess) n = 2;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_split<0>, 64 * MOR_SP_NW, 0) != hipSuccess) n = 2;
   return n < 1 ? 1 : n;
 }

@@ -11,7 +11,7 @@ SRC = os.path.join(ROOT, "dynamicslamtool_amd", "csrc", "mor_kernels.hip")
 
 # kernel: (max VGPRs, max scratch bytes per lane, max LDS bytes per workgroup)
 LIMITS = {
-    "k_split<false>": (80, 0, 28 * 1024),           # three 512-thread workgroups per CU (round 6: eight waves × four rows — 2048-record tiles at 73 VGPRs; 48 bytes of LDS per thread are the compiler's: the tiles' class arrays promoted from private memory)
+    "k_split<0>": (80, 0, 28 * 1024),           # three 512-thread workgroups per CU (round 6: eight waves × four rows — 2048-record tiles at 73 VGPRs; 48 bytes of LDS per thread are the compiler's: the tiles' class arrays promoted from private memory)
     "k_gridcount": (64, 0, 36 * 1024),
     "k_gridplace": (80, 0, 24 * 1024),
     "k_cellboxes": (128, 0, 1024),
@@ -37,7 +37,8 @@ def _usage(tmp_path):
         if m:
             name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
             cur = re.sub(r"\(MorDev.*$", "", re.sub(r"^void ", "", name))
-            cur = re.sub(r"<\d+>", "", cur)          # k_cg_slab<1024> → k_cg_slab
+            if not cur.startswith("k_split"):
+                cur = re.sub(r"<\d+>", "", cur)      # k_cg_slab<1024> → k_cg_slab (k_split<0|1|2>: the crop variant's split, pass A and pass B of the voxel ground variant)
             res[cur] = {}
         for key, pat in (("vgpr", r" VGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)"), ("occ", r"Occupancy \[waves/SIMD\]: (\d+)")):
             m = re.search(pat, line)
