@@ -393,6 +393,9 @@ __global__ __launch_bounds__(GC_T) void k_gridplace(MorDev d) {
 // overflowed (nothing published yet: the caller re-runs with a bigger table).  `cells` lists the claimed slots in
 // discovery order — every per-cell phase walks it (a few entries per thread) instead of the whole table; `rowlist`
 // first holds the x of the cells of every row, then (same memory) the point counts in compact-id order.
+#ifndef GH_SW
+#define GH_SW 8   // chunk entries per thread and round trip of the sweep (round 6: 4 → 8, + 0.5 … 1 % on the street scenes and the million-point clouds; 16: no further gain)
+#endif
 template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(const MorDev &d, const MorGrid &G, int s, int M, int *tkey, int *tval, int H, int cell_cap, int *rows, int *cells, int *rowlist, int *l_misc, int *l_sh, int *l_bits) {
   const size_t so = (size_t)s * d.Nmax;
   int *cstart = d.cstart + (size_t)s * (d.Nmax + 1), *ckey = d.ckey + so;
@@ -416,13 +419,13 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
     __syncthreads();
     cpre[tid] = ex;
     __syncthreads();
-    // (four entries per thread and round trip: the workgroup has a CU to itself — sixteen waves are all that hides the latency of its loads —, and an entry per round trip left the
+    // (GH_SW entries per thread and round trip: the workgroup has a CU to itself — sixteen waves are all that hides the latency of its loads —, and an entry per round trip left the
     //  sweep of the million-point clouds' 60 000 entries at 60 exposed trips)
-    for (int g0 = tid; g0 < total; g0 += 4 * GH_T) {
+    for (int g0 = tid; g0 < total; g0 += GH_SW * GH_T) {
       if (gh_ld<true>(&l_misc[1])) break;
-      size_t at[4]; int2 kc[4];
+      size_t at[GH_SW]; int2 kc[GH_SW];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < GH_SW; ++u) {
         const int g = min(g0 + u * GH_T, total - 1);
         int lo = 0, hi = nch - 1;   // last chunk whose prefix ≤ g
         while (lo < hi) { const int m = (lo + hi + 1) >> 1; if (cpre[m] <= g) lo = m; else hi = m - 1; }
@@ -430,7 +433,7 @@ template <bool TL, bool RL, bool CL> __device__ __forceinline__ bool gh_run(cons
         kc[u] = clist[at[u]];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < GH_SW; ++u) {
         if (g0 + u * GH_T >= total) break;
         const int want = kc[u].x + 1; unsigned h = hash_slot(kc[u].x, hshift); bool ok = false;
         for (int probes = 0; probes < H; ++probes) {
