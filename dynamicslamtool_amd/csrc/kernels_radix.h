@@ -19,6 +19,9 @@ __device__ __forceinline__ int radix_count(const MorDev &d, const MorRadix &j, i
 // With j.fuse the stream's LAST workgroup to arrive (stream_last_block) turns the stream's raw per-tile histograms into offsets in place — offsets[tile][digit] = Σ smaller digits +
 // Σ earlier tiles, one thread per digit — so that k_rscatter reads ONE word per thread and tile.  (Rounds 2 – 5 had every workgroup of k_rscatter re-derive its offsets from the raw
 // histograms of all the stream's tiles: 59 loads per thread and tile, 226 MB of L2 reads per pass for 112 MB of keys and values — the scatter's price in the pipeline, 50 µs per pass.)
+#ifndef RH_COL
+#define RH_COL 32   // tiles per round trip of the offsets scan
+#endif
 __global__ __launch_bounds__(MOR_BT) void k_rhist(MorDev d, MorRadix j) {
   int s, t0; map_block(d.B, d.tiles_m, s, t0);
   if (j.unpack && t0 == 0 && threadIdx.x == 0) publish_zgrid(d, s);   // (the single-read pass A left the z range to its kernel boundary: origin and layers of the stream's grids for the kernels BEHIND this one; this launch works them out itself, voxel_z)
@@ -42,6 +45,28 @@ __global__ __launch_bounds__(MOR_BT) void k_rhist(MorDev d, MorRadix j) {
   if (!stream_last_block(d.tickets + (size_t)s * TK_COUNT + TK_RADIX, d.tiles_m, &l_last)) return;
   int *hh = j.hist + (size_t)s * d.tiles_max * 256 + threadIdx.x;
   const int nt = (count + MOR_TILE - 1) / MOR_TILE;
+  if (nt <= 4 * RH_COL) {   // the digit's column RH_COL tiles per round trip: totals first (the base needs the sum over ALL tiles), then the running sums — loads of a batch are independent, so a
+    // stream of 59 tiles takes four round trips where the loop below takes eight and a second pass; RH_COL registers per thread (64 of them cost the histogram loop above its waves: − 1 %)
+    int total = 0;
+    for (int t0 = 0; t0 < nt; t0 += RH_COL) {
+      int v[RH_COL];
+#pragma unroll
+      for (int u = 0; u < RH_COL; ++u) v[u] = t0 + u < nt ? ld_agent(&hh[(t0 + u) * 256]) : 0;
+#pragma unroll
+      for (int u = 0; u < RH_COL; ++u) total += v[u];
+    }
+    int tot; int run = block_excl_scan(total, sh, &tot);
+    for (int t0 = 0; t0 < nt; t0 += RH_COL) {
+      int v[RH_COL];
+#pragma unroll
+      for (int u = 0; u < RH_COL; ++u) v[u] = t0 + u < nt ? ld_agent(&hh[(t0 + u) * 256]) : 0;
+#pragma unroll
+      for (int u = 0; u < RH_COL; ++u) { const int x = v[u]; v[u] = run; run += x; }
+#pragma unroll
+      for (int u = 0; u < RH_COL; ++u) if (t0 + u < nt) hh[(t0 + u) * 256] = v[u];
+    }
+    return;
+  }
   int run = 0, t = 0;
   for (; t + 8 <= nt; t += 8) {   // eight independent loads per step
     int v[8];
