@@ -836,12 +836,13 @@ def test_voxel_covariance_ground_hdl64():
     assert o.counts().n_ground > 20000   # the ground plane is the dominant bin
 
 
-@pytest.mark.parametrize("env", [{"MOR_G2_NOBET": "1"}, {"MOR_LABEL_PREFILL": "0"}, {"MOR_LABEL_PREFILL": "1"}, {"MOR_G2_PASSA2": "1"}])
+@pytest.mark.parametrize("env", [{"MOR_G2_NOBET": "1"}, {"MOR_LABEL_PREFILL": "0"}, {"MOR_LABEL_PREFILL": "1"}, {"MOR_G2_PASSA2": "1"}, {"MOR_SP_G": "64"}, {"MOR_SP_G": "2"}])
 def test_voxel_covariance_ground_paths_chosen_by_timing(env):
     """Two choices of the voxel ground variant depend on what the device has reported by the time the host enqueues a frame: the mode bin a frame bets its
     speculative ground marks on (lost on the first frame, won afterwards — MOR_G2_NOBET makes EVERY frame lose it, so k_g2_mark marks the ground of every frame) and where the −1
     of unclustered cloud points is written (`label_prefill`: forced off and on).  MOR_G2_PASSA2=1 is the switch of pass A: count pass + scatter pass (rounds 2 – 5) instead of the
-    single-read split that leaves packed lattice coordinates to radix pass 0 (round 6).  Each forced path against the oracle, frame by frame, then without waits against synchronous use."""
+    single-read split that leaves packed lattice coordinates to radix pass 0 (round 6); MOR_SP_G runs both single-read passes of the variant (A: trim, B: by ground flag) with 64 workgroups
+    per stream — more than the GPU holds at once, the look-back's hard case — and with two.  Each forced path against the oracle, frame by frame, then without waits against synchronous use."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = _VARIANT_SCRIPT.replace("p = kitti_params(1)", "p = kitti_params(1); p.ground_method = 1")
