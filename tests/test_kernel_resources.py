@@ -12,6 +12,8 @@ SRC = os.path.join(ROOT, "dynamicslamtool_amd", "csrc", "mor_kernels.hip")
 # kernel: (max VGPRs, max scratch bytes per lane, max LDS bytes per workgroup)
 LIMITS = {
     "k_split<0>": (80, 0, 28 * 1024),           # three 512-thread workgroups per CU (round 6: eight waves × four rows — 2048-record tiles at 73 VGPRs; 48 bytes of LDS per thread are the compiler's: the tiles' class arrays promoted from private memory)
+    "k_split<1>": (80, 0, 28 * 1024),           # pass A of the voxel ground variant: the same tiles and the same three workgroups per CU
+    "k_rhist": (64, 0, 2 * 1024),                   # eight waves per SIMD for the histogram loop (round 6: the offsets scan with a 64-tile column in registers took 98 VGPRs and 1 % of the variant)
     "k_gridcount": (64, 0, 36 * 1024),
     "k_gridplace": (80, 0, 24 * 1024),
     "k_cellboxes": (128, 0, 1024),
