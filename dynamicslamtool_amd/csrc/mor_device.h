@@ -115,7 +115,7 @@ struct MorDev {
   int xcd_map;               // 1: the workgroups of a stream share an XCD (its tables stay in that L2); 0: streams spread over all XCDs
   int sp_g;                  // workgroups per stream of the single-read split (2 … 64)
   int g2_passa2;             // voxel ground variant: pass A as count pass + scatter pass (MOR_G2_PASSA2=1; default: the single-read split, k_split<1>)
-  int two_pass_split;        // 1 (default): count pass + scatter pass; 0: the single-pass split with decoupled look-back (MOR_SINGLE_PASS_SPLIT)
+  int two_pass_split;        // 0 (default): the single-read split with decoupled look-back (k_split); 1: count pass + scatter pass (MOR_SINGLE_PASS_SPLIT=0, or a batch wider than half the workgroups the GPU holds)
   int cur, prev, has_prev;   // cluster-array slots of cb and ca (four slots rotate: up to three frames are in flight in the stage pipeline); whether ca exists (:534)
   // ---- device arrays (per-stream stride noted)
   const MorStreamArgs *args; // [B]

@@ -213,7 +213,7 @@ static int configure(mor_batch *b) {
   }
   d.score_R = p.pde_ub > 0.f ? (int)std::floor(std::sqrt((double)p.pde_ub) * d.g.inv_cs * 1.001) + 1 : 1;
   d.g2_passa2 = getenv("MOR_G2_PASSA2") ? atoi(getenv("MOR_G2_PASSA2")) != 0 : 0;
-  d.two_pass_split = (getenv("MOR_SINGLE_PASS_SPLIT") && atoi(getenv("MOR_SINGLE_PASS_SPLIT")) == 0) ? 1 : 0;   // default: the single-read split (k_split); MOR_SINGLE_PASS_SPLIT=0: count pass + scatter pass (what pass A of the voxel ground variant always uses)
+  d.two_pass_split = (getenv("MOR_SINGLE_PASS_SPLIT") && atoi(getenv("MOR_SINGLE_PASS_SPLIT")) == 0) ? 1 : 0;   // default: the single-read split (k_split); MOR_SINGLE_PASS_SPLIT=0: count pass + scatter pass (every split of the frame; MOR_G2_PASSA2=1: pass A of the voxel ground variant only)
   {  // workgroups per stream of the single-read split: what the device holds at once, shared out over the streams (a matter of speed only:
      // tiles are handed out by ticket, so the look-back does not depend on which workgroups are resident)
     int ncu = 256; hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b->device);
